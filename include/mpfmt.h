@@ -1,0 +1,164 @@
+/*
+ * mpfmt.h -- C ABI of libmpfmt.so: the MI355X (gfx950) implementation of the FMT* batch-expand
+ * hot path of schmrlng/MotionPlanning.jl (r-disc neighbour graph, segment-vs-AABB sweep,
+ * per-edge cost, FMT* expansion).
+ *
+ * The reference has no FFI: its plugin surface is Julia multiple dispatch on the abstract types
+ * SampleSet / DistanceDataStructure / CollisionChecker / StateSpace held in the abstract fields of
+ * MPProblem (src/problems.jl:12-30).  Each export below names the reference method it stands behind
+ * (paths relative to the reference repository); INTEGRATION.md shows the Julia `ccall` glue.
+ *
+ * Conventions
+ *   - every call returns int32 status: 0 = MPFMT_OK, negative = error; mpfmt_last_error(ctx) has text.
+ *     No exception crosses the ABI.
+ *   - the caller (Julia) owns every host array passed in; the library owns device memory inside ctx.
+ *   - sample / edge INDICES ARE 1-BASED Int64 at this ABI (Julia `Int`), like every index the
+ *     reference stores (rowval of SparseMatrixCSC, A = parents, path).  colptr is 1-based too.
+ *   - samples: const double* X = d x N column-major, i.e. the memory of Vector{SVector{d,Float64}}
+ *     (zero-copy view `statevec2mat`, src/primitivetypes.jl:21-24).
+ *   - boxes:   const double* lohi = (2*dw) x M column-major: lo(dw) then hi(dw) per box, the memory of
+ *     Vector{BoxBounds{dw,Float64}} (src/collisioncheckers/boxesND.jl:5-13).
+ *   - bit masks: uint64 words, bit e of word e>>6, LSB first == BitVector.chunks.
+ *   - calls are blocking and must come from one host thread per ctx (the reference is single-threaded).
+ *   - arithmetic that decides a mask bit is IEEE binary64, unfused, in the reference's written order;
+ *     masks and indices are bit-exact against the CPU oracle, costs within 1e-6 relative.
+ */
+#ifndef MPFMT_H
+#define MPFMT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPFMT_OK              0
+#define MPFMT_ERR_ARG        -1   /* bad argument (null pointer, dimension out of range, index out of range) */
+#define MPFMT_ERR_STATE      -2   /* call out of order (e.g. fill before count, sweep before boxes) */
+#define MPFMT_ERR_HIP        -3   /* HIP runtime error (text in mpfmt_last_error) */
+#define MPFMT_ERR_NODEVICE   -4   /* no gfx950 device visible: the library has NO CPU fallback */
+#define MPFMT_ERR_CAPACITY   -5   /* caller buffer too small */
+#define MPFMT_ERR_INFEASIBLE -6   /* fmtstar: initial state infeasible (src/planners/fmt.jl:24-29) */
+
+#define MPFMT_MAX_DIM 16
+
+typedef struct mpfmt_ctx mpfmt_ctx;
+
+/* goal kinds for mpfmt_fmtstar (src/goals.jl): params = [lo(d),hi(d)] | [center(d),radius] | [pt(d)] */
+#define MPFMT_GOAL_RECT  0   /* RectangleGoal   src/goals.jl:8-12,96  */
+#define MPFMT_GOAL_BALL  1   /* BallGoal        src/goals.jl:17-21,100 */
+#define MPFMT_GOAL_POINT 2   /* PointGoal       src/goals.jl:45,111-114 */
+
+/* ---- context ------------------------------------------------------------------------------------- */
+
+/* device = HIP device ordinal (one ctx per GPU; one process per GPU in multi-GPU runs). */
+int32_t mpfmt_ctx_create(int32_t device, mpfmt_ctx** out);
+int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx);
+const char* mpfmt_last_error(const mpfmt_ctx* ctx);
+/* Version string of the library build ("mpfmt <semver> gfx950"). */
+const char* mpfmt_version(void);
+/* Launch on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream. */
+int32_t mpfmt_set_stream(mpfmt_ctx* ctx, void* hip_stream);
+/* Multi-GPU: this ctx owns shard `rank` of `world` (contiguous ranges of the library's cell-sorted
+ * sample order).  Graph build / sweep then only produce the columns of the shard.  Default (0,1). */
+int32_t mpfmt_set_shard(mpfmt_ctx* ctx, int32_t rank, int32_t world);
+
+/* ---- index build: helper_data_structures(V, dist) (src/nearneighbors.jl:95-100,
+ *      src/statespaces/geometric.jl:14) called by MetricNN(V, dist, init) (src/nearneighbors.jl:70-74)
+ *      every time addpoints runs (src/sampling.jl:43). --------------------------------------------- */
+int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t d);
+
+/* ---- collision checker: PointRobotNDBoxes(boxes) (src/collisioncheckers/boxesND.jl:15-23) and the
+ *      BoundedStateSpace bounds used by in_state_space (src/statespaces.jl:29-34,150).
+ *      ss_lo/ss_hi: d_state doubles each, or both NULL (no bounds test).
+ *      dw = workspace dimension (Identity s2w: dw == d). ------------------------------------------- */
+int32_t mpfmt_upload_boxes(mpfmt_ctx* ctx, const double* lohi, int32_t M, int32_t dw,
+                           const double* ss_lo, const double* ss_hi, int32_t d_state);
+
+/* ---- r-disc neighbour graph = ImmutableNNC(D::SparseMatrixCSC, r) (src/nearneighbors.jl:23-27):
+ *      column v = inball(V, dist, DS, v, r) (src/nearneighbors.jl:179-183) for every v.
+ *      Two-phase so Julia allocates exact sizes:
+ *        count: colptr[N+1] (1-based, colptr[1] == 1), *nnz = colptr[N+1]-1
+ *        fill : rowval[nnz] (1-based, strictly ascending inside a column, self excluded), nzval[nnz].
+ *      With a shard set, only the shard's columns are non-empty. ------------------------------------ */
+int32_t mpfmt_rdisc_count(mpfmt_ctx* ctx, double r, int64_t* colptr, int64_t* nnz);
+int32_t mpfmt_rdisc_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval);
+
+/* One query = inball(V, dist, DS, v, r, forwards) (src/nearneighbors.jl:179-183), the MutableNNC
+ * cache-miss path (src/nearneighbors.jl:129-135).  v 1-based.  *k = neighbour count; at most cap
+ * entries are written (MPFMT_ERR_CAPACITY if k > cap, *k still set). */
+int32_t mpfmt_rdisc_query(mpfmt_ctx* ctx, int64_t v, double r, int64_t* inds, double* ds, int64_t cap, int64_t* k);
+
+/* ---- batch validity ------------------------------------------------------------------------------
+ * points_free: bit e = is_free_state(V[idx[e]], CC, SS) (src/statespaces.jl:151-152,
+ *              src/collisioncheckers/boxesND.jl:42-43); idx NULL = all N samples in order
+ *              (the checkpts sweep, src/planners/fmt.jl:31-36).
+ * edges_free : bit e = is_free_motion(V[src[e]], V[dst[e]], CC, SS) (src/statespaces.jl:153-158,
+ *              src/collisioncheckers/boxesND.jl:26,44-56); src = parent first (src/planners/fmt.jl:75).
+ * graph_edges_free: the same over every stored graph entry, CSC order: entry e in column x with
+ *              row y  <->  is_free_motion(V[y], V[x]).  mask has ceil(nnz/64) words. */
+int32_t mpfmt_points_free(mpfmt_ctx* ctx, const int64_t* idx, int64_t n, uint64_t* mask);
+int32_t mpfmt_edges_free(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, uint64_t* mask);
+int32_t mpfmt_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask);
+/* Same three on explicit points (not sample indices): P = d x n column-major; Q likewise (segment ends).
+ * is_free_state(v, CC, SS) / is_free_motion(v, w, CC, SS) for states that are not samples
+ * (sampler candidates src/sampling.jl:25, shortcut segments src/postprocessors.jl:6-39). */
+int32_t mpfmt_states_free(mpfmt_ctx* ctx, const double* P, int64_t n, uint64_t* mask);
+int32_t mpfmt_motions_free(mpfmt_ctx* ctx, const double* P, const double* Q, int64_t n, uint64_t* mask);
+
+/* ---- batch expand: the body of the FMT* loop (src/planners/fmt.jl:70-82) for a set of z.
+ *      For every unvisited (W) and valid (F, may be NULL) sample x with a forward neighbour in zs:
+ *        y_min = first argmin over open (H) backward neighbours y of C[y] + d(y,x)   (fmt.jl:72-74)
+ *        free  = is_free_motion(V[y_min], V[x], CC, SS)                              (fmt.jl:75)
+ *      Results are reported sorted by x ascending.  W,H,F: N-bit masks; C: N doubles; zs 1-based.
+ *      Requires a built graph (mpfmt_rdisc_count).  xs/ymin/cmin/free_out need capacity cap. */
+int32_t mpfmt_expand(mpfmt_ctx* ctx, const uint64_t* W, const uint64_t* H, const uint64_t* F, const double* C,
+                     const int64_t* zs, int64_t nz,
+                     int64_t* xs, int64_t* ymin, double* cmin, uint8_t* free_out, int64_t cap, int64_t* nx);
+
+/* ---- whole solve: fmtstar!(P, N; r, init_idx, checkpts) with connections = :R
+ *      (src/planners/fmt.jl:3-119).  The GPU builds the r-disc graph, the checkpts bitmap and the
+ *      per-edge free mask; the sequential dynamic-programming recursion (fmt.jl:68-90) then runs on the
+ *      host over those arrays, so tree, costs and path equal the lazy reference loop's.
+ *      A (parents, 1-based, 0 = none), C (cost-to-come): N entries.  path: capacity N.
+ *      collision_checks counts the edge checks the loop ASKED for (P.CC.count, boxesND.jl:26). */
+typedef struct {
+    int32_t status;            /* 1 = :solved, 0 = :failed                      (fmt.jl:103) */
+    double  cost;              /* C[z]                                          (fmt.jl:107) */
+    int64_t z;                 /* last dequeued sample, 1-based */
+    int64_t collision_checks;  /* metadata["collision_checks"]                  (fmt.jl:106) */
+    int64_t path_len;          /* metadata["path"] length                       (fmt.jl:92-101) */
+    int64_t nnz;               /* directed edges in the r-disc graph */
+    double  ms_graph;          /* device time: r-disc graph build */
+    double  ms_sweep;          /* device time: point + edge validity sweeps */
+    double  ms_host_loop;      /* host time: sequential FMT* recursion */
+} mpfmt_fmt_result;
+
+int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts,
+                      int32_t goal_kind, const double* goal_params,
+                      int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
+
+/* ---- device-resident forms (bench / multi-GPU: no PCIe in the timed region) -----------------------
+ * graph_build_device: count+fill on the device only; outputs stay in HBM.  Returns nnz.
+ * graph_sweep_device: per-edge free mask of the resident graph into HBM.
+ * Pointers to the resident arrays (device addresses, valid until the next build / ctx destroy):
+ *   colptr int64[N+1] 0-based offsets, rowval int32[nnz] 0-based, nzval double[nnz], free uint64[ceil(nnz/64)]. */
+int32_t mpfmt_graph_build_device(mpfmt_ctx* ctx, double r, int64_t* nnz);
+int32_t mpfmt_graph_sweep_device(mpfmt_ctx* ctx);
+int32_t mpfmt_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** rowval, void** nzval, void** free_mask);
+/* Shard bookkeeping for the all-gather: column range (in the library's sorted order) and the number
+ * of edges this shard produced. */
+int32_t mpfmt_shard_info(mpfmt_ctx* ctx, int64_t* col_begin, int64_t* col_end, int64_t* shard_nnz);
+
+/* ---- measurement: average device milliseconds per launch of a named kernel group since the last
+ *      reset, measured with HIP events on the launch stream.  names: "rdisc_count", "rdisc_fill",
+ *      "rdisc_sort", "grid", "sweep_graph", "sweep_points", "sweep_edges", "expand". */
+int32_t mpfmt_timing_reset(mpfmt_ctx* ctx);
+int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
+/* work counters of the last graph build: candidate pairs distance-tested, tiles, slices. */
+int32_t mpfmt_graph_stats(mpfmt_ctx* ctx, int64_t* pairs_tested, int64_t* tiles, int64_t* slices, int64_t* cells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPFMT_H */

@@ -1,0 +1,316 @@
+"""ctypes loader for libmpfmt.so (the C ABI of include/mpfmt.h).
+
+The product path has NO CPU fallback: if the shared library is missing this module raises, and if
+no gfx950 device is visible `Context()` raises `MPFMTError` (MPFMT_ERR_NODEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmpfmt.so")
+_LIB = None
+
+OK, ERR_ARG, ERR_STATE, ERR_HIP, ERR_NODEVICE, ERR_CAPACITY, ERR_INFEASIBLE = 0, -1, -2, -3, -4, -5, -6
+GOAL_RECT, GOAL_BALL, GOAL_POINT = 0, 1, 2
+MAX_DIM = 16
+
+c_d_p = C.POINTER(C.c_double)
+c_i64_p = C.POINTER(C.c_int64)
+c_u64_p = C.POINTER(C.c_uint64)
+c_u8_p = C.POINTER(C.c_uint8)
+
+
+class MPFMTError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmpfmt error %d: %s" % (code, msg))
+        self.code = code
+
+
+class FmtResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("cost", C.c_double), ("z", C.c_int64), ("collision_checks", C.c_int64),
+                ("path_len", C.c_int64), ("nnz", C.c_int64), ("ms_graph", C.c_double), ("ms_sweep", C.c_double),
+                ("ms_host_loop", C.c_double)]
+
+
+# every symbol include/mpfmt.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("mpfmt_ctx_create", C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
+    ("mpfmt_ctx_destroy", C.c_int32, [C.c_void_p]),
+    ("mpfmt_last_error", C.c_char_p, [C.c_void_p]),
+    ("mpfmt_version", C.c_char_p, []),
+    ("mpfmt_set_stream", C.c_int32, [C.c_void_p, C.c_void_p]),
+    ("mpfmt_set_shard", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    ("mpfmt_upload_samples", C.c_int32, [C.c_void_p, c_d_p, C.c_int64, C.c_int32]),
+    ("mpfmt_upload_boxes", C.c_int32, [C.c_void_p, c_d_p, C.c_int32, C.c_int32, c_d_p, c_d_p, C.c_int32]),
+    ("mpfmt_rdisc_count", C.c_int32, [C.c_void_p, C.c_double, c_i64_p, c_i64_p]),
+    ("mpfmt_rdisc_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p]),
+    ("mpfmt_rdisc_query", C.c_int32, [C.c_void_p, C.c_int64, C.c_double, c_i64_p, c_d_p, C.c_int64, c_i64_p]),
+    ("mpfmt_points_free", C.c_int32, [C.c_void_p, c_i64_p, C.c_int64, c_u64_p]),
+    ("mpfmt_edges_free", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, C.c_int64, c_u64_p]),
+    ("mpfmt_graph_edges_free", C.c_int32, [C.c_void_p, c_u64_p]),
+    ("mpfmt_states_free", C.c_int32, [C.c_void_p, c_d_p, C.c_int64, c_u64_p]),
+    ("mpfmt_motions_free", C.c_int32, [C.c_void_p, c_d_p, c_d_p, C.c_int64, c_u64_p]),
+    ("mpfmt_expand", C.c_int32, [C.c_void_p, c_u64_p, c_u64_p, c_u64_p, c_d_p, c_i64_p, C.c_int64,
+                                 c_i64_p, c_i64_p, c_d_p, c_u8_p, C.c_int64, c_i64_p]),
+    ("mpfmt_fmtstar", C.c_int32, [C.c_void_p, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
+                                  c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
+    ("mpfmt_graph_build_device", C.c_int32, [C.c_void_p, C.c_double, c_i64_p]),
+    ("mpfmt_graph_sweep_device", C.c_int32, [C.c_void_p]),
+    ("mpfmt_graph_device_ptrs", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("mpfmt_shard_info", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, c_i64_p]),
+    ("mpfmt_timing_reset", C.c_int32, [C.c_void_p]),
+    ("mpfmt_timing_get", C.c_int32, [C.c_void_p, C.c_char_p, c_d_p, c_i64_p]),
+    ("mpfmt_graph_stats", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, c_i64_p, c_i64_p]),
+]
+
+
+def so_path():
+    return _SO
+
+
+def lib():
+    """Load libmpfmt.so.  torch is imported first so that the one HIP runtime already mapped into the
+    process (torch bundles libamdhip64.so.7) also serves this library (same SONAME)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise ImportError("libmpfmt.so is not built (%s); run `python __graft_entry__.py` / `make -C %s`; "
+                              "there is no CPU fallback" % (_SO, os.path.join(_HERE, "csrc")))
+        try:
+            import torch  # noqa: F401  (maps the HIP runtime)
+        except Exception:  # pragma: no cover - torch is plumbing only
+            pass
+        L = C.CDLL(_SO)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def nwords(n):
+    return (int(n) + 63) // 64
+
+
+def unpack_bits(mask, n):
+    b = np.unpackbits(np.ascontiguousarray(mask).view(np.uint8), bitorder="little")
+    return b[:n].astype(bool)
+
+
+def pack_bits(bits):
+    bits = np.asarray(bits, dtype=bool)
+    pad = np.zeros(max(nwords(bits.size), 1) * 64, dtype=np.uint8)
+    pad[:bits.size] = bits
+    return np.packbits(pad, bitorder="little").view(np.uint64)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_d_p)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(c_i64_p)
+
+
+def _up(a):
+    return None if a is None else a.ctypes.data_as(c_u64_p)
+
+
+class Context:
+    """One GPU context = one `mpfmt_ctx`.  Thin, numpy-in / numpy-out; indices 1-based like the ABI."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.mpfmt_ctx_create(int(device), C.byref(h))
+        if rc != OK:
+            raise MPFMTError(rc, self._L.mpfmt_last_error(None).decode())
+        self._h = h
+        self.N = 0
+        self.d = 0
+        self.nnz = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mpfmt_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise MPFMTError(rc, self._L.mpfmt_last_error(self._h).decode())
+
+    # ---- setup ----------------------------------------------------------------------------------
+    def set_stream(self, stream_handle):
+        self._chk(self._L.mpfmt_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def set_shard(self, rank, world):
+        self._chk(self._L.mpfmt_set_shard(self._h, int(rank), int(world)))
+
+    def upload_samples(self, X):
+        """X: (N, d) float64 C-contiguous == Julia d x N column-major."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError("X must be (N, d)")
+        self._chk(self._L.mpfmt_upload_samples(self._h, _dp(X), X.shape[0], X.shape[1]))
+        self.N, self.d = X.shape
+        self.nnz = None
+
+    def upload_boxes(self, lohi, ss_lo=None, ss_hi=None, dw=None):
+        """lohi: (M, 2, dw) float64 (lo then hi per box)."""
+        lohi = np.ascontiguousarray(lohi, dtype=np.float64)
+        if lohi.size == 0:
+            if dw is None:
+                dw = self.d
+            lohi = np.zeros((0, 2, dw))
+        if lohi.ndim != 3 or lohi.shape[1] != 2:
+            raise ValueError("lohi must be (M, 2, dw)")
+        M, _, dw = lohi.shape
+        lo = None if ss_lo is None else np.ascontiguousarray(ss_lo, dtype=np.float64)
+        hi = None if ss_hi is None else np.ascontiguousarray(ss_hi, dtype=np.float64)
+        ds = 0 if lo is None else lo.size
+        self._chk(self._L.mpfmt_upload_boxes(self._h, _dp(lohi), M, dw, _dp(lo), _dp(hi), ds))
+
+    # ---- r-disc ---------------------------------------------------------------------------------
+    def rdisc_count(self, r):
+        colptr = np.empty(self.N + 1, dtype=np.int64)
+        nnz = C.c_int64()
+        self._chk(self._L.mpfmt_rdisc_count(self._h, float(r), _ip(colptr), C.byref(nnz)))
+        self.nnz = nnz.value
+        return colptr, nnz.value
+
+    def rdisc_fill(self):
+        nnz = self.nnz
+        rowval = np.empty(max(nnz, 1), dtype=np.int64)
+        nzval = np.empty(max(nnz, 1), dtype=np.float64)
+        self._chk(self._L.mpfmt_rdisc_fill(self._h, _ip(rowval), _dp(nzval)))
+        return rowval[:nnz], nzval[:nnz]
+
+    def rdisc_graph(self, r):
+        """(colptr, rowval, nzval), all 1-based like SparseMatrixCSC."""
+        colptr, _ = self.rdisc_count(r)
+        rowval, nzval = self.rdisc_fill()
+        return colptr, rowval, nzval
+
+    def rdisc_query(self, v, r, cap=None):
+        cap = self.N if cap is None else cap
+        inds = np.empty(max(cap, 1), dtype=np.int64)
+        ds = np.empty(max(cap, 1), dtype=np.float64)
+        k = C.c_int64()
+        self._chk(self._L.mpfmt_rdisc_query(self._h, int(v), float(r), _ip(inds), _dp(ds), cap, C.byref(k)))
+        return inds[:k.value].copy(), ds[:k.value].copy()
+
+    # ---- sweeps ---------------------------------------------------------------------------------
+    def points_free(self, idx=None):
+        n = self.N if idx is None else len(idx)
+        idx = None if idx is None else np.ascontiguousarray(idx, dtype=np.int64)
+        mask = np.zeros(max(nwords(n), 1), dtype=np.uint64)
+        self._chk(self._L.mpfmt_points_free(self._h, _ip(idx), n, _up(mask)))
+        return mask[:nwords(n)]
+
+    def edges_free(self, src, dst):
+        src = np.ascontiguousarray(src, dtype=np.int64)
+        dst = np.ascontiguousarray(dst, dtype=np.int64)
+        E = src.size
+        mask = np.zeros(max(nwords(E), 1), dtype=np.uint64)
+        self._chk(self._L.mpfmt_edges_free(self._h, _ip(src), _ip(dst), E, _up(mask)))
+        return mask[:nwords(E)]
+
+    def graph_edges_free(self):
+        mask = np.zeros(max(nwords(self.nnz), 1), dtype=np.uint64)
+        self._chk(self._L.mpfmt_graph_edges_free(self._h, _up(mask)))
+        return mask[:nwords(self.nnz)]
+
+    def states_free(self, P):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        n = P.shape[0]
+        mask = np.zeros(max(nwords(n), 1), dtype=np.uint64)
+        self._chk(self._L.mpfmt_states_free(self._h, _dp(P), n, _up(mask)))
+        return mask[:nwords(n)]
+
+    def motions_free(self, P, Q):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        n = P.shape[0]
+        mask = np.zeros(max(nwords(n), 1), dtype=np.uint64)
+        self._chk(self._L.mpfmt_motions_free(self._h, _dp(P), _dp(Q), n, _up(mask)))
+        return mask[:nwords(n)]
+
+    # ---- expand / solve ---------------------------------------------------------------------------
+    def expand(self, W, H, F, Cc, zs, cap=None):
+        W = np.ascontiguousarray(W, dtype=np.uint64)
+        H = np.ascontiguousarray(H, dtype=np.uint64)
+        F = None if F is None else np.ascontiguousarray(F, dtype=np.uint64)
+        Cc = np.ascontiguousarray(Cc, dtype=np.float64)
+        zs = np.ascontiguousarray(zs, dtype=np.int64)
+        cap = self.N if cap is None else cap
+        xs = np.empty(max(cap, 1), dtype=np.int64)
+        ym = np.empty(max(cap, 1), dtype=np.int64)
+        cm = np.empty(max(cap, 1), dtype=np.float64)
+        fr = np.empty(max(cap, 1), dtype=np.uint8)
+        nx = C.c_int64()
+        self._chk(self._L.mpfmt_expand(self._h, _up(W), _up(H), _up(F), _dp(Cc), _ip(zs), zs.size, _ip(xs), _ip(ym),
+                                       _dp(cm), fr.ctypes.data_as(c_u8_p), cap, C.byref(nx)))
+        n = nx.value
+        return xs[:n].copy(), ym[:n].copy(), cm[:n].copy(), fr[:n].astype(bool)
+
+    def fmtstar(self, r, goal_kind, goal_params, init_idx=1, checkpts=True):
+        g = np.ascontiguousarray(goal_params, dtype=np.float64)
+        A = np.empty(max(self.N, 1), dtype=np.int64)
+        Cc = np.empty(max(self.N, 1), dtype=np.float64)
+        path = np.empty(max(self.N, 1), dtype=np.int64)
+        res = FmtResult()
+        self._chk(self._L.mpfmt_fmtstar(self._h, float(r), int(init_idx), int(bool(checkpts)), int(goal_kind), _dp(g),
+                                        _ip(A), _dp(Cc), _ip(path), C.byref(res)))
+        return dict(status=int(res.status), cost=float(res.cost), z=int(res.z),
+                    collision_checks=int(res.collision_checks), nnz=int(res.nnz),
+                    ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
+                    A=A[:self.N], C=Cc[:self.N], path=path[:res.path_len].copy())
+
+    # ---- device-resident -------------------------------------------------------------------------
+    def graph_build_device(self, r):
+        nnz = C.c_int64()
+        self._chk(self._L.mpfmt_graph_build_device(self._h, float(r), C.byref(nnz)))
+        self.nnz = nnz.value
+        return nnz.value
+
+    def graph_sweep_device(self):
+        self._chk(self._L.mpfmt_graph_sweep_device(self._h))
+
+    def graph_device_ptrs(self):
+        p = [C.c_void_p() for _ in range(4)]
+        self._chk(self._L.mpfmt_graph_device_ptrs(self._h, *[C.byref(x) for x in p]))
+        return tuple(x.value for x in p)
+
+    def shard_info(self):
+        a, b, n = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self._L.mpfmt_shard_info(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
+    def timing_reset(self):
+        self._chk(self._L.mpfmt_timing_reset(self._h))
+
+    def timing(self, name):
+        ms, n = C.c_double(), C.c_int64()
+        self._chk(self._L.mpfmt_timing_get(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def graph_stats(self):
+        v = [C.c_int64() for _ in range(4)]
+        self._chk(self._L.mpfmt_graph_stats(self._h, *[C.byref(x) for x in v]))
+        return dict(pairs_tested=v[0].value, tiles=v[1].value, slices=v[2].value, cells=v[3].value)

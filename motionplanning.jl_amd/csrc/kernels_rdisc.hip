@@ -1,0 +1,620 @@
+// r-disc neighbour graph on gfx950: cell-grid binning + tile-vs-cell-run distance sweep.
+//
+// Replaces, for every sample v at once, inball(V, dist, DS::TreeDistanceDS, v, r)
+// (reference src/nearneighbors.jl:179-183: KD-tree inrange + drop self + colwise distances) and
+// the index build helper_data_structures(V, Euclidean) (src/statespaces/geometric.jl:14).
+//
+// Canonical arithmetic (must equal the CPU parity checker under oracle/ bit for bit): d2 = sum_i (q_i - c_i)^2
+// accumulated in index order, fp64, unfused (-ffp-contract=off); neighbour <=> i != v && d2 <= r*r;
+// dist = sqrt(d2).
+//
+// Design (MI355X): samples are binned into a uniform grid with cells >= r wide, sorted by cell id
+// and stored as 64-sample tiles in SoA form ([tile][dim][64], 512 B contiguous per dimension, so a
+// wavefront's query load is one coalesced 512 B read per dimension).  One wavefront = one tile of 64
+// queries (lane = query, coordinates in VGPRs).  Candidate samples are the contiguous runs of the
+// sorted array that cover the grid cells within r of the tile's tight bounding box; each 64-sample
+// candidate chunk is staged once into LDS and broadcast to all 64 lanes (every lane reads the same
+// LDS address: conflict-free broadcast), so HBM/L2 traffic per pair test is 1/64 of a gather.
+// The kernel is fp64-VALU bound (3 ops per dimension per pair); the grid cuts the pair count from
+// N^2 to ~N * (candidates in the Minkowski sum of the tile box and the r-ball).
+//
+// Two passes with identical arithmetic: COUNT (degrees -> scan -> colptr) and FILL (lane-private
+// sequential slots, no atomics), then a per-column rank sort puts row indices in ascending order
+// (the SparseVector contract of nearneighbors.jl:138-198).
+#include "mpfmt_internal.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <cmath>
+#include <algorithm>
+
+#define NXCD 8
+
+// ------------------------------------------------------------------------------------------------
+// grid build
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cell_of(double x, double lo, double inv_w, int g)
+{
+    double f = floor((x - lo) * inv_w);
+    int c = (int)f;
+    if (!(f >= 0.0)) c = 0;
+    if (f >= (double)g) c = g - 1;
+    return c;
+}
+
+__global__ void k_cellkey(const double* __restrict__ Xo, int64_t N, int d, mpfmt_grid G,
+                          uint32_t* __restrict__ key, int32_t* __restrict__ val)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    int64_t id = 0;
+    for (int i = 0; i < d; ++i)
+        id += (int64_t)cell_of(Xo[p * d + i], G.lo[i], G.inv_w[i], G.g[i]) * G.stride[i];
+    key[p] = (uint32_t)id;
+    val[p] = (int32_t)p;
+}
+
+// sorted position s -> tile layout; pads the last tile with NaN coordinates (NaN never passes d2 <= r2)
+__global__ void k_scatter_tiles(const double* __restrict__ Xo, const int32_t* __restrict__ perm_sorted,
+                                int64_t N, int64_t npad, int d,
+                                int32_t* __restrict__ perm, int32_t* __restrict__ iperm, double* __restrict__ Xt)
+{
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= npad) return;
+    int64_t tile = s >> 6;
+    int lane = (int)(s & 63);
+    if (s < N) {
+        int32_t o = perm_sorted[s];
+        perm[s] = o;
+        iperm[o] = (int32_t)s;
+        for (int i = 0; i < d; ++i) Xt[(tile * d + i) * 64 + lane] = Xo[(int64_t)o * d + i];
+    } else {
+        perm[s] = -1;
+        for (int i = 0; i < d; ++i) Xt[(tile * d + i) * 64 + lane] = __builtin_nan("");
+    }
+}
+
+__global__ void k_cellstart(const uint32_t* __restrict__ key_sorted, int64_t N, int64_t ncells,
+                            int32_t* __restrict__ cellstart)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > ncells) return;
+    int64_t lo = 0, hi = N;                 // lower_bound(key_sorted, c)
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)key_sorted[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    cellstart[c] = (int32_t)lo;
+}
+
+__global__ __launch_bounds__(64) void k_tile_bbox(const double* __restrict__ Xt, int64_t ntiles, int d,
+                                                  double* __restrict__ tile_lo, double* __restrict__ tile_hi)
+{
+    int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int lane = threadIdx.x;
+    for (int i = 0; i < d; ++i) {
+        double x = Xt[(tile * d + i) * 64 + lane];
+        double mn = x, mx = x;                       // fmin/fmax ignore the NaN pads
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = fmin(mn, __shfl_xor(mn, off));
+            mx = fmax(mx, __shfl_xor(mx, off));
+        }
+        if (lane == 0) { tile_lo[tile * d + i] = mn; tile_hi[tile * d + i] = mx; }
+    }
+}
+
+static inline int32_t ensure(mpfmt_ctx* ctx, void** p, size_t bytes) { return mpfmt_ensure(ctx, p, bytes); }
+
+int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
+{
+    if (ctx->grid_r == r && ctx->Xt) return MPFMT_OK;
+    const int64_t N = ctx->N;
+    const int d = ctx->d;
+    mpfmt_time_begin(ctx);
+
+    // ---- choose cells: width >= r, total cells <= max(1, N/8) and < 2^31 ----------------------------
+    mpfmt_grid& G = ctx->grid;
+    G.gd = d;
+    const int64_t cmax = std::max<int64_t>(1, std::min<int64_t>(N / 8, (int64_t)1 << 24));
+    int gcap = 1024;
+    for (;;) {
+        int64_t prod = 1;
+        for (int i = 0; i < d; ++i) {
+            double ext = ctx->bb_hi[i] - ctx->bb_lo[i];
+            int g = 1;
+            if (r > 0.0 && ext > 0.0 && std::isfinite(ext / r)) {
+                double q = std::floor(ext / r);
+                g = (q >= (double)gcap) ? gcap : (int)q;
+                if (g < 1) g = 1;
+                // cell width ext/g must be >= r even after rounding
+                while (g > 1 && ext / (double)g < r * (1.0 + 1e-9)) --g;
+            } else if (!(r > 0.0) && ext > 0.0) {
+                g = gcap;                        // r == 0: only exact duplicates match; finest grid allowed
+            }
+            G.g[i] = g;
+            prod *= g;
+            if (prod > ((int64_t)1 << 40)) break;
+        }
+        if (prod <= cmax || gcap == 1) break;
+        gcap = (gcap > 2) ? gcap - std::max(1, gcap / 8) : 1;
+    }
+    int64_t stride = 1;
+    for (int i = d - 1; i >= 0; --i) {
+        G.stride[i] = stride;
+        stride *= G.g[i];
+        double ext = ctx->bb_hi[i] - ctx->bb_lo[i];
+        G.lo[i] = ctx->bb_lo[i];
+        G.w[i] = (G.g[i] > 1) ? ext / (double)G.g[i] : (ext > 0 ? ext : 1.0);
+        G.inv_w[i] = (G.g[i] > 1) ? (double)G.g[i] / ext : 0.0;
+    }
+    G.ncells = stride;
+    for (int i = d; i < MPFMT_MAX_DIM; ++i) { G.g[i] = 1; G.stride[i] = 0; G.lo[i] = 0; G.w[i] = 1; G.inv_w[i] = 0; }
+
+    ctx->ntiles = (N + 63) / 64;
+    const int64_t npad = ctx->ntiles * 64;
+
+    int32_t rc;
+    if ((rc = ensure(ctx, (void**)&ctx->perm, sizeof(int32_t) * npad))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->iperm, sizeof(int32_t) * N))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->cellkey, sizeof(uint32_t) * N))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->cellstart, sizeof(int32_t) * (G.ncells + 1)))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->Xt, sizeof(double) * npad * d))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->tile_lo, sizeof(double) * ctx->ntiles * d))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->tile_hi, sizeof(double) * ctx->ntiles * d))) return rc;
+
+    if (N > 0) {
+        // keys / values, radix sort by cell id (stable: samples stay in index order inside a cell)
+        uint32_t* key_in; int32_t* val_in; int32_t* val_out;
+        size_t tmp_bytes = 0;
+        int bits = 1;
+        while (((int64_t)1 << bits) < G.ncells) ++bits;
+        HIPCHK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                              (int32_t*)nullptr, (int32_t*)nullptr, (size_t)N, 0, bits, ctx->stream));
+        size_t off_key = 0, off_val = off_key + sizeof(uint32_t) * N, off_vout = off_val + sizeof(int32_t) * N;
+        size_t off_tmp = (off_vout + sizeof(int32_t) * N + 255) & ~(size_t)255;
+        void* scr;
+        if ((rc = mpfmt_scratch(ctx, off_tmp + tmp_bytes, &scr))) return rc;
+        key_in = (uint32_t*)((char*)scr + off_key);
+        val_in = (int32_t*)((char*)scr + off_val);
+        val_out = (int32_t*)((char*)scr + off_vout);
+        void* tmp = (char*)scr + off_tmp;
+        const int B = 256;
+        hipLaunchKernelGGL(k_cellkey, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream,
+                           ctx->Xo, N, d, G, key_in, val_in);
+        HIPCHK(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, ctx->cellkey, val_in, val_out, (size_t)N, 0, bits, ctx->stream));
+        hipLaunchKernelGGL(k_scatter_tiles, dim3((unsigned)((npad + B - 1) / B)), dim3(B), 0, ctx->stream,
+                           ctx->Xo, val_out, N, npad, d, ctx->perm, ctx->iperm, ctx->Xt);
+        hipLaunchKernelGGL(k_cellstart, dim3((unsigned)((G.ncells + 1 + B - 1) / B)), dim3(B), 0, ctx->stream,
+                           ctx->cellkey, N, G.ncells, ctx->cellstart);
+        hipLaunchKernelGGL(k_tile_bbox, dim3((unsigned)ctx->ntiles), dim3(64), 0, ctx->stream,
+                           ctx->Xt, ctx->ntiles, d, ctx->tile_lo, ctx->tile_hi);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    mpfmt_time_end(ctx, "grid");
+    ctx->grid_r = r;
+    ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
+    return MPFMT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the pair sweep
+// ------------------------------------------------------------------------------------------------
+struct rdisc_args {
+    const double* Xt;
+    const int32_t* perm;
+    const int32_t* cellstart;
+    const double* tile_lo;
+    const double* tile_hi;
+    double r2;        // r*r  (the membership threshold, exact)
+    double rpad;      // r*(1+1e-9): conservative radius for cell pruning only
+    int32_t S;
+    int64_t tile_begin;
+    int64_t nitems;   // (tile_end - tile_begin) * S
+    int64_t npad;
+    int32_t* slice_cnt;
+    const int64_t* colptr;
+    int32_t* rowtmp;
+    double* valtmp;
+    unsigned long long* pairs;
+};
+
+template <int D, bool FILL>
+__global__ __launch_bounds__(64) void k_rdisc(rdisc_args a, mpfmt_grid G)
+{
+    __shared__ double sh[D * 64];
+    __shared__ int32_t shp[64];
+    const int lane = threadIdx.x;
+
+    // XCD-aware item mapping: blocks b, b+8, b+16.. run on the same XCD (private 4 MiB L2); give each
+    // XCD a contiguous range of tiles so neighbouring tiles (which share candidate cells) share an L2.
+    const int64_t nblk = gridDim.x;
+    const int64_t per_xcd = nblk / NXCD;
+    const int64_t b = blockIdx.x;
+    const int64_t item = (b % NXCD) * per_xcd + (b / NXCD);
+    if (item >= a.nitems) return;
+    const int64_t tile = a.tile_begin + item / a.S;
+    const int slice = (int)(item % a.S);
+    const int64_t qpos = tile * 64 + lane;
+
+    double q[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) q[i] = a.Xt[(tile * D + i) * 64 + lane];
+
+    // tile bounding box and per-dimension cell ranges (wave-uniform)
+    double tlo[D], thi[D];
+    int clo[D], chi[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        tlo[i] = a.tile_lo[tile * D + i];
+        thi[i] = a.tile_hi[tile * D + i];
+        clo[i] = cell_of(tlo[i] - a.rpad, G.lo[i], G.inv_w[i], G.g[i]);
+        chi[i] = cell_of(thi[i] + a.rpad, G.lo[i], G.inv_w[i], G.g[i]);
+    }
+    const double rpad2 = a.rpad * a.rpad;
+    constexpr int L = D - 1;                    // last dimension: contiguous in the sorted order
+
+    int64_t base = 0;
+    int32_t cnt = 0;
+    if (FILL) {
+        const int32_t o = a.perm[qpos];
+        if (o >= 0) {
+            base = a.colptr[o];
+            for (int s = 0; s < slice; ++s) base += a.slice_cnt[(int64_t)s * a.npad + qpos];
+        }
+    }
+
+    int64_t rows = 1;
+#pragma unroll
+    for (int i = 0; i < L; ++i) rows *= (chi[i] - clo[i] + 1);
+
+    unsigned long long tested = 0;
+    int64_t blk = 0;
+    for (int64_t row = 0; row < rows; ++row) {
+        // decode the row into cell coordinates of dims 0..L-1 (dim L-1 fastest), accumulate the
+        // squared gap between the tile box and the cell slab in those dims
+        int64_t rem = row;
+        int64_t cbase = 0;
+        double partial = 0.0;
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            const int span = chi[i] - clo[i] + 1;
+            const int c = clo[i] + (int)(rem % span);
+            rem /= span;
+            cbase += (int64_t)c * G.stride[i];
+            const double eps = G.w[i] * 1e-9;
+            const double blo = G.lo[i] + (double)c * G.w[i] - eps;
+            const double bhi = G.lo[i] + (double)(c + 1) * G.w[i] + eps;
+            double gap = fmax(fmax(blo - thi[i], tlo[i] - bhi), 0.0);
+            if (G.g[i] == 1) gap = 0.0;
+            partial += gap * gap;
+        }
+        if (partial > rpad2) continue;
+        // trim the run along the last dimension
+        int c0 = clo[L], c1 = chi[L];
+        if (G.g[L] > 1) {
+            const double eps = G.w[L] * 1e-9;
+            while (c0 <= c1) {
+                const double bhi = G.lo[L] + (double)(c0 + 1) * G.w[L] + eps;
+                const double gap = fmax(tlo[L] - bhi, 0.0);
+                if (partial + gap * gap > rpad2) ++c0; else break;
+            }
+            while (c1 >= c0) {
+                const double blo = G.lo[L] + (double)c1 * G.w[L] - eps;
+                const double gap = fmax(blo - thi[L], 0.0);
+                if (partial + gap * gap > rpad2) --c1; else break;
+            }
+            if (c0 > c1) continue;
+        }
+        const int64_t ra = a.cellstart[cbase + c0];
+        const int64_t rb = a.cellstart[cbase + c1 + 1];
+        if (rb <= ra) continue;
+        for (int64_t cb = ra >> 6; cb <= ((rb - 1) >> 6); ++cb, ++blk) {
+            if ((int)(blk % a.S) != slice) continue;
+            const int j0 = (int)(std::max<int64_t>(ra, cb * 64) - cb * 64);
+            const int j1 = (int)(std::min<int64_t>(rb, cb * 64 + 64) - cb * 64);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < D; ++i) sh[i * 64 + lane] = a.Xt[(cb * D + i) * 64 + lane];
+            if (FILL) shp[lane] = a.perm[cb * 64 + lane];
+            __syncthreads();
+            const int64_t cpos0 = cb * 64;
+            tested += (unsigned long long)(j1 - j0);
+#pragma unroll 4
+            for (int j = j0; j < j1; ++j) {
+                double d2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    const double t = q[i] - sh[i * 64 + j];
+                    const double tt = t * t;
+                    d2 = (i == 0) ? tt : d2 + tt;
+                }
+                const bool hit = (d2 <= a.r2) && (cpos0 + j != qpos);
+                if (FILL) {
+                    if (hit) {
+                        a.rowtmp[base + cnt] = shp[j];
+                        a.valtmp[base + cnt] = sqrt(d2);
+                    }
+                }
+                cnt += hit ? 1 : 0;
+            }
+        }
+    }
+    if (!FILL) {
+        a.slice_cnt[(int64_t)slice * a.npad + qpos] = cnt;
+        if (lane == 0 && a.pairs) atomicAdd(a.pairs, tested * 64ull);
+    }
+}
+
+// degree of each ORIGINAL column = sum over slices of the sorted query's hits
+__global__ void k_degree(const int32_t* __restrict__ slice_cnt, const int32_t* __restrict__ perm, int S, int64_t npad,
+                         int64_t pos_begin, int64_t pos_end, int64_t* __restrict__ deg)
+{
+    int64_t s = pos_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= pos_end) return;
+    const int32_t o = perm[s];
+    if (o < 0) return;
+    int64_t k = 0;
+    for (int i = 0; i < S; ++i) k += slice_cnt[(int64_t)i * npad + s];
+    deg[o] = k;
+}
+
+// Per-column ordering: rank each entry by counting smaller row indices (indices in a column are
+// distinct), one wavefront per column.  Columns up to SORT_LDS entries are staged once in LDS.
+#define SORT_LDS 2048
+__global__ __launch_bounds__(64) void k_sortcols(const int64_t* __restrict__ colptr, int64_t N,
+                                                 const int32_t* __restrict__ rowtmp, const double* __restrict__ valtmp,
+                                                 int32_t* __restrict__ rowval, double* __restrict__ nzval)
+{
+    __shared__ int32_t sidx[SORT_LDS];
+    const int lane = threadIdx.x;
+    for (int64_t col = blockIdx.x; col < N; col += gridDim.x) {
+        const int64_t beg = colptr[col];
+        const int64_t k = colptr[col + 1] - beg;
+        if (k == 0) continue;
+        if (k <= SORT_LDS) {
+            __syncthreads();
+            for (int64_t e = lane; e < k; e += 64) sidx[e] = rowtmp[beg + e];
+            __syncthreads();
+            for (int64_t e0 = 0; e0 < k; e0 += 64) {
+                const int64_t e = e0 + lane;
+                const int32_t mine = (e < k) ? sidx[e] : 0x7fffffff;
+                int32_t rank = 0;
+                for (int64_t j = 0; j < k; ++j) rank += (sidx[j] < mine) ? 1 : 0;
+                if (e < k) {
+                    rowval[beg + rank] = mine;
+                    nzval[beg + rank] = valtmp[beg + e];
+                }
+            }
+        } else {
+            for (int64_t e0 = 0; e0 < k; e0 += 64) {
+                const int64_t e = e0 + lane;
+                const int32_t mine = (e < k) ? rowtmp[beg + e] : 0x7fffffff;
+                int64_t rank = 0;
+                for (int64_t c0 = 0; c0 < k; c0 += SORT_LDS) {
+                    const int64_t cn = std::min<int64_t>(SORT_LDS, k - c0);
+                    __syncthreads();
+                    for (int64_t j = lane; j < cn; j += 64) sidx[j] = rowtmp[beg + c0 + j];
+                    __syncthreads();
+                    for (int64_t j = 0; j < cn; ++j) rank += (sidx[j] < mine) ? 1 : 0;
+                }
+                if (e < k) {
+                    rowval[beg + rank] = mine;
+                    nzval[beg + rank] = valtmp[beg + e];
+                }
+            }
+        }
+    }
+}
+
+template <bool FILL>
+static int32_t launch_rdisc(mpfmt_ctx* ctx, const rdisc_args& a, unsigned nblocks)
+{
+    const mpfmt_grid& G = ctx->grid;
+#define CASE(DD) case DD: hipLaunchKernelGGL((k_rdisc<DD, FILL>), dim3(nblocks), dim3(64), 0, ctx->stream, a, G); break;
+    switch (ctx->d) {
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+        CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
+        default: return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unsupported dimension %d", ctx->d);
+    }
+#undef CASE
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
+static void fill_args(mpfmt_ctx* ctx, double r, rdisc_args& a)
+{
+    a.Xt = ctx->Xt; a.perm = ctx->perm; a.cellstart = ctx->cellstart;
+    a.tile_lo = ctx->tile_lo; a.tile_hi = ctx->tile_hi;
+    a.r2 = r * r;
+    a.rpad = r * (1.0 + 1e-9) + 1e-300;
+    a.S = ctx->S;
+    a.tile_begin = ctx->tile_begin;
+    a.nitems = (ctx->tile_end - ctx->tile_begin) * ctx->S;
+    a.npad = ctx->ntiles * 64;
+    a.slice_cnt = ctx->slice_cnt;
+    a.colptr = ctx->colptr;
+    a.rowtmp = ctx->rowtmp; a.valtmp = ctx->valtmp;
+    a.pairs = ctx->d_pairs;
+}
+
+int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
+{
+    int32_t rc;
+    if ((rc = mpfmt_build_grid(ctx, r))) return rc;
+    const int64_t N = ctx->N;
+    // shard: contiguous tile range of the cell-sorted order
+    ctx->tile_begin = ctx->ntiles * ctx->rank / ctx->world;
+    ctx->tile_end = ctx->ntiles * (ctx->rank + 1) / ctx->world;
+    const int64_t nt = ctx->tile_end - ctx->tile_begin;
+    int S = 1;
+    if (nt > 0) S = (int)std::min<int64_t>(MPFMT_MAXS, std::max<int64_t>(1, (32768 + nt - 1) / nt));
+    ctx->S = S;
+    const int64_t npad = ctx->ntiles * 64;
+    if ((rc = ensure(ctx, (void**)&ctx->slice_cnt, sizeof(int32_t) * (size_t)S * npad))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->deg, sizeof(int64_t) * (N + 1)))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (N + 1)))) return rc;
+    if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (N + 1), ctx->stream));
+
+    rdisc_args a;
+    fill_args(ctx, r, a);
+    mpfmt_time_begin(ctx);
+    if (a.nitems > 0) {
+        const int64_t nblk = ((a.nitems + NXCD - 1) / NXCD) * NXCD;
+        if ((rc = launch_rdisc<false>(ctx, a, (unsigned)nblk))) return rc;
+        const int B = 256;
+        const int64_t pb = ctx->tile_begin * 64, pe = ctx->tile_end * 64;
+        hipLaunchKernelGGL(k_degree, dim3((unsigned)((pe - pb + B - 1) / B)), dim3(B), 0, ctx->stream,
+                           ctx->slice_cnt, ctx->perm, S, npad, pb, pe, ctx->deg);
+    }
+    // exclusive scan of deg[0..N] -> colptr[0..N]
+    size_t tmp_bytes = 0;
+    HIPCHK(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, ctx->deg, ctx->colptr, (int64_t)0, (size_t)(N + 1),
+                                        rocprim::plus<int64_t>(), ctx->stream));
+    void* tmp;
+    if ((rc = mpfmt_scratch(ctx, tmp_bytes, &tmp))) return rc;
+    HIPCHK(ctx, rocprim::exclusive_scan(tmp, tmp_bytes, ctx->deg, ctx->colptr, (int64_t)0, (size_t)(N + 1),
+                                        rocprim::plus<int64_t>(), ctx->stream));
+    mpfmt_time_end(ctx, "rdisc_count");
+    int64_t nnz = 0;
+    unsigned long long pairs = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&nnz, ctx->colptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&pairs, ctx->d_pairs, sizeof(pairs), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->nnz = nnz;
+    ctx->pairs_tested = (int64_t)pairs;
+    ctx->graph_r = r;
+    ctx->graph_counted = true;
+    ctx->graph_filled = false;
+    ctx->graph_swept = false;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
+{
+    if (!ctx->graph_counted || ctx->graph_r != r)
+        return mpfmt_fail(ctx, MPFMT_ERR_STATE, "rdisc_fill without a matching rdisc_count");
+    int32_t rc;
+    const int64_t nnz = ctx->nnz;
+    if ((rc = ensure(ctx, (void**)&ctx->rowtmp, sizeof(int32_t) * (size_t)nnz))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->valtmp, sizeof(double) * (size_t)nnz))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->rowval, sizeof(int32_t) * (size_t)nnz))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->nzval, sizeof(double) * (size_t)nnz))) return rc;
+    rdisc_args a;
+    fill_args(ctx, r, a);
+    a.pairs = nullptr;
+    if (a.nitems > 0 && nnz > 0) {
+        mpfmt_time_begin(ctx);
+        const int64_t nblk = ((a.nitems + NXCD - 1) / NXCD) * NXCD;
+        if ((rc = launch_rdisc<true>(ctx, a, (unsigned)nblk))) return rc;
+        mpfmt_time_end(ctx, "rdisc_fill");
+        mpfmt_time_begin(ctx);
+        const unsigned nb = (unsigned)std::min<int64_t>(ctx->N, 1 << 20);
+        hipLaunchKernelGGL(k_sortcols, dim3(nb), dim3(64), 0, ctx->stream,
+                           ctx->colptr, ctx->N, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval);
+        HIPCHK(ctx, hipGetLastError());
+        mpfmt_time_end(ctx, "rdisc_sort");
+    }
+    ctx->graph_filled = true;
+    return MPFMT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single query (the MutableNNC cache-miss path, nearneighbors.jl:129-135): one workgroup scans the
+// grid cells around the query, collects hits, rank-sorts them, emits 1-based indices + distances.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_rdisc_query(const double* __restrict__ Xt, const int32_t* __restrict__ perm,
+                                                     const int32_t* __restrict__ cellstart, const int32_t* __restrict__ iperm,
+                                                     mpfmt_grid G, int64_t v0, double r2, double rpad,
+                                                     int32_t* __restrict__ hit_idx, double* __restrict__ hit_val,
+                                                     int64_t* __restrict__ k_out, int64_t* __restrict__ out_idx,
+                                                     double* __restrict__ out_val, int64_t cap)
+{
+    __shared__ int nhits;
+    const int tid = threadIdx.x;
+    if (tid == 0) nhits = 0;
+    __syncthreads();
+    const int64_t qpos = iperm[v0];
+    double q[D];
+    int clo[D], chi[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        q[i] = Xt[((qpos >> 6) * D + i) * 64 + (qpos & 63)];
+        clo[i] = cell_of(q[i] - rpad, G.lo[i], G.inv_w[i], G.g[i]);
+        chi[i] = cell_of(q[i] + rpad, G.lo[i], G.inv_w[i], G.g[i]);
+    }
+    constexpr int L = D - 1;
+    int64_t rows = 1;
+#pragma unroll
+    for (int i = 0; i < L; ++i) rows *= (chi[i] - clo[i] + 1);
+    for (int64_t row = 0; row < rows; ++row) {
+        int64_t rem = row, cbase = 0;
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            const int span = chi[i] - clo[i] + 1;
+            cbase += (int64_t)(clo[i] + (int)(rem % span)) * G.stride[i];
+            rem /= span;
+        }
+        const int64_t ra = cellstart[cbase + clo[L]], rb = cellstart[cbase + chi[L] + 1];
+        for (int64_t p = ra + tid; p < rb; p += 256) {
+            double d2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double t = q[i] - Xt[((p >> 6) * D + i) * 64 + (p & 63)];
+                const double tt = t * t;
+                d2 = (i == 0) ? tt : d2 + tt;
+            }
+            if (d2 <= r2 && p != qpos) {
+                const int slot = atomicAdd(&nhits, 1);
+                hit_idx[slot] = perm[p];
+                hit_val[slot] = sqrt(d2);
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t k = nhits;
+    if (tid == 0) *k_out = k;
+    __threadfence_block();
+    for (int64_t e = tid; e < k; e += 256) {
+        const int32_t mine = hit_idx[e];
+        int64_t rank = 0;
+        for (int64_t j = 0; j < k; ++j) rank += (hit_idx[j] < mine) ? 1 : 0;
+        if (rank < cap) { out_idx[rank] = (int64_t)mine + 1; out_val[rank] = hit_val[e]; }
+    }
+}
+
+int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
+                                 int64_t* inds_host, double* ds_host, int64_t cap)
+{
+    int32_t rc;
+    if ((rc = mpfmt_build_grid(ctx, r))) return rc;
+    const int64_t N = ctx->N;
+    // scratch: hit_idx[N] hit_val[N] out_idx[N] out_val[N] k
+    size_t o_hi = 0, o_hv = o_hi + ((sizeof(int32_t) * N + 15) & ~(size_t)15), o_oi = o_hv + sizeof(double) * N,
+           o_ov = o_oi + sizeof(int64_t) * N, o_k = o_ov + sizeof(double) * N;
+    void* scr;
+    if ((rc = mpfmt_scratch(ctx, o_k + 16, &scr))) return rc;
+    char* s = (char*)scr;
+    const double rpad = r * (1.0 + 1e-9) + 1e-300;
+    const mpfmt_grid& G = ctx->grid;
+#define CASE(DD) case DD: hipLaunchKernelGGL((k_rdisc_query<DD>), dim3(1), dim3(256), 0, ctx->stream, ctx->Xt, ctx->perm, \
+        ctx->cellstart, ctx->iperm, G, v0, r * r, rpad, (int32_t*)(s + o_hi), (double*)(s + o_hv), (int64_t*)(s + o_k), \
+        (int64_t*)(s + o_oi), (double*)(s + o_ov), N); break;
+    switch (ctx->d) {
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+        CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
+        default: return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unsupported dimension %d", ctx->d);
+    }
+#undef CASE
+    HIPCHK(ctx, hipGetLastError());
+    int64_t k = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&k, s + o_k, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *k_out = k;
+    const int64_t kk = std::min(k, cap);
+    if (kk > 0 && inds_host) HIPCHK(ctx, hipMemcpy(inds_host, s + o_oi, sizeof(int64_t) * kk, hipMemcpyDeviceToHost));
+    if (kk > 0 && ds_host) HIPCHK(ctx, hipMemcpy(ds_host, s + o_ov, sizeof(double) * kk, hipMemcpyDeviceToHost));
+    return (k > cap) ? MPFMT_ERR_CAPACITY : MPFMT_OK;
+}

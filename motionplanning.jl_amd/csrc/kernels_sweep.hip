@@ -1,0 +1,418 @@
+// Segment-vs-AABB-set and point-vs-AABB-set sweeps on gfx950.
+//
+// Replaces the PointRobotNDBoxes checker of the reference for batches:
+//   is_free_state(v, BL)      src/collisioncheckers/boxesND.jl:42-43
+//   broadphase / narrow phase src/collisioncheckers/boxesND.jl:44-51 (blend: src/utilities/utils.jl:41-51)
+//   is_free_motion(v, w, BL)  src/collisioncheckers/boxesND.jl:52-56
+// wrapped like src/statespaces.jl:150-158 (in_state_space of the segment's first point, Identity s2w,
+// collision_waypoints = (v, w) of src/statespaces/geometric.jl:20).
+//
+// Every predicate is a pure function of its fp64 inputs, evaluated with the reference's operations in
+// the reference's order, unfused (-ffp-contract=off), IEEE division: masks are bit-exact against the
+// oracle.  The reference's @any/@all short-circuits only skip work, never change a result, so the
+// kernels are free to evaluate boxes in any order and to skip boxes that provably cannot matter.
+//
+// Design (MI355X): lane = edge (endpoints in VGPRs).  The obstacle set is staged once per workgroup in
+// LDS ([box][lo(dw),hi(dw)], 16*dw bytes per box; 19.2 KB at dw=6, M=200) and reused by every wavefront
+// of a persistent workgroup.  Before the per-edge loop each wavefront culls the set against the
+// bounding box of ALL its 64 edges: lane l tests box 64*c+l, __ballot gives a 64-bit survivor mask,
+// and the per-edge loop walks only the set bits (wave-uniform s_ff1 loop, LDS broadcast reads).  For
+// graph sweeps a wavefront owns one CSC column, whose edges all live inside the r-ball of the column's
+// sample, so ~7% of the boxes survive at the north-star workload.  The 64 results of a wavefront are
+// one __ballot = one UInt64 chunk of a Julia BitVector (LSB = lowest edge index).
+#include "mpfmt_internal.h"
+#include <algorithm>
+
+#define SWEEP_THREADS 256
+#define SWEEP_LDS_BYTES (60 * 1024)
+
+// ---- exact predicates -----------------------------------------------------------------------------
+
+// in_state_space(v, SS) = @all [lo[i] <= v[i] <= hi[i]]          statespaces.jl:150
+template <int D>
+__device__ __forceinline__ bool in_state_space(const double (&v)[D], const mpfmt_ss& ss)
+{
+    if (!ss.has) return true;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < D; ++i) ok = ok && (ss.lo[i] <= v[i]) && (v[i] <= ss.hi[i]);
+    return ok;
+}
+
+// is_free_state(v, BB) = @any [!(lo[i] <= v[i] <= hi[i])]         boxesND.jl:42
+template <int D>
+__device__ __forceinline__ bool point_outside_box(const double (&v)[D], const double* lo, const double* hi)
+{
+    bool out = false;
+#pragma unroll
+    for (int i = 0; i < D; ++i) out = out || !((lo[i] <= v[i]) && (v[i] <= hi[i]));
+    return out;
+}
+
+// is_free_motion_broadphase(l, h, BB) = @any [hi[i] < l[i] || lo[i] > h[i]]     boxesND.jl:44-45
+template <int D>
+__device__ __forceinline__ bool broadphase_free(const double (&l)[D], const double (&h)[D], const double* lo, const double* hi)
+{
+    bool sep = false;
+#pragma unroll
+    for (int i = 0; i < D; ++i) sep = sep || (hi[i] < l[i]) || (lo[i] > h[i]);
+    return sep;
+}
+
+// is_free_motion(v, w, BB)                                         boxesND.jl:46-51
+template <int D>
+__device__ __forceinline__ bool narrow_free(const double (&v)[D], const double (&w)[D], const double* lo, const double* hi)
+{
+    double v_to_w[D], lambdas[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) v_to_w[i] = w[i] - v[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double corner = (v[i] < lo[i]) ? lo[i] : hi[i];          // blend(v .< lo, lo, hi)
+        lambdas[i] = (corner - v[i]) / v_to_w[i];                      // IEEE: may be +-Inf / NaN
+    }
+    bool hit = false;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        bool all = true;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (j == i) continue;
+            const double prod = v_to_w[j] * lambdas[i];
+            const double x = v[j] + prod;                              // unfused
+            all = all && (lo[j] <= x) && (x <= hi[j]);
+        }
+        hit = hit || all;
+    }
+    return !hit;
+}
+
+template <int D>
+__device__ __forceinline__ void seg_bbox(const double (&v)[D], const double (&w)[D], double (&l)[D], double (&h)[D])
+{
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        l[i] = (w[i] < v[i]) ? w[i] : v[i];        // map(min, v, w)
+        h[i] = (v[i] < w[i]) ? w[i] : v[i];        // map(max, v, w)
+    }
+}
+
+// Stage boxes [b0, b0+nb) into LDS (whole workgroup), layout [box][2*D].
+template <int D>
+__device__ __forceinline__ void stage_boxes(double* sbox, const double* __restrict__ boxes, int b0, int nb)
+{
+    const int n = nb * 2 * D;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) sbox[t] = boxes[(int64_t)b0 * 2 * D + t];
+}
+
+// Wave-level cull of nb (<= SWEEP_CHUNK) staged boxes against the union box [ulo, uhi] of the
+// wavefront's segments.  Survivor words stay in (wave-uniform) registers.
+#define SWEEP_CHUNK 256
+#define SWEEP_WORDS (SWEEP_CHUNK / 64)
+template <int D>
+__device__ __forceinline__ void cull_boxes(const double* sbox, int nb, const double (&ulo)[D], const double (&uhi)[D],
+                                           unsigned long long (&smask)[SWEEP_WORDS], int lane)
+{
+#pragma unroll
+    for (int c = 0; c < SWEEP_WORDS; ++c) {
+        const int k = c * 64 + lane;
+        bool keep = false;
+        if (k < nb) {
+            const double* lo = sbox + (int64_t)k * 2 * D;
+            const double* hi = lo + D;
+            keep = true;
+#pragma unroll
+            for (int i = 0; i < D; ++i) keep = keep && !((hi[i] < ulo[i]) || (lo[i] > uhi[i]));
+        }
+        smask[c] = __ballot(keep);
+    }
+}
+
+// Test one segment against the surviving staged boxes; returns "free so far".
+template <int D>
+__device__ __forceinline__ bool sweep_segment(const double* sbox, const unsigned long long (&smask)[SWEEP_WORDS],
+                                              const double (&v)[D], const double (&w)[D], bool freeflag)
+{
+    double l[D], h[D];
+    seg_bbox<D>(v, w, l, h);
+#pragma unroll
+    for (int c = 0; c < SWEEP_WORDS; ++c) {
+        unsigned long long m = smask[c];
+        while (m) {
+            const int k = c * 64 + (__ffsll((long long)m) - 1);
+            m &= m - 1;
+            const double* lo = sbox + (int64_t)k * 2 * D;
+            const double* hi = lo + D;
+            if (freeflag && !broadphase_free<D>(l, h, lo, hi)) freeflag = narrow_free<D>(v, w, lo, hi);
+        }
+    }
+    return freeflag;
+}
+
+// ---- points ---------------------------------------------------------------------------------------
+// bit e = in_state_space(p) && all boxes: point outside box.  P: explicit points [n][D] (idx1 == null)
+// or samples gathered through 1-based idx1 (or identity if both null and use_samples).
+template <int D>
+__global__ __launch_bounds__(SWEEP_THREADS) void k_points_free(const double* __restrict__ X, const int64_t* __restrict__ idx1,
+                                                               int64_t n, const double* __restrict__ boxes, int M, int chunk,
+                                                               mpfmt_ss ss, uint64_t* __restrict__ mask)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sbox = (double*)smem;
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * SWEEP_THREADS + threadIdx.x;
+    const bool active = e < n;
+    double v[D];
+    int64_t src = 0;
+    if (active) src = idx1 ? idx1[e] - 1 : e;
+#pragma unroll
+    for (int i = 0; i < D; ++i) v[i] = active ? X[src * D + i] : 0.0;
+    bool fr = active && in_state_space<D>(v, ss);
+    for (int b0 = 0; b0 < M; b0 += chunk) {
+        const int nb = min(chunk, M - b0);
+        __syncthreads();
+        stage_boxes<D>(sbox, boxes, b0, nb);
+        __syncthreads();
+        for (int k = 0; k < nb; ++k) {
+            const double* lo = sbox + (int64_t)k * 2 * D;
+            fr = fr && point_outside_box<D>(v, lo, lo + D);
+        }
+    }
+    const unsigned long long bits = __ballot(fr);
+    if (lane == 0 && (e - lane) < n) mask[(e - lane) >> 6] = bits;
+}
+
+// ---- explicit edge lists -----------------------------------------------------------------------------
+// bit e = in_state_space(v) && is_free_motion(v, w, boxes);  v/w gathered from samples via 1-based
+// src1/dst1, or read from explicit arrays P/Q when src1 == null.
+template <int D>
+__global__ __launch_bounds__(SWEEP_THREADS) void k_edges_free(const double* __restrict__ X, const int64_t* __restrict__ src1,
+                                                              const int64_t* __restrict__ dst1, const double* __restrict__ P,
+                                                              const double* __restrict__ Q, int64_t E,
+                                                              const double* __restrict__ boxes, int M, int chunk,
+                                                              mpfmt_ss ss, uint64_t* __restrict__ mask)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sbox = (double*)smem;
+    unsigned long long smask[SWEEP_WORDS];
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * SWEEP_THREADS + threadIdx.x;
+    const bool active = e < E;
+    double v[D], w[D];
+    if (src1) {
+        const int64_t s = active ? src1[e] - 1 : 0, t = active ? dst1[e] - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) { v[i] = active ? X[s * D + i] : 0.0; w[i] = active ? X[t * D + i] : 0.0; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < D; ++i) { v[i] = active ? P[e * D + i] : 0.0; w[i] = active ? Q[e * D + i] : 0.0; }
+    }
+    bool fr = active && in_state_space<D>(v, ss);
+    // union box of the wavefront's active segments
+    double ulo[D], uhi[D];
+    {
+        double l[D], h[D];
+        seg_bbox<D>(v, w, l, h);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double mn = active ? l[i] : __builtin_inf(), mx = active ? h[i] : -__builtin_inf();
+            for (int off = 32; off > 0; off >>= 1) {
+                const double a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
+                mn = (a < mn) ? a : mn;
+                mx = (b > mx) ? b : mx;
+            }
+            ulo[i] = mn; uhi[i] = mx;
+        }
+    }
+    for (int b0 = 0; b0 < M; b0 += chunk) {
+        const int nb = min(chunk, M - b0);
+        __syncthreads();
+        stage_boxes<D>(sbox, boxes, b0, nb);
+        __syncthreads();
+        cull_boxes<D>(sbox, nb, ulo, uhi, smask, lane);
+        fr = sweep_segment<D>(sbox, smask, v, w, fr);
+    }
+    const unsigned long long bits = __ballot(fr);
+    if (lane == 0 && (e - lane) < E) mask[(e - lane) >> 6] = bits;
+}
+
+// ---- graph sweep ---------------------------------------------------------------------------------
+// One wavefront per CSC column x (persistent workgroups, boxes staged once): entry e with row y gets
+// bit e = in_state_space(V[y]) && is_free_motion(V[y], V[x]).  All rows lie within rpad of V[x], so the
+// cull box is V[x] +- rpad.  Mask words are shared between adjacent columns -> atomicOr into a zeroed mask.
+template <int D>
+__global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
+                                                               const int32_t* __restrict__ rowval, int64_t N, double rpad,
+                                                               const double* __restrict__ boxes, int M, int chunk,
+                                                               mpfmt_ss ss, unsigned long long* __restrict__ mask)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sbox = (double*)smem;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long smask[SWEEP_WORDS];
+    const int64_t nwaves = (int64_t)gridDim.x * (SWEEP_THREADS / 64);
+    const int64_t wid = (int64_t)blockIdx.x * (SWEEP_THREADS / 64) + wave;
+
+    for (int b0 = 0; b0 < M || b0 == 0; b0 += chunk) {
+        const int nb = max(0, min(chunk, M - b0));
+        __syncthreads();
+        stage_boxes<D>(sbox, boxes, b0, nb);
+        __syncthreads();
+        for (int64_t x = wid; x < N; x += nwaves) {
+            const int64_t beg = colptr[x], end = colptr[x + 1];
+            if (end == beg) continue;
+            double w[D], ulo[D], uhi[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { w[i] = X[x * D + i]; ulo[i] = w[i] - rpad; uhi[i] = w[i] + rpad; }
+            cull_boxes<D>(sbox, nb, ulo, uhi, smask, lane);
+            for (int64_t wd = beg >> 6; wd <= ((end - 1) >> 6); ++wd) {
+                const int64_t e = wd * 64 + lane;
+                const bool active = (e >= beg) && (e < end);
+                double v[D];
+                const int64_t y = active ? rowval[e] : x;
+#pragma unroll
+                for (int i = 0; i < D; ++i) v[i] = X[y * D + i];
+                // first chunk decides in_state_space; later chunks can only clear bits
+                bool fr = active && (b0 > 0 || in_state_space<D>(v, ss));
+                fr = sweep_segment<D>(sbox, smask, v, w, fr);
+                unsigned long long bits = __ballot(fr);
+                if (b0 > 0) {
+                    // multi-chunk obstacle sets: AND with what earlier chunks left
+                    const unsigned long long act = __ballot(active);
+                    if (lane == 0) atomicAnd(&mask[wd], bits | ~act);
+                } else if (lane == 0 && bits) {
+                    atomicOr(&mask[wd], bits);
+                }
+            }
+        }
+        if (M == 0) break;
+    }
+}
+
+// ---- launchers -------------------------------------------------------------------------------------
+static int box_chunk(int M, int D, bool culled)
+{
+    // boxes per LDS stage: 16*D bytes per box; culled kernels keep survivor words in registers
+    int chunk = (int)((SWEEP_LDS_BYTES - 64) / (16 * D));
+    chunk = std::max(64, (chunk / 64) * 64);
+    if (culled) chunk = std::min(chunk, SWEEP_CHUNK);
+    if (M < chunk) chunk = std::max(1, M);
+    return chunk;
+}
+static size_t sweep_lds(int chunk, int D)
+{
+    return (size_t)chunk * 2 * D * sizeof(double) + 16;
+}
+
+#define DISPATCH_D(DIM, EXPR)                                                                         \
+    switch (DIM) {                                                                                    \
+        case 1: { constexpr int DD = 1; EXPR; } break;   case 2: { constexpr int DD = 2; EXPR; } break;   \
+        case 3: { constexpr int DD = 3; EXPR; } break;   case 4: { constexpr int DD = 4; EXPR; } break;   \
+        case 5: { constexpr int DD = 5; EXPR; } break;   case 6: { constexpr int DD = 6; EXPR; } break;   \
+        case 7: { constexpr int DD = 7; EXPR; } break;   case 8: { constexpr int DD = 8; EXPR; } break;   \
+        case 9: { constexpr int DD = 9; EXPR; } break;   case 10: { constexpr int DD = 10; EXPR; } break; \
+        case 11: { constexpr int DD = 11; EXPR; } break; case 12: { constexpr int DD = 12; EXPR; } break; \
+        case 13: { constexpr int DD = 13; EXPR; } break; case 14: { constexpr int DD = 14; EXPR; } break; \
+        case 15: { constexpr int DD = 15; EXPR; } break; case 16: { constexpr int DD = 16; EXPR; } break; \
+        default: return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unsupported dimension %d", (int)(DIM));       \
+    }
+
+static int32_t check_boxes(mpfmt_ctx* ctx, int d)
+{
+    if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
+    if (ctx->dw != d)
+        return mpfmt_fail(ctx, MPFMT_ERR_ARG, "workspace dim %d != state dim %d (only Identity state2workspace on this path)", ctx->dw, d);
+    return MPFMT_OK;
+}
+
+static int32_t launch_points(mpfmt_ctx* ctx, const double* X, const int64_t* idx1, int64_t n, int d, uint64_t* d_mask)
+{
+    if (n == 0) return MPFMT_OK;
+    const int chunk = box_chunk(ctx->M, d, false);
+    const size_t lds = sweep_lds(chunk, d);
+    const unsigned nb = (unsigned)((n + SWEEP_THREADS - 1) / SWEEP_THREADS);
+    DISPATCH_D(d, hipLaunchKernelGGL((k_points_free<DD>), dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream,
+                                     X, idx1, n, ctx->boxes, ctx->M, chunk, ctx->ss, d_mask));
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_launch_points_free(mpfmt_ctx* ctx, const int64_t* d_idx1, int64_t n, uint64_t* d_mask)
+{
+    int32_t rc;
+    if ((rc = check_boxes(ctx, ctx->d))) return rc;
+    mpfmt_time_begin(ctx);
+    rc = launch_points(ctx, ctx->Xo, d_idx1, n, ctx->d, d_mask);
+    mpfmt_time_end(ctx, "sweep_points");
+    return rc;
+}
+
+int32_t mpfmt_launch_states_free(mpfmt_ctx* ctx, const double* d_P, int64_t n, uint64_t* d_mask)
+{
+    int32_t rc;
+    if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
+    mpfmt_time_begin(ctx);
+    rc = launch_points(ctx, d_P, nullptr, n, ctx->dw, d_mask);
+    mpfmt_time_end(ctx, "sweep_points");
+    return rc;
+}
+
+static int32_t launch_edges(mpfmt_ctx* ctx, const int64_t* s1, const int64_t* t1, const double* P, const double* Q,
+                            int64_t E, int d, uint64_t* d_mask)
+{
+    if (E == 0) return MPFMT_OK;
+    const int chunk = box_chunk(ctx->M, d, true);
+    const size_t lds = sweep_lds(chunk, d);
+    const unsigned nb = (unsigned)((E + SWEEP_THREADS - 1) / SWEEP_THREADS);
+    DISPATCH_D(d, hipLaunchKernelGGL((k_edges_free<DD>), dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream,
+                                     ctx->Xo, s1, t1, P, Q, E, ctx->boxes, ctx->M, chunk, ctx->ss, d_mask));
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_launch_edges_free(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, uint64_t* d_mask)
+{
+    int32_t rc;
+    if ((rc = check_boxes(ctx, ctx->d))) return rc;
+    mpfmt_time_begin(ctx);
+    rc = launch_edges(ctx, d_src1, d_dst1, nullptr, nullptr, E, ctx->d, d_mask);
+    mpfmt_time_end(ctx, "sweep_edges");
+    return rc;
+}
+
+int32_t mpfmt_launch_motions_free(mpfmt_ctx* ctx, const double* d_P, const double* d_Q, int64_t n, uint64_t* d_mask)
+{
+    int32_t rc;
+    if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
+    mpfmt_time_begin(ctx);
+    rc = launch_edges(ctx, nullptr, nullptr, d_P, d_Q, n, ctx->dw, d_mask);
+    mpfmt_time_end(ctx, "sweep_edges");
+    return rc;
+}
+
+int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
+{
+    int32_t rc;
+    if ((rc = check_boxes(ctx, ctx->d))) return rc;
+    if (!ctx->graph_filled) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "graph sweep before the r-disc graph is filled");
+    const int64_t words = (ctx->nnz + 63) / 64;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->graph_free, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1)))) return rc;
+    mpfmt_time_begin(ctx);
+    HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
+    if (ctx->nnz > 0) {
+        const int d = ctx->d;
+        const int waves = SWEEP_THREADS / 64;
+        const int chunk = box_chunk(ctx->M, d, true);
+        const size_t lds = sweep_lds(chunk, d);
+        const double rpad = ctx->graph_r * (1.0 + 1e-9) + 1e-300;
+        // persistent workgroups: boxes are staged once per workgroup, columns are grid-strided
+        const unsigned nb = (unsigned)std::min<int64_t>((ctx->N + waves - 1) / waves, 256 * 8);
+        DISPATCH_D(d, hipLaunchKernelGGL((k_graph_sweep<DD>), dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream,
+                                         ctx->Xo, ctx->colptr, ctx->rowval, ctx->N, rpad, ctx->boxes, ctx->M, chunk,
+                                         ctx->ss, (unsigned long long*)ctx->graph_free));
+        HIPCHK(ctx, hipGetLastError());
+    }
+    mpfmt_time_end(ctx, "sweep_graph");
+    ctx->graph_swept = true;
+    return MPFMT_OK;
+}

@@ -1,0 +1,687 @@
+// C ABI of libmpfmt.so (see include/mpfmt.h).  Host-side plumbing only: argument checks, device
+// buffers for caller-owned host arrays, 1-based <-> 0-based conversion, and the sequential FMT*
+// recursion of the reference (src/planners/fmt.jl:68-90) run over GPU-built arrays.
+// There is NO CPU fallback for any compute entry point: without a gfx950 device ctx_create fails.
+#include "mpfmt_internal.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <chrono>
+#include <algorithm>
+#include <vector>
+
+static thread_local std::string g_create_err;
+
+int32_t mpfmt_fail(mpfmt_ctx* ctx, int32_t code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_err = buf;
+    return code;
+}
+
+int32_t mpfmt_scratch(mpfmt_ctx* ctx, size_t bytes, void** out)
+{
+    if (bytes > ctx->scratch_bytes) {
+        if (ctx->scratch) HIPCHK(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        HIPCHK(ctx, hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_ensure(mpfmt_ctx* ctx, void** p, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    auto it = ctx->caps.find((void*)p);
+    if (*p && it != ctx->caps.end() && it->second >= bytes) return MPFMT_OK;
+    if (*p) { HIPCHK(ctx, hipFree(*p)); *p = nullptr; }
+    HIPCHK(ctx, hipMalloc(p, bytes));
+    ctx->caps[(void*)p] = bytes;
+    return MPFMT_OK;
+}
+
+// ---- timing: HIP events on the launch stream, small stack so groups may nest ------------------------
+#define TIMER_DEPTH 4
+struct timer_stack { hipEvent_t a[TIMER_DEPTH], b[TIMER_DEPTH]; int depth; bool init; };
+static std::map<mpfmt_ctx*, timer_stack> g_timers;
+
+void mpfmt_time_begin(mpfmt_ctx* ctx)
+{
+    if (!ctx->timing_enabled) return;
+    timer_stack& t = g_timers[ctx];
+    if (!t.init) {
+        for (int i = 0; i < TIMER_DEPTH; ++i) { hipEventCreate(&t.a[i]); hipEventCreate(&t.b[i]); }
+        t.depth = 0; t.init = true;
+    }
+    if (t.depth < TIMER_DEPTH) hipEventRecord(t.a[t.depth], ctx->stream);
+    ++t.depth;
+}
+
+void mpfmt_time_end(mpfmt_ctx* ctx, const char* name)
+{
+    if (!ctx->timing_enabled) return;
+    timer_stack& t = g_timers[ctx];
+    if (!t.init || t.depth <= 0) return;
+    --t.depth;
+    if (t.depth >= TIMER_DEPTH) return;
+    hipEventRecord(t.b[t.depth], ctx->stream);
+    hipEventSynchronize(t.b[t.depth]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.a[t.depth], t.b[t.depth]) == hipSuccess) {
+        mpfmt_timer& tm = ctx->timers[name];
+        tm.total_ms += ms;
+        tm.launches += 1;
+    }
+}
+
+// ---- small conversion kernels --------------------------------------------------------------------------
+__global__ void k_add1_i64(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + 1;
+}
+__global__ void k_i32_to_i64_add1(const int32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int64_t)in[i] + 1;
+}
+
+extern "C" {
+
+const char* mpfmt_version(void) { return "mpfmt 0.1.0 gfx950"; }
+
+const char* mpfmt_last_error(const mpfmt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int32_t mpfmt_ctx_create(int32_t device, mpfmt_ctx** out)
+{
+    if (!out) return mpfmt_fail(nullptr, MPFMT_ERR_ARG, "ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return mpfmt_fail(nullptr, MPFMT_ERR_NODEVICE, "no HIP device visible (%s); libmpfmt has no CPU fallback",
+                          e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return mpfmt_fail(nullptr, MPFMT_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+        return mpfmt_fail(nullptr, MPFMT_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return mpfmt_fail(nullptr, MPFMT_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    if ((e = hipSetDevice(device)) != hipSuccess)
+        return mpfmt_fail(nullptr, MPFMT_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    mpfmt_ctx* ctx = new mpfmt_ctx();
+    ctx->device = device;
+    ctx->ss.has = 0; ctx->ss.d = 0;
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete ctx;
+        return mpfmt_fail(nullptr, MPFMT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
+{
+    if (!ctx) return MPFMT_OK;
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi,
+                    ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
+                    ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch};
+    for (void* b : bufs) if (b) hipFree(b);
+    auto it = g_timers.find(ctx);
+    if (it != g_timers.end()) {
+        if (it->second.init) for (int i = 0; i < TIMER_DEPTH; ++i) { hipEventDestroy(it->second.a[i]); hipEventDestroy(it->second.b[i]); }
+        g_timers.erase(it);
+    }
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_set_stream(mpfmt_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_set_shard(mpfmt_ctx* ctx, int32_t rank, int32_t world)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (world < 1 || rank < 0 || rank >= world) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "bad shard %d of %d", rank, world);
+    ctx->rank = rank; ctx->world = world;
+    ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t d)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (N < 0 || N >= ((int64_t)1 << 31) - 64) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "N = %lld out of range", (long long)N);
+    if (d < 1 || d > MPFMT_MAX_DIM) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "d = %d out of range [1,%d]", d, MPFMT_MAX_DIM);
+    if (N > 0 && !X) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "X is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < d; ++i) { ctx->bb_lo[i] = INFINITY; ctx->bb_hi[i] = -INFINITY; }
+    for (int64_t p = 0; p < N; ++p)
+        for (int i = 0; i < d; ++i) {
+            const double a = X[p * d + i];
+            if (!std::isfinite(a)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "sample %lld has a non-finite coordinate", (long long)(p + 1));
+            if (a < ctx->bb_lo[i]) ctx->bb_lo[i] = a;
+            if (a > ctx->bb_hi[i]) ctx->bb_hi[i] = a;
+        }
+    if (N == 0) for (int i = 0; i < d; ++i) { ctx->bb_lo[i] = 0; ctx->bb_hi[i] = 0; }
+    int32_t rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->Xo, sizeof(double) * (size_t)N * d))) return rc;
+    if (N > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->Xo, X, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->N = N; ctx->d = d;
+    ctx->grid_r = -1.0; ctx->graph_r = -1.0;
+    ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
+    ctx->nnz = 0;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_upload_boxes(mpfmt_ctx* ctx, const double* lohi, int32_t M, int32_t dw,
+                           const double* ss_lo, const double* ss_hi, int32_t d_state)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (M < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "M = %d < 0", M);
+    if (dw < 1 || dw > MPFMT_MAX_DIM) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "dw = %d out of range", dw);
+    if (M > 0 && !lohi) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "lohi is NULL");
+    if ((ss_lo == nullptr) != (ss_hi == nullptr)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "ss_lo / ss_hi must both be given or both NULL");
+    if (ss_lo && (d_state < 1 || d_state > MPFMT_MAX_DIM)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "d_state = %d out of range", d_state);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->boxes, sizeof(double) * (size_t)M * 2 * dw))) return rc;
+    if (M > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->boxes, lohi, sizeof(double) * (size_t)M * 2 * dw, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->M = M; ctx->dw = dw; ctx->have_boxes = true;
+    ctx->ss.has = ss_lo ? 1 : 0;
+    ctx->ss.d = ss_lo ? d_state : 0;
+    for (int i = 0; i < MPFMT_MAX_DIM; ++i) { ctx->ss.lo[i] = -INFINITY; ctx->ss.hi[i] = INFINITY; }
+    if (ss_lo) for (int i = 0; i < d_state; ++i) { ctx->ss.lo[i] = ss_lo[i]; ctx->ss.hi[i] = ss_hi[i]; }
+    ctx->graph_swept = false;
+    return MPFMT_OK;
+}
+
+// ---- r-disc graph ------------------------------------------------------------------------------------
+
+int32_t mpfmt_graph_build_device(mpfmt_ctx* ctx, double r, int64_t* nnz)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!(r >= 0.0) || !std::isfinite(r)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "radius must be finite and >= 0");
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
+    if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
+    if (nnz) *nnz = ctx->nnz;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_rdisc_count(mpfmt_ctx* ctx, double r, int64_t* colptr, int64_t* nnz)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!colptr || !nnz) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "colptr / nnz is NULL");
+    if (!(r >= 0.0) || !std::isfinite(r)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "radius must be finite and >= 0");
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
+    const int64_t n1 = ctx->N + 1;
+    void* scr;
+    if ((rc = mpfmt_scratch(ctx, sizeof(int64_t) * n1, &scr))) return rc;
+    hipLaunchKernelGGL(k_add1_i64, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->colptr, n1, (int64_t*)scr);
+    HIPCHK(ctx, hipMemcpyAsync(colptr, scr, sizeof(int64_t) * n1, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *nnz = ctx->nnz;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_rdisc_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->graph_counted) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "rdisc_fill before rdisc_count");
+    if (ctx->nnz > 0 && (!rowval || !nzval)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "rowval / nzval is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if (!ctx->graph_filled && (rc = mpfmt_launch_rdisc_fill(ctx, ctx->graph_r))) return rc;
+    const int64_t nnz = ctx->nnz;
+    if (nnz > 0) {
+        // convert in slabs so the staging buffer stays small
+        const int64_t slab = std::min<int64_t>(nnz, (int64_t)1 << 26);
+        void* scr;
+        if ((rc = mpfmt_scratch(ctx, sizeof(int64_t) * slab, &scr))) return rc;
+        for (int64_t o = 0; o < nnz; o += slab) {
+            const int64_t n = std::min(slab, nnz - o);
+            hipLaunchKernelGGL(k_i32_to_i64_add1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->rowval + o, n, (int64_t*)scr);
+            HIPCHK(ctx, hipMemcpyAsync(rowval + o, scr, sizeof(int64_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        HIPCHK(ctx, hipMemcpyAsync(nzval, ctx->nzval, sizeof(double) * nnz, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_rdisc_query(mpfmt_ctx* ctx, int64_t v, double r, int64_t* inds, double* ds, int64_t cap, int64_t* k)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!k) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "k is NULL");
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    if (v < 1 || v > ctx->N) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "query index %lld out of range [1,%lld]", (long long)v, (long long)ctx->N);
+    if (!(r >= 0.0) || !std::isfinite(r)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "radius must be finite and >= 0");
+    if (cap < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "cap < 0");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc = mpfmt_launch_rdisc_query(ctx, v - 1, r, k, inds, ds, cap);
+    if (rc == MPFMT_ERR_CAPACITY) return mpfmt_fail(ctx, rc, "rdisc_query: %lld neighbours exceed capacity %lld", (long long)*k, (long long)cap);
+    return rc;
+}
+
+// ---- validity sweeps ---------------------------------------------------------------------------------
+
+static int32_t up_i64(mpfmt_ctx* ctx, const int64_t* h, int64_t n, int64_t** d)
+{
+    *d = nullptr;
+    HIPCHK(ctx, hipMalloc((void**)d, sizeof(int64_t) * (size_t)std::max<int64_t>(n, 1)));
+    if (n > 0) HIPCHK(ctx, hipMemcpyAsync(*d, h, sizeof(int64_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    return MPFMT_OK;
+}
+
+static int32_t check_idx(mpfmt_ctx* ctx, const int64_t* idx, int64_t n, const char* what)
+{
+    for (int64_t i = 0; i < n; ++i)
+        if (idx[i] < 1 || idx[i] > ctx->N)
+            return mpfmt_fail(ctx, MPFMT_ERR_ARG, "%s[%lld] = %lld out of range [1,%lld]", what, (long long)i, (long long)idx[i], (long long)ctx->N);
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_points_free(mpfmt_ctx* ctx, const int64_t* idx, int64_t n, uint64_t* mask)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    if (!idx) n = ctx->N;
+    if (n < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "n < 0");
+    if (n > 0 && !mask) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "mask is NULL");
+    if (n == 0) return MPFMT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if (idx && (rc = check_idx(ctx, idx, n, "idx"))) return rc;
+    const int64_t words = (n + 63) / 64;
+    int64_t* d_idx = nullptr; uint64_t* d_mask = nullptr;
+    if (idx && (rc = up_i64(ctx, idx, n, &d_idx))) return rc;
+    HIPCHK(ctx, hipMalloc((void**)&d_mask, sizeof(uint64_t) * words));
+    rc = mpfmt_launch_points_free(ctx, d_idx, n, d_mask);
+    if (rc == MPFMT_OK) {
+        hipError_t e = hipMemcpyAsync(mask, d_mask, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "points_free copy back: %s", hipGetErrorString(e));
+    }
+    if (d_idx) hipFree(d_idx);
+    hipFree(d_mask);
+    return rc;
+}
+
+int32_t mpfmt_edges_free(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, uint64_t* mask)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    if (E < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "E < 0");
+    if (E == 0) return MPFMT_OK;
+    if (!src || !dst || !mask) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "src / dst / mask is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = check_idx(ctx, src, E, "src")) || (rc = check_idx(ctx, dst, E, "dst"))) return rc;
+    const int64_t words = (E + 63) / 64;
+    int64_t *d_s = nullptr, *d_t = nullptr; uint64_t* d_mask = nullptr;
+    if ((rc = up_i64(ctx, src, E, &d_s))) return rc;
+    if ((rc = up_i64(ctx, dst, E, &d_t))) { hipFree(d_s); return rc; }
+    HIPCHK(ctx, hipMalloc((void**)&d_mask, sizeof(uint64_t) * words));
+    rc = mpfmt_launch_edges_free(ctx, d_s, d_t, E, d_mask);
+    if (rc == MPFMT_OK) {
+        hipError_t e = hipMemcpyAsync(mask, d_mask, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "edges_free copy back: %s", hipGetErrorString(e));
+    }
+    hipFree(d_s); hipFree(d_t); hipFree(d_mask);
+    return rc;
+}
+
+static int32_t explicit_sweep(mpfmt_ctx* ctx, const double* P, const double* Q, int64_t n, uint64_t* mask)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (n < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "n < 0");
+    if (n == 0) return MPFMT_OK;
+    if (!P || !mask) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "P / mask is NULL");
+    if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int d = ctx->dw;
+    const int64_t words = (n + 63) / 64;
+    const size_t pb = sizeof(double) * (size_t)n * d;
+    double *dP = nullptr, *dQ = nullptr; uint64_t* d_mask = nullptr;
+    HIPCHK(ctx, hipMalloc((void**)&dP, pb));
+    HIPCHK(ctx, hipMemcpyAsync(dP, P, pb, hipMemcpyHostToDevice, ctx->stream));
+    if (Q) {
+        HIPCHK(ctx, hipMalloc((void**)&dQ, pb));
+        HIPCHK(ctx, hipMemcpyAsync(dQ, Q, pb, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(ctx, hipMalloc((void**)&d_mask, sizeof(uint64_t) * words));
+    int32_t rc = Q ? mpfmt_launch_motions_free(ctx, dP, dQ, n, d_mask) : mpfmt_launch_states_free(ctx, dP, n, d_mask);
+    if (rc == MPFMT_OK) {
+        hipError_t e = hipMemcpyAsync(mask, d_mask, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "sweep copy back: %s", hipGetErrorString(e));
+    }
+    hipFree(dP); if (dQ) hipFree(dQ); hipFree(d_mask);
+    return rc;
+}
+
+int32_t mpfmt_states_free(mpfmt_ctx* ctx, const double* P, int64_t n, uint64_t* mask) { return explicit_sweep(ctx, P, nullptr, n, mask); }
+
+int32_t mpfmt_motions_free(mpfmt_ctx* ctx, const double* P, const double* Q, int64_t n, uint64_t* mask)
+{
+    if (ctx && n > 0 && !Q) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "Q is NULL");
+    return explicit_sweep(ctx, P, Q, n, mask);
+}
+
+int32_t mpfmt_graph_sweep_device(mpfmt_ctx* ctx)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return mpfmt_launch_graph_sweep(ctx);
+}
+
+int32_t mpfmt_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if (!ctx->graph_counted) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "graph_edges_free before rdisc_count");
+    if (!ctx->graph_filled && (rc = mpfmt_launch_rdisc_fill(ctx, ctx->graph_r))) return rc;
+    if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+    const int64_t words = (ctx->nnz + 63) / 64;
+    if (words > 0) {
+        if (!mask) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "mask is NULL");
+        HIPCHK(ctx, hipMemcpyAsync(mask, ctx->graph_free, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** rowval, void** nzval, void** free_mask)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->graph_filled) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no resident graph");
+    if (colptr) *colptr = ctx->colptr;
+    if (rowval) *rowval = ctx->rowval;
+    if (nzval) *nzval = ctx->nzval;
+    if (free_mask) *free_mask = ctx->graph_swept ? ctx->graph_free : nullptr;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_shard_info(mpfmt_ctx* ctx, int64_t* col_begin, int64_t* col_end, int64_t* shard_nnz)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->graph_counted) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no graph counted");
+    if (col_begin) *col_begin = std::min<int64_t>(ctx->tile_begin * 64, ctx->N);
+    if (col_end) *col_end = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
+    if (shard_nnz) *shard_nnz = ctx->nnz;
+    return MPFMT_OK;
+}
+
+// ---- expand --------------------------------------------------------------------------------------------
+
+int32_t mpfmt_expand(mpfmt_ctx* ctx, const uint64_t* W, const uint64_t* H, const uint64_t* F, const double* C,
+                     const int64_t* zs, int64_t nz,
+                     int64_t* xs, int64_t* ymin, double* cmin, uint8_t* free_out, int64_t cap, int64_t* nx)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!W || !H || !C || !nx) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "W / H / C / nx is NULL");
+    if (nz < 0 || cap < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "nz / cap < 0");
+    if (!ctx->graph_filled) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "expand needs a built r-disc graph (mpfmt_rdisc_count + fill)");
+    if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
+    *nx = 0;
+    if (nz == 0) return MPFMT_OK;
+    if (!zs) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "zs is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = check_idx(ctx, zs, nz, "zs"))) return rc;
+    const int64_t N = ctx->N, words = (N + 63) / 64;
+    uint64_t *dW = nullptr, *dH = nullptr, *dF = nullptr; double* dC = nullptr; int64_t* dz = nullptr;
+    int64_t *dxs = nullptr, *dym = nullptr; double* dcm = nullptr; uint8_t* dfr = nullptr;
+    const int64_t capd = std::max<int64_t>(cap, 1);
+    HIPCHK(ctx, hipMalloc((void**)&dW, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&dH, 8 * words));
+    HIPCHK(ctx, hipMalloc((void**)&dC, 8 * N));
+    HIPCHK(ctx, hipMemcpyAsync(dW, W, 8 * words, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dH, H, 8 * words, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dC, C, 8 * N, hipMemcpyHostToDevice, ctx->stream));
+    if (F) { HIPCHK(ctx, hipMalloc((void**)&dF, 8 * words)); HIPCHK(ctx, hipMemcpyAsync(dF, F, 8 * words, hipMemcpyHostToDevice, ctx->stream)); }
+    if ((rc = up_i64(ctx, zs, nz, &dz))) return rc;
+    HIPCHK(ctx, hipMalloc((void**)&dxs, 8 * capd)); HIPCHK(ctx, hipMalloc((void**)&dym, 8 * capd));
+    HIPCHK(ctx, hipMalloc((void**)&dcm, 8 * capd)); HIPCHK(ctx, hipMalloc((void**)&dfr, capd));
+    rc = mpfmt_launch_expand(ctx, dW, dH, dF, dC, dz, nz, dxs, dym, dcm, dfr, cap, nx);
+    if (rc == MPFMT_OK && *nx > 0) {
+        const int64_t n = *nx;
+        if (!xs || !ymin || !cmin || !free_out) rc = mpfmt_fail(ctx, MPFMT_ERR_ARG, "output array is NULL");
+        else {
+            hipMemcpyAsync(xs, dxs, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+            hipMemcpyAsync(ymin, dym, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+            hipMemcpyAsync(cmin, dcm, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+            hipMemcpyAsync(free_out, dfr, n, hipMemcpyDeviceToHost, ctx->stream);
+            hipError_t e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "expand copy back: %s", hipGetErrorString(e));
+        }
+    }
+    hipFree(dW); hipFree(dH); hipFree(dC); if (dF) hipFree(dF); hipFree(dz);
+    hipFree(dxs); hipFree(dym); hipFree(dcm); hipFree(dfr);
+    return rc;
+}
+
+// ---- fmtstar -------------------------------------------------------------------------------------------
+
+namespace {
+
+// binary min-heap on (cost, index): Base.Collections.PriorityQueue of fmt.jl:51,66,78,86.  Ties on cost are
+// broken by the lowest sample index (the reference leaves the order of equal priorities unspecified).
+struct Heap {
+    std::vector<double> pri; std::vector<int64_t> idx;
+    bool less(size_t a, size_t b) const { return pri[a] < pri[b] || (pri[a] == pri[b] && idx[a] < idx[b]); }
+    void push(int64_t i, double p)
+    {
+        pri.push_back(p); idx.push_back(i);
+        size_t c = pri.size() - 1;
+        while (c > 0) { size_t par = (c - 1) / 2; if (less(c, par)) { std::swap(pri[c], pri[par]); std::swap(idx[c], idx[par]); c = par; } else break; }
+    }
+    int64_t pop()
+    {
+        int64_t top = idx[0];
+        pri[0] = pri.back(); idx[0] = idx.back(); pri.pop_back(); idx.pop_back();
+        size_t n = pri.size(), c = 0;
+        for (;;) {
+            size_t l = 2 * c + 1, r = l + 1, m = c;
+            if (l < n && less(l, m)) m = l;
+            if (r < n && less(r, m)) m = r;
+            if (m == c) break;
+            std::swap(pri[c], pri[m]); std::swap(idx[c], idx[m]); c = m;
+        }
+        return top;
+    }
+    bool empty() const { return pri.empty(); }
+};
+
+// goal predicates, src/goals.jl:96 (Rectangle), :100 (Ball), :111-114 (Point), Identity state2workspace
+bool is_goal_pt(const double* v, int d, int kind, const double* g)
+{
+    if (kind == MPFMT_GOAL_RECT) {
+        for (int i = 0; i < d; ++i) if (!(g[i] <= v[i] && v[i] <= g[d + i])) return false;
+        return true;
+    }
+    if (kind == MPFMT_GOAL_BALL) {
+        double s = 0.0;
+        for (int i = 0; i < d; ++i) { double t = v[i] - g[i]; double tt = t * t; s = (i == 0) ? tt : s + tt; }
+        return std::sqrt(s) <= g[d];
+    }
+    for (int i = 0; i < d; ++i) if (!(v[i] == g[i])) return false;
+    return true;
+}
+
+inline bool bit(const std::vector<uint64_t>& m, int64_t i) { return (m[i >> 6] >> (i & 63)) & 1ull; }
+
+}  // namespace
+
+int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts,
+                      int32_t goal_kind, const double* goal_params,
+                      int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!A || !C || !path || !res || !goal_params) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "NULL output / goal pointer");
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
+    if (ctx->world != 1) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "fmtstar runs on an unsharded ctx");
+    const int64_t N = ctx->N;
+    const int d = ctx->d;
+    if (init_idx < 1 || init_idx > N) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "init_idx out of range");
+    if (goal_kind < 0 || goal_kind > 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown goal kind %d", goal_kind);
+    if (!(r > 0.0) || !std::isfinite(r)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "radius must be finite and > 0");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    memset(res, 0, sizeof *res);
+    res->cost = INFINITY;
+    int32_t rc;
+
+    // checkpts bitmap F (fmt.jl:31-36) -- also answers is_free_state(init) (fmt.jl:24-29)
+    const int64_t words = (N + 63) / 64;
+    std::vector<uint64_t> F(words, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    if ((rc = mpfmt_points_free(ctx, nullptr, N, F.data()))) return rc;
+    if (!bit(F, init_idx - 1)) return mpfmt_fail(ctx, MPFMT_ERR_INFEASIBLE, "initial state is infeasible");
+    auto t1 = std::chrono::steady_clock::now();
+
+    // r-disc graph + per-edge free mask, all edges, on the device
+    if ((rc = mpfmt_graph_build_device(ctx, r, nullptr))) return rc;
+    auto t2 = std::chrono::steady_clock::now();
+    if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    auto t3 = std::chrono::steady_clock::now();
+    const int64_t nnz = ctx->nnz;
+    std::vector<int64_t> colptr(N + 1);
+    std::vector<int32_t> rowval((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<double> nzval((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<uint64_t> efree((size_t)std::max<int64_t>((nnz + 63) / 64, 1));
+    std::vector<double> X((size_t)N * d);
+    HIPCHK(ctx, hipMemcpy(colptr.data(), ctx->colptr, sizeof(int64_t) * (N + 1), hipMemcpyDeviceToHost));
+    if (nnz > 0) {
+        HIPCHK(ctx, hipMemcpy(rowval.data(), ctx->rowval, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(nzval.data(), ctx->nzval, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(efree.data(), ctx->graph_free, sizeof(uint64_t) * ((nnz + 63) / 64), hipMemcpyDeviceToHost));
+    }
+    HIPCHK(ctx, hipMemcpy(X.data(), ctx->Xo, sizeof(double) * (size_t)N * d, hipMemcpyDeviceToHost));
+    auto t4 = std::chrono::steady_clock::now();
+
+    // the sequential recursion, fmt.jl:43-90, 0-based internally
+    std::vector<uint8_t> Wm(N, 1), Hm(N, 0);
+    std::vector<int64_t> Hnew;
+    for (int64_t i = 0; i < N; ++i) { A[i] = 0; C[i] = 0.0; }
+    Heap heap;
+    const int64_t i0 = init_idx - 1;
+    Wm[i0] = 0; Hm[i0] = 1;
+    heap.push(i0, 0.0);
+    int64_t z = heap.pop();
+    int64_t count = 0;
+    while (!is_goal_pt(&X[(size_t)z * d], d, goal_kind, goal_params)) {
+        Hnew.clear();
+        for (int64_t a = colptr[z]; a < colptr[z + 1]; ++a) {                 // fmt.jl:70
+            const int64_t x = rowval[a];
+            if (!Wm[x]) continue;
+            if (checkpts && !bit(F, x)) continue;                             // fmt.jl:71
+            int64_t y_min = -1, e_min = -1; double c_min = 0.0;
+            for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {             // fmt.jl:72-74
+                const int64_t y = rowval[b];
+                if (!Hm[y]) continue;
+                const double c = C[y] + nzval[b];
+                if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
+            }
+            if (y_min < 0) continue;
+            ++count;                                                          // boxesND.jl:26
+            if (bit(efree, e_min)) {                                          // fmt.jl:75
+                A[x] = y_min + 1; C[x] = c_min;
+                heap.push(x, c_min);
+                Hnew.push_back(x);
+                Wm[x] = 0;
+            }
+        }
+        for (int64_t x : Hnew) Hm[x] = 1;                                     // fmt.jl:83
+        Hm[z] = 0;                                                            // fmt.jl:84
+        if (!heap.empty()) z = heap.pop(); else break;                        // fmt.jl:85-89
+    }
+    // path back-trace, fmt.jl:92-101 (walks until sample 1)
+    std::vector<int64_t> rev;
+    int64_t cur = z;
+    rev.push_back(cur + 1);
+    while (cur != 0) {
+        const int64_t p = A[cur];
+        if (p == 0) break;
+        cur = p - 1;
+        rev.push_back(cur + 1);
+    }
+    for (size_t i = 0; i < rev.size(); ++i) path[i] = rev[rev.size() - 1 - i];
+    auto t5 = std::chrono::steady_clock::now();
+
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    res->status = is_goal_pt(&X[(size_t)z * d], d, goal_kind, goal_params) ? 1 : 0;
+    res->cost = C[z];
+    res->z = z + 1;
+    res->collision_checks = count;
+    res->path_len = (int64_t)rev.size();
+    res->nnz = nnz;
+    res->ms_graph = ms(t1, t2);
+    res->ms_sweep = ms(t0, t1) + ms(t2, t3);
+    res->ms_host_loop = ms(t4, t5);
+    return MPFMT_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------------
+
+int32_t mpfmt_timing_reset(mpfmt_ctx* ctx)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    ctx->timers.clear();
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64_t* launches)
+{
+    if (!ctx || !name) return MPFMT_ERR_ARG;
+    auto it = ctx->timers.find(name);
+    double a = 0.0; int64_t n = 0;
+    if (it != ctx->timers.end() && it->second.launches > 0) { n = it->second.launches; a = it->second.total_ms / (double)n; }
+    if (avg_ms) *avg_ms = a;
+    if (launches) *launches = n;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_graph_stats(mpfmt_ctx* ctx, int64_t* pairs_tested, int64_t* tiles, int64_t* slices, int64_t* cells)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->graph_counted) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no graph counted");
+    if (pairs_tested) *pairs_tested = ctx->pairs_tested;
+    if (tiles) *tiles = ctx->tile_end - ctx->tile_begin;
+    if (slices) *slices = ctx->S;
+    if (cells) *cells = ctx->grid.ncells;
+    return MPFMT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// Internal declarations shared by the translation units of libmpfmt.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <map>
+#include <vector>
+#include "../../include/mpfmt.h"
+
+#define MPFMT_WAVE 64           // CDNA wavefront width; tile of samples = one wavefront of queries
+#define MPFMT_MAXS 16           // max candidate slices per tile
+
+struct mpfmt_timer {
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+// Geometry of the uniform cell grid that bins the samples for one radius (host copy; passed by value
+// to kernels).  Cells are at least r wide in every gridded dimension, so the neighbours of a point in
+// cell c lie in cells c-1..c+1.  Linear cell id is row-major with the LAST gridded dimension fastest,
+// so a run of cells along that dimension is a contiguous range of the cell-sorted sample array.
+struct mpfmt_grid {
+    int32_t gd;                          // dims are all gridded; g[i] == 1 means "not split"
+    int32_t g[MPFMT_MAX_DIM];            // cells per dimension
+    double  lo[MPFMT_MAX_DIM];           // lower corner of the sample bounding box
+    double  w[MPFMT_MAX_DIM];            // cell width
+    double  inv_w[MPFMT_MAX_DIM];
+    int64_t stride[MPFMT_MAX_DIM];       // linear-id stride per dimension
+    int64_t ncells;
+};
+
+struct mpfmt_boxes_dev {                 // obstacle set in HBM: [M][2][dw] (lo then hi per box)
+    const double* lohi;
+    int32_t M;
+    int32_t dw;
+};
+
+struct mpfmt_ss {                        // BoundedStateSpace bounds (statespaces.jl:29-34)
+    int32_t has;
+    int32_t d;
+    double lo[MPFMT_MAX_DIM];
+    double hi[MPFMT_MAX_DIM];
+};
+
+struct mpfmt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    int rank = 0, world = 1;
+
+    // ---- samples -------------------------------------------------------------------------------
+    int64_t N = 0;
+    int32_t d = 0;
+    double* Xo = nullptr;                // [N][d] original order (AoS = the caller's layout)
+    double bb_lo[MPFMT_MAX_DIM], bb_hi[MPFMT_MAX_DIM];
+
+    // ---- cell grid for radius grid_r --------------------------------------------------------------
+    double grid_r = -1.0;
+    mpfmt_grid grid;
+    int64_t ntiles = 0;                  // ceil(N/64)
+    int32_t* perm = nullptr;             // [ntiles*64] sorted position -> original index (pad = -1)
+    int32_t* iperm = nullptr;            // [N] original index -> sorted position
+    uint32_t* cellkey = nullptr;         // [N] cell id of each sorted position
+    int32_t* cellstart = nullptr;        // [ncells+1]
+    double* Xt = nullptr;                // [ntiles][d][64] tiled SoA, cell-sorted, NaN padded
+    double* tile_lo = nullptr;           // [ntiles][d] tight bounding box of each tile
+    double* tile_hi = nullptr;
+
+    // ---- r-disc graph (device resident) ------------------------------------------------------------
+    double graph_r = -1.0;
+    bool graph_counted = false, graph_filled = false;
+    int32_t S = 1;                       // candidate slices per tile
+    int64_t tile_begin = 0, tile_end = 0;  // shard tile range
+    int32_t* slice_cnt = nullptr;        // [S][ntiles*64] hits per (slice, sorted query)
+    int64_t* deg = nullptr;              // [N] degree by original index
+    int64_t* colptr = nullptr;           // [N+1] 0-based offsets by original index
+    int64_t nnz = 0;
+    int32_t* rowtmp = nullptr;           // [nnz] unsorted fill
+    double* valtmp = nullptr;
+    int32_t* rowval = nullptr;           // [nnz] 0-based, ascending per column
+    double* nzval = nullptr;
+    uint64_t* graph_free = nullptr;      // [ceil(nnz/64)]
+    bool graph_swept = false;
+    unsigned long long* d_pairs = nullptr;   // device counter: candidate pairs tested
+    int64_t pairs_tested = 0;
+
+    // ---- obstacles -----------------------------------------------------------------------------
+    double* boxes = nullptr;             // [M][2][dw]
+    int32_t M = 0, dw = 0;
+    bool have_boxes = false;
+    mpfmt_ss ss;
+
+    // ---- scratch -------------------------------------------------------------------------------
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::map<void*, size_t> caps;       // capacity (bytes) of each grow-only device buffer, keyed by member address
+    std::map<std::string, mpfmt_timer> timers;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_enabled = true;
+};
+
+// error helpers ---------------------------------------------------------------------------------
+int32_t mpfmt_fail(mpfmt_ctx* ctx, int32_t code, const char* fmt, ...);
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return mpfmt_fail((ctx), MPFMT_ERR_HIP, "%s failed: %s (%s:%d)", #call,                \
+                              hipGetErrorString(e_), __FILE__, __LINE__);                          \
+    } while (0)
+
+int32_t mpfmt_scratch(mpfmt_ctx* ctx, size_t bytes, void** out);
+// grow-only device buffer: (re)allocates *p when it is smaller than bytes
+int32_t mpfmt_ensure(mpfmt_ctx* ctx, void** p, size_t bytes);
+void mpfmt_time_begin(mpfmt_ctx* ctx);
+void mpfmt_time_end(mpfmt_ctx* ctx, const char* name);
+
+// kernels_rdisc.hip -----------------------------------------------------------------------------
+int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r);
+int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r);
+int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r);
+int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
+                                 int64_t* inds_host, double* ds_host, int64_t cap);
+
+// kernels_sweep.hip -----------------------------------------------------------------------------
+int32_t mpfmt_launch_points_free(mpfmt_ctx* ctx, const int64_t* d_idx1, int64_t n, uint64_t* d_mask);
+int32_t mpfmt_launch_states_free(mpfmt_ctx* ctx, const double* d_P, int64_t n, uint64_t* d_mask);
+int32_t mpfmt_launch_edges_free(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, uint64_t* d_mask);
+int32_t mpfmt_launch_motions_free(mpfmt_ctx* ctx, const double* d_P, const double* d_Q, int64_t n, uint64_t* d_mask);
+int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx);
+
+// kernels_expand.hip ----------------------------------------------------------------------------
+int32_t mpfmt_launch_expand(mpfmt_ctx* ctx, const uint64_t* d_W, const uint64_t* d_H, const uint64_t* d_F,
+                            const double* d_C, const int64_t* d_zs1, int64_t nz,
+                            int64_t* d_xs, int64_t* d_ymin, double* d_cmin, uint8_t* d_free, int64_t cap,
+                            int64_t* nx_host);

@@ -1,0 +1,99 @@
+"""Synthetic workloads of SURVEY.md section 8(d): the configurations BASELINE.json names.
+
+Samples i.i.d. uniform in [0,1]^d (fp64); V[1] = init; last sample = goal centre; obstacles = M AABBs,
+centre ~ U[0,1]^d, half-width per axis ~ U[h_lo,h_hi], boxes containing init or goal rejected.
+numpy's PCG64 stream is deterministic for a given seed, so the CPU oracle, the HIP library and the
+tests all see identical inputs.
+"""
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class Workload:
+    name: str
+    X: np.ndarray          # (N, d)
+    lohi: np.ndarray       # (M, 2, d)
+    r: float
+    init: np.ndarray
+    goal_center: np.ndarray
+    goal_radius: float
+    ss_lo: np.ndarray
+    ss_hi: np.ndarray
+
+    @property
+    def N(self):
+        return self.X.shape[0]
+
+    @property
+    def d(self):
+        return self.X.shape[1]
+
+    @property
+    def M(self):
+        return self.lohi.shape[0]
+
+    def goal_params(self):
+        return np.concatenate([self.goal_center, [self.goal_radius]])
+
+
+def fmt_radius(rm, d, vol, N):
+    """src/planners/fmt.jl:39, evaluated left to right like the Julia expression."""
+    zeta = math.pi ** (d / 2) / math.gamma(d / 2 + 1)
+    inner = 1 / d * vol / zeta * math.log(N) / N
+    return rm * 2 * inner ** (1 / d)
+
+
+def make_boxes(rng, M, d, h_lo, h_hi, keep_out):
+    out = np.empty((M, 2, d))
+    k = 0
+    while k < M:
+        c = rng.random(d)
+        h = h_lo + (h_hi - h_lo) * rng.random(d)
+        lo, hi = c - h, c + h
+        if any(np.all((lo <= p) & (p <= hi)) for p in keep_out):
+            continue
+        out[k, 0], out[k, 1] = lo, hi
+        k += 1
+    return out
+
+
+def make(name, N, d, M, h_lo, h_hi, seed, init_v=0.1, goal_v=0.9, goal_radius=0.15, rm=1.0, r=None):
+    rng = np.random.default_rng(seed)
+    init = np.full(d, init_v)
+    goal = np.full(d, goal_v)
+    lohi = make_boxes(rng, M, d, h_lo, h_hi, [init, goal])
+    X = rng.random((N, d))
+    X[0] = init
+    X[-1] = goal
+    if r is None:
+        r = fmt_radius(rm, d, 1.0, N)
+    return Workload(name, X, lohi, float(r), init, goal, goal_radius, np.zeros(d), np.ones(d))
+
+
+def cfg1(N=1000):
+    """FMT* in 2-D, N=1000, 20 AABBs (BASELINE.json configs[0], the CPU-runnable plumbing case)."""
+    return make("cfg1_2d_n1000_m20", N, 2, 20, 0.02, 0.08, seed=1, goal_radius=0.05)
+
+
+def cfg2(N=100_000):
+    """FMT* in R^6, N=100k, 200 AABBs (BASELINE.json configs[1])."""
+    return make("cfg2_r6_n100k_m200", N, 6, 200, 0.10, 0.20, seed=2)
+
+
+def north_star(N=1_000_000):
+    """FMT* in R^6, N=1e6, 200 AABBs: the configuration BASELINE.json's metric is quoted on."""
+    return make("ns_r6_n1m_m200", N, 6, 200, 0.10, 0.20, seed=3)
+
+
+def cfg3(N=1_000_000, deg=256.0):
+    """R^12 all-pairs r-disc graph (BASELINE.json configs[2]); r chosen for an expected interior degree."""
+    d = 12
+    zeta = math.pi ** (d / 2) / math.gamma(d / 2 + 1)
+    r = (deg / (N * zeta)) ** (1.0 / d)
+    return make("cfg3_r12_n1m_m200", N, d, 200, 0.20, 0.35, seed=4, r=r)
+
+
+BY_NAME = {"cfg1": cfg1, "cfg2": cfg2, "north_star": north_star, "cfg3": cfg3}

@@ -1,0 +1,319 @@
+"""ctypes binding of the CPU oracle (oracle/mpfmt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: may be imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.  PARITY UNPINNED (see the
+header of mpfmt_oracle.c): the reference has no tests and cannot be run here.
+
+Array conventions (the memory layouts of the reference's Julia objects):
+  X     : float64 (N, d) C-contiguous  == Julia d x N column-major == Vector{SVector{d,Float64}}
+  lohi  : float64 (M, 2, d)            == Vector{BoxBounds{d}} = [lo(d); hi(d)] per box
+  masks : uint64 words, bit e of word e>>6 (LSB first) == BitVector.chunks
+Indices are 0-based here (the C ABI of the product is 1-based like Julia; tests convert).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_d_p = C.POINTER(C.c_double)
+c_i64_p = C.POINTER(C.c_int64)
+c_u64_p = C.POINTER(C.c_uint64)
+c_u8_p = C.POINTER(C.c_uint8)
+
+
+class FmtResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("cost", C.c_double), ("z", C.c_int64),
+                ("collision_checks", C.c_int64), ("path_len", C.c_int64), ("nn_queries", C.c_int64)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "mpfmt_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.orc_sqdist.restype = C.c_double
+        L.orc_dist.restype = C.c_double
+        L.orc_inball.restype = C.c_int64
+        L.orc_rdisc_count.restype = C.c_int64
+        L.orc_rdisc_fill.restype = None
+        L.orc_kdtree_build.restype = C.c_void_p
+        L.orc_kdtree_free.restype = None
+        L.orc_kdtree_inball.restype = C.c_int64
+        L.orc_expand.restype = C.c_int64
+        L.orc_di_pairwise.restype = C.c_int64
+        L.orc_fmt_radius.restype = C.c_double
+        for f in ("orc_di_cost", "orc_di_dcost", "orc_di_ddcost"):
+            getattr(L, f).restype = C.c_double
+    return _LIB
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(c_d_p)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(c_i64_p)
+
+
+def _u(a):
+    return None if a is None else a.ctypes.data_as(c_u64_p)
+
+
+def _X(X):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    assert X.ndim == 2
+    return X, X.shape[0], X.shape[1]
+
+
+def _boxes(lohi, d):
+    if lohi is None:
+        return np.zeros((0, 2, d)), 0
+    lohi = np.ascontiguousarray(lohi, dtype=np.float64)
+    if lohi.size == 0:
+        return np.zeros((0, 2, d)), 0
+    assert lohi.ndim == 3 and lohi.shape[1] == 2
+    return lohi, lohi.shape[0]
+
+
+def _vec(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def nwords(n):
+    return (n + 63) // 64
+
+
+def unpack(mask, n):
+    """uint64 LSB-first words -> bool array of length n."""
+    b = np.unpackbits(np.ascontiguousarray(mask).view(np.uint8), bitorder="little")
+    return b[:n].astype(bool)
+
+
+def pack(bits):
+    bits = np.asarray(bits, dtype=bool)
+    n = bits.size
+    pad = np.zeros(nwords(n) * 64, dtype=np.uint8)
+    pad[:n] = bits
+    return np.packbits(pad, bitorder="little").view(np.uint64)
+
+
+def sqdist(a, b):
+    a = _vec(a); b = _vec(b)
+    return lib().orc_sqdist(_d(a), _d(b), C.c_int32(a.size))
+
+
+def inball(X, v, r, mode=0):
+    X, N, d = _X(X)
+    inds = np.empty(N, dtype=np.int64); ds = np.empty(N, dtype=np.float64)
+    k = lib().orc_inball(_d(X), C.c_int64(N), C.c_int32(d), C.c_int64(v), C.c_double(r), C.c_int32(mode),
+                         _i(inds), _d(ds), C.c_int64(N))
+    return inds[:k].copy(), ds[:k].copy()
+
+
+def rdisc_graph(X, r, mode=0):
+    """Full r-disc graph as 0-based CSC (colptr, rowval, nzval)."""
+    X, N, d = _X(X)
+    colptr = np.empty(N + 1, dtype=np.int64)
+    nnz = lib().orc_rdisc_count(_d(X), C.c_int64(N), C.c_int32(d), C.c_double(r), C.c_int32(mode), _i(colptr))
+    rowval = np.empty(max(nnz, 1), dtype=np.int64); nzval = np.empty(max(nnz, 1), dtype=np.float64)
+    lib().orc_rdisc_fill(_d(X), C.c_int64(N), C.c_int32(d), C.c_double(r), C.c_int32(mode), _i(colptr), _i(rowval), _d(nzval))
+    return colptr, rowval[:nnz], nzval[:nnz]
+
+
+class KDTree:
+    def __init__(self, X):
+        self.X, self.N, self.d = _X(X)
+        self._t = C.c_void_p(lib().orc_kdtree_build(_d(self.X), C.c_int64(self.N), C.c_int32(self.d)))
+        self._inds = np.empty(max(self.N, 1), dtype=np.int64)
+        self._ds = np.empty(max(self.N, 1), dtype=np.float64)
+
+    def inball(self, v, r):
+        k = lib().orc_kdtree_inball(self._t, C.c_int64(v), C.c_double(r), _i(self._inds), _d(self._ds), C.c_int64(self.N))
+        return self._inds[:k].copy(), self._ds[:k].copy()
+
+    def inball_count_only(self, v, r):
+        return lib().orc_kdtree_inball(self._t, C.c_int64(v), C.c_double(r), _i(self._inds), _d(self._ds), C.c_int64(self.N))
+
+    def __del__(self):
+        try:
+            lib().orc_kdtree_free(self._t)
+        except Exception:
+            pass
+
+
+def point_free_boxes(v, lohi):
+    v = _vec(v); lohi, M = _boxes(lohi, v.size)
+    return bool(lib().orc_point_free_boxes(_d(v), _d(lohi), C.c_int32(M), C.c_int32(v.size)))
+
+
+def motion_free_boxes(v, w, lohi):
+    v = _vec(v); w = _vec(w); lohi, M = _boxes(lohi, v.size)
+    return bool(lib().orc_motion_free_boxes(_d(v), _d(w), _d(lohi), C.c_int32(M), C.c_int32(v.size)))
+
+
+def box_phases(v, w, lo, hi):
+    """(broadphase_free, narrow_free) for one box (boxesND.jl:44-51)."""
+    v = _vec(v); w = _vec(w); lo = _vec(lo); hi = _vec(hi)
+    d = C.c_int32(v.size)
+    return (bool(lib().orc_box_broadphase_free(_d(v), _d(w), _d(lo), _d(hi), d)),
+            bool(lib().orc_box_narrow_free(_d(v), _d(w), _d(lo), _d(hi), d)))
+
+
+def is_free_state(v, lohi, ss_lo=None, ss_hi=None):
+    v = _vec(v); lohi, M = _boxes(lohi, v.size); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi)
+    return bool(lib().orc_is_free_state(_d(v), C.c_int32(v.size), _d(lohi), C.c_int32(M), _d(ss_lo), _d(ss_hi)))
+
+
+def is_free_motion(v, w, lohi, ss_lo=None, ss_hi=None):
+    v = _vec(v); w = _vec(w); lohi, M = _boxes(lohi, v.size); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi)
+    return bool(lib().orc_is_free_motion(_d(v), _d(w), C.c_int32(v.size), _d(lohi), C.c_int32(M), _d(ss_lo), _d(ss_hi)))
+
+
+def points_free(X, lohi, ss_lo=None, ss_hi=None, idx=None):
+    X, N, d = _X(X); lohi, M = _boxes(lohi, d); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi)
+    if idx is not None:
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+    n = N if idx is None else idx.size
+    mask = np.zeros(max(nwords(n), 1), dtype=np.uint64)
+    lib().orc_points_free(_d(X), C.c_int64(N), C.c_int32(d), _i(idx), C.c_int64(n), _d(lohi), C.c_int32(M),
+                          _d(ss_lo), _d(ss_hi), _u(mask))
+    return mask[:nwords(n)]
+
+
+def edges_free(X, src, dst, lohi, ss_lo=None, ss_hi=None):
+    X, N, d = _X(X); lohi, M = _boxes(lohi, d); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi)
+    src = np.ascontiguousarray(src, dtype=np.int64); dst = np.ascontiguousarray(dst, dtype=np.int64)
+    E = src.size
+    mask = np.zeros(max(nwords(E), 1), dtype=np.uint64)
+    lib().orc_edges_free(_d(X), C.c_int64(N), C.c_int32(d), _i(src), _i(dst), C.c_int64(E), _d(lohi), C.c_int32(M),
+                         _d(ss_lo), _d(ss_hi), _u(mask))
+    return mask[:nwords(E)]
+
+
+def graph_edges_free(X, colptr, rowval, lohi, ss_lo=None, ss_hi=None):
+    X, N, d = _X(X); lohi, M = _boxes(lohi, d); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi)
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64); rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+    nnz = int(colptr[N])
+    mask = np.zeros(max(nwords(nnz), 1), dtype=np.uint64)
+    lib().orc_graph_edges_free(_d(X), C.c_int64(N), C.c_int32(d), _i(colptr), _i(rowval), _d(lohi), C.c_int32(M),
+                               _d(ss_lo), _d(ss_hi), _u(mask))
+    return mask[:nwords(nnz)]
+
+
+GOAL_RECT, GOAL_BALL, GOAL_POINT = 0, 1, 2
+
+
+def is_goal_pt(v, kind, g):
+    v = _vec(v); g = _vec(g)
+    return bool(lib().orc_is_goal_pt(_d(v), C.c_int32(v.size), C.c_int32(kind), _d(g)))
+
+
+def expand(X, r, W, H, F, Cc, zs, lohi, ss_lo=None, ss_hi=None):
+    X, N, d = _X(X); lohi, M = _boxes(lohi, d); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi)
+    W = np.ascontiguousarray(W, dtype=np.uint64); H = np.ascontiguousarray(H, dtype=np.uint64)
+    F = None if F is None else np.ascontiguousarray(F, dtype=np.uint64)
+    Cc = _vec(Cc); zs = np.ascontiguousarray(zs, dtype=np.int64)
+    xs = np.empty(max(N, 1), dtype=np.int64); ym = np.empty(max(N, 1), dtype=np.int64)
+    cm = np.empty(max(N, 1), dtype=np.float64); fr = np.empty(max(N, 1), dtype=np.uint8)
+    nx = lib().orc_expand(_d(X), C.c_int64(N), C.c_int32(d), C.c_double(r), _u(W), _u(H), _u(F), _d(Cc),
+                          _i(zs), C.c_int64(zs.size), _d(lohi), C.c_int32(M), _d(ss_lo), _d(ss_hi),
+                          _i(xs), _i(ym), _d(cm), fr.ctypes.data_as(c_u8_p))
+    return xs[:nx].copy(), ym[:nx].copy(), cm[:nx].copy(), fr[:nx].astype(bool)
+
+
+def fmtstar(X, r, goal_kind, goal, lohi, ss_lo=None, ss_hi=None, init_idx=0, checkpts=True, nn_mode=0):
+    X, N, d = _X(X); lohi, M = _boxes(lohi, d); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi); goal = _vec(goal)
+    A = np.empty(N, dtype=np.int64); Cc = np.empty(N, dtype=np.float64); path = np.empty(N, dtype=np.int64)
+    res = FmtResult()
+    rc = lib().orc_fmtstar(_d(X), C.c_int64(N), C.c_int32(d), C.c_double(r), C.c_int64(init_idx), C.c_int32(int(checkpts)),
+                           C.c_int32(goal_kind), _d(goal), _d(lohi), C.c_int32(M), _d(ss_lo), _d(ss_hi),
+                           C.c_int32(nn_mode), _i(A), _d(Cc), _i(path), C.byref(res))
+    return dict(rc=rc, status=int(res.status), cost=float(res.cost), z=int(res.z),
+                collision_checks=int(res.collision_checks), nn_queries=int(res.nn_queries),
+                A=A, C=Cc, path=path[:res.path_len].copy())
+
+
+def fmtstar_graph(X, colptr, rowval, nzval, free_mask, Fmask, goal_kind, goal, lohi, ss_lo=None, ss_hi=None, init_idx=0):
+    X, N, d = _X(X); lohi, M = _boxes(lohi, d); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi); goal = _vec(goal)
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64); rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+    nzval = _vec(nzval)
+    free_mask = None if free_mask is None else np.ascontiguousarray(free_mask, dtype=np.uint64)
+    Fmask = None if Fmask is None else np.ascontiguousarray(Fmask, dtype=np.uint64)
+    A = np.empty(N, dtype=np.int64); Cc = np.empty(N, dtype=np.float64); path = np.empty(N, dtype=np.int64)
+    res = FmtResult()
+    rc = lib().orc_fmtstar_graph(_d(X), C.c_int64(N), C.c_int32(d), C.c_int64(init_idx), _i(colptr), _i(rowval), _d(nzval),
+                                 _u(free_mask), _u(Fmask), C.c_int32(goal_kind), _d(goal), _d(lohi), C.c_int32(M),
+                                 _d(ss_lo), _d(ss_hi), _i(A), _d(Cc), _i(path), C.byref(res))
+    return dict(rc=rc, status=int(res.status), cost=float(res.cost), z=int(res.z),
+                collision_checks=int(res.collision_checks), A=A, C=Cc, path=path[:res.path_len].copy())
+
+
+def fmt_radius(rm, d, vol, N):
+    return lib().orc_fmt_radius(C.c_double(rm), C.c_int32(d), C.c_double(vol), C.c_int64(N))
+
+
+# --- double integrator (LQ) -------------------------------------------------------------------
+
+def di_cost(x0, x1, rho, t):
+    x0 = _vec(x0); x1 = _vec(x1)
+    return lib().orc_di_cost(_d(x0), _d(x1), C.c_int32(x0.size // 2), C.c_double(rho), C.c_double(t))
+
+
+def di_dcost(x0, x1, rho, t):
+    x0 = _vec(x0); x1 = _vec(x1)
+    return lib().orc_di_dcost(_d(x0), _d(x1), C.c_int32(x0.size // 2), C.c_double(rho), C.c_double(t))
+
+
+def di_ddcost(x0, x1, rho, t):
+    x0 = _vec(x0); x1 = _vec(x1)
+    return lib().orc_di_ddcost(_d(x0), _d(x1), C.c_int32(x0.size // 2), C.c_double(rho), C.c_double(t))
+
+
+def di_steer(x0, x1, rho, r):
+    x0 = _vec(x0); x1 = _vec(x1)
+    cost = C.c_double(); t = C.c_double()
+    lib().orc_di_steer(_d(x0), _d(x1), C.c_int32(x0.size // 2), C.c_double(rho), C.c_double(r), C.byref(cost), C.byref(t))
+    return cost.value, t.value
+
+
+def di_state(x0, x1, rho, t, s):
+    x0 = _vec(x0); x1 = _vec(x1)
+    out = np.empty(x0.size)
+    lib().orc_di_state(_d(x0), _d(x1), C.c_int32(x0.size // 2), C.c_double(rho), C.c_double(t), C.c_double(s), _d(out))
+    return out
+
+
+def di_waypoints(x0, x1, rho, r):
+    x0 = _vec(x0); x1 = _vec(x1)
+    out = np.empty((5, x0.size))
+    lib().orc_di_waypoints(_d(x0), _d(x1), C.c_int32(x0.size // 2), C.c_double(rho), C.c_double(r), _d(out))
+    return out
+
+
+def di_is_free_motion(x0, x1, rho, r, lohi, ss_lo=None, ss_hi=None):
+    x0 = _vec(x0); x1 = _vec(x1); m = x0.size // 2
+    lohi, M = _boxes(lohi, m); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi)
+    return bool(lib().orc_di_is_free_motion(_d(x0), _d(x1), C.c_int32(m), C.c_double(rho), C.c_double(r),
+                                            _d(lohi), C.c_int32(M), _d(ss_lo), _d(ss_hi)))
+
+
+def di_pairwise(X, rho, r):
+    """Sparse DSB cost matrix (column j = sources i that reach j with cost <= r), 0-based CSC + optimal times."""
+    X, N, n = _X(X)
+    colptr = np.empty(N + 1, dtype=np.int64)
+    nnz = lib().orc_di_pairwise(_d(X), C.c_int64(N), C.c_int32(n // 2), C.c_double(rho), C.c_double(r), _i(colptr), None, None, None)
+    rowval = np.empty(max(nnz, 1), dtype=np.int64); nzval = np.empty(max(nnz, 1)); tval = np.empty(max(nnz, 1))
+    lib().orc_di_pairwise(_d(X), C.c_int64(N), C.c_int32(n // 2), C.c_double(rho), C.c_double(r), _i(colptr), _i(rowval), _d(nzval), _d(tval))
+    return colptr, rowval[:nnz], nzval[:nnz], tval[:nnz]

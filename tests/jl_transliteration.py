@@ -1,0 +1,191 @@
+"""Independent pure-Python restatement of the reference's hot-path Julia functions.
+
+Purpose: a second, structurally different statement of the same reference lines that the C
+oracle (oracle/mpfmt_oracle.c) follows, so that the oracle is cross-checked by something
+other than itself (the reference ships no tests and Julia is not installed).  Python floats
+are IEEE binary64 and CPython never fuses a*b+c, so arithmetic matches the declared canon.
+Pure-Python loops: small cases only.  1-based indices are used where the reference uses them.
+"""
+import heapq
+import math
+
+
+# src/utilities/utils.jl:3-39 -- @any / @all are short-circuit loops over a comprehension
+def jl_any(gen):
+    for x in gen:
+        if x:
+            return True
+    return False
+
+
+def jl_all(gen):
+    for x in gen:
+        if not x:
+            return False
+    return True
+
+
+# src/utilities/utils.jl:41-51
+def blend(b, a1, a2):
+    return [a1[j] if b[j] else a2[j] for j in range(len(b))]
+
+
+# src/collisioncheckers/boxesND.jl:42
+def is_free_state_box(v, lo, hi):
+    return jl_any(not (lo[i] <= v[i] <= hi[i]) for i in range(len(lo)))
+
+
+# src/collisioncheckers/boxesND.jl:43
+def is_free_state_boxes(v, boxes):
+    return jl_all(is_free_state_box(v, lo, hi) for (lo, hi) in boxes)
+
+
+# src/collisioncheckers/boxesND.jl:44-45
+def is_free_motion_broadphase(l, h, lo, hi):
+    return jl_any(hi[i] < l[i] or lo[i] > h[i] for i in range(len(lo)))
+
+
+def _div(a, b):
+    """IEEE division (Python raises on /0)."""
+    if b == 0.0:
+        if a == 0.0 or a != a:
+            return float("nan")
+        neg = (math.copysign(1.0, a) < 0) != (math.copysign(1.0, b) < 0)
+        return -math.inf if neg else math.inf
+    return a / b
+
+
+# src/collisioncheckers/boxesND.jl:46-51
+def is_free_motion_box(v, w, lo, hi):
+    n = len(lo)
+    v_to_w = [w[i] - v[i] for i in range(n)]
+    corner = blend([v[i] < lo[i] for i in range(n)], lo, hi)
+    lambdas = [_div(corner[i] - v[i], v_to_w[i]) for i in range(n)]
+    return not jl_any(
+        jl_all(i == j or (lo[j] <= v[j] + v_to_w[j] * lambdas[i] <= hi[j]) for j in range(n))
+        for i in range(n))
+
+
+# src/collisioncheckers/boxesND.jl:52-56
+def is_free_motion_boxes(v, w, boxes):
+    bb_min = [min(a, b) for a, b in zip(v, w)]
+    bb_max = [max(a, b) for a, b in zip(v, w)]
+    return jl_all(is_free_motion_broadphase(bb_min, bb_max, lo, hi) or is_free_motion_box(v, w, lo, hi)
+                  for (lo, hi) in boxes)
+
+
+# src/statespaces.jl:150
+def in_state_space(v, ss_lo, ss_hi):
+    return jl_all(ss_lo[i] <= v[i] <= ss_hi[i] for i in range(len(v)))
+
+
+# src/statespaces.jl:151-152 (s2w = Identity)
+def is_free_state(v, boxes, ss_lo, ss_hi):
+    return in_state_space(v, ss_lo, ss_hi) and is_free_state_boxes(v, boxes)
+
+
+# src/statespaces.jl:153-158 with collision_waypoints = (v, w) (geometric.jl:20)
+def is_free_motion(v, w, boxes, ss_lo, ss_hi):
+    wps = (v, w)
+    return jl_all(in_state_space(wps[i], ss_lo, ss_hi) and is_free_motion_boxes(wps[i], wps[i + 1], boxes)
+                  for i in range(len(wps) - 1))
+
+
+def sqeuclid(a, b):
+    s = 0.0
+    for i in range(len(a)):
+        t = a[i] - b[i]
+        s = t * t if i == 0 else s + t * t
+    return s
+
+
+# src/nearneighbors.jl:179-183 (tree semantics: reduced distance <= r^2), 1-based indices
+def inball_tree(V, v, r):
+    q = V[v - 1]
+    inds = [i for i in range(1, len(V) + 1) if sqeuclid(q, V[i - 1]) <= r * r]   # inrange(..., sorted)
+    if v in inds:
+        inds.remove(v)                                                            # deleteat!(self)
+    ds = [math.sqrt(sqeuclid(q, V[i - 1])) for i in inds]                         # colwise
+    return inds, ds
+
+
+# src/nearneighbors.jl:138-150 (generic fallback: sqrt distance <= r)
+def inball_generic(V, v, r):
+    allds = [math.sqrt(sqeuclid(V[v - 1], w)) for w in V]
+    inds, ds = [], []
+    for i in range(1, len(V) + 1):
+        if i != v and allds[i - 1] <= r:
+            inds.append(i)
+            ds.append(allds[i - 1])
+    return inds, ds
+
+
+# src/nearneighbors.jl:104-107
+def filter_neighborhood(n, f):
+    inds, ds = n
+    keep = [f[i] for i in inds]
+    return [i for i, k in zip(inds, keep) if k], [d for d, k in zip(ds, keep) if k]
+
+
+def is_goal_ball(v, center, radius):
+    return math.sqrt(sqeuclid(v, center)) <= radius
+
+
+# src/planners/fmt.jl:3-119, connections = :R, 1-based like the reference.
+# V: list of points, V[0] is sample 1 (= init).  is_goal: predicate on a point.
+def fmtstar(V, r, is_goal, boxes, ss_lo, ss_hi, checkpts=True, init_idx=1):
+    N = len(V)
+    count = 0
+    if not is_free_state(V[init_idx - 1], boxes, ss_lo, ss_hi):
+        return None
+    F = {i: True for i in range(1, N + 1)}
+    if checkpts:
+        for i in range(1, N + 1):
+            F[i] = is_free_state(V[i - 1], boxes, ss_lo, ss_hi)
+    A = {i: 0 for i in range(1, N + 1)}
+    W = {i: True for i in range(1, N + 1)}
+    H = {i: False for i in range(1, N + 1)}
+    Cc = {i: 0.0 for i in range(1, N + 1)}
+    cache = {}
+
+    def near(v):
+        if v not in cache:
+            cache[v] = inball_tree(V, v, r)
+        return cache[v]
+
+    W[init_idx] = False
+    H[init_idx] = True
+    heap = [(0.0, init_idx)]
+    z = heapq.heappop(heap)[1]
+    while not is_goal(V[z - 1]):
+        H_new = []
+        xs, _ = filter_neighborhood(near(z), W)
+        for x in xs:
+            if checkpts and not F[x]:
+                continue
+            inds, ds = filter_neighborhood(near(x), H)
+            costs = [Cc[y] + dd for y, dd in zip(inds, ds)]
+            c_min = min(costs)
+            y_idx = costs.index(c_min)          # findmin: first minimal element
+            y_min = inds[y_idx]
+            count += 1
+            if is_free_motion(V[y_min - 1], V[x - 1], boxes, ss_lo, ss_hi):
+                A[x] = y_min
+                Cc[x] = c_min
+                heapq.heappush(heap, (c_min, x))
+                H_new.append(x)
+                W[x] = False
+        for x in H_new:
+            H[x] = True
+        H[z] = False
+        if heap:
+            z = heapq.heappop(heap)[1]
+        else:
+            break
+    sol = [z]
+    while sol[0] != 1:
+        sol.insert(0, A[sol[0]])
+        if sol[0] == 0:
+            break
+    return dict(status=is_goal(V[z - 1]), cost=Cc[z], z=z, collision_checks=count,
+                A=[A[i] for i in range(1, N + 1)], C=[Cc[i] for i in range(1, N + 1)], path=sol)

@@ -1,0 +1,52 @@
+"""CPU tests of the boundary: libmpfmt.so loads, exports every symbol include/mpfmt.h declares, and fails
+loudly (no CPU fallback) when no gfx950 device is present."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import motionplanning_jl_amd as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    h = open(os.path.join(ROOT, "include", "mpfmt.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpfmt_[a-z0-9_]+)\s*\(", h)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(mp._lib.so_path())
+    syms = header_symbols()
+    assert len(syms) >= 24
+    for s in syms:
+        assert hasattr(L, s), "libmpfmt.so does not export %s" % s
+    # and the Python binding table covers the header exactly
+    assert sorted(n for n, _, _ in mp._lib.SYMBOLS) == syms
+
+
+def test_version_string():
+    assert mp._lib.lib().mpfmt_version().decode().endswith("gfx950")
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(mp.MPFMTError) as e:
+        mp.Context(0)
+    assert e.value.code == mp._lib.ERR_NODEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing in the package may reference it."""
+    pkg = os.path.join(ROOT, "motionplanning.jl_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "liboracle" not in txt and "mpfmt_oracle" not in txt and "from oracle" not in txt \
+                    and "import oracle" not in txt, os.path.join(dp, f)

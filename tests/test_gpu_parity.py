@@ -1,0 +1,351 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI of include/mpfmt.h, against the CPU
+oracle on the same seeded inputs and against the committed golden fixtures.
+
+Bar (BASELINE.json north_star): bit-exact neighbour / collision masks and indices; edge costs within
+1e-6 relative (the tests first check them bit-exact and report the tighter result).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import motionplanning_jl_amd as mp
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+COST_RTOL = 1e-6     # north_star tolerance for edge costs
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = mp.Context(0)
+    yield c
+    c.close()
+
+
+def to0(colptr, rowval):
+    return colptr - 1, rowval - 1
+
+
+def check_costs(got, want):
+    assert got.shape == want.shape
+    if want.size:
+        rel = np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-300))
+        assert rel <= COST_RTOL, rel
+
+
+# ---- golden fixtures -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["BOXES2D", "BOXES3D"])
+def test_golden_segments(ctx, name):
+    z = np.load(os.path.join(G, "segments_%s.npz" % name))
+    P, Q = z["P"], z["Q"]
+    ctx.upload_boxes(z["lohi"], z["ss_lo"], z["ss_hi"])
+    got = mp._lib.unpack_bits(ctx.motions_free(P, Q), len(P))
+    assert np.array_equal(got, z["free_full"])
+    ctx.upload_boxes(z["lohi"])                          # no state-space bounds: the box predicate alone
+    got = mp._lib.unpack_bits(ctx.motions_free(P, Q), len(P))
+    assert np.array_equal(got, z["free_boxes"])
+    ctx.upload_boxes(z["lohi"], z["ss_lo"], z["ss_hi"])
+    got = mp._lib.unpack_bits(ctx.states_free(P), len(P))
+    assert np.array_equal(got, z["point_free"])
+
+
+def test_golden_known_answers(ctx):
+    fx = json.load(open(os.path.join(G, "boxes_nd.json")))
+    lo, hi = fx["BOXES2D"][1]
+    cases = fx["known_answers_BOXES2D_box2"]["cases"]
+    ctx.upload_boxes(np.array([[lo, hi]]))
+    P = np.array([c[0] for c in cases]); Q = np.array([c[1] for c in cases])
+    got = mp._lib.unpack_bits(ctx.motions_free(P, Q), len(P))
+    assert got.tolist() == [c[4] for c in cases]
+
+
+@pytest.mark.parametrize("tag", ["d2_n1000", "d6_n1500"])
+def test_golden_rdisc(ctx, tag):
+    z = np.load(os.path.join(G, "rdisc_%s.npz" % tag))
+    ctx.upload_samples(z["X"])
+    colptr, rowval, nzval = ctx.rdisc_graph(float(z["r"]))
+    c0, r0 = to0(colptr, rowval)
+    assert np.array_equal(c0, z["colptr"])
+    assert np.array_equal(r0, z["rowval"])
+    check_costs(nzval, z["nzval"])
+
+
+def test_golden_fmt_cfg1(ctx):
+    z = np.load(os.path.join(G, "fmt_cfg1.npz"))
+    ctx.upload_samples(z["X"])
+    ctx.upload_boxes(z["lohi"], np.zeros(2), np.ones(2))
+    res = ctx.fmtstar(float(z["r"]), mp._lib.GOAL_BALL, z["goal"], init_idx=1, checkpts=True)
+    assert res["status"] == 1 == int(z["status"])
+    assert res["collision_checks"] == int(z["collision_checks"])
+    assert np.array_equal(res["A"] - 1, z["A"])
+    assert np.array_equal(res["path"] - 1, z["path"])
+    assert res["z"] - 1 == int(z["z"])
+    check_costs(res["C"], z["C"])
+    assert abs(res["cost"] - float(z["cost"])) <= COST_RTOL * float(z["cost"])
+
+
+# ---- seeded random parity -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N,d,r", [(5000, 2, 0.03), (4000, 3, 0.09), (6000, 4, 0.16), (20000, 6, 0.33),
+                                   (3000, 12, 0.95), (777, 1, 0.01), (2500, 5, 0.3), (1500, 16, 1.3)])
+def test_rdisc_random(ctx, orc, N, d, r):
+    rng = np.random.default_rng(100 + d)
+    X = rng.random((N, d))
+    ctx.upload_samples(X)
+    colptr, rowval, nzval = ctx.rdisc_graph(r)
+    oc, orow, oval = orc.rdisc_graph(X, r)
+    c0, r0 = to0(colptr, rowval)
+    assert np.array_equal(c0, oc)
+    assert np.array_equal(r0, orow)
+    check_costs(nzval, oval)
+
+
+def test_sqrt_is_correctly_rounded(ctx, orc):
+    """Edge costs are sqrt(d2); if the device sqrt is IEEE-correct the costs are bit-identical to the oracle."""
+    rng = np.random.default_rng(3)
+    X = rng.random((8000, 6))
+    ctx.upload_samples(X)
+    _, _, nzval = ctx.rdisc_graph(0.4)
+    _, _, oval = orc.rdisc_graph(X, 0.4)
+    assert np.array_equal(nzval, oval)
+
+
+def test_rdisc_clustered_and_duplicates(ctx, orc):
+    rng = np.random.default_rng(8)
+    X = np.concatenate([0.5 + 0.01 * rng.standard_normal((1500, 3)), rng.random((1500, 3)),
+                        np.tile(rng.random((1, 3)), (40, 1))])          # dense cluster + 40 identical points
+    rng.shuffle(X)
+    ctx.upload_samples(X)
+    for r in (0.0, 0.02, 0.25):
+        colptr, rowval, nzval = ctx.rdisc_graph(r)
+        oc, orow, oval = orc.rdisc_graph(X, r)
+        c0, r0 = to0(colptr, rowval)
+        assert np.array_equal(c0, oc) and np.array_equal(r0, orow)
+        check_costs(nzval, oval)
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 129])
+def test_rdisc_tiny_and_ragged(ctx, orc, N):
+    rng = np.random.default_rng(N)
+    X = rng.random((N, 3))
+    ctx.upload_samples(X)
+    for r in (0.3, 5.0):                  # r = 5: every pair is a neighbour (brute-force regime)
+        colptr, rowval, nzval = ctx.rdisc_graph(r)
+        oc, orow, oval = orc.rdisc_graph(X, r)
+        c0, r0 = to0(colptr, rowval)
+        assert np.array_equal(c0, oc) and np.array_equal(r0, orow)
+        check_costs(nzval, oval)
+
+
+def test_rdisc_high_degree_columns(ctx, orc):
+    """Columns longer than the LDS-resident sort window (exercises the chunked rank path)."""
+    rng = np.random.default_rng(17)
+    X = rng.random((3000, 2))
+    ctx.upload_samples(X)
+    colptr, rowval, nzval = ctx.rdisc_graph(1.2)
+    oc, orow, oval = orc.rdisc_graph(X, 1.2)
+    c0, r0 = to0(colptr, rowval)
+    assert int(np.max(np.diff(oc))) > 2048
+    assert np.array_equal(c0, oc) and np.array_equal(r0, orow)
+    check_costs(nzval, oval)
+
+
+def test_rdisc_query(ctx, orc):
+    rng = np.random.default_rng(9)
+    X = rng.random((5000, 4))
+    ctx.upload_samples(X)
+    for v in (1, 2, 2500, 5000):
+        inds, ds = ctx.rdisc_query(v, 0.2)
+        oi, od = orc.inball(X, v - 1, 0.2)
+        assert np.array_equal(inds - 1, oi)
+        check_costs(ds, od)
+    with pytest.raises(mp.MPFMTError) as e:
+        ctx.rdisc_query(1, 0.2, cap=1)
+    assert e.value.code == mp._lib.ERR_CAPACITY
+
+
+def random_world(rng, N, d, M, h_lo, h_hi):
+    X = rng.random((N, d))
+    c = rng.random((M, d)); h = h_lo + (h_hi - h_lo) * rng.random((M, d))
+    lohi = np.stack([c - h, c + h], axis=1)
+    return X, lohi
+
+
+@pytest.mark.parametrize("d,M,h", [(2, 20, (0.02, 0.08)), (3, 10, (0.05, 0.2)), (6, 200, (0.1, 0.2)), (6, 0, (0.1, 0.2)),
+                                   (6, 700, (0.05, 0.15)), (12, 64, (0.2, 0.35))])
+def test_edges_and_points_random(ctx, orc, d, M, h):
+    rng = np.random.default_rng(200 + d + M)
+    N = 20000
+    X, lohi = random_world(rng, N, d, M, *h)
+    X[:50] = X[:50] * 1.2 - 0.1               # some samples outside the state-space bounds
+    ss_lo, ss_hi = np.zeros(d), np.ones(d)
+    ctx.upload_samples(X)
+    ctx.upload_boxes(lohi, ss_lo, ss_hi, dw=d)
+    assert np.array_equal(ctx.points_free(), orc.points_free(X, lohi, ss_lo, ss_hi))
+    idx = rng.integers(1, N + 1, size=3001)
+    assert np.array_equal(ctx.points_free(idx), orc.points_free(X, lohi, ss_lo, ss_hi, idx=idx - 1))
+    E = 100003
+    src = rng.integers(1, N + 1, size=E)
+    near = X[src - 1] + 0.1 * (rng.random((E, d)) - 0.5)          # FMT*-like short edges: snap to nearest-ish sample
+    dst = rng.integers(1, N + 1, size=E)
+    dst[:200] = src[:200]                                          # zero-length edges
+    got = ctx.edges_free(src, dst)
+    want = orc.edges_free(X, src - 1, dst - 1, lohi, ss_lo, ss_hi)
+    assert np.array_equal(got, want)
+    # explicit short segments
+    got = ctx.motions_free(X[src - 1], near)
+    want = orc.pack(np.array([orc.is_free_motion(a, b, lohi, ss_lo, ss_hi) for a, b in zip(X[src[:4000] - 1], near[:4000])]))
+    assert np.array_equal(mp._lib.unpack_bits(got, E)[:4000], orc.unpack(want, 4000))
+
+
+@pytest.mark.parametrize("N,d,M,r", [(1000, 2, 20, 0.0663), (6000, 6, 200, 0.4), (4000, 3, 300, 0.12)])
+def test_graph_edges_free(ctx, orc, N, d, M, r):
+    rng = np.random.default_rng(300 + d)
+    X, lohi = random_world(rng, N, d, M, 0.05, 0.15)
+    ss_lo, ss_hi = np.full(d, 0.02), np.full(d, 0.98)
+    ctx.upload_samples(X)
+    ctx.upload_boxes(lohi, ss_lo, ss_hi)
+    colptr, rowval, _ = ctx.rdisc_graph(r)
+    got = ctx.graph_edges_free()
+    c0, r0 = to0(colptr, rowval)
+    want = orc.graph_edges_free(X, c0, r0, lohi, ss_lo, ss_hi)
+    assert np.array_equal(got, want)
+    # the same bits through the explicit edge list entry point (rows are parents, columns children)
+    cols = np.repeat(np.arange(1, N + 1), np.diff(colptr))
+    assert np.array_equal(ctx.edges_free(rowval, cols), want)
+
+
+def test_expand_step(ctx, orc):
+    rng = np.random.default_rng(41)
+    N, d, r = 5000, 3, 0.1
+    X, lohi = random_world(rng, N, d, 30, 0.05, 0.15)
+    ss_lo, ss_hi = np.zeros(d), np.ones(d)
+    ctx.upload_samples(X)
+    ctx.upload_boxes(lohi, ss_lo, ss_hi)
+    ctx.rdisc_graph(r)
+    F = ctx.points_free()
+    H = rng.random(N) < 0.1
+    W = ~H & (rng.random(N) < 0.8)
+    Cc = np.where(H, rng.random(N), 0.0)
+    zs = np.flatnonzero(H)[:40] + 1
+    for swept in (False, True):
+        if swept:
+            ctx.graph_edges_free()
+        xs, ym, cm, fr = ctx.expand(mp._lib.pack_bits(W), mp._lib.pack_bits(H), F, Cc, zs)
+        oxs, oym, ocm, ofr = orc.expand(X, r, orc.pack(W), orc.pack(H), F, Cc, zs - 1, lohi, ss_lo, ss_hi)
+        assert np.array_equal(xs - 1, oxs) and np.array_equal(ym - 1, oym)
+        check_costs(cm, ocm)
+        assert np.array_equal(fr, ofr)
+
+
+@pytest.mark.parametrize("N,d,M,seed", [(3000, 2, 25, 1), (5000, 3, 40, 2), (8000, 6, 100, 3)])
+def test_fmtstar_matches_oracle(ctx, orc, N, d, M, seed):
+    w = mp.workloads.make("t", N, d, M, 0.05, 0.12, seed=seed, goal_radius=0.1)
+    ctx.upload_samples(w.X)
+    ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+    res = ctx.fmtstar(w.r, mp._lib.GOAL_BALL, w.goal_params())
+    ref = orc.fmtstar(w.X, w.r, orc.GOAL_BALL, w.goal_params(), w.lohi, w.ss_lo, w.ss_hi, nn_mode=1)
+    assert res["status"] == ref["status"]
+    assert res["collision_checks"] == ref["collision_checks"]
+    assert np.array_equal(res["A"] - 1, ref["A"])
+    assert np.array_equal(res["path"] - 1, ref["path"])
+    check_costs(res["C"], ref["C"])
+
+
+def test_fmtstar_infeasible_init(ctx):
+    X = np.array([[0.1, 0.1], [0.5, 0.5], [0.9, 0.9]])
+    ctx.upload_samples(X)
+    ctx.upload_boxes(np.array([[[0.0, 0.0], [0.2, 0.2]]]), np.zeros(2), np.ones(2))
+    with pytest.raises(mp.MPFMTError) as e:
+        ctx.fmtstar(0.7, mp._lib.GOAL_BALL, [0.9, 0.9, 0.05])
+    assert e.value.code == mp._lib.ERR_INFEASIBLE
+
+
+def test_error_behaviour(ctx):
+    ctx.upload_samples(np.random.default_rng(0).random((100, 3)))
+    with pytest.raises(mp.MPFMTError) as e:
+        ctx.rdisc_query(0, 0.1)
+    assert e.value.code == mp._lib.ERR_ARG
+    with pytest.raises(mp.MPFMTError) as e:
+        ctx.edges_free([1], [101])
+    assert e.value.code == mp._lib.ERR_ARG
+    c2 = mp.Context(0)
+    c2.upload_samples(np.zeros((4, 2)))
+    with pytest.raises(mp.MPFMTError) as e:
+        c2.points_free()
+    assert e.value.code == mp._lib.ERR_STATE
+    c2.close()
+
+
+def test_determinism(ctx):
+    w = mp.workloads.make("t", 30000, 6, 200, 0.1, 0.2, seed=5)
+    outs = []
+    for _ in range(2):
+        ctx.upload_samples(w.X)
+        ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+        colptr, rowval, nzval = ctx.rdisc_graph(0.3)
+        outs.append((colptr, rowval, nzval, ctx.graph_edges_free()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_shards_partition_the_graph(ctx, orc):
+    """Two shards on one GPU: their column sets are disjoint and their union is the full graph."""
+    rng = np.random.default_rng(77)
+    X = rng.random((9000, 6))
+    r = 0.35
+    oc, orow, _ = orc.rdisc_graph(X, r)
+    deg = np.zeros(9000, dtype=np.int64)
+    rows_by_col = {}
+    for rank in range(2):
+        c = mp.Context(0)
+        c.set_shard(rank, 2)
+        c.upload_samples(X)
+        colptr, rowval, _ = c.rdisc_graph(r)
+        k = np.diff(colptr)
+        assert np.all((deg == 0) | (k == 0))
+        for v in np.flatnonzero(k):
+            rows_by_col[v] = rowval[colptr[v] - 1:colptr[v + 1] - 1] - 1
+        deg += k
+        c.close()
+    assert np.array_equal(deg, np.diff(oc))
+    for v in range(0, 9000, 41):
+        assert np.array_equal(rows_by_col.get(v, np.zeros(0, np.int64)), orow[oc[v]:oc[v + 1]])
+
+
+# ---- full-size properties (BASELINE.json configs[1]: R^6, N=100k, M=200) ---------------------------------
+
+def test_cfg2_full_size_properties(ctx, orc):
+    w = mp.workloads.cfg2()
+    N = w.N
+    ctx.upload_samples(w.X)
+    ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+    colptr, rowval, nzval = ctx.rdisc_graph(w.r)
+    c0, r0 = to0(colptr, rowval)
+    nnz = len(rowval)
+    assert c0[0] == 0 and c0[-1] == nnz and nnz % 2 == 0
+    cols = np.repeat(np.arange(N), np.diff(c0))
+    assert np.all(r0 != cols)                                             # self excluded
+    same_col = cols[1:] == cols[:-1]
+    assert np.all(np.diff(r0)[same_col] > 0)                              # ascending inside every column
+    assert np.all(nzval <= w.r * (1 + 1e-12))
+    # symmetry of the metric graph: the multiset of (i,j) equals the multiset of (j,i)
+    k1 = np.sort(cols.astype(np.int64) * N + r0)
+    k2 = np.sort(r0.astype(np.int64) * N + cols)
+    assert np.array_equal(k1, k2)
+    # sampled columns against the oracle KD-tree
+    kd = orc.KDTree(w.X)
+    rng = np.random.default_rng(1)
+    for v in rng.integers(0, N, size=300):
+        oi, od = kd.inball(int(v), w.r)
+        assert np.array_equal(r0[c0[v]:c0[v + 1]], oi)
+        check_costs(nzval[c0[v]:c0[v + 1]], od)
+    # edge mask: sampled entries against the oracle, plus the point mask in full
+    mask = mp._lib.unpack_bits(ctx.graph_edges_free(), nnz)
+    es = rng.integers(0, nnz, size=200000)
+    want = orc.unpack(orc.edges_free(w.X, r0[es], cols[es], w.lohi, w.ss_lo, w.ss_hi), len(es))
+    assert np.array_equal(mask[es], want)
+    assert np.array_equal(ctx.points_free(), orc.points_free(w.X, w.lohi, w.ss_lo, w.ss_hi))

@@ -1,0 +1,175 @@
+"""CPU tests: the oracle against the golden vectors, the hand-derived known answers and the independent
+Python transliteration of the reference's Julia lines.  No GPU, no libmpfmt compute calls."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import jl_transliteration as jl
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_boxes(name):
+    return np.array(json.load(open(os.path.join(G, "boxes_nd.json")))[name], dtype=np.float64)
+
+
+def test_known_answers_boxes2d(orc):
+    """Hand-derived broad/narrow answers on the reference fixture BOXES2D[2]."""
+    fx = json.load(open(os.path.join(G, "boxes_nd.json")))
+    lo, hi = fx["BOXES2D"][1]
+    for v, w, bp, nf, res in fx["known_answers_BOXES2D_box2"]["cases"]:
+        b, n = orc.box_phases(v, w, lo, hi)
+        assert b == bp
+        if nf is not None:
+            assert n == nf
+        assert orc.motion_free_boxes(v, w, [[lo, hi]]) == res
+        # and the independent transliteration agrees
+        l = [min(a, c) for a, c in zip(v, w)]
+        h = [max(a, c) for a, c in zip(v, w)]
+        assert jl.is_free_motion_broadphase(l, h, lo, hi) == bp
+        assert jl.is_free_motion_boxes(v, w, [(lo, hi)]) == res
+
+
+@pytest.mark.parametrize("name", ["BOXES2D", "BOXES3D"])
+def test_segment_goldens(orc, name):
+    z = np.load(os.path.join(G, "segments_%s.npz" % name))
+    P, Q, lohi = z["P"], z["Q"], z["lohi"]
+    got = orc.unpack(orc.motions_free_explicit(P, Q, lohi, z["ss_lo"], z["ss_hi"]), len(P)) if hasattr(orc, "motions_free_explicit") else None
+    free_boxes = np.array([orc.motion_free_boxes(p, q, lohi) for p, q in zip(P, Q)])
+    free_full = np.array([orc.is_free_motion(p, q, lohi, z["ss_lo"], z["ss_hi"]) for p, q in zip(P, Q)])
+    pfree = np.array([orc.is_free_state(p, lohi, z["ss_lo"], z["ss_hi"]) for p in P])
+    assert np.array_equal(free_boxes, z["free_boxes"])
+    assert np.array_equal(free_full, z["free_full"])
+    assert np.array_equal(pfree, z["point_free"])
+    assert got is None or np.array_equal(got, z["free_full"])
+    assert np.array_equal(lohi, load_boxes(name))
+
+
+def test_zero_length_segment_inside_box_is_free_quirk(orc):
+    """boxesND.jl:46-51 reports a zero-length segment inside a box as free (lambda = NaN/Inf)."""
+    lohi = load_boxes("BOXES2D")
+    c = 0.5 * (lohi[1, 0] + lohi[1, 1])
+    assert orc.motion_free_boxes(c, c, lohi)
+    assert not orc.point_free_boxes(c, lohi)
+
+
+@pytest.mark.parametrize("tag", ["d2_n1000", "d6_n1500"])
+def test_rdisc_goldens(orc, tag):
+    z = np.load(os.path.join(G, "rdisc_%s.npz" % tag))
+    X, r = z["X"], float(z["r"])
+    colptr, rowval, nzval = orc.rdisc_graph(X, r, mode=0)
+    assert np.array_equal(colptr, z["colptr"])
+    assert np.array_equal(rowval, z["rowval"])
+    assert np.array_equal(nzval, z["nzval"])
+    # contract of nearneighbors.jl:138-198: ascending, self excluded, symmetric for a metric
+    N = len(X)
+    for v in range(0, N, 97):
+        rows = rowval[colptr[v]:colptr[v + 1]]
+        assert np.all(np.diff(rows) > 0) and v not in rows
+    A = set(zip(np.repeat(np.arange(N), np.diff(colptr)).tolist(), rowval.tolist()))
+    assert all((j, i) in A for (i, j) in list(A)[:5000])
+    # the duplicate pair is mutually adjacent at distance 0
+    a = rowval[colptr[3]:colptr[4]].tolist()
+    assert 7 in a and nzval[colptr[3] + a.index(7)] == 0.0
+
+
+def test_kdtree_equals_brute(orc):
+    rng = np.random.default_rng(5)
+    for d in (2, 3, 6):
+        X = rng.random((600, d))
+        r = 0.2 if d < 6 else 0.5
+        kd = orc.KDTree(X)
+        for v in range(0, 600, 13):
+            bi, bd = orc.inball(X, v, r, mode=0)
+            ki, kd_d = kd.inball(v, r)
+            assert np.array_equal(bi, ki) and np.array_equal(bd, kd_d)
+
+
+def test_inball_modes_agree_away_from_threshold(orc):
+    rng = np.random.default_rng(6)
+    X = rng.random((400, 3))
+    for v in range(0, 400, 17):
+        a, _ = orc.inball(X, v, 0.21, mode=0)
+        b, _ = orc.inball(X, v, 0.21, mode=1)
+        assert np.array_equal(a, b)
+
+
+def test_inball_matches_transliteration(orc):
+    rng = np.random.default_rng(7)
+    X = rng.random((300, 4))
+    V = X.tolist()
+    for v in (0, 5, 150, 299):
+        inds, ds = jl.inball_tree(V, v + 1, 0.35)
+        oi, od = orc.inball(X, v, 0.35, mode=0)
+        assert [i - 1 for i in inds] == oi.tolist() and ds == od.tolist()
+        gi, gd = jl.inball_generic(V, v + 1, 0.35)
+        oi1, od1 = orc.inball(X, v, 0.35, mode=1)
+        assert [i - 1 for i in gi] == oi1.tolist() and gd == od1.tolist()
+
+
+def test_fmt_golden_cfg1(orc):
+    z = np.load(os.path.join(G, "fmt_cfg1.npz"))
+    for nn_mode in (0, 1):
+        res = orc.fmtstar(z["X"], float(z["r"]), orc.GOAL_BALL, z["goal"], z["lohi"], np.zeros(2), np.ones(2),
+                          init_idx=0, checkpts=True, nn_mode=nn_mode)
+        assert res["status"] == int(z["status"]) == 1
+        assert res["cost"] == float(z["cost"])
+        assert res["collision_checks"] == int(z["collision_checks"])
+        assert np.array_equal(res["A"], z["A"]) and np.array_equal(res["C"], z["C"]) and np.array_equal(res["path"], z["path"])
+    # sanity: cost is at least the straight-line distance to the goal ball
+    assert float(z["cost"]) >= np.linalg.norm(z["X"][-1] - z["X"][0]) - 0.05
+
+
+def test_fmt_graph_driver_equals_lazy(orc):
+    """The eager-graph driver (prebuilt CSC + per-edge free mask) reproduces the lazy loop exactly."""
+    import motionplanning_jl_amd as mp
+    w = mp.workloads.cfg1()
+    lazy = orc.fmtstar(w.X, w.r, orc.GOAL_BALL, w.goal_params(), w.lohi, w.ss_lo, w.ss_hi)
+    colptr, rowval, nzval = orc.rdisc_graph(w.X, w.r)
+    emask = orc.graph_edges_free(w.X, colptr, rowval, w.lohi, w.ss_lo, w.ss_hi)
+    F = orc.points_free(w.X, w.lohi, w.ss_lo, w.ss_hi)
+    eager = orc.fmtstar_graph(w.X, colptr, rowval, nzval, emask, F, orc.GOAL_BALL, w.goal_params(), w.lohi, w.ss_lo, w.ss_hi)
+    for k in ("status", "cost", "z", "collision_checks"):
+        assert lazy[k] == eager[k]
+    assert np.array_equal(lazy["A"], eager["A"]) and np.array_equal(lazy["C"], eager["C"])
+    assert np.array_equal(lazy["path"], eager["path"])
+
+
+def test_fmt_infeasible_init(orc):
+    lohi = np.array([[[0.0, 0.0], [0.2, 0.2]]])
+    X = np.array([[0.1, 0.1], [0.5, 0.5], [0.9, 0.9]])
+    res = orc.fmtstar(X, 0.7, orc.GOAL_BALL, [0.9, 0.9, 0.05], lohi, np.zeros(2), np.ones(2))
+    assert res["rc"] == -1
+
+
+def test_expand_step_matches_fmt_first_iteration(orc):
+    import motionplanning_jl_amd as mp
+    w = mp.workloads.cfg1()
+    N = w.N
+    W = np.ones(N, bool); W[0] = False
+    H = np.zeros(N, bool); H[0] = True
+    F = orc.unpack(orc.points_free(w.X, w.lohi, w.ss_lo, w.ss_hi), N)
+    xs, ym, cm, fr = orc.expand(w.X, w.r, orc.pack(W), orc.pack(H), orc.pack(F), np.zeros(N), [0], w.lohi, w.ss_lo, w.ss_hi)
+    inds, ds = orc.inball(w.X, 0, w.r)
+    keep = F[inds]
+    assert np.array_equal(xs, inds[keep]) and np.all(ym == 0) and np.array_equal(cm, ds[keep])
+    assert np.array_equal(fr, [orc.is_free_motion(w.X[0], w.X[x], w.lohi, w.ss_lo, w.ss_hi) for x in xs])
+
+
+def test_radius_rule(orc):
+    import motionplanning_jl_amd as mp
+    for (d, N) in ((2, 1000), (6, 100000), (6, 1000000)):
+        a = orc.fmt_radius(1.0, d, 1.0, N)
+        b = mp.workloads.fmt_radius(1.0, d, 1.0, N)
+        assert abs(a - b) <= 4e-16 * a
+    assert abs(orc.fmt_radius(1.0, 6, 1.0, 1000000) - 0.17479) < 1e-5
+    assert abs(orc.fmt_radius(1.0, 6, 1.0, 100000) - 0.24888) < 1e-5
+
+
+def test_bitmask_layout(orc):
+    bits = np.zeros(130, bool); bits[[0, 63, 64, 129]] = True
+    m = orc.pack(bits)
+    assert m[0] == (1 | (1 << 63)) and m[1] == 1 and m[2] == 2
+    assert np.array_equal(orc.unpack(m, 130), bits)
