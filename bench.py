@@ -27,14 +27,6 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # fp64 vector == fp64 matrix (MFMA) dense peak, FMA = 2 flop
 
 
-class DevArray:
-    """Expose a raw device pointer to torch through __cuda_array_interface__ (no copy)."""
-
-    def __init__(self, ptr, nelem, typestr):
-        self.__cuda_array_interface__ = {"shape": (int(nelem),), "typestr": typestr, "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
-
-
 def cpu_baseline(w, mp, seconds=12.0):
     """The oracle ("port" of the reference path, single thread) on a bounded sample of the same workload."""
     from oracle import oracle as orc
@@ -109,20 +101,11 @@ def main():
     ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
 
     def step():
-        nnz = ctx.graph_build_device(w.r)
-        ctx.graph_sweep_device()
         if world > 1:
-            _, _, _, fptr = ctx.graph_device_ptrs()
-            words = (nnz + 63) // 64
-            cnt = torch.tensor([words], dtype=torch.int64, device=dev)
-            cnts = torch.empty(world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(cnts, cnt)
-            mx = int(cnts.max().item())
-            send = torch.zeros(mx, dtype=torch.int64, device=dev)
-            if words:
-                send[:words] = torch.as_tensor(DevArray(fptr, words, "<i8"), device=dev)
-            out = torch.empty(world * mx, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(out, send)          # the global free-edge mask, one collective per step
+            nnz, _, _ = mp.distributed.sharded_step(ctx, w.r, dist, world, dev)   # graph + sweep + ONE mask all-gather
+        else:
+            nnz = ctx.graph_build_device(w.r)
+            ctx.graph_sweep_device()
         return nnz
 
     for _ in range(args.warmup):

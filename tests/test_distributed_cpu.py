@@ -1,0 +1,64 @@
+"""world_size-2 gloo test (CPU) of the N>1 exchange: per-shard free-edge masks are padded, all-gathered and
+split back; the assembled shards equal the oracle's masks.  The oracle is the compute stand-in here
+(tests only) -- the product path computes the shard masks on the GPU (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as tmp
+
+import motionplanning_jl_amd as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    w = mp.workloads.cfg1()
+    N = w.N
+    colptr, rowval, _ = orc.rdisc_graph(w.X, w.r)
+    # shard = contiguous column range (stand-in for the library's cell-sorted tile range)
+    a, b = N * rank // world, N * (rank + 1) // world
+    if rank == 1:
+        b = a                                  # ragged case: one shard is EMPTY
+    cp = colptr[a:b + 1] - colptr[a]
+    rv = rowval[colptr[a]:colptr[b]]
+    full_cp = np.zeros(N + 1, dtype=np.int64)
+    full_cp[a + 1:b + 1] = cp[1:]
+    full_cp[b + 1:] = cp[-1] if len(cp) else 0
+    local = orc.graph_edges_free(w.X, full_cp, rv, w.lohi, w.ss_lo, w.ss_hi) if len(rv) else np.zeros(0, np.uint64)
+    t = torch.from_numpy(local.view(np.int64).copy())
+    gathered, counts = mp.distributed.all_gather_mask(t, dist, world)
+    parts = mp.distributed.split_gathered(gathered, counts)
+    q.put((rank, [p.numpy().view(np.uint64).copy() for p in parts], local))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_mask_world2_gloo():
+    world = 2
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda x: x[0])
+    locals_ = [r[2] for r in res]
+    for rank, parts, _ in res:
+        assert len(parts) == world
+        for g in range(world):
+            assert np.array_equal(parts[g], locals_[g]), (rank, g)
+    assert len(locals_[1]) == 0 and len(locals_[0]) > 0
