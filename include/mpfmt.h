@@ -155,6 +155,12 @@ int32_t mpfmt_shard_info(mpfmt_ctx* ctx, int64_t* col_begin, int64_t* col_end, i
  *      "rdisc_sort", "grid", "sweep_graph", "sweep_points", "sweep_edges", "expand". */
 int32_t mpfmt_timing_reset(mpfmt_ctx* ctx);
 int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
+/* Tuning / test knobs.  "rdisc_path": 0 = auto, 1 = exact fp64 VALU pair kernel, 2 = fp16 MFMA distance-matrix
+ * filter + exact fp64 refine (both give bit-identical graphs).  "timing": 0/1 event timing off/on. */
+int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value);
+/* Counters of the last graph build: "rdisc_path_used", "pairs_tested", "survivors" (pairs that passed the
+ * MFMA filter), "nnz", "slices", "cells". */
+int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value);
 /* work counters of the last graph build: candidate pairs distance-tested, tiles, slices. */
 int32_t mpfmt_graph_stats(mpfmt_ctx* ctx, int64_t* pairs_tested, int64_t* tiles, int64_t* slices, int64_t* cells);
 

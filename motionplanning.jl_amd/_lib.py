@@ -63,6 +63,8 @@ SYMBOLS = [
     ("mpfmt_shard_info", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, c_i64_p]),
     ("mpfmt_timing_reset", C.c_int32, [C.c_void_p]),
     ("mpfmt_timing_get", C.c_int32, [C.c_void_p, C.c_char_p, c_d_p, c_i64_p]),
+    ("mpfmt_set_option", C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
+    ("mpfmt_get_stat", C.c_int32, [C.c_void_p, C.c_char_p, c_i64_p]),
     ("mpfmt_graph_stats", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, c_i64_p, c_i64_p]),
 ]
 
@@ -309,6 +311,14 @@ class Context:
         ms, n = C.c_double(), C.c_int64()
         self._chk(self._L.mpfmt_timing_get(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def set_option(self, name, value):
+        self._chk(self._L.mpfmt_set_option(self._h, name.encode(), int(value)))
+
+    def stat(self, name):
+        v = C.c_int64()
+        self._chk(self._L.mpfmt_get_stat(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def graph_stats(self):
         v = [C.c_int64() for _ in range(4)]

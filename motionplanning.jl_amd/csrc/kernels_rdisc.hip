@@ -212,7 +212,7 @@ struct rdisc_args {
     int64_t nitems;   // (tile_end - tile_begin) * S
     int64_t npad;
     int32_t* slice_cnt;
-    const int64_t* colptr;
+    const int64_t* tptr;       // offsets of the sorted-order staging CSC
     int32_t* rowtmp;
     double* valtmp;
     unsigned long long* pairs;
@@ -256,11 +256,8 @@ __global__ __launch_bounds__(64) void k_rdisc(rdisc_args a, mpfmt_grid G)
     int64_t base = 0;
     int32_t cnt = 0;
     if (FILL) {
-        const int32_t o = a.perm[qpos];
-        if (o >= 0) {
-            base = a.colptr[o];
-            for (int s = 0; s < slice; ++s) base += a.slice_cnt[(int64_t)s * a.npad + qpos];
-        }
+        base = a.tptr[qpos];
+        for (int s = 0; s < slice; ++s) base += a.slice_cnt[(int64_t)s * a.npad + qpos];
     }
 
     int64_t rows = 1;
@@ -347,7 +344,7 @@ __global__ __launch_bounds__(64) void k_rdisc(rdisc_args a, mpfmt_grid G)
 
 // degree of each ORIGINAL column = sum over slices of the sorted query's hits
 __global__ void k_degree(const int32_t* __restrict__ slice_cnt, const int32_t* __restrict__ perm, int S, int64_t npad,
-                         int64_t pos_begin, int64_t pos_end, int64_t* __restrict__ deg)
+                         int64_t pos_begin, int64_t pos_end, int64_t* __restrict__ deg, int64_t* __restrict__ degs)
 {
     int64_t s = pos_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= pos_end) return;
@@ -356,21 +353,25 @@ __global__ void k_degree(const int32_t* __restrict__ slice_cnt, const int32_t* _
     int64_t k = 0;
     for (int i = 0; i < S; ++i) k += slice_cnt[(int64_t)i * npad + s];
     deg[o] = k;
+    degs[s] = k;
 }
 
 // Per-column ordering: rank each entry by counting smaller row indices (indices in a column are
 // distinct), one wavefront per column.  Columns up to SORT_LDS entries are staged once in LDS.
 #define SORT_LDS 2048
-__global__ __launch_bounds__(64) void k_sortcols(const int64_t* __restrict__ colptr, int64_t N,
+// one wavefront per sorted position s: staging segment [tptr[s], tptr[s+1]) -> final column perm[s]
+__global__ __launch_bounds__(64) void k_sortcols(const int64_t* __restrict__ tptr, const int64_t* __restrict__ colptr,
+                                                 const int32_t* __restrict__ perm, int64_t pos_begin, int64_t pos_end,
                                                  const int32_t* __restrict__ rowtmp, const double* __restrict__ valtmp,
                                                  int32_t* __restrict__ rowval, double* __restrict__ nzval)
 {
     __shared__ int32_t sidx[SORT_LDS];
     const int lane = threadIdx.x;
-    for (int64_t col = blockIdx.x; col < N; col += gridDim.x) {
-        const int64_t beg = colptr[col];
-        const int64_t k = colptr[col + 1] - beg;
+    for (int64_t sp = pos_begin + blockIdx.x; sp < pos_end; sp += gridDim.x) {
+        const int64_t beg = tptr[sp];
+        const int64_t k = tptr[sp + 1] - beg;
         if (k == 0) continue;
+        const int64_t out = colptr[perm[sp]];
         if (k <= SORT_LDS) {
             __syncthreads();
             for (int64_t e = lane; e < k; e += 64) sidx[e] = rowtmp[beg + e];
@@ -381,8 +382,8 @@ __global__ __launch_bounds__(64) void k_sortcols(const int64_t* __restrict__ col
                 int32_t rank = 0;
                 for (int64_t j = 0; j < k; ++j) rank += (sidx[j] < mine) ? 1 : 0;
                 if (e < k) {
-                    rowval[beg + rank] = mine;
-                    nzval[beg + rank] = valtmp[beg + e];
+                    rowval[out + rank] = mine;
+                    nzval[out + rank] = valtmp[beg + e];
                 }
             }
         } else {
@@ -398,8 +399,8 @@ __global__ __launch_bounds__(64) void k_sortcols(const int64_t* __restrict__ col
                     for (int64_t j = 0; j < cn; ++j) rank += (sidx[j] < mine) ? 1 : 0;
                 }
                 if (e < k) {
-                    rowval[beg + rank] = mine;
-                    nzval[beg + rank] = valtmp[beg + e];
+                    rowval[out + rank] = mine;
+                    nzval[out + rank] = valtmp[beg + e];
                 }
             }
         }
@@ -432,9 +433,20 @@ static void fill_args(mpfmt_ctx* ctx, double r, rdisc_args& a)
     a.nitems = (ctx->tile_end - ctx->tile_begin) * ctx->S;
     a.npad = ctx->ntiles * 64;
     a.slice_cnt = ctx->slice_cnt;
-    a.colptr = ctx->colptr;
+    a.tptr = ctx->tptr;
     a.rowtmp = ctx->rowtmp; a.valtmp = ctx->valtmp;
     a.pairs = ctx->d_pairs;
+}
+
+static int32_t scan_i64(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t n)
+{
+    size_t tmp_bytes = 0;
+    HIPCHK(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (int64_t)0, n, rocprim::plus<int64_t>(), ctx->stream));
+    void* tmp;
+    int32_t rc;
+    if ((rc = mpfmt_scratch(ctx, tmp_bytes, &tmp))) return rc;
+    HIPCHK(ctx, rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (int64_t)0, n, rocprim::plus<int64_t>(), ctx->stream));
+    return MPFMT_OK;
 }
 
 int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
@@ -442,48 +454,71 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
     int32_t rc;
     if ((rc = mpfmt_build_grid(ctx, r))) return rc;
     const int64_t N = ctx->N;
-    // shard: contiguous tile range of the cell-sorted order
-    ctx->tile_begin = ctx->ntiles * ctx->rank / ctx->world;
-    ctx->tile_end = ctx->ntiles * (ctx->rank + 1) / ctx->world;
+    // shard: contiguous range of 256-sample blocks (4 tiles) of the cell-sorted order
+    const int64_t nblocks4 = (ctx->ntiles + 3) / 4;
+    ctx->tile_begin = std::min<int64_t>(ctx->ntiles, 4 * (nblocks4 * ctx->rank / ctx->world));
+    ctx->tile_end = std::min<int64_t>(ctx->ntiles, 4 * (nblocks4 * (ctx->rank + 1) / ctx->world));
     const int64_t nt = ctx->tile_end - ctx->tile_begin;
+
+    // path: MFMA fp16 filter + exact refine when it is usable, else the exact fp64 VALU kernel
+    bool mf = false;
+    float negT = 0.f;
+    if (ctx->rdisc_path != 1) {
+        if ((rc = mpfmt_mfma_prepare(ctx, r, &negT, &mf))) return rc;
+        if (ctx->rdisc_path == 2 && !mf)
+            return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path requested but not usable (d > 12 or radius too small for the fp16 shell)");
+    }
+    ctx->rdisc_path_used = mf ? 2 : 1;
+    ctx->mf_negT = negT;
+    if (mf && ctx->ops_r != ctx->grid_r) {
+        mpfmt_time_begin(ctx);
+        if ((rc = mpfmt_mfma_build_operands(ctx))) return rc;
+        mpfmt_time_end(ctx, "grid");
+        ctx->ops_r = ctx->grid_r;
+    }
+
     int S = 1;
-    if (nt > 0) S = (int)std::min<int64_t>(MPFMT_MAXS, std::max<int64_t>(1, (32768 + nt - 1) / nt));
+    const int64_t units = nt;                                   // work items before slicing (one wavefront each)
+    const int64_t target = mf ? ctx->mf_target_items : 32768;
+    if (units > 0) S = (int)std::min<int64_t>(MPFMT_MAXS, std::max<int64_t>(1, (target + units - 1) / units));
     ctx->S = S;
     const int64_t npad = ctx->ntiles * 64;
     if ((rc = ensure(ctx, (void**)&ctx->slice_cnt, sizeof(int32_t) * (size_t)S * npad))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->deg, sizeof(int64_t) * (N + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (N + 1)))) return rc;
-    if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, sizeof(unsigned long long)));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, sizeof(unsigned long long), ctx->stream));
+    if ((rc = ensure(ctx, (void**)&ctx->degs, sizeof(int64_t) * (npad + 1)))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->tptr, sizeof(int64_t) * (npad + 1)))) return rc;
+    if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 2 * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 2 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (N + 1), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->degs, 0, sizeof(int64_t) * (npad + 1), ctx->stream));
 
-    rdisc_args a;
-    fill_args(ctx, r, a);
     mpfmt_time_begin(ctx);
-    if (a.nitems > 0) {
-        const int64_t nblk = ((a.nitems + NXCD - 1) / NXCD) * NXCD;
-        if ((rc = launch_rdisc<false>(ctx, a, (unsigned)nblk))) return rc;
+    if (nt > 0) {
+        if (mf) {
+            if ((rc = mpfmt_launch_rdisc_mfma<false>(ctx, r, negT))) return rc;
+        } else {
+            rdisc_args a;
+            fill_args(ctx, r, a);
+            const int64_t nblk = ((a.nitems + NXCD - 1) / NXCD) * NXCD;
+            if ((rc = launch_rdisc<false>(ctx, a, (unsigned)nblk))) return rc;
+        }
         const int B = 256;
         const int64_t pb = ctx->tile_begin * 64, pe = ctx->tile_end * 64;
         hipLaunchKernelGGL(k_degree, dim3((unsigned)((pe - pb + B - 1) / B)), dim3(B), 0, ctx->stream,
-                           ctx->slice_cnt, ctx->perm, S, npad, pb, pe, ctx->deg);
+                           ctx->slice_cnt, ctx->perm, S, npad, pb, pe, ctx->deg, ctx->degs);
     }
-    // exclusive scan of deg[0..N] -> colptr[0..N]
-    size_t tmp_bytes = 0;
-    HIPCHK(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, ctx->deg, ctx->colptr, (int64_t)0, (size_t)(N + 1),
-                                        rocprim::plus<int64_t>(), ctx->stream));
-    void* tmp;
-    if ((rc = mpfmt_scratch(ctx, tmp_bytes, &tmp))) return rc;
-    HIPCHK(ctx, rocprim::exclusive_scan(tmp, tmp_bytes, ctx->deg, ctx->colptr, (int64_t)0, (size_t)(N + 1),
-                                        rocprim::plus<int64_t>(), ctx->stream));
+    if ((rc = scan_i64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1)))) return rc;      // columns in original order
+    if ((rc = scan_i64(ctx, ctx->degs, ctx->tptr, (size_t)(npad + 1)))) return rc;    // staging in sorted order
     mpfmt_time_end(ctx, "rdisc_count");
     int64_t nnz = 0;
-    unsigned long long pairs = 0;
+    unsigned long long pairs[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(&nnz, ctx->colptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(&pairs, ctx->d_pairs, sizeof(pairs), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pairs, ctx->d_pairs, sizeof(pairs), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->nnz = nnz;
-    ctx->pairs_tested = (int64_t)pairs;
+    ctx->pairs_tested = (int64_t)pairs[0];
+    ctx->survivors = (int64_t)pairs[1];
     ctx->graph_r = r;
     ctx->graph_counted = true;
     ctx->graph_filled = false;
@@ -501,18 +536,23 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
     if ((rc = ensure(ctx, (void**)&ctx->valtmp, sizeof(double) * (size_t)nnz))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->rowval, sizeof(int32_t) * (size_t)nnz))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->nzval, sizeof(double) * (size_t)nnz))) return rc;
-    rdisc_args a;
-    fill_args(ctx, r, a);
-    a.pairs = nullptr;
-    if (a.nitems > 0 && nnz > 0) {
+    if (ctx->tile_end > ctx->tile_begin && nnz > 0) {
         mpfmt_time_begin(ctx);
-        const int64_t nblk = ((a.nitems + NXCD - 1) / NXCD) * NXCD;
-        if ((rc = launch_rdisc<true>(ctx, a, (unsigned)nblk))) return rc;
+        if (ctx->rdisc_path_used == 2) {
+            if ((rc = mpfmt_launch_rdisc_mfma<true>(ctx, r, ctx->mf_negT))) return rc;
+        } else {
+            rdisc_args a;
+            fill_args(ctx, r, a);
+            a.pairs = nullptr;
+            const int64_t nblk = ((a.nitems + NXCD - 1) / NXCD) * NXCD;
+            if ((rc = launch_rdisc<true>(ctx, a, (unsigned)nblk))) return rc;
+        }
         mpfmt_time_end(ctx, "rdisc_fill");
         mpfmt_time_begin(ctx);
-        const unsigned nb = (unsigned)std::min<int64_t>(ctx->N, 1 << 20);
+        const int64_t pb = ctx->tile_begin * 64, pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
+        const unsigned nb = (unsigned)std::min<int64_t>(pe - pb, 1 << 20);
         hipLaunchKernelGGL(k_sortcols, dim3(nb), dim3(64), 0, ctx->stream,
-                           ctx->colptr, ctx->N, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval);
+                           ctx->tptr, ctx->colptr, ctx->perm, pb, pe, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval);
         HIPCHK(ctx, hipGetLastError());
         mpfmt_time_end(ctx, "rdisc_sort");
     }

@@ -1,0 +1,473 @@
+// r-disc pair sweep with an fp16 MFMA distance-matrix FILTER and an exact fp64 REFINE (gfx950).
+//
+// Same contract as k_rdisc in kernels_rdisc.hip (inball for every sample, reference
+// src/nearneighbors.jl:179-183; canonical membership  i != v && sum_i (q_i-c_i)^2 <= r*r  in fp64,
+// unfused, index order), but the N x d . d^T x N distance-matrix block is evaluated on the matrix cores:
+//
+//   filter : every sorted sample carries a 16-slot fp16 operand  (u_0..u_{d-1}, 0.., 1, 1, n_hi, n_lo)
+//            with u = (x - lo) * s quantised to fp16 and n = |u^|^2.  With the query operand
+//            (-2u_0.., n_hi, n_lo, 1, 1) one v_mfma_f32_32x32x16_f16 gives, for 32 queries x 32
+//            candidates,   acc = |u^_q|^2 + |u^_c|^2 - 2 u^_q.u^_c - T = |u^_q - u^_c|^2 - T   (C input = -T).
+//            u^ are EXACT coordinates of slightly moved points (|u^ - u| <= 2^-12 per coordinate), so
+//            | |u^_q-u^_c| - s|q-c| | <= 2 sqrt(d) 2^-12 and the threshold
+//                T = (s r + 2 sqrt(d) e_c)^2 + accumulation margin
+//            can never reject a true neighbour (proof in DESIGN.md section 3).  It passes a few per cent of
+//            extra pairs in a thin shell around the r-ball.
+//   extract: the sign bits of the 16 accumulators are funnelled into one 16-bit word per lane
+//            (v_alignbit_b32), lanes with survivors append (query, candidate) to a wave-private LDS queue
+//            (__ballot + mbcnt prefix), ~0.3 % of the pairs.
+//   refine : when 64 survivors are queued, lane = survivor: exact canonical fp64 d2 from the fp64
+//            coordinates, membership test, count or emit (row index, sqrt(d2)).  All 64 lanes busy.
+//
+// Work mapping: workgroup = 4 wavefronts = 256 consecutive cell-sorted queries (wavefront = one 64-sample
+// tile, its two 32-row A fragments stay in VGPRs for the whole kernel); candidate chunks (64 samples, 2 KB
+// of operands) are staged once per workgroup in LDS, double buffered, one barrier per chunk, the next
+// chunk's global loads in flight during the MFMAs.  Chunks farther than r from a wavefront's tight tile
+// box are skipped per wavefront (tight box vs tight box).
+#include "mpfmt_internal.h"
+#include <algorithm>
+#include <cmath>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NXCD 8
+#define MF_THREADS 256
+#define MF_WAVES 4
+#define MF_QCAP 256                 // survivor queue entries per wavefront (drained in batches of 64)
+#define MF_PAD_NORM 60000.0f        // |u|^2 stand-in for padding samples: never below any threshold
+
+struct mf_args {
+    const uint4* ops;               // [npad][2] 16 fp16 slots per sorted sample (candidate role)
+    const double* Xs;               // [npad][D] sorted AoS fp64 (NaN padded)
+    const int32_t* perm;
+    const int32_t* cellstart;
+    const double* tile_lo;
+    const double* tile_hi;
+    double r2;                      // exact membership threshold r*r
+    double rpad;                    // conservative radius for box pruning
+    float negT;                     // -T, filter threshold in normalised squared units
+    int32_t S;
+    int32_t xcd_mode;               // item -> XCD placement: 0 contiguous range per XCD, 1 round robin, >=2 interleaved groups of that many items
+    int64_t blk_begin;              // first 256-query block of the shard
+    int64_t nitems;                 // blocks * S
+    int64_t npad;
+    int64_t ntiles;
+    int32_t* slice_cnt;             // [S][npad]
+    const int64_t* tptr;            // [npad+1] offsets of the sorted-order staging CSC
+    int32_t* rowtmp;
+    double* valtmp;
+    unsigned long long* pairs;
+    unsigned long long* survivors;
+};
+
+__device__ __forceinline__ int cell_of_m(double x, double lo, double inv_w, int g)
+{
+    double f = floor((x - lo) * inv_w);
+    int c = (int)f;
+    if (!(f >= 0.0)) c = 0;
+    if (f >= (double)g) c = g - 1;
+    return c;
+}
+
+// ---- operand construction --------------------------------------------------------------------------------
+// one thread per sorted position; writes the candidate-role operand (32 B).
+__global__ void k_make_ops(const double* __restrict__ Xs, int64_t N, int64_t npad, int d,
+                           mpfmt_grid G, double scale, uint4* __restrict__ ops)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npad) return;
+    _Float16 h[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) h[k] = (_Float16)0.0f;
+    float n = 0.0f;
+    if (p < N) {
+        for (int i = 0; i < d; ++i) {
+            const float u = (float)((Xs[p * d + i] - G.lo[i]) * scale);
+            const _Float16 q = (_Float16)u;                 // round to nearest even
+            h[i] = q;
+            const float qf = (float)q;
+            n += qf * qf;                                   // exact products, fp32 sum
+        }
+    } else {
+        n = MF_PAD_NORM;
+    }
+    const _Float16 nh = (_Float16)n;
+    const _Float16 nl = (_Float16)(n - (float)nh);
+    h[12] = (_Float16)1.0f; h[13] = (_Float16)1.0f; h[14] = nh; h[15] = nl;
+    union { _Float16 hh[16]; uint4 v[2]; } u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) u.hh[k] = h[k];
+    ops[p * 2] = u.v[0];
+    ops[p * 2 + 1] = u.v[1];
+}
+
+__global__ void k_sorted_aos(const double* __restrict__ Xo, const int32_t* __restrict__ perm, int64_t npad, int d,
+                             double* __restrict__ Xs)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npad) return;
+    const int32_t o = perm[p];
+    for (int i = 0; i < d; ++i) Xs[p * d + i] = (o >= 0) ? Xo[(int64_t)o * d + i] : __builtin_nan("");
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------------
+// One independent wavefront per (tile, slice): no workgroup barriers.
+//   prologue : lanes = grid-cell rows of the tile's neighbourhood -> contiguous candidate runs -> flattened
+//              64-sample chunks; each lane tests one chunk's tight box against the tile's tight box (the 2*d
+//              box loads of 64 chunks are in flight together) and the survivors are ballot-compacted into an
+//              LDS list of chunk ids.
+//   main loop: for each listed chunk, the two 32-candidate B fragments are 16 B/lane coalesced loads from the
+//              operand array (L2/MALL resident, 32 B per sample), prefetched two chunks ahead; 4 MFMAs
+//              (2 query row blocks x 2 candidate column blocks), sign-bit extraction, survivor queue, refine.
+#define MF_LIST 1024                // chunk ids per list round (4 KB LDS)
+
+template <int D, bool FILL>
+__global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
+{
+    __shared__ double s_q[64 * D];                        // fp64 query coordinates (AoS) for the refine
+    __shared__ uint32_t s_list[MF_LIST];
+    __shared__ int32_t s_sega[64];                        // first chunk of each row's run
+    __shared__ int32_t s_segp[64];                        // exclusive prefix of the runs' chunk counts
+    __shared__ uint32_t s_qj[MF_QCAP];                    // survivor queue: candidate sorted position
+    __shared__ uint32_t s_qq[MF_QCAP];                    //                 query lane
+    __shared__ int32_t s_cnt[64];
+    __shared__ int64_t s_base[64];
+
+    const int lane = threadIdx.x;
+    const int64_t nblk = gridDim.x;
+    const int64_t per_xcd = nblk / NXCD;
+    const int64_t b = blockIdx.x;
+    // block b runs on XCD b % 8 (private L2).  Items are handed to XCDs in interleaved groups: neighbouring tiles
+    // (which share candidate chunks) stay on one L2, while every XCD sees the same mix of boundary / interior
+    // tiles (whose work differs by >1.5x), so no XCD runs dry early.
+    int64_t item;
+    if (a.xcd_mode == 0) item = (b % NXCD) * per_xcd + (b / NXCD);
+    else if (a.xcd_mode == 1) item = b;
+    else {
+        const int64_t gsz = a.xcd_mode;
+        const int64_t x = b % NXCD, k = b / NXCD;              // k-th block of XCD x
+        item = ((k / gsz) * NXCD + x) * gsz + (k % gsz);
+    }
+    if (item >= a.nitems) return;
+    const int64_t tile = a.blk_begin + item / a.S;
+    const int slice = (int)(item % a.S);
+    const int64_t qpos = tile * 64 + lane;
+    const int kb = lane >> 5, col = lane & 31;
+
+    // ---- setup: fp64 query coordinates to LDS, A fragments to VGPRs, counters --------------------------------
+#pragma unroll
+    for (int i = 0; i < D; ++i) s_q[lane * D + i] = a.Xs[qpos * D + i];
+    s_cnt[lane] = 0;
+    if (FILL) {
+        int64_t base = a.tptr[qpos];
+        for (int s = 0; s < slice; ++s) base += a.slice_cnt[(int64_t)s * a.npad + qpos];
+        s_base[lane] = base;
+    }
+    half8 aF[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const uint4 raw = a.ops[(tile * 64 + rb * 32 + col) * 2 + kb];
+        union { uint4 u; _Float16 h[8]; } cv; cv.u = raw;
+        half8 v;
+        if (kb == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (_Float16)(-2.0f * (float)cv.h[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (_Float16)(-2.0f * (float)cv.h[k]);
+            // |u_q|^2 - T, re-split into hi + lo: the threshold rides in the query operand, so the MFMA's C
+            // input is the inline constant 0 and sign(acc) <=> filtered distance below the threshold
+            const float nT = ((float)cv.h[6] + (float)cv.h[7]) + a.negT;
+            const _Float16 nh = (_Float16)nT;
+            v[4] = nh; v[5] = (_Float16)(nT - (float)nh);
+            v[6] = (_Float16)1.0f; v[7] = (_Float16)1.0f;
+        }
+        aF[rb] = v;
+    }
+    f32x16 zero16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) zero16[k] = 0.0f;
+    const double rpad2 = a.rpad * a.rpad;
+
+    // ---- refine: exact fp64 test of n queued survivors (lane = survivor) ---------------------------------------
+    int qcount = 0;                                           // wave-uniform queue length
+    auto drain = [&](int n) {
+        // takes the LAST n queue entries (order is irrelevant: columns are sorted afterwards), so nothing moves
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int first = qcount - n;
+        if (lane < n) {
+            const uint32_t jg = s_qj[first + lane], ql = s_qq[first + lane];
+            double d2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double t = s_q[ql * D + i] - a.Xs[(int64_t)jg * D + i];
+                const double tt = t * t;
+                d2 = (i == 0) ? tt : d2 + tt;
+            }
+            if (d2 <= a.r2 && (int64_t)jg != tile * 64 + (int64_t)ql) {
+                const int slot = atomicAdd(&s_cnt[ql], 1);
+                if (FILL) {
+                    const int64_t pos = s_base[ql] + slot;
+                    a.rowtmp[pos] = a.perm[jg];
+                    a.valtmp[pos] = sqrt(d2);
+                }
+            }
+        }
+        qcount = __builtin_amdgcn_readfirstlane(first);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- extract the survivors of one chunk (4 accumulator tiles) into the queue ---------------------------------
+    // H: 16 sign bits per 32x32 tile t = cbk*2 + rb at bits [16t, 16t+16); bit (15 - r) <-> accumulator register r.
+    unsigned long long surv = 0;
+    auto extract = [&](unsigned long long H, int64_t c) {
+        for (;;) {
+            const unsigned long long m = __ballot(H != 0);
+            if (!m) break;
+            if (qcount > MF_QCAP - 64) drain(64);
+            if (H != 0) {
+                const int bpos = __ffsll((long long)H) - 1;
+                const int t = bpos >> 4;
+                const int r = 15 - (bpos & 15);
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
+                const int pos = qcount + (int)__popcll(m & ((1ull << lane) - 1ull));
+                s_qj[pos] = (uint32_t)(c * 64 + (t >> 1) * 32 + col);
+                s_qq[pos] = (uint32_t)((t & 1) * 32 + row);
+                H &= H - 1;
+            }
+            const int np = (int)__popcll(m);
+            qcount = __builtin_amdgcn_readfirstlane(qcount + np);
+            surv += (unsigned long long)np;
+        }
+    };
+
+    // ---- main loop over a list of chunk ids ------------------------------------------------------------------------
+    unsigned long long tested = 0;
+    auto load_b = [&](int64_t c, uint4 (&bq)[2]) {
+        bq[0] = a.ops[(c * 64 + col) * 2 + kb];
+        bq[1] = a.ops[(c * 64 + 32 + col) * 2 + kb];
+    };
+    auto run_list = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (n <= 0) return;
+        uint4 b0[2], b1[2], b2[2];
+        load_b((int64_t)s_list[0], b0);
+        if (n > 1) load_b((int64_t)s_list[1], b1);
+        for (int k = 0; k < n; ++k) {
+            const int64_t c = (int64_t)s_list[k];
+            if (k + 2 < n) load_b((int64_t)s_list[k + 2], b2);        // two chunks ahead, in flight during the MFMAs
+            tested += 64ull * 64ull;
+            union { uint4 u; half8 h; } bf0, bf1;
+            bf0.u = b0[0]; bf1.u = b0[1];
+            // 4 independent MFMAs back to back (2 query row blocks x 2 candidate column blocks), C = 0
+            const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf0.h, zero16, 0, 0, 0);
+            const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf0.h, zero16, 0, 0, 0);
+            const f32x16 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf1.h, zero16, 0, 0, 0);
+            const f32x16 acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf1.h, zero16, 0, 0, 0);
+            uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                h0 = __builtin_amdgcn_alignbit(h0, __float_as_uint(acc0[r]), 31);
+                h1 = __builtin_amdgcn_alignbit(h1, __float_as_uint(acc1[r]), 31);
+                h2 = __builtin_amdgcn_alignbit(h2, __float_as_uint(acc2[r]), 31);
+                h3 = __builtin_amdgcn_alignbit(h3, __float_as_uint(acc3[r]), 31);
+            }
+            const unsigned long long H = (unsigned long long)(h0 | (h1 << 16)) | ((unsigned long long)(h2 | (h3 << 16)) << 32);
+            extract(H, c);
+            b0[0] = b1[0]; b0[1] = b1[1];
+            b1[0] = b2[0]; b1[1] = b2[1];
+        }
+    };
+
+    // ---- prologue: candidate chunk list --------------------------------------------------------------------------------
+    double wlo[D], whi[D];
+    int clo[D], chi[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        wlo[i] = a.tile_lo[tile * D + i];
+        whi[i] = a.tile_hi[tile * D + i];
+        clo[i] = cell_of_m(wlo[i] - a.rpad, G.lo[i], G.inv_w[i], G.g[i]);
+        chi[i] = cell_of_m(whi[i] + a.rpad, G.lo[i], G.inv_w[i], G.g[i]);
+    }
+    constexpr int L = D - 1;
+    int64_t rows = 1;
+#pragma unroll
+    for (int i = 0; i < L; ++i) rows *= (chi[i] - clo[i] + 1);
+
+    int lcount = 0;                  // chunk ids in s_list (uniform)
+    int64_t gcount = 0;              // unique surviving chunks seen so far (slice selector, uniform)
+    int64_t carry = -1;              // last chunk id of the previous flattened batch (dedupe)
+    for (int64_t row0 = 0; row0 < rows; row0 += 64) {
+        // lane = one row: candidate run [ca, ca+n) in chunk units
+        const int64_t row = row0 + lane;
+        int32_t ca = 0, n = 0;
+        if (row < rows) {
+            int64_t rem = row, cbase = 0;
+            double partial = 0.0;
+#pragma unroll
+            for (int i = L - 1; i >= 0; --i) {
+                const int span = chi[i] - clo[i] + 1;
+                const int c = clo[i] + (int)(rem % span);
+                rem /= span;
+                cbase += (int64_t)c * G.stride[i];
+                const double eps = G.w[i] * 1e-9;
+                const double lo = G.lo[i] + (double)c * G.w[i] - eps;
+                const double hi = G.lo[i] + (double)(c + 1) * G.w[i] + eps;
+                double gap = fmax(fmax(lo - whi[i], wlo[i] - hi), 0.0);
+                if (G.g[i] == 1) gap = 0.0;
+                partial += gap * gap;
+            }
+            if (partial <= rpad2) {
+                int c0 = clo[L], c1 = chi[L];
+                if (G.g[L] > 1) {
+                    const double eps = G.w[L] * 1e-9;
+                    while (c0 <= c1) {
+                        const double hi = G.lo[L] + (double)(c0 + 1) * G.w[L] + eps;
+                        const double gap = fmax(wlo[L] - hi, 0.0);
+                        if (partial + gap * gap > rpad2) ++c0; else break;
+                    }
+                    while (c1 >= c0) {
+                        const double lo = G.lo[L] + (double)c1 * G.w[L] - eps;
+                        const double gap = fmax(lo - whi[L], 0.0);
+                        if (partial + gap * gap > rpad2) --c1; else break;
+                    }
+                }
+                if (c0 <= c1) {
+                    const int64_t ra = a.cellstart[cbase + c0];
+                    const int64_t rb = a.cellstart[cbase + c1 + 1];
+                    if (rb > ra) { ca = (int32_t)(ra >> 6); n = (int32_t)(((rb - 1) >> 6) - (ra >> 6) + 1); }
+                }
+            }
+        }
+        // exclusive prefix of n over the lanes
+        int32_t incl = n;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const int32_t T = __shfl(incl, 63);
+        __builtin_amdgcn_wave_barrier();
+        s_sega[lane] = ca;
+        s_segp[lane] = incl - n;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t t0 = 0; t0 < T; t0 += 64) {
+            const int32_t t = t0 + lane;
+            const bool act = t < T;
+            // run owning flattened index t: the largest j with s_segp[j] <= t
+            int j = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+                const int jj = j + step;
+                if (jj < 64 && s_segp[jj] <= t) j = jj;
+            }
+            int64_t c = act ? (int64_t)s_sega[j] + (t - s_segp[j]) : -2;
+            // dedupe: consecutive runs may share their boundary chunk
+            int64_t prevc = __shfl_up(c, 1);
+            if (lane == 0) prevc = carry;
+            const int lastl = min(63, T - t0 - 1);
+            carry = __shfl(c, lastl);
+            bool keep = act && (c != prevc);
+            if (keep) {
+                double gap2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    const double gp = fmax(fmax(a.tile_lo[c * D + i] - whi[i], wlo[i] - a.tile_hi[c * D + i]), 0.0);
+                    gap2 += gp * gp;
+                }
+                keep = gap2 <= rpad2;
+            }
+            const unsigned long long m = __ballot(keep);
+            const int64_t gidx = gcount + (int64_t)__popcll(m & ((1ull << lane) - 1ull));
+            gcount += (int64_t)__popcll(m);
+            const bool keep2 = keep && ((int)(gidx % a.S) == slice);
+            const unsigned long long m2 = __ballot(keep2);
+            if (keep2) s_list[lcount + (int)__popcll(m2 & ((1ull << lane) - 1ull))] = (uint32_t)c;
+            lcount += (int)__popcll(m2);
+            if (lcount > MF_LIST - 64) { run_list(lcount); lcount = 0; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    run_list(lcount);
+    while (qcount > 0) drain(min(qcount, 64));
+
+    if (!FILL) {
+        a.slice_cnt[(int64_t)slice * a.npad + qpos] = s_cnt[lane];
+        if (lane == 0 && a.pairs) { atomicAdd(a.pairs, tested); atomicAdd(a.survivors, surv); }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------
+int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usable)
+{
+    // normalisation: one common scale so that every coordinate lies in [0,1]
+    const int d = ctx->d;
+    double ext = 0.0;
+    for (int i = 0; i < d; ++i) ext = std::max(ext, ctx->bb_hi[i] - ctx->bb_lo[i]);
+    *usable = false;
+    if (d > 12 || !(ext > 0.0) || !(r > 0.0)) return MPFMT_OK;
+    const double s = 1.0 / ext;
+    const double e_c = 2.5e-4;                       // > 2^-12 (fp16 rounding on [0,1]) + fp32 conversion slack
+    const double shell = 2.0 * std::sqrt((double)d) * e_c;
+    const double Rh = s * r * (1.0 + 1e-9) + shell;
+    const double T = Rh * Rh * (1.0 + 1e-6) + 2e-5 * d;
+    // the filter is only worth running when the shell is thin compared with the ball
+    if (shell > 0.08 * s * r) return MPFMT_OK;
+    *negT_out = -(float)(T * (1.0 + 1e-6));
+    *usable = true;
+    ctx->mf_scale = s;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
+{
+    const int64_t npad = ctx->ntiles * 64;
+    int32_t rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->Xs, sizeof(double) * (size_t)npad * ctx->d))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->ops, 32 * (size_t)npad))) return rc;
+    if (npad == 0) return MPFMT_OK;
+    const int B = 256;
+    hipLaunchKernelGGL(k_sorted_aos, dim3((unsigned)((npad + B - 1) / B)), dim3(B), 0, ctx->stream,
+                       ctx->Xo, ctx->perm, npad, ctx->d, ctx->Xs);
+    hipLaunchKernelGGL(k_make_ops, dim3((unsigned)((npad + B - 1) / B)), dim3(B), 0, ctx->stream,
+                       ctx->Xs, ctx->N, npad, ctx->d, ctx->grid, ctx->mf_scale, (uint4*)ctx->ops);
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
+template <bool FILL>
+int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
+{
+    mf_args a;
+    a.ops = (const uint4*)ctx->ops; a.Xs = ctx->Xs; a.perm = ctx->perm; a.cellstart = ctx->cellstart;
+    a.tile_lo = ctx->tile_lo; a.tile_hi = ctx->tile_hi;
+    a.r2 = r * r; a.rpad = r * (1.0 + 1e-9) + 1e-300; a.negT = negT;
+    a.S = ctx->S;
+    a.xcd_mode = ctx->mf_xcd_mode;
+    a.blk_begin = ctx->tile_begin;                             // first tile of the shard
+    a.nitems = (ctx->tile_end - ctx->tile_begin) * ctx->S;
+    a.npad = ctx->ntiles * 64; a.ntiles = ctx->ntiles;
+    a.slice_cnt = ctx->slice_cnt; a.tptr = ctx->tptr; a.rowtmp = ctx->rowtmp; a.valtmp = ctx->valtmp;
+    a.pairs = FILL ? nullptr : ctx->d_pairs;
+    a.survivors = FILL ? nullptr : ctx->d_pairs + 1;
+    if (a.nitems <= 0) return MPFMT_OK;
+    const int64_t gran = NXCD * (int64_t)std::max(1, a.xcd_mode);
+    const unsigned nblk = (unsigned)(((a.nitems + gran - 1) / gran) * gran);
+    const mpfmt_grid& G = ctx->grid;
+#define CASE(DD) case DD: hipLaunchKernelGGL((k_rdisc_mfma<DD, FILL>), dim3(nblk), dim3(64), 0, ctx->stream, a, G); break;
+    switch (ctx->d) {
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
+        default: return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path supports d <= 12 (got %d)", ctx->d);
+    }
+#undef CASE
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
+template int32_t mpfmt_launch_rdisc_mfma<false>(mpfmt_ctx*, double, float);
+template int32_t mpfmt_launch_rdisc_mfma<true>(mpfmt_ctx*, double, float);

@@ -136,7 +136,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     hipDeviceSynchronize();
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
-                    ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch};
+                    ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops};
     for (void* b : bufs) if (b) hipFree(b);
     auto it = g_timers.find(ctx);
     if (it != g_timers.end()) {
@@ -186,7 +186,7 @@ int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t
     if (N > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->Xo, X, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->N = N; ctx->d = d;
-    ctx->grid_r = -1.0; ctx->graph_r = -1.0;
+    ctx->grid_r = -1.0; ctx->graph_r = -1.0; ctx->ops_r = -1.0;
     ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
     ctx->nnz = 0;
     return MPFMT_OK;
@@ -671,6 +671,33 @@ int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64
     if (avg_ms) *avg_ms = a;
     if (launches) *launches = n;
     return MPFMT_OK;
+}
+
+int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
+{
+    if (!ctx || !name) return MPFMT_ERR_ARG;
+    if (strcmp(name, "rdisc_path") == 0) {
+        if (value < 0 || value > 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "rdisc_path must be 0 (auto), 1 (fp64 VALU) or 2 (MFMA filter)");
+        ctx->rdisc_path = (int32_t)value;
+        ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
+        return MPFMT_OK;
+    }
+    if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }
+    if (strcmp(name, "mf_target_items") == 0) { ctx->mf_target_items = value; return MPFMT_OK; }
+    if (strcmp(name, "timing") == 0) { ctx->timing_enabled = value != 0; return MPFMT_OK; }
+    return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown option %s", name);
+}
+
+int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value)
+{
+    if (!ctx || !name || !value) return MPFMT_ERR_ARG;
+    if (strcmp(name, "rdisc_path_used") == 0) { *value = ctx->rdisc_path_used; return MPFMT_OK; }
+    if (strcmp(name, "survivors") == 0) { *value = ctx->survivors; return MPFMT_OK; }
+    if (strcmp(name, "pairs_tested") == 0) { *value = ctx->pairs_tested; return MPFMT_OK; }
+    if (strcmp(name, "nnz") == 0) { *value = ctx->nnz; return MPFMT_OK; }
+    if (strcmp(name, "slices") == 0) { *value = ctx->S; return MPFMT_OK; }
+    if (strcmp(name, "cells") == 0) { *value = ctx->grid.ncells; return MPFMT_OK; }
+    return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown stat %s", name);
 }
 
 int32_t mpfmt_graph_stats(mpfmt_ctx* ctx, int64_t* pairs_tested, int64_t* tiles, int64_t* slices, int64_t* cells)

@@ -73,7 +73,20 @@ struct mpfmt_ctx {
     int32_t S = 1;                       // candidate slices per tile
     int64_t tile_begin = 0, tile_end = 0;  // shard tile range
     int32_t* slice_cnt = nullptr;        // [S][ntiles*64] hits per (slice, sorted query)
-    int64_t* deg = nullptr;              // [N] degree by original index
+    int64_t* deg = nullptr;              // [N+1] degree by original index
+    int64_t* degs = nullptr;             // [npad+1] degree by sorted position
+    int64_t* tptr = nullptr;             // [npad+1] offsets of the sorted-order staging CSC (rowtmp/valtmp)
+    // MFMA filter path (kernels_rdisc_mfma.hip)
+    double* Xs = nullptr;                // [npad][d] cell-sorted AoS fp64 (NaN padded): exact refine gathers
+    void* ops = nullptr;                 // [npad] 16 fp16 slots (32 B) per sorted sample: MFMA operands
+    double mf_scale = 1.0;
+    double ops_r = -1.0;                 // grid radius the operands were built for
+    int32_t rdisc_path = 0;              // 0 auto, 1 exact fp64 VALU kernel, 2 MFMA filter + exact refine
+    int32_t rdisc_path_used = 0;
+    int32_t mf_xcd_mode = 512;
+    int64_t mf_target_items = 70000;     // work items (tile x slice) the MFMA path aims for
+    float mf_negT = 0.f;
+    int64_t survivors = 0;
     int64_t* colptr = nullptr;           // [N+1] 0-based offsets by original index
     int64_t nnz = 0;
     int32_t* rowtmp = nullptr;           // [nnz] unsorted fill
@@ -120,6 +133,9 @@ void mpfmt_time_end(mpfmt_ctx* ctx, const char* name);
 int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r);
+int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usable);
+int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx);
+template <bool FILL> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);
 

@@ -28,6 +28,24 @@ def to0(colptr, rowval):
     return colptr - 1, rowval - 1
 
 
+def graphs_both_paths(ctx, r):
+    """Build the r-disc graph through both pair kernels (exact fp64 VALU; fp16 MFMA filter + exact refine)
+    and require identical output.  Returns the (1-based) graph and the list of paths that ran."""
+    outs, ran = [], []
+    for path in (1, 2):
+        ctx.set_option("rdisc_path", path)
+        try:
+            outs.append(ctx.rdisc_graph(r))
+            ran.append(ctx.stat("rdisc_path_used"))
+        except mp.MPFMTError as e:
+            assert path == 2 and e.code == mp._lib.ERR_ARG      # filter not usable for this (d, r)
+    ctx.set_option("rdisc_path", 0)
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert np.array_equal(x, y)
+    return outs[0], ran
+
+
 def check_costs(got, want):
     assert got.shape == want.shape
     if want.size:
@@ -66,7 +84,8 @@ def test_golden_known_answers(ctx):
 def test_golden_rdisc(ctx, tag):
     z = np.load(os.path.join(G, "rdisc_%s.npz" % tag))
     ctx.upload_samples(z["X"])
-    colptr, rowval, nzval = ctx.rdisc_graph(float(z["r"]))
+    (colptr, rowval, nzval), ran = graphs_both_paths(ctx, float(z["r"]))
+    assert ran == [1, 2]
     c0, r0 = to0(colptr, rowval)
     assert np.array_equal(c0, z["colptr"])
     assert np.array_equal(r0, z["rowval"])
@@ -95,7 +114,8 @@ def test_rdisc_random(ctx, orc, N, d, r):
     rng = np.random.default_rng(100 + d)
     X = rng.random((N, d))
     ctx.upload_samples(X)
-    colptr, rowval, nzval = ctx.rdisc_graph(r)
+    (colptr, rowval, nzval), ran = graphs_both_paths(ctx, r)
+    assert (2 in ran) == (d <= 12)
     oc, orow, oval = orc.rdisc_graph(X, r)
     c0, r0 = to0(colptr, rowval)
     assert np.array_equal(c0, oc)
@@ -120,7 +140,7 @@ def test_rdisc_clustered_and_duplicates(ctx, orc):
     rng.shuffle(X)
     ctx.upload_samples(X)
     for r in (0.0, 0.02, 0.25):
-        colptr, rowval, nzval = ctx.rdisc_graph(r)
+        (colptr, rowval, nzval), _ = graphs_both_paths(ctx, r)
         oc, orow, oval = orc.rdisc_graph(X, r)
         c0, r0 = to0(colptr, rowval)
         assert np.array_equal(c0, oc) and np.array_equal(r0, orow)
@@ -133,7 +153,7 @@ def test_rdisc_tiny_and_ragged(ctx, orc, N):
     X = rng.random((N, 3))
     ctx.upload_samples(X)
     for r in (0.3, 5.0):                  # r = 5: every pair is a neighbour (brute-force regime)
-        colptr, rowval, nzval = ctx.rdisc_graph(r)
+        (colptr, rowval, nzval), _ = graphs_both_paths(ctx, r)
         oc, orow, oval = orc.rdisc_graph(X, r)
         c0, r0 = to0(colptr, rowval)
         assert np.array_equal(c0, oc) and np.array_equal(r0, orow)
@@ -145,7 +165,8 @@ def test_rdisc_high_degree_columns(ctx, orc):
     rng = np.random.default_rng(17)
     X = rng.random((3000, 2))
     ctx.upload_samples(X)
-    colptr, rowval, nzval = ctx.rdisc_graph(1.2)
+    (colptr, rowval, nzval), ran = graphs_both_paths(ctx, 1.2)
+    assert ran == [1, 2]
     oc, orow, oval = orc.rdisc_graph(X, 1.2)
     c0, r0 = to0(colptr, rowval)
     assert int(np.max(np.diff(oc))) > 2048
@@ -304,7 +325,8 @@ def test_shards_partition_the_graph(ctx, orc):
         c = mp.Context(0)
         c.set_shard(rank, 2)
         c.upload_samples(X)
-        colptr, rowval, _ = c.rdisc_graph(r)
+        (colptr, rowval, _), ran = graphs_both_paths(c, r)
+        assert ran == [1, 2]
         k = np.diff(colptr)
         assert np.all((deg == 0) | (k == 0))
         for v in np.flatnonzero(k):
@@ -324,6 +346,7 @@ def test_cfg2_full_size_properties(ctx, orc):
     ctx.upload_samples(w.X)
     ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
     colptr, rowval, nzval = ctx.rdisc_graph(w.r)
+    assert ctx.stat("rdisc_path_used") == 2               # the shipped (auto) path is the MFMA filter
     c0, r0 = to0(colptr, rowval)
     nnz = len(rowval)
     assert c0[0] == 0 and c0[-1] == nnz and nnz % 2 == 0
