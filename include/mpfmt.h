@@ -138,6 +138,31 @@ int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkp
                       int32_t goal_kind, const double* goal_params,
                       int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
+/* ---- double-integrator (LinearQuadratic quasi-metric) space: DoubleIntegrator(m; vmax, r=rho)
+ *      (src/statespaces/linearquadratic.jl:46-53).  Samples are states (p, v) in R^{2m} (upload_samples with
+ *      d = 2m); obstacles live in the workspace (first m coordinates, OutputMatrix C = [I 0], :51-52), so
+ *      upload_boxes takes dw = m and the 2m state-space bounds (lo, -vmax..; hi, +vmax..).
+ *      di_graph_count/fill : helper_data_structures(V, M::LinearQuadratic) = all-pairs steer_pairwise
+ *             (:68-77,196-225): sparse cost matrix Dmat, entry (i -> j) kept when cost(i -> j) <= r.
+ *             CSC: column j lists the sources i (ascending, 1-based) = DSB (backward sets, nearB);
+ *             DSF (forward sets) is its transpose.  nzval = cost, tval = optimal time t* (the duration of the
+ *             DurationAndTargetControl of :222-224; pass NULL to skip).
+ *      di_graph_edges_free : entry e (row y -> column x): is_free_motion(V[y], V[x], CC, SS) with the 5
+ *             collision waypoints x(v, w, t*, s), s = linspace(0, t*, 5) (:85-88; src/statespaces.jl:153-158).
+ *             nseg[e] (may be NULL) = workspace segment tests the reference would have made for that edge
+ *             (its CC.count increments, boxesND.jl:26), so collision_checks can be reproduced.
+ *      di_steer : batch steer(L, x0, x1, r) -> (cost, t*) (:191-195) on explicit pairs, X0/X1 = 2m x n col-major.
+ *      di_fmtstar : fmtstar! (src/planners/fmt.jl:3-119) over that graph; POINT goal = StateGoal (exact state,
+ *             src/goals.jl:128-131), RECT/BALL act on the workspace coordinates. */
+int32_t mpfmt_di_graph_count(mpfmt_ctx* ctx, double rho, double r, int64_t* colptr, int64_t* nnz);
+int32_t mpfmt_di_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval, double* tval);
+int32_t mpfmt_di_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg);
+int32_t mpfmt_di_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, int32_t m, double rho, double r,
+                       double* cost, double* topt);
+int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx, int32_t checkpts,
+                         int32_t goal_kind, const double* goal_params,
+                         int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
+
 /* ---- device-resident forms (bench / multi-GPU: no PCIe in the timed region) -----------------------
  * graph_build_device: count+fill on the device only; outputs stay in HBM.  Returns nnz.
  * graph_sweep_device: per-edge free mask of the resident graph into HBM.

@@ -56,6 +56,12 @@ SYMBOLS = [
                                  c_i64_p, c_i64_p, c_d_p, c_u8_p, C.c_int64, c_i64_p]),
     ("mpfmt_fmtstar", C.c_int32, [C.c_void_p, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
                                   c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
+    ("mpfmt_di_graph_count", C.c_int32, [C.c_void_p, C.c_double, C.c_double, c_i64_p, c_i64_p]),
+    ("mpfmt_di_graph_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p, c_d_p]),
+    ("mpfmt_di_graph_edges_free", C.c_int32, [C.c_void_p, c_u64_p, c_u8_p]),
+    ("mpfmt_di_steer", C.c_int32, [C.c_void_p, c_d_p, c_d_p, C.c_int64, C.c_int32, C.c_double, C.c_double, c_d_p, c_d_p]),
+    ("mpfmt_di_fmtstar", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
+                                     c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
     ("mpfmt_graph_build_device", C.c_int32, [C.c_void_p, C.c_double, c_i64_p]),
     ("mpfmt_graph_sweep_device", C.c_int32, [C.c_void_p]),
     ("mpfmt_graph_device_ptrs", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
@@ -282,6 +288,46 @@ class Context:
         return dict(status=int(res.status), cost=float(res.cost), z=int(res.z),
                     collision_checks=int(res.collision_checks), nnz=int(res.nnz),
                     ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
+                    A=A[:self.N], C=Cc[:self.N], path=path[:res.path_len].copy())
+
+    # ---- double integrator ------------------------------------------------------------------------
+    def di_graph(self, rho, r):
+        """Sparse cost matrix of the double-integrator space, CSC 1-based: (colptr, rowval, nzval, tval)."""
+        colptr = np.empty(self.N + 1, dtype=np.int64)
+        nnz = C.c_int64()
+        self._chk(self._L.mpfmt_di_graph_count(self._h, float(rho), float(r), _ip(colptr), C.byref(nnz)))
+        self.nnz = n = nnz.value
+        rowval = np.empty(max(n, 1), dtype=np.int64)
+        nzval = np.empty(max(n, 1), dtype=np.float64)
+        tval = np.empty(max(n, 1), dtype=np.float64)
+        self._chk(self._L.mpfmt_di_graph_fill(self._h, _ip(rowval), _dp(nzval), _dp(tval)))
+        return colptr, rowval[:n], nzval[:n], tval[:n]
+
+    def di_graph_edges_free(self):
+        n = self.nnz
+        mask = np.zeros(max(nwords(n), 1), dtype=np.uint64)
+        nseg = np.zeros(max(n, 1), dtype=np.uint8)
+        self._chk(self._L.mpfmt_di_graph_edges_free(self._h, _up(mask), nseg.ctypes.data_as(c_u8_p)))
+        return mask[:nwords(n)], nseg[:n]
+
+    def di_steer(self, X0, X1, rho, r):
+        X0 = np.ascontiguousarray(X0, dtype=np.float64)
+        X1 = np.ascontiguousarray(X1, dtype=np.float64)
+        n, ns = X0.shape
+        cost = np.empty(max(n, 1)); t = np.empty(max(n, 1))
+        self._chk(self._L.mpfmt_di_steer(self._h, _dp(X0), _dp(X1), n, ns // 2, float(rho), float(r), _dp(cost), _dp(t)))
+        return cost[:n], t[:n]
+
+    def di_fmtstar(self, rho, r, goal_kind, goal_params, init_idx=1, checkpts=True):
+        g = np.ascontiguousarray(goal_params, dtype=np.float64)
+        A = np.empty(max(self.N, 1), dtype=np.int64)
+        Cc = np.empty(max(self.N, 1), dtype=np.float64)
+        path = np.empty(max(self.N, 1), dtype=np.int64)
+        res = FmtResult()
+        self._chk(self._L.mpfmt_di_fmtstar(self._h, float(rho), float(r), int(init_idx), int(bool(checkpts)), int(goal_kind),
+                                           _dp(g), _ip(A), _dp(Cc), _ip(path), C.byref(res)))
+        return dict(status=int(res.status), cost=float(res.cost), z=int(res.z), collision_checks=int(res.collision_checks),
+                    nnz=int(res.nnz), ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
                     A=A[:self.N], C=Cc[:self.N], path=path[:res.path_len].copy())
 
     # ---- device-resident -------------------------------------------------------------------------

@@ -190,6 +190,7 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
                            ctx->Xt, ctx->ntiles, d, ctx->tile_lo, ctx->tile_hi);
         HIPCHK(ctx, hipGetLastError());
     }
+    if ((rc = mpfmt_build_sorted_aos(ctx))) return rc;     // cell-sorted AoS copy (refine gathers, graph sweep)
     mpfmt_time_end(ctx, "grid");
     ctx->grid_r = r;
     ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;

@@ -424,16 +424,26 @@ int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usab
     return MPFMT_OK;
 }
 
-int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
+int32_t mpfmt_build_sorted_aos(mpfmt_ctx* ctx)
 {
     const int64_t npad = ctx->ntiles * 64;
     int32_t rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->Xs, sizeof(double) * (size_t)npad * ctx->d))) return rc;
-    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->ops, 32 * (size_t)npad))) return rc;
     if (npad == 0) return MPFMT_OK;
     const int B = 256;
     hipLaunchKernelGGL(k_sorted_aos, dim3((unsigned)((npad + B - 1) / B)), dim3(B), 0, ctx->stream,
                        ctx->Xo, ctx->perm, npad, ctx->d, ctx->Xs);
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
+{
+    const int64_t npad = ctx->ntiles * 64;
+    int32_t rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->ops, 32 * (size_t)npad))) return rc;
+    if (npad == 0) return MPFMT_OK;
+    const int B = 256;
     hipLaunchKernelGGL(k_make_ops, dim3((unsigned)((npad + B - 1) / B)), dim3(B), 0, ctx->stream,
                        ctx->Xs, ctx->N, npad, ctx->d, ctx->grid, ctx->mf_scale, (uint4*)ctx->ops);
     HIPCHK(ctx, hipGetLastError());

@@ -136,7 +136,8 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     hipDeviceSynchronize();
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
-                    ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops};
+                    ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
+                    ctx->tvaltmp, ctx->tval, ctx->di_nseg};
     for (void* b : bufs) if (b) hipFree(b);
     auto it = g_timers.find(ctx);
     if (it != g_timers.end()) {
@@ -188,6 +189,7 @@ int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t
     ctx->N = N; ctx->d = d;
     ctx->grid_r = -1.0; ctx->graph_r = -1.0; ctx->ops_r = -1.0;
     ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
+    ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
     ctx->nnz = 0;
     return MPFMT_OK;
 }
@@ -212,6 +214,7 @@ int32_t mpfmt_upload_boxes(mpfmt_ctx* ctx, const double* lohi, int32_t M, int32_
     for (int i = 0; i < MPFMT_MAX_DIM; ++i) { ctx->ss.lo[i] = -INFINITY; ctx->ss.hi[i] = INFINITY; }
     if (ss_lo) for (int i = 0; i < d_state; ++i) { ctx->ss.lo[i] = ss_lo[i]; ctx->ss.hi[i] = ss_hi[i]; }
     ctx->graph_swept = false;
+    ctx->di_swept = false;
     return MPFMT_OK;
 }
 
@@ -224,6 +227,7 @@ int32_t mpfmt_graph_build_device(mpfmt_ctx* ctx, double r, int64_t* nnz)
     if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int32_t rc;
+    ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
     if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
     if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
     if (nnz) *nnz = ctx->nnz;
@@ -238,6 +242,7 @@ int32_t mpfmt_rdisc_count(mpfmt_ctx* ctx, double r, int64_t* colptr, int64_t* nn
     if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int32_t rc;
+    ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
     if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
     const int64_t n1 = ctx->N + 1;
     void* scr;
@@ -613,7 +618,11 @@ int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkp
                 if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
             }
             if (y_min < 0) continue;
-            ++count;                                                          // boxesND.jl:26
+            {   // boxesND.jl:26 is only reached when in_state_space(V[y_min]) held (statespaces.jl:155-157)
+                bool inb = true;
+                if (ctx->ss.has) for (int q = 0; q < d; ++q) inb = inb && (ctx->ss.lo[q] <= X[(size_t)y_min * d + q]) && (X[(size_t)y_min * d + q] <= ctx->ss.hi[q]);
+                if (inb) ++count;
+            }
             if (bit(efree, e_min)) {                                          // fmt.jl:75
                 A[x] = y_min + 1; C[x] = c_min;
                 heap.push(x, c_min);
@@ -650,6 +659,229 @@ int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkp
     res->ms_graph = ms(t1, t2);
     res->ms_sweep = ms(t0, t1) + ms(t2, t3);
     res->ms_host_loop = ms(t4, t5);
+    return MPFMT_OK;
+}
+
+// ---- double integrator (LinearQuadratic quasi-metric space) ----------------------------------------------------
+
+static int32_t di_check(mpfmt_ctx* ctx, double rho, double r)
+{
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    if (ctx->d % 2 != 0 || ctx->d / 2 < 1 || ctx->d / 2 > 6)
+        return mpfmt_fail(ctx, MPFMT_ERR_ARG, "double-integrator states need an even dimension 2..12 (got %d)", ctx->d);
+    if (!(rho > 0.0) || !std::isfinite(rho)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "rho must be finite and > 0");
+    if (!(r > 0.0) || !std::isfinite(r)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "cost radius must be finite and > 0");
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_di_graph_count(mpfmt_ctx* ctx, double rho, double r, int64_t* colptr, int64_t* nnz)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!colptr || !nnz) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "colptr / nnz is NULL");
+    int32_t rc;
+    if ((rc = di_check(ctx, rho, r))) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = mpfmt_di_count(ctx, rho, r))) return rc;
+    const int64_t n1 = ctx->N + 1;
+    void* scr;
+    if ((rc = mpfmt_scratch(ctx, sizeof(int64_t) * n1, &scr))) return rc;
+    hipLaunchKernelGGL(k_add1_i64, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->colptr, n1, (int64_t*)scr);
+    HIPCHK(ctx, hipMemcpyAsync(colptr, scr, sizeof(int64_t) * n1, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *nnz = ctx->nnz;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_di_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval, double* tval)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->di_counted) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "di_graph_fill before di_graph_count");
+    if (ctx->nnz > 0 && (!rowval || !nzval)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "rowval / nzval is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if (!ctx->di_filled && (rc = mpfmt_di_fill(ctx))) return rc;
+    const int64_t nnz = ctx->nnz;
+    if (nnz > 0) {
+        void* scr;
+        if ((rc = mpfmt_scratch(ctx, sizeof(int64_t) * nnz, &scr))) return rc;
+        hipLaunchKernelGGL(k_i32_to_i64_add1, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rowval, nnz, (int64_t*)scr);
+        HIPCHK(ctx, hipMemcpyAsync(rowval, scr, sizeof(int64_t) * nnz, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(nzval, ctx->nzval, sizeof(double) * nnz, hipMemcpyDeviceToHost, ctx->stream));
+        if (tval) HIPCHK(ctx, hipMemcpyAsync(tval, ctx->tval, sizeof(double) * nnz, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_di_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->di_counted) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "di_graph_edges_free before di_graph_count");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if (!ctx->di_filled && (rc = mpfmt_di_fill(ctx))) return rc;
+    if ((rc = mpfmt_di_sweep(ctx))) return rc;
+    const int64_t nnz = ctx->nnz, words = (nnz + 63) / 64;
+    if (nnz > 0) {
+        if (!mask) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "mask is NULL");
+        HIPCHK(ctx, hipMemcpyAsync(mask, ctx->graph_free, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, ctx->stream));
+        if (nseg) HIPCHK(ctx, hipMemcpyAsync(nseg, ctx->di_nseg, (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_di_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, int32_t m, double rho, double r,
+                       double* cost, double* topt)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (n < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "n < 0");
+    if (n == 0) return MPFMT_OK;
+    if (!X0 || !X1 || !cost || !topt) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "NULL array");
+    if (m < 1 || m > 6) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "workspace dim m must be 1..6");
+    if (!(rho > 0.0) || !(r > 0.0)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "rho and r must be > 0");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t pb = sizeof(double) * (size_t)n * 2 * m;
+    double *d0 = nullptr, *d1 = nullptr, *dc = nullptr, *dt = nullptr;
+    HIPCHK(ctx, hipMalloc((void**)&d0, pb)); HIPCHK(ctx, hipMalloc((void**)&d1, pb));
+    HIPCHK(ctx, hipMalloc((void**)&dc, 8 * n)); HIPCHK(ctx, hipMalloc((void**)&dt, 8 * n));
+    HIPCHK(ctx, hipMemcpyAsync(d0, X0, pb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d1, X1, pb, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = mpfmt_di_steer_launch(ctx, m, d0, d1, n, rho, r, dc, dt);
+    if (rc == MPFMT_OK) {
+        hipMemcpyAsync(cost, dc, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+        hipMemcpyAsync(topt, dt, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "di_steer copy back: %s", hipGetErrorString(e));
+    }
+    hipFree(d0); hipFree(d1); hipFree(dc); hipFree(dt);
+    return rc;
+}
+
+int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx, int32_t checkpts,
+                         int32_t goal_kind, const double* goal_params,
+                         int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!A || !C || !path || !res || !goal_params) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "NULL output / goal pointer");
+    int32_t rc;
+    if ((rc = di_check(ctx, rho, r))) return rc;
+    if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
+    const int64_t N = ctx->N;
+    const int n = ctx->d, m = n / 2;
+    if (init_idx < 1 || init_idx > N) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "init_idx out of range");
+    if (goal_kind < 0 || goal_kind > 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown goal kind %d", goal_kind);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    memset(res, 0, sizeof *res);
+    res->cost = INFINITY;
+    auto t0 = std::chrono::steady_clock::now();
+    // checkpts bitmap: is_free_state(v, CC, SS) = in_state_space(v) && point-vs-boxes on the workspace coordinates.
+    // The point kernel works on dw-dimensional points, so gather the workspace coordinates of every state.
+    std::vector<double> X((size_t)N * n);
+    HIPCHK(ctx, hipMemcpy(X.data(), ctx->Xo, sizeof(double) * (size_t)N * n, hipMemcpyDeviceToHost));
+    std::vector<double> P((size_t)N * m);
+    for (int64_t i = 0; i < N; ++i) for (int q = 0; q < m; ++q) P[(size_t)i * m + q] = X[(size_t)i * n + q];
+    const int64_t words = (N + 63) / 64;
+    std::vector<uint64_t> F(words, 0);
+    {
+        const mpfmt_ss keep = ctx->ss;            // the workspace sweep must not apply the 2m-dim bounds
+        ctx->ss.has = 0;
+        rc = mpfmt_states_free(ctx, P.data(), N, F.data());
+        ctx->ss = keep;
+        if (rc) return rc;
+        if (keep.has)
+            for (int64_t i = 0; i < N; ++i) {
+                bool ok = true;
+                for (int q = 0; q < n; ++q) ok = ok && (keep.lo[q] <= X[(size_t)i * n + q]) && (X[(size_t)i * n + q] <= keep.hi[q]);
+                if (!ok) F[i >> 6] &= ~(1ull << (i & 63));
+            }
+    }
+    if (!bit(F, init_idx - 1)) return mpfmt_fail(ctx, MPFMT_ERR_INFEASIBLE, "initial state is infeasible");
+    auto t1 = std::chrono::steady_clock::now();
+    if ((rc = mpfmt_di_count(ctx, rho, r))) return rc;
+    if ((rc = mpfmt_di_fill(ctx))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    auto t2 = std::chrono::steady_clock::now();
+    if ((rc = mpfmt_di_sweep(ctx))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    auto t3 = std::chrono::steady_clock::now();
+    const int64_t nnz = ctx->nnz;
+    std::vector<int64_t> colptr(N + 1);
+    std::vector<int32_t> rowval((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<double> nzval((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<uint64_t> efree((size_t)std::max<int64_t>((nnz + 63) / 64, 1));
+    std::vector<uint8_t> nseg((size_t)std::max<int64_t>(nnz, 1));
+    HIPCHK(ctx, hipMemcpy(colptr.data(), ctx->colptr, sizeof(int64_t) * (N + 1), hipMemcpyDeviceToHost));
+    if (nnz > 0) {
+        HIPCHK(ctx, hipMemcpy(rowval.data(), ctx->rowval, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(nzval.data(), ctx->nzval, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(efree.data(), ctx->graph_free, sizeof(uint64_t) * ((nnz + 63) / 64), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(nseg.data(), ctx->di_nseg, (size_t)nnz, hipMemcpyDeviceToHost));
+    }
+    auto t4 = std::chrono::steady_clock::now();
+    // forward sets: CSR of the cost matrix (DSF = Dmat', linearquadratic.jl:73), rows ascending in target index
+    std::vector<int64_t> rowptr(N + 1, 0), cur(N);
+    std::vector<int32_t> colidx((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t e = 0; e < nnz; ++e) rowptr[rowval[e] + 1]++;
+    for (int64_t i = 0; i < N; ++i) rowptr[i + 1] += rowptr[i];
+    for (int64_t i = 0; i < N; ++i) cur[i] = rowptr[i];
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t e = colptr[j]; e < colptr[j + 1]; ++e) colidx[cur[rowval[e]]++] = (int32_t)j;
+    auto goal_hit = [&](int64_t z) {
+        const double* v = &X[(size_t)z * n];
+        if (goal_kind == MPFMT_GOAL_POINT) {                      // StateGoal: exact state equality (goals.jl:128-131)
+            for (int q = 0; q < n; ++q) if (!(v[q] == goal_params[q])) return false;
+            return true;
+        }
+        return is_goal_pt(v, m, goal_kind, goal_params);           // workspace goals act on C*v = first m coordinates
+    };
+    std::vector<uint8_t> Wm(N, 1), Hm(N, 0);
+    std::vector<int64_t> Hnew;
+    for (int64_t i = 0; i < N; ++i) { A[i] = 0; C[i] = 0.0; }
+    Heap heap;
+    const int64_t i0 = init_idx - 1;
+    Wm[i0] = 0; Hm[i0] = 1;
+    heap.push(i0, 0.0);
+    int64_t z = heap.pop();
+    int64_t count = 0;
+    while (!goal_hit(z)) {
+        Hnew.clear();
+        for (int64_t a = rowptr[z]; a < rowptr[z + 1]; ++a) {                  // nearF(V, z, r, W), fmt.jl:70
+            const int64_t x = colidx[a];
+            if (!Wm[x]) continue;
+            if (checkpts && !bit(F, x)) continue;
+            int64_t y_min = -1, e_min = -1; double c_min = 0.0;
+            for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {              // nearB(V, x, r, H), fmt.jl:72-74
+                const int64_t y = rowval[b];
+                if (!Hm[y]) continue;
+                const double c = C[y] + nzval[b];
+                if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
+            }
+            if (y_min < 0) continue;
+            count += nseg[e_min];                                              // boxesND.jl:26 per tested segment
+            if (bit(efree, e_min)) {
+                A[x] = y_min + 1; C[x] = c_min;
+                heap.push(x, c_min);
+                Hnew.push_back(x);
+                Wm[x] = 0;
+            }
+        }
+        for (int64_t x : Hnew) Hm[x] = 1;
+        Hm[z] = 0;
+        if (!heap.empty()) z = heap.pop(); else break;
+    }
+    std::vector<int64_t> rev;
+    int64_t cu = z;
+    rev.push_back(cu + 1);
+    while (cu != 0) { const int64_t p = A[cu]; if (p == 0) break; cu = p - 1; rev.push_back(cu + 1); }
+    for (size_t i = 0; i < rev.size(); ++i) path[i] = rev[rev.size() - 1 - i];
+    auto t5 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    res->status = goal_hit(z) ? 1 : 0;
+    res->cost = C[z]; res->z = z + 1; res->collision_checks = count; res->path_len = (int64_t)rev.size(); res->nnz = nnz;
+    res->ms_graph = ms(t1, t2); res->ms_sweep = ms(t0, t1) + ms(t2, t3); res->ms_host_loop = ms(t4, t5);
     return MPFMT_OK;
 }
 

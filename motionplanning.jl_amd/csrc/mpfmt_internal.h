@@ -98,6 +98,14 @@ struct mpfmt_ctx {
     unsigned long long* d_pairs = nullptr;   // device counter: candidate pairs tested
     int64_t pairs_tested = 0;
 
+    // ---- double-integrator (LinearQuadratic) graph: shares colptr / rowval / nzval / graph_free -------------
+    int32_t di_S = 1;
+    double di_rho = 1.0, di_r = 0.0;
+    bool di_counted = false, di_filled = false, di_swept = false;
+    double* tvaltmp = nullptr;           // [nnz] optimal times, unsorted staging
+    double* tval = nullptr;              // [nnz] optimal times t* per entry
+    uint8_t* di_nseg = nullptr;          // [nnz] workspace segment tests the reference would have made per edge
+
     // ---- obstacles -----------------------------------------------------------------------------
     double* boxes = nullptr;             // [M][2][dw]
     int32_t M = 0, dw = 0;
@@ -135,6 +143,7 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usable);
 int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx);
+int32_t mpfmt_build_sorted_aos(mpfmt_ctx* ctx);
 template <bool FILL> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);
@@ -145,6 +154,13 @@ int32_t mpfmt_launch_states_free(mpfmt_ctx* ctx, const double* d_P, int64_t n, u
 int32_t mpfmt_launch_edges_free(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, uint64_t* d_mask);
 int32_t mpfmt_launch_motions_free(mpfmt_ctx* ctx, const double* d_P, const double* d_Q, int64_t n, uint64_t* d_mask);
 int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx);
+
+// kernels_di.hip ----------------------------------------------------------------------------------
+int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r);
+int32_t mpfmt_di_fill(mpfmt_ctx* ctx);
+int32_t mpfmt_di_sweep(mpfmt_ctx* ctx);
+int32_t mpfmt_di_steer_launch(mpfmt_ctx* ctx, int m, const double* dX0, const double* dX1, int64_t n, double rho, double r,
+                              double* dcost, double* dt);
 
 // kernels_expand.hip ----------------------------------------------------------------------------
 int32_t mpfmt_launch_expand(mpfmt_ctx* ctx, const uint64_t* d_W, const uint64_t* d_H, const uint64_t* d_F,

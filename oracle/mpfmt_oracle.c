@@ -610,7 +610,9 @@ int32_t orc_fmtstar(const double *X, int64_t N, int32_t d, double r, int64_t ini
                 if (y_min < 0 || c < c_min) { y_min = y; c_min = c; }
             }
             if (y_min < 0) continue;    /* unreachable for a symmetric metric (z itself is open) */
-            ++count;                                                       /* boxesND.jl:26 */
+            /* boxesND.jl:26: the counter sits inside is_free_motion(v, w, CC), which statespaces.jl:155-157
+             * only reaches when in_state_space(v) held */
+            if (orc_in_state_space(X + (size_t)y_min * d, ss_lo, ss_hi, d)) ++count;
             if (orc_is_free_motion(X + (size_t)y_min * d, X + (size_t)x * d, d, lohi, M, ss_lo, ss_hi)) { /* fmt.jl:75 */
                 A[x] = y_min; C[x] = c_min;                                /* fmt.jl:76-77 */
                 heap_push(&heap, x, c_min);                                /* fmt.jl:78 */
@@ -685,7 +687,7 @@ int32_t orc_fmtstar_graph(const double *X, int64_t N, int32_t d, int64_t init_id
                 if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
             }
             if (y_min < 0) continue;
-            ++count;
+            if (orc_in_state_space(X + (size_t)y_min * d, ss_lo, ss_hi, d)) ++count;
             int fr = free_mask ? get_bit(free_mask, e_min)
                                : orc_is_free_motion(X + (size_t)y_min * d, X + (size_t)x * d, d, lohi, M, ss_lo, ss_hi);
             if (fr) { A[x] = y_min; C[x] = c_min; heap_push(&heap, x, c_min); Hnew[nnew++] = x; Wm[x] = 0; }
@@ -864,4 +866,115 @@ double orc_fmt_radius(double rm, int32_t d, double free_volume_ub, int64_t N)
     double zeta = pow(M_PI, dd / 2) / tgamma(dd / 2 + 1);
     double inner = 1 / dd * free_volume_ub / zeta * log((double)N) / (double)N;
     return rm * 2 * pow(inner, 1 / dd);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a1 for the LinearQuadratic (double integrator) quasi-metric space:         */
+/* fmtstar! (fmt.jl:3-119) with nearF = inballF! = row z of the sparse cost   */
+/* matrix (DSF = Dmat', linearquadratic.jl:73) and nearB = column x (DSB).    */
+/* colptr/rowval/nzval: Dmat in CSC (column j = sources i that reach j).      */
+/* Goal kinds: RECT/BALL act on the workspace (first m coordinates, C=[I 0]); */
+/* POINT is a StateGoal (exact state equality, goals.jl:128-131).             */
+/* ------------------------------------------------------------------------- */
+static int di_is_goal(const double *v, int32_t m, int32_t kind, const double *g)
+{
+    if (kind == 2) {
+        for (int32_t i = 0; i < 2 * m; ++i) if (!(v[i] == g[i])) return 0;
+        return 1;
+    }
+    return orc_is_goal_pt(v, m, kind, g);
+}
+
+int32_t orc_di_fmtstar(const double *X, int64_t N, int32_t m, double rho, double r, int64_t init_idx, int32_t checkpts,
+                       const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                       int32_t goal_kind, const double *goal,
+                       const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi,
+                       int64_t *A, double *C, int64_t *path, orc_fmt_result *res)
+{
+    const int32_t n = 2 * m;
+    memset(res, 0, sizeof *res);
+    res->cost = INFINITY;
+    /* is_free_state(v, CC, SS) = in_state_space(v) && is_free_state(C*v, CC) (statespaces.jl:151-152) */
+#define DI_FREE_STATE(p) (orc_in_state_space((p), ss_lo, ss_hi, n) && orc_point_free_boxes((p), lohi, M, m))
+    if (!DI_FREE_STATE(X + (size_t)init_idx * n)) return -1;
+    uint8_t *F = NULL;
+    if (checkpts) {
+        F = (uint8_t *)malloc((size_t)N);
+        for (int64_t i = 0; i < N; ++i) F[i] = (uint8_t)DI_FREE_STATE(X + (size_t)i * n);
+    }
+#undef DI_FREE_STATE
+    /* CSR of Dmat (forward sets): row i lists targets j ascending */
+    int64_t nnz = colptr[N];
+    int64_t *rowptr = (int64_t *)calloc((size_t)N + 1, sizeof(int64_t));
+    int64_t *colidx = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz > 0 ? nnz : 1));
+    for (int64_t e = 0; e < nnz; ++e) rowptr[rowval[e] + 1]++;
+    for (int64_t i = 0; i < N; ++i) rowptr[i + 1] += rowptr[i];
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)(N > 0 ? N : 1));
+    memcpy(cur, rowptr, sizeof(int64_t) * (size_t)N);
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t e = colptr[j]; e < colptr[j + 1]; ++e) colidx[cur[rowval[e]]++] = j;
+
+    uint8_t *Wm = (uint8_t *)malloc((size_t)N), *Hm = (uint8_t *)calloc((size_t)N, 1);
+    memset(Wm, 1, (size_t)N);
+    for (int64_t i = 0; i < N; ++i) { A[i] = -1; C[i] = 0.0; }
+    int64_t *Hnew = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    int64_t *rev = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    orc_heap heap = {0};
+    Wm[init_idx] = 0; Hm[init_idx] = 1;
+    heap_push(&heap, init_idx, 0.0);
+    int64_t z = heap_pop(&heap), count = 0;
+    while (!di_is_goal(X + (size_t)z * n, m, goal_kind, goal)) {
+        int64_t nnew = 0;
+        for (int64_t a = rowptr[z]; a < rowptr[z + 1]; ++a) {            /* nearF(V, z, r, W) */
+            int64_t x = colidx[a];
+            if (!Wm[x]) continue;
+            if (checkpts && !F[x]) continue;
+            int64_t y_min = -1; double c_min = 0.0;
+            for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {        /* nearB(V, x, r, H) */
+                int64_t y = rowval[b];
+                if (!Hm[y]) continue;
+                double c = C[y] + nzval[b];
+                if (y_min < 0 || c < c_min) { y_min = y; c_min = c; }
+            }
+            if (y_min < 0) continue;
+            /* CC.count is incremented once per workspace segment actually tested (boxesND.jl:26 inside the
+             * @all of statespaces.jl:155): count the segments up to and including the first failure */
+            {
+                double wps[5 * ORC_MAXD];
+                orc_di_waypoints(X + (size_t)y_min * n, X + (size_t)x * n, m, rho, r, wps);
+                int ok = 1;
+                for (int32_t q = 0; q < 4 && ok; ++q) {
+                    const double *p = wps + (size_t)q * n, *pn = wps + (size_t)(q + 1) * n;
+                    if (!orc_in_state_space(p, ss_lo, ss_hi, n)) { ok = 0; break; }
+                    ++count;
+                    if (!orc_motion_free_boxes(p, pn, lohi, M, m)) ok = 0;
+                }
+                if (ok) { A[x] = y_min; C[x] = c_min; heap_push(&heap, x, c_min); Hnew[nnew++] = x; Wm[x] = 0; }
+            }
+        }
+        for (int64_t a = 0; a < nnew; ++a) Hm[Hnew[a]] = 1;
+        Hm[z] = 0;
+        if (heap.n > 0) z = heap_pop(&heap); else break;
+    }
+    int64_t len = 0, c2 = z;
+    rev[len++] = c2;
+    while (c2 != 0) { c2 = A[c2]; if (c2 < 0) break; rev[len++] = c2; }
+    for (int64_t i = 0; i < len; ++i) path[i] = rev[len - 1 - i];
+    res->status = di_is_goal(X + (size_t)z * n, m, goal_kind, goal);
+    res->cost = C[z]; res->z = z; res->collision_checks = count; res->path_len = len; res->nn_queries = 0;
+    free(F); free(rowptr); free(colidx); free(cur); free(Wm); free(Hm); free(Hnew); free(rev); free(heap.pri); free(heap.idx);
+    return 0;
+}
+
+/* Batch form of is_free_motion for the DI space over a CSC graph: entry e (row y -> column x). */
+void orc_di_graph_edges_free(const double *X, int64_t N, int32_t m, double rho, double r,
+                             const int64_t *colptr, const int64_t *rowval,
+                             const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi, uint64_t *mask)
+{
+    int64_t nnz = colptr[N];
+    int32_t n = 2 * m;
+    memset(mask, 0, sizeof(uint64_t) * (size_t)((nnz + 63) / 64));
+    for (int64_t x = 0; x < N; ++x)
+        for (int64_t e = colptr[x]; e < colptr[x + 1]; ++e)
+            set_bit(mask, e, orc_di_is_free_motion(X + (size_t)rowval[e] * n, X + (size_t)x * n, m, rho, r, lohi, M, ss_lo, ss_hi));
 }

@@ -317,3 +317,28 @@ def di_pairwise(X, rho, r):
     rowval = np.empty(max(nnz, 1), dtype=np.int64); nzval = np.empty(max(nnz, 1)); tval = np.empty(max(nnz, 1))
     lib().orc_di_pairwise(_d(X), C.c_int64(N), C.c_int32(n // 2), C.c_double(rho), C.c_double(r), _i(colptr), _i(rowval), _d(nzval), _d(tval))
     return colptr, rowval[:nnz], nzval[:nnz], tval[:nnz]
+
+
+def di_graph_edges_free(X, rho, r, colptr, rowval, lohi, ss_lo=None, ss_hi=None):
+    X, N, n = _X(X); m = n // 2
+    lohi, M = _boxes(lohi, m); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi)
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64); rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+    nnz = int(colptr[N])
+    mask = np.zeros(max(nwords(nnz), 1), dtype=np.uint64)
+    lib().orc_di_graph_edges_free(_d(X), C.c_int64(N), C.c_int32(m), C.c_double(rho), C.c_double(r), _i(colptr), _i(rowval),
+                                  _d(lohi), C.c_int32(M), _d(ss_lo), _d(ss_hi), _u(mask))
+    return mask[:nwords(nnz)]
+
+
+def di_fmtstar(X, rho, r, colptr, rowval, nzval, goal_kind, goal, lohi, ss_lo=None, ss_hi=None, init_idx=0, checkpts=True):
+    X, N, n = _X(X); m = n // 2
+    lohi, M = _boxes(lohi, m); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi); goal = _vec(goal)
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64); rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+    nzval = _vec(nzval)
+    A = np.empty(N, dtype=np.int64); Cc = np.empty(N, dtype=np.float64); path = np.empty(N, dtype=np.int64)
+    res = FmtResult()
+    rc = lib().orc_di_fmtstar(_d(X), C.c_int64(N), C.c_int32(m), C.c_double(rho), C.c_double(r), C.c_int64(init_idx),
+                              C.c_int32(int(checkpts)), _i(colptr), _i(rowval), _d(nzval), C.c_int32(goal_kind), _d(goal),
+                              _d(lohi), C.c_int32(M), _d(ss_lo), _d(ss_hi), _i(A), _d(Cc), _i(path), C.byref(res))
+    return dict(rc=rc, status=int(res.status), cost=float(res.cost), z=int(res.z),
+                collision_checks=int(res.collision_checks), A=A, C=Cc, path=path[:res.path_len].copy())

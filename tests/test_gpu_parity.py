@@ -372,3 +372,67 @@ def test_cfg2_full_size_properties(ctx, orc):
     want = orc.unpack(orc.edges_free(w.X, r0[es], cols[es], w.lohi, w.ss_lo, w.ss_hi), len(es))
     assert np.array_equal(mask[es], want)
     assert np.array_equal(ctx.points_free(), orc.points_free(w.X, w.lohi, w.ss_lo, w.ss_hi))
+
+
+# ---- double integrator (BASELINE.json configs[3]) ------------------------------------------
+
+def di_world(N, seed, M=20):
+    rng = np.random.default_rng(seed)
+    X = np.concatenate([rng.random((N, 2)), rng.random((N, 2)) - 0.5], axis=1)
+    X[0] = [0.1, 0.1, 0.0, 0.0]
+    X[-1] = [0.9, 0.9, 0.0, 0.0]
+    X[5] = X[3]                                     # duplicate state (steer returns (0, 0))
+    lohi = mp.workloads.make_boxes(rng, M, 2, 0.02, 0.08, [X[0, :2], X[-1, :2]])
+    ss_lo = np.array([0.0, 0.0, -0.5, -0.5]); ss_hi = np.array([1.0, 1.0, 0.5, 0.5])
+    return X, lohi, ss_lo, ss_hi
+
+
+def test_di_steer_batch(ctx, orc):
+    rng = np.random.default_rng(31)
+    n = 4096
+    X0 = np.concatenate([rng.random((n, 2)), rng.random((n, 2)) - 0.5], axis=1)
+    X1 = X0 + np.concatenate([0.3 * (rng.random((n, 2)) - 0.5), 0.4 * (rng.random((n, 2)) - 0.5)], axis=1)
+    X1[:7] = X0[:7]                                 # identical states
+    for rho, r in ((1.0, 1.0), (0.3, 0.7)):
+        cost, t = ctx.di_steer(X0, X1, rho, r)
+        ref = np.array([orc.di_steer(a, b, rho, r) for a, b in zip(X0, X1)])
+        assert np.array_equal(cost, ref[:, 0]) and np.array_equal(t, ref[:, 1])      # identical operation sequences
+    # 3-D workspace (6-D state)
+    X0 = np.concatenate([rng.random((512, 3)), rng.random((512, 3)) - 0.5], axis=1)
+    X1 = np.concatenate([rng.random((512, 3)), rng.random((512, 3)) - 0.5], axis=1)
+    cost, t = ctx.di_steer(X0, X1, 1.0, 1.5)
+    ref = np.array([orc.di_steer(a, b, 1.0, 1.5) for a, b in zip(X0, X1)])
+    check_costs(cost, ref[:, 0]); check_costs(t, ref[:, 1])
+
+
+@pytest.mark.parametrize("N,rho,r", [(1500, 1.0, 1.0), (900, 0.5, 0.6), (130, 1.0, 3.0)])
+def test_di_graph_and_sweep(ctx, orc, N, rho, r):
+    X, lohi, ss_lo, ss_hi = di_world(N, 40 + N)
+    ctx.upload_samples(X)
+    ctx.upload_boxes(lohi, ss_lo, ss_hi)
+    colptr, rowval, nzval, tval = ctx.di_graph(rho, r)
+    oc, orow, oval, otv = orc.di_pairwise(X, rho, r)
+    assert np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow)
+    check_costs(nzval, oval); check_costs(tval, otv)
+    assert np.array_equal(nzval, oval) and np.array_equal(tval, otv)
+    mask, nseg = ctx.di_graph_edges_free()
+    assert np.array_equal(mask, orc.di_graph_edges_free(X, rho, r, oc, orow, lohi, ss_lo, ss_hi))
+    assert nseg.max() <= 4
+
+
+def test_di_fmtstar_matches_oracle(ctx, orc):
+    X, lohi, ss_lo, ss_hi = di_world(2500, 77)
+    ctx.upload_samples(X)
+    ctx.upload_boxes(lohi, ss_lo, ss_hi)
+    res = ctx.di_fmtstar(1.0, 1.0, mp._lib.GOAL_POINT, X[-1])
+    oc, orow, oval, _ = orc.di_pairwise(X, 1.0, 1.0)
+    ref = orc.di_fmtstar(X, 1.0, 1.0, oc, orow, oval, orc.GOAL_POINT, X[-1], lohi, ss_lo, ss_hi)
+    assert res["status"] == ref["status"] == 1
+    assert res["collision_checks"] == ref["collision_checks"]
+    assert np.array_equal(res["A"] - 1, ref["A"]) and np.array_equal(res["path"] - 1, ref["path"])
+    check_costs(res["C"], ref["C"])
+    # workspace ball goal
+    res = ctx.di_fmtstar(1.0, 1.0, mp._lib.GOAL_BALL, [0.9, 0.9, 0.1])
+    ref = orc.di_fmtstar(X, 1.0, 1.0, oc, orow, oval, orc.GOAL_BALL, [0.9, 0.9, 0.1], lohi, ss_lo, ss_hi)
+    assert res["status"] == ref["status"] and np.array_equal(res["A"] - 1, ref["A"])
+    assert res["collision_checks"] == ref["collision_checks"]
