@@ -6,7 +6,8 @@ _lib.py (ctypes binding), host mirror of the reference's Julia interface (states
 checkers, near-neighbour sets, goals, problem, planner), workloads.py (synthetic BASELINE configs).
 No CPU fallback exists for any compute entry point.
 """
-from . import _lib, workloads, distributed  # noqa: F401
+from . import _lib, workloads, distributed, mirror  # noqa: F401
+from .mirror import *  # noqa: F401,F403  (the reference's names: MPProblem, UnitHypercube, fmtstar_, ...)
 from ._lib import Context, MPFMTError  # noqa: F401
 
 __version__ = "0.1.0"

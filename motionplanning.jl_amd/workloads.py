@@ -97,3 +97,32 @@ def cfg3(N=1_000_000, deg=256.0):
 
 
 BY_NAME = {"cfg1": cfg1, "cfg2": cfg2, "north_star": north_star, "cfg3": cfg3}
+
+
+@dataclass
+class DIWorkload:
+    name: str
+    X: np.ndarray          # (N, 2m) states (p, v)
+    lohi: np.ndarray       # (M, 2, m) workspace boxes
+    rho: float
+    r: float               # cost radius
+    ss_lo: np.ndarray
+    ss_hi: np.ndarray
+
+    @property
+    def N(self):
+        return self.X.shape[0]
+
+
+def cfg4(N=100_000, m=2, M=20, vmax=0.5, rho=1.0, r=1.0, seed=5):
+    """Kinodynamic FMT*: DoubleIntegrator(2; vmax=0.5, r=1.) (linearquadratic.jl:46-53), state R^4, cost radius 1
+    (docs/MotionPlanning.ipynb cell 8), 20 2-D boxes.  BASELINE.json configs[3]."""
+    rng = np.random.default_rng(seed)
+    init = np.concatenate([np.full(m, 0.1), np.zeros(m)])
+    goal = np.concatenate([np.full(m, 0.9), np.zeros(m)])
+    lohi = make_boxes(rng, M, m, 0.02, 0.08, [init[:m], goal[:m]])
+    X = np.concatenate([rng.random((N, m)), vmax * (2 * rng.random((N, m)) - 1)], axis=1)
+    X[0] = init
+    X[-1] = goal
+    return DIWorkload("cfg4_di_r4_n%d" % N, X, lohi, rho, r, np.concatenate([np.zeros(m), -vmax * np.ones(m)]),
+                      np.concatenate([np.ones(m), vmax * np.ones(m)]))

@@ -1,0 +1,88 @@
+"""GPU tests of the host-side mirror of the reference's Julia interface (motionplanning.jl_amd/mirror.py): the
+calls read like the reference's notebook (docs/MotionPlanning.ipynb cells 4-8) and results are checked against the
+CPU oracle run on the samples the mirror drew."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import motionplanning_jl_amd as mp
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def boxes2d():
+    return [mp.BoxBounds(lo, hi) for lo, hi in json.load(open(os.path.join(G, "boxes_nd.json")))["BOXES2D"]]
+
+
+def test_geometric_planning_like_the_notebook(orc):
+    statespace = mp.UnitHypercube(2)
+    init = [0.1, 0.1]
+    goal = mp.BallGoal([0.9, 0.9], 0.05)
+    collisionchecker = mp.PointRobotNDBoxes(boxes2d())
+    P = mp.MPProblem(statespace, init, goal, collisionchecker)
+    rng = np.random.default_rng(123)
+    status, cost, elapsed = mp.fmtstar_(P, 2000, connections="R", rm=1.5, rng=rng)
+    assert status == "solved" and len(P.V) == 2000
+    assert np.array_equal(P.V[1], init) and np.array_equal(P.V.V[0], init)
+    md = P.solution.metadata
+    X, lohi = P.V.V, collisionchecker.lohi()
+    assert orc.unpack(orc.points_free(X, lohi, statespace.lo, statespace.hi), len(X)).all()      # sampler keeps free states
+    ref = orc.fmtstar(X, md["r"], orc.GOAL_BALL, goal.params(), lohi, statespace.lo, statespace.hi)
+    assert ref["status"] == 1 and abs(ref["cost"] - cost) <= 1e-6 * cost
+    assert np.array_equal(md["tree"] - 1, ref["A"]) and np.array_equal(md["path"] - 1, ref["path"])
+    assert md["collision_checks"] == ref["collision_checks"] == collisionchecker.count
+    assert cost >= np.linalg.norm(np.array([0.9, 0.9]) - init) - 0.05
+    # cached and uncached neighbour queries agree with each other and with the oracle (nearneighbors.jl:120-136)
+    inds, ds = mp.inball(P.V, 7, md["r"])
+    oi, od = orc.inball(X, 6, md["r"])
+    assert np.array_equal(inds - 1, oi) and np.allclose(ds, od, rtol=1e-6, atol=0)
+    mp.build_cache_(P.V, md["r"])
+    i2, d2 = mp.inball_(P.V, 7, md["r"])
+    assert np.array_equal(i2, inds) and np.array_equal(d2, ds)
+    W = np.ones(len(X), bool); W[inds[0] - 1] = False
+    i3, _ = mp.inball_(P.V, 7, md["r"], W)
+    assert np.array_equal(i3, inds[1:])
+
+
+def test_scalar_validity_calls_and_count(orc):
+    SS = mp.UnitHypercube(2)
+    CC = mp.PointRobotNDBoxes(boxes2d())
+    P = mp.MPProblem(SS, [0.1, 0.1], mp.PointGoal([0.9, 0.9]), CC)
+    assert mp.is_free_state([0.1, 0.1], CC, SS, P.ctx) and not mp.is_free_state([0.45, 0.25], CC, SS, P.ctx)
+    assert not mp.is_free_state([1.2, 0.5], CC, SS, P.ctx)                     # outside the state space
+    CC.count = 0
+    assert not mp.is_free_motion([0.30, 0.25], [0.60, 0.25], CC, SS, P.ctx)
+    assert mp.is_free_motion([0.30, 0.10], [0.60, 0.10], CC, SS, P.ctx)
+    assert CC.count == 2
+    bigger = CC.inflate(0.2)
+    assert len(bigger.boxes) == 5 and np.allclose(bigger.boxes[0].lo, CC.boxes[0].lo - 0.2)
+    assert len(CC.addblocker([0.5, 0.5], 0.05).boxes) == 6
+
+
+def test_infeasible_init_warns():
+    SS = mp.UnitHypercube(2)
+    P = mp.MPProblem(SS, [0.45, 0.25], mp.PointGoal([0.9, 0.9]), mp.PointRobotNDBoxes(boxes2d()))
+    with pytest.warns(UserWarning, match="infeasible"):
+        out = mp.fmtstar_(P, 100)
+    assert out == np.inf and P.status == "failed"
+
+
+def test_double_integrator_planning_like_the_notebook(orc):
+    statespace = mp.DoubleIntegrator(2, vmax=0.5)
+    init = [0.1, 0.1, 0.0, 0.0]
+    goal = mp.StateGoal([0.9, 0.9, 0.0, 0.0])
+    P = mp.MPProblem(statespace, init, goal, mp.PointRobotNDBoxes(boxes2d()))
+    status, cost, _ = mp.fmtstar_(P, 1500, connections="R", r=1.0, rng=np.random.default_rng(7))
+    X = P.V.V
+    assert np.array_equal(X[-1], [0.9, 0.9, 0.0, 0.0])                         # goal sample in the tail (sampling.jl:38-42)
+    lohi = P.CC.lohi()
+    oc, orow, oval, _ = orc.di_pairwise(X, 1.0, 1.0)
+    ref = orc.di_fmtstar(X, 1.0, 1.0, oc, orow, oval, orc.GOAL_POINT, X[-1], lohi, statespace.lo, statespace.hi)
+    assert (status == "solved") == bool(ref["status"])
+    assert np.array_equal(P.solution.metadata["tree"] - 1, ref["A"])
+    assert P.solution.metadata["collision_checks"] == ref["collision_checks"]
+    if ref["status"]:
+        assert abs(cost - ref["cost"]) <= 1e-6 * ref["cost"]
