@@ -359,51 +359,45 @@ __global__ void k_degree(const int32_t* __restrict__ slice_cnt, const int32_t* _
 
 // Per-column ordering: rank each entry by counting smaller row indices (indices in a column are
 // distinct), one wavefront per column.  Columns up to SORT_LDS entries are staged once in LDS.
-#define SORT_LDS 2048
-// one wavefront per sorted position s: staging segment [tptr[s], tptr[s+1]) -> final column perm[s]
+// one wavefront per sorted position s: staging segment [tptr[s], tptr[s+1]) -> final column perm[s].
+// Rank by counting: rank(e) = #{j : row_j < row_e} (row indices inside a column are distinct).  The compared
+// index row_j is wave-uniform, so it is read with scalar loads straight from the staging array (s_load into
+// SGPRs, no LDS traffic) and each comparison is one v_cmp + one v_addc.
 __global__ __launch_bounds__(64) void k_sortcols(const int64_t* __restrict__ tptr, const int64_t* __restrict__ colptr,
                                                  const int32_t* __restrict__ perm, int64_t pos_begin, int64_t pos_end,
                                                  const int32_t* __restrict__ rowtmp, const double* __restrict__ valtmp,
                                                  int32_t* __restrict__ rowval, double* __restrict__ nzval)
 {
-    __shared__ int32_t sidx[SORT_LDS];
     const int lane = threadIdx.x;
     for (int64_t sp = pos_begin + blockIdx.x; sp < pos_end; sp += gridDim.x) {
-        const int64_t beg = tptr[sp];
+        const int64_t beg = __builtin_amdgcn_readfirstlane((int)(tptr[sp] & 0xffffffff)) |
+                            ((int64_t)__builtin_amdgcn_readfirstlane((int)(tptr[sp] >> 32)) << 32);
         const int64_t k = tptr[sp + 1] - beg;
         if (k == 0) continue;
         const int64_t out = colptr[perm[sp]];
-        if (k <= SORT_LDS) {
-            __syncthreads();
-            for (int64_t e = lane; e < k; e += 64) sidx[e] = rowtmp[beg + e];
-            __syncthreads();
-            for (int64_t e0 = 0; e0 < k; e0 += 64) {
-                const int64_t e = e0 + lane;
-                const int32_t mine = (e < k) ? sidx[e] : 0x7fffffff;
-                int32_t rank = 0;
-                for (int64_t j = 0; j < k; ++j) rank += (sidx[j] < mine) ? 1 : 0;
-                if (e < k) {
-                    rowval[out + rank] = mine;
-                    nzval[out + rank] = valtmp[beg + e];
+        const int32_t* __restrict__ col = rowtmp + beg;            // wave-uniform base
+        for (int64_t e0 = 0; e0 < k; e0 += 128) {
+            // two entries per lane per round: the uniform index stream is read once for both
+            const int64_t ea = e0 + lane, eb = e0 + 64 + lane;
+            const int32_t ma = (ea < k) ? col[ea] : 0x7fffffff;
+            const int32_t mb = (eb < k) ? col[eb] : 0x7fffffff;
+            int32_t ra = 0, rb = 0;
+            int64_t j = 0;
+            for (; j + 8 <= k; j += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int32_t v = col[j + u];
+                    ra += (v < ma) ? 1 : 0;
+                    rb += (v < mb) ? 1 : 0;
                 }
             }
-        } else {
-            for (int64_t e0 = 0; e0 < k; e0 += 64) {
-                const int64_t e = e0 + lane;
-                const int32_t mine = (e < k) ? rowtmp[beg + e] : 0x7fffffff;
-                int64_t rank = 0;
-                for (int64_t c0 = 0; c0 < k; c0 += SORT_LDS) {
-                    const int64_t cn = std::min<int64_t>(SORT_LDS, k - c0);
-                    __syncthreads();
-                    for (int64_t j = lane; j < cn; j += 64) sidx[j] = rowtmp[beg + c0 + j];
-                    __syncthreads();
-                    for (int64_t j = 0; j < cn; ++j) rank += (sidx[j] < mine) ? 1 : 0;
-                }
-                if (e < k) {
-                    rowval[out + rank] = mine;
-                    nzval[out + rank] = valtmp[beg + e];
-                }
+            for (; j < k; ++j) {
+                const int32_t v = col[j];
+                ra += (v < ma) ? 1 : 0;
+                rb += (v < mb) ? 1 : 0;
             }
+            if (ea < k) { rowval[out + ra] = ma; nzval[out + ra] = valtmp[beg + ea]; }
+            if (eb < k) { rowval[out + rb] = mb; nzval[out + rb] = valtmp[beg + eb]; }
         }
     }
 }
