@@ -136,7 +136,7 @@ def main():
     stats = ctx.graph_stats()
     path_used = ctx.stat("rdisc_path_used")
     survivors = ctx.stat("survivors")
-    tm = {k: ctx.timing(k) for k in ("grid", "rdisc_count", "rdisc_fill", "rdisc_sort", "sweep_graph")}
+    tm = {k: ctx.timing(k) for k in ("grid", "rdisc_count", "rdisc_finalize", "rdisc_fill", "rdisc_sort", "sweep_graph")}
     d = w.d
     # dominant kernel: the r-disc pair sweep (count pass and fill pass run the same pair tests)
     pair_ms = tm["rdisc_count"][0] + tm["rdisc_fill"][0]

@@ -26,6 +26,7 @@
 #include <rocprim/rocprim.hpp>
 #include <cmath>
 #include <algorithm>
+#include <vector>
 
 #define NXCD 8
 
@@ -488,10 +489,40 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
     HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (N + 1), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->degs, 0, sizeof(int64_t) * (npad + 1), ctx->stream));
 
+    // single-pass pool: capacity from the last build of the same (N, r), else from the ball-volume estimate
+    bool pool = mf && ctx->use_pool && nt > 0;
+    if (pool) {
+        double want;
+        if (ctx->pool_hint_N == N && ctx->pool_hint_r == r && ctx->rank == 0 && ctx->world == 1) {
+            want = (double)ctx->pool_hint_nnz * 1.02 + 4096.0;
+        } else {
+            const int d = ctx->d;
+            double vol = 1.0;
+            for (int i = 0; i < d; ++i) vol *= std::max(ctx->bb_hi[i] - ctx->bb_lo[i], 1e-300);
+            const double ball = std::pow(M_PI, d / 2.0) / std::tgamma(d / 2.0 + 1.0) * std::pow(r, (double)d);
+            want = std::min(1.0, ball / vol) * (double)N * (double)(nt * 64) * 1.15 + 64.0 * (double)N;
+        }
+        want = std::min(want, (double)N * (double)(nt * 64));
+        // every (tile, slice, column) owns a fixed-capacity slot list; per-list counts vary, so lists get 4x the
+        // mean plus a fixed slack -- an overflow falls back to the fill pass
+        const int64_t items = nt * S;
+        const int64_t capc = (int64_t)(want / ((double)items * 64.0) * 4.0) + 32;
+        if ((double)capc * (double)items * 64.0 * 12.0 > 96e9) pool = false;      // cap the slot lists at 96 GB of the 288
+        else {
+            const size_t cap = (size_t)capc * (size_t)items * 64;
+            if ((rc = ensure(ctx, (void**)&ctx->pool_j, sizeof(int32_t) * cap))) return rc;
+            if ((rc = ensure(ctx, (void**)&ctx->pool_d, sizeof(double) * cap))) return rc;
+            if (!ctx->pool_flag) HIPCHK(ctx, hipMalloc((void**)&ctx->pool_flag, sizeof(int32_t)));
+            HIPCHK(ctx, hipMemsetAsync(ctx->pool_flag, 0, sizeof(int32_t), ctx->stream));
+            ctx->pool_cap = capc;
+        }
+    }
+    ctx->pool_valid = false;
     mpfmt_time_begin(ctx);
     if (nt > 0) {
         if (mf) {
-            if ((rc = mpfmt_launch_rdisc_mfma<false>(ctx, r, negT))) return rc;
+            if (pool) { if ((rc = mpfmt_launch_rdisc_mfma<2>(ctx, r, negT))) return rc; }
+            else if ((rc = mpfmt_launch_rdisc_mfma<0>(ctx, r, negT))) return rc;
         } else {
             rdisc_args a;
             fill_args(ctx, r, a);
@@ -510,7 +541,11 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
     unsigned long long pairs[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(&nnz, ctx->colptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(pairs, ctx->d_pairs, sizeof(pairs), hipMemcpyDeviceToHost, ctx->stream));
+    int32_t pool_over = 0;
+    if (pool) HIPCHK(ctx, hipMemcpyAsync(&pool_over, ctx->pool_flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pool_valid = pool && pool_over == 0;
+    ctx->pool_hint_N = N; ctx->pool_hint_r = r; ctx->pool_hint_nnz = nnz;
     ctx->nnz = nnz;
     ctx->pairs_tested = (int64_t)pairs[0];
     ctx->survivors = (int64_t)pairs[1];
@@ -527,29 +562,41 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
         return mpfmt_fail(ctx, MPFMT_ERR_STATE, "rdisc_fill without a matching rdisc_count");
     int32_t rc;
     const int64_t nnz = ctx->nnz;
-    if ((rc = ensure(ctx, (void**)&ctx->rowtmp, sizeof(int32_t) * (size_t)nnz))) return rc;
-    if ((rc = ensure(ctx, (void**)&ctx->valtmp, sizeof(double) * (size_t)nnz))) return rc;
+    if (!(ctx->rdisc_path_used == 2 && ctx->pool_valid)) {        // the staging CSC is only needed by the two-pass forms
+        if ((rc = ensure(ctx, (void**)&ctx->rowtmp, sizeof(int32_t) * (size_t)nnz))) return rc;
+        if ((rc = ensure(ctx, (void**)&ctx->valtmp, sizeof(double) * (size_t)nnz))) return rc;
+    }
     if ((rc = ensure(ctx, (void**)&ctx->rowval, sizeof(int32_t) * (size_t)nnz))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->nzval, sizeof(double) * (size_t)nnz))) return rc;
     if (ctx->tile_end > ctx->tile_begin && nnz > 0) {
-        mpfmt_time_begin(ctx);
-        if (ctx->rdisc_path_used == 2) {
-            if ((rc = mpfmt_launch_rdisc_mfma<true>(ctx, r, ctx->mf_negT))) return rc;
-        } else {
-            rdisc_args a;
-            fill_args(ctx, r, a);
-            a.pairs = nullptr;
-            const int64_t nblk = ((a.nitems + NXCD - 1) / NXCD) * NXCD;
-            if ((rc = launch_rdisc<true>(ctx, a, (unsigned)nblk))) return rc;
+        int done = 0;
+        if (ctx->rdisc_path_used == 2 && ctx->pool_valid) {
+            // single pass: the hits are already in the slot lists; order each column straight into the final CSC
+            mpfmt_time_begin(ctx);
+            if ((rc = mpfmt_sortcols_slots(ctx))) return rc;
+            mpfmt_time_end(ctx, "rdisc_sort");
+            done = 1;
         }
-        mpfmt_time_end(ctx, "rdisc_fill");
-        mpfmt_time_begin(ctx);
-        const int64_t pb = ctx->tile_begin * 64, pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
-        const unsigned nb = (unsigned)std::min<int64_t>(pe - pb, 1 << 20);
-        hipLaunchKernelGGL(k_sortcols, dim3(nb), dim3(64), 0, ctx->stream,
-                           ctx->tptr, ctx->colptr, ctx->perm, pb, pe, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval);
-        HIPCHK(ctx, hipGetLastError());
-        mpfmt_time_end(ctx, "rdisc_sort");
+        if (!done) {
+            mpfmt_time_begin(ctx);
+            if (ctx->rdisc_path_used == 2) {
+                if ((rc = mpfmt_launch_rdisc_mfma<1>(ctx, r, ctx->mf_negT))) return rc;
+            } else {
+                rdisc_args a;
+                fill_args(ctx, r, a);
+                a.pairs = nullptr;
+                const int64_t nblk = ((a.nitems + NXCD - 1) / NXCD) * NXCD;
+                if ((rc = launch_rdisc<true>(ctx, a, (unsigned)nblk))) return rc;
+            }
+            mpfmt_time_end(ctx, "rdisc_fill");
+            mpfmt_time_begin(ctx);
+            const int64_t pb = ctx->tile_begin * 64, pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
+            const unsigned nb = (unsigned)std::min<int64_t>(pe - pb, 1 << 20);
+            hipLaunchKernelGGL(k_sortcols, dim3(nb), dim3(64), 0, ctx->stream,
+                               ctx->tptr, ctx->colptr, ctx->perm, pb, pe, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval);
+            HIPCHK(ctx, hipGetLastError());
+            mpfmt_time_end(ctx, "rdisc_sort");
+        }
     }
     ctx->graph_filled = true;
     return MPFMT_OK;

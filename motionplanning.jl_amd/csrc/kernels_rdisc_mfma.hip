@@ -59,6 +59,11 @@ struct mf_args {
     double* valtmp;
     unsigned long long* pairs;
     unsigned long long* survivors;
+    // MODE 2 (single pass): exact hits are appended to a pool while they are counted
+    int32_t* pool_flag;             // set to 1 when a slot list overflows (the build then falls back to a fill pass)
+    long long pool_cap;             // capacity of ONE (item, column) slot list
+    int32_t* pool_j;                // sample index of the row (candidate)
+    double* pool_d;                 // sqrt(d2)
 };
 
 __device__ __forceinline__ int cell_of_m(double x, double lo, double inv_w, int g)
@@ -122,7 +127,8 @@ __global__ void k_sorted_aos(const double* __restrict__ Xo, const int32_t* __res
 //              (2 query row blocks x 2 candidate column blocks), sign-bit extraction, survivor queue, refine.
 #define MF_LIST 1024                // chunk ids per list round (4 KB LDS)
 
-template <int D, bool FILL>
+// MODE 0: count only   1: fill the staging CSC (needs offsets from a count pass)   2: count AND append hits to the pool
+template <int D, int MODE>
 __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
 {
     __shared__ double s_q[64 * D];                        // fp64 query coordinates (AoS) for the refine
@@ -159,6 +165,7 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
 #pragma unroll
     for (int i = 0; i < D; ++i) s_q[lane * D + i] = a.Xs[qpos * D + i];
     s_cnt[lane] = 0;
+    constexpr bool FILL = (MODE == 1);
     if (FILL) {
         int64_t base = a.tptr[qpos];
         for (int s = 0; s < slice; ++s) base += a.slice_cnt[(int64_t)s * a.npad + qpos];
@@ -192,26 +199,41 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
 
     // ---- refine: exact fp64 test of n queued survivors (lane = survivor) ---------------------------------------
     int qcount = 0;                                           // wave-uniform queue length
+    int pool_over = 0;
     auto drain = [&](int n) {
         // takes the LAST n queue entries (order is irrelevant: columns are sorted afterwards), so nothing moves
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int first = qcount - n;
+        bool hit = false;
+        uint32_t jg = 0, ql = 0;
+        double d2 = 0.0;
         if (lane < n) {
-            const uint32_t jg = s_qj[first + lane], ql = s_qq[first + lane];
-            double d2 = 0.0;
+            jg = s_qj[first + lane]; ql = s_qq[first + lane];
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 const double t = s_q[ql * D + i] - a.Xs[(int64_t)jg * D + i];
                 const double tt = t * t;
                 d2 = (i == 0) ? tt : d2 + tt;
             }
-            if (d2 <= a.r2 && (int64_t)jg != tile * 64 + (int64_t)ql) {
+            hit = (d2 <= a.r2) && ((int64_t)jg != tile * 64 + (int64_t)ql);
+            if (hit) {
                 const int slot = atomicAdd(&s_cnt[ql], 1);
                 if (FILL) {
                     const int64_t pos = s_base[ql] + slot;
                     a.rowtmp[pos] = a.perm[jg];
                     a.valtmp[pos] = sqrt(d2);
+                }
+                if (MODE == 2) {
+                    // single pass: the hit goes straight into the fixed-capacity slot list of (item, column); the
+                    // LDS counter that numbers it is the same one that counts the column's degree
+                    if (slot < a.pool_cap) {
+                        const long long p = ((long long)item * 64 + ql) * a.pool_cap + slot;
+                        a.pool_j[p] = a.perm[jg];                        // sample index of the row
+                        a.pool_d[p] = sqrt(d2);
+                    } else {
+                        pool_over = 1;
+                    }
                 }
             }
         }
@@ -396,7 +418,8 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
     run_list(lcount);
     while (qcount > 0) drain(min(qcount, 64));
 
-    if (!FILL) {
+    if (MODE == 2 && pool_over) *a.pool_flag = 1;                 // overflow: the build falls back to a fill pass
+    if (MODE != 1) {
         a.slice_cnt[(int64_t)slice * a.npad + qpos] = s_cnt[lane];
         if (lane == 0 && a.pairs) { atomicAdd(a.pairs, tested); atomicAdd(a.survivors, surv); }
     }
@@ -450,7 +473,82 @@ int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
     return MPFMT_OK;
 }
 
-template <bool FILL>
+// Column ordering for the single-pass build: one wavefront per sorted position.  The column's hits sit in S slot
+// lists (one per candidate slice, counts in slice_cnt); they are gathered, ranked by counting through LDS and
+// written to the final CSC column -- contiguous stores, no staging CSC.
+__global__ __launch_bounds__(64) void k_sortcols_slots(const int32_t* __restrict__ pool_j, const double* __restrict__ pool_d,
+                                                       int64_t capc, int S, const int32_t* __restrict__ slice_cnt, int64_t npad,
+                                                       int64_t tile_begin, int64_t pos_begin, int64_t pos_end,
+                                                       const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm,
+                                                       int32_t* __restrict__ rowval, double* __restrict__ nzval)
+{
+    const int lane = threadIdx.x;
+    for (int64_t sp = pos_begin + blockIdx.x; sp < pos_end; sp += gridDim.x) {
+        const int32_t o = perm[sp];
+        if (o < 0) continue;
+        const int64_t t = (sp >> 6) - tile_begin;
+        const int ql = (int)(sp & 63);
+        // prefix of the per-slice counts (S <= 16): entry e of the column lives in slice s at position e - pre[s]
+        int pre[MPFMT_MAXS + 1];
+        pre[0] = 0;
+#pragma unroll
+        for (int s = 0; s < MPFMT_MAXS; ++s) pre[s + 1] = pre[s] + ((s < S) ? slice_cnt[(int64_t)s * npad + sp] : 0);
+        const int k = pre[MPFMT_MAXS];
+        if (k == 0) continue;
+        const int64_t out = colptr[o];
+        const long long col0 = ((long long)t * S * 64 + ql) * capc;          // slice s adds s*64*capc
+        auto src = [&](int e) -> long long {
+            int s = 0;
+#pragma unroll
+            for (int u = 1; u < MPFMT_MAXS; ++u) s += (e >= pre[u]) ? 1 : 0;
+            return col0 + (long long)s * 64 * capc + (e - pre[s]);
+        };
+        for (int e0 = 0; e0 < k; e0 += 128) {
+            const int ea = e0 + lane, eb = e0 + 64 + lane;
+            const long long pa = (ea < k) ? src(ea) : col0, pb = (eb < k) ? src(eb) : col0;
+            const int32_t ma = (ea < k) ? pool_j[pa] : 0x7fffffff;
+            const int32_t mb = (eb < k) ? pool_j[pb] : 0x7fffffff;
+            const double da = (ea < k) ? pool_d[pa] : 0.0;
+            const double db = (eb < k) ? pool_d[pb] : 0.0;
+            int32_t ra = 0, rb = 0;
+            // rank by counting; the compared index stream is wave-uniform (scalar loads from the S slot lists)
+#pragma unroll 1
+            for (int s = 0; s < S; ++s) {
+                const int n = pre[s + 1] - pre[s];
+                const int32_t* __restrict__ lst = pool_j + col0 + (long long)s * 64 * capc;
+                int j = 0;
+                for (; j + 8 <= n; j += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int32_t v = lst[j + u];
+                        ra += (v < ma) ? 1 : 0;
+                        rb += (v < mb) ? 1 : 0;
+                    }
+                }
+                for (; j < n; ++j) {
+                    const int32_t v = lst[j];
+                    ra += (v < ma) ? 1 : 0;
+                    rb += (v < mb) ? 1 : 0;
+                }
+            }
+            if (ea < k) { rowval[out + ra] = ma; nzval[out + ra] = da; }
+            if (eb < k) { rowval[out + rb] = mb; nzval[out + rb] = db; }
+        }
+    }
+}
+
+int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx)
+{
+    const int64_t pb = ctx->tile_begin * 64, pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
+    if (ctx->nnz == 0 || pe <= pb) return MPFMT_OK;
+    const unsigned nb = (unsigned)std::min<int64_t>(pe - pb, 1 << 20);
+    hipLaunchKernelGGL(k_sortcols_slots, dim3(nb), dim3(64), 0, ctx->stream, ctx->pool_j, ctx->pool_d, ctx->pool_cap, ctx->S,
+                       ctx->slice_cnt, ctx->ntiles * 64, ctx->tile_begin, pb, pe, ctx->colptr, ctx->perm, ctx->rowval, ctx->nzval);
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
+template <int MODE>
 int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
 {
     mf_args a;
@@ -463,13 +561,15 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.nitems = (ctx->tile_end - ctx->tile_begin) * ctx->S;
     a.npad = ctx->ntiles * 64; a.ntiles = ctx->ntiles;
     a.slice_cnt = ctx->slice_cnt; a.tptr = ctx->tptr; a.rowtmp = ctx->rowtmp; a.valtmp = ctx->valtmp;
-    a.pairs = FILL ? nullptr : ctx->d_pairs;
-    a.survivors = FILL ? nullptr : ctx->d_pairs + 1;
+    a.pairs = (MODE == 1) ? nullptr : ctx->d_pairs;
+    a.survivors = (MODE == 1) ? nullptr : ctx->d_pairs + 1;
+    a.pool_flag = ctx->pool_flag; a.pool_cap = ctx->pool_cap;
+    a.pool_j = ctx->pool_j; a.pool_d = ctx->pool_d;
     if (a.nitems <= 0) return MPFMT_OK;
     const int64_t gran = NXCD * (int64_t)std::max(1, a.xcd_mode);
     const unsigned nblk = (unsigned)(((a.nitems + gran - 1) / gran) * gran);
     const mpfmt_grid& G = ctx->grid;
-#define CASE(DD) case DD: hipLaunchKernelGGL((k_rdisc_mfma<DD, FILL>), dim3(nblk), dim3(64), 0, ctx->stream, a, G); break;
+#define CASE(DD) case DD: hipLaunchKernelGGL((k_rdisc_mfma<DD, MODE>), dim3(nblk), dim3(64), 0, ctx->stream, a, G); break;
     switch (ctx->d) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
         default: return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path supports d <= 12 (got %d)", ctx->d);
@@ -479,5 +579,6 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     return MPFMT_OK;
 }
 
-template int32_t mpfmt_launch_rdisc_mfma<false>(mpfmt_ctx*, double, float);
-template int32_t mpfmt_launch_rdisc_mfma<true>(mpfmt_ctx*, double, float);
+template int32_t mpfmt_launch_rdisc_mfma<0>(mpfmt_ctx*, double, float);
+template int32_t mpfmt_launch_rdisc_mfma<1>(mpfmt_ctx*, double, float);
+template int32_t mpfmt_launch_rdisc_mfma<2>(mpfmt_ctx*, double, float);

@@ -137,7 +137,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
-                    ctx->tvaltmp, ctx->tval, ctx->di_nseg};
+                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->pool_flag, ctx->pool_j, ctx->pool_d};
     for (void* b : bufs) if (b) hipFree(b);
     auto it = g_timers.find(ctx);
     if (it != g_timers.end()) {
@@ -914,6 +914,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
         ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
         return MPFMT_OK;
     }
+    if (strcmp(name, "rdisc_pool") == 0) { ctx->use_pool = value != 0; return MPFMT_OK; }
     if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }
     if (strcmp(name, "mf_target_items") == 0) { ctx->mf_target_items = value; return MPFMT_OK; }
     if (strcmp(name, "timing") == 0) { ctx->timing_enabled = value != 0; return MPFMT_OK; }
@@ -924,6 +925,7 @@ int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value)
 {
     if (!ctx || !name || !value) return MPFMT_ERR_ARG;
     if (strcmp(name, "rdisc_path_used") == 0) { *value = ctx->rdisc_path_used; return MPFMT_OK; }
+    if (strcmp(name, "pool_used") == 0) { *value = ctx->pool_valid ? 1 : 0; return MPFMT_OK; }
     if (strcmp(name, "survivors") == 0) { *value = ctx->survivors; return MPFMT_OK; }
     if (strcmp(name, "pairs_tested") == 0) { *value = ctx->pairs_tested; return MPFMT_OK; }
     if (strcmp(name, "nnz") == 0) { *value = ctx->nnz; return MPFMT_OK; }

@@ -86,6 +86,14 @@ struct mpfmt_ctx {
     int32_t mf_xcd_mode = 512;
     int64_t mf_target_items = 70000;     // work items (tile x slice) the MFMA path aims for
     float mf_negT = 0.f;
+    // single-pass hit pool (MFMA path): hits found by the count pass are kept, so the fill pass is a scatter
+    int32_t use_pool = 1;                // option "rdisc_pool"
+    int32_t* pool_flag = nullptr;        // overflow flag
+    int64_t pool_cap = 0;                // capacity of one (item, column) slot list
+    int32_t* pool_j = nullptr;
+    double* pool_d = nullptr;
+    bool pool_valid = false;             // pool holds exactly the nnz hits of the counted graph
+    int64_t pool_hint_N = -1; double pool_hint_r = -1.0; int64_t pool_hint_nnz = 0;   // capacity hint from the last build
     int64_t survivors = 0;
     int64_t* colptr = nullptr;           // [N+1] 0-based offsets by original index
     int64_t nnz = 0;
@@ -144,7 +152,8 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usable);
 int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx);
 int32_t mpfmt_build_sorted_aos(mpfmt_ctx* ctx);
-template <bool FILL> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT);
+template <int MODE> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT);
+int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);
 

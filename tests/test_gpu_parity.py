@@ -147,6 +147,25 @@ def test_rdisc_clustered_and_duplicates(ctx, orc):
         check_costs(nzval, oval)
 
 
+def test_rdisc_pool_overflow_falls_back(orc):
+    """A dense cluster defeats the pool's capacity estimate: the build must notice the overflow and run the fill pass."""
+    rng = np.random.default_rng(81)
+    X = np.concatenate([0.5 + 0.004 * rng.standard_normal((3000, 3)), rng.random((500, 3))])
+    c = mp.Context(0)
+    c.upload_samples(X)
+    used = []
+    for _ in range(2):                                    # second build has the capacity hint of the first
+        colptr, rowval, nzval = c.rdisc_graph(0.2)
+        used.append(c.stat("pool_used"))
+    c.set_option("rdisc_pool", 0)
+    c2, r2, n2 = c.rdisc_graph(0.2)
+    assert np.array_equal(colptr, c2) and np.array_equal(rowval, r2) and np.array_equal(nzval, n2)
+    oc, orow, oval = orc.rdisc_graph(X, 0.2)
+    assert np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow) and np.array_equal(nzval, oval)
+    assert used == [0, 1]
+    c.close()
+
+
 @pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 129])
 def test_rdisc_tiny_and_ragged(ctx, orc, N):
     rng = np.random.default_rng(N)
@@ -347,6 +366,7 @@ def test_cfg2_full_size_properties(ctx, orc):
     ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
     colptr, rowval, nzval = ctx.rdisc_graph(w.r)
     assert ctx.stat("rdisc_path_used") == 2               # the shipped (auto) path is the MFMA filter
+    assert ctx.stat("pool_used") == 1                     # ... in its single-pass form (hits pooled by the count pass)
     c0, r0 = to0(colptr, rowval)
     nnz = len(rowval)
     assert c0[0] == 0 and c0[-1] == nnz and nnz % 2 == 0
