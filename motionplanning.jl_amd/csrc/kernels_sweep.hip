@@ -239,7 +239,13 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_edges_free(const double* __re
 // ---- graph sweep ---------------------------------------------------------------------------------
 // One wavefront per CSC column x (persistent workgroups, boxes staged once): entry e with row y gets
 // bit e = in_state_space(V[y]) && is_free_motion(V[y], V[x]).  All rows lie within rpad of V[x], so the
-// cull box is V[x] +- rpad.  Mask words are shared between adjacent columns -> atomicOr into a zeroed mask.
+// cull box is V[x] +- rpad (~2.5 % of the boxes survive at the north-star workload).
+//   - the cull reads a transposed (SoA) copy of the boxes: lane k reads box k's i-th bound at [i][k], conflict free;
+//   - rounds of 64 consecutive entries start at the column's first entry (no idle lanes in front); the 64 result
+//     bits are shifted into the two mask words they straddle (atomicOr, the mask is zeroed before the launch);
+//   - the narrow phase is deferred: each lane remembers the (at most two) boxes whose broad phase it failed and
+//     the exact slab test runs once per round for all lanes together, instead of once per surviving box with
+//     a handful of live lanes.
 template <int D>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
                                                                const int32_t* __restrict__ rowval, int64_t N, double rpad,
@@ -247,9 +253,9 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __r
                                                                mpfmt_ss ss, unsigned long long* __restrict__ mask)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sbox = (double*)smem;
+    double* sbox = (double*)smem;                          // [box][lo(D), hi(D)]  broadcast reads
+    double* sboxT = sbox + (int64_t)chunk * 2 * D;         // [2*D][chunk]         cull reads (lane = box)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned long long smask[SWEEP_WORDS];
     const int64_t nwaves = (int64_t)gridDim.x * (SWEEP_THREADS / 64);
     const int64_t wid = (int64_t)blockIdx.x * (SWEEP_THREADS / 64) + wave;
 
@@ -257,6 +263,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __r
         const int nb = max(0, min(chunk, M - b0));
         __syncthreads();
         stage_boxes<D>(sbox, boxes, b0, nb);
+        for (int t = threadIdx.x; t < nb * 2 * D; t += blockDim.x) {
+            const int k = t / (2 * D), i = t - k * 2 * D;
+            sboxT[(int64_t)i * chunk + k] = boxes[(int64_t)b0 * 2 * D + t];
+        }
         __syncthreads();
         for (int64_t x = wid; x < N; x += nwaves) {
             const int64_t beg = colptr[x], end = colptr[x + 1];
@@ -264,24 +274,63 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __r
             double w[D], ulo[D], uhi[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) { w[i] = X[x * D + i]; ulo[i] = w[i] - rpad; uhi[i] = w[i] + rpad; }
-            cull_boxes<D>(sbox, nb, ulo, uhi, smask, lane);
-            for (int64_t wd = beg >> 6; wd <= ((end - 1) >> 6); ++wd) {
-                const int64_t e = wd * 64 + lane;
-                const bool active = (e >= beg) && (e < end);
+            unsigned long long smask[SWEEP_WORDS];
+#pragma unroll
+            for (int c = 0; c < SWEEP_WORDS; ++c) {
+                const int k = c * 64 + lane;
+                bool keep = k < nb;
+                if (keep) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+                        keep = keep && !((sboxT[(int64_t)(D + i) * chunk + k] < ulo[i]) || (sboxT[(int64_t)i * chunk + k] > uhi[i]));
+                }
+                smask[c] = __ballot(keep);
+            }
+            for (int64_t e0 = beg; e0 < end; e0 += 64) {
+                const int64_t e = e0 + lane;
+                const bool active = e < end;
                 double v[D];
                 const int64_t y = active ? rowval[e] : x;
 #pragma unroll
                 for (int i = 0; i < D; ++i) v[i] = X[y * D + i];
                 // first chunk decides in_state_space; later chunks can only clear bits
                 bool fr = active && (b0 > 0 || in_state_space<D>(v, ss));
-                fr = sweep_segment<D>(sbox, smask, v, w, fr);
-                unsigned long long bits = __ballot(fr);
+                double l[D], h[D];
+                seg_bbox<D>(v, w, l, h);
+                int p0 = -1, p1 = -1;                    // boxes whose broad phase this lane failed
+#pragma unroll
+                for (int c = 0; c < SWEEP_WORDS; ++c) {
+                    unsigned long long m = smask[c];
+                    while (m) {
+                        const int k = c * 64 + (__ffsll((long long)m) - 1);
+                        m &= m - 1;
+                        const double* lo = sbox + (int64_t)k * 2 * D;
+                        if (fr && !broadphase_free<D>(l, h, lo, lo + D)) {
+                            if (p0 < 0) p0 = k;
+                            else if (p1 < 0) p1 = k;
+                            else fr = narrow_free<D>(v, w, lo, lo + D);      // third pending box: rare, test in place
+                        }
+                    }
+                }
+                if (__ballot(fr && p0 >= 0)) {
+                    if (fr && p0 >= 0) { const double* lo = sbox + (int64_t)p0 * 2 * D; fr = narrow_free<D>(v, w, lo, lo + D); }
+                    if (__ballot(fr && p1 >= 0)) {
+                        if (fr && p1 >= 0) { const double* lo = sbox + (int64_t)p1 * 2 * D; fr = narrow_free<D>(v, w, lo, lo + D); }
+                    }
+                }
+                const unsigned long long bits = __ballot(fr);
+                const int sh = (int)(e0 & 63);
+                const int64_t wd = e0 >> 6;
                 if (b0 > 0) {
                     // multi-chunk obstacle sets: AND with what earlier chunks left
-                    const unsigned long long act = __ballot(active);
-                    if (lane == 0) atomicAnd(&mask[wd], bits | ~act);
+                    const unsigned long long keepm = bits | ~__ballot(active);
+                    if (lane == 0) {
+                        atomicAnd(&mask[wd], (keepm << sh) | ((1ull << sh) - 1ull));
+                        if (sh && ((end - 1) >> 6) > wd) atomicAnd(&mask[wd + 1], (keepm >> (64 - sh)) | ~((1ull << sh) - 1ull));
+                    }
                 } else if (lane == 0 && bits) {
-                    atomicOr(&mask[wd], bits);
+                    atomicOr(&mask[wd], bits << sh);
+                    if (sh && (bits >> (64 - sh))) atomicOr(&mask[wd + 1], bits >> (64 - sh));
                 }
             }
         }
@@ -403,7 +452,7 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
         const int d = ctx->d;
         const int waves = SWEEP_THREADS / 64;
         const int chunk = box_chunk(ctx->M, d, true);
-        const size_t lds = sweep_lds(chunk, d);
+        const size_t lds = 2 * sweep_lds(chunk, d);              // AoS copy + transposed (SoA) copy of the staged boxes
         const double rpad = ctx->graph_r * (1.0 + 1e-9) + 1e-300;
         // persistent workgroups: boxes are staged once per workgroup, columns are grid-strided
         const unsigned nb = (unsigned)std::min<int64_t>((ctx->N + waves - 1) / waves, 256 * 8);
