@@ -25,6 +25,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # fp64 vector == fp64 matrix (MFMA) dense peak, FMA = 2 flop
+FP16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 PFLOP/s
+# HBM bytes per launch measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, profiles/*pmc*):
+# (FETCH_SIZE*2 + WRITE_SIZE) KiB -> bytes.  Keyed by (workload, n_gpus[, kernel]).
+PROFILED_TRAFFIC_BYTES = {}
 
 
 def cpu_baseline(w, mp, seconds=12.0):
@@ -136,15 +140,23 @@ def main():
     stats = ctx.graph_stats()
     path_used = ctx.stat("rdisc_path_used")
     survivors = ctx.stat("survivors")
-    tm = {k: ctx.timing(k) for k in ("grid", "rdisc_count", "rdisc_finalize", "rdisc_fill", "rdisc_sort", "sweep_graph")}
+    single_pass = ctx.stat("pool_used") == 1
+    tm = {k: ctx.timing(k) for k in ("grid", "rdisc_count", "rdisc_fill", "rdisc_sort", "sweep_graph")}
     d = w.d
-    # dominant kernel: the r-disc pair sweep (count pass and fill pass run the same pair tests)
+    # dominant kernel: the r-disc pair sweep k_rdisc_mfma (single pass) -- or count + fill in the two-pass forms
     pair_ms = tm["rdisc_count"][0] + tm["rdisc_fill"][0]
-    pairs_per_launch = stats["pairs_tested"]
-    ach_tflops = (2.0 * pairs_per_launch * 2 * d) / (pair_ms * 1e-3) / 1e12 if pair_ms > 0 else 0.0
+    passes = 1 if single_pass else 2
+    pairs_per_pass = stats["pairs_tested"]
+    # algorithmic flops: 2*d per tested pair; MFMA flops actually issued: K = 16 slots -> 32 per pair
+    ach_tflops = (passes * pairs_per_pass * 2.0 * d) / (pair_ms * 1e-3) / 1e12 if pair_ms > 0 else 0.0
+    mfma_tflops = (passes * pairs_per_pass * 32.0) / (pair_ms * 1e-3) / 1e12 if pair_ms > 0 and path_used == 2 else 0.0
+    peak = FP16_MFMA_PEAK_TFLOPS if path_used == 2 else FP64_PEAK_TFLOPS
     sweep_ms = tm["sweep_graph"][0]
     sweep_bytes = nnz * (2 * d * 8 + 8 + 1.0 / 8.0)
     sweep_gbs = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    # measured HBM traffic per launch of the dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
+    # tools/pmc_summary.py; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) -- filled in from profiles/
+    traffic = PROFILED_TRAFFIC_BYTES.get((w.name, world))
 
     out = {
         "metric": "edges checked/sec + r-disc queries/sec, FMT* N=1e6 R^6, 1/2/4/8 MI355X",
@@ -168,25 +180,29 @@ def main():
             "rdisc_queries_per_s_graph_kernels": ((stats["tiles"] * 64) / ((pair_ms + tm["rdisc_sort"][0] + tm["grid"][0]) * 1e-3))
             if pair_ms > 0 else None,
             "kernel_ms": {k: v[0] for k, v in tm.items()},
-            "pairs_tested_per_pass": pairs_per_launch,
+            "pairs_tested_per_pass": pairs_per_pass,
+            "pair_passes": passes,
             "rdisc_pair_kernel": "fp16 MFMA filter + exact fp64 refine" if path_used == 2 else "exact fp64 VALU",
             "filter_survivors_per_pass": survivors,
             "grid_cells": stats["cells"], "tiles": stats["tiles"], "slices": stats["slices"],
         },
         "roofline": {
-            "kernel": "k_rdisc (count pass + fill pass, identical pair tests)",
-            "bound": "mfma", "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach_tflops / FP64_PEAK_TFLOPS,
-            "traffic": None,
-            "note": "algorithmic flops = pairs_tested x 2d (Gram-form count, SURVEY 8d) over the count+fill passes; "
-                    "priced against the fp64 peak (78.6 TFLOP/s) because the result is the exact fp64 graph, although the "
-                    "distance-matrix block itself runs as an fp16 v_mfma_f32_32x32x16_f16 filter (dense fp16 peak 2.5 PFLOP/s; "
-                    "K=16 slots per pair = 32 MFMA flop) with an exact fp64 VALU refine of the survivors",
+            "kernel": "k_rdisc_mfma<6,2> (single pass: fp16 MFMA distance-matrix filter + exact fp64 refine + slot emit)"
+            if single_pass else "k_rdisc (count + fill passes)",
+            "bound": "mfma", "achieved": ach_tflops, "peak": peak, "unit": "TFLOP/s",
+            "frac": ach_tflops / peak,
+            "traffic": traffic,
+            "mfma_flops_issued_tflops": mfma_tflops,
+            "frac_of_fp64_peak": ach_tflops / FP64_PEAK_TFLOPS,
+            "note": "achieved = pairs_tested x 2d algorithmic flop (SURVEY 8d) / kernel time; peak = dense fp16 MFMA "
+                    "(the filter runs v_mfma_f32_32x32x16_f16, 32 flop per pair with the norm slots); the kernel is "
+                    "VALU-issue bound on sign-bit extraction (16 v_alignbit per MFMA), not MFMA bound; the result is the "
+                    "exact fp64 graph, so frac_of_fp64_peak compares with what an fp64 Gram kernel could reach",
         },
         "roofline_sweep": {
             "kernel": "k_graph_sweep", "bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": None,
-            "note": "algorithmic bytes = (2*d*8 + 8 + 1/8) per edge = %.3f B" % (2 * d * 8 + 8 + 0.125),
+            "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": PROFILED_TRAFFIC_BYTES.get((w.name, world, "sweep")),
+            "note": "algorithmic bytes = (2*d*8 + 8 + 1/8) per edge = %.3f B; instruction-issue bound in practice" % (2 * d * 8 + 8 + 0.125),
         },
     }
     if rank == 0:
