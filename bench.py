@@ -101,6 +101,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_shard(rank, world)
+    ctx.set_option("rebuild_index", 1)           # every step rebuilds the cell grid + MFMA operands (the index build)
     ctx.upload_samples(w.X)                       # inputs resident in HBM before the timed region
     ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
 

@@ -493,7 +493,7 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
     bool pool = mf && ctx->use_pool && nt > 0;
     if (pool) {
         double want;
-        if (ctx->pool_hint_N == N && ctx->pool_hint_r == r && ctx->rank == 0 && ctx->world == 1) {
+        if (ctx->pool_hint_N == N && ctx->pool_hint_r == r && ctx->pool_hint_rank == ctx->rank && ctx->pool_hint_world == ctx->world) {
             want = (double)ctx->pool_hint_nnz * 1.02 + 4096.0;
         } else {
             const int d = ctx->d;
@@ -546,6 +546,7 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->pool_valid = pool && pool_over == 0;
     ctx->pool_hint_N = N; ctx->pool_hint_r = r; ctx->pool_hint_nnz = nnz;
+    ctx->pool_hint_rank = ctx->rank; ctx->pool_hint_world = ctx->world;
     ctx->nnz = nnz;
     ctx->pairs_tested = (int64_t)pairs[0];
     ctx->survivors = (int64_t)pairs[1];

@@ -48,38 +48,68 @@ int32_t mpfmt_ensure(mpfmt_ctx* ctx, void** p, size_t bytes)
     return MPFMT_OK;
 }
 
-// ---- timing: HIP events on the launch stream, small stack so groups may nest ------------------------
+// ---- timing: HIP events on the launch stream.  Begin/end only RECORD events (no host sync in the hot path);
+//      pending intervals are resolved when a timing is queried.  A small stack lets groups nest.
 #define TIMER_DEPTH 4
-struct timer_stack { hipEvent_t a[TIMER_DEPTH], b[TIMER_DEPTH]; int depth; bool init; };
-static std::map<mpfmt_ctx*, timer_stack> g_timers;
+struct timer_rec { std::string name; hipEvent_t a, b; };
+struct timer_state {
+    std::vector<hipEvent_t> free_events;
+    std::vector<timer_rec> pending;
+    hipEvent_t open_a[TIMER_DEPTH];
+    int depth = 0;
+};
+static std::map<mpfmt_ctx*, timer_state> g_timers;
+
+static hipEvent_t timer_event(timer_state& t)
+{
+    if (!t.free_events.empty()) { hipEvent_t e = t.free_events.back(); t.free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+static void timer_resolve(mpfmt_ctx* ctx)
+{
+    auto it = g_timers.find(ctx);
+    if (it == g_timers.end()) return;
+    timer_state& t = it->second;
+    for (timer_rec& r : t.pending) {
+        hipEventSynchronize(r.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            mpfmt_timer& tm = ctx->timers[r.name];
+            tm.total_ms += ms;
+            tm.launches += 1;
+        }
+        t.free_events.push_back(r.a);
+        t.free_events.push_back(r.b);
+    }
+    t.pending.clear();
+}
 
 void mpfmt_time_begin(mpfmt_ctx* ctx)
 {
     if (!ctx->timing_enabled) return;
-    timer_stack& t = g_timers[ctx];
-    if (!t.init) {
-        for (int i = 0; i < TIMER_DEPTH; ++i) { hipEventCreate(&t.a[i]); hipEventCreate(&t.b[i]); }
-        t.depth = 0; t.init = true;
+    timer_state& t = g_timers[ctx];
+    if (t.depth < TIMER_DEPTH) {
+        t.open_a[t.depth] = timer_event(t);
+        hipEventRecord(t.open_a[t.depth], ctx->stream);
     }
-    if (t.depth < TIMER_DEPTH) hipEventRecord(t.a[t.depth], ctx->stream);
     ++t.depth;
 }
 
 void mpfmt_time_end(mpfmt_ctx* ctx, const char* name)
 {
     if (!ctx->timing_enabled) return;
-    timer_stack& t = g_timers[ctx];
-    if (!t.init || t.depth <= 0) return;
+    timer_state& t = g_timers[ctx];
+    if (t.depth <= 0) return;
     --t.depth;
     if (t.depth >= TIMER_DEPTH) return;
-    hipEventRecord(t.b[t.depth], ctx->stream);
-    hipEventSynchronize(t.b[t.depth]);
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, t.a[t.depth], t.b[t.depth]) == hipSuccess) {
-        mpfmt_timer& tm = ctx->timers[name];
-        tm.total_ms += ms;
-        tm.launches += 1;
-    }
+    timer_rec r;
+    r.name = name; r.a = t.open_a[t.depth]; r.b = timer_event(t);
+    hipEventRecord(r.b, ctx->stream);
+    t.pending.push_back(r);
+    if (t.pending.size() > 4096) timer_resolve(ctx);
 }
 
 // ---- small conversion kernels --------------------------------------------------------------------------
@@ -139,9 +169,10 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
                     ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->pool_flag, ctx->pool_j, ctx->pool_d};
     for (void* b : bufs) if (b) hipFree(b);
+    timer_resolve(ctx);
     auto it = g_timers.find(ctx);
     if (it != g_timers.end()) {
-        if (it->second.init) for (int i = 0; i < TIMER_DEPTH; ++i) { hipEventDestroy(it->second.a[i]); hipEventDestroy(it->second.b[i]); }
+        for (hipEvent_t e : it->second.free_events) hipEventDestroy(e);
         g_timers.erase(it);
     }
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -228,6 +259,7 @@ int32_t mpfmt_graph_build_device(mpfmt_ctx* ctx, double r, int64_t* nnz)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int32_t rc;
     ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
+    if (ctx->rebuild_index) { ctx->grid_r = -1.0; ctx->ops_r = -1.0; }    // index build (cell grid + operands) is part of the build
     if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
     if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
     if (nnz) *nnz = ctx->nnz;
@@ -890,6 +922,7 @@ int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx,
 int32_t mpfmt_timing_reset(mpfmt_ctx* ctx)
 {
     if (!ctx) return MPFMT_ERR_ARG;
+    timer_resolve(ctx);
     ctx->timers.clear();
     return MPFMT_OK;
 }
@@ -897,6 +930,7 @@ int32_t mpfmt_timing_reset(mpfmt_ctx* ctx)
 int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64_t* launches)
 {
     if (!ctx || !name) return MPFMT_ERR_ARG;
+    timer_resolve(ctx);
     auto it = ctx->timers.find(name);
     double a = 0.0; int64_t n = 0;
     if (it != ctx->timers.end() && it->second.launches > 0) { n = it->second.launches; a = it->second.total_ms / (double)n; }
@@ -914,6 +948,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
         ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
         return MPFMT_OK;
     }
+    if (strcmp(name, "rebuild_index") == 0) { ctx->rebuild_index = value != 0; return MPFMT_OK; }
     if (strcmp(name, "rdisc_pool") == 0) { ctx->use_pool = value != 0; return MPFMT_OK; }
     if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }
     if (strcmp(name, "mf_target_items") == 0) { ctx->mf_target_items = value; return MPFMT_OK; }

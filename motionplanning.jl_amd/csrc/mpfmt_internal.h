@@ -93,7 +93,7 @@ struct mpfmt_ctx {
     int32_t* pool_j = nullptr;
     double* pool_d = nullptr;
     bool pool_valid = false;             // pool holds exactly the nnz hits of the counted graph
-    int64_t pool_hint_N = -1; double pool_hint_r = -1.0; int64_t pool_hint_nnz = 0;   // capacity hint from the last build
+    int64_t pool_hint_N = -1; double pool_hint_r = -1.0; int64_t pool_hint_nnz = 0; int pool_hint_rank = -1, pool_hint_world = -1;   // capacity hint from the last build
     int64_t survivors = 0;
     int64_t* colptr = nullptr;           // [N+1] 0-based offsets by original index
     int64_t nnz = 0;
@@ -125,8 +125,8 @@ struct mpfmt_ctx {
     size_t scratch_bytes = 0;
     std::map<void*, size_t> caps;       // capacity (bytes) of each grow-only device buffer, keyed by member address
     std::map<std::string, mpfmt_timer> timers;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_enabled = true;
+    bool rebuild_index = false;          // option "rebuild_index": graph_build_device rebuilds the cell grid every call
 };
 
 // error helpers ---------------------------------------------------------------------------------
