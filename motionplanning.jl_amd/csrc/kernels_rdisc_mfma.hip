@@ -476,63 +476,83 @@ int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
 // Column ordering for the single-pass build: one wavefront per sorted position.  The column's hits sit in S slot
 // lists (one per candidate slice, counts in slice_cnt); they are gathered, ranked by counting through LDS and
 // written to the final CSC column -- contiguous stores, no staging CSC.
+#define SLOT_LDS 1024
 __global__ __launch_bounds__(64) void k_sortcols_slots(const int32_t* __restrict__ pool_j, const double* __restrict__ pool_d,
                                                        int64_t capc, int S, const int32_t* __restrict__ slice_cnt, int64_t npad,
                                                        int64_t tile_begin, int64_t pos_begin, int64_t pos_end,
                                                        const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm,
                                                        int32_t* __restrict__ rowval, double* __restrict__ nzval)
 {
+    __shared__ __attribute__((aligned(16))) int32_t s_o[SLOT_LDS + 4];
     const int lane = threadIdx.x;
     for (int64_t sp = pos_begin + blockIdx.x; sp < pos_end; sp += gridDim.x) {
         const int32_t o = perm[sp];
         if (o < 0) continue;
         const int64_t t = (sp >> 6) - tile_begin;
         const int ql = (int)(sp & 63);
-        // prefix of the per-slice counts (S <= 16): entry e of the column lives in slice s at position e - pre[s]
-        int pre[MPFMT_MAXS + 1];
-        pre[0] = 0;
-#pragma unroll
-        for (int s = 0; s < MPFMT_MAXS; ++s) pre[s + 1] = pre[s] + ((s < S) ? slice_cnt[(int64_t)s * npad + sp] : 0);
-        const int k = pre[MPFMT_MAXS];
+        const long long col0 = ((long long)t * S * 64 + ql) * capc;          // slice s adds s*64*capc
+        const long long sstride = 64 * capc;
+        // the column's hits sit in S slot lists; entry e of the concatenation lives in slice s at e - pre_s
+        int k = 0;
+        for (int s = 0; s < S; ++s) k += slice_cnt[(int64_t)s * npad + sp];
         if (k == 0) continue;
         const int64_t out = colptr[o];
-        const long long col0 = ((long long)t * S * 64 + ql) * capc;          // slice s adds s*64*capc
         auto src = [&](int e) -> long long {
-            int s = 0;
-#pragma unroll
-            for (int u = 1; u < MPFMT_MAXS; ++u) s += (e >= pre[u]) ? 1 : 0;
-            return col0 + (long long)s * 64 * capc + (e - pre[s]);
-        };
-        for (int e0 = 0; e0 < k; e0 += 128) {
-            const int ea = e0 + lane, eb = e0 + 64 + lane;
-            const long long pa = (ea < k) ? src(ea) : col0, pb = (eb < k) ? src(eb) : col0;
-            const int32_t ma = (ea < k) ? pool_j[pa] : 0x7fffffff;
-            const int32_t mb = (eb < k) ? pool_j[pb] : 0x7fffffff;
-            const double da = (ea < k) ? pool_d[pa] : 0.0;
-            const double db = (eb < k) ? pool_d[pb] : 0.0;
-            int32_t ra = 0, rb = 0;
-            // rank by counting; the compared index stream is wave-uniform (scalar loads from the S slot lists)
-#pragma unroll 1
+            long long p = col0;
+            int rem = e;
             for (int s = 0; s < S; ++s) {
-                const int n = pre[s + 1] - pre[s];
-                const int32_t* __restrict__ lst = pool_j + col0 + (long long)s * 64 * capc;
-                int j = 0;
-                for (; j + 8 <= n; j += 8) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int32_t v = lst[j + u];
-                        ra += (v < ma) ? 1 : 0;
-                        rb += (v < mb) ? 1 : 0;
-                    }
-                }
-                for (; j < n; ++j) {
-                    const int32_t v = lst[j];
-                    ra += (v < ma) ? 1 : 0;
-                    rb += (v < mb) ? 1 : 0;
-                }
+                const int n = slice_cnt[(int64_t)s * npad + sp];
+                if (rem < n) break;
+                rem -= n; p += sstride;
             }
-            if (ea < k) { rowval[out + ra] = ma; nzval[out + ra] = da; }
-            if (eb < k) { rowval[out + rb] = mb; nzval[out + rb] = db; }
+            return p + rem;
+        };
+        __syncthreads();
+        if (k <= SLOT_LDS) {
+            for (int e0 = 0; e0 < k; e0 += 128) {
+                // gather (two entries per lane per round), publish the indices to LDS for the rank loop
+                const int ea = e0 + lane, eb = e0 + 64 + lane;
+                const long long pa = (ea < k) ? src(ea) : col0, pb = (eb < k) ? src(eb) : col0;
+                const int32_t ma = (ea < k) ? pool_j[pa] : 0x7fffffff;
+                const int32_t mb = (eb < k) ? pool_j[pb] : 0x7fffffff;
+                if (ea < k) s_o[ea] = ma;
+                if (eb < k) s_o[eb] = mb;
+            }
+            if (lane < 4) s_o[k + lane] = 0x7fffffff;        // pad so the rank loop can run in fours
+            __syncthreads();
+            for (int e0 = 0; e0 < k; e0 += 128) {
+                const int ea = e0 + lane, eb = e0 + 64 + lane;
+                const int32_t ma = (ea < k) ? s_o[ea] : 0x7fffffff;
+                const int32_t mb = (eb < k) ? s_o[eb] : 0x7fffffff;
+                const double da = (ea < k) ? pool_d[src(ea)] : 0.0;           // in flight during the rank loop
+                const double db = (eb < k) ? pool_d[src(eb)] : 0.0;
+                int32_t ra = 0, rb = 0;
+                for (int j = 0; j < k; j += 4) {
+                    const int4 v = *reinterpret_cast<const int4*>(&s_o[j]);   // wave-uniform ds_read_b128 (broadcast)
+                    ra += (v.x < ma) ? 1 : 0; rb += (v.x < mb) ? 1 : 0;
+                    ra += (v.y < ma) ? 1 : 0; rb += (v.y < mb) ? 1 : 0;
+                    ra += (v.z < ma) ? 1 : 0; rb += (v.z < mb) ? 1 : 0;
+                    ra += (v.w < ma) ? 1 : 0; rb += (v.w < mb) ? 1 : 0;
+                }
+                if (ea < k) { rowval[out + ra] = ma; nzval[out + ra] = da; }
+                if (eb < k) { rowval[out + rb] = mb; nzval[out + rb] = db; }
+            }
+        } else {
+            // very long columns: stream the concatenated lists through LDS in windows
+            for (int e0 = 0; e0 < k; e0 += 64) {
+                const int e = e0 + lane;
+                const long long pe = (e < k) ? src(e) : col0;
+                const int32_t mine = (e < k) ? pool_j[pe] : 0x7fffffff;
+                int64_t rank = 0;
+                for (int c0 = 0; c0 < k; c0 += SLOT_LDS) {
+                    const int cn = min(SLOT_LDS, k - c0);
+                    __syncthreads();
+                    for (int j = lane; j < cn; j += 64) s_o[j] = pool_j[src(c0 + j)];
+                    __syncthreads();
+                    for (int j = 0; j < cn; ++j) rank += (s_o[j] < mine) ? 1 : 0;
+                }
+                if (e < k) { rowval[out + rank] = mine; nzval[out + rank] = pool_d[pe]; }
+            }
         }
     }
 }
