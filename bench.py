@@ -28,7 +28,12 @@ FP64_PEAK_TFLOPS = 78.6        # fp64 vector == fp64 matrix (MFMA) dense peak, F
 FP16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 PFLOP/s
 # HBM bytes per launch measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, profiles/*pmc*):
 # (FETCH_SIZE*2 + WRITE_SIZE) KiB -> bytes.  Keyed by (workload, n_gpus[, kernel]).
-PROFILED_TRAFFIC_BYTES = {}
+PROFILED_TRAFFIC_BYTES = {
+    # profiles/r01_pmc_v2_rdisc.txt: FETCH_SIZE 5571876 KiB (x2, gfx950 half-count), WRITE_SIZE 3174048 KiB per launch
+    ("ns_r6_n1m_m200", 1): (5571876.3 * 2 + 3174048.1) * 1024,
+    # profiles/r01_pmc_v2_sweep.txt: FETCH_SIZE 8114987 KiB (x2), WRITE_SIZE 115841 KiB per launch
+    ("ns_r6_n1m_m200", 1, "sweep"): (8114986.5 * 2 + 115840.5) * 1024,
+}
 
 
 def cpu_baseline(w, mp, seconds=12.0):

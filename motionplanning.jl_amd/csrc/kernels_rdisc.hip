@@ -506,7 +506,7 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
         // every (tile, slice, column) owns a fixed-capacity slot list; per-list counts vary, so lists get 4x the
         // mean plus a fixed slack -- an overflow falls back to the fill pass
         const int64_t items = nt * S;
-        const int64_t capc = (int64_t)(want / ((double)items * 64.0) * 4.0) + 32;
+        const int64_t capc = (int64_t)(want / ((double)items * 64.0) * 4.0) + 64;
         if ((double)capc * (double)items * 64.0 * 12.0 > 96e9) pool = false;      // cap the slot lists at 96 GB of the 288
         else {
             const size_t cap = (size_t)capc * (size_t)items * 64;

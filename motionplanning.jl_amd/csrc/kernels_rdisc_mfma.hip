@@ -19,11 +19,10 @@
 //   refine : when 64 survivors are queued, lane = survivor: exact canonical fp64 d2 from the fp64
 //            coordinates, membership test, count or emit (row index, sqrt(d2)).  All 64 lanes busy.
 //
-// Work mapping: workgroup = 4 wavefronts = 256 consecutive cell-sorted queries (wavefront = one 64-sample
-// tile, its two 32-row A fragments stay in VGPRs for the whole kernel); candidate chunks (64 samples, 2 KB
-// of operands) are staged once per workgroup in LDS, double buffered, one barrier per chunk, the next
-// chunk's global loads in flight during the MFMAs.  Chunks farther than r from a wavefront's tight tile
-// box are skipped per wavefront (tight box vs tight box).
+// Work mapping: one independent wavefront per (64-query tile, slice of its candidate chunks), no workgroup barriers;
+// the tile's two 32-row A fragments stay in VGPRs; B fragments are 1 KB coalesced loads from the operand array,
+// prefetched two chunks ahead; chunks farther than r from the tile's tight box are pruned by a lane-parallel prologue.
+// MODE 2 (single pass) also writes every exact hit into the fixed-capacity slot list of its (tile, slice, column).
 #include "mpfmt_internal.h"
 #include <algorithm>
 #include <cmath>
