@@ -456,3 +456,49 @@ def test_di_fmtstar_matches_oracle(ctx, orc):
     ref = orc.di_fmtstar(X, 1.0, 1.0, oc, orow, oval, orc.GOAL_BALL, [0.9, 0.9, 0.1], lohi, ss_lo, ss_hi)
     assert res["status"] == ref["status"] and np.array_equal(res["A"] - 1, ref["A"])
     assert res["collision_checks"] == ref["collision_checks"]
+
+
+# ---- full size: the configuration BASELINE.json's metric is quoted on (R^6, N=1e6, M=200) -----------------
+
+def test_north_star_full_size_properties(orc):
+    """Size-independent properties at N=1e6 (the oracle cannot brute-force this size): column contract, symmetry of
+    the metric graph (checksum of the (i,j) and (j,i) key multisets), sampled columns against the oracle's KD-tree,
+    sampled edge bits and the whole point mask against the oracle."""
+    w = mp.workloads.north_star()
+    N = w.N
+    ctx = mp.Context(0)
+    ctx.upload_samples(w.X)
+    ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+    colptr, rowval, nzval = ctx.rdisc_graph(w.r)
+    assert ctx.stat("rdisc_path_used") == 2
+    nnz = len(rowval)
+    deg = np.diff(colptr)
+    assert colptr[0] == 1 and colptr[-1] == nnz + 1 and nnz % 2 == 0 and deg.min() >= 0
+    cols = np.repeat(np.arange(1, N + 1, dtype=np.int64), deg)
+    assert not np.any(rowval == cols)                                            # self excluded
+    d = np.diff(rowval)
+    same = cols[1:] == cols[:-1]
+    assert np.all(d[same] > 0)                                                   # ascending inside every column
+    del d, same
+    assert nzval.max() <= w.r * (1 + 1e-12) and nzval.min() > 0
+    # symmetry: sum and xor checksums of the directed keys and of their transposes agree
+    k1 = cols * N + rowval
+    k2 = rowval * N + cols
+    assert int(k1.sum()) == int(k2.sum()) and int(np.bitwise_xor.reduce(k1)) == int(np.bitwise_xor.reduce(k2))
+    del k1, k2
+    # every undirected edge carries the same cost in both directions: sum of nzval over (i<j) == over (i>j)
+    up = rowval < cols
+    assert abs(float(nzval[up].sum()) - float(nzval[~up].sum())) <= 1e-9 * float(nzval.sum())
+    kd = orc.KDTree(w.X)
+    rng = np.random.default_rng(2)
+    for v in rng.integers(0, N, size=400):
+        oi, od = kd.inball(int(v), w.r)
+        a, b = colptr[v] - 1, colptr[v + 1] - 1
+        assert np.array_equal(rowval[a:b] - 1, oi)
+        assert np.array_equal(nzval[a:b], od)
+    mask = mp._lib.unpack_bits(ctx.graph_edges_free(), nnz)
+    es = rng.integers(0, nnz, size=300000)
+    want = orc.unpack(orc.edges_free(w.X, rowval[es] - 1, cols[es] - 1, w.lohi, w.ss_lo, w.ss_hi), len(es))
+    assert np.array_equal(mask[es], want)
+    assert np.array_equal(ctx.points_free(), orc.points_free(w.X, w.lohi, w.ss_lo, w.ss_hi))
+    ctx.close()
