@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64) void k_rdisc(rdisc_args a, mpfmt_grid G)
     }
     if (!FILL) {
         a.slice_cnt[(int64_t)slice * a.npad + qpos] = cnt;
-        if (lane == 0 && a.pairs) atomicAdd(a.pairs, tested * 64ull);
+        if (lane == 0 && a.pairs) atomicAdd(a.pairs + 2 * (blockIdx.x & 255), tested * 64ull);
     }
 }
 
@@ -464,14 +464,23 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
         if (ctx->rdisc_path == 2 && !mf)
             return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path requested but not usable (d > 12 or radius too small for the fp16 shell)");
     }
+    if (mf) {
+        mpfmt_time_begin(ctx);
+        if (ctx->ops_r != ctx->grid_r) {
+            if ((rc = mpfmt_mfma_build_operands(ctx))) return rc;
+            ctx->ops_r = ctx->grid_r;
+            ctx->lists_r = -1.0;
+        }
+        bool ok = true;
+        if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok))) return rc;          // per-tile candidate chunk lists
+        mpfmt_time_end(ctx, "grid");
+        if (!ok) {
+            if (ctx->rdisc_path == 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path requested but its chunk lists exceed 32 GB");
+            mf = false;
+        }
+    }
     ctx->rdisc_path_used = mf ? 2 : 1;
     ctx->mf_negT = negT;
-    if (mf && ctx->ops_r != ctx->grid_r) {
-        mpfmt_time_begin(ctx);
-        if ((rc = mpfmt_mfma_build_operands(ctx))) return rc;
-        mpfmt_time_end(ctx, "grid");
-        ctx->ops_r = ctx->grid_r;
-    }
 
     int S = 1;
     const int64_t units = nt;                                   // work items before slicing (one wavefront each)
@@ -484,8 +493,8 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
     if ((rc = ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (N + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->degs, sizeof(int64_t) * (npad + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->tptr, sizeof(int64_t) * (npad + 1)))) return rc;
-    if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 2 * sizeof(unsigned long long)));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 512 * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 512 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (N + 1), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->degs, 0, sizeof(int64_t) * (npad + 1), ctx->stream));
 
@@ -538,7 +547,7 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
     if ((rc = scan_i64(ctx, ctx->degs, ctx->tptr, (size_t)(npad + 1)))) return rc;    // staging in sorted order
     mpfmt_time_end(ctx, "rdisc_count");
     int64_t nnz = 0;
-    unsigned long long pairs[2] = {0, 0};
+    unsigned long long pairs[512];
     HIPCHK(ctx, hipMemcpyAsync(&nnz, ctx->colptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(pairs, ctx->d_pairs, sizeof(pairs), hipMemcpyDeviceToHost, ctx->stream));
     int32_t pool_over = 0;
@@ -548,6 +557,7 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
     ctx->pool_hint_N = N; ctx->pool_hint_r = r; ctx->pool_hint_nnz = nnz;
     ctx->pool_hint_rank = ctx->rank; ctx->pool_hint_world = ctx->world;
     ctx->nnz = nnz;
+    for (int i = 1; i < 256; ++i) { pairs[0] += pairs[2 * i]; pairs[1] += pairs[2 * i + 1]; }
     ctx->pairs_tested = (int64_t)pairs[0];
     ctx->survivors = (int64_t)pairs[1];
     ctx->graph_r = r;

@@ -47,6 +47,7 @@ struct mf_args {
     double rpad;                    // conservative radius for box pruning
     float negT;                     // -T, filter threshold in normalised squared units
     int32_t S;
+    int32_t ablate;                 // timing experiments only (results invalid): 1 skip extraction, 2 skip refine, 4 skip MFMA
     int32_t xcd_mode;               // item -> XCD placement: 0 contiguous range per XCD, 1 round robin, >=2 interleaved groups of that many items
     int64_t blk_begin;              // first 256-query block of the shard
     int64_t nitems;                 // blocks * S
@@ -56,6 +57,9 @@ struct mf_args {
     const int64_t* tptr;            // [npad+1] offsets of the sorted-order staging CSC
     int32_t* rowtmp;
     double* valtmp;
+    const uint32_t* lists;          // [tiles of the shard][list_cap] candidate chunk ids of each tile (k_chunk_lists)
+    const int32_t* list_len;        // [tiles of the shard]
+    int64_t list_cap;
     unsigned long long* pairs;
     unsigned long long* survivors;
     // MODE 2 (single pass): exact hits are appended to a pool while they are counted
@@ -115,12 +119,137 @@ __global__ void k_sorted_aos(const double* __restrict__ Xo, const int32_t* __res
     for (int i = 0; i < d; ++i) Xs[p * d + i] = (o >= 0) ? Xo[(int64_t)o * d + i] : __builtin_nan("");
 }
 
+// ---- candidate chunk lists -------------------------------------------------------------------------------------
+// One wavefront per tile, run once per (grid, radius): the tile's neighbourhood -- grid rows -> contiguous runs of the
+// sorted array -> 64-sample chunks -- is flattened lane-parallel, every chunk's tight box is tested against the tile's
+// tight box (64 box tests in flight together) and the surviving unique chunk ids are ballot-compacted into the tile's
+// list in global memory (ascending).  The pair kernel's items then take contiguous slices of these lists.
+template <int D>
+__global__ __launch_bounds__(64) void k_chunk_lists(const int32_t* __restrict__ cellstart, const double* __restrict__ tile_lo,
+                                                    const double* __restrict__ tile_hi, mpfmt_grid G, double rpad,
+                                                    int64_t tile_begin, int64_t nt, int64_t list_cap,
+                                                    uint32_t* __restrict__ lists, int32_t* __restrict__ list_len,
+                                                    int32_t* __restrict__ max_len)
+{
+    __shared__ int32_t s_sega[64];                        // first chunk of each row's run
+    __shared__ int32_t s_segp[64];                        // exclusive prefix of the runs' chunk counts
+    const int lane = threadIdx.x;
+    const int64_t tl = blockIdx.x;
+    if (tl >= nt) return;
+    const int64_t tile = tile_begin + tl;
+    const double rpad2 = rpad * rpad;
+    double wlo[D], whi[D];
+    int clo[D], chi[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        wlo[i] = tile_lo[tile * D + i];
+        whi[i] = tile_hi[tile * D + i];
+        clo[i] = cell_of_m(wlo[i] - rpad, G.lo[i], G.inv_w[i], G.g[i]);
+        chi[i] = cell_of_m(whi[i] + rpad, G.lo[i], G.inv_w[i], G.g[i]);
+    }
+    constexpr int L = D - 1;
+    uint32_t rows = 1;                                    // <= number of grid cells <= 2^24
+#pragma unroll
+    for (int i = 0; i < L; ++i) rows *= (uint32_t)(chi[i] - clo[i] + 1);
+
+    uint32_t* __restrict__ out = lists + tl * list_cap;
+    int32_t gcount = 0;              // unique surviving chunks so far (uniform)
+    int64_t carry = -1;              // last chunk id of the previous flattened batch (dedupe)
+    for (uint32_t row0 = 0; row0 < rows; row0 += 64) {
+        // lane = one row: candidate run [ca, ca+n) in chunk units
+        const uint32_t row = row0 + lane;
+        int32_t ca = 0, n = 0;
+        if (row < rows) {
+            uint32_t rem = row;
+            int64_t cbase = 0;
+            double partial = 0.0;
+#pragma unroll
+            for (int i = L - 1; i >= 0; --i) {
+                const uint32_t span = (uint32_t)(chi[i] - clo[i] + 1);
+                const uint32_t qd = rem / span;
+                const int c = clo[i] + (int)(rem - qd * span);
+                rem = qd;
+                cbase += (int64_t)c * G.stride[i];
+                const double eps = G.w[i] * 1e-9;
+                const double lo = G.lo[i] + (double)c * G.w[i] - eps;
+                const double hi = G.lo[i] + (double)(c + 1) * G.w[i] + eps;
+                double gap = fmax(fmax(lo - whi[i], wlo[i] - hi), 0.0);
+                if (G.g[i] == 1) gap = 0.0;
+                partial += gap * gap;
+            }
+            if (partial <= rpad2) {
+                int c0 = clo[L], c1 = chi[L];
+                if (G.g[L] > 1) {
+                    const double eps = G.w[L] * 1e-9;
+                    while (c0 <= c1) {
+                        const double hi = G.lo[L] + (double)(c0 + 1) * G.w[L] + eps;
+                        const double gap = fmax(wlo[L] - hi, 0.0);
+                        if (partial + gap * gap > rpad2) ++c0; else break;
+                    }
+                    while (c1 >= c0) {
+                        const double lo = G.lo[L] + (double)c1 * G.w[L] - eps;
+                        const double gap = fmax(lo - whi[L], 0.0);
+                        if (partial + gap * gap > rpad2) --c1; else break;
+                    }
+                }
+                if (c0 <= c1) {
+                    const int64_t ra = cellstart[cbase + c0];
+                    const int64_t rb = cellstart[cbase + c1 + 1];
+                    if (rb > ra) { ca = (int32_t)(ra >> 6); n = (int32_t)(((rb - 1) >> 6) - (ra >> 6) + 1); }
+                }
+            }
+        }
+        // exclusive prefix of n over the lanes
+        int32_t incl = n;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const int32_t T = __shfl(incl, 63);
+        __builtin_amdgcn_wave_barrier();
+        s_sega[lane] = ca;
+        s_segp[lane] = incl - n;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t t0 = 0; t0 < T; t0 += 64) {
+            const int32_t t = t0 + lane;
+            const bool act = t < T;
+            // run owning flattened index t: the largest j with s_segp[j] <= t
+            int j = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+                const int jj = j + step;
+                if (jj < 64 && s_segp[jj] <= t) j = jj;
+            }
+            int64_t c = act ? (int64_t)s_sega[j] + (t - s_segp[j]) : -2;
+            // dedupe: consecutive runs may share their boundary chunk
+            int64_t prevc = __shfl_up(c, 1);
+            if (lane == 0) prevc = carry;
+            const int lastl = min(63, T - t0 - 1);
+            carry = __shfl(c, lastl);
+            bool keep = act && (c != prevc);
+            if (keep) {
+                double gap2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    const double gp = fmax(fmax(tile_lo[c * D + i] - whi[i], wlo[i] - tile_hi[c * D + i]), 0.0);
+                    gap2 += gp * gp;
+                }
+                keep = gap2 <= rpad2;
+            }
+            const unsigned long long m = __ballot(keep);
+            const int32_t gidx = gcount + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (keep && gidx < list_cap) out[gidx] = (uint32_t)c;
+            gcount += (int32_t)__popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) { list_len[tl] = gcount; atomicMax(max_len, gcount); }
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------------------
-// One independent wavefront per (tile, slice): no workgroup barriers.
-//   prologue : lanes = grid-cell rows of the tile's neighbourhood -> contiguous candidate runs -> flattened
-//              64-sample chunks; each lane tests one chunk's tight box against the tile's tight box (the 2*d
-//              box loads of 64 chunks are in flight together) and the survivors are ballot-compacted into an
-//              LDS list of chunk ids.
+// One independent wavefront per (tile, slice of the tile's chunk list): no workgroup barriers.
 //   main loop: for each listed chunk, the two 32-candidate B fragments are 16 B/lane coalesced loads from the
 //              operand array (L2/MALL resident, 32 B per sample), prefetched two chunks ahead; 4 MFMAs
 //              (2 query row blocks x 2 candidate column blocks), sign-bit extraction, survivor queue, refine.
@@ -132,8 +261,6 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
 {
     __shared__ double s_q[64 * D];                        // fp64 query coordinates (AoS) for the refine
     __shared__ uint32_t s_list[MF_LIST];
-    __shared__ int32_t s_sega[64];                        // first chunk of each row's run
-    __shared__ int32_t s_segp[64];                        // exclusive prefix of the runs' chunk counts
     __shared__ uint32_t s_qj[MF_QCAP];                    // survivor queue: candidate sorted position
     __shared__ uint32_t s_qq[MF_QCAP];                    //                 query lane
     __shared__ int32_t s_cnt[64];
@@ -204,6 +331,7 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int first = qcount - n;
+        if (a.ablate & 2) { qcount = __builtin_amdgcn_readfirstlane(first); return; }
         bool hit = false;
         uint32_t jg = 0, ql = 0;
         double d2 = 0.0;
@@ -274,7 +402,7 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
     auto run_list = [&](int n) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (n <= 0) return;
+        if (n <= 0 || (a.ablate & 8)) return;
         uint4 b0[2], b1[2], b2[2];
         load_b((int64_t)s_list[0], b0);
         if (n > 1) load_b((int64_t)s_list[1], b1);
@@ -284,6 +412,12 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
             tested += 64ull * 64ull;
             union { uint4 u; half8 h; } bf0, bf1;
             bf0.u = b0[0]; bf1.u = b0[1];
+            if (a.ablate & 4) {
+                asm volatile("" :: "v"(bf0.u.x), "v"(bf1.u.x));
+                b0[0] = b1[0]; b0[1] = b1[1];
+                b1[0] = b2[0]; b1[1] = b2[1];
+                continue;
+            }
             // 4 independent MFMAs back to back (2 query row blocks x 2 candidate column blocks), C = 0
             const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf0.h, zero16, 0, 0, 0);
             const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf0.h, zero16, 0, 0, 0);
@@ -298,129 +432,34 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
                 h3 = __builtin_amdgcn_alignbit(h3, __float_as_uint(acc3[r]), 31);
             }
             const unsigned long long H = (unsigned long long)(h0 | (h1 << 16)) | ((unsigned long long)(h2 | (h3 << 16)) << 32);
-            extract(H, c);
+            if (a.ablate & 1) { asm volatile("" :: "v"(H)); } else extract(H, c);
             b0[0] = b1[0]; b0[1] = b1[1];
             b1[0] = b2[0]; b1[1] = b2[1];
         }
     };
 
-    // ---- prologue: candidate chunk list --------------------------------------------------------------------------------
-    double wlo[D], whi[D];
-    int clo[D], chi[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        wlo[i] = a.tile_lo[tile * D + i];
-        whi[i] = a.tile_hi[tile * D + i];
-        clo[i] = cell_of_m(wlo[i] - a.rpad, G.lo[i], G.inv_w[i], G.g[i]);
-        chi[i] = cell_of_m(whi[i] + a.rpad, G.lo[i], G.inv_w[i], G.g[i]);
+    // ---- this item's slice of the tile's candidate chunk list (built once per tile by k_chunk_lists) ------------------
+    {
+        const int64_t tl = tile - a.blk_begin;
+        const int64_t len = a.list_len[tl];
+        // slices interleave the list (entry k belongs to slice k mod S): every slice sees the same near/far mix of
+        // chunks, so hits, refine work and slot-list fill are even across the slices of a tile
+        const int64_t cnt = (len > slice) ? (len - slice + a.S - 1) / a.S : 0;
+        const uint32_t* __restrict__ lst = a.lists + tl * a.list_cap + slice;
+        for (int64_t k0 = 0; k0 < cnt; k0 += MF_LIST) {
+            const int n = (int)min((int64_t)MF_LIST, cnt - k0);
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < n; e += 64) s_list[e] = lst[(k0 + e) * a.S];
+            run_list(n);
+        }
     }
-    constexpr int L = D - 1;
-    int64_t rows = 1;
-#pragma unroll
-    for (int i = 0; i < L; ++i) rows *= (chi[i] - clo[i] + 1);
-
-    int lcount = 0;                  // chunk ids in s_list (uniform)
-    int64_t gcount = 0;              // unique surviving chunks seen so far (slice selector, uniform)
-    int64_t carry = -1;              // last chunk id of the previous flattened batch (dedupe)
-    for (int64_t row0 = 0; row0 < rows; row0 += 64) {
-        // lane = one row: candidate run [ca, ca+n) in chunk units
-        const int64_t row = row0 + lane;
-        int32_t ca = 0, n = 0;
-        if (row < rows) {
-            int64_t rem = row, cbase = 0;
-            double partial = 0.0;
-#pragma unroll
-            for (int i = L - 1; i >= 0; --i) {
-                const int span = chi[i] - clo[i] + 1;
-                const int c = clo[i] + (int)(rem % span);
-                rem /= span;
-                cbase += (int64_t)c * G.stride[i];
-                const double eps = G.w[i] * 1e-9;
-                const double lo = G.lo[i] + (double)c * G.w[i] - eps;
-                const double hi = G.lo[i] + (double)(c + 1) * G.w[i] + eps;
-                double gap = fmax(fmax(lo - whi[i], wlo[i] - hi), 0.0);
-                if (G.g[i] == 1) gap = 0.0;
-                partial += gap * gap;
-            }
-            if (partial <= rpad2) {
-                int c0 = clo[L], c1 = chi[L];
-                if (G.g[L] > 1) {
-                    const double eps = G.w[L] * 1e-9;
-                    while (c0 <= c1) {
-                        const double hi = G.lo[L] + (double)(c0 + 1) * G.w[L] + eps;
-                        const double gap = fmax(wlo[L] - hi, 0.0);
-                        if (partial + gap * gap > rpad2) ++c0; else break;
-                    }
-                    while (c1 >= c0) {
-                        const double lo = G.lo[L] + (double)c1 * G.w[L] - eps;
-                        const double gap = fmax(lo - whi[L], 0.0);
-                        if (partial + gap * gap > rpad2) --c1; else break;
-                    }
-                }
-                if (c0 <= c1) {
-                    const int64_t ra = a.cellstart[cbase + c0];
-                    const int64_t rb = a.cellstart[cbase + c1 + 1];
-                    if (rb > ra) { ca = (int32_t)(ra >> 6); n = (int32_t)(((rb - 1) >> 6) - (ra >> 6) + 1); }
-                }
-            }
-        }
-        // exclusive prefix of n over the lanes
-        int32_t incl = n;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int32_t v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        const int32_t T = __shfl(incl, 63);
-        __builtin_amdgcn_wave_barrier();
-        s_sega[lane] = ca;
-        s_segp[lane] = incl - n;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int32_t t0 = 0; t0 < T; t0 += 64) {
-            const int32_t t = t0 + lane;
-            const bool act = t < T;
-            // run owning flattened index t: the largest j with s_segp[j] <= t
-            int j = 0;
-#pragma unroll
-            for (int step = 32; step > 0; step >>= 1) {
-                const int jj = j + step;
-                if (jj < 64 && s_segp[jj] <= t) j = jj;
-            }
-            int64_t c = act ? (int64_t)s_sega[j] + (t - s_segp[j]) : -2;
-            // dedupe: consecutive runs may share their boundary chunk
-            int64_t prevc = __shfl_up(c, 1);
-            if (lane == 0) prevc = carry;
-            const int lastl = min(63, T - t0 - 1);
-            carry = __shfl(c, lastl);
-            bool keep = act && (c != prevc);
-            if (keep) {
-                double gap2 = 0.0;
-#pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    const double gp = fmax(fmax(a.tile_lo[c * D + i] - whi[i], wlo[i] - a.tile_hi[c * D + i]), 0.0);
-                    gap2 += gp * gp;
-                }
-                keep = gap2 <= rpad2;
-            }
-            const unsigned long long m = __ballot(keep);
-            const int64_t gidx = gcount + (int64_t)__popcll(m & ((1ull << lane) - 1ull));
-            gcount += (int64_t)__popcll(m);
-            const bool keep2 = keep && ((int)(gidx % a.S) == slice);
-            const unsigned long long m2 = __ballot(keep2);
-            if (keep2) s_list[lcount + (int)__popcll(m2 & ((1ull << lane) - 1ull))] = (uint32_t)c;
-            lcount += (int)__popcll(m2);
-            if (lcount > MF_LIST - 64) { run_list(lcount); lcount = 0; }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    run_list(lcount);
     while (qcount > 0) drain(min(qcount, 64));
 
     if (MODE == 2 && pool_over) *a.pool_flag = 1;                 // overflow: the build falls back to a fill pass
     if (MODE != 1) {
         a.slice_cnt[(int64_t)slice * a.npad + qpos] = s_cnt[lane];
-        if (lane == 0 && a.pairs) { atomicAdd(a.pairs, tested); atomicAdd(a.survivors, surv); }
+        // per-XCD-sharded counters: a single hot address saturates at ~88 atomics/us (156k items would cost 1.8 ms)
+        if (lane == 0 && a.pairs) { atomicAdd(a.pairs + 2 * (blockIdx.x & 255), tested); atomicAdd(a.pairs + 2 * (blockIdx.x & 255) + 1, surv); }
     }
 }
 
@@ -567,6 +606,44 @@ int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx)
     return MPFMT_OK;
 }
 
+// (re)build the per-tile candidate chunk lists of this ctx's shard for radius r; grows the list capacity until every
+// list fits.  *usable = false when the lists would need more than 32 GB (caller then takes the exact VALU path).
+int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable)
+{
+    *usable = true;
+    const int64_t nt = ctx->tile_end - ctx->tile_begin;
+    if (nt <= 0) return MPFMT_OK;
+    if (ctx->lists_r == r && ctx->lists_begin == ctx->tile_begin && ctx->lists_end == ctx->tile_end && ctx->lists) return MPFMT_OK;
+    int32_t rc;
+    int64_t cap = std::min<int64_t>(ctx->ntiles, std::max<int64_t>(ctx->list_cap, 2048));
+    const double rpad = r * (1.0 + 1e-9) + 1e-300;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->list_len, sizeof(int32_t) * (size_t)(nt + 1)))) return rc;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if ((double)cap * (double)nt * 4.0 > 32e9) { *usable = false; return MPFMT_OK; }
+        if ((rc = mpfmt_ensure(ctx, (void**)&ctx->lists, sizeof(uint32_t) * (size_t)cap * (size_t)nt))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->list_len + nt, 0, sizeof(int32_t), ctx->stream));
+        const mpfmt_grid& G = ctx->grid;
+#define CASE(DD) case DD: hipLaunchKernelGGL((k_chunk_lists<DD>), dim3((unsigned)nt), dim3(64), 0, ctx->stream, ctx->cellstart, \
+            ctx->tile_lo, ctx->tile_hi, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt); break;
+        switch (ctx->d) {
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
+            default: return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path supports d <= 12 (got %d)", ctx->d);
+        }
+#undef CASE
+        HIPCHK(ctx, hipGetLastError());
+        int32_t mx = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&mx, ctx->list_len + nt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (mx <= cap) {
+            ctx->list_cap = cap; ctx->lists_r = r; ctx->lists_begin = ctx->tile_begin; ctx->lists_end = ctx->tile_end;
+            return MPFMT_OK;
+        }
+        cap = std::min<int64_t>(ctx->ntiles, ((int64_t)mx + 255) / 256 * 256);
+    }
+    *usable = false;
+    return MPFMT_OK;
+}
+
 template <int MODE>
 int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
 {
@@ -576,12 +653,14 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.r2 = r * r; a.rpad = r * (1.0 + 1e-9) + 1e-300; a.negT = negT;
     a.S = ctx->S;
     a.xcd_mode = ctx->mf_xcd_mode;
+    a.ablate = ctx->mf_ablate;
     a.blk_begin = ctx->tile_begin;                             // first tile of the shard
     a.nitems = (ctx->tile_end - ctx->tile_begin) * ctx->S;
     a.npad = ctx->ntiles * 64; a.ntiles = ctx->ntiles;
     a.slice_cnt = ctx->slice_cnt; a.tptr = ctx->tptr; a.rowtmp = ctx->rowtmp; a.valtmp = ctx->valtmp;
-    a.pairs = (MODE == 1) ? nullptr : ctx->d_pairs;
-    a.survivors = (MODE == 1) ? nullptr : ctx->d_pairs + 1;
+    a.lists = (const uint32_t*)ctx->lists; a.list_len = ctx->list_len; a.list_cap = ctx->list_cap;
+    a.pairs = (MODE == 1) ? nullptr : ctx->d_pairs;              // 256 x {tested, survivors} sharded counters
+    a.survivors = nullptr;
     a.pool_flag = ctx->pool_flag; a.pool_cap = ctx->pool_cap;
     a.pool_j = ctx->pool_j; a.pool_d = ctx->pool_d;
     if (a.nitems <= 0) return MPFMT_OK;

@@ -167,7 +167,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
-                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->pool_flag, ctx->pool_j, ctx->pool_d};
+                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->pool_flag, ctx->pool_j, ctx->pool_d, ctx->lists, ctx->list_len};
     for (void* b : bufs) if (b) hipFree(b);
     timer_resolve(ctx);
     auto it = g_timers.find(ctx);
@@ -218,7 +218,7 @@ int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t
     if (N > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->Xo, X, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->N = N; ctx->d = d;
-    ctx->grid_r = -1.0; ctx->graph_r = -1.0; ctx->ops_r = -1.0;
+    ctx->grid_r = -1.0; ctx->graph_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0;
     ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
     ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
     ctx->nnz = 0;
@@ -259,7 +259,7 @@ int32_t mpfmt_graph_build_device(mpfmt_ctx* ctx, double r, int64_t* nnz)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int32_t rc;
     ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
-    if (ctx->rebuild_index) { ctx->grid_r = -1.0; ctx->ops_r = -1.0; }    // index build (cell grid + operands) is part of the build
+    if (ctx->rebuild_index) { ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; }    // index build (cell grid + operands) is part of the build
     if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
     if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
     if (nnz) *nnz = ctx->nnz;
@@ -950,6 +950,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "rebuild_index") == 0) { ctx->rebuild_index = value != 0; return MPFMT_OK; }
     if (strcmp(name, "rdisc_pool") == 0) { ctx->use_pool = value != 0; return MPFMT_OK; }
+    if (strcmp(name, "mf_ablate") == 0) { ctx->mf_ablate = (int32_t)value; return MPFMT_OK; }
     if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }
     if (strcmp(name, "mf_target_items") == 0) { ctx->mf_target_items = value; return MPFMT_OK; }
     if (strcmp(name, "timing") == 0) { ctx->timing_enabled = value != 0; return MPFMT_OK; }

@@ -84,8 +84,13 @@ struct mpfmt_ctx {
     int32_t rdisc_path = 0;              // 0 auto, 1 exact fp64 VALU kernel, 2 MFMA filter + exact refine
     int32_t rdisc_path_used = 0;
     int32_t mf_xcd_mode = 512;
+    int32_t mf_ablate = 0;               // timing experiments only
     int64_t mf_target_items = 70000;     // work items (tile x slice) the MFMA path aims for
     float mf_negT = 0.f;
+    void* lists = nullptr;               // [shard tiles][list_cap] candidate chunk ids per tile
+    int32_t* list_len = nullptr;         // [shard tiles + 1] lengths, last = max
+    int64_t list_cap = 0;
+    double lists_r = -1.0; int64_t lists_begin = -1, lists_end = -1;
     // single-pass hit pool (MFMA path): hits found by the count pass are kept, so the fill pass is a scatter
     int32_t use_pool = 1;                // option "rdisc_pool"
     int32_t* pool_flag = nullptr;        // overflow flag
@@ -154,6 +159,7 @@ int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx);
 int32_t mpfmt_build_sorted_aos(mpfmt_ctx* ctx);
 template <int MODE> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT);
 int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx);
+int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);
 
