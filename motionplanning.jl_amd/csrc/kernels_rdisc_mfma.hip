@@ -28,6 +28,7 @@
 #include <cmath>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define NXCD 8
@@ -102,6 +103,15 @@ __global__ void k_make_ops(const double* __restrict__ Xs, int64_t N, int64_t npa
     }
     const _Float16 nh = (_Float16)n;
     const _Float16 nl = (_Float16)(n - (float)nh);
+    if (d <= 6) {
+        // K = 8 layout (16 B per sample): u_0..u_5, n_hi, n_lo -- the query's norm and the threshold ride in the MFMA's C
+        union { _Float16 hh[8]; uint4 v; } u8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) u8.hh[k] = h[k];
+        u8.hh[6] = nh; u8.hh[7] = nl;
+        ops[p] = u8.v;
+        return;
+    }
     h[12] = (_Float16)1.0f; h[13] = (_Float16)1.0f; h[14] = nh; h[15] = nl;
     union { _Float16 hh[16]; uint4 v[2]; } u;
 #pragma unroll
@@ -297,30 +307,61 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
         for (int s = 0; s < slice; ++s) base += a.slice_cnt[(int64_t)s * a.npad + qpos];
         s_base[lane] = base;
     }
+    // d <= 6: K = 8 operands (16 B per sample, v_mfma_f32_32x32x8_f16), half the operand traffic of the K = 16 form.
+    constexpr bool K8 = (D <= 6);
     half8 aF[2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const uint4 raw = a.ops[(tile * 64 + rb * 32 + col) * 2 + kb];
-        union { uint4 u; _Float16 h[8]; } cv; cv.u = raw;
-        half8 v;
-        if (kb == 0) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = (_Float16)(-2.0f * (float)cv.h[k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (_Float16)(-2.0f * (float)cv.h[k]);
-            // |u_q|^2 - T, re-split into hi + lo: the threshold rides in the query operand, so the MFMA's C
-            // input is the inline constant 0 and sign(acc) <=> filtered distance below the threshold
-            const float nT = ((float)cv.h[6] + (float)cv.h[7]) + a.negT;
-            const _Float16 nh = (_Float16)nT;
-            v[4] = nh; v[5] = (_Float16)(nT - (float)nh);
-            v[6] = (_Float16)1.0f; v[7] = (_Float16)1.0f;
-        }
-        aF[rb] = v;
-    }
+    half4 aF4[2];
+    f32x16 cinit[2];                                          // K8: C input = |u_q|^2 - T per accumulator row
     f32x16 zero16;
 #pragma unroll
     for (int k = 0; k < 16; ++k) zero16[k] = 0.0f;
+    if constexpr (K8) {
+        const uint2* __restrict__ ops2 = reinterpret_cast<const uint2*>(a.ops);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const uint2 raw = ops2[(tile * 64 + rb * 32 + col) * 2 + kb];
+            union { uint2 u; _Float16 h[4]; } cv; cv.u = raw;
+            half4 v;
+            if (kb == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (_Float16)(-2.0f * (float)cv.h[k]);
+            } else {
+                v[0] = (_Float16)(-2.0f * (float)cv.h[0]); v[1] = (_Float16)(-2.0f * (float)cv.h[1]);
+                v[2] = (_Float16)1.0f; v[3] = (_Float16)1.0f;          // multiply the candidate's n_hi, n_lo
+            }
+            aF4[rb] = v;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
+                union { uint2 u; _Float16 h[4]; } qn; qn.u = ops2[(tile * 64 + rb * 32 + row) * 2 + 1];
+                cinit[rb][r] = ((float)qn.h[2] + (float)qn.h[3]) + a.negT;
+            }
+            aF[rb] = half8{};
+        }
+    } else {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const uint4 raw = a.ops[(tile * 64 + rb * 32 + col) * 2 + kb];
+            union { uint4 u; _Float16 h[8]; } cv; cv.u = raw;
+            half8 v;
+            if (kb == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (_Float16)(-2.0f * (float)cv.h[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (_Float16)(-2.0f * (float)cv.h[k]);
+                // |u_q|^2 - T, re-split into hi + lo: the threshold rides in the query operand, so the MFMA's C
+                // input is the inline constant 0 and sign(acc) <=> filtered distance below the threshold
+                const float nT = ((float)cv.h[6] + (float)cv.h[7]) + a.negT;
+                const _Float16 nh = (_Float16)nT;
+                v[4] = nh; v[5] = (_Float16)(nT - (float)nh);
+                v[6] = (_Float16)1.0f; v[7] = (_Float16)1.0f;
+            }
+            aF[rb] = v;
+            aF4[rb] = half4{};
+            cinit[rb] = zero16;
+        }
+    }
     const double rpad2 = a.rpad * a.rpad;
 
     // ---- refine: exact fp64 test of n queued survivors (lane = survivor) ---------------------------------------
@@ -396,8 +437,15 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
     // ---- main loop over a list of chunk ids ------------------------------------------------------------------------
     unsigned long long tested = 0;
     auto load_b = [&](int64_t c, uint4 (&bq)[2]) {
-        bq[0] = a.ops[(c * 64 + col) * 2 + kb];
-        bq[1] = a.ops[(c * 64 + 32 + col) * 2 + kb];
+        if constexpr (K8) {
+            const uint2* __restrict__ ops2 = reinterpret_cast<const uint2*>(a.ops);
+            const uint2 x0 = ops2[(c * 64 + col) * 2 + kb], x1 = ops2[(c * 64 + 32 + col) * 2 + kb];
+            bq[0] = make_uint4(x0.x, x0.y, 0u, 0u);
+            bq[1] = make_uint4(x1.x, x1.y, 0u, 0u);
+        } else {
+            bq[0] = a.ops[(c * 64 + col) * 2 + kb];
+            bq[1] = a.ops[(c * 64 + 32 + col) * 2 + kb];
+        }
     };
     auto run_list = [&](int n) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -410,19 +458,29 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
             const int64_t c = (int64_t)s_list[k];
             if (k + 2 < n) load_b((int64_t)s_list[k + 2], b2);        // two chunks ahead, in flight during the MFMAs
             tested += 64ull * 64ull;
-            union { uint4 u; half8 h; } bf0, bf1;
-            bf0.u = b0[0]; bf1.u = b0[1];
             if (a.ablate & 4) {
-                asm volatile("" :: "v"(bf0.u.x), "v"(bf1.u.x));
+                asm volatile("" :: "v"(b0[0].x), "v"(b0[1].x));
                 b0[0] = b1[0]; b0[1] = b1[1];
                 b1[0] = b2[0]; b1[1] = b2[1];
                 continue;
             }
-            // 4 independent MFMAs back to back (2 query row blocks x 2 candidate column blocks), C = 0
-            const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf0.h, zero16, 0, 0, 0);
-            const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf0.h, zero16, 0, 0, 0);
-            const f32x16 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf1.h, zero16, 0, 0, 0);
-            const f32x16 acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf1.h, zero16, 0, 0, 0);
+            // 4 independent MFMAs back to back (2 query row blocks x 2 candidate column blocks)
+            f32x16 acc0, acc1, acc2, acc3;
+            if constexpr (K8) {
+                union { uint2 u; half4 h; } bf0, bf1;
+                bf0.u = make_uint2(b0[0].x, b0[0].y); bf1.u = make_uint2(b0[1].x, b0[1].y);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[0], bf0.h, cinit[0], 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[1], bf0.h, cinit[1], 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[0], bf1.h, cinit[0], 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[1], bf1.h, cinit[1], 0, 0, 0);
+            } else {
+                union { uint4 u; half8 h; } bf0, bf1;
+                bf0.u = b0[0]; bf1.u = b0[1];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf0.h, zero16, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf0.h, zero16, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf1.h, zero16, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf1.h, zero16, 0, 0, 0);
+            }
             uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
