@@ -626,13 +626,17 @@ int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkp
     HIPCHK(ctx, hipMemcpy(X.data(), ctx->Xo, sizeof(double) * (size_t)N * d, hipMemcpyDeviceToHost));
     auto t4 = std::chrono::steady_clock::now();
 
-    // the sequential recursion, fmt.jl:43-90, 0-based internally
-    std::vector<uint8_t> Wm(N, 1), Hm(N, 0);
+    // the sequential recursion, fmt.jl:43-90, 0-based internally.  W and H are bit sets (125 KB each at N = 1e6, cache
+    // resident): the inner loop touches C[y] only for the few open neighbours.
+    std::vector<uint64_t> Wb((size_t)words, ~0ull), Hb((size_t)words, 0ull);
+    auto getb = [](const std::vector<uint64_t>& m, int64_t i) { return (m[(size_t)(i >> 6)] >> (i & 63)) & 1ull; };
+    auto setb = [](std::vector<uint64_t>& m, int64_t i) { m[(size_t)(i >> 6)] |= 1ull << (i & 63); };
+    auto clrb = [](std::vector<uint64_t>& m, int64_t i) { m[(size_t)(i >> 6)] &= ~(1ull << (i & 63)); };
     std::vector<int64_t> Hnew;
     for (int64_t i = 0; i < N; ++i) { A[i] = 0; C[i] = 0.0; }
     Heap heap;
     const int64_t i0 = init_idx - 1;
-    Wm[i0] = 0; Hm[i0] = 1;
+    clrb(Wb, i0); setb(Hb, i0);
     heap.push(i0, 0.0);
     int64_t z = heap.pop();
     int64_t count = 0;
@@ -640,12 +644,12 @@ int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkp
         Hnew.clear();
         for (int64_t a = colptr[z]; a < colptr[z + 1]; ++a) {                 // fmt.jl:70
             const int64_t x = rowval[a];
-            if (!Wm[x]) continue;
+            if (!getb(Wb, x)) continue;
             if (checkpts && !bit(F, x)) continue;                             // fmt.jl:71
             int64_t y_min = -1, e_min = -1; double c_min = 0.0;
             for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {             // fmt.jl:72-74
                 const int64_t y = rowval[b];
-                if (!Hm[y]) continue;
+                if (!getb(Hb, y)) continue;
                 const double c = C[y] + nzval[b];
                 if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
             }
@@ -659,11 +663,11 @@ int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkp
                 A[x] = y_min + 1; C[x] = c_min;
                 heap.push(x, c_min);
                 Hnew.push_back(x);
-                Wm[x] = 0;
+                clrb(Wb, x);
             }
         }
-        for (int64_t x : Hnew) Hm[x] = 1;                                     // fmt.jl:83
-        Hm[z] = 0;                                                            // fmt.jl:84
+        for (int64_t x : Hnew) setb(Hb, x);                                   // fmt.jl:83
+        clrb(Hb, z);                                                          // fmt.jl:84
         if (!heap.empty()) z = heap.pop(); else break;                        // fmt.jl:85-89
     }
     // path back-trace, fmt.jl:92-101 (walks until sample 1)
