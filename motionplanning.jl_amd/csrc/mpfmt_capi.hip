@@ -58,7 +58,11 @@ struct timer_state {
     hipEvent_t open_a[TIMER_DEPTH];
     int depth = 0;
 };
-static std::map<mpfmt_ctx*, timer_state> g_timers;
+static timer_state& timers_of(mpfmt_ctx* ctx)
+{
+    if (!ctx->timer_state) ctx->timer_state = new timer_state();
+    return *(timer_state*)ctx->timer_state;
+}
 
 static hipEvent_t timer_event(timer_state& t)
 {
@@ -70,9 +74,8 @@ static hipEvent_t timer_event(timer_state& t)
 
 static void timer_resolve(mpfmt_ctx* ctx)
 {
-    auto it = g_timers.find(ctx);
-    if (it == g_timers.end()) return;
-    timer_state& t = it->second;
+    if (!ctx->timer_state) return;
+    timer_state& t = timers_of(ctx);
     for (timer_rec& r : t.pending) {
         hipEventSynchronize(r.b);
         float ms = 0.f;
@@ -90,7 +93,7 @@ static void timer_resolve(mpfmt_ctx* ctx)
 void mpfmt_time_begin(mpfmt_ctx* ctx)
 {
     if (!ctx->timing_enabled) return;
-    timer_state& t = g_timers[ctx];
+    timer_state& t = timers_of(ctx);
     if (t.depth < TIMER_DEPTH) {
         t.open_a[t.depth] = timer_event(t);
         hipEventRecord(t.open_a[t.depth], ctx->stream);
@@ -101,7 +104,7 @@ void mpfmt_time_begin(mpfmt_ctx* ctx)
 void mpfmt_time_end(mpfmt_ctx* ctx, const char* name)
 {
     if (!ctx->timing_enabled) return;
-    timer_state& t = g_timers[ctx];
+    timer_state& t = timers_of(ctx);
     if (t.depth <= 0) return;
     --t.depth;
     if (t.depth >= TIMER_DEPTH) return;
@@ -111,6 +114,19 @@ void mpfmt_time_end(mpfmt_ctx* ctx, const char* name)
     t.pending.push_back(r);
     if (t.pending.size() > 4096) timer_resolve(ctx);
 }
+
+// ---- temporaries of one ABI call: device buffers freed on every exit path -----------------------------------
+struct DevTmp {
+    std::vector<void*> p;
+    ~DevTmp() { for (void* q : p) if (q) hipFree(q); }
+    template <class T> hipError_t get(T** out, size_t bytes)
+    {
+        void* q = nullptr;
+        const hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+        if (e == hipSuccess) { p.push_back(q); *out = (T*)q; }
+        return e;
+    }
+};
 
 // ---- small conversion kernels --------------------------------------------------------------------------
 __global__ void k_add1_i64(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ out)
@@ -170,10 +186,11 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
                     ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->pool_flag, ctx->pool_j, ctx->pool_d, ctx->lists, ctx->list_len};
     for (void* b : bufs) if (b) hipFree(b);
     timer_resolve(ctx);
-    auto it = g_timers.find(ctx);
-    if (it != g_timers.end()) {
-        for (hipEvent_t e : it->second.free_events) hipEventDestroy(e);
-        g_timers.erase(it);
+    if (ctx->timer_state) {
+        timer_state* t = (timer_state*)ctx->timer_state;
+        for (hipEvent_t e : t->free_events) hipEventDestroy(e);
+        delete t;
+        ctx->timer_state = nullptr;
     }
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -329,10 +346,10 @@ int32_t mpfmt_rdisc_query(mpfmt_ctx* ctx, int64_t v, double r, int64_t* inds, do
 
 // ---- validity sweeps ---------------------------------------------------------------------------------
 
-static int32_t up_i64(mpfmt_ctx* ctx, const int64_t* h, int64_t n, int64_t** d)
+static int32_t up_i64(mpfmt_ctx* ctx, DevTmp& tmp, const int64_t* h, int64_t n, int64_t** d)
 {
     *d = nullptr;
-    HIPCHK(ctx, hipMalloc((void**)d, sizeof(int64_t) * (size_t)std::max<int64_t>(n, 1)));
+    HIPCHK(ctx, tmp.get(d, sizeof(int64_t) * (size_t)std::max<int64_t>(n, 1)));
     if (n > 0) HIPCHK(ctx, hipMemcpyAsync(*d, h, sizeof(int64_t) * n, hipMemcpyHostToDevice, ctx->stream));
     return MPFMT_OK;
 }
@@ -357,17 +374,16 @@ int32_t mpfmt_points_free(mpfmt_ctx* ctx, const int64_t* idx, int64_t n, uint64_
     int32_t rc;
     if (idx && (rc = check_idx(ctx, idx, n, "idx"))) return rc;
     const int64_t words = (n + 63) / 64;
+    DevTmp tmp;
     int64_t* d_idx = nullptr; uint64_t* d_mask = nullptr;
-    if (idx && (rc = up_i64(ctx, idx, n, &d_idx))) return rc;
-    HIPCHK(ctx, hipMalloc((void**)&d_mask, sizeof(uint64_t) * words));
+    if (idx && (rc = up_i64(ctx, tmp, idx, n, &d_idx))) return rc;
+    HIPCHK(ctx, tmp.get(&d_mask, sizeof(uint64_t) * words));
     rc = mpfmt_launch_points_free(ctx, d_idx, n, d_mask);
     if (rc == MPFMT_OK) {
         hipError_t e = hipMemcpyAsync(mask, d_mask, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "points_free copy back: %s", hipGetErrorString(e));
     }
-    if (d_idx) hipFree(d_idx);
-    hipFree(d_mask);
     return rc;
 }
 
@@ -382,17 +398,17 @@ int32_t mpfmt_edges_free(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst,
     int32_t rc;
     if ((rc = check_idx(ctx, src, E, "src")) || (rc = check_idx(ctx, dst, E, "dst"))) return rc;
     const int64_t words = (E + 63) / 64;
+    DevTmp tmp;
     int64_t *d_s = nullptr, *d_t = nullptr; uint64_t* d_mask = nullptr;
-    if ((rc = up_i64(ctx, src, E, &d_s))) return rc;
-    if ((rc = up_i64(ctx, dst, E, &d_t))) { hipFree(d_s); return rc; }
-    HIPCHK(ctx, hipMalloc((void**)&d_mask, sizeof(uint64_t) * words));
+    if ((rc = up_i64(ctx, tmp, src, E, &d_s))) return rc;
+    if ((rc = up_i64(ctx, tmp, dst, E, &d_t))) return rc;
+    HIPCHK(ctx, tmp.get(&d_mask, sizeof(uint64_t) * words));
     rc = mpfmt_launch_edges_free(ctx, d_s, d_t, E, d_mask);
     if (rc == MPFMT_OK) {
         hipError_t e = hipMemcpyAsync(mask, d_mask, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "edges_free copy back: %s", hipGetErrorString(e));
     }
-    hipFree(d_s); hipFree(d_t); hipFree(d_mask);
     return rc;
 }
 
@@ -407,21 +423,21 @@ static int32_t explicit_sweep(mpfmt_ctx* ctx, const double* P, const double* Q, 
     const int d = ctx->dw;
     const int64_t words = (n + 63) / 64;
     const size_t pb = sizeof(double) * (size_t)n * d;
+    DevTmp tmp;
     double *dP = nullptr, *dQ = nullptr; uint64_t* d_mask = nullptr;
-    HIPCHK(ctx, hipMalloc((void**)&dP, pb));
+    HIPCHK(ctx, tmp.get(&dP, pb));
     HIPCHK(ctx, hipMemcpyAsync(dP, P, pb, hipMemcpyHostToDevice, ctx->stream));
     if (Q) {
-        HIPCHK(ctx, hipMalloc((void**)&dQ, pb));
+        HIPCHK(ctx, tmp.get(&dQ, pb));
         HIPCHK(ctx, hipMemcpyAsync(dQ, Q, pb, hipMemcpyHostToDevice, ctx->stream));
     }
-    HIPCHK(ctx, hipMalloc((void**)&d_mask, sizeof(uint64_t) * words));
+    HIPCHK(ctx, tmp.get(&d_mask, sizeof(uint64_t) * words));
     int32_t rc = Q ? mpfmt_launch_motions_free(ctx, dP, dQ, n, d_mask) : mpfmt_launch_states_free(ctx, dP, n, d_mask);
     if (rc == MPFMT_OK) {
         hipError_t e = hipMemcpyAsync(mask, d_mask, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "sweep copy back: %s", hipGetErrorString(e));
     }
-    hipFree(dP); if (dQ) hipFree(dQ); hipFree(d_mask);
     return rc;
 }
 
@@ -496,18 +512,19 @@ int32_t mpfmt_expand(mpfmt_ctx* ctx, const uint64_t* W, const uint64_t* H, const
     int32_t rc;
     if ((rc = check_idx(ctx, zs, nz, "zs"))) return rc;
     const int64_t N = ctx->N, words = (N + 63) / 64;
+    DevTmp tmp;
     uint64_t *dW = nullptr, *dH = nullptr, *dF = nullptr; double* dC = nullptr; int64_t* dz = nullptr;
     int64_t *dxs = nullptr, *dym = nullptr; double* dcm = nullptr; uint8_t* dfr = nullptr;
     const int64_t capd = std::max<int64_t>(cap, 1);
-    HIPCHK(ctx, hipMalloc((void**)&dW, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&dH, 8 * words));
-    HIPCHK(ctx, hipMalloc((void**)&dC, 8 * N));
+    HIPCHK(ctx, tmp.get(&dW, 8 * words)); HIPCHK(ctx, tmp.get(&dH, 8 * words));
+    HIPCHK(ctx, tmp.get(&dC, 8 * N));
     HIPCHK(ctx, hipMemcpyAsync(dW, W, 8 * words, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dH, H, 8 * words, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dC, C, 8 * N, hipMemcpyHostToDevice, ctx->stream));
-    if (F) { HIPCHK(ctx, hipMalloc((void**)&dF, 8 * words)); HIPCHK(ctx, hipMemcpyAsync(dF, F, 8 * words, hipMemcpyHostToDevice, ctx->stream)); }
-    if ((rc = up_i64(ctx, zs, nz, &dz))) return rc;
-    HIPCHK(ctx, hipMalloc((void**)&dxs, 8 * capd)); HIPCHK(ctx, hipMalloc((void**)&dym, 8 * capd));
-    HIPCHK(ctx, hipMalloc((void**)&dcm, 8 * capd)); HIPCHK(ctx, hipMalloc((void**)&dfr, capd));
+    if (F) { HIPCHK(ctx, tmp.get(&dF, 8 * words)); HIPCHK(ctx, hipMemcpyAsync(dF, F, 8 * words, hipMemcpyHostToDevice, ctx->stream)); }
+    if ((rc = up_i64(ctx, tmp, zs, nz, &dz))) return rc;
+    HIPCHK(ctx, tmp.get(&dxs, 8 * capd)); HIPCHK(ctx, tmp.get(&dym, 8 * capd));
+    HIPCHK(ctx, tmp.get(&dcm, 8 * capd)); HIPCHK(ctx, tmp.get(&dfr, capd));
     rc = mpfmt_launch_expand(ctx, dW, dH, dF, dC, dz, nz, dxs, dym, dcm, dfr, cap, nx);
     if (rc == MPFMT_OK && *nx > 0) {
         const int64_t n = *nx;
@@ -521,8 +538,6 @@ int32_t mpfmt_expand(mpfmt_ctx* ctx, const uint64_t* W, const uint64_t* H, const
             if (e != hipSuccess) rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "expand copy back: %s", hipGetErrorString(e));
         }
     }
-    hipFree(dW); hipFree(dH); hipFree(dC); if (dF) hipFree(dF); hipFree(dz);
-    hipFree(dxs); hipFree(dym); hipFree(dcm); hipFree(dfr);
     return rc;
 }
 
@@ -778,9 +793,10 @@ int32_t mpfmt_di_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64
     if (!(rho > 0.0) || !(r > 0.0)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "rho and r must be > 0");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t pb = sizeof(double) * (size_t)n * 2 * m;
+    DevTmp tmp;
     double *d0 = nullptr, *d1 = nullptr, *dc = nullptr, *dt = nullptr;
-    HIPCHK(ctx, hipMalloc((void**)&d0, pb)); HIPCHK(ctx, hipMalloc((void**)&d1, pb));
-    HIPCHK(ctx, hipMalloc((void**)&dc, 8 * n)); HIPCHK(ctx, hipMalloc((void**)&dt, 8 * n));
+    HIPCHK(ctx, tmp.get(&d0, pb)); HIPCHK(ctx, tmp.get(&d1, pb));
+    HIPCHK(ctx, tmp.get(&dc, 8 * n)); HIPCHK(ctx, tmp.get(&dt, 8 * n));
     HIPCHK(ctx, hipMemcpyAsync(d0, X0, pb, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d1, X1, pb, hipMemcpyHostToDevice, ctx->stream));
     int32_t rc = mpfmt_di_steer_launch(ctx, m, d0, d1, n, rho, r, dc, dt);
@@ -790,7 +806,6 @@ int32_t mpfmt_di_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "di_steer copy back: %s", hipGetErrorString(e));
     }
-    hipFree(d0); hipFree(d1); hipFree(dc); hipFree(dt);
     return rc;
 }
 

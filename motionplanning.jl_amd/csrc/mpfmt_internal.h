@@ -130,6 +130,7 @@ struct mpfmt_ctx {
     size_t scratch_bytes = 0;
     std::map<void*, size_t> caps;       // capacity (bytes) of each grow-only device buffer, keyed by member address
     std::map<std::string, mpfmt_timer> timers;
+    void* timer_state = nullptr;         // HIP-event timing records of this ctx (mpfmt_capi.hip)
     bool timing_enabled = true;
     bool rebuild_index = false;          // option "rebuild_index": graph_build_device rebuilds the cell grid every call
 };
