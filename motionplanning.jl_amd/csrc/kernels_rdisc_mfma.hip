@@ -447,52 +447,58 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
             bq[1] = a.ops[(c * 64 + 32 + col) * 2 + kb];
         }
     };
+    // one chunk: 4 independent MFMAs back to back (2 query row blocks x 2 candidate column blocks), sign extraction
+    auto process = [&](int64_t c, const uint4 (&bq)[2]) {
+        tested += 64ull * 64ull;
+        if (a.ablate & 4) { asm volatile("" :: "v"(bq[0].x), "v"(bq[1].x)); return; }
+        f32x16 acc0, acc1, acc2, acc3;
+        if constexpr (K8) {
+            union { uint2 u; half4 h; } bf0, bf1;
+            bf0.u = make_uint2(bq[0].x, bq[0].y); bf1.u = make_uint2(bq[1].x, bq[1].y);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[0], bf0.h, cinit[0], 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[1], bf0.h, cinit[1], 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[0], bf1.h, cinit[0], 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[1], bf1.h, cinit[1], 0, 0, 0);
+        } else {
+            union { uint4 u; half8 h; } bf0, bf1;
+            bf0.u = bq[0]; bf1.u = bq[1];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf0.h, zero16, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf0.h, zero16, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf1.h, zero16, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf1.h, zero16, 0, 0, 0);
+        }
+        uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            h0 = __builtin_amdgcn_alignbit(h0, __float_as_uint(acc0[r]), 31);
+            h1 = __builtin_amdgcn_alignbit(h1, __float_as_uint(acc1[r]), 31);
+            h2 = __builtin_amdgcn_alignbit(h2, __float_as_uint(acc2[r]), 31);
+            h3 = __builtin_amdgcn_alignbit(h3, __float_as_uint(acc3[r]), 31);
+        }
+        const unsigned long long H = (unsigned long long)(h0 | (h1 << 16)) | ((unsigned long long)(h2 | (h3 << 16)) << 32);
+        if (a.ablate & 1) { asm volatile("" :: "v"(H)); } else extract(H, c);
+    };
+    // B fragments are prefetched PF chunks ahead (a ring of PF register sets, statically indexed): the stream is
+    // latency x concurrency bound (L2 / MALL round trips), so more loads in flight per wavefront = more bandwidth.
+    constexpr int PF = K8 ? 4 : 2;
     auto run_list = [&](int n) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (n <= 0 || (a.ablate & 8)) return;
-        uint4 b0[2], b1[2], b2[2];
-        load_b((int64_t)s_list[0], b0);
-        if (n > 1) load_b((int64_t)s_list[1], b1);
-        for (int k = 0; k < n; ++k) {
-            const int64_t c = (int64_t)s_list[k];
-            if (k + 2 < n) load_b((int64_t)s_list[k + 2], b2);        // two chunks ahead, in flight during the MFMAs
-            tested += 64ull * 64ull;
-            if (a.ablate & 4) {
-                asm volatile("" :: "v"(b0[0].x), "v"(b0[1].x));
-                b0[0] = b1[0]; b0[1] = b1[1];
-                b1[0] = b2[0]; b1[1] = b2[1];
-                continue;
-            }
-            // 4 independent MFMAs back to back (2 query row blocks x 2 candidate column blocks)
-            f32x16 acc0, acc1, acc2, acc3;
-            if constexpr (K8) {
-                union { uint2 u; half4 h; } bf0, bf1;
-                bf0.u = make_uint2(b0[0].x, b0[0].y); bf1.u = make_uint2(b0[1].x, b0[1].y);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[0], bf0.h, cinit[0], 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[1], bf0.h, cinit[1], 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[0], bf1.h, cinit[0], 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[1], bf1.h, cinit[1], 0, 0, 0);
-            } else {
-                union { uint4 u; half8 h; } bf0, bf1;
-                bf0.u = b0[0]; bf1.u = b0[1];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf0.h, zero16, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf0.h, zero16, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf1.h, zero16, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf1.h, zero16, 0, 0, 0);
-            }
-            uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+        uint4 ring[PF][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                h0 = __builtin_amdgcn_alignbit(h0, __float_as_uint(acc0[r]), 31);
-                h1 = __builtin_amdgcn_alignbit(h1, __float_as_uint(acc1[r]), 31);
-                h2 = __builtin_amdgcn_alignbit(h2, __float_as_uint(acc2[r]), 31);
-                h3 = __builtin_amdgcn_alignbit(h3, __float_as_uint(acc3[r]), 31);
+        for (int u = 0; u < PF; ++u) if (u < n) load_b((int64_t)s_list[u], ring[u]);
+        for (int k = 0; k < n; k += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (k + u < n) {
+                    const int64_t c = (int64_t)s_list[k + u];
+                    uint4 cur[2];
+                    cur[0] = ring[u][0]; cur[1] = ring[u][1];
+                    if (k + u + PF < n) load_b((int64_t)s_list[k + u + PF], ring[u]);   // in flight during PF chunks of MFMAs
+                    process(c, cur);
+                }
             }
-            const unsigned long long H = (unsigned long long)(h0 | (h1 << 16)) | ((unsigned long long)(h2 | (h3 << 16)) << 32);
-            if (a.ablate & 1) { asm volatile("" :: "v"(H)); } else extract(H, c);
-            b0[0] = b1[0]; b0[1] = b1[1];
-            b1[0] = b2[0]; b1[1] = b2[1];
         }
     };
 
