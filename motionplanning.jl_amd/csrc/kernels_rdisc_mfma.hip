@@ -362,7 +362,6 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
             cinit[rb] = zero16;
         }
     }
-    const double rpad2 = a.rpad * a.rpad;
 
     // ---- refine: exact fp64 test of n queued survivors (lane = survivor) ---------------------------------------
     int qcount = 0;                                           // wave-uniform queue length

@@ -97,6 +97,69 @@ __device__ __forceinline__ void seg_bbox(const double (&v)[D], const double (&w)
     }
 }
 
+// ---- straight-line forms for the graph sweep -----------------------------------------------------------------
+// The && / || forms above short-circuit: when an operand is an LDS read the compiler must keep it behind a branch,
+// which turns a 2*D-term predicate into 2*D serial LDS round trips.  These take the box in registers and combine the
+// IEEE comparisons without control flow (same truth table, including NaN / Inf operands).
+template <int D>
+struct box_regs { double lo[D], hi[D]; };
+
+template <int D>
+__device__ __forceinline__ box_regs<D> load_box(const double* sbox, int k)
+{
+    box_regs<D> b;
+    const double* p = sbox + (int64_t)k * 2 * D;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { b.lo[i] = p[i]; b.hi[i] = p[D + i]; }
+    return b;
+}
+
+template <int D>
+__device__ __forceinline__ bool in_state_space_sl(const double (&v)[D], const mpfmt_ss& ss)
+{
+    if (!ss.has) return true;
+    int ok = 1;
+#pragma unroll
+    for (int i = 0; i < D; ++i) ok &= (int)(ss.lo[i] <= v[i]) & (int)(v[i] <= ss.hi[i]);
+    return ok != 0;
+}
+
+template <int D>
+__device__ __forceinline__ bool broadphase_free_sl(const double (&l)[D], const double (&h)[D], const box_regs<D>& b)
+{
+    int sep = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) sep |= (int)(b.hi[i] < l[i]) | (int)(b.lo[i] > h[i]);
+    return sep != 0;
+}
+
+// is_free_motion(v, w, BB) (boxesND.jl:46-51): face i is hit iff all 2*(D-1) in-range comparisons of the other
+// coordinates hold; they are counted (v_cmp + add-with-carry on the vector ALU) instead of and-ed.
+template <int D>
+__device__ __forceinline__ bool narrow_free_sl(const double (&v)[D], const double (&w)[D], const box_regs<D>& b)
+{
+    double v_to_w[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) v_to_w[i] = w[i] - v[i];
+    int best = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double corner = (v[i] < b.lo[i]) ? b.lo[i] : b.hi[i];        // blend(v .< lo, lo, hi)
+        const double lambda = (corner - v[i]) / v_to_w[i];                 // IEEE: may be +-Inf / NaN
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (j == i) continue;
+            const double prod = v_to_w[j] * lambda;
+            const double x = v[j] + prod;                                  // unfused
+            cnt += (int)(b.lo[j] <= x);
+            cnt += (int)(x <= b.hi[j]);
+        }
+        best = max(best, cnt);
+    }
+    return best != 2 * (D - 1);
+}
+
 // Stage boxes [b0, b0+nb) into LDS (whole workgroup), layout [box][2*D].
 template <int D>
 __device__ __forceinline__ void stage_boxes(double* sbox, const double* __restrict__ boxes, int b0, int nb)
@@ -236,6 +299,24 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_edges_free(const double* __re
     if (lane == 0 && (e - lane) < E) mask[(e - lane) >> 6] = bits;
 }
 
+// lane-uniform values loaded through the vector memory path are moved to SGPRs
+__device__ __forceinline__ int64_t uniform_i64(int64_t v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v);
+    const int hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    return __longlong_as_double(uniform_i64(__double_as_longlong(v)));
+}
+__device__ __forceinline__ int opaque_zero()
+{
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+
 // ---- graph sweep ---------------------------------------------------------------------------------
 // One wavefront per CSC column x (persistent workgroups, boxes staged once): entry e with row y gets
 // bit e = in_state_space(V[y]) && is_free_motion(V[y], V[x]).  All rows lie within rpad of V[x], so the
@@ -255,7 +336,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sbox = (double*)smem;                          // [box][lo(D), hi(D)]  broadcast reads
     double* sboxT = sbox + (int64_t)chunk * 2 * D;         // [2*D][chunk]         cull reads (lane = box)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave id is made provably uniform so the column header (colptr, V[x], the cull box) lives in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t nwaves = (int64_t)gridDim.x * (SWEEP_THREADS / 64);
     const int64_t wid = (int64_t)blockIdx.x * (SWEEP_THREADS / 64) + wave;
 
@@ -268,71 +350,112 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __r
             sboxT[(int64_t)i * chunk + k] = boxes[(int64_t)b0 * 2 * D + t];
         }
         __syncthreads();
-        for (int64_t x = wid; x < N; x += nwaves) {
-            const int64_t beg = colptr[x], end = colptr[x + 1];
-            if (end == beg) continue;
-            double w[D], ulo[D], uhi[D];
+        // Software pipeline.  A column costs a chain of dependent memory round trips (colptr -> row ids -> row states,
+        // plus V[x]); left serial they idle the wavefront for longer than its arithmetic takes.  So:
+        //   - the row ids and row states of the NEXT round (of this column, or the first round of the wave's next
+        //     column) are requested before the current round's slab tests;
+        //   - the header of the next column (V[xn]) and the colptr pair of the one after are requested one column
+        //     ahead, as VECTOR loads (vmcnt is counted in order; scalar loads share lgkmcnt with the LDS box reads and
+        //     would stall them), and moved to SGPRs with readfirstlane when the wave advances.
+        const int vz = opaque_zero();                         // keeps the header loads on the vector memory path
+        int64_t x = wid;
+        int64_t beg = 0, end = 0, nbeg = 0, nend = 0;
+        double w[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) { w[i] = X[x * D + i]; ulo[i] = w[i] - rpad; uhi[i] = w[i] + rpad; }
-            unsigned long long smask[SWEEP_WORDS];
+        for (int i = 0; i < D; ++i) w[i] = 0.0;
+        if (x < N) {
+            beg = colptr[x]; end = colptr[x + 1];
 #pragma unroll
-            for (int c = 0; c < SWEEP_WORDS; ++c) {
-                const int k = c * 64 + lane;
-                bool keep = k < nb;
-                if (keep) {
+            for (int i = 0; i < D; ++i) w[i] = X[x * D + i];
+        }
+        if (x + nwaves < N) { nbeg = colptr[x + nwaves]; nend = colptr[x + nwaves + 1]; }
+        int64_t py;
+        double pv[D];
+        auto request = [&](int64_t e0, int64_t eend, int64_t xcol) {
+            const int64_t e = e0 + lane;
+            py = e < eend ? (int64_t)rowval[e] : xcol;
 #pragma unroll
-                    for (int i = 0; i < D; ++i)
-                        keep = keep && !((sboxT[(int64_t)(D + i) * chunk + k] < ulo[i]) || (sboxT[(int64_t)i * chunk + k] > uhi[i]));
-                }
-                smask[c] = __ballot(keep);
-            }
-            for (int64_t e0 = beg; e0 < end; e0 += 64) {
-                const int64_t e = e0 + lane;
-                const bool active = e < end;
-                double v[D];
-                const int64_t y = active ? rowval[e] : x;
+            for (int i = 0; i < D; ++i) pv[i] = X[py * D + i];
+        };
+        request(beg, end, x < N ? x : 0);
+        while (x < N) {
+            const int64_t xn = x + nwaves, xnn = xn + nwaves;
+            const int64_t xn_ok = xn < N ? xn : x;
+            // header prefetch (vector loads, lane-uniform values)
+            const int64_t cidx = (xnn < N ? xnn : 0) + vz;
+            int64_t c0 = colptr[cidx], c1 = colptr[cidx + 1];
+            if (xnn >= N) { c0 = 0; c1 = 0; }
+            double nwv[D];
 #pragma unroll
-                for (int i = 0; i < D; ++i) v[i] = X[y * D + i];
-                // first chunk decides in_state_space; later chunks can only clear bits
-                bool fr = active && (b0 > 0 || in_state_space<D>(v, ss));
-                double l[D], h[D];
-                seg_bbox<D>(v, w, l, h);
-                int p0 = -1, p1 = -1;                    // boxes whose broad phase this lane failed
+            for (int i = 0; i < D; ++i) nwv[i] = X[(xn_ok + vz) * D + i];
+            if (end == beg) {
+                request(nbeg, nend, xn_ok);
+            } else {
+                double ulo[D], uhi[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) { ulo[i] = w[i] - rpad; uhi[i] = w[i] + rpad; }
+                unsigned long long smask[SWEEP_WORDS];
 #pragma unroll
                 for (int c = 0; c < SWEEP_WORDS; ++c) {
-                    unsigned long long m = smask[c];
-                    while (m) {
-                        const int k = c * 64 + (__ffsll((long long)m) - 1);
-                        m &= m - 1;
-                        const double* lo = sbox + (int64_t)k * 2 * D;
-                        if (fr && !broadphase_free<D>(l, h, lo, lo + D)) {
-                            if (p0 < 0) p0 = k;
-                            else if (p1 < 0) p1 = k;
-                            else fr = narrow_free<D>(v, w, lo, lo + D);      // third pending box: rare, test in place
+                    const int k = c * 64 + lane;
+                    int out = 0;                             // k < chunk: always inside the staged array
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+                        out |= (int)(sboxT[(int64_t)(D + i) * chunk + k] < ulo[i]) | (int)(sboxT[(int64_t)i * chunk + k] > uhi[i]);
+                    smask[c] = __ballot(k < nb && !out);
+                }
+                for (int64_t e0 = beg; e0 < end; e0 += 64) {
+                    const bool active = e0 + lane < end;
+                    double v[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) v[i] = pv[i];
+                    if (e0 + 64 < end) request(e0 + 64, end, x);
+                    else request(nbeg, nend, xn_ok);
+                    // first chunk decides in_state_space; later chunks can only clear bits
+                    bool fr = active && (b0 > 0 || in_state_space_sl<D>(v, ss));
+                    double l[D], h[D];
+                    seg_bbox<D>(v, w, l, h);
+                    int p0 = -1, p1 = -1;                    // boxes whose broad phase this lane failed
+#pragma unroll
+                    for (int c = 0; c < SWEEP_WORDS; ++c) {
+                        unsigned long long m = smask[c];
+                        while (m) {
+                            const int k = c * 64 + (__ffsll((long long)m) - 1);
+                            m &= m - 1;
+                            const box_regs<D> bx = load_box<D>(sbox, k);              // wave-uniform k: broadcast reads
+                            if (fr && !broadphase_free_sl<D>(l, h, bx)) {
+                                if (p0 < 0) p0 = k;
+                                else if (p1 < 0) p1 = k;
+                                else fr = narrow_free_sl<D>(v, w, bx);           // third pending box: rare, test in place
+                            }
                         }
                     }
-                }
-                if (__ballot(fr && p0 >= 0)) {
-                    if (fr && p0 >= 0) { const double* lo = sbox + (int64_t)p0 * 2 * D; fr = narrow_free<D>(v, w, lo, lo + D); }
-                    if (__ballot(fr && p1 >= 0)) {
-                        if (fr && p1 >= 0) { const double* lo = sbox + (int64_t)p1 * 2 * D; fr = narrow_free<D>(v, w, lo, lo + D); }
+                    if (__ballot(fr && p0 >= 0)) {
+                        if (fr && p0 >= 0) fr = narrow_free_sl<D>(v, w, load_box<D>(sbox, p0));
+                        if (__ballot(fr && p1 >= 0)) {
+                            if (fr && p1 >= 0) fr = narrow_free_sl<D>(v, w, load_box<D>(sbox, p1));
+                        }
                     }
-                }
-                const unsigned long long bits = __ballot(fr);
-                const int sh = (int)(e0 & 63);
-                const int64_t wd = e0 >> 6;
-                if (b0 > 0) {
-                    // multi-chunk obstacle sets: AND with what earlier chunks left
-                    const unsigned long long keepm = bits | ~__ballot(active);
-                    if (lane == 0) {
-                        atomicAnd(&mask[wd], (keepm << sh) | ((1ull << sh) - 1ull));
-                        if (sh && ((end - 1) >> 6) > wd) atomicAnd(&mask[wd + 1], (keepm >> (64 - sh)) | ~((1ull << sh) - 1ull));
+                    const unsigned long long bits = __ballot(fr);
+                    const int sh = (int)(e0 & 63);
+                    const int64_t wd = e0 >> 6;
+                    if (b0 > 0) {
+                        // multi-chunk obstacle sets: AND with what earlier chunks left
+                        const unsigned long long keepm = bits | ~__ballot(active);
+                        if (lane == 0) {
+                            atomicAnd(&mask[wd], (keepm << sh) | ((1ull << sh) - 1ull));
+                            if (sh && ((end - 1) >> 6) > wd) atomicAnd(&mask[wd + 1], (keepm >> (64 - sh)) | ~((1ull << sh) - 1ull));
+                        }
+                    } else if (lane == 0 && bits) {
+                        atomicOr(&mask[wd], bits << sh);
+                        if (sh && (bits >> (64 - sh))) atomicOr(&mask[wd + 1], bits >> (64 - sh));
                     }
-                } else if (lane == 0 && bits) {
-                    atomicOr(&mask[wd], bits << sh);
-                    if (sh && (bits >> (64 - sh))) atomicOr(&mask[wd + 1], bits >> (64 - sh));
                 }
             }
+            x = xn; beg = nbeg; end = nend;
+            nbeg = uniform_i64(c0); nend = uniform_i64(c1);
+#pragma unroll
+            for (int i = 0; i < D; ++i) w[i] = uniform_f64(nwv[i]);
         }
         if (M == 0) break;
     }
