@@ -299,49 +299,64 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_edges_free(const double* __re
     if (lane == 0 && (e - lane) < E) mask[(e - lane) >> 6] = bits;
 }
 
-// lane-uniform values loaded through the vector memory path are moved to SGPRs
-__device__ __forceinline__ int64_t uniform_i64(int64_t v)
+// wave-uniform lane reads (results live in SGPRs)
+__device__ __forceinline__ int64_t lane_i64(int64_t v, int l)
 {
-    const int lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v);
-    const int hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, l);
+    const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l);
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
-__device__ __forceinline__ double uniform_f64(double v)
+__device__ __forceinline__ double lane_f64(double v, int l)
 {
-    return __longlong_as_double(uniform_i64(__double_as_longlong(v)));
-}
-__device__ __forceinline__ int opaque_zero()
-{
-    int z;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-    return z;
+    return __longlong_as_double(lane_i64(__double_as_longlong(v), l));
 }
 
 // ---- graph sweep ---------------------------------------------------------------------------------
-// One wavefront per CSC column x (persistent workgroups, boxes staged once): entry e with row y gets
-// bit e = in_state_space(V[y]) && is_free_motion(V[y], V[x]).  All rows lie within rpad of V[x], so the
-// cull box is V[x] +- rpad (~2.5 % of the boxes survive at the north-star workload).
+// Bit e of the mask = in_state_space(V[y]) && is_free_motion(V[y], V[x]) for CSC entry e = (row y, column x).
+// All rows of a column lie within rpad of V[x], so the cull box is V[x] +- rpad (~2.5 % of the boxes survive at the
+// north-star workload).  Work is handed out in TASKS of SWEEP_TC consecutive columns (a dynamic counter), one
+// wavefront per task, 64 entries ("a round") at a time within a column:
+//   - the task header -- the SWEEP_TC+1 column pointers and the SWEEP_TC column states -- is one coalesced load held in
+//     registers (lane = column); per-column values are read out with v_readlane, so a column costs no memory round trip
+//     of its own.  The header of the next task is requested while the current one is processed (two register sets);
+//   - the dependent chain row ids -> row states is software-pipelined over rounds: row ids are requested two rounds
+//     ahead, the 8*D-byte row-state gathers one round ahead, both before the current round's arithmetic.  The round
+//     sequence (column, first entry) is wave-uniform scalar state that is advanced ahead of the arithmetic; an empty
+//     column counts as one null round so the look-ahead never leaves the two resident headers;
 //   - the cull reads a transposed (SoA) copy of the boxes: lane k reads box k's i-th bound at [i][k], conflict free;
-//   - rounds of 64 consecutive entries start at the column's first entry (no idle lanes in front); the 64 result
-//     bits are shifted into the two mask words they straddle (atomicOr, the mask is zeroed before the launch);
-//   - the narrow phase is deferred: each lane remembers the (at most two) boxes whose broad phase it failed and
-//     the exact slab test runs once per round for all lanes together, instead of once per surviving box with
-//     a handful of live lanes.
+//   - the mask is preset to ones; a round clears the bits of its blocked entries in the two words they straddle (atomicAnd);
+//   - the narrow phase is deferred: each lane remembers the (at most two) boxes whose broad phase it failed and the
+//     exact slab test runs once per round for all lanes together;
+//   - predicates are the straight-line forms on register-held boxes (see above).
+#define SWEEP_TC 16
+
+struct sweep_round {
+    int valid, first, hs, c;          // hs: which of the two resident task headers; c: column within the task
+    int64_t t, e0, end;               // task id, first entry of the round, end of the column
+};
+
+template <int D>
+struct sweep_hdr { int64_t cp; double w[D]; };
+
 template <int D>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
                                                                const int32_t* __restrict__ rowval, int64_t N, double rpad,
                                                                const double* __restrict__ boxes, int M, int chunk,
-                                                               mpfmt_ss ss, unsigned long long* __restrict__ mask)
+                                                               mpfmt_ss ss, unsigned long long* __restrict__ mask,
+                                                               int* __restrict__ task_ctr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sbox = (double*)smem;                          // [box][lo(D), hi(D)]  broadcast reads
     double* sboxT = sbox + (int64_t)chunk * 2 * D;         // [2*D][chunk]         cull reads (lane = box)
-    // the wave id is made provably uniform so the column header (colptr, V[x], the cull box) lives in SGPRs
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int64_t nwaves = (int64_t)gridDim.x * (SWEEP_THREADS / 64);
-    const int64_t wid = (int64_t)blockIdx.x * (SWEEP_THREADS / 64) + wave;
+    const int lane = threadIdx.x & 63;
+    const int64_t ntasks = (N + SWEEP_TC - 1) / SWEEP_TC;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {               // padding bits of the last word are zero
+        const int64_t nnz = colptr[N];
+        if (nnz & 63) atomicAnd(&mask[nnz >> 6], (1ull << (nnz & 63)) - 1ull);
+    }
 
-    for (int b0 = 0; b0 < M || b0 == 0; b0 += chunk) {
+    int ci = 0;
+    for (int b0 = 0; b0 < M || b0 == 0; b0 += chunk, ++ci) {
         const int nb = max(0, min(chunk, M - b0));
         __syncthreads();
         stage_boxes<D>(sbox, boxes, b0, nb);
@@ -350,112 +365,154 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __r
             sboxT[(int64_t)i * chunk + k] = boxes[(int64_t)b0 * 2 * D + t];
         }
         __syncthreads();
-        // Software pipeline.  A column costs a chain of dependent memory round trips (colptr -> row ids -> row states,
-        // plus V[x]); left serial they idle the wavefront for longer than its arithmetic takes.  So:
-        //   - the row ids and row states of the NEXT round (of this column, or the first round of the wave's next
-        //     column) are requested before the current round's slab tests;
-        //   - the header of the next column (V[xn]) and the colptr pair of the one after are requested one column
-        //     ahead, as VECTOR loads (vmcnt is counted in order; scalar loads share lgkmcnt with the LDS box reads and
-        //     would stall them), and moved to SGPRs with readfirstlane when the wave advances.
-        const int vz = opaque_zero();                         // keeps the header loads on the vector memory path
-        int64_t x = wid;
-        int64_t beg = 0, end = 0, nbeg = 0, nend = 0;
-        double w[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) w[i] = 0.0;
-        if (x < N) {
-            beg = colptr[x]; end = colptr[x + 1];
-#pragma unroll
-            for (int i = 0; i < D; ++i) w[i] = X[x * D + i];
-        }
-        if (x + nwaves < N) { nbeg = colptr[x + nwaves]; nend = colptr[x + nwaves + 1]; }
-        int64_t py;
-        double pv[D];
-        auto request = [&](int64_t e0, int64_t eend, int64_t xcol) {
-            const int64_t e = e0 + lane;
-            py = e < eend ? (int64_t)rowval[e] : xcol;
-#pragma unroll
-            for (int i = 0; i < D; ++i) pv[i] = X[py * D + i];
+
+        int* ctr = task_ctr + ci;
+        auto grab = [&]() -> int64_t {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(ctr, 1);
+            return (int64_t)__builtin_amdgcn_readfirstlane(t);
         };
-        request(beg, end, x < N ? x : 0);
-        while (x < N) {
-            const int64_t xn = x + nwaves, xnn = xn + nwaves;
-            const int64_t xn_ok = xn < N ? xn : x;
-            // header prefetch (vector loads, lane-uniform values)
-            const int64_t cidx = (xnn < N ? xnn : 0) + vz;
-            int64_t c0 = colptr[cidx], c1 = colptr[cidx + 1];
-            if (xnn >= N) { c0 = 0; c1 = 0; }
-            double nwv[D];
+        sweep_hdr<D> H0, H1;
+        auto load_hdr = [&](int64_t t, sweep_hdr<D>& h) {
+            const int64_t x = t * SWEEP_TC + lane;
+            h.cp = colptr[x < N ? x : N];
+            const int64_t xr = x < N ? x : N - 1;
 #pragma unroll
-            for (int i = 0; i < D; ++i) nwv[i] = X[(xn_ok + vz) * D + i];
-            if (end == beg) {
-                request(nbeg, nend, xn_ok);
-            } else {
-                double ulo[D], uhi[D];
+            for (int i = 0; i < D; ++i) h.w[i] = X[xr * D + i];
+        };
+        int64_t tset0 = grab(), tset1 = -1;
+        if (tset0 >= ntasks) continue;                       // (uniform) nothing left for this wave
+        load_hdr(tset0, H0);
+        auto col_range = [&](const sweep_round& r, int64_t& beg, int64_t& end) {
+            const int64_t b0_ = lane_i64(H0.cp, r.c), e0_ = lane_i64(H0.cp, r.c + 1);
+            const int64_t b1_ = lane_i64(H1.cp, r.c), e1_ = lane_i64(H1.cp, r.c + 1);
+            beg = r.hs ? b1_ : b0_;
+            end = r.hs ? e1_ : e0_;
+        };
+        auto enter_col = [&](sweep_round& r) {
+            int64_t beg, end;
+            col_range(r, beg, end);
+            r.e0 = beg; r.end = end; r.first = 1;
+        };
+        // next round in sequence; crossing into the other header's task reads the task id it was loaded for
+        auto advance = [&](sweep_round& r) {
+            if (r.e0 + 64 < r.end) { r.e0 += 64; r.first = 0; return; }
+            r.c += 1;
+            if (r.c >= SWEEP_TC || r.t * SWEEP_TC + r.c >= N) {
+                r.hs ^= 1;
+                r.t = r.hs ? tset1 : tset0;
+                r.c = 0;
+                if (r.t < 0 || r.t >= ntasks) { r.valid = 0; r.e0 = r.end = 0; r.first = 0; return; }
+            }
+            enter_col(r);
+        };
+        auto request_rows = [&](const sweep_round& r) -> int32_t {
+            const int64_t e = r.e0 + lane;
+            return (r.valid && e < r.end) ? rowval[e] : 0;
+        };
+        auto request_states = [&](int32_t y, double (&pv)[D]) {
 #pragma unroll
-                for (int i = 0; i < D; ++i) { ulo[i] = w[i] - rpad; uhi[i] = w[i] + rpad; }
-                unsigned long long smask[SWEEP_WORDS];
+            for (int i = 0; i < D; ++i) pv[i] = X[(int64_t)y * D + i];
+        };
+
+        sweep_round R0;
+        R0.valid = 1; R0.hs = 0; R0.c = 0; R0.t = tset0; R0.first = 1; R0.e0 = R0.end = 0;
+        enter_col(R0);
+        int32_t py0 = request_rows(R0);
+        sweep_round R1 = R0;
+        // the second header must be resident before the look-ahead can cross into it
+        tset1 = grab();
+        if (tset1 < ntasks) load_hdr(tset1, H1);
+        int entered = 1;                                      // R0's task already has its successor requested
+        advance(R1);
+        int32_t py1 = request_rows(R1);
+        double pv0[D], pv1[D];
+        request_states(py0, pv0);
+
+        double w[D], ulo[D], uhi[D];
+        unsigned long long smask[SWEEP_WORDS];
 #pragma unroll
-                for (int c = 0; c < SWEEP_WORDS; ++c) {
-                    const int k = c * 64 + lane;
-                    int out = 0;                             // k < chunk: always inside the staged array
+        for (int i = 0; i < D; ++i) w[i] = ulo[i] = uhi[i] = 0.0;
 #pragma unroll
-                    for (int i = 0; i < D; ++i)
-                        out |= (int)(sboxT[(int64_t)(D + i) * chunk + k] < ulo[i]) | (int)(sboxT[(int64_t)i * chunk + k] > uhi[i]);
-                    smask[c] = __ballot(k < nb && !out);
+        for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] = 0;
+
+        while (R0.valid) {
+            // entering a task: hand its predecessor's header set to the task after it
+            if (R0.first && R0.c == 0) {
+                if (!entered) {
+                    const int64_t tn = grab();
+                    if (R0.hs) { tset0 = tn; if (tn < ntasks) load_hdr(tn, H0); }
+                    else       { tset1 = tn; if (tn < ntasks) load_hdr(tn, H1); }
                 }
-                for (int64_t e0 = beg; e0 < end; e0 += 64) {
-                    const bool active = e0 + lane < end;
-                    double v[D];
+                entered = 0;
+            }
+            sweep_round R2 = R1;
+            advance(R2);
+            const int32_t py2 = request_rows(R2);
+            request_states(py1, pv1);
+
+            if (R0.e0 < R0.end) {
+                if (R0.first) {
 #pragma unroll
-                    for (int i = 0; i < D; ++i) v[i] = pv[i];
-                    if (e0 + 64 < end) request(e0 + 64, end, x);
-                    else request(nbeg, nend, xn_ok);
-                    // first chunk decides in_state_space; later chunks can only clear bits
-                    bool fr = active && (b0 > 0 || in_state_space_sl<D>(v, ss));
-                    double l[D], h[D];
-                    seg_bbox<D>(v, w, l, h);
-                    int p0 = -1, p1 = -1;                    // boxes whose broad phase this lane failed
+                    for (int i = 0; i < D; ++i) {
+                        const double a = lane_f64(H0.w[i], R0.c), b = lane_f64(H1.w[i], R0.c);
+                        w[i] = R0.hs ? b : a;
+                        ulo[i] = w[i] - rpad; uhi[i] = w[i] + rpad;
+                    }
 #pragma unroll
                     for (int c = 0; c < SWEEP_WORDS; ++c) {
-                        unsigned long long m = smask[c];
-                        while (m) {
-                            const int k = c * 64 + (__ffsll((long long)m) - 1);
-                            m &= m - 1;
-                            const box_regs<D> bx = load_box<D>(sbox, k);              // wave-uniform k: broadcast reads
-                            if (fr && !broadphase_free_sl<D>(l, h, bx)) {
-                                if (p0 < 0) p0 = k;
-                                else if (p1 < 0) p1 = k;
-                                else fr = narrow_free_sl<D>(v, w, bx);           // third pending box: rare, test in place
-                            }
-                        }
-                    }
-                    if (__ballot(fr && p0 >= 0)) {
-                        if (fr && p0 >= 0) fr = narrow_free_sl<D>(v, w, load_box<D>(sbox, p0));
-                        if (__ballot(fr && p1 >= 0)) {
-                            if (fr && p1 >= 0) fr = narrow_free_sl<D>(v, w, load_box<D>(sbox, p1));
-                        }
-                    }
-                    const unsigned long long bits = __ballot(fr);
-                    const int sh = (int)(e0 & 63);
-                    const int64_t wd = e0 >> 6;
-                    if (b0 > 0) {
-                        // multi-chunk obstacle sets: AND with what earlier chunks left
-                        const unsigned long long keepm = bits | ~__ballot(active);
-                        if (lane == 0) {
-                            atomicAnd(&mask[wd], (keepm << sh) | ((1ull << sh) - 1ull));
-                            if (sh && ((end - 1) >> 6) > wd) atomicAnd(&mask[wd + 1], (keepm >> (64 - sh)) | ~((1ull << sh) - 1ull));
-                        }
-                    } else if (lane == 0 && bits) {
-                        atomicOr(&mask[wd], bits << sh);
-                        if (sh && (bits >> (64 - sh))) atomicOr(&mask[wd + 1], bits >> (64 - sh));
+                        const int k = c * 64 + lane;
+                        int out = 0;                             // k < chunk: always inside the staged array
+#pragma unroll
+                        for (int i = 0; i < D; ++i)
+                            out |= (int)(sboxT[(int64_t)(D + i) * chunk + k] < ulo[i]) | (int)(sboxT[(int64_t)i * chunk + k] > uhi[i]);
+                        smask[c] = __ballot(k < nb && !out);
                     }
                 }
-            }
-            x = xn; beg = nbeg; end = nend;
-            nbeg = uniform_i64(c0); nend = uniform_i64(c1);
+                const int64_t e0 = R0.e0, end = R0.end;
+                const bool active = e0 + lane < end;
+                double v[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) w[i] = uniform_f64(nwv[i]);
+                for (int i = 0; i < D; ++i) v[i] = pv0[i];
+                // first chunk decides in_state_space; later chunks can only clear bits
+                bool fr = active && (b0 > 0 || in_state_space_sl<D>(v, ss));
+                double l[D], h[D];
+                seg_bbox<D>(v, w, l, h);
+                int p0 = -1, p1 = -1;                    // boxes whose broad phase this lane failed
+#pragma unroll
+                for (int c = 0; c < SWEEP_WORDS; ++c) {
+                    unsigned long long m = smask[c];
+                    while (m) {
+                        const int k = c * 64 + (__ffsll((long long)m) - 1);
+                        m &= m - 1;
+                        const box_regs<D> bx = load_box<D>(sbox, k);              // wave-uniform k: broadcast reads
+                        if (fr && !broadphase_free_sl<D>(l, h, bx)) {
+                            if (p0 < 0) p0 = k;
+                            else if (p1 < 0) p1 = k;
+                            else fr = narrow_free_sl<D>(v, w, bx);           // third pending box: rare, test in place
+                        }
+                    }
+                }
+                if (__ballot(fr && p0 >= 0)) {
+                    if (fr && p0 >= 0) fr = narrow_free_sl<D>(v, w, load_box<D>(sbox, p0));
+                    if (__ballot(fr && p1 >= 0)) {
+                        if (fr && p1 >= 0) fr = narrow_free_sl<D>(v, w, load_box<D>(sbox, p1));
+                    }
+                }
+                const unsigned long long bits = __ballot(fr);
+                const int sh = (int)(e0 & 63);
+                const int64_t wd = e0 >> 6;
+                // the mask starts all-ones and every obstacle chunk only clears bits, so chunks (and the waves that
+                // happen to claim a task in each of them) commute
+                const unsigned long long clr = ~bits & __ballot(active);
+                if (lane == 0 && clr) {
+                    atomicAnd(&mask[wd], ~(clr << sh));
+                    if (sh && (clr >> (64 - sh))) atomicAnd(&mask[wd + 1], ~(clr >> (64 - sh)));
+                }
+            }
+            R0 = R1; R1 = R2; py1 = py2;
+#pragma unroll
+            for (int i = 0; i < D; ++i) pv0[i] = pv1[i];
         }
         if (M == 0) break;
     }
@@ -570,18 +627,27 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
     const int64_t words = (ctx->nnz + 63) / 64;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->graph_free, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1)))) return rc;
     mpfmt_time_begin(ctx);
-    HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
+    // preset to ones (the sweep clears blocked entries); an empty graph keeps one zero word
+    HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, ctx->nnz > 0 ? 0xFF : 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
     if (ctx->nnz > 0) {
         const int d = ctx->d;
         const int waves = SWEEP_THREADS / 64;
         const int chunk = box_chunk(ctx->M, d, true);
         const size_t lds = 2 * sweep_lds(chunk, d);              // AoS copy + transposed (SoA) copy of the staged boxes
         const double rpad = ctx->graph_r * (1.0 + 1e-9) + 1e-300;
-        // persistent workgroups: boxes are staged once per workgroup, columns are grid-strided
-        const unsigned nb = (unsigned)std::min<int64_t>((ctx->N + waves - 1) / waves, 256 * 8);
+        // persistent workgroups (one resident set): boxes are staged once per workgroup, tasks of SWEEP_TC columns
+        // are claimed from a counter per obstacle chunk
+        const int nchunks = std::max(1, (ctx->M + chunk - 1) / chunk);
+        if ((rc = mpfmt_ensure(ctx, (void**)&ctx->sweep_ctr, sizeof(int) * (size_t)nchunks))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->sweep_ctr, 0, sizeof(int) * (size_t)nchunks, ctx->stream));
+        const int64_t ntasks = (ctx->N + SWEEP_TC - 1) / SWEEP_TC;
+        int per_cu = 0;
+        DISPATCH_D(d, HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_graph_sweep<DD>, SWEEP_THREADS, lds)));
+        const unsigned nb = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ntasks + waves - 1) / waves,
+                                                                             (int64_t)std::max(per_cu, 1) * ctx->num_cus));
         DISPATCH_D(d, hipLaunchKernelGGL((k_graph_sweep<DD>), dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream,
                                          ctx->Xo, ctx->colptr, ctx->rowval, ctx->N, rpad, ctx->boxes, ctx->M, chunk,
-                                         ctx->ss, (unsigned long long*)ctx->graph_free));
+                                         ctx->ss, (unsigned long long*)ctx->graph_free, ctx->sweep_ctr));
         HIPCHK(ctx, hipGetLastError());
     }
     mpfmt_time_end(ctx, "sweep_graph");

@@ -85,6 +85,8 @@ struct mpfmt_ctx {
     int32_t rdisc_path_used = 0;
     int32_t mf_xcd_mode = 512;
     int32_t mf_ablate = 0;               // timing experiments only
+    int32_t num_cus = 256;               // compute units of the device (persistent-grid sizing)
+    int* sweep_ctr = nullptr;            // graph sweep: one task counter per obstacle chunk
     int64_t mf_target_items = 70000;     // work items (tile x slice) the MFMA path aims for
     float mf_negT = 0.f;
     void* lists = nullptr;               // [shard tiles][list_cap] candidate chunk ids per tile
