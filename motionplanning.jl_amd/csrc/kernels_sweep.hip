@@ -25,6 +25,7 @@
 
 #define SWEEP_THREADS 256
 #define SWEEP_LDS_BYTES (60 * 1024)
+#define SWEEP_CHUNK 256          // boxes per LDS stage of the culled kernels (= row stride of the SoA staging)
 
 // ---- exact predicates -----------------------------------------------------------------------------
 
@@ -160,6 +161,18 @@ __device__ __forceinline__ bool narrow_free_sl(const double (&v)[D], const doubl
     return best != 2 * (D - 1);
 }
 
+// box k of the transposed (SoA) staging [2*D][SWEEP_CHUNK] (fixed row stride: one address register, the bound index
+// is an immediate offset): uniform k = broadcast reads, per-lane k = gather
+template <int D>
+__device__ __forceinline__ box_regs<D> load_box_T(const double* sboxT, int k)
+{
+    box_regs<D> b;
+    const double* p = sboxT + k;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { b.lo[i] = p[i * SWEEP_CHUNK]; b.hi[i] = p[(D + i) * SWEEP_CHUNK]; }
+    return b;
+}
+
 // Stage boxes [b0, b0+nb) into LDS (whole workgroup), layout [box][2*D].
 template <int D>
 __device__ __forceinline__ void stage_boxes(double* sbox, const double* __restrict__ boxes, int b0, int nb)
@@ -170,7 +183,6 @@ __device__ __forceinline__ void stage_boxes(double* sbox, const double* __restri
 
 // Wave-level cull of nb (<= SWEEP_CHUNK) staged boxes against the union box [ulo, uhi] of the
 // wavefront's segments.  Survivor words stay in (wave-uniform) registers.
-#define SWEEP_CHUNK 256
 #define SWEEP_WORDS (SWEEP_CHUNK / 64)
 template <int D>
 __device__ __forceinline__ void cull_boxes(const double* sbox, int nb, const double (&ulo)[D], const double (&uhi)[D],
@@ -323,12 +335,17 @@ __device__ __forceinline__ double lane_f64(double v, int l)
 //     ahead, the 8*D-byte row-state gathers one round ahead, both before the current round's arithmetic.  The round
 //     sequence (column, first entry) is wave-uniform scalar state that is advanced ahead of the arithmetic; an empty
 //     column counts as one null round so the look-ahead never leaves the two resident headers;
-//   - the cull reads a transposed (SoA) copy of the boxes: lane k reads box k's i-th bound at [i][k], conflict free;
+//   - boxes are staged transposed (SoA, [bound][box]): the cull reads lane k = box k conflict free, the broad phase
+//     reads one box by broadcast;
 //   - the mask is preset to ones; a round clears the bits of its blocked entries in the two words they straddle (atomicAnd);
-//   - the narrow phase is deferred: each lane remembers the (at most two) boxes whose broad phase it failed and the
-//     exact slab test runs once per round for all lanes together;
+//   - the narrow phase is COMPACTED: only ~1 entry in 5 fails a broad phase, so running the exact slab test in the
+//     round that found it would use a fifth of the lanes.  A lane instead pushes (row state, entry, column, box) to
+//     its wave's LDS queue and reports the entry free for now; whenever 64 items are queued one full-width pass
+//     tests them (lane = item, the column state comes from the task header by lane exchange) and clears the bits of
+//     the blocked ones.  The queue is flushed before the task header is recycled;
 //   - predicates are the straight-line forms on register-held boxes (see above).
 #define SWEEP_TC 16
+#define SWEEP_QCAP 128
 
 struct sweep_round {
     int valid, first, hs, c;          // hs: which of the two resident task headers; c: column within the task
@@ -336,19 +353,23 @@ struct sweep_round {
 };
 
 template <int D>
-struct sweep_hdr { int64_t cp; double w[D]; };
+struct sweep_hdr { int64_t cp; double w[D]; };              // lane = column of the task: first entry, state
 
 template <int D>
-__global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
+__global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 1)) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
                                                                const int32_t* __restrict__ rowval, int64_t N, double rpad,
                                                                const double* __restrict__ boxes, int M, int chunk,
                                                                mpfmt_ss ss, unsigned long long* __restrict__ mask,
                                                                int* __restrict__ task_ctr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sbox = (double*)smem;                          // [box][lo(D), hi(D)]  broadcast reads
-    double* sboxT = sbox + (int64_t)chunk * 2 * D;         // [2*D][chunk]         cull reads (lane = box)
+    double* sboxT = (double*)smem;                         // [2*D][SWEEP_CHUNK]
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // per-wave narrow-phase queue (SoA): row state [D][QCAP], entry offset within the task, (column << 16 | box)
+    double* qv = sboxT + (int64_t)SWEEP_CHUNK * 2 * D + (int64_t)wave * (D + 1) * SWEEP_QCAP;
+    uint32_t* qe = (uint32_t*)(qv + (int64_t)D * SWEEP_QCAP);
+    uint32_t* qk = qe + SWEEP_QCAP;
     const int64_t ntasks = (N + SWEEP_TC - 1) / SWEEP_TC;
     if (blockIdx.x == 0 && threadIdx.x == 0) {               // padding bits of the last word are zero
         const int64_t nnz = colptr[N];
@@ -359,10 +380,9 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __r
     for (int b0 = 0; b0 < M || b0 == 0; b0 += chunk, ++ci) {
         const int nb = max(0, min(chunk, M - b0));
         __syncthreads();
-        stage_boxes<D>(sbox, boxes, b0, nb);
         for (int t = threadIdx.x; t < nb * 2 * D; t += blockDim.x) {
             const int k = t / (2 * D), i = t - k * 2 * D;
-            sboxT[(int64_t)i * chunk + k] = boxes[(int64_t)b0 * 2 * D + t];
+            sboxT[i * SWEEP_CHUNK + k] = boxes[(int64_t)b0 * 2 * D + t];
         }
         __syncthreads();
 
@@ -415,6 +435,47 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __r
             for (int i = 0; i < D; ++i) pv[i] = X[(int64_t)y * D + i];
         };
 
+        // ---- narrow-phase queue ----
+        int qcount = 0;                                       // wave-uniform
+        auto push = [&](bool pred, const double (&v)[D], uint32_t eoff, uint32_t ck) {
+            const unsigned long long m = __ballot(pred);
+            if (m == 0) return;
+            const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (pred) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) qv[i * SWEEP_QCAP + pos] = v[i];
+                qe[pos] = eoff; qk[pos] = ck;
+            }
+            qcount += __popcll(m);
+        };
+        // test the last n (<= 64) queued items, lane = item; hs = header set of the task they belong to
+        auto drain = [&](int n, int hs) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int idx = qcount - n + lane;
+            const bool on = lane < n;
+            const int qi = on ? idx : 0;
+            double v[D], w[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) v[i] = qv[i * SWEEP_QCAP + qi];
+            const uint32_t eoff = qe[qi], ck = qk[qi];
+            const int c = on ? (int)(ck >> 16) : 0, k = on ? (int)(ck & 0xffffu) : 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double a = __shfl(H0.w[i], c), b = __shfl(H1.w[i], c);
+                w[i] = hs ? b : a;
+            }
+            const int64_t ebase = hs ? __shfl(H1.cp, c) : __shfl(H0.cp, c);
+            const bool free_ = narrow_free_sl<D>(v, w, load_box_T<D>(sboxT, k));
+            if (on && !free_) {
+                const int64_t e = ebase + (int64_t)eoff;
+                atomicAnd(&mask[e >> 6], ~(1ull << (e & 63)));
+            }
+            qcount -= n;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+
         sweep_round R0;
         R0.valid = 1; R0.hs = 0; R0.c = 0; R0.t = tset0; R0.first = 1; R0.e0 = R0.end = 0;
         enter_col(R0);
@@ -436,7 +497,13 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __r
 #pragma unroll
         for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] = 0;
 
-        while (R0.valid) {
+        int hs_q = 0;                                         // header set of the task the queued items belong to
+        while (true) {
+            // the one place queued exact tests run (few live registers here): full passes, and a flush of the
+            // remainder before the header of the task they belong to is recycled / at the end
+            const bool flush = !R0.valid || (R0.first && R0.c == 0 && !entered);
+            while (qcount >= 64 || (flush && qcount > 0)) drain(min(qcount, 64), hs_q);
+            if (!R0.valid) break;
             // entering a task: hand its predecessor's header set to the task after it
             if (R0.first && R0.c == 0) {
                 if (!entered) {
@@ -462,10 +529,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __r
 #pragma unroll
                     for (int c = 0; c < SWEEP_WORDS; ++c) {
                         const int k = c * 64 + lane;
-                        int out = 0;                             // k < chunk: always inside the staged array
+                        const box_regs<D> bx = load_box_T<D>(sboxT, k);      // k < SWEEP_CHUNK: inside the staged array
+                        int out = 0;
 #pragma unroll
-                        for (int i = 0; i < D; ++i)
-                            out |= (int)(sboxT[(int64_t)(D + i) * chunk + k] < ulo[i]) | (int)(sboxT[(int64_t)i * chunk + k] > uhi[i]);
+                        for (int i = 0; i < D; ++i) out |= (int)(bx.hi[i] < ulo[i]) | (int)(bx.lo[i] > uhi[i]);
                         smask[c] = __ballot(k < nb && !out);
                     }
                 }
@@ -485,19 +552,23 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_graph_sweep(const double* __r
                     while (m) {
                         const int k = c * 64 + (__ffsll((long long)m) - 1);
                         m &= m - 1;
-                        const box_regs<D> bx = load_box<D>(sbox, k);              // wave-uniform k: broadcast reads
-                        if (fr && !broadphase_free_sl<D>(l, h, bx)) {
-                            if (p0 < 0) p0 = k;
-                            else if (p1 < 0) p1 = k;
-                            else fr = narrow_free_sl<D>(v, w, bx);           // third pending box: rare, test in place
+                        const box_regs<D> bx = load_box_T<D>(sboxT, k);           // wave-uniform k: broadcast reads
+                        const bool pend = fr & !broadphase_free_sl<D>(l, h, bx);
+                        const bool third = pend & (p1 >= 0);
+                        p1 = (pend & (p0 >= 0) & (p1 < 0)) ? k : p1;
+                        p0 = (pend & (p0 < 0)) ? k : p0;
+                        if (__ballot(third)) {                                     // third pending box: rare, test in place
+                            if (third) fr = narrow_free_sl<D>(v, w, bx);
                         }
                     }
                 }
-                if (__ballot(fr && p0 >= 0)) {
-                    if (fr && p0 >= 0) fr = narrow_free_sl<D>(v, w, load_box<D>(sbox, p0));
-                    if (__ballot(fr && p1 >= 0)) {
-                        if (fr && p1 >= 0) fr = narrow_free_sl<D>(v, w, load_box<D>(sbox, p1));
-                    }
+                // queue the pending exact tests (the entry counts as free until a pass says otherwise)
+                const uint32_t eoff = (uint32_t)(e0 + lane - (R0.hs ? lane_i64(H1.cp, R0.c) : lane_i64(H0.cp, R0.c)));
+                hs_q = R0.hs;
+                push(fr && p0 >= 0, v, eoff, ((uint32_t)R0.c << 16) | (uint32_t)max(p0, 0));
+                if (__ballot(fr && p1 >= 0)) {
+                    if (qcount + 64 <= SWEEP_QCAP) push(fr && p1 >= 0, v, eoff, ((uint32_t)R0.c << 16) | (uint32_t)max(p1, 0));
+                    else if (fr && p1 >= 0) fr = narrow_free_sl<D>(v, w, load_box_T<D>(sboxT, p1));   // no room: in place
                 }
                 const unsigned long long bits = __ballot(fr);
                 const int sh = (int)(e0 & 63);
@@ -633,7 +704,8 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
         const int d = ctx->d;
         const int waves = SWEEP_THREADS / 64;
         const int chunk = box_chunk(ctx->M, d, true);
-        const size_t lds = 2 * sweep_lds(chunk, d);              // AoS copy + transposed (SoA) copy of the staged boxes
+        // transposed (SoA) boxes + one narrow-phase queue per wave
+        const size_t lds = (size_t)SWEEP_CHUNK * 2 * d * sizeof(double) + (size_t)waves * (d + 1) * SWEEP_QCAP * sizeof(double);
         const double rpad = ctx->graph_r * (1.0 + 1e-9) + 1e-300;
         // persistent workgroups (one resident set): boxes are staged once per workgroup, tasks of SWEEP_TC columns
         // are claimed from a counter per obstacle chunk
@@ -642,6 +714,8 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
         HIPCHK(ctx, hipMemsetAsync(ctx->sweep_ctr, 0, sizeof(int) * (size_t)nchunks, ctx->stream));
         const int64_t ntasks = (ctx->N + SWEEP_TC - 1) / SWEEP_TC;
         int per_cu = 0;
+        if (lds > 64 * 1024)                                     // beyond the default dynamic-LDS limit (gfx950 has 160 KB)
+            DISPATCH_D(d, HIPCHK(ctx, hipFuncSetAttribute((const void*)k_graph_sweep<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
         DISPATCH_D(d, HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_graph_sweep<DD>, SWEEP_THREADS, lds)));
         const unsigned nb = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ntasks + waves - 1) / waves,
                                                                              (int64_t)std::max(per_cu, 1) * ctx->num_cus));

@@ -241,7 +241,8 @@ def test_edges_and_points_random(ctx, orc, d, M, h):
     assert np.array_equal(mp._lib.unpack_bits(got, E)[:4000], orc.unpack(want, 4000))
 
 
-@pytest.mark.parametrize("N,d,M,r", [(1000, 2, 20, 0.0663), (6000, 6, 200, 0.4), (4000, 3, 300, 0.12)])
+@pytest.mark.parametrize("N,d,M,r", [(1000, 2, 20, 0.0663), (6000, 6, 200, 0.4), (4000, 3, 300, 0.12),
+                                     (3000, 8, 100, 0.5), (2000, 12, 50, 0.7), (5000, 6, 600, 0.35)])
 def test_graph_edges_free(ctx, orc, N, d, M, r):
     rng = np.random.default_rng(300 + d)
     X, lohi = random_world(rng, N, d, M, 0.05, 0.15)
