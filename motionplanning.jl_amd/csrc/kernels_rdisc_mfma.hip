@@ -575,85 +575,147 @@ int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
 }
 
 // Column ordering for the single-pass build: one wavefront per sorted position.  The column's hits sit in S slot
-// lists (one per candidate slice, counts in slice_cnt); they are gathered, ranked by counting through LDS and
-// written to the final CSC column -- contiguous stores, no staging CSC.
+// lists (one per candidate slice, counts in slice_cnt); they are gathered and written to the final CSC column in
+// ascending row order -- contiguous stores, no staging CSC.
+//   - columns of up to 128 hits (an FMT* r-disc graph has a mean degree ~100) are ranked by BUCKETS: row ids are
+//     near-uniform over [0, N), so bucket = floor(id * 128 / N) (monotone in id) spreads them about one per bucket;
+//     an LDS histogram with returning atomics gives each hit its arrival slot, a 64-lane scan gives the bucket bases,
+//     and a hit's final rank is base + (number of smaller ids in its own bucket) -- a handful of LDS reads instead
+//     of a comparison against every other hit;
+//   - longer columns are ranked by counting through LDS.
 #define SLOT_LDS 1024
+#define SLOT_TC 16               // columns per wavefront
+// A column on its own is a chain of dependent round trips (perm -> slice counts / colptr -> slot entries -> stores), so
+// a wavefront takes SLOT_TC consecutive sorted positions: their headers are loaded together (lane = column, the
+// per-slice prefix sums go to LDS), and the slot entries of column c+1 are requested before column c is ranked.
 __global__ __launch_bounds__(64) void k_sortcols_slots(const int32_t* __restrict__ pool_j, const double* __restrict__ pool_d,
                                                        int64_t capc, int S, const int32_t* __restrict__ slice_cnt, int64_t npad,
                                                        int64_t tile_begin, int64_t pos_begin, int64_t pos_end,
                                                        const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm,
-                                                       int32_t* __restrict__ rowval, double* __restrict__ nzval)
+                                                       int32_t* __restrict__ rowval, double* __restrict__ nzval, uint32_t bucket_mul)
 {
     __shared__ __attribute__((aligned(16))) int32_t s_o[SLOT_LDS + 4];
+    __shared__ __attribute__((aligned(16))) int32_t s_cnt[128], s_base[128];
+    __shared__ int32_t s_pre[SLOT_TC][MPFMT_MAXS + 1];      // [column][slice] first entry of the slice's hits
     const int lane = threadIdx.x;
-    for (int64_t sp = pos_begin + blockIdx.x; sp < pos_end; sp += gridDim.x) {
-        const int32_t o = perm[sp];
-        if (o < 0) continue;
-        const int64_t t = (sp >> 6) - tile_begin;
-        const int ql = (int)(sp & 63);
-        const long long col0 = ((long long)t * S * 64 + ql) * capc;          // slice s adds s*64*capc
-        const long long sstride = 64 * capc;
-        // the column's hits sit in S slot lists; entry e of the concatenation lives in slice s at e - pre_s
-        int k = 0;
-        for (int s = 0; s < S; ++s) k += slice_cnt[(int64_t)s * npad + sp];
-        if (k == 0) continue;
-        const int64_t out = colptr[o];
-        auto src = [&](int e) -> long long {
-            long long p = col0;
-            int rem = e;
-            for (int s = 0; s < S; ++s) {
-                const int n = slice_cnt[(int64_t)s * npad + sp];
-                if (rem < n) break;
-                rem -= n; p += sstride;
-            }
-            return p + rem;
-        };
+    const long long sstride = 64 * capc;
+    const int64_t ntasks = (pos_end - pos_begin + SLOT_TC - 1) / SLOT_TC;
+    for (int64_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const int64_t sp0 = pos_begin + task * SLOT_TC;
         __syncthreads();
-        if (k <= SLOT_LDS) {
-            for (int e0 = 0; e0 < k; e0 += 128) {
-                // gather (two entries per lane per round), publish the indices to LDS for the rank loop
-                const int ea = e0 + lane, eb = e0 + 64 + lane;
-                const long long pa = (ea < k) ? src(ea) : col0, pb = (eb < k) ? src(eb) : col0;
-                const int32_t ma = (ea < k) ? pool_j[pa] : 0x7fffffff;
-                const int32_t mb = (eb < k) ? pool_j[pb] : 0x7fffffff;
-                if (ea < k) s_o[ea] = ma;
-                if (eb < k) s_o[eb] = mb;
-            }
-            if (lane < 4) s_o[k + lane] = 0x7fffffff;        // pad so the rank loop can run in fours
-            __syncthreads();
-            for (int e0 = 0; e0 < k; e0 += 128) {
-                const int ea = e0 + lane, eb = e0 + 64 + lane;
-                const int32_t ma = (ea < k) ? s_o[ea] : 0x7fffffff;
-                const int32_t mb = (eb < k) ? s_o[eb] : 0x7fffffff;
-                const double da = (ea < k) ? pool_d[src(ea)] : 0.0;           // in flight during the rank loop
-                const double db = (eb < k) ? pool_d[src(eb)] : 0.0;
-                int32_t ra = 0, rb = 0;
-                for (int j = 0; j < k; j += 4) {
-                    const int4 v = *reinterpret_cast<const int4*>(&s_o[j]);   // wave-uniform ds_read_b128 (broadcast)
-                    ra += (v.x < ma) ? 1 : 0; rb += (v.x < mb) ? 1 : 0;
-                    ra += (v.y < ma) ? 1 : 0; rb += (v.y < mb) ? 1 : 0;
-                    ra += (v.z < ma) ? 1 : 0; rb += (v.z < mb) ? 1 : 0;
-                    ra += (v.w < ma) ? 1 : 0; rb += (v.w < mb) ? 1 : 0;
+        // ---- headers, lane = column ----
+        int kk = 0;
+        int64_t outp = 0;
+        if (lane < SLOT_TC && sp0 + lane < pos_end) {
+            const int64_t sp = sp0 + lane;
+            const int32_t o = perm[sp];
+            int run = 0;
+#pragma unroll 4
+            for (int sl = 0; sl < S; ++sl) { s_pre[lane][sl] = run; run += slice_cnt[(int64_t)sl * npad + sp]; }
+            s_pre[lane][S] = run;
+            if (o >= 0) { kk = run; outp = colptr[o]; }
+        }
+        __syncthreads();
+        // entry e of column c's concatenated slot lists -> pool index
+        auto col_base = [&](int c) -> long long {
+            const int64_t sp = sp0 + c;
+            return (((long long)((sp >> 6) - tile_begin)) * S * 64 + (long long)(sp & 63)) * capc;
+        };
+        auto src = [&](int c, long long col0, int e) -> long long {
+            int sl = 0;
+            for (int q = 1; q < S; ++q) sl += (e >= s_pre[c][q]) ? 1 : 0;
+            return col0 + (long long)sl * sstride + (e - s_pre[c][sl]);
+        };
+        struct ents { int32_t ma, mb; double da, db; };
+        auto fetch = [&](int c, ents& E) {
+            const int k = __builtin_amdgcn_readlane(kk, c);
+            E.ma = E.mb = 0; E.da = E.db = 0.0;
+            if (k == 0 || k > 128) return;
+            const long long col0 = col_base(c);
+            if (lane < k) { const long long pa = src(c, col0, lane); E.ma = pool_j[pa]; E.da = pool_d[pa]; }
+            if (64 + lane < k) { const long long pb = src(c, col0, 64 + lane); E.mb = pool_j[pb]; E.db = pool_d[pb]; }
+        };
+        ents cur, nxt;
+        fetch(0, cur);
+        for (int c = 0; c < SLOT_TC; ++c) {
+            nxt.ma = nxt.mb = 0; nxt.da = nxt.db = 0.0;
+            if (c + 1 < SLOT_TC) fetch(c + 1, nxt);
+            const int k = __builtin_amdgcn_readlane(kk, c);
+            const int64_t out = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)outp >> 32), c) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)outp, c));
+            if (k > 0 && k <= 128) {
+                __syncthreads();
+                *reinterpret_cast<int2*>(&s_cnt[2 * lane]) = make_int2(0, 0);
+                const bool ha = lane < k, hb = 64 + lane < k;
+                const int32_t ma = cur.ma, mb = cur.mb;
+                // bucket_mul = floor(2^32 * 128 / N) (0: N <= 128, the id is its own bucket)
+                const int ba = bucket_mul ? min(127, (int)__umulhi((uint32_t)ma, bucket_mul)) : (ma & 127);
+                const int bb = bucket_mul ? min(127, (int)__umulhi((uint32_t)mb, bucket_mul)) : (mb & 127);
+                __syncthreads();
+                const int ia = ha ? atomicAdd(&s_cnt[ba], 1) : 0;
+                const int ib = hb ? atomicAdd(&s_cnt[bb], 1) : 0;
+                __syncthreads();
+                {   // exclusive scan of the 128 bucket counts, two per lane
+                    const int2 cc = *reinterpret_cast<const int2*>(&s_cnt[2 * lane]);
+                    const int tot = cc.x + cc.y;
+                    int inc = tot;
+#pragma unroll
+                    for (int o2 = 1; o2 < 64; o2 <<= 1) {
+                        const int up = __shfl_up(inc, o2);
+                        if (lane >= o2) inc += up;
+                    }
+                    const int excl = inc - tot;
+                    *reinterpret_cast<int2*>(&s_base[2 * lane]) = make_int2(excl, excl + cc.x);
                 }
-                if (ea < k) { rowval[out + ra] = ma; nzval[out + ra] = da; }
-                if (eb < k) { rowval[out + rb] = mb; nzval[out + rb] = db; }
-            }
-        } else {
-            // very long columns: stream the concatenated lists through LDS in windows
-            for (int e0 = 0; e0 < k; e0 += 64) {
-                const int e = e0 + lane;
-                const long long pe = (e < k) ? src(e) : col0;
-                const int32_t mine = (e < k) ? pool_j[pe] : 0x7fffffff;
-                int64_t rank = 0;
-                for (int c0 = 0; c0 < k; c0 += SLOT_LDS) {
-                    const int cn = min(SLOT_LDS, k - c0);
+                __syncthreads();
+                const int basea = s_base[ba], baseb = s_base[bb];
+                const int na = s_cnt[ba], nb_ = s_cnt[bb];
+                if (ha) s_o[basea + ia] = ma;                  // ids grouped by bucket (arrival order inside)
+                if (hb) s_o[baseb + ib] = mb;
+                __syncthreads();
+                int ra = 0, rb = 0;
+                if (ha) for (int m = 0; m < na; ++m) ra += (s_o[basea + m] < ma) ? 1 : 0;
+                if (hb) for (int m = 0; m < nb_; ++m) rb += (s_o[baseb + m] < mb) ? 1 : 0;
+                if (ha) { rowval[out + basea + ra] = ma; nzval[out + basea + ra] = cur.da; }
+                if (hb) { rowval[out + baseb + rb] = mb; nzval[out + baseb + rb] = cur.db; }
+            } else if (k > 128) {
+                // long columns: rank by counting through LDS (streamed in windows beyond SLOT_LDS hits)
+                const long long col0 = col_base(c);
+                __syncthreads();
+                if (k <= SLOT_LDS) {
+                    for (int e = lane; e < k; e += 64) s_o[e] = pool_j[src(c, col0, e)];
+                    if (lane < 4) s_o[k + lane] = 0x7fffffff;    // pad so the rank loop can run in fours
                     __syncthreads();
-                    for (int j = lane; j < cn; j += 64) s_o[j] = pool_j[src(c0 + j)];
-                    __syncthreads();
-                    for (int j = 0; j < cn; ++j) rank += (s_o[j] < mine) ? 1 : 0;
+                    for (int e0 = 0; e0 < k; e0 += 64) {
+                        const int e = e0 + lane;
+                        const int32_t mine = (e < k) ? s_o[e] : 0x7fffffff;
+                        const double dm = (e < k) ? pool_d[src(c, col0, e)] : 0.0;   // in flight during the rank loop
+                        int32_t r = 0;
+                        for (int j = 0; j < k; j += 4) {
+                            const int4 v = *reinterpret_cast<const int4*>(&s_o[j]);   // wave-uniform ds_read_b128 (broadcast)
+                            r += (v.x < mine) ? 1 : 0; r += (v.y < mine) ? 1 : 0;
+                            r += (v.z < mine) ? 1 : 0; r += (v.w < mine) ? 1 : 0;
+                        }
+                        if (e < k) { rowval[out + r] = mine; nzval[out + r] = dm; }
+                    }
+                } else {
+                    for (int e0 = 0; e0 < k; e0 += 64) {
+                        const int e = e0 + lane;
+                        const long long pe = (e < k) ? src(c, col0, e) : col0;
+                        const int32_t mine = (e < k) ? pool_j[pe] : 0x7fffffff;
+                        int64_t rank = 0;
+                        for (int c0 = 0; c0 < k; c0 += SLOT_LDS) {
+                            const int cn = min(SLOT_LDS, k - c0);
+                            __syncthreads();
+                            for (int j = lane; j < cn; j += 64) s_o[j] = pool_j[src(c, col0, c0 + j)];
+                            __syncthreads();
+                            for (int j = 0; j < cn; ++j) rank += (s_o[j] < mine) ? 1 : 0;
+                        }
+                        if (e < k) { rowval[out + rank] = mine; nzval[out + rank] = pool_d[pe]; }
+                    }
                 }
-                if (e < k) { rowval[out + rank] = mine; nzval[out + rank] = pool_d[pe]; }
             }
+            cur = nxt;
         }
     }
 }
@@ -662,9 +724,10 @@ int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx)
 {
     const int64_t pb = ctx->tile_begin * 64, pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
     if (ctx->nnz == 0 || pe <= pb) return MPFMT_OK;
-    const unsigned nb = (unsigned)std::min<int64_t>(pe - pb, 1 << 20);
+    const unsigned nb = (unsigned)std::min<int64_t>((pe - pb + SLOT_TC - 1) / SLOT_TC, 1 << 20);
     hipLaunchKernelGGL(k_sortcols_slots, dim3(nb), dim3(64), 0, ctx->stream, ctx->pool_j, ctx->pool_d, ctx->pool_cap, ctx->S,
-                       ctx->slice_cnt, ctx->ntiles * 64, ctx->tile_begin, pb, pe, ctx->colptr, ctx->perm, ctx->rowval, ctx->nzval);
+                       ctx->slice_cnt, ctx->ntiles * 64, ctx->tile_begin, pb, pe, ctx->colptr, ctx->perm, ctx->rowval, ctx->nzval,
+                       ctx->N > 128 ? (uint32_t)((128ull << 32) / (uint64_t)ctx->N) : 0u);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
