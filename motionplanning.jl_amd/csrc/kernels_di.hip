@@ -73,9 +73,9 @@ __device__ __forceinline__ double di_topt_newton(di_coef k, double rho, double t
 template <int M>
 __device__ __forceinline__ void di_steer(const double* x0, const double* x1, double rho, double r, double& cost, double& topt)
 {
-    bool same = true;
+    int same = 1;
 #pragma unroll
-    for (int i = 0; i < 2 * M; ++i) same = same && (x0[i] == x1[i]);
+    for (int i = 0; i < 2 * M; ++i) same &= (int)(x0[i] == x1[i]);
     if (same) { cost = 0.0; topt = 0.0; return; }
     const di_coef k = di_coefs<M>(x0, x1);
     const double t = di_topt_newton(k, rho, r);
@@ -265,10 +265,10 @@ template <int M>
 __device__ __forceinline__ bool ws_point_in_ss(const double (&p)[2 * M], const mpfmt_ss& ss)
 {
     if (!ss.has) return true;
-    bool ok = true;
+    int ok = 1;                                              // straight line: no branch per term
 #pragma unroll
-    for (int i = 0; i < 2 * M; ++i) ok = ok && (ss.lo[i] <= p[i]) && (p[i] <= ss.hi[i]);
-    return ok;
+    for (int i = 0; i < 2 * M; ++i) ok &= (int)(ss.lo[i] <= p[i]) & (int)(p[i] <= ss.hi[i]);
+    return ok != 0;
 }
 
 template <int M>
@@ -312,34 +312,35 @@ __global__ __launch_bounds__(256) void k_di_sweep(const double* __restrict__ X, 
                 h[i] = (pv[i] < pw[i]) ? pw[i] : pv[i];
             }
             for (int k = 0; k < nbox && fr; ++k) {
-                const double* blo = sbox + (int64_t)k * 2 * M;
-                const double* bhi = blo + M;
-                bool sep = false;
+                // box in registers, comparisons combined without control flow (an LDS operand behind && / || becomes
+                // one serial round trip per term)
+                double blo[M], bhi[M];
 #pragma unroll
-                for (int i = 0; i < M; ++i) sep = sep || (bhi[i] < l[i]) || (blo[i] > h[i]);
+                for (int i = 0; i < M; ++i) { blo[i] = sbox[(int64_t)k * 2 * M + i]; bhi[i] = sbox[(int64_t)k * 2 * M + M + i]; }
+                int sep = 0;
+#pragma unroll
+                for (int i = 0; i < M; ++i) sep |= (int)(bhi[i] < l[i]) | (int)(blo[i] > h[i]);
                 if (!sep) {
-                    double v2w[M], lam[M];
+                    double v2w[M];
 #pragma unroll
                     for (int i = 0; i < M; ++i) v2w[i] = pw[i] - pv[i];
+                    int best = 0;
 #pragma unroll
                     for (int i = 0; i < M; ++i) {
                         const double corner = (pv[i] < blo[i]) ? blo[i] : bhi[i];
-                        lam[i] = (corner - pv[i]) / v2w[i];
-                    }
-                    bool hit = false;
-#pragma unroll
-                    for (int i = 0; i < M; ++i) {
-                        bool all = true;
+                        const double lam = (corner - pv[i]) / v2w[i];
+                        int cnt = 0;
 #pragma unroll
                         for (int jx = 0; jx < M; ++jx) {
                             if (jx == i) continue;
-                            const double prod = v2w[jx] * lam[i];
+                            const double prod = v2w[jx] * lam;
                             const double xx = pv[jx] + prod;
-                            all = all && (blo[jx] <= xx) && (xx <= bhi[jx]);
+                            cnt += (int)(blo[jx] <= xx);
+                            cnt += (int)(xx <= bhi[jx]);
                         }
-                        hit = hit || all;
+                        best = max(best, cnt);
                     }
-                    if (hit) fr = false;
+                    if (best == 2 * (M - 1)) fr = false;
                 }
             }
 #pragma unroll

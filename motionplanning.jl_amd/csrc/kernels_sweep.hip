@@ -98,7 +98,7 @@ __device__ __forceinline__ void seg_bbox(const double (&v)[D], const double (&w)
     }
 }
 
-// ---- straight-line forms for the graph sweep -----------------------------------------------------------------
+// ---- straight-line forms (used by the kernels) -----------------------------------------------------------------
 // The && / || forms above short-circuit: when an operand is an LDS read the compiler must keep it behind a branch,
 // which turns a 2*D-term predicate into 2*D serial LDS round trips.  These take the box in registers and combine the
 // IEEE comparisons without control flow (same truth table, including NaN / Inf operands).
@@ -191,15 +191,11 @@ __device__ __forceinline__ void cull_boxes(const double* sbox, int nb, const dou
 #pragma unroll
     for (int c = 0; c < SWEEP_WORDS; ++c) {
         const int k = c * 64 + lane;
-        bool keep = false;
-        if (k < nb) {
-            const double* lo = sbox + (int64_t)k * 2 * D;
-            const double* hi = lo + D;
-            keep = true;
+        const box_regs<D> b = load_box<D>(sbox, min(k, nb - 1));     // unconditional loads, no branch per term
+        int out = 0;
 #pragma unroll
-            for (int i = 0; i < D; ++i) keep = keep && !((hi[i] < ulo[i]) || (lo[i] > uhi[i]));
-        }
-        smask[c] = __ballot(keep);
+        for (int i = 0; i < D; ++i) out |= (int)(b.hi[i] < ulo[i]) | (int)(b.lo[i] > uhi[i]);
+        smask[c] = __ballot(k < nb && !out);
     }
 }
 
@@ -216,9 +212,11 @@ __device__ __forceinline__ bool sweep_segment(const double* sbox, const unsigned
         while (m) {
             const int k = c * 64 + (__ffsll((long long)m) - 1);
             m &= m - 1;
-            const double* lo = sbox + (int64_t)k * 2 * D;
-            const double* hi = lo + D;
-            if (freeflag && !broadphase_free<D>(l, h, lo, hi)) freeflag = narrow_free<D>(v, w, lo, hi);
+            const box_regs<D> b = load_box<D>(sbox, k);                 // wave-uniform k: broadcast reads
+            const bool pend = freeflag & !broadphase_free_sl<D>(l, h, b);
+            if (__ballot(pend)) {
+                if (pend) freeflag = narrow_free_sl<D>(v, w, b);
+            }
         }
     }
     return freeflag;
@@ -242,15 +240,18 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_points_free(const double* __r
     if (active) src = idx1 ? idx1[e] - 1 : e;
 #pragma unroll
     for (int i = 0; i < D; ++i) v[i] = active ? X[src * D + i] : 0.0;
-    bool fr = active && in_state_space<D>(v, ss);
+    bool fr = active && in_state_space_sl<D>(v, ss);
     for (int b0 = 0; b0 < M; b0 += chunk) {
         const int nb = min(chunk, M - b0);
         __syncthreads();
         stage_boxes<D>(sbox, boxes, b0, nb);
         __syncthreads();
         for (int k = 0; k < nb; ++k) {
-            const double* lo = sbox + (int64_t)k * 2 * D;
-            fr = fr && point_outside_box<D>(v, lo, lo + D);
+            const box_regs<D> b = load_box<D>(sbox, k);
+            int outside = 0;                                     // @any [!(lo[i] <= v[i] <= hi[i])]
+#pragma unroll
+            for (int i = 0; i < D; ++i) outside |= (int)!(b.lo[i] <= v[i]) | (int)!(v[i] <= b.hi[i]);
+            fr = fr & (outside != 0);
         }
     }
     const unsigned long long bits = __ballot(fr);
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_edges_free(const double* __re
 #pragma unroll
         for (int i = 0; i < D; ++i) { v[i] = active ? P[e * D + i] : 0.0; w[i] = active ? Q[e * D + i] : 0.0; }
     }
-    bool fr = active && in_state_space<D>(v, ss);
+    bool fr = active && in_state_space_sl<D>(v, ss);
     // union box of the wavefront's active segments
     double ulo[D], uhi[D];
     {
