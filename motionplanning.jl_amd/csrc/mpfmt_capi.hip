@@ -874,11 +874,12 @@ int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx,
     // forward sets: CSR of the cost matrix (DSF = Dmat', linearquadratic.jl:73), rows ascending in target index
     std::vector<int64_t> rowptr(N + 1, 0), cur(N);
     std::vector<int32_t> colidx((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<int64_t> centry((size_t)std::max<int64_t>(nnz, 1));        // CSR entry -> its CSC entry (cost, masks)
     for (int64_t e = 0; e < nnz; ++e) rowptr[rowval[e] + 1]++;
     for (int64_t i = 0; i < N; ++i) rowptr[i + 1] += rowptr[i];
     for (int64_t i = 0; i < N; ++i) cur[i] = rowptr[i];
     for (int64_t j = 0; j < N; ++j)
-        for (int64_t e = colptr[j]; e < colptr[j + 1]; ++e) colidx[cur[rowval[e]]++] = (int32_t)j;
+        for (int64_t e = colptr[j]; e < colptr[j + 1]; ++e) { const int64_t a = cur[rowval[e]]++; colidx[a] = (int32_t)j; centry[a] = e; }
     auto goal_hit = [&](int64_t z) {
         const double* v = &X[(size_t)z * n];
         if (goal_kind == MPFMT_GOAL_POINT) {                      // StateGoal: exact state equality (goals.jl:128-131)
@@ -887,12 +888,33 @@ int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx,
         }
         return is_goal_pt(v, m, goal_kind, goal_params);           // workspace goals act on C*v = first m coordinates
     };
+    // The recursion of fmt.jl:43-90.  DI neighbourhoods are large (hundreds of entries) and arcs are often blocked, so a
+    // sample can be examined by many expanding neighbours; rescanning nearB(x) & H each time is what the reference does
+    // and is O(N deg^2).  Here the argmin over the OPEN backward neighbours is maintained instead: when y opens it
+    // relaxes best[x] of its forward neighbours still in W; when the best itself has closed, x is rescanned once.  The
+    // order is the reference's (lowest cost, then lowest index = first minimum of its scan), so A, C, the path and the
+    // collision count are unchanged.
     std::vector<uint8_t> Wm(N, 1), Hm(N, 0);
     std::vector<int64_t> Hnew;
+    std::vector<int64_t> by(N, -1), be(N, -1);       // best open parent of x and its CSC entry (-1 none, -2 rescan)
+    std::vector<double> bc(N, 0.0);
     for (int64_t i = 0; i < N; ++i) { A[i] = 0; C[i] = 0.0; }
+    auto open_node = [&](int64_t y) {                 // y has just entered H: offer it to its forward neighbours
+        Hm[y] = 1;
+        const double cy = C[y];
+        for (int64_t a = rowptr[y]; a < rowptr[y + 1]; ++a) {
+            const int64_t x = colidx[a];
+            if (!Wm[x] || by[x] == -2) continue;
+            if (by[x] >= 0 && !Hm[by[x]]) { by[x] = -2; continue; }           // its best has closed: rescan when examined
+            const int64_t e = centry[a];
+            const double c = cy + nzval[e];
+            if (by[x] < 0 || c < bc[x] || (c == bc[x] && y < by[x])) { by[x] = y; bc[x] = c; be[x] = e; }
+        }
+    };
     Heap heap;
     const int64_t i0 = init_idx - 1;
-    Wm[i0] = 0; Hm[i0] = 1;
+    Wm[i0] = 0;
+    open_node(i0);
     heap.push(i0, 0.0);
     int64_t z = heap.pop();
     int64_t count = 0;
@@ -902,24 +924,28 @@ int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx,
             const int64_t x = colidx[a];
             if (!Wm[x]) continue;
             if (checkpts && !bit(F, x)) continue;
-            int64_t y_min = -1, e_min = -1; double c_min = 0.0;
-            for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {              // nearB(V, x, r, H), fmt.jl:72-74
-                const int64_t y = rowval[b];
-                if (!Hm[y]) continue;
-                const double c = C[y] + nzval[b];
-                if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
+            if (by[x] == -2 || (by[x] >= 0 && !Hm[by[x]])) {                   // nearB(V, x, r, H), fmt.jl:72-74
+                int64_t y_min = -1, e_min = -1; double c_min = 0.0;
+                for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {
+                    const int64_t y = rowval[b];
+                    if (!Hm[y]) continue;
+                    const double c = C[y] + nzval[b];
+                    if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
+                }
+                by[x] = y_min; bc[x] = c_min; be[x] = e_min;
             }
-            if (y_min < 0) continue;
+            if (by[x] < 0) continue;
+            const int64_t y_min = by[x], e_min = be[x];
             count += nseg[e_min];                                              // boxesND.jl:26 per tested segment
             if (bit(efree, e_min)) {
-                A[x] = y_min + 1; C[x] = c_min;
-                heap.push(x, c_min);
+                A[x] = y_min + 1; C[x] = bc[x];
+                heap.push(x, bc[x]);
                 Hnew.push_back(x);
                 Wm[x] = 0;
             }
         }
-        for (int64_t x : Hnew) Hm[x] = 1;
-        Hm[z] = 0;
+        Hm[z] = 0;                                                             // fmt.jl:84 (before 83: same final sets)
+        for (int64_t x : Hnew) open_node(x);                                   // fmt.jl:83
         if (!heap.empty()) z = heap.pop(); else break;
     }
     std::vector<int64_t> rev;
