@@ -138,6 +138,17 @@ int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkp
                       int32_t goal_kind, const double* goal_params,
                       int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
+/* The sequential part of fmtstar! on its own (src/planners/fmt.jl:43-101): host code, no ctx and no device.  Input is
+ * the finished r-disc graph in the device-native format -- colptr[N+1] 0-based offsets, rowval[nnz] 0-based int32 rows
+ * (ascending per column), nzval[nnz] distances, efree = one bit per entry (row -> column motion free), F = checkpts
+ * bitmap over samples (NULL: checkpts = false), ss_lo/ss_hi = state-space bounds (both NULL: none).  init_idx is 1-based;
+ * A / path are 1-based like mpfmt_fmtstar's; res gets status, cost, z, collision_checks, path_len, nnz.
+ * mpfmt_fmtstar = graph_build_device + graph_sweep_device + this. */
+int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const int64_t* colptr, const int32_t* rowval,
+                                 const double* nzval, const uint64_t* efree, const uint64_t* F, const double* ss_lo,
+                                 const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params,
+                                 int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
+
 /* ---- double-integrator (LinearQuadratic quasi-metric) space: DoubleIntegrator(m; vmax, r=rho)
  *      (src/statespaces/linearquadratic.jl:46-53).  Samples are states (p, v) in R^{2m} (upload_samples with
  *      d = 2m); obstacles live in the workspace (first m coordinates, OutputMatrix C = [I 0], :51-52), so

@@ -56,6 +56,9 @@ SYMBOLS = [
                                  c_i64_p, c_i64_p, c_d_p, c_u8_p, C.c_int64, c_i64_p]),
     ("mpfmt_fmtstar", C.c_int32, [C.c_void_p, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
                                   c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
+    ("mpfmt_host_fmt_recursion", C.c_int32, [C.c_int64, C.c_int32, c_d_p, c_i64_p, C.POINTER(C.c_int32), c_d_p, c_u64_p, c_u64_p,
+                                             c_d_p, c_d_p, C.c_int64, C.c_int32, c_d_p, c_i64_p, c_d_p, c_i64_p,
+                                             C.POINTER(FmtResult)]),
     ("mpfmt_di_graph_count", C.c_int32, [C.c_void_p, C.c_double, C.c_double, c_i64_p, c_i64_p]),
     ("mpfmt_di_graph_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p, c_d_p]),
     ("mpfmt_di_graph_edges_free", C.c_int32, [C.c_void_p, c_u64_p, c_u8_p]),
@@ -126,6 +129,31 @@ def _ip(a):
 
 def _up(a):
     return None if a is None else a.ctypes.data_as(c_u64_p)
+
+
+def host_fmt_recursion(X, colptr0, rowval0, nzval, efree, F, goal_kind, goal_params, ss_lo=None, ss_hi=None, init_idx=1):
+    """The sequential part of fmtstar! (fmt.jl:43-101) on a finished graph; host only, no GPU needed.
+    colptr0 / rowval0 are 0-based (rowval0 int32), efree / F packed uint64 bit masks (F None: checkpts=false)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    N, d = X.shape
+    colptr0 = np.ascontiguousarray(colptr0, dtype=np.int64)
+    rowval0 = np.ascontiguousarray(rowval0, dtype=np.int32)
+    nzval = np.ascontiguousarray(nzval, dtype=np.float64)
+    efree = np.ascontiguousarray(efree, dtype=np.uint64)
+    Fp = None if F is None else np.ascontiguousarray(F, dtype=np.uint64)
+    lo = None if ss_lo is None else np.ascontiguousarray(ss_lo, dtype=np.float64)
+    hi = None if ss_hi is None else np.ascontiguousarray(ss_hi, dtype=np.float64)
+    g = np.ascontiguousarray(goal_params, dtype=np.float64)
+    A = np.empty(N, dtype=np.int64); Cc = np.empty(N, dtype=np.float64); path = np.empty(N, dtype=np.int64)
+    res = FmtResult()
+    rc = lib().mpfmt_host_fmt_recursion(N, d, _dp(X), _ip(colptr0), rowval0.ctypes.data_as(C.POINTER(C.c_int32)), _dp(nzval),
+                                        _up(efree), None if Fp is None else _up(Fp), None if lo is None else _dp(lo),
+                                        None if hi is None else _dp(hi), int(init_idx), int(goal_kind), _dp(g),
+                                        _ip(A), _dp(Cc), _ip(path), C.byref(res))
+    if rc != 0:
+        raise MPFMTError(rc, "mpfmt_host_fmt_recursion rejected its arguments")
+    return dict(status=int(res.status), cost=float(res.cost), z=int(res.z), collision_checks=int(res.collision_checks),
+                nnz=int(res.nnz), ms_host_loop=float(res.ms_host_loop), A=A, C=Cc, path=path[:res.path_len].copy())
 
 
 class Context:

@@ -594,6 +594,97 @@ inline bool bit(const std::vector<uint64_t>& m, int64_t i) { return (m[i >> 6] >
 
 }  // namespace
 
+// The sequential recursion of fmt.jl:43-101 on a finished r-disc graph: CSC (0-based colptr / int32 rows, ascending
+// rows = the order the reference's neighbourhood scans run in), per-entry free bits (row -> column motions) and the
+// optional checkpts bitmap F.  Pure host code, no device use -- the GPU's job ends where this starts.
+//   - W and H are bit sets (125 KB each at N = 1e6, cache resident): the inner scan touches C[y] / nzval only for the
+//     few open neighbours;
+//   - the candidates x in near(z) & W are collected first, so the adjacency rows of the NEXT candidates can be
+//     prefetched while the current one is scanned (each row is a random ~400-byte read from a GB-sized array).
+int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const int64_t* colptr, const int32_t* rowval,
+                                 const double* nzval, const uint64_t* efree, const uint64_t* F, const double* ss_lo,
+                                 const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params,
+                                 int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
+{
+    if (!X || !colptr || !rowval || !nzval || !efree || !goal_params || !A || !C || !path || !res) return MPFMT_ERR_ARG;
+    if (N < 1 || d < 1 || d > MPFMT_MAX_DIM || init_idx < 1 || init_idx > N || goal_kind < 0 || goal_kind > 2) return MPFMT_ERR_ARG;
+    if ((ss_lo == nullptr) != (ss_hi == nullptr)) return MPFMT_ERR_ARG;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const int64_t words = (N + 63) / 64;
+    std::vector<uint64_t> Wb((size_t)words, ~0ull), Hb((size_t)words, 0ull);
+    auto getb = [](const uint64_t* m, int64_t i) { return (m[(size_t)(i >> 6)] >> (i & 63)) & 1ull; };
+    auto setb = [](std::vector<uint64_t>& m, int64_t i) { m[(size_t)(i >> 6)] |= 1ull << (i & 63); };
+    auto clrb = [](std::vector<uint64_t>& m, int64_t i) { m[(size_t)(i >> 6)] &= ~(1ull << (i & 63)); };
+    std::vector<int64_t> Hnew, cand;
+    for (int64_t i = 0; i < N; ++i) { A[i] = 0; C[i] = 0.0; }
+    Heap heap;
+    const int64_t i0 = init_idx - 1;
+    clrb(Wb, i0); setb(Hb, i0);
+    heap.push(i0, 0.0);
+    int64_t z = heap.pop();
+    int64_t count = 0;
+    auto prefetch_row = [&](int64_t x) {
+        const char* p = (const char*)(rowval + colptr[x]);
+        const char* e = (const char*)(rowval + colptr[x + 1]);
+        for (int q = 0; q < 8 && p < e; ++q, p += 64) __builtin_prefetch(p, 0, 1);
+    };
+    while (!is_goal_pt(&X[(size_t)z * d], d, goal_kind, goal_params)) {
+        Hnew.clear();
+        cand.clear();
+        for (int64_t a = colptr[z]; a < colptr[z + 1]; ++a) {                 // fmt.jl:70-71
+            const int64_t x = rowval[a];
+            if (getb(Wb.data(), x) && (!F || getb(F, x))) cand.push_back(x);
+        }
+        const size_t nc = cand.size();
+        for (size_t q = 0; q < nc && q < 3; ++q) prefetch_row(cand[q]);
+        for (size_t q = 0; q < nc; ++q) {
+            if (q + 3 < nc) prefetch_row(cand[q + 3]);
+            const int64_t x = cand[q];
+            int64_t y_min = -1, e_min = -1; double c_min = 0.0;
+            for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {             // fmt.jl:72-74
+                const int64_t y = rowval[b];
+                if (!getb(Hb.data(), y)) continue;
+                const double c = C[y] + nzval[b];
+                if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
+            }
+            if (y_min < 0) continue;
+            {   // boxesND.jl:26 is only reached when in_state_space(V[y_min]) held (statespaces.jl:155-157)
+                bool inb = true;
+                if (ss_lo) for (int k = 0; k < d; ++k) inb = inb && (ss_lo[k] <= X[(size_t)y_min * d + k]) && (X[(size_t)y_min * d + k] <= ss_hi[k]);
+                if (inb) ++count;
+            }
+            if (getb(efree, e_min)) {                                         // fmt.jl:75
+                A[x] = y_min + 1; C[x] = c_min;
+                heap.push(x, c_min);
+                Hnew.push_back(x);
+                clrb(Wb, x);
+            }
+        }
+        for (int64_t x : Hnew) setb(Hb, x);                                   // fmt.jl:83
+        clrb(Hb, z);                                                          // fmt.jl:84
+        if (!heap.empty()) z = heap.pop(); else break;                        // fmt.jl:85-89
+    }
+    // path back-trace, fmt.jl:92-101 (walks until sample 1)
+    std::vector<int64_t> rev;
+    int64_t cur = z;
+    rev.push_back(cur + 1);
+    while (cur != 0) {
+        const int64_t p = A[cur];
+        if (p == 0) break;
+        cur = p - 1;
+        rev.push_back(cur + 1);
+    }
+    for (size_t i = 0; i < rev.size(); ++i) path[i] = rev[rev.size() - 1 - i];
+    res->status = is_goal_pt(&X[(size_t)z * d], d, goal_kind, goal_params) ? 1 : 0;
+    res->cost = C[z];
+    res->z = z + 1;
+    res->collision_checks = count;
+    res->path_len = (int64_t)rev.size();
+    res->nnz = colptr[N];
+    res->ms_host_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return MPFMT_OK;
+}
+
 int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts,
                       int32_t goal_kind, const double* goal_params,
                       int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
@@ -642,71 +733,14 @@ int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkp
     HIPCHK(ctx, hipMemcpy(X.data(), ctx->Xo, sizeof(double) * (size_t)N * d, hipMemcpyDeviceToHost));
     auto t4 = std::chrono::steady_clock::now();
 
-    // the sequential recursion, fmt.jl:43-90, 0-based internally.  W and H are bit sets (125 KB each at N = 1e6, cache
-    // resident): the inner loop touches C[y] only for the few open neighbours.
-    std::vector<uint64_t> Wb((size_t)words, ~0ull), Hb((size_t)words, 0ull);
-    auto getb = [](const std::vector<uint64_t>& m, int64_t i) { return (m[(size_t)(i >> 6)] >> (i & 63)) & 1ull; };
-    auto setb = [](std::vector<uint64_t>& m, int64_t i) { m[(size_t)(i >> 6)] |= 1ull << (i & 63); };
-    auto clrb = [](std::vector<uint64_t>& m, int64_t i) { m[(size_t)(i >> 6)] &= ~(1ull << (i & 63)); };
-    std::vector<int64_t> Hnew;
-    for (int64_t i = 0; i < N; ++i) { A[i] = 0; C[i] = 0.0; }
-    Heap heap;
-    const int64_t i0 = init_idx - 1;
-    clrb(Wb, i0); setb(Hb, i0);
-    heap.push(i0, 0.0);
-    int64_t z = heap.pop();
-    int64_t count = 0;
-    while (!is_goal_pt(&X[(size_t)z * d], d, goal_kind, goal_params)) {
-        Hnew.clear();
-        for (int64_t a = colptr[z]; a < colptr[z + 1]; ++a) {                 // fmt.jl:70
-            const int64_t x = rowval[a];
-            if (!getb(Wb, x)) continue;
-            if (checkpts && !bit(F, x)) continue;                             // fmt.jl:71
-            int64_t y_min = -1, e_min = -1; double c_min = 0.0;
-            for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {             // fmt.jl:72-74
-                const int64_t y = rowval[b];
-                if (!getb(Hb, y)) continue;
-                const double c = C[y] + nzval[b];
-                if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
-            }
-            if (y_min < 0) continue;
-            {   // boxesND.jl:26 is only reached when in_state_space(V[y_min]) held (statespaces.jl:155-157)
-                bool inb = true;
-                if (ctx->ss.has) for (int q = 0; q < d; ++q) inb = inb && (ctx->ss.lo[q] <= X[(size_t)y_min * d + q]) && (X[(size_t)y_min * d + q] <= ctx->ss.hi[q]);
-                if (inb) ++count;
-            }
-            if (bit(efree, e_min)) {                                          // fmt.jl:75
-                A[x] = y_min + 1; C[x] = c_min;
-                heap.push(x, c_min);
-                Hnew.push_back(x);
-                clrb(Wb, x);
-            }
-        }
-        for (int64_t x : Hnew) setb(Hb, x);                                   // fmt.jl:83
-        clrb(Hb, z);                                                          // fmt.jl:84
-        if (!heap.empty()) z = heap.pop(); else break;                        // fmt.jl:85-89
-    }
-    // path back-trace, fmt.jl:92-101 (walks until sample 1)
-    std::vector<int64_t> rev;
-    int64_t cur = z;
-    rev.push_back(cur + 1);
-    while (cur != 0) {
-        const int64_t p = A[cur];
-        if (p == 0) break;
-        cur = p - 1;
-        rev.push_back(cur + 1);
-    }
-    for (size_t i = 0; i < rev.size(); ++i) path[i] = rev[rev.size() - 1 - i];
+    if ((rc = mpfmt_host_fmt_recursion(N, d, X.data(), colptr.data(), rowval.data(), nzval.data(), efree.data(),
+                                       checkpts ? F.data() : nullptr, ctx->ss.has ? ctx->ss.lo : nullptr,
+                                       ctx->ss.has ? ctx->ss.hi : nullptr, init_idx, goal_kind, goal_params, A, C, path, res)))
+        return mpfmt_fail(ctx, rc, "host recursion rejected its arguments");
     auto t5 = std::chrono::steady_clock::now();
-
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
-    res->status = is_goal_pt(&X[(size_t)z * d], d, goal_kind, goal_params) ? 1 : 0;
-    res->cost = C[z];
-    res->z = z + 1;
-    res->collision_checks = count;
-    res->path_len = (int64_t)rev.size();
     res->nnz = nnz;
     res->ms_graph = ms(t1, t2);
     res->ms_sweep = ms(t0, t1) + ms(t2, t3);

@@ -41,3 +41,42 @@ def test_bit_packing_matches_bitvector_chunks():
     m = mp._lib.pack_bits(bits)
     assert m[0] == (1 | (1 << 63)) and m[1] == 1 and m[3] == (1 << 7)
     assert np.array_equal(mp._lib.unpack_bits(m, 200), bits)
+
+
+def _host_case(N, d, M, seed, goal_radius):
+    from oracle import oracle as orc
+    rng = np.random.default_rng(seed)
+    w = mp.workloads.make("t", N, d, M, 0.05, 0.15, seed=seed, goal_radius=goal_radius)
+    colptr, rowval, nzval = orc.rdisc_graph(w.X, w.r)                       # 0-based CSC, ascending rows
+    efree = orc.graph_edges_free(w.X, colptr, rowval, w.lohi, w.ss_lo, w.ss_hi)
+    F = orc.points_free(w.X, w.lohi, w.ss_lo, w.ss_hi)
+    return orc, w, colptr, rowval, nzval, efree, F
+
+
+def test_host_fmt_recursion_matches_oracle():
+    """The C++ host recursion the library runs after the GPU phases (mpfmt_host_fmt_recursion, no device needed)
+    against the oracle's recursion on the same graph: same tree, costs, path and collision count."""
+    for (N, d, M, seed, gr) in [(1500, 2, 20, 11, 0.05), (3000, 3, 40, 12, 0.1), (2000, 6, 100, 13, 0.3)]:
+        orc, w, colptr, rowval, nzval, efree, F = _host_case(N, d, M, seed, gr)
+        goal = w.goal_params()
+        for use_F in (True, False):
+            want = orc.fmtstar_graph(w.X, colptr, rowval, nzval, efree, F if use_F else None, mp._lib.GOAL_BALL, goal,
+                                     w.lohi, w.ss_lo, w.ss_hi, init_idx=0)
+            got = mp._lib.host_fmt_recursion(w.X, colptr, rowval, nzval, efree, F if use_F else None, mp._lib.GOAL_BALL,
+                                             goal, w.ss_lo, w.ss_hi, init_idx=1)
+            assert got["status"] == want["status"] and got["z"] == want["z"] + 1
+            assert got["cost"] == want["cost"] and got["collision_checks"] == want["collision_checks"]
+            assert np.array_equal(got["A"], want["A"] + 1)                  # the oracle's parents are 0-based (-1 = none)
+            assert np.array_equal(got["C"], want["C"])
+            assert np.array_equal(got["path"], want["path"] + 1)
+
+
+def test_host_fmt_recursion_rejects_bad_arguments():
+    import pytest
+    X = np.zeros((4, 2)); cp = np.zeros(5, np.int64); rv = np.zeros(1, np.int32); nz = np.zeros(1); m = np.zeros(1, np.uint64)
+    with pytest.raises(mp.MPFMTError):
+        mp._lib.host_fmt_recursion(X, cp, rv, nz, m, None, mp._lib.GOAL_POINT, [0.0, 0.0], init_idx=0)      # 1-based index
+    with pytest.raises(mp.MPFMTError):
+        mp._lib.host_fmt_recursion(X, cp, rv, nz, m, None, 7, [0.0, 0.0])                                     # unknown goal kind
+    with pytest.raises(mp.MPFMTError):
+        mp._lib.host_fmt_recursion(X, cp, rv, nz, m, None, mp._lib.GOAL_POINT, [0.0, 0.0], ss_lo=[0.0, 0.0])  # lo without hi
