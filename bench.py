@@ -29,10 +29,10 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 
 # HBM bytes per launch measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, profiles/*pmc*):
 # (FETCH_SIZE*2 + WRITE_SIZE) KiB -> bytes.  Keyed by (workload, n_gpus[, kernel]).
 PROFILED_TRAFFIC_BYTES = {
-    # profiles/r01_pmc_v2_rdisc.txt: FETCH_SIZE 5571876 KiB (x2, gfx950 half-count), WRITE_SIZE 3174048 KiB per launch
-    ("ns_r6_n1m_m200", 1): (5571876.3 * 2 + 3174048.1) * 1024,
-    # profiles/r01_pmc_v2_sweep.txt: FETCH_SIZE 8114987 KiB (x2), WRITE_SIZE 115841 KiB per launch
-    ("ns_r6_n1m_m200", 1, "sweep"): (8114986.5 * 2 + 115840.5) * 1024,
+    # profiles/r01_pmc_v4.txt: FETCH_SIZE 2621212 KiB (x2, gfx950 half-count), WRITE_SIZE 3191064 KiB per launch
+    ("ns_r6_n1m_m200", 1): (2621211.7 * 2 + 3191064.3) * 1024,
+    # profiles/r01_pmc_v4.txt: FETCH_SIZE 7984937 KiB (x2), WRITE_SIZE 449945 KiB per launch
+    ("ns_r6_n1m_m200", 1, "sweep"): (7984937.2 * 2 + 449945.2) * 1024,
 }
 
 
@@ -208,7 +208,7 @@ def main():
         "roofline_sweep": {
             "kernel": "k_graph_sweep", "bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": PROFILED_TRAFFIC_BYTES.get((w.name, world, "sweep")),
-            "note": "algorithmic bytes = (2*d*8 + 8 + 1/8) per edge = %.3f B; instruction-issue bound in practice" % (2 * d * 8 + 8 + 0.125),
+            "note": "algorithmic bytes = (2*d*8 + 8 + 1/8) per edge = %.3f B; bound by the random 48-byte row-state gathers and VALU issue in about equal parts" % (2 * d * 8 + 8 + 0.125),
         },
     }
     if rank == 0:
