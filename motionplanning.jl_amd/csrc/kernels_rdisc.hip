@@ -516,11 +516,10 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
         // mean plus a fixed slack -- an overflow falls back to the fill pass
         const int64_t items = nt * S;
         const int64_t capc = (int64_t)(want / ((double)items * 64.0) * 4.0) + 64;
-        if ((double)capc * (double)items * 64.0 * 12.0 > 96e9) pool = false;      // cap the slot lists at 96 GB of the 288
+        if ((double)capc * (double)items * 64.0 * 16.0 > 96e9) pool = false;      // cap the slot lists at 96 GB of the 288
         else {
             const size_t cap = (size_t)capc * (size_t)items * 64;
-            if ((rc = ensure(ctx, (void**)&ctx->pool_j, sizeof(int32_t) * cap))) return rc;
-            if ((rc = ensure(ctx, (void**)&ctx->pool_d, sizeof(double) * cap))) return rc;
+            if ((rc = ensure(ctx, (void**)&ctx->pool, sizeof(mpfmt_hit) * cap))) return rc;
             if (!ctx->pool_flag) HIPCHK(ctx, hipMalloc((void**)&ctx->pool_flag, sizeof(int32_t)));
             HIPCHK(ctx, hipMemsetAsync(ctx->pool_flag, 0, sizeof(int32_t), ctx->stream));
             ctx->pool_cap = capc;

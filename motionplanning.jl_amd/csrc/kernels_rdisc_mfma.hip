@@ -66,8 +66,7 @@ struct mf_args {
     // MODE 2 (single pass): exact hits are appended to a pool while they are counted
     int32_t* pool_flag;             // set to 1 when a slot list overflows (the build then falls back to a fill pass)
     long long pool_cap;             // capacity of ONE (item, column) slot list
-    int32_t* pool_j;                // sample index of the row (candidate)
-    double* pool_d;                 // sqrt(d2)
+    mpfmt_hit* pool;                // (sample index of the row, sqrt(d2)) records
 };
 
 __device__ __forceinline__ int cell_of_m(double x, double lo, double inv_w, int g)
@@ -396,8 +395,9 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
                     // LDS counter that numbers it is the same one that counts the column's degree
                     if (slot < a.pool_cap) {
                         const long long p = ((long long)item * 64 + ql) * a.pool_cap + slot;
-                        a.pool_j[p] = a.perm[jg];                        // sample index of the row
-                        a.pool_d[p] = sqrt(d2);
+                        mpfmt_hit h;
+                        h.j = a.perm[jg]; h.pad = 0; h.d = sqrt(d2);     // sample index of the row, edge cost
+                        *reinterpret_cast<uint4*>(&a.pool[p]) = *reinterpret_cast<const uint4*>(&h);   // one 16-byte store
                     } else {
                         pool_over = 1;
                     }
@@ -583,12 +583,20 @@ int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
 //     and a hit's final rank is base + (number of smaller ids in its own bucket) -- a handful of LDS reads instead
 //     of a comparison against every other hit;
 //   - longer columns are ranked by counting through LDS.
+__device__ __forceinline__ mpfmt_hit load_hit(const mpfmt_hit* __restrict__ pool, long long p)
+{
+    const uint4 u = *reinterpret_cast<const uint4*>(&pool[p]);            // one 16-byte load
+    mpfmt_hit h;
+    *reinterpret_cast<uint4*>(&h) = u;
+    return h;
+}
+
 #define SLOT_LDS 1024
 #define SLOT_TC 16               // columns per wavefront
 // A column on its own is a chain of dependent round trips (perm -> slice counts / colptr -> slot entries -> stores), so
 // a wavefront takes SLOT_TC consecutive sorted positions: their headers are loaded together (lane = column, the
 // per-slice prefix sums go to LDS), and the slot entries of column c+1 are requested before column c is ranked.
-__global__ __launch_bounds__(64) void k_sortcols_slots(const int32_t* __restrict__ pool_j, const double* __restrict__ pool_d,
+__global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restrict__ pool,
                                                        int64_t capc, int S, const int32_t* __restrict__ slice_cnt, int64_t npad,
                                                        int64_t tile_begin, int64_t pos_begin, int64_t pos_end,
                                                        const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm,
@@ -632,8 +640,8 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const int32_t* __restrict
             E.ma = E.mb = 0; E.da = E.db = 0.0;
             if (k == 0 || k > 128) return;
             const long long col0 = col_base(c);
-            if (lane < k) { const long long pa = src(c, col0, lane); E.ma = pool_j[pa]; E.da = pool_d[pa]; }
-            if (64 + lane < k) { const long long pb = src(c, col0, 64 + lane); E.mb = pool_j[pb]; E.db = pool_d[pb]; }
+            if (lane < k) { const mpfmt_hit h = load_hit(pool, src(c, col0, lane)); E.ma = h.j; E.da = h.d; }
+            if (64 + lane < k) { const mpfmt_hit h = load_hit(pool, src(c, col0, 64 + lane)); E.mb = h.j; E.db = h.d; }
         };
         ents cur, nxt;
         fetch(0, cur);
@@ -683,13 +691,13 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const int32_t* __restrict
                 const long long col0 = col_base(c);
                 __syncthreads();
                 if (k <= SLOT_LDS) {
-                    for (int e = lane; e < k; e += 64) s_o[e] = pool_j[src(c, col0, e)];
+                    for (int e = lane; e < k; e += 64) s_o[e] = pool[src(c, col0, e)].j;
                     if (lane < 4) s_o[k + lane] = 0x7fffffff;    // pad so the rank loop can run in fours
                     __syncthreads();
                     for (int e0 = 0; e0 < k; e0 += 64) {
                         const int e = e0 + lane;
                         const int32_t mine = (e < k) ? s_o[e] : 0x7fffffff;
-                        const double dm = (e < k) ? pool_d[src(c, col0, e)] : 0.0;   // in flight during the rank loop
+                        const double dm = (e < k) ? pool[src(c, col0, e)].d : 0.0;   // in flight during the rank loop
                         int32_t r = 0;
                         for (int j = 0; j < k; j += 4) {
                             const int4 v = *reinterpret_cast<const int4*>(&s_o[j]);   // wave-uniform ds_read_b128 (broadcast)
@@ -702,16 +710,16 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const int32_t* __restrict
                     for (int e0 = 0; e0 < k; e0 += 64) {
                         const int e = e0 + lane;
                         const long long pe = (e < k) ? src(c, col0, e) : col0;
-                        const int32_t mine = (e < k) ? pool_j[pe] : 0x7fffffff;
+                        const int32_t mine = (e < k) ? pool[pe].j : 0x7fffffff;
                         int64_t rank = 0;
                         for (int c0 = 0; c0 < k; c0 += SLOT_LDS) {
                             const int cn = min(SLOT_LDS, k - c0);
                             __syncthreads();
-                            for (int j = lane; j < cn; j += 64) s_o[j] = pool_j[src(c, col0, c0 + j)];
+                            for (int j = lane; j < cn; j += 64) s_o[j] = pool[src(c, col0, c0 + j)].j;
                             __syncthreads();
                             for (int j = 0; j < cn; ++j) rank += (s_o[j] < mine) ? 1 : 0;
                         }
-                        if (e < k) { rowval[out + rank] = mine; nzval[out + rank] = pool_d[pe]; }
+                        if (e < k) { rowval[out + rank] = mine; nzval[out + rank] = pool[pe].d; }
                     }
                 }
             }
@@ -725,7 +733,7 @@ int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx)
     const int64_t pb = ctx->tile_begin * 64, pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
     if (ctx->nnz == 0 || pe <= pb) return MPFMT_OK;
     const unsigned nb = (unsigned)std::min<int64_t>((pe - pb + SLOT_TC - 1) / SLOT_TC, 1 << 20);
-    hipLaunchKernelGGL(k_sortcols_slots, dim3(nb), dim3(64), 0, ctx->stream, ctx->pool_j, ctx->pool_d, ctx->pool_cap, ctx->S,
+    hipLaunchKernelGGL(k_sortcols_slots, dim3(nb), dim3(64), 0, ctx->stream, ctx->pool, ctx->pool_cap, ctx->S,
                        ctx->slice_cnt, ctx->ntiles * 64, ctx->tile_begin, pb, pe, ctx->colptr, ctx->perm, ctx->rowval, ctx->nzval,
                        ctx->N > 128 ? (uint32_t)((128ull << 32) / (uint64_t)ctx->N) : 0u);
     HIPCHK(ctx, hipGetLastError());
@@ -788,7 +796,7 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.pairs = (MODE == 1) ? nullptr : ctx->d_pairs;              // 256 x {tested, survivors} sharded counters
     a.survivors = nullptr;
     a.pool_flag = ctx->pool_flag; a.pool_cap = ctx->pool_cap;
-    a.pool_j = ctx->pool_j; a.pool_d = ctx->pool_d;
+    a.pool = ctx->pool;
     if (a.nitems <= 0) return MPFMT_OK;
     const int64_t gran = NXCD * (int64_t)std::max(1, a.xcd_mode);
     const unsigned nblk = (unsigned)(((a.nitems + gran - 1) / gran) * gran);

@@ -42,6 +42,9 @@ struct mpfmt_ss {                        // BoundedStateSpace bounds (statespace
     double hi[MPFMT_MAX_DIM];
 };
 
+// one hit of the single-pass build: row sample index + distance in ONE 16-byte record (one store, one sector)
+struct __attribute__((aligned(16))) mpfmt_hit { int32_t j; int32_t pad; double d; };
+
 struct mpfmt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -97,8 +100,7 @@ struct mpfmt_ctx {
     int32_t use_pool = 1;                // option "rdisc_pool"
     int32_t* pool_flag = nullptr;        // overflow flag
     int64_t pool_cap = 0;                // capacity of one (item, column) slot list
-    int32_t* pool_j = nullptr;
-    double* pool_d = nullptr;
+    mpfmt_hit* pool = nullptr;           // [items][64 columns][pool_cap] hit records
     bool pool_valid = false;             // pool holds exactly the nnz hits of the counted graph
     int64_t pool_hint_N = -1; double pool_hint_r = -1.0; int64_t pool_hint_nnz = 0; int pool_hint_rank = -1, pool_hint_world = -1;   // capacity hint from the last build
     int64_t survivors = 0;
