@@ -179,6 +179,43 @@ def test_rdisc_tiny_and_ragged(ctx, orc, N):
         check_costs(nzval, oval)
 
 
+@pytest.mark.parametrize("N", [1, 2, 15, 16, 17, 63, 64, 65, 129])
+def test_graph_sweep_tiny_and_ragged(ctx, orc, N):
+    """Graph sweep on fewer columns than one task / one wavefront, empty columns, all-pairs degree > 64 (several rounds
+    per column), with and without obstacles."""
+    rng = np.random.default_rng(500 + N)
+    X = rng.random((N, 3))
+    lohi = mp.workloads.make_boxes(rng, 7, 3, 0.05, 0.2, [])
+    ss_lo, ss_hi = np.full(3, 0.05), np.full(3, 0.95)
+    ctx.upload_samples(X)
+    for boxes in (lohi, lohi[:0]):
+        ctx.upload_boxes(boxes, ss_lo, ss_hi)
+        for r in (0.25, 5.0):
+            colptr, rowval, _ = ctx.rdisc_graph(r)
+            got = ctx.graph_edges_free()
+            c0, r0 = to0(colptr, rowval)
+            want = orc.graph_edges_free(X, c0, r0, boxes, ss_lo, ss_hi)
+            assert np.array_equal(got, want)
+
+
+def test_graph_sweep_long_columns_fill_the_queue(ctx, orc):
+    """Dense graph in a cluttered world: most entries fail some broad phase, so the narrow-phase queue runs full
+    passes, flushes at task boundaries, overflows into the in-place path, and columns span many rounds."""
+    rng = np.random.default_rng(77)
+    N, d = 700, 2
+    X = rng.random((N, d))
+    lohi = mp.workloads.make_boxes(rng, 150, d, 0.01, 0.04, [])
+    ctx.upload_samples(X)
+    ctx.upload_boxes(lohi, np.zeros(d), np.ones(d))
+    colptr, rowval, _ = ctx.rdisc_graph(0.6)
+    got = ctx.graph_edges_free()
+    c0, r0 = to0(colptr, rowval)
+    assert int(np.max(np.diff(c0))) > 300
+    want = orc.graph_edges_free(X, c0, r0, lohi, np.zeros(d), np.ones(d))
+    assert np.array_equal(got, want)
+    assert 0.02 < mp._lib.unpack_bits(got, len(r0)).mean() < 0.98
+
+
 def test_rdisc_high_degree_columns(ctx, orc):
     """Columns longer than the LDS-resident sort window (exercises the chunked rank path)."""
     rng = np.random.default_rng(17)
