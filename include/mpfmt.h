@@ -149,6 +149,19 @@ int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const in
                                  const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params,
                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
+/* ---- batch free-space sampler: sample_free!(P, N, true; ensure_goal_ct) of src/sampling.jl:11-45 with
+ *      the rejection loop (sample_space, statespaces.jl:40; is_free_state, statespaces.jl:151-152) run in batches on the
+ *      device.  Needs mpfmt_upload_boxes with state-space bounds (the BoundedStateSpace lo / hi) and an Identity
+ *      state2workspace (d_state == dw).  The reference draws from Julia's unseeded global RNG; here candidates come from
+ *      a counter-based stream (Philox4x32-10, key = seed, counter = candidate index), tested IN ORDER like the reference's
+ *      loop, so the result is a pure function of (seed, N, bounds, obstacles, goal) -- independent of batching and
+ *      reproducible by a scalar loop.  V[1] = init when init != NULL (sampling.jl:15-20); the last min(goal_ct, N-1)
+ *      samples are free goal samples, V[N+1-i] = the i-th one (sampling.jl:37-41; sample_goal, goals.jl:97,101-108,115).
+ *      The set is left uploaded in ctx (as by mpfmt_upload_samples); X_out (N*d, may be NULL) receives a copy;
+ *      attempts = sample_space candidates the sequential loop would have consumed.  goal_bias is not supported (0). */
+int32_t mpfmt_sample_free(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double* init, int32_t goal_kind,
+                          const double* goal_params, int32_t goal_ct, double* X_out, int64_t* attempts);
+
 /* ---- double-integrator (LinearQuadratic quasi-metric) space: DoubleIntegrator(m; vmax, r=rho)
  *      (src/statespaces/linearquadratic.jl:46-53).  Samples are states (p, v) in R^{2m} (upload_samples with
  *      d = 2m); obstacles live in the workspace (first m coordinates, OutputMatrix C = [I 0], :51-52), so

@@ -59,6 +59,7 @@ SYMBOLS = [
     ("mpfmt_host_fmt_recursion", C.c_int32, [C.c_int64, C.c_int32, c_d_p, c_i64_p, C.POINTER(C.c_int32), c_d_p, c_u64_p, c_u64_p,
                                              c_d_p, c_d_p, C.c_int64, C.c_int32, c_d_p, c_i64_p, c_d_p, c_i64_p,
                                              C.POINTER(FmtResult)]),
+    ("mpfmt_sample_free", C.c_int32, [C.c_void_p, C.c_uint64, C.c_int64, c_d_p, C.c_int32, c_d_p, C.c_int32, c_d_p, c_i64_p]),
     ("mpfmt_di_graph_count", C.c_int32, [C.c_void_p, C.c_double, C.c_double, c_i64_p, c_i64_p]),
     ("mpfmt_di_graph_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p, c_d_p]),
     ("mpfmt_di_graph_edges_free", C.c_int32, [C.c_void_p, c_u64_p, c_u8_p]),
@@ -168,6 +169,7 @@ class Context:
         self._h = h
         self.N = 0
         self.d = 0
+        self.dw = 0
         self.nnz = None
 
     def close(self):
@@ -221,6 +223,7 @@ class Context:
         hi = None if ss_hi is None else np.ascontiguousarray(ss_hi, dtype=np.float64)
         ds = 0 if lo is None else lo.size
         self._chk(self._L.mpfmt_upload_boxes(self._h, _dp(lohi), M, dw, _dp(lo), _dp(hi), ds))
+        self.dw = dw
 
     # ---- r-disc ---------------------------------------------------------------------------------
     def rdisc_count(self, r):
@@ -317,6 +320,19 @@ class Context:
                     collision_checks=int(res.collision_checks), nnz=int(res.nnz),
                     ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
                     A=A[:self.N], C=Cc[:self.N], path=path[:res.path_len].copy())
+
+    def sample_free(self, seed, N, init=None, goal_kind=0, goal_params=None, goal_ct=0):
+        """sample_free!(P, N): N free samples drawn on the device (counter-based stream, sequential semantics), left
+        uploaded in the context.  Returns (X, attempts)."""
+        d = self.dw
+        X = np.empty((max(int(N), 1), d), dtype=np.float64)
+        att = C.c_int64()
+        ini = None if init is None else np.ascontiguousarray(init, dtype=np.float64)
+        g = None if goal_params is None else np.ascontiguousarray(goal_params, dtype=np.float64)
+        self._chk(self._L.mpfmt_sample_free(self._h, int(seed), int(N), None if ini is None else _dp(ini), int(goal_kind),
+                                            None if g is None else _dp(g), int(goal_ct), _dp(X), C.byref(att)))
+        self.N, self.d = int(N), d
+        return X[:N], int(att.value)
 
     # ---- double integrator ------------------------------------------------------------------------
     def di_graph(self, rho, r):

@@ -291,11 +291,20 @@ def sample_free_goal(P, rng):
             return v
 
 
-def sample_free_(P, N, ensure_goal=True, ensure_goal_ct=5, rng=None):
+def sample_free_(P, N, ensure_goal=True, ensure_goal_ct=5, rng=None, seed=None):
     """sample_free!(P, N): N new free samples (rejection sampling, batched: candidates are validity-checked on the
-    GPU in blocks), goal samples written into the tail (sampling.jl:11-45).  Returns volume(SS)."""
+    GPU in blocks), goal samples written into the tail (sampling.jl:11-45).  Returns volume(SS).
+    With `seed` (and an empty sample set, a Euclidean space, a Rectangle/Ball/Point goal) the whole loop runs on the
+    device from a counter-based stream (`Context.sample_free`, mpfmt_sample_free); otherwise candidates come from `rng`."""
     rng = np.random.default_rng() if rng is None else rng
     if N <= 0:
+        return volume(P.SS)
+    has_init = len(P.V.V) > 0 and np.array_equal(P.V.V[0], P.init)                 # sampling.jl:15-20
+    if seed is not None and len(P.V.V) <= 1 and not isinstance(P.SS.dist, LinearQuadratic) and hasattr(P.goal, "kind"):
+        P.CC._bind(P.ctx, P.SS)
+        W, _ = P.ctx.sample_free(seed, N, init=None if has_init else P.init, goal_kind=P.goal.kind,
+                                 goal_params=P.goal.params(), goal_ct=ensure_goal_ct if ensure_goal else 0)
+        P.V = addpoints(P.V, W)
         return volume(P.SS)
     W = np.empty((N, dim(P.SS)))
     have = 0
@@ -316,7 +325,7 @@ def sample_free_(P, N, ensure_goal=True, ensure_goal_ct=5, rng=None):
 
 
 # ---- planner (src/planners/fmt.jl) -------------------------------------------------------------------------------------------------
-def fmtstar_(P, N=None, rm=1.0, connections="R", r=0.0, ensure_goal_ct=1, init_idx=1, checkpts=True, rng=None):
+def fmtstar_(P, N=None, rm=1.0, connections="R", r=0.0, ensure_goal_ct=1, init_idx=1, checkpts=True, rng=None, seed=None):
     """fmtstar!(P, N; rm, connections, r, ensure_goal_ct, init_idx, checkpts)  (fmt.jl:3-119).  Returns
     (status, cost, elapsed) and fills P.solution like the reference."""
     t0 = time.time()
@@ -332,7 +341,7 @@ def fmtstar_(P, N=None, rm=1.0, connections="R", r=0.0, ensure_goal_ct=1, init_i
         P.status = "failed"
         P.solution = MPSolution(P.status, math.inf, time.time() - t0, {})
         return math.inf
-    free_volume_ub = sample_free_(P, N - len(P.V), ensure_goal_ct=ensure_goal_ct, rng=rng)
+    free_volume_ub = sample_free_(P, N - len(P.V), ensure_goal_ct=ensure_goal_ct, rng=rng, seed=seed)
     if r == 0:
         d = dim(P.SS)
         r = rm * 2 * (1 / d * free_volume_ub / (math.pi ** (d / 2) / math.gamma(d / 2 + 1)) * math.log(N) / N) ** (1 / d)

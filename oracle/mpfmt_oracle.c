@@ -978,3 +978,99 @@ void orc_di_graph_edges_free(const double *X, int64_t N, int32_t m, double rho, 
         for (int64_t e = colptr[x]; e < colptr[x + 1]; ++e)
             set_bit(mask, e, orc_di_is_free_motion(X + (size_t)rowval[e] * n, X + (size_t)x * n, m, rho, r, lohi, M, ss_lo, ss_hi));
 }
+
+/* ---- batch free-space sampler: sample_free! of src/sampling.jl:11-45 ------------------------------
+ * The reference draws from Julia's global MersenneTwister (unseeded), so its stream cannot be reproduced; the build
+ * declares a counter-based stream instead so that the sequential semantics (candidates tested IN ORDER, the first
+ * accepted ones kept, sampling.jl:21-36) do not depend on how candidates are batched:
+ *   Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123), key = seed,
+ *   counter = (candidate lo32, candidate hi32, coordinate pair j, stream) ; stream 0 = sample_space, 1 = sample_goal.
+ *   A call yields words x0..x3; coordinate 2j uses (x0, x1), 2j+1 uses (x2, x3):
+ *   u = ((xa >> 5) * 2^26 + (xb >> 6)) * 2^-53  in [0, 1)   (53 random bits, exact in fp64).
+ * sample_space(SS) = lo + rand .* (hi - lo)              (statespaces.jl:40), evaluated unfused. */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static double u53(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+/* uniform numbers u[0..d) of candidate c in stream s */
+void orc_sample_uniforms(uint64_t seed, uint64_t c, uint32_t stream, int32_t d, double *u)
+{
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int32_t j = 0; 2 * j < d; ++j) {
+        const uint32_t ctr[4] = {(uint32_t)c, (uint32_t)(c >> 32), (uint32_t)j, stream};
+        uint32_t x[4];
+        orc_philox4x32_10(ctr, key, x);
+        u[2 * j] = u53(x[0], x[1]);
+        if (2 * j + 1 < d) u[2 * j + 1] = u53(x[2], x[3]);
+    }
+}
+
+/* sample_goal: Rectangle lo + (hi-lo).*rand (goals.jl:97); Ball center + 2*radius*(rand - .5), rejected outside the
+ * ball (goals.jl:101-108); Point = the point (goals.jl:115).  Returns 1 if a candidate was produced (Ball may reject). */
+static int goal_candidate(uint64_t seed, uint64_t g, int32_t d, int32_t kind, const double *gp, double *v)
+{
+    double u[ORC_MAXD];
+    orc_sample_uniforms(seed, g, 1u, d, u);
+    if (kind == 0) {                 /* rectangle: gp = [lo(d), hi(d)] */
+        for (int32_t i = 0; i < d; ++i) { const double w = gp[d + i] - gp[i]; const double p = w * u[i]; v[i] = gp[i] + p; }
+        return 1;
+    }
+    if (kind == 1) {                 /* ball: gp = [center(d), radius] */
+        double s = 0.0;
+        for (int32_t i = 0; i < d; ++i) {
+            const double a = 2 * gp[d]; const double b = u[i] - .5; const double p = a * b;
+            v[i] = gp[i] + p;
+            const double t = v[i] - gp[i]; const double tt = t * t;
+            s = (i == 0) ? tt : s + tt;
+        }
+        return sqrt(s) <= gp[d];
+    }
+    for (int32_t i = 0; i < d; ++i) v[i] = gp[i];
+    return 1;
+}
+
+/* sample_free!(P, N, true; ensure_goal_ct = goal_ct) into W[N][d]: W[0] = init when init != NULL (sampling.jl:15-20),
+ * then free candidates in order (21-36), then W[N-i] = i-th free goal sample, i = 1..min(goal_ct, N-1) (37-41).
+ * attempts = number of sample_space candidates consumed.  Returns 0, or -1 when the goal cannot be sampled
+ * (max_goal_tries exhausted: the reference would loop forever). */
+int32_t orc_sample_free(uint64_t seed, int64_t N, int32_t d, const double *init, const double *lohi, int32_t M,
+                        const double *ss_lo, const double *ss_hi, int32_t goal_kind, const double *goal_params,
+                        int32_t goal_ct, double *W, int64_t *attempts)
+{
+    int64_t have = 0;
+    uint64_t c = 0;
+    if (N <= 0) { if (attempts) *attempts = 0; return 0; }
+    if (init) { memcpy(W, init, sizeof(double) * (size_t)d); have = 1; }
+    double u[ORC_MAXD], v[ORC_MAXD];
+    while (have < N) {
+        orc_sample_uniforms(seed, c++, 0u, d, u);
+        for (int32_t i = 0; i < d; ++i) { const double w = ss_hi[i] - ss_lo[i]; const double p = u[i] * w; v[i] = ss_lo[i] + p; }
+        if (orc_is_free_state(v, d, lohi, M, ss_lo, ss_hi)) { memcpy(W + (size_t)have * d, v, sizeof(double) * (size_t)d); ++have; }
+    }
+    if (attempts) *attempts = (int64_t)c;
+    const int64_t ng = (goal_ct < N - 1) ? goal_ct : N - 1;
+    uint64_t g = 0;
+    for (int64_t i = 1; i <= ng; ++i) {
+        for (;;) {
+            if (g > 1000000u) return -1;
+            const int ok = goal_candidate(seed, g++, d, goal_kind, goal_params, v);
+            if (ok && orc_is_free_state(v, d, lohi, M, ss_lo, ss_hi)) break;
+        }
+        memcpy(W + (size_t)(N - i) * d, v, sizeof(double) * (size_t)d);
+    }
+    return 0;
+}

@@ -342,3 +342,26 @@ def di_fmtstar(X, rho, r, colptr, rowval, nzval, goal_kind, goal, lohi, ss_lo=No
                               _d(lohi), C.c_int32(M), _d(ss_lo), _d(ss_hi), _i(A), _d(Cc), _i(path), C.byref(res))
     return dict(rc=rc, status=int(res.status), cost=float(res.cost), z=int(res.z),
                 collision_checks=int(res.collision_checks), A=A, C=Cc, path=path[:res.path_len].copy())
+
+
+# ---- batch free-space sampler -------------------------------------------------------------------
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
+
+
+def sample_uniforms(seed, c, stream, d):
+    u = np.empty(d)
+    lib().orc_sample_uniforms(C.c_uint64(seed), C.c_uint64(c), C.c_uint32(stream), C.c_int32(d), _d(u))
+    return u
+
+
+def sample_free(seed, N, d, init, lohi, ss_lo, ss_hi, goal_kind, goal, goal_ct=1):
+    lohi, M = _boxes(lohi, d); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi); goal = _vec(goal)
+    init = None if init is None else _vec(init)
+    W = np.empty((max(N, 0), d)); att = C.c_int64()
+    rc = lib().orc_sample_free(C.c_uint64(seed), C.c_int64(N), C.c_int32(d), None if init is None else _d(init), _d(lohi),
+                               C.c_int32(M), _d(ss_lo), _d(ss_hi), C.c_int32(goal_kind), _d(goal), C.c_int32(goal_ct),
+                               _d(W), C.byref(att))
+    return rc, W, int(att.value)

