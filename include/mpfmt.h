@@ -149,6 +149,14 @@ int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const in
                                  const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params,
                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
+/* ---- graph persistence: install a graph exported earlier by mpfmt_rdisc_count / mpfmt_rdisc_fill (same
+ *      1-based CSC: colptr[N+1], rowval[nnz] strictly ascending per column, nzval[nnz]) for the samples now uploaded --
+ *      the reference's ImmutableNNC(D, r) (src/nearneighbors.jl:23-28; its saveNN / loadNN! are commented out, :114-116).
+ *      Afterwards mpfmt_graph_edges_free / mpfmt_graph_sweep_device / mpfmt_expand / mpfmt_fmtstar(r) use it without
+ *      running the pair phase (mpfmt_fmtstar reuses any filled graph of the same radius).  The arrays are validated
+ *      (monotone colptr, rows in range, ascending, no self loops); distances are taken as given. */
+int32_t mpfmt_graph_import(mpfmt_ctx* ctx, double r, const int64_t* colptr, const int64_t* rowval, const double* nzval);
+
 /* ---- batch free-space sampler: sample_free!(P, N, true; ensure_goal_ct) of src/sampling.jl:11-45 with
  *      the rejection loop (sample_space, statespaces.jl:40; is_free_state, statespaces.jl:151-152) run in batches on the
  *      device.  Needs mpfmt_upload_boxes with state-space bounds (the BoundedStateSpace lo / hi) and an Identity

@@ -59,6 +59,7 @@ SYMBOLS = [
     ("mpfmt_host_fmt_recursion", C.c_int32, [C.c_int64, C.c_int32, c_d_p, c_i64_p, C.POINTER(C.c_int32), c_d_p, c_u64_p, c_u64_p,
                                              c_d_p, c_d_p, C.c_int64, C.c_int32, c_d_p, c_i64_p, c_d_p, c_i64_p,
                                              C.POINTER(FmtResult)]),
+    ("mpfmt_graph_import", C.c_int32, [C.c_void_p, C.c_double, c_i64_p, c_i64_p, c_d_p]),
     ("mpfmt_sample_free", C.c_int32, [C.c_void_p, C.c_uint64, C.c_int64, c_d_p, C.c_int32, c_d_p, C.c_int32, c_d_p, c_i64_p]),
     ("mpfmt_di_graph_count", C.c_int32, [C.c_void_p, C.c_double, C.c_double, c_i64_p, c_i64_p]),
     ("mpfmt_di_graph_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p, c_d_p]),
@@ -320,6 +321,14 @@ class Context:
                     collision_checks=int(res.collision_checks), nnz=int(res.nnz),
                     ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
                     A=A[:self.N], C=Cc[:self.N], path=path[:res.path_len].copy())
+
+    def graph_import(self, r, colptr, rowval, nzval):
+        """Install an exported graph (1-based CSC as returned by rdisc_graph) for the uploaded samples."""
+        colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+        nzval = np.ascontiguousarray(nzval, dtype=np.float64)
+        self._chk(self._L.mpfmt_graph_import(self._h, float(r), _ip(colptr), _ip(rowval), _dp(nzval)))
+        self.nnz = int(colptr[-1] - 1)
 
     def sample_free(self, seed, N, init=None, goal_kind=0, goal_params=None, goal_ct=0):
         """sample_free!(P, N): N free samples drawn on the device (counter-based stream, sequential semantics), left

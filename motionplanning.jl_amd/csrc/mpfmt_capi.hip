@@ -331,6 +331,52 @@ int32_t mpfmt_rdisc_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval)
     return MPFMT_OK;
 }
 
+// Install a previously exported r-disc graph (the reference's ImmutableNNC(D, r), nearneighbors.jl:23-28,
+// whose saveNN / loadNN! were left commented out, :114-116) so that re-plans on the same samples -- new obstacles, new
+// goals, another process -- skip the pair phase.  Same format mpfmt_rdisc_count / _fill hand out.
+int32_t mpfmt_graph_import(mpfmt_ctx* ctx, double r, const int64_t* colptr, const int64_t* rowval, const double* nzval)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    if (ctx->world != 1) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "graph_import needs an unsharded ctx");
+    if (!(r >= 0.0) || !std::isfinite(r)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "radius must be finite and >= 0");
+    if (!colptr) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "colptr is NULL");
+    const int64_t N = ctx->N;
+    if (colptr[0] != 1) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "colptr[1] must be 1 (1-based CSC)");
+    for (int64_t j = 0; j < N; ++j)
+        if (colptr[j + 1] < colptr[j]) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "colptr decreases at column %lld", (long long)(j + 1));
+    const int64_t nnz = colptr[N] - 1;
+    if (nnz > 0 && (!rowval || !nzval)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "rowval / nzval is NULL");
+    std::vector<int64_t> cp0((size_t)N + 1);
+    std::vector<int32_t> rv0((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t j = 0; j <= N; ++j) cp0[j] = colptr[j] - 1;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t e = cp0[j]; e < cp0[j + 1]; ++e) {
+            const int64_t y = rowval[e];
+            if (y < 1 || y > N || y == j + 1) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "column %lld: row %lld out of range or a self loop", (long long)(j + 1), (long long)y);
+            if (e > cp0[j] && rowval[e - 1] >= y) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "column %lld: rows are not strictly ascending", (long long)(j + 1));
+            rv0[e] = (int32_t)(y - 1);
+        }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (size_t)(N + 1)))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rowval, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->nzval, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->colptr, cp0.data(), sizeof(int64_t) * (size_t)(N + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (nnz > 0) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->rowval, rv0.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->nzval, nzval, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->nnz = nnz;
+    ctx->graph_r = r;
+    ctx->graph_counted = ctx->graph_filled = true;
+    ctx->graph_swept = false;
+    ctx->pool_valid = false;
+    ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
+    return MPFMT_OK;
+}
+
 int32_t mpfmt_rdisc_query(mpfmt_ctx* ctx, int64_t v, double r, int64_t* inds, double* ds, int64_t cap, int64_t* k)
 {
     if (!ctx) return MPFMT_ERR_ARG;
@@ -712,8 +758,9 @@ int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkp
     if (!bit(F, init_idx - 1)) return mpfmt_fail(ctx, MPFMT_ERR_INFEASIBLE, "initial state is infeasible");
     auto t1 = std::chrono::steady_clock::now();
 
-    // r-disc graph + per-edge free mask, all edges, on the device
-    if ((rc = mpfmt_graph_build_device(ctx, r, nullptr))) return rc;
+    // r-disc graph + per-edge free mask, all edges, on the device.  A filled graph of the same samples and radius (a
+    // previous plan, or mpfmt_graph_import) is reused: only the obstacle-dependent sweep is redone.
+    if (!(ctx->graph_filled && ctx->graph_r == r) && (rc = mpfmt_graph_build_device(ctx, r, nullptr))) return rc;
     auto t2 = std::chrono::steady_clock::now();
     if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -602,3 +602,42 @@ def test_sample_free_north_star_size_properties(orc):
     assert np.array_equal(X[:3000], W)                                     # same stream, same order
     assert abs(X[1:-5].mean() - 0.5) < 0.01
     c.close()
+
+
+# ---- graph persistence ---------------------------------------------------------------------------------
+
+def test_graph_export_import_replan(orc, tmp_path):
+    """Export the r-disc graph, load it into a fresh context (as another process would from disk), re-plan against a
+    different obstacle set without the pair phase: masks, tree, costs identical to a from-scratch plan."""
+    w = mp.workloads.make("t", 4000, 3, 60, 0.05, 0.15, seed=21, goal_radius=0.15)
+    a = mp.Context(0)
+    a.upload_samples(w.X); a.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+    colptr, rowval, nzval = a.rdisc_graph(w.r)
+    np.savez(tmp_path / "graph.npz", colptr=colptr, rowval=rowval, nzval=nzval, r=w.r)
+    ref = a.fmtstar(w.r, mp._lib.GOAL_BALL, w.goal_params())
+    z = np.load(tmp_path / "graph.npz")
+    b = mp.Context(0)
+    b.upload_samples(w.X); b.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+    b.graph_import(float(z["r"]), z["colptr"], z["rowval"], z["nzval"])
+    assert np.array_equal(b.graph_edges_free(), a.graph_edges_free())
+    b.timing_reset()
+    got = b.fmtstar(w.r, mp._lib.GOAL_BALL, w.goal_params())
+    assert b.timing("rdisc_count")[1] == 0                       # the pair kernels never ran in the second context
+    for k in ("status", "cost", "z", "collision_checks"):
+        assert got[k] == ref[k]
+    assert np.array_equal(got["A"], ref["A"]) and np.array_equal(got["C"], ref["C"]) and np.array_equal(got["path"], ref["path"])
+    # new obstacles, same samples: only the sweep is redone, and it matches the oracle on the imported graph
+    rng = np.random.default_rng(4)
+    lohi2 = mp.workloads.make_boxes(rng, 30, 3, 0.05, 0.2, [w.init, w.goal_center])
+    b.upload_boxes(lohi2, w.ss_lo, w.ss_hi)
+    got2 = b.fmtstar(w.r, mp._lib.GOAL_BALL, w.goal_params())
+    assert b.timing("rdisc_count")[1] == 0
+    want2 = orc.fmtstar(w.X, w.r, orc.GOAL_BALL, w.goal_params(), lohi2, w.ss_lo, w.ss_hi)
+    assert got2["status"] == want2["status"] and got2["cost"] == want2["cost"] and got2["collision_checks"] == want2["collision_checks"]
+    assert np.array_equal(got2["A"] - 1, want2["A"])
+    # malformed input is refused
+    bad = z["rowval"].copy(); bad[[0, 1]] = bad[[1, 0]]
+    with pytest.raises(mp.MPFMTError) as e:
+        b.graph_import(w.r, z["colptr"], bad, z["nzval"])
+    assert e.value.code == mp._lib.ERR_ARG
+    a.close(); b.close()
