@@ -149,6 +149,21 @@ int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const in
                                  const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params,
                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
+/* ---- 2-D SAT world: PointRobot2D(Compound2D(parts)) of src/collisioncheckers/robots2D.jl:12-14 and
+ *      SAT2D.jl -- parts are Circle(c, r) (:14-28) and convex Polygon(points) (:32-58; Box2D = 4-point polygon, :59-62).
+ *      Switches the ctx's collision checker: afterwards mpfmt_points_free / _states_free = is_free_state (point vs
+ *      shapes, SAT2D.jl:121-133), mpfmt_edges_free / _motions_free / _graph_edges_free / graph sweep / expand / fmtstar =
+ *      is_free_motion = !colliding(Line(v, w), obstacles) (SAT2D.jl:154-178), both wrapped in the state-space checks of
+ *      statespaces.jl:150-158.  mpfmt_upload_boxes switches back.  Samples must be 2-D.
+ *      kinds[i]: 0 = circle, data = (cx, cy, r); 1 = polygon with nverts[i] (3..16) vertices, data = (x1, y1, x2, y2, ...);
+ *      data is the concatenation in shape order (nverts is ignored for circles).  The library runs the reference's
+ *      constructors (orientation, unit normals, extrema per normal, AABBs; non-convex polygons are refused like :49).
+ *      Nested Compound2D parts are not represented: flatten them (every basic test starts with its own AABB check). */
+#define MPFMT_SHAPE_CIRCLE  0
+#define MPFMT_SHAPE_POLYGON 1
+int32_t mpfmt_upload_shapes2d(mpfmt_ctx* ctx, int32_t n_shapes, const int32_t* kinds, const int32_t* nverts, const double* data,
+                              const double* ss_lo, const double* ss_hi);
+
 /* ---- graph persistence: install a graph exported earlier by mpfmt_rdisc_count / mpfmt_rdisc_fill (same
  *      1-based CSC: colptr[N+1], rowval[nnz] strictly ascending per column, nzval[nnz]) for the samples now uploaded --
  *      the reference's ImmutableNNC(D, r) (src/nearneighbors.jl:23-28; its saveNN / loadNN! are commented out, :114-116).

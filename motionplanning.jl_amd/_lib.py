@@ -59,6 +59,7 @@ SYMBOLS = [
     ("mpfmt_host_fmt_recursion", C.c_int32, [C.c_int64, C.c_int32, c_d_p, c_i64_p, C.POINTER(C.c_int32), c_d_p, c_u64_p, c_u64_p,
                                              c_d_p, c_d_p, C.c_int64, C.c_int32, c_d_p, c_i64_p, c_d_p, c_i64_p,
                                              C.POINTER(FmtResult)]),
+    ("mpfmt_upload_shapes2d", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_d_p, c_d_p, c_d_p]),
     ("mpfmt_graph_import", C.c_int32, [C.c_void_p, C.c_double, c_i64_p, c_i64_p, c_d_p]),
     ("mpfmt_sample_free", C.c_int32, [C.c_void_p, C.c_uint64, C.c_int64, c_d_p, C.c_int32, c_d_p, C.c_int32, c_d_p, c_i64_p]),
     ("mpfmt_di_graph_count", C.c_int32, [C.c_void_p, C.c_double, C.c_double, c_i64_p, c_i64_p]),
@@ -225,6 +226,20 @@ class Context:
         ds = 0 if lo is None else lo.size
         self._chk(self._L.mpfmt_upload_boxes(self._h, _dp(lohi), M, dw, _dp(lo), _dp(hi), ds))
         self.dw = dw
+
+    def upload_shapes2d(self, shapes, ss_lo=None, ss_hi=None):
+        """2-D SAT world: shapes = [("circle", (cx, cy), r) | ("polygon", [(x, y), ...]), ...] (a flat Compound2D)."""
+        kinds = np.array([0 if s[0] == "circle" else 1 for s in shapes], dtype=np.int32)
+        nv = np.array([0 if s[0] == "circle" else len(s[1]) for s in shapes], dtype=np.int32)
+        parts = [np.array([s[1][0], s[1][1], s[2]], dtype=np.float64) if s[0] == "circle"
+                 else np.ascontiguousarray(s[1], dtype=np.float64).reshape(-1) for s in shapes]
+        data = np.concatenate(parts) if parts else np.zeros(1)
+        lo = None if ss_lo is None else np.ascontiguousarray(ss_lo, dtype=np.float64)
+        hi = None if ss_hi is None else np.ascontiguousarray(ss_hi, dtype=np.float64)
+        i32 = C.POINTER(C.c_int32)
+        self._chk(self._L.mpfmt_upload_shapes2d(self._h, len(shapes), kinds.ctypes.data_as(i32), nv.ctypes.data_as(i32), _dp(data),
+                                                None if lo is None else _dp(lo), None if hi is None else _dp(hi)))
+        self.dw = 2
 
     # ---- r-disc ---------------------------------------------------------------------------------
     def rdisc_count(self, r):

@@ -458,6 +458,7 @@ int32_t mpfmt_di_sweep(mpfmt_ctx* ctx)
 {
     if (!ctx->di_filled) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "di sweep before the di graph is filled");
     if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
+    if (ctx->cc_kind != 0) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the double-integrator sweep runs against the AABB checker (mpfmt_upload_boxes)");
     const int m = ctx->d / 2;
     if (ctx->dw != m) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "workspace dim %d != state dim / 2 = %d", ctx->dw, m);
     if (ctx->ss.has && ctx->ss.d != ctx->d) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "state-space bounds have %d dims, states %d", ctx->ss.d, ctx->d);

@@ -629,6 +629,7 @@ static int32_t check_boxes(mpfmt_ctx* ctx, int d)
 static int32_t launch_points(mpfmt_ctx* ctx, const double* X, const int64_t* idx1, int64_t n, int d, uint64_t* d_mask)
 {
     if (n == 0) return MPFMT_OK;
+    if (ctx->cc_kind == 1) return mpfmt_2d_launch_points(ctx, X, idx1, n, d_mask);
     const int chunk = box_chunk(ctx->M, d, false);
     const size_t lds = sweep_lds(chunk, d);
     const unsigned nb = (unsigned)((n + SWEEP_THREADS - 1) / SWEEP_THREADS);
@@ -662,6 +663,7 @@ static int32_t launch_edges(mpfmt_ctx* ctx, const int64_t* s1, const int64_t* t1
                             int64_t E, int d, uint64_t* d_mask)
 {
     if (E == 0) return MPFMT_OK;
+    if (ctx->cc_kind == 1) return mpfmt_2d_launch_edges(ctx, s1, t1, P, Q, E, d_mask);
     const int chunk = box_chunk(ctx->M, d, true);
     const size_t lds = sweep_lds(chunk, d);
     const unsigned nb = (unsigned)((E + SWEEP_THREADS - 1) / SWEEP_THREADS);
@@ -698,6 +700,15 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
     if (!ctx->graph_filled) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "graph sweep before the r-disc graph is filled");
     const int64_t words = (ctx->nnz + 63) / 64;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->graph_free, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1)))) return rc;
+    if (ctx->cc_kind == 1) {                                         // 2-D SAT world: lane = entry, whole words written
+        mpfmt_time_begin(ctx);
+        HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
+        rc = mpfmt_2d_launch_graph(ctx);
+        mpfmt_time_end(ctx, "sweep_graph");
+        if (rc) return rc;
+        ctx->graph_swept = true;
+        return MPFMT_OK;
+    }
     mpfmt_time_begin(ctx);
     // preset to ones (the sweep clears blocked entries); an empty graph keeps one zero word
     HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, ctx->nnz > 0 ? 0xFF : 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));

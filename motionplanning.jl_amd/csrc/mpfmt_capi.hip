@@ -184,7 +184,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
-                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->pool_flag, ctx->pool, ctx->lists, ctx->list_len, ctx->sweep_ctr};
+                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->pool_flag, ctx->pool, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->shapes2d};
     for (void* b : bufs) if (b) hipFree(b);
     timer_resolve(ctx);
     if (ctx->timer_state) {
@@ -257,7 +257,7 @@ int32_t mpfmt_upload_boxes(mpfmt_ctx* ctx, const double* lohi, int32_t M, int32_
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->boxes, sizeof(double) * (size_t)M * 2 * dw))) return rc;
     if (M > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->boxes, lohi, sizeof(double) * (size_t)M * 2 * dw, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->M = M; ctx->dw = dw; ctx->have_boxes = true;
+    ctx->M = M; ctx->dw = dw; ctx->have_boxes = true; ctx->cc_kind = 0;
     ctx->ss.has = ss_lo ? 1 : 0;
     ctx->ss.d = ss_lo ? d_state : 0;
     for (int i = 0; i < MPFMT_MAX_DIM; ++i) { ctx->ss.lo[i] = -INFINITY; ctx->ss.hi[i] = INFINITY; }

@@ -45,6 +45,16 @@ struct mpfmt_ss {                        // BoundedStateSpace bounds (statespace
 // one hit of the single-pass build: row sample index + distance in ONE 16-byte record (one store, one sector)
 struct __attribute__((aligned(16))) mpfmt_hit { int32_t j; int32_t pad; double d; };
 
+// 2-D SAT world (kernels_sat2d.hip): a Circle or a convex Polygon with the fields the predicates read
+#define MPFMT_MAX_POLY 16
+struct mpfmt_shape2d {
+    int32_t kind, n;
+    double c[2], r;
+    double xr[2], yr[2];
+    double pts[MPFMT_MAX_POLY][2], normals[MPFMT_MAX_POLY][2], nex[MPFMT_MAX_POLY][2];
+};
+struct mpfmt_aabb2d { double xr[2], yr[2]; };
+
 struct mpfmt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -127,6 +137,9 @@ struct mpfmt_ctx {
     double* boxes = nullptr;             // [M][2][dw]
     int32_t M = 0, dw = 0;
     bool have_boxes = false;
+    int32_t cc_kind = 0;                 // collision checker: 0 = PointRobotNDBoxes, 1 = PointRobot2D (SAT)
+    mpfmt_shape2d* shapes2d = nullptr;   // [M] when cc_kind == 1
+    mpfmt_aabb2d aabb2d;                 // Compound2D bounding box
     mpfmt_ss ss;
 
     // ---- scratch -------------------------------------------------------------------------------
@@ -170,6 +183,9 @@ int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* 
 
 // kernels_sweep.hip -----------------------------------------------------------------------------
 int32_t mpfmt_launch_points_free(mpfmt_ctx* ctx, const int64_t* d_idx1, int64_t n, uint64_t* d_mask);
+int32_t mpfmt_2d_launch_points(mpfmt_ctx* ctx, const double* X, const int64_t* idx1, int64_t n, uint64_t* d_mask);
+int32_t mpfmt_2d_launch_edges(mpfmt_ctx* ctx, const int64_t* s1, const int64_t* t1, const double* P, const double* Q, int64_t E, uint64_t* d_mask);
+int32_t mpfmt_2d_launch_graph(mpfmt_ctx* ctx);
 int32_t mpfmt_launch_states_free(mpfmt_ctx* ctx, const double* d_P, int64_t n, uint64_t* d_mask);
 int32_t mpfmt_launch_edges_free(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, uint64_t* d_mask);
 int32_t mpfmt_launch_motions_free(mpfmt_ctx* ctx, const double* d_P, const double* d_Q, int64_t n, uint64_t* d_mask);

@@ -116,6 +116,65 @@ class PointRobotNDBoxes:
         return self.addobstacle(BoxBounds(v - r, v + r))
 
 
+# ---- 2-D shapes and the SAT point robot (src/collisioncheckers/SAT2D.jl, robots2D.jl) ---------------------------------------
+class Circle:
+    def __init__(self, c, r):
+        if r <= 0:
+            raise ValueError("Radius must be positive")                      # SAT2D.jl:22
+        self.c, self.r = (float(c[0]), float(c[1])), float(r)
+
+    def parts(self):
+        return [("circle", self.c, self.r)]
+
+
+class Polygon:
+    def __init__(self, points):
+        if len(points) < 3:
+            raise ValueError("Polygons need at least 3 points! Try Line?")    # SAT2D.jl:42
+        self.points = [(float(p[0]), float(p[1])) for p in points]
+
+    def parts(self):
+        return [("polygon", self.points)]
+
+
+def Box2D(xr, yr):                                                            # SAT2D.jl:59-62
+    return Polygon([(xr[0], yr[0]), (xr[1], yr[0]), (xr[1], yr[1]), (xr[0], yr[1])])
+
+
+class Compound2D:
+    """Compound2D(parts...) -- nested compounds are flattened (every basic test begins with its own AABB check)."""
+
+    def __init__(self, *parts):
+        if len(parts) == 1 and isinstance(parts[0], (list, tuple)):
+            parts = tuple(parts[0])
+        self._parts = list(parts)
+
+    def parts(self):
+        return [q for P in self._parts for q in P.parts()]
+
+
+class PointRobot2D:
+    """Point robot among 2-D shapes; `count` = segment checks asked for (robots2D.jl:5-14)."""
+
+    def __init__(self, obstacles):
+        self.obstacles = obstacles if isinstance(obstacles, Compound2D) else Compound2D(obstacles)
+        self.count = 0
+        self._ctx = None
+        self._ss = None
+
+    def _bind(self, ctx, SS):
+        if SS.workspace_dim != 2 or dim(SS) != 2:
+            raise ValueError("PointRobot2D needs a 2-D state space")
+        ctx.upload_shapes2d(self.obstacles.parts(), SS.lo, SS.hi)
+        self._ctx, self._ss = ctx, SS
+
+    def addobstacle(self, o):                                                 # robots2D.jl:23
+        return PointRobot2D(Compound2D(self.obstacles, o))
+
+    def addblocker(self, p, r):                                               # robots2D.jl:24
+        return self.addobstacle(Circle(p, r))
+
+
 def is_free_state(v, CC, SS, ctx):
     """in_state_space(v, SS) && is_free_state(state2workspace(v), CC)   (statespaces.jl:151-152); v: (d,) or (n, d)."""
     V = np.atleast_2d(np.asarray(v, dtype=np.float64))

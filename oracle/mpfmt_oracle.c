@@ -39,6 +39,7 @@
 #include <string.h>
 
 #define ORC_MAXD 16
+#define ORC_MAXPOLY 16     /* vertices per convex polygon of the 2-D SAT world */
 
 /* ------------------------------------------------------------------------- */
 /* a4: distance evaluation  (src/statespaces/geometric.jl:4-6)                */
@@ -1073,4 +1074,187 @@ int32_t orc_sample_free(uint64_t seed, int64_t N, int32_t d, const double *init,
         memcpy(W + (size_t)(N - i) * d, v, sizeof(double) * (size_t)d);
     }
     return 0;
+}
+
+/* ---- 2-D SAT world: PointRobot2D over a Compound2D of Circle / convex Polygon parts ------------------
+ * src/collisioncheckers/SAT2D.jl, robots2D.jl:12-14, utilities/vec2Dutils.jl.  Canon as elsewhere: fp64, unfused,
+ * dot(a,b) = a1*b1 + a2*b2, cross(a,b) = a1*b2 - a2*b1 (vec2Dutils.jl:5-7), normalize(v) = v / norm(v).
+ * NOTE (bug compatibility): colliding(p, P::Polygon) is written `@all [!ininterval(dot(p, n_i), nextrema_i)]`
+ * (SAT2D.jl:124-127), i.e. a point collides with a polygon only if it projects OUTSIDE the polygon's extent on every
+ * edge normal -- the restatement follows the reference as written. */
+typedef struct {
+    int32_t kind;                 /* 0 circle, 1 polygon */
+    int32_t n;                    /* polygon vertex count */
+    double c[2], r;               /* circle */
+    double xr[2], yr[2];          /* AABB (xrange, yrange) */
+    double pts[ORC_MAXPOLY][2], edges[ORC_MAXPOLY][2], normals[ORC_MAXPOLY][2], nex[ORC_MAXPOLY][2];
+} orc_shape2d;
+
+static inline double dot2(const double *a, const double *b) { const double p = a[0] * b[0]; const double q = a[1] * b[1]; return p + q; }
+static inline double cross2(const double *a, const double *b) { const double p = a[0] * b[1]; const double q = a[1] * b[0]; return p - q; }
+static inline int overlapping(const double *i1, const double *i2) { return i1[0] <= i2[1] && i2[0] <= i1[1]; }   /* vec2Dutils.jl:33 */
+static inline int ininterval(double x, const double *i) { return i[0] <= x && x <= i[1]; }                         /* :34 */
+static void project_extrema(const double (*pts)[2], int n, const double *ax, double *out)                           /* :19-28 */
+{
+    double dmin = INFINITY, dmax = -INFINITY;
+    for (int i = 0; i < n; ++i) { const double d = dot2(pts[i], ax); if (d < dmin) dmin = d; if (d > dmax) dmax = d; }
+    out[0] = dmin; out[1] = dmax;
+}
+
+/* Circle(c, r) (SAT2D.jl:26-28) / Polygon(points) (SAT2D.jl:40-55).  data: circle [cx, cy, r]; polygon [x1,y1,...].
+ * Returns 0, -1 bad arguments (r <= 0, n < 3, n > ORC_MAXPOLY), -2 polygon not convex. */
+int32_t orc_shape2d_build(int32_t kind, int32_t n, const double *data, orc_shape2d *S)
+{
+    memset(S, 0, sizeof *S);
+    S->kind = kind;
+    if (kind == 0) {
+        if (!(data[2] > 0)) return -1;
+        S->c[0] = data[0]; S->c[1] = data[1]; S->r = data[2];
+        S->xr[0] = data[0] - data[2]; S->xr[1] = data[0] + data[2];
+        S->yr[0] = data[1] - data[2]; S->yr[1] = data[1] + data[2];
+        return 0;
+    }
+    if (n < 3 || n > ORC_MAXPOLY) return -1;
+    S->n = n;
+    for (int i = 0; i < n; ++i) { S->pts[i][0] = data[2 * i]; S->pts[i][1] = data[2 * i + 1]; }
+    double area = 0.0;                                   /* sum([...]) accumulates left to right from zero */
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1 < n) ? i + 1 : 0;
+        const double a = S->pts[j][0] - S->pts[i][0], b = S->pts[j][1] + S->pts[i][1];
+        const double t = a * b;
+        area = (i == 0) ? t : area + t;
+    }
+    if (area > 0)                                        /* reverse!(points) */
+        for (int i = 0; i < n / 2; ++i)
+            for (int k = 0; k < 2; ++k) { const double t = S->pts[i][k]; S->pts[i][k] = S->pts[n - 1 - i][k]; S->pts[n - 1 - i][k] = t; }
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1 < n) ? i + 1 : 0;
+        S->edges[i][0] = S->pts[j][0] - S->pts[i][0]; S->edges[i][1] = S->pts[j][1] - S->pts[i][1];
+        const double px = S->edges[i][1], py = -S->edges[i][0];            /* perp(g) = (g2, -g1) */
+        const double p = px * px, q = py * py;
+        const double nrm = sqrt(p + q);
+        S->normals[i][0] = px / nrm; S->normals[i][1] = py / nrm;
+    }
+    for (int i = 0; i < n; ++i) {                        /* convexity: consecutive normal angles must not step in [-pi, 0] */
+        const int j = (i + 1 < n) ? i + 1 : 0;
+        const double di = atan2(S->normals[j][1], S->normals[j][0]) - atan2(S->normals[i][1], S->normals[i][0]);
+        if (-M_PI <= di && di <= 0) return -2;
+    }
+    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    for (int i = 0; i < n; ++i) {
+        if (S->pts[i][0] < xmin) xmin = S->pts[i][0];
+        if (S->pts[i][0] > xmax) xmax = S->pts[i][0];
+        if (S->pts[i][1] < ymin) ymin = S->pts[i][1];
+        if (S->pts[i][1] > ymax) ymax = S->pts[i][1];
+    }
+    S->xr[0] = xmin; S->xr[1] = xmax; S->yr[0] = ymin; S->yr[1] = ymax;
+    for (int i = 0; i < n; ++i) project_extrema(S->pts, n, S->normals[i], S->nex[i]);
+    return 0;
+}
+int64_t orc_shape2d_sizeof(void) { return (int64_t)sizeof(orc_shape2d); }
+
+/* colliding(p, S) (SAT2D.jl:121-133) */
+static int point_colliding_shape(const double *p, const orc_shape2d *S)
+{
+    if (S->kind == 0) {
+        const double t[2] = {p[0] - S->c[0], p[1] - S->c[1]};
+        return dot2(t, t) <= S->r * S->r;
+    }
+    if (!(ininterval(p[0], S->xr) && ininterval(p[1], S->yr))) return 0;
+    for (int i = 0; i < S->n; ++i)
+        if (ininterval(dot2(p, S->normals[i]), S->nex[i])) return 0;       /* @all [!ininterval(...)] as written */
+    return 1;
+}
+
+/* colliding_ends_free(L, S) (SAT2D.jl:163-174) with L = Line(v, w) (SAT2D.jl:66-81) */
+static int line_colliding_ends_free(const double *v, const double *w, const orc_shape2d *S)
+{
+    const double edge[2] = {w[0] - v[0], w[1] - v[1]};
+    const double lx[2] = {v[0] < w[0] ? v[0] : w[0], v[0] < w[0] ? w[0] : v[0]};     /* minmaxV */
+    const double ly[2] = {v[1] < w[1] ? v[1] : w[1], v[1] < w[1] ? w[1] : v[1]};
+    if (!(overlapping(lx, S->xr) && overlapping(ly, S->yr))) return 0;                 /* AABBseparated */
+    if (S->kind == 0) {
+        const double vc[2] = {S->c[0] - v[0], S->c[1] - v[1]};
+        const double d2 = dot2(edge, edge);
+        const double cr = cross2(edge, vc);
+        const double lhs = d2 * (S->r * S->r), rhs = cr * cr;                          /* d2*C.r^2 < cross(...)^2 */
+        if (lhs < rhs) return 0;
+        const double t = dot2(vc, edge);
+        return 0 <= t && t <= d2;
+    }
+    const double normal[2] = {edge[1], -edge[0]};                                      /* perp(edge), not normalised */
+    const double ndotv = dot2(v, normal);
+    double ex[2];
+    project_extrema(S->pts, S->n, normal, ex);
+    if (!ininterval(ndotv, ex)) return 0;                                              /* is_separating_axis(L, P) */
+    for (int i = 0; i < S->n; ++i) {                                                   /* is_separating_axis(P, L, i) */
+        const double a = dot2(v, S->normals[i]), b = dot2(w, S->normals[i]);
+        const double li[2] = {a < b ? a : b, a < b ? b : a};
+        if (!overlapping(S->nex[i], li)) return 0;
+    }
+    return 1;
+}
+
+/* colliding(L, B) = colliding_ends_free(L,B) || colliding(L.v,B) || colliding(L.w,B) (SAT2D.jl:176) */
+static int line_colliding_shape(const double *v, const double *w, const orc_shape2d *S)
+{
+    return line_colliding_ends_free(v, w, S) || point_colliding_shape(v, S) || point_colliding_shape(w, S);
+}
+
+static void compound_aabb(const orc_shape2d *S, int32_t n, double *xr, double *yr)     /* Compound2D ctor, SAT2D.jl:88-97 */
+{
+    if (n == 0) { xr[0] = xr[1] = yr[0] = yr[1] = 0.0; return; }
+    xr[0] = yr[0] = INFINITY; xr[1] = yr[1] = -INFINITY;
+    for (int32_t i = 0; i < n; ++i) {
+        if (S[i].xr[0] < xr[0]) xr[0] = S[i].xr[0];
+        if (S[i].xr[1] > xr[1]) xr[1] = S[i].xr[1];
+        if (S[i].yr[0] < yr[0]) yr[0] = S[i].yr[0];
+        if (S[i].yr[1] > yr[1]) yr[1] = S[i].yr[1];
+    }
+}
+
+/* is_free_state(v, CC::PointRobot2D) = !colliding(v, CC.obstacles) (robots2D.jl:12; compound SAT2D.jl:129-132) */
+int32_t orc_2d_point_free(const double *p, const orc_shape2d *S, int32_t n)
+{
+    double xr[2], yr[2];
+    compound_aabb(S, n, xr, yr);
+    if (!(ininterval(p[0], xr) && ininterval(p[1], yr))) return 1;
+    for (int32_t i = 0; i < n; ++i) if (point_colliding_shape(p, &S[i])) return 0;
+    return 1;
+}
+
+/* is_free_motion(v, w, CC::PointRobot2D) = !colliding(Line(v,w), CC.obstacles) (robots2D.jl:13-14; SAT2D.jl:154-157,178) */
+int32_t orc_2d_motion_free(const double *v, const double *w, const orc_shape2d *S, int32_t n)
+{
+    double xr[2], yr[2];
+    compound_aabb(S, n, xr, yr);
+    const double lx[2] = {v[0] < w[0] ? v[0] : w[0], v[0] < w[0] ? w[0] : v[0]};
+    const double ly[2] = {v[1] < w[1] ? v[1] : w[1], v[1] < w[1] ? w[1] : v[1]};
+    if (!(overlapping(xr, lx) && overlapping(yr, ly))) return 1;                       /* AABBseparated(C, L) */
+    for (int32_t i = 0; i < n; ++i) if (line_colliding_shape(v, w, &S[i])) return 0;
+    return 1;
+}
+
+/* batch forms with the state-space wrappers of statespaces.jl:150-158 (Identity state2workspace, d = 2) */
+void orc_2d_points_free(const double *P, int64_t n, const orc_shape2d *S, int32_t ns, const double *ss_lo, const double *ss_hi, uint64_t *mask)
+{
+    memset(mask, 0, sizeof(uint64_t) * (size_t)((n + 63) / 64));
+    for (int64_t e = 0; e < n; ++e)
+        set_bit(mask, e, orc_in_state_space(P + 2 * e, ss_lo, ss_hi, 2) && orc_2d_point_free(P + 2 * e, S, ns));
+}
+void orc_2d_motions_free(const double *P, const double *Q, int64_t n, const orc_shape2d *S, int32_t ns, const double *ss_lo, const double *ss_hi, uint64_t *mask)
+{
+    memset(mask, 0, sizeof(uint64_t) * (size_t)((n + 63) / 64));
+    for (int64_t e = 0; e < n; ++e)
+        set_bit(mask, e, orc_in_state_space(P + 2 * e, ss_lo, ss_hi, 2) && orc_2d_motion_free(P + 2 * e, Q + 2 * e, S, ns));
+}
+void orc_2d_graph_edges_free(const double *X, int64_t N, const int64_t *colptr, const int64_t *rowval, const orc_shape2d *S, int32_t ns,
+                             const double *ss_lo, const double *ss_hi, uint64_t *mask)
+{
+    memset(mask, 0, sizeof(uint64_t) * (size_t)((colptr[N] + 63) / 64));
+    for (int64_t x = 0; x < N; ++x)
+        for (int64_t e = colptr[x]; e < colptr[x + 1]; ++e) {
+            const double *v = X + 2 * rowval[e], *w = X + 2 * x;
+            set_bit(mask, e, orc_in_state_space(v, ss_lo, ss_hi, 2) && orc_2d_motion_free(v, w, S, ns));
+        }
 }

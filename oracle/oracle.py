@@ -365,3 +365,50 @@ def sample_free(seed, N, d, init, lohi, ss_lo, ss_hi, goal_kind, goal, goal_ct=1
                                C.c_int32(M), _d(ss_lo), _d(ss_hi), C.c_int32(goal_kind), _d(goal), C.c_int32(goal_ct),
                                _d(W), C.byref(att))
     return rc, W, int(att.value)
+
+
+# ---- 2-D SAT world ------------------------------------------------------------------------------------
+class Shapes2D:
+    """Compound2D of Circle / Polygon parts.  shapes: list of ("circle", (cx, cy), r) | ("polygon", [(x, y), ...])."""
+
+    def __init__(self, shapes):
+        L = lib()
+        L.orc_shape2d_sizeof.restype = C.c_int64
+        self.sz = int(L.orc_shape2d_sizeof())
+        self.n = len(shapes)
+        self.buf = C.create_string_buffer(max(self.n, 1) * self.sz)
+        for i, s in enumerate(shapes):
+            if s[0] == "circle":
+                data = np.array([s[1][0], s[1][1], s[2]], dtype=np.float64); kind, nv = 0, 0
+            else:
+                data = np.ascontiguousarray(s[1], dtype=np.float64).reshape(-1); kind, nv = 1, len(s[1])
+            rc = L.orc_shape2d_build(C.c_int32(kind), C.c_int32(nv), _d(data), C.c_void_p(C.addressof(self.buf) + i * self.sz))
+            if rc != 0:
+                raise ValueError("shape %d rejected (%d)" % (i, rc))
+
+    @property
+    def ptr(self):
+        return C.c_void_p(C.addressof(self.buf))
+
+
+def points_free_2d(P, S, ss_lo=None, ss_hi=None):
+    P = np.ascontiguousarray(P, dtype=np.float64); n = len(P)
+    mask = np.zeros(max(nwords(n), 1), dtype=np.uint64)
+    lib().orc_2d_points_free(_d(P), C.c_int64(n), S.ptr, C.c_int32(S.n), _d(_vec(ss_lo)), _d(_vec(ss_hi)), _u(mask))
+    return mask[:nwords(n)]
+
+
+def motions_free_2d(P, Q, S, ss_lo=None, ss_hi=None):
+    P = np.ascontiguousarray(P, dtype=np.float64); Q = np.ascontiguousarray(Q, dtype=np.float64); n = len(P)
+    mask = np.zeros(max(nwords(n), 1), dtype=np.uint64)
+    lib().orc_2d_motions_free(_d(P), _d(Q), C.c_int64(n), S.ptr, C.c_int32(S.n), _d(_vec(ss_lo)), _d(_vec(ss_hi)), _u(mask))
+    return mask[:nwords(n)]
+
+
+def graph_edges_free_2d(X, colptr, rowval, S, ss_lo=None, ss_hi=None):
+    X, N, d = _X(X)
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64); rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+    nnz = int(colptr[-1])
+    mask = np.zeros(max(nwords(nnz), 1), dtype=np.uint64)
+    lib().orc_2d_graph_edges_free(_d(X), C.c_int64(N), _i(colptr), _i(rowval), S.ptr, C.c_int32(S.n), _d(_vec(ss_lo)), _d(_vec(ss_hi)), _u(mask))
+    return mask[:nwords(nnz)]

@@ -189,3 +189,157 @@ def fmtstar(V, r, is_goal, boxes, ss_lo, ss_hi, checkpts=True, init_idx=1):
             break
     return dict(status=is_goal(V[z - 1]), cost=Cc[z], z=z, collision_checks=count,
                 A=[A[i] for i in range(1, N + 1)], C=[Cc[i] for i in range(1, N + 1)], path=sol)
+
+
+# ---- 2-D SAT world: src/collisioncheckers/SAT2D.jl, robots2D.jl, utilities/vec2Dutils.jl ----------------------------
+# Shapes are plain dicts; every function below is the Julia line it cites, evaluated with Python floats (IEEE fp64,
+# one rounding per operation, like Julia's un-fused scalar code).
+import math as _m
+
+
+def dot(a, b):                 # dot(::SVector{2}, ::SVector{2})
+    return a[0] * b[0] + a[1] * b[1]
+
+
+def cross(a, b):               # vec2Dutils.jl:7
+    return a[0] * b[1] - a[1] * b[0]
+
+
+def norm2(v):                  # vec2Dutils.jl:5
+    return dot(v, v)
+
+
+def perp(v):                   # vec2Dutils.jl:6
+    return (v[1], -v[0])
+
+
+def minmaxV(x, y):             # vec2Dutils.jl:35
+    return (x, y) if x < y else (y, x)
+
+
+def overlapping(i1, i2):       # vec2Dutils.jl:33
+    return i1[0] <= i2[1] and i2[0] <= i1[1]
+
+
+def ininterval(x, i):          # vec2Dutils.jl:34
+    return i[0] <= x <= i[1]
+
+
+def wrap1(i, n):               # vec2Dutils.jl:36 (1-based)
+    return n if i < 1 else 1 if i > n else i
+
+
+def projectNextrema(pts, n):   # vec2Dutils.jl:19-28
+    dmin, dmax = _m.inf, -_m.inf
+    for p in pts:
+        d = dot(p, n)
+        if d < dmin:
+            dmin = d
+        if d > dmax:
+            dmax = d
+    return (dmin, dmax)
+
+
+def Circle(c, r):              # SAT2D.jl:14-28
+    if r <= 0:
+        raise ValueError("Radius must be positive")
+    return dict(kind="circle", c=(c[0], c[1]), r=r, xrange=(c[0] - r, c[0] + r), yrange=(c[1] - r, c[1] + r))
+
+
+def Polygon(points):           # SAT2D.jl:40-58
+    pts = [(float(p[0]), float(p[1])) for p in points]
+    N = len(pts)
+    if N < 3:
+        raise ValueError("Polygons need at least 3 points")
+    s = 0.0
+    for i in range(1, N + 1):
+        a, b = pts[wrap1(i + 1, N) - 1], pts[i - 1]
+        t = (a[0] - b[0]) * (a[1] + b[1])
+        s = t if i == 1 else s + t
+    if s > 0:
+        pts.reverse()
+    edges = [(pts[wrap1(i + 1, N) - 1][0] - pts[i - 1][0], pts[wrap1(i + 1, N) - 1][1] - pts[i - 1][1]) for i in range(1, N + 1)]
+    normals = []
+    for g in edges:
+        p = perp(g)
+        nrm = _m.sqrt(p[0] * p[0] + p[1] * p[1])
+        normals.append((p[0] / nrm, p[1] / nrm))
+    ang = [_m.atan2(n[1], n[0]) for n in normals] + [_m.atan2(normals[0][1], normals[0][0])]
+    if any(-_m.pi <= ang[i + 1] - ang[i] <= 0 for i in range(N)):
+        raise ValueError("Polygon must be convex")
+    xs = [p[0] for p in pts]; ys = [p[1] for p in pts]
+    return dict(kind="polygon", points=pts, edges=edges, normals=normals, xrange=(min(xs), max(xs)), yrange=(min(ys), max(ys)),
+                nextrema=[projectNextrema(pts, n) for n in normals])
+
+
+def Box2D(xr, yr):             # SAT2D.jl:59-62
+    return Polygon([(xr[0], yr[0]), (xr[1], yr[0]), (xr[1], yr[1]), (xr[0], yr[1])])
+
+
+def Compound2D(parts):         # SAT2D.jl:83-97
+    if not parts:
+        return dict(kind="compound", parts=[], xrange=(0.0, 0.0), yrange=(0.0, 0.0))
+    return dict(kind="compound", parts=list(parts),
+                xrange=(min(P["xrange"][0] for P in parts), max(P["xrange"][1] for P in parts)),
+                yrange=(min(P["yrange"][0] for P in parts), max(P["yrange"][1] for P in parts)))
+
+
+def Line(v, w):                # SAT2D.jl:66-81
+    edge = (w[0] - v[0], w[1] - v[1])
+    normal = perp(edge)
+    return dict(kind="line", v=(v[0], v[1]), w=(w[0], w[1]), edge=edge, normal=normal, xrange=minmaxV(v[0], w[0]),
+                yrange=minmaxV(v[1], w[1]), ndotv=dot(v, normal))
+
+
+def AABBseparated(S1, S2):     # SAT2D.jl:119
+    return not (overlapping(S1["xrange"], S2["xrange"]) and overlapping(S1["yrange"], S2["yrange"]))
+
+
+def pointinAABB(p, S):         # SAT2D.jl:120
+    return ininterval(p[0], S["xrange"]) and ininterval(p[1], S["yrange"])
+
+
+def colliding_point(p, S):     # SAT2D.jl:121-133
+    if S["kind"] == "circle":
+        t = (p[0] - S["c"][0], p[1] - S["c"][1])
+        return norm2(t) <= S["r"] ** 2
+    if S["kind"] == "polygon":
+        if not pointinAABB(p, S):
+            return False
+        return jl_all(not ininterval(dot(p, S["normals"][i]), S["nextrema"][i]) for i in range(len(S["normals"])))
+    if not pointinAABB(p, S):
+        return False
+    return jl_any(colliding_point(p, P) for P in S["parts"])
+
+
+def colliding_ends_free(L, S):  # SAT2D.jl:163-174,179-182
+    if S["kind"] == "circle":
+        if AABBseparated(L, S):
+            return False
+        vc = (S["c"][0] - L["v"][0], S["c"][1] - L["v"][1])
+        d2 = norm2(L["edge"])
+        if d2 * S["r"] ** 2 < cross(L["edge"], vc) ** 2:
+            return False
+        return 0 <= dot(vc, L["edge"]) <= d2
+    if AABBseparated(L, S):
+        return False
+    if not ininterval(L["ndotv"], projectNextrema(S["points"], L["normal"])):          # is_separating_axis(L, P), :113
+        return False
+    return not jl_any(not overlapping(S["nextrema"][i], minmaxV(dot(L["v"], S["normals"][i]), dot(L["w"], S["normals"][i])))
+                      for i in range(len(S["normals"])))                               # :112, :80
+
+
+def colliding_line(L, S):      # SAT2D.jl:154-157,176-178
+    if S["kind"] == "compound":
+        if AABBseparated(S, L):
+            return False
+        return jl_any(colliding_line(L, P) for P in S["parts"])
+    return colliding_ends_free(L, S) or colliding_point(L["v"], S) or colliding_point(L["w"], S)
+
+
+def is_free_state_2d(v, obstacles, ss_lo=None, ss_hi=None):       # statespaces.jl:151-152 + robots2D.jl:12
+    return (ss_lo is None or in_state_space(v, ss_lo, ss_hi)) and not colliding_point(v, obstacles)
+
+
+def is_free_motion_2d(v, w, obstacles, ss_lo=None, ss_hi=None):   # statespaces.jl:153-158 + robots2D.jl:13-14
+    return (ss_lo is None or in_state_space(v, ss_lo, ss_hi)) and not colliding_line(Line(v, w), obstacles)

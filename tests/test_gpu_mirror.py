@@ -103,3 +103,29 @@ def test_double_integrator_planning_like_the_notebook(orc):
     assert P.solution.metadata["collision_checks"] == ref["collision_checks"]
     if ref["status"]:
         assert abs(cost - ref["cost"]) <= 1e-6 * ref["cost"]
+
+
+def test_polygon_world_planning_like_the_notebook(orc):
+    """The notebook's 2-D setup (PointRobot2D over ISRR_POLY-style obstacles, SAT2D.jl) through the mirror types."""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shapes_2d.json")))
+    parts = [mp.Circle(s[1], s[2]) if s[0] == "circle" else mp.Polygon(s[1]) for s in fx["worlds"]["ISRR_POLY"]]
+    CC = mp.PointRobot2D(mp.Compound2D(parts))
+    SS = mp.UnitHypercube(2)
+    P = mp.MPProblem(SS, [0.1, 0.1], mp.BallGoal([0.9, 0.9], 0.05), CC)
+    status, cost, _ = mp.fmtstar_(P, 2500, rm=1.5, seed=9)
+    assert status == "solved"
+    md = P.solution.metadata
+    X = P.V.V
+    S = orc.Shapes2D([("circle", tuple(s[1]), s[2]) if s[0] == "circle" else ("polygon", [tuple(p) for p in s[1]])
+                      for s in fx["worlds"]["ISRR_POLY"]])
+    assert orc.unpack(orc.points_free_2d(X, S, SS.lo, SS.hi), len(X)).all()
+    path = md["path"] - 1
+    seg_free = orc.unpack(orc.motions_free_2d(X[path[:-1]], X[path[1:]], S, SS.lo, SS.hi), len(path) - 1)
+    assert seg_free.all()                                         # the returned path is collision free
+    assert abs(cost - np.sum(np.linalg.norm(X[path[1:]] - X[path[:-1]], axis=1))) <= 1e-9 * cost
+    assert not mp.is_free_motion([0.3, 0.5], [0.6, 0.5], CC, SS, P.ctx)       # through the big hexagon
+    assert mp.is_free_motion([0.05, 0.05], [0.95, 0.05], CC, SS, P.ctx)
+    assert CC.count == md["collision_checks"] + 2
+    blocked = CC.addblocker([0.5, 0.05], 0.04)
+    assert not mp.is_free_motion([0.05, 0.05], [0.95, 0.05], blocked, SS, P.ctx)

@@ -641,3 +641,75 @@ def test_graph_export_import_replan(orc, tmp_path):
         b.graph_import(w.r, z["colptr"], bad, z["nzval"])
     assert e.value.code == mp._lib.ERR_ARG
     a.close(); b.close()
+
+
+# ---- 2-D SAT world -------------------------------------------------------------------------------------
+
+def _shapes(fx_shapes):
+    return [("circle", tuple(s[1]), s[2]) if s[0] == "circle" else ("polygon", [tuple(p) for p in s[1]]) for s in fx_shapes]
+
+
+@pytest.mark.parametrize("name", ["ISRR_2H", "TRI_BALLS", "ISRR_POLY", "ISRR_POLY_WITH_SPIKE", "EMPTY_2D"])
+def test_sat2d_goldens(ctx, name):
+    fx = json.load(open(os.path.join(G, "shapes_2d.json")))
+    z = np.load(os.path.join(G, "segments2d_%s.npz" % name))
+    P, Q, n = z["P"], z["Q"], len(z["P"])
+    ctx.upload_shapes2d(_shapes(fx["worlds"][name]))
+    assert np.array_equal(mp._lib.unpack_bits(ctx.motions_free(P, Q), n), z["free_motion"])
+    assert np.array_equal(mp._lib.unpack_bits(ctx.states_free(P), n), z["free_state"])
+    ctx.upload_shapes2d(_shapes(fx["worlds"][name]), z["ss_lo"], z["ss_hi"])
+    assert np.array_equal(mp._lib.unpack_bits(ctx.motions_free(P, Q), n), z["free_motion_ss"])
+    assert np.array_equal(mp._lib.unpack_bits(ctx.states_free(P), n), z["free_state_ss"])
+    for c in fx["known"]:
+        if c[0] == name:
+            ctx.upload_shapes2d(_shapes(fx["worlds"][name]))
+            assert bool(mp._lib.unpack_bits(ctx.motions_free(np.array([c[1]]), np.array([c[2]])), 1)[0]) == c[3]
+            assert bool(mp._lib.unpack_bits(ctx.states_free(np.array([c[1]])), 1)[0]) == c[4]
+
+
+def test_sat2d_random_world_graph_and_plan(ctx, orc):
+    """Random circles and convex polygons: point / edge / whole-graph masks against the oracle, then a full FMT* plan in
+    the SAT world (same tree, cost and collision count as the oracle recursion fed with the oracle's masks)."""
+    rng = np.random.default_rng(31)
+    shapes = []
+    for _ in range(14):
+        c = 0.15 + 0.7 * rng.random(2)
+        if rng.random() < 0.4:
+            shapes.append(("circle", tuple(c), 0.03 + 0.05 * rng.random()))
+        else:
+            k = int(rng.integers(3, 9))
+            ang = np.sort(rng.random(k) * 2 * np.pi)
+            if np.max(np.diff(np.concatenate([ang, [ang[0] + 2 * np.pi]]))) > 0.95 * np.pi:
+                continue                                                     # keep the hull well conditioned
+            rad = 0.04 + 0.05 * rng.random()
+            shapes.append(("polygon", [(c[0] + rad * np.cos(a), c[1] + rad * np.sin(a)) for a in ang]))
+    init, goal = np.array([0.03, 0.03]), np.array([0.97, 0.97, 0.04])
+    S = orc.Shapes2D(shapes)
+    lo, hi = np.zeros(2), np.ones(2)
+    N = 6000
+    X = rng.random((N, 2)); X[0] = init; X[-1] = goal[:2]
+    ctx.upload_samples(X)
+    ctx.upload_shapes2d(shapes, lo, hi)
+    r = 0.035
+    colptr, rowval, nzval = ctx.rdisc_graph(r)
+    c0, r0 = to0(colptr, rowval)
+    Fo = orc.points_free_2d(X, S, lo, hi)
+    assert np.array_equal(ctx.points_free(), Fo)
+    eo = orc.graph_edges_free_2d(X, c0, r0, S, lo, hi)
+    assert np.array_equal(ctx.graph_edges_free(), eo)
+    cols = np.repeat(np.arange(1, N + 1), np.diff(colptr))
+    assert np.array_equal(ctx.edges_free(rowval, cols), eo)
+    assert 0.5 < mp._lib.unpack_bits(eo, len(r0)).mean() < 0.99
+    got = ctx.fmtstar(r, mp._lib.GOAL_BALL, goal)
+    want = orc.fmtstar_graph(X, c0, r0, nzval, eo, Fo, orc.GOAL_BALL, goal, np.zeros((0, 2, 2)), lo, hi, init_idx=0)
+    assert got["status"] == want["status"] == 1
+    assert got["cost"] == want["cost"] and got["collision_checks"] == want["collision_checks"]
+    assert np.array_equal(got["A"] - 1, want["A"]) and np.array_equal(got["path"] - 1, want["path"])
+    # sampler and checker switching
+    Xs, _ = ctx.sample_free(5, 2000, init=init, goal_kind=mp._lib.GOAL_BALL, goal_params=goal, goal_ct=2)
+    assert orc.unpack(orc.points_free_2d(Xs, S, lo, hi), 2000).all()
+    ctx.upload_boxes(np.zeros((0, 2, 2)), lo, hi)                            # back to the (empty) AABB checker
+    assert mp._lib.unpack_bits(ctx.points_free(), 2000).all()
+    with pytest.raises(mp.MPFMTError) as e:
+        ctx.upload_shapes2d([("polygon", [(0, 0), (1, 0), (0.2, 0.2), (0, 1)])])
+    assert e.value.code == mp._lib.ERR_ARG

@@ -212,3 +212,33 @@ def test_oracle_sampler_semantics():
     assert k == N                                                    # the att-th candidate filled the last slot
     u = np.concatenate([orc.sample_uniforms(1, c, 0, 6) for c in range(2000)])
     assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02
+
+
+def _world2d(orc, shapes):
+    return orc.Shapes2D([("circle", tuple(s[1]), s[2]) if s[0] == "circle" else ("polygon", [tuple(p) for p in s[1]]) for s in shapes])
+
+
+def test_sat2d_oracle_against_goldens_and_known_answers():
+    """2-D SAT world (SAT2D.jl): the oracle on the reference's obstacle fixtures (test/obstaclesets/2D.jl) reproduces the
+    committed masks and the hand-derived answers."""
+    import json, os
+    from oracle import oracle as orc
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fx = json.load(open(os.path.join(G, "shapes_2d.json")))
+    for name, shapes in fx["worlds"].items():
+        S = _world2d(orc, shapes)
+        z = np.load(os.path.join(G, "segments2d_%s.npz" % name))
+        n = len(z["P"])
+        assert np.array_equal(orc.unpack(orc.motions_free_2d(z["P"], z["Q"], S), n), z["free_motion"])
+        assert np.array_equal(orc.unpack(orc.motions_free_2d(z["P"], z["Q"], S, z["ss_lo"], z["ss_hi"]), n), z["free_motion_ss"])
+        assert np.array_equal(orc.unpack(orc.points_free_2d(z["P"], S), n), z["free_state"])
+        assert np.array_equal(orc.unpack(orc.points_free_2d(z["P"], S, z["ss_lo"], z["ss_hi"]), n), z["free_state_ss"])
+        for c in fx["known"]:
+            if c[0] == name:
+                assert bool(orc.unpack(orc.motions_free_2d([c[1]], [c[2]], S), 1)[0]) == c[3]
+                assert bool(orc.unpack(orc.points_free_2d([c[1]], S), 1)[0]) == c[4]
+    import pytest
+    with pytest.raises(ValueError):
+        orc.Shapes2D([("polygon", [(0, 0), (1, 0), (0.2, 0.2), (0, 1)])])       # not convex (SAT2D.jl:49)
+    with pytest.raises(ValueError):
+        orc.Shapes2D([("circle", (0, 0), 0.0)])                                 # SAT2D.jl:22
