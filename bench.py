@@ -155,7 +155,8 @@ def main():
     pairs_per_pass = stats["pairs_tested"]
     # algorithmic flops: 2*d per tested pair; MFMA flops actually issued: K = 16 slots -> 32 per pair
     ach_tflops = (passes * pairs_per_pass * 2.0 * d) / (pair_ms * 1e-3) / 1e12 if pair_ms > 0 else 0.0
-    mfma_tflops = (passes * pairs_per_pass * 32.0) / (pair_ms * 1e-3) / 1e12 if pair_ms > 0 and path_used == 2 else 0.0
+    mfma_k = 8 if d <= 6 else 16                     # v_mfma_f32_32x32x8_f16 (d <= 6) / 32x32x16_f16 (7 <= d <= 12)
+    mfma_tflops = (passes * pairs_per_pass * 2.0 * mfma_k) / (pair_ms * 1e-3) / 1e12 if pair_ms > 0 and path_used == 2 else 0.0
     peak = FP16_MFMA_PEAK_TFLOPS if path_used == 2 else FP64_PEAK_TFLOPS
     sweep_ms = tm["sweep_graph"][0]
     sweep_bytes = nnz * (2 * d * 8 + 8 + 1.0 / 8.0)
@@ -201,7 +202,7 @@ def main():
             "mfma_flops_issued_tflops": mfma_tflops,
             "frac_of_fp64_peak": ach_tflops / FP64_PEAK_TFLOPS,
             "note": "achieved = pairs_tested x 2d algorithmic flop (SURVEY 8d) / kernel time; peak = dense fp16 MFMA "
-                    "(the filter runs v_mfma_f32_32x32x16_f16, 32 flop per pair with the norm slots); the kernel is "
+                    "(the filter runs v_mfma_f32_32x32x%d_f16, %d flop per pair with the norm slots); the kernel is " % (mfma_k, 2 * mfma_k) +
                     "VALU-issue bound on sign-bit extraction (16 v_alignbit per MFMA), not MFMA bound; the result is the "
                     "exact fp64 graph, so frac_of_fp64_peak compares with what an fp64 Gram kernel could reach",
         },
