@@ -54,24 +54,32 @@ __global__ void k_cellkey(const double* __restrict__ Xo, int64_t N, int d, mpfmt
     val[p] = (int32_t)p;
 }
 
-// sorted position s -> tile layout; pads the last tile with NaN coordinates (NaN never passes d2 <= r2)
-__global__ void k_scatter_tiles(const double* __restrict__ Xo, const int32_t* __restrict__ perm_sorted,
-                                int64_t N, int64_t npad, int d,
-                                int32_t* __restrict__ perm, int32_t* __restrict__ iperm, double* __restrict__ Xt)
+// sorted position s -> perm / iperm and the cell-sorted AoS copy Xs (one thread per coordinate: coalesced stores, the d
+// threads of a sample read one contiguous row); pad positions get perm = -1 and NaN coordinates (NaN never passes d2 <= r2)
+__global__ void k_sorted_perm_aos(const double* __restrict__ Xo, const int32_t* __restrict__ perm_sorted, int64_t N, int64_t npad,
+                                  int d, int32_t* __restrict__ perm, int32_t* __restrict__ iperm, double* __restrict__ Xs)
 {
-    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= npad) return;
-    int64_t tile = s >> 6;
-    int lane = (int)(s & 63);
-    if (s < N) {
-        int32_t o = perm_sorted[s];
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npad * d) return;
+    const int64_t s = t / d;
+    const int i = (int)(t - s * d);
+    const int32_t o = (s < N) ? perm_sorted[s] : -1;
+    if (i == 0) {
         perm[s] = o;
-        iperm[o] = (int32_t)s;
-        for (int i = 0; i < d; ++i) Xt[(tile * d + i) * 64 + lane] = Xo[(int64_t)o * d + i];
-    } else {
-        perm[s] = -1;
-        for (int i = 0; i < d; ++i) Xt[(tile * d + i) * 64 + lane] = __builtin_nan("");
+        if (o >= 0) iperm[o] = (int32_t)s;
     }
+    Xs[t] = (o >= 0) ? Xo[(int64_t)o * d + i] : __builtin_nan("");
+}
+
+// tiled SoA copy Xt[tile][i][lane] from the sorted AoS copy (coalesced stores; the exact VALU pair kernel and the tile boxes read it)
+__global__ void k_tiles_from_aos(const double* __restrict__ Xs, int64_t npad, int d, double* __restrict__ Xt)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npad * d) return;
+    const int64_t tile = t / (64 * d);
+    const int rem = (int)(t - tile * 64 * d);
+    const int i = rem >> 6, lane = rem & 63;
+    Xt[t] = Xs[(tile * 64 + lane) * d + i];
 }
 
 __global__ void k_cellstart(const uint32_t* __restrict__ key_sorted, int64_t N, int64_t ncells,
@@ -160,6 +168,7 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
     if ((rc = ensure(ctx, (void**)&ctx->cellkey, sizeof(uint32_t) * N))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->cellstart, sizeof(int32_t) * (G.ncells + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->Xt, sizeof(double) * npad * d))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->Xs, sizeof(double) * std::max<int64_t>(npad, 1) * d))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->tile_lo, sizeof(double) * ctx->ntiles * d))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->tile_hi, sizeof(double) * ctx->ntiles * d))) return rc;
 
@@ -183,15 +192,16 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
         hipLaunchKernelGGL(k_cellkey, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream,
                            ctx->Xo, N, d, G, key_in, val_in);
         HIPCHK(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, ctx->cellkey, val_in, val_out, (size_t)N, 0, bits, ctx->stream));
-        hipLaunchKernelGGL(k_scatter_tiles, dim3((unsigned)((npad + B - 1) / B)), dim3(B), 0, ctx->stream,
-                           ctx->Xo, val_out, N, npad, d, ctx->perm, ctx->iperm, ctx->Xt);
+        const int64_t ne = npad * d;
+        hipLaunchKernelGGL(k_sorted_perm_aos, dim3((unsigned)((ne + B - 1) / B)), dim3(B), 0, ctx->stream,
+                           ctx->Xo, val_out, N, npad, d, ctx->perm, ctx->iperm, ctx->Xs);
+        hipLaunchKernelGGL(k_tiles_from_aos, dim3((unsigned)((ne + B - 1) / B)), dim3(B), 0, ctx->stream, ctx->Xs, npad, d, ctx->Xt);
         hipLaunchKernelGGL(k_cellstart, dim3((unsigned)((G.ncells + 1 + B - 1) / B)), dim3(B), 0, ctx->stream,
                            ctx->cellkey, N, G.ncells, ctx->cellstart);
         hipLaunchKernelGGL(k_tile_bbox, dim3((unsigned)ctx->ntiles), dim3(64), 0, ctx->stream,
                            ctx->Xt, ctx->ntiles, d, ctx->tile_lo, ctx->tile_hi);
         HIPCHK(ctx, hipGetLastError());
     }
-    if ((rc = mpfmt_build_sorted_aos(ctx))) return rc;     // cell-sorted AoS copy (refine gathers, graph sweep)
     mpfmt_time_end(ctx, "grid");
     ctx->grid_r = r;
     ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;

@@ -119,15 +119,6 @@ __global__ void k_make_ops(const double* __restrict__ Xs, int64_t N, int64_t npa
     ops[p * 2 + 1] = u.v[1];
 }
 
-__global__ void k_sorted_aos(const double* __restrict__ Xo, const int32_t* __restrict__ perm, int64_t npad, int d,
-                             double* __restrict__ Xs)
-{
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npad) return;
-    const int32_t o = perm[p];
-    for (int i = 0; i < d; ++i) Xs[p * d + i] = (o >= 0) ? Xo[(int64_t)o * d + i] : __builtin_nan("");
-}
-
 // ---- candidate chunk lists -------------------------------------------------------------------------------------
 // One wavefront per tile, run once per (grid, radius): the tile's neighbourhood -- grid rows -> contiguous runs of the
 // sorted array -> 64-sample chunks -- is flattened lane-parallel, every chunk's tight box is tested against the tile's
@@ -545,19 +536,6 @@ int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usab
     *negT_out = -(float)(T * (1.0 + 1e-6));
     *usable = true;
     ctx->mf_scale = s;
-    return MPFMT_OK;
-}
-
-int32_t mpfmt_build_sorted_aos(mpfmt_ctx* ctx)
-{
-    const int64_t npad = ctx->ntiles * 64;
-    int32_t rc;
-    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->Xs, sizeof(double) * (size_t)npad * ctx->d))) return rc;
-    if (npad == 0) return MPFMT_OK;
-    const int B = 256;
-    hipLaunchKernelGGL(k_sorted_aos, dim3((unsigned)((npad + B - 1) / B)), dim3(B), 0, ctx->stream,
-                       ctx->Xo, ctx->perm, npad, ctx->d, ctx->Xs);
-    HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
 

@@ -329,8 +329,8 @@ __device__ __forceinline__ double lane_f64(double v, int l)
 // All rows of a column lie within rpad of V[x], so the cull box is V[x] +- rpad (~2.5 % of the boxes survive at the
 // north-star workload).  Work is handed out in TASKS of SWEEP_TC consecutive columns (a dynamic counter), one
 // wavefront per task, 64 entries ("a round") at a time within a column:
-//   - the task header -- the SWEEP_TC+1 column pointers and the SWEEP_TC column states -- is one coalesced load held in
-//     registers (lane = column); per-column values are read out with v_readlane, so a column costs no memory round trip
+//   - the task header -- per column its entry range and its state -- is loaded once and held in registers
+//     (lane = column); per-column values are read out with v_readlane, so a column costs no memory round trip
 //     of its own.  The header of the next task is requested while the current one is processed (two register sets);
 //   - the dependent chain row ids -> row states is software-pipelined over rounds: row ids are requested two rounds
 //     ahead, the 8*D-byte row-state gathers one round ahead, both before the current round's arithmetic.  The round
@@ -354,14 +354,15 @@ struct sweep_round {
 };
 
 template <int D>
-struct sweep_hdr { int64_t cp; double w[D]; };              // lane = column of the task: first entry, state
+struct sweep_hdr { int64_t cpb, cpe; double w[D]; };        // lane = column of the task: entry range, state
 
 template <int D>
 __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 1)) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
                                                                const int32_t* __restrict__ rowval, int64_t N, double rpad,
                                                                const double* __restrict__ boxes, int M, int chunk,
                                                                mpfmt_ss ss, unsigned long long* __restrict__ mask,
-                                                               int* __restrict__ task_ctr)
+                                                               int* __restrict__ task_ctr, const int32_t* __restrict__ perm,
+                                                               int64_t sp_begin, int64_t sp_end)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sboxT = (double*)smem;                         // [2*D][SWEEP_CHUNK]
@@ -371,7 +372,10 @@ __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 1)) void k_graph_sweep
     double* qv = sboxT + (int64_t)SWEEP_CHUNK * 2 * D + (int64_t)wave * (D + 1) * SWEEP_QCAP;
     uint32_t* qe = (uint32_t*)(qv + (int64_t)D * SWEEP_QCAP);
     uint32_t* qk = qe + SWEEP_QCAP;
-    const int64_t ntasks = (N + SWEEP_TC - 1) / SWEEP_TC;
+    // columns visited: every sample in caller order (perm == NULL, sp range = [0, N)), or -- on a sharded ctx -- the
+    // shard's own cell-sorted positions through perm, so that a task holds SWEEP_TC non-empty columns instead of mostly
+    // columns other ranks own
+    const int64_t ntasks = (sp_end - sp_begin + SWEEP_TC - 1) / SWEEP_TC;
     if (blockIdx.x == 0 && threadIdx.x == 0) {               // padding bits of the last word are zero
         const int64_t nnz = colptr[N];
         if (nnz & 63) atomicAnd(&mask[nnz >> 6], (1ull << (nnz & 63)) - 1ull);
@@ -395,9 +399,12 @@ __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 1)) void k_graph_sweep
         };
         sweep_hdr<D> H0, H1;
         auto load_hdr = [&](int64_t t, sweep_hdr<D>& h) {
-            const int64_t x = t * SWEEP_TC + lane;
-            h.cp = colptr[x < N ? x : N];
-            const int64_t xr = x < N ? x : N - 1;
+            const int64_t sp = sp_begin + t * SWEEP_TC + lane;
+            int64_t x = -1;                                       // pad positions of the sorted order hold -1
+            if (sp < sp_end && lane < SWEEP_TC) x = perm ? (int64_t)perm[sp] : sp;
+            h.cpb = x >= 0 ? colptr[x] : 0;
+            h.cpe = x >= 0 ? colptr[x + 1] : 0;
+            const int64_t xr = x >= 0 ? x : 0;
 #pragma unroll
             for (int i = 0; i < D; ++i) h.w[i] = X[xr * D + i];
         };
@@ -405,8 +412,8 @@ __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 1)) void k_graph_sweep
         if (tset0 >= ntasks) continue;                       // (uniform) nothing left for this wave
         load_hdr(tset0, H0);
         auto col_range = [&](const sweep_round& r, int64_t& beg, int64_t& end) {
-            const int64_t b0_ = lane_i64(H0.cp, r.c), e0_ = lane_i64(H0.cp, r.c + 1);
-            const int64_t b1_ = lane_i64(H1.cp, r.c), e1_ = lane_i64(H1.cp, r.c + 1);
+            const int64_t b0_ = lane_i64(H0.cpb, r.c), e0_ = lane_i64(H0.cpe, r.c);
+            const int64_t b1_ = lane_i64(H1.cpb, r.c), e1_ = lane_i64(H1.cpe, r.c);
             beg = r.hs ? b1_ : b0_;
             end = r.hs ? e1_ : e0_;
         };
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 1)) void k_graph_sweep
         auto advance = [&](sweep_round& r) {
             if (r.e0 + 64 < r.end) { r.e0 += 64; r.first = 0; return; }
             r.c += 1;
-            if (r.c >= SWEEP_TC || r.t * SWEEP_TC + r.c >= N) {
+            if (r.c >= SWEEP_TC || sp_begin + r.t * SWEEP_TC + r.c >= sp_end) {
                 r.hs ^= 1;
                 r.t = r.hs ? tset1 : tset0;
                 r.c = 0;
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 1)) void k_graph_sweep
                 const double a = __shfl(H0.w[i], c), b = __shfl(H1.w[i], c);
                 w[i] = hs ? b : a;
             }
-            const int64_t ebase = hs ? __shfl(H1.cp, c) : __shfl(H0.cp, c);
+            const int64_t ebase = hs ? __shfl(H1.cpb, c) : __shfl(H0.cpb, c);
             const bool free_ = narrow_free_sl<D>(v, w, load_box_T<D>(sboxT, k));
             if (on && !free_) {
                 const int64_t e = ebase + (int64_t)eoff;
@@ -564,7 +571,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 1)) void k_graph_sweep
                     }
                 }
                 // queue the pending exact tests (the entry counts as free until a pass says otherwise)
-                const uint32_t eoff = (uint32_t)(e0 + lane - (R0.hs ? lane_i64(H1.cp, R0.c) : lane_i64(H0.cp, R0.c)));
+                const uint32_t eoff = (uint32_t)(e0 + lane - (R0.hs ? lane_i64(H1.cpb, R0.c) : lane_i64(H0.cpb, R0.c)));
                 hs_q = R0.hs;
                 push(fr && p0 >= 0, v, eoff, ((uint32_t)R0.c << 16) | (uint32_t)max(p0, 0));
                 if (__ballot(fr && p1 >= 0)) {
@@ -724,7 +731,12 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
         const int nchunks = std::max(1, (ctx->M + chunk - 1) / chunk);
         if ((rc = mpfmt_ensure(ctx, (void**)&ctx->sweep_ctr, sizeof(int) * (size_t)nchunks))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->sweep_ctr, 0, sizeof(int) * (size_t)nchunks, ctx->stream));
-        const int64_t ntasks = (ctx->N + SWEEP_TC - 1) / SWEEP_TC;
+        // unsharded: all columns in caller order; sharded: only this shard's cell-sorted positions (via perm)
+        const bool sharded = ctx->world > 1 && ctx->perm != nullptr && ctx->tile_end > ctx->tile_begin;
+        const int32_t* sweep_perm = sharded ? ctx->perm : nullptr;
+        const int64_t sp_begin = sharded ? ctx->tile_begin * 64 : 0;
+        const int64_t sp_end = sharded ? std::min<int64_t>(ctx->tile_end * 64, ctx->ntiles * 64) : ctx->N;
+        const int64_t ntasks = (sp_end - sp_begin + SWEEP_TC - 1) / SWEEP_TC;
         int per_cu = 0;
         if (lds > 64 * 1024)                                     // beyond the default dynamic-LDS limit (gfx950 has 160 KB)
             DISPATCH_D(d, HIPCHK(ctx, hipFuncSetAttribute((const void*)k_graph_sweep<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
@@ -733,7 +745,7 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
                                                                              (int64_t)std::max(per_cu, 1) * ctx->num_cus));
         DISPATCH_D(d, hipLaunchKernelGGL((k_graph_sweep<DD>), dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream,
                                          ctx->Xo, ctx->colptr, ctx->rowval, ctx->N, rpad, ctx->boxes, ctx->M, chunk,
-                                         ctx->ss, (unsigned long long*)ctx->graph_free, ctx->sweep_ctr));
+                                         ctx->ss, (unsigned long long*)ctx->graph_free, ctx->sweep_ctr, sweep_perm, sp_begin, sp_end));
         HIPCHK(ctx, hipGetLastError());
     }
     mpfmt_time_end(ctx, "sweep_graph");

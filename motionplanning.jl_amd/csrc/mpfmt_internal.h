@@ -174,7 +174,6 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usable);
 int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx);
-int32_t mpfmt_build_sorted_aos(mpfmt_ctx* ctx);
 template <int MODE> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT);
 int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx);
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable);
