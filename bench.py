@@ -29,10 +29,10 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 
 # HBM bytes per launch measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, profiles/*pmc*):
 # (FETCH_SIZE*2 + WRITE_SIZE) KiB -> bytes.  Keyed by (workload, n_gpus[, kernel]).
 PROFILED_TRAFFIC_BYTES = {
-    # profiles/r01_pmc_v4.txt: FETCH_SIZE 2621212 KiB (x2, gfx950 half-count), WRITE_SIZE 3191064 KiB per launch
-    ("ns_r6_n1m_m200", 1): (2621211.7 * 2 + 3191064.3) * 1024,
-    # profiles/r01_pmc_v4.txt: FETCH_SIZE 7984937 KiB (x2), WRITE_SIZE 449945 KiB per launch
-    ("ns_r6_n1m_m200", 1, "sweep"): (7984937.2 * 2 + 449945.2) * 1024,
+    # profiles/r01_pmc_v5.txt: FETCH_SIZE 2129553 KiB (x2, gfx950 half-count), WRITE_SIZE 2423634 KiB per launch
+    ("ns_r6_n1m_m200", 1): (2129552.6 * 2 + 2423634.0) * 1024,
+    # profiles/r01_pmc_v5.txt: FETCH_SIZE 7930748 KiB (x2), WRITE_SIZE 449945 KiB per launch
+    ("ns_r6_n1m_m200", 1, "sweep"): (7930748.1 * 2 + 449945.2) * 1024,
 }
 
 
