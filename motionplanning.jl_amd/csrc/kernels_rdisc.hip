@@ -525,7 +525,8 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
         // every (tile, slice, column) owns a fixed-capacity slot list; per-list counts vary, so lists get 4x the
         // mean plus a fixed slack -- an overflow falls back to the fill pass
         const int64_t items = nt * S;
-        const int64_t capc = (int64_t)(want / ((double)items * 64.0) * 4.0) + 64;
+        // (a build that overflowed doubles the slack of the following ones)
+        const int64_t capc = ((int64_t)(want / ((double)items * 64.0) * 4.0) + 64) * ctx->pool_slack;
         if ((double)capc * (double)items * 64.0 * 16.0 > 96e9) pool = false;      // cap the slot lists at 96 GB of the 288
         else {
             const size_t cap = (size_t)capc * (size_t)items * 64;
@@ -563,6 +564,7 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
     if (pool) HIPCHK(ctx, hipMemcpyAsync(&pool_over, ctx->pool_flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->pool_valid = pool && pool_over == 0;
+    if (pool && pool_over && ctx->pool_slack < 8) ctx->pool_slack *= 2;
     ctx->pool_hint_N = N; ctx->pool_hint_r = r; ctx->pool_hint_nnz = nnz;
     ctx->pool_hint_rank = ctx->rank; ctx->pool_hint_world = ctx->world;
     ctx->nnz = nnz;

@@ -496,14 +496,20 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
     {
         const int64_t tl = tile - a.blk_begin;
         const int64_t len = a.list_len[tl];
-        // slices interleave the list (entry k belongs to slice k mod S): every slice sees the same near/far mix of
-        // chunks, so hits, refine work and slot-list fill are even across the slices of a tile
-        const int64_t cnt = (len > slice) ? (len - slice + a.S - 1) / a.S : 0;
-        const uint32_t* __restrict__ lst = a.lists + tl * a.list_cap + slice;
+        // slices interleave the list: round j (entries [j*S, j*S + S)) gives slice s the entry at offset (s + h(j)) mod S,
+        // h a multiplicative hash of j.  Every slice sees the same near/far mix of chunks, and -- unlike a plain k mod S --
+        // a periodic structure in the list (rows of the cell grid are ~3 chunks each) cannot line its hits up in one
+        // slice (seen: 90 of a column's 155 hits in one of 16 slices, overflowing that slot list on every build).
+        const int S = a.S;
+        const int64_t full = len / S;
+        const int rem = (int)(len - full * S);
+        auto off = [&](int64_t j) -> int { return (int)(((uint32_t)slice + (((uint32_t)j * 2654435761u) >> 24)) % (uint32_t)S); };
+        const int64_t cnt = full + ((rem > 0 && off(full) < rem) ? 1 : 0);
+        const uint32_t* __restrict__ lst = a.lists + tl * a.list_cap;
         for (int64_t k0 = 0; k0 < cnt; k0 += MF_LIST) {
             const int n = (int)min((int64_t)MF_LIST, cnt - k0);
             __builtin_amdgcn_wave_barrier();
-            for (int e = lane; e < n; e += 64) s_list[e] = lst[(k0 + e) * a.S];
+            for (int e = lane; e < n; e += 64) s_list[e] = lst[(k0 + e) * S + off(k0 + e)];
             run_list(n);
         }
     }

@@ -327,7 +327,7 @@ __device__ __forceinline__ double lane_f64(double v, int l)
 // ---- graph sweep ---------------------------------------------------------------------------------
 // Bit e of the mask = in_state_space(V[y]) && is_free_motion(V[y], V[x]) for CSC entry e = (row y, column x).
 // All rows of a column lie within rpad of V[x], so the cull box is V[x] +- rpad (~2.5 % of the boxes survive at the
-// north-star workload).  Work is handed out in TASKS of SWEEP_TC consecutive columns (a dynamic counter), one
+// north-star workload).  Work is handed out in TASKS of SWEEP_TC (16 or 8) consecutive columns (a dynamic counter), one
 // wavefront per task, 64 entries ("a round") at a time within a column:
 //   - the task header -- per column its entry range and its state -- is loaded once and held in registers
 //     (lane = column); per-column values are read out with v_readlane, so a column costs no memory round trip
@@ -345,7 +345,6 @@ __device__ __forceinline__ double lane_f64(double v, int l)
 //     tests them (lane = item, the column state comes from the task header by lane exchange) and clears the bits of
 //     the blocked ones.  The queue is flushed before the task header is recycled;
 //   - predicates are the straight-line forms on register-held boxes (see above).
-#define SWEEP_TC 16
 #define SWEEP_QCAP 128
 
 struct sweep_round {
@@ -356,7 +355,7 @@ struct sweep_round {
 template <int D>
 struct sweep_hdr { int64_t cpb, cpe; double w[D]; };        // lane = column of the task: entry range, state
 
-template <int D>
+template <int D, int SWEEP_TC>
 __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 1)) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
                                                                const int32_t* __restrict__ rowval, int64_t N, double rpad,
                                                                const double* __restrict__ boxes, int M, int chunk,
@@ -700,6 +699,32 @@ int32_t mpfmt_launch_motions_free(mpfmt_ctx* ctx, const double* d_P, const doubl
     return rc;
 }
 
+// tasks of 16 columns; of 8 when that would leave fewer than ~6 tasks per resident wavefront (a shard of a multi-GPU
+// build, small graphs): finer tasks balance the tail.  One resident set of workgroups.
+template <int D>
+static int32_t launch_graph_sweep_d(mpfmt_ctx* ctx, size_t lds, double rpad, int chunk, const int32_t* sweep_perm, int64_t sp_begin,
+                                    int64_t sp_end)
+{
+    constexpr auto k16 = k_graph_sweep<D, 16>;
+    constexpr auto k8 = k_graph_sweep<D, 8>;
+    const int waves = SWEEP_THREADS / 64;
+    if (lds > 64 * 1024) {                                       // beyond the default dynamic-LDS limit (gfx950 has 160 KB)
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    int per_cu = 0;
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k16, SWEEP_THREADS, lds));
+    const int64_t resident = (int64_t)std::max(per_cu, 1) * ctx->num_cus;
+    const int tc = ((sp_end - sp_begin + 15) / 16 < 6 * resident * waves) ? 8 : 16;
+    const int64_t ntasks = (sp_end - sp_begin + tc - 1) / tc;
+    const unsigned nb = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ntasks + waves - 1) / waves, resident));
+    hipLaunchKernelGGL(tc == 8 ? k8 : k16, dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream, ctx->Xo, ctx->colptr, ctx->rowval, ctx->N,
+                       rpad, ctx->boxes, ctx->M, chunk, ctx->ss, (unsigned long long*)ctx->graph_free, ctx->sweep_ctr, sweep_perm,
+                       sp_begin, sp_end);
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
 int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
 {
     int32_t rc;
@@ -736,16 +761,8 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
         const int32_t* sweep_perm = sharded ? ctx->perm : nullptr;
         const int64_t sp_begin = sharded ? ctx->tile_begin * 64 : 0;
         const int64_t sp_end = sharded ? std::min<int64_t>(ctx->tile_end * 64, ctx->ntiles * 64) : ctx->N;
-        const int64_t ntasks = (sp_end - sp_begin + SWEEP_TC - 1) / SWEEP_TC;
-        int per_cu = 0;
-        if (lds > 64 * 1024)                                     // beyond the default dynamic-LDS limit (gfx950 has 160 KB)
-            DISPATCH_D(d, HIPCHK(ctx, hipFuncSetAttribute((const void*)k_graph_sweep<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
-        DISPATCH_D(d, HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_graph_sweep<DD>, SWEEP_THREADS, lds)));
-        const unsigned nb = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ntasks + waves - 1) / waves,
-                                                                             (int64_t)std::max(per_cu, 1) * ctx->num_cus));
-        DISPATCH_D(d, hipLaunchKernelGGL((k_graph_sweep<DD>), dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream,
-                                         ctx->Xo, ctx->colptr, ctx->rowval, ctx->N, rpad, ctx->boxes, ctx->M, chunk,
-                                         ctx->ss, (unsigned long long*)ctx->graph_free, ctx->sweep_ctr, sweep_perm, sp_begin, sp_end));
+        DISPATCH_D(d, rc = launch_graph_sweep_d<DD>(ctx, lds, rpad, chunk, sweep_perm, sp_begin, sp_end));
+        if (rc) return rc;
         HIPCHK(ctx, hipGetLastError());
     }
     mpfmt_time_end(ctx, "sweep_graph");

@@ -111,6 +111,7 @@ struct mpfmt_ctx {
     int32_t* pool_flag = nullptr;        // overflow flag
     int64_t pool_cap = 0;                // capacity of one (item, column) slot list
     mpfmt_hit* pool = nullptr;           // [items][64 columns][pool_cap] hit records
+    int32_t pool_slack = 1;              // doubled after a build whose slot lists overflowed
     bool pool_valid = false;             // pool holds exactly the nnz hits of the counted graph
     int64_t pool_hint_N = -1; double pool_hint_r = -1.0; int64_t pool_hint_nnz = 0; int pool_hint_rank = -1, pool_hint_world = -1;   // capacity hint from the last build
     int64_t survivors = 0;
