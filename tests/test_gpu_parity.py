@@ -395,6 +395,33 @@ def test_shards_partition_the_graph(ctx, orc):
         assert np.array_equal(rows_by_col.get(v, np.zeros(0, np.int64)), orow[oc[v]:oc[v + 1]])
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_sweep_masks(orc, world):
+    """Each shard sweeps only its own columns (visited in cell-sorted order through perm): the mask over its local CSC
+    equals the oracle's on the same local graph, and the shards' free-edge counts add up to the unsharded total."""
+    rng = np.random.default_rng(123)
+    N, d, r = 12000, 3, 0.11
+    X, lohi = random_world(rng, N, d, 80, 0.04, 0.12)
+    lo, hi = np.full(d, 0.03), np.full(d, 0.97)
+    full = mp.Context(0)
+    full.upload_samples(X); full.upload_boxes(lohi, lo, hi)
+    colptr, rowval, _ = full.rdisc_graph(r)
+    total_free = int(mp._lib.unpack_bits(full.graph_edges_free(), len(rowval)).sum())
+    full.close()
+    got_free = 0
+    for rank in range(world):
+        c = mp.Context(0)
+        c.set_shard(rank, world)
+        c.upload_samples(X); c.upload_boxes(lohi, lo, hi)
+        cp, rv, _ = c.rdisc_graph(r)
+        m = c.graph_edges_free()
+        want = orc.graph_edges_free(X, cp - 1, rv - 1, lohi, lo, hi)
+        assert np.array_equal(m, want)
+        got_free += int(mp._lib.unpack_bits(m, len(rv)).sum())
+        c.close()
+    assert got_free == total_free
+
+
 # ---- full-size properties (BASELINE.json configs[1]: R^6, N=100k, M=200) ---------------------------------
 
 def test_cfg2_full_size_properties(ctx, orc):
