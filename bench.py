@@ -118,6 +118,12 @@ def main():
             ctx.graph_sweep_device()
         return nnz
 
+    if dist is not None:
+        # create the RCCL communicator outside the steps (lazy init on the first collective takes seconds)
+        probe = torch.zeros(1, dtype=torch.int64, device=dev)
+        gathered = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gathered, probe)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     if dist is not None:
