@@ -28,6 +28,8 @@ FP64_PEAK_TFLOPS = 78.6        # fp64 vector == fp64 matrix (MFMA) dense peak, F
 FP16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 PFLOP/s
 # HBM bytes per launch measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, profiles/*pmc*):
 # (FETCH_SIZE*2 + WRITE_SIZE) KiB -> bytes.  Keyed by (workload, n_gpus[, kernel]).
+GATHER_CEILING_ROWS_PER_S = 4.51e10      # measured: 1e8 random 48-byte rows of a 48 MB array in 2.219 ms (profiles/r01_ubench_fetch_calib.txt)
+
 PROFILED_TRAFFIC_BYTES = {
     # profiles/r01_pmc_v5.txt: FETCH_SIZE 2129553 KiB (x2, gfx950 half-count), WRITE_SIZE 2423634 KiB per launch
     ("ns_r6_n1m_m200", 1): (2129552.6 * 2 + 2423634.0) * 1024,
@@ -215,7 +217,11 @@ def main():
         "roofline_sweep": {
             "kernel": "k_graph_sweep", "bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": PROFILED_TRAFFIC_BYTES.get((w.name, world, "sweep")),
-            "note": "algorithmic bytes = (2*d*8 + 8 + 1/8) per edge = %.3f B; bound by the random 48-byte row-state gathers and VALU issue in about equal parts" % (2 * d * 8 + 8 + 0.125),
+            "gather_ceiling_edges_per_s": GATHER_CEILING_ROWS_PER_S if d == 6 else None,
+            "frac_of_gather_ceiling": (nnz / (tm["sweep_graph"][0] * 1e-3) / GATHER_CEILING_ROWS_PER_S) if (d == 6 and tm["sweep_graph"][0] > 0) else None,
+            "note": "algorithmic bytes = (2*d*8 + 8 + 1/8) per edge = %.3f B; every edge needs one random 48-byte row-state gather, and a "
+                    "kernel that does nothing but such gathers reaches 4.5e10 rows/s on this GPU (tools/ubench/fetch_calib.hip, "
+                    "profiles/r01_ubench_fetch_calib.txt) -- that, not the 8 TB/s streaming figure, is the ceiling the sweep runs against" % (2 * d * 8 + 8 + 0.125),
         },
     }
     if rank == 0:
