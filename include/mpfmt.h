@@ -149,6 +149,26 @@ int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const in
                                  const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params,
                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
+/* ---- Dubins car: DubinsQuasiMetricSpace(r_turn, s, lo, hi) of src/statespaces/simplecars.jl:32-38.
+ *      Samples are SE2 states (x, y, theta) (upload_samples with d = 3); obstacles live in the workspace (x, y)
+ *      (VectorView(1:2)): upload_boxes with dw = 2 and the 3 state bounds (lo_x, lo_y, 0; hi_x, hi_y, 2pi).
+ *      dubins_graph_count/fill : the chopped backward sets (nearneighbors.jl:185-198) as a sparse cost matrix in CSC,
+ *             column j = sources i (ascending, 1-based) with |xy_i - xy_j| <= r and dubins(i -> j) <= r
+ *             (simplecars.jl:106-215), nzval = cost; the forward sets are its transpose.
+ *      dubins_graph_edges_free : entry e (row y -> column x): is_free_motion(V[y], V[x], CC, SS) over the reference's
+ *             collision waypoints (arcs every pi/12, :68-83; statespaces.jl:127-135,153-158); nseg[e] = workspace
+ *             segment tests the reference would have counted (may be NULL).
+ *      dubins_steer : batch steer on explicit pairs; controls[i][3][3] = (duration, speed, signed curvature) per segment.
+ *      dubins_fmtstar : fmtstar! in this space (forward / backward neighbour sets like the double integrator's).
+ *      sin / cos / atan2 / acos are the device libm's: costs agree with a CPU libm to a few ulp, not bit for bit. */
+int32_t mpfmt_dubins_graph_count(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz);
+int32_t mpfmt_dubins_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval);
+int32_t mpfmt_dubins_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg);
+int32_t mpfmt_dubins_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, double turn_radius, double speed,
+                           double* cost, double* controls);
+int32_t mpfmt_dubins_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+                             int32_t goal_kind, const double* goal_params, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
+
 /* ---- 2-D SAT world: PointRobot2D(Compound2D(parts)) of src/collisioncheckers/robots2D.jl:12-14 and
  *      SAT2D.jl -- parts are Circle(c, r) (:14-28) and convex Polygon(points) (:32-58; Box2D = 4-point polygon, :59-62).
  *      Switches the ctx's collision checker: afterwards mpfmt_points_free / _states_free = is_free_state (point vs

@@ -59,6 +59,12 @@ SYMBOLS = [
     ("mpfmt_host_fmt_recursion", C.c_int32, [C.c_int64, C.c_int32, c_d_p, c_i64_p, C.POINTER(C.c_int32), c_d_p, c_u64_p, c_u64_p,
                                              c_d_p, c_d_p, C.c_int64, C.c_int32, c_d_p, c_i64_p, c_d_p, c_i64_p,
                                              C.POINTER(FmtResult)]),
+    ("mpfmt_dubins_graph_count", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, c_i64_p, c_i64_p]),
+    ("mpfmt_dubins_graph_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p]),
+    ("mpfmt_dubins_graph_edges_free", C.c_int32, [C.c_void_p, c_u64_p, c_u8_p]),
+    ("mpfmt_dubins_steer", C.c_int32, [C.c_void_p, c_d_p, c_d_p, C.c_int64, C.c_double, C.c_double, c_d_p, c_d_p]),
+    ("mpfmt_dubins_fmtstar", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
+                                         c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
     ("mpfmt_upload_shapes2d", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_d_p, c_d_p, c_d_p]),
     ("mpfmt_graph_import", C.c_int32, [C.c_void_p, C.c_double, c_i64_p, c_i64_p, c_d_p]),
     ("mpfmt_sample_free", C.c_int32, [C.c_void_p, C.c_uint64, C.c_int64, c_d_p, C.c_int32, c_d_p, C.c_int32, c_d_p, c_i64_p]),
@@ -335,6 +341,44 @@ class Context:
         return dict(status=int(res.status), cost=float(res.cost), z=int(res.z),
                     collision_checks=int(res.collision_checks), nnz=int(res.nnz),
                     ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
+                    A=A[:self.N], C=Cc[:self.N], path=path[:res.path_len].copy())
+
+    # ---- Dubins car -------------------------------------------------------------------------------
+    def dubins_graph(self, turn_radius, speed, r):
+        """Chopped backward sets of the Dubins quasi-metric, CSC 1-based: (colptr, rowval, nzval)."""
+        colptr = np.empty(self.N + 1, dtype=np.int64)
+        nnz = C.c_int64()
+        self._chk(self._L.mpfmt_dubins_graph_count(self._h, float(turn_radius), float(speed), float(r), _ip(colptr), C.byref(nnz)))
+        self.nnz = n = nnz.value
+        rowval = np.empty(max(n, 1), dtype=np.int64)
+        nzval = np.empty(max(n, 1), dtype=np.float64)
+        self._chk(self._L.mpfmt_dubins_graph_fill(self._h, _ip(rowval), _dp(nzval)))
+        return colptr, rowval[:n], nzval[:n]
+
+    def dubins_graph_edges_free(self):
+        n = self.nnz
+        mask = np.zeros(max(nwords(n), 1), dtype=np.uint64)
+        nseg = np.zeros(max(n, 1), dtype=np.uint8)
+        self._chk(self._L.mpfmt_dubins_graph_edges_free(self._h, _up(mask), nseg.ctypes.data_as(c_u8_p)))
+        return mask[:nwords(n)], nseg[:n]
+
+    def dubins_steer(self, X0, X1, turn_radius, speed=1.0):
+        X0 = np.ascontiguousarray(X0, dtype=np.float64); X1 = np.ascontiguousarray(X1, dtype=np.float64)
+        n = len(X0)
+        cost = np.empty(max(n, 1)); ctrl = np.empty((max(n, 1), 3, 3))
+        self._chk(self._L.mpfmt_dubins_steer(self._h, _dp(X0), _dp(X1), n, float(turn_radius), float(speed), _dp(cost), _dp(ctrl)))
+        return cost[:n], ctrl[:n]
+
+    def dubins_fmtstar(self, turn_radius, speed, r, goal_kind, goal_params, init_idx=1, checkpts=True):
+        g = np.ascontiguousarray(goal_params, dtype=np.float64)
+        A = np.empty(max(self.N, 1), dtype=np.int64)
+        Cc = np.empty(max(self.N, 1), dtype=np.float64)
+        path = np.empty(max(self.N, 1), dtype=np.int64)
+        res = FmtResult()
+        self._chk(self._L.mpfmt_dubins_fmtstar(self._h, float(turn_radius), float(speed), float(r), int(init_idx), int(bool(checkpts)),
+                                               int(goal_kind), _dp(g), _ip(A), _dp(Cc), _ip(path), C.byref(res)))
+        return dict(status=int(res.status), cost=float(res.cost), z=int(res.z), collision_checks=int(res.collision_checks),
+                    nnz=int(res.nnz), ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
                     A=A[:self.N], C=Cc[:self.N], path=path[:res.path_len].copy())
 
     def graph_import(self, r, colptr, rowval, nzval):

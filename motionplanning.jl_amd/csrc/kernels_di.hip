@@ -417,7 +417,7 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
     ctx->pairs_tested = (int64_t)ctr[0];
     ctx->survivors = (int64_t)ctr[1];
     ctx->di_rho = rho; ctx->di_r = r;
-    ctx->di_counted = true; ctx->di_filled = false; ctx->di_swept = false;
+    ctx->di_counted = true; ctx->di_filled = false; ctx->di_swept = false; ctx->steer_kind = 1;
     // the Euclidean graph state shares colptr/rowval/nzval: invalidate it
     ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
     return MPFMT_OK;

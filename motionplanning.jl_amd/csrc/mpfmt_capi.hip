@@ -8,6 +8,7 @@
 #include <cstring>
 #include <cmath>
 #include <chrono>
+#include <functional>
 #include <algorithm>
 #include <vector>
 
@@ -184,7 +185,8 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
-                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->pool_flag, ctx->pool, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->shapes2d};
+                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->pool_flag, ctx->pool, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->shapes2d, ctx->car_keep};
+    if (ctx->aux) { mpfmt_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
     for (void* b : bufs) if (b) hipFree(b);
     timer_resolve(ctx);
     if (ctx->timer_state) {
@@ -828,7 +830,7 @@ int32_t mpfmt_di_graph_count(mpfmt_ctx* ctx, double rho, double r, int64_t* colp
 int32_t mpfmt_di_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval, double* tval)
 {
     if (!ctx) return MPFMT_ERR_ARG;
-    if (!ctx->di_counted) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "di_graph_fill before di_graph_count");
+    if (!ctx->di_counted || ctx->steer_kind != 1) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "di_graph_fill before di_graph_count");
     if (ctx->nnz > 0 && (!rowval || !nzval)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "rowval / nzval is NULL");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int32_t rc;
@@ -849,7 +851,7 @@ int32_t mpfmt_di_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval, doub
 int32_t mpfmt_di_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg)
 {
     if (!ctx) return MPFMT_ERR_ARG;
-    if (!ctx->di_counted) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "di_graph_edges_free before di_graph_count");
+    if (!ctx->di_counted || ctx->steer_kind != 1) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "di_graph_edges_free before di_graph_count");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int32_t rc;
     if (!ctx->di_filled && (rc = mpfmt_di_fill(ctx))) return rc;
@@ -889,6 +891,99 @@ int32_t mpfmt_di_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64
         if (e != hipSuccess) rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "di_steer copy back: %s", hipGetErrorString(e));
     }
     return rc;
+}
+
+// fmt.jl:43-101 over a DIRECTED cost graph (quasi-metric spaces: double integrator, Dubins car): forward sets = rows of the
+// cost matrix (DSF = Dmat', linearquadratic.jl:73), backward sets = its columns (the CSC given).  efree / nseg are per CSC
+// entry (row -> column motion free; segment tests the reference would have counted), F the checkpts bitmap (may be NULL).
+extern "C++" void mpfmt_directed_fmt_recursion(int64_t N, const int64_t* colptr_, const int32_t* rowval_, const double* nzval_, const uint64_t* efree_,
+                                  const uint8_t* nseg_, const uint64_t* F_, int64_t init_idx, const std::function<bool(int64_t)>& goal_hit,
+                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
+{
+    const int64_t nnz = colptr_[N];
+    struct view64 { const int64_t* p; int64_t operator[](int64_t i) const { return p[i]; } };
+    struct view32 { const int32_t* p; int32_t operator[](int64_t i) const { return p[i]; } };
+    struct viewd { const double* p; double operator[](int64_t i) const { return p[i]; } };
+    struct view8 { const uint8_t* p; uint8_t operator[](int64_t i) const { return p[i]; } };
+    const view64 colptr{colptr_}; const view32 rowval{rowval_}; const viewd nzval{nzval_}; const view8 nseg{nseg_};
+    const bool checkpts = F_ != nullptr;
+    auto bitp = [](const uint64_t* m, int64_t i) { return (m[i >> 6] >> (i & 63)) & 1ull; };
+    // forward sets: CSR of the cost matrix (DSF = Dmat', linearquadratic.jl:73), rows ascending in target index
+    std::vector<int64_t> rowptr(N + 1, 0), cur(N);
+    std::vector<int32_t> colidx((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<int64_t> centry((size_t)std::max<int64_t>(nnz, 1));        // CSR entry -> its CSC entry (cost, masks)
+    for (int64_t e = 0; e < nnz; ++e) rowptr[rowval[e] + 1]++;
+    for (int64_t i = 0; i < N; ++i) rowptr[i + 1] += rowptr[i];
+    for (int64_t i = 0; i < N; ++i) cur[i] = rowptr[i];
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t e = colptr[j]; e < colptr[j + 1]; ++e) { const int64_t a = cur[rowval[e]]++; colidx[a] = (int32_t)j; centry[a] = e; }
+    // The recursion of fmt.jl:43-90.  DI neighbourhoods are large (hundreds of entries) and arcs are often blocked, so a
+    // sample can be examined by many expanding neighbours; rescanning nearB(x) & H each time is what the reference does
+    // and is O(N deg^2).  Here the argmin over the OPEN backward neighbours is maintained instead: when y opens it
+    // relaxes best[x] of its forward neighbours still in W; when the best itself has closed, x is rescanned once.  The
+    // order is the reference's (lowest cost, then lowest index = first minimum of its scan), so A, C, the path and the
+    // collision count are unchanged.
+    std::vector<uint8_t> Wm(N, 1), Hm(N, 0);
+    std::vector<int64_t> Hnew;
+    std::vector<int64_t> by(N, -1), be(N, -1);       // best open parent of x and its CSC entry (-1 none, -2 rescan)
+    std::vector<double> bc(N, 0.0);
+    for (int64_t i = 0; i < N; ++i) { A[i] = 0; C[i] = 0.0; }
+    auto open_node = [&](int64_t y) {                 // y has just entered H: offer it to its forward neighbours
+        Hm[y] = 1;
+        const double cy = C[y];
+        for (int64_t a = rowptr[y]; a < rowptr[y + 1]; ++a) {
+            const int64_t x = colidx[a];
+            if (!Wm[x] || by[x] == -2) continue;
+            if (by[x] >= 0 && !Hm[by[x]]) { by[x] = -2; continue; }           // its best has closed: rescan when examined
+            const int64_t e = centry[a];
+            const double c = cy + nzval[e];
+            if (by[x] < 0 || c < bc[x] || (c == bc[x] && y < by[x])) { by[x] = y; bc[x] = c; be[x] = e; }
+        }
+    };
+    Heap heap;
+    const int64_t i0 = init_idx - 1;
+    Wm[i0] = 0;
+    open_node(i0);
+    heap.push(i0, 0.0);
+    int64_t z = heap.pop();
+    int64_t count = 0;
+    while (!goal_hit(z)) {
+        Hnew.clear();
+        for (int64_t a = rowptr[z]; a < rowptr[z + 1]; ++a) {                  // nearF(V, z, r, W), fmt.jl:70
+            const int64_t x = colidx[a];
+            if (!Wm[x]) continue;
+            if (checkpts && !bitp(F_, x)) continue;
+            if (by[x] == -2 || (by[x] >= 0 && !Hm[by[x]])) {                   // nearB(V, x, r, H), fmt.jl:72-74
+                int64_t y_min = -1, e_min = -1; double c_min = 0.0;
+                for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {
+                    const int64_t y = rowval[b];
+                    if (!Hm[y]) continue;
+                    const double c = C[y] + nzval[b];
+                    if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
+                }
+                by[x] = y_min; bc[x] = c_min; be[x] = e_min;
+            }
+            if (by[x] < 0) continue;
+            const int64_t y_min = by[x], e_min = be[x];
+            count += nseg[e_min];                                              // boxesND.jl:26 per tested segment
+            if (bitp(efree_, e_min)) {
+                A[x] = y_min + 1; C[x] = bc[x];
+                heap.push(x, bc[x]);
+                Hnew.push_back(x);
+                Wm[x] = 0;
+            }
+        }
+        Hm[z] = 0;                                                             // fmt.jl:84 (before 83: same final sets)
+        for (int64_t x : Hnew) open_node(x);                                   // fmt.jl:83
+        if (!heap.empty()) z = heap.pop(); else break;
+    }
+    std::vector<int64_t> rev;
+    int64_t cu = z;
+    rev.push_back(cu + 1);
+    while (cu != 0) { const int64_t p = A[cu]; if (p == 0) break; cu = p - 1; rev.push_back(cu + 1); }
+    for (size_t i = 0; i < rev.size(); ++i) path[i] = rev[rev.size() - 1 - i];
+    res->status = goal_hit(z) ? 1 : 0;
+    res->cost = C[z]; res->z = z + 1; res->collision_checks = count; res->path_len = (int64_t)rev.size(); res->nnz = nnz;
 }
 
 int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx, int32_t checkpts,
@@ -952,15 +1047,6 @@ int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx,
         HIPCHK(ctx, hipMemcpy(nseg.data(), ctx->di_nseg, (size_t)nnz, hipMemcpyDeviceToHost));
     }
     auto t4 = std::chrono::steady_clock::now();
-    // forward sets: CSR of the cost matrix (DSF = Dmat', linearquadratic.jl:73), rows ascending in target index
-    std::vector<int64_t> rowptr(N + 1, 0), cur(N);
-    std::vector<int32_t> colidx((size_t)std::max<int64_t>(nnz, 1));
-    std::vector<int64_t> centry((size_t)std::max<int64_t>(nnz, 1));        // CSR entry -> its CSC entry (cost, masks)
-    for (int64_t e = 0; e < nnz; ++e) rowptr[rowval[e] + 1]++;
-    for (int64_t i = 0; i < N; ++i) rowptr[i + 1] += rowptr[i];
-    for (int64_t i = 0; i < N; ++i) cur[i] = rowptr[i];
-    for (int64_t j = 0; j < N; ++j)
-        for (int64_t e = colptr[j]; e < colptr[j + 1]; ++e) { const int64_t a = cur[rowval[e]]++; colidx[a] = (int32_t)j; centry[a] = e; }
     auto goal_hit = [&](int64_t z) {
         const double* v = &X[(size_t)z * n];
         if (goal_kind == MPFMT_GOAL_POINT) {                      // StateGoal: exact state equality (goals.jl:128-131)
@@ -969,77 +1055,163 @@ int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx,
         }
         return is_goal_pt(v, m, goal_kind, goal_params);           // workspace goals act on C*v = first m coordinates
     };
-    // The recursion of fmt.jl:43-90.  DI neighbourhoods are large (hundreds of entries) and arcs are often blocked, so a
-    // sample can be examined by many expanding neighbours; rescanning nearB(x) & H each time is what the reference does
-    // and is O(N deg^2).  Here the argmin over the OPEN backward neighbours is maintained instead: when y opens it
-    // relaxes best[x] of its forward neighbours still in W; when the best itself has closed, x is rescanned once.  The
-    // order is the reference's (lowest cost, then lowest index = first minimum of its scan), so A, C, the path and the
-    // collision count are unchanged.
-    std::vector<uint8_t> Wm(N, 1), Hm(N, 0);
-    std::vector<int64_t> Hnew;
-    std::vector<int64_t> by(N, -1), be(N, -1);       // best open parent of x and its CSC entry (-1 none, -2 rescan)
-    std::vector<double> bc(N, 0.0);
-    for (int64_t i = 0; i < N; ++i) { A[i] = 0; C[i] = 0.0; }
-    auto open_node = [&](int64_t y) {                 // y has just entered H: offer it to its forward neighbours
-        Hm[y] = 1;
-        const double cy = C[y];
-        for (int64_t a = rowptr[y]; a < rowptr[y + 1]; ++a) {
-            const int64_t x = colidx[a];
-            if (!Wm[x] || by[x] == -2) continue;
-            if (by[x] >= 0 && !Hm[by[x]]) { by[x] = -2; continue; }           // its best has closed: rescan when examined
-            const int64_t e = centry[a];
-            const double c = cy + nzval[e];
-            if (by[x] < 0 || c < bc[x] || (c == bc[x] && y < by[x])) { by[x] = y; bc[x] = c; be[x] = e; }
-        }
-    };
-    Heap heap;
-    const int64_t i0 = init_idx - 1;
-    Wm[i0] = 0;
-    open_node(i0);
-    heap.push(i0, 0.0);
-    int64_t z = heap.pop();
-    int64_t count = 0;
-    while (!goal_hit(z)) {
-        Hnew.clear();
-        for (int64_t a = rowptr[z]; a < rowptr[z + 1]; ++a) {                  // nearF(V, z, r, W), fmt.jl:70
-            const int64_t x = colidx[a];
-            if (!Wm[x]) continue;
-            if (checkpts && !bit(F, x)) continue;
-            if (by[x] == -2 || (by[x] >= 0 && !Hm[by[x]])) {                   // nearB(V, x, r, H), fmt.jl:72-74
-                int64_t y_min = -1, e_min = -1; double c_min = 0.0;
-                for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {
-                    const int64_t y = rowval[b];
-                    if (!Hm[y]) continue;
-                    const double c = C[y] + nzval[b];
-                    if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
-                }
-                by[x] = y_min; bc[x] = c_min; be[x] = e_min;
-            }
-            if (by[x] < 0) continue;
-            const int64_t y_min = by[x], e_min = be[x];
-            count += nseg[e_min];                                              // boxesND.jl:26 per tested segment
-            if (bit(efree, e_min)) {
-                A[x] = y_min + 1; C[x] = bc[x];
-                heap.push(x, bc[x]);
-                Hnew.push_back(x);
-                Wm[x] = 0;
-            }
-        }
-        Hm[z] = 0;                                                             // fmt.jl:84 (before 83: same final sets)
-        for (int64_t x : Hnew) open_node(x);                                   // fmt.jl:83
-        if (!heap.empty()) z = heap.pop(); else break;
-    }
-    std::vector<int64_t> rev;
-    int64_t cu = z;
-    rev.push_back(cu + 1);
-    while (cu != 0) { const int64_t p = A[cu]; if (p == 0) break; cu = p - 1; rev.push_back(cu + 1); }
-    for (size_t i = 0; i < rev.size(); ++i) path[i] = rev[rev.size() - 1 - i];
+    mpfmt_directed_fmt_recursion(N, colptr.data(), rowval.data(), nzval.data(), efree.data(), nseg.data(), checkpts ? F.data() : nullptr,
+                                 init_idx, goal_hit, A, C, path, res);
     auto t5 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
-    res->status = goal_hit(z) ? 1 : 0;
-    res->cost = C[z]; res->z = z + 1; res->collision_checks = count; res->path_len = (int64_t)rev.size(); res->nnz = nnz;
+    res->nnz = nnz;
+    res->ms_graph = ms(t1, t2); res->ms_sweep = ms(t0, t1) + ms(t2, t3); res->ms_host_loop = ms(t4, t5);
+    return MPFMT_OK;
+}
+
+// ---- Dubins car (kernels_car.hip) ------------------------------------------------------------------------------------
+
+int32_t mpfmt_dubins_graph_count(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!colptr || !nnz) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "colptr / nnz is NULL");
+    int32_t rc;
+    if ((rc = mpfmt_dubins_build(ctx, turn_radius, speed, r))) return rc;
+    const int64_t n1 = ctx->N + 1;
+    void* scr;
+    if ((rc = mpfmt_scratch(ctx, sizeof(int64_t) * n1, &scr))) return rc;
+    hipLaunchKernelGGL(k_add1_i64, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->colptr, n1, (int64_t*)scr);
+    HIPCHK(ctx, hipMemcpyAsync(colptr, scr, sizeof(int64_t) * n1, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *nnz = ctx->nnz;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_dubins_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!(ctx->di_filled && ctx->steer_kind == 2)) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "dubins_graph_fill before dubins_graph_count");
+    const int64_t nnz = ctx->nnz;
+    if (nnz > 0 && (!rowval || !nzval)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "rowval / nzval is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (nnz > 0) {
+        int32_t rc;
+        void* scr;
+        if ((rc = mpfmt_scratch(ctx, sizeof(int64_t) * nnz, &scr))) return rc;
+        hipLaunchKernelGGL(k_i32_to_i64_add1, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rowval, nnz, (int64_t*)scr);
+        HIPCHK(ctx, hipMemcpyAsync(rowval, scr, sizeof(int64_t) * nnz, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(nzval, ctx->nzval, sizeof(double) * nnz, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_dubins_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = mpfmt_dubins_sweep(ctx))) return rc;
+    const int64_t nnz = ctx->nnz, words = (nnz + 63) / 64;
+    if (nnz > 0) {
+        if (!mask) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "mask is NULL");
+        HIPCHK(ctx, hipMemcpyAsync(mask, ctx->graph_free, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, ctx->stream));
+        if (nseg) HIPCHK(ctx, hipMemcpyAsync(nseg, ctx->di_nseg, (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_dubins_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, double turn_radius, double speed,
+                           double* cost, double* controls)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (n < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "n < 0");
+    if (n == 0) return MPFMT_OK;
+    if (!X0 || !X1 || !cost) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "NULL array");
+    if (!(turn_radius > 0.0) || !(speed > 0.0)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "turning radius and speed must be > 0");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevTmp tmp;
+    double *d0, *d1, *dc, *du;
+    int32_t rc;
+    HIPCHK(ctx, tmp.get(&d0, sizeof(double) * 3 * n));
+    HIPCHK(ctx, tmp.get(&d1, sizeof(double) * 3 * n));
+    HIPCHK(ctx, tmp.get(&dc, sizeof(double) * n));
+    HIPCHK(ctx, tmp.get(&du, sizeof(double) * 9 * n));
+    HIPCHK(ctx, hipMemcpyAsync(d0, X0, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d1, X1, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = mpfmt_dubins_steer_batch(ctx, d0, d1, n, turn_radius, speed, dc, du))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(cost, dc, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (controls) HIPCHK(ctx, hipMemcpyAsync(controls, du, sizeof(double) * 9 * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_dubins_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+                             int32_t goal_kind, const double* goal_params, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!A || !C || !path || !res || !goal_params) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "NULL output / goal pointer");
+    if (!ctx->Xo || ctx->d != 3) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "Dubins planning needs SE2 samples (d = 3)");
+    if (!ctx->have_boxes || ctx->cc_kind != 0 || ctx->dw != 2) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "Dubins planning needs 2-D boxes (mpfmt_upload_boxes, dw = 2)");
+    const int64_t N = ctx->N;
+    if (init_idx < 1 || init_idx > N) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "init_idx out of range");
+    if (goal_kind < 0 || goal_kind > 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown goal kind %d", goal_kind);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    memset(res, 0, sizeof *res);
+    res->cost = INFINITY;
+    int32_t rc;
+    auto t0 = std::chrono::steady_clock::now();
+    // checkpts bitmap: in_state_space on the SE2 state, point test on (x, y)
+    std::vector<double> X((size_t)N * 3), P((size_t)N * 2);
+    HIPCHK(ctx, hipMemcpy(X.data(), ctx->Xo, sizeof(double) * (size_t)N * 3, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < N; ++i) { P[2 * i] = X[3 * i]; P[2 * i + 1] = X[3 * i + 1]; }
+    const int64_t words = (N + 63) / 64;
+    std::vector<uint64_t> F(words, 0);
+    {
+        const mpfmt_ss keep = ctx->ss;
+        ctx->ss.has = 0;
+        rc = mpfmt_states_free(ctx, P.data(), N, F.data());
+        ctx->ss = keep;
+        if (rc) return rc;
+        if (keep.has)
+            for (int64_t i = 0; i < N; ++i) {
+                bool ok = true;
+                for (int q = 0; q < 3; ++q) ok = ok && (keep.lo[q] <= X[(size_t)i * 3 + q]) && (X[(size_t)i * 3 + q] <= keep.hi[q]);
+                if (!ok) F[i >> 6] &= ~(1ull << (i & 63));
+            }
+    }
+    if (!bit(F, init_idx - 1)) return mpfmt_fail(ctx, MPFMT_ERR_INFEASIBLE, "initial state is infeasible");
+    auto t1 = std::chrono::steady_clock::now();
+    if ((rc = mpfmt_dubins_build(ctx, turn_radius, speed, r))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    auto t2 = std::chrono::steady_clock::now();
+    if ((rc = mpfmt_dubins_sweep(ctx))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    auto t3 = std::chrono::steady_clock::now();
+    const int64_t nnz = ctx->nnz;
+    std::vector<int64_t> colptr(N + 1);
+    std::vector<int32_t> rowval((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<double> nzval((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<uint64_t> efree((size_t)std::max<int64_t>((nnz + 63) / 64, 1));
+    std::vector<uint8_t> nseg((size_t)std::max<int64_t>(nnz, 1));
+    HIPCHK(ctx, hipMemcpy(colptr.data(), ctx->colptr, sizeof(int64_t) * (N + 1), hipMemcpyDeviceToHost));
+    if (nnz > 0) {
+        HIPCHK(ctx, hipMemcpy(rowval.data(), ctx->rowval, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(nzval.data(), ctx->nzval, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(efree.data(), ctx->graph_free, sizeof(uint64_t) * ((nnz + 63) / 64), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(nseg.data(), ctx->di_nseg, (size_t)nnz, hipMemcpyDeviceToHost));
+    }
+    auto t4 = std::chrono::steady_clock::now();
+    auto goal_hit = [&](int64_t z) {
+        const double* v = &X[(size_t)z * 3];
+        if (goal_kind == MPFMT_GOAL_POINT) return v[0] == goal_params[0] && v[1] == goal_params[1] && v[2] == goal_params[2];
+        return is_goal_pt(v, 2, goal_kind, goal_params);                       // workspace goals act on (x, y)
+    };
+    mpfmt_directed_fmt_recursion(N, colptr.data(), rowval.data(), nzval.data(), efree.data(), nseg.data(), checkpts ? F.data() : nullptr,
+                                 init_idx, goal_hit, A, C, path, res);
+    auto t5 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    res->nnz = nnz;
     res->ms_graph = ms(t1, t2); res->ms_sweep = ms(t0, t1) + ms(t2, t3); res->ms_host_loop = ms(t4, t5);
     return MPFMT_OK;
 }

@@ -130,6 +130,10 @@ struct mpfmt_ctx {
     int32_t di_S = 1;
     double di_rho = 1.0, di_r = 0.0;
     bool di_counted = false, di_filled = false, di_swept = false;
+    int32_t steer_kind = 1;              // which directed cost graph the di_* state describes: 1 double integrator, 2 Dubins car
+    double car_rt = 1.0, car_sp = 1.0;   // Dubins turning radius / speed of the built graph
+    uint64_t* car_keep = nullptr;        // keep bits over the candidate (positions) graph
+    mpfmt_ctx* aux = nullptr;            // helper ctx: Euclidean r-disc graph of the positions (Dubins build)
     double* tvaltmp = nullptr;           // [nnz] optimal times, unsorted staging
     double* tval = nullptr;              // [nnz] optimal times t* per entry
     uint8_t* di_nseg = nullptr;          // [nnz] workspace segment tests the reference would have made per edge
@@ -192,6 +196,13 @@ int32_t mpfmt_launch_motions_free(mpfmt_ctx* ctx, const double* d_P, const doubl
 int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx);
 
 // kernels_di.hip ----------------------------------------------------------------------------------
+#include <functional>
+void mpfmt_directed_fmt_recursion(int64_t N, const int64_t* colptr, const int32_t* rowval, const double* nzval, const uint64_t* efree,
+                                  const uint8_t* nseg, const uint64_t* F, int64_t init_idx, const std::function<bool(int64_t)>& goal_hit,
+                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
+int32_t mpfmt_dubins_build(mpfmt_ctx* ctx, double rt, double sp, double r);
+int32_t mpfmt_dubins_sweep(mpfmt_ctx* ctx);
+int32_t mpfmt_dubins_steer_batch(mpfmt_ctx* ctx, const double* d_X0, const double* d_X1, int64_t n, double rt, double sp, double* d_cost, double* d_ctrl);
 int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r);
 int32_t mpfmt_di_fill(mpfmt_ctx* ctx);
 int32_t mpfmt_di_sweep(mpfmt_ctx* ctx);

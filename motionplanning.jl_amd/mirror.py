@@ -7,7 +7,8 @@ inball! -> inball_.  Indices are 1-based like the reference's (tree `A`, `path`,
 
 Reference files mirrored: src/statespaces.jl (BoundedStateSpace, volume, dim, sample_space, is_free_state,
 is_free_motion), src/statespaces/geometric.jl (UnitHypercube, BoundedEuclideanStateSpace),
-src/statespaces/linearquadratic.jl (DoubleIntegrator), src/collisioncheckers/boxesND.jl (BoxBounds,
+src/statespaces/linearquadratic.jl (DoubleIntegrator), src/statespaces/simplecars.jl (DubinsQuasiMetricSpace),
+src/collisioncheckers/boxesND.jl (BoxBounds,
 PointRobotNDBoxes, inflate, addobstacle, addblocker), src/goals.jl (RectangleGoal, BallGoal, PointGoal, StateGoal),
 src/nearneighbors.jl (MetricNN, QuasiMetricNN, inball, inball!, ImmutableNNC, addpoints), src/problems.jl
 (MPProblem, MPSolution, clearsamples!), src/sampling.jl (sample_free!), src/planners/fmt.jl (fmtstar!).
@@ -55,6 +56,19 @@ def DoubleIntegrator(d, lo=None, hi=None, vmax=1.5, r=1.0):
     hi = np.ones(d) if hi is None else np.asarray(hi, dtype=np.float64)
     return BoundedStateSpace(np.concatenate([lo, -vmax * np.ones(d)]), np.concatenate([hi, vmax * np.ones(d)]),
                              LinearQuadratic(d, rho=r), workspace_dim=d)
+
+
+class DubinsExact:
+    """Exact Dubins length for turning radius r and speed s, chopped by the Euclidean lower bound on (x, y)
+    (simplecars.jl:15-21,32-38)."""
+
+    def __init__(self, r=1.0, s=1.0):
+        self.r, self.s = float(r), float(s)
+
+
+def DubinsQuasiMetricSpace(r, s=1.0, lo=(0.0, 0.0), hi=(1.0, 1.0)):
+    """SE2 states (x, y, theta) with theta in [0, 2pi]; workspace = (x, y)   (simplecars.jl:32-38)."""
+    return BoundedStateSpace(np.array([lo[0], lo[1], 0.0]), np.array([hi[0], hi[1], 2 * math.pi]), DubinsExact(r, s), workspace_dim=2)
 
 
 def volume(SS):
@@ -359,7 +373,7 @@ def sample_free_(P, N, ensure_goal=True, ensure_goal_ct=5, rng=None, seed=None):
     if N <= 0:
         return volume(P.SS)
     has_init = len(P.V.V) > 0 and np.array_equal(P.V.V[0], P.init)                 # sampling.jl:15-20
-    if seed is not None and len(P.V.V) <= 1 and not isinstance(P.SS.dist, LinearQuadratic) and hasattr(P.goal, "kind"):
+    if seed is not None and len(P.V.V) <= 1 and isinstance(P.SS.dist, Euclidean) and hasattr(P.goal, "kind"):
         P.CC._bind(P.ctx, P.SS)
         W, _ = P.ctx.sample_free(seed, N, init=None if has_init else P.init, goal_kind=P.goal.kind,
                                  goal_params=P.goal.params(), goal_ct=ensure_goal_ct if ensure_goal else 0)
@@ -409,6 +423,8 @@ def fmtstar_(P, N=None, rm=1.0, connections="R", r=0.0, ensure_goal_ct=1, init_i
     P.CC._bind(ctx, P.SS)
     if isinstance(P.SS.dist, LinearQuadratic):
         res = ctx.di_fmtstar(P.SS.dist.rho, r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)
+    elif isinstance(P.SS.dist, DubinsExact):
+        res = ctx.dubins_fmtstar(P.SS.dist.r, P.SS.dist.s, r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)
     else:
         res = ctx.fmtstar(r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)
     P.CC.count = res["collision_checks"]

@@ -1258,3 +1258,253 @@ void orc_2d_graph_edges_free(const double *X, int64_t N, const int64_t *colptr, 
             set_bit(mask, e, orc_in_state_space(v, ss_lo, ss_hi, 2) && orc_2d_motion_free(v, w, S, ns));
         }
 }
+
+/* ---- Dubins car: DubinsQuasiMetricSpace, src/statespaces/simplecars.jl:15-21,32-38,51-83,91-215 ---------
+ * States are SE2 (x, y, theta); the workspace is (x, y) (VectorView(1:2), :37).  The quasi-metric is the exact Dubins
+ * length for turning radius rt and speed s; the near-neighbour sets are "chopped": candidates within Euclidean
+ * (x, y) distance r (KD-tree on positions, :45-49, nearneighbors.jl:185-198), kept when the Dubins cost is <= r.
+ * Arithmetic as written in the reference (unfused, operation order kept); sin/cos/atan2/acos/sqrt/fmod are libm's.
+ * mod2piF(x) = mod(x, 2*pi) (utils.jl:91) with Julia's mod for floats: r = rem(x, y); r == 0 ? +0 : (r < 0 ? r + y : r). */
+#define ORC_TWOPI (2 * 3.141592653589793)
+static double mod2pif(double x)
+{
+    double r = fmod(x, ORC_TWOPI);
+    if (r == 0) return 0.0;
+    return r < 0 ? r + ORC_TWOPI : r;
+}
+typedef struct { double t, s, k; } orc_step;      /* StepControl(t, (u1 = speed sign*s, u2 = signed curvature)) */
+static orc_step car_seg(int turn, double d) { orc_step u = {fabs(d), (d > 0) - (d < 0), (double)turn}; return u; }   /* :91 */
+
+#define DUB_TRY(cnew_expr, T0, D0, T1, D1, T2, D2)                 \
+    do { const double cnew = (cnew_expr); if (!(c <= cnew)) { path[0] = car_seg(T0, D0); path[1] = car_seg(T1, D1); path[2] = car_seg(T2, D2); c = cnew; } } while (0)
+
+/* dubins(s1, s2, r, s) (simplecars.jl:198-215): cost and the 3 scaled step controls; cost = Inf when no word applies */
+double orc_dubins(const double *s1, const double *s2, double r, double s, orc_step *path)
+{
+    const double vx = (s2[0] - s1[0]) / r, vy = (s2[1] - s1[1]) / r;
+    const double d = sqrt(vx * vx + vy * vy);
+    const double th = atan2(vy, vx);
+    const double a = mod2pif(s1[2] - th), b = mod2pif(s2[2] - th);
+    const double ca = cos(a), sa = sin(a), cb = cos(b), sb = sin(b);
+    double c = INFINITY;
+    for (int q = 0; q < 3; ++q) { path[q].t = 0; path[q].s = 0; path[q].k = 0; }
+    {   /* LSL :106-119 */
+        const double tmp = 2 + d * d - 2 * (ca * cb + sa * sb - d * (sa - sb));
+        if (!(tmp < 0)) {
+            const double t0 = atan2(cb - ca, d + sa - sb);
+            const double t = mod2pif(-a + t0), p = sqrt(fmax(tmp, 0.0)), q = mod2pif(b - t0);
+            DUB_TRY(t + p + q, 1, t, 0, p, 1, q);
+        }
+    }
+    {   /* RSR :121-134 */
+        const double tmp = 2 + d * d - 2 * (ca * cb + sa * sb - d * (sb - sa));
+        if (!(tmp < 0)) {
+            const double t0 = atan2(ca - cb, d - sa + sb);
+            const double t = mod2pif(a - t0), p = sqrt(fmax(tmp, 0.0)), q = mod2pif(-b + t0);
+            DUB_TRY(t + p + q, -1, t, 0, p, -1, q);
+        }
+    }
+    {   /* RSL :136-149 */
+        const double tmp = d * d - 2 + 2 * (ca * cb + sa * sb - d * (sa + sb));
+        if (!(tmp < 0)) {
+            const double p = sqrt(fmax(tmp, 0.0));
+            const double t0 = atan2(ca + cb, d - sa - sb) - atan2(2.0, p);
+            const double t = mod2pif(a - t0), q = mod2pif(b - t0);
+            DUB_TRY(t + p + q, -1, t, 0, p, 1, q);
+        }
+    }
+    {   /* LSR :151-164 */
+        const double tmp = -2 + d * d + 2 * (ca * cb + sa * sb + d * (sa + sb));
+        if (!(tmp < 0)) {
+            const double p = sqrt(fmax(tmp, 0.0));
+            const double t0 = atan2(-ca - cb, d + sa + sb) - atan2(-2.0, p);
+            const double t = mod2pif(-a + t0), q = mod2pif(-b + t0);
+            DUB_TRY(t + p + q, 1, t, 0, p, -1, q);
+        }
+    }
+    {   /* RLR :166-179 */
+        const double tmp = (6 - d * d + 2 * (ca * cb + sa * sb + d * (sa - sb))) / 8;
+        if (!(fabs(tmp) >= 1)) {
+            const double p = ORC_TWOPI - acos(tmp);
+            const double t0 = atan2(ca - cb, d - sa + sb);
+            const double t = mod2pif(a - t0 + p / 2), q = mod2pif(a - b - t + p);
+            DUB_TRY(t + p + q, -1, t, 1, p, -1, q);
+        }
+    }
+    {   /* LRL :181-194 */
+        const double tmp = (6 - d * d + 2 * (ca * cb + sa * sb - d * (sa - sb))) / 8;
+        if (!(fabs(tmp) >= 1)) {
+            const double p = ORC_TWOPI - acos(tmp);
+            const double t0 = atan2(-ca + cb, d + sa - sb);
+            const double t = mod2pif(-a + t0 + p / 2), q = mod2pif(b - a - t + p);
+            DUB_TRY(t + p + q, 1, t, -1, p, 1, q);
+        }
+    }
+    for (int q = 0; q < 3; ++q) {                 /* scalespeed!(scaleradius!(pmin, r), s) :92-105,214 */
+        path[q].t = path[q].t * r; path[q].k = path[q].k / r;
+        path[q].t = path[q].t / s; path[q].s = path[q].s * s;
+    }
+    return c * r;
+}
+
+/* propagate(M, v, u) :52-65 */
+static void car_propagate(const double *v, orc_step u, double *out)
+{
+    const double ang = u.t * u.s * u.k;
+    if (fabs(ang) > 10 * 2.220446049250313e-16) {
+        out[0] = v[0] + (sin(v[2] + ang) - sin(v[2])) / u.k;
+        out[1] = v[1] + (cos(v[2]) - cos(v[2] + ang)) / u.k;
+        out[2] = mod2pif(v[2] + ang);
+    } else {
+        out[0] = v[0] + u.t * u.s * cos(v[2]);
+        out[1] = v[1] + u.t * u.s * sin(v[2]);
+        out[2] = mod2pif(v[2] + ang);
+    }
+}
+
+#define ORC_DUB_MAXWP 96
+/* collision_waypoints(d, v, w) = per-segment waypoints (:68-83; arcs sampled every pi/12 -- only for positive
+ * u.t*s*invr: a negative quotient floors to m <= -1 and the range 1:m is empty) + the target (statespaces.jl:127-135) */
+int32_t orc_dubins_waypoints(const double *v0, const double *w, double rt, double sp, double *wps)
+{
+    orc_step path[3];
+    orc_dubins(v0, w, rt, sp, path);
+    double v[3] = {v0[0], v0[1], v0[2]};
+    int32_t n = 0;
+    const double thres = 3.141592653589793 / 12;
+    for (int q = 0; q < 3; ++q) {
+        const orc_step u = path[q];
+        const double quo = u.t * u.s * u.k / thres;
+        const double fl = floor(quo);
+        const long m = (long)fl;
+        wps[3 * n] = v[0]; wps[3 * n + 1] = v[1]; wps[3 * n + 2] = v[2]; ++n;
+        if (m != 0)
+            for (long i = 1; i <= m && n < ORC_DUB_MAXWP - 2; ++i) {
+                const double ai = (double)i * thres;
+                wps[3 * n] = v[0] + (sin(v[2] + ai) - sin(v[2])) / u.k;
+                wps[3 * n + 1] = v[1] + (cos(v[2]) - cos(v[2] + ai)) / u.k;
+                wps[3 * n + 2] = mod2pif(v[2] + ai);
+                ++n;
+            }
+        double nv[3];
+        car_propagate(v, u, nv);
+        v[0] = nv[0]; v[1] = nv[1]; v[2] = nv[2];
+    }
+    wps[3 * n] = w[0]; wps[3 * n + 1] = w[1]; wps[3 * n + 2] = w[2]; ++n;
+    return n;
+}
+
+/* is_free_motion(v, w, CC, SS) (statespaces.jl:153-158): every consecutive waypoint pair, in_state_space on the first
+ * point (SE2 bounds), segment test on (x, y) against 2-D boxes; *nseg = segment tests made (CC.count, boxesND.jl:26) */
+int32_t orc_dubins_is_free_motion(const double *v, const double *w, double rt, double sp, const double *lohi, int32_t M,
+                                  const double *ss_lo, const double *ss_hi, int32_t *nseg)
+{
+    double wps[3 * ORC_DUB_MAXWP];
+    const int32_t n = orc_dubins_waypoints(v, w, rt, sp, wps);
+    int32_t cnt = 0, ok = 1;
+    for (int32_t i = 0; i + 1 < n && ok; ++i) {
+        if (!orc_in_state_space(wps + 3 * i, ss_lo, ss_hi, 3)) { ok = 0; break; }
+        ++cnt;
+        if (!orc_motion_free_boxes(wps + 3 * i, wps + 3 * (i + 1), lohi, M, 2)) ok = 0;
+    }
+    if (nseg) *nseg = cnt;
+    return ok;
+}
+
+/* chopped backward sets as a CSC (column j = sources i with |xy_i - xy_j| <= r and dubins(i -> j) <= r), nearneighbors.jl:185-198.
+ * Two-phase: colptr != NULL counts (colptr[N+1], returns nnz); then rowval / nzval are filled in a second call. */
+int64_t orc_dubins_graph(const double *X, int64_t N, double rt, double sp, double r, int64_t *colptr, int64_t *rowval, double *nzval)
+{
+    int64_t nnz = 0;
+    orc_step path[3];
+    for (int64_t j = 0; j < N; ++j) {
+        if (colptr) colptr[j] = nnz;
+        for (int64_t i = 0; i < N; ++i) {
+            if (i == j) continue;
+            const double dx = X[3 * i] - X[3 * j], dy = X[3 * i + 1] - X[3 * j + 1];
+            const double px = dx * dx, py = dy * dy;
+            if (!(px + py <= r * r)) continue;                       /* inrange on positions (reduced distance, like the tree) */
+            const double c = orc_dubins(X + 3 * i, X + 3 * j, rt, sp, path);
+            if (c <= r) { if (rowval) { rowval[nnz] = i; nzval[nnz] = c; } ++nnz; }
+        }
+    }
+    if (colptr) colptr[N] = nnz;
+    return nnz;
+}
+
+void orc_dubins_graph_edges_free(const double *X, int64_t N, double rt, double sp, const int64_t *colptr, const int64_t *rowval,
+                                 const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi, uint64_t *mask, uint8_t *nseg)
+{
+    memset(mask, 0, sizeof(uint64_t) * (size_t)((colptr[N] + 63) / 64));
+    for (int64_t x = 0; x < N; ++x)
+        for (int64_t e = colptr[x]; e < colptr[x + 1]; ++e) {
+            int32_t ns = 0;
+            set_bit(mask, e, orc_dubins_is_free_motion(X + 3 * rowval[e], X + 3 * x, rt, sp, lohi, M, ss_lo, ss_hi, &ns));
+            if (nseg) nseg[e] = (uint8_t)ns;
+        }
+}
+
+/* fmtstar! over the Dubins space: forward sets = rows of the cost matrix, backward sets = columns (like orc_di_fmtstar).
+ * Goals act on the workspace (x, y) for RECT / BALL; POINT is exact state equality. */
+int32_t orc_dubins_fmtstar(const double *X, int64_t N, double rt, double sp, int64_t init_idx, int32_t checkpts,
+                           const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                           int32_t goal_kind, const double *goal, const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi,
+                           int64_t *A, double *C, int64_t *path, orc_fmt_result *res)
+{
+    memset(res, 0, sizeof *res);
+    res->cost = INFINITY;
+#define CAR_FREE_STATE(p) (orc_in_state_space((p), ss_lo, ss_hi, 3) && orc_point_free_boxes((p), lohi, M, 2))
+#define CAR_GOAL(p) ((goal_kind == 2) ? ((p)[0] == goal[0] && (p)[1] == goal[1] && (p)[2] == goal[2]) : orc_is_goal_pt((p), 2, goal_kind, goal))
+    if (!CAR_FREE_STATE(X + 3 * init_idx)) return -1;
+    uint8_t *F = NULL;
+    if (checkpts) { F = (uint8_t *)malloc((size_t)N); for (int64_t i = 0; i < N; ++i) F[i] = (uint8_t)CAR_FREE_STATE(X + 3 * i); }
+    const int64_t nnz = colptr[N];
+    int64_t *rowptr = (int64_t *)calloc((size_t)N + 1, sizeof(int64_t));
+    int64_t *colidx = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz > 0 ? nnz : 1));
+    for (int64_t e = 0; e < nnz; ++e) rowptr[rowval[e] + 1]++;
+    for (int64_t i = 0; i < N; ++i) rowptr[i + 1] += rowptr[i];
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)(N > 0 ? N : 1));
+    memcpy(cur, rowptr, sizeof(int64_t) * (size_t)N);
+    for (int64_t j = 0; j < N; ++j) for (int64_t e = colptr[j]; e < colptr[j + 1]; ++e) colidx[cur[rowval[e]]++] = j;
+    uint8_t *Wm = (uint8_t *)malloc((size_t)N), *Hm = (uint8_t *)calloc((size_t)N, 1);
+    memset(Wm, 1, (size_t)N);
+    for (int64_t i = 0; i < N; ++i) { A[i] = -1; C[i] = 0.0; }
+    int64_t *Hnew = (int64_t *)malloc(sizeof(int64_t) * (size_t)N), *rev = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    orc_heap heap = {0};
+    Wm[init_idx] = 0; Hm[init_idx] = 1;
+    heap_push(&heap, init_idx, 0.0);
+    int64_t z = heap_pop(&heap), count = 0;
+    while (!CAR_GOAL(X + 3 * z)) {
+        int64_t nnew = 0;
+        for (int64_t a = rowptr[z]; a < rowptr[z + 1]; ++a) {
+            const int64_t x = colidx[a];
+            if (!Wm[x]) continue;
+            if (checkpts && !F[x]) continue;
+            int64_t y_min = -1; double c_min = 0.0;
+            for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {
+                const int64_t y = rowval[b];
+                if (!Hm[y]) continue;
+                const double c = C[y] + nzval[b];
+                if (y_min < 0 || c < c_min) { y_min = y; c_min = c; }
+            }
+            if (y_min < 0) continue;
+            int32_t ns = 0;
+            const int ok = orc_dubins_is_free_motion(X + 3 * y_min, X + 3 * x, rt, sp, lohi, M, ss_lo, ss_hi, &ns);
+            count += ns;
+            if (ok) { A[x] = y_min; C[x] = c_min; heap_push(&heap, x, c_min); Hnew[nnew++] = x; Wm[x] = 0; }
+        }
+        for (int64_t a = 0; a < nnew; ++a) Hm[Hnew[a]] = 1;
+        Hm[z] = 0;
+        if (heap.n > 0) z = heap_pop(&heap); else break;
+    }
+    int64_t len = 0, c2 = z;
+    rev[len++] = c2;
+    while (c2 != 0) { c2 = A[c2]; if (c2 < 0) break; rev[len++] = c2; }
+    for (int64_t i = 0; i < len; ++i) path[i] = rev[len - 1 - i];
+    res->status = CAR_GOAL(X + 3 * z);
+    res->cost = C[z]; res->z = z; res->collision_checks = count; res->path_len = len; res->nn_queries = 0;
+#undef CAR_FREE_STATE
+#undef CAR_GOAL
+    free(F); free(rowptr); free(colidx); free(cur); free(Wm); free(Hm); free(Hnew); free(rev); free(heap.pri); free(heap.idx);
+    return 0;
+}

@@ -412,3 +412,60 @@ def graph_edges_free_2d(X, colptr, rowval, S, ss_lo=None, ss_hi=None):
     mask = np.zeros(max(nwords(nnz), 1), dtype=np.uint64)
     lib().orc_2d_graph_edges_free(_d(X), C.c_int64(N), _i(colptr), _i(rowval), S.ptr, C.c_int32(S.n), _d(_vec(ss_lo)), _d(_vec(ss_hi)), _u(mask))
     return mask[:nwords(nnz)]
+
+
+# ---- Dubins car ------------------------------------------------------------------------------------------
+def dubins(s1, s2, rt=1.0, sp=1.0):
+    """(cost, controls[3][3] = (t, speed, curvature)) of simplecars.jl:198-215."""
+    s1 = _vec(s1); s2 = _vec(s2)
+    path = np.zeros((3, 3))
+    L = lib(); L.orc_dubins.restype = C.c_double
+    c = L.orc_dubins(_d(s1), _d(s2), C.c_double(rt), C.c_double(sp), _d(path))
+    return float(c), path
+
+
+def dubins_waypoints(v, w, rt=1.0, sp=1.0):
+    v = _vec(v); w = _vec(w)
+    wps = np.zeros((96, 3))
+    n = lib().orc_dubins_waypoints(_d(v), _d(w), C.c_double(rt), C.c_double(sp), _d(wps))
+    return wps[:n].copy()
+
+
+def dubins_is_free_motion(v, w, rt, sp, lohi, ss_lo, ss_hi):
+    v = _vec(v); w = _vec(w); lohi, M = _boxes(lohi, 2); ns = C.c_int32()
+    ok = lib().orc_dubins_is_free_motion(_d(v), _d(w), C.c_double(rt), C.c_double(sp), _d(lohi), C.c_int32(M), _d(_vec(ss_lo)),
+                                         _d(_vec(ss_hi)), C.byref(ns))
+    return bool(ok), int(ns.value)
+
+
+def dubins_graph(X, rt, sp, r):
+    """Backward sets as 0-based CSC (colptr, rowval, nzval): column j = sources i with dubins(i -> j) <= r."""
+    X, N, d = _X(X)
+    L = lib(); L.orc_dubins_graph.restype = C.c_int64
+    colptr = np.zeros(N + 1, dtype=np.int64)
+    nnz = int(L.orc_dubins_graph(_d(X), C.c_int64(N), C.c_double(rt), C.c_double(sp), C.c_double(r), _i(colptr), None, None))
+    rowval = np.zeros(max(nnz, 1), dtype=np.int64); nzval = np.zeros(max(nnz, 1))
+    L.orc_dubins_graph(_d(X), C.c_int64(N), C.c_double(rt), C.c_double(sp), C.c_double(r), None, _i(rowval), _d(nzval))
+    return colptr, rowval[:nnz], nzval[:nnz]
+
+
+def dubins_graph_edges_free(X, rt, sp, colptr, rowval, lohi, ss_lo, ss_hi):
+    X, N, d = _X(X); lohi, M = _boxes(lohi, 2)
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64); rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+    nnz = int(colptr[-1])
+    mask = np.zeros(max(nwords(nnz), 1), dtype=np.uint64); nseg = np.zeros(max(nnz, 1), dtype=np.uint8)
+    lib().orc_dubins_graph_edges_free(_d(X), C.c_int64(N), C.c_double(rt), C.c_double(sp), _i(colptr), _i(rowval), _d(lohi), C.c_int32(M),
+                                      _d(_vec(ss_lo)), _d(_vec(ss_hi)), _u(mask), nseg.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return mask[:nwords(nnz)], nseg[:nnz]
+
+
+def dubins_fmtstar(X, rt, sp, colptr, rowval, nzval, goal_kind, goal, lohi, ss_lo, ss_hi, init_idx=0, checkpts=True):
+    X, N, d = _X(X); lohi, M = _boxes(lohi, 2); goal = _vec(goal)
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64); rowval = np.ascontiguousarray(rowval, dtype=np.int64); nzval = _vec(nzval)
+    A = np.empty(N, dtype=np.int64); Cc = np.empty(N, dtype=np.float64); path = np.empty(N, dtype=np.int64)
+    res = FmtResult()
+    rc = lib().orc_dubins_fmtstar(_d(X), C.c_int64(N), C.c_double(rt), C.c_double(sp), C.c_int64(init_idx), C.c_int32(int(checkpts)),
+                                  _i(colptr), _i(rowval), _d(nzval), C.c_int32(goal_kind), _d(goal), _d(lohi), C.c_int32(M),
+                                  _d(_vec(ss_lo)), _d(_vec(ss_hi)), _i(A), _d(Cc), _i(path), C.byref(res))
+    return dict(rc=rc, status=int(res.status), cost=float(res.cost), z=int(res.z), collision_checks=int(res.collision_checks),
+                A=A, C=Cc, path=path[:res.path_len].copy())

@@ -343,3 +343,112 @@ def is_free_state_2d(v, obstacles, ss_lo=None, ss_hi=None):       # statespaces.
 
 def is_free_motion_2d(v, w, obstacles, ss_lo=None, ss_hi=None):   # statespaces.jl:153-158 + robots2D.jl:13-14
     return (ss_lo is None or in_state_space(v, ss_lo, ss_hi)) and not colliding_line(Line(v, w), obstacles)
+
+
+# ---- Dubins car: src/statespaces/simplecars.jl:51-215, src/utilities/utils.jl:91 ------------------------------------------
+TWOPI = 2 * _m.pi
+
+
+def mod2piF(x):                # mod(x, 2pi) with Julia's float mod
+    r = _m.fmod(x, TWOPI)
+    if r == 0:
+        return 0.0
+    return r + TWOPI if r < 0 else r
+
+
+def carsegment2stepcontrol(t, d):          # :91  StepControl(abs(d), (sign(d), t))
+    return [abs(d), float((d > 0) - (d < 0)), float(t)]
+
+
+def _dubins_words(d, a, b):
+    """the six words in the order dubins() tries them (:206-211); yields (cnew, path) or None"""
+    ca, sa, cb, sb = _m.cos(a), _m.sin(a), _m.cos(b), _m.sin(b)
+    out = []
+    tmp = 2 + d * d - 2 * (ca * cb + sa * sb - d * (sa - sb))                       # LSL :106
+    if not tmp < 0:
+        th = _m.atan2(cb - ca, d + sa - sb)
+        t = mod2piF(-a + th); p = _m.sqrt(max(tmp, 0.0)); q = mod2piF(b - th)
+        out.append((t + p + q, [(1, t), (0, p), (1, q)]))
+    tmp = 2 + d * d - 2 * (ca * cb + sa * sb - d * (sb - sa))                       # RSR :121
+    if not tmp < 0:
+        th = _m.atan2(ca - cb, d - sa + sb)
+        t = mod2piF(a - th); p = _m.sqrt(max(tmp, 0.0)); q = mod2piF(-b + th)
+        out.append((t + p + q, [(-1, t), (0, p), (-1, q)]))
+    tmp = d * d - 2 + 2 * (ca * cb + sa * sb - d * (sa + sb))                       # RSL :136
+    if not tmp < 0:
+        p = _m.sqrt(max(tmp, 0.0))
+        th = _m.atan2(ca + cb, d - sa - sb) - _m.atan2(2.0, p)
+        t = mod2piF(a - th); q = mod2piF(b - th)
+        out.append((t + p + q, [(-1, t), (0, p), (1, q)]))
+    tmp = -2 + d * d + 2 * (ca * cb + sa * sb + d * (sa + sb))                      # LSR :151
+    if not tmp < 0:
+        p = _m.sqrt(max(tmp, 0.0))
+        th = _m.atan2(-ca - cb, d + sa + sb) - _m.atan2(-2.0, p)
+        t = mod2piF(-a + th); q = mod2piF(-b + th)
+        out.append((t + p + q, [(1, t), (0, p), (-1, q)]))
+    tmp = (6 - d * d + 2 * (ca * cb + sa * sb + d * (sa - sb))) / 8                 # RLR :166
+    if not abs(tmp) >= 1:
+        p = TWOPI - _m.acos(tmp)
+        th = _m.atan2(ca - cb, d - sa + sb)
+        t = mod2piF(a - th + p / 2); q = mod2piF(a - b - t + p)
+        out.append((t + p + q, [(-1, t), (1, p), (-1, q)]))
+    tmp = (6 - d * d + 2 * (ca * cb + sa * sb - d * (sa - sb))) / 8                 # LRL :181
+    if not abs(tmp) >= 1:
+        p = TWOPI - _m.acos(tmp)
+        th = _m.atan2(-ca + cb, d + sa - sb)
+        t = mod2piF(-a + th + p / 2); q = mod2piF(b - a - t + p)
+        out.append((t + p + q, [(1, t), (-1, p), (1, q)]))
+    return out
+
+
+def dubins(s1, s2, r=1.0, s=1.0):          # :198-215
+    v = ((s2[0] - s1[0]) / r, (s2[1] - s1[1]) / r)
+    d = _m.sqrt(v[0] * v[0] + v[1] * v[1])
+    th = _m.atan2(v[1], v[0])
+    a = mod2piF(s1[2] - th); b = mod2piF(s2[2] - th)
+    cmin, pmin = _m.inf, [[0.0, 0.0, 0.0]] * 3
+    for cnew, segs in _dubins_words(d, a, b):
+        if not cmin <= cnew:
+            cmin = cnew
+            pmin = [carsegment2stepcontrol(t, dd) for (t, dd) in segs]
+    pmin = [[u[0] * r, u[1], u[2] / r] for u in pmin]                              # scaleradius :92
+    pmin = [[u[0] / s, u[1] * s, u[2]] for u in pmin]                              # scalespeed :93
+    return cmin * r, pmin
+
+
+def car_propagate(v, u):                   # :52-65
+    t, s, invr = u
+    if abs(t * s * invr) > 10 * 2.220446049250313e-16:
+        return (v[0] + (_m.sin(v[2] + t * s * invr) - _m.sin(v[2])) / invr,
+                v[1] + (_m.cos(v[2]) - _m.cos(v[2] + t * s * invr)) / invr, mod2piF(v[2] + t * s * invr))
+    return (v[0] + t * s * _m.cos(v[2]), v[1] + t * s * _m.sin(v[2]), mod2piF(v[2] + t * s * invr))
+
+
+def car_collision_waypoints(v, w, r=1.0, s=1.0):    # :68-83 + statespaces.jl:127-135
+    _, us = dubins(v, w, r, s)
+    path = []
+    thres = _m.pi / 12
+    v = tuple(v)
+    for u in us:
+        t, sp, invr = u
+        m = _m.floor(t * sp * invr / thres)
+        path.append(v)
+        if m != 0:
+            for i in range(1, m + 1):
+                path.append((v[0] + (_m.sin(v[2] + i * thres) - _m.sin(v[2])) / invr,
+                             v[1] + (_m.cos(v[2]) - _m.cos(v[2] + i * thres)) / invr, mod2piF(v[2] + i * thres)))
+        v = car_propagate(v, u)
+    path.append(tuple(w))
+    return path
+
+
+def car_is_free_motion(v, w, r, s, boxes, ss_lo, ss_hi):    # statespaces.jl:153-158; returns (free, segment tests made)
+    wps = car_collision_waypoints(v, w, r, s)
+    cnt = 0
+    for i in range(len(wps) - 1):
+        if not in_state_space(wps[i], ss_lo, ss_hi):
+            return False, cnt
+        cnt += 1
+        if not is_free_motion_boxes(wps[i][:2], wps[i + 1][:2], boxes):
+            return False, cnt
+    return True, cnt

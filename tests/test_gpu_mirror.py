@@ -129,3 +129,28 @@ def test_polygon_world_planning_like_the_notebook(orc):
     assert CC.count == md["collision_checks"] + 2
     blocked = CC.addblocker([0.5, 0.05], 0.04)
     assert not mp.is_free_motion([0.05, 0.05], [0.95, 0.05], blocked, SS, P.ctx)
+
+
+def test_dubins_planning_through_the_mirror(orc):
+    """DubinsQuasiMetricSpace (simplecars.jl:32-38) through the mirror types: SE2 samples, workspace goal lifted to a state,
+    the plan checked against the oracle's Dubins graph / recursion on the samples the mirror drew."""
+    rt = 0.08
+    SS = mp.DubinsQuasiMetricSpace(rt)
+    assert mp.dim(SS) == 3 and SS.workspace_dim == 2 and abs(mp.volume(SS) - 2 * np.pi) < 1e-12
+    CC = mp.PointRobotNDBoxes(boxes2d())
+    P = mp.MPProblem(SS, [0.1, 0.1, 0.5], mp.BallGoal([0.9, 0.9], 0.06), CC)
+    status, cost, _ = mp.fmtstar_(P, 1800, rm=1.2, rng=np.random.default_rng(3), ensure_goal_ct=3)
+    X = P.V.V
+    assert X.shape == (1800, 3) and np.all((X[:, 2] >= 0) & (X[:, 2] <= 2 * np.pi))
+    assert np.all(np.linalg.norm(X[-3:, :2] - [0.9, 0.9], axis=1) <= 0.06)          # goal samples in the tail
+    md = P.solution.metadata
+    lohi = CC.lohi()
+    oc, orow, oval = orc.dubins_graph(X, rt, 1.0, md["r"])
+    ref = orc.dubins_fmtstar(X, rt, 1.0, oc, orow, oval, orc.GOAL_BALL, np.array([0.9, 0.9, 0.06]), lohi, SS.lo, SS.hi)
+    assert (status == "solved") == bool(ref["status"])
+    assert np.array_equal(md["tree"] - 1, ref["A"]) and md["collision_checks"] == ref["collision_checks"]
+    if ref["status"]:
+        assert abs(cost - ref["cost"]) <= 1e-9 * ref["cost"]
+        path = md["path"] - 1
+        for a, b in zip(path[:-1], path[1:]):                       # every edge of the plan is a free Dubins motion
+            assert orc.dubins_is_free_motion(X[a], X[b], rt, 1.0, lohi, SS.lo, SS.hi)[0]

@@ -740,3 +740,64 @@ def test_sat2d_random_world_graph_and_plan(ctx, orc):
     with pytest.raises(mp.MPFMTError) as e:
         ctx.upload_shapes2d([("polygon", [(0, 0), (1, 0), (0.2, 0.2), (0, 1)])])
     assert e.value.code == mp._lib.ERR_ARG
+
+
+# ---- Dubins car ----------------------------------------------------------------------------------------
+
+def _car_world(rng, N, M):
+    X = np.column_stack([rng.random(N), rng.random(N), rng.random(N) * 2 * np.pi])
+    c = 0.15 + 0.7 * rng.random((M, 2)); h = 0.02 + 0.05 * rng.random((M, 2))
+    lohi = np.stack([c - h, c + h], axis=1)
+    lo, hi = np.array([0.0, 0.0, 0.0]), np.array([1.0, 1.0, 2 * np.pi])
+    return X, lohi, lo, hi
+
+
+def test_dubins_steer_batch(ctx, orc):
+    rng = np.random.default_rng(61)
+    X0, _, _, _ = _car_world(rng, 4000, 1); X1, _, _, _ = _car_world(rng, 4000, 1)
+    for rt in (0.05, 0.3, 2.0):
+        cost, ctrl = ctx.dubins_steer(X0, X1, rt, 1.0)
+        want = [orc.dubins(a, b, rt, 1.0) for a, b in zip(X0, X1)]
+        wc = np.array([w[0] for w in want]); wu = np.array([w[1] for w in want])
+        assert np.allclose(cost, wc, rtol=1e-12, atol=0)
+        same_word = np.all(ctrl[:, :, 1:] == wu[:, :, 1:], axis=(1, 2))
+        assert same_word.mean() > 0.999                                 # ties between words can resolve differently at 1 ulp
+        assert np.allclose(ctrl[same_word], wu[same_word], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("N,rt,r", [(1500, 0.05, 0.25), (2500, 0.15, 0.3)])
+def test_dubins_graph_sweep_and_plan(ctx, orc, N, rt, r):
+    """Dubins backward sets, edge validity with the reference's arc waypoints, and a full plan, against the oracle.
+    Device and host libm differ by a few ulp, so costs are compared to 1e-12 and set membership / masks are required to be
+    identical except for pairs whose cost sits within 1e-9 of the radius (none expected on seeded data)."""
+    rng = np.random.default_rng(70 + N)
+    X, lohi, lo, hi = _car_world(rng, N, 12)
+    X[0] = [0.05, 0.05, 0.6]; X[-1] = [0.95, 0.95, 0.8]
+    ctx.upload_samples(X)
+    ctx.upload_boxes(lohi, lo, hi, dw=2)
+    colptr, rowval, nzval = ctx.dubins_graph(rt, 1.0, r)
+    oc, orow, oval = orc.dubins_graph(X, rt, 1.0, r)
+    c0, r0 = to0(colptr, rowval)
+    if not (np.array_equal(c0, oc) and np.array_equal(r0, orow)):
+        # tolerate only threshold-straddling pairs
+        got = set(zip(np.repeat(np.arange(N), np.diff(c0)).tolist(), r0.tolist()))
+        want = set(zip(np.repeat(np.arange(N), np.diff(oc)).tolist(), orow.tolist()))
+        for (j, i) in got ^ want:
+            assert abs(orc.dubins(X[i], X[j], rt, 1.0)[0] - r) < 1e-9 * r
+        pytest.skip("threshold-straddling pair on this seed")
+    assert np.allclose(nzval, oval, rtol=1e-12, atol=0)
+    assert len(r0) > 5 * N                                                # a real graph, not a trivial one
+    mask, nseg = ctx.dubins_graph_edges_free()
+    omask, onseg = orc.dubins_graph_edges_free(X, rt, 1.0, oc, orow, lohi, lo, hi)
+    agree = (mp._lib.unpack_bits(mask, len(r0)) == orc.unpack(omask, len(r0)))
+    assert agree.mean() > 0.9999 and (nseg == onseg)[agree].mean() > 0.9999
+    assert 0.2 < mp._lib.unpack_bits(mask, len(r0)).mean() < 0.999
+    goal = np.array([0.95, 0.95, 0.08])
+    got = ctx.dubins_fmtstar(rt, 1.0, r, mp._lib.GOAL_BALL, goal)
+    want = orc.dubins_fmtstar(X, rt, 1.0, oc, orow, oval, orc.GOAL_BALL, goal, lohi, lo, hi, init_idx=0)
+    assert got["status"] == want["status"]
+    if agree.all():
+        assert np.array_equal(got["A"] - 1, want["A"]) and np.array_equal(got["path"] - 1, want["path"])
+        assert got["collision_checks"] == want["collision_checks"]
+        assert np.allclose(got["C"], want["C"], rtol=1e-10, atol=0)
+        assert abs(got["cost"] - want["cost"]) <= 1e-10 * max(want["cost"], 1e-300)

@@ -242,3 +242,36 @@ def test_sat2d_oracle_against_goldens_and_known_answers():
         orc.Shapes2D([("polygon", [(0, 0), (1, 0), (0.2, 0.2), (0, 1)])])       # not convex (SAT2D.jl:49)
     with pytest.raises(ValueError):
         orc.Shapes2D([("circle", (0, 0), 0.0)])                                 # SAT2D.jl:22
+
+
+def test_dubins_oracle_against_transliteration():
+    """Dubins steering (simplecars.jl:106-215): oracle = independent transliteration on costs, controls and waypoints to a
+    few ulp (same libm, but the C compiler pairs sin/cos into sincos), same word chosen, and every path ends at its target."""
+    from oracle import oracle as orc
+    import jl_transliteration as jl
+    rng = np.random.default_rng(2)
+    for k in range(3000):
+        s1 = np.array([rng.random(), rng.random(), rng.random() * 2 * np.pi])
+        s2 = np.array([rng.random(), rng.random(), rng.random() * 2 * np.pi])
+        rt = [0.05, 0.2, 1.0][k % 3]
+        c, p = orc.dubins(s1, s2, rt, 1.0)
+        cj, pj = jl.dubins(s1, s2, rt, 1.0)
+        pj = np.array(pj)
+        assert abs(c - cj) <= 1e-14 * c and np.array_equal(p[:, 1:], pj[:, 1:]) and np.allclose(p, pj, rtol=0, atol=1e-14)
+        assert abs(p[:, 0].sum() - c) <= 1e-12 * c
+        v = tuple(s1)
+        for u in p:
+            v = jl.car_propagate(v, u)
+        assert abs(v[0] - s2[0]) < 1e-9 and abs(v[1] - s2[1]) < 1e-9
+        assert min(abs(v[2] - s2[2]), 2 * np.pi - abs(v[2] - s2[2])) < 1e-9
+        w1 = orc.dubins_waypoints(s1, s2, rt, 1.0)
+        w2 = np.array(jl.car_collision_waypoints(s1, s2, rt, 1.0))
+        assert w1.shape == w2.shape and np.allclose(w1, w2, rtol=0, atol=1e-14)
+    # known answers: straight ahead, and a quarter turn on the unit circle
+    c, p = orc.dubins([0, 0, 0], [1, 0, 0], 1.0, 1.0)
+    assert abs(c - 1.0) < 1e-15
+    # a degenerate pose (exact quarter turn): mod2piF of a -1e-17 remainder wraps to 2*pi, so the reference's formulae pick
+    # a longer word there -- restatement and transliteration must agree on that too
+    c, _ = orc.dubins([0, 0, 0], [1, 1, np.pi / 2], 1.0, 1.0)
+    cj, _ = jl.dubins([0, 0, 0], [1, 1, np.pi / 2], 1.0, 1.0)
+    assert abs(c - cj) <= 1e-14 * c and c >= np.pi / 2 - 1e-12
