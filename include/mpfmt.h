@@ -149,6 +149,16 @@ int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const in
                                  const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params,
                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
+/* ---- Monte-Carlo collision probability of candidate edges (BASELINE.json configs[4]).  The reference
+ *      has no implementation (README.md:9-10 cites the papers only); the workload is the one SURVEY 8d defines: per edge
+ *      (src[e] -> dst[e], 1-based sample indices) `rollouts` perturbed copies of the 2-point trajectory, each put through
+ *      is_free_motion(v', w', CC, SS) (statespaces.jl:153-158, boxesND.jl:44-56).  v' = v + sigma z with z a standardised
+ *      Irwin-Hall(8) variate built from the halfwords of Philox4x32-10(key = seed, counter = (rollout, edge, coordinate, 2))
+ *      -- integer sums and unfused fp64 only, so a scalar loop reproduces hits[e] (colliding rollouts) exactly.
+ *      Needs the AABB checker; E and rollouts < 2^32. */
+int32_t mpfmt_mc_edges_collision(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double sigma, int64_t rollouts,
+                                 uint64_t seed, int64_t* hits);
+
 /* ---- Dubins car: DubinsQuasiMetricSpace(r_turn, s, lo, hi) of src/statespaces/simplecars.jl:32-38.
  *      Samples are SE2 states (x, y, theta) (upload_samples with d = 3); obstacles live in the workspace (x, y)
  *      (VectorView(1:2)): upload_boxes with dw = 2 and the 3 state bounds (lo_x, lo_y, 0; hi_x, hi_y, 2pi).

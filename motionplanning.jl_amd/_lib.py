@@ -59,6 +59,7 @@ SYMBOLS = [
     ("mpfmt_host_fmt_recursion", C.c_int32, [C.c_int64, C.c_int32, c_d_p, c_i64_p, C.POINTER(C.c_int32), c_d_p, c_u64_p, c_u64_p,
                                              c_d_p, c_d_p, C.c_int64, C.c_int32, c_d_p, c_i64_p, c_d_p, c_i64_p,
                                              C.POINTER(FmtResult)]),
+    ("mpfmt_mc_edges_collision", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, C.c_int64, C.c_double, C.c_int64, C.c_uint64, c_i64_p]),
     ("mpfmt_dubins_graph_count", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, c_i64_p, c_i64_p]),
     ("mpfmt_dubins_graph_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p]),
     ("mpfmt_dubins_graph_edges_free", C.c_int32, [C.c_void_p, c_u64_p, c_u8_p]),
@@ -342,6 +343,13 @@ class Context:
                     collision_checks=int(res.collision_checks), nnz=int(res.nnz),
                     ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
                     A=A[:self.N], C=Cc[:self.N], path=path[:res.path_len].copy())
+
+    def mc_edges_collision(self, src, dst, sigma, rollouts, seed=0):
+        """Colliding rollouts per edge (1-based src / dst): Monte-Carlo collision probability = hits / rollouts."""
+        src = np.ascontiguousarray(src, dtype=np.int64); dst = np.ascontiguousarray(dst, dtype=np.int64)
+        hits = np.zeros(max(len(src), 1), dtype=np.int64)
+        self._chk(self._L.mpfmt_mc_edges_collision(self._h, _ip(src), _ip(dst), len(src), float(sigma), int(rollouts), int(seed), _ip(hits)))
+        return hits[:len(src)]
 
     # ---- Dubins car -------------------------------------------------------------------------------
     def dubins_graph(self, turn_radius, speed, r):

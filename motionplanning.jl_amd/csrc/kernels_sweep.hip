@@ -699,6 +699,124 @@ int32_t mpfmt_launch_motions_free(mpfmt_ctx* ctx, const double* d_P, const doubl
     return rc;
 }
 
+// ---- Monte-Carlo collision probability of candidate edges (BASELINE configs[4]) ----------------------
+// The reference has no implementation (README.md:9-10 cites papers only); SURVEY 8d defines the workload: per candidate
+// edge, many perturbed copies of the 2-point trajectory, each swept with the segment test of boxesND.jl:44-56.  The noise
+// is declared so that a scalar loop reproduces the counts bit for bit (integer sums, unfused fp64, no transcendentals):
+//   rollout k of edge e, coordinate c (0..d-1 parent, d..2d-1 child): Philox4x32-10(key = seed, counter = (k, e, c, 2))
+//   -> 8 halfwords, S = their sum (Irwin-Hall of 8 uniforms), z = (S - 262140) / 53509.92 (mean 0, variance 1, |z| < 4.9);
+//   v' = v + sigma z.  hits[e] = rollouts with !is_free_motion(v', w', CC, SS).
+// One workgroup per (edge, slice of the rollouts); lane = rollout; the boxes are culled once per workgroup against the
+// edge's box grown by 4.9 sigma, so a rollout tests only the few boxes it can reach.
+#define MC_SCALE (1.0 / 53509.91992145008)
+#define MC_ZMAX 4.9
+__device__ __forceinline__ double mc_normal(uint32_t k0, uint32_t k1, uint32_t k, uint32_t e, uint32_t c)
+{
+    uint32_t c0 = k, c1 = e, c2 = c, c3 = 2u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint32_t S = (c0 & 0xffffu) + (c0 >> 16) + (c1 & 0xffffu) + (c1 >> 16) + (c2 & 0xffffu) + (c2 >> 16) + (c3 & 0xffffu) + (c3 >> 16);
+    return ((double)S - 262140.0) * MC_SCALE;
+}
+
+template <int D>
+__global__ __launch_bounds__(SWEEP_THREADS) void k_mc_edges(const double* __restrict__ X, const int64_t* __restrict__ src1,
+                                                            const int64_t* __restrict__ dst1, double sigma, int64_t rollouts,
+                                                            int64_t per_block, uint64_t seed, const double* __restrict__ boxes, int M,
+                                                            int chunk, mpfmt_ss ss, unsigned long long* __restrict__ hits, int64_t e_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sbox = (double*)smem;
+    __shared__ unsigned long long s_hits;
+    const int lane = threadIdx.x & 63;
+    const int64_t e = blockIdx.x;
+    const int64_t k_begin = (int64_t)blockIdx.y * per_block, k_end = min(rollouts, k_begin + per_block);
+    if (threadIdx.x == 0) s_hits = 0;
+    double v0[D], w0[D], ulo[D], uhi[D];
+    const int64_t s = src1[e] - 1, t = dst1[e] - 1;
+    const double reach = MC_ZMAX * sigma;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        v0[i] = X[s * D + i]; w0[i] = X[t * D + i];
+        ulo[i] = ((w0[i] < v0[i]) ? w0[i] : v0[i]) - reach;
+        uhi[i] = ((v0[i] < w0[i]) ? w0[i] : v0[i]) + reach;
+    }
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int nchunks = (M + chunk - 1) / max(chunk, 1);
+    unsigned long long smask[SWEEP_WORDS];
+#pragma unroll
+    for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] = 0;
+    if (nchunks == 1) {                                   // the common case: the whole obstacle set staged and culled once
+        __syncthreads();
+        stage_boxes<D>(sbox, boxes, 0, M);
+        __syncthreads();
+        cull_boxes<D>(sbox, M, ulo, uhi, smask, lane);
+    }
+    unsigned long long mine = 0;
+    for (int64_t kb = k_begin; kb < k_end; kb += SWEEP_THREADS) {        // uniform trip count: barriers inside are safe
+        const int64_t k = kb + threadIdx.x;
+        const bool act = k < k_end;
+        double v[D], w[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double pv = sigma * mc_normal(k0, k1, (uint32_t)k, (uint32_t)(e_off + e), (uint32_t)i);
+            const double pw = sigma * mc_normal(k0, k1, (uint32_t)k, (uint32_t)(e_off + e), (uint32_t)(D + i));
+            v[i] = v0[i] + pv; w[i] = w0[i] + pw;
+        }
+        bool fr = act && in_state_space_sl<D>(v, ss);
+        if (nchunks <= 1) {
+            if (M > 0) fr = sweep_segment<D>(sbox, smask, v, w, fr);
+        } else {
+            for (int b0 = 0; b0 < M; b0 += chunk) {
+                const int nb = min(chunk, M - b0);
+                __syncthreads();
+                stage_boxes<D>(sbox, boxes, b0, nb);
+                __syncthreads();
+                cull_boxes<D>(sbox, nb, ulo, uhi, smask, lane);
+                fr = sweep_segment<D>(sbox, smask, v, w, fr);
+            }
+        }
+        mine += (unsigned long long)__popcll(__ballot(act && !fr));
+    }
+    if (lane == 0 && mine) atomicAdd(&s_hits, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_hits) atomicAdd(&hits[e], s_hits);
+}
+
+int32_t mpfmt_launch_mc_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, double sigma, int64_t rollouts,
+                              uint64_t seed, unsigned long long* d_hits)
+{
+    int32_t rc;
+    if ((rc = check_boxes(ctx, ctx->d))) return rc;
+    if (ctx->cc_kind != 0) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the Monte-Carlo evaluator runs against the AABB checker");
+    if (E == 0 || rollouts == 0) return MPFMT_OK;
+    const int d = ctx->d;
+    const int chunk = box_chunk(ctx->M, d, true);
+    const size_t lds = sweep_lds(std::max(chunk, 1), d);
+    // enough workgroups to fill the GPU even for a single edge, at least 4 batches of rollouts per workgroup
+    int64_t slices = std::max<int64_t>(1, std::min<int64_t>((rollouts + 4 * SWEEP_THREADS - 1) / (4 * SWEEP_THREADS),
+                                                            std::max<int64_t>(1, (int64_t)ctx->num_cus * 8 / std::max<int64_t>(E, 1))));
+    slices = std::min<int64_t>(slices, 65535);
+    const int64_t per_block = ((rollouts + slices - 1) / slices + SWEEP_THREADS - 1) / SWEEP_THREADS * SWEEP_THREADS;
+    slices = (rollouts + per_block - 1) / per_block;
+    mpfmt_time_begin(ctx);
+    for (int64_t e0 = 0; e0 < E; e0 += 1 << 20) {                    // gridDim.x limit
+        const int64_t ne = std::min<int64_t>(E - e0, 1 << 20);
+        DISPATCH_D(d, hipLaunchKernelGGL((k_mc_edges<DD>), dim3((unsigned)ne, (unsigned)slices), dim3(SWEEP_THREADS), lds, ctx->stream,
+                                         ctx->Xo, d_src1 + e0, d_dst1 + e0, sigma, rollouts, per_block, seed, ctx->boxes, ctx->M,
+                                         std::max(chunk, 1), ctx->ss, d_hits + e0, e0));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    mpfmt_time_end(ctx, "mc_edges");
+    return MPFMT_OK;
+}
+
 // tasks of 16 columns; of 8 when that would leave fewer than ~6 tasks per resident wavefront (a shard of a multi-GPU
 // build, small graphs): finer tasks balance the tail.  One resident set of workgroups.
 template <int D>

@@ -193,6 +193,8 @@ int32_t mpfmt_2d_launch_graph(mpfmt_ctx* ctx);
 int32_t mpfmt_launch_states_free(mpfmt_ctx* ctx, const double* d_P, int64_t n, uint64_t* d_mask);
 int32_t mpfmt_launch_edges_free(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, uint64_t* d_mask);
 int32_t mpfmt_launch_motions_free(mpfmt_ctx* ctx, const double* d_P, const double* d_Q, int64_t n, uint64_t* d_mask);
+int32_t mpfmt_launch_mc_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, double sigma, int64_t rollouts,
+                              uint64_t seed, unsigned long long* d_hits);
 int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx);
 
 // kernels_di.hip ----------------------------------------------------------------------------------

@@ -1508,3 +1508,44 @@ int32_t orc_dubins_fmtstar(const double *X, int64_t N, double rt, double sp, int
     free(F); free(rowptr); free(colidx); free(cur); free(Wm); free(Hm); free(Hnew); free(rev); free(heap.pri); free(heap.idx);
     return 0;
 }
+
+/* ---- Monte-Carlo collision probability of an edge (BASELINE configs[4] / SURVEY 8d cfg5) ------------------------------
+ * The reference has no implementation (README.md:9-10 cites papers only); SURVEY 8d defines the workload: per candidate
+ * edge, many perturbed copies of the 2-point trajectory, each swept with the segment test of boxesND.jl:44-56.  Declared
+ * here so that a scalar loop and the device kernel agree bit for bit (integer sums, unfused fp64, no transcendentals):
+ *   rollout k of edge e, coordinate c (0..d-1 of the parent v, d..2d-1 of the child w):
+ *     Philox4x32-10 (key = seed, counter = (k, e, c, 2)) -> 8 halfwords h_0..h_7;  S = sum h_i  (Irwin-Hall of 8 uniforms)
+ *     z = ((double)S - 262140.0) * ORC_MC_SCALE     (mean 0, variance 1: 8 * (65536^2 - 1) / 12 = 53509.92...^2)
+ *     v'_c = v_c + sigma * z   (resp. w');
+ *   outcome = !is_free_motion(v', w', CC, SS)  (statespaces.jl:153-158: in_state_space(v') && segment test);
+ *   hits[e] = number of colliding rollouts; the estimate is hits / rollouts. */
+#define ORC_MC_SCALE (1.0 / 53509.91992145008)
+static double mc_normal(uint64_t seed, uint32_t k, uint32_t e, uint32_t c)
+{
+    const uint32_t ctr[4] = {k, e, c, 2u}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t x[4];
+    orc_philox4x32_10(ctr, key, x);
+    uint32_t S = 0;
+    for (int i = 0; i < 4; ++i) S += (x[i] & 0xffffu) + (x[i] >> 16);
+    return ((double)S - 262140.0) * ORC_MC_SCALE;
+}
+
+void orc_mc_edges(const double *X, int32_t d, const int64_t *src, const int64_t *dst, int64_t E, double sigma, int64_t rollouts,
+                  uint64_t seed, const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi, int64_t *hits)
+{
+    double v[ORC_MAXD], w[ORC_MAXD];
+    for (int64_t e = 0; e < E; ++e) {
+        const double *v0 = X + (size_t)src[e] * d, *w0 = X + (size_t)dst[e] * d;
+        int64_t h = 0;
+        for (int64_t k = 0; k < rollouts; ++k) {
+            for (int32_t c = 0; c < d; ++c) {
+                const double zv = mc_normal(seed, (uint32_t)k, (uint32_t)e, (uint32_t)c);
+                const double zw = mc_normal(seed, (uint32_t)k, (uint32_t)e, (uint32_t)(d + c));
+                const double pv = sigma * zv, pw = sigma * zw;
+                v[c] = v0[c] + pv; w[c] = w0[c] + pw;
+            }
+            if (!orc_is_free_motion(v, w, d, lohi, M, ss_lo, ss_hi)) ++h;
+        }
+        hits[e] = h;
+    }
+}

@@ -469,3 +469,13 @@ def dubins_fmtstar(X, rt, sp, colptr, rowval, nzval, goal_kind, goal, lohi, ss_l
                                   _d(_vec(ss_lo)), _d(_vec(ss_hi)), _i(A), _d(Cc), _i(path), C.byref(res))
     return dict(rc=rc, status=int(res.status), cost=float(res.cost), z=int(res.z), collision_checks=int(res.collision_checks),
                 A=A, C=Cc, path=path[:res.path_len].copy())
+
+
+# ---- Monte-Carlo collision probability per edge (BASELINE configs[4]) ------------------------------------------------
+def mc_edges(X, src, dst, sigma, rollouts, seed, lohi, ss_lo=None, ss_hi=None):
+    X, N, d = _X(X); lohi, M = _boxes(lohi, d)
+    src = np.ascontiguousarray(src, dtype=np.int64); dst = np.ascontiguousarray(dst, dtype=np.int64)
+    hits = np.zeros(max(len(src), 1), dtype=np.int64)
+    lib().orc_mc_edges(_d(X), C.c_int32(d), _i(src), _i(dst), C.c_int64(len(src)), C.c_double(sigma), C.c_int64(rollouts),
+                       C.c_uint64(seed), _d(lohi), C.c_int32(M), _d(_vec(ss_lo)), _d(_vec(ss_hi)), _i(hits))
+    return hits[:len(src)]

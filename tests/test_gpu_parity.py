@@ -801,3 +801,36 @@ def test_dubins_graph_sweep_and_plan(ctx, orc, N, rt, r):
         assert got["collision_checks"] == want["collision_checks"]
         assert np.allclose(got["C"], want["C"], rtol=1e-10, atol=0)
         assert abs(got["cost"] - want["cost"]) <= 1e-10 * max(want["cost"], 1e-300)
+
+
+# ---- Monte-Carlo collision probability of edges (BASELINE configs[4]) -------------------------------------------------
+
+@pytest.mark.parametrize("d,M,sigma,R", [(2, 20, 0.02, 3000), (6, 200, 0.03, 1500), (3, 300, 0.05, 1000), (6, 0, 0.1, 500)])
+def test_mc_edges_match_scalar_loop(ctx, orc, d, M, sigma, R):
+    """Per-edge colliding-rollout counts equal the scalar loop's exactly (integer noise sums, unfused fp64)."""
+    rng = np.random.default_rng(800 + d + M)
+    X, lohi = random_world(rng, 400, d, M, 0.04, 0.12)
+    lo, hi = np.full(d, 0.02), np.full(d, 0.98)
+    ctx.upload_samples(X); ctx.upload_boxes(lohi, lo, hi)
+    src = rng.integers(1, 401, 60); dst = rng.integers(1, 401, 60)
+    got = ctx.mc_edges_collision(src, dst, sigma, R, seed=77)
+    want = orc.mc_edges(X, src - 1, dst - 1, sigma, R, 77, lohi, lo, hi)
+    assert np.array_equal(got, want)
+    assert got.min() >= 0 and got.max() <= R
+    if M > 0:
+        assert 0 < (got > 0).sum()                       # some edges do hit something
+    # sigma = 0 reproduces the deterministic check
+    det = ctx.mc_edges_collision(src, dst, 0.0, 7, seed=1)
+    free = mp._lib.unpack_bits(ctx.edges_free(src, dst), len(src))
+    assert np.array_equal(det, np.where(free, 0, 7))
+
+
+def test_mc_one_edge_many_rollouts(ctx, orc):
+    """1e6 rollouts of one edge (the configuration BASELINE.json names): the estimate is stable across seeds to the
+    binomial error and a 20k-rollout prefix equals the scalar loop."""
+    X = np.array([[0.2, 0.2], [0.8, 0.2]])
+    lohi = np.array([[[0.45, 0.26], [0.55, 0.5]]])                 # a box 2 sigma above the segment
+    ctx.upload_samples(X); ctx.upload_boxes(lohi, np.zeros(2), np.ones(2))
+    p = [ctx.mc_edges_collision([1], [2], 0.03, 1_000_000, seed=s)[0] / 1e6 for s in (1, 2, 3)]
+    assert 1e-3 < p[0] < 1e-2 and max(p) - min(p) < 6 * np.sqrt(p[0] / 1e6)
+    assert ctx.mc_edges_collision([1], [2], 0.03, 20000, seed=1)[0] == orc.mc_edges(X, [0], [1], 0.03, 20000, 1, lohi, np.zeros(2), np.ones(2))[0]
