@@ -115,11 +115,18 @@ struct di_args {
     double* valtmp;
     double* tvaltmp;
     unsigned long long* counters;   // [0] pairs tested, [1] candidates
+    int64_t tile_step;              // 1; > 1 for the pilot launch that only visits every tile_step-th tile
+    // single-pass slot lists (MODE 2): accepted hits kept per (item, target lane)
+    int32_t* pool_i; double* pool_c; double* pool_t;
+    int64_t pool_cap;
+    int32_t* pool_flag;
 };
 
-template <int M, bool FILL>
+// MODE 0: count   1: fill the staging CSC from the counts   2: count AND keep the accepted hits in slot lists (single pass)
+template <int M, int MODE>
 __global__ __launch_bounds__(64) void k_di_pairs(di_args a)
 {
+    constexpr bool FILL = (MODE == 1);
     constexpr int NS = 2 * M;
     __shared__ double s_src[64 * NS];        // staged source chunk (AoS)
     __shared__ double s_tgt[64 * NS];        // this tile's targets (AoS) for the refine
@@ -129,8 +136,9 @@ __global__ __launch_bounds__(64) void k_di_pairs(di_args a)
     __shared__ int64_t s_base[64];
     const int lane = threadIdx.x;
     const int64_t item = blockIdx.x;
-    const int64_t tile = item / a.S;
+    const int64_t tile = (item / a.S) * a.tile_step;
     const int slice = (int)(item % a.S);
+    const int64_t slot_item = tile * a.S + slice;
     const int64_t j = tile * 64 + lane;
     const bool jact = j < a.N;
     const int64_t npad = a.ntiles * 64;
@@ -147,6 +155,7 @@ __global__ __launch_bounds__(64) void k_di_pairs(di_args a)
     const int64_t i0 = a.N * slice / a.S, i1 = a.N * (slice + 1) / a.S;
 
     int qcount = 0;
+    int pool_over = 0;
     unsigned long long ncand = 0;
     auto drain = [&](int n) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -169,6 +178,16 @@ __global__ __launch_bounds__(64) void k_di_pairs(di_args a)
                         a.rowtmp[pos] = (int32_t)i;
                         a.valtmp[pos] = cost;
                         a.tvaltmp[pos] = t;
+                    }
+                    if (MODE == 2) {
+                        if (slot < a.pool_cap) {
+                            const int64_t pos = (slot_item * 64 + tl) * a.pool_cap + slot;
+                            a.pool_i[pos] = (int32_t)i;
+                            a.pool_c[pos] = cost;
+                            a.pool_t[pos] = t;
+                        } else {
+                            pool_over = 1;
+                        }
                     }
                 }
             }
@@ -214,6 +233,7 @@ __global__ __launch_bounds__(64) void k_di_pairs(di_args a)
         }
     }
     while (qcount > 0) drain(min(qcount, 64));
+    if (MODE == 2 && pool_over) *a.pool_flag = 1;
     if (!FILL) {
         if (jact) a.slice_cnt[(int64_t)slice * npad + j] = s_cnt[lane];
         if (lane == 0 && a.counters) {
@@ -230,6 +250,31 @@ __global__ void k_di_degree(const int32_t* __restrict__ slice_cnt, int S, int64_
     int64_t k = 0;
     for (int s = 0; s < S; ++s) k += slice_cnt[(int64_t)s * npad + j];
     deg[j] = k;
+}
+
+// single pass: one wavefront per column moves its S slot lists (contiguous runs) into the staging CSC
+__global__ __launch_bounds__(64) void k_di_gather_slots(const int32_t* __restrict__ pool_i, const double* __restrict__ pool_c,
+                                                        const double* __restrict__ pool_t, int64_t capc, int S,
+                                                        const int32_t* __restrict__ slice_cnt, int64_t npad, int64_t N,
+                                                        const int64_t* __restrict__ colptr, int32_t* __restrict__ rowtmp,
+                                                        double* __restrict__ valtmp, double* __restrict__ tvaltmp)
+{
+    const int lane = threadIdx.x;
+    for (int64_t j = blockIdx.x; j < N; j += gridDim.x) {
+        const int64_t tile = j >> 6;
+        const int tl = (int)(j & 63);
+        int64_t out = colptr[j];
+        for (int sl = 0; sl < S; ++sl) {
+            const int n = slice_cnt[(int64_t)sl * npad + j];
+            const int64_t base = ((tile * S + sl) * 64 + tl) * capc;
+            for (int e = lane; e < n; e += 64) {
+                rowtmp[out + e] = pool_i[base + e];
+                valtmp[out + e] = pool_c[base + e];
+                tvaltmp[out + e] = pool_t[base + e];
+            }
+            out += n;
+        }
+    }
 }
 
 // per-column ordering by source index, carrying (cost, t): one wavefront per column, rank by counting
@@ -400,9 +445,43 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
     a.i2 = 1.0 / (r * r); a.i3 = a.i2 / r; a.i4 = a.i2 * a.i2;
     a.S = S; a.ntiles = ntiles; a.slice_cnt = ctx->slice_cnt; a.colptr = ctx->colptr;
     a.rowtmp = nullptr; a.valtmp = nullptr; a.tvaltmp = nullptr; a.counters = ctx->d_pairs;
+    a.tile_step = 1; a.pool_i = nullptr; a.pool_c = nullptr; a.pool_t = nullptr; a.pool_cap = 0; a.pool_flag = nullptr;
     mpfmt_time_begin(ctx);
+    // Single pass: the accepted hits of the count pass are kept in slot lists, so the pairs are not steered twice.  The
+    // list capacity comes from a pilot over every 32nd tile (tiles are in caller order, i.e. statistically alike); an
+    // overflow, or lists beyond 64 GB, falls back to the second (fill) pass.
+    bool pool = false;
+    ctx->di_pool_valid = false;
+    if (ntiles >= 64 && ctx->use_pool) {
+        di_args pa = a;
+        pa.tile_step = 32; pa.counters = nullptr;
+        const int64_t ptiles = (ntiles + 31) / 32;
+        HIPCHK(ctx, hipMemsetAsync(ctx->slice_cnt, 0, sizeof(int32_t) * (size_t)S * npad, ctx->stream));
+        DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, 0>), dim3((unsigned)(ptiles * S)), dim3(64), 0, ctx->stream, pa));
+        std::vector<int32_t> sc((size_t)S * npad);
+        HIPCHK(ctx, hipMemcpyAsync(sc.data(), ctx->slice_cnt, sizeof(int32_t) * sc.size(), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        int64_t mx = 0;
+        for (int64_t t = 0; t < ntiles; t += 32)
+            for (int sl = 0; sl < S; ++sl)
+                for (int64_t j = t * 64; j < std::min<int64_t>(t * 64 + 64, N); ++j) mx = std::max<int64_t>(mx, sc[(size_t)sl * npad + j]);
+        const int64_t capc = mx + mx / 2 + 32;
+        const double bytes = (double)capc * (double)ntiles * S * 64.0 * 20.0;
+        if (bytes <= 64e9) {
+            const size_t cap = (size_t)capc * (size_t)ntiles * S * 64;
+            if ((rc = mpfmt_ensure(ctx, (void**)&ctx->di_pool_i, sizeof(int32_t) * cap))) return rc;
+            if ((rc = mpfmt_ensure(ctx, (void**)&ctx->di_pool_c, sizeof(double) * cap))) return rc;
+            if ((rc = mpfmt_ensure(ctx, (void**)&ctx->di_pool_t, sizeof(double) * cap))) return rc;
+            if (!ctx->pool_flag) HIPCHK(ctx, hipMalloc((void**)&ctx->pool_flag, sizeof(int32_t)));
+            HIPCHK(ctx, hipMemsetAsync(ctx->pool_flag, 0, sizeof(int32_t), ctx->stream));
+            a.pool_i = ctx->di_pool_i; a.pool_c = ctx->di_pool_c; a.pool_t = ctx->di_pool_t; a.pool_cap = capc; a.pool_flag = ctx->pool_flag;
+            ctx->di_pool_cap = capc;
+            pool = true;
+        }
+    }
     if (ntiles > 0) {
-        DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, false>), dim3((unsigned)(ntiles * S)), dim3(64), 0, ctx->stream, a));
+        if (pool) { DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, 2>), dim3((unsigned)(ntiles * S)), dim3(64), 0, ctx->stream, a)); }
+        else { DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, 0>), dim3((unsigned)(ntiles * S)), dim3(64), 0, ctx->stream, a)); }
         hipLaunchKernelGGL(k_di_degree, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, ctx->slice_cnt, S, npad, N, ctx->deg);
         HIPCHK(ctx, hipGetLastError());
     }
@@ -412,7 +491,10 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
     unsigned long long ctr[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(&nnz, ctx->colptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctr, ctx->d_pairs, sizeof(ctr), hipMemcpyDeviceToHost, ctx->stream));
+    int32_t pool_over = 0;
+    if (pool) HIPCHK(ctx, hipMemcpyAsync(&pool_over, ctx->pool_flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->di_pool_valid = pool && pool_over == 0;
     ctx->nnz = nnz;
     ctx->pairs_tested = (int64_t)ctr[0];
     ctx->survivors = (int64_t)ctr[1];
@@ -441,9 +523,16 @@ int32_t mpfmt_di_fill(mpfmt_ctx* ctx)
     a.i2 = 1.0 / (a.r * a.r); a.i3 = a.i2 / a.r; a.i4 = a.i2 * a.i2;
     a.S = ctx->di_S; a.ntiles = ntiles; a.slice_cnt = ctx->slice_cnt; a.colptr = ctx->colptr;
     a.rowtmp = ctx->rowtmp; a.valtmp = ctx->valtmp; a.tvaltmp = ctx->tvaltmp; a.counters = nullptr;
+    a.tile_step = 1; a.pool_i = nullptr; a.pool_c = nullptr; a.pool_t = nullptr; a.pool_cap = 0; a.pool_flag = nullptr;
     if (nnz > 0) {
         mpfmt_time_begin(ctx);
-        DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, true>), dim3((unsigned)(ntiles * a.S)), dim3(64), 0, ctx->stream, a));
+        if (ctx->di_pool_valid) {
+            hipLaunchKernelGGL(k_di_gather_slots, dim3((unsigned)std::min<int64_t>(N, 1 << 20)), dim3(64), 0, ctx->stream, ctx->di_pool_i,
+                               ctx->di_pool_c, ctx->di_pool_t, ctx->di_pool_cap, a.S, ctx->slice_cnt, ntiles * 64, N, ctx->colptr,
+                               ctx->rowtmp, ctx->valtmp, ctx->tvaltmp);
+        } else {
+            DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, 1>), dim3((unsigned)(ntiles * a.S)), dim3(64), 0, ctx->stream, a));
+        }
         const unsigned nb = (unsigned)std::min<int64_t>(N, 1 << 20);
         hipLaunchKernelGGL(k_di_sortcols, dim3(nb), dim3(64), 0, ctx->stream, ctx->colptr, N, ctx->rowtmp, ctx->valtmp,
                            ctx->tvaltmp, ctx->rowval, ctx->nzval, ctx->tval);

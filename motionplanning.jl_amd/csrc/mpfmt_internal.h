@@ -130,6 +130,8 @@ struct mpfmt_ctx {
     int32_t di_S = 1;
     double di_rho = 1.0, di_r = 0.0;
     bool di_counted = false, di_filled = false, di_swept = false;
+    int32_t* di_pool_i = nullptr; double* di_pool_c = nullptr; double* di_pool_t = nullptr;   // DI single-pass slot lists
+    int64_t di_pool_cap = 0; bool di_pool_valid = false;
     int32_t steer_kind = 1;              // which directed cost graph the di_* state describes: 1 double integrator, 2 Dubins car
     double car_rt = 1.0, car_sp = 1.0;   // Dubins turning radius / speed of the built graph
     uint64_t* car_keep = nullptr;        // keep bits over the candidate (positions) graph

@@ -505,6 +505,37 @@ def test_di_graph_and_sweep(ctx, orc, N, rho, r):
     assert nseg.max() <= 4
 
 
+def test_di_single_pass_build(orc):
+    """N >= 4096 takes the single-pass build (hits kept in slot lists sized by a pilot); it must equal both the oracle and the
+    two-pass build, and a capacity overflow must fall back cleanly."""
+    N = 4300
+    X, lohi, ss_lo, ss_hi = di_world(N, 5)
+    oc, orow, oval, otv = orc.di_pairwise(X, 1.0, 0.7)
+    outs = []
+    for pool in (1, 0):
+        c = mp.Context(0)
+        c.set_option("rdisc_pool", pool)
+        c.upload_samples(X); c.upload_boxes(lohi, ss_lo, ss_hi)
+        c.timing_reset()
+        outs.append(c.di_graph(1.0, 0.7))
+        assert (c.timing("di_fill")[0] > 0)
+        c.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    colptr, rowval, nzval, tval = outs[0]
+    assert np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow)
+    assert np.array_equal(nzval, oval) and np.array_equal(tval, otv)
+    # a cluster the pilot does not see (only every 32nd tile is sampled): the tail tiles are far denser -> overflow -> fallback
+    X2 = X.copy()
+    X2[-200:, :2] = 0.5 + 0.002 * np.random.default_rng(1).standard_normal((200, 2)); X2[-200:, 2:] = 0.0
+    c = mp.Context(0)
+    c.upload_samples(X2); c.upload_boxes(lohi, ss_lo, ss_hi)
+    cp, rv, nz, tv = c.di_graph(1.0, 0.7)
+    o2 = orc.di_pairwise(X2, 1.0, 0.7)
+    assert np.array_equal(cp - 1, o2[0]) and np.array_equal(rv - 1, o2[1]) and np.array_equal(nz, o2[2])
+    c.close()
+
+
 def test_di_fmtstar_matches_oracle(ctx, orc):
     X, lohi, ss_lo, ss_hi = di_world(2500, 77)
     ctx.upload_samples(X)
