@@ -277,16 +277,64 @@ __global__ __launch_bounds__(64) void k_di_gather_slots(const int32_t* __restric
     }
 }
 
-// per-column ordering by source index, carrying (cost, t): one wavefront per column, rank by counting
+// per-column ordering by source index, carrying (cost, t): one wavefront per column.  DI columns are long (hundreds of
+// entries), so ranking by comparing against every other entry is quadratic; source indices are near-uniform over [0, N),
+// so columns of up to DI_SORT_MAX entries are ranked by buckets instead: bucket = floor(i * DI_SORT_BUCKETS / N) (monotone in i),
+// LDS histogram with returning atomics, 64-lane scan of the bucket counts, rank = bucket base + smaller ids in the same
+// bucket.  Longer columns fall back to counting.
+#define DI_SORT_MAX 4096          // longest column ranked through LDS
+#define DI_SORT_BUCKETS 1024
 __global__ __launch_bounds__(64) void k_di_sortcols(const int64_t* __restrict__ colptr, int64_t N,
                                                     const int32_t* __restrict__ rowtmp, const double* __restrict__ valtmp,
                                                     const double* __restrict__ tvaltmp, int32_t* __restrict__ rowval,
-                                                    double* __restrict__ nzval, double* __restrict__ tval)
+                                                    double* __restrict__ nzval, double* __restrict__ tval, uint32_t bucket_mul)
 {
+    __shared__ int32_t s_cnt[DI_SORT_BUCKETS], s_base[DI_SORT_BUCKETS];
+    __shared__ int32_t s_key[DI_SORT_MAX];       // ids grouped by bucket
+    __shared__ uint16_t s_arr[DI_SORT_MAX];      // arrival number of entry e inside its bucket
     const int lane = threadIdx.x;
+    auto bucket_of = [&](int32_t key) -> int {
+        return bucket_mul ? min(DI_SORT_BUCKETS - 1, (int)__umulhi((uint32_t)key, bucket_mul)) : (key & (DI_SORT_BUCKETS - 1));
+    };
     for (int64_t col = blockIdx.x; col < N; col += gridDim.x) {
         const int64_t beg = colptr[col];
         const int64_t k = colptr[col + 1] - beg;
+        if (k == 0) continue;
+        if (k <= DI_SORT_MAX) {
+            const int kk = (int)k;
+            __syncthreads();
+            for (int b = lane; b < DI_SORT_BUCKETS; b += 64) s_cnt[b] = 0;
+            __syncthreads();
+            for (int e = lane; e < kk; e += 64) s_arr[e] = (uint16_t)atomicAdd(&s_cnt[bucket_of(rowtmp[beg + e])], 1);
+            __syncthreads();
+            {   // exclusive scan of the bucket counts: 16 consecutive counts per lane
+                constexpr int R = DI_SORT_BUCKETS / 64;
+                int loc[R]; int tot = 0;
+#pragma unroll
+                for (int q = 0; q < R; ++q) { loc[q] = tot; tot += s_cnt[lane * R + q]; }
+                int inc = tot;
+#pragma unroll
+                for (int o2 = 1; o2 < 64; o2 <<= 1) { const int up = __shfl_up(inc, o2); if (lane >= o2) inc += up; }
+                const int excl = inc - tot;
+#pragma unroll
+                for (int q = 0; q < R; ++q) s_base[lane * R + q] = excl + loc[q];
+            }
+            __syncthreads();
+            for (int e = lane; e < kk; e += 64) { const int32_t key = rowtmp[beg + e]; s_key[s_base[bucket_of(key)] + s_arr[e]] = key; }
+            __syncthreads();
+            for (int e = lane; e < kk; e += 64) {
+                const int32_t key = rowtmp[beg + e];
+                const int bk = bucket_of(key);
+                const int b0 = s_base[bk], n = s_cnt[bk];
+                int r = 0;
+                for (int m2 = 0; m2 < n; ++m2) r += (s_key[b0 + m2] < key) ? 1 : 0;
+                const int64_t o = beg + b0 + r;
+                rowval[o] = key;
+                nzval[o] = valtmp[beg + e];
+                tval[o] = tvaltmp[beg + e];
+            }
+            continue;
+        }
         for (int64_t e0 = 0; e0 < k; e0 += 64) {
             const int64_t e = e0 + lane;
             const int32_t mine = (e < k) ? rowtmp[beg + e] : 0x7fffffff;
@@ -453,18 +501,33 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
     bool pool = false;
     ctx->di_pool_valid = false;
     if (ntiles >= 64 && ctx->use_pool) {
+        // the pilot splits every source slice into 8 sub-slices (8x the wavefronts, 1/8 the work each: a pilot item would
+        // otherwise run as long as a full item while occupying a fraction of the GPU); counts are summed back per slice
         di_args pa = a;
-        pa.tile_step = 32; pa.counters = nullptr;
+        const int SUB = std::max(1, std::min(8, 64 / S));
+        pa.S = S * SUB; pa.tile_step = 32; pa.counters = nullptr;
         const int64_t ptiles = (ntiles + 31) / 32;
-        HIPCHK(ctx, hipMemsetAsync(ctx->slice_cnt, 0, sizeof(int32_t) * (size_t)S * npad, ctx->stream));
-        DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, 0>), dim3((unsigned)(ptiles * S)), dim3(64), 0, ctx->stream, pa));
-        std::vector<int32_t> sc((size_t)S * npad);
-        HIPCHK(ctx, hipMemcpyAsync(sc.data(), ctx->slice_cnt, sizeof(int32_t) * sc.size(), hipMemcpyDeviceToHost, ctx->stream));
+        int32_t* pcnt;
+        {
+            void* scr;
+            if ((rc = mpfmt_scratch(ctx, sizeof(int32_t) * (size_t)pa.S * npad, &scr))) return rc;
+            pcnt = (int32_t*)scr;
+        }
+        pa.slice_cnt = pcnt;
+        HIPCHK(ctx, hipMemsetAsync(pcnt, 0, sizeof(int32_t) * (size_t)pa.S * npad, ctx->stream));
+        DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, 0>), dim3((unsigned)(ptiles * pa.S)), dim3(64), 0, ctx->stream, pa));
+        std::vector<int32_t> sc((size_t)pa.S * npad);
+        HIPCHK(ctx, hipMemcpyAsync(sc.data(), pcnt, sizeof(int32_t) * sc.size(), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         int64_t mx = 0;
         for (int64_t t = 0; t < ntiles; t += 32)
             for (int sl = 0; sl < S; ++sl)
-                for (int64_t j = t * 64; j < std::min<int64_t>(t * 64 + 64, N); ++j) mx = std::max<int64_t>(mx, sc[(size_t)sl * npad + j]);
+                for (int64_t j = t * 64; j < std::min<int64_t>(t * 64 + 64, N); ++j) {
+                    int64_t c = 0;
+                    // sub-slice q of the pilot covers sources [N*q/(S*SUB), N*(q+1)/(S*SUB)); slice sl = sub-slices sl*SUB .. sl*SUB+SUB-1
+                    for (int u = 0; u < SUB; ++u) c += sc[(size_t)(sl * SUB + u) * npad + j];
+                    mx = std::max(mx, c);
+                }
         const int64_t capc = mx + mx / 2 + 32;
         const double bytes = (double)capc * (double)ntiles * S * 64.0 * 20.0;
         if (bytes <= 64e9) {
@@ -535,7 +598,8 @@ int32_t mpfmt_di_fill(mpfmt_ctx* ctx)
         }
         const unsigned nb = (unsigned)std::min<int64_t>(N, 1 << 20);
         hipLaunchKernelGGL(k_di_sortcols, dim3(nb), dim3(64), 0, ctx->stream, ctx->colptr, N, ctx->rowtmp, ctx->valtmp,
-                           ctx->tvaltmp, ctx->rowval, ctx->nzval, ctx->tval);
+                           ctx->tvaltmp, ctx->rowval, ctx->nzval, ctx->tval,
+                           N > DI_SORT_BUCKETS ? (uint32_t)(((uint64_t)DI_SORT_BUCKETS << 32) / (uint64_t)N) : 0u);
         HIPCHK(ctx, hipGetLastError());
         mpfmt_time_end(ctx, "di_fill");
     }

@@ -12,3 +12,13 @@ dt = time.time() - t0
 print("N", n, "status", res["status"], "cost", res["cost"], "nnz", res["nnz"], "checks", res["collision_checks"],
       "ms_graph", res["ms_graph"], "ms_sweep", res["ms_sweep"], "ms_host", res["ms_host_loop"], "wall", dt)
 print({k: ctx.timing(k) for k in ("di_count", "di_fill", "di_sweep")}, ctx.stat("pairs_tested"), ctx.stat("survivors"))
+# steady state: count + fill + sweep repeated (buffers already allocated and touched)
+import numpy as np, ctypes as C
+colptr = np.empty(n + 1, dtype=np.int64); nnz = C.c_int64()
+for i in range(3):
+    ctx.timing_reset()
+    t0 = time.time()
+    ctx._chk(ctx._L.mpfmt_di_graph_count(ctx._h, float(w.rho), float(w.r), colptr.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nnz)))
+    ctx.nnz = nnz.value
+    ctx.di_graph_edges_free()
+    print("repeat", i, {k: round(ctx.timing(k)[0], 2) for k in ("di_count", "di_fill", "di_sweep")}, "wall %.1f ms" % ((time.time() - t0) * 1e3), flush=True)
