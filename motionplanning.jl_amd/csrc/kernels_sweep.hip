@@ -356,7 +356,7 @@ template <int D>
 struct sweep_hdr { int64_t cpb, cpe; double w[D]; };        // lane = column of the task: entry range, state
 
 template <int D, int SWEEP_TC>
-__global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 1)) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
+__global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 2)) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
                                                                const int32_t* __restrict__ rowval, int64_t N, double rpad,
                                                                const double* __restrict__ boxes, int M, int chunk,
                                                                mpfmt_ss ss, unsigned long long* __restrict__ mask,
@@ -572,10 +572,21 @@ __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 1)) void k_graph_sweep
                 // queue the pending exact tests (the entry counts as free until a pass says otherwise)
                 const uint32_t eoff = (uint32_t)(e0 + lane - (R0.hs ? lane_i64(H1.cpb, R0.c) : lane_i64(H0.cpb, R0.c)));
                 hs_q = R0.hs;
-                push(fr && p0 >= 0, v, eoff, ((uint32_t)R0.c << 16) | (uint32_t)max(p0, 0));
-                if (__ballot(fr && p1 >= 0)) {
-                    if (qcount + 64 <= SWEEP_QCAP) push(fr && p1 >= 0, v, eoff, ((uint32_t)R0.c << 16) | (uint32_t)max(p1, 0));
-                    else if (fr && p1 >= 0) fr = narrow_free_sl<D>(v, w, load_box_T<D>(sboxT, p1));   // no room: in place
+                if constexpr (D <= 8) {
+                    push(fr && p0 >= 0, v, eoff, ((uint32_t)R0.c << 16) | (uint32_t)max(p0, 0));
+                    if (__ballot(fr && p1 >= 0)) {
+                        if (qcount + 64 <= SWEEP_QCAP) push(fr && p1 >= 0, v, eoff, ((uint32_t)R0.c << 16) | (uint32_t)max(p1, 0));
+                        else if (fr && p1 >= 0) fr = narrow_free_sl<D>(v, w, load_box_T<D>(sboxT, p1));   // no room: in place
+                    }
+                } else {
+                    // d > 8: the per-wave queue would cost (d+1) KB of LDS per wavefront and halve the residency of a kernel
+                    // that already needs the whole register file; the exact tests run in place
+                    if (__ballot(fr && p0 >= 0)) {
+                        if (fr && p0 >= 0) fr = narrow_free_sl<D>(v, w, load_box_T<D>(sboxT, p0));
+                        if (__ballot(fr && p1 >= 0)) {
+                            if (fr && p1 >= 0) fr = narrow_free_sl<D>(v, w, load_box_T<D>(sboxT, p1));
+                        }
+                    }
                 }
                 const unsigned long long bits = __ballot(fr);
                 const int sh = (int)(e0 & 63);
@@ -867,7 +878,7 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
         const int waves = SWEEP_THREADS / 64;
         const int chunk = box_chunk(ctx->M, d, true);
         // transposed (SoA) boxes + one narrow-phase queue per wave
-        const size_t lds = (size_t)SWEEP_CHUNK * 2 * d * sizeof(double) + (size_t)waves * (d + 1) * SWEEP_QCAP * sizeof(double);
+        const size_t lds = (size_t)SWEEP_CHUNK * 2 * d * sizeof(double) + (d <= 8 ? (size_t)waves * (d + 1) * SWEEP_QCAP * sizeof(double) : 0);
         const double rpad = ctx->graph_r * (1.0 + 1e-9) + 1e-300;
         // persistent workgroups (one resident set): boxes are staged once per workgroup, tasks of SWEEP_TC columns
         // are claimed from a counter per obstacle chunk
