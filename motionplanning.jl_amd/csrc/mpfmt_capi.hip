@@ -923,7 +923,7 @@ int32_t mpfmt_di_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64
 // entry (row -> column motion free; segment tests the reference would have counted), F the checkpts bitmap (may be NULL).
 extern "C++" void mpfmt_directed_fmt_recursion(int64_t N, const int64_t* colptr_, const int32_t* rowval_, const double* nzval_, const uint64_t* efree_,
                                   const uint8_t* nseg_, const uint64_t* F_, int64_t init_idx, const std::function<bool(int64_t)>& goal_hit,
-                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
+                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res, const mpfmt_csr_view* pre)
 {
     const int64_t nnz = colptr_[N];
     struct view64 { const int64_t* p; int64_t operator[](int64_t i) const { return p[i]; } };
@@ -933,15 +933,26 @@ extern "C++" void mpfmt_directed_fmt_recursion(int64_t N, const int64_t* colptr_
     const view64 colptr{colptr_}; const view32 rowval{rowval_}; const viewd nzval{nzval_}; const view8 nseg{nseg_};
     const bool checkpts = F_ != nullptr;
     auto bitp = [](const uint64_t* m, int64_t i) { return (m[i >> 6] >> (i & 63)) & 1ull; };
-    // forward sets: CSR of the cost matrix (DSF = Dmat', linearquadratic.jl:73), rows ascending in target index
-    std::vector<int64_t> rowptr(N + 1, 0), cur(N);
-    std::vector<int32_t> colidx((size_t)std::max<int64_t>(nnz, 1));
-    std::vector<int64_t> centry((size_t)std::max<int64_t>(nnz, 1));        // CSR entry -> its CSC entry (cost, masks)
-    for (int64_t e = 0; e < nnz; ++e) rowptr[rowval[e] + 1]++;
-    for (int64_t i = 0; i < N; ++i) rowptr[i + 1] += rowptr[i];
-    for (int64_t i = 0; i < N; ++i) cur[i] = rowptr[i];
-    for (int64_t j = 0; j < N; ++j)
-        for (int64_t e = colptr[j]; e < colptr[j + 1]; ++e) { const int64_t a = cur[rowval[e]]++; colidx[a] = (int32_t)j; centry[a] = e; }
+    // forward sets: CSR of the cost matrix (DSF = Dmat', linearquadratic.jl:73), rows ascending in target index -- taken from
+    // the device transpose when the caller has one (mpfmt_csc_transpose_device), else built here
+    std::vector<int64_t> rowptr_own, centry_own;
+    std::vector<int32_t> colidx_own;
+    const int64_t* rowptr;
+    const int32_t* colidx;
+    const uint32_t* centry32 = nullptr;
+    if (pre) {
+        rowptr = pre->rowptr; colidx = pre->colidx; centry32 = pre->centry;
+    } else {
+        rowptr_own.assign((size_t)N + 1, 0); colidx_own.resize((size_t)std::max<int64_t>(nnz, 1)); centry_own.resize((size_t)std::max<int64_t>(nnz, 1));
+        std::vector<int64_t> cur((size_t)N);
+        for (int64_t e = 0; e < nnz; ++e) rowptr_own[rowval[e] + 1]++;
+        for (int64_t i = 0; i < N; ++i) rowptr_own[i + 1] += rowptr_own[i];
+        for (int64_t i = 0; i < N; ++i) cur[i] = rowptr_own[i];
+        for (int64_t j = 0; j < N; ++j)
+            for (int64_t e = colptr[j]; e < colptr[j + 1]; ++e) { const int64_t a = cur[rowval[e]]++; colidx_own[a] = (int32_t)j; centry_own[a] = e; }
+        rowptr = rowptr_own.data(); colidx = colidx_own.data();
+    }
+    auto centry_at = [&](int64_t a) -> int64_t { return centry32 ? (int64_t)centry32[a] : centry_own[a]; };
     // The recursion of fmt.jl:43-90.  DI neighbourhoods are large (hundreds of entries) and arcs are often blocked, so a
     // sample can be examined by many expanding neighbours; rescanning nearB(x) & H each time is what the reference does
     // and is O(N deg^2).  Here the argmin over the OPEN backward neighbours is maintained instead: when y opens it
@@ -960,7 +971,7 @@ extern "C++" void mpfmt_directed_fmt_recursion(int64_t N, const int64_t* colptr_
             const int64_t x = colidx[a];
             if (!Wm[x] || by[x] == -2) continue;
             if (by[x] >= 0 && !Hm[by[x]]) { by[x] = -2; continue; }           // its best has closed: rescan when examined
-            const int64_t e = centry[a];
+            const int64_t e = centry_at(a);
             const double c = cy + nzval[e];
             if (by[x] < 0 || c < bc[x] || (c == bc[x] && y < by[x])) { by[x] = y; bc[x] = c; be[x] = e; }
         }
@@ -1080,8 +1091,12 @@ int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx,
         }
         return is_goal_pt(v, m, goal_kind, goal_params);           // workspace goals act on C*v = first m coordinates
     };
+    mpfmt_csr_host csr;
+    mpfmt_csr_view csr_view;
+    const mpfmt_csr_view* pre_ptr = nullptr;
+    if (mpfmt_csc_transpose_device(ctx, &csr) == MPFMT_OK) { csr_view = {csr.rowptr.data(), csr.colidx.data(), csr.centry.data()}; pre_ptr = &csr_view; }
     mpfmt_directed_fmt_recursion(N, colptr.data(), rowval.data(), nzval.data(), efree.data(), nseg.data(), checkpts ? F.data() : nullptr,
-                                 init_idx, goal_hit, A, C, path, res);
+                                 init_idx, goal_hit, A, C, path, res, pre_ptr);
     auto t5 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
@@ -1230,8 +1245,12 @@ int32_t mpfmt_dubins_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, d
         if (goal_kind == MPFMT_GOAL_POINT) return v[0] == goal_params[0] && v[1] == goal_params[1] && v[2] == goal_params[2];
         return is_goal_pt(v, 2, goal_kind, goal_params);                       // workspace goals act on (x, y)
     };
+    mpfmt_csr_host csr;
+    mpfmt_csr_view csr_view;
+    const mpfmt_csr_view* pre_ptr = nullptr;
+    if (mpfmt_csc_transpose_device(ctx, &csr) == MPFMT_OK) { csr_view = {csr.rowptr.data(), csr.colidx.data(), csr.centry.data()}; pre_ptr = &csr_view; }
     mpfmt_directed_fmt_recursion(N, colptr.data(), rowval.data(), nzval.data(), efree.data(), nseg.data(), checkpts ? F.data() : nullptr,
-                                 init_idx, goal_hit, A, C, path, res);
+                                 init_idx, goal_hit, A, C, path, res, pre_ptr);
     auto t5 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();

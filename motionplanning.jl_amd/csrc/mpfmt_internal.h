@@ -201,9 +201,15 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx);
 
 // kernels_di.hip ----------------------------------------------------------------------------------
 #include <functional>
+#include <vector>
+// forward sets of a directed cost graph (CSR view of the CSC held in the ctx): rowptr[N+1], colidx[nnz] (target of each
+// entry, ascending inside a row), centry[nnz] (the CSC entry it came from)
+struct mpfmt_csr_view { const int64_t* rowptr; const int32_t* colidx; const uint32_t* centry; };
+struct mpfmt_csr_host { std::vector<int64_t> rowptr; std::vector<int32_t> colidx; std::vector<uint32_t> centry; };
+int32_t mpfmt_csc_transpose_device(mpfmt_ctx* ctx, mpfmt_csr_host* out);      // kernels_di.hip; needs nnz < 2^32
 void mpfmt_directed_fmt_recursion(int64_t N, const int64_t* colptr, const int32_t* rowval, const double* nzval, const uint64_t* efree,
                                   const uint8_t* nseg, const uint64_t* F, int64_t init_idx, const std::function<bool(int64_t)>& goal_hit,
-                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
+                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res, const mpfmt_csr_view* pre);
 int32_t mpfmt_dubins_build(mpfmt_ctx* ctx, double rt, double sp, double r);
 int32_t mpfmt_dubins_sweep(mpfmt_ctx* ctx);
 int32_t mpfmt_dubins_steer_batch(mpfmt_ctx* ctx, const double* d_X0, const double* d_X1, int64_t n, double rt, double sp, double* d_cost, double* d_ctrl);
