@@ -223,7 +223,7 @@ class Context:
         lohi = np.ascontiguousarray(lohi, dtype=np.float64)
         if lohi.size == 0:
             if dw is None:
-                dw = self.d
+                dw = lohi.shape[2] if (lohi.ndim == 3 and lohi.shape[2] > 0) else (len(ss_lo) if ss_lo is not None else self.d)
             lohi = np.zeros((0, 2, dw))
         if lohi.ndim != 3 or lohi.shape[1] != 2:
             raise ValueError("lohi must be (M, 2, dw)")
