@@ -179,6 +179,27 @@ int32_t mpfmt_dubins_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, i
 int32_t mpfmt_dubins_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
                              int32_t goal_kind, const double* goal_params, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
+/* ---- Reeds-Shepp car: ReedsSheppMetricSpace(r_turn, s, lo, hi) of src/statespaces/simplecars.jl:29-34 --
+ *      the car that may reverse; a symmetric (chopped) metric, so forward and backward neighbour sets coincide
+ *      (nearneighbors.jl:200-203).  Same world set-up as the Dubins car above.
+ *      reedsshepp_graph_count/fill : column v = { w : |xy_w - xy_v| <= r and reedsshepp(v, w) <= r } (simplecars.jl:266-364
+ *             with the word families :367-553), rows ascending 1-based, nzval = reedsshepp(v, w) -- evaluated in that
+ *             argument order: the two directions can differ in the last bits, and the reference's inball(v) holds d(v, w).
+ *      reedsshepp_graph_edges_free : entry e (row w of column v): is_free_motion(V[w], V[v], CC, SS) -- the motion
+ *             fmtstar! tests when it connects v to the open parent w (fmt.jl:75) -- over the waypoints of
+ *             steering_control(V[w], V[v]) (:68, :70-82); nseg[e] as above.
+ *      reedsshepp_steer : batch steer; controls[i][5][3] = (duration, speed, signed curvature), segments >= nsegs[i]
+ *             are zero (nsegs may be NULL).
+ *      reedsshepp_fmtstar : fmtstar! in this space (the symmetric recursion of fmt.jl:36-100); workspace goals act on
+ *             (x, y), MPFMT_GOAL_POINT takes a whole state (3 doubles). */
+int32_t mpfmt_reedsshepp_graph_count(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz);
+int32_t mpfmt_reedsshepp_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval);
+int32_t mpfmt_reedsshepp_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg);
+int32_t mpfmt_reedsshepp_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, double turn_radius, double speed,
+                               double* cost, double* controls, int32_t* nsegs);
+int32_t mpfmt_reedsshepp_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+                                 int32_t goal_kind, const double* goal_params, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
+
 /* ---- 2-D SAT world: PointRobot2D(Compound2D(parts)) of src/collisioncheckers/robots2D.jl:12-14 and
  *      SAT2D.jl -- parts are Circle(c, r) (:14-28) and convex Polygon(points) (:32-58; Box2D = 4-point polygon, :59-62).
  *      Switches the ctx's collision checker: afterwards mpfmt_points_free / _states_free = is_free_state (point vs

@@ -66,6 +66,13 @@ SYMBOLS = [
     ("mpfmt_dubins_steer", C.c_int32, [C.c_void_p, c_d_p, c_d_p, C.c_int64, C.c_double, C.c_double, c_d_p, c_d_p]),
     ("mpfmt_dubins_fmtstar", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
                                          c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
+    ("mpfmt_reedsshepp_graph_count", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, c_i64_p, c_i64_p]),
+    ("mpfmt_reedsshepp_graph_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p]),
+    ("mpfmt_reedsshepp_graph_edges_free", C.c_int32, [C.c_void_p, c_u64_p, c_u8_p]),
+    ("mpfmt_reedsshepp_steer", C.c_int32, [C.c_void_p, c_d_p, c_d_p, C.c_int64, C.c_double, C.c_double, c_d_p, c_d_p,
+                                           C.POINTER(C.c_int32)]),
+    ("mpfmt_reedsshepp_fmtstar", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
+                                             c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
     ("mpfmt_upload_shapes2d", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_d_p, c_d_p, c_d_p]),
     ("mpfmt_graph_import", C.c_int32, [C.c_void_p, C.c_double, c_i64_p, c_i64_p, c_d_p]),
     ("mpfmt_sample_free", C.c_int32, [C.c_void_p, C.c_uint64, C.c_int64, c_d_p, C.c_int32, c_d_p, C.c_int32, c_d_p, c_i64_p]),
@@ -351,24 +358,43 @@ class Context:
         self._chk(self._L.mpfmt_mc_edges_collision(self._h, _ip(src), _ip(dst), len(src), float(sigma), int(rollouts), int(seed), _ip(hits)))
         return hits[:len(src)]
 
-    # ---- Dubins car -------------------------------------------------------------------------------
-    def dubins_graph(self, turn_radius, speed, r):
-        """Chopped backward sets of the Dubins quasi-metric, CSC 1-based: (colptr, rowval, nzval)."""
+    # ---- Dubins and Reeds-Shepp cars --------------------------------------------------------------
+    def _car_graph(self, car, turn_radius, speed, r):
         colptr = np.empty(self.N + 1, dtype=np.int64)
         nnz = C.c_int64()
-        self._chk(self._L.mpfmt_dubins_graph_count(self._h, float(turn_radius), float(speed), float(r), _ip(colptr), C.byref(nnz)))
+        self._chk(getattr(self._L, f"mpfmt_{car}_graph_count")(self._h, float(turn_radius), float(speed), float(r), _ip(colptr), C.byref(nnz)))
         self.nnz = n = nnz.value
         rowval = np.empty(max(n, 1), dtype=np.int64)
         nzval = np.empty(max(n, 1), dtype=np.float64)
-        self._chk(self._L.mpfmt_dubins_graph_fill(self._h, _ip(rowval), _dp(nzval)))
+        self._chk(getattr(self._L, f"mpfmt_{car}_graph_fill")(self._h, _ip(rowval), _dp(nzval)))
         return colptr, rowval[:n], nzval[:n]
 
-    def dubins_graph_edges_free(self):
+    def _car_graph_edges_free(self, car):
         n = self.nnz
         mask = np.zeros(max(nwords(n), 1), dtype=np.uint64)
         nseg = np.zeros(max(n, 1), dtype=np.uint8)
-        self._chk(self._L.mpfmt_dubins_graph_edges_free(self._h, _up(mask), nseg.ctypes.data_as(c_u8_p)))
+        self._chk(getattr(self._L, f"mpfmt_{car}_graph_edges_free")(self._h, _up(mask), nseg.ctypes.data_as(c_u8_p)))
         return mask[:nwords(n)], nseg[:n]
+
+    def _car_fmtstar(self, car, turn_radius, speed, r, goal_kind, goal_params, init_idx, checkpts):
+        g = np.ascontiguousarray(goal_params, dtype=np.float64)
+        A = np.empty(max(self.N, 1), dtype=np.int64)
+        Cc = np.empty(max(self.N, 1), dtype=np.float64)
+        path = np.empty(max(self.N, 1), dtype=np.int64)
+        res = FmtResult()
+        self._chk(getattr(self._L, f"mpfmt_{car}_fmtstar")(self._h, float(turn_radius), float(speed), float(r), int(init_idx),
+                                                           int(bool(checkpts)), int(goal_kind), _dp(g), _ip(A), _dp(Cc), _ip(path),
+                                                           C.byref(res)))
+        return dict(status=int(res.status), cost=float(res.cost), z=int(res.z), collision_checks=int(res.collision_checks),
+                    nnz=int(res.nnz), ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
+                    A=A[:self.N], C=Cc[:self.N], path=path[:res.path_len].copy())
+
+    def dubins_graph(self, turn_radius, speed, r):
+        """Chopped backward sets of the Dubins quasi-metric, CSC 1-based: (colptr, rowval, nzval)."""
+        return self._car_graph("dubins", turn_radius, speed, r)
+
+    def dubins_graph_edges_free(self):
+        return self._car_graph_edges_free("dubins")
 
     def dubins_steer(self, X0, X1, turn_radius, speed=1.0):
         X0 = np.ascontiguousarray(X0, dtype=np.float64); X1 = np.ascontiguousarray(X1, dtype=np.float64)
@@ -378,16 +404,26 @@ class Context:
         return cost[:n], ctrl[:n]
 
     def dubins_fmtstar(self, turn_radius, speed, r, goal_kind, goal_params, init_idx=1, checkpts=True):
-        g = np.ascontiguousarray(goal_params, dtype=np.float64)
-        A = np.empty(max(self.N, 1), dtype=np.int64)
-        Cc = np.empty(max(self.N, 1), dtype=np.float64)
-        path = np.empty(max(self.N, 1), dtype=np.int64)
-        res = FmtResult()
-        self._chk(self._L.mpfmt_dubins_fmtstar(self._h, float(turn_radius), float(speed), float(r), int(init_idx), int(bool(checkpts)),
-                                               int(goal_kind), _dp(g), _ip(A), _dp(Cc), _ip(path), C.byref(res)))
-        return dict(status=int(res.status), cost=float(res.cost), z=int(res.z), collision_checks=int(res.collision_checks),
-                    nnz=int(res.nnz), ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
-                    A=A[:self.N], C=Cc[:self.N], path=path[:res.path_len].copy())
+        return self._car_fmtstar("dubins", turn_radius, speed, r, goal_kind, goal_params, init_idx, checkpts)
+
+    def reedsshepp_graph(self, turn_radius, speed, r):
+        """Chopped Reeds-Shepp neighbourhoods, CSC 1-based: column v = rows w with nzval = reedsshepp(v, w)."""
+        return self._car_graph("reedsshepp", turn_radius, speed, r)
+
+    def reedsshepp_graph_edges_free(self):
+        return self._car_graph_edges_free("reedsshepp")
+
+    def reedsshepp_steer(self, X0, X1, turn_radius, speed=1.0):
+        """(cost, controls (n,5,3), nsegs)."""
+        X0 = np.ascontiguousarray(X0, dtype=np.float64); X1 = np.ascontiguousarray(X1, dtype=np.float64)
+        n = len(X0)
+        cost = np.empty(max(n, 1)); ctrl = np.empty((max(n, 1), 5, 3)); nsegs = np.zeros(max(n, 1), dtype=np.int32)
+        self._chk(self._L.mpfmt_reedsshepp_steer(self._h, _dp(X0), _dp(X1), n, float(turn_radius), float(speed), _dp(cost), _dp(ctrl),
+                                                 nsegs.ctypes.data_as(C.POINTER(C.c_int32))))
+        return cost[:n], ctrl[:n], nsegs[:n]
+
+    def reedsshepp_fmtstar(self, turn_radius, speed, r, goal_kind, goal_params, init_idx=1, checkpts=True):
+        return self._car_fmtstar("reedsshepp", turn_radius, speed, r, goal_kind, goal_params, init_idx, checkpts)
 
     def graph_import(self, r, colptr, rowval, nzval):
         """Install an exported graph (1-based CSC as returned by rdisc_graph) for the uploaded samples."""

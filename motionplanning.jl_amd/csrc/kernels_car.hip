@@ -115,6 +115,147 @@ __host__ __device__ __forceinline__ void car_propagate(const double* v, const ca
     out[2] = mod2pif(v[2] + ang);
 }
 
+// ---- Reeds-Shepp (simplecars.jl:228-524): nine word families tried on the target and its time-flipped / reflected /
+// backwards images in the reference's order; negative segment lengths are reverse gear -----------------------------------------
+#define CAR_PI 3.141592653589793
+struct rs_best { double c; int l, post; car_step p[5]; };
+__host__ __device__ __forceinline__ void rs_R(double x, double y, double& r, double& th) { r = sqrt(x * x + y * y); th = atan2(y, x); }
+__host__ __device__ __forceinline__ double rs_M(double t) { const double m = mod2pif(t); return m > CAR_PI ? m - CAR_TWOPI : m; }
+__host__ __device__ inline double rs_Tau(double u, double v, double E, double N)
+{
+    const double delta = rs_M(u - v);
+    const double A = sin(u) - sin(delta);
+    const double B = cos(u) - cos(delta) - 1;
+    double r, th;
+    rs_R(E * A + N * B, N * A - E * B, r, th);
+    const double t = 2 * cos(delta) - 2 * cos(v) - 2 * cos(u) + 3;
+    return t < 0 ? rs_M(th + CAR_PI) : rs_M(th);
+}
+__host__ __device__ inline double rs_Omega(double u, double v, double E, double N, double t) { return rs_M(rs_Tau(u, v, E, N) - u + v - t); }
+__host__ __device__ __forceinline__ void rs_accept(rs_best& b, double cnew, int l, int post, car_step a0, car_step a1, car_step a2,
+                                                   car_step a3, car_step a4)
+{
+    if (!(b.c <= cnew)) { b.p[0] = a0; b.p[1] = a1; b.p[2] = a2; b.p[3] = a3; b.p[4] = a4; b.c = cnew; b.l = l; b.post = post; }
+}
+// family f (0..8) on the transformed target T
+__host__ __device__ inline void rs_family(int f, const double* T, rs_best& b, int post)
+{
+    const car_step z = car_seg(0, 0.0);
+    const double st = sin(T[2]), ct = cos(T[2]);
+    if (f == 0) {                                                         // (8.1) L+ S+ L+
+        double r, th; rs_R(T[0] - st, T[1] - 1 + ct, r, th);
+        const double u = r, t = mod2pif(th), v = mod2pif(T[2] - t);
+        rs_accept(b, t + u + v, 3, post, car_seg(1, t), car_seg(0, u), car_seg(1, v), z, z);
+    } else if (f == 1) {                                                  // (8.2) L+ S+ R+
+        double r, th, r1, th1; rs_R(T[0] + st, T[1] - 1 - ct, r, th);
+        if (r * r < 4) return;
+        const double u = sqrt(r * r - 4);
+        rs_R(u, 2.0, r1, th1);
+        const double t = mod2pif(th + th1), v = mod2pif(t - T[2]);
+        rs_accept(b, t + u + v, 3, post, car_seg(1, t), car_seg(0, u), car_seg(-1, v), z, z);
+    } else if (f == 2 || f == 3) {                                        // (8.3) L+ R- L+   (8.4) L+ R- L-
+        const double E = T[0] - st, N = T[1] + ct - 1;
+        if (E * E + N * N > 16) return;
+        double r, th; rs_R(E, N, r, th);
+        double u = acos(1 - r * r / 8);
+        const double t = mod2pif(th - u / 2 + CAR_PI);
+        double v = mod2pif(CAR_PI - u / 2 - th + T[2]);
+        if (f == 3) v = v - CAR_TWOPI;
+        u = -u;
+        rs_accept(b, f == 2 ? t - u + v : t - u - v, 3, post, car_seg(1, t), car_seg(-1, u), car_seg(1, v), z, z);
+    } else if (f == 4) {                                                  // (8.7) L+ R+u L-u R-
+        const double E = T[0] + st, N = T[1] - ct - 1;
+        const double p = (2 + sqrt(E * E + N * N)) / 4;
+        if (p < 0 || p > 1) return;
+        const double u = acos(p);
+        const double t = mod2pif(rs_Tau(u, -u, E, N)), v = mod2pif(rs_Omega(u, -u, E, N, T[2])) - CAR_TWOPI;
+        rs_accept(b, t + 2 * u - v, 4, post, car_seg(1, t), car_seg(-1, u), car_seg(1, -u), car_seg(-1, v), z);
+    } else if (f == 5) {                                                  // (8.8) L+ R-u L-u R+
+        const double E = T[0] + st, N = T[1] - ct - 1;
+        const double p = (20 - E * E - N * N) / 16;
+        if (p < 0 || p > 1) return;
+        const double u = -acos(p);
+        const double t = mod2pif(rs_Tau(u, u, E, N)), v = mod2pif(rs_Omega(u, u, E, N, T[2]));
+        rs_accept(b, t - 2 * u + v, 4, post, car_seg(1, t), car_seg(-1, u), car_seg(1, u), car_seg(-1, v), z);
+    } else if (f == 6) {                                                  // (8.9) L+ R- S- L-
+        const double E = T[0] - st, N = T[1] + ct - 1;
+        double D, be; rs_R(E, N, D, be);
+        if (D < 2) return;
+        const double ga = acos(2 / D), F = sqrt(D * D / 4 - 1);
+        const double t = mod2pif(CAR_PI + be - ga), u = 2 - 2 * F;
+        if (u > 0) return;
+        const double v = mod2pif(-3 * CAR_PI / 2 + ga + T[2] - be) - CAR_TWOPI;
+        rs_accept(b, t + CAR_PI / 2 - u - v, 4, post, car_seg(1, t), car_seg(-1, -CAR_PI / 2), car_seg(0, u), car_seg(1, v), z);
+    } else if (f == 7) {                                                  // (8.10) L+ R- S- R-
+        const double E = T[0] + st, N = T[1] - ct - 1;
+        double D, be; rs_R(E, N, D, be);
+        if (D < 2) return;
+        const double t = mod2pif(be + CAR_PI / 2), u = 2 - D;
+        if (u > 0) return;
+        const double v = mod2pif(-CAR_PI - T[2] + be) - CAR_TWOPI;
+        rs_accept(b, t + CAR_PI / 2 - u - v, 4, post, car_seg(1, t), car_seg(-1, -CAR_PI / 2), car_seg(0, u), car_seg(-1, v), z);
+    } else {                                                              // (8.11) L+ R- S- L- R+
+        const double E = T[0] + st, N = T[1] - ct - 1;
+        double D, be; rs_R(E, N, D, be);
+        if (D < 2) return;
+        const double ga = acos(2 / D), F = sqrt(D * D / 4 - 1);
+        const double t = mod2pif(CAR_PI + be - ga), u = 4 - 2 * F;
+        if (u > 0) return;
+        const double v = mod2pif(CAR_PI + be - T[2] - ga);
+        rs_accept(b, t + CAR_PI - u + v, 5, post, car_seg(1, t), car_seg(-1, -CAR_PI / 2), car_seg(0, u), car_seg(1, -CAR_PI / 2), car_seg(-1, v));
+    }
+}
+
+// reedsshepp(s1, s2, r, s) (:265-363): cost, controls path[0..L)
+__host__ __device__ inline double rs_steer(const double* s1, const double* s2, double r, double s, car_step* path, int& L)
+{
+    const double dx = (s2[0] - s1[0]) / r, dy = (s2[1] - s1[1]) / r;
+    const double ct = cos(s1[2]), st = sin(s1[2]);
+    double T[8][3];                 // images in the reference's POST numbering: 0 id, 1 T, 2 R, 3 B, 4 R_T, 5 B_T, 6 B_R, 7 B_R_T
+    T[0][0] = dx * ct + dy * st; T[0][1] = -dx * st + dy * ct; T[0][2] = mod2pif(s2[2] - s1[2]);
+    T[1][0] = -T[0][0]; T[1][1] = T[0][1]; T[1][2] = -T[0][2];                       // timeflip
+    T[2][0] = T[0][0]; T[2][1] = -T[0][1]; T[2][2] = -T[0][2];                       // reflect
+    T[4][0] = T[1][0]; T[4][1] = -T[1][1]; T[4][2] = -T[1][2];                       // reflect(timeflip)
+    T[3][0] = T[0][0] * cos(T[0][2]) + T[0][1] * sin(T[0][2]);                       // backwards (:247)
+    T[3][1] = T[0][0] * sin(T[0][2]) - T[0][1] * cos(T[0][2]);
+    T[3][2] = T[0][2];
+    T[5][0] = -T[3][0]; T[5][1] = T[3][1]; T[5][2] = -T[3][2];
+    T[6][0] = T[3][0]; T[6][1] = -T[3][1]; T[6][2] = -T[3][2];
+    T[7][0] = T[5][0]; T[7][1] = -T[5][1]; T[7][2] = -T[5][2];
+    rs_best b;
+    b.c = INFINITY; b.l = 0; b.post = 0;
+    for (int q = 0; q < 5; ++q) b.p[q] = car_seg(0, 0.0);
+    const int order8[8] = {0, 1, 2, 4, 3, 5, 6, 7};
+    // images tried per family: 4 (id, T, R, R_T), 2 for (8.3) (id, R), 8 for (8.4), (8.9), (8.10)
+    const int count[9] = {4, 4, 2, 8, 4, 4, 8, 8, 4};
+    for (int f = 0; f < 9; ++f)
+        for (int q = 0; q < count[f]; ++q) {
+            const int img = (f == 2) ? (q == 0 ? 0 : 2) : order8[q];
+            rs_family(f, T[img], b, img);
+        }
+    for (int q = 0; q < b.l; ++q) {
+        b.p[q].t = b.p[q].t * r; b.p[q].k = b.p[q].k / r;
+        b.p[q].t = b.p[q].t / s; b.p[q].s = b.p[q].s * s;
+    }
+    const bool tf = (b.post == 1 || b.post == 4 || b.post == 5 || b.post == 7);     // timeflip!: negate speed
+    const bool rf = (b.post == 2 || b.post == 4 || b.post == 6 || b.post == 7);     // reflect!: negate curvature
+    const bool bw = (b.post == 3 || b.post == 5 || b.post == 6 || b.post == 7);     // backwards!: reverse the order
+    for (int q = 0; q < b.l; ++q) { if (tf) b.p[q].s = -b.p[q].s; if (rf) b.p[q].k = -b.p[q].k; }
+    for (int q = 0; q < 5; ++q) path[q] = (q < b.l) ? (bw ? b.p[b.l - 1 - q] : b.p[q]) : car_seg(0, 0.0);
+    L = b.l;
+    return b.c * r;
+}
+
+// KIND 1 = Dubins (3 segments), 2 = Reeds-Shepp (up to 5)
+template <int KIND>
+__host__ __device__ __forceinline__ double car_steer(const double* s1, const double* s2, double r, double s, car_step* path, int& L)
+{
+    if (KIND == 2) return rs_steer(s1, s2, r, s, path, L);
+    L = 3;
+    path[3] = car_seg(0, 0.0); path[4] = path[3];
+    return dubins_steer(s1, s2, r, s, path);
+}
+
 // ---- 2-D box predicates on (x, y) (boxesND.jl:44-56 at d = 2, straight line) ---------------------------------------------
 __device__ __forceinline__ bool seg_free_boxes2(double vx, double vy, double wx, double wy, const double* __restrict__ boxes, int M)
 {
@@ -144,11 +285,13 @@ __device__ __forceinline__ bool in_ss3(const double* p, const mpfmt_ss& ss)
 }
 
 // is_free_motion(v, w, CC, SS) over the reference's collision waypoints; *nseg = segment tests made (CC.count)
+template <int KIND>
 __device__ inline bool car_motion_free(const double* v0, const double* w, double rt, double sp, const double* __restrict__ boxes, int M,
                                        const mpfmt_ss& ss, int* nseg)
 {
-    car_step path[3];
-    dubins_steer(v0, w, rt, sp, path);
+    car_step path[5];
+    int L;
+    car_steer<KIND>(v0, w, rt, sp, path, L);
     const double thres = 3.141592653589793 / 12;
     double v[3] = {v0[0], v0[1], v0[2]};
     double prev[3] = {0, 0, 0};
@@ -161,7 +304,7 @@ __device__ inline bool car_motion_free(const double* v0, const double* w, double
         }
         prev[0] = p[0]; prev[1] = p[1]; prev[2] = p[2]; have_prev = true;
     };
-    for (int q = 0; q < 3 && ok; ++q) {
+    for (int q = 0; q < L && ok; ++q) {
         const car_step u = path[q];
         const double quo = u.t * u.s * u.k / thres;
         const long m = (long)floor(quo);
@@ -188,7 +331,9 @@ __global__ __launch_bounds__(256) void k_car_xy(const double* __restrict__ X, in
     if (i < N) { XY[2 * i] = X[3 * i]; XY[2 * i + 1] = X[3 * i + 1]; }
 }
 
-// lane = candidate entry e of the positions graph (row i, column j): cost(i -> j); keep bit = cost <= r
+// lane = candidate entry e of the positions graph (row i, column j): Dubins: cost(i -> j) (backward set of j); Reeds-Shepp:
+// cost(j -> i) (inball(j), ds = colwise(dist, V[j], V[inds])); keep bit = cost <= r
+template <int KIND>
 __global__ __launch_bounds__(256) void k_car_cost(const double* __restrict__ X, int64_t N, const int64_t* __restrict__ ccolptr,
                                                   const int32_t* __restrict__ crowval, int64_t cnnz, double rt, double sp, double r,
                                                   double* __restrict__ cost, uint64_t* __restrict__ keep)
@@ -200,8 +345,9 @@ __global__ __launch_bounds__(256) void k_car_cost(const double* __restrict__ X, 
         int64_t lo = 0, hi = N;
         while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (ccolptr[mid] <= e) lo = mid; else hi = mid; }
         const int64_t j = lo, i = crowval[e];
-        car_step path[3];
-        const double c = dubins_steer(X + 3 * i, X + 3 * j, rt, sp, path);
+        car_step path[5];
+        int L;
+        const double c = (KIND == 2) ? car_steer<KIND>(X + 3 * j, X + 3 * i, rt, sp, path, L) : car_steer<KIND>(X + 3 * i, X + 3 * j, rt, sp, path, L);
         cost[e] = c;
         k = c <= r;
     }
@@ -252,6 +398,7 @@ __global__ __launch_bounds__(64) void k_car_compact(const int64_t* __restrict__ 
 }
 
 // lane = CSC entry (row y -> column x): bit = is_free_motion(V[y], V[x]), nseg = segment tests the reference would count
+template <int KIND>
 __global__ __launch_bounds__(256) void k_car_sweep(const double* __restrict__ X, int64_t N, const int64_t* __restrict__ colptr,
                                                    const int32_t* __restrict__ rowval, int64_t nnz, double rt, double sp,
                                                    const double* __restrict__ boxes, int M, mpfmt_ss ss, uint64_t* __restrict__ mask,
@@ -265,21 +412,25 @@ __global__ __launch_bounds__(256) void k_car_sweep(const double* __restrict__ X,
         while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (colptr[mid] <= e) lo = mid; else hi = mid; }
         const int64_t x = lo, y = rowval[e];
         int ns = 0;
-        fr = car_motion_free(X + 3 * y, X + 3 * x, rt, sp, boxes, M, ss, &ns);
+        fr = car_motion_free<KIND>(X + 3 * y, X + 3 * x, rt, sp, boxes, M, ss, &ns);
         nseg[e] = (uint8_t)min(ns, 255);
     }
     const unsigned long long bits = __ballot(fr);
     if (lane == 0 && (e - lane) < nnz) mask[(e - lane) >> 6] = bits;
 }
 
+// controls: [n][5][3] = (duration, speed, signed curvature), unused segments zero; nseg[i] = segments used
+template <int KIND>
 __global__ __launch_bounds__(256) void k_car_steer(const double* __restrict__ X0, const double* __restrict__ X1, int64_t n, double rt,
-                                                   double sp, double* __restrict__ cost, double* __restrict__ ctrl)
+                                                   double sp, double* __restrict__ cost, double* __restrict__ ctrl, int32_t* __restrict__ nseg)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    car_step path[3];
-    cost[i] = dubins_steer(X0 + 3 * i, X1 + 3 * i, rt, sp, path);
-    for (int q = 0; q < 3; ++q) { ctrl[9 * i + 3 * q] = path[q].t; ctrl[9 * i + 3 * q + 1] = path[q].s; ctrl[9 * i + 3 * q + 2] = path[q].k; }
+    car_step path[5];
+    int L;
+    cost[i] = car_steer<KIND>(X0 + 3 * i, X1 + 3 * i, rt, sp, path, L);
+    for (int q = 0; q < 5; ++q) { ctrl[15 * i + 3 * q] = path[q].t; ctrl[15 * i + 3 * q + 1] = path[q].s; ctrl[15 * i + 3 * q + 2] = path[q].k; }
+    if (nseg) nseg[i] = L;
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
@@ -304,7 +455,7 @@ static int32_t car_scan(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t 
     return MPFMT_OK;
 }
 
-int32_t mpfmt_dubins_build(mpfmt_ctx* ctx, double rt, double sp, double r)
+int32_t mpfmt_car_build(mpfmt_ctx* ctx, int kind, double rt, double sp, double r)
 {
     int32_t rc;
     if ((rc = car_check(ctx, rt, sp, r))) return rc;
@@ -331,8 +482,12 @@ int32_t mpfmt_dubins_build(mpfmt_ctx* ctx, double rt, double sp, double r)
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (size_t)(N + 1)))) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (size_t)(N + 1), ctx->stream));
     if (cnnz > 0) {
-        hipLaunchKernelGGL(k_car_cost, dim3((unsigned)((cnnz + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xo, N, ax->colptr, ax->rowval, cnnz,
-                           rt, sp, r, ctx->valtmp, ctx->car_keep);
+        if (kind == 2)
+            hipLaunchKernelGGL(k_car_cost<2>, dim3((unsigned)((cnnz + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xo, N, ax->colptr, ax->rowval,
+                               cnnz, rt, sp, r, ctx->valtmp, ctx->car_keep);
+        else
+            hipLaunchKernelGGL(k_car_cost<1>, dim3((unsigned)((cnnz + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xo, N, ax->colptr, ax->rowval,
+                               cnnz, rt, sp, r, ctx->valtmp, ctx->car_keep);
         hipLaunchKernelGGL(k_car_degree, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, ax->colptr, ctx->car_keep, N, ctx->deg);
         HIPCHK(ctx, hipGetLastError());
     }
@@ -352,15 +507,15 @@ int32_t mpfmt_dubins_build(mpfmt_ctx* ctx, double rt, double sp, double r)
     ctx->nnz = nnz;
     ctx->pairs_tested = cnnz;
     ctx->car_rt = rt; ctx->car_sp = sp; ctx->di_r = r;
-    ctx->steer_kind = 2;
+    ctx->steer_kind = (kind == 2) ? 3 : 2;
     ctx->di_counted = ctx->di_filled = true; ctx->di_swept = false;
     ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
     return MPFMT_OK;
 }
 
-int32_t mpfmt_dubins_sweep(mpfmt_ctx* ctx)
+int32_t mpfmt_car_sweep(mpfmt_ctx* ctx)
 {
-    if (!(ctx->di_filled && ctx->steer_kind == 2)) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "Dubins sweep before the Dubins graph is built");
+    if (!(ctx->di_filled && (ctx->steer_kind == 2 || ctx->steer_kind == 3))) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car sweep before the car graph is built");
     if (!ctx->have_boxes || ctx->cc_kind != 0 || ctx->dw != 2)
         return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the Dubins sweep needs 2-D boxes (mpfmt_upload_boxes with dw = 2 and the 3 SE2 bounds)");
     if (ctx->ss.has && ctx->ss.d != 3) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "state-space bounds must have 3 dims for SE2 states");
@@ -371,8 +526,12 @@ int32_t mpfmt_dubins_sweep(mpfmt_ctx* ctx)
     mpfmt_time_begin(ctx);
     HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
     if (nnz > 0) {
-        hipLaunchKernelGGL(k_car_sweep, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xo, ctx->N, ctx->colptr, ctx->rowval,
-                           nnz, ctx->car_rt, ctx->car_sp, ctx->boxes, ctx->M, ctx->ss, ctx->graph_free, ctx->di_nseg);
+        if (ctx->steer_kind == 3)
+            hipLaunchKernelGGL(k_car_sweep<2>, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xo, ctx->N, ctx->colptr,
+                               ctx->rowval, nnz, ctx->car_rt, ctx->car_sp, ctx->boxes, ctx->M, ctx->ss, ctx->graph_free, ctx->di_nseg);
+        else
+            hipLaunchKernelGGL(k_car_sweep<1>, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xo, ctx->N, ctx->colptr,
+                               ctx->rowval, nnz, ctx->car_rt, ctx->car_sp, ctx->boxes, ctx->M, ctx->ss, ctx->graph_free, ctx->di_nseg);
         HIPCHK(ctx, hipGetLastError());
     }
     mpfmt_time_end(ctx, "car_sweep");
@@ -380,10 +539,11 @@ int32_t mpfmt_dubins_sweep(mpfmt_ctx* ctx)
     return MPFMT_OK;
 }
 
-int32_t mpfmt_dubins_steer_batch(mpfmt_ctx* ctx, const double* d_X0, const double* d_X1, int64_t n, double rt, double sp, double* d_cost,
-                                 double* d_ctrl)
+int32_t mpfmt_car_steer_batch(mpfmt_ctx* ctx, int kind, const double* d_X0, const double* d_X1, int64_t n, double rt, double sp, double* d_cost,
+                              double* d_ctrl, int32_t* d_nseg)
 {
-    hipLaunchKernelGGL(k_car_steer, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_X0, d_X1, n, rt, sp, d_cost, d_ctrl);
+    if (kind == 2) hipLaunchKernelGGL(k_car_steer<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_X0, d_X1, n, rt, sp, d_cost, d_ctrl, d_nseg);
+    else hipLaunchKernelGGL(k_car_steer<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_X0, d_X1, n, rt, sp, d_cost, d_ctrl, d_nseg);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }

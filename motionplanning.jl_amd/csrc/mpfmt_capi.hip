@@ -674,10 +674,26 @@ inline bool bit(const std::vector<uint64_t>& m, int64_t i) { return (m[i >> 6] >
 //     few open neighbours;
 //   - the candidates x in near(z) & W are collected first, so the adjacency rows of the NEXT candidates can be
 //     prefetched while the current one is scanned (each row is a random ~400-byte read from a GB-sized array).
+// gd = coordinates the goal predicate reads (d for Euclidean spaces; 2 = workspace (x, y) / 3 = whole state for SE2 cars);
+// nseg != NULL: per-entry count of the segment tests the reference would make (car spaces), else one test per edge check
+static int32_t host_fmt_recursion_impl(int64_t N, int32_t d, const double* X, const int64_t* colptr, const int32_t* rowval,
+                                       const double* nzval, const uint64_t* efree, const uint64_t* F, const double* ss_lo,
+                                       const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params, int32_t gd,
+                                       const uint8_t* nseg, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
+
 int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const int64_t* colptr, const int32_t* rowval,
                                  const double* nzval, const uint64_t* efree, const uint64_t* F, const double* ss_lo,
                                  const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params,
                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
+{
+    return host_fmt_recursion_impl(N, d, X, colptr, rowval, nzval, efree, F, ss_lo, ss_hi, init_idx, goal_kind, goal_params, d, nullptr,
+                                   A, C, path, res);
+}
+
+static int32_t host_fmt_recursion_impl(int64_t N, int32_t d, const double* X, const int64_t* colptr, const int32_t* rowval,
+                                       const double* nzval, const uint64_t* efree, const uint64_t* F, const double* ss_lo,
+                                       const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params, int32_t gd,
+                                       const uint8_t* nseg, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
 {
     if (!X || !colptr || !rowval || !nzval || !efree || !goal_params || !A || !C || !path || !res) return MPFMT_ERR_ARG;
     if (N < 1 || d < 1 || d > MPFMT_MAX_DIM || init_idx < 1 || init_idx > N || goal_kind < 0 || goal_kind > 2) return MPFMT_ERR_ARG;
@@ -701,7 +717,7 @@ int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const in
         const char* e = (const char*)(rowval + colptr[x + 1]);
         for (int q = 0; q < 8 && p < e; ++q, p += 64) __builtin_prefetch(p, 0, 1);
     };
-    while (!is_goal_pt(&X[(size_t)z * d], d, goal_kind, goal_params)) {
+    while (!is_goal_pt(&X[(size_t)z * d], gd, goal_kind, goal_params)) {
         Hnew.clear();
         cand.clear();
         for (int64_t a = colptr[z]; a < colptr[z + 1]; ++a) {                 // fmt.jl:70-71
@@ -721,7 +737,9 @@ int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const in
                 if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
             }
             if (y_min < 0) continue;
-            {   // boxesND.jl:26 is only reached when in_state_space(V[y_min]) held (statespaces.jl:155-157)
+            if (nseg) {
+                count += nseg[e_min];
+            } else {   // boxesND.jl:26 is only reached when in_state_space(V[y_min]) held (statespaces.jl:155-157)
                 bool inb = true;
                 if (ss_lo) for (int k = 0; k < d; ++k) inb = inb && (ss_lo[k] <= X[(size_t)y_min * d + k]) && (X[(size_t)y_min * d + k] <= ss_hi[k]);
                 if (inb) ++count;
@@ -748,7 +766,7 @@ int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const in
         rev.push_back(cur + 1);
     }
     for (size_t i = 0; i < rev.size(); ++i) path[i] = rev[rev.size() - 1 - i];
-    res->status = is_goal_pt(&X[(size_t)z * d], d, goal_kind, goal_params) ? 1 : 0;
+    res->status = is_goal_pt(&X[(size_t)z * d], gd, goal_kind, goal_params) ? 1 : 0;
     res->cost = C[z];
     res->z = z + 1;
     res->collision_checks = count;
@@ -1106,14 +1124,14 @@ int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx,
     return MPFMT_OK;
 }
 
-// ---- Dubins car (kernels_car.hip) ------------------------------------------------------------------------------------
+// ---- Dubins and Reeds-Shepp cars (kernels_car.hip) ------------------------------------------------------------------
 
-int32_t mpfmt_dubins_graph_count(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz)
+static int32_t car_graph_count(mpfmt_ctx* ctx, int kind, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz)
 {
     if (!ctx) return MPFMT_ERR_ARG;
     if (!colptr || !nnz) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "colptr / nnz is NULL");
     int32_t rc;
-    if ((rc = mpfmt_dubins_build(ctx, turn_radius, speed, r))) return rc;
+    if ((rc = mpfmt_car_build(ctx, kind, turn_radius, speed, r))) return rc;
     const int64_t n1 = ctx->N + 1;
     void* scr;
     if ((rc = mpfmt_scratch(ctx, sizeof(int64_t) * n1, &scr))) return rc;
@@ -1124,10 +1142,10 @@ int32_t mpfmt_dubins_graph_count(mpfmt_ctx* ctx, double turn_radius, double spee
     return MPFMT_OK;
 }
 
-int32_t mpfmt_dubins_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval)
+static int32_t car_graph_fill(mpfmt_ctx* ctx, int kind, int64_t* rowval, double* nzval)
 {
     if (!ctx) return MPFMT_ERR_ARG;
-    if (!(ctx->di_filled && ctx->steer_kind == 2)) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "dubins_graph_fill before dubins_graph_count");
+    if (!(ctx->di_filled && ctx->steer_kind == kind + 1)) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car graph_fill before graph_count");
     const int64_t nnz = ctx->nnz;
     if (nnz > 0 && (!rowval || !nzval)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "rowval / nzval is NULL");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1143,12 +1161,13 @@ int32_t mpfmt_dubins_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval)
     return MPFMT_OK;
 }
 
-int32_t mpfmt_dubins_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg)
+static int32_t car_graph_edges_free(mpfmt_ctx* ctx, int kind, uint64_t* mask, uint8_t* nseg)
 {
     if (!ctx) return MPFMT_ERR_ARG;
+    if (!(ctx->di_filled && ctx->steer_kind == kind + 1)) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car graph_edges_free before graph_count");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int32_t rc;
-    if ((rc = mpfmt_dubins_sweep(ctx))) return rc;
+    if ((rc = mpfmt_car_sweep(ctx))) return rc;
     const int64_t nnz = ctx->nnz, words = (nnz + 63) / 64;
     if (nnz > 0) {
         if (!mask) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "mask is NULL");
@@ -1159,8 +1178,9 @@ int32_t mpfmt_dubins_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* n
     return MPFMT_OK;
 }
 
-int32_t mpfmt_dubins_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, double turn_radius, double speed,
-                           double* cost, double* controls)
+// controls out: [n][nctl][3]; nctl = 3 (Dubins) or 5 (Reeds-Shepp); nsegs (may be NULL) = segments used per pair
+static int32_t car_steer_pairs(mpfmt_ctx* ctx, int kind, const double* X0, const double* X1, int64_t n, double turn_radius, double speed,
+                               double* cost, double* controls, int32_t* nsegs)
 {
     if (!ctx) return MPFMT_ERR_ARG;
     if (n < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "n < 0");
@@ -1169,28 +1189,35 @@ int32_t mpfmt_dubins_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, i
     if (!(turn_radius > 0.0) || !(speed > 0.0)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "turning radius and speed must be > 0");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DevTmp tmp;
-    double *d0, *d1, *dc, *du;
+    double *d0, *d1, *dc, *du; int32_t* dn;
     int32_t rc;
     HIPCHK(ctx, tmp.get(&d0, sizeof(double) * 3 * n));
     HIPCHK(ctx, tmp.get(&d1, sizeof(double) * 3 * n));
     HIPCHK(ctx, tmp.get(&dc, sizeof(double) * n));
-    HIPCHK(ctx, tmp.get(&du, sizeof(double) * 9 * n));
+    HIPCHK(ctx, tmp.get(&du, sizeof(double) * 15 * n));
+    HIPCHK(ctx, tmp.get(&dn, sizeof(int32_t) * n));
     HIPCHK(ctx, hipMemcpyAsync(d0, X0, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d1, X1, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = mpfmt_dubins_steer_batch(ctx, d0, d1, n, turn_radius, speed, dc, du))) return rc;
+    if ((rc = mpfmt_car_steer_batch(ctx, kind, d0, d1, n, turn_radius, speed, dc, du, dn))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(cost, dc, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
-    if (controls) HIPCHK(ctx, hipMemcpyAsync(controls, du, sizeof(double) * 9 * n, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> u5;
+    if (controls) { u5.resize((size_t)15 * n); HIPCHK(ctx, hipMemcpyAsync(u5.data(), du, sizeof(double) * 15 * n, hipMemcpyDeviceToHost, ctx->stream)); }
+    if (nsegs) HIPCHK(ctx, hipMemcpyAsync(nsegs, dn, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (controls) {
+        const int nctl = (kind == 2) ? 5 : 3;
+        for (int64_t i = 0; i < n; ++i) memcpy(controls + (size_t)i * nctl * 3, u5.data() + (size_t)i * 15, sizeof(double) * nctl * 3);
+    }
     return MPFMT_OK;
 }
 
-int32_t mpfmt_dubins_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
-                             int32_t goal_kind, const double* goal_params, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
+static int32_t car_fmtstar(mpfmt_ctx* ctx, int kind, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+                           int32_t goal_kind, const double* goal_params, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
 {
     if (!ctx) return MPFMT_ERR_ARG;
     if (!A || !C || !path || !res || !goal_params) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "NULL output / goal pointer");
-    if (!ctx->Xo || ctx->d != 3) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "Dubins planning needs SE2 samples (d = 3)");
-    if (!ctx->have_boxes || ctx->cc_kind != 0 || ctx->dw != 2) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "Dubins planning needs 2-D boxes (mpfmt_upload_boxes, dw = 2)");
+    if (!ctx->Xo || ctx->d != 3) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car planning needs SE2 samples (d = 3)");
+    if (!ctx->have_boxes || ctx->cc_kind != 0 || ctx->dw != 2) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car planning needs 2-D boxes (mpfmt_upload_boxes, dw = 2)");
     const int64_t N = ctx->N;
     if (init_idx < 1 || init_idx > N) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "init_idx out of range");
     if (goal_kind < 0 || goal_kind > 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown goal kind %d", goal_kind);
@@ -1220,10 +1247,10 @@ int32_t mpfmt_dubins_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, d
     }
     if (!bit(F, init_idx - 1)) return mpfmt_fail(ctx, MPFMT_ERR_INFEASIBLE, "initial state is infeasible");
     auto t1 = std::chrono::steady_clock::now();
-    if ((rc = mpfmt_dubins_build(ctx, turn_radius, speed, r))) return rc;
+    if ((rc = mpfmt_car_build(ctx, kind, turn_radius, speed, r))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     auto t2 = std::chrono::steady_clock::now();
-    if ((rc = mpfmt_dubins_sweep(ctx))) return rc;
+    if ((rc = mpfmt_car_sweep(ctx))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     auto t3 = std::chrono::steady_clock::now();
     const int64_t nnz = ctx->nnz;
@@ -1240,17 +1267,28 @@ int32_t mpfmt_dubins_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, d
         HIPCHK(ctx, hipMemcpy(nseg.data(), ctx->di_nseg, (size_t)nnz, hipMemcpyDeviceToHost));
     }
     auto t4 = std::chrono::steady_clock::now();
-    auto goal_hit = [&](int64_t z) {
-        const double* v = &X[(size_t)z * 3];
-        if (goal_kind == MPFMT_GOAL_POINT) return v[0] == goal_params[0] && v[1] == goal_params[1] && v[2] == goal_params[2];
-        return is_goal_pt(v, 2, goal_kind, goal_params);                       // workspace goals act on (x, y)
-    };
-    mpfmt_csr_host csr;
-    mpfmt_csr_view csr_view;
-    const mpfmt_csr_view* pre_ptr = nullptr;
-    if (mpfmt_csc_transpose_device(ctx, &csr) == MPFMT_OK) { csr_view = {csr.rowptr.data(), csr.colidx.data(), csr.centry.data()}; pre_ptr = &csr_view; }
-    mpfmt_directed_fmt_recursion(N, colptr.data(), rowval.data(), nzval.data(), efree.data(), nseg.data(), checkpts ? F.data() : nullptr,
-                                 init_idx, goal_hit, A, C, path, res, pre_ptr);
+    if (kind == 2) {
+        // Reeds-Shepp: a (chopped) metric -- forward and backward sets coincide (nearneighbors.jl:200-203): the symmetric
+        // recursion on column = inball; the goal acts on (x, y), POINT = exact state
+        std::vector<double> gp3;
+        const double* gp = goal_params;
+        if ((rc = host_fmt_recursion_impl(N, 3, X.data(), colptr.data(), rowval.data(), nzval.data(), efree.data(),
+                                          checkpts ? F.data() : nullptr, nullptr, nullptr, init_idx, goal_kind, gp, goal_kind == MPFMT_GOAL_POINT ? 3 : 2,
+                                          nseg.data(), A, C, path, res)))
+            return mpfmt_fail(ctx, rc, "host recursion rejected its arguments");
+    } else {
+        auto goal_hit = [&](int64_t z) {
+            const double* v = &X[(size_t)z * 3];
+            if (goal_kind == MPFMT_GOAL_POINT) return v[0] == goal_params[0] && v[1] == goal_params[1] && v[2] == goal_params[2];
+            return is_goal_pt(v, 2, goal_kind, goal_params);                       // workspace goals act on (x, y)
+        };
+        mpfmt_csr_host csr;
+        mpfmt_csr_view csr_view;
+        const mpfmt_csr_view* pre_ptr = nullptr;
+        if (mpfmt_csc_transpose_device(ctx, &csr) == MPFMT_OK) { csr_view = {csr.rowptr.data(), csr.colidx.data(), csr.centry.data()}; pre_ptr = &csr_view; }
+        mpfmt_directed_fmt_recursion(N, colptr.data(), rowval.data(), nzval.data(), efree.data(), nseg.data(), checkpts ? F.data() : nullptr,
+                                     init_idx, goal_hit, A, C, path, res, pre_ptr);
+    }
     auto t5 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
@@ -1259,6 +1297,28 @@ int32_t mpfmt_dubins_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, d
     res->ms_graph = ms(t1, t2); res->ms_sweep = ms(t0, t1) + ms(t2, t3); res->ms_host_loop = ms(t4, t5);
     return MPFMT_OK;
 }
+
+int32_t mpfmt_dubins_graph_count(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz)
+{ return car_graph_count(ctx, 1, turn_radius, speed, r, colptr, nnz); }
+int32_t mpfmt_dubins_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval) { return car_graph_fill(ctx, 1, rowval, nzval); }
+int32_t mpfmt_dubins_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg) { return car_graph_edges_free(ctx, 1, mask, nseg); }
+int32_t mpfmt_dubins_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, double turn_radius, double speed,
+                           double* cost, double* controls)
+{ return car_steer_pairs(ctx, 1, X0, X1, n, turn_radius, speed, cost, controls, nullptr); }
+int32_t mpfmt_dubins_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+                             int32_t goal_kind, const double* goal_params, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
+{ return car_fmtstar(ctx, 1, turn_radius, speed, r, init_idx, checkpts, goal_kind, goal_params, A, C, path, res); }
+
+int32_t mpfmt_reedsshepp_graph_count(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz)
+{ return car_graph_count(ctx, 2, turn_radius, speed, r, colptr, nnz); }
+int32_t mpfmt_reedsshepp_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval) { return car_graph_fill(ctx, 2, rowval, nzval); }
+int32_t mpfmt_reedsshepp_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg) { return car_graph_edges_free(ctx, 2, mask, nseg); }
+int32_t mpfmt_reedsshepp_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, double turn_radius, double speed,
+                               double* cost, double* controls, int32_t* nsegs)
+{ return car_steer_pairs(ctx, 2, X0, X1, n, turn_radius, speed, cost, controls, nsegs); }
+int32_t mpfmt_reedsshepp_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+                                 int32_t goal_kind, const double* goal_params, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
+{ return car_fmtstar(ctx, 2, turn_radius, speed, r, init_idx, checkpts, goal_kind, goal_params, A, C, path, res); }
 
 // ---- measurement ---------------------------------------------------------------------------------------
 

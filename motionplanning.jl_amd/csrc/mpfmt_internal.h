@@ -132,7 +132,7 @@ struct mpfmt_ctx {
     bool di_counted = false, di_filled = false, di_swept = false;
     int32_t* di_pool_i = nullptr; double* di_pool_c = nullptr; double* di_pool_t = nullptr;   // DI single-pass slot lists
     int64_t di_pool_cap = 0; bool di_pool_valid = false;
-    int32_t steer_kind = 1;              // which directed cost graph the di_* state describes: 1 double integrator, 2 Dubins car
+    int32_t steer_kind = 1;              // which steering graph the di_* state describes: 1 double integrator, 2 Dubins car, 3 Reeds-Shepp car
     double car_rt = 1.0, car_sp = 1.0;   // Dubins turning radius / speed of the built graph
     uint64_t* car_keep = nullptr;        // keep bits over the candidate (positions) graph
     mpfmt_ctx* aux = nullptr;            // helper ctx: Euclidean r-disc graph of the positions (Dubins build)
@@ -210,9 +210,10 @@ int32_t mpfmt_csc_transpose_device(mpfmt_ctx* ctx, mpfmt_csr_host* out);      //
 void mpfmt_directed_fmt_recursion(int64_t N, const int64_t* colptr, const int32_t* rowval, const double* nzval, const uint64_t* efree,
                                   const uint8_t* nseg, const uint64_t* F, int64_t init_idx, const std::function<bool(int64_t)>& goal_hit,
                                   int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res, const mpfmt_csr_view* pre);
-int32_t mpfmt_dubins_build(mpfmt_ctx* ctx, double rt, double sp, double r);
-int32_t mpfmt_dubins_sweep(mpfmt_ctx* ctx);
-int32_t mpfmt_dubins_steer_batch(mpfmt_ctx* ctx, const double* d_X0, const double* d_X1, int64_t n, double rt, double sp, double* d_cost, double* d_ctrl);
+int32_t mpfmt_car_build(mpfmt_ctx* ctx, int kind, double rt, double sp, double r);      // kind 1 Dubins, 2 Reeds-Shepp
+int32_t mpfmt_car_sweep(mpfmt_ctx* ctx);
+int32_t mpfmt_car_steer_batch(mpfmt_ctx* ctx, int kind, const double* d_X0, const double* d_X1, int64_t n, double rt, double sp, double* d_cost,
+                              double* d_ctrl, int32_t* d_nseg);
 int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r);
 int32_t mpfmt_di_fill(mpfmt_ctx* ctx);
 int32_t mpfmt_di_sweep(mpfmt_ctx* ctx);

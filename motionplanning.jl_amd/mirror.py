@@ -7,7 +7,7 @@ inball! -> inball_.  Indices are 1-based like the reference's (tree `A`, `path`,
 
 Reference files mirrored: src/statespaces.jl (BoundedStateSpace, volume, dim, sample_space, is_free_state,
 is_free_motion), src/statespaces/geometric.jl (UnitHypercube, BoundedEuclideanStateSpace),
-src/statespaces/linearquadratic.jl (DoubleIntegrator), src/statespaces/simplecars.jl (DubinsQuasiMetricSpace),
+src/statespaces/linearquadratic.jl (DoubleIntegrator), src/statespaces/simplecars.jl (DubinsQuasiMetricSpace, ReedsSheppMetricSpace),
 src/collisioncheckers/boxesND.jl (BoxBounds,
 PointRobotNDBoxes, inflate, addobstacle, addblocker), src/goals.jl (RectangleGoal, BallGoal, PointGoal, StateGoal),
 src/nearneighbors.jl (MetricNN, QuasiMetricNN, inball, inball!, ImmutableNNC, addpoints), src/problems.jl
@@ -69,6 +69,18 @@ class DubinsExact:
 def DubinsQuasiMetricSpace(r, s=1.0, lo=(0.0, 0.0), hi=(1.0, 1.0)):
     """SE2 states (x, y, theta) with theta in [0, 2pi]; workspace = (x, y)   (simplecars.jl:32-38)."""
     return BoundedStateSpace(np.array([lo[0], lo[1], 0.0]), np.array([hi[0], hi[1], 2 * math.pi]), DubinsExact(r, s), workspace_dim=2)
+
+
+class ReedsSheppExact:
+    """Exact Reeds-Shepp length (the car may reverse) for turning radius r and speed s   (simplecars.jl:5-12,23)."""
+
+    def __init__(self, r=1.0, s=1.0):
+        self.r, self.s = float(r), float(s)
+
+
+def ReedsSheppMetricSpace(r, s=1.0, lo=(0.0, 0.0), hi=(1.0, 1.0)):
+    """SE2 states with the chopped Reeds-Shepp metric; workspace = (x, y)   (simplecars.jl:29-34)."""
+    return BoundedStateSpace(np.array([lo[0], lo[1], 0.0]), np.array([hi[0], hi[1], 2 * math.pi]), ReedsSheppExact(r, s), workspace_dim=2)
 
 
 def volume(SS):
@@ -425,6 +437,8 @@ def fmtstar_(P, N=None, rm=1.0, connections="R", r=0.0, ensure_goal_ct=1, init_i
         res = ctx.di_fmtstar(P.SS.dist.rho, r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)
     elif isinstance(P.SS.dist, DubinsExact):
         res = ctx.dubins_fmtstar(P.SS.dist.r, P.SS.dist.s, r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)
+    elif isinstance(P.SS.dist, ReedsSheppExact):
+        res = ctx.reedsshepp_fmtstar(P.SS.dist.r, P.SS.dist.s, r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)
     else:
         res = ctx.fmtstar(r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)
     P.CC.count = res["collision_checks"]

@@ -1362,17 +1362,185 @@ static void car_propagate(const double *v, orc_step u, double *out)
     }
 }
 
-#define ORC_DUB_MAXWP 96
+/* ---- Reeds-Shepp car: simplecars.jl:228-524 (ReedsSheppMetricSpace :26-31).  Nine word families, each tried on the target
+ * and its time-flipped / reflected / backwards images in the reference's order; a later candidate replaces the incumbent only
+ * when strictly shorter.  Negative segment lengths mean reverse gear (carsegment2stepcontrol: speed = sign(d)). */
+static void rs_R(double x, double y, double *r, double *th) { *r = sqrt(x * x + y * y); *th = atan2(y, x); }      /* :230 */
+static double rs_M(double t) { const double m = mod2pif(t); return m > 3.141592653589793 ? m - ORC_TWOPI : m; }      /* :232-235 */
+static double rs_Tau(double u, double v, double E, double N)                                                          /* :236-243 */
+{
+    const double delta = rs_M(u - v);
+    const double A = sin(u) - sin(delta);
+    const double B = cos(u) - cos(delta) - 1;
+    double r, th;
+    rs_R(E * A + N * B, N * A - E * B, &r, &th);
+    const double t = 2 * cos(delta) - 2 * cos(v) - 2 * cos(u) + 3;
+    return t < 0 ? rs_M(th + 3.141592653589793) : rs_M(th);
+}
+static double rs_Omega(double u, double v, double E, double N, double t) { return rs_M(rs_Tau(u, v, E, N) - u + v - t); }   /* :244 */
+
+typedef struct { double c; int l; int post; orc_step p[5]; } rs_best;
+#define RS_ACCEPT(B, CNEW, L, POSTV, ...)                                                                   \
+    do { const double cnew_ = (CNEW); if (!((B)->c <= cnew_)) { const orc_step tmp_[5] = {__VA_ARGS__}; for (int q_ = 0; q_ < (L); ++q_) (B)->p[q_] = tmp_[q_]; (B)->c = cnew_; (B)->l = (L); (B)->post = (POSTV); } } while (0)
+
+static void rs_LpSpLp(const double *T, rs_best *b, int post)                   /* (8.1) :365-376 */
+{
+    double r, th;
+    rs_R(T[0] - sin(T[2]), T[1] - 1 + cos(T[2]), &r, &th);
+    const double u = r, t = mod2pif(th), v = mod2pif(T[2] - t);
+    RS_ACCEPT(b, t + u + v, 3, post, car_seg(1, t), car_seg(0, u), car_seg(1, v));
+}
+static void rs_LpSpRp(const double *T, rs_best *b, int post)                   /* (8.2) :378-391 */
+{
+    double r, th, r1, th1;
+    rs_R(T[0] + sin(T[2]), T[1] - 1 - cos(T[2]), &r, &th);
+    if (r * r < 4) return;
+    const double u = sqrt(r * r - 4);
+    rs_R(u, 2.0, &r1, &th1);
+    const double t = mod2pif(th + th1), v = mod2pif(t - T[2]);
+    RS_ACCEPT(b, t + u + v, 3, post, car_seg(1, t), car_seg(0, u), car_seg(-1, v));
+}
+static void rs_LpRmLp(const double *T, rs_best *b, int post)                   /* (8.3) :393-408 */
+{
+    const double E = T[0] - sin(T[2]), N = T[1] + cos(T[2]) - 1;
+    if (E * E + N * N > 16) return;
+    double r, th;
+    rs_R(E, N, &r, &th);
+    double u = acos(1 - r * r / 8);
+    const double t = mod2pif(th - u / 2 + 3.141592653589793), v = mod2pif(3.141592653589793 - u / 2 - th + T[2]);
+    u = -u;
+    RS_ACCEPT(b, t - u + v, 3, post, car_seg(1, t), car_seg(-1, u), car_seg(1, v));
+}
+static void rs_LpRmLm(const double *T, rs_best *b, int post)                   /* (8.4) :410-425 */
+{
+    const double E = T[0] - sin(T[2]), N = T[1] + cos(T[2]) - 1;
+    if (E * E + N * N > 16) return;
+    double r, th;
+    rs_R(E, N, &r, &th);
+    double u = acos(1 - r * r / 8);
+    const double t = mod2pif(th - u / 2 + 3.141592653589793), v = mod2pif(3.141592653589793 - u / 2 - th + T[2]) - ORC_TWOPI;
+    u = -u;
+    RS_ACCEPT(b, t - u - v, 3, post, car_seg(1, t), car_seg(-1, u), car_seg(1, v));
+}
+static void rs_LpRpuLmuRm(const double *T, rs_best *b, int post)               /* (8.7) :427-442 */
+{
+    const double E = T[0] + sin(T[2]), N = T[1] - cos(T[2]) - 1;
+    const double p = (2 + sqrt(E * E + N * N)) / 4;
+    if (p < 0 || p > 1) return;
+    const double u = acos(p);
+    const double t = mod2pif(rs_Tau(u, -u, E, N)), v = mod2pif(rs_Omega(u, -u, E, N, T[2])) - ORC_TWOPI;
+    RS_ACCEPT(b, t + 2 * u - v, 4, post, car_seg(1, t), car_seg(-1, u), car_seg(1, -u), car_seg(-1, v));
+}
+static void rs_LpRmuLmuRp(const double *T, rs_best *b, int post)               /* (8.8) :444-459 */
+{
+    const double E = T[0] + sin(T[2]), N = T[1] - cos(T[2]) - 1;
+    const double p = (20 - E * E - N * N) / 16;
+    if (p < 0 || p > 1) return;
+    const double u = -acos(p);
+    const double t = mod2pif(rs_Tau(u, u, E, N)), v = mod2pif(rs_Omega(u, u, E, N, T[2]));
+    RS_ACCEPT(b, t - 2 * u + v, 4, post, car_seg(1, t), car_seg(-1, u), car_seg(1, u), car_seg(-1, v));
+}
+static void rs_LpRmSmLm(const double *T, rs_best *b, int post)                 /* (8.9) :461-479 */
+{
+    const double E = T[0] - sin(T[2]), N = T[1] + cos(T[2]) - 1;
+    double D, be;
+    rs_R(E, N, &D, &be);
+    if (D < 2) return;
+    const double ga = acos(2 / D), F = sqrt(D * D / 4 - 1);
+    const double t = mod2pif(3.141592653589793 + be - ga), u = 2 - 2 * F;
+    if (u > 0) return;
+    const double v = mod2pif(-3 * 3.141592653589793 / 2 + ga + T[2] - be) - ORC_TWOPI;
+    RS_ACCEPT(b, t + 3.141592653589793 / 2 - u - v, 4, post, car_seg(1, t), car_seg(-1, -3.141592653589793 / 2), car_seg(0, u), car_seg(1, v));
+}
+static void rs_LpRmSmRm(const double *T, rs_best *b, int post)                 /* (8.10) :481-497 */
+{
+    const double E = T[0] + sin(T[2]), N = T[1] - cos(T[2]) - 1;
+    double D, be;
+    rs_R(E, N, &D, &be);
+    if (D < 2) return;
+    const double t = mod2pif(be + 3.141592653589793 / 2), u = 2 - D;
+    if (u > 0) return;
+    const double v = mod2pif(-3.141592653589793 - T[2] + be) - ORC_TWOPI;
+    RS_ACCEPT(b, t + 3.141592653589793 / 2 - u - v, 4, post, car_seg(1, t), car_seg(-1, -3.141592653589793 / 2), car_seg(0, u), car_seg(-1, v));
+}
+static void rs_LpRmSmLmRp(const double *T, rs_best *b, int post)               /* (8.11) :499-518 */
+{
+    const double E = T[0] + sin(T[2]), N = T[1] - cos(T[2]) - 1;
+    double D, be;
+    rs_R(E, N, &D, &be);
+    if (D < 2) return;
+    const double ga = acos(2 / D), F = sqrt(D * D / 4 - 1);
+    const double t = mod2pif(3.141592653589793 + be - ga), u = 4 - 2 * F;
+    if (u > 0) return;
+    const double v = mod2pif(3.141592653589793 + be - T[2] - ga);
+    RS_ACCEPT(b, t + 3.141592653589793 - u + v, 5, post, car_seg(1, t), car_seg(-1, -3.141592653589793 / 2), car_seg(0, u),
+              car_seg(1, -3.141592653589793 / 2), car_seg(-1, v));
+}
+
+/* reedsshepp(s1, s2, r, s) :265-363: cost, controls path[0..*L) */
+double orc_reedsshepp(const double *s1, const double *s2, double r, double s, orc_step *path, int32_t *L)
+{
+    const double dx = (s2[0] - s1[0]) / r, dy = (s2[1] - s1[1]) / r;
+    const double ct = cos(s1[2]), st = sin(s1[2]);
+    double T[8][3];            /* POST, T, R, B, R_T, B_T, B_R, B_R_T in the reference's numbering 0..7 */
+    T[0][0] = dx * ct + dy * st; T[0][1] = -dx * st + dy * ct; T[0][2] = mod2pif(s2[2] - s1[2]);
+#define RS_TIMEFLIP(D, S) do { (D)[0] = -(S)[0]; (D)[1] = (S)[1]; (D)[2] = -(S)[2]; } while (0)
+#define RS_REFLECT(D, S) do { (D)[0] = (S)[0]; (D)[1] = -(S)[1]; (D)[2] = -(S)[2]; } while (0)
+    RS_TIMEFLIP(T[1], T[0]);                       /* tTarget   */
+    RS_REFLECT(T[2], T[0]);                        /* rTarget   */
+    RS_REFLECT(T[4], T[1]);                        /* trTarget  */
+    T[3][0] = T[0][0] * cos(T[0][2]) + T[0][1] * sin(T[0][2]);      /* bTarget = backwards(target) :247 */
+    T[3][1] = T[0][0] * sin(T[0][2]) - T[0][1] * cos(T[0][2]);
+    T[3][2] = T[0][2];
+    RS_TIMEFLIP(T[5], T[3]);                       /* btTarget  */
+    RS_REFLECT(T[6], T[3]);                        /* brTarget  */
+    RS_REFLECT(T[7], T[5]);                        /* btrTarget */
+    rs_best b; b.c = INFINITY; b.l = 0; b.post = 0;
+    static const int four[4] = {0, 1, 2, 4}, eight[8] = {0, 1, 2, 4, 3, 5, 6, 7};
+    for (int q = 0; q < 4; ++q) rs_LpSpLp(T[four[q]], &b, four[q]);
+    for (int q = 0; q < 4; ++q) rs_LpSpRp(T[four[q]], &b, four[q]);
+    rs_LpRmLp(T[0], &b, 0); rs_LpRmLp(T[2], &b, 2);
+    for (int q = 0; q < 8; ++q) rs_LpRmLm(T[eight[q]], &b, eight[q]);
+    for (int q = 0; q < 4; ++q) rs_LpRpuLmuRm(T[four[q]], &b, four[q]);
+    for (int q = 0; q < 4; ++q) rs_LpRmuLmuRp(T[four[q]], &b, four[q]);
+    for (int q = 0; q < 8; ++q) rs_LpRmSmLm(T[eight[q]], &b, eight[q]);
+    for (int q = 0; q < 8; ++q) rs_LpRmSmRm(T[eight[q]], &b, eight[q]);
+    for (int q = 0; q < 4; ++q) rs_LpRmSmLmRp(T[four[q]], &b, four[q]);
+    for (int q = 0; q < b.l; ++q) {               /* scalespeed!(scaleradius!(p[1:l], r), s) */
+        b.p[q].t = b.p[q].t * r; b.p[q].k = b.p[q].k / r;
+        b.p[q].t = b.p[q].t / s; b.p[q].s = b.p[q].s * s;
+    }
+    const int tf = (b.post == 1 || b.post == 4 || b.post == 5 || b.post == 7);      /* timeflip!: negate speed */
+    const int rf = (b.post == 2 || b.post == 4 || b.post == 6 || b.post == 7);      /* reflect!: negate curvature */
+    const int bw = (b.post == 3 || b.post == 5 || b.post == 6 || b.post == 7);      /* backwards!: reverse the order */
+    for (int q = 0; q < b.l; ++q) { if (tf) b.p[q].s = -b.p[q].s; if (rf) b.p[q].k = -b.p[q].k; }
+    for (int q = 0; q < b.l; ++q) path[q] = bw ? b.p[b.l - 1 - q] : b.p[q];
+    for (int q = b.l; q < 5; ++q) { path[q].t = 0; path[q].s = 0; path[q].k = 0; }
+    *L = b.l;
+    return b.c * r;
+}
+
+/* kind 1 = Dubins, 2 = Reeds-Shepp */
+static double car_steer(int32_t kind, const double *s1, const double *s2, double rt, double sp, orc_step *path, int32_t *L)
+{
+    if (kind == 2) return orc_reedsshepp(s1, s2, rt, sp, path, L);
+    *L = 3;
+    path[3].t = path[3].s = path[3].k = 0; path[4] = path[3];
+    return orc_dubins(s1, s2, rt, sp, path);
+}
+
+#define ORC_DUB_MAXWP 160
 /* collision_waypoints(d, v, w) = per-segment waypoints (:68-83; arcs sampled every pi/12 -- only for positive
  * u.t*s*invr: a negative quotient floors to m <= -1 and the range 1:m is empty) + the target (statespaces.jl:127-135) */
-int32_t orc_dubins_waypoints(const double *v0, const double *w, double rt, double sp, double *wps)
+int32_t orc_car_waypoints(int32_t kind, const double *v0, const double *w, double rt, double sp, double *wps)
 {
-    orc_step path[3];
-    orc_dubins(v0, w, rt, sp, path);
+    orc_step path[5];
+    int32_t L = 3;
+    car_steer(kind, v0, w, rt, sp, path, &L);
     double v[3] = {v0[0], v0[1], v0[2]};
     int32_t n = 0;
     const double thres = 3.141592653589793 / 12;
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < L; ++q) {
         const orc_step u = path[q];
         const double quo = u.t * u.s * u.k / thres;
         const double fl = floor(quo);
@@ -1393,14 +1561,15 @@ int32_t orc_dubins_waypoints(const double *v0, const double *w, double rt, doubl
     wps[3 * n] = w[0]; wps[3 * n + 1] = w[1]; wps[3 * n + 2] = w[2]; ++n;
     return n;
 }
+int32_t orc_dubins_waypoints(const double *v0, const double *w, double rt, double sp, double *wps) { return orc_car_waypoints(1, v0, w, rt, sp, wps); }
 
 /* is_free_motion(v, w, CC, SS) (statespaces.jl:153-158): every consecutive waypoint pair, in_state_space on the first
  * point (SE2 bounds), segment test on (x, y) against 2-D boxes; *nseg = segment tests made (CC.count, boxesND.jl:26) */
-int32_t orc_dubins_is_free_motion(const double *v, const double *w, double rt, double sp, const double *lohi, int32_t M,
-                                  const double *ss_lo, const double *ss_hi, int32_t *nseg)
+int32_t orc_car_is_free_motion(int32_t kind, const double *v, const double *w, double rt, double sp, const double *lohi, int32_t M,
+                               const double *ss_lo, const double *ss_hi, int32_t *nseg)
 {
     double wps[3 * ORC_DUB_MAXWP];
-    const int32_t n = orc_dubins_waypoints(v, w, rt, sp, wps);
+    const int32_t n = orc_car_waypoints(kind, v, w, rt, sp, wps);
     int32_t cnt = 0, ok = 1;
     for (int32_t i = 0; i + 1 < n && ok; ++i) {
         if (!orc_in_state_space(wps + 3 * i, ss_lo, ss_hi, 3)) { ok = 0; break; }
@@ -1409,6 +1578,11 @@ int32_t orc_dubins_is_free_motion(const double *v, const double *w, double rt, d
     }
     if (nseg) *nseg = cnt;
     return ok;
+}
+int32_t orc_dubins_is_free_motion(const double *v, const double *w, double rt, double sp, const double *lohi, int32_t M,
+                                  const double *ss_lo, const double *ss_hi, int32_t *nseg)
+{
+    return orc_car_is_free_motion(1, v, w, rt, sp, lohi, M, ss_lo, ss_hi, nseg);
 }
 
 /* chopped backward sets as a CSC (column j = sources i with |xy_i - xy_j| <= r and dubins(i -> j) <= r), nearneighbors.jl:185-198.
@@ -1548,4 +1722,97 @@ void orc_mc_edges(const double *X, int32_t d, const int64_t *src, const int64_t 
         }
         hits[e] = h;
     }
+}
+
+/* ---- Reeds-Shepp space: chopped METRIC (ChoppedMetric, MetricNN): inball(v) = { w : |xy_v - xy_w| <= r, rs(v -> w) <= r } with
+ * ds = rs(v -> w) (colwise(dist, V[v], V[inds]), nearneighbors.jl:185-198); forward and backward sets coincide (:200-203).
+ * CSC: column v = inball(v).  Two-phase like orc_dubins_graph. */
+int64_t orc_rs_graph(const double *X, int64_t N, double rt, double sp, double r, int64_t *colptr, int64_t *rowval, double *nzval)
+{
+    int64_t nnz = 0;
+    orc_step path[5];
+    int32_t L;
+    for (int64_t v = 0; v < N; ++v) {
+        if (colptr) colptr[v] = nnz;
+        for (int64_t w = 0; w < N; ++w) {
+            if (w == v) continue;
+            const double dx = X[3 * w] - X[3 * v], dy = X[3 * w + 1] - X[3 * v + 1];
+            const double px = dx * dx, py = dy * dy;
+            if (!(px + py <= r * r)) continue;
+            const double c = orc_reedsshepp(X + 3 * v, X + 3 * w, rt, sp, path, &L);
+            if (c <= r) { if (rowval) { rowval[nnz] = w; nzval[nnz] = c; } ++nnz; }
+        }
+    }
+    if (colptr) colptr[N] = nnz;
+    return nnz;
+}
+
+/* entry e (row y, column x): is_free_motion(V[y], V[x], CC, SS) (fmt.jl:75: parent first), kind 1 Dubins / 2 Reeds-Shepp */
+void orc_car_graph_edges_free(int32_t kind, const double *X, int64_t N, double rt, double sp, const int64_t *colptr, const int64_t *rowval,
+                              const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi, uint64_t *mask, uint8_t *nseg)
+{
+    memset(mask, 0, sizeof(uint64_t) * (size_t)((colptr[N] + 63) / 64));
+    for (int64_t x = 0; x < N; ++x)
+        for (int64_t e = colptr[x]; e < colptr[x + 1]; ++e) {
+            int32_t ns = 0;
+            set_bit(mask, e, orc_car_is_free_motion(kind, X + 3 * rowval[e], X + 3 * x, rt, sp, lohi, M, ss_lo, ss_hi, &ns));
+            if (nseg) nseg[e] = (uint8_t)ns;
+        }
+}
+
+/* fmtstar! over the Reeds-Shepp space (symmetric neighbour sets: near(z) = column z, near(x) & H scans column x with
+ * c = C[y] + ds(x, y), fmt.jl:70-75); lazy edge checks counted per waypoint segment. */
+int32_t orc_rs_fmtstar(const double *X, int64_t N, double rt, double sp, int64_t init_idx, int32_t checkpts,
+                       const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                       int32_t goal_kind, const double *goal, const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi,
+                       int64_t *A, double *C, int64_t *path, orc_fmt_result *res)
+{
+    memset(res, 0, sizeof *res);
+    res->cost = INFINITY;
+#define CAR_FREE_STATE(p) (orc_in_state_space((p), ss_lo, ss_hi, 3) && orc_point_free_boxes((p), lohi, M, 2))
+#define CAR_GOAL(p) ((goal_kind == 2) ? ((p)[0] == goal[0] && (p)[1] == goal[1] && (p)[2] == goal[2]) : orc_is_goal_pt((p), 2, goal_kind, goal))
+    if (!CAR_FREE_STATE(X + 3 * init_idx)) return -1;
+    uint8_t *F = NULL;
+    if (checkpts) { F = (uint8_t *)malloc((size_t)N); for (int64_t i = 0; i < N; ++i) F[i] = (uint8_t)CAR_FREE_STATE(X + 3 * i); }
+    uint8_t *Wm = (uint8_t *)malloc((size_t)N), *Hm = (uint8_t *)calloc((size_t)N, 1);
+    memset(Wm, 1, (size_t)N);
+    for (int64_t i = 0; i < N; ++i) { A[i] = -1; C[i] = 0.0; }
+    int64_t *Hnew = (int64_t *)malloc(sizeof(int64_t) * (size_t)N), *rev = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    orc_heap heap = {0};
+    Wm[init_idx] = 0; Hm[init_idx] = 1;
+    heap_push(&heap, init_idx, 0.0);
+    int64_t z = heap_pop(&heap), count = 0;
+    while (!CAR_GOAL(X + 3 * z)) {
+        int64_t nnew = 0;
+        for (int64_t a = colptr[z]; a < colptr[z + 1]; ++a) {
+            const int64_t x = rowval[a];
+            if (!Wm[x]) continue;
+            if (checkpts && !F[x]) continue;
+            int64_t y_min = -1; double c_min = 0.0;
+            for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {
+                const int64_t y = rowval[b];
+                if (!Hm[y]) continue;
+                const double c = C[y] + nzval[b];
+                if (y_min < 0 || c < c_min) { y_min = y; c_min = c; }
+            }
+            if (y_min < 0) continue;
+            int32_t ns = 0;
+            const int ok = orc_car_is_free_motion(2, X + 3 * y_min, X + 3 * x, rt, sp, lohi, M, ss_lo, ss_hi, &ns);
+            count += ns;
+            if (ok) { A[x] = y_min; C[x] = c_min; heap_push(&heap, x, c_min); Hnew[nnew++] = x; Wm[x] = 0; }
+        }
+        for (int64_t a = 0; a < nnew; ++a) Hm[Hnew[a]] = 1;
+        Hm[z] = 0;
+        if (heap.n > 0) z = heap_pop(&heap); else break;
+    }
+    int64_t len = 0, c2 = z;
+    rev[len++] = c2;
+    while (c2 != 0) { c2 = A[c2]; if (c2 < 0) break; rev[len++] = c2; }
+    for (int64_t i = 0; i < len; ++i) path[i] = rev[len - 1 - i];
+    res->status = CAR_GOAL(X + 3 * z);
+    res->cost = C[z]; res->z = z; res->collision_checks = count; res->path_len = len; res->nn_queries = 0;
+#undef CAR_FREE_STATE
+#undef CAR_GOAL
+    free(F); free(Wm); free(Hm); free(Hnew); free(rev); free(heap.pri); free(heap.idx);
+    return 0;
 }

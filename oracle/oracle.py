@@ -426,7 +426,7 @@ def dubins(s1, s2, rt=1.0, sp=1.0):
 
 def dubins_waypoints(v, w, rt=1.0, sp=1.0):
     v = _vec(v); w = _vec(w)
-    wps = np.zeros((96, 3))
+    wps = np.zeros((160, 3))
     n = lib().orc_dubins_waypoints(_d(v), _d(w), C.c_double(rt), C.c_double(sp), _d(wps))
     return wps[:n].copy()
 
@@ -479,3 +479,60 @@ def mc_edges(X, src, dst, sigma, rollouts, seed, lohi, ss_lo=None, ss_hi=None):
     lib().orc_mc_edges(_d(X), C.c_int32(d), _i(src), _i(dst), C.c_int64(len(src)), C.c_double(sigma), C.c_int64(rollouts),
                        C.c_uint64(seed), _d(lohi), C.c_int32(M), _d(_vec(ss_lo)), _d(_vec(ss_hi)), _i(hits))
     return hits[:len(src)]
+
+
+# ---- Reeds-Shepp car (second half) ---------------------------------------------------------------------
+def reedsshepp(s1, s2, rt=1.0, sp=1.0):
+    """(cost, controls[L][3] = (t, speed, curvature)) of simplecars.jl:265-363."""
+    s1 = _vec(s1); s2 = _vec(s2)
+    path = np.zeros((5, 3)); L = C.c_int32()
+    Lb = lib(); Lb.orc_reedsshepp.restype = C.c_double
+    c = Lb.orc_reedsshepp(_d(s1), _d(s2), C.c_double(rt), C.c_double(sp), _d(path), C.byref(L))
+    return float(c), path[:L.value].copy()
+
+
+def car_waypoints(kind, v, w, rt=1.0, sp=1.0):
+    v = _vec(v); w = _vec(w)
+    wps = np.zeros((160, 3))
+    n = lib().orc_car_waypoints(C.c_int32(kind), _d(v), _d(w), C.c_double(rt), C.c_double(sp), _d(wps))
+    return wps[:n].copy()
+
+
+def car_is_free_motion(kind, v, w, rt, sp, lohi, ss_lo, ss_hi):
+    v = _vec(v); w = _vec(w); lohi, M = _boxes(lohi, 2); ns = C.c_int32()
+    ok = lib().orc_car_is_free_motion(C.c_int32(kind), _d(v), _d(w), C.c_double(rt), C.c_double(sp), _d(lohi), C.c_int32(M),
+                                      _d(_vec(ss_lo)), _d(_vec(ss_hi)), C.byref(ns))
+    return bool(ok), int(ns.value)
+
+
+def rs_graph(X, rt, sp, r):
+    """inball sets of the Reeds-Shepp space as 0-based CSC: column v = { w : rs(v -> w) <= r }, nzval = rs(v -> w)."""
+    X, N, d = _X(X)
+    L = lib(); L.orc_rs_graph.restype = C.c_int64
+    colptr = np.zeros(N + 1, dtype=np.int64)
+    nnz = int(L.orc_rs_graph(_d(X), C.c_int64(N), C.c_double(rt), C.c_double(sp), C.c_double(r), _i(colptr), None, None))
+    rowval = np.zeros(max(nnz, 1), dtype=np.int64); nzval = np.zeros(max(nnz, 1))
+    L.orc_rs_graph(_d(X), C.c_int64(N), C.c_double(rt), C.c_double(sp), C.c_double(r), None, _i(rowval), _d(nzval))
+    return colptr, rowval[:nnz], nzval[:nnz]
+
+
+def car_graph_edges_free(kind, X, rt, sp, colptr, rowval, lohi, ss_lo, ss_hi):
+    X, N, d = _X(X); lohi, M = _boxes(lohi, 2)
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64); rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+    nnz = int(colptr[-1])
+    mask = np.zeros(max(nwords(nnz), 1), dtype=np.uint64); nseg = np.zeros(max(nnz, 1), dtype=np.uint8)
+    lib().orc_car_graph_edges_free(C.c_int32(kind), _d(X), C.c_int64(N), C.c_double(rt), C.c_double(sp), _i(colptr), _i(rowval), _d(lohi),
+                                   C.c_int32(M), _d(_vec(ss_lo)), _d(_vec(ss_hi)), _u(mask), nseg.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return mask[:nwords(nnz)], nseg[:nnz]
+
+
+def rs_fmtstar(X, rt, sp, colptr, rowval, nzval, goal_kind, goal, lohi, ss_lo, ss_hi, init_idx=0, checkpts=True):
+    X, N, d = _X(X); lohi, M = _boxes(lohi, 2); goal = _vec(goal)
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64); rowval = np.ascontiguousarray(rowval, dtype=np.int64); nzval = _vec(nzval)
+    A = np.empty(N, dtype=np.int64); Cc = np.empty(N, dtype=np.float64); path = np.empty(N, dtype=np.int64)
+    res = FmtResult()
+    rc = lib().orc_rs_fmtstar(_d(X), C.c_int64(N), C.c_double(rt), C.c_double(sp), C.c_int64(init_idx), C.c_int32(int(checkpts)),
+                              _i(colptr), _i(rowval), _d(nzval), C.c_int32(goal_kind), _d(goal), _d(lohi), C.c_int32(M),
+                              _d(_vec(ss_lo)), _d(_vec(ss_hi)), _i(A), _d(Cc), _i(path), C.byref(res))
+    return dict(rc=rc, status=int(res.status), cost=float(res.cost), z=int(res.z), collision_checks=int(res.collision_checks),
+                A=A, C=Cc, path=path[:res.path_len].copy())

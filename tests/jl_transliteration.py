@@ -452,3 +452,218 @@ def car_is_free_motion(v, w, r, s, boxes, ss_lo, ss_hi):    # statespaces.jl:153
         if not is_free_motion_boxes(wps[i][:2], wps[i + 1][:2], boxes):
             return False, cnt
     return True, cnt
+
+
+# ---- Reeds-Shepp car: src/statespaces/simplecars.jl:228-524 ------------------------------------------------------------------
+def _R(x, y):                              # :230
+    return _m.sqrt(x * x + y * y), _m.atan2(y, x)
+
+
+def _M(t):                                 # :232-235
+    m = mod2piF(t)
+    return m - TWOPI if m > _m.pi else m
+
+
+def _Tau(u, v, E, N):                      # :236-243
+    delta = _M(u - v)
+    A = _m.sin(u) - _m.sin(delta)
+    B = _m.cos(u) - _m.cos(delta) - 1
+    r, th = _R(E * A + N * B, N * A - E * B)
+    t = 2 * _m.cos(delta) - 2 * _m.cos(v) - 2 * _m.cos(u) + 3
+    return _M(th + _m.pi) if t < 0 else _M(th)
+
+
+def _Omega(u, v, E, N, t):                 # :244
+    return _M(_Tau(u, v, E, N) - u + v - t)
+
+
+def _timeflip(s):                          # :245
+    return (-s[0], s[1], -s[2])
+
+
+def _reflect(s):                           # :246
+    return (s[0], -s[1], -s[2])
+
+
+def _backwards(s):                         # :247
+    return (s[0] * _m.cos(s[2]) + s[1] * _m.sin(s[2]), s[0] * _m.sin(s[2]) - s[1] * _m.cos(s[2]), s[2])
+
+
+def _LpSpLp(T, c):                         # :365-376
+    tx, ty, tt = T
+    r, th = _R(tx - _m.sin(tt), ty - 1 + _m.cos(tt))
+    u = r; t = mod2piF(th); v = mod2piF(tt - t)
+    cnew = t + u + v
+    if c <= cnew:
+        return None
+    return cnew, [(1, t), (0, u), (1, v)]
+
+
+def _LpSpRp(T, c):                         # :378-391
+    tx, ty, tt = T
+    r, th = _R(tx + _m.sin(tt), ty - 1 - _m.cos(tt))
+    if r * r < 4:
+        return None
+    u = _m.sqrt(r * r - 4)
+    r1, th1 = _R(u, 2.0)
+    t = mod2piF(th + th1); v = mod2piF(t - tt)
+    cnew = t + u + v
+    if c <= cnew:
+        return None
+    return cnew, [(1, t), (0, u), (-1, v)]
+
+
+def _LpRmLp(T, c):                         # :393-408
+    tx, ty, tt = T
+    E = tx - _m.sin(tt); N = ty + _m.cos(tt) - 1
+    if E * E + N * N > 16:
+        return None
+    r, th = _R(E, N)
+    u = _m.acos(1 - r * r / 8)
+    t = mod2piF(th - u / 2 + _m.pi); v = mod2piF(_m.pi - u / 2 - th + tt)
+    u = -u
+    cnew = t - u + v
+    if c <= cnew:
+        return None
+    return cnew, [(1, t), (-1, u), (1, v)]
+
+
+def _LpRmLm(T, c):                         # :410-425
+    tx, ty, tt = T
+    E = tx - _m.sin(tt); N = ty + _m.cos(tt) - 1
+    if E * E + N * N > 16:
+        return None
+    r, th = _R(E, N)
+    u = _m.acos(1 - r * r / 8)
+    t = mod2piF(th - u / 2 + _m.pi); v = mod2piF(_m.pi - u / 2 - th + tt) - TWOPI
+    u = -u
+    cnew = t - u - v
+    if c <= cnew:
+        return None
+    return cnew, [(1, t), (-1, u), (1, v)]
+
+
+def _LpRpuLmuRm(T, c):                     # :427-442
+    tx, ty, tt = T
+    E = tx + _m.sin(tt); N = ty - _m.cos(tt) - 1
+    p = (2 + _m.sqrt(E * E + N * N)) / 4
+    if p < 0 or p > 1:
+        return None
+    u = _m.acos(p)
+    t = mod2piF(_Tau(u, -u, E, N)); v = mod2piF(_Omega(u, -u, E, N, tt)) - TWOPI
+    cnew = t + 2 * u - v
+    if c <= cnew:
+        return None
+    return cnew, [(1, t), (-1, u), (1, -u), (-1, v)]
+
+
+def _LpRmuLmuRp(T, c):                     # :444-459
+    tx, ty, tt = T
+    E = tx + _m.sin(tt); N = ty - _m.cos(tt) - 1
+    p = (20 - E * E - N * N) / 16
+    if p < 0 or p > 1:
+        return None
+    u = -_m.acos(p)
+    t = mod2piF(_Tau(u, u, E, N)); v = mod2piF(_Omega(u, u, E, N, tt))
+    cnew = t - 2 * u + v
+    if c <= cnew:
+        return None
+    return cnew, [(1, t), (-1, u), (1, u), (-1, v)]
+
+
+def _LpRmSmLm(T, c):                       # :461-479
+    tx, ty, tt = T
+    E = tx - _m.sin(tt); N = ty + _m.cos(tt) - 1
+    D, be = _R(E, N)
+    if D < 2:
+        return None
+    ga = _m.acos(2 / D); F = _m.sqrt(D * D / 4 - 1)
+    t = mod2piF(_m.pi + be - ga); u = 2 - 2 * F
+    if u > 0:
+        return None
+    v = mod2piF(-3 * _m.pi / 2 + ga + tt - be) - TWOPI
+    cnew = t + _m.pi / 2 - u - v
+    if c <= cnew:
+        return None
+    return cnew, [(1, t), (-1, -_m.pi / 2), (0, u), (1, v)]
+
+
+def _LpRmSmRm(T, c):                       # :481-497
+    tx, ty, tt = T
+    E = tx + _m.sin(tt); N = ty - _m.cos(tt) - 1
+    D, be = _R(E, N)
+    if D < 2:
+        return None
+    t = mod2piF(be + _m.pi / 2); u = 2 - D
+    if u > 0:
+        return None
+    v = mod2piF(-_m.pi - tt + be) - TWOPI
+    cnew = t + _m.pi / 2 - u - v
+    if c <= cnew:
+        return None
+    return cnew, [(1, t), (-1, -_m.pi / 2), (0, u), (-1, v)]
+
+
+def _LpRmSmLmRp(T, c):                     # :499-518
+    tx, ty, tt = T
+    E = tx + _m.sin(tt); N = ty - _m.cos(tt) - 1
+    D, be = _R(E, N)
+    if D < 2:
+        return None
+    ga = _m.acos(2 / D); F = _m.sqrt(D * D / 4 - 1)
+    t = mod2piF(_m.pi + be - ga); u = 4 - 2 * F
+    if u > 0:
+        return None
+    v = mod2piF(_m.pi + be - tt - ga)
+    cnew = t + _m.pi - u + v
+    if c <= cnew:
+        return None
+    return cnew, [(1, t), (-1, -_m.pi / 2), (0, u), (1, -_m.pi / 2), (-1, v)]
+
+
+def reedsshepp(s1, s2, r=1.0, s=1.0):      # :265-363
+    dx, dy = (s2[0] - s1[0]) / r, (s2[1] - s1[1]) / r
+    ct, st = _m.cos(s1[2]), _m.sin(s1[2])
+    target = (dx * ct + dy * st, -dx * st + dy * ct, mod2piF(s2[2] - s1[2]))
+    tT = _timeflip(target); rT = _reflect(target); trT = _reflect(tT)
+    bT = _backwards(target); btT = _timeflip(bT); brT = _reflect(bT); btrT = _reflect(btT)
+    POST, POST_T, POST_R, POST_B, POST_R_T, POST_B_T, POST_B_R, POST_B_R_T = range(8)
+    four = [(target, POST), (tT, POST_T), (rT, POST_R), (trT, POST_R_T)]
+    eight = four + [(bT, POST_B), (btT, POST_B_T), (brT, POST_B_R), (btrT, POST_B_R_T)]
+    c, p, post = _m.inf, None, None
+    plan = [(_LpSpLp, four), (_LpSpRp, four), (_LpRmLp, [(target, POST), (rT, POST_R)]), (_LpRmLm, eight), (_LpRpuLmuRm, four),
+            (_LpRmuLmuRp, four), (_LpRmSmLm, eight), (_LpRmSmRm, eight), (_LpRmSmLmRp, four)]
+    for f, targets in plan:
+        for T, code in targets:
+            out = f(T, c)
+            if out is not None:
+                c, segs = out
+                p = [carsegment2stepcontrol(t, d) for (t, d) in segs]
+                post = code
+    u = [[q[0] * r, q[1], q[2] / r] for q in p]
+    u = [[q[0] / s, q[1] * s, q[2]] for q in u]
+    if post in (POST_T, POST_R_T, POST_B_T, POST_B_R_T):
+        u = [[q[0], -q[1], q[2]] for q in u]            # timeflip! :248-253
+    if post in (POST_R, POST_R_T, POST_B_R, POST_B_R_T):
+        u = [[q[0], q[1], -q[2]] for q in u]            # reflect! :254-259
+    if post in (POST_B, POST_B_T, POST_B_R, POST_B_R_T):
+        u = u[::-1]                                     # backwards! :260
+    return c * r, u
+
+
+def car_collision_waypoints_rs(v, w, r=1.0, s=1.0):     # :68-83 + statespaces.jl:127-135 with the Reeds-Shepp controls
+    _, us = reedsshepp(v, w, r, s)
+    path = []
+    thres = _m.pi / 12
+    v = tuple(v)
+    for u in us:
+        t, sp, invr = u
+        m = _m.floor(t * sp * invr / thres)
+        path.append(v)
+        if m != 0:
+            for i in range(1, m + 1):
+                path.append((v[0] + (_m.sin(v[2] + i * thres) - _m.sin(v[2])) / invr,
+                             v[1] + (_m.cos(v[2]) - _m.cos(v[2] + i * thres)) / invr, mod2piF(v[2] + i * thres)))
+        v = car_propagate(v, u)
+    path.append(tuple(w))
+    return path

@@ -154,3 +154,30 @@ def test_dubins_planning_through_the_mirror(orc):
         path = md["path"] - 1
         for a, b in zip(path[:-1], path[1:]):                       # every edge of the plan is a free Dubins motion
             assert orc.dubins_is_free_motion(X[a], X[b], rt, 1.0, lohi, SS.lo, SS.hi)[0]
+
+
+def test_reedsshepp_planning_through_the_mirror(orc):
+    """ReedsSheppMetricSpace (simplecars.jl:29-34) through the mirror types; the plan is checked against the oracle's
+    Reeds-Shepp graph / recursion on the samples the mirror drew, and never costs more than the Dubins plan's bound."""
+    rt = 0.08
+    SS = mp.ReedsSheppMetricSpace(rt)
+    assert mp.dim(SS) == 3 and SS.workspace_dim == 2
+    CC = mp.PointRobotNDBoxes(boxes2d())
+    P = mp.MPProblem(SS, [0.1, 0.1, 0.5], mp.BallGoal([0.9, 0.9], 0.06), CC)
+    status, cost, _ = mp.fmtstar_(P, 1500, rm=1.0, rng=np.random.default_rng(4), ensure_goal_ct=3)
+    X = P.V.V
+    md = P.solution.metadata
+    lohi = CC.lohi()
+    oc, orow, oval = orc.rs_graph(X, rt, 1.0, md["r"])
+    colptr, rowval, nzval = P.ctx.reedsshepp_graph(rt, 1.0, md["r"])
+    assert np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow) and np.allclose(nzval, oval, rtol=1e-12, atol=0)
+    # C|C|C words tie exactly in exact arithmetic (see test_reedsshepp_graph_sweep_and_plan): pin the recursion on the
+    # device's own edge costs
+    ref = orc.rs_fmtstar(X, rt, 1.0, oc, orow, nzval, orc.GOAL_BALL, np.array([0.9, 0.9, 0.06]), lohi, SS.lo, SS.hi)
+    assert (status == "solved") == bool(ref["status"])
+    assert np.array_equal(md["tree"] - 1, ref["A"]) and md["collision_checks"] == ref["collision_checks"]
+    if ref["status"]:
+        assert abs(cost - ref["cost"]) <= 1e-9 * ref["cost"]
+        path = md["path"] - 1
+        for a, b in zip(path[:-1], path[1:]):
+            assert orc.car_is_free_motion(2, X[a], X[b], rt, 1.0, lohi, SS.lo, SS.hi)[0]

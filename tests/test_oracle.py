@@ -275,3 +275,64 @@ def test_dubins_oracle_against_transliteration():
     c, _ = orc.dubins([0, 0, 0], [1, 1, np.pi / 2], 1.0, 1.0)
     cj, _ = jl.dubins([0, 0, 0], [1, 1, np.pi / 2], 1.0, 1.0)
     assert abs(c - cj) <= 1e-14 * c and c >= np.pi / 2 - 1e-12
+
+
+def test_reedsshepp_oracle_against_transliteration():
+    """Reeds-Shepp steering (simplecars.jl:266-364 and the word families :367-553): oracle = independent transliteration on
+    costs, controls and collision waypoints, every path reaches its target, and allowing reverse never costs more than the
+    Dubins word between the same poses."""
+    from oracle import oracle as orc
+    import jl_transliteration as jl
+    rng = np.random.default_rng(12)
+    for k in range(3000):
+        s1 = np.array([rng.random(), rng.random(), rng.random() * 2 * np.pi])
+        s2 = np.array([rng.random(), rng.random(), rng.random() * 2 * np.pi])
+        rt = [0.05, 0.2, 1.0][k % 3]
+        c, p = orc.reedsshepp(s1, s2, rt, 1.0)
+        cj, pj = jl.reedsshepp(s1, s2, rt, 1.0)
+        pj = np.array(pj)
+        assert p.shape == pj.shape and abs(c - cj) <= 1e-14 * c
+        assert np.array_equal(p[:, 1:], pj[:, 1:]) and np.allclose(p, pj, rtol=0, atol=1e-14)
+        assert abs(np.abs(p[:, 0]).sum() - c) <= 1e-12 * c
+        assert c <= orc.dubins(s1, s2, rt, 1.0)[0] * (1 + 1e-12)
+        v = tuple(s1)
+        for u in p:
+            v = jl.car_propagate(v, u)
+        assert abs(v[0] - s2[0]) < 1e-9 and abs(v[1] - s2[1]) < 1e-9
+        assert min(abs(v[2] - s2[2]), 2 * np.pi - abs(v[2] - s2[2])) < 1e-9
+        w1 = orc.car_waypoints(2, s1, s2, rt, 1.0)
+        w2 = np.array(jl.car_collision_waypoints_rs(s1, s2, rt, 1.0))
+        assert w1.shape == w2.shape and np.allclose(w1, w2, rtol=0, atol=1e-14)
+    # known answers: straight ahead, and straight back (one reversed straight segment of the same length)
+    c, p = orc.reedsshepp([0, 0, 0], [1, 0, 0], 1.0, 1.0)
+    assert abs(c - 1.0) < 1e-15
+    c, p = orc.reedsshepp([1, 0, 0], [0, 0, 0], 1.0, 1.0)
+    assert abs(c - 1.0) < 1e-12 and (p[np.abs(p[:, 0]) > 1e-12][:, 1] < 0).all()
+
+
+def test_reedsshepp_oracle_graph_and_plan():
+    """inball sets of the chopped Reeds-Shepp metric and a plan over them: neighbourhoods are symmetric as sets (a metric),
+    every edge of the plan is a free motion, cumulative costs add up."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(5)
+    N, rt, r = 400, 0.1, 0.3
+    X = np.column_stack([rng.random(N), rng.random(N), rng.random(N) * 2 * np.pi])
+    X[0] = [0.05, 0.05, 0.6]; X[-1] = [0.95, 0.95, 0.8]
+    c0 = 0.2 + 0.6 * rng.random((8, 2)); h = 0.02 + 0.05 * rng.random((8, 2))
+    lohi = np.stack([c0 - h, c0 + h], axis=1)
+    lo, hi = np.array([0.0, 0.0, 0.0]), np.array([1.0, 1.0, 2 * np.pi])
+    colptr, rowval, nzval = orc.rs_graph(X, rt, 1.0, r)
+    cols = np.repeat(np.arange(N), np.diff(colptr))
+    fwd = set(zip(cols.tolist(), rowval.tolist())); bwd = set(zip(rowval.tolist(), cols.tolist()))
+    for (a, b) in fwd ^ bwd:                                             # only pairs whose two directions straddle r in the last bits
+        assert abs(orc.reedsshepp(X[a], X[b], rt, 1.0)[0] - r) < 1e-9
+    assert len(rowval) > 5 * N and (nzval <= r).all()
+    res = orc.rs_fmtstar(X, rt, 1.0, colptr, rowval, nzval, orc.GOAL_BALL, np.array([0.95, 0.95, 0.08]), lohi, lo, hi)
+    assert res["rc"] == 0 and res["status"] == 1
+    path = res["path"]
+    tot = 0.0
+    for a, b in zip(path[:-1], path[1:]):
+        assert orc.car_is_free_motion(2, X[a], X[b], rt, 1.0, lohi, lo, hi)[0]
+        assert res["A"][b] == a
+        tot += orc.reedsshepp(X[b], X[a], rt, 1.0)[0]                    # inball(b) holds d(b, a)   (fmt.jl:70-75)
+    assert abs(tot - res["cost"]) <= 1e-12 * tot
