@@ -200,6 +200,27 @@ int32_t mpfmt_reedsshepp_steer(mpfmt_ctx* ctx, const double* X0, const double* X
 int32_t mpfmt_reedsshepp_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
                                  int32_t goal_kind, const double* goal_params, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
+/* ---- Closest obstacle points in a Mahalanobis metric: closest(p, CC, W) / closeR(p, CC, W, r2) of
+ *      src/collisioncheckers/boxesND.jl:33-34,61-86 (boxes, through bvls of src/collisioncheckers/bvls.jl:19-218) and
+ *      src/collisioncheckers/robots2D.jl:25-26 + SAT2D.jl:208-285 (circles / convex polygons / compounds), batched over n
+ *      query points P [n][dw] against the ctx's current obstacle set (mpfmt_upload_boxes or mpfmt_upload_shapes2d).
+ *      W [dw][dw] symmetric positive definite; W = NULL selects the Euclidean SAT2D methods (:208-211, :239, :260-269) and
+ *      is an error for boxes (the reference has no such method).
+ *      mpfmt_closest : d2min[i], vmin[i][dw] and kmin[i] (1-based obstacle, 0 = none) = the minimum over the obstacles
+ *             with strict < (first minimum wins); no obstacle: (Inf, p) for boxes, (Inf, 0) for shapes, as the reference.
+ *      mpfmt_closeR  : per point the obstacles with d2 < r2 in ascending d2 (ties in obstacle order: the reference's
+ *             sort! is stable): ptr [n+1] 1-based offsets (always written), then obstacle / d2 / v [*total][dw];
+ *             MPFMT_ERR_CAPACITY with *total set when *total > cap (nothing else written).
+ *      *failures (may be NULL) counts the (point, box) pairs on which the reference's bvls exhausts its 10n iterations and
+ *             returns `nothing` (closest() then throws a MethodError) -- the same pairs are detected here, reported and
+ *             left out of the minimum / the lists; for circles, pairs whose multiplier iteration (SAT2D.jl:222-235,
+ *             unbounded in the reference) has not ended after 200 Newton steps.
+ *      Values agree with the reference's LAPACK route (QR least squares, eigfact) to rounding, not bit for bit. */
+int32_t mpfmt_closest(mpfmt_ctx* ctx, const double* P, int64_t n, const double* W, double* d2min, double* vmin, int64_t* kmin,
+                      int64_t* failures);
+int32_t mpfmt_closeR(mpfmt_ctx* ctx, const double* P, int64_t n, const double* W, double r2, int64_t* ptr, int64_t cap,
+                     int64_t* obstacle, double* d2, double* v, int64_t* total, int64_t* failures);
+
 /* ---- 2-D SAT world: PointRobot2D(Compound2D(parts)) of src/collisioncheckers/robots2D.jl:12-14 and
  *      SAT2D.jl -- parts are Circle(c, r) (:14-28) and convex Polygon(points) (:32-58; Box2D = 4-point polygon, :59-62).
  *      Switches the ctx's collision checker: afterwards mpfmt_points_free / _states_free = is_free_state (point vs

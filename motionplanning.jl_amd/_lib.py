@@ -73,6 +73,9 @@ SYMBOLS = [
                                            C.POINTER(C.c_int32)]),
     ("mpfmt_reedsshepp_fmtstar", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
                                              c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
+    ("mpfmt_closest", C.c_int32, [C.c_void_p, c_d_p, C.c_int64, c_d_p, c_d_p, c_d_p, c_i64_p, c_i64_p]),
+    ("mpfmt_closeR", C.c_int32, [C.c_void_p, c_d_p, C.c_int64, c_d_p, C.c_double, c_i64_p, C.c_int64, c_i64_p, c_d_p, c_d_p,
+                                 c_i64_p, c_i64_p]),
     ("mpfmt_upload_shapes2d", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_d_p, c_d_p, c_d_p]),
     ("mpfmt_graph_import", C.c_int32, [C.c_void_p, C.c_double, c_i64_p, c_i64_p, c_d_p]),
     ("mpfmt_sample_free", C.c_int32, [C.c_void_p, C.c_uint64, C.c_int64, c_d_p, C.c_int32, c_d_p, C.c_int32, c_d_p, c_i64_p]),
@@ -424,6 +427,36 @@ class Context:
 
     def reedsshepp_fmtstar(self, turn_radius, speed, r, goal_kind, goal_params, init_idx=1, checkpts=True):
         return self._car_fmtstar("reedsshepp", turn_radius, speed, r, goal_kind, goal_params, init_idx, checkpts)
+
+    # ---- closest obstacle points ----------------------------------------------------------------
+    def closest(self, P, W=None):
+        """closest(p, CC, W) per row of P: (d2min, vmin, kmin 1-based / 0, failures)."""
+        P = np.ascontiguousarray(np.atleast_2d(P), dtype=np.float64)
+        n, d = P.shape
+        Wp = None if W is None else _dp(np.ascontiguousarray(W, dtype=np.float64).reshape(d, d))
+        d2 = np.empty(max(n, 1)); v = np.empty((max(n, 1), d)); k = np.empty(max(n, 1), dtype=np.int64)
+        fails = C.c_int64()
+        self._chk(self._L.mpfmt_closest(self._h, _dp(P), n, Wp, _dp(d2), _dp(v), _ip(k), C.byref(fails)))
+        return d2[:n], v[:n], k[:n], fails.value
+
+    def closeR(self, P, W, r2):
+        """closeR(p, CC, W, r2) per row of P: (ptr 1-based, obstacle 1-based, d2, v, failures)."""
+        P = np.ascontiguousarray(np.atleast_2d(P), dtype=np.float64)
+        n, d = P.shape
+        Wa = np.ascontiguousarray(W, dtype=np.float64).reshape(d, d)
+        ptr = np.empty(n + 1, dtype=np.int64)
+        total = C.c_int64(); fails = C.c_int64()
+        cap = max(4 * n, 1024)
+        while True:
+            idx = np.empty(cap, dtype=np.int64); d2 = np.empty(cap); v = np.empty((cap, d))
+            rc = self._L.mpfmt_closeR(self._h, _dp(P), n, _dp(Wa), float(r2), _ip(ptr), cap, _ip(idx), _dp(d2), _dp(v),
+                                      C.byref(total), C.byref(fails))
+            if rc == ERR_CAPACITY:
+                cap = total.value
+                continue
+            self._chk(rc)
+            t = total.value
+            return ptr, idx[:t], d2[:t], v[:t], fails.value
 
     def graph_import(self, r, colptr, rowval, nzval):
         """Install an exported graph (1-based CSC as returned by rdisc_graph) for the uploaded samples."""

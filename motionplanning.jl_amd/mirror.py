@@ -230,6 +230,42 @@ def is_free_motion(v, w, CC, SS, ctx):
     return bool(out[0]) if np.ndim(v) == 1 else out
 
 
+# ---- closest obstacle points (boxesND.jl:33-34,61-86; robots2D.jl:25-26; SAT2D.jl:208-285) ------------------------------
+def _closest_ctx(CC, ctx, d):
+    ctx = CC._ctx if ctx is None else ctx
+    if ctx is None:
+        raise ValueError("the collision checker is not bound to a device context yet: pass ctx=")
+    if CC._ctx is not ctx:
+        if isinstance(CC, PointRobot2D):
+            ctx.upload_shapes2d(CC.obstacles.parts(), None, None)
+        else:
+            ctx.upload_boxes(CC.lohi(), None, None, dw=d)
+        CC._ctx, CC._ss = ctx, None
+    return ctx
+
+
+def closest(p, CC, W=None, ctx=None):
+    """closest(p, CC, W): (d2min, vmin) for p (d,), arrays for p (n, d).  Raises where the reference throws (bvls returned
+    `nothing` for some box)."""
+    Pm = np.atleast_2d(np.asarray(p, dtype=np.float64))
+    ctx = _closest_ctx(CC, ctx, Pm.shape[1])
+    d2, v, _, fails = ctx.closest(Pm, W)
+    if fails:
+        raise RuntimeError("bvls exhausted its iterations on %d (point, box) pair(s): the reference throws here (bvls.jl:67)" % fails)
+    return (float(d2[0]), v[0]) if np.ndim(p) == 1 else (d2, v)
+
+
+def closeR(p, CC, W, r2, ctx=None):
+    """closeR(p, CC, W, r2): [(d2, v), ...] ascending for p (d,); a list of such lists for p (n, d)."""
+    Pm = np.atleast_2d(np.asarray(p, dtype=np.float64))
+    ctx = _closest_ctx(CC, ctx, Pm.shape[1])
+    ptr, _, d2, v, fails = ctx.closeR(Pm, W, r2)
+    if fails:
+        raise RuntimeError("bvls exhausted its iterations on %d (point, box) pair(s): the reference throws here (bvls.jl:67)" % fails)
+    out = [[(float(d2[e]), v[e]) for e in range(ptr[i] - 1, ptr[i + 1] - 1)] for i in range(len(Pm))]
+    return out[0] if np.ndim(p) == 1 else out
+
+
 # ---- goals (src/goals.jl) -----------------------------------------------------------------------------------------------
 class RectangleGoal:
     kind = _lib.GOAL_RECT

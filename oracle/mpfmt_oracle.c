@@ -1816,3 +1816,363 @@ int32_t orc_rs_fmtstar(const double *X, int64_t N, double rt, double sp, int64_t
     free(F); free(Wm); free(Hm); free(Hnew); free(rev); free(heap.pri); free(heap.idx);
     return 0;
 }
+
+/* ======================================================================================================================
+ * Closest obstacle points in a Mahalanobis metric: closest / closeR of
+ * src/collisioncheckers/boxesND.jl:61-86 (boxes, through bvls.jl:19-222) and src/collisioncheckers/SAT2D.jl:208-285
+ * (circles, convex polygons, compounds).  Test infrastructure like the rest of this file.
+ * ==================================================================================================================== */
+
+/* chol(W) (boxesND.jl:65): the upper factor U with U'U = W; returns -1 when W is not positive definite */
+static int chol_upper(const double *W, int n, double U[ORC_MAXD][ORC_MAXD])
+{
+    for (int j = 0; j < n; ++j) {
+        for (int i = 0; i < n; ++i) U[j][i] = 0.0;
+        double s = W[j * n + j];
+        for (int k = 0; k < j; ++k) s = s - U[k][j] * U[k][j];
+        if (!(s > 0.0)) return -1;
+        U[j][j] = sqrt(s);
+        for (int i = j + 1; i < n; ++i) {
+            double t = W[j * n + i];
+            for (int k = 0; k < j; ++k) t = t - U[k][j] * U[k][i];
+            U[j][i] = t / U[j][j];
+        }
+    }
+    return 0;
+}
+
+/* z = A \ b for an m x k matrix of full column rank, k <= m (bvls.jl:136): Householder QR, then back substitution.
+ * A and b are overwritten. */
+static void ls_solve(int m, int k, double A[ORC_MAXD][ORC_MAXD], double *b, double *z)
+{
+    for (int j = 0; j < k; ++j) {
+        double nrm = 0.0;
+        for (int i = j; i < m; ++i) nrm = nrm + A[i][j] * A[i][j];
+        nrm = sqrt(nrm);
+        if (nrm == 0.0) continue;
+        const double alpha = (A[j][j] > 0.0) ? -nrm : nrm;
+        double v[ORC_MAXD];
+        for (int i = j; i < m; ++i) v[i] = A[i][j];
+        v[j] = v[j] - alpha;
+        double vv = 0.0;
+        for (int i = j; i < m; ++i) vv = vv + v[i] * v[i];
+        if (vv == 0.0) continue;
+        for (int c = j; c < k; ++c) {
+            double s = 0.0;
+            for (int i = j; i < m; ++i) s = s + v[i] * A[i][c];
+            s = 2.0 * s / vv;
+            for (int i = j; i < m; ++i) A[i][c] = A[i][c] - s * v[i];
+        }
+        double s = 0.0;
+        for (int i = j; i < m; ++i) s = s + v[i] * b[i];
+        s = 2.0 * s / vv;
+        for (int i = j; i < m; ++i) b[i] = b[i] - s * v[i];
+    }
+    for (int j = k - 1; j >= 0; --j) {
+        double s = b[j];
+        for (int c = j + 1; c < k; ++c) s = s - A[j][c] * z[c];
+        z[j] = s / A[j][j];
+    }
+}
+
+/* bvls(A, b, l, u) (bvls.jl:19-218), A n x n here.  Returns the iteration count, or -1 when the 10n iterations run out
+ * (the reference then returns `nothing`).  The bookkeeping quirks are kept: a freed variable that wants to leave through
+ * its own bound is locked again with state 0 (:151-164, state was zeroed at :113), and criti persists across iterations. */
+int32_t orc_bvls(int32_t n, const double *Aflat, const double *b, const double *l, const double *u, double *x)
+{
+    double A[ORC_MAXD][ORC_MAXD];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[i][j] = Aflat[i * n + j];
+    int oops[ORC_MAXD] = {0}, state[ORC_MAXD], atbound[ORC_MAXD] = {0}, between[ORC_MAXD] = {0};
+    int criti = -1, crits = 0;
+    const double myeps = 1.0e-10;
+    for (int i = 0; i < n; ++i) {                                                            /* :41-63 */
+        if (u[i] >= INFINITY && l[i] <= -INFINITY) { x[i] = 0.0; state[i] = 0; between[i] = 1; }
+        else if (u[i] >= INFINITY) { x[i] = l[i]; state[i] = 1; atbound[i] = 1; }
+        else if (l[i] <= -INFINITY) { x[i] = u[i]; state[i] = 2; atbound[i] = 1; }
+        else if (fabs(l[i]) <= fabs(u[i])) { x[i] = l[i]; state[i] = 1; atbound[i] = 1; }
+        else { x[i] = u[i]; state[i] = 2; atbound[i] = 1; }
+    }
+    double nb = 0.0;
+    for (int i = 0; i < n; ++i) nb = nb + b[i] * b[i];
+    nb = sqrt(nb);
+    for (int iter = 1; iter <= 10 * n; ++iter) {                                            /* :67-69 */
+        double res[ORC_MAXD], grad[ORC_MAXD];
+        for (int i = 0; i < n; ++i) { double s = 0.0; for (int j = 0; j < n; ++j) s = s + A[i][j] * x[j]; res[i] = s - b[i]; }
+        for (int j = 0; j < n; ++j) { double s = 0.0; for (int i = 0; i < n; ++i) s = s + A[i][j] * res[i]; grad[j] = oops[j] ? 0.0 : s; }   /* :73-77 */
+        int done = 1;
+        for (int i = 0; i < n; ++i)                                                          /* :81-89 */
+            if ((fabs(grad[i]) > (1.0 + nb) * myeps && state[i] == 0) || (grad[i] < 0.0 && state[i] == 1) || (grad[i] > 0.0 && state[i] == 2)) { done = 0; break; }
+        if (done) return iter;
+        int newi = -1; double newg = 0.0;                                                    /* :94-112 */
+        for (int i = 0; i < n; ++i) {
+            if (!atbound[i] || i == criti) continue;
+            if (grad[i] > 0.0 && state[i] == 2 && fabs(grad[i]) > newg) { newi = i; newg = fabs(grad[i]); }
+            if (grad[i] < 0.0 && state[i] == 1 && fabs(grad[i]) > newg) { newi = i; newg = fabs(grad[i]); }
+        }
+        if (newi >= 0) { atbound[newi] = 0; state[newi] = 0; between[newi] = 1; }           /* :116-120 */
+        double Ap[ORC_MAXD][ORC_MAXD], bp[ORC_MAXD], z[ORC_MAXD], xnew[ORC_MAXD];
+        int cols[ORC_MAXD], k = 0;
+        for (int j = 0; j < n; ++j) if (between[j]) cols[k++] = j;
+        for (int i = 0; i < n; ++i) {                                                        /* :131-138 */
+            double s = 0.0;
+            for (int j = 0; j < n; ++j) if (atbound[j]) s = s + A[i][j] * x[j];
+            bp[i] = b[i] - s;
+            for (int c = 0; c < k; ++c) Ap[i][c] = A[i][cols[c]];
+        }
+        ls_solve(n, k, Ap, bp, z);                                                           /* :142 */
+        for (int i = 0; i < n; ++i) xnew[i] = x[i];
+        for (int c = 0; c < k; ++c) xnew[cols[c]] = z[c];
+        if (newi >= 0 && ((xnew[newi] <= l[newi] && x[newi] == l[newi]) || (xnew[newi] >= u[newi] && x[newi] == u[newi]))) {   /* :146-165 */
+            oops[newi] = 1;
+            if (xnew[newi] <= l[newi] && state[newi] == 1) { state[newi] = 1; x[newi] = l[newi]; }
+            if (xnew[newi] >= u[newi] && state[newi] == 2) { state[newi] = 2; x[newi] = u[newi]; }
+            atbound[newi] = 1; between[newi] = 0;
+            continue;
+        }
+        for (int i = 0; i < n; ++i) oops[i] = 0;                                             /* :169 */
+        double alpha = 1.0;                                                                  /* :174-195 */
+        for (int i = 0; i < n; ++i) {
+            if (!between[i]) continue;
+            if (xnew[i] > u[i]) { const double na = fmin(alpha, (u[i] - x[i]) / (xnew[i] - x[i])); if (na < alpha) { criti = i; crits = 2; alpha = na; } }
+            if (xnew[i] < l[i]) { const double na = fmin(alpha, (l[i] - x[i]) / (xnew[i] - x[i])); if (na < alpha) { criti = i; crits = 1; alpha = na; } }
+        }
+        for (int i = 0; i < n; ++i) x[i] = x[i] + alpha * (xnew[i] - x[i]);                  /* :199 */
+        if (alpha < 1.0) { between[criti] = 0; atbound[criti] = 1; state[criti] = crits; }   /* :203-207 */
+        for (int i = 0; i < n; ++i) {                                                        /* :209-222 */
+            if (x[i] >= u[i]) { x[i] = u[i]; state[i] = 2; between[i] = 0; atbound[i] = 1; }
+            if (x[i] <= l[i]) { x[i] = l[i]; state[i] = 1; between[i] = 0; atbound[i] = 1; }
+        }
+    }
+    return -1;
+}
+
+static double quad_form(const double *W, int n, const double *v, const double *p)      /* dot(v - p, W*(v - p)) */
+{
+    double t[ORC_MAXD], acc = 0.0;
+    for (int i = 0; i < n; ++i) t[i] = v[i] - p[i];
+    for (int i = 0; i < n; ++i) { double s = 0.0; for (int j = 0; j < n; ++j) s = s + W[i * n + j] * t[j]; acc = acc + t[i] * s; }
+    return acc;
+}
+
+/* closest(p, BB, W) (boxesND.jl:61-70): d2min; v = closest point of the box lo..hi.  Returns bvls' iteration count, -1 on
+ * its failure, -2 when W is not positive definite. */
+int32_t orc_closest_box(const double *p, const double *lo, const double *hi, const double *W, int32_t n, double *d2, double *v)
+{
+    double U[ORC_MAXD][ORC_MAXD], A[ORC_MAXD * ORC_MAXD], b[ORC_MAXD];
+    if (chol_upper(W, n, U)) return -2;
+    for (int i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) { A[i * n + j] = U[i][j]; s = s + U[i][j] * p[j]; }
+        b[i] = s;
+    }
+    const int32_t it = orc_bvls(n, A, b, lo, hi, v);
+    if (it < 0) { *d2 = NAN; return it; }
+    *d2 = quad_form(W, n, v, p);
+    return it;
+}
+
+/* closest(p, BL, W) (boxesND.jl:72-81) for each of the n points: strict <, so the first minimum wins; no boxes: (Inf, p).
+ * lohi [M][2][d]; kmin 0-based, -1 = none.  Returns the number of bvls failures. */
+int64_t orc_closest_boxes(const double *P, int64_t n, const double *lohi, int32_t M, const double *W, int32_t d,
+                          double *d2min, double *vmin, int64_t *kmin)
+{
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *p = P + (size_t)i * d;
+        double best = INFINITY; int64_t kb = -1;
+        for (int q = 0; q < d; ++q) vmin[(size_t)i * d + q] = p[q];
+        for (int32_t k = 0; k < M; ++k) {
+            double d2, v[ORC_MAXD];
+            if (orc_closest_box(p, lohi + (size_t)k * 2 * d, lohi + (size_t)k * 2 * d + d, W, d, &d2, v) < 0) { ++bad; continue; }
+            if (d2 < best) { best = d2; kb = k; for (int q = 0; q < d; ++q) vmin[(size_t)i * d + q] = v[q]; }
+        }
+        d2min[i] = best; if (kmin) kmin[i] = kb;
+    }
+    return bad;
+}
+
+typedef struct { double d2; int32_t k; double v[ORC_MAXD]; } orc_cp;
+static void cp_sort(orc_cp *a, int n)                      /* stable (sort! by=first is a merge sort): insertion sort, strict > */
+{
+    for (int i = 1; i < n; ++i) {
+        orc_cp t = a[i]; int j = i - 1;
+        while (j >= 0 && a[j].d2 > t.d2) { a[j + 1] = a[j]; --j; }
+        a[j + 1] = t;
+    }
+}
+
+/* closeR(p, BL, W, r2) (boxesND.jl:83-86) for each point: obstacles with d2 < r2, ascending d2 (ties in obstacle order).
+ * ptr [n+1] always written; idx / d2 / v (may be NULL: counting pass) receive the lists back to back. */
+int64_t orc_closeR_boxes(const double *P, int64_t n, const double *lohi, int32_t M, const double *W, int32_t d, double r2,
+                         int64_t *ptr, int64_t *idx, double *d2out, double *vout)
+{
+    orc_cp *cps = (orc_cp *)malloc(sizeof(orc_cp) * (size_t)(M > 0 ? M : 1));
+    int64_t tot = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *p = P + (size_t)i * d;
+        int c = 0;
+        for (int32_t k = 0; k < M; ++k) {
+            orc_cp t; t.k = k;
+            if (orc_closest_box(p, lohi + (size_t)k * 2 * d, lohi + (size_t)k * 2 * d + d, W, d, &t.d2, t.v) < 0) continue;
+            if (t.d2 < r2) cps[c++] = t;
+        }
+        cp_sort(cps, c);
+        ptr[i] = tot;
+        if (idx) for (int j = 0; j < c; ++j) {
+            idx[tot + j] = cps[j].k; d2out[tot + j] = cps[j].d2;
+            for (int q = 0; q < d; ++q) vout[(size_t)(tot + j) * d + q] = cps[j].v[q];
+        }
+        tot += c;
+    }
+    ptr[n] = tot;
+    free(cps);
+    return tot;
+}
+
+/* ---- 2-D shapes (SAT2D.jl:208-285) ---- */
+
+/* eigfact of the symmetric 2x2 W: ascending values, orthonormal vectors (closed form; LAPACK differs in the last bits and
+ * possibly in the vectors' signs, which cancel in every use below) */
+static void eig2(const double *W, double *s1, double *s2, double *v1, double *v2)
+{
+    const double a = W[0], b = 0.5 * (W[1] + W[2]), c = W[3];
+    const double h = 0.5 * (a - c), m = 0.5 * (a + c), rad = sqrt(h * h + b * b);
+    *s1 = m - rad; *s2 = m + rad;
+    if (b == 0.0) {
+        if (a <= c) { v1[0] = 1.0; v1[1] = 0.0; v2[0] = 0.0; v2[1] = 1.0; }
+        else        { v1[0] = 0.0; v1[1] = 1.0; v2[0] = 1.0; v2[1] = 0.0; }
+        return;
+    }
+    /* eigenvector of s2: (b, s2 - a) or (s2 - c, b), whichever has the larger first-step magnitude */
+    double e0, e1;
+    if (fabs(*s2 - a) >= fabs(*s2 - c)) { e0 = b; e1 = *s2 - a; } else { e0 = *s2 - c; e1 = b; }
+    const double nn = sqrt(e0 * e0 + e1 * e1);
+    v2[0] = e0 / nn; v2[1] = e1 / nn;
+    v1[0] = -v2[1]; v1[1] = v2[0];
+}
+
+#define CIRC_F(lam) (((p1 * s1 / ((lam) + s1)) * (p1 * s1 / ((lam) + s1)) + (p2 * s2 / ((lam) + s2)) * (p2 * s2 / ((lam) + s2))) - C->r * C->r)
+/* closest(p, C::Circle, EF) (SAT2D.jl:213-238): Newton on the multiplier with the reference's halving line search.  The
+ * reference's loops are unbounded; 200 Newton steps / 64 halvings stop a run that would not have ended there either
+ * (returns -1, outputs NaN). */
+static int closest_circle_W(const double *p, const orc_shape2d *C, const double *W, double *d2, double *x)
+{
+    double s1, s2, v1[2], v2[2];
+    eig2(W, &s1, &s2, v1, v2);
+    const double ctop[2] = {p[0] - C->c[0], p[1] - C->c[1]};
+    const double p1 = dot2(v1, ctop), p2 = dot2(v2, ctop);
+    double lambda = 1.0;
+    double f = CIRC_F(lambda);
+    int it = 0;
+    while (fabs(f) > 1e-8) {
+        if (++it > 200 || !(f == f)) { *d2 = NAN; x[0] = x[1] = NAN; return -1; }
+        const double q1 = p1 * s1 / (lambda + s1), q2 = p2 * s2 / (lambda + s2);
+        const double fp = -2.0 / (lambda + s1) * (q1 * q1) + -2.0 / (lambda + s2) * (q2 * q2);
+        double alpha = 1.0, lnew = 1.0, fnew = 1.0;
+        int h = 0;
+        for (;;) {
+            lnew = lambda - alpha * f / fp;
+            fnew = CIRC_F(lnew);
+            if (fabs(fnew) < fabs(f)) break;
+            alpha = alpha / 2.0;
+            if (++h > 64) { *d2 = NAN; x[0] = x[1] = NAN; return -1; }
+        }
+        f = fnew; lambda = lnew;
+    }
+    const double k1 = p1 * s1 / (lambda + s1), k2 = p2 * s2 / (lambda + s2);
+    x[0] = (C->c[0] + v1[0] * k1) + v2[0] * k2;
+    x[1] = (C->c[1] + v1[1] * k1) + v2[1] * k2;
+    *d2 = s1 * ((p1 - k1) * (p1 - k1)) + s2 * ((p2 - k2) * (p2 - k2));
+    return 0;
+}
+
+/* closest_polypts (SAT2D.jl:240-254) */
+static void closest_polypts(const double *p, const double (*pts)[2], int n, double *d2min, double *vmin)
+{
+    *d2min = INFINITY; vmin[0] = pts[0][0]; vmin[1] = pts[0][1];
+    for (int i = 0; i < n; ++i) {
+        const int nx = (i + 1 < n) ? i + 1 : 0;
+        const double e[2] = {pts[nx][0] - pts[i][0], pts[nx][1] - pts[i][1]};
+        const double w[2] = {p[0] - pts[i][0], p[1] - pts[i][1]};
+        const double t = dot2(e, w) / dot2(e, e);
+        double v[2];
+        if (t < 0.0) { v[0] = pts[i][0]; v[1] = pts[i][1]; }
+        else if (t < 1.0) { v[0] = pts[i][0] + t * e[0]; v[1] = pts[i][1] + t * e[1]; }
+        else { v[0] = pts[nx][0]; v[1] = pts[nx][1]; }
+        const double u[2] = {p[0] - v[0], p[1] - v[1]};
+        const double dd = dot2(u, u);
+        if (dd < *d2min) { *d2min = dd; vmin[0] = v[0]; vmin[1] = v[1]; }
+    }
+}
+
+/* closest(p, S [, W]) for one shape; W == NULL: the Euclidean methods (SAT2D.jl:208-211, 239).  Returns 0, -1 (circle
+ * iteration did not end), -2 (W not positive definite). */
+int32_t orc_closest_shape(const double *p, const void *shape, const double *W, double *d2, double *x)
+{
+    const orc_shape2d *S = (const orc_shape2d *)shape;
+    if (!W) {
+        if (S->kind == 0) {
+            const double v[2] = {p[0] - S->c[0], p[1] - S->c[1]};
+            const double nv = sqrt(dot2(v, v));
+            x[0] = S->c[0] + S->r * (v[0] / nv); x[1] = S->c[1] + S->r * (v[1] / nv);
+            const double u[2] = {p[0] - x[0], p[1] - x[1]};
+            *d2 = dot2(u, u);
+        } else closest_polypts(p, S->pts, S->n, d2, x);
+        return 0;
+    }
+    if (S->kind == 0) return closest_circle_W(p, S, W, d2, x);
+    double U[ORC_MAXD][ORC_MAXD];                                                            /* SAT2D.jl:255-259 */
+    if (chol_upper(W, 2, U)) return -2;
+    double tp[ORC_MAXPOLY][2];
+    for (int i = 0; i < S->n; ++i) { tp[i][0] = U[0][0] * S->pts[i][0] + U[0][1] * S->pts[i][1]; tp[i][1] = U[1][1] * S->pts[i][1]; }
+    const double lp[2] = {U[0][0] * p[0] + U[0][1] * p[1], U[1][1] * p[1]};
+    double dd, y[2];
+    closest_polypts(lp, tp, S->n, &dd, y);
+    const double det = U[0][0] * U[1][1];                                                    /* inv of the 2x2 SMatrix: adjugate / det */
+    x[0] = (U[1][1] / det) * y[0] + (-U[0][1] / det) * y[1];
+    x[1] = (U[0][0] / det) * y[1];
+    *d2 = quad_form(W, 2, x, p);
+    return 0;
+}
+
+/* closest(p, C::Compound2D [, W]) (SAT2D.jl:260-279) per point: strict <, init (Inf, zeros).  Returns failures. */
+int64_t orc_closest_shapes(const double *P, int64_t n, const void *shapes, int32_t M, const double *W, double *d2min, double *vmin, int64_t *kmin)
+{
+    const orc_shape2d *S = (const orc_shape2d *)shapes;
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double best = INFINITY; int64_t kb = -1;
+        vmin[2 * i] = 0.0; vmin[2 * i + 1] = 0.0;
+        for (int32_t k = 0; k < M; ++k) {
+            double d2, v[2];
+            if (orc_closest_shape(P + 2 * i, S + k, W, &d2, v)) { ++bad; continue; }
+            if (d2 < best) { best = d2; kb = k; vmin[2 * i] = v[0]; vmin[2 * i + 1] = v[1]; }
+        }
+        d2min[i] = best; if (kmin) kmin[i] = kb;
+    }
+    return bad;
+}
+
+/* closeR(p, C::Compound2D, W, r2) (SAT2D.jl:281-285) per point */
+int64_t orc_closeR_shapes(const double *P, int64_t n, const void *shapes, int32_t M, const double *W, double r2,
+                          int64_t *ptr, int64_t *idx, double *d2out, double *vout)
+{
+    const orc_shape2d *S = (const orc_shape2d *)shapes;
+    orc_cp *cps = (orc_cp *)malloc(sizeof(orc_cp) * (size_t)(M > 0 ? M : 1));
+    int64_t tot = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int c = 0;
+        for (int32_t k = 0; k < M; ++k) {
+            orc_cp t; t.k = k;
+            if (orc_closest_shape(P + 2 * i, S + k, W, &t.d2, t.v)) continue;
+            if (t.d2 < r2) cps[c++] = t;
+        }
+        cp_sort(cps, c);
+        ptr[i] = tot;
+        if (idx) for (int j = 0; j < c; ++j) { idx[tot + j] = cps[j].k; d2out[tot + j] = cps[j].d2; vout[2 * (tot + j)] = cps[j].v[0]; vout[2 * (tot + j) + 1] = cps[j].v[1]; }
+        tot += c;
+    }
+    ptr[n] = tot;
+    free(cps);
+    return tot;
+}

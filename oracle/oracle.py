@@ -536,3 +536,62 @@ def rs_fmtstar(X, rt, sp, colptr, rowval, nzval, goal_kind, goal, lohi, ss_lo, s
                               _d(_vec(ss_lo)), _d(_vec(ss_hi)), _i(A), _d(Cc), _i(path), C.byref(res))
     return dict(rc=rc, status=int(res.status), cost=float(res.cost), z=int(res.z), collision_checks=int(res.collision_checks),
                 A=A, C=Cc, path=path[:res.path_len].copy())
+
+
+# ---- closest obstacle points in a Mahalanobis metric --------------------------------------------------
+def bvls(A, b, l, u):
+    """bvls(A, b, l, u) of bvls.jl:19-218 (A square); returns (x, iterations) -- iterations < 0: ran out (`nothing`)."""
+    A = np.ascontiguousarray(A, dtype=np.float64); n = A.shape[0]
+    b = _vec(b); l = _vec(l); u = _vec(u); x = np.zeros(n)
+    it = lib().orc_bvls(C.c_int32(n), _d(A), _d(b), _d(l), _d(u), _d(x))
+    return x, int(it)
+
+
+def _W(W, d):
+    W = np.ascontiguousarray(W, dtype=np.float64)
+    assert W.shape == (d, d)
+    return W
+
+
+def closest_boxes(P, lohi, W):
+    """closest(p, BL, W) (boxesND.jl:72-81) per point: (d2min, vmin, kmin 0-based / -1, failures).  failures = (point, box)
+    pairs on which bvls ran out of its 10n iterations (the reference then throws); they are skipped in the minimum."""
+    P = np.ascontiguousarray(np.atleast_2d(P), dtype=np.float64); n, d = P.shape
+    lohi, M = _boxes(lohi, d); W = _W(W, d)
+    d2 = np.zeros(max(n, 1)); v = np.zeros((max(n, 1), d)); k = np.zeros(max(n, 1), dtype=np.int64)
+    L = lib(); L.orc_closest_boxes.restype = C.c_int64
+    bad = L.orc_closest_boxes(_d(P), C.c_int64(n), _d(lohi), C.c_int32(M), _d(W), C.c_int32(d), _d(d2), _d(v), _i(k))
+    return d2[:n], v[:n], k[:n], int(bad)
+
+
+def closeR_boxes(P, lohi, W, r2):
+    """closeR(p, BL, W, r2) (boxesND.jl:83-86) per point as (ptr, idx 0-based, d2, v)."""
+    P = np.ascontiguousarray(np.atleast_2d(P), dtype=np.float64); n, d = P.shape
+    lohi, M = _boxes(lohi, d); W = _W(W, d)
+    L = lib(); L.orc_closeR_boxes.restype = C.c_int64
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    tot = int(L.orc_closeR_boxes(_d(P), C.c_int64(n), _d(lohi), C.c_int32(M), _d(W), C.c_int32(d), C.c_double(r2), _i(ptr), None, None, None))
+    idx = np.zeros(max(tot, 1), dtype=np.int64); d2 = np.zeros(max(tot, 1)); v = np.zeros((max(tot, 1), d))
+    L.orc_closeR_boxes(_d(P), C.c_int64(n), _d(lohi), C.c_int32(M), _d(W), C.c_int32(d), C.c_double(r2), _i(ptr), _i(idx), _d(d2), _d(v))
+    return ptr, idx[:tot], d2[:tot], v[:tot]
+
+
+def closest_shapes(P, S, W=None):
+    """closest(p, C::Compound2D [, W]) (SAT2D.jl:260-279) per point."""
+    P = np.ascontiguousarray(np.atleast_2d(P), dtype=np.float64); n = len(P)
+    Wp = None if W is None else _d(_W(W, 2))
+    d2 = np.zeros(max(n, 1)); v = np.zeros((max(n, 1), 2)); k = np.zeros(max(n, 1), dtype=np.int64)
+    L = lib(); L.orc_closest_shapes.restype = C.c_int64
+    bad = L.orc_closest_shapes(_d(P), C.c_int64(n), S.ptr, C.c_int32(S.n), Wp, _d(d2), _d(v), _i(k))
+    return d2[:n], v[:n], k[:n], int(bad)
+
+
+def closeR_shapes(P, S, W, r2):
+    P = np.ascontiguousarray(np.atleast_2d(P), dtype=np.float64); n = len(P)
+    W = _W(W, 2)
+    L = lib(); L.orc_closeR_shapes.restype = C.c_int64
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    tot = int(L.orc_closeR_shapes(_d(P), C.c_int64(n), S.ptr, C.c_int32(S.n), _d(W), C.c_double(r2), _i(ptr), None, None, None))
+    idx = np.zeros(max(tot, 1), dtype=np.int64); d2 = np.zeros(max(tot, 1)); v = np.zeros((max(tot, 1), 2))
+    L.orc_closeR_shapes(_d(P), C.c_int64(n), S.ptr, C.c_int32(S.n), _d(W), C.c_double(r2), _i(ptr), _i(idx), _d(d2), _d(v))
+    return ptr, idx[:tot], d2[:tot], v[:tot]

@@ -667,3 +667,201 @@ def car_collision_waypoints_rs(v, w, r=1.0, s=1.0):     # :68-83 + statespaces.j
         v = car_propagate(v, u)
     path.append(tuple(w))
     return path
+
+
+# ======================================================================================================================
+# closest / closeR (boxesND.jl:61-86 through bvls.jl:19-218; SAT2D.jl:208-285).  numpy's LAPACK plays the part of Julia's
+# (`\` = least squares, chol, eigfact), so this path shares no arithmetic with the C restatement's hand-written QR.
+# ======================================================================================================================
+import numpy as _np
+
+
+def bvls(A, b, l, u):                       # bvls.jl:19-218; returns x, or None when the 10n iterations run out
+    A = _np.asarray(A, dtype=float); b = _np.asarray(b, dtype=float)
+    m, n = A.shape
+    oopslist = _np.zeros(n, dtype=bool)
+    state = _np.zeros(n, dtype=int)
+    x = _np.zeros(n)
+    atbound = _np.zeros(n, dtype=bool)
+    between = _np.zeros(n, dtype=bool)
+    criti = -1
+    crits = 0
+    myeps = 1.0e-10
+    for i in range(n):
+        if u[i] >= _np.inf and l[i] <= -_np.inf:
+            x[i] = 0; state[i] = 0; between[i] = True
+        elif u[i] >= _np.inf:
+            x[i] = l[i]; state[i] = 1; atbound[i] = True
+        elif l[i] <= -_np.inf:
+            x[i] = u[i]; state[i] = 2; atbound[i] = True
+        elif abs(l[i]) <= abs(u[i]):
+            x[i] = l[i]; state[i] = 1; atbound[i] = True
+        else:
+            x[i] = u[i]; state[i] = 2; atbound[i] = True
+    it = 0
+    while it < 10 * n:
+        it += 1
+        grad = A.T @ (A @ x - b)
+        grad[oopslist] = 0.0
+        done = True
+        for i in range(n):
+            if (abs(grad[i]) > (1 + _np.linalg.norm(b)) * myeps and state[i] == 0) or (grad[i] < 0 and state[i] == 1) or \
+                    (grad[i] > 0 and state[i] == 2):
+                done = False
+                break
+        if done:
+            return x
+        newi = -1
+        newg = 0.0
+        for i in range(n):
+            if atbound[i]:
+                if i == criti:
+                    continue
+                if grad[i] > 0 and state[i] == 2 and abs(grad[i]) > newg:
+                    newi = i; newg = abs(grad[i])
+                if grad[i] < 0 and state[i] == 1 and abs(grad[i]) > newg:
+                    newi = i; newg = abs(grad[i])
+        if newi != -1:
+            atbound[newi] = False; state[newi] = 0; between[newi] = True
+        Aproj = A[:, between]
+        An = A[:, atbound]
+        bproj = b - An @ x[atbound] if atbound.any() else b
+        z = _np.linalg.lstsq(Aproj, bproj, rcond=None)[0] if between.any() else _np.zeros(0)
+        xnew = x.copy()
+        xnew[between] = z
+        if newi != -1 and ((xnew[newi] <= l[newi] and x[newi] == l[newi]) or (xnew[newi] >= u[newi] and x[newi] == u[newi])):
+            oopslist[newi] = True
+            if xnew[newi] <= l[newi] and state[newi] == 1:
+                state[newi] = 1; x[newi] = l[newi]
+            if xnew[newi] >= u[newi] and state[newi] == 2:
+                state[newi] = 2; x[newi] = u[newi]
+            atbound[newi] = True
+            between[newi] = False
+            continue
+        oopslist[:] = False
+        alpha = 1.0
+        for i in range(n):
+            if between[i]:
+                if xnew[i] > u[i]:
+                    newalpha = min(alpha, (u[i] - x[i]) / (xnew[i] - x[i]))
+                    if newalpha < alpha:
+                        criti = i; crits = 2; alpha = newalpha
+                if xnew[i] < l[i]:
+                    newalpha = min(alpha, (l[i] - x[i]) / (xnew[i] - x[i]))
+                    if newalpha < alpha:
+                        criti = i; crits = 1; alpha = newalpha
+        x = x + alpha * (xnew - x)
+        if alpha < 1:
+            between[criti] = False; atbound[criti] = True; state[criti] = crits
+        for i in range(n):
+            if x[i] >= u[i]:
+                x[i] = u[i]; state[i] = 2; between[i] = False; atbound[i] = True
+            if x[i] <= l[i]:
+                x[i] = l[i]; state[i] = 1; between[i] = False; atbound[i] = True
+    return None
+
+
+def closest_box(p, lo, hi, W):              # boxesND.jl:61-70
+    p = _np.asarray(p, dtype=float)
+    L = _np.linalg.cholesky(W).T            # chol(W): upper
+    vmin = bvls(L, L @ p, lo, hi)
+    if vmin is None:
+        return None                         # the reference throws here (nothing - p)
+    return float((vmin - p) @ (W @ (vmin - p))), vmin
+
+
+def closest_boxlist(p, boxes, W):           # boxesND.jl:72-81; boxes = [(lo, hi), ...]
+    d2min, vmin, kmin = _m.inf, _np.asarray(p, dtype=float), -1
+    for k, (lo, hi) in enumerate(boxes):
+        out = closest_box(p, lo, hi, W)
+        if out is None:
+            continue                        # counted as a failure by the callers of this file
+        d2, v = out
+        if d2 < d2min:
+            d2min, vmin, kmin = d2, v, k
+    return d2min, vmin, kmin
+
+
+def closeR_boxlist(p, boxes, W, r2):        # boxesND.jl:83-86 (sort! by=first is stable)
+    cps = [(closest_box(p, lo, hi, W), k) for k, (lo, hi) in enumerate(boxes)]
+    return sorted([c + (k,) for c, k in cps if c is not None and c[0] < r2], key=lambda c: c[0])
+
+
+def closest_circle(p, c, r, W=None):        # SAT2D.jl:208-238
+    p = _np.asarray(p, dtype=float); c = _np.asarray(c, dtype=float)
+    if W is None:
+        xmin = c + r * (p - c) / _np.linalg.norm(p - c)
+        return float((p - xmin) @ (p - xmin)), xmin
+    vals, vecs = _np.linalg.eigh(_np.asarray(W, dtype=float))
+    ctop = p - c
+    v1, v2 = vecs[:, 0], vecs[:, 1]
+    p1, p2 = v1 @ ctop, v2 @ ctop
+    s1, s2 = vals
+    lam = 1.0
+    f = (p1 * s1 / (lam + s1)) ** 2 + (p2 * s2 / (lam + s2)) ** 2 - r ** 2
+    it = 0
+    while abs(f) > 1e-8:
+        it += 1
+        if it > 200 or f != f:              # the reference's loops are unbounded; the restatements stop here and report it
+            return None
+        fp = -2 / (lam + s1) * (p1 * s1 / (lam + s1)) ** 2 + -2 / (lam + s2) * (p2 * s2 / (lam + s2)) ** 2
+        alpha = 1.0
+        h = 0
+        while True:
+            lamnew = lam - alpha * f / fp
+            fnew = (p1 * s1 / (lamnew + s1)) ** 2 + (p2 * s2 / (lamnew + s2)) ** 2 - r ** 2
+            if abs(fnew) < abs(f):
+                break
+            alpha /= 2
+            h += 1
+            if h > 64:
+                return None
+        f = fnew
+        lam = lamnew
+    xmin = c + v1 * p1 * s1 / (lam + s1) + v2 * p2 * s2 / (lam + s2)
+    return float(s1 * (p1 - p1 * s1 / (lam + s1)) ** 2 + s2 * (p2 - p2 * s2 / (lam + s2)) ** 2), xmin
+
+
+def closest_polypts(p, points):             # SAT2D.jl:240-254
+    p = _np.asarray(p, dtype=float); points = [_np.asarray(q, dtype=float) for q in points]
+    N = len(points)
+    d2min, vmin = _m.inf, points[0]
+    for i in range(N):
+        nxt = points[(i + 1) % N]
+        edge = nxt - points[i]
+        x = (edge @ (p - points[i])) / (edge @ edge)
+        v = points[i] if x < 0 else (points[i] + x * edge if x < 1 else nxt)
+        d2 = float((p - v) @ (p - v))
+        if d2 < d2min:
+            d2min, vmin = d2, v
+    return d2min, vmin
+
+
+def closest_polygon(p, points, W=None):     # SAT2D.jl:239, 255-259
+    if W is None:
+        return closest_polypts(p, points)
+    p = _np.asarray(p, dtype=float)
+    L = _np.linalg.cholesky(W).T
+    xmin = _np.linalg.inv(L) @ closest_polypts(L @ p, [L @ _np.asarray(q, dtype=float) for q in points])[1]
+    return float((xmin - p) @ (W @ (xmin - p))), xmin
+
+
+def closest_compound(p, shapes, W=None):    # SAT2D.jl:260-279; shapes as in oracle.Shapes2D
+    d2min, vmin, kmin = _m.inf, _np.zeros(2), -1
+    for k, s in enumerate(shapes):
+        out = closest_circle(p, s[1], s[2], W) if s[0] == "circle" else closest_polygon(p, s[1], W)
+        if out is None:
+            continue
+        d2, v = out
+        if d2 < d2min:
+            d2min, vmin, kmin = d2, v, k
+    return d2min, vmin, kmin
+
+
+def closeR_compound(p, shapes, W, r2):      # SAT2D.jl:281-285
+    out = []
+    for k, s in enumerate(shapes):
+        cp = closest_circle(p, s[1], s[2], W) if s[0] == "circle" else closest_polygon(p, s[1], W)
+        if cp is not None and cp[0] < r2:
+            out.append((cp[0], cp[1], k))
+    return sorted(out, key=lambda c: c[0])

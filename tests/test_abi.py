@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_symbols():
     h = open(os.path.join(ROOT, "include", "mpfmt.h")).read()
     h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
-    return sorted(set(re.findall(r"\b(mpfmt_[a-z0-9_]+)\s*\(", h)))
+    return sorted(set(re.findall(r"\b(mpfmt_[A-Za-z0-9_]+)\s*\(", h)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -181,3 +181,22 @@ def test_reedsshepp_planning_through_the_mirror(orc):
         path = md["path"] - 1
         for a, b in zip(path[:-1], path[1:]):
             assert orc.car_is_free_motion(2, X[a], X[b], rt, 1.0, lohi, SS.lo, SS.hi)[0]
+
+
+def test_closest_through_the_mirror(orc):
+    """closest(p, CC, W) / closeR(p, CC, W, r2) with the mirror's collision checkers (boxesND.jl:33-34, robots2D.jl:25-26)."""
+    ctx = mp.Context(0)
+    CC = mp.PointRobotNDBoxes(boxes2d())
+    W = np.array([[2.0, 0.3], [0.3, 0.5]])
+    p = np.array([0.05, 0.5])
+    d2, v = mp.closest(p, CC, W, ctx=ctx)
+    od2, ov, ok, bad = orc.closest_boxes(p, CC.lohi(), W)
+    assert bad == 0 and abs(d2 - od2[0]) <= 1e-12 and np.abs(v - ov[0]).max() <= 1e-12
+    lst = mp.closeR(p, CC, W, 10.0)
+    optr, oidx, odd, ovv = orc.closeR_boxes(p, CC.lohi(), W, 10.0)
+    assert len(lst) == len(oidx) == len(CC.boxes) and np.allclose([c[0] for c in lst], odd, rtol=1e-12, atol=1e-15)
+    C2 = mp.PointRobot2D(mp.Compound2D(mp.Circle((0.3, 0.4), 0.1), mp.Box2D((0.6, 0.8), (0.2, 0.5))))
+    d2, v = mp.closest(np.array([0.3, 0.9]), C2, None, ctx=ctx)                      # Euclidean: towards the circle
+    assert abs(d2 - 0.16) < 1e-14 and np.allclose(v, [0.3, 0.5], atol=1e-14)
+    d2b, vb = mp.closest(np.array([[0.3, 0.9], [0.7, 0.0]]), C2, W)
+    assert d2b.shape == (2,) and vb.shape == (2, 2)

@@ -935,3 +935,104 @@ def test_mc_one_edge_many_rollouts(ctx, orc):
     p = [ctx.mc_edges_collision([1], [2], 0.03, 1_000_000, seed=s)[0] / 1e6 for s in (1, 2, 3)]
     assert 1e-3 < p[0] < 1e-2 and max(p) - min(p) < 6 * np.sqrt(p[0] / 1e6)
     assert ctx.mc_edges_collision([1], [2], 0.03, 20000, seed=1)[0] == orc.mc_edges(X, [0], [1], 0.03, 20000, 1, lohi, np.zeros(2), np.ones(2))[0]
+
+
+# ---- closest obstacle points in a Mahalanobis metric ---------------------------------------------------
+
+def _spd(rng, d):
+    A = rng.standard_normal((d, d))
+    return (A @ A.T + 0.3 * np.eye(d)) * 10 ** rng.uniform(-1, 1)
+
+
+@pytest.mark.parametrize("d,M,n", [(1, 3, 500), (2, 12, 4000), (3, 40, 3000), (6, 200, 2000), (8, 30, 1500), (12, 10, 600)])
+def test_closest_boxes_match_oracle(ctx, orc, d, M, n):
+    """closest(p, CC, W) / closeR(p, CC, W, r2) over boxes (boxesND.jl:61-86 through bvls.jl): same winning box, same
+    (point, box) pairs on which bvls exhausts its iterations, d2 / closest points to rounding (the device solves the projected
+    problems by Cholesky on the normal equations, the oracle by Householder QR)."""
+    rng = np.random.default_rng(300 + d)
+    _, lohi = random_world(rng, 1, d, M, 0.02, 0.15)
+    P = rng.random((n, d)) * 1.3 - 0.15
+    P[: n // 8] = (lohi[0, 0] + (lohi[0, 1] - lohi[0, 0]) * rng.random((n // 8, d)))     # inside box 1
+    P[n // 8] = lohi[0, 0]                                                               # a corner
+    W = _spd(rng, d)
+    ctx.upload_samples(P[:2]); ctx.upload_boxes(lohi, None, None)
+    d2, v, k, fails = ctx.closest(P, W)
+    od2, ov, ok, obad = orc.closest_boxes(P, lohi, W)
+    assert fails == obad
+    same = (k - 1 == ok)
+    assert same.mean() > 0.999                                           # two boxes at equal distance to rounding may swap
+    scale = np.maximum(od2, 1e-6 * np.trace(W))
+    assert np.all(np.abs(d2 - od2) <= 1e-9 * scale)
+    assert np.abs(v[same] - ov[same]).max() <= 1e-8
+    # closeR at a radius that keeps a handful of boxes per point
+    r2 = float(np.quantile(od2[np.isfinite(od2)], 0.5)) * 4 + 1e-3
+    ptr, idx, dd, vv, fails2 = ctx.closeR(P, W, r2)
+    optr, oidx, odd, ovv = orc.closeR_boxes(P, lohi, W, r2)
+    assert fails2 == obad
+    if np.array_equal(ptr - 1, optr) and np.array_equal(idx - 1, oidx):
+        assert np.allclose(dd, odd, rtol=1e-9, atol=1e-9 * np.trace(W) * 1e-6) and np.abs(vv - ovv).max() <= 1e-8
+    else:                                                                # only entries within rounding of r2 or of each other may differ
+        cnt_diff = np.abs(np.diff(ptr) - np.diff(optr)).sum()
+        assert cnt_diff <= 2 + len(idx) // 1000
+    for i in range(0, n, max(n // 50, 1)):                               # ascending lists
+        assert (np.diff(dd[ptr[i] - 1:ptr[i + 1] - 1]) >= 0).all()
+    assert len(idx) > n // 4                                             # a real workload, not empty lists
+    # capacity protocol of the C ABI
+    import ctypes as C
+    from motionplanning_jl_amd._lib import _dp, _ip
+    tot = C.c_int64(); pbuf = np.empty(n + 1, dtype=np.int64)
+    rc = ctx._L.mpfmt_closeR(ctx._h, _dp(np.ascontiguousarray(P)), n, _dp(np.ascontiguousarray(W)), r2, _ip(pbuf), 1,
+                             _ip(np.empty(1, dtype=np.int64)), _dp(np.empty(1)), _dp(np.empty(d)), C.byref(tot), None)
+    assert rc == mp._lib.ERR_CAPACITY and tot.value == len(idx) and np.array_equal(pbuf, ptr)
+
+
+def test_closest_boxes_edge_cases(ctx, orc):
+    P = np.array([[0.5, 0.5], [0.1, 0.9]])
+    ctx.upload_samples(P); ctx.upload_boxes(np.zeros((0, 2, 2)), None, None, dw=2)
+    d2, v, k, fails = ctx.closest(P, np.eye(2))
+    assert np.isinf(d2).all() and (k == 0).all() and np.array_equal(v, P) and fails == 0      # (Inf, p)   boxesND.jl:73
+    ptr, idx, dd, vv, _ = ctx.closeR(P, np.eye(2), 1.0)
+    assert np.array_equal(ptr, [1, 1, 1]) and len(idx) == 0
+    lohi = np.array([[[0.2, 0.2], [0.4, 0.6]]])
+    ctx.upload_boxes(lohi, None, None)
+    d2, v, k, fails = ctx.closest(np.array([[0.9, 0.5], [0.0, 0.0], [0.3, 0.9]]), np.eye(2))   # Euclidean projections
+    assert np.allclose(v, [[0.4, 0.5], [0.2, 0.2], [0.3, 0.6]], atol=1e-15) and np.allclose(d2, [0.25, 0.08, 0.09], atol=1e-15)
+    d2, v, k, fails = ctx.closest(np.zeros((0, 2)), np.eye(2))
+    assert len(d2) == 0
+    with pytest.raises(mp.MPFMTError):
+        ctx.closest(P, None)                                             # boxes have no unweighted method (boxesND.jl:61)
+    with pytest.raises(mp.MPFMTError):
+        ctx.closest(P, np.array([[1.0, 2.0], [2.0, 1.0]]))               # not positive definite: chol(W) throws
+    with pytest.raises(mp.MPFMTError):
+        ctx.closest(P, np.array([[1.0, 0.5], [0.0, 1.0]]))               # not symmetric
+
+
+def test_closest_shapes_match_oracle(ctx, orc):
+    """closest / closeR over circles, convex polygons and compounds (SAT2D.jl:208-285), Euclidean and weighted."""
+    rng = np.random.default_rng(77)
+    shapes = [("circle", (0.3, 0.4), 0.1), ("polygon", [(0.6, 0.1), (0.9, 0.2), (0.8, 0.5), (0.55, 0.4)]), ("circle", (0.7, 0.8), 0.15),
+              ("polygon", [(0.1, 0.7), (0.3, 0.7), (0.3, 0.9), (0.1, 0.9)]), ("polygon", [(0.45, 0.6), (0.55, 0.55), (0.5, 0.75)])]
+    S = orc.Shapes2D(shapes)
+    P = rng.random((6000, 2)) * 1.2 - 0.1
+    ctx.upload_samples(P[:2]); ctx.upload_shapes2d(shapes)
+    try:
+        for W in (None, _spd(rng, 2), np.diag([4.0, 0.25]), _spd(rng, 2)):
+            d2, v, k, fails = ctx.closest(P, W)
+            od2, ov, ok, obad = orc.closest_shapes(P, S, W)
+            assert fails == obad
+            same = (k - 1 == ok)
+            assert same.mean() > 0.999
+            assert np.abs(d2 - od2).max() <= 1e-7                        # circles stop at |f| <= 1e-8: last Newton step may differ
+            assert np.abs(v[same] - ov[same]).max() <= 1e-6
+            poly = same & np.isin(ok, [1, 3, 4])
+            assert np.abs(d2[poly] - od2[poly]).max() <= 1e-12 and np.abs(v[poly] - ov[poly]).max() <= 1e-12
+            if W is not None:
+                r2 = 0.05 * np.trace(W)
+                ptr, idx, dd, vv, _ = ctx.closeR(P, W, r2)
+                optr, oidx, odd, ovv = orc.closeR_shapes(P, S, W, r2)
+                assert np.abs(np.diff(ptr) - np.diff(optr)).sum() <= 3
+                if np.array_equal(idx - 1, oidx):
+                    assert np.abs(dd - odd).max() <= 1e-7 and np.abs(vv - ovv).max() <= 1e-6
+                assert len(idx) > 1000
+    finally:
+        ctx.upload_boxes(np.zeros((0, 2, 2)), None, None, dw=2)          # back to the box checker for the tests that follow

@@ -336,3 +336,84 @@ def test_reedsshepp_oracle_graph_and_plan():
         assert res["A"][b] == a
         tot += orc.reedsshepp(X[b], X[a], rt, 1.0)[0]                    # inball(b) holds d(b, a)   (fmt.jl:70-75)
     assert abs(tot - res["cost"]) <= 1e-12 * tot
+
+
+def _spd(rng, d):
+    A = rng.standard_normal((d, d))
+    return (A @ A.T + 0.3 * np.eye(d)) * 10 ** rng.uniform(-1, 1)
+
+
+def test_closest_boxes_oracle_against_transliteration():
+    """closest / closeR over boxes (boxesND.jl:61-86, bvls.jl:19-218): the C restatement (hand-written Householder QR) equals
+    the transliteration (numpy's LAPACK for `\\`, chol) to rounding, picks the same box, and both run out of bvls' 10n
+    iterations on the same (point, box) pairs -- where the reference returns `nothing` and closest() throws."""
+    from oracle import oracle as orc
+    import jl_transliteration as jl
+    rng = np.random.default_rng(0)
+    nfail = 0
+    for d in (1, 2, 3, 6, 8):
+        for t in range(120):
+            W = _spd(rng, d)
+            c = rng.random((5, d)); h = 0.02 + 0.2 * rng.random((5, d))
+            lohi = np.stack([c - h, c + h], axis=1)
+            p = rng.random(d) * 1.4 - 0.2
+            if t % 7 == 0:
+                p = c[0] + 0.5 * h[0] * (rng.random(d) - 0.5)              # inside a box
+            boxes = [(b[0], b[1]) for b in lohi]
+            fails_j = sum(jl.closest_box(p, lo, hi, W) is None for lo, hi in boxes)
+            d2, v, k, bad = orc.closest_boxes(p, lohi, W)
+            assert bad == fails_j
+            nfail += bad
+            dj, vj, kj = jl.closest_boxlist(p, boxes, W)
+            assert k[0] == kj and abs(d2[0] - dj) <= 1e-11 * max(dj, 1e-3) and np.abs(v[0] - vj).max() <= 1e-10
+            if kj >= 0 and t % 7:
+                # the closest point is the constrained minimiser: no feasible perturbation lowers the quadratic form
+                for _ in range(5):
+                    q = np.clip(vj + 1e-3 * rng.standard_normal(d), lohi[kj, 0], lohi[kj, 1])
+                    assert (q - p) @ W @ (q - p) >= dj - 1e-12
+            ds = sorted(x[0] for x in [jl.closest_box(p, lo, hi, W) for lo, hi in boxes] if x is not None)
+            r2 = 0.5 * (ds[1] + ds[2]) if len(ds) > 2 and ds[2] > ds[1] * (1 + 1e-6) + 1e-12 else 1e9   # not on a value: strict < must not flip
+            ptr, idx, dd, vv = orc.closeR_boxes(p, lohi, W, r2)
+            want = jl.closeR_boxlist(p, boxes, W, r2)
+            assert list(idx) == [w[2] for w in want] and ptr[-1] == len(want)
+            assert np.allclose(dd, [w[0] for w in want], rtol=1e-11, atol=1e-13)
+            assert (np.diff(dd) >= 0).all()
+    assert nfail > 0                                                        # the failure branch was exercised
+    # known answers: identity weight = Euclidean projection onto the box
+    lohi = np.array([[[0.2, 0.2], [0.4, 0.6]]])
+    d2, v, k, bad = orc.closest_boxes(np.array([[0.9, 0.5], [0.0, 0.0], [0.3, 0.9]]), lohi, np.eye(2))
+    assert bad == 0 and np.allclose(v, [[0.4, 0.5], [0.2, 0.2], [0.3, 0.6]], atol=1e-15) and np.allclose(d2, [0.25, 0.08, 0.09], atol=1e-15)
+    d2, v, k, bad = orc.closest_boxes(np.array([[0.5, 0.5]]), np.zeros((0, 2, 2)), np.eye(2))
+    assert np.isinf(d2[0]) and k[0] == -1 and np.array_equal(v[0], [0.5, 0.5])   # (Inf, p)   boxesND.jl:73
+
+
+def test_closest_shapes_oracle_against_transliteration():
+    """closest / closeR over circles, convex polygons and compounds (SAT2D.jl:208-285), Euclidean and weighted."""
+    from oracle import oracle as orc
+    import jl_transliteration as jl
+    rng = np.random.default_rng(1)
+    shapes = [("circle", (0.3, 0.4), 0.1), ("polygon", [(0.6, 0.1), (0.9, 0.2), (0.8, 0.5), (0.55, 0.4)]), ("circle", (0.7, 0.8), 0.15),
+              ("polygon", [(0.1, 0.7), (0.3, 0.7), (0.3, 0.9), (0.1, 0.9)])]
+    S = orc.Shapes2D(shapes)
+    nbad = 0
+    for t in range(1500):
+        W = _spd(rng, 2) if t % 3 else None
+        p = rng.random(2) * 1.2 - 0.1
+        d2, v, k, bad = orc.closest_shapes(p, S, W)
+        dj, vj, kj = jl.closest_compound(p, shapes, W)
+        # a circle whose multiplier iteration does not end (the reference would not return; e.g. some points inside the
+        # circle) is reported by both restatements on the same pairs
+        bad_j = 0 if W is None else sum(jl.closest_circle(p, s[1], s[2], W) is None for s in shapes if s[0] == "circle")
+        nbad += bad
+        assert bad == bad_j and k[0] == kj and abs(d2[0] - dj) <= 1e-12 and np.abs(v[0] - vj).max() <= 1e-12
+        if W is not None:
+            ptr, idx, dd, vv = orc.closeR_shapes(p, S, W, 0.3 * np.trace(W))
+            want = jl.closeR_compound(p, shapes, W, 0.3 * np.trace(W))
+            assert list(idx) == [w[2] for w in want]
+            assert np.allclose(dd, [w[0] for w in want], rtol=0, atol=1e-12)
+            assert np.allclose(vv, np.array([w[1] for w in want]).reshape(-1, 2), rtol=0, atol=1e-12)
+    # known answers (Euclidean): circle boundary point towards p; polygon edge projection
+    d2, v, k, bad = orc.closest_shapes(np.array([[0.3, 0.9]]), orc.Shapes2D([("circle", (0.3, 0.4), 0.1)]))
+    assert np.allclose(v, [[0.3, 0.5]], atol=1e-15) and abs(d2[0] - 0.16) < 1e-15
+    d2, v, k, bad = orc.closest_shapes(np.array([[0.5, 0.0]]), orc.Shapes2D([("polygon", [(0.4, 0.2), (0.6, 0.2), (0.6, 0.4), (0.4, 0.4)])]))
+    assert np.allclose(v, [[0.5, 0.2]], atol=1e-15) and abs(d2[0] - 0.04) < 1e-15
