@@ -116,8 +116,7 @@ def main():
         if world > 1:
             nnz, _, _ = mp.distributed.sharded_step(ctx, w.r, dist, world, dev)   # graph + sweep + ONE mask all-gather
         else:
-            nnz = ctx.graph_build_device(w.r)
-            ctx.graph_sweep_device()
+            nnz = ctx.graph_step_device(w.r)      # graph + sweep, one host synchronisation (include/mpfmt.h)
         return nnz
 
     if dist is not None:

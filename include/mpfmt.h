@@ -289,6 +289,13 @@ int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx,
  *   colptr int64[N+1] 0-based offsets, rowval int32[nnz] 0-based, nzval double[nnz], free uint64[ceil(nnz/64)]. */
 int32_t mpfmt_graph_build_device(mpfmt_ctx* ctx, double r, int64_t* nnz);
 int32_t mpfmt_graph_sweep_device(mpfmt_ctx* ctx);
+/* graph_step_device: graph_build_device + graph_sweep_device as ONE call with one host synchronisation -- the planner's
+ * whole step (fmt.jl:70-75's neighbour sets and edge checks for every sample).  The two-call form needs the host between
+ * its kernels (nnz sizes the CSC and the mask).  When the previous step of the same (N, r, shard) took the single-pass
+ * path, this call trusts its sizes, issues every kernel back to back, lets a device flag void the kernels after a capacity
+ * that did not hold, validates after the synchronisation and transparently redoes the step the careful way if needed.
+ * Results are identical to the two-call form. */
+int32_t mpfmt_graph_step_device(mpfmt_ctx* ctx, double r, int64_t* nnz);
 int32_t mpfmt_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** rowval, void** nzval, void** free_mask);
 /* Shard bookkeeping for the all-gather: column range (in the library's sorted order) and the number
  * of edges this shard produced. */

@@ -86,6 +86,7 @@ SYMBOLS = [
     ("mpfmt_di_fmtstar", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
                                      c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
     ("mpfmt_graph_build_device", C.c_int32, [C.c_void_p, C.c_double, c_i64_p]),
+    ("mpfmt_graph_step_device", C.c_int32, [C.c_void_p, C.c_double, c_i64_p]),
     ("mpfmt_graph_sweep_device", C.c_int32, [C.c_void_p]),
     ("mpfmt_graph_device_ptrs", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
@@ -528,6 +529,13 @@ class Context:
 
     def graph_sweep_device(self):
         self._chk(self._L.mpfmt_graph_sweep_device(self._h))
+
+    def graph_step_device(self, r):
+        """graph_build_device + graph_sweep_device with one host synchronisation (see include/mpfmt.h)."""
+        nnz = C.c_int64()
+        self._chk(self._L.mpfmt_graph_step_device(self._h, float(r), C.byref(nnz)))
+        self.nnz = nnz.value
+        return nnz.value
 
     def graph_device_ptrs(self):
         p = [C.c_void_p() for _ in range(4)]

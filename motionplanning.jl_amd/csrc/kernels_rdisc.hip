@@ -178,7 +178,10 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
         size_t tmp_bytes = 0;
         int bits = 1;
         while (((int64_t)1 << bits) < G.ncells) ++bits;
-        HIPCHK(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
+        // rocprim's default takes its merge sort (about 20 launches) up to 2^20 items; the cell key has few bits, so the
+        // onesweep radix sort (histogram + one pass per 8 bits) is the shorter pipeline from a few thousand samples on
+        using sort_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
+        HIPCHK(ctx, rocprim::radix_sort_pairs<sort_cfg>(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                               (int32_t*)nullptr, (int32_t*)nullptr, (size_t)N, 0, bits, ctx->stream));
         size_t off_key = 0, off_val = off_key + sizeof(uint32_t) * N, off_vout = off_val + sizeof(int32_t) * N;
         size_t off_tmp = (off_vout + sizeof(int32_t) * N + 255) & ~(size_t)255;
@@ -191,7 +194,7 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
         const int B = 256;
         hipLaunchKernelGGL(k_cellkey, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream,
                            ctx->Xo, N, d, G, key_in, val_in);
-        HIPCHK(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, ctx->cellkey, val_in, val_out, (size_t)N, 0, bits, ctx->stream));
+        HIPCHK(ctx, rocprim::radix_sort_pairs<sort_cfg>(tmp, tmp_bytes, key_in, ctx->cellkey, val_in, val_out, (size_t)N, 0, bits, ctx->stream));
         const int64_t ne = npad * d;
         hipLaunchKernelGGL(k_sorted_perm_aos, dim3((unsigned)((ne + B - 1) / B)), dim3(B), 0, ctx->stream,
                            ctx->Xo, val_out, N, npad, d, ctx->perm, ctx->iperm, ctx->Xs);
@@ -455,7 +458,21 @@ static int32_t scan_i64(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t 
     return MPFMT_OK;
 }
 
+// device-side verdict of a speculative step: any capacity that did not hold sets the flag every later kernel checks
+__global__ void k_spec_check(const int32_t* __restrict__ pool_flag, const int32_t* __restrict__ list_max, int64_t list_cap,
+                             const int64_t* __restrict__ nnz, int64_t nnz_cap, int32_t* __restrict__ spec_fail)
+{
+    *spec_fail = (*pool_flag != 0) || (list_max && (int64_t)*list_max > list_cap) || (*nnz >= nnz_cap);
+}
+
 int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
+{
+    int32_t rc;
+    if ((rc = mpfmt_rdisc_count_launch(ctx, r, false))) return rc;
+    return mpfmt_rdisc_count_finish(ctx, r, nullptr);
+}
+
+int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
 {
     int32_t rc;
     if ((rc = mpfmt_build_grid(ctx, r))) return rc;
@@ -482,7 +499,7 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
             ctx->lists_r = -1.0;
         }
         bool ok = true;
-        if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok))) return rc;          // per-tile candidate chunk lists
+        if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok, spec))) return rc;    // per-tile candidate chunk lists
         mpfmt_time_end(ctx, "grid");
         if (!ok) {
             if (ctx->rdisc_path == 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path requested but its chunk lists exceed 32 GB");
@@ -556,13 +573,36 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
     if ((rc = scan_i64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1)))) return rc;      // columns in original order
     if ((rc = scan_i64(ctx, ctx->degs, ctx->tptr, (size_t)(npad + 1)))) return rc;    // staging in sorted order
     mpfmt_time_end(ctx, "rdisc_count");
+    ctx->cnt_pool = pool; ctx->cnt_mf = mf;
+    return MPFMT_OK;
+}
+
+// the count's read-back (nnz, pair counters, pool overflow, and -- after a speculative list build -- the list maximum)
+// behind the one synchronisation.  *spec_failed (speculative callers) reports a truncated chunk list or pool overflow.
+int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
+{
+    const int64_t N = ctx->N;
+    const bool pool = ctx->cnt_pool;
+    const int64_t nt = ctx->tile_end - ctx->tile_begin;
+    if (spec_failed) *spec_failed = false;
     int64_t nnz = 0;
     unsigned long long pairs[512];
     HIPCHK(ctx, hipMemcpyAsync(&nnz, ctx->colptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(pairs, ctx->d_pairs, sizeof(pairs), hipMemcpyDeviceToHost, ctx->stream));
     int32_t pool_over = 0;
     if (pool) HIPCHK(ctx, hipMemcpyAsync(&pool_over, ctx->pool_flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    int32_t list_mx = 0;
+    if (ctx->spec_lists && nt > 0) HIPCHK(ctx, hipMemcpyAsync(&list_mx, ctx->list_len + nt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->spec_lists && list_mx > ctx->list_cap) {             // lists were truncated: everything after them is void
+        ctx->lists_r = -1.0; ctx->lists_cap_trusted = -1;
+        ctx->list_cap = std::min<int64_t>(ctx->ntiles, ((int64_t)list_mx + 255) / 256 * 256);
+        ctx->spec_lists = false;
+        if (spec_failed) { *spec_failed = true; return MPFMT_OK; }
+        return mpfmt_launch_rdisc_count(ctx, r);
+    }
+    ctx->spec_lists = false;
+    if (spec_failed && pool && pool_over) *spec_failed = true;
     ctx->pool_valid = pool && pool_over == 0;
     if (pool && pool_over && ctx->pool_slack < 8) ctx->pool_slack *= 2;
     ctx->pool_hint_N = N; ctx->pool_hint_r = r; ctx->pool_hint_nnz = nnz;
@@ -621,6 +661,61 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
         }
     }
     ctx->graph_filled = true;
+    return MPFMT_OK;
+}
+
+// One whole step -- index, r-disc graph, column order, collision sweep -- with a single host synchronisation.
+// mpfmt_launch_rdisc_count + _fill + mpfmt_launch_graph_sweep need the host between them (nnz sizes the CSC and the mask,
+// the list maximum and the pool flag decide the path).  When the previous build of the same (N, r, shard) went through the
+// single-pass path, its sizes are taken on trust instead: every launch is issued back to back, k_spec_check raises a device
+// flag if a capacity does not hold (the kernels after it then return at once), and the host validates after the one
+// synchronisation -- falling back to the step-by-step path when the trust was misplaced.
+int32_t mpfmt_graph_step(mpfmt_ctx* ctx, double r)
+{
+    int32_t rc;
+    const int64_t N = ctx->N;
+    const bool spec = ctx->spec_ready && ctx->use_pool && ctx->pool_hint_N == N && ctx->pool_hint_r == r && ctx->pool_hint_rank == ctx->rank &&
+                      ctx->pool_hint_world == ctx->world && ctx->pool_hint_nnz > 0 && ctx->cc_kind == 0 && ctx->have_boxes && ctx->dw == ctx->d;
+    if (spec) {
+        if ((rc = mpfmt_rdisc_count_launch(ctx, r, true))) return rc;
+        if (ctx->cnt_mf && ctx->cnt_pool) {
+            const int64_t cap = (int64_t)((double)ctx->pool_hint_nnz * 1.02) + 4096;
+            if ((rc = ensure(ctx, (void**)&ctx->rowval, sizeof(int32_t) * (size_t)cap))) return rc;
+            if ((rc = ensure(ctx, (void**)&ctx->nzval, sizeof(double) * (size_t)cap))) return rc;
+            if (!ctx->spec_fail) HIPCHK(ctx, hipMalloc((void**)&ctx->spec_fail, sizeof(int32_t)));
+            const int64_t nt = ctx->tile_end - ctx->tile_begin;
+            hipLaunchKernelGGL(k_spec_check, dim3(1), dim3(1), 0, ctx->stream, ctx->pool_flag,
+                               (ctx->spec_lists && nt > 0) ? ctx->list_len + nt : nullptr, ctx->list_cap, ctx->colptr + N, cap, ctx->spec_fail);
+            ctx->nnz = ctx->pool_hint_nnz;                          // provisional: replaced by the count's own value below
+            ctx->nnz_cap = cap;
+            ctx->pool_valid = true; ctx->rdisc_path_used = 2;
+            ctx->graph_r = r; ctx->graph_counted = true;
+            mpfmt_time_begin(ctx);
+            if ((rc = mpfmt_sortcols_slots(ctx, ctx->spec_fail))) return rc;
+            mpfmt_time_end(ctx, "rdisc_sort");
+            ctx->graph_filled = true;
+            if ((rc = mpfmt_launch_graph_sweep(ctx, ctx->spec_fail, cap))) return rc;
+            bool failed = false;
+            if ((rc = mpfmt_rdisc_count_finish(ctx, r, &failed))) return rc;
+            if (!failed && ctx->nnz < cap && ctx->pool_valid) {
+                ctx->graph_filled = true; ctx->graph_swept = true;  // (finish resets the flags it owns)
+                return MPFMT_OK;
+            }
+            // the trust was misplaced: redo the step the careful way (capacities have been corrected by finish)
+            ctx->spec_ready = false;
+            ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
+        } else {
+            if ((rc = mpfmt_rdisc_count_finish(ctx, r, nullptr))) return rc;
+            if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
+            if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+            ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
+            return MPFMT_OK;
+        }
+    }
+    if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
+    if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
+    if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+    ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
     return MPFMT_OK;
 }
 

@@ -245,7 +245,8 @@ __global__ __launch_bounds__(64) void k_chunk_lists(const int32_t* __restrict__ 
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (lane == 0) { list_len[tl] = gcount; atomicMax(max_len, gcount); }
+    // the stored length never exceeds what was written (a truncated list voids the build: max_len tells the host / k_spec_check)
+    if (lane == 0) { list_len[tl] = min(gcount, (int32_t)list_cap); atomicMax(max_len, gcount); }
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
@@ -584,8 +585,10 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restri
                                                        int64_t capc, int S, const int32_t* __restrict__ slice_cnt, int64_t npad,
                                                        int64_t tile_begin, int64_t pos_begin, int64_t pos_end,
                                                        const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm,
-                                                       int32_t* __restrict__ rowval, double* __restrict__ nzval, uint32_t bucket_mul)
+                                                       int32_t* __restrict__ rowval, double* __restrict__ nzval, uint32_t bucket_mul,
+                                                       const int32_t* __restrict__ spec_fail)
 {
+    if (spec_fail && *spec_fail) return;                     // speculative step whose capacities did not hold: redone by the host
     __shared__ __attribute__((aligned(16))) int32_t s_o[SLOT_LDS + 4];
     __shared__ __attribute__((aligned(16))) int32_t s_cnt[128], s_base[128];
     __shared__ int32_t s_pre[SLOT_TC][MPFMT_MAXS + 1];      // [column][slice] first entry of the slice's hits
@@ -712,23 +715,24 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restri
     }
 }
 
-int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx)
+int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx, const int32_t* spec_fail)
 {
     const int64_t pb = ctx->tile_begin * 64, pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
     if (ctx->nnz == 0 || pe <= pb) return MPFMT_OK;
     const unsigned nb = (unsigned)std::min<int64_t>((pe - pb + SLOT_TC - 1) / SLOT_TC, 1 << 20);
     hipLaunchKernelGGL(k_sortcols_slots, dim3(nb), dim3(64), 0, ctx->stream, ctx->pool, ctx->pool_cap, ctx->S,
                        ctx->slice_cnt, ctx->ntiles * 64, ctx->tile_begin, pb, pe, ctx->colptr, ctx->perm, ctx->rowval, ctx->nzval,
-                       ctx->N > 128 ? (uint32_t)((128ull << 32) / (uint64_t)ctx->N) : 0u);
+                       ctx->N > 128 ? (uint32_t)((128ull << 32) / (uint64_t)ctx->N) : 0u, spec_fail);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
 
 // (re)build the per-tile candidate chunk lists of this ctx's shard for radius r; grows the list capacity until every
 // list fits.  *usable = false when the lists would need more than 32 GB (caller then takes the exact VALU path).
-int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable)
+int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec)
 {
     *usable = true;
+    ctx->spec_lists = false;
     const int64_t nt = ctx->tile_end - ctx->tile_begin;
     if (nt <= 0) return MPFMT_OK;
     if (ctx->lists_r == r && ctx->lists_begin == ctx->tile_begin && ctx->lists_end == ctx->tile_end && ctx->lists) return MPFMT_OK;
@@ -749,10 +753,18 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable)
         }
 #undef CASE
         HIPCHK(ctx, hipGetLastError());
+        if (spec && attempt == 0 && ctx->lists_cap_trusted == cap) {
+            // same geometry as the build that established this capacity: the maximum is checked on the device
+            // (k_spec_check) and by the host after the step's only synchronisation
+            ctx->spec_lists = true;
+            ctx->list_cap = cap; ctx->lists_r = r; ctx->lists_begin = ctx->tile_begin; ctx->lists_end = ctx->tile_end;
+            return MPFMT_OK;
+        }
         int32_t mx = 0;
         HIPCHK(ctx, hipMemcpyAsync(&mx, ctx->list_len + nt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (mx <= cap) {
+            ctx->lists_cap_trusted = cap;
             ctx->list_cap = cap; ctx->lists_r = r; ctx->lists_begin = ctx->tile_begin; ctx->lists_end = ctx->tile_end;
             return MPFMT_OK;
         }

@@ -361,8 +361,9 @@ __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 2)) void k_graph_sweep
                                                                const double* __restrict__ boxes, int M, int chunk,
                                                                mpfmt_ss ss, unsigned long long* __restrict__ mask,
                                                                int* __restrict__ task_ctr, const int32_t* __restrict__ perm,
-                                                               int64_t sp_begin, int64_t sp_end)
+                                                               int64_t sp_begin, int64_t sp_end, const int32_t* __restrict__ spec_fail)
 {
+    if (spec_fail && *spec_fail) return;                   // speculative step whose capacities did not hold: redone by the host
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sboxT = (double*)smem;                         // [2*D][SWEEP_CHUNK]
     const int lane = threadIdx.x & 63;
@@ -832,7 +833,7 @@ int32_t mpfmt_launch_mc_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64
 // build, small graphs): finer tasks balance the tail.  One resident set of workgroups.
 template <int D>
 static int32_t launch_graph_sweep_d(mpfmt_ctx* ctx, size_t lds, double rpad, int chunk, const int32_t* sweep_perm, int64_t sp_begin,
-                                    int64_t sp_end)
+                                    int64_t sp_end, const int32_t* spec_fail)
 {
     constexpr auto k16 = k_graph_sweep<D, 16>;
     constexpr auto k8 = k_graph_sweep<D, 8>;
@@ -849,17 +850,19 @@ static int32_t launch_graph_sweep_d(mpfmt_ctx* ctx, size_t lds, double rpad, int
     const unsigned nb = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ntasks + waves - 1) / waves, resident));
     hipLaunchKernelGGL(tc == 8 ? k8 : k16, dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream, ctx->Xo, ctx->colptr, ctx->rowval, ctx->N,
                        rpad, ctx->boxes, ctx->M, chunk, ctx->ss, (unsigned long long*)ctx->graph_free, ctx->sweep_ctr, sweep_perm,
-                       sp_begin, sp_end);
+                       sp_begin, sp_end, spec_fail);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
 
-int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
+// spec_fail / mask_entries: the speculative step (mpfmt_graph_step) sweeps before the host knows nnz -- the mask is then
+// sized and preset for mask_entries (the trusted capacity) and the kernel bails out on the device flag
+int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail, int64_t mask_entries)
 {
     int32_t rc;
     if ((rc = check_boxes(ctx, ctx->d))) return rc;
     if (!ctx->graph_filled) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "graph sweep before the r-disc graph is filled");
-    const int64_t words = (ctx->nnz + 63) / 64;
+    const int64_t words = (std::max<int64_t>(ctx->nnz, mask_entries) + 63) / 64;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->graph_free, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1)))) return rc;
     if (ctx->cc_kind == 1) {                                         // 2-D SAT world: lane = entry, whole words written
         mpfmt_time_begin(ctx);
@@ -890,7 +893,7 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx)
         const int32_t* sweep_perm = sharded ? ctx->perm : nullptr;
         const int64_t sp_begin = sharded ? ctx->tile_begin * 64 : 0;
         const int64_t sp_end = sharded ? std::min<int64_t>(ctx->tile_end * 64, ctx->ntiles * 64) : ctx->N;
-        DISPATCH_D(d, rc = launch_graph_sweep_d<DD>(ctx, lds, rpad, chunk, sweep_perm, sp_begin, sp_end));
+        DISPATCH_D(d, rc = launch_graph_sweep_d<DD>(ctx, lds, rpad, chunk, sweep_perm, sp_begin, sp_end, spec_fail));
         if (rc) return rc;
         HIPCHK(ctx, hipGetLastError());
     }

@@ -286,6 +286,20 @@ int32_t mpfmt_graph_build_device(mpfmt_ctx* ctx, double r, int64_t* nnz)
     return MPFMT_OK;
 }
 
+int32_t mpfmt_graph_step_device(mpfmt_ctx* ctx, double r, int64_t* nnz)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!(r >= 0.0) || !std::isfinite(r)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "radius must be finite and >= 0");
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
+    if (ctx->rebuild_index) { ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; }
+    if ((rc = mpfmt_graph_step(ctx, r))) return rc;
+    if (nnz) *nnz = ctx->nnz;
+    return MPFMT_OK;
+}
+
 int32_t mpfmt_rdisc_count(mpfmt_ctx* ctx, double r, int64_t* colptr, int64_t* nnz)
 {
     if (!ctx) return MPFMT_ERR_ARG;

@@ -113,6 +113,14 @@ struct mpfmt_ctx {
     mpfmt_hit* pool = nullptr;           // [items][64 columns][pool_cap] hit records
     int32_t pool_slack = 1;              // doubled after a build whose slot lists overflowed
     bool pool_valid = false;             // pool holds exactly the nnz hits of the counted graph
+    // speculative single-sync step (mpfmt_graph_step): capacities of the previous identical build are trusted, every kernel
+    // after the count bails out on the device flag spec_fail, and the host validates once at the end
+    bool spec_ready = false;             // the previous build of the same (N, r, shard) went through the single-pass pool path
+    bool spec_lists = false;             // chunk lists of the pending count were built without reading back their maximum
+    bool cnt_pool = false, cnt_mf = false;   // the pending count used the pool / the MFMA pair kernel
+    int32_t* spec_fail = nullptr;        // device flag: pool overflow, truncated chunk list or nnz beyond the trusted capacity
+    int64_t nnz_cap = 0;                 // entries rowval / nzval / the mask are sized for
+    int64_t lists_cap_trusted = -1;      // list capacity that a verified build found sufficient
     int64_t pool_hint_N = -1; double pool_hint_r = -1.0; int64_t pool_hint_nnz = 0; int pool_hint_rank = -1, pool_hint_world = -1;   // capacity hint from the last build
     int64_t survivors = 0;
     int64_t* colptr = nullptr;           // [N+1] 0-based offsets by original index
@@ -178,12 +186,15 @@ void mpfmt_time_end(mpfmt_ctx* ctx, const char* name);
 // kernels_rdisc.hip -----------------------------------------------------------------------------
 int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r);
+int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec);
+int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed);
+int32_t mpfmt_graph_step(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usable);
 int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx);
 template <int MODE> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT);
-int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx);
-int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable);
+int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr);
+int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);
 
@@ -197,7 +208,7 @@ int32_t mpfmt_launch_edges_free(mpfmt_ctx* ctx, const int64_t* d_src1, const int
 int32_t mpfmt_launch_motions_free(mpfmt_ctx* ctx, const double* d_P, const double* d_Q, int64_t n, uint64_t* d_mask);
 int32_t mpfmt_launch_mc_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, double sigma, int64_t rollouts,
                               uint64_t seed, unsigned long long* d_hits);
-int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx);
+int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr, int64_t mask_entries = -1);
 
 // kernels_di.hip ----------------------------------------------------------------------------------
 #include <functional>

@@ -43,8 +43,7 @@ def sharded_step(ctx, r, dist, world, device):
     """One batch-expand step on this rank's shard of `ctx` (a `_lib.Context` with set_shard done):
     r-disc graph + edge sweep on the GPU, then the all-gather of the free-edge mask.
     Returns (local nnz, gathered mask [world, max_words], counts)."""
-    nnz = ctx.graph_build_device(r)
-    ctx.graph_sweep_device()
+    nnz = ctx.graph_step_device(r)
     _, _, _, fptr = ctx.graph_device_ptrs()
     words = (nnz + 63) // 64
     if words:

@@ -1036,3 +1036,50 @@ def test_closest_shapes_match_oracle(ctx, orc):
                 assert len(idx) > 1000
     finally:
         ctx.upload_boxes(np.zeros((0, 2, 2)), None, None, dw=2)          # back to the box checker for the tests that follow
+
+
+# ---- the single-synchronisation step (mpfmt_graph_step_device) -------------------------------------------------------
+
+def _resident_graph(ctx, N):
+    import torch
+    from motionplanning_jl_amd.distributed import DevArray
+    cp, rv, nz, fr = ctx.graph_device_ptrs()
+    colptr = torch.as_tensor(DevArray(cp, N + 1, "<i8"), device="cuda:0").cpu().numpy()
+    nnz = int(colptr[-1])
+    if nnz == 0:
+        return colptr, np.zeros(0, np.int32), np.zeros(0), np.zeros(0, np.int64)
+    rowval = torch.as_tensor(DevArray(rv, nnz, "<i4"), device="cuda:0").cpu().numpy()
+    nzval = torch.as_tensor(DevArray(nz, nnz, "<f8"), device="cuda:0").cpu().numpy()
+    free = torch.as_tensor(DevArray(fr, (nnz + 63) // 64, "<i8"), device="cuda:0").cpu().numpy()
+    return colptr, rowval, nzval, free
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_graph_step_device_equals_build_plus_sweep(orc, world):
+    """mpfmt_graph_step_device (one host synchronisation; sizes of the previous identical step taken on trust, validated
+    afterwards) gives the same resident graph and mask as graph_build_device + graph_sweep_device -- on the first call
+    (careful path), on repeats (speculative path), when the samples change under the same (N, r) (speculation may or may
+    not hold) and when they change so much that every trusted capacity is wrong (device flag voids the kernels, host
+    redoes the step)."""
+    rng = np.random.default_rng(4242)
+    N, d, M = 20000, 4, 30
+    X, lohi = random_world(rng, N, d, M, 0.03, 0.1)
+    r = 0.11
+    lo, hi = np.full(d, 0.01), np.full(d, 0.99)
+    for g in range(world):
+        a = mp.Context(0); b = mp.Context(0)
+        for c in (a, b):
+            c.set_shard(g, world); c.set_option("rebuild_index", 1)
+            c.upload_samples(X); c.upload_boxes(lohi, lo, hi)
+        Xs = [X, X, X, rng.random((N, d)), rng.random((N, d)),
+              0.5 + 0.04 * rng.standard_normal((N, d)),             # a tight cluster: degrees explode, every capacity is too small
+              rng.random((N, d))]                                   # and back: capacities far too large
+        for it, Xi in enumerate(Xs):
+            a.upload_samples(Xi); b.upload_samples(Xi)
+            nnz_b = b.graph_build_device(r); b.graph_sweep_device()
+            nnz_a = a.graph_step_device(r)
+            assert nnz_a == nnz_b, (g, it)
+            ga, gb = _resident_graph(a, N), _resident_graph(b, N)
+            for u, v in zip(ga, gb):
+                assert np.array_equal(u, v), (g, it)
+        assert nnz_a > 10 * N // world // 4

@@ -9,6 +9,6 @@ c.set_shard(g, G)
 c.upload_samples(w.X); c.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
 c.set_option("rebuild_index", 1)
 for _ in range(12):
-    nnz = c.graph_build_device(w.r); c.graph_sweep_device()
+    nnz = c.graph_step_device(w.r)
 torch.cuda.synchronize()
 print("nnz", nnz, "slices", c.stat("slices"))

@@ -12,11 +12,11 @@ for G in (1, 2, 4, 8):
         c.upload_samples(w.X); c.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
         c.set_option("rebuild_index", 1)
         for _ in range(2):
-            nnz = c.graph_build_device(w.r); c.graph_sweep_device()
+            nnz = c.graph_step_device(w.r)
         c.timing_reset()
         torch.cuda.synchronize(); t = time.time()
         for _ in range(5):
-            nnz = c.graph_build_device(w.r); c.graph_sweep_device()
+            nnz = c.graph_step_device(w.r)
         c.graph_device_ptrs(); torch.cuda.synchronize()
         dt = (time.time() - t) / 5
         worst = max(worst, dt)
