@@ -479,8 +479,34 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     const int64_t N = ctx->N;
     // shard: contiguous range of 256-sample blocks (4 tiles) of the cell-sorted order
     const int64_t nblocks4 = (ctx->ntiles + 3) / 4;
-    ctx->tile_begin = std::min<int64_t>(ctx->ntiles, 4 * (nblocks4 * ctx->rank / ctx->world));
-    ctx->tile_end = std::min<int64_t>(ctx->ntiles, 4 * (nblocks4 * (ctx->rank + 1) / ctx->world));
+    // Boundaries at equal ESTIMATED WORK rather than equal sample counts: a column's work (candidate pairs, edges) goes
+    // with the number of grid cells around its own -- 2 instead of 3 per dimension at the faces of the domain -- so the
+    // first and last shards of an equal-count split would idle while the interior ones finish (30 % at 8 shards on the
+    // north star).  Weight of a cell = prod_i (cells within +-1 along i); the cut positions assume a uniform density
+    // (only the balance depends on that, never the result), and every rank derives the same cuts from the grid alone.
+    auto shard_cut = [&](int g) -> int64_t {                       // first 256-sample block of shard g
+        if (g <= 0) return 0;
+        if (g >= ctx->world) return nblocks4;
+        const mpfmt_grid& G = ctx->grid;
+        const int d = ctx->d;
+        // cells are sorted with dimension 0 most significant: weight prefix over (c0, c1) slabs is enough resolution
+        // (finer dimensions only matter inside one slab, where the weights of the remaining dimensions average out)
+        const int g0 = std::max(1, G.g[0]), g1 = d > 1 ? std::max(1, G.g[1]) : 1;
+        auto nb = [](int c, int n) { return n == 1 ? 1 : ((c == 0 || c == n - 1) ? 2 : 3); };
+        double total = 0.0;
+        for (int a = 0; a < g0; ++a) for (int b = 0; b < g1; ++b) total += (double)nb(a, g0) * (double)nb(b, g1);
+        const double want = total * (double)g / (double)ctx->world;
+        double acc = 0.0, frac = 1.0;
+        for (int a = 0; a < g0 && frac == 1.0; ++a)
+            for (int b = 0; b < g1; ++b) {
+                const double w = (double)nb(a, g0) * (double)nb(b, g1);
+                if (acc + w >= want) { frac = ((double)(a * g1 + b) + (want - acc) / w) / (double)(g0 * g1); break; }
+                acc += w;
+            }
+        return std::min<int64_t>(nblocks4, std::max<int64_t>(0, (int64_t)std::llround(frac * (double)nblocks4)));
+    };
+    ctx->tile_begin = std::min<int64_t>(ctx->ntiles, 4 * shard_cut(ctx->rank));
+    ctx->tile_end = std::min<int64_t>(ctx->ntiles, 4 * shard_cut(ctx->rank + 1));
     const int64_t nt = ctx->tile_end - ctx->tile_begin;
 
     // path: MFMA fp16 filter + exact refine when it is usable, else the exact fp64 VALU kernel
