@@ -124,26 +124,39 @@ __global__ void k_make_ops(const double* __restrict__ Xs, int64_t N, int64_t npa
 // sorted array -> 64-sample chunks -- is flattened lane-parallel, every chunk's tight box is tested against the tile's
 // tight box (64 box tests in flight together) and the surviving unique chunk ids are ballot-compacted into the tile's
 // list in global memory (ascending).  The pair kernel's items then take contiguous slices of these lists.
-template <int D>
-__global__ __launch_bounds__(64) void k_chunk_lists(const int32_t* __restrict__ cellstart, const double* __restrict__ tile_lo,
-                                                    const double* __restrict__ tile_hi, mpfmt_grid G, double rpad,
+// NW = 1: as described.  NW = 4 (small shards, where one wavefront per tile leaves most of the chip idle and the kernel is
+// one long latency chain): the tile's rows are split into NW contiguous ranges, one per wavefront; each stages its kept
+// ids in LDS, and the ranges are concatenated in order -- a chunk straddling two ranges is kept by both or by neither
+// (same box test), so dropping a range's first id when it equals the previous range's last restores the dedupe exactly.
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restrict__ cellstart, const double* __restrict__ tile_lo,
+                                                    const double* __restrict__ tile_hi, const double* __restrict__ tile_sub,
+                                                    mpfmt_grid G, double rpad,
                                                     int64_t tile_begin, int64_t nt, int64_t list_cap,
                                                     uint32_t* __restrict__ lists, int32_t* __restrict__ list_len,
                                                     int32_t* __restrict__ max_len)
 {
-    __shared__ int32_t s_sega[64];                        // first chunk of each row's run
-    __shared__ int32_t s_segp[64];                        // exclusive prefix of the runs' chunk counts
-    const int lane = threadIdx.x;
+    __shared__ int32_t s_sega_[NW][64];                   // first chunk of each row's run
+    __shared__ int32_t s_segp_[NW][64];                   // exclusive prefix of the runs' chunk counts
+    __shared__ int32_t s_wcnt[NW], s_wfirst[NW], s_wlast[NW];
+    extern __shared__ uint32_t s_stage[];                 // NW > 1: [NW][list_cap] kept ids of each wavefront's row range
+    const int lane = threadIdx.x & 63;
+    const int wave = (NW > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    int32_t* const s_sega = s_sega_[wave];
+    int32_t* const s_segp = s_segp_[wave];
     const int64_t tl = blockIdx.x;
     if (tl >= nt) return;
     const int64_t tile = tile_begin + tl;
     const double rpad2 = rpad * rpad;
     double wlo[D], whi[D];
+    double qal[D], qah[D], qbl[D], qbh[D];                // the tile's two sub-boxes (k_tile_bbox)
     int clo[D], chi[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         wlo[i] = tile_lo[tile * D + i];
         whi[i] = tile_hi[tile * D + i];
+        qal[i] = tile_sub[(tile * 4 + 0) * D + i]; qah[i] = tile_sub[(tile * 4 + 1) * D + i];
+        qbl[i] = tile_sub[(tile * 4 + 2) * D + i]; qbh[i] = tile_sub[(tile * 4 + 3) * D + i];
         clo[i] = cell_of_m(wlo[i] - rpad, G.lo[i], G.inv_w[i], G.g[i]);
         chi[i] = cell_of_m(whi[i] + rpad, G.lo[i], G.inv_w[i], G.g[i]);
     }
@@ -153,16 +166,20 @@ __global__ __launch_bounds__(64) void k_chunk_lists(const int32_t* __restrict__ 
     for (int i = 0; i < L; ++i) rows *= (uint32_t)(chi[i] - clo[i] + 1);
 
     uint32_t* __restrict__ out = lists + tl * list_cap;
+    uint32_t* const stage = (NW > 1) ? s_stage + (int64_t)wave * list_cap : nullptr;
     int32_t gcount = 0;              // unique surviving chunks so far (uniform)
     int64_t carry = -1;              // last chunk id of the previous flattened batch (dedupe)
-    for (uint32_t row0 = 0; row0 < rows; row0 += 64) {
+    int64_t firstkept = -1, lastkept = -1;
+    const uint32_t nbatch = (rows + 63) / 64, bq = (nbatch + NW - 1) / NW;
+    const uint32_t row_begin = (uint32_t)wave * bq * 64, row_end = min(rows, (uint32_t)(wave + 1) * bq * 64);
+    for (uint32_t row0 = row_begin; row0 < row_end; row0 += 64) {
         // lane = one row: candidate run [ca, ca+n) in chunk units
         const uint32_t row = row0 + lane;
         int32_t ca = 0, n = 0;
-        if (row < rows) {
+        if (row < row_end) {
             uint32_t rem = row;
             int64_t cbase = 0;
-            double partial = 0.0;
+            double partial = 0.0, pa = 0.0, pb = 0.0;      // row cell vs the hull / sub-box A / sub-box B
 #pragma unroll
             for (int i = L - 1; i >= 0; --i) {
                 const uint32_t span = (uint32_t)(chi[i] - clo[i] + 1);
@@ -174,10 +191,13 @@ __global__ __launch_bounds__(64) void k_chunk_lists(const int32_t* __restrict__ 
                 const double lo = G.lo[i] + (double)c * G.w[i] - eps;
                 const double hi = G.lo[i] + (double)(c + 1) * G.w[i] + eps;
                 double gap = fmax(fmax(lo - whi[i], wlo[i] - hi), 0.0);
-                if (G.g[i] == 1) gap = 0.0;
+                double ga = fmax(fmax(lo - qah[i], qal[i] - hi), 0.0);
+                double gb = fmax(fmax(lo - qbh[i], qbl[i] - hi), 0.0);
+                if (G.g[i] == 1) { gap = 0.0; ga = 0.0; gb = (qbl[i] > qbh[i]) ? gb : 0.0; }
                 partial += gap * gap;
+                pa += ga * ga; pb += gb * gb;
             }
-            if (partial <= rpad2) {
+            if (partial <= rpad2 && fmin(pa, pb) <= rpad2) {
                 int c0 = clo[L], c1 = chi[L];
                 if (G.g[L] > 1) {
                     const double eps = G.w[L] * 1e-9;
@@ -230,23 +250,55 @@ __global__ __launch_bounds__(64) void k_chunk_lists(const int32_t* __restrict__ 
             carry = __shfl(c, lastl);
             bool keep = act && (c != prevc);
             if (keep) {
-                double gap2 = 0.0;
+                double gaa = 0.0, gab = 0.0, gba = 0.0, gbb = 0.0;      // query sub-box x candidate sub-box
+                const double* __restrict__ cs = tile_sub + c * 4 * D;
 #pragma unroll
                 for (int i = 0; i < D; ++i) {
-                    const double gp = fmax(fmax(tile_lo[c * D + i] - whi[i], wlo[i] - tile_hi[c * D + i]), 0.0);
-                    gap2 += gp * gp;
+                    const double cal = cs[i], cah = cs[D + i], cbl = cs[2 * D + i], cbh = cs[3 * D + i];
+                    const double g0 = fmax(fmax(cal - qah[i], qal[i] - cah), 0.0);
+                    const double g1 = fmax(fmax(cbl - qah[i], qal[i] - cbh), 0.0);
+                    const double g2 = fmax(fmax(cal - qbh[i], qbl[i] - cah), 0.0);
+                    const double g3 = fmax(fmax(cbl - qbh[i], qbl[i] - cbh), 0.0);
+                    gaa += g0 * g0; gab += g1 * g1; gba += g2 * g2; gbb += g3 * g3;
                 }
-                keep = gap2 <= rpad2;
+                keep = fmin(fmin(gaa, gab), fmin(gba, gbb)) <= rpad2;
             }
             const unsigned long long m = __ballot(keep);
             const int32_t gidx = gcount + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (keep && gidx < list_cap) out[gidx] = (uint32_t)c;
+            if (NW == 1) { if (keep && gidx < list_cap) out[gidx] = (uint32_t)c; }
+            else {
+                if (keep && gidx < list_cap) stage[gidx] = (uint32_t)c;
+                if (m) {
+                    if (firstkept < 0) firstkept = __shfl(c, __builtin_ctzll(m));
+                    lastkept = __shfl(c, 63 - __builtin_clzll(m));
+                }
+            }
             gcount += (int32_t)__popcll(m);
         }
         __builtin_amdgcn_wave_barrier();
     }
     // the stored length never exceeds what was written (a truncated list voids the build: max_len tells the host / k_spec_check)
-    if (lane == 0) { list_len[tl] = min(gcount, (int32_t)list_cap); atomicMax(max_len, gcount); }
+    if (NW == 1) {
+        if (lane == 0) { list_len[tl] = min(gcount, (int32_t)list_cap); atomicMax(max_len, gcount); }
+        return;
+    }
+    if (lane == 0) { s_wcnt[wave] = gcount; s_wfirst[wave] = (int32_t)firstkept; s_wlast[wave] = (int32_t)lastkept; }
+    __syncthreads();
+    int32_t off = 0, total = 0, mydrop = 0, prevlast = -1;
+#pragma unroll
+    for (int v = 0; v < NW; ++v) {
+        const int32_t cv = s_wcnt[v];
+        const int32_t drop = (cv > 0 && prevlast >= 0 && s_wfirst[v] == prevlast) ? 1 : 0;
+        if (v == wave) { off = total; mydrop = drop; }
+        total += cv - drop;
+        if (cv > 0) prevlast = s_wlast[v];
+    }
+    const int32_t staged = min(gcount, (int32_t)list_cap);
+    for (int32_t i = mydrop + lane; i < staged; i += 64) {
+        const int32_t o = off + i - mydrop;
+        if (o < list_cap) out[o] = stage[i];
+    }
+    if (threadIdx.x == 0) { list_len[tl] = min(total, (int32_t)list_cap); atomicMax(max_len, total); }
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
@@ -745,8 +797,12 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
         if ((rc = mpfmt_ensure(ctx, (void**)&ctx->lists, sizeof(uint32_t) * (size_t)cap * (size_t)nt))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->list_len + nt, 0, sizeof(int32_t), ctx->stream));
         const mpfmt_grid& G = ctx->grid;
-#define CASE(DD) case DD: hipLaunchKernelGGL((k_chunk_lists<DD>), dim3((unsigned)nt), dim3(64), 0, ctx->stream, ctx->cellstart, \
-            ctx->tile_lo, ctx->tile_hi, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt); break;
+        // few tiles (a small shard): four wavefronts per tile, kept ids staged in LDS (4 x cap x 4 bytes)
+        const bool wide = nt < 16 * (int64_t)ctx->num_cus && cap <= 3072;
+#define CASE(DD) case DD: if (wide) hipLaunchKernelGGL((k_chunk_lists<DD, 4>), dim3((unsigned)nt), dim3(256), (size_t)cap * 16, ctx->stream, ctx->cellstart, \
+            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt); \
+        else hipLaunchKernelGGL((k_chunk_lists<DD, 1>), dim3((unsigned)nt), dim3(64), 0, ctx->stream, ctx->cellstart, \
+            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt); break;
         switch (ctx->d) {
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
             default: return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path supports d <= 12 (got %d)", ctx->d);

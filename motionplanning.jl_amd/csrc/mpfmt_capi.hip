@@ -182,7 +182,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     if (!ctx) return MPFMT_OK;
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
-    void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi,
+    void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
                     ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->pool_flag, ctx->pool, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t};
@@ -1379,6 +1379,7 @@ int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value)
     if (!ctx || !name || !value) return MPFMT_ERR_ARG;
     if (strcmp(name, "rdisc_path_used") == 0) { *value = ctx->rdisc_path_used; return MPFMT_OK; }
     if (strcmp(name, "pool_used") == 0) { *value = ctx->pool_valid ? 1 : 0; return MPFMT_OK; }
+    if (strcmp(name, "list_cap") == 0) { *value = ctx->list_cap; return MPFMT_OK; }
     if (strcmp(name, "survivors") == 0) { *value = ctx->survivors; return MPFMT_OK; }
     if (strcmp(name, "pairs_tested") == 0) { *value = ctx->pairs_tested; return MPFMT_OK; }
     if (strcmp(name, "nnz") == 0) { *value = ctx->nnz; return MPFMT_OK; }

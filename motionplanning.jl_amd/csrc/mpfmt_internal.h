@@ -79,6 +79,7 @@ struct mpfmt_ctx {
     double* Xt = nullptr;                // [ntiles][d][64] tiled SoA, cell-sorted, NaN padded
     double* tile_lo = nullptr;           // [ntiles][d] tight bounding box of each tile
     double* tile_hi = nullptr;
+    double* tile_sub = nullptr;          // [ntiles][4][d] two sub-boxes per tile (k_tile_bbox)
 
     // ---- r-disc graph (device resident) ------------------------------------------------------------
     double graph_r = -1.0;

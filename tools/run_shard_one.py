@@ -11,4 +11,4 @@ c.set_option("rebuild_index", 1)
 for _ in range(12):
     nnz = c.graph_step_device(w.r)
 torch.cuda.synchronize()
-print("nnz", nnz, "slices", c.stat("slices"))
+print("nnz", nnz, "slices", c.stat("slices"), "list_cap", c.stat("list_cap"))
