@@ -31,10 +31,10 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 
 GATHER_CEILING_ROWS_PER_S = 4.51e10      # measured: 1e8 random 48-byte rows of a 48 MB array in 2.219 ms (profiles/r01_ubench_fetch_calib.txt)
 
 PROFILED_TRAFFIC_BYTES = {
-    # profiles/r01_pmc_v6.txt: FETCH_SIZE 2096418 KiB (x2, gfx950 half-count), WRITE_SIZE 2461455 KiB per launch
-    ("ns_r6_n1m_m200", 1): (2096417.7 * 2 + 2461454.8) * 1024,
-    # profiles/r01_pmc_v6.txt: FETCH_SIZE 7930482 KiB (x2), WRITE_SIZE 449945 KiB per launch
-    ("ns_r6_n1m_m200", 1, "sweep"): (7930482.4 * 2 + 449945.2) * 1024,
+    # profiles/r01_pmc_v7.txt: FETCH_SIZE 1600901 KiB (x2, gfx950 half-count), WRITE_SIZE 2479673 KiB per launch
+    ("ns_r6_n1m_m200", 1): (1600900.8 * 2 + 2479673.1) * 1024,
+    # profiles/r01_pmc_v7.txt: FETCH_SIZE 7930694 KiB (x2), WRITE_SIZE 449945 KiB per launch
+    ("ns_r6_n1m_m200", 1, "sweep"): (7930693.5 * 2 + 449945.2) * 1024,
 }
 
 

@@ -121,18 +121,15 @@ __global__ __launch_bounds__(64) void k_tile_bbox(const double* __restrict__ Xt,
     const int split = (jump > 0) ? where + 1 : 64;         // A = lanes [0, split), B = lanes [split, 64)
     for (int i = 0; i < d; ++i) {
         const double x = Xt[(tile * d + i) * 64 + lane];
-        double mn = x, mx = x;                       // fmin/fmax ignore the NaN pads
-        double amn = lane < split ? x : NAN, amx = amn, bmn = lane < split ? NAN : x, bmx = bmn;
+        double amn = lane < split ? x : NAN, amx = amn, bmn = lane < split ? NAN : x, bmx = bmn;   // fmin/fmax ignore NaN (pads too)
         for (int off = 32; off > 0; off >>= 1) {
-            mn = fmin(mn, __shfl_xor(mn, off));
-            mx = fmax(mx, __shfl_xor(mx, off));
             amn = fmin(amn, __shfl_xor(amn, off));
             amx = fmax(amx, __shfl_xor(amx, off));
             bmn = fmin(bmn, __shfl_xor(bmn, off));
             bmx = fmax(bmx, __shfl_xor(bmx, off));
         }
         if (lane == 0) {
-            tile_lo[tile * d + i] = mn; tile_hi[tile * d + i] = mx;
+            tile_lo[tile * d + i] = fmin(amn, bmn); tile_hi[tile * d + i] = fmax(amx, bmx);      // the hull
             double* t = tile_sub + tile * 4 * d;
             t[i] = (amn == amn) ? amn : 1e300; t[d + i] = (amx == amx) ? amx : -1e300;
             t[2 * d + i] = (bmn == bmn) ? bmn : 1e300; t[3 * d + i] = (bmx == bmx) ? bmx : -1e300;
