@@ -42,7 +42,12 @@ __device__ __forceinline__ int cell_of(double x, double lo, double inv_w, int g)
     return c;
 }
 
-__global__ void k_cellkey(const double* __restrict__ Xo, int64_t N, int d, mpfmt_grid G,
+// Sort key = cell id (row-major, last dimension fastest) followed by fb bits of the sample's position INSIDE its cell along
+// the last dimension.  A tile is 64 consecutive samples of the sorted order and usually takes the tail of one cell and the
+// head of the next one in the row; with the samples of a cell in index order both parts span their whole cells (tile extent
+// two cells along the last dimension), with this key they are the upper end of one cell and the lower end of the next --
+// one cell width.  Any order inside a cell is valid (columns are sorted afterwards); ties keep the index order (stable).
+__global__ void k_cellkey(const double* __restrict__ Xo, int64_t N, int d, mpfmt_grid G, int fb,
                           uint32_t* __restrict__ key, int32_t* __restrict__ val)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,7 +55,16 @@ __global__ void k_cellkey(const double* __restrict__ Xo, int64_t N, int d, mpfmt
     int64_t id = 0;
     for (int i = 0; i < d; ++i)
         id += (int64_t)cell_of(Xo[p * d + i], G.lo[i], G.inv_w[i], G.g[i]) * G.stride[i];
-    key[p] = (uint32_t)id;
+    uint32_t fine = 0;
+    if (fb > 0) {
+        const int L = d - 1;
+        const double wdt = (G.g[L] > 1) ? G.w[L] : fmax(G.w[L], 1e-300);
+        const double t = (Xo[p * d + L] - G.lo[L]) / wdt - (double)cell_of(Xo[p * d + L], G.lo[L], G.inv_w[L], G.g[L]);
+        const double q = floor(fmin(fmax(t, 0.0), 1.0) * (double)(1u << fb));
+        fine = min((uint32_t)q, (1u << fb) - 1u);
+        if (!(t == t)) fine = 0;
+    }
+    key[p] = ((uint32_t)id << fb) | fine;
     val[p] = (int32_t)p;
 }
 
@@ -82,7 +96,7 @@ __global__ void k_tiles_from_aos(const double* __restrict__ Xs, int64_t npad, in
     Xt[t] = Xs[(tile * 64 + lane) * d + i];
 }
 
-__global__ void k_cellstart(const uint32_t* __restrict__ key_sorted, int64_t N, int64_t ncells,
+__global__ void k_cellstart(const uint32_t* __restrict__ key_sorted, int fb, int64_t N, int64_t ncells,
                             int32_t* __restrict__ cellstart)
 {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,7 +104,7 @@ __global__ void k_cellstart(const uint32_t* __restrict__ key_sorted, int64_t N, 
     int64_t lo = 0, hi = N;                 // lower_bound(key_sorted, c)
     while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)key_sorted[mid] < c) lo = mid + 1; else hi = mid;
+        if ((int64_t)(key_sorted[mid] >> fb) < c) lo = mid + 1; else hi = mid;
     }
     cellstart[c] = (int32_t)lo;
 }
@@ -101,7 +115,7 @@ __global__ void k_cellstart(const uint32_t* __restrict__ key_sorted, int64_t N, 
 // cell key jumps the most and each side gets its own box (tile_sub [tile][A lo, A hi, B lo, B hi][d]; B is an empty box
 // (+1e300, -1e300) when the tile lies in one cell) -- the candidate lists test sub-box against sub-box, which keeps them
 // ~30 % shorter than hull against hull.  Any split is valid: every sample lies in A or in B.
-__global__ __launch_bounds__(64) void k_tile_bbox(const double* __restrict__ Xt, const uint32_t* __restrict__ cellkey, int64_t N,
+__global__ __launch_bounds__(64) void k_tile_bbox(const double* __restrict__ Xt, const uint32_t* __restrict__ cellkey, int fb, int64_t N,
                                                   int64_t ntiles, int d, double* __restrict__ tile_lo, double* __restrict__ tile_hi,
                                                   double* __restrict__ tile_sub)
 {
@@ -109,7 +123,7 @@ __global__ __launch_bounds__(64) void k_tile_bbox(const double* __restrict__ Xt,
     if (tile >= ntiles) return;
     int lane = threadIdx.x;
     const int64_t sp = tile * 64 + lane;
-    const int64_t key = (int64_t)cellkey[min(sp, N - 1)];
+    const int64_t key = (int64_t)(cellkey[min(sp, N - 1)] >> fb);
     const int64_t nxt = __shfl_down(key, 1);
     int64_t jump = (lane < 63 && sp + 1 < N) ? llabs(nxt - key) : 0;
     int where = lane;
@@ -204,6 +218,8 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
         size_t tmp_bytes = 0;
         int bits = 1;
         while (((int64_t)1 << bits) < G.ncells) ++bits;
+        const int fb = std::min(8, 32 - bits);                         // position bits inside the cell (see k_cellkey)
+        bits += fb;
         // rocprim's default takes its merge sort (about 20 launches) up to 2^20 items; the cell key has few bits, so the
         // onesweep radix sort (histogram + one pass per 8 bits) is the shorter pipeline from a few thousand samples on
         using sort_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
@@ -219,16 +235,16 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
         void* tmp = (char*)scr + off_tmp;
         const int B = 256;
         hipLaunchKernelGGL(k_cellkey, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream,
-                           ctx->Xo, N, d, G, key_in, val_in);
+                           ctx->Xo, N, d, G, fb, key_in, val_in);
         HIPCHK(ctx, rocprim::radix_sort_pairs<sort_cfg>(tmp, tmp_bytes, key_in, ctx->cellkey, val_in, val_out, (size_t)N, 0, bits, ctx->stream));
         const int64_t ne = npad * d;
         hipLaunchKernelGGL(k_sorted_perm_aos, dim3((unsigned)((ne + B - 1) / B)), dim3(B), 0, ctx->stream,
                            ctx->Xo, val_out, N, npad, d, ctx->perm, ctx->iperm, ctx->Xs);
         hipLaunchKernelGGL(k_tiles_from_aos, dim3((unsigned)((ne + B - 1) / B)), dim3(B), 0, ctx->stream, ctx->Xs, npad, d, ctx->Xt);
         hipLaunchKernelGGL(k_cellstart, dim3((unsigned)((G.ncells + 1 + B - 1) / B)), dim3(B), 0, ctx->stream,
-                           ctx->cellkey, N, G.ncells, ctx->cellstart);
+                           ctx->cellkey, fb, N, G.ncells, ctx->cellstart);
         hipLaunchKernelGGL(k_tile_bbox, dim3((unsigned)ctx->ntiles), dim3(64), 0, ctx->stream,
-                           ctx->Xt, ctx->cellkey, N, ctx->ntiles, d, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub);
+                           ctx->Xt, ctx->cellkey, fb, N, ctx->ntiles, d, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub);
         HIPCHK(ctx, hipGetLastError());
     }
     mpfmt_time_end(ctx, "grid");
