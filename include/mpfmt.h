@@ -294,7 +294,8 @@ int32_t mpfmt_graph_sweep_device(mpfmt_ctx* ctx);
  * its kernels (nnz sizes the CSC and the mask).  When the previous step of the same (N, r, shard) took the single-pass
  * path, this call trusts its sizes, issues every kernel back to back, lets a device flag void the kernels after a capacity
  * that did not hold, validates after the synchronisation and transparently redoes the step the careful way if needed.
- * Results are identical to the two-call form. */
+ * Results are identical to the two-call form and complete in HBM when the call returns (graph_sweep_device, by contrast,
+ * only enqueues its kernel on the ctx's stream). */
 int32_t mpfmt_graph_step_device(mpfmt_ctx* ctx, double r, int64_t* nnz);
 int32_t mpfmt_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** rowval, void** nzval, void** free_mask);
 /* Shard bookkeeping for the all-gather: column range (in the library's sorted order) and the number

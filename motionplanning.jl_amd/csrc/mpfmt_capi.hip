@@ -296,6 +296,9 @@ int32_t mpfmt_graph_step_device(mpfmt_ctx* ctx, double r, int64_t* nnz)
     ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
     if (ctx->rebuild_index) { ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; }
     if ((rc = mpfmt_graph_step(ctx, r))) return rc;
+    // results are complete on return (the speculative path has synchronised after its last launch already; the careful
+    // path launched the sweep after its last read-back)
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (nnz) *nnz = ctx->nnz;
     return MPFMT_OK;
 }

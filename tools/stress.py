@@ -3,14 +3,16 @@ random sizes / dimensions / radii / obstacle counts.  Usage: python tools/stress
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch
 import motionplanning_jl_amd as mp
+from motionplanning_jl_amd.distributed import DevArray
 from oracle import oracle as orc
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t0 = time.time(); cases = 0; edges = 0
 while time.time() - t0 < budget:
     d = int(rng.integers(1, (int(sys.argv[3]) if len(sys.argv) > 3 else 8) + 1))
-    N = int(rng.choice([1, 2, 17, 64, 65, 200, 700, 1500, 3000]))
+    N = int(rng.choice([1, 2, 17, 64, 65, 200, 700, 1500, 3000, 9000]))
     M = int(rng.choice([0, 1, 7, 60, 257, 520]))
     X = rng.random((N, d))
     if rng.random() < 0.3:
@@ -61,6 +63,16 @@ while time.time() - t0 < budget:
         if len(rowval):
             cols = np.repeat(np.arange(1, N + 1), k)
             assert np.array_equal(ctx.edges_free(rowval, cols), want), ("edges_free", d, N, M, r)
+        # the single-synchronisation step: first call careful, repeats speculative -- same resident graph and mask
+        for rep in range(3):
+            nnz = ctx.graph_step_device(r)
+            assert nnz == len(rowval), ("step nnz", d, N, r, world, rank, rep)
+            cp, rv, nz, fr = ctx.graph_device_ptrs()
+            dev = lambda ptr, n, ts: torch.as_tensor(DevArray(ptr, n, ts), device="cuda:0").cpu().numpy()
+            assert np.array_equal(dev(cp, N + 1, "<i8"), colptr - 1), ("step colptr", d, N, r, world, rank, rep)
+            if nnz:
+                assert np.array_equal(dev(rv, nnz, "<i4"), rowval - 1) and np.array_equal(dev(nz, nnz, "<f8"), nzval), ("step graph", d, N, r, world, rank, rep)
+                assert np.array_equal(dev(fr, (nnz + 63) // 64, "<i8").view(np.uint64), want), ("step mask", d, N, M, r, world, rank, rep)
         ctx.close()
     assert tot == len(orow), ("shard total", d, N, r, world)
     cases += 1; edges += len(orow)
