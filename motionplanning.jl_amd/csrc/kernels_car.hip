@@ -246,6 +246,117 @@ __host__ __device__ inline double rs_steer(const double* s1, const double* s2, d
     return b.c * r;
 }
 
+// Cost only (the graph's cost filter evaluates 1e8+ candidate pairs and keeps the cost alone): the same 46 evaluations in
+// the same order with the same accept rule, but no controls are stored (rs_steer's path arrays and its runtime-indexed image
+// table live in scratch: 336 bytes per lane, 2 wavefronts per SIMD), every image is a compile-time case, and the images'
+// sin / cos come from ONE sincos of the heading difference -- the eight images only flip its sign (sin odd, cos even).
+template <int F>
+__device__ __forceinline__ void rs_fam_cost(const double x, const double y, const double th, const double st, const double ct, double& c)
+{
+    double cnew;
+    if constexpr (F == 0) {
+        double r, a; rs_R(x - st, y - 1 + ct, r, a);
+        const double u = r, t = mod2pif(a), v = mod2pif(th - t);
+        cnew = t + u + v;
+    } else if constexpr (F == 1) {
+        double r, a, r1, a1; rs_R(x + st, y - 1 - ct, r, a);
+        if (r * r < 4) return;
+        const double u = sqrt(r * r - 4);
+        rs_R(u, 2.0, r1, a1);
+        const double t = mod2pif(a + a1), v = mod2pif(t - th);
+        cnew = t + u + v;
+    } else if constexpr (F == 2 || F == 3) {
+        const double E = x - st, N = y + ct - 1;
+        if (E * E + N * N > 16) return;
+        double r, a; rs_R(E, N, r, a);
+        double u = acos(1 - r * r / 8);
+        const double t = mod2pif(a - u / 2 + CAR_PI);
+        double v = mod2pif(CAR_PI - u / 2 - a + th);
+        if (F == 3) v = v - CAR_TWOPI;
+        u = -u;
+        cnew = (F == 2) ? t - u + v : t - u - v;
+    } else if constexpr (F == 4) {
+        const double E = x + st, N = y - ct - 1;
+        const double p = (2 + sqrt(E * E + N * N)) / 4;
+        if (p < 0 || p > 1) return;
+        const double u = acos(p);
+        const double t = mod2pif(rs_Tau(u, -u, E, N)), v = mod2pif(rs_Omega(u, -u, E, N, th)) - CAR_TWOPI;
+        cnew = t + 2 * u - v;
+    } else if constexpr (F == 5) {
+        const double E = x + st, N = y - ct - 1;
+        const double p = (20 - E * E - N * N) / 16;
+        if (p < 0 || p > 1) return;
+        const double u = -acos(p);
+        const double t = mod2pif(rs_Tau(u, u, E, N)), v = mod2pif(rs_Omega(u, u, E, N, th));
+        cnew = t - 2 * u + v;
+    } else if constexpr (F == 6) {
+        const double E = x - st, N = y + ct - 1;
+        double D, be; rs_R(E, N, D, be);
+        if (D < 2) return;
+        const double ga = acos(2 / D), Fq = sqrt(D * D / 4 - 1);
+        const double t = mod2pif(CAR_PI + be - ga), u = 2 - 2 * Fq;
+        if (u > 0) return;
+        const double v = mod2pif(-3 * CAR_PI / 2 + ga + th - be) - CAR_TWOPI;
+        cnew = t + CAR_PI / 2 - u - v;
+    } else if constexpr (F == 7) {
+        const double E = x + st, N = y - ct - 1;
+        double D, be; rs_R(E, N, D, be);
+        if (D < 2) return;
+        const double t = mod2pif(be + CAR_PI / 2), u = 2 - D;
+        if (u > 0) return;
+        const double v = mod2pif(-CAR_PI - th + be) - CAR_TWOPI;
+        cnew = t + CAR_PI / 2 - u - v;
+    } else {
+        const double E = x + st, N = y - ct - 1;
+        double D, be; rs_R(E, N, D, be);
+        if (D < 2) return;
+        const double ga = acos(2 / D), Fq = sqrt(D * D / 4 - 1);
+        const double t = mod2pif(CAR_PI + be - ga), u = 4 - 2 * Fq;
+        if (u > 0) return;
+        const double v = mod2pif(CAR_PI + be - th - ga);
+        cnew = t + CAR_PI - u + v;
+    }
+    if (!(c <= cnew)) c = cnew;                                           // rs_accept's rule
+}
+
+__device__ inline double rs_cost(const double* s1, const double* s2, double r)
+{
+    const double dx = (s2[0] - s1[0]) / r, dy = (s2[1] - s1[1]) / r;
+    const double c1 = cos(s1[2]), s1n = sin(s1[2]);
+    const double X = dx * c1 + dy * s1n, Y = -dx * s1n + dy * c1, th = mod2pif(s2[2] - s1[2]);
+    const double st = sin(th), ct = cos(th);
+    const double Xb = X * ct + Y * st, Yb = X * st - Y * ct;              // backwards image (:247)
+    double c = INFINITY;
+    // image i of rs_steer's table: 0 id, 1 T, 2 R, 4 R_T, 3 B, 5 B_T, 6 B_R, 7 B_R_T (angle th or -th: sin flips, cos stays)
+#define RS_IMG0(F) rs_fam_cost<F>(X, Y, th, st, ct, c)
+#define RS_IMG1(F) rs_fam_cost<F>(-X, Y, -th, -st, ct, c)
+#define RS_IMG2(F) rs_fam_cost<F>(X, -Y, -th, -st, ct, c)
+#define RS_IMG4(F) rs_fam_cost<F>(-X, -Y, th, st, ct, c)
+#define RS_IMG3(F) rs_fam_cost<F>(Xb, Yb, th, st, ct, c)
+#define RS_IMG5(F) rs_fam_cost<F>(-Xb, Yb, -th, -st, ct, c)
+#define RS_IMG6(F) rs_fam_cost<F>(Xb, -Yb, -th, -st, ct, c)
+#define RS_IMG7(F) rs_fam_cost<F>(-Xb, -Yb, th, st, ct, c)
+#define RS_FOUR(F) RS_IMG0(F); RS_IMG1(F); RS_IMG2(F); RS_IMG4(F)
+#define RS_EIGHT(F) RS_FOUR(F); RS_IMG3(F); RS_IMG5(F); RS_IMG6(F); RS_IMG7(F)
+    RS_FOUR(0); RS_FOUR(1);
+    RS_IMG0(2); RS_IMG2(2);
+    RS_EIGHT(3);
+    RS_FOUR(4); RS_FOUR(5);
+    RS_EIGHT(6); RS_EIGHT(7);
+    RS_FOUR(8);
+#undef RS_IMG0
+#undef RS_IMG1
+#undef RS_IMG2
+#undef RS_IMG3
+#undef RS_IMG4
+#undef RS_IMG5
+#undef RS_IMG6
+#undef RS_IMG7
+#undef RS_FOUR
+#undef RS_EIGHT
+    return c * r;
+}
+
 // KIND 1 = Dubins (3 segments), 2 = Reeds-Shepp (up to 5)
 template <int KIND>
 __host__ __device__ __forceinline__ double car_steer(const double* s1, const double* s2, double r, double s, car_step* path, int& L)
@@ -345,9 +456,13 @@ __global__ __launch_bounds__(256) void k_car_cost(const double* __restrict__ X, 
         int64_t lo = 0, hi = N;
         while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (ccolptr[mid] <= e) lo = mid; else hi = mid; }
         const int64_t j = lo, i = crowval[e];
-        car_step path[5];
-        int L;
-        const double c = (KIND == 2) ? car_steer<KIND>(X + 3 * j, X + 3 * i, rt, sp, path, L) : car_steer<KIND>(X + 3 * i, X + 3 * j, rt, sp, path, L);
+        double c;
+        if constexpr (KIND == 2) c = rs_cost(X + 3 * j, X + 3 * i, rt);
+        else {
+            car_step path[5];
+            int L;
+            c = car_steer<KIND>(X + 3 * i, X + 3 * j, rt, sp, path, L);
+        }
         cost[e] = c;
         k = c <= r;
     }
