@@ -148,6 +148,9 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
     if (tl >= nt) return;
     const int64_t tile = tile_begin + tl;
     const double rpad2 = rpad * rpad;
+    bool use_sub = false;
+#pragma unroll
+    for (int i = 0; i < D; ++i) use_sub = use_sub || (G.g[i] >= 3);
     double wlo[D], whi[D];
     double qal[D], qah[D], qbl[D], qbh[D];                // the tile's two sub-boxes (k_tile_bbox)
     int clo[D], chi[D];
@@ -249,7 +252,15 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
             const int lastl = min(63, T - t0 - 1);
             carry = __shfl(c, lastl);
             bool keep = act && (c != prevc);
-            if (keep) {
+            if (keep && !use_sub) {                       // coarse grid (<= 2 cells per dimension): every cell neighbours every other
+                double gap2 = 0.0;                        // one, a tile running over a row end loses nothing -- hull against hull
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    const double gp = fmax(fmax(tile_lo[c * D + i] - whi[i], wlo[i] - tile_hi[c * D + i]), 0.0);
+                    gap2 += gp * gp;
+                }
+                keep = gap2 <= rpad2;
+            } else if (keep) {
                 double gaa = 0.0, gab = 0.0, gba = 0.0, gbb = 0.0;      // query sub-box x candidate sub-box
                 const double* __restrict__ cs = tile_sub + c * 4 * D;
 #pragma unroll
