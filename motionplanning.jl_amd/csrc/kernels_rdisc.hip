@@ -507,6 +507,21 @@ __global__ void k_spec_check(const int32_t* __restrict__ pool_flag, const int32_
     *spec_fail = (*pool_flag != 0) || (list_max && (int64_t)*list_max > list_cap) || (*nnz >= nnz_cap);
 }
 
+// everything the host wants to know after a count, gathered into one block so that ONE copy into pinned memory brings it
+// back (four separate copies into pageable host variables are four blocking round trips: ~100 us of idle GPU per step)
+struct count_readback { unsigned long long pairs[512]; long long nnz; int pool_over, list_mx; };
+__global__ __launch_bounds__(512) void k_count_readback(const unsigned long long* __restrict__ pairs, const int64_t* __restrict__ nnz,
+                                                        const int32_t* __restrict__ pool_flag, const int32_t* __restrict__ list_max,
+                                                        count_readback* __restrict__ out)
+{
+    out->pairs[threadIdx.x] = pairs[threadIdx.x];
+    if (threadIdx.x == 0) {
+        out->nnz = *nnz;
+        out->pool_over = pool_flag ? *pool_flag : 0;
+        out->list_mx = list_max ? *list_max : 0;
+    }
+}
+
 int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
 {
     int32_t rc;
@@ -653,15 +668,17 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     const bool pool = ctx->cnt_pool;
     const int64_t nt = ctx->tile_end - ctx->tile_begin;
     if (spec_failed) *spec_failed = false;
-    int64_t nnz = 0;
-    unsigned long long pairs[512];
-    HIPCHK(ctx, hipMemcpyAsync(&nnz, ctx->colptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(pairs, ctx->d_pairs, sizeof(pairs), hipMemcpyDeviceToHost, ctx->stream));
-    int32_t pool_over = 0;
-    if (pool) HIPCHK(ctx, hipMemcpyAsync(&pool_over, ctx->pool_flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    int32_t list_mx = 0;
-    if (ctx->spec_lists && nt > 0) HIPCHK(ctx, hipMemcpyAsync(&list_mx, ctx->list_len + nt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx->rb_dev) HIPCHK(ctx, hipMalloc(&ctx->rb_dev, sizeof(count_readback)));
+    if (!ctx->rb_host) HIPCHK(ctx, hipHostMalloc(&ctx->rb_host, sizeof(count_readback), hipHostMallocDefault));
+    hipLaunchKernelGGL(k_count_readback, dim3(1), dim3(512), 0, ctx->stream, ctx->d_pairs, ctx->colptr + N, pool ? ctx->pool_flag : nullptr,
+                       (ctx->spec_lists && nt > 0) ? ctx->list_len + nt : nullptr, (count_readback*)ctx->rb_dev);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rb_host, ctx->rb_dev, sizeof(count_readback), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const count_readback* rb = (const count_readback*)ctx->rb_host;
+    const int64_t nnz = rb->nnz;
+    const int32_t pool_over = rb->pool_over, list_mx = rb->list_mx;
+    unsigned long long pairs[512];
+    memcpy(pairs, rb->pairs, sizeof pairs);
     if (ctx->spec_lists && list_mx > ctx->list_cap) {             // lists were truncated: everything after them is void
         ctx->lists_r = -1.0; ctx->lists_cap_trusted = -1;
         ctx->list_cap = std::min<int64_t>(ctx->ntiles, ((int64_t)list_mx + 255) / 256 * 256);

@@ -121,6 +121,8 @@ struct mpfmt_ctx {
     bool cnt_pool = false, cnt_mf = false;   // the pending count used the pool / the MFMA pair kernel
     int32_t* spec_fail = nullptr;        // device flag: pool overflow, truncated chunk list or nnz beyond the trusted capacity
     int64_t nnz_cap = 0;                 // entries rowval / nzval / the mask are sized for
+    void* rb_dev = nullptr;              // count read-back block (device) and its pinned host mirror
+    void* rb_host = nullptr;
     int64_t lists_cap_trusted = -1;      // list capacity that a verified build found sufficient
     int64_t pool_hint_N = -1; double pool_hint_r = -1.0; int64_t pool_hint_nnz = 0; int pool_hint_rank = -1, pool_hint_world = -1;   // capacity hint from the last build
     int64_t survivors = 0;
