@@ -251,7 +251,8 @@ __host__ __device__ inline double rs_steer(const double* s1, const double* s2, d
 // table live in scratch: 336 bytes per lane, 2 wavefronts per SIMD), every image is a compile-time case, and the images'
 // sin / cos come from ONE sincos of the heading difference -- the eight images only flip its sign (sin odd, cos even).
 template <int F>
-__device__ __forceinline__ void rs_fam_cost(const double x, const double y, const double th, const double st, const double ct, double& c)
+__device__ __forceinline__ void rs_fam_cost(const double x, const double y, const double th, const double st, const double ct, double& c,
+                                            int& win, const int id)
 {
     double cnew;
     if constexpr (F == 0) {
@@ -316,26 +317,24 @@ __device__ __forceinline__ void rs_fam_cost(const double x, const double y, cons
         const double v = mod2pif(CAR_PI + be - th - ga);
         cnew = t + CAR_PI - u + v;
     }
-    if (!(c <= cnew)) c = cnew;                                           // rs_accept's rule
+    if (!(c <= cnew)) { c = cnew; win = id; }                             // rs_accept's rule; id = family * 8 + image
 }
 
-__device__ inline double rs_cost(const double* s1, const double* s2, double r)
+// returns the cost / r and the winning (family * 8 + image); the images are those of rs_steer's table
+__device__ __forceinline__ double rs_cost_win(const double X, const double Y, const double th, const double st, const double ct,
+                                              const double Xb, const double Yb, int& win)
 {
-    const double dx = (s2[0] - s1[0]) / r, dy = (s2[1] - s1[1]) / r;
-    const double c1 = cos(s1[2]), s1n = sin(s1[2]);
-    const double X = dx * c1 + dy * s1n, Y = -dx * s1n + dy * c1, th = mod2pif(s2[2] - s1[2]);
-    const double st = sin(th), ct = cos(th);
-    const double Xb = X * ct + Y * st, Yb = X * st - Y * ct;              // backwards image (:247)
     double c = INFINITY;
+    win = -1;
     // image i of rs_steer's table: 0 id, 1 T, 2 R, 4 R_T, 3 B, 5 B_T, 6 B_R, 7 B_R_T (angle th or -th: sin flips, cos stays)
-#define RS_IMG0(F) rs_fam_cost<F>(X, Y, th, st, ct, c)
-#define RS_IMG1(F) rs_fam_cost<F>(-X, Y, -th, -st, ct, c)
-#define RS_IMG2(F) rs_fam_cost<F>(X, -Y, -th, -st, ct, c)
-#define RS_IMG4(F) rs_fam_cost<F>(-X, -Y, th, st, ct, c)
-#define RS_IMG3(F) rs_fam_cost<F>(Xb, Yb, th, st, ct, c)
-#define RS_IMG5(F) rs_fam_cost<F>(-Xb, Yb, -th, -st, ct, c)
-#define RS_IMG6(F) rs_fam_cost<F>(Xb, -Yb, -th, -st, ct, c)
-#define RS_IMG7(F) rs_fam_cost<F>(-Xb, -Yb, th, st, ct, c)
+#define RS_IMG0(F) rs_fam_cost<F>(X, Y, th, st, ct, c, win, F * 8 + 0)
+#define RS_IMG1(F) rs_fam_cost<F>(-X, Y, -th, -st, ct, c, win, F * 8 + 1)
+#define RS_IMG2(F) rs_fam_cost<F>(X, -Y, -th, -st, ct, c, win, F * 8 + 2)
+#define RS_IMG4(F) rs_fam_cost<F>(-X, -Y, th, st, ct, c, win, F * 8 + 4)
+#define RS_IMG3(F) rs_fam_cost<F>(Xb, Yb, th, st, ct, c, win, F * 8 + 3)
+#define RS_IMG5(F) rs_fam_cost<F>(-Xb, Yb, -th, -st, ct, c, win, F * 8 + 5)
+#define RS_IMG6(F) rs_fam_cost<F>(Xb, -Yb, -th, -st, ct, c, win, F * 8 + 6)
+#define RS_IMG7(F) rs_fam_cost<F>(-Xb, -Yb, th, st, ct, c, win, F * 8 + 7)
 #define RS_FOUR(F) RS_IMG0(F); RS_IMG1(F); RS_IMG2(F); RS_IMG4(F)
 #define RS_EIGHT(F) RS_FOUR(F); RS_IMG3(F); RS_IMG5(F); RS_IMG6(F); RS_IMG7(F)
     RS_FOUR(0); RS_FOUR(1);
@@ -354,14 +353,84 @@ __device__ inline double rs_cost(const double* s1, const double* s2, double r)
 #undef RS_IMG7
 #undef RS_FOUR
 #undef RS_EIGHT
-    return c * r;
+    return c;
+}
+
+__device__ inline double rs_cost(const double* s1, const double* s2, double r)
+{
+    const double dx = (s2[0] - s1[0]) / r, dy = (s2[1] - s1[1]) / r;
+    const double c1 = cos(s1[2]), s1n = sin(s1[2]);
+    const double X = dx * c1 + dy * s1n, Y = -dx * s1n + dy * c1, th = mod2pif(s2[2] - s1[2]);
+    const double st = sin(th), ct = cos(th);
+    const double Xb = X * ct + Y * st, Yb = X * st - Y * ct;              // backwards image (:247)
+    int win;
+    return rs_cost_win(X, Y, th, st, ct, Xb, Yb, win) * r;
+}
+
+// reedsshepp with its controls, device form: the 46 evaluations run cost-only (above) and remember the winner; only the
+// winning word is then evaluated again with its segments -- the same formulas on the same image, so the same cost and
+// controls as rs_steer, without carrying five segments through every accept.
+__device__ inline double rs_steer_dev(const double* s1, const double* s2, double r, double s, car_step* path, int& L)
+{
+    const double dx = (s2[0] - s1[0]) / r, dy = (s2[1] - s1[1]) / r;
+    const double c1 = cos(s1[2]), s1n = sin(s1[2]);
+    const double X = dx * c1 + dy * s1n, Y = -dx * s1n + dy * c1, th = mod2pif(s2[2] - s1[2]);
+    const double st = sin(th), ct = cos(th);
+    const double Xb = X * ct + Y * st, Yb = X * st - Y * ct;
+    int win;
+    rs_cost_win(X, Y, th, st, ct, Xb, Yb, win);
+    rs_best b;
+    b.c = INFINITY; b.l = 0; b.post = 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) b.p[q] = car_seg(0, 0.0);
+    if (win >= 0) {
+        const int f = win >> 3, img = win & 7;
+        const bool back = (img == 3 || img == 5 || img == 6 || img == 7);
+        const bool fx = (img == 1 || img == 4 || img == 5 || img == 7);     // x negated (timeflip)
+        const bool fy = (img == 2 || img == 4 || img == 6 || img == 7);     // y negated (reflect)
+        const double bx = back ? Xb : X, by = back ? Yb : Y;
+        double T[3];
+        T[0] = fx ? -bx : bx; T[1] = fy ? -by : by; T[2] = (fx != fy) ? -th : th;
+        rs_family(f, T, b, img);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        if (q < b.l) {
+            b.p[q].t = b.p[q].t * r; b.p[q].k = b.p[q].k / r;
+            b.p[q].t = b.p[q].t / s; b.p[q].s = b.p[q].s * s;
+        }
+    }
+    const bool tf = (b.post == 1 || b.post == 4 || b.post == 5 || b.post == 7);
+    const bool rf = (b.post == 2 || b.post == 4 || b.post == 6 || b.post == 7);
+    const bool bw = (b.post == 3 || b.post == 5 || b.post == 6 || b.post == 7);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) if (q < b.l) { if (tf) b.p[q].s = -b.p[q].s; if (rf) b.p[q].k = -b.p[q].k; }
+    // backwards!: reverse the first l segments (static indexing: l is 3, 4 or 5)
+    car_step o[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) o[q] = b.p[q];
+    if (bw) {
+        if (b.l == 3) { o[0] = b.p[2]; o[2] = b.p[0]; }
+        else if (b.l == 4) { o[0] = b.p[3]; o[1] = b.p[2]; o[2] = b.p[1]; o[3] = b.p[0]; }
+        else if (b.l == 5) { o[0] = b.p[4]; o[1] = b.p[3]; o[3] = b.p[1]; o[4] = b.p[0]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) path[q] = o[q];
+    L = b.l;
+    return b.c * r;
 }
 
 // KIND 1 = Dubins (3 segments), 2 = Reeds-Shepp (up to 5)
 template <int KIND>
 __host__ __device__ __forceinline__ double car_steer(const double* s1, const double* s2, double r, double s, car_step* path, int& L)
 {
-    if (KIND == 2) return rs_steer(s1, s2, r, s, path, L);
+    if (KIND == 2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return rs_steer_dev(s1, s2, r, s, path, L);
+#else
+        return rs_steer(s1, s2, r, s, path, L);
+#endif
+    }
     L = 3;
     path[3] = car_seg(0, 0.0); path[4] = path[3];
     return dubins_steer(s1, s2, r, s, path);
