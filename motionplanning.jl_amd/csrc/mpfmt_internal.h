@@ -101,7 +101,7 @@ struct mpfmt_ctx {
     int32_t mf_ablate = 0;               // timing experiments only
     int32_t num_cus = 256;               // compute units of the device (persistent-grid sizing)
     int* sweep_ctr = nullptr;            // graph sweep: one task counter per obstacle chunk
-    int64_t mf_target_items = 70000;     // work items (tile x slice) the MFMA path aims for
+    int64_t mf_target_items = 40000;     // work items (tile x slice) the MFMA path aims for (tools/run_shard_sweep_items.py: flat from 40k up at 1 shard, best at 2 and 4)
     float mf_negT = 0.f;
     void* lists = nullptr;               // [shard tiles][list_cap] candidate chunk ids per tile
     int32_t* list_len = nullptr;         // [shard tiles + 1] lengths, last = max

@@ -5,7 +5,7 @@ import torch
 import motionplanning_jl_amd as mp
 w = mp.workloads.north_star()
 for G, g in ((8, 4), (4, 2), (2, 1), (1, 0)):
-    for items in (70000,):
+    for items in (12000, 20000, 30000, 40000, 70000):
         c = mp.Context(0)
         c.set_shard(g, G)
         c.upload_samples(w.X); c.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
