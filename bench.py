@@ -112,9 +112,11 @@ def main():
     ctx.upload_samples(w.X)                       # inputs resident in HBM before the timed region
     ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
 
+    gather = mp.distributed.MaskGather(dist, world, dev) if world > 1 else None
+
     def step():
         if world > 1:
-            nnz, _, _ = mp.distributed.sharded_step(ctx, w.r, dist, world, dev)   # graph + sweep + ONE mask all-gather
+            nnz, _, _ = mp.distributed.sharded_step(ctx, w.r, dist, world, dev, gather)   # graph + sweep + ONE mask all-gather
         else:
             nnz = ctx.graph_step_device(w.r)      # graph + sweep, one host synchronisation (include/mpfmt.h)
         return nnz

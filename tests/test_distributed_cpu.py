@@ -38,7 +38,19 @@ def _worker(rank, world, port, q):
     t = torch.from_numpy(local.view(np.int64).copy())
     gathered, counts = mp.distributed.all_gather_mask(t, dist, world)
     parts = mp.distributed.split_gathered(gathered, counts)
-    q.put((rank, [p.numpy().view(np.uint64).copy() for p in parts], local))
+    # the steady-state exchange (one collective per step): first call learns the lengths, the second runs on the agreed
+    # capacity, the third makes rank 0's shard outgrow it (every rank must take the repeat-at-exact-size branch), the fourth
+    # runs on the enlarged capacity again
+    mg = mp.distributed.MaskGather(dist, world)
+    seq = []
+    for it in range(4):
+        mine = t if it != 2 else (torch.cat([t, t, t]) if rank == 0 else t)
+        g2, c2 = mg(mine)
+        seq.append([p.numpy().copy() for p in mp.distributed.split_gathered(g2, c2)])
+        want0 = t if it != 2 else torch.cat([t, t, t])
+        if rank == 0:
+            assert np.array_equal(seq[-1][0], want0.numpy())
+    q.put((rank, [p.numpy().view(np.uint64).copy() for p in parts], local, seq))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,7 +69,14 @@ def test_all_gather_mask_world2_gloo():
         assert p.exitcode == 0
     res.sort(key=lambda x: x[0])
     locals_ = [r[2] for r in res]
-    for rank, parts, _ in res:
+    for rank, _, _, seq in res:                      # MaskGather: every step, every rank holds every shard's words
+        for it, parts in enumerate(seq):
+            for g in range(world):
+                want = locals_[g].view(np.int64)
+                if it == 2 and g == 0:
+                    want = np.concatenate([want, want, want])
+                assert np.array_equal(parts[g], want), (rank, it, g)
+    for rank, parts, _, _ in res:
         assert len(parts) == world
         for g in range(world):
             assert np.array_equal(parts[g], locals_[g]), (rank, g)

@@ -18,5 +18,10 @@ torch.cuda.synchronize()
 ref = ctx.graph_edges_free()
 got = gathered[0, :int(counts[0])].cpu().numpy().view(np.uint64)
 assert np.array_equal(got, ref), "all-gathered mask differs"
+gather = mp.distributed.MaskGather(dist, 1, dev)
+for it in range(3):                                   # one collective per step from the second call on
+    nnz2, g2, c2 = mp.distributed.sharded_step(ctx, w.r, dist, 1, dev, gather)
+    torch.cuda.synchronize()
+    assert nnz2 == nnz and np.array_equal(g2[0, :int(c2[0])].cpu().numpy().view(np.uint64), ref), "MaskGather step %d differs" % it
 print("dist 1-rank ok: nnz", nnz, "words", int(counts[0]))
 dist.destroy_process_group()
