@@ -845,7 +845,10 @@ static int32_t launch_graph_sweep_d(mpfmt_ctx* ctx, size_t lds, double rpad, int
     int per_cu = 0;
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k16, SWEEP_THREADS, lds));
     const int64_t resident = (int64_t)std::max(per_cu, 1) * ctx->num_cus;
-    const int tc = ((sp_end - sp_begin + 15) / 16 < 6 * resident * waves) ? 8 : 16;
+    // 8-column tasks everywhere: measured equal to 16 on the unsharded north star (2.89 vs 2.91 ms) and cfg3, 8 % better on
+    // 2 shards (1.59 vs 1.73 ms) and 17-20 % on 4 and 8 (finer dynamic balance over the resident grid); fewer resident
+    // workgroups than the occupancy allows is always worse (tools/run_shard_all.py)
+    const int tc = 8;
     const int64_t ntasks = (sp_end - sp_begin + tc - 1) / tc;
     const unsigned nb = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ntasks + waves - 1) / waves, resident));
     hipLaunchKernelGGL(tc == 8 ? k8 : k16, dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream, ctx->Xo, ctx->colptr, ctx->rowval, ctx->N,
