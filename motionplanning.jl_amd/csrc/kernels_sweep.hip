@@ -327,7 +327,7 @@ __device__ __forceinline__ double lane_f64(double v, int l)
 // ---- graph sweep ---------------------------------------------------------------------------------
 // Bit e of the mask = in_state_space(V[y]) && is_free_motion(V[y], V[x]) for CSC entry e = (row y, column x).
 // All rows of a column lie within rpad of V[x], so the cull box is V[x] +- rpad (~2.5 % of the boxes survive at the
-// north-star workload).  Work is handed out in TASKS of SWEEP_TC (16 or 8) consecutive columns (a dynamic counter), one
+// north-star workload).  Work is handed out in TASKS of SWEEP_TC (8 or 4) consecutive columns (a dynamic counter), one
 // wavefront per task, 64 entries ("a round") at a time within a column:
 //   - the task header -- per column its entry range and its state -- is loaded once and held in registers
 //     (lane = column); per-column values are read out with v_readlane, so a column costs no memory round trip
@@ -835,23 +835,25 @@ template <int D>
 static int32_t launch_graph_sweep_d(mpfmt_ctx* ctx, size_t lds, double rpad, int chunk, const int32_t* sweep_perm, int64_t sp_begin,
                                     int64_t sp_end, const int32_t* spec_fail)
 {
-    constexpr auto k16 = k_graph_sweep<D, 16>;
     constexpr auto k8 = k_graph_sweep<D, 8>;
+    constexpr auto k4 = k_graph_sweep<D, 4>;
     const int waves = SWEEP_THREADS / 64;
     if (lds > 64 * 1024) {                                       // beyond the default dynamic-LDS limit (gfx950 has 160 KB)
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(ctx, hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     int per_cu = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k16, SWEEP_THREADS, lds));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k8, SWEEP_THREADS, lds));
     const int64_t resident = (int64_t)std::max(per_cu, 1) * ctx->num_cus;
     // 8-column tasks everywhere: measured equal to 16 on the unsharded north star (2.89 vs 2.91 ms) and cfg3, 8 % better on
     // 2 shards (1.59 vs 1.73 ms) and 17-20 % on 4 and 8 (finer dynamic balance over the resident grid); fewer resident
     // workgroups than the occupancy allows is always worse (tools/run_shard_all.py)
-    const int tc = 8;
+    // (and 4-column tasks when a wavefront would get fewer than six 8-column ones -- the interior ranks of 8 shards: 5-8 %;
+    // with more tasks per wavefront 4 is worse: 15 % at a dozen, 19 % on the unsharded graph)
+    const int tc = ((sp_end - sp_begin + 7) / 8 < 6 * resident * waves) ? 4 : 8;
     const int64_t ntasks = (sp_end - sp_begin + tc - 1) / tc;
     const unsigned nb = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ntasks + waves - 1) / waves, resident));
-    hipLaunchKernelGGL(tc == 8 ? k8 : k16, dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream, ctx->Xo, ctx->colptr, ctx->rowval, ctx->N,
+    hipLaunchKernelGGL(tc == 4 ? k4 : k8, dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream, ctx->Xo, ctx->colptr, ctx->rowval, ctx->N,
                        rpad, ctx->boxes, ctx->M, chunk, ctx->ss, (unsigned long long*)ctx->graph_free, ctx->sweep_ctr, sweep_perm,
                        sp_begin, sp_end, spec_fail);
     HIPCHK(ctx, hipGetLastError());
