@@ -680,8 +680,12 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restri
             return (((long long)((sp >> 6) - tile_begin)) * S * 64 + (long long)(sp & 63)) * capc;
         };
         auto src = [&](int c, long long col0, int e) -> long long {
-            int sl = 0;
-            for (int q = 1; q < S; ++q) sl += (e >= s_pre[c][q]) ? 1 : 0;
+            int sl = 0;                                 // the last slice whose first entry is <= e (prefix sums: binary search)
+#pragma unroll
+            for (int step = MPFMT_MAXS / 2; step > 0; step >>= 1) {
+                const int t = sl + step;
+                if (t < S && s_pre[c][t] <= e) sl = t;
+            }
             return col0 + (long long)sl * sstride + (e - s_pre[c][sl]);
         };
         struct ents { int32_t ma, mb; double da, db; };
