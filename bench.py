@@ -95,9 +95,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if os.environ.get("MPFMT_BENCH_ONE_DEVICE"):
+            # functional check of the N > 1 code path on a box with ONE GPU (tools/test_bench_2rank_1gpu.sh): every rank
+            # uses device 0 and the collectives go through gloo -- RCCL refuses two ranks on one device.  Not a measurement.
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
