@@ -325,8 +325,8 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
 {
     __shared__ double s_q[64 * D];                        // fp64 query coordinates (AoS) for the refine
     __shared__ uint32_t s_list[MF_LIST];
-    __shared__ uint32_t s_qj[MF_QCAP];                    // survivor queue: candidate sorted position
-    __shared__ uint32_t s_qq[MF_QCAP];                    //                 query lane
+    __shared__ uint32_t s_qj[MF_QCAP];                    // survivor queue: candidate chunk id
+    __shared__ uint32_t s_qq[MF_QCAP];                    //                 (finding lane << 6) | sign-bit position; decoded in drain
     __shared__ int32_t s_cnt[64];
     __shared__ int64_t s_base[64];
 
@@ -430,7 +430,14 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
         uint32_t jg = 0, ql = 0;
         double d2 = 0.0;
         if (lane < n) {
-            jg = s_qj[first + lane]; ql = s_qq[first + lane];
+            // decode (the push stores the raw coordinates of the sign bit: decoding once per drain -- 64 survivors wide -- is an
+            // order of magnitude cheaper than in the extraction loop, which runs per chunk with a handful of active lanes)
+            const uint32_t qc = s_qj[first + lane], pk = s_qq[first + lane];
+            const int bpos = (int)(pk & 63u), fl = (int)(pk >> 6);
+            const int t = bpos >> 4, r = 15 - (bpos & 15);
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (fl >> 5);
+            jg = qc * 64u + (uint32_t)((t >> 1) * 32 + (fl & 31));
+            ql = (uint32_t)((t & 1) * 32 + row);
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 const double t = s_q[ql * D + i] - a.Xs[(int64_t)jg * D + i];
@@ -474,12 +481,9 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
             if (qcount > MF_QCAP - 64) drain(64);
             if (H != 0) {
                 const int bpos = __ffsll((long long)H) - 1;
-                const int t = bpos >> 4;
-                const int r = 15 - (bpos & 15);
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
                 const int pos = qcount + (int)__popcll(m & ((1ull << lane) - 1ull));
-                s_qj[pos] = (uint32_t)(c * 64 + (t >> 1) * 32 + col);
-                s_qq[pos] = (uint32_t)((t & 1) * 32 + row);
+                s_qj[pos] = (uint32_t)c;
+                s_qq[pos] = ((uint32_t)lane << 6) | (uint32_t)bpos;
                 H &= H - 1;
             }
             const int np = (int)__popcll(m);
