@@ -31,10 +31,10 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 
 GATHER_CEILING_ROWS_PER_S = 4.51e10      # measured: 1e8 random 48-byte rows of a 48 MB array in 2.219 ms (profiles/r01_ubench_fetch_calib.txt)
 
 PROFILED_TRAFFIC_BYTES = {
-    # profiles/r01_pmc_v9.txt: FETCH_SIZE 1723962 KiB (x2, gfx950 half-count), WRITE_SIZE 2429648 KiB per launch
-    ("ns_r6_n1m_m200", 1): (1723962.2 * 2 + 2429647.8) * 1024,
-    # profiles/r01_pmc_v9.txt: FETCH_SIZE 7937320 KiB (x2), WRITE_SIZE 453055 KiB per launch
-    ("ns_r6_n1m_m200", 1, "sweep"): (7937319.7 * 2 + 453054.8) * 1024,
+    # profiles/r01_pmc_v10.txt: FETCH_SIZE 1715632 KiB (x2, gfx950 half-count), WRITE_SIZE 2447395 KiB per launch
+    ("ns_r6_n1m_m200", 1): (1715631.5 * 2 + 2447394.8) * 1024,
+    # profiles/r01_pmc_v10.txt: FETCH_SIZE 7937494 KiB (x2), WRITE_SIZE 453055 KiB per launch
+    ("ns_r6_n1m_m200", 1, "sweep"): (7937494.2 * 2 + 453054.8) * 1024,
 }
 
 
