@@ -352,8 +352,28 @@ struct sweep_round {
     int64_t t, e0, end;               // task id, first entry of the round, end of the column
 };
 
-template <int D>
-struct sweep_hdr { int64_t cpb, cpe; double w[D]; };        // lane = column of the task: entry range, state
+// Task header: per column its entry range and state, 2 + D eight-byte fields.  Field f of column c sits in lane
+// (f % FPR) * TC + c of register f / FPR (FPR = 64 / TC fields per register): all 64 lanes of a register carry data, where a
+// lane = column layout would fill TC of them and spend 2 x (2 + D) VGPR pairs on the two resident headers.
+template <int D, int TC>
+struct sweep_hdr {
+    static constexpr int FPR = 64 / TC, NR = (2 + D + FPR - 1) / FPR;
+    unsigned long long v[NR];
+};
+template <int D, int TC> __device__ __forceinline__ int64_t hdr_i64(const sweep_hdr<D, TC>& h, int f, int c)        // wave-uniform c
+{
+    constexpr int FPR = sweep_hdr<D, TC>::FPR;
+    return lane_i64((int64_t)h.v[f / FPR], (f % FPR) * TC + c);
+}
+template <int D, int TC> __device__ __forceinline__ double hdr_f64(const sweep_hdr<D, TC>& h, int f, int c)
+{
+    return __longlong_as_double(hdr_i64<D, TC>(h, f, c));
+}
+template <int D, int TC> __device__ __forceinline__ int64_t hdr_i64_lane(const sweep_hdr<D, TC>& h, int f, int c)   // per-lane c
+{
+    constexpr int FPR = sweep_hdr<D, TC>::FPR;
+    return (int64_t)__shfl(h.v[f / FPR], (f % FPR) * TC + c);
+}
 
 template <int D, int SWEEP_TC>
 __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 2)) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
@@ -397,23 +417,30 @@ __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 2)) void k_graph_sweep
             if (lane == 0) t = atomicAdd(ctr, 1);
             return (int64_t)__builtin_amdgcn_readfirstlane(t);
         };
-        sweep_hdr<D> H0, H1;
-        auto load_hdr = [&](int64_t t, sweep_hdr<D>& h) {
-            const int64_t sp = sp_begin + t * SWEEP_TC + lane;
+        sweep_hdr<D, SWEEP_TC> H0, H1;
+        auto load_hdr = [&](int64_t t, sweep_hdr<D, SWEEP_TC>& h) {
+            constexpr int FPR = sweep_hdr<D, SWEEP_TC>::FPR, NR = sweep_hdr<D, SWEEP_TC>::NR;
+            const int c = lane % SWEEP_TC;
+            const int64_t sp = sp_begin + t * SWEEP_TC + c;
             int64_t x = -1;                                       // pad positions of the sorted order hold -1
-            if (sp < sp_end && lane < SWEEP_TC) x = perm ? (int64_t)perm[sp] : sp;
-            h.cpb = x >= 0 ? colptr[x] : 0;
-            h.cpe = x >= 0 ? colptr[x + 1] : 0;
+            if (sp < sp_end) x = perm ? (int64_t)perm[sp] : sp;
             const int64_t xr = x >= 0 ? x : 0;
 #pragma unroll
-            for (int i = 0; i < D; ++i) h.w[i] = X[xr * D + i];
+            for (int q = 0; q < NR; ++q) {
+                const int f = q * FPR + lane / SWEEP_TC;          // this lane's field: 0 = cpb, 1 = cpe, 2 + i = w[i]
+                const unsigned long long* src = (f < 2) ? reinterpret_cast<const unsigned long long*>(colptr + xr + f)
+                                                        : reinterpret_cast<const unsigned long long*>(X + xr * D + min(f - 2, D - 1));
+                unsigned long long val = *src;
+                if (f < 2 && x < 0) val = 0;                      // empty range for a pad column
+                h.v[q] = val;
+            }
         };
         int64_t tset0 = grab(), tset1 = -1;
         if (tset0 >= ntasks) continue;                       // (uniform) nothing left for this wave
         load_hdr(tset0, H0);
         auto col_range = [&](const sweep_round& r, int64_t& beg, int64_t& end) {
-            const int64_t b0_ = lane_i64(H0.cpb, r.c), e0_ = lane_i64(H0.cpe, r.c);
-            const int64_t b1_ = lane_i64(H1.cpb, r.c), e1_ = lane_i64(H1.cpe, r.c);
+            const int64_t b0_ = hdr_i64<D, SWEEP_TC>(H0, 0, r.c), e0_ = hdr_i64<D, SWEEP_TC>(H0, 1, r.c);
+            const int64_t b1_ = hdr_i64<D, SWEEP_TC>(H1, 0, r.c), e1_ = hdr_i64<D, SWEEP_TC>(H1, 1, r.c);
             beg = r.hs ? b1_ : b0_;
             end = r.hs ? e1_ : e0_;
         };
@@ -470,10 +497,10 @@ __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 2)) void k_graph_sweep
             const int c = on ? (int)(ck >> 16) : 0, k = on ? (int)(ck & 0xffffu) : 0;
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                const double a = __shfl(H0.w[i], c), b = __shfl(H1.w[i], c);
-                w[i] = hs ? b : a;
+                const int64_t a = hdr_i64_lane<D, SWEEP_TC>(H0, 2 + i, c), b = hdr_i64_lane<D, SWEEP_TC>(H1, 2 + i, c);
+                w[i] = __longlong_as_double(hs ? b : a);
             }
-            const int64_t ebase = hs ? __shfl(H1.cpb, c) : __shfl(H0.cpb, c);
+            const int64_t ebase = hs ? hdr_i64_lane<D, SWEEP_TC>(H1, 0, c) : hdr_i64_lane<D, SWEEP_TC>(H0, 0, c);
             const bool free_ = narrow_free_sl<D>(v, w, load_box_T<D>(sboxT, k));
             if (on && !free_) {
                 const int64_t e = ebase + (int64_t)eoff;
@@ -530,7 +557,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 2)) void k_graph_sweep
                 if (R0.first) {
 #pragma unroll
                     for (int i = 0; i < D; ++i) {
-                        const double a = lane_f64(H0.w[i], R0.c), b = lane_f64(H1.w[i], R0.c);
+                        const double a = hdr_f64<D, SWEEP_TC>(H0, 2 + i, R0.c), b = hdr_f64<D, SWEEP_TC>(H1, 2 + i, R0.c);
                         w[i] = R0.hs ? b : a;
                         ulo[i] = w[i] - rpad; uhi[i] = w[i] + rpad;
                     }
@@ -571,7 +598,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 2)) void k_graph_sweep
                     }
                 }
                 // queue the pending exact tests (the entry counts as free until a pass says otherwise)
-                const uint32_t eoff = (uint32_t)(e0 + lane - (R0.hs ? lane_i64(H1.cpb, R0.c) : lane_i64(H0.cpb, R0.c)));
+                const uint32_t eoff = (uint32_t)(e0 + lane - (R0.hs ? hdr_i64<D, SWEEP_TC>(H1, 0, R0.c) : hdr_i64<D, SWEEP_TC>(H0, 0, R0.c)));
                 hs_q = R0.hs;
                 if constexpr (D <= 8) {
                     push(fr && p0 >= 0, v, eoff, ((uint32_t)R0.c << 16) | (uint32_t)max(p0, 0));
