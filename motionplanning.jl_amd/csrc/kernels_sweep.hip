@@ -24,6 +24,10 @@
 #include <algorithm>
 
 #define SWEEP_THREADS 256
+// the graph sweep for d <= 6 runs 16 wavefronts per workgroup: at 4 waves per SIMD (127 VGPRs) the obstacle table (24.5 KB at
+// d = 6) is staged once per CU and the 16 narrow-phase queues (7 KB each) still fit the 160 KB of LDS -- four 4-wave
+// workgroups (4 x 53 KB) would not; d = 7, 8 keep three 4-wave workgroups per CU (their queues are larger), d > 8 two
+#define SWEEP_GT(D) ((D) <= 6 ? 1024 : 256)
 #define SWEEP_LDS_BYTES (60 * 1024)
 #define SWEEP_CHUNK 256          // boxes per LDS stage of the culled kernels (= row stride of the SoA staging)
 
@@ -376,7 +380,7 @@ template <int D, int TC> __device__ __forceinline__ int64_t hdr_i64_lane(const s
 }
 
 template <int D, int SWEEP_TC>
-__global__ __launch_bounds__(SWEEP_THREADS, (D <= 8 ? 3 : 2)) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
+__global__ __launch_bounds__(SWEEP_GT(D), (D <= 6 ? 1 : D <= 8 ? 3 : 2)) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
                                                                const int32_t* __restrict__ rowval, int64_t N, double rpad,
                                                                const double* __restrict__ boxes, int M, int chunk,
                                                                mpfmt_ss ss, unsigned long long* __restrict__ mask,
@@ -864,23 +868,23 @@ static int32_t launch_graph_sweep_d(mpfmt_ctx* ctx, size_t lds, double rpad, int
 {
     constexpr auto k8 = k_graph_sweep<D, 8>;
     constexpr auto k4 = k_graph_sweep<D, 4>;
-    const int waves = SWEEP_THREADS / 64;
+    const int waves = SWEEP_GT(D) / 64;
     if (lds > 64 * 1024) {                                       // beyond the default dynamic-LDS limit (gfx950 has 160 KB)
         HIPCHK(ctx, hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(ctx, hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     int per_cu = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k8, SWEEP_THREADS, lds));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k8, SWEEP_GT(D), lds));
     const int64_t resident = (int64_t)std::max(per_cu, 1) * ctx->num_cus;
     // 8-column tasks everywhere: measured equal to 16 on the unsharded north star (2.89 vs 2.91 ms) and cfg3, 8 % better on
     // 2 shards (1.59 vs 1.73 ms) and 17-20 % on 4 and 8 (finer dynamic balance over the resident grid); fewer resident
     // workgroups than the occupancy allows is always worse (tools/run_shard_all.py)
-    // (and 4-column tasks when a wavefront would get fewer than six 8-column ones -- the interior ranks of 8 shards: 5-8 %;
+    // (and 4-column tasks when a wavefront would get fewer than 4.5 8-column ones -- the interior ranks of 8 shards: 5-8 %;
     // with more tasks per wavefront 4 is worse: 15 % at a dozen, 19 % on the unsharded graph)
-    const int tc = ((sp_end - sp_begin + 7) / 8 < 6 * resident * waves) ? 4 : 8;
+    const int tc = ((sp_end - sp_begin + 7) / 8 < (9 * resident * waves) / 2) ? 4 : 8;
     const int64_t ntasks = (sp_end - sp_begin + tc - 1) / tc;
     const unsigned nb = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ntasks + waves - 1) / waves, resident));
-    hipLaunchKernelGGL(tc == 4 ? k4 : k8, dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream, ctx->Xo, ctx->colptr, ctx->rowval, ctx->N,
+    hipLaunchKernelGGL(tc == 4 ? k4 : k8, dim3(nb), dim3(SWEEP_GT(D)), lds, ctx->stream, ctx->Xo, ctx->colptr, ctx->rowval, ctx->N,
                        rpad, ctx->boxes, ctx->M, chunk, ctx->ss, (unsigned long long*)ctx->graph_free, ctx->sweep_ctr, sweep_perm,
                        sp_begin, sp_end, spec_fail);
     HIPCHK(ctx, hipGetLastError());
@@ -910,7 +914,7 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail, int64
     HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, ctx->nnz > 0 ? 0xFF : 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
     if (ctx->nnz > 0) {
         const int d = ctx->d;
-        const int waves = SWEEP_THREADS / 64;
+        const int waves = SWEEP_GT(d) / 64;
         const int chunk = box_chunk(ctx->M, d, true);
         // transposed (SoA) boxes + one narrow-phase queue per wave
         const size_t lds = (size_t)SWEEP_CHUNK * 2 * d * sizeof(double) + (d <= 8 ? (size_t)waves * (d + 1) * SWEEP_QCAP * sizeof(double) : 0);
