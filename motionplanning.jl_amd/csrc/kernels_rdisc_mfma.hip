@@ -320,8 +320,10 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
 #define MF_LIST 1024                // chunk ids per list round (4 KB LDS)
 
 // MODE 0: count only   1: fill the staging CSC (needs offsets from a count pass)   2: count AND append hits to the pool
-template <int D, int MODE>
-__global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
+// W4: built for 4 wavefronts per SIMD (128 VGPRs): the K = 8 form then runs a B-fragment ring of 2 instead of 4 -- 2.12 vs
+// 2.20 ms on the north star (a ring of 4 at 128 VGPRs spills inside the loop: 3.7 ms; the K = 16 form is slower at 4: cfg3 58 vs 55 ms)
+template <int D, int MODE, bool W4>
+__device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
 {
     __shared__ double s_q[64 * D];                        // fp64 query coordinates (AoS) for the refine
     __shared__ uint32_t s_list[MF_LIST];
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
     };
     // B fragments are prefetched PF chunks ahead (a ring of PF register sets, statically indexed): the stream is
     // latency x concurrency bound (L2 / MALL round trips), so more loads in flight per wavefront = more bandwidth.
-    constexpr int PF = K8 ? 4 : 2;
+    constexpr int PF = (K8 && !W4) ? 4 : 2;
     auto run_list = [&](int n) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -589,6 +591,14 @@ __global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G)
         // per-XCD-sharded counters: a single hot address saturates at ~88 atomics/us (156k items would cost 1.8 ms)
         if (lane == 0 && a.pairs) { atomicAdd(a.pairs + 2 * (blockIdx.x & 255), tested); atomicAdd(a.pairs + 2 * (blockIdx.x & 255) + 1, surv); }
     }
+}
+
+template <int D, int MODE>
+__global__ __launch_bounds__(64) void k_rdisc_mfma(mf_args a, mpfmt_grid G) { rdisc_mfma_body<D, MODE, false>(a, G); }
+template <int D, int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rdisc_mfma_w4(mf_args a, mpfmt_grid G)
+{
+    rdisc_mfma_body<D, MODE, true>(a, G);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
@@ -849,6 +859,13 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
     return MPFMT_OK;
 }
 
+template <int DD, int MODE>
+static void launch_pair_kernel(mpfmt_ctx* ctx, unsigned nblk, const mf_args& a, const mpfmt_grid& G)
+{
+    if constexpr (DD <= 6) hipLaunchKernelGGL((k_rdisc_mfma_w4<DD, MODE>), dim3(nblk), dim3(64), 0, ctx->stream, a, G);
+    else hipLaunchKernelGGL((k_rdisc_mfma<DD, MODE>), dim3(nblk), dim3(64), 0, ctx->stream, a, G);
+}
+
 template <int MODE>
 int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
 {
@@ -872,7 +889,7 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     const int64_t gran = NXCD * (int64_t)std::max(1, a.xcd_mode);
     const unsigned nblk = (unsigned)(((a.nitems + gran - 1) / gran) * gran);
     const mpfmt_grid& G = ctx->grid;
-#define CASE(DD) case DD: hipLaunchKernelGGL((k_rdisc_mfma<DD, MODE>), dim3(nblk), dim3(64), 0, ctx->stream, a, G); break;
+#define CASE(DD) case DD: launch_pair_kernel<DD, MODE>(ctx, nblk, a, G); break;
     switch (ctx->d) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
         default: return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path supports d <= 12 (got %d)", ctx->d);
