@@ -31,10 +31,10 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 
 GATHER_CEILING_ROWS_PER_S = 4.51e10      # measured: 1e8 random 48-byte rows of a 48 MB array in 2.219 ms (profiles/r01_ubench_fetch_calib.txt)
 
 PROFILED_TRAFFIC_BYTES = {
-    # profiles/r01_pmc_v10.txt: FETCH_SIZE 1715632 KiB (x2, gfx950 half-count), WRITE_SIZE 2447395 KiB per launch
-    ("ns_r6_n1m_m200", 1): (1715631.5 * 2 + 2447394.8) * 1024,
-    # profiles/r01_pmc_v10.txt: FETCH_SIZE 7937494 KiB (x2), WRITE_SIZE 453055 KiB per launch
-    ("ns_r6_n1m_m200", 1, "sweep"): (7937494.2 * 2 + 453054.8) * 1024,
+    # profiles/r01_pmc_v11.txt: FETCH_SIZE 2052613 KiB (x2, gfx950 half-count), WRITE_SIZE 2598168 KiB per launch
+    ("ns_r6_n1m_m200", 1): (2052613.0 * 2 + 2598167.7) * 1024,
+    # profiles/r01_pmc_v11.txt: FETCH_SIZE 7994656 KiB (x2), WRITE_SIZE 455135 KiB per launch
+    ("ns_r6_n1m_m200", 1, "sweep"): (7994655.9 * 2 + 455134.8) * 1024,
 }
 
 
@@ -213,7 +213,7 @@ def main():
     # `roofline` describes the DOMINANT kernel = the one with the larger measured average launch duration in this run
     # (the collision sweep since the candidate lists were tightened; the pair kernel before); the other one is kept beside it
     roof_rdisc = {
-            "kernel": "k_rdisc_mfma<6,2> (single pass: fp16 MFMA distance-matrix filter + exact fp64 refine + slot emit)"
+            "kernel": "k_rdisc_mfma_w4<6,2> (single pass: fp16 MFMA distance-matrix filter + exact fp64 refine + slot emit)"
             if single_pass else "k_rdisc (count + fill passes)",
             "bound": "mfma", "achieved": ach_tflops, "peak": peak, "unit": "TFLOP/s",
             "frac": ach_tflops / peak,
