@@ -26,8 +26,9 @@
 #define SWEEP_THREADS 256
 // the graph sweep for d <= 6 runs 16 wavefronts per workgroup: at 4 waves per SIMD (127 VGPRs) the obstacle table (24.5 KB at
 // d = 6) is staged once per CU and the 16 narrow-phase queues (7 KB each) still fit the 160 KB of LDS -- four 4-wave
-// workgroups (4 x 53 KB) would not; d = 7, 8 keep three 4-wave workgroups per CU (their queues are larger), d > 8 two
-#define SWEEP_GT(D) ((D) <= 6 ? 1024 : 256)
+// workgroups (4 x 53 KB) would not; d = 7, 8 run one 12-wavefront workgroup (3 per SIMD: their queues are larger -- 4-wave
+// workgroups of 61 / 70 KB fit only twice), d > 8 has no queue and is register-bound at two
+#define SWEEP_GT(D) ((D) <= 6 ? 1024 : (D) <= 8 ? 768 : 256)
 #define SWEEP_LDS_BYTES (60 * 1024)
 #define SWEEP_CHUNK 256          // boxes per LDS stage of the culled kernels (= row stride of the SoA staging)
 
@@ -380,7 +381,7 @@ template <int D, int TC> __device__ __forceinline__ int64_t hdr_i64_lane(const s
 }
 
 template <int D, int SWEEP_TC>
-__global__ __launch_bounds__(SWEEP_GT(D), (D <= 6 ? 1 : D <= 8 ? 3 : 2)) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
+__global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(const double* __restrict__ X, const int64_t* __restrict__ colptr,
                                                                const int32_t* __restrict__ rowval, int64_t N, double rpad,
                                                                const double* __restrict__ boxes, int M, int chunk,
                                                                mpfmt_ss ss, unsigned long long* __restrict__ mask,
