@@ -5,8 +5,13 @@ One "step" = one pass of the hot path over the whole sample set: the r-disc grap
 (N inball queries, src/nearneighbors.jl:179-183) followed by the collision sweep of every graph edge
 (is_free_motion, src/collisioncheckers/boxesND.jl:26,44-56), inputs resident in HBM, outputs left in HBM.
 Workload at N=1: the configuration BASELINE.json's metric is quoted on (FMT*, N=1e6 samples in R^6,
-200 AABBs).  With --gpus G the samples shard by (cell-sorted) index range over the ranks, samples and
-obstacles replicated, and one RCCL all-gather per step assembles the global free-edge mask.
+200 AABBs).
+
+`python bench.py --gpus G` with G > 1 starts G ranks itself (one process per GPU, torch.distributed.run on
+127.0.0.1) BEFORE anything touches the GPU and relays rank 0's JSON line; under an external launcher
+(WORLD_SIZE set) it is one of the ranks.  The samples shard by (cell-sorted) index range over the ranks, samples and
+obstacles replicated, and ONE RCCL all-gather per step -- issued through the C ABI (mpfmt_allgather_free_mask_*, on the
+ctx's communication stream, overlapping the next step's index build) -- assembles the global free-edge mask.
 
 Prints ONE JSON line (rank 0).  value = edges checked per second, whole job; r-disc queries per second is
 reported next to it in "submetrics".
@@ -14,6 +19,8 @@ reported next to it in "submetrics".
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,22 +32,31 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # fp64 vector == fp64 matrix (MFMA) dense peak, FMA = 2 flop
+FP64_VALU_LANE_OPS = 39.3e12   # unfused fp64 lane-ops/s
 FP16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 PFLOP/s
-# HBM bytes per launch measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, profiles/*pmc*):
-# (FETCH_SIZE*2 + WRITE_SIZE) KiB -> bytes.  Keyed by (workload, n_gpus[, kernel]).
 GATHER_CEILING_ROWS_PER_S = 4.51e10      # measured: 1e8 random 48-byte rows of a 48 MB array in 2.219 ms (profiles/r01_ubench_fetch_calib.txt)
-
-PROFILED_TRAFFIC_BYTES = {
-    # profiles/r01_pmc_v11.txt: FETCH_SIZE 2052613 KiB (x2, gfx950 half-count), WRITE_SIZE 2598168 KiB per launch
-    ("ns_r6_n1m_m200", 1): (2052613.0 * 2 + 2598167.7) * 1024,
-    # profiles/r01_pmc_v11.txt: FETCH_SIZE 7994656 KiB (x2), WRITE_SIZE 455135 KiB per launch
-    ("ns_r6_n1m_m200", 1, "sweep"): (7994655.9 * 2 + 455134.8) * 1024,
-}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")      # written by tools/pmc_traffic.py from a rocprofv3 --pmc run
 
 
-def cpu_baseline(w, mp, seconds=12.0):
-    """The oracle ("port" of the reference path, single thread) on a bounded sample of the same workload."""
+def profiled_traffic(lib_version, workload, world):
+    """HBM bytes per launch of the pair kernel and of the sweep from the committed PMC summary (profiles/traffic.json, made by
+    tools/pmc_traffic.py out of separate FETCH_SIZE / WRITE_SIZE passes).  None when the summary was taken on another
+    build of the library, another workload or another shard count -- a stale constant is worse than no number."""
+    try:
+        t = json.load(open(TRAFFIC_FILE))
+    except Exception:
+        return {}
+    if t.get("lib_version") != lib_version or t.get("workload") != workload or t.get("n_gpus") != world:
+        return {}
+    return t
+
+
+def cpu_baseline(w, mp, seconds=14.0):
+    """The oracle ("port" of the reference path) on a bounded sample of the same workload: single thread = the analogue of
+    the single-process Julia reference (headline), in the two r-disc variants BASELINE.md section 3 names, plus an all-core
+    figure for context."""
     from oracle import oracle as orc
+    import concurrent.futures as cf
     orc.lib()
     t0 = time.perf_counter()
     kd = orc.KDTree(w.X)
@@ -50,29 +66,77 @@ def cpu_baseline(w, mp, seconds=12.0):
     nq = 0
     edges_src, edges_dst = [], []
     t0 = time.perf_counter()
-    while nq < len(qs) and time.perf_counter() - t0 < seconds / 2:
+    while nq < len(qs) and time.perf_counter() - t0 < seconds * 0.3:
         v = int(qs[nq])
         inds, _ = kd.inball(v, w.r)
         if len(edges_src) < 400:
             edges_src.append(inds.copy()); edges_dst.append(np.full(len(inds), v))
         nq += 1
     t_q = time.perf_counter() - t0
+    # generic inball (nearneighbors.jl:138-150): colwise against all N per query
+    nb = 0
+    t0 = time.perf_counter()
+    while nb < 10000 and time.perf_counter() - t0 < seconds * 0.2:
+        orc.inball(w.X, int(qs[nb]), w.r, mode=0)
+        nb += 1
+    t_b = time.perf_counter() - t0
     src = np.concatenate(edges_src) if edges_src else np.zeros(0, np.int64)
     dst = np.concatenate(edges_dst) if edges_dst else np.zeros(0, np.int64)
-    # time edge checks in repeated passes over the sampled edges
     ne = 0
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds / 2 and len(src):
+    while time.perf_counter() - t0 < seconds * 0.3 and len(src):
         orc.edges_free(w.X, src, dst, w.lohi, w.ss_lo, w.ss_hi)
         ne += len(src)
     t_e = time.perf_counter() - t0
+    # all cores (context only): the same edge loop from a thread pool -- the oracle's C loop releases the GIL (ctypes)
+    cores = os.cpu_count() or 1
+    nthr = min(cores, 64)
+    ne_all, t_all = 0, 0.0
+    if len(src) and nthr > 1:
+        def work(_):
+            n, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < seconds * 0.15:
+                orc.edges_free(w.X, src, dst, w.lohi, w.ss_lo, w.ss_hi)
+                n += len(src)
+            return n
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(nthr) as ex:
+            ne_all = sum(ex.map(work, range(nthr)))
+        t_all = time.perf_counter() - t0
     q_rate = nq / t_q if t_q > 0 else 0.0
     e_rate = ne / t_e if t_e > 0 else 0.0
     return {"value": e_rate, "unit": "edges checked/s", "cores": 1, "kind": "port",
             "rdisc_queries_per_s": q_rate,
-            "sample": "KD-tree inball (oracle, build %.2fs excluded) on %d random queries of the N=%d set in %.1fs; "
-                      "is_free_motion on %d graph edges in %.1fs; host cores available: %d"
-                      % (t_build, nq, w.N, t_q, ne, t_e, os.cpu_count() or 0)}
+            "rdisc_queries_per_s_brute_scan": (nb / t_b) if t_b > 0 else None,
+            "all_cores": {"threads": nthr, "edges_checked_per_s": (ne_all / t_all) if t_all > 0 else None},
+            "sample": "1 thread: KD-tree inball (oracle, build %.2fs excluded) on %d random queries of the N=%d set in %.1fs; "
+                      "generic all-N scan inball (nearneighbors.jl:138-150) on %d queries in %.1fs; "
+                      "is_free_motion on %d graph edges in %.1fs; %d threads: the same edge loop, %d edges in %.1fs; "
+                      "host cores available: %d"
+                      % (t_build, nq, w.N, t_q, nb, t_b, ne, t_e, nthr, ne_all, t_all, cores)}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """--gpus N without a launcher: start N ranks (children are created before this process makes any GPU call; it never
+    makes one) and exit with their status.  Rank 0 prints the JSON line on the inherited stdout."""
+    import torch            # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (n, have))
+        sys.exit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -83,19 +147,30 @@ def main():
     ap.add_argument("--workload", default="north_star", choices=["north_star", "cfg2", "cfg1", "cfg3"])
     ap.add_argument("--n", type=int, default=0, help="override the sample count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solve", action="store_true", help="skip the whole-solve submetric (wavefront FMT*)")
     args = ap.parse_args()
+
+    one_device = bool(os.environ.get("MPFMT_BENCH_ONE_DEVICE"))
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            spawn_ranks(args.gpus)             # does not return
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            sys.stderr.write("bench.py: --gpus %d does not match WORLD_SIZE=%d\n" % (args.gpus, world))
+            sys.exit(2)
 
     import torch
     import motionplanning_jl_amd as mp
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("MPFMT_BENCH_ONE_DEVICE"):
+        if one_device:
             # functional check of the N > 1 code path on a box with ONE GPU (tools/test_bench_2rank_1gpu.sh): every rank
             # uses device 0 and the collectives go through gloo -- RCCL refuses two ranks on one device.  Not a measurement.
             local_rank = 0
@@ -114,28 +189,53 @@ def main():
     ctx = mp.Context(local_rank if world > 1 else 0)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
-    ctx.set_shard(rank, world)
     ctx.set_option("rebuild_index", 1)           # every step rebuilds the cell grid + MFMA operands (the index build)
     ctx.upload_samples(w.X)                       # inputs resident in HBM before the timed region
     ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
 
-    gather = mp.distributed.MaskGather(dist, world, dev) if world > 1 else None
+    rccl_abi = world > 1 and not one_device
+    gather = None
+    if rccl_abi:
+        # the library's own RCCL communicator: rank 0 makes the id, the control plane (torch.distributed) hands it round
+        uid = torch.zeros(mp._lib.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(mp._lib.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        ctx.comm_create(rank, world, uid.cpu().numpy().tobytes())       # also sets the shard (rank, world)
+    else:
+        ctx.set_shard(rank, world)
+        if world > 1:
+            gather = mp.distributed.MaskGather(dist, world, dev)
+
+    pending = [False]
 
     def step():
-        if world > 1:
-            nnz, _, _ = mp.distributed.sharded_step(ctx, w.r, dist, world, dev, gather)   # graph + sweep + ONE mask all-gather
+        if rccl_abi:
+            nnz = ctx.graph_step_device(w.r)      # graph + sweep of this rank's shard
+            if pending[0]:
+                ctx.allgather_free_mask_finish(world)      # the previous step's gather ran beside this step's kernels
+            ctx.allgather_free_mask_launch()      # ONE all-gather per step, on the communication stream
+            pending[0] = True
+        elif world > 1:
+            nnz, _, _ = mp.distributed.sharded_step(ctx, w.r, dist, world, dev, gather)
         else:
             nnz = ctx.graph_step_device(w.r)      # graph + sweep, one host synchronisation (include/mpfmt.h)
         return nnz
 
+    def drain():
+        if pending[0]:
+            ctx.allgather_free_mask_finish(world)
+            pending[0] = False
+
     if dist is not None:
-        # create the RCCL communicator outside the steps (lazy init on the first collective takes seconds)
+        # create torch's communicator outside the steps (lazy init on the first collective takes seconds)
         probe = torch.zeros(1, dtype=torch.int64, device=dev)
         gathered = torch.empty(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(gathered, probe)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    drain()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -144,6 +244,7 @@ def main():
     nnz = 0
     for _ in range(args.steps):
         nnz = step()
+    drain()                                        # the last step's mask is assembled on every rank before the clock stops
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -177,9 +278,8 @@ def main():
     sweep_ms = tm["sweep_graph"][0]
     sweep_bytes = nnz * (2 * d * 8 + 8 + 1.0 / 8.0)
     sweep_gbs = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-    # measured HBM traffic per launch of the dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
-    # tools/pmc_summary.py; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) -- filled in from profiles/
-    traffic = PROFILED_TRAFFIC_BYTES.get((w.name, world))
+    lib_version = mp._lib.lib().mpfmt_version().decode()
+    prof = profiled_traffic(lib_version, w.name, world)
 
     out = {
         "metric": "edges checked/sec + r-disc queries/sec, FMT* N=1e6 R^6, 1/2/4/8 MI355X",
@@ -196,6 +296,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": w.name, "N": w.N, "d": w.d, "M": w.M, "r": w.r, "nnz": nnz_total,
                    "parallelism": "shard%d" % world,
+                   "exchange": ("none" if world == 1 else
+                                "one RCCL all-gather of the free-edge mask per step through the C ABI (mpfmt_allgather_free_mask_*), "
+                                "overlapped with the next step's index build" if rccl_abi else "gloo (one-device functional check)"),
                    "step": "r-disc graph of all N samples + collision sweep of all nnz directed edges"},
         "submetrics": {
             "rdisc_queries_per_s": w.N * args.steps / dt,
@@ -208,44 +311,76 @@ def main():
             "rdisc_pair_kernel": "fp16 MFMA filter + exact fp64 refine" if path_used == 2 else "exact fp64 VALU",
             "filter_survivors_per_pass": survivors,
             "grid_cells": stats["cells"], "tiles": stats["tiles"], "slices": stats["slices"],
+            "lib_version": lib_version,
         }
     }
-    # `roofline` describes the DOMINANT kernel = the one with the larger measured average launch duration in this run
-    # (the collision sweep since the candidate lists were tightened; the pair kernel before); the other one is kept beside it
+    # `roofline` describes the DOMINANT kernel = the one with the larger measured average launch duration in this run;
+    # the other one is kept beside it.  `traffic` comes from profiles/traffic.json (rocprofv3 --pmc, tools/pmc_traffic.py)
+    # and is null whenever that summary was not taken on this build / workload / shard count.
     roof_rdisc = {
-            "kernel": "k_rdisc_mfma_w4<6,2> (single pass: fp16 MFMA distance-matrix filter + exact fp64 refine + slot emit)"
+            "kernel": "k_rdisc_mfma_w4 (single pass: fp16 MFMA distance-matrix filter + exact fp64 refine + hit emit)"
             if single_pass else "k_rdisc (count + fill passes)",
             "bound": "mfma", "achieved": ach_tflops, "peak": peak, "unit": "TFLOP/s",
             "frac": ach_tflops / peak,
-            "traffic": traffic,
+            "traffic": prof.get("pair", {}).get("bytes"),
+            "traffic_source": prof.get("source") if prof.get("pair") else None,
             "mfma_flops_issued_tflops": mfma_tflops,
             "frac_of_fp64_peak": ach_tflops / FP64_PEAK_TFLOPS,
+            "valu_per_mfma": prof.get("pair", {}).get("valu_per_mfma"),
+            "avg_launch_ms": pair_ms,
             "note": "achieved = pairs_tested x 2d algorithmic flop (SURVEY 8d) / kernel time; peak = dense fp16 MFMA "
                     "(the filter runs v_mfma_f32_32x32x%d_f16, %d flop per pair with the norm slots); the kernel is " % (mfma_k, 2 * mfma_k) +
-                    "VALU-issue bound on sign-bit extraction (16 v_alignbit per MFMA), not MFMA bound; the result is the "
-                    "exact fp64 graph, so frac_of_fp64_peak compares with what an fp64 Gram kernel could reach",
+                    "VALU-issue bound on sign-bit extraction, not MFMA bound; the result is the exact fp64 graph"
         }
-    roof_rdisc["avg_launch_ms"] = pair_ms
-    roof_rdisc["note"] += ("; tighter candidate lists lower pairs_tested (4.04e10 -> 2.73e10 on the north star) and with it this "
-                           "'algorithmic flop' figure, while the kernel and the step get faster -- queries/s is the figure to follow")
+    # SURVEY 8d asks for both fractions of the sweep: algorithmic bytes/s over 8 TB/s and fp64 lane-ops/s over 39.3e12.
+    # Lane-ops per edge come from the PMC run (SQ_INSTS_VALU x 64 lanes / edges) when the summary matches this build.
+    valu_per_edge = prof.get("sweep", {}).get("valu_lane_ops_per_edge")
+    valu_frac = (valu_per_edge * nnz / (sweep_ms * 1e-3) / FP64_VALU_LANE_OPS) if (valu_per_edge and sweep_ms > 0) else None
     roof_sweep = {
             "kernel": "k_graph_sweep", "bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": PROFILED_TRAFFIC_BYTES.get((w.name, world, "sweep")),
+            "frac": sweep_gbs / HBM_PEAK_GBS,
+            "traffic": prof.get("sweep", {}).get("bytes"),
+            "traffic_source": prof.get("source") if prof.get("sweep") else None,
+            "valu_frac": valu_frac,
             "gather_ceiling_edges_per_s": GATHER_CEILING_ROWS_PER_S if d == 6 else None,
-            "frac_of_gather_ceiling": (nnz / (tm["sweep_graph"][0] * 1e-3) / GATHER_CEILING_ROWS_PER_S) if (d == 6 and tm["sweep_graph"][0] > 0) else None,
-            "note": "algorithmic bytes = (2*d*8 + 8 + 1/8) per edge = %.3f B; every edge needs one random 48-byte row-state gather, and a "
+            "frac_of_gather_ceiling": (nnz / (sweep_ms * 1e-3) / GATHER_CEILING_ROWS_PER_S) if (d == 6 and sweep_ms > 0) else None,
+            "avg_launch_ms": sweep_ms,
+            "note": "algorithmic bytes = (2*d*8 + 8 + 1/8) per edge = %.3f B; valu_frac = measured vector lane-ops per edge x edges/s over the "
+                    "39.3e12 unfused fp64 lane-op/s of SURVEY 8d; every edge needs one random 48-byte row-state gather, and a "
                     "kernel that does nothing but such gathers reaches 4.5e10 rows/s on this GPU (tools/ubench/fetch_calib.hip, "
-                    "profiles/r01_ubench_fetch_calib.txt) -- that, not the 8 TB/s streaming figure, is the ceiling the sweep runs against" % (2 * d * 8 + 8 + 0.125),
+                    "profiles/r01_ubench_fetch_calib.txt)" % (2 * d * 8 + 8 + 0.125),
         }
-    roof_sweep["avg_launch_ms"] = sweep_ms
     if sweep_ms >= pair_ms:
         out["roofline"], out["roofline_rdisc"] = roof_sweep, roof_rdisc
     else:
         out["roofline"], out["roofline_sweep"] = roof_rdisc, roof_sweep
+
+    # whole solve (outside the timed region): fmtstar! with the recursion on the device (mpfmt_fmtstar_wavefront) --
+    # what a planner call costs end to end, next to the eager step above
+    if world == 1 and not args.no_solve and args.workload != "cfg3":
+        try:
+            ctx.set_option("rebuild_index", 0)
+            band = 0.25 * w.r
+            best = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                res = ctx.fmtstar_wavefront(w.r, mp._lib.GOAL_BALL, w.goal_params(), band=band, want_tree=False)
+                ms = 1e3 * (time.perf_counter() - t1)
+                if best is None or ms < best[0]:
+                    best = (ms, res)
+            ms, res = best
+            out["submetrics"]["fmt_solve"] = {
+                "what": "mpfmt_fmtstar_wavefront: checkpts sweep + wavefront recursion on the device (graph of the timed steps reused), band = 0.25 r",
+                "ms": ms, "ms_loop": res["ms_host_loop"], "status": res["status"], "cost": res["cost"],
+                "collision_checks": res["collision_checks"], "wavefronts": res["info"]["iters"],
+                "samples_examined": res["info"]["tot_x"], "samples_connected": res["info"]["tot_conn"]}
+        except mp.MPFMTError as e:            # never lose the headline line to the extra
+            out["submetrics"]["fmt_solve"] = {"error": str(e)}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, mp)
         print(json.dumps(out))
+        sys.stdout.flush()
     ctx.close()
     if dist is not None:
         dist.barrier()

@@ -302,6 +302,77 @@ int32_t mpfmt_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** rowval, vo
  * of edges this shard produced. */
 int32_t mpfmt_shard_info(mpfmt_ctx* ctx, int64_t* col_begin, int64_t* col_end, int64_t* shard_nnz);
 
+/* ---- wavefront solve: fmtstar! (src/planners/fmt.jl:3-119) with the dynamic-programming recursion ON THE DEVICE.
+ *      mpfmt_fmtstar runs the loop fmt.jl:68-90 on one host core over GPU-built arrays; here W / H / C / A live in HBM and
+ *      one step expands a whole cost band of open nodes Z = { z in H : C[z] <= min_H C + band } with the loop body
+ *      fmt.jl:70-82 evaluated for every z of the batch against the same (W, H, C), the deferred H update fmt.jl:83-84 per
+ *      batch, and the stop test fmt.jl:68 on the batch (answer = goal node of lowest (cost, index)).  Edge checks are lazy
+ *      like the reference's (is_free_motion only for the y_min of an examined x, fmt.jl:75); collision_checks counts them.
+ *        flags & MPFMT_WF_SINGLE : the batch is the ONE lowest (cost, index) open node: every step is one iteration of the
+ *              reference loop -- tree, costs, path, collision_checks identical to mpfmt_fmtstar / the sequential recursion.
+ *        band > 0 : every step equals mpfmt_expand (the batch form of the loop body) on the same sets; the tree is a valid
+ *              FMT* tree of the same graph whose cost can exceed the sequential one slightly (reported by the tests / bench).
+ *        flags & MPFMT_WF_EAGER  : answer edge tests from the swept graph mask (mpfmt_graph_step_device) instead of testing
+ *              lazily; forced for checkers without a lane-per-obstacle form here (2-D SAT world, non-identity workspace).
+ *      mpfmt_fmtstar_wavefront = begin + steps until done + finish.  A / C / path may be NULL (skips the 12 N-byte copy).
+ *      Step-wise form (tests, drivers that interleave other work): wf_begin, wf_step ... until info.done, wf_finish;
+ *      wf_state copies the sets out (W, H as the next step will see them; A 1-based, 0 = none), wf_batch the z of the
+ *      last step (1-based).
+ *      Sharded ctx (mpfmt_set_shard / mpfmt_comm_create): every rank holds the whole (W, H, C, A) and the columns
+ *      of its own samples; a step examines the rank's own unvisited samples and ONE all-gather per wavefront carries every
+ *      rank's (x, y_min, c_min) connections (counts ride in the slot headers).  Without a communicator the same exchange is
+ *      made by the caller: wf_step on every ctx, wf_triples from each, wf_commit of all of them to each. */
+#define MPFMT_WF_SINGLE 1
+#define MPFMT_WF_EAGER  2
+typedef struct {
+    int32_t done;              /* 0 running, 1 goal reached (:solved), 2 open set exhausted (:failed) */
+    int32_t nz;                /* batch size of the last step */
+    int32_t nx;                /* samples examined (fmt.jl:70-74) */
+    int32_t nconn;             /* samples connected (fmt.jl:76-80), all ranks */
+    int32_t ntrip;             /* connections found by this rank (sharded) */
+    int64_t iters;             /* steps so far */
+    int64_t checks;            /* edge checks so far (this rank) */
+    double  cmin;              /* lowest open cost at the last step */
+    int64_t tot_z, tot_x, tot_conn;   /* sums over the steps */
+} mpfmt_wf_info;
+int32_t mpfmt_fmtstar_wavefront(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind, const double* goal_params,
+                                double band, int32_t flags, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res, mpfmt_wf_info* info);
+int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind, const double* goal_params,
+                       double band, int32_t flags);
+int32_t mpfmt_wf_step(mpfmt_ctx* ctx, mpfmt_wf_info* info);
+int32_t mpfmt_wf_state(mpfmt_ctx* ctx, uint64_t* W, uint64_t* H, double* C, int64_t* A);
+int32_t mpfmt_wf_batch(mpfmt_ctx* ctx, int64_t* zs, int64_t cap, int64_t* nz);
+int32_t mpfmt_wf_triples(mpfmt_ctx* ctx, int64_t cap, int64_t* x, int64_t* y, double* c, int64_t* n);
+int32_t mpfmt_wf_commit(mpfmt_ctx* ctx, int64_t n, const int64_t* x, const int64_t* y, const double* c);
+int32_t mpfmt_wf_finish(mpfmt_ctx* ctx, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
+
+/* ---- multi-GPU exchange: RCCL over xGMI behind the ABI.  The reference has no analogue (single thread,
+ *      src/planners/fmt.jl); the exchange assembles on every GPU what the single process of the reference holds in one
+ *      address space: the free bit of every graph edge (is_free_motion results, statespaces.jl:153-158) and, in the
+ *      wavefront solve below, the connections of every wavefront (fmt.jl:76-80).
+ *      comm_unique_id : 128-byte RCCL id; rank 0 obtains it, the host hands it to every rank (file, socket, Julia array).
+ *      comm_create    : ncclCommInitRank on the ctx's device + mpfmt_set_shard(rank, world).  world = 1 is allowed.
+ *      group_begin/end: ncclGroupStart / ncclGroupEnd, for ONE host thread that drives several ctxs (a Julia process
+ *                       holding G handles): bracket the comm_create calls, and each round of *_launch calls, with them.
+ *      allgather_free_mask : after mpfmt_graph_step_device on every rank -- one all-gather of the per-shard free-edge masks.
+ *                       *gathered = device address of [world][*stride_words] uint64: per rank (mask words, nnz, then the
+ *                       mask, zero padded); words_each / nnz_each [world] on the host (may be NULL).  Steady state is ONE
+ *                       collective: the lengths ride in front of the payload and every rank derives the next capacity
+ *                       from the lengths it saw (a shard that outgrew it makes every rank repeat at the exact size).
+ *                       _launch / _finish split the call: the gather runs on the ctx's communication stream and overlaps
+ *                       whatever is enqueued next (the following step's index build); cap_hint > 0 = capacity in words
+ *                       the caller guarantees to be identical on all ranks (needed by a single-thread driver on the
+ *                       first step, when the blocking lengths exchange would wait on a peer it has yet to launch). */
+#define MPFMT_COMM_ID_BYTES 128
+int32_t mpfmt_comm_unique_id(uint8_t* id128);
+int32_t mpfmt_comm_create(mpfmt_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id128);
+int32_t mpfmt_comm_destroy(mpfmt_ctx* ctx);
+int32_t mpfmt_group_begin(void);
+int32_t mpfmt_group_end(void);
+int32_t mpfmt_allgather_free_mask(mpfmt_ctx* ctx, void** gathered, int64_t* stride_words, int64_t* words_each, int64_t* nnz_each);
+int32_t mpfmt_allgather_free_mask_launch(mpfmt_ctx* ctx, int64_t cap_hint);
+int32_t mpfmt_allgather_free_mask_finish(mpfmt_ctx* ctx, void** gathered, int64_t* stride_words, int64_t* words_each, int64_t* nnz_each);
+
 /* ---- measurement: average device milliseconds per launch of a named kernel group since the last
  *      reset, measured with HIP events on the launch stream.  names: "rdisc_count", "rdisc_fill",
  *      "rdisc_sort", "grid", "sweep_graph", "sweep_points", "sweep_edges", "expand". */

@@ -34,6 +34,15 @@ class FmtResult(C.Structure):
                 ("ms_host_loop", C.c_double)]
 
 
+class WfInfo(C.Structure):
+    _fields_ = [("done", C.c_int32), ("nz", C.c_int32), ("nx", C.c_int32), ("nconn", C.c_int32), ("ntrip", C.c_int32),
+                ("iters", C.c_int64), ("checks", C.c_int64), ("cmin", C.c_double), ("tot_z", C.c_int64), ("tot_x", C.c_int64),
+                ("tot_conn", C.c_int64)]
+
+
+WF_SINGLE, WF_EAGER = 1, 2
+COMM_ID_BYTES = 128
+
 # every symbol include/mpfmt.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("mpfmt_ctx_create", C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
@@ -91,6 +100,23 @@ SYMBOLS = [
     ("mpfmt_graph_device_ptrs", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("mpfmt_shard_info", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, c_i64_p]),
+    ("mpfmt_fmtstar_wavefront", C.c_int32, [C.c_void_p, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p, C.c_double, C.c_int32,
+                                            c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult), C.POINTER(WfInfo)]),
+    ("mpfmt_wf_begin", C.c_int32, [C.c_void_p, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p, C.c_double, C.c_int32]),
+    ("mpfmt_wf_step", C.c_int32, [C.c_void_p, C.POINTER(WfInfo)]),
+    ("mpfmt_wf_state", C.c_int32, [C.c_void_p, c_u64_p, c_u64_p, c_d_p, c_i64_p]),
+    ("mpfmt_wf_batch", C.c_int32, [C.c_void_p, c_i64_p, C.c_int64, c_i64_p]),
+    ("mpfmt_wf_triples", C.c_int32, [C.c_void_p, C.c_int64, c_i64_p, c_i64_p, c_d_p, c_i64_p]),
+    ("mpfmt_wf_commit", C.c_int32, [C.c_void_p, C.c_int64, c_i64_p, c_i64_p, c_d_p]),
+    ("mpfmt_wf_finish", C.c_int32, [C.c_void_p, c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
+    ("mpfmt_comm_unique_id", C.c_int32, [c_u8_p]),
+    ("mpfmt_comm_create", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, c_u8_p]),
+    ("mpfmt_comm_destroy", C.c_int32, [C.c_void_p]),
+    ("mpfmt_group_begin", C.c_int32, []),
+    ("mpfmt_group_end", C.c_int32, []),
+    ("mpfmt_allgather_free_mask", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), c_i64_p, c_i64_p, c_i64_p]),
+    ("mpfmt_allgather_free_mask_launch", C.c_int32, [C.c_void_p, C.c_int64]),
+    ("mpfmt_allgather_free_mask_finish", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), c_i64_p, c_i64_p, c_i64_p]),
     ("mpfmt_timing_reset", C.c_int32, [C.c_void_p]),
     ("mpfmt_timing_get", C.c_int32, [C.c_void_p, C.c_char_p, c_d_p, c_i64_p]),
     ("mpfmt_set_option", C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
@@ -124,6 +150,15 @@ def lib():
     return _LIB
 
 
+def comm_unique_id():
+    """128-byte RCCL id (rank 0 calls this; the host distributes it)."""
+    u = np.zeros(COMM_ID_BYTES, dtype=np.uint8)
+    rc = lib().mpfmt_comm_unique_id(u.ctypes.data_as(c_u8_p))
+    if rc != OK:
+        raise MPFMTError(rc, lib().mpfmt_last_error(None).decode())
+    return u.tobytes()
+
+
 def nwords(n):
     return (int(n) + 63) // 64
 
@@ -146,6 +181,10 @@ def _dp(a):
 
 def _ip(a):
     return None if a is None else a.ctypes.data_as(c_i64_p)
+
+
+def _dp_or_none(a):
+    return None if a is None else a.ctypes.data_as(c_d_p)
 
 
 def _up(a):
@@ -354,6 +393,98 @@ class Context:
                     collision_checks=int(res.collision_checks), nnz=int(res.nnz),
                     ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
                     A=A[:self.N], C=Cc[:self.N], path=path[:res.path_len].copy())
+
+    # ---- wavefront solve (recursion on the device) -------------------------------------------------
+    @staticmethod
+    def _wf_info(i):
+        return {k: getattr(i, k) for k, _ in WfInfo._fields_}
+
+    def _fmt_out(self, res, A, Cc, path):
+        return dict(status=int(res.status), cost=float(res.cost), z=int(res.z), collision_checks=int(res.collision_checks),
+                    nnz=int(res.nnz), ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
+                    A=None if A is None else A[:self.N], C=None if Cc is None else Cc[:self.N], path=path[:res.path_len].copy())
+
+    def fmtstar_wavefront(self, r, goal_kind, goal_params, band=0.0, single=False, eager=False, init_idx=1, checkpts=True,
+                          want_tree=True):
+        """fmtstar! with the recursion on the device (include/mpfmt.h): band = cost width of a batch; single = one node per
+        step (the reference's order exactly)."""
+        g = np.ascontiguousarray(goal_params, dtype=np.float64)
+        A = np.empty(max(self.N, 1), dtype=np.int64) if want_tree else None
+        Cc = np.empty(max(self.N, 1), dtype=np.float64) if want_tree else None
+        path = np.empty(max(self.N, 1), dtype=np.int64)
+        res, info = FmtResult(), WfInfo()
+        flags = (WF_SINGLE if single else 0) | (WF_EAGER if eager else 0)
+        self._chk(self._L.mpfmt_fmtstar_wavefront(self._h, float(r), int(init_idx), int(bool(checkpts)), int(goal_kind), _dp(g), float(band),
+                                                  flags, _ip(A), _dp(Cc), _ip(path), C.byref(res), C.byref(info)))
+        out = self._fmt_out(res, A, Cc, path)
+        out["info"] = self._wf_info(info)
+        return out
+
+    def wf_begin(self, r, goal_kind, goal_params, band=0.0, single=False, eager=False, init_idx=1, checkpts=True):
+        g = np.ascontiguousarray(goal_params, dtype=np.float64)
+        flags = (WF_SINGLE if single else 0) | (WF_EAGER if eager else 0)
+        self._chk(self._L.mpfmt_wf_begin(self._h, float(r), int(init_idx), int(bool(checkpts)), int(goal_kind), _dp(g), float(band), flags))
+
+    def wf_step(self):
+        info = WfInfo()
+        self._chk(self._L.mpfmt_wf_step(self._h, C.byref(info)))
+        return self._wf_info(info)
+
+    def wf_state(self):
+        """(W, H, C, A): packed uint64 masks, costs, parents (1-based, 0 = none)."""
+        nw = max(nwords(self.N), 1)
+        W = np.zeros(nw, dtype=np.uint64); H = np.zeros(nw, dtype=np.uint64)
+        Cc = np.empty(max(self.N, 1)); A = np.empty(max(self.N, 1), dtype=np.int64)
+        self._chk(self._L.mpfmt_wf_state(self._h, _up(W), _up(H), _dp(Cc), _ip(A)))
+        return W[:nwords(self.N)], H[:nwords(self.N)], Cc[:self.N], A[:self.N]
+
+    def wf_batch(self):
+        zs = np.empty(max(self.N, 1), dtype=np.int64)
+        n = C.c_int64()
+        self._chk(self._L.mpfmt_wf_batch(self._h, _ip(zs), self.N, C.byref(n)))
+        return zs[:n.value].copy()
+
+    def wf_triples(self):
+        x = np.empty(max(self.N, 1), dtype=np.int64); y = np.empty(max(self.N, 1), dtype=np.int64); c = np.empty(max(self.N, 1))
+        n = C.c_int64()
+        self._chk(self._L.mpfmt_wf_triples(self._h, self.N, _ip(x), _ip(y), _dp(c), C.byref(n)))
+        return x[:n.value].copy(), y[:n.value].copy(), c[:n.value].copy()
+
+    def wf_commit(self, x, y, c):
+        x = np.ascontiguousarray(x, dtype=np.int64); y = np.ascontiguousarray(y, dtype=np.int64); c = np.ascontiguousarray(c, dtype=np.float64)
+        self._chk(self._L.mpfmt_wf_commit(self._h, len(x), _ip(x), _ip(y), _dp(c)))
+
+    def wf_finish(self, want_tree=True):
+        A = np.empty(max(self.N, 1), dtype=np.int64) if want_tree else None
+        Cc = np.empty(max(self.N, 1), dtype=np.float64) if want_tree else None
+        path = np.empty(max(self.N, 1), dtype=np.int64)
+        res = FmtResult()
+        self._chk(self._L.mpfmt_wf_finish(self._h, _ip(A), _dp(Cc), _ip(path), C.byref(res)))
+        return self._fmt_out(res, A, Cc, path)
+
+    # ---- multi-GPU exchange (RCCL behind the ABI) ---------------------------------------------------
+    def comm_create(self, rank, world, uid):
+        """uid: 128 bytes from comm_unique_id() of rank 0, handed to every rank by the host."""
+        u = np.frombuffer(bytes(uid), dtype=np.uint8).copy()
+        assert u.size == COMM_ID_BYTES
+        self._chk(self._L.mpfmt_comm_create(self._h, int(rank), int(world), u.ctypes.data_as(c_u8_p)))
+
+    def comm_destroy(self):
+        self._chk(self._L.mpfmt_comm_destroy(self._h))
+
+    def allgather_free_mask_launch(self, cap_hint=0):
+        self._chk(self._L.mpfmt_allgather_free_mask_launch(self._h, int(cap_hint)))
+
+    def allgather_free_mask_finish(self, world):
+        ptr, stride = C.c_void_p(), C.c_int64()
+        words = np.zeros(world, dtype=np.int64); nnz = np.zeros(world, dtype=np.int64)
+        self._chk(self._L.mpfmt_allgather_free_mask_finish(self._h, C.byref(ptr), C.byref(stride), _ip(words), _ip(nnz)))
+        return ptr.value, stride.value, words, nnz
+
+    def allgather_free_mask(self, world):
+        """One RCCL all-gather of the per-shard free-edge masks: (device ptr, stride in words, words per rank, nnz per rank)."""
+        self.allgather_free_mask_launch(0)
+        return self.allgather_free_mask_finish(world)
 
     def mc_edges_collision(self, src, dst, sigma, rollouts, seed=0):
         """Colliding rollouts per edge (1-based src / dst): Monte-Carlo collision probability = hits / rollouts."""

@@ -1,0 +1,796 @@
+// Device-resident wavefront FMT* (gfx950): the reference's dynamic-programming recursion (src/planners/fmt.jl:43-101)
+// with W / H / C / A held in HBM and a whole cost band of open nodes expanded per step.
+//
+// The reference pops ONE lowest-cost open node z per iteration (fmt.jl:66,85-89) and runs the body fmt.jl:70-82 for it.
+// Here one step takes the batch Z = { z in H : C[z] <= min_H C + band } and runs that body for every z of the batch
+// against the SAME sets (W, H, C) -- the batch step SURVEY.md 7(5ii) / 8e calls a wavefront (Ichter, Schmerling, Pavone,
+// "Group Marching Tree", 2017, is FMT* expanded this way):
+//     for x in nearF(V, z, r, W), z in Z        -> mark: x unvisited, valid (checkpts), adjacent to the batch   (fmt.jl:70-71)
+//        y_min = first argmin_{y in nearB(x) & H} C[y] + d(y, x)                                                (fmt.jl:72-74)
+//        is_free_motion(V[y_min], V[x], CC, SS) -> A[x] = y_min, C[x] = c_min, W[x] = false, H_new += x         (fmt.jl:75-80)
+//     H = (H \ Z) + H_new                        (the reference's deferred H update, fmt.jl:83-84, per batch)
+//     stop when a batch holds a goal node (fmt.jl:68): the answer is the goal node of lowest (cost, index).
+// With the batch forced to the single lowest (cost, index) open node (option `single`) every step IS one iteration of the
+// reference loop, and tree, costs, path and collision_checks equal the sequential recursion's exactly; with a band the
+// result of every step equals the batch form of the loop body (mpfmt_expand / the oracle's orc_expand) on the same sets.
+// Edge checks are LAZY like the reference's (one per examined x per step): collision_checks counts what the loop asked for.
+//
+// Kernels per step (no host round trip inside a step; counters live in HBM, a `done` flag voids the kernels after the end):
+//   k_wf_apply_min : H = (H & ~Z) | Hnew, clear Z / Hnew / cand; lexicographic minimum (C, index) over H -> per-block partials
+//   k_wf_select    : reduce the partials; Z = nodes within the band (or the one minimum); batch list; goal test
+//   k_wf_mark      : wavefront per batch node: mark unvisited valid neighbours once, append to the candidate list
+//                    (sharded ctx: wavefront per OWNED unvisited sample, looks for a batch node in its own column)
+//   k_wf_connect   : wavefront per candidate x: first-minimum over open neighbours (lexicographic wave reduce), then the
+//                    edge test with LANE = OBSTACLE (boxes in LDS, predicates of sweep_predicates.h) or a bit of the swept
+//                    mask; connect in place (1 GPU) or emit a (x, y_min, c_min) triple for the exchange (sharded)
+//   k_wf_commit    : apply exchanged triples (sharded: after the all-gather every rank applies every rank's triples)
+#include "sweep_predicates.h"
+#include <cstring>
+#include <cmath>
+#include <chrono>
+#include <algorithm>
+#include <vector>
+
+#define WF_MAXPARTS 1024
+
+struct wf_goal { int32_t kind; int32_t gd; double g[2 * MPFMT_MAX_DIM + 1]; };
+
+struct wf_ctr {
+    int32_t done;                 // 0 running, 2 open set exhausted, 1 goal in batch (set by k_wf_final; while running the
+                                  // goal condition is goal_cbits != ~0, see wf_stop)
+    int32_t nz, nz_prev;          // batch size of this / the previous step
+    int32_t nx;                   // candidates of this step
+    int32_t nconn;                // connections of this step
+    int32_t ntrip;                // triples emitted this step (sharded)
+    int64_t checks;               // collision checks so far (this rank)
+    int64_t iters;
+    unsigned long long goal_cbits;   // lowest cost (as bits) of a goal node in the batch, ~0 = none
+    int64_t final_z;              // resolved by k_wf_final
+    double cmin;                  // lowest open cost at this step
+    int64_t imin;
+    int64_t tot_z, tot_x, tot_conn;
+};
+
+// the solve has ended: every kernel enqueued after that point returns at once and the sets stay as they were
+__device__ __forceinline__ bool wf_stop(const wf_ctr* c) { return c->done != 0 || c->goal_cbits != ~0ull; }
+
+struct wf_trip { int32_t x, y; double c; };
+#define WF_XCAP 16384             // triples per rank and exchange round (256 KB): a wavefront rarely connects more per rank
+
+struct mpfmt_wf {
+    int64_t N = 0, words = 0;
+    uint64_t *W = nullptr, *H = nullptr, *Z = nullptr, *Hn = nullptr, *cand = nullptr, *F = nullptr;
+    double* C = nullptr;
+    int32_t* A = nullptr;
+    int32_t *zlist = nullptr, *xlist = nullptr;
+    double* part_c = nullptr; int64_t* part_i = nullptr;
+    wf_trip* mytrips = nullptr;   // [N] connections of this rank in the current step (sharded)
+    wf_trip* xbuf = nullptr;      // [world][WF_XCAP + 1] exchange slots: header (x = the rank's total count) + one round's triples
+    wf_trip* hdr_host = nullptr;  // pinned [world] headers of the last exchange round
+    int world_alloc = 0;
+    wf_ctr* ctr = nullptr;        // device
+    wf_ctr* ctr_host = nullptr;   // pinned
+    int64_t* path_dev = nullptr;
+    wf_goal goal;
+    double band = 0.0;
+    int32_t single = 0, checkpts = 1, use_mask = 0, sharded = 0;
+    int64_t init = 0;
+    double r = 0.0;
+    bool active = false;
+    int nparts = 1;
+    std::chrono::steady_clock::time_point t_begin;
+    double ms_graph = 0.0, ms_sweep = 0.0;
+};
+
+__device__ __forceinline__ bool wf_bit(const uint64_t* m, int64_t i) { return (m[i >> 6] >> (i & 63)) & 1ull; }
+
+// src/goals.jl:96 (Rectangle), :100 (Ball), :111-114 (Point), Identity state2workspace
+__device__ __forceinline__ bool wf_is_goal(const double* v, const wf_goal& G)
+{
+    const int d = G.gd;
+    if (G.kind == MPFMT_GOAL_RECT) {
+        bool ok = true;
+        for (int i = 0; i < d; ++i) ok = ok && (G.g[i] <= v[i]) && (v[i] <= G.g[d + i]);
+        return ok;
+    }
+    if (G.kind == MPFMT_GOAL_BALL) {
+        double s = 0.0;
+        for (int i = 0; i < d; ++i) { const double t = v[i] - G.g[i]; const double tt = t * t; s = (i == 0) ? tt : s + tt; }
+        return sqrt(s) <= G.g[d];
+    }
+    bool ok = true;
+    for (int i = 0; i < d; ++i) ok = ok && (v[i] == G.g[i]);
+    return ok;
+}
+
+__device__ __forceinline__ void wf_lexmin_wave(double& c, int64_t& i)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oc = __shfl_xor(c, off);
+        const int64_t oi = __shfl_xor(i, off);
+        if (oi >= 0 && (i < 0 || oc < c || (oc == c && oi < i))) { c = oc; i = oi; }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_wf_init(int64_t N, int64_t words, int64_t init, uint64_t* W, uint64_t* H, uint64_t* Z,
+                                                uint64_t* Hn, uint64_t* cand, double* C, int32_t* A, wf_ctr* ctr)
+{
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    for (int64_t w = t; w < words; w += (int64_t)gridDim.x * 64) {
+        uint64_t full = ~0ull;
+        if (w == words - 1 && (N & 63)) full = (1ull << (N & 63)) - 1;
+        if (w == (init >> 6)) { W[w] = full & ~(1ull << (init & 63)); H[w] = 1ull << (init & 63); }
+        else { W[w] = full; H[w] = 0; }
+        Z[w] = 0; Hn[w] = 0; cand[w] = 0;
+    }
+    for (int64_t i = t; i < N; i += (int64_t)gridDim.x * 64) { C[i] = 0.0; A[i] = -1; }
+    if (t == 0) {
+        wf_ctr z;
+        memset(&z, 0, sizeof z);
+        z.goal_cbits = ~0ull; z.final_z = init; z.imin = -1;
+        *ctr = z;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __restrict__ H, uint64_t* __restrict__ Z,
+                                                     uint64_t* __restrict__ Hn, uint64_t* __restrict__ cand,
+                                                     const double* __restrict__ C, double* __restrict__ part_c,
+                                                     int64_t* __restrict__ part_i, wf_ctr* __restrict__ ctr)
+{
+    if (wf_stop(ctr)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {          // totals of the finished step, then the per-step counters start over
+        ctr->tot_z += ctr->nz; ctr->tot_x += ctr->nx; ctr->tot_conn += ctr->nconn;      // (no other thread of this kernel
+        ctr->nz_prev = ctr->nz; ctr->nz = 0; ctr->nx = 0; ctr->nconn = 0; ctr->ntrip = 0;   //  touches these fields)
+        ctr->iters += 1;
+    }
+    double bc = 0.0; int64_t bi = -1;
+    for (int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 64) {
+        uint64_t h = (H[w] & ~Z[w]) | Hn[w];
+        H[w] = h; Z[w] = 0; Hn[w] = 0; cand[w] = 0;
+        while (h) {
+            const int b = __ffsll((long long)h) - 1;
+            h &= h - 1;
+            const int64_t i = w * 64 + b;
+            const double c = C[i];
+            if (bi < 0 || c < bc) { bc = c; bi = i; }         // ascending i per thread: first minimum
+        }
+    }
+    wf_lexmin_wave(bc, bi);
+    if (threadIdx.x == 0) { part_c[blockIdx.x] = bc; part_i[blockIdx.x] = bi; }
+}
+
+// `done` / goal_cbits are only ever written here AFTER every block has passed its entry test: goal_cbits by atomicMin from
+// blocks that did select (a late block that sees it set must still select, hence the entry test reads `done` alone --
+// done == 2 is decided identically by every block from the partials)
+__global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, const uint64_t* __restrict__ H, uint64_t* __restrict__ Z,
+                                                  const double* __restrict__ C, const double* __restrict__ X, int d,
+                                                  const double* __restrict__ part_c, const int64_t* __restrict__ part_i,
+                                                  double band, int single, wf_goal G, int32_t* __restrict__ zlist,
+                                                  wf_ctr* __restrict__ ctr)
+{
+    if (ctr->done) return;
+    double cm = 0.0; int64_t im = -1;
+    for (int p = threadIdx.x; p < nparts; p += 64) {
+        const double c = part_c[p]; const int64_t i = part_i[p];
+        if (i >= 0 && (im < 0 || c < cm || (c == cm && i < im))) { cm = c; im = i; }
+    }
+    wf_lexmin_wave(cm, im);
+    if (im < 0) {                                   // H is empty: fmt.jl:85-89 `break`
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctr->done = 2;
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr->cmin = cm; ctr->imin = im; }
+    const double thr = cm + band;
+    for (int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 64) {
+        uint64_t h = H[w], z = 0;
+        while (h) {
+            const int b = __ffsll((long long)h) - 1;
+            h &= h - 1;
+            const int64_t i = w * 64 + b;
+            const double c = C[i];
+            const bool sel = single ? (i == im) : (c <= thr);
+            if (!sel) continue;
+            z |= 1ull << b;
+            if (wf_is_goal(X + i * d, G))           // fmt.jl:68
+                atomicMin(&ctr->goal_cbits, (unsigned long long)__double_as_longlong(c));
+        }
+        if (z) {
+            Z[w] = z;
+            int o = atomicAdd(&ctr->nz, __popcll(z));             // one atomic per word, not per node
+            while (z) { const int b = __ffsll((long long)z) - 1; z &= z - 1; zlist[o++] = (int32_t)(w * 64 + b); }
+        }
+    }
+}
+
+// the node the reference's loop would end on: goal node of lowest (cost, index) in the batch, or -- open set exhausted --
+// the last node of the previous batch in pop order = highest (cost, index) (fmt.jl:85-89 leaves z at the last dequeued node)
+__global__ __launch_bounds__(64) void k_wf_final(const int32_t* __restrict__ zlist, const double* __restrict__ C, const double* __restrict__ X,
+                                                 int d, wf_goal G, wf_ctr* __restrict__ ctr)
+{
+    const bool goal = ctr->goal_cbits != ~0ull;
+    if (!goal && ctr->done != 2) return;
+    const int n = goal ? ctr->nz : ctr->nz_prev;
+    double bc = 0.0; int64_t bi = -1;
+    for (int k = threadIdx.x; k < n; k += 64) {
+        const int64_t i = zlist[k];
+        const double c = C[i];
+        if (goal) {
+            if (!wf_is_goal(X + i * d, G)) continue;
+            if (bi < 0 || c < bc || (c == bc && i < bi)) { bc = c; bi = i; }
+        } else {
+            if (bi < 0 || c > bc || (c == bc && i > bi)) { bc = c; bi = i; }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oc = __shfl_xor(bc, off);
+        const int64_t oi = __shfl_xor(bi, off);
+        const bool take = (oi >= 0) && (bi < 0 || (goal ? (oc < bc || (oc == bc && oi < bi)) : (oc > bc || (oc == bc && oi > bi))));
+        if (take) { bc = oc; bi = oi; }
+    }
+    if (threadIdx.x == 0) {
+        if (bi >= 0) ctr->final_z = bi;
+        if (goal) ctr->done = 1;
+    }
+}
+
+// mark pass, one wavefront per batch node (symmetric metric: forward set == column, nearneighbors.jl:200-203)
+__global__ __launch_bounds__(256) void k_wf_mark(const int32_t* __restrict__ zlist, const int64_t* __restrict__ colptr,
+                                                 const int32_t* __restrict__ rowval, const uint64_t* __restrict__ W,
+                                                 const uint64_t* __restrict__ F, unsigned long long* __restrict__ cand,
+                                                 int32_t* __restrict__ xlist, wf_ctr* __restrict__ ctr)
+{
+    if (wf_stop(ctr)) return;
+    const int lane = threadIdx.x & 63;
+    const int nz = ctr->nz;
+    const int wpb = blockDim.x >> 6;
+    for (int iz = blockIdx.x * wpb + (threadIdx.x >> 6); iz < nz; iz += gridDim.x * wpb) {
+        const int64_t z = zlist[iz];
+        const int64_t beg = colptr[z], end = colptr[z + 1];
+        for (int64_t e = beg + lane; e < end; e += 64) {
+            const int64_t x = rowval[e];
+            if (!wf_bit(W, x) || (F && !wf_bit(F, x))) continue;          // fmt.jl:70-71
+            const unsigned long long bit = 1ull << (x & 63);
+            if (cand[x >> 6] & bit) continue;                             // seen already (a stale read only costs an atomic)
+            const unsigned long long old = atomicOr(&cand[x >> 6], bit);
+            if (!(old & bit)) xlist[atomicAdd(&ctr->nx, 1)] = (int32_t)x;
+        }
+    }
+}
+
+// sharded ctx: the columns of the batch nodes live on their owners, so each rank walks its OWN unvisited samples and
+// looks for a batch node in the sample's own column (x in nearF(z) <=> z in col(x) for a metric)
+__global__ __launch_bounds__(256) void k_wf_mark_owned(const int32_t* __restrict__ perm, int64_t p_begin, int64_t p_end,
+                                                       const int64_t* __restrict__ colptr, const int32_t* __restrict__ rowval,
+                                                       const uint64_t* __restrict__ W, const uint64_t* __restrict__ F,
+                                                       const uint64_t* __restrict__ Z, int32_t* __restrict__ xlist,
+                                                       wf_ctr* __restrict__ ctr)
+{
+    if (wf_stop(ctr)) return;
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int64_t p = p_begin + blockIdx.x * wpb + (threadIdx.x >> 6); p < p_end; p += (int64_t)gridDim.x * wpb) {
+        const int64_t x = perm[p];
+        if (x < 0 || !wf_bit(W, x) || (F && !wf_bit(F, x))) continue;
+        const int64_t beg = colptr[x], end = colptr[x + 1];
+        bool hit = false;
+        for (int64_t e0 = beg; e0 < end && !hit; e0 += 64) {
+            const int64_t e = e0 + lane;
+            const bool mine = (e < end) && wf_bit(Z, rowval[e]);
+            hit = __ballot(mine) != 0;
+        }
+        if (hit && lane == 0) xlist[atomicAdd(&ctr->nx, 1)] = (int32_t)x;
+    }
+}
+
+// obstacle k of the transposed staging [2*D][mpad]: lane = obstacle reads consecutive words (no bank conflicts)
+template <int D>
+__device__ __forceinline__ box_regs<D> wf_load_box_T(const double* sT, int mpad, int k)
+{
+    box_regs<D> b;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { b.lo[i] = sT[i * mpad + k]; b.hi[i] = sT[(D + i) * mpad + k]; }
+    return b;
+}
+
+// one wavefront per candidate x.  MODE 0: connect in place; MODE 1: emit triples (sharded)
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void k_wf_connect(const int32_t* __restrict__ xlist, const int64_t* __restrict__ colptr,
+                                                    const int32_t* __restrict__ rowval, const double* __restrict__ nzval,
+                                                    const uint64_t* __restrict__ H, double* __restrict__ C, int32_t* __restrict__ A,
+                                                    unsigned long long* __restrict__ W, unsigned long long* __restrict__ Hn,
+                                                    const double* __restrict__ X, const double* __restrict__ boxes, int M, int mpad,
+                                                    mpfmt_ss ss, const uint64_t* __restrict__ gfree, wf_trip* __restrict__ mytrips,
+                                                    wf_ctr* __restrict__ ctr)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (wf_stop(ctr)) return;
+    double* sT = (double*)smem;
+    if (!gfree && mpad) {                                               // obstacle set staged once per workgroup, transposed
+        for (int t = threadIdx.x; t < M * 2 * D; t += blockDim.x) {
+            const int k = t / (2 * D), j = t - k * 2 * D;
+            sT[j * mpad + k] = boxes[t];
+        }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int nx = ctr->nx;
+    int my_checks = 0;
+    for (int ix = blockIdx.x * wpb + (threadIdx.x >> 6); ix < nx; ix += gridDim.x * wpb) {
+        const int64_t x = xlist[ix];
+        const int64_t beg = colptr[x], end = colptr[x + 1];
+        double best = 0.0;
+        int64_t be = -1;
+        for (int64_t e = beg + lane; e < end; e += 64) {                   // nearB(V, x, r, H) + findmin, fmt.jl:72-74
+            const int64_t y = rowval[e];
+            if (!wf_bit(H, y)) continue;
+            const double c = C[y] + nzval[e];
+            if (be < 0 || c < best) { best = c; be = e; }                  // ascending e per lane keeps the first minimum
+        }
+        wf_lexmin_wave(best, be);                                          // rows ascend with e: first minimum = lowest e
+        if (be < 0) continue;
+        const int64_t y = rowval[be];
+        double v[D], w[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) { v[i] = X[y * D + i]; w[i] = X[x * D + i]; }
+        const bool inb = in_state_space_sl<D>(v, ss);                      // statespaces.jl:155: first point of the segment
+        if (lane == 0 && inb) ++my_checks;                                 // boxesND.jl:26 is reached only then
+        bool fr;
+        if (gfree) {
+            fr = wf_bit(gfree, be);
+        } else {
+            double l[D], h[D];
+            seg_bbox<D>(v, w, l, h);
+            bool blocked = false;
+            for (int k0 = 0; k0 < M; k0 += 64) {                           // lane = obstacle (boxesND.jl:52-56; @all in any order)
+                const int k = k0 + lane;
+                const int kk = min(k, M - 1);
+                const box_regs<D> b = mpad ? wf_load_box_T<D>(sT, mpad, kk) : load_box<D>(boxes, kk);
+                const bool pend = (k < M) && !broadphase_free_sl<D>(l, h, b);
+                if (__ballot(pend)) {
+                    if (pend) blocked = blocked || !narrow_free_sl<D>(v, w, b);
+                }
+            }
+            fr = inb && (__ballot(blocked) == 0);
+        }
+        if (fr && lane == 0) {                                             // fmt.jl:76-80
+            if (MODE == 0) {
+                A[x] = (int32_t)y; C[x] = best;
+                atomicAnd(&W[x >> 6], ~(1ull << (x & 63)));
+                atomicOr(&Hn[x >> 6], 1ull << (x & 63));
+                atomicAdd(&ctr->nconn, 1);
+            } else {
+                wf_trip r; r.x = (int32_t)x; r.y = (int32_t)y; r.c = best;
+                mytrips[atomicAdd(&ctr->ntrip, 1)] = r;                    // at most one per owned candidate: capacity N holds
+            }
+        }
+    }
+    if (lane == 0 && my_checks) atomicAdd((unsigned long long*)&ctr->checks, (unsigned long long)my_checks);
+}
+
+// exchange round `round` of this rank: header (x = total count of the step; 0 once the solve has ended) + its chunk
+__global__ __launch_bounds__(256) void k_wf_pack(const wf_trip* __restrict__ mytrips, int round, wf_trip* __restrict__ slot, const wf_ctr* __restrict__ ctr)
+{
+    const int total = wf_stop(ctr) ? 0 : ctr->ntrip;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) { wf_trip hd; hd.x = total; hd.y = round; hd.c = (double)ctr->checks; slot[0] = hd; }   // c: this rank's edge checks so far
+    const int64_t src = (int64_t)round * WF_XCAP + t;
+    if (t < WF_XCAP && src < total) slot[1 + t] = mytrips[src];
+}
+
+// apply round `round` of `nslots` exchange slots
+__global__ __launch_bounds__(256) void k_wf_commit(const wf_trip* __restrict__ xbuf, int nslots, int round,
+                                                   double* __restrict__ C, int32_t* __restrict__ A, unsigned long long* __restrict__ W,
+                                                   unsigned long long* __restrict__ Hn, wf_ctr* __restrict__ ctr)
+{
+    if (wf_stop(ctr)) return;
+    for (int s = 0; s < nslots; ++s) {
+        const wf_trip* slot = xbuf + (int64_t)s * (WF_XCAP + 1);
+        const int64_t left = (int64_t)slot[0].x - (int64_t)round * WF_XCAP;
+        const int64_t n = left < 0 ? 0 : (left > WF_XCAP ? WF_XCAP : left);
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+            const wf_trip r = slot[1 + t];
+            const int64_t x = r.x;
+            A[x] = r.y; C[x] = r.c;
+            atomicAnd(&W[x >> 6], ~(1ull << (x & 63)));
+            atomicOr(&Hn[x >> 6], 1ull << (x & 63));
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&ctr->nconn, (int)n);
+    }
+}
+
+// back-trace fmt.jl:92-101 from final_z to the root, written root first; path[N] = length
+__global__ void k_wf_path(const int32_t* __restrict__ A, int64_t N, const wf_ctr* __restrict__ ctr, int64_t* __restrict__ path)
+{
+    int64_t cur = ctr->final_z, n = 1;
+    while (n < N && A[cur] >= 0) { cur = A[cur]; ++n; }
+    path[N] = n;
+    cur = ctr->final_z;
+    for (int64_t k = n - 1; k >= 0; --k) { path[k] = cur + 1; if (k) cur = A[cur]; }
+}
+
+__global__ void k_wf_A_to_i64(const int32_t* __restrict__ A, int64_t N, int64_t* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[i] = (int64_t)A[i] + 1;
+}
+
+__global__ void k_wf_zs_to_i64(const int32_t* __restrict__ zl, int64_t n, int64_t* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int64_t)zl[i] + 1;
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------
+
+static mpfmt_wf* wf_of(mpfmt_ctx* ctx) { return (mpfmt_wf*)ctx->wf; }
+
+void mpfmt_wf_free(mpfmt_ctx* ctx)
+{
+    mpfmt_wf* s = wf_of(ctx);
+    if (!s) return;
+    void* bufs[] = {s->W, s->H, s->Z, s->Hn, s->cand, s->F, s->C, s->A, s->zlist, s->xlist, s->part_c, s->part_i, s->mytrips, s->xbuf, s->ctr, s->path_dev};
+    for (void* b : bufs) if (b) hipFree(b);
+    if (s->ctr_host) hipHostFree(s->ctr_host);
+    if (s->hdr_host) hipHostFree(s->hdr_host);
+    delete s;
+    ctx->wf = nullptr;
+}
+
+static int32_t wf_alloc(mpfmt_ctx* ctx, mpfmt_wf* s, int64_t N, int world)
+{
+    const int64_t words = (N + 63) / 64;
+    if (s->N != N) {
+        void** bufs[] = {(void**)&s->W, (void**)&s->H, (void**)&s->Z, (void**)&s->Hn, (void**)&s->cand, (void**)&s->F, (void**)&s->C,
+                         (void**)&s->A, (void**)&s->zlist, (void**)&s->xlist, (void**)&s->path_dev, (void**)&s->mytrips};
+        for (void** b : bufs) if (*b) { HIPCHK(ctx, hipFree(*b)); *b = nullptr; }
+        HIPCHK(ctx, hipMalloc((void**)&s->W, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->H, 8 * words));
+        HIPCHK(ctx, hipMalloc((void**)&s->Z, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->Hn, 8 * words));
+        HIPCHK(ctx, hipMalloc((void**)&s->cand, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->F, 8 * words));
+        HIPCHK(ctx, hipMalloc((void**)&s->C, 8 * N)); HIPCHK(ctx, hipMalloc((void**)&s->A, 4 * N));
+        HIPCHK(ctx, hipMalloc((void**)&s->zlist, 4 * N)); HIPCHK(ctx, hipMalloc((void**)&s->xlist, 4 * N));
+        HIPCHK(ctx, hipMalloc((void**)&s->path_dev, 8 * (N + 1)));
+        s->N = N; s->words = words;
+    }
+    if (!s->part_c) { HIPCHK(ctx, hipMalloc((void**)&s->part_c, 8 * WF_MAXPARTS)); HIPCHK(ctx, hipMalloc((void**)&s->part_i, 8 * WF_MAXPARTS)); }
+    if (!s->ctr) { HIPCHK(ctx, hipMalloc((void**)&s->ctr, sizeof(wf_ctr))); HIPCHK(ctx, hipHostMalloc((void**)&s->ctr_host, sizeof(wf_ctr))); }
+    if (world > 1) {
+        if (!s->mytrips) HIPCHK(ctx, hipMalloc((void**)&s->mytrips, sizeof(wf_trip) * (size_t)N));
+        if (s->world_alloc < world) {
+            if (s->xbuf) { HIPCHK(ctx, hipFree(s->xbuf)); s->xbuf = nullptr; }
+            if (s->hdr_host) { HIPCHK(ctx, hipHostFree(s->hdr_host)); s->hdr_host = nullptr; }
+            HIPCHK(ctx, hipMalloc((void**)&s->xbuf, sizeof(wf_trip) * (size_t)(WF_XCAP + 1) * (size_t)world));
+            HIPCHK(ctx, hipHostMalloc((void**)&s->hdr_host, sizeof(wf_trip) * (size_t)world));
+            s->world_alloc = world;
+        }
+    }
+    return MPFMT_OK;
+}
+
+// the per-rank part of one step: apply + select + mark + connect (sharded: connections are left in mytrips)
+static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
+{
+    const int64_t words = s->words;
+    const int nparts = s->nparts;
+    hipStream_t st = ctx->stream;
+    const int d = ctx->d;
+    hipLaunchKernelGGL(k_wf_apply_min, dim3(nparts), dim3(64), 0, st, words, s->H, s->Z, s->Hn, s->cand, s->C, s->part_c, s->part_i, s->ctr);
+    hipLaunchKernelGGL(k_wf_select, dim3(nparts), dim3(64), 0, st, words, nparts, s->H, s->Z, s->C, ctx->Xo, d, s->part_c, s->part_i, s->band,
+                       s->single, s->goal, s->zlist, s->ctr);
+    const uint64_t* F = s->checkpts ? s->F : nullptr;
+    const int grid = ctx->num_cus * 8;
+    if (!s->sharded) {
+        hipLaunchKernelGGL(k_wf_mark, dim3(grid), dim3(256), 0, st, s->zlist, ctx->colptr, ctx->rowval, s->W, F,
+                           (unsigned long long*)s->cand, s->xlist, s->ctr);
+    } else {
+        const int64_t pb = std::min<int64_t>(ctx->tile_begin * 64, ctx->N), pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
+        hipLaunchKernelGGL(k_wf_mark_owned, dim3(grid), dim3(256), 0, st, ctx->perm, pb, pe, ctx->colptr, ctx->rowval, s->W, F, s->Z,
+                           s->xlist, s->ctr);
+    }
+    const uint64_t* gfree = s->use_mask ? ctx->graph_free : nullptr;
+    const int mpad = ((ctx->M + 63) / 64) * 64 + 1;                      // odd row stride
+    const size_t box_bytes = sizeof(double) * 2 * (size_t)d * (size_t)mpad;
+    const bool lds_boxes = !gfree && ctx->M > 0 && box_bytes <= 60 * 1024;
+    const size_t lds = lds_boxes ? box_bytes : 0;
+    const int mp = lds_boxes ? mpad : 0;
+    if (!s->sharded) {
+        DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 0>), dim3(grid), dim3(256), lds, st, s->xlist, ctx->colptr, ctx->rowval, ctx->nzval,
+                                         s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo, ctx->boxes, ctx->M,
+                                         mp, ctx->ss, gfree, (wf_trip*)nullptr, s->ctr));
+    } else {
+        DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 1>), dim3(grid), dim3(256), lds, st, s->xlist, ctx->colptr, ctx->rowval, ctx->nzval,
+                                         s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo, ctx->boxes, ctx->M,
+                                         mp, ctx->ss, gfree, s->mytrips, s->ctr));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
+// ONE all-gather per wavefront: every rank's (x, y_min, c_min) connections, the counts riding in the slot
+// headers; a rank that connected more than WF_XCAP nodes makes every rank run further rounds -- all of them read the same
+// headers, so the decision is the same everywhere and the collectives stay matched.  Costs one host look per wavefront.
+static int32_t wf_exchange(mpfmt_ctx* ctx, mpfmt_wf* s)
+{
+    int rank = 0, world = 1;
+    mpfmt_comm_world(ctx, &rank, &world);
+    hipStream_t st = ctx->stream;
+    const size_t slot_bytes = sizeof(wf_trip) * (size_t)(WF_XCAP + 1);
+    int32_t rc;
+    for (int round = 0;; ++round) {
+        wf_trip* myslot = s->xbuf + (size_t)rank * (WF_XCAP + 1);
+        hipLaunchKernelGGL(k_wf_pack, dim3((WF_XCAP + 255) / 256), dim3(256), 0, st, s->mytrips, round, myslot, s->ctr);
+        if ((rc = mpfmt_comm_allgather_inplace(ctx, s->xbuf, slot_bytes, st))) return rc;
+        hipLaunchKernelGGL(k_wf_commit, dim3(64), dim3(256), 0, st, s->xbuf, world, round, s->C, s->A, (unsigned long long*)s->W,
+                           (unsigned long long*)s->Hn, s->ctr);
+        HIPCHK(ctx, hipMemcpy2DAsync(s->hdr_host, sizeof(wf_trip), s->xbuf, slot_bytes, sizeof(wf_trip), (size_t)world, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        int64_t mx = 0;
+        for (int g = 0; g < world; ++g) mx = std::max<int64_t>(mx, s->hdr_host[g].x);
+        if (mx <= (int64_t)(round + 1) * WF_XCAP) break;
+    }
+    return MPFMT_OK;
+}
+
+static int32_t wf_read_ctr(mpfmt_ctx* ctx, mpfmt_wf* s)
+{
+    HIPCHK(ctx, hipMemcpyAsync(s->ctr_host, s->ctr, sizeof(wf_ctr), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MPFMT_OK;
+}
+
+static bool wf_ended(const mpfmt_wf* s) { return s->ctr_host->done != 0 || s->ctr_host->goal_cbits != ~0ull; }
+
+static void wf_fill_info(const mpfmt_wf* s, mpfmt_wf_info* info)
+{
+    const wf_ctr& c = *s->ctr_host;
+    const bool goal = c.goal_cbits != ~0ull;
+    info->done = goal ? 1 : c.done;
+    info->nz = c.done == 2 ? 0 : c.nz; info->nx = c.nx; info->nconn = c.nconn; info->ntrip = c.ntrip;
+    info->iters = c.iters; info->checks = c.checks; info->cmin = c.cmin;
+    // the totals on the device are brought up to date at the start of the following step
+    info->tot_z = c.tot_z + info->nz; info->tot_x = c.tot_x + c.nx; info->tot_conn = c.tot_conn + c.nconn;
+}
+
+extern "C" {
+
+int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind, const double* goal_params,
+                       double band, int32_t flags)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!goal_params) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "goal_params is NULL");
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
+    const int64_t N = ctx->N;
+    const int d = ctx->d;
+    if (N < 1) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "no samples");
+    if (init_idx < 1 || init_idx > N) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "init_idx out of range");
+    if (goal_kind < 0 || goal_kind > 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown goal kind %d", goal_kind);
+    if (!(r > 0.0) || !std::isfinite(r)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "radius must be finite and > 0");
+    if (!(band >= 0.0) || !std::isfinite(band)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "band must be finite and >= 0");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if (!ctx->wf) ctx->wf = new mpfmt_wf();
+    mpfmt_wf* s = wf_of(ctx);
+    s->active = false;
+    s->t_begin = std::chrono::steady_clock::now();
+    int rank = 0, world = 1;
+    mpfmt_comm_world(ctx, &rank, &world);
+    s->sharded = world > 1 || ctx->wf_force_sharded;
+    if ((rc = wf_alloc(ctx, s, N, s->sharded ? std::max(world, 2) : 1))) return rc;
+    s->band = band; s->single = (flags & MPFMT_WF_SINGLE) ? 1 : 0; s->checkpts = checkpts ? 1 : 0;
+    s->init = init_idx - 1; s->r = r;
+    s->goal.kind = goal_kind; s->goal.gd = d;
+    const int ng = goal_kind == MPFMT_GOAL_RECT ? 2 * d : goal_kind == MPFMT_GOAL_BALL ? d + 1 : d;
+    memset(s->goal.g, 0, sizeof s->goal.g);
+    for (int i = 0; i < ng; ++i) s->goal.g[i] = goal_params[i];
+    s->nparts = (int)std::min<int64_t>(WF_MAXPARTS, (s->words + 63) / 64);
+    if (s->nparts < 1) s->nparts = 1;
+
+    // checkpts bitmap F (fmt.jl:31-36); also answers is_free_state(init) (fmt.jl:24-29)
+    auto t0 = std::chrono::steady_clock::now();
+    if ((rc = mpfmt_launch_points_free(ctx, nullptr, N, s->F))) return rc;
+    uint64_t fw = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&fw, s->F + (s->init >> 6), 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!((fw >> (s->init & 63)) & 1ull)) return mpfmt_fail(ctx, MPFMT_ERR_INFEASIBLE, "initial state is infeasible");
+    auto t1 = std::chrono::steady_clock::now();
+    // r-disc graph (reused when one of this radius is resident); the edge tests stay lazy unless the checker has no
+    // lane-per-obstacle form here (2-D SAT world, non-identity workspace) or the caller asks for the eager mask
+    if (!(ctx->graph_filled && ctx->graph_r == r) && (rc = mpfmt_graph_build_device(ctx, r, nullptr))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    auto t2 = std::chrono::steady_clock::now();
+    const bool lazy_ok = ctx->cc_kind == 0 && ctx->dw == d;
+    s->use_mask = ((flags & MPFMT_WF_EAGER) || !lazy_ok) ? 1 : 0;
+    if (s->use_mask && !ctx->graph_swept) {
+        if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    auto t3 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    s->ms_graph = ms(t1, t2); s->ms_sweep = ms(t0, t1) + ms(t2, t3);
+    hipLaunchKernelGGL(k_wf_init, dim3(256), dim3(64), 0, ctx->stream, N, s->words, s->init, s->W, s->H, s->Z, s->Hn, s->cand, s->C, s->A, s->ctr);
+    HIPCHK(ctx, hipGetLastError());
+    s->active = true;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_wf_step(mpfmt_ctx* ctx, mpfmt_wf_info* info)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    mpfmt_wf* s = wf_of(ctx);
+    if (!s || !s->active) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no wavefront solve in progress (mpfmt_wf_begin)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = wf_enqueue_local(ctx, s))) return rc;
+    if (s->sharded && ctx->comm && (rc = wf_exchange(ctx, s))) return rc;
+    if ((rc = wf_read_ctr(ctx, s))) return rc;
+    if (info) wf_fill_info(s, info);
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_wf_state(mpfmt_ctx* ctx, uint64_t* W, uint64_t* H, double* C, int64_t* A)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    mpfmt_wf* s = wf_of(ctx);
+    if (!s || !s->active) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no wavefront solve in progress (mpfmt_wf_begin)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t N = s->N, words = s->words;
+    if (W) HIPCHK(ctx, hipMemcpy(W, s->W, 8 * words, hipMemcpyDeviceToHost));
+    if (H) {   // the open set as the NEXT step will see it: H = (H \ Z) + Hnew is applied at the start of a step
+        std::vector<uint64_t> h(words), z(words), hn(words);
+        HIPCHK(ctx, hipMemcpy(h.data(), s->H, 8 * words, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(z.data(), s->Z, 8 * words, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(hn.data(), s->Hn, 8 * words, hipMemcpyDeviceToHost));
+        for (int64_t w = 0; w < words; ++w) H[w] = (h[w] & ~z[w]) | hn[w];
+    }
+    if (C) HIPCHK(ctx, hipMemcpy(C, s->C, 8 * N, hipMemcpyDeviceToHost));
+    if (A) {
+        void* scr;
+        int32_t rc;
+        if ((rc = mpfmt_scratch(ctx, 8 * (size_t)N, &scr))) return rc;
+        hipLaunchKernelGGL(k_wf_A_to_i64, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, s->A, N, (int64_t*)scr);
+        HIPCHK(ctx, hipMemcpyAsync(A, scr, 8 * N, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_wf_batch(mpfmt_ctx* ctx, int64_t* zs, int64_t cap, int64_t* nz)
+{
+    if (!ctx || !nz) return MPFMT_ERR_ARG;
+    mpfmt_wf* s = wf_of(ctx);
+    if (!s || !s->active) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no wavefront solve in progress (mpfmt_wf_begin)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = wf_read_ctr(ctx, s))) return rc;
+    const int64_t n = s->ctr_host->done == 2 ? 0 : s->ctr_host->nz;
+    *nz = n;
+    if (n > cap) return mpfmt_fail(ctx, MPFMT_ERR_CAPACITY, "batch of %lld exceeds capacity %lld", (long long)n, (long long)cap);
+    if (n > 0) {
+        if (!zs) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "zs is NULL");
+        void* scr;
+        if ((rc = mpfmt_scratch(ctx, 8 * (size_t)n, &scr))) return rc;
+        hipLaunchKernelGGL(k_wf_zs_to_i64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, s->zlist, n, (int64_t*)scr);
+        HIPCHK(ctx, hipMemcpyAsync(zs, scr, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MPFMT_OK;
+}
+
+// manual exchange for a sharded ctx without a communicator (one host thread driving G ctxs; the tests): read this rank's
+// connections of the step just made, then hand every rank's connections to every ctx with mpfmt_wf_commit
+int32_t mpfmt_wf_triples(mpfmt_ctx* ctx, int64_t cap, int64_t* x, int64_t* y, double* c, int64_t* n)
+{
+    if (!ctx || !n) return MPFMT_ERR_ARG;
+    mpfmt_wf* s = wf_of(ctx);
+    if (!s || !s->active || !s->sharded) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no sharded wavefront solve in progress");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = wf_read_ctr(ctx, s))) return rc;
+    const int64_t cnt = wf_ended(s) ? 0 : s->ctr_host->ntrip;
+    *n = cnt;
+    if (cnt > cap) return mpfmt_fail(ctx, MPFMT_ERR_CAPACITY, "%lld triples exceed capacity %lld", (long long)cnt, (long long)cap);
+    if (cnt > 0) {
+        if (!x || !y || !c) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "x / y / c is NULL");
+        std::vector<wf_trip> t((size_t)cnt);
+        HIPCHK(ctx, hipMemcpy(t.data(), s->mytrips, sizeof(wf_trip) * (size_t)cnt, hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < cnt; ++k) { x[k] = (int64_t)t[k].x + 1; y[k] = (int64_t)t[k].y + 1; c[k] = t[k].c; }
+    }
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_wf_commit(mpfmt_ctx* ctx, int64_t n, const int64_t* x, const int64_t* y, const double* c)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    mpfmt_wf* s = wf_of(ctx);
+    if (!s || !s->active || !s->sharded) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no sharded wavefront solve in progress");
+    if (n < 0 || n > s->N) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "n out of range");
+    if (n == 0) return MPFMT_OK;
+    if (!x || !y || !c) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "x / y / c is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<wf_trip> t((size_t)WF_XCAP + 1);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t o = 0; o < n; o += WF_XCAP) {
+        const int64_t m = std::min<int64_t>(WF_XCAP, n - o);
+        t[0].x = (int32_t)m; t[0].y = 0; t[0].c = 0.0;
+        for (int64_t k = 0; k < m; ++k) {
+            if (x[o + k] < 1 || x[o + k] > s->N || y[o + k] < 1 || y[o + k] > s->N) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "triple %lld out of range", (long long)(o + k));
+            t[k + 1].x = (int32_t)(x[o + k] - 1); t[k + 1].y = (int32_t)(y[o + k] - 1); t[k + 1].c = c[o + k];
+        }
+        HIPCHK(ctx, hipMemcpy(s->xbuf, t.data(), sizeof(wf_trip) * (size_t)(m + 1), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_wf_commit, dim3(64), dim3(256), 0, ctx->stream, s->xbuf, 1, 0, s->C, s->A, (unsigned long long*)s->W,
+                           (unsigned long long*)s->Hn, s->ctr);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_wf_finish(mpfmt_ctx* ctx, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
+{
+    if (!ctx || !res) return MPFMT_ERR_ARG;
+    mpfmt_wf* s = wf_of(ctx);
+    if (!s || !s->active) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no wavefront solve in progress (mpfmt_wf_begin)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t N = s->N;
+    int32_t rc;
+    hipLaunchKernelGGL(k_wf_final, dim3(1), dim3(64), 0, ctx->stream, s->zlist, s->C, ctx->Xo, ctx->d, s->goal, s->ctr);
+    hipLaunchKernelGGL(k_wf_path, dim3(1), dim3(1), 0, ctx->stream, s->A, N, s->ctr, s->path_dev);
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = wf_read_ctr(ctx, s))) return rc;
+    const wf_ctr& c = *s->ctr_host;
+    int64_t plen = 0;
+    HIPCHK(ctx, hipMemcpy(&plen, s->path_dev + N, 8, hipMemcpyDeviceToHost));
+    if (path) HIPCHK(ctx, hipMemcpy(path, s->path_dev, 8 * plen, hipMemcpyDeviceToHost));
+    double cz = 0.0;
+    HIPCHK(ctx, hipMemcpy(&cz, s->C + c.final_z, 8, hipMemcpyDeviceToHost));
+    if (A || C) { if ((rc = mpfmt_wf_state(ctx, nullptr, nullptr, C, A))) return rc; }
+    memset(res, 0, sizeof *res);
+    res->status = c.done == 1 ? 1 : 0;
+    res->cost = cz;
+    res->z = c.final_z + 1;
+    res->collision_checks = c.checks;
+    if (s->sharded && ctx->comm) {          // every rank counted the checks of its own samples; the headers of the last exchange hold all counts
+        int rank = 0, world = 1;
+        mpfmt_comm_world(ctx, &rank, &world);
+        int64_t tot = 0;
+        for (int g = 0; g < world; ++g) tot += (int64_t)s->hdr_host[g].c;
+        res->collision_checks = tot;
+    }
+    res->path_len = plen;
+    res->nnz = ctx->nnz;
+    res->ms_graph = s->ms_graph; res->ms_sweep = s->ms_sweep;
+    res->ms_host_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s->t_begin).count() - s->ms_graph - s->ms_sweep;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_fmtstar_wavefront(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind, const double* goal_params,
+                                double band, int32_t flags, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res, mpfmt_wf_info* info)
+{
+    if (!ctx || !res) return MPFMT_ERR_ARG;
+    int32_t rc;
+    if ((rc = mpfmt_wf_begin(ctx, r, init_idx, checkpts, goal_kind, goal_params, band, flags))) return rc;
+    mpfmt_wf* s = wf_of(ctx);
+    if (s->sharded && !ctx->comm) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "a sharded wavefront solve needs a communicator (mpfmt_comm_create), or the manual mpfmt_wf_step / _triples / _commit loop");
+    // steps are enqueued in groups; the end condition voids the kernels issued after it, the host looks once per group
+    // (sharded: the exchange looks at the slot headers every step anyway)
+    const int group = s->sharded ? 1 : (s->single ? 16 : 4);
+    const int64_t max_steps = 4 * s->N + 64;
+    for (int64_t it = 0; it < max_steps; it += group) {
+        for (int g = 0; g < group; ++g) {
+            if ((rc = wf_enqueue_local(ctx, s))) return rc;
+            if (s->sharded && (rc = wf_exchange(ctx, s))) return rc;
+        }
+        if ((rc = wf_read_ctr(ctx, s))) return rc;
+        if (wf_ended(s)) break;
+    }
+    if (!wf_ended(s)) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "wavefront solve did not terminate");
+    if ((rc = mpfmt_wf_finish(ctx, A, C, path, res))) return rc;
+    if (info) wf_fill_info(s, info);
+    return MPFMT_OK;
+}
+
+}  // extern "C"

@@ -187,6 +187,8 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
                     ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->pool_flag, ctx->pool, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev};
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
+    mpfmt_comm_destroy(ctx);
+    mpfmt_wf_free(ctx);
     if (ctx->aux) { mpfmt_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
     for (void* b : bufs) if (b) hipFree(b);
     timer_resolve(ctx);
@@ -1375,6 +1377,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }
     if (strcmp(name, "mf_target_items") == 0) { ctx->mf_target_items = value; return MPFMT_OK; }
     if (strcmp(name, "timing") == 0) { ctx->timing_enabled = value != 0; return MPFMT_OK; }
+    if (strcmp(name, "wf_force_sharded") == 0) { ctx->wf_force_sharded = value != 0; return MPFMT_OK; }
     return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown option %s", name);
 }
 

@@ -1,0 +1,298 @@
+// Multi-GPU exchange behind the C ABI: RCCL over xGMI, called directly -- no Python in the data path.
+//
+// One communicator per ctx (= per GPU).  Two ways to drive it:
+//   - one process per GPU (bench.py under torch.distributed.run): every rank calls mpfmt_comm_create with the same
+//     128-byte id (rank 0 obtains it from mpfmt_comm_unique_id and the host distributes it);
+//   - ONE host thread driving G ctxs (the single-threaded Julia reference, src/problems.jl:12-30 holding G handles):
+//     the same calls bracketed by mpfmt_group_begin / mpfmt_group_end (ncclGroupStart / ncclGroupEnd), and the split
+//     launch / finish forms so that no call blocks on a peer that the same thread has yet to launch.
+// The collectives run on a communication stream of their own, ordered after the compute stream by an event, so the
+// mask gather of step k overlaps the index build of step k+1.
+//
+// RCCL is resolved at run time (dlopen of librccl.so.1: the copy torch has already mapped when there is one, the ROCm
+// one otherwise), so single-GPU users of libmpfmt.so do not need it.
+#include "mpfmt_internal.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <cstring>
+#include <algorithm>
+#include <mutex>
+
+namespace {
+
+struct rccl_api {
+    void* dl = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+rccl_api g_rccl;
+std::once_flag g_rccl_once;
+
+void rccl_load()
+{
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        g_rccl.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.dl) break;
+    }
+    if (!g_rccl.dl) { g_rccl.err = std::string("cannot load RCCL: ") + dlerror(); return; }
+#define SYM(field, name)                                                                   \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(g_rccl.dl, name);                          \
+    if (!g_rccl.field) { g_rccl.err = std::string("RCCL lacks ") + name; return; }
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllGather, "ncclAllGather")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+}
+
+int32_t rccl_ready(mpfmt_ctx* ctx)
+{
+    std::call_once(g_rccl_once, rccl_load);
+    if (!g_rccl.err.empty()) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "%s", g_rccl.err.c_str());
+    return MPFMT_OK;
+}
+
+#define NCCLCHK(ctx, call)                                                                                  \
+    do {                                                                                                    \
+        ncclResult_t r_ = (call);                                                                           \
+        if (r_ != ncclSuccess)                                                                              \
+            return mpfmt_fail((ctx), MPFMT_ERR_HIP, "%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(r_), \
+                              __FILE__, __LINE__);                                                          \
+    } while (0)
+
+}  // namespace
+
+struct mpfmt_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t stream = nullptr;            // communication stream
+    hipEvent_t ev_compute = nullptr;         // compute stream -> communication stream
+    hipEvent_t ev_done = nullptr;            // communication stream -> host / compute stream
+    // free-mask gather: [world][2 + cap] words; slot g = (mask words of rank g, nnz of rank g, mask...)
+    uint64_t* gbuf = nullptr;
+    int64_t gbuf_words = 0;
+    int64_t cap = -1;                        // mask words per rank agreed for the NEXT exchange (-1: not agreed yet)
+    int64_t slot_last = 0;                   // words per rank slot (2 header words + capacity) of the last exchange
+    int64_t* hdr_host = nullptr;             // pinned [world][2]
+    int64_t* hdr_dev = nullptr;              // [world][2] staging of the first (lengths only) exchange
+    bool pending = false;
+    int64_t my_words = 0, my_nnz = 0;
+    // generic all-gather staging (wavefront triples): [world][slot]
+    void* abuf = nullptr;
+    size_t abuf_bytes = 0;
+};
+
+static int32_t comm_of(mpfmt_ctx* ctx, mpfmt_comm** out)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->comm) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no communicator (mpfmt_comm_create)");
+    *out = (mpfmt_comm*)ctx->comm;
+    return MPFMT_OK;
+}
+
+__global__ void k_pack_mask(const uint64_t* __restrict__ mask, int64_t words, int64_t nnz, int64_t cap, uint64_t* __restrict__ slot)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { slot[0] = (uint64_t)words; slot[1] = (uint64_t)nnz; }
+    if (i < cap) slot[2 + i] = (i < words) ? mask[i] : 0ull;      // zero padded, as the interface promises; words > cap: the
+                                                                  // header carries the true length and _finish repeats
+}
+
+// all-gather of `bytes` per rank from the communicator's staging buffer; send data must already be in slot `rank`
+int32_t mpfmt_comm_allgather_inplace(mpfmt_ctx* ctx, void* buf, size_t bytes_per_rank, hipStream_t stream)
+{
+    mpfmt_comm* c;
+    int32_t rc;
+    if ((rc = comm_of(ctx, &c))) return rc;
+    NCCLCHK(ctx, g_rccl.AllGather((const char*)buf + (size_t)c->rank * bytes_per_rank, buf, bytes_per_rank, ncclChar, c->comm, stream));
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_comm_world(const mpfmt_ctx* ctx, int* rank, int* world)
+{
+    if (ctx->comm) { const mpfmt_comm* c = (const mpfmt_comm*)ctx->comm; *rank = c->rank; *world = c->world; return 1; }
+    *rank = ctx->rank; *world = ctx->world;
+    return 0;
+}
+
+extern "C" {
+
+int32_t mpfmt_comm_unique_id(uint8_t* id128)
+{
+    if (!id128) return MPFMT_ERR_ARG;
+    int32_t rc;
+    if ((rc = rccl_ready(nullptr))) return rc;
+    static_assert(sizeof(ncclUniqueId) == MPFMT_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    NCCLCHK(nullptr, g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_group_begin(void)
+{
+    int32_t rc;
+    if ((rc = rccl_ready(nullptr))) return rc;
+    NCCLCHK(nullptr, g_rccl.GroupStart());
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_group_end(void)
+{
+    int32_t rc;
+    if ((rc = rccl_ready(nullptr))) return rc;
+    NCCLCHK(nullptr, g_rccl.GroupEnd());
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_comm_create(mpfmt_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id128)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!id128) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "id128 is NULL");
+    if (world < 1 || rank < 0 || rank >= world) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "bad rank %d of %d", rank, world);
+    if (ctx->comm) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "ctx already has a communicator");
+    int32_t rc;
+    if ((rc = rccl_ready(ctx))) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    mpfmt_comm* c = new mpfmt_comm();
+    c->rank = rank; c->world = world;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return mpfmt_fail(ctx, MPFMT_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_compute, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->hdr_host, sizeof(int64_t) * 2 * (size_t)world);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->hdr_dev, sizeof(int64_t) * 2 * (size_t)world);
+    if (e != hipSuccess) {
+        ctx->comm = c;
+        mpfmt_comm_destroy(ctx);
+        return mpfmt_fail(ctx, MPFMT_ERR_HIP, "communicator resources: %s", hipGetErrorString(e));
+    }
+    ctx->comm = c;
+    return mpfmt_set_shard(ctx, rank, world);
+}
+
+int32_t mpfmt_comm_destroy(mpfmt_ctx* ctx)
+{
+    if (!ctx || !ctx->comm) return MPFMT_OK;
+    mpfmt_comm* c = (mpfmt_comm*)ctx->comm;
+    hipSetDevice(ctx->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->gbuf) hipFree(c->gbuf);
+    if (c->abuf) hipFree(c->abuf);
+    if (c->hdr_dev) hipFree(c->hdr_dev);
+    if (c->hdr_host) hipHostFree(c->hdr_host);
+    if (c->ev_compute) hipEventDestroy(c->ev_compute);
+    if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    ctx->comm = nullptr;
+    return MPFMT_OK;
+}
+
+// Capacity agreement: every rank must use the same per-rank word count.  cap_hint > 0: the caller guarantees the value is
+// the same on every rank (a single-thread driver that has seen all shards).  cap_hint == 0: the first exchange gathers
+// the lengths alone (blocking), afterwards the lengths ride in front of the payload and every rank re-derives the same
+// capacity from what it saw.
+int32_t mpfmt_allgather_free_mask_launch(mpfmt_ctx* ctx, int64_t cap_hint)
+{
+    mpfmt_comm* c;
+    int32_t rc;
+    if ((rc = comm_of(ctx, &c))) return rc;
+    if (!ctx->graph_swept) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no swept graph (mpfmt_graph_step_device)");
+    if (c->pending) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "a mask gather is already in flight (call _finish)");
+    if (cap_hint < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "cap_hint < 0");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t words = (ctx->nnz + 63) / 64;
+    c->my_words = words; c->my_nnz = ctx->nnz;
+    if (cap_hint > 0) {
+        c->cap = cap_hint;
+    } else if (c->cap < 0) {
+        int64_t mine[2] = {words, ctx->nnz};
+        HIPCHK(ctx, hipMemcpyAsync(c->hdr_dev + 2 * c->rank, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+        NCCLCHK(ctx, g_rccl.AllGather(c->hdr_dev + 2 * c->rank, c->hdr_dev, 2, ncclInt64, c->comm, c->stream));
+        HIPCHK(ctx, hipMemcpyAsync(c->hdr_host, c->hdr_dev, sizeof(int64_t) * 2 * c->world, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(ctx, hipStreamSynchronize(c->stream));
+        int64_t mx = 0;
+        for (int g = 0; g < c->world; ++g) mx = std::max(mx, c->hdr_host[2 * g]);
+        c->cap = mx + mx / 20 + 8;
+    }
+    const int64_t slot = c->cap + 2;
+    if (c->gbuf_words < slot * c->world) {
+        if (c->gbuf) { HIPCHK(ctx, hipStreamSynchronize(c->stream)); HIPCHK(ctx, hipFree(c->gbuf)); c->gbuf = nullptr; }
+        HIPCHK(ctx, hipMalloc((void**)&c->gbuf, sizeof(uint64_t) * (size_t)(slot * c->world)));
+        c->gbuf_words = slot * c->world;
+    }
+    // pack on the compute stream (after the sweep), exchange on the communication stream
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done, 0));        // the previous gather has left the buffer
+    uint64_t* mine = c->gbuf + (size_t)c->rank * slot;
+    hipLaunchKernelGGL(k_pack_mask, dim3((unsigned)((std::max<int64_t>(c->cap, 1) + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ctx->graph_free, words, ctx->nnz, c->cap, mine);
+    HIPCHK(ctx, hipGetLastError());
+    c->slot_last = slot;
+    HIPCHK(ctx, hipEventRecord(c->ev_compute, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(c->stream, c->ev_compute, 0));
+    NCCLCHK(ctx, g_rccl.AllGather(mine, c->gbuf, (size_t)slot, ncclUint64, c->comm, c->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(c->hdr_host, 2 * sizeof(int64_t), c->gbuf, (size_t)slot * sizeof(uint64_t), 2 * sizeof(int64_t),
+                                 (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(ctx, hipEventRecord(c->ev_done, c->stream));
+    c->pending = true;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_allgather_free_mask_finish(mpfmt_ctx* ctx, void** gathered, int64_t* stride_words, int64_t* words_each, int64_t* nnz_each)
+{
+    mpfmt_comm* c;
+    int32_t rc;
+    if ((rc = comm_of(ctx, &c))) return rc;
+    if (!c->pending) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no mask gather in flight");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventSynchronize(c->ev_done));
+    c->pending = false;
+    int64_t mx = 0;
+    for (int g = 0; g < c->world; ++g) mx = std::max(mx, c->hdr_host[2 * g]);
+    if (mx > c->cap) {
+        // a shard outgrew the agreed capacity: every rank sees the same lengths, so all of them repeat at the exact size
+        c->cap = mx + mx / 20 + 8;
+        if ((rc = mpfmt_allgather_free_mask_launch(ctx, c->cap))) return rc;
+        HIPCHK(ctx, hipEventSynchronize(c->ev_done));
+        c->pending = false;
+    } else if (mx < c->cap / 2) {
+        c->cap = mx + mx / 20 + 8;            // shards shrank a lot: tighten for the next step (same decision on every rank)
+    }
+    for (int g = 0; g < c->world; ++g) {
+        if (words_each) words_each[g] = c->hdr_host[2 * g];
+        if (nnz_each) nnz_each[g] = c->hdr_host[2 * g + 1];
+    }
+    if (gathered) *gathered = c->gbuf;
+    if (stride_words) *stride_words = c->slot_last;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_allgather_free_mask(mpfmt_ctx* ctx, void** gathered, int64_t* stride_words, int64_t* words_each, int64_t* nnz_each)
+{
+    int32_t rc;
+    if ((rc = mpfmt_allgather_free_mask_launch(ctx, 0))) return rc;
+    return mpfmt_allgather_free_mask_finish(ctx, gathered, stride_words, words_each, nnz_each);
+}
+
+}  // extern "C"

@@ -168,6 +168,11 @@ struct mpfmt_ctx {
     void* timer_state = nullptr;         // HIP-event timing records of this ctx (mpfmt_capi.hip)
     bool timing_enabled = true;
     bool rebuild_index = false;          // option "rebuild_index": graph_build_device rebuilds the cell grid every call
+
+    // ---- multi-GPU exchange (mpfmt_comm.hip) and the device-resident wavefront FMT* driver (kernels_wavefront.hip) ----
+    void* comm = nullptr;                // mpfmt_comm: RCCL communicator + communication stream of this ctx
+    int32_t wf_force_sharded = 0;        // option: run the sharded form of the wavefront step (own-column marking, triples, exchange) at world = 1
+    void* wf = nullptr;                  // mpfmt_wf: W / H / C / A and the batch lists of a running wavefront solve
 };
 
 // error helpers ---------------------------------------------------------------------------------
@@ -233,6 +238,13 @@ int32_t mpfmt_di_fill(mpfmt_ctx* ctx);
 int32_t mpfmt_di_sweep(mpfmt_ctx* ctx);
 int32_t mpfmt_di_steer_launch(mpfmt_ctx* ctx, int m, const double* dX0, const double* dX1, int64_t n, double rho, double r,
                               double* dcost, double* dt);
+
+// mpfmt_comm.hip -----------------------------------------------------------------------------------
+int32_t mpfmt_comm_allgather_inplace(mpfmt_ctx* ctx, void* buf, size_t bytes_per_rank, hipStream_t stream);
+int32_t mpfmt_comm_world(const mpfmt_ctx* ctx, int* rank, int* world);      // 1 when a communicator exists
+
+// kernels_wavefront.hip -----------------------------------------------------------------------------
+void mpfmt_wf_free(mpfmt_ctx* ctx);
 
 // kernels_expand.hip ----------------------------------------------------------------------------
 int32_t mpfmt_launch_expand(mpfmt_ctx* ctx, const uint64_t* d_W, const uint64_t* d_H, const uint64_t* d_F,

@@ -707,6 +707,99 @@ int32_t orc_fmtstar_graph(const double *X, int64_t N, int32_t d, int64_t init_id
     return 0;
 }
 
+/* Wavefront (batched) form of the same loop on a prebuilt graph: the checker of libmpfmt's device-resident driver
+ * (mpfmt_fmtstar_wavefront).  Not a reference function: the reference pops one node per iteration (fmt.jl:66,85-89); this
+ * runs the loop BODY fmt.jl:70-82 for the whole batch Z = { z in H : C[z] <= min_H C + band } (or, single != 0, the one
+ * lowest (cost, index) node) against the same (W, H, C), then the deferred update fmt.jl:83-84 for the batch, and stops when a
+ * batch holds a goal node (fmt.jl:68) with z = the goal node of lowest (cost, index).  With single != 0 it is
+ * orc_fmtstar_graph step for step.  iters (may be NULL) receives the number of batches, the last (unexpanded) one included. */
+int32_t orc_fmt_wavefront_graph(const double *X, int64_t N, int32_t d, int64_t init_idx,
+                                const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                                const uint64_t *free_mask, const uint64_t *Fmask,
+                                int32_t goal_kind, const double *goal,
+                                const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi,
+                                double band, int32_t single,
+                                int64_t *A, double *C, int64_t *path, orc_fmt_result *res, int64_t *iters)
+{
+    memset(res, 0, sizeof *res);
+    res->cost = INFINITY;
+    if (!orc_is_free_state(X + (size_t)init_idx * d, d, lohi, M, ss_lo, ss_hi)) return -1;
+    uint8_t *Wm = (uint8_t *)malloc((size_t)N), *Hm = (uint8_t *)calloc((size_t)N, 1), *Zm = (uint8_t *)calloc((size_t)N, 1);
+    uint8_t *cand = (uint8_t *)calloc((size_t)N, 1);
+    memset(Wm, 1, (size_t)N);
+    for (int64_t i = 0; i < N; ++i) { A[i] = -1; C[i] = 0.0; }
+    int64_t *zs = (int64_t *)malloc(sizeof(int64_t) * (size_t)N), *zprev = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    int64_t *xs = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    int64_t *cx = (int64_t *)malloc(sizeof(int64_t) * (size_t)N), *cy = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    double *cc = (double *)malloc(sizeof(double) * (size_t)N);
+    int64_t *rev = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    Wm[init_idx] = 0; Hm[init_idx] = 1;
+    int64_t count = 0, z_final = init_idx, nprev = 0, it = 0;
+    int32_t status = 0;
+    for (;;) {
+        /* lowest (cost, index) open node */
+        int64_t im = -1; double cm = 0.0;
+        for (int64_t i = 0; i < N; ++i) if (Hm[i] && (im < 0 || C[i] < cm)) { cm = C[i]; im = i; }
+        if (im < 0) {                                     /* fmt.jl:85-89 break: z stays at the last dequeued node */
+            int64_t bi = -1; double bc = 0.0;
+            for (int64_t k = 0; k < nprev; ++k) { int64_t i = zprev[k]; if (bi < 0 || C[i] > bc || (C[i] == bc && i > bi)) { bc = C[i]; bi = i; } }
+            if (bi >= 0) z_final = bi;
+            break;
+        }
+        ++it;
+        int64_t nz = 0;
+        const double thr = cm + band;
+        for (int64_t i = 0; i < N; ++i) if (Hm[i] && (single ? i == im : C[i] <= thr)) { zs[nz++] = i; Zm[i] = 1; }
+        /* fmt.jl:68 on the batch */
+        int64_t gi = -1; double gc = 0.0;
+        for (int64_t k = 0; k < nz; ++k) {
+            int64_t i = zs[k];
+            if (orc_is_goal_pt(X + (size_t)i * d, d, goal_kind, goal) && (gi < 0 || C[i] < gc)) { gc = C[i]; gi = i; }
+        }
+        if (gi >= 0) { z_final = gi; status = 1; break; }
+        /* fmt.jl:70-71: x unvisited, valid, adjacent to the batch */
+        int64_t nx = 0;
+        for (int64_t k = 0; k < nz; ++k)
+            for (int64_t a = colptr[zs[k]]; a < colptr[zs[k] + 1]; ++a) {
+                int64_t x = rowval[a];
+                if (!Wm[x] || cand[x]) continue;
+                if (Fmask && !get_bit(Fmask, x)) continue;
+                cand[x] = 1; xs[nx++] = x;
+            }
+        /* fmt.jl:72-80 against the same (W, H, C) for every x */
+        int64_t nconn = 0;
+        for (int64_t q = 0; q < nx; ++q) {
+            int64_t x = xs[q];
+            cand[x] = 0;
+            int64_t y_min = -1, e_min = -1; double c_min = 0.0;
+            for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {
+                int64_t y = rowval[b];
+                if (!Hm[y]) continue;
+                double c = C[y] + nzval[b];
+                if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
+            }
+            if (y_min < 0) continue;
+            if (orc_in_state_space(X + (size_t)y_min * d, ss_lo, ss_hi, d)) ++count;
+            int fr = free_mask ? get_bit(free_mask, e_min)
+                               : orc_is_free_motion(X + (size_t)y_min * d, X + (size_t)x * d, d, lohi, M, ss_lo, ss_hi);
+            if (fr) { cx[nconn] = x; cy[nconn] = y_min; cc[nconn] = c_min; ++nconn; }
+        }
+        for (int64_t k = 0; k < nconn; ++k) { A[cx[k]] = cy[k]; C[cx[k]] = cc[k]; Wm[cx[k]] = 0; }
+        for (int64_t k = 0; k < nz; ++k) { Hm[zs[k]] = 0; Zm[zs[k]] = 0; zprev[k] = zs[k]; }      /* fmt.jl:84 */
+        nprev = nz;
+        for (int64_t k = 0; k < nconn; ++k) Hm[cx[k]] = 1;                                          /* fmt.jl:83 */
+    }
+    int64_t len = 0, cur = z_final;
+    rev[len++] = cur;
+    while (cur != 0) { cur = A[cur]; if (cur < 0) break; rev[len++] = cur; }
+    for (int64_t i = 0; i < len; ++i) path[i] = rev[len - 1 - i];
+    res->status = status;
+    res->cost = C[z_final]; res->z = z_final; res->collision_checks = count; res->path_len = len; res->nn_queries = 0;
+    if (iters) *iters = it;
+    free(Wm); free(Hm); free(Zm); free(cand); free(zs); free(zprev); free(xs); free(cx); free(cy); free(cc); free(rev);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* a9: double-integrator LQ steer  (src/statespaces/linearquadratic.jl).      */
 /* The reference generates cost/dcost/ddcost/x closures with SymPy at load    */

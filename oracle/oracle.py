@@ -260,6 +260,24 @@ def fmtstar_graph(X, colptr, rowval, nzval, free_mask, Fmask, goal_kind, goal, l
                 collision_checks=int(res.collision_checks), A=A, C=Cc, path=path[:res.path_len].copy())
 
 
+def fmt_wavefront_graph(X, colptr, rowval, nzval, free_mask, Fmask, goal_kind, goal, lohi, ss_lo=None, ss_hi=None, init_idx=0,
+                        band=0.0, single=False):
+    """The batched (wavefront) form of the loop on a prebuilt graph: checker of mpfmt_fmtstar_wavefront."""
+    X, N, d = _X(X); lohi, M = _boxes(lohi, d); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi); goal = _vec(goal)
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64); rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+    nzval = _vec(nzval)
+    free_mask = None if free_mask is None else np.ascontiguousarray(free_mask, dtype=np.uint64)
+    Fmask = None if Fmask is None else np.ascontiguousarray(Fmask, dtype=np.uint64)
+    A = np.empty(N, dtype=np.int64); Cc = np.empty(N, dtype=np.float64); path = np.empty(N, dtype=np.int64)
+    res = FmtResult(); iters = C.c_int64()
+    rc = lib().orc_fmt_wavefront_graph(_d(X), C.c_int64(N), C.c_int32(d), C.c_int64(init_idx), _i(colptr), _i(rowval), _d(nzval),
+                                       _u(free_mask), _u(Fmask), C.c_int32(goal_kind), _d(goal), _d(lohi), C.c_int32(M),
+                                       _d(ss_lo), _d(ss_hi), C.c_double(band), C.c_int32(int(single)), _i(A), _d(Cc), _i(path),
+                                       C.byref(res), C.byref(iters))
+    return dict(rc=rc, status=int(res.status), cost=float(res.cost), z=int(res.z), iters=int(iters.value),
+                collision_checks=int(res.collision_checks), A=A, C=Cc, path=path[:res.path_len].copy())
+
+
 def fmt_radius(rm, d, vol, N):
     return lib().orc_fmt_radius(C.c_double(rm), C.c_int32(d), C.c_double(vol), C.c_int64(N))
 

@@ -84,10 +84,20 @@ def is_free_state(v, boxes, ss_lo, ss_hi):
     return in_state_space(v, ss_lo, ss_hi) and is_free_state_boxes(v, boxes)
 
 
-# src/statespaces.jl:153-158 with collision_waypoints = (v, w) (geometric.jl:20)
-def is_free_motion(v, w, boxes, ss_lo, ss_hi):
+# src/collisioncheckers/boxesND.jl:26: is_free_motion(v, w, CC::PointRobotNDBoxes) = (CC.count += 1; is_free_motion(v, w, CC.boxes))
+# CC = a dict holding `boxes` and the mutable `count` of boxesND.jl:15-23
+def is_free_motion_cc(v, w, CC):
+    CC["count"] += 1
+    return is_free_motion_boxes(v, w, CC["boxes"])
+
+
+# src/statespaces.jl:153-158 with collision_waypoints = (v, w) (geometric.jl:20).  The checker -- and with it the count
+# increment of boxesND.jl:26 -- is only reached when in_state_space(wps[i]) held (&& short circuit, :155-156).
+def is_free_motion(v, w, boxes, ss_lo, ss_hi, CC=None):
     wps = (v, w)
-    return jl_all(in_state_space(wps[i], ss_lo, ss_hi) and is_free_motion_boxes(wps[i], wps[i + 1], boxes)
+    if CC is None:
+        CC = {"boxes": boxes, "count": 0}
+    return jl_all(in_state_space(wps[i], ss_lo, ss_hi) and is_free_motion_cc(wps[i], wps[i + 1], CC)
                   for i in range(len(wps) - 1))
 
 
@@ -135,7 +145,7 @@ def is_goal_ball(v, center, radius):
 # V: list of points, V[0] is sample 1 (= init).  is_goal: predicate on a point.
 def fmtstar(V, r, is_goal, boxes, ss_lo, ss_hi, checkpts=True, init_idx=1):
     N = len(V)
-    count = 0
+    CC = {"boxes": boxes, "count": 0}           # P.CC.count = 0, fmt.jl:12
     if not is_free_state(V[init_idx - 1], boxes, ss_lo, ss_hi):
         return None
     F = {i: True for i in range(1, N + 1)}
@@ -168,8 +178,7 @@ def fmtstar(V, r, is_goal, boxes, ss_lo, ss_hi, checkpts=True, init_idx=1):
             c_min = min(costs)
             y_idx = costs.index(c_min)          # findmin: first minimal element
             y_min = inds[y_idx]
-            count += 1
-            if is_free_motion(V[y_min - 1], V[x - 1], boxes, ss_lo, ss_hi):
+            if is_free_motion(V[y_min - 1], V[x - 1], boxes, ss_lo, ss_hi, CC):      # counts inside the checker (boxesND.jl:26)
                 A[x] = y_min
                 Cc[x] = c_min
                 heapq.heappush(heap, (c_min, x))
@@ -187,7 +196,7 @@ def fmtstar(V, r, is_goal, boxes, ss_lo, ss_hi, checkpts=True, init_idx=1):
         sol.insert(0, A[sol[0]])
         if sol[0] == 0:
             break
-    return dict(status=is_goal(V[z - 1]), cost=Cc[z], z=z, collision_checks=count,
+    return dict(status=is_goal(V[z - 1]), cost=Cc[z], z=z, collision_checks=CC["count"],
                 A=[A[i] for i in range(1, N + 1)], C=[Cc[i] for i in range(1, N + 1)], path=sol)
 
 

@@ -1,0 +1,211 @@
+"""GPU parity tests (-m gpu) of the path bench.py actually times (mpfmt_graph_step_device: speculative sizes, k_spec_check,
+redo path) against the ORACLE, of the fp16 MFMA filter's no-false-negative claim on adversarial inputs, of the
+out-of-bounds-parent counting rule, and of BASELINE.json configs[2] / configs[3] at full size.
+"""
+import numpy as np
+import pytest
+
+import motionplanning_jl_amd as mp
+from test_gpu_parity import _resident_graph, random_world, graphs_both_paths, to0
+
+pytestmark = pytest.mark.gpu
+L = mp._lib
+
+
+# ---- (a) the timed path against the oracle ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_graph_step_device_against_oracle(orc, world):
+    """Resident CSC + free mask of mpfmt_graph_step_device vs the oracle's graph and edge predicate: the first (careful)
+    call, two speculative repeats, new samples under the same (N, r), a capacity-busting cluster (device flag voids the
+    kernels, host redoes the step) and the way back (capacities far too large)."""
+    rng = np.random.default_rng(777)
+    N, d, M = 12000, 4, 30
+    X, lohi = random_world(rng, N, d, M, 0.03, 0.1)
+    r = 0.12
+    lo, hi = np.full(d, 0.01), np.full(d, 0.99)
+    Xs = [X, X, X, rng.random((N, d)), 0.5 + 0.05 * rng.standard_normal((N, d)), rng.random((N, d))]
+    refs = []
+    for Xi in Xs:
+        if refs and Xi is Xs[0]:
+            refs.append(refs[0]); continue
+        oc, orow, oval = orc.rdisc_graph(Xi, r)
+        refs.append((oc, orow, oval, orc.graph_edges_free(Xi, oc, orow, lohi, lo, hi)))
+    for g in range(world):
+        with mp.Context(0) as c:
+            c.set_shard(g, world); c.set_option("rebuild_index", 1)
+            c.upload_boxes(lohi, lo, hi)
+            for it, (Xi, (oc, orow, oval, omask)) in enumerate(zip(Xs, refs)):
+                c.upload_samples(Xi)
+                nnz = c.graph_step_device(r)
+                colptr, rowval, nzval, free = _resident_graph(c, N)
+                deg = np.diff(colptr)
+                own = np.flatnonzero(deg)
+                if world == 1:
+                    assert np.array_equal(colptr, oc) and np.array_equal(rowval, orow) and np.array_equal(nzval, oval), it
+                    assert np.array_equal(free.view(np.uint64), omask), it
+                else:
+                    odeg = np.diff(oc)
+                    assert np.array_equal(deg[own], odeg[own]), (g, it)
+                    # entries of the owned columns, in CSC order, against the oracle's same columns
+                    oidx = np.concatenate([np.arange(oc[v], oc[v + 1]) for v in own]) if len(own) else np.zeros(0, np.int64)
+                    assert np.array_equal(rowval, orow[oidx]) and np.array_equal(nzval, oval[oidx]), (g, it)
+                    assert np.array_equal(L.unpack_bits(free.view(np.uint64), nnz), orc.unpack(omask, len(orow))[oidx]), (g, it)
+                assert nnz == deg.sum()
+
+
+def test_trimmed_stress_in_suite(orc):
+    """tools/stress.py with fixed seeds and a bounded budget: random sizes / dimensions / radii / obstacle counts / shards,
+    both pair kernels, graph + costs + masks + the three-call graph_step_device sequence, all against the oracle."""
+    import importlib.util
+    import os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress.py")
+    spec = importlib.util.spec_from_file_location("mpfmt_stress", p)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    cases, edges = m.run(budget=40.0, seed=20260, maxd=12, max_cases=60)
+    assert cases >= 20 and edges > 100000
+
+
+# ---- (b) adversarial inputs for the fp16 filter ----------------------------------------------------------------------
+
+def adversarial_set(rng, N, d, r, scale=1.0, offset=0.0):
+    """Random cloud + pairs at distance exactly r, r(1 +- k ulp), r(1 +- 1e-12), r(1 +- 1e-9), duplicates, points hugging the
+    low corner of the cloud (fp16-denormal normalised coordinates), axis-aligned and diagonal displacements."""
+    X = rng.random((N, d))
+    k = 0
+    def put(p):
+        nonlocal k
+        X[k] = p; k += 1
+    for _ in range(60):
+        p = 0.2 + 0.6 * rng.random(d)
+        for eps in (0.0, 2.3e-16, -2.3e-16, 1e-15, -1e-15, 1e-12, -1e-12, 1e-9, -1e-9, 3e-5, -3e-5):
+            u = rng.standard_normal(d); u /= np.linalg.norm(u)
+            put(p); put(p + r * (1 + eps) * u)
+        ax = np.zeros(d); ax[rng.integers(0, d)] = 1.0
+        put(p); put(p + r * ax); put(p - r * ax)
+        put(p); put(p + r * np.ones(d) / np.sqrt(d))
+        put(p); put(p.copy())                                          # duplicate
+    for j in range(80):                                                 # the low corner: normalised coordinates 1e-7 .. 6e-5
+        p = rng.random(d) * 10.0 ** rng.uniform(-7, -4.2)
+        put(p)
+        u = rng.random(d); u /= np.linalg.norm(u)
+        put(p + r * (1 + (1e-12 if j & 1 else -1e-12)) * u)
+    X[k] = 0.0; k += 1                                                  # the corner itself
+    X[k] = 1.0; k += 1
+    assert k < N
+    return X * scale + offset
+
+
+@pytest.mark.parametrize("d,r", [(1, 0.004), (2, 0.05), (3, 0.12), (6, 0.45), (7, 0.55), (12, 0.95)])
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1e-3, 0.0), (1e3, 0.0), (1.0, 1000.0)])
+def test_filter_has_no_false_negatives_on_adversarial_pairs(orc, d, r, scale, offset):
+    rng = np.random.default_rng(900 + d)
+    N = 3500
+    X = adversarial_set(rng, N, d, r, scale, offset)
+    rr = r * scale
+    with mp.Context(0) as c:
+        c.upload_samples(X)
+        (colptr, rowval, nzval), ran = graphs_both_paths(c, rr)
+        assert 1 in ran
+        oc, orow, oval = orc.rdisc_graph(X, rr)
+        c0, r0 = to0(colptr, rowval)
+        assert np.array_equal(c0, oc) and np.array_equal(r0, orow)
+        assert np.array_equal(nzval, oval)
+        if d <= 12 and d >= 2:
+            assert 2 in ran, "the MFMA filter path did not run for d = %d" % d
+        # the pairs sit on the threshold: the oracle must see members on both sides of it
+        cols = np.repeat(np.arange(N), np.diff(oc))
+        assert (oval >= rr * (1 - 1e-9)).sum() > 50
+
+
+# ---- (e) out-of-bounds parents: in_state_space short circuit before the checker's count ------------------------------
+
+def test_out_of_bounds_parent_counting(orc):
+    from test_oracle import oob_parent_world
+    X, lohi, lo, hi, r, goal = oob_parent_world()
+    ref = orc.fmtstar(X, r, orc.GOAL_BALL, goal, lohi, lo, hi, checkpts=False, nn_mode=1)
+    with mp.Context(0) as c:
+        c.upload_samples(X); c.upload_boxes(lohi, lo, hi)
+        seq = c.fmtstar(r, L.GOAL_BALL, goal, checkpts=False)
+        for got in (seq, c.fmtstar_wavefront(r, L.GOAL_BALL, goal, single=True, checkpts=False),
+                    c.fmtstar_wavefront(r, L.GOAL_BALL, goal, single=True, checkpts=False, eager=True)):
+            assert got["status"] == ref["status"] and got["collision_checks"] == ref["collision_checks"]
+            assert np.array_equal(got["A"] - 1, ref["A"]) and np.array_equal(got["C"], ref["C"])
+            assert np.array_equal(got["path"] - 1, ref["path"])
+
+
+# ---- (c) BASELINE.json configs[2] and configs[3] at full size ---------------------------------------------------------
+
+def test_cfg3_r12_full_size_properties(orc):
+    """PRM*-style all-pairs r-disc graph in R^12, N = 1e6 (BASELINE.json configs[2]): column contract, symmetry checksums,
+    sampled columns against the oracle's KD-tree, sampled edge bits and the point mask against the oracle."""
+    w = mp.workloads.cfg3()
+    N = w.N
+    with mp.Context(0) as c:
+        c.upload_samples(w.X)
+        c.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+        colptr, rowval, nzval = c.rdisc_graph(w.r)
+        assert c.stat("rdisc_path_used") == 2
+        nnz = len(rowval)
+        deg = np.diff(colptr)
+        assert colptr[0] == 1 and colptr[-1] == nnz + 1 and nnz % 2 == 0 and nnz > 2e7
+        cols = np.repeat(np.arange(1, N + 1, dtype=np.int64), deg)
+        assert not np.any(rowval == cols)
+        dd = np.diff(rowval); same = cols[1:] == cols[:-1]
+        assert np.all(dd[same] > 0)
+        del dd, same
+        assert nzval.max() <= w.r * (1 + 1e-12) and nzval.min() > 0
+        k1 = cols * N + rowval; k2 = rowval * N + cols
+        assert int(k1.sum()) == int(k2.sum()) and int(np.bitwise_xor.reduce(k1)) == int(np.bitwise_xor.reduce(k2))
+        del k1, k2
+        kd = orc.KDTree(w.X)
+        rng = np.random.default_rng(5)
+        for v in rng.integers(0, N, size=150):
+            oi, od = kd.inball(int(v), w.r)
+            a, b = colptr[v] - 1, colptr[v + 1] - 1
+            assert np.array_equal(rowval[a:b] - 1, oi) and np.array_equal(nzval[a:b], od)
+        mask = L.unpack_bits(c.graph_edges_free(), nnz)
+        es = rng.integers(0, nnz, size=200000)
+        want = orc.unpack(orc.edges_free(w.X, rowval[es] - 1, cols[es] - 1, w.lohi, w.ss_lo, w.ss_hi), len(es))
+        assert np.array_equal(mask[es], want)
+        assert np.array_equal(c.points_free(), orc.points_free(w.X, w.lohi, w.ss_lo, w.ss_hi))
+
+
+def test_cfg4_double_integrator_full_size_properties(orc):
+    """Kinodynamic FMT* graph, double integrator in R^4, N = 1e5 (BASELINE.json configs[3]): 1e10 pairs through the pilot-sized
+    slot lists.  Column contract; the graph induced on a 2500-sample subset against the oracle's all-pairs steer of the
+    subset (membership, cost, optimal time); sampled 5-waypoint edge bits against the oracle."""
+    w = mp.workloads.cfg4()
+    N = w.N
+    m = w.X.shape[1] // 2
+    with mp.Context(0) as c:
+        c.upload_samples(w.X)
+        c.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+        colptr, rowval, nzval, tval = c.di_graph(w.rho, w.r)
+        nnz = len(rowval)
+        deg = np.diff(colptr)
+        assert colptr[0] == 1 and colptr[-1] == nnz + 1 and nnz > 5e7
+        cols = np.repeat(np.arange(1, N + 1, dtype=np.int64), deg)
+        assert not np.any(rowval == cols)
+        dd = np.diff(rowval); same = cols[1:] == cols[:-1]
+        assert np.all(dd[same] > 0)
+        del dd, same
+        assert nzval.max() <= w.r and nzval.min() > 0 and tval.min() > 0 and tval.max() <= w.r
+        rng = np.random.default_rng(6)
+        S = np.sort(rng.choice(N, size=2500, replace=False))
+        oc, orow, oval, otv = orc.di_pairwise(w.X[S], w.rho, w.r)
+        pos = np.full(N + 1, -1, dtype=np.int64); pos[S + 1] = np.arange(len(S))
+        insub = (pos[rowval] >= 0) & (pos[cols] >= 0)
+        gr, gc = pos[rowval[insub]], pos[cols[insub]]
+        ocol = np.repeat(np.arange(len(S)), np.diff(oc))
+        assert np.array_equal(gc, ocol) and np.array_equal(gr, orow)           # CSC order is preserved by the restriction
+        assert np.array_equal(nzval[insub], oval) and np.array_equal(tval[insub], otv)
+        mask, nseg = c.di_graph_edges_free()
+        mask = L.unpack_bits(mask, nnz)
+        es = rng.integers(0, nnz, size=3000)
+        assert nseg.max() <= 4
+        for e in es:
+            fr = orc.di_is_free_motion(w.X[rowval[e] - 1], w.X[cols[e] - 1], w.rho, w.r, w.lohi, w.ss_lo, w.ss_hi)
+            assert bool(mask[e]) == bool(fr), e
+            assert (nseg[e] == 4) or not fr                                 # a free motion has passed all 4 segment tests

@@ -80,3 +80,19 @@ def test_host_fmt_recursion_rejects_bad_arguments():
         mp._lib.host_fmt_recursion(X, cp, rv, nz, m, None, 7, [0.0, 0.0])                                     # unknown goal kind
     with pytest.raises(mp.MPFMTError):
         mp._lib.host_fmt_recursion(X, cp, rv, nz, m, None, mp._lib.GOAL_POINT, [0.0, 0.0], ss_lo=[0.0, 0.0])  # lo without hi
+
+
+def test_bench_gpus_flag_is_honoured():
+    """bench.py --gpus N must either start N ranks or fail loudly -- never run one rank and call it N.
+    Without GPUs here: the parent refuses before spawning; a launcher whose WORLD_SIZE disagrees is refused too."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "only 0 GPU" in p.stderr and p.stdout.strip() == ""
+    env2 = dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "does not match WORLD_SIZE" in p.stderr

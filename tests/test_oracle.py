@@ -417,3 +417,63 @@ def test_closest_shapes_oracle_against_transliteration():
     assert np.allclose(v, [[0.3, 0.5]], atol=1e-15) and abs(d2[0] - 0.16) < 1e-15
     d2, v, k, bad = orc.closest_shapes(np.array([[0.5, 0.0]]), orc.Shapes2D([("polygon", [(0.4, 0.2), (0.6, 0.2), (0.6, 0.4), (0.4, 0.4)])]))
     assert np.allclose(v, [[0.5, 0.2]], atol=1e-15) and abs(d2[0] - 0.04) < 1e-15
+
+
+def test_oracle_wavefront_single_is_the_sequential_loop(orc):
+    """orc_fmt_wavefront_graph with one node per batch must be orc_fmtstar_graph step for step; with a band it stays a valid
+    FMT* tree (parents are graph neighbours, costs add up) whose cost is not below the sequential one."""
+    import motionplanning_jl_amd as mp
+    for (N, d, M, seed) in [(800, 2, 20, 1), (1500, 3, 30, 2), (1200, 6, 60, 3)]:
+        w = mp.workloads.make("t", N, d, M, 0.05, 0.12, seed=seed, goal_radius=0.1)
+        colptr, rowval, nzval = orc.rdisc_graph(w.X, w.r)
+        F = orc.points_free(w.X, w.lohi, w.ss_lo, w.ss_hi)
+        args = (w.X, colptr, rowval, nzval, None, F, orc.GOAL_BALL, w.goal_params(), w.lohi, w.ss_lo, w.ss_hi)
+        seq = orc.fmtstar_graph(*args)
+        one = orc.fmt_wavefront_graph(*args, single=True)
+        for k in ("status", "cost", "z", "collision_checks"):
+            assert one[k] == seq[k], k
+        assert np.array_equal(one["A"], seq["A"]) and np.array_equal(one["C"], seq["C"]) and np.array_equal(one["path"], seq["path"])
+        emask = orc.graph_edges_free(w.X, colptr, rowval, w.lohi, w.ss_lo, w.ss_hi)
+        for bandf in (0.0, 0.3, 1.5):
+            b = orc.fmt_wavefront_graph(*args, band=bandf * w.r)
+            be = orc.fmt_wavefront_graph(w.X, colptr, rowval, nzval, emask, F, *args[6:], band=bandf * w.r)
+            assert np.array_equal(b["A"], be["A"]) and b["collision_checks"] == be["collision_checks"]    # lazy == eager mask
+            assert b["status"] == seq["status"]
+            if seq["status"] == 1:
+                assert b["cost"] >= seq["cost"] * (1 - 1e-12)
+            kids = np.flatnonzero(b["A"] >= 0)
+            par = b["A"][kids]
+            dist = np.sqrt(((w.X[kids] - w.X[par]) ** 2).sum(1))
+            assert dist.max() <= w.r and np.allclose(b["C"][kids], b["C"][par] + dist, rtol=1e-12, atol=0)
+
+
+def oob_parent_world(seed=12, N=700):
+    """Samples spill over the state-space bounds and checkpts = false lets them into the tree: an out-of-bounds sample that
+    has been connected (only the FIRST point of a segment is bounds-checked, statespaces.jl:155) later becomes the y_min of
+    a neighbour, where in_state_space(V[y_min]) fails before the checker -- and its count (boxesND.jl:26) -- is reached."""
+    rng = np.random.default_rng(seed)
+    X = rng.random((N, 2))
+    X[0] = (0.2, 0.2); X[-1] = (0.8, 0.8)
+    c = rng.random((12, 2)); h = 0.02 + 0.05 * rng.random((12, 2))
+    lohi = np.stack([c - h, c + h], axis=1)
+    keep = ~np.array([np.all((lo <= X[0]) & (X[0] <= hi)) or np.all((lo <= X[-1]) & (X[-1] <= hi)) for lo, hi in lohi])
+    return X, lohi[keep], np.full(2, 0.12), np.full(2, 0.88), 0.09, np.array([0.8, 0.8, 0.06])
+
+
+def test_out_of_bounds_parent_is_not_counted(orc):
+    import jl_transliteration as jl
+    X, lohi, lo, hi, r, goal = oob_parent_world()
+    res = orc.fmtstar(X, r, orc.GOAL_BALL, goal, lohi, lo, hi, checkpts=False, nn_mode=1)
+    ref = jl.fmtstar(X.tolist(), r, lambda v: jl.is_goal_ball(v, goal[:2].tolist(), goal[2]), [(a.tolist(), b.tolist()) for a, b in lohi],
+                     lo.tolist(), hi.tolist(), checkpts=False)
+    assert res["status"] == int(ref["status"]) and res["collision_checks"] == ref["collision_checks"]
+    assert np.array_equal(res["A"] + 1, ref["A"]) and np.array_equal(res["C"], ref["C"])
+    assert np.array_equal(res["path"] + 1, ref["path"])
+    # the case is really exercised: some connected sample lies outside the bounds, and fewer checks were counted than
+    # parents examined (every examination of an out-of-bounds parent skips the count)
+    conn = np.flatnonzero(res["A"] >= 0)
+    oob = ~np.all((lo <= X) & (X <= hi), axis=1)
+    assert oob[conn].any()
+    colptr, rowval, nzval = orc.rdisc_graph(X, r)
+    counted_all = orc.fmtstar(X, r, orc.GOAL_BALL, goal, lohi, np.full(2, -1.0), np.full(2, 2.0), checkpts=False, nn_mode=1)
+    assert counted_all["collision_checks"] != res["collision_checks"] or not np.array_equal(counted_all["A"], res["A"])
