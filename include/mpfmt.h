@@ -106,6 +106,18 @@ int32_t mpfmt_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask);
 int32_t mpfmt_states_free(mpfmt_ctx* ctx, const double* P, int64_t n, uint64_t* mask);
 int32_t mpfmt_motions_free(mpfmt_ctx* ctx, const double* P, const double* Q, int64_t n, uint64_t* mask);
 
+/* ---- Euclidean per-edge steer, src/statespaces/geometric.jl:18-19, batched over E edges src[e] -> dst[e]
+ *      (1-based sample indices):
+ *        euclid_steer     : steering_control(M::Euclidean, v, w) = StepControl(evaluate(M, v, w), normalize(w - v)):
+ *                           t[e] = |w - v| (the graph's edge cost, bit for bit), u[e][d] = unit direction = inv(|w - v|) * (w - v)
+ *                           (a zero-length edge gives t = 0 and NaN directions, as in the reference).
+ *        euclid_propagate : propagate(M::Euclidean, v, u::StepControl) = v + u.t * u.u from v = V[src[e]]; with s != NULL the
+ *                           partial form of src/statespaces.jl:79-81: s[e] <= 0 -> v, s[e] >= t[e] -> full step, else v + s[e] * u.
+ *      collision_waypoints(::Euclidean, v, w) = (v, w) (geometric.jl:20) is what mpfmt_edges_free sweeps. */
+int32_t mpfmt_euclid_steer(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double* t, double* u);
+int32_t mpfmt_euclid_propagate(mpfmt_ctx* ctx, const int64_t* src, int64_t E, const double* t, const double* u, const double* s,
+                               double* out);
+
 /* ---- batch expand: the body of the FMT* loop (src/planners/fmt.jl:70-82) for a set of z.
  *      For every unvisited (W) and valid (F, may be NULL) sample x with a forward neighbour in zs:
  *        y_min = first argmin over open (H) backward neighbours y of C[y] + d(y,x)   (fmt.jl:72-74)
@@ -297,6 +309,12 @@ int32_t mpfmt_graph_sweep_device(mpfmt_ctx* ctx);
  * Results are identical to the two-call form and complete in HBM when the call returns (graph_sweep_device, by contrast,
  * only enqueues its kernel on the ctx's stream). */
 int32_t mpfmt_graph_step_device(mpfmt_ctx* ctx, double r, int64_t* nnz);
+/* The same step in two calls, for ONE host thread that drives several ctxs (a Julia process holding one ctx per GPU, SURVEY
+ * 8e): _launch issues the step's kernels and returns without waiting when the previous step's sizes can be trusted (otherwise
+ * it runs the careful form to completion), _finish makes the one synchronisation, validates and repairs.  graph_step_device
+ * = _launch + _finish. */
+int32_t mpfmt_graph_step_launch(mpfmt_ctx* ctx, double r);
+int32_t mpfmt_graph_step_finish(mpfmt_ctx* ctx, int64_t* nnz);
 int32_t mpfmt_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** rowval, void** nzval, void** free_mask);
 /* Shard bookkeeping for the all-gather: column range (in the library's sorted order) and the number
  * of edges this shard produced. */

@@ -61,6 +61,8 @@ SYMBOLS = [
     ("mpfmt_graph_edges_free", C.c_int32, [C.c_void_p, c_u64_p]),
     ("mpfmt_states_free", C.c_int32, [C.c_void_p, c_d_p, C.c_int64, c_u64_p]),
     ("mpfmt_motions_free", C.c_int32, [C.c_void_p, c_d_p, c_d_p, C.c_int64, c_u64_p]),
+    ("mpfmt_euclid_steer", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, C.c_int64, c_d_p, c_d_p]),
+    ("mpfmt_euclid_propagate", C.c_int32, [C.c_void_p, c_i64_p, C.c_int64, c_d_p, c_d_p, c_d_p, c_d_p]),
     ("mpfmt_expand", C.c_int32, [C.c_void_p, c_u64_p, c_u64_p, c_u64_p, c_d_p, c_i64_p, C.c_int64,
                                  c_i64_p, c_i64_p, c_d_p, c_u8_p, C.c_int64, c_i64_p]),
     ("mpfmt_fmtstar", C.c_int32, [C.c_void_p, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
@@ -96,6 +98,8 @@ SYMBOLS = [
                                      c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
     ("mpfmt_graph_build_device", C.c_int32, [C.c_void_p, C.c_double, c_i64_p]),
     ("mpfmt_graph_step_device", C.c_int32, [C.c_void_p, C.c_double, c_i64_p]),
+    ("mpfmt_graph_step_launch", C.c_int32, [C.c_void_p, C.c_double]),
+    ("mpfmt_graph_step_finish", C.c_int32, [C.c_void_p, c_i64_p]),
     ("mpfmt_graph_sweep_device", C.c_int32, [C.c_void_p]),
     ("mpfmt_graph_device_ptrs", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
@@ -362,6 +366,25 @@ class Context:
         mask = np.zeros(max(nwords(n), 1), dtype=np.uint64)
         self._chk(self._L.mpfmt_motions_free(self._h, _dp(P), _dp(Q), n, _up(mask)))
         return mask[:nwords(n)]
+
+    # ---- Euclidean steer (geometric.jl:18-19) -----------------------------------------------------
+    def euclid_steer(self, src, dst):
+        """steering_control per edge: (t = |w - v|, u = unit direction) for 1-based src -> dst."""
+        src = np.ascontiguousarray(src, dtype=np.int64); dst = np.ascontiguousarray(dst, dtype=np.int64)
+        E = src.size
+        t = np.empty(max(E, 1)); u = np.empty((max(E, 1), self.d))
+        self._chk(self._L.mpfmt_euclid_steer(self._h, _ip(src), _ip(dst), E, _dp(t), _dp(u)))
+        return t[:E], u[:E]
+
+    def euclid_propagate(self, src, t, u, s=None):
+        """propagate(M, V[src], StepControl(t, u)[, s])."""
+        src = np.ascontiguousarray(src, dtype=np.int64)
+        t = np.ascontiguousarray(t, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+        s = None if s is None else np.ascontiguousarray(s, dtype=np.float64)
+        E = src.size
+        out = np.empty((max(E, 1), self.d))
+        self._chk(self._L.mpfmt_euclid_propagate(self._h, _ip(src), E, _dp(t), _dp(u), _dp(s), _dp(out)))
+        return out[:E]
 
     # ---- expand / solve ---------------------------------------------------------------------------
     def expand(self, W, H, F, Cc, zs, cap=None):
@@ -665,6 +688,15 @@ class Context:
         """graph_build_device + graph_sweep_device with one host synchronisation (see include/mpfmt.h)."""
         nnz = C.c_int64()
         self._chk(self._L.mpfmt_graph_step_device(self._h, float(r), C.byref(nnz)))
+        self.nnz = nnz.value
+        return nnz.value
+
+    def graph_step_launch(self, r):
+        self._chk(self._L.mpfmt_graph_step_launch(self._h, float(r)))
+
+    def graph_step_finish(self):
+        nnz = C.c_int64()
+        self._chk(self._L.mpfmt_graph_step_finish(self._h, C.byref(nnz)))
         self.nnz = nnz.value
         return nnz.value
 

@@ -658,7 +658,7 @@ int32_t mpfmt_car_build(mpfmt_ctx* ctx, int kind, double rt, double sp, double r
     if ((rc = mpfmt_graph_build_device(ax, r, &cnnz))) return mpfmt_fail(ctx, rc, "helper ctx: %s", mpfmt_last_error(ax));
     HIPCHK(ctx, hipStreamSynchronize(ax->stream));
     // (2) exact Dubins cost per candidate edge
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm1(ctx);
     const int64_t cw = (cnnz + 63) / 64;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->valtmp, sizeof(double) * (size_t)std::max<int64_t>(cnnz, 1)))) return rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->car_keep, sizeof(uint64_t) * (size_t)std::max<int64_t>(cw, 1)))) return rc;
@@ -687,7 +687,7 @@ int32_t mpfmt_car_build(mpfmt_ctx* ctx, int kind, double rt, double sp, double r
                            ctx->valtmp, ctx->car_keep, N, ctx->colptr, ctx->rowval, ctx->nzval);
         HIPCHK(ctx, hipGetLastError());
     }
-    mpfmt_time_end(ctx, "car_graph");
+    tm1.end("car_graph");
     ctx->nnz = nnz;
     ctx->pairs_tested = cnnz;
     ctx->car_rt = rt; ctx->car_sp = sp; ctx->di_r = r;
@@ -707,7 +707,7 @@ int32_t mpfmt_car_sweep(mpfmt_ctx* ctx)
     const int64_t nnz = ctx->nnz, words = (nnz + 63) / 64;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->graph_free, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1)))) return rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->di_nseg, (size_t)std::max<int64_t>(nnz, 1)))) return rc;
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm2(ctx);
     HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
     if (nnz > 0) {
         if (ctx->steer_kind == 3)
@@ -718,7 +718,7 @@ int32_t mpfmt_car_sweep(mpfmt_ctx* ctx)
                                ctx->rowval, nnz, ctx->car_rt, ctx->car_sp, ctx->boxes, ctx->M, ctx->ss, ctx->graph_free, ctx->di_nseg);
         HIPCHK(ctx, hipGetLastError());
     }
-    mpfmt_time_end(ctx, "car_sweep");
+    tm2.end("car_sweep");
     ctx->di_swept = true;
     return MPFMT_OK;
 }

@@ -545,13 +545,13 @@ int32_t cl_pairs(mpfmt_ctx* ctx, const cl_setup& s, const double* dP, int64_t n,
     const int64_t pairs = n * (int64_t)s.M;
     if (pairs == 0) return MPFMT_OK;
     const unsigned nb = (unsigned)((pairs + CL_THREADS - 1) / CL_THREADS);
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm1(ctx);
     if (s.shapes)
         hipLaunchKernelGGL(k_cl_pairs_shapes, dim3(nb), dim3(CL_THREADS), 0, ctx->stream, dP, n, (const mpfmt_shape2d*)s.obst, s.M, s.K, d2all);
     else
         CL_DISPATCH_D(s.d, hipLaunchKernelGGL((k_cl_pairs_boxes<DD>), dim3(nb), dim3(CL_THREADS), 0, ctx->stream, dP, n, (const double*)s.obst, s.M,
                                               make_w<DD>(s), CL_MYEPS, d2all));
-    mpfmt_time_end(ctx, "closest_pairs");
+    tm1.end("closest_pairs");
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
@@ -582,14 +582,14 @@ int32_t mpfmt_closest(mpfmt_ctx* ctx, const double* P, int64_t n, const double* 
     HIPCHK(ctx, hipMemsetAsync(dfail, 0, sizeof(unsigned long long), ctx->stream));
     if ((rc = cl_pairs(ctx, s, dP, n, d2all))) return rc;
     const unsigned nb = (unsigned)((n + CL_THREADS - 1) / CL_THREADS);
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm2(ctx);
     if (s.shapes)
         hipLaunchKernelGGL((k_cl_min<2, true>), dim3(nb), dim3(CL_THREADS), 0, ctx->stream, dP, n, s.obst, s.M, make_w<2>(s), s.K, CL_MYEPS, d2all,
                            dd2, dv, dk, dfail);
     else
         CL_DISPATCH_D(d, hipLaunchKernelGGL((k_cl_min<DD, false>), dim3(nb), dim3(CL_THREADS), 0, ctx->stream, dP, n, s.obst, s.M, make_w<DD>(s), s.K,
                                             CL_MYEPS, d2all, dd2, dv, dk, dfail));
-    mpfmt_time_end(ctx, "closest_select");
+    tm2.end("closest_select");
     HIPCHK(ctx, hipGetLastError());
     unsigned long long nf = 0;
     HIPCHK(ctx, hipMemcpyAsync(d2min, dd2, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
@@ -648,14 +648,14 @@ int32_t mpfmt_closeR(mpfmt_ctx* ctx, const double* P, int64_t n, const double* W
     HIPCHK(ctx, tmp.get(&dd2, sizeof(double) * (size_t)tot));
     HIPCHK(ctx, tmp.get(&dv, sizeof(double) * (size_t)tot * d));
     HIPCHK(ctx, hipMemcpyAsync(dptr, hp.data(), sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm3(ctx);
     if (s.shapes)
         hipLaunchKernelGGL((k_cl_fill<2, true>), dim3(nb), dim3(CL_THREADS), 0, ctx->stream, dP, n, s.obst, s.M, make_w<2>(s), s.K, CL_MYEPS, r2, d2all,
                            dptr, didx, dd2, dv);
     else
         CL_DISPATCH_D(d, hipLaunchKernelGGL((k_cl_fill<DD, false>), dim3(nb), dim3(CL_THREADS), 0, ctx->stream, dP, n, s.obst, s.M, make_w<DD>(s), s.K,
                                             CL_MYEPS, r2, d2all, dptr, didx, dd2, dv));
-    mpfmt_time_end(ctx, "closest_select");
+    tm3.end("closest_select");
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(obstacle, didx, sizeof(int64_t) * (size_t)tot, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d2, dd2, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost, ctx->stream));

@@ -494,7 +494,7 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
     a.S = S; a.ntiles = ntiles; a.slice_cnt = ctx->slice_cnt; a.colptr = ctx->colptr;
     a.rowtmp = nullptr; a.valtmp = nullptr; a.tvaltmp = nullptr; a.counters = ctx->d_pairs;
     a.tile_step = 1; a.pool_i = nullptr; a.pool_c = nullptr; a.pool_t = nullptr; a.pool_cap = 0; a.pool_flag = nullptr;
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm1(ctx);
     // Single pass: the accepted hits of the count pass are kept in slot lists, so the pairs are not steered twice.  The
     // list capacity comes from a pilot over every 32nd tile (tiles are in caller order, i.e. statistically alike); an
     // overflow, or lists beyond 64 GB, falls back to the second (fill) pass.
@@ -549,7 +549,7 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
         HIPCHK(ctx, hipGetLastError());
     }
     if ((rc = scan64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1)))) return rc;
-    mpfmt_time_end(ctx, "di_count");
+    tm1.end("di_count");
     int64_t nnz = 0;
     unsigned long long ctr[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(&nnz, ctx->colptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -588,7 +588,7 @@ int32_t mpfmt_di_fill(mpfmt_ctx* ctx)
     a.rowtmp = ctx->rowtmp; a.valtmp = ctx->valtmp; a.tvaltmp = ctx->tvaltmp; a.counters = nullptr;
     a.tile_step = 1; a.pool_i = nullptr; a.pool_c = nullptr; a.pool_t = nullptr; a.pool_cap = 0; a.pool_flag = nullptr;
     if (nnz > 0) {
-        mpfmt_time_begin(ctx);
+        mpfmt_timed tm2(ctx);
         if (ctx->di_pool_valid) {
             hipLaunchKernelGGL(k_di_gather_slots, dim3((unsigned)std::min<int64_t>(N, 1 << 20)), dim3(64), 0, ctx->stream, ctx->di_pool_i,
                                ctx->di_pool_c, ctx->di_pool_t, ctx->di_pool_cap, a.S, ctx->slice_cnt, ntiles * 64, N, ctx->colptr,
@@ -601,7 +601,7 @@ int32_t mpfmt_di_fill(mpfmt_ctx* ctx)
                            ctx->tvaltmp, ctx->rowval, ctx->nzval, ctx->tval,
                            N > DI_SORT_BUCKETS ? (uint32_t)(((uint64_t)DI_SORT_BUCKETS << 32) / (uint64_t)N) : 0u);
         HIPCHK(ctx, hipGetLastError());
-        mpfmt_time_end(ctx, "di_fill");
+        tm2.end("di_fill");
     }
     ctx->di_filled = true;
     return MPFMT_OK;
@@ -622,13 +622,13 @@ int32_t mpfmt_di_sweep(mpfmt_ctx* ctx)
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->graph_free, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1)))) return rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->di_nseg, (size_t)std::max<int64_t>(nnz, 1)))) return rc;
     if (nnz > 0) {
-        mpfmt_time_begin(ctx);
+        mpfmt_timed tm3(ctx);
         const unsigned nb = (unsigned)((nnz + 255) / 256);
         DISPATCH_M(m, hipLaunchKernelGGL((k_di_sweep<DM>), dim3(nb), dim3(256), lds, ctx->stream, ctx->Xo, ctx->N, ctx->colptr,
                                          ctx->rowval, ctx->tval, nnz, ctx->di_rho, ctx->boxes, ctx->M, ctx->ss, ctx->graph_free,
                                          ctx->di_nseg));
         HIPCHK(ctx, hipGetLastError());
-        mpfmt_time_end(ctx, "di_sweep");
+        tm3.end("di_sweep");
     }
     ctx->di_swept = true;
     return MPFMT_OK;

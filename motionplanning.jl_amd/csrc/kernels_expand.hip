@@ -130,7 +130,7 @@ int32_t mpfmt_launch_expand(mpfmt_ctx* ctx, const uint64_t* d_W, const uint64_t*
     int64_t* src1 = (int64_t*)(s + o_src);
     uint64_t* emask = (uint64_t*)(s + o_mask);
 
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm1(ctx);
     HIPCHK(ctx, hipMemsetAsync(cand, 0, 8 * words, ctx->stream));
     hipLaunchKernelGGL(k_expand_mark, dim3((unsigned)nz), dim3(64), 0, ctx->stream, d_zs1, nz, N, ctx->colptr, ctx->rowval,
                        d_W, d_F, cand);
@@ -157,6 +157,6 @@ int32_t mpfmt_launch_expand(mpfmt_ctx* ctx, const uint64_t* d_W, const uint64_t*
             HIPCHK(ctx, hipGetLastError());
         }
     }
-    mpfmt_time_end(ctx, "expand");
+    tm1.end("expand");
     return MPFMT_OK;
 }

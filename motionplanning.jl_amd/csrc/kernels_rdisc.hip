@@ -212,7 +212,7 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
     if (ctx->grid_r == r && ctx->Xt) return MPFMT_OK;
     const int64_t N = ctx->N;
     const int d = ctx->d;
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm1(ctx);
 
     // ---- choose cells: width >= r, total cells <= max(1, N/8) and < 2^31 ----------------------------
     mpfmt_grid& G = ctx->grid;
@@ -306,7 +306,7 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
         }
         HIPCHK(ctx, hipGetLastError());
     }
-    mpfmt_time_end(ctx, "grid");
+    tm1.end("grid");
     ctx->grid_r = r;
     ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
     return MPFMT_OK;
@@ -634,7 +634,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path requested but not usable (d > 12 or radius too small for the fp16 shell)");
     }
     if (mf) {
-        mpfmt_time_begin(ctx);
+        mpfmt_timed tm2(ctx);
         if (ctx->ops_r != ctx->grid_r) {
             if ((rc = mpfmt_mfma_build_operands(ctx))) return rc;
             ctx->ops_r = ctx->grid_r;
@@ -642,7 +642,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         }
         bool ok = true;
         if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok, spec))) return rc;    // per-tile candidate chunk lists
-        mpfmt_time_end(ctx, "grid");
+        tm2.end("grid");
         if (!ok) {
             if (ctx->rdisc_path == 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path requested but its chunk lists exceed 32 GB");
             mf = false;
@@ -697,7 +697,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         }
     }
     ctx->pool_valid = false;
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm3(ctx);
     if (nt > 0) {
         if (mf) {
             if (pool) { if ((rc = mpfmt_launch_rdisc_mfma<2>(ctx, r, negT))) return rc; }
@@ -715,7 +715,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     }
     if ((rc = scan_i64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1)))) return rc;      // columns in original order
     if ((rc = scan_i64(ctx, ctx->degs, ctx->tptr, (size_t)(npad + 1)))) return rc;    // staging in sorted order
-    mpfmt_time_end(ctx, "rdisc_count");
+    tm3.end("rdisc_count");
     ctx->cnt_pool = pool; ctx->cnt_mf = mf;
     return MPFMT_OK;
 }
@@ -779,13 +779,13 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
         int done = 0;
         if (ctx->rdisc_path_used == 2 && ctx->pool_valid) {
             // single pass: the hits are already in the slot lists; order each column straight into the final CSC
-            mpfmt_time_begin(ctx);
+            mpfmt_timed tm4(ctx);
             if ((rc = mpfmt_sortcols_slots(ctx))) return rc;
-            mpfmt_time_end(ctx, "rdisc_sort");
+            tm4.end("rdisc_sort");
             done = 1;
         }
         if (!done) {
-            mpfmt_time_begin(ctx);
+            mpfmt_timed tm5(ctx);
             if (ctx->rdisc_path_used == 2) {
                 if ((rc = mpfmt_launch_rdisc_mfma<1>(ctx, r, ctx->mf_negT))) return rc;
             } else {
@@ -795,14 +795,14 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
                 const int64_t nblk = ((a.nitems + NXCD - 1) / NXCD) * NXCD;
                 if ((rc = launch_rdisc<true>(ctx, a, (unsigned)nblk))) return rc;
             }
-            mpfmt_time_end(ctx, "rdisc_fill");
-            mpfmt_time_begin(ctx);
+            tm5.end("rdisc_fill");
+            mpfmt_timed tm6(ctx);
             const int64_t pb = ctx->tile_begin * 64, pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
             const unsigned nb = (unsigned)std::min<int64_t>(pe - pb, 1 << 20);
             hipLaunchKernelGGL(k_sortcols, dim3(nb), dim3(64), 0, ctx->stream,
                                ctx->tptr, ctx->colptr, ctx->perm, pb, pe, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval);
             HIPCHK(ctx, hipGetLastError());
-            mpfmt_time_end(ctx, "rdisc_sort");
+            tm6.end("rdisc_sort");
         }
     }
     ctx->graph_filled = true;
@@ -815,10 +815,14 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
 // single-pass path, its sizes are taken on trust instead: every launch is issued back to back, k_spec_check raises a device
 // flag if a capacity does not hold (the kernels after it then return at once), and the host validates after the one
 // synchronisation -- falling back to the step-by-step path when the trust was misplaced.
-int32_t mpfmt_graph_step(mpfmt_ctx* ctx, double r)
+// The step is split in two so that ONE host thread can keep several ctxs (GPUs) busy: _launch issues the kernels of the
+// speculative form without waiting (or, when nothing can be trusted yet, runs the careful form to completion), _finish makes
+// the one synchronisation, validates, and redoes the step the careful way if a trusted capacity did not hold.
+int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r)
 {
     int32_t rc;
     const int64_t N = ctx->N;
+    ctx->step_state = 0; ctx->step_r = r;
     const bool spec = ctx->spec_ready && ctx->use_pool && ctx->pool_hint_N == N && ctx->pool_hint_r == r && ctx->pool_hint_rank == ctx->rank &&
                       ctx->pool_hint_world == ctx->world && ctx->pool_hint_nnz > 0 && ctx->cc_kind == 0 && ctx->have_boxes && ctx->dw == ctx->d;
     if (spec) {
@@ -831,37 +835,64 @@ int32_t mpfmt_graph_step(mpfmt_ctx* ctx, double r)
             const int64_t nt = ctx->tile_end - ctx->tile_begin;
             hipLaunchKernelGGL(k_spec_check, dim3(1), dim3(1), 0, ctx->stream, ctx->pool_flag,
                                (ctx->spec_lists && nt > 0) ? ctx->list_len + nt : nullptr, ctx->list_cap, ctx->colptr + N, cap, ctx->spec_fail);
-            ctx->nnz = ctx->pool_hint_nnz;                          // provisional: replaced by the count's own value below
+            ctx->nnz = ctx->pool_hint_nnz;                          // provisional: replaced by the count's own value in _finish
             ctx->nnz_cap = cap;
             ctx->pool_valid = true; ctx->rdisc_path_used = 2;
             ctx->graph_r = r; ctx->graph_counted = true;
-            mpfmt_time_begin(ctx);
+            mpfmt_timed tm7(ctx);
             if ((rc = mpfmt_sortcols_slots(ctx, ctx->spec_fail))) return rc;
-            mpfmt_time_end(ctx, "rdisc_sort");
+            tm7.end("rdisc_sort");
             ctx->graph_filled = true;
             if ((rc = mpfmt_launch_graph_sweep(ctx, ctx->spec_fail, cap))) return rc;
-            bool failed = false;
-            if ((rc = mpfmt_rdisc_count_finish(ctx, r, &failed))) return rc;
-            if (!failed && ctx->nnz < cap && ctx->pool_valid) {
-                ctx->graph_filled = true; ctx->graph_swept = true;  // (finish resets the flags it owns)
-                return MPFMT_OK;
-            }
-            // the trust was misplaced: redo the step the careful way (capacities have been corrected by finish)
-            ctx->spec_ready = false;
-            ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
-        } else {
-            if ((rc = mpfmt_rdisc_count_finish(ctx, r, nullptr))) return rc;
-            if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
-            if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
-            ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
+            ctx->step_state = 1;                                    // speculative kernels in flight
             return MPFMT_OK;
         }
+        if ((rc = mpfmt_rdisc_count_finish(ctx, r, nullptr))) return rc;
+        if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
+        if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+        ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
+        ctx->step_state = 2;
+        return MPFMT_OK;
     }
     if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
     if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
     if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
     ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
+    ctx->step_state = 2;
     return MPFMT_OK;
+}
+
+int32_t mpfmt_graph_step_finish_impl(mpfmt_ctx* ctx)
+{
+    int32_t rc;
+    const double r = ctx->step_r;
+    if (ctx->step_state == 0) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "graph_step_finish without graph_step_launch");
+    if (ctx->step_state == 1) {
+        ctx->step_state = 0;
+        bool failed = false;
+        if ((rc = mpfmt_rdisc_count_finish(ctx, r, &failed))) return rc;
+        if (!failed && ctx->nnz < ctx->nnz_cap && ctx->pool_valid) {
+            ctx->graph_filled = true; ctx->graph_swept = true;      // (finish resets the flags it owns)
+            return MPFMT_OK;
+        }
+        // the trust was misplaced: redo the step the careful way (capacities have been corrected by finish)
+        ctx->spec_ready = false;
+        ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
+        if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
+        if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
+        if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+        ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
+        return MPFMT_OK;
+    }
+    ctx->step_state = 0;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_graph_step(mpfmt_ctx* ctx, double r)
+{
+    int32_t rc;
+    if ((rc = mpfmt_graph_step_launch_impl(ctx, r))) return rc;
+    return mpfmt_graph_step_finish_impl(ctx);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -614,9 +614,13 @@ int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usab
     const double e_c = 2.5e-4;                       // > 2^-12 (fp16 rounding on [0,1]) + fp32 conversion slack
     const double shell = 2.0 * std::sqrt((double)d) * e_c;
     const double Rh = s * r * (1.0 + 1e-9) + shell;
-    const double T = Rh * Rh * (1.0 + 1e-6) + 2e-5 * d;
+    // 2e-5 d: fp32 accumulation of <= 17 terms of magnitude <= 4d + the hi/lo split of the norms; 1.25e-4 > 2 * 2^-14: the
+    // n_lo slots (and coordinates below 6.1e-5) are fp16 subnormals -- should the matrix core flush subnormal inputs, each of
+    // the two norms of a pair loses at most 2^-14, so the bound holds whatever the flush behaviour is
+    const double ftz = 1.25e-4;
+    const double T = Rh * Rh * (1.0 + 1e-6) + 2e-5 * d + ftz;
     // the filter is only worth running when the shell is thin compared with the ball
-    if (shell > 0.08 * s * r) return MPFMT_OK;
+    if (shell > 0.08 * s * r || ftz > 0.16 * (s * r) * (s * r)) return MPFMT_OK;
     *negT_out = -(float)(T * (1.0 + 1e-6));
     *usable = true;
     ctx->mf_scale = s;

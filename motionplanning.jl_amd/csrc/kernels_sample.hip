@@ -128,7 +128,7 @@ int32_t mpfmt_sample_free(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double
     struct guard2 { long long* p; ~guard2() { if (p) hipFree(p); } } gA{d_att};
     HIPCHK(ctx, hipMemsetAsync(d_att, 0, sizeof(long long), ctx->stream));
     uint64_t c0 = 0;
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm1(ctx);
     while (have < N) {
         const int64_t need = N - have;
         const int64_t B = ((std::max<int64_t>(65536, need + need / 2 + 4096) + 63) / 64) * 64;
@@ -162,7 +162,7 @@ int32_t mpfmt_sample_free(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double
         if (accepted == 0 && c0 > (uint64_t)N * 1000ull + (1ull << 24))
             return mpfmt_fail(ctx, MPFMT_ERR_INFEASIBLE, "free space appears to be empty: %llu candidates, none accepted", (unsigned long long)c0);
     }
-    mpfmt_time_end(ctx, "sample_free");
+    tm1.end("sample_free");
     long long att = 0;
     HIPCHK(ctx, hipMemcpy(&att, d_att, sizeof(long long), hipMemcpyDeviceToHost));
     if (attempts_out) *attempts_out = (int64_t)att;

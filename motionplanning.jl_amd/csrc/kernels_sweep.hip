@@ -528,9 +528,9 @@ int32_t mpfmt_launch_points_free(mpfmt_ctx* ctx, const int64_t* d_idx1, int64_t 
 {
     int32_t rc;
     if ((rc = check_boxes(ctx, ctx->d))) return rc;
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm1(ctx);
     rc = launch_points(ctx, ctx->Xo, d_idx1, n, ctx->d, d_mask);
-    mpfmt_time_end(ctx, "sweep_points");
+    tm1.end("sweep_points");
     return rc;
 }
 
@@ -538,9 +538,9 @@ int32_t mpfmt_launch_states_free(mpfmt_ctx* ctx, const double* d_P, int64_t n, u
 {
     int32_t rc;
     if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm2(ctx);
     rc = launch_points(ctx, d_P, nullptr, n, ctx->dw, d_mask);
-    mpfmt_time_end(ctx, "sweep_points");
+    tm2.end("sweep_points");
     return rc;
 }
 
@@ -562,9 +562,9 @@ int32_t mpfmt_launch_edges_free(mpfmt_ctx* ctx, const int64_t* d_src1, const int
 {
     int32_t rc;
     if ((rc = check_boxes(ctx, ctx->d))) return rc;
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm3(ctx);
     rc = launch_edges(ctx, d_src1, d_dst1, nullptr, nullptr, E, ctx->d, d_mask);
-    mpfmt_time_end(ctx, "sweep_edges");
+    tm3.end("sweep_edges");
     return rc;
 }
 
@@ -572,9 +572,9 @@ int32_t mpfmt_launch_motions_free(mpfmt_ctx* ctx, const double* d_P, const doubl
 {
     int32_t rc;
     if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm4(ctx);
     rc = launch_edges(ctx, nullptr, nullptr, d_P, d_Q, n, ctx->dw, d_mask);
-    mpfmt_time_end(ctx, "sweep_edges");
+    tm4.end("sweep_edges");
     return rc;
 }
 
@@ -684,7 +684,7 @@ int32_t mpfmt_launch_mc_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64
     slices = std::min<int64_t>(slices, 65535);
     const int64_t per_block = ((rollouts + slices - 1) / slices + SWEEP_THREADS - 1) / SWEEP_THREADS * SWEEP_THREADS;
     slices = (rollouts + per_block - 1) / per_block;
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm5(ctx);
     for (int64_t e0 = 0; e0 < E; e0 += 1 << 20) {                    // gridDim.x limit
         const int64_t ne = std::min<int64_t>(E - e0, 1 << 20);
         DISPATCH_D(d, hipLaunchKernelGGL((k_mc_edges<DD>), dim3((unsigned)ne, (unsigned)slices), dim3(SWEEP_THREADS), lds, ctx->stream,
@@ -692,7 +692,7 @@ int32_t mpfmt_launch_mc_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64
                                          std::max(chunk, 1), ctx->ss, d_hits + e0, e0));
     }
     HIPCHK(ctx, hipGetLastError());
-    mpfmt_time_end(ctx, "mc_edges");
+    tm5.end("mc_edges");
     return MPFMT_OK;
 }
 
@@ -737,15 +737,15 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail, int64
     const int64_t words = (std::max<int64_t>(ctx->nnz, mask_entries) + 63) / 64;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->graph_free, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1)))) return rc;
     if (ctx->cc_kind == 1) {                                         // 2-D SAT world: lane = entry, whole words written
-        mpfmt_time_begin(ctx);
+        mpfmt_timed tm6(ctx);
         HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
         rc = mpfmt_2d_launch_graph(ctx);
-        mpfmt_time_end(ctx, "sweep_graph");
+        tm6.end("sweep_graph");
         if (rc) return rc;
         ctx->graph_swept = true;
         return MPFMT_OK;
     }
-    mpfmt_time_begin(ctx);
+    mpfmt_timed tm7(ctx);
     // preset to ones (the sweep clears blocked entries); an empty graph keeps one zero word
     HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, ctx->nnz > 0 ? 0xFF : 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
     if (ctx->nnz > 0) {
@@ -769,7 +769,7 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail, int64
         if (rc) return rc;
         HIPCHK(ctx, hipGetLastError());
     }
-    mpfmt_time_end(ctx, "sweep_graph");
+    tm7.end("sweep_graph");
     ctx->graph_swept = true;
     return MPFMT_OK;
 }

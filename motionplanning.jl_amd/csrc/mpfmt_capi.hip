@@ -116,6 +116,15 @@ void mpfmt_time_end(mpfmt_ctx* ctx, const char* name)
     if (t.pending.size() > 4096) timer_resolve(ctx);
 }
 
+void mpfmt_time_abandon(mpfmt_ctx* ctx)
+{
+    if (!ctx->timing_enabled) return;
+    timer_state& t = timers_of(ctx);
+    if (t.depth <= 0) return;
+    --t.depth;
+    if (t.depth < TIMER_DEPTH) t.free_events.push_back(t.open_a[t.depth]);
+}
+
 // ---- temporaries of one ABI call: device buffers freed on every exit path -----------------------------------
 struct DevTmp {
     std::vector<void*> p;
@@ -306,6 +315,28 @@ int32_t mpfmt_graph_step_device(mpfmt_ctx* ctx, double r, int64_t* nnz)
     return MPFMT_OK;
 }
 
+int32_t mpfmt_graph_step_launch(mpfmt_ctx* ctx, double r)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!(r >= 0.0) || !std::isfinite(r)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "radius must be finite and >= 0");
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
+    if (ctx->rebuild_index) { ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; }
+    return mpfmt_graph_step_launch_impl(ctx, r);
+}
+
+int32_t mpfmt_graph_step_finish(mpfmt_ctx* ctx, int64_t* nnz)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = mpfmt_graph_step_finish_impl(ctx))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (nnz) *nnz = ctx->nnz;
+    return MPFMT_OK;
+}
+
 int32_t mpfmt_rdisc_count(mpfmt_ctx* ctx, double r, int64_t* colptr, int64_t* nnz)
 {
     if (!ctx) return MPFMT_ERR_ARG;
@@ -369,16 +400,12 @@ int32_t mpfmt_graph_import(mpfmt_ctx* ctx, double r, const int64_t* colptr, cons
         if (colptr[j + 1] < colptr[j]) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "colptr decreases at column %lld", (long long)(j + 1));
     const int64_t nnz = colptr[N] - 1;
     if (nnz > 0 && (!rowval || !nzval)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "rowval / nzval is NULL");
+    char verr[160];
+    if (mpfmt_validate_csc(N, colptr, rowval, verr, sizeof verr) != 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "%s", verr);
     std::vector<int64_t> cp0((size_t)N + 1);
     std::vector<int32_t> rv0((size_t)std::max<int64_t>(nnz, 1));
     for (int64_t j = 0; j <= N; ++j) cp0[j] = colptr[j] - 1;
-    for (int64_t j = 0; j < N; ++j)
-        for (int64_t e = cp0[j]; e < cp0[j + 1]; ++e) {
-            const int64_t y = rowval[e];
-            if (y < 1 || y > N || y == j + 1) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "column %lld: row %lld out of range or a self loop", (long long)(j + 1), (long long)y);
-            if (e > cp0[j] && rowval[e - 1] >= y) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "column %lld: rows are not strictly ascending", (long long)(j + 1));
-            rv0[e] = (int32_t)(y - 1);
-        }
+    for (int64_t e = 0; e < nnz; ++e) rv0[e] = (int32_t)(rowval[e] - 1);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int32_t rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (size_t)(N + 1)))) return rc;
@@ -588,6 +615,61 @@ int32_t mpfmt_shard_info(mpfmt_ctx* ctx, int64_t* col_begin, int64_t* col_end, i
     return MPFMT_OK;
 }
 
+// ---- Euclidean per-edge steer (geometric.jl:18-19) ---------------------------------------------------------------------
+
+int32_t mpfmt_euclid_steer(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double* t, double* u)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    if (E < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "E < 0");
+    if (E == 0) return MPFMT_OK;
+    if (!src || !dst || !t || !u) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "src / dst / t / u is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = check_idx(ctx, src, E, "src")) || (rc = check_idx(ctx, dst, E, "dst"))) return rc;
+    const int d = ctx->d;
+    DevTmp tmp;
+    int64_t *d_s = nullptr, *d_t = nullptr; double *dt = nullptr, *du = nullptr;
+    if ((rc = up_i64(ctx, tmp, src, E, &d_s))) return rc;
+    if ((rc = up_i64(ctx, tmp, dst, E, &d_t))) return rc;
+    HIPCHK(ctx, tmp.get(&dt, sizeof(double) * (size_t)E));
+    HIPCHK(ctx, tmp.get(&du, sizeof(double) * (size_t)E * d));
+    if ((rc = mpfmt_launch_euclid_steer(ctx, d_s, d_t, E, dt, du))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(t, dt, sizeof(double) * (size_t)E, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(u, du, sizeof(double) * (size_t)E * d, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_euclid_propagate(mpfmt_ctx* ctx, const int64_t* src, int64_t E, const double* t, const double* u, const double* s, double* out)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    if (E < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "E < 0");
+    if (E == 0) return MPFMT_OK;
+    if (!src || !t || !u || !out) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "src / t / u / out is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = check_idx(ctx, src, E, "src"))) return rc;
+    const int d = ctx->d;
+    DevTmp tmp;
+    int64_t* d_s = nullptr; double *dt = nullptr, *du = nullptr, *ds = nullptr, *dout = nullptr;
+    if ((rc = up_i64(ctx, tmp, src, E, &d_s))) return rc;
+    HIPCHK(ctx, tmp.get(&dt, sizeof(double) * (size_t)E));
+    HIPCHK(ctx, tmp.get(&du, sizeof(double) * (size_t)E * d));
+    HIPCHK(ctx, tmp.get(&dout, sizeof(double) * (size_t)E * d));
+    HIPCHK(ctx, hipMemcpyAsync(dt, t, sizeof(double) * (size_t)E, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(du, u, sizeof(double) * (size_t)E * d, hipMemcpyHostToDevice, ctx->stream));
+    if (s) {
+        HIPCHK(ctx, tmp.get(&ds, sizeof(double) * (size_t)E));
+        HIPCHK(ctx, hipMemcpyAsync(ds, s, sizeof(double) * (size_t)E, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if ((rc = mpfmt_launch_euclid_propagate(ctx, d_s, E, dt, du, ds, dout))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out, dout, sizeof(double) * (size_t)E * d, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MPFMT_OK;
+}
+
 // ---- expand --------------------------------------------------------------------------------------------
 
 int32_t mpfmt_expand(mpfmt_ctx* ctx, const uint64_t* W, const uint64_t* H, const uint64_t* F, const double* C,
@@ -598,6 +680,7 @@ int32_t mpfmt_expand(mpfmt_ctx* ctx, const uint64_t* W, const uint64_t* H, const
     if (!W || !H || !C || !nx) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "W / H / C / nx is NULL");
     if (nz < 0 || cap < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "nz / cap < 0");
     if (!ctx->graph_filled) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "expand needs a built r-disc graph (mpfmt_rdisc_count + fill)");
+    if (ctx->world != 1) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "expand runs on an unsharded ctx (a shard holds only its own columns: the frontier would be partial); the sharded batch step is mpfmt_wf_step");
     if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
     *nx = 0;
     if (nz == 0) return MPFMT_OK;
@@ -637,164 +720,11 @@ int32_t mpfmt_expand(mpfmt_ctx* ctx, const uint64_t* W, const uint64_t* H, const
 
 // ---- fmtstar -------------------------------------------------------------------------------------------
 
-namespace {
-
-// binary min-heap on (cost, index): Base.Collections.PriorityQueue of fmt.jl:51,66,78,86.  Ties on cost are
-// broken by the lowest sample index (the reference leaves the order of equal priorities unspecified).
-struct Heap {
-    std::vector<double> pri; std::vector<int64_t> idx;
-    bool less(size_t a, size_t b) const { return pri[a] < pri[b] || (pri[a] == pri[b] && idx[a] < idx[b]); }
-    void push(int64_t i, double p)
-    {
-        pri.push_back(p); idx.push_back(i);
-        size_t c = pri.size() - 1;
-        while (c > 0) { size_t par = (c - 1) / 2; if (less(c, par)) { std::swap(pri[c], pri[par]); std::swap(idx[c], idx[par]); c = par; } else break; }
-    }
-    int64_t pop()
-    {
-        int64_t top = idx[0];
-        pri[0] = pri.back(); idx[0] = idx.back(); pri.pop_back(); idx.pop_back();
-        size_t n = pri.size(), c = 0;
-        for (;;) {
-            size_t l = 2 * c + 1, r = l + 1, m = c;
-            if (l < n && less(l, m)) m = l;
-            if (r < n && less(r, m)) m = r;
-            if (m == c) break;
-            std::swap(pri[c], pri[m]); std::swap(idx[c], idx[m]); c = m;
-        }
-        return top;
-    }
-    bool empty() const { return pri.empty(); }
-};
-
-// goal predicates, src/goals.jl:96 (Rectangle), :100 (Ball), :111-114 (Point), Identity state2workspace
-bool is_goal_pt(const double* v, int d, int kind, const double* g)
-{
-    if (kind == MPFMT_GOAL_RECT) {
-        for (int i = 0; i < d; ++i) if (!(g[i] <= v[i] && v[i] <= g[d + i])) return false;
-        return true;
-    }
-    if (kind == MPFMT_GOAL_BALL) {
-        double s = 0.0;
-        for (int i = 0; i < d; ++i) { double t = v[i] - g[i]; double tt = t * t; s = (i == 0) ? tt : s + tt; }
-        return std::sqrt(s) <= g[d];
-    }
-    for (int i = 0; i < d; ++i) if (!(v[i] == g[i])) return false;
-    return true;
-}
-
-inline bool bit(const std::vector<uint64_t>& m, int64_t i) { return (m[i >> 6] >> (i & 63)) & 1ull; }
-
-}  // namespace
-
-// The sequential recursion of fmt.jl:43-101 on a finished r-disc graph: CSC (0-based colptr / int32 rows, ascending
-// rows = the order the reference's neighbourhood scans run in), per-entry free bits (row -> column motions) and the
-// optional checkpts bitmap F.  Pure host code, no device use -- the GPU's job ends where this starts.
-//   - W and H are bit sets (125 KB each at N = 1e6, cache resident): the inner scan touches C[y] / nzval only for the
-//     few open neighbours;
-//   - the candidates x in near(z) & W are collected first, so the adjacency rows of the NEXT candidates can be
-//     prefetched while the current one is scanned (each row is a random ~400-byte read from a GB-sized array).
-// gd = coordinates the goal predicate reads (d for Euclidean spaces; 2 = workspace (x, y) / 3 = whole state for SE2 cars);
-// nseg != NULL: per-entry count of the segment tests the reference would make (car spaces), else one test per edge check
-static int32_t host_fmt_recursion_impl(int64_t N, int32_t d, const double* X, const int64_t* colptr, const int32_t* rowval,
-                                       const double* nzval, const uint64_t* efree, const uint64_t* F, const double* ss_lo,
-                                       const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params, int32_t gd,
-                                       const uint8_t* nseg, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
-
-int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const int64_t* colptr, const int32_t* rowval,
-                                 const double* nzval, const uint64_t* efree, const uint64_t* F, const double* ss_lo,
-                                 const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params,
-                                 int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
-{
-    return host_fmt_recursion_impl(N, d, X, colptr, rowval, nzval, efree, F, ss_lo, ss_hi, init_idx, goal_kind, goal_params, d, nullptr,
-                                   A, C, path, res);
-}
-
-static int32_t host_fmt_recursion_impl(int64_t N, int32_t d, const double* X, const int64_t* colptr, const int32_t* rowval,
-                                       const double* nzval, const uint64_t* efree, const uint64_t* F, const double* ss_lo,
-                                       const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params, int32_t gd,
-                                       const uint8_t* nseg, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res)
-{
-    if (!X || !colptr || !rowval || !nzval || !efree || !goal_params || !A || !C || !path || !res) return MPFMT_ERR_ARG;
-    if (N < 1 || d < 1 || d > MPFMT_MAX_DIM || init_idx < 1 || init_idx > N || goal_kind < 0 || goal_kind > 2) return MPFMT_ERR_ARG;
-    if ((ss_lo == nullptr) != (ss_hi == nullptr)) return MPFMT_ERR_ARG;
-    const auto t_begin = std::chrono::steady_clock::now();
-    const int64_t words = (N + 63) / 64;
-    std::vector<uint64_t> Wb((size_t)words, ~0ull), Hb((size_t)words, 0ull);
-    auto getb = [](const uint64_t* m, int64_t i) { return (m[(size_t)(i >> 6)] >> (i & 63)) & 1ull; };
-    auto setb = [](std::vector<uint64_t>& m, int64_t i) { m[(size_t)(i >> 6)] |= 1ull << (i & 63); };
-    auto clrb = [](std::vector<uint64_t>& m, int64_t i) { m[(size_t)(i >> 6)] &= ~(1ull << (i & 63)); };
-    std::vector<int64_t> Hnew, cand;
-    for (int64_t i = 0; i < N; ++i) { A[i] = 0; C[i] = 0.0; }
-    Heap heap;
-    const int64_t i0 = init_idx - 1;
-    clrb(Wb, i0); setb(Hb, i0);
-    heap.push(i0, 0.0);
-    int64_t z = heap.pop();
-    int64_t count = 0;
-    auto prefetch_row = [&](int64_t x) {
-        const char* p = (const char*)(rowval + colptr[x]);
-        const char* e = (const char*)(rowval + colptr[x + 1]);
-        for (int q = 0; q < 8 && p < e; ++q, p += 64) __builtin_prefetch(p, 0, 1);
-    };
-    while (!is_goal_pt(&X[(size_t)z * d], gd, goal_kind, goal_params)) {
-        Hnew.clear();
-        cand.clear();
-        for (int64_t a = colptr[z]; a < colptr[z + 1]; ++a) {                 // fmt.jl:70-71
-            const int64_t x = rowval[a];
-            if (getb(Wb.data(), x) && (!F || getb(F, x))) cand.push_back(x);
-        }
-        const size_t nc = cand.size();
-        for (size_t q = 0; q < nc && q < 3; ++q) prefetch_row(cand[q]);
-        for (size_t q = 0; q < nc; ++q) {
-            if (q + 3 < nc) prefetch_row(cand[q + 3]);
-            const int64_t x = cand[q];
-            int64_t y_min = -1, e_min = -1; double c_min = 0.0;
-            for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {             // fmt.jl:72-74
-                const int64_t y = rowval[b];
-                if (!getb(Hb.data(), y)) continue;
-                const double c = C[y] + nzval[b];
-                if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
-            }
-            if (y_min < 0) continue;
-            if (nseg) {
-                count += nseg[e_min];
-            } else {   // boxesND.jl:26 is only reached when in_state_space(V[y_min]) held (statespaces.jl:155-157)
-                bool inb = true;
-                if (ss_lo) for (int k = 0; k < d; ++k) inb = inb && (ss_lo[k] <= X[(size_t)y_min * d + k]) && (X[(size_t)y_min * d + k] <= ss_hi[k]);
-                if (inb) ++count;
-            }
-            if (getb(efree, e_min)) {                                         // fmt.jl:75
-                A[x] = y_min + 1; C[x] = c_min;
-                heap.push(x, c_min);
-                Hnew.push_back(x);
-                clrb(Wb, x);
-            }
-        }
-        for (int64_t x : Hnew) setb(Hb, x);                                   // fmt.jl:83
-        clrb(Hb, z);                                                          // fmt.jl:84
-        if (!heap.empty()) z = heap.pop(); else break;                        // fmt.jl:85-89
-    }
-    // path back-trace, fmt.jl:92-101 (walks until sample 1)
-    std::vector<int64_t> rev;
-    int64_t cur = z;
-    rev.push_back(cur + 1);
-    while (cur != 0) {
-        const int64_t p = A[cur];
-        if (p == 0) break;
-        cur = p - 1;
-        rev.push_back(cur + 1);
-    }
-    for (size_t i = 0; i < rev.size(); ++i) path[i] = rev[rev.size() - 1 - i];
-    res->status = is_goal_pt(&X[(size_t)z * d], gd, goal_kind, goal_params) ? 1 : 0;
-    res->cost = C[z];
-    res->z = z + 1;
-    res->collision_checks = count;
-    res->path_len = (int64_t)rev.size();
-    res->nnz = colptr[N];
-    res->ms_host_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    return MPFMT_OK;
-}
+// The sequential recursion itself (fmt.jl:43-101 over finished arrays), the binary heap and the goal predicates live in
+// mpfmt_host.cpp: plain C++ without HIP, so the same translation unit is also built with -fsanitize=address,undefined for the
+// CPU test suite (tests/asan/).
+static inline bool bit(const std::vector<uint64_t>& m, int64_t i) { return (m[i >> 6] >> (i & 63)) & 1ull; }
+static inline bool is_goal_pt(const double* v, int d, int kind, const double* g) { return mpfmt_is_goal_pt(v, d, kind, g); }
 
 int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts,
                       int32_t goal_kind, const double* goal_params,
@@ -954,110 +884,6 @@ int32_t mpfmt_di_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64
         if (e != hipSuccess) rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "di_steer copy back: %s", hipGetErrorString(e));
     }
     return rc;
-}
-
-// fmt.jl:43-101 over a DIRECTED cost graph (quasi-metric spaces: double integrator, Dubins car): forward sets = rows of the
-// cost matrix (DSF = Dmat', linearquadratic.jl:73), backward sets = its columns (the CSC given).  efree / nseg are per CSC
-// entry (row -> column motion free; segment tests the reference would have counted), F the checkpts bitmap (may be NULL).
-extern "C++" void mpfmt_directed_fmt_recursion(int64_t N, const int64_t* colptr_, const int32_t* rowval_, const double* nzval_, const uint64_t* efree_,
-                                  const uint8_t* nseg_, const uint64_t* F_, int64_t init_idx, const std::function<bool(int64_t)>& goal_hit,
-                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res, const mpfmt_csr_view* pre)
-{
-    const int64_t nnz = colptr_[N];
-    struct view64 { const int64_t* p; int64_t operator[](int64_t i) const { return p[i]; } };
-    struct view32 { const int32_t* p; int32_t operator[](int64_t i) const { return p[i]; } };
-    struct viewd { const double* p; double operator[](int64_t i) const { return p[i]; } };
-    struct view8 { const uint8_t* p; uint8_t operator[](int64_t i) const { return p[i]; } };
-    const view64 colptr{colptr_}; const view32 rowval{rowval_}; const viewd nzval{nzval_}; const view8 nseg{nseg_};
-    const bool checkpts = F_ != nullptr;
-    auto bitp = [](const uint64_t* m, int64_t i) { return (m[i >> 6] >> (i & 63)) & 1ull; };
-    // forward sets: CSR of the cost matrix (DSF = Dmat', linearquadratic.jl:73), rows ascending in target index -- taken from
-    // the device transpose when the caller has one (mpfmt_csc_transpose_device), else built here
-    std::vector<int64_t> rowptr_own, centry_own;
-    std::vector<int32_t> colidx_own;
-    const int64_t* rowptr;
-    const int32_t* colidx;
-    const uint32_t* centry32 = nullptr;
-    if (pre) {
-        rowptr = pre->rowptr; colidx = pre->colidx; centry32 = pre->centry;
-    } else {
-        rowptr_own.assign((size_t)N + 1, 0); colidx_own.resize((size_t)std::max<int64_t>(nnz, 1)); centry_own.resize((size_t)std::max<int64_t>(nnz, 1));
-        std::vector<int64_t> cur((size_t)N);
-        for (int64_t e = 0; e < nnz; ++e) rowptr_own[rowval[e] + 1]++;
-        for (int64_t i = 0; i < N; ++i) rowptr_own[i + 1] += rowptr_own[i];
-        for (int64_t i = 0; i < N; ++i) cur[i] = rowptr_own[i];
-        for (int64_t j = 0; j < N; ++j)
-            for (int64_t e = colptr[j]; e < colptr[j + 1]; ++e) { const int64_t a = cur[rowval[e]]++; colidx_own[a] = (int32_t)j; centry_own[a] = e; }
-        rowptr = rowptr_own.data(); colidx = colidx_own.data();
-    }
-    auto centry_at = [&](int64_t a) -> int64_t { return centry32 ? (int64_t)centry32[a] : centry_own[a]; };
-    // The recursion of fmt.jl:43-90.  DI neighbourhoods are large (hundreds of entries) and arcs are often blocked, so a
-    // sample can be examined by many expanding neighbours; rescanning nearB(x) & H each time is what the reference does
-    // and is O(N deg^2).  Here the argmin over the OPEN backward neighbours is maintained instead: when y opens it
-    // relaxes best[x] of its forward neighbours still in W; when the best itself has closed, x is rescanned once.  The
-    // order is the reference's (lowest cost, then lowest index = first minimum of its scan), so A, C, the path and the
-    // collision count are unchanged.
-    std::vector<uint8_t> Wm(N, 1), Hm(N, 0);
-    std::vector<int64_t> Hnew;
-    std::vector<int64_t> by(N, -1), be(N, -1);       // best open parent of x and its CSC entry (-1 none, -2 rescan)
-    std::vector<double> bc(N, 0.0);
-    for (int64_t i = 0; i < N; ++i) { A[i] = 0; C[i] = 0.0; }
-    auto open_node = [&](int64_t y) {                 // y has just entered H: offer it to its forward neighbours
-        Hm[y] = 1;
-        const double cy = C[y];
-        for (int64_t a = rowptr[y]; a < rowptr[y + 1]; ++a) {
-            const int64_t x = colidx[a];
-            if (!Wm[x] || by[x] == -2) continue;
-            if (by[x] >= 0 && !Hm[by[x]]) { by[x] = -2; continue; }           // its best has closed: rescan when examined
-            const int64_t e = centry_at(a);
-            const double c = cy + nzval[e];
-            if (by[x] < 0 || c < bc[x] || (c == bc[x] && y < by[x])) { by[x] = y; bc[x] = c; be[x] = e; }
-        }
-    };
-    Heap heap;
-    const int64_t i0 = init_idx - 1;
-    Wm[i0] = 0;
-    open_node(i0);
-    heap.push(i0, 0.0);
-    int64_t z = heap.pop();
-    int64_t count = 0;
-    while (!goal_hit(z)) {
-        Hnew.clear();
-        for (int64_t a = rowptr[z]; a < rowptr[z + 1]; ++a) {                  // nearF(V, z, r, W), fmt.jl:70
-            const int64_t x = colidx[a];
-            if (!Wm[x]) continue;
-            if (checkpts && !bitp(F_, x)) continue;
-            if (by[x] == -2 || (by[x] >= 0 && !Hm[by[x]])) {                   // nearB(V, x, r, H), fmt.jl:72-74
-                int64_t y_min = -1, e_min = -1; double c_min = 0.0;
-                for (int64_t b = colptr[x]; b < colptr[x + 1]; ++b) {
-                    const int64_t y = rowval[b];
-                    if (!Hm[y]) continue;
-                    const double c = C[y] + nzval[b];
-                    if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
-                }
-                by[x] = y_min; bc[x] = c_min; be[x] = e_min;
-            }
-            if (by[x] < 0) continue;
-            const int64_t y_min = by[x], e_min = be[x];
-            count += nseg[e_min];                                              // boxesND.jl:26 per tested segment
-            if (bitp(efree_, e_min)) {
-                A[x] = y_min + 1; C[x] = bc[x];
-                heap.push(x, bc[x]);
-                Hnew.push_back(x);
-                Wm[x] = 0;
-            }
-        }
-        Hm[z] = 0;                                                             // fmt.jl:84 (before 83: same final sets)
-        for (int64_t x : Hnew) open_node(x);                                   // fmt.jl:83
-        if (!heap.empty()) z = heap.pop(); else break;
-    }
-    std::vector<int64_t> rev;
-    int64_t cu = z;
-    rev.push_back(cu + 1);
-    while (cu != 0) { const int64_t p = A[cu]; if (p == 0) break; cu = p - 1; rev.push_back(cu + 1); }
-    for (size_t i = 0; i < rev.size(); ++i) path[i] = rev[rev.size() - 1 - i];
-    res->status = goal_hit(z) ? 1 : 0;
-    res->cost = C[z]; res->z = z + 1; res->collision_checks = count; res->path_len = (int64_t)rev.size(); res->nnz = nnz;
 }
 
 int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx, int32_t checkpts,
@@ -1292,7 +1118,7 @@ static int32_t car_fmtstar(mpfmt_ctx* ctx, int kind, double turn_radius, double 
         // recursion on column = inball; the goal acts on (x, y), POINT = exact state
         std::vector<double> gp3;
         const double* gp = goal_params;
-        if ((rc = host_fmt_recursion_impl(N, 3, X.data(), colptr.data(), rowval.data(), nzval.data(), efree.data(),
+        if ((rc = mpfmt_host_fmt_recursion_impl(N, 3, X.data(), colptr.data(), rowval.data(), nzval.data(), efree.data(),
                                           checkpts ? F.data() : nullptr, nullptr, nullptr, init_idx, goal_kind, gp, goal_kind == MPFMT_GOAL_POINT ? 3 : 2,
                                           nseg.data(), A, C, path, res)))
             return mpfmt_fail(ctx, rc, "host recursion rejected its arguments");

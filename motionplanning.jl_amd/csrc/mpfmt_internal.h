@@ -6,6 +6,7 @@
 #include <map>
 #include <vector>
 #include "../../include/mpfmt.h"
+#include "mpfmt_host.h"
 
 #define MPFMT_WAVE 64           // CDNA wavefront width; tile of samples = one wavefront of queries
 #define MPFMT_MAXS 16           // max candidate slices per tile
@@ -171,6 +172,7 @@ struct mpfmt_ctx {
 
     // ---- multi-GPU exchange (mpfmt_comm.hip) and the device-resident wavefront FMT* driver (kernels_wavefront.hip) ----
     void* comm = nullptr;                // mpfmt_comm: RCCL communicator + communication stream of this ctx
+    int32_t step_state = 0; double step_r = 0.0;   // graph_step_launch / _finish: 0 none, 1 speculative kernels in flight, 2 complete
     int32_t wf_force_sharded = 0;        // option: run the sharded form of the wavefront step (own-column marking, triples, exchange) at world = 1
     void* wf = nullptr;                  // mpfmt_wf: W / H / C / A and the batch lists of a running wavefront solve
 };
@@ -190,6 +192,17 @@ int32_t mpfmt_scratch(mpfmt_ctx* ctx, size_t bytes, void** out);
 int32_t mpfmt_ensure(mpfmt_ctx* ctx, void** p, size_t bytes);
 void mpfmt_time_begin(mpfmt_ctx* ctx);
 void mpfmt_time_end(mpfmt_ctx* ctx, const char* name);
+void mpfmt_time_abandon(mpfmt_ctx* ctx);
+// one timed interval; an error return between begin and end abandons it (the stack depth and the opening event are given
+// back), so failed calls cannot wedge the timers of the ctx
+struct mpfmt_timed {
+    mpfmt_ctx* ctx; bool open;
+    explicit mpfmt_timed(mpfmt_ctx* c) : ctx(c), open(true) { mpfmt_time_begin(c); }
+    void end(const char* name) { if (open) { mpfmt_time_end(ctx, name); open = false; } }
+    ~mpfmt_timed() { if (open) mpfmt_time_abandon(ctx); }
+    mpfmt_timed(const mpfmt_timed&) = delete;
+    mpfmt_timed& operator=(const mpfmt_timed&) = delete;
+};
 
 // kernels_rdisc.hip -----------------------------------------------------------------------------
 int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r);
@@ -197,6 +210,8 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec);
 int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed);
 int32_t mpfmt_graph_step(mpfmt_ctx* ctx, double r);
+int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r);
+int32_t mpfmt_graph_step_finish_impl(mpfmt_ctx* ctx);
 int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usable);
 int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx);
@@ -221,14 +236,7 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail = null
 // kernels_di.hip ----------------------------------------------------------------------------------
 #include <functional>
 #include <vector>
-// forward sets of a directed cost graph (CSR view of the CSC held in the ctx): rowptr[N+1], colidx[nnz] (target of each
-// entry, ascending inside a row), centry[nnz] (the CSC entry it came from)
-struct mpfmt_csr_view { const int64_t* rowptr; const int32_t* colidx; const uint32_t* centry; };
-struct mpfmt_csr_host { std::vector<int64_t> rowptr; std::vector<int32_t> colidx; std::vector<uint32_t> centry; };
 int32_t mpfmt_csc_transpose_device(mpfmt_ctx* ctx, mpfmt_csr_host* out);      // kernels_di.hip; needs nnz < 2^32
-void mpfmt_directed_fmt_recursion(int64_t N, const int64_t* colptr, const int32_t* rowval, const double* nzval, const uint64_t* efree,
-                                  const uint8_t* nseg, const uint64_t* F, int64_t init_idx, const std::function<bool(int64_t)>& goal_hit,
-                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res, const mpfmt_csr_view* pre);
 int32_t mpfmt_car_build(mpfmt_ctx* ctx, int kind, double rt, double sp, double r);      // kind 1 Dubins, 2 Reeds-Shepp
 int32_t mpfmt_car_sweep(mpfmt_ctx* ctx);
 int32_t mpfmt_car_steer_batch(mpfmt_ctx* ctx, int kind, const double* d_X0, const double* d_X1, int64_t n, double rt, double sp, double* d_cost,
@@ -242,6 +250,11 @@ int32_t mpfmt_di_steer_launch(mpfmt_ctx* ctx, int m, const double* dX0, const do
 // mpfmt_comm.hip -----------------------------------------------------------------------------------
 int32_t mpfmt_comm_allgather_inplace(mpfmt_ctx* ctx, void* buf, size_t bytes_per_rank, hipStream_t stream);
 int32_t mpfmt_comm_world(const mpfmt_ctx* ctx, int* rank, int* world);      // 1 when a communicator exists
+
+// kernels_steer.hip ---------------------------------------------------------------------------------
+int32_t mpfmt_launch_euclid_steer(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, double* d_t, double* d_u);
+int32_t mpfmt_launch_euclid_propagate(mpfmt_ctx* ctx, const int64_t* d_src1, int64_t E, const double* d_t, const double* d_u,
+                                      const double* d_s, double* d_out);
 
 // kernels_wavefront.hip -----------------------------------------------------------------------------
 void mpfmt_wf_free(mpfmt_ctx* ctx);

@@ -42,12 +42,15 @@ class MaskGather:
     from them, put their own length in front of their words and gather capacity + 1 words each.  The lengths come back
     with the payload; if one exceeds the capacity (a rank's shard grew by more than the 5 % margin) every rank sees that
     and all of them repeat the payload exchange at the exact size -- the same decision everywhere, so the collectives
-    stay matched.  Returns the same (gathered [world, >= max words], counts) as `all_gather_mask`."""
+    stay matched.  Returns the same (gathered [world, >= max words], counts) as `all_gather_mask`: rows are zero padded
+    beyond `counts[g]` words.  The returned tensor is a VIEW of a buffer the next call overwrites (one-step lifetime):
+    clone it to keep a step's mask while the next gather is in flight."""
 
     def __init__(self, dist, world, device=None):
         self.dist, self.world, self.device = dist, world, device
         self.cap = None
         self._send = self._out = None
+        self._last_m = 0
 
     def __call__(self, local_words):
         dist, world = self.dist, self.world
@@ -61,11 +64,15 @@ class MaskGather:
         if self._send is None or self._send.numel() != cap + 1:
             self._send = torch.zeros(cap + 1, dtype=torch.int64, device=device)
             self._out = torch.empty(world * (cap + 1), dtype=torch.int64, device=device)
+            self._last_m = 0
         send = self._send
         send[0] = n
         m = min(n, cap)
         if m:
             send[1:1 + m] = local_words[:m]
+        if self._last_m > m:
+            send[1 + m:1 + self._last_m] = 0          # a shorter mask than last step: no stale words in the padding
+        self._last_m = m
         dist.all_gather_into_tensor(self._out, send)
         view = self._out.view(world, cap + 1)
         counts = view[:, 0].clone()

@@ -2,8 +2,10 @@
 
 Samples i.i.d. uniform in [0,1]^d (fp64); V[1] = init; last sample = goal centre; obstacles = M AABBs,
 centre ~ U[0,1]^d, half-width per axis ~ U[h_lo,h_hi], boxes containing init or goal rejected.
-numpy's PCG64 stream is deterministic for a given seed, so the CPU oracle, the HIP library and the
-tests all see identical inputs.
+Random numbers come from SplitMix64 (Steele, Lea, Flood 2014; the generator xoshiro's authors seed with), used as a
+counter-based stream: draw i (0-based) of seed s is mix(s + (i + 1) * 0x9E3779B97F4A7C15), i.e. exactly the i-th output of
+the textbook generator, and u = (draw >> 11) * 2^-53.  Five lines in any language, so a Julia harness regenerates the bench
+inputs bit for bit; tests/golden/stream_heads.json pins the first draws of every seed used here.
 """
 import math
 from dataclasses import dataclass
@@ -39,6 +41,34 @@ class Workload:
         return np.concatenate([self.goal_center, [self.goal_radius]])
 
 
+_GAMMA = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def splitmix64(seed, n, offset=0):
+    """Outputs offset .. offset+n-1 (0-based) of SplitMix64 seeded with `seed`, as uint64 (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        i = np.arange(offset + 1, offset + n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + i * _GAMMA
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+class Stream:
+    """Sequential view of the counter-based stream: .random(shape) hands out the next prod(shape) uniforms in [0, 1), C order."""
+
+    def __init__(self, seed):
+        self.seed, self.pos = int(seed), 0
+
+    def random(self, shape=None):
+        n = int(np.prod(shape)) if shape is not None else 1
+        u = (splitmix64(self.seed, n, self.pos) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+        self.pos += n
+        return u.reshape(shape) if shape is not None else float(u[0])
+
+
 def fmt_radius(rm, d, vol, N):
     """src/planners/fmt.jl:39, evaluated left to right like the Julia expression."""
     zeta = math.pi ** (d / 2) / math.gamma(d / 2 + 1)
@@ -61,7 +91,7 @@ def make_boxes(rng, M, d, h_lo, h_hi, keep_out):
 
 
 def make(name, N, d, M, h_lo, h_hi, seed, init_v=0.1, goal_v=0.9, goal_radius=0.15, rm=1.0, r=None):
-    rng = np.random.default_rng(seed)
+    rng = Stream(seed)
     init = np.full(d, init_v)
     goal = np.full(d, goal_v)
     lohi = make_boxes(rng, M, d, h_lo, h_hi, [init, goal])
@@ -117,7 +147,7 @@ class DIWorkload:
 def cfg4(N=100_000, m=2, M=20, vmax=0.5, rho=1.0, r=1.0, seed=5):
     """Kinodynamic FMT*: DoubleIntegrator(2; vmax=0.5, r=1.) (linearquadratic.jl:46-53), state R^4, cost radius 1
     (docs/MotionPlanning.ipynb cell 8), 20 2-D boxes.  BASELINE.json configs[3]."""
-    rng = np.random.default_rng(seed)
+    rng = Stream(seed)
     init = np.concatenate([np.full(m, 0.1), np.zeros(m)])
     goal = np.concatenate([np.full(m, 0.9), np.zeros(m)])
     lohi = make_boxes(rng, M, m, 0.02, 0.08, [init[:m], goal[:m]])

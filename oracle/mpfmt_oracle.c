@@ -707,6 +707,46 @@ int32_t orc_fmtstar_graph(const double *X, int64_t N, int32_t d, int64_t init_id
     return 0;
 }
 
+/* The portable input stream of the synthetic workloads: SplitMix64 (Steele, Lea, Flood, "Fast splittable
+ * pseudorandom number generators", OOPSLA 2014; Vigna's splitmix64.c), used counter-based.  Draw i (0-based) of seed s:
+ *   z = s + (i + 1) * 0x9E3779B97F4A7C15;  z = (z ^ z >> 30) * 0xBF58476D1CE4E5B9;  z = (z ^ z >> 27) * 0x94D049BB133111EB;  z ^ z >> 31
+ * and u = (z >> 11) * 2^-53.  Not a reference function (the reference uses Julia's unseeded global RNG). */
+uint64_t orc_splitmix64(uint64_t seed, uint64_t i)
+{
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void orc_stream_uniform(uint64_t seed, uint64_t offset, int64_t n, double *u)
+{
+    for (int64_t i = 0; i < n; ++i) u[i] = (double)(orc_splitmix64(seed, offset + (uint64_t)i) >> 11) * 0x1.0p-53;
+}
+
+/* a8: Euclidean steer, src/statespaces/geometric.jl:18-19 and the partial propagate of src/statespaces.jl:79-81.
+ *   steering_control(M::Euclidean, v, w) = StepControl(evaluate(M, v, w), normalize(w - v))
+ *   propagate(M::Euclidean, v, u::StepControl) = v + u.t * u.u
+ * Declared arithmetic: t = orc_dist (the canonical index-order norm); normalize = inv(norm) * (w - v) (StaticArrays /
+ * Base.normalize multiply by the reciprocal); v + t*u unfused. */
+void orc_euclid_steer(const double *v, const double *w, int32_t d, double *t, double *u)
+{
+    const double n = orc_dist(v, w, d);
+    const double inv = 1.0 / n;
+    *t = n;
+    for (int32_t i = 0; i < d; ++i) u[i] = inv * (w[i] - v[i]);
+}
+
+void orc_euclid_propagate(const double *v, int32_t d, double t, const double *u, int32_t have_s, double s, double *out)
+{
+    double step = t;
+    if (have_s) {
+        if (s <= 0.0) { for (int32_t i = 0; i < d; ++i) out[i] = v[i]; return; }     /* statespaces.jl:80 */
+        if (!(s >= t)) step = s;
+    }
+    for (int32_t i = 0; i < d; ++i) { double p = step * u[i]; out[i] = v[i] + p; }
+}
+
 /* Wavefront (batched) form of the same loop on a prebuilt graph: the checker of libmpfmt's device-resident driver
  * (mpfmt_fmtstar_wavefront).  Not a reference function: the reference pops one node per iteration (fmt.jl:66,85-89); this
  * runs the loop BODY fmt.jl:70-82 for the whole batch Z = { z in H : C[z] <= min_H C + band } (or, single != 0, the one

@@ -52,6 +52,10 @@ def lib():
         L.orc_kdtree_free.restype = None
         L.orc_kdtree_inball.restype = C.c_int64
         L.orc_expand.restype = C.c_int64
+        L.orc_splitmix64.restype = C.c_uint64
+        L.orc_stream_uniform.restype = None
+        L.orc_euclid_steer.restype = None
+        L.orc_euclid_propagate.restype = None
         L.orc_di_pairwise.restype = C.c_int64
         L.orc_fmt_radius.restype = C.c_double
         for f in ("orc_di_cost", "orc_di_dcost", "orc_di_ddcost"):
@@ -258,6 +262,30 @@ def fmtstar_graph(X, colptr, rowval, nzval, free_mask, Fmask, goal_kind, goal, l
                                  _d(ss_lo), _d(ss_hi), _i(A), _d(Cc), _i(path), C.byref(res))
     return dict(rc=rc, status=int(res.status), cost=float(res.cost), z=int(res.z),
                 collision_checks=int(res.collision_checks), A=A, C=Cc, path=path[:res.path_len].copy())
+
+
+def splitmix64(seed, i):
+    return int(lib().orc_splitmix64(C.c_uint64(seed), C.c_uint64(i)))
+
+
+def stream_uniform(seed, n, offset=0):
+    u = np.empty(n)
+    lib().orc_stream_uniform(C.c_uint64(seed), C.c_uint64(offset), C.c_int64(n), _d(u))
+    return u
+
+
+def euclid_steer(v, w):
+    v = _vec(v); w = _vec(w)
+    t = C.c_double(); u = np.empty(v.size)
+    lib().orc_euclid_steer(_d(v), _d(w), C.c_int32(v.size), C.byref(t), _d(u))
+    return t.value, u
+
+
+def euclid_propagate(v, t, u, s=None):
+    v = _vec(v); u = _vec(u); out = np.empty(v.size)
+    lib().orc_euclid_propagate(_d(v), C.c_int32(v.size), C.c_double(t), _d(u), C.c_int32(0 if s is None else 1),
+                               C.c_double(0.0 if s is None else s), _d(out))
+    return out
 
 
 def fmt_wavefront_graph(X, colptr, rowval, nzval, free_mask, Fmask, goal_kind, goal, lohi, ss_lo=None, ss_hi=None, init_idx=0,

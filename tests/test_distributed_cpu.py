@@ -50,6 +50,14 @@ def _worker(rank, world, port, q):
         want0 = t if it != 2 else torch.cat([t, t, t])
         if rank == 0:
             assert np.array_equal(seq[-1][0], want0.numpy())
+    # shard sizes shrink, then grow again inside the same capacity: the rows must stay ZERO padded beyond counts[g]
+    # (stale words of the longer previous mask used to stay in the padding)
+    ones = torch.full((64,), -1, dtype=torch.int64)         # same length on every rank (rank 1's own shard is empty)
+    for n in (len(ones), 3, len(ones) // 2, 0, 5):
+        g3, c3 = mg(ones[:n] if rank == 0 else t)
+        assert int(c3[0]) == n
+        row = g3[0].numpy()
+        assert (row[:n] == -1).all() and not row[n:].any(), (rank, n)
     q.put((rank, [p.numpy().view(np.uint64).copy() for p in parts], local, seq))
     dist.barrier()
     dist.destroy_process_group()

@@ -1,0 +1,137 @@
+"""GPU tests (-m gpu) of the boundary itself: a gcc-built C caller that uses the `ccall` argument widths of julia/MPFmtHIP.jl
+(tests/abi_c/abi_caller.c), the Euclidean steer export, the launch / finish split of the step, and the
+guards on a sharded ctx."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import motionplanning_jl_amd as mp
+
+pytestmark = pytest.mark.gpu
+L = mp._lib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_caller_with_ccall_widths(orc, tmp_path):
+    w = mp.workloads.make("t", 2500, 3, 30, 0.05, 0.12, seed=5, goal_radius=0.1)
+    exe = str(tmp_path / "abi_caller")
+    pkg = os.path.join(ROOT, "motionplanning.jl_amd")
+    subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Werror=incompatible-pointer-types", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_c", "abi_caller.c"), "-o", exe, "-L", pkg, "-lmpfmt", "-Wl,-rpath," + pkg])
+    N, d, M = w.N, w.d, w.M
+    band = 0.4 * w.r
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(np.array([N, d, M], dtype=np.int64).tobytes())
+        f.write(np.array([w.r, band], dtype=np.float64).tobytes())
+        for a in (w.X, w.lohi, w.ss_lo, w.ss_hi, w.goal_params()):
+            f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+    env = dict(os.environ)
+    import torch
+    env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(os.path.dirname(torch.__file__), "lib"), "/opt/rocm/lib", env.get("LD_LIBRARY_PATH", "")])
+    p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    buf = open(tmp_path / "out.bin", "rb").read()
+    pos = [0]
+
+    def take(dtype, n):
+        a = np.frombuffer(buf, dtype=dtype, count=n, offset=pos[0])
+        pos[0] += a.nbytes
+        return a
+    oc, orow, oval = orc.rdisc_graph(w.X, w.r)
+    for v in (0, N - 1):
+        k = int(take(np.int64, 1)[0])
+        inds, ds = take(np.int64, k), take(np.float64, k)
+        assert np.array_equal(inds - 1, orow[oc[v]:oc[v + 1]]) and np.array_equal(ds, oval[oc[v]:oc[v + 1]])
+    nnz = int(take(np.int64, 1)[0])
+    colptr, rowval, nzval = take(np.int64, N + 1), take(np.int64, nnz), take(np.float64, nnz)
+    free = take(np.uint64, (nnz + 63) // 64)
+    assert np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow) and np.array_equal(nzval, oval)
+    assert np.array_equal(free, orc.graph_edges_free(w.X, oc, orow, w.lohi, w.ss_lo, w.ss_hi))
+    F = orc.points_free(w.X, w.lohi, w.ss_lo, w.ss_hi)
+    for single in (True, False):
+        res = L.FmtResult.from_buffer_copy(buf, pos[0]); pos[0] += ctypes.sizeof(L.FmtResult)
+        info = L.WfInfo.from_buffer_copy(buf, pos[0]); pos[0] += ctypes.sizeof(L.WfInfo)
+        A, C = take(np.int64, N), take(np.float64, N)
+        path = take(np.int64, res.path_len)
+        ref = orc.fmt_wavefront_graph(w.X, oc, orow, oval, None, F, orc.GOAL_BALL, w.goal_params(), w.lohi, w.ss_lo, w.ss_hi,
+                                      band=0.0 if single else band, single=single)
+        assert res.status == ref["status"] and res.z - 1 == ref["z"] and res.collision_checks == ref["collision_checks"]
+        assert res.cost == ref["cost"] and res.nnz == nnz and info.iters == ref["iters"]
+        assert np.array_equal(A - 1, ref["A"]) and np.array_equal(C, ref["C"]) and np.array_equal(path - 1, ref["path"])
+    nnz2, stride, wcount, ncount = take(np.int64, 4)
+    assert nnz2 == nnz and ncount == nnz and wcount == (nnz + 63) // 64 and stride == wcount + 16 + 2
+    assert pos[0] == len(buf)
+
+
+@pytest.mark.parametrize("d", [2, 3, 6, 12])
+def test_euclid_steer_and_propagate(orc, d):
+    """steering_control / propagate of src/statespaces/geometric.jl:18-19 per edge, bit for bit against the oracle; the step
+    length is the graph's edge cost; propagating the full control lands on the target."""
+    rng = np.random.default_rng(30 + d)
+    N = 4000
+    X = rng.random((N, d))
+    X[7] = X[3]                                                  # a zero-length edge: t = 0, NaN direction (IEEE, as in Julia)
+    r = 0.7 * (60.0 / N) ** (1.0 / d)
+    with mp.Context(0) as c:
+        c.upload_samples(X)
+        colptr, rowval, nzval = c.rdisc_graph(r)
+        cols = np.repeat(np.arange(1, N + 1), np.diff(colptr))
+        E = min(len(rowval), 30000)
+        src = np.concatenate([rowval[:E], [4]]); dst = np.concatenate([cols[:E], [8]])
+        t, u = c.euclid_steer(src, dst)
+        assert np.array_equal(t[:E], nzval[:E])                  # evaluate(M, v, w) == the stored edge cost
+        for e in list(rng.integers(0, E, size=300)) + [E]:
+            ot, ou = orc.euclid_steer(X[src[e] - 1], X[dst[e] - 1])
+            assert t[e] == ot and np.array_equal(u[e], ou, equal_nan=True)
+        assert t[E] == 0.0 and np.isnan(u[E]).all()
+        full = c.euclid_propagate(src[:E], t[:E], u[:E])
+        assert np.abs(full - X[dst[:E] - 1]).max() <= 4e-16 * max(1.0, np.abs(X).max()) * 4
+        s = rng.random(E) * 2.0 * t[:E] - 0.3 * t[:E]            # below 0, inside, beyond the duration
+        part = c.euclid_propagate(src[:E], t[:E], u[:E], s)
+        for e in rng.integers(0, E, size=300):
+            assert np.array_equal(part[e], orc.euclid_propagate(X[src[e] - 1], t[e], u[e], s[e]))
+            assert np.array_equal(full[e], orc.euclid_propagate(X[src[e] - 1], t[e], u[e]))
+        assert np.array_equal(part[s <= 0], X[src[:E][s <= 0] - 1]) and np.array_equal(part[s >= t[:E]], full[s >= t[:E]])
+
+
+def test_step_launch_finish_two_ctxs_one_thread(orc):
+    """One host thread keeps two ctxs (here on one GPU; one per GPU in a multi-GPU host) in flight: launch both steps, then
+    finish both.  Same resident graphs as the blocking call."""
+    from test_gpu_parity import _resident_graph
+    w = mp.workloads.make("t", 30000, 4, 40, 0.05, 0.12, seed=9)
+    cs = [mp.Context(0) for _ in range(2)]
+    try:
+        for g, c in enumerate(cs):
+            c.set_shard(g, 2); c.set_option("rebuild_index", 1)
+            c.upload_samples(w.X); c.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+        ref = []
+        for c in cs:
+            c.graph_step_device(w.r)
+            ref.append(_resident_graph(c, w.N))
+        with pytest.raises(mp.MPFMTError) as e:
+            cs[0].graph_step_finish()
+        assert e.value.code == L.ERR_STATE
+        for rep in range(3):                                     # speculative from the first repeat on
+            for c in cs:
+                c.graph_step_launch(w.r)
+            for c, want in zip(cs, ref):
+                c.graph_step_finish()
+                for a, b in zip(_resident_graph(c, w.N), want):
+                    assert np.array_equal(a, b)
+        with pytest.raises(mp.MPFMTError) as e:                  # expand needs all columns: refused on a shard
+            cs[0].expand(np.zeros(L.nwords(w.N), np.uint64), np.zeros(L.nwords(w.N), np.uint64), None, np.zeros(w.N), np.array([1]))
+        assert e.value.code == L.ERR_STATE
+    finally:
+        for c in cs:
+            c.close()
+
+
+def test_golden_di_pairs_on_the_device(orc):
+    """the committed double-integrator pairs -> (cost, t*) through mpfmt_di_steer, bit for bit."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "di_pairs.npz"))
+    with mp.Context(0) as c:
+        cost, topt = c.di_steer(z["X0"], z["X1"], float(z["rho"]), float(z["r"]))
+    assert np.array_equal(cost, z["cost"]) and np.array_equal(topt, z["topt"])

@@ -96,3 +96,42 @@ def test_bench_gpus_flag_is_honoured():
     env2 = dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=300)
     assert p.returncode == 2 and "does not match WORLD_SIZE" in p.stderr
+
+
+def test_host_side_under_asan_ubsan(orc, tmp_path):
+    """The host part of libmpfmt.so (mpfmt_host.cpp: sequential recursion, directed recursion, import validation) built with
+    -fsanitize=address,undefined and run on an oracle-made graph: no sanitizer report, and the tree equals the oracle's."""
+    import ctypes
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(ROOT, "motionplanning.jl_amd", "csrc")
+    exe = str(tmp_path / "host_asan")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off",
+                           os.path.join(ROOT, "tests", "asan", "host_asan.cpp"), os.path.join(csrc, "mpfmt_host.cpp"), "-o", exe])
+    w = mp.workloads.make("t", 1500, 3, 30, 0.05, 0.12, seed=8, goal_radius=0.1)
+    colptr, rowval, nzval = orc.rdisc_graph(w.X, w.r)
+    emask = orc.graph_edges_free(w.X, colptr, rowval, w.lohi, w.ss_lo, w.ss_hi)
+    F = orc.points_free(w.X, w.lohi, w.ss_lo, w.ss_hi)
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(np.array([w.N, w.d, len(rowval), 1], dtype=np.int64).tobytes())
+        f.write(w.X.tobytes()); f.write(colptr.astype(np.int64).tobytes()); f.write(rowval.astype(np.int32).tobytes())
+        f.write(nzval.tobytes()); f.write(emask.tobytes()); f.write(F.tobytes())
+        f.write(w.ss_lo.tobytes()); f.write(w.ss_hi.tobytes()); f.write(w.goal_params().tobytes())
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "ERROR" not in p.stderr and "runtime error" not in p.stderr, p.stderr
+    buf = open(tmp_path / "out.bin", "rb").read()
+    R = mp._lib.FmtResult
+    res = R.from_buffer_copy(buf, 0)
+    o = ctypes.sizeof(R)
+    N = w.N
+    A = np.frombuffer(buf, np.int64, N, o); Cc = np.frombuffer(buf, np.float64, N, o + 8 * N)
+    path = np.frombuffer(buf, np.int64, res.path_len, o + 16 * N)
+    res2 = R.from_buffer_copy(buf, o + 16 * N + 8 * res.path_len)
+    ref = orc.fmtstar_graph(w.X, colptr, rowval, nzval, emask, F, orc.GOAL_BALL, w.goal_params(), w.lohi, w.ss_lo, w.ss_hi)
+    assert res.status == ref["status"] and res.collision_checks == ref["collision_checks"] and res.cost == ref["cost"]
+    assert np.array_equal(A - 1, ref["A"]) and np.array_equal(Cc, ref["C"]) and np.array_equal(path - 1, ref["path"])
+    # the directed recursion on a symmetric graph is the same recursion
+    assert res2.status == res.status and res2.cost == res.cost and res2.collision_checks == res.collision_checks

@@ -477,3 +477,39 @@ def test_out_of_bounds_parent_is_not_counted(orc):
     colptr, rowval, nzval = orc.rdisc_graph(X, r)
     counted_all = orc.fmtstar(X, r, orc.GOAL_BALL, goal, lohi, np.full(2, -1.0), np.full(2, 2.0), checkpts=False, nn_mode=1)
     assert counted_all["collision_checks"] != res["collision_checks"] or not np.array_equal(counted_all["A"], res["A"])
+
+
+def test_golden_stream_heads_and_splitmix_known_answer(orc):
+    """the workload stream is SplitMix64 -- pinned to the published known answers of the generator and to the
+    committed heads of every seed the workloads use; the numpy and the C restatement agree."""
+    import json
+    import motionplanning_jl_amd as mp
+    g = json.load(open(os.path.join(G, "stream_heads.json")))
+    kat = [6457827717110365317, 3203168211198807973, 9817491932198370423, 4593380528125082431, 16408922859458223821]
+    assert [int(x) for x in g["splitmix64_seed_1234567_first5"]] == kat
+    assert [int(x) for x in mp.workloads.splitmix64(1234567, 5)] == kat
+    assert [orc.splitmix64(1234567, i) for i in range(5)] == kat
+    for seed, head in g["heads"].items():
+        want = np.array([float.fromhex(h) for h in head])
+        assert np.array_equal(mp.workloads.Stream(int(seed)).random((16,)), want)
+        assert np.array_equal(orc.stream_uniform(int(seed), 16), want)
+    st = mp.workloads.Stream(3)
+    a = np.concatenate([st.random((5, 3)).ravel(), st.random((7,))])
+    assert np.array_equal(a, orc.stream_uniform(3, 22)) and a.min() >= 0.0 and a.max() < 1.0
+
+
+def test_golden_di_pairs(orc):
+    """512 double-integrator pairs -> (cost, t*) and the 5 collision waypoints."""
+    z = np.load(os.path.join(G, "di_pairs.npz"))
+    rho, r = float(z["rho"]), float(z["r"])
+    for i in range(len(z["X0"])):
+        c, t = orc.di_steer(z["X0"][i], z["X1"][i], rho, r)
+        assert c == z["cost"][i] and t == z["topt"][i]
+        assert np.array_equal(orc.di_waypoints(z["X0"][i], z["X1"][i], rho, r), z["waypoints"][i], equal_nan=True)   # t* = 0: 0/0 as in the reference
+    assert z["cost"][5] == 0.0 and z["topt"][5] == 0.0
+    inside = z["cost"] <= r
+    assert 100 < inside.sum() < 500
+    ok = np.arange(len(z["X0"])) != 5
+    # a waypoint set starts at x0 and, for a pair within the radius, ends at x1 (to rounding)
+    assert np.array_equal(z["waypoints"][ok, 0], z["X0"][ok])
+    assert np.abs(z["waypoints"][inside & ok, 4] - z["X1"][inside & ok]).max() < 1e-12
