@@ -620,7 +620,7 @@ int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usab
     const double ftz = 1.25e-4;
     const double T = Rh * Rh * (1.0 + 1e-6) + 2e-5 * d + ftz;
     // the filter is only worth running when the shell is thin compared with the ball
-    if (shell > 0.08 * s * r || ftz > 0.16 * (s * r) * (s * r)) return MPFMT_OK;
+    if (shell > 0.08 * s * r || ftz > 2.0 * (s * r) * (s * r)) return MPFMT_OK;
     *negT_out = -(float)(T * (1.0 + 1e-6));
     *usable = true;
     ctx->mf_scale = s;

@@ -546,7 +546,8 @@ static void wf_fill_info(const mpfmt_wf* s, mpfmt_wf_info* info)
     const bool goal = c.goal_cbits != ~0ull;
     info->done = goal ? 1 : c.done;
     info->nz = c.done == 2 ? 0 : c.nz; info->nx = c.nx; info->nconn = c.nconn; info->ntrip = c.ntrip;
-    info->iters = c.iters; info->checks = c.checks; info->cmin = c.cmin;
+    info->iters = c.iters - (c.done == 2 ? 1 : 0);       // the step that found the open set empty expanded no batch
+    info->checks = c.checks; info->cmin = c.cmin;
     // the totals on the device are brought up to date at the start of the following step
     info->tot_z = c.tot_z + info->nz; info->tot_x = c.tot_x + c.nx; info->tot_conn = c.tot_conn + c.nconn;
 }
