@@ -32,24 +32,22 @@
 #include <vector>
 
 #define WF_MAXPARTS 1024
+#define WF_MAXBLK 4096            // per-block statistics slots (no hot atomics: a single address sustains ~90 atomics / us)
 
 struct wf_goal { int32_t kind; int32_t gd; double g[2 * MPFMT_MAX_DIM + 1]; };
 
 struct wf_ctr {
     int32_t done;                 // 0 running, 2 open set exhausted, 1 goal in batch (set by k_wf_final; while running the
                                   // goal condition is goal_cbits != ~0, see wf_stop)
-    int32_t nz, nz_prev;          // batch size of this / the previous step
-    int32_t nx;                   // candidates of this step
-    int32_t nconn;                // connections of this step
     int32_t ntrip;                // triples emitted this step (sharded)
-    int64_t checks;               // collision checks so far (this rank)
     int64_t iters;
     unsigned long long goal_cbits;   // lowest cost (as bits) of a goal node in the batch, ~0 = none
     int64_t final_z;              // resolved by k_wf_final
     double cmin;                  // lowest open cost at this step
     int64_t imin;
-    int64_t tot_z, tot_x, tot_conn;
+    int64_t tot[4];               // sums of the per-block statistics: batch nodes, samples examined, connected, edge checks
 };
+enum { WF_NZ = 0, WF_NX = 1, WF_NCONN = 2, WF_CHECKS = 3 };
 
 // the solve has ended: every kernel enqueued after that point returns at once and the sets stay as they were
 __device__ __forceinline__ bool wf_stop(const wf_ctr* c) { return c->done != 0 || c->goal_cbits != ~0ull; }
@@ -59,17 +57,21 @@ struct wf_trip { int32_t x, y; double c; };
 
 struct mpfmt_wf {
     int64_t N = 0, words = 0;
-    uint64_t *W = nullptr, *H = nullptr, *Z = nullptr, *Hn = nullptr, *cand = nullptr, *F = nullptr;
+    uint64_t *W = nullptr, *H = nullptr, *Z = nullptr, *Zp = nullptr, *Hn = nullptr, *cand = nullptr, *F = nullptr;
     double* C = nullptr;
     int32_t* A = nullptr;
-    int32_t *zlist = nullptr, *xlist = nullptr;
-    double* part_c = nullptr; int64_t* part_i = nullptr;
+    double* part_c = nullptr; int64_t* part_i = nullptr;          // per-block lexicographic minima of the open set
+    double* last_c = nullptr; int64_t* last_i = nullptr;          // per-block lexicographic maxima of the batch (last node in pop order)
+    int64_t* stats = nullptr;     // [WF_MAXBLK][4] per-block cumulative statistics
+    double* boxT = nullptr;       // obstacle set transposed [2*d][mpad]: lane = obstacle reads are coalesced
+    int mpad = 0;
     wf_trip* mytrips = nullptr;   // [N] connections of this rank in the current step (sharded)
     wf_trip* xbuf = nullptr;      // [world][WF_XCAP + 1] exchange slots: header (x = the rank's total count) + one round's triples
     wf_trip* hdr_host = nullptr;  // pinned [world] headers of the last exchange round
     int world_alloc = 0;
     wf_ctr* ctr = nullptr;        // device
     wf_ctr* ctr_host = nullptr;   // pinned
+    int64_t prev_tot[4] = {0, 0, 0, 0};
     int64_t* path_dev = nullptr;
     wf_goal goal;
     double band = 0.0;
@@ -111,9 +113,24 @@ __device__ __forceinline__ void wf_lexmin_wave(double& c, int64_t& i)
         if (oi >= 0 && (i < 0 || oc < c || (oc == c && oi < i))) { c = oc; i = oi; }
     }
 }
+__device__ __forceinline__ void wf_lexmax_wave(double& c, int64_t& i)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oc = __shfl_xor(c, off);
+        const int64_t oi = __shfl_xor(i, off);
+        if (oi >= 0 && (i < 0 || oc > c || (oc == c && oi > i))) { c = oc; i = oi; }
+    }
+}
 
-__global__ __launch_bounds__(64) void k_wf_init(int64_t N, int64_t words, int64_t init, uint64_t* W, uint64_t* H, uint64_t* Z,
-                                                uint64_t* Hn, uint64_t* cand, double* C, int32_t* A, wf_ctr* ctr)
+// statistics of one block: added to the block's own slot (the only writer of that slot; launches on a stream are ordered)
+__device__ __forceinline__ void wf_block_stat(int64_t* stats, int which, int v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd((unsigned long long*)&stats[(blockIdx.x % WF_MAXBLK) * 4 + which], (unsigned long long)v);
+}
+
+__global__ __launch_bounds__(64) void k_wf_init(int64_t N, int64_t words, int64_t init, uint64_t* W, uint64_t* H, uint64_t* Z, uint64_t* Zp,
+                                                uint64_t* Hn, uint64_t* cand, double* C, int32_t* A, int64_t* stats, wf_ctr* ctr)
 {
     const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
     for (int64_t w = t; w < words; w += (int64_t)gridDim.x * 64) {
@@ -121,9 +138,10 @@ __global__ __launch_bounds__(64) void k_wf_init(int64_t N, int64_t words, int64_
         if (w == words - 1 && (N & 63)) full = (1ull << (N & 63)) - 1;
         if (w == (init >> 6)) { W[w] = full & ~(1ull << (init & 63)); H[w] = 1ull << (init & 63); }
         else { W[w] = full; H[w] = 0; }
-        Z[w] = 0; Hn[w] = 0; cand[w] = 0;
+        Z[w] = 0; Zp[w] = 0; Hn[w] = 0; cand[w] = 0;
     }
     for (int64_t i = t; i < N; i += (int64_t)gridDim.x * 64) { C[i] = 0.0; A[i] = -1; }
+    for (int64_t i = t; i < WF_MAXBLK * 4; i += (int64_t)gridDim.x * 64) stats[i] = 0;
     if (t == 0) {
         wf_ctr z;
         memset(&z, 0, sizeof z);
@@ -132,21 +150,18 @@ __global__ __launch_bounds__(64) void k_wf_init(int64_t N, int64_t words, int64_
     }
 }
 
-__global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __restrict__ H, uint64_t* __restrict__ Z,
+__global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __restrict__ H, uint64_t* __restrict__ Z, uint64_t* __restrict__ Zp,
                                                      uint64_t* __restrict__ Hn, uint64_t* __restrict__ cand,
                                                      const double* __restrict__ C, double* __restrict__ part_c,
                                                      int64_t* __restrict__ part_i, wf_ctr* __restrict__ ctr)
 {
     if (wf_stop(ctr)) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {          // totals of the finished step, then the per-step counters start over
-        ctr->tot_z += ctr->nz; ctr->tot_x += ctr->nx; ctr->tot_conn += ctr->nconn;      // (no other thread of this kernel
-        ctr->nz_prev = ctr->nz; ctr->nz = 0; ctr->nx = 0; ctr->nconn = 0; ctr->ntrip = 0;   //  touches these fields)
-        ctr->iters += 1;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr->iters += 1; ctr->ntrip = 0; }
     double bc = 0.0; int64_t bi = -1;
     for (int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 64) {
-        uint64_t h = (H[w] & ~Z[w]) | Hn[w];
-        H[w] = h; Z[w] = 0; Hn[w] = 0; cand[w] = 0;
+        const uint64_t z = Z[w];
+        uint64_t h = (H[w] & ~z) | Hn[w];                     // fmt.jl:83-84 for the batch of the previous step
+        H[w] = h; Zp[w] = z; Z[w] = 0; Hn[w] = 0; cand[w] = 0;
         while (h) {
             const int b = __ffsll((long long)h) - 1;
             h &= h - 1;
@@ -159,13 +174,12 @@ __global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __
     if (threadIdx.x == 0) { part_c[blockIdx.x] = bc; part_i[blockIdx.x] = bi; }
 }
 
-// `done` / goal_cbits are only ever written here AFTER every block has passed its entry test: goal_cbits by atomicMin from
-// blocks that did select (a late block that sees it set must still select, hence the entry test reads `done` alone --
-// done == 2 is decided identically by every block from the partials)
+// goal_cbits is written (atomicMin) only by blocks that have passed the entry test, which therefore reads `done` alone: a
+// block starting late must still select its words.  done = 2 is decided identically by every block from the partials.
 __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, const uint64_t* __restrict__ H, uint64_t* __restrict__ Z,
                                                   const double* __restrict__ C, const double* __restrict__ X, int d,
                                                   const double* __restrict__ part_c, const int64_t* __restrict__ part_i,
-                                                  double band, int single, wf_goal G, int32_t* __restrict__ zlist,
+                                                  double band, int single, wf_goal G, int64_t* __restrict__ stats,
                                                   wf_ctr* __restrict__ ctr)
 {
     if (ctr->done) return;
@@ -181,6 +195,7 @@ __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, con
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { ctr->cmin = cm; ctr->imin = im; }
     const double thr = cm + band;
+    int nsel = 0;
     for (int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 64) {
         uint64_t h = H[w], z = 0;
         while (h) {
@@ -194,65 +209,83 @@ __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, con
             if (wf_is_goal(X + i * d, G))           // fmt.jl:68
                 atomicMin(&ctr->goal_cbits, (unsigned long long)__double_as_longlong(c));
         }
-        if (z) {
-            Z[w] = z;
-            int o = atomicAdd(&ctr->nz, __popcll(z));             // one atomic per word, not per node
-            while (z) { const int b = __ffsll((long long)z) - 1; z &= z - 1; zlist[o++] = (int32_t)(w * 64 + b); }
-        }
+        if (z) { Z[w] = z; nsel += __popcll(z); }
     }
+    wf_block_stat(stats, WF_NZ, nsel);
 }
 
-// the node the reference's loop would end on: goal node of lowest (cost, index) in the batch, or -- open set exhausted --
-// the last node of the previous batch in pop order = highest (cost, index) (fmt.jl:85-89 leaves z at the last dequeued node)
-__global__ __launch_bounds__(64) void k_wf_final(const int32_t* __restrict__ zlist, const double* __restrict__ C, const double* __restrict__ X,
-                                                 int d, wf_goal G, wf_ctr* __restrict__ ctr)
+// the node the reference's loop would end on: goal node of lowest (cost, index) in the batch Z, or -- open set exhausted --
+// the last node of the previous batch Zp in pop order = highest (cost, index) (fmt.jl:85-89 leaves z at the last dequeued node)
+__global__ __launch_bounds__(64) void k_wf_final(int64_t words, const uint64_t* __restrict__ Z, const uint64_t* __restrict__ Zp,
+                                                 const double* __restrict__ C, const double* __restrict__ X, int d, wf_goal G,
+                                                 wf_ctr* __restrict__ ctr)
 {
     const bool goal = ctr->goal_cbits != ~0ull;
     if (!goal && ctr->done != 2) return;
-    const int n = goal ? ctr->nz : ctr->nz_prev;
+    const uint64_t* S = goal ? Z : Zp;
     double bc = 0.0; int64_t bi = -1;
-    for (int k = threadIdx.x; k < n; k += 64) {
-        const int64_t i = zlist[k];
-        const double c = C[i];
-        if (goal) {
-            if (!wf_is_goal(X + i * d, G)) continue;
-            if (bi < 0 || c < bc || (c == bc && i < bi)) { bc = c; bi = i; }
-        } else {
-            if (bi < 0 || c > bc || (c == bc && i > bi)) { bc = c; bi = i; }
+    for (int64_t w = threadIdx.x; w < words; w += 64) {
+        uint64_t m = S[w];
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int64_t i = w * 64 + b;
+            const double c = C[i];
+            if (goal) {
+                if (!wf_is_goal(X + i * d, G)) continue;
+                if (bi < 0 || c < bc || (c == bc && i < bi)) { bc = c; bi = i; }
+            } else {
+                if (bi < 0 || c > bc || (c == bc && i > bi)) { bc = c; bi = i; }
+            }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oc = __shfl_xor(bc, off);
-        const int64_t oi = __shfl_xor(bi, off);
-        const bool take = (oi >= 0) && (bi < 0 || (goal ? (oc < bc || (oc == bc && oi < bi)) : (oc > bc || (oc == bc && oi > bi))));
-        if (take) { bc = oc; bi = oi; }
-    }
+    if (goal) wf_lexmin_wave(bc, bi); else wf_lexmax_wave(bc, bi);
     if (threadIdx.x == 0) {
         if (bi >= 0) ctr->final_z = bi;
         if (goal) ctr->done = 1;
     }
 }
 
-// mark pass, one wavefront per batch node (symmetric metric: forward set == column, nearneighbors.jl:200-203)
-__global__ __launch_bounds__(256) void k_wf_mark(const int32_t* __restrict__ zlist, const int64_t* __restrict__ colptr,
+__global__ __launch_bounds__(256) void k_wf_sum_stats(const int64_t* __restrict__ stats, wf_ctr* __restrict__ ctr)
+{
+    __shared__ long long acc[4];
+    if (threadIdx.x < 4) acc[threadIdx.x] = 0;
+    __syncthreads();
+    long long v[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < WF_MAXBLK; b += blockDim.x)
+        for (int k = 0; k < 4; ++k) v[k] += stats[b * 4 + k];
+    for (int k = 0; k < 4; ++k) {
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
+        if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)&acc[k], (unsigned long long)v[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) ctr->tot[threadIdx.x] = acc[threadIdx.x];
+}
+
+// mark pass: one wavefront per word of the batch mask; for every batch node of the word the wavefront walks the node's column
+// (symmetric metric: forward set == column, nearneighbors.jl:200-203) and sets the candidate bit of every unvisited valid row
+__global__ __launch_bounds__(256) void k_wf_mark(int64_t words, const uint64_t* __restrict__ Z, const int64_t* __restrict__ colptr,
                                                  const int32_t* __restrict__ rowval, const uint64_t* __restrict__ W,
                                                  const uint64_t* __restrict__ F, unsigned long long* __restrict__ cand,
-                                                 int32_t* __restrict__ xlist, wf_ctr* __restrict__ ctr)
+                                                 const wf_ctr* __restrict__ ctr)
 {
     if (wf_stop(ctr)) return;
     const int lane = threadIdx.x & 63;
-    const int nz = ctr->nz;
     const int wpb = blockDim.x >> 6;
-    for (int iz = blockIdx.x * wpb + (threadIdx.x >> 6); iz < nz; iz += gridDim.x * wpb) {
-        const int64_t z = zlist[iz];
-        const int64_t beg = colptr[z], end = colptr[z + 1];
-        for (int64_t e = beg + lane; e < end; e += 64) {
-            const int64_t x = rowval[e];
-            if (!wf_bit(W, x) || (F && !wf_bit(F, x))) continue;          // fmt.jl:70-71
-            const unsigned long long bit = 1ull << (x & 63);
-            if (cand[x >> 6] & bit) continue;                             // seen already (a stale read only costs an atomic)
-            const unsigned long long old = atomicOr(&cand[x >> 6], bit);
-            if (!(old & bit)) xlist[atomicAdd(&ctr->nx, 1)] = (int32_t)x;
+    for (int64_t w = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); w < words; w += (int64_t)gridDim.x * wpb) {
+        uint64_t zm = Z[w];
+        while (zm) {
+            const int b = __ffsll((long long)zm) - 1;
+            zm &= zm - 1;
+            const int64_t z = w * 64 + b;
+            const int64_t beg = colptr[z], end = colptr[z + 1];
+            for (int64_t e = beg + lane; e < end; e += 64) {
+                const int64_t x = rowval[e];
+                if (!wf_bit(W, x) || (F && !wf_bit(F, x))) continue;          // fmt.jl:70-71
+                const unsigned long long bit = 1ull << (x & 63);
+                if (cand[x >> 6] & bit) continue;                             // seen already (a stale read only costs an atomic)
+                atomicOr(&cand[x >> 6], bit);
+            }
         }
     }
 }
@@ -262,8 +295,8 @@ __global__ __launch_bounds__(256) void k_wf_mark(const int32_t* __restrict__ zli
 __global__ __launch_bounds__(256) void k_wf_mark_owned(const int32_t* __restrict__ perm, int64_t p_begin, int64_t p_end,
                                                        const int64_t* __restrict__ colptr, const int32_t* __restrict__ rowval,
                                                        const uint64_t* __restrict__ W, const uint64_t* __restrict__ F,
-                                                       const uint64_t* __restrict__ Z, int32_t* __restrict__ xlist,
-                                                       wf_ctr* __restrict__ ctr)
+                                                       const uint64_t* __restrict__ Z, unsigned long long* __restrict__ cand,
+                                                       const wf_ctr* __restrict__ ctr)
 {
     if (wf_stop(ctr)) return;
     const int lane = threadIdx.x & 63;
@@ -278,102 +311,112 @@ __global__ __launch_bounds__(256) void k_wf_mark_owned(const int32_t* __restrict
             const bool mine = (e < end) && wf_bit(Z, rowval[e]);
             hit = __ballot(mine) != 0;
         }
-        if (hit && lane == 0) xlist[atomicAdd(&ctr->nx, 1)] = (int32_t)x;
+        if (hit && lane == 0) atomicOr(&cand[x >> 6], 1ull << (x & 63));
     }
 }
 
-// obstacle k of the transposed staging [2*D][mpad]: lane = obstacle reads consecutive words (no bank conflicts)
+// obstacle k of the transposed table [2*D][mpad]: lane = obstacle reads consecutive words
 template <int D>
-__device__ __forceinline__ box_regs<D> wf_load_box_T(const double* sT, int mpad, int k)
+__device__ __forceinline__ box_regs<D> wf_load_box_T(const double* __restrict__ bT, int mpad, int k)
 {
     box_regs<D> b;
 #pragma unroll
-    for (int i = 0; i < D; ++i) { b.lo[i] = sT[i * mpad + k]; b.hi[i] = sT[(D + i) * mpad + k]; }
+    for (int i = 0; i < D; ++i) { b.lo[i] = bT[i * mpad + k]; b.hi[i] = bT[(D + i) * mpad + k]; }
     return b;
 }
 
-// one wavefront per candidate x.  MODE 0: connect in place; MODE 1: emit triples (sharded)
+__global__ void k_wf_box_transpose(const double* __restrict__ boxes, int M, int d2, int mpad, double* __restrict__ bT)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= mpad * d2) return;
+    const int j = t / mpad, k = t - j * mpad;
+    bT[t] = boxes[(int64_t)min(k, M - 1) * d2 + j];               // padding repeats the last box
+}
+
+// one wavefront per word of the candidate mask, one candidate x at a time.  MODE 0: connect in place; MODE 1: emit triples
 template <int D, int MODE>
-__global__ __launch_bounds__(256) void k_wf_connect(const int32_t* __restrict__ xlist, const int64_t* __restrict__ colptr,
+__global__ __launch_bounds__(256) void k_wf_connect(int64_t words, const unsigned long long* __restrict__ cand, const int64_t* __restrict__ colptr,
                                                     const int32_t* __restrict__ rowval, const double* __restrict__ nzval,
                                                     const uint64_t* __restrict__ H, double* __restrict__ C, int32_t* __restrict__ A,
                                                     unsigned long long* __restrict__ W, unsigned long long* __restrict__ Hn,
-                                                    const double* __restrict__ X, const double* __restrict__ boxes, int M, int mpad,
+                                                    const double* __restrict__ X, const double* __restrict__ bT, int M, int mpad,
                                                     mpfmt_ss ss, const uint64_t* __restrict__ gfree, wf_trip* __restrict__ mytrips,
-                                                    wf_ctr* __restrict__ ctr)
+                                                    int64_t* __restrict__ stats, wf_ctr* __restrict__ ctr)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     if (wf_stop(ctr)) return;
-    double* sT = (double*)smem;
-    if (!gfree && mpad) {                                               // obstacle set staged once per workgroup, transposed
-        for (int t = threadIdx.x; t < M * 2 * D; t += blockDim.x) {
-            const int k = t / (2 * D), j = t - k * 2 * D;
-            sT[j * mpad + k] = boxes[t];
-        }
-        __syncthreads();
-    }
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
-    const int nx = ctr->nx;
-    int my_checks = 0;
-    for (int ix = blockIdx.x * wpb + (threadIdx.x >> 6); ix < nx; ix += gridDim.x * wpb) {
-        const int64_t x = xlist[ix];
-        const int64_t beg = colptr[x], end = colptr[x + 1];
-        double best = 0.0;
-        int64_t be = -1;
-        for (int64_t e = beg + lane; e < end; e += 64) {                   // nearB(V, x, r, H) + findmin, fmt.jl:72-74
-            const int64_t y = rowval[e];
-            if (!wf_bit(H, y)) continue;
-            const double c = C[y] + nzval[e];
-            if (be < 0 || c < best) { best = c; be = e; }                  // ascending e per lane keeps the first minimum
-        }
-        wf_lexmin_wave(best, be);                                          // rows ascend with e: first minimum = lowest e
-        if (be < 0) continue;
-        const int64_t y = rowval[be];
-        double v[D], w[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) { v[i] = X[y * D + i]; w[i] = X[x * D + i]; }
-        const bool inb = in_state_space_sl<D>(v, ss);                      // statespaces.jl:155: first point of the segment
-        if (lane == 0 && inb) ++my_checks;                                 // boxesND.jl:26 is reached only then
-        bool fr;
-        if (gfree) {
-            fr = wf_bit(gfree, be);
-        } else {
-            double l[D], h[D];
-            seg_bbox<D>(v, w, l, h);
-            bool blocked = false;
-            for (int k0 = 0; k0 < M; k0 += 64) {                           // lane = obstacle (boxesND.jl:52-56; @all in any order)
-                const int k = k0 + lane;
-                const int kk = min(k, M - 1);
-                const box_regs<D> b = mpad ? wf_load_box_T<D>(sT, mpad, kk) : load_box<D>(boxes, kk);
-                const bool pend = (k < M) && !broadphase_free_sl<D>(l, h, b);
-                if (__ballot(pend)) {
-                    if (pend) blocked = blocked || !narrow_free_sl<D>(v, w, b);
-                }
+    int my_nx = 0, my_checks = 0, my_conn = 0;                             // lane 0 counts for its wavefront
+    for (int64_t wd = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); wd < words; wd += (int64_t)gridDim.x * wpb) {
+        unsigned long long xm = cand[wd];
+        while (xm) {
+            const int xb = __ffsll((long long)xm) - 1;
+            xm &= xm - 1;
+            const int64_t x = wd * 64 + xb;
+            const int64_t beg = colptr[x], end = colptr[x + 1];
+            double best = 0.0;
+            int64_t be = -1;
+            for (int64_t e = beg + lane; e < end; e += 64) {               // nearB(V, x, r, H) + findmin, fmt.jl:72-74
+                const int64_t y = rowval[e];
+                if (!wf_bit(H, y)) continue;
+                const double c = C[y] + nzval[e];
+                if (be < 0 || c < best) { best = c; be = e; }              // ascending e per lane keeps the first minimum
             }
-            fr = inb && (__ballot(blocked) == 0);
-        }
-        if (fr && lane == 0) {                                             // fmt.jl:76-80
-            if (MODE == 0) {
-                A[x] = (int32_t)y; C[x] = best;
-                atomicAnd(&W[x >> 6], ~(1ull << (x & 63)));
-                atomicOr(&Hn[x >> 6], 1ull << (x & 63));
-                atomicAdd(&ctr->nconn, 1);
+            wf_lexmin_wave(best, be);                                      // rows ascend with e: first minimum = lowest e
+            if (lane == 0) ++my_nx;
+            if (be < 0) continue;
+            const int64_t y = rowval[be];
+            double v[D], w[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { v[i] = X[y * D + i]; w[i] = X[x * D + i]; }
+            const bool inb = in_state_space_sl<D>(v, ss);                  // statespaces.jl:155: first point of the segment
+            if (lane == 0 && inb) ++my_checks;                             // boxesND.jl:26 is reached only then
+            bool fr;
+            if (gfree) {
+                fr = wf_bit(gfree, be);
             } else {
-                wf_trip r; r.x = (int32_t)x; r.y = (int32_t)y; r.c = best;
-                mytrips[atomicAdd(&ctr->ntrip, 1)] = r;                    // at most one per owned candidate: capacity N holds
+                double l[D], h[D];
+                seg_bbox<D>(v, w, l, h);
+                bool blocked = false;
+                for (int k0 = 0; k0 < M; k0 += 64) {                       // lane = obstacle (boxesND.jl:52-56; @all in any order)
+                    const int k = k0 + lane;
+                    const box_regs<D> b = wf_load_box_T<D>(bT, mpad, k);   // k < mpad always: the table is padded to 64 lanes
+                    const bool pend = (k < M) && !broadphase_free_sl<D>(l, h, b);
+                    if (__ballot(pend)) {
+                        if (pend) blocked = blocked || !narrow_free_sl<D>(v, w, b);
+                    }
+                }
+                fr = inb && (__ballot(blocked) == 0);
+            }
+            if (fr && lane == 0) {                                         // fmt.jl:76-80
+                if (MODE == 0) {
+                    A[x] = (int32_t)y; C[x] = best;
+                    atomicAnd(&W[x >> 6], ~(1ull << (x & 63)));
+                    atomicOr(&Hn[x >> 6], 1ull << (x & 63));
+                    ++my_conn;
+                } else {
+                    wf_trip r; r.x = (int32_t)x; r.y = (int32_t)y; r.c = best;
+                    mytrips[atomicAdd(&ctr->ntrip, 1)] = r;                // at most one per owned candidate: capacity N holds
+                }
             }
         }
     }
-    if (lane == 0 && my_checks) atomicAdd((unsigned long long*)&ctr->checks, (unsigned long long)my_checks);
+    wf_block_stat(stats, WF_NX, my_nx);
+    wf_block_stat(stats, WF_CHECKS, my_checks);
+    wf_block_stat(stats, WF_NCONN, my_conn);
 }
 
 // exchange round `round` of this rank: header (x = total count of the step; 0 once the solve has ended) + its chunk
-__global__ __launch_bounds__(256) void k_wf_pack(const wf_trip* __restrict__ mytrips, int round, wf_trip* __restrict__ slot, const wf_ctr* __restrict__ ctr)
+__global__ __launch_bounds__(256) void k_wf_pack(const wf_trip* __restrict__ mytrips, int round, wf_trip* __restrict__ slot,
+                                                 const int64_t* __restrict__ stats, const wf_ctr* __restrict__ ctr)
 {
     const int total = wf_stop(ctr) ? 0 : ctr->ntrip;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) { wf_trip hd; hd.x = total; hd.y = round; hd.c = (double)ctr->checks; slot[0] = hd; }   // c: this rank's edge checks so far
+    if (t == 0) {
+        long long checks = 0;
+        for (int b = 0; b < WF_MAXBLK; ++b) checks += stats[b * 4 + WF_CHECKS];
+        wf_trip hd; hd.x = total; hd.y = round; hd.c = (double)checks; slot[0] = hd;            // c: this rank's edge checks so far
+    }
     const int64_t src = (int64_t)round * WF_XCAP + t;
     if (t < WF_XCAP && src < total) slot[1 + t] = mytrips[src];
 }
@@ -381,7 +424,7 @@ __global__ __launch_bounds__(256) void k_wf_pack(const wf_trip* __restrict__ myt
 // apply round `round` of `nslots` exchange slots
 __global__ __launch_bounds__(256) void k_wf_commit(const wf_trip* __restrict__ xbuf, int nslots, int round,
                                                    double* __restrict__ C, int32_t* __restrict__ A, unsigned long long* __restrict__ W,
-                                                   unsigned long long* __restrict__ Hn, wf_ctr* __restrict__ ctr)
+                                                   unsigned long long* __restrict__ Hn, int64_t* __restrict__ stats, wf_ctr* __restrict__ ctr)
 {
     if (wf_stop(ctr)) return;
     for (int s = 0; s < nslots; ++s) {
@@ -395,7 +438,7 @@ __global__ __launch_bounds__(256) void k_wf_commit(const wf_trip* __restrict__ x
             atomicAnd(&W[x >> 6], ~(1ull << (x & 63)));
             atomicOr(&Hn[x >> 6], 1ull << (x & 63));
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&ctr->nconn, (int)n);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && n) stats[WF_NCONN] += n;
     }
 }
 
@@ -415,12 +458,6 @@ __global__ void k_wf_A_to_i64(const int32_t* __restrict__ A, int64_t N, int64_t*
     if (i < N) out[i] = (int64_t)A[i] + 1;
 }
 
-__global__ void k_wf_zs_to_i64(const int32_t* __restrict__ zl, int64_t n, int64_t* __restrict__ out)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (int64_t)zl[i] + 1;
-}
-
 // ---- host side -----------------------------------------------------------------------------------------------------
 
 static mpfmt_wf* wf_of(mpfmt_ctx* ctx) { return (mpfmt_wf*)ctx->wf; }
@@ -429,7 +466,8 @@ void mpfmt_wf_free(mpfmt_ctx* ctx)
 {
     mpfmt_wf* s = wf_of(ctx);
     if (!s) return;
-    void* bufs[] = {s->W, s->H, s->Z, s->Hn, s->cand, s->F, s->C, s->A, s->zlist, s->xlist, s->part_c, s->part_i, s->mytrips, s->xbuf, s->ctr, s->path_dev};
+    void* bufs[] = {s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->F, s->C, s->A, s->part_c, s->part_i, s->stats, s->boxT, s->mytrips, s->xbuf,
+                    s->ctr, s->path_dev};
     for (void* b : bufs) if (b) hipFree(b);
     if (s->ctr_host) hipHostFree(s->ctr_host);
     if (s->hdr_host) hipHostFree(s->hdr_host);
@@ -441,18 +479,19 @@ static int32_t wf_alloc(mpfmt_ctx* ctx, mpfmt_wf* s, int64_t N, int world)
 {
     const int64_t words = (N + 63) / 64;
     if (s->N != N) {
-        void** bufs[] = {(void**)&s->W, (void**)&s->H, (void**)&s->Z, (void**)&s->Hn, (void**)&s->cand, (void**)&s->F, (void**)&s->C,
-                         (void**)&s->A, (void**)&s->zlist, (void**)&s->xlist, (void**)&s->path_dev, (void**)&s->mytrips};
+        void** bufs[] = {(void**)&s->W, (void**)&s->H, (void**)&s->Z, (void**)&s->Zp, (void**)&s->Hn, (void**)&s->cand, (void**)&s->F,
+                         (void**)&s->C, (void**)&s->A, (void**)&s->path_dev, (void**)&s->mytrips};
         for (void** b : bufs) if (*b) { HIPCHK(ctx, hipFree(*b)); *b = nullptr; }
         HIPCHK(ctx, hipMalloc((void**)&s->W, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->H, 8 * words));
-        HIPCHK(ctx, hipMalloc((void**)&s->Z, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->Hn, 8 * words));
+        HIPCHK(ctx, hipMalloc((void**)&s->Z, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->Zp, 8 * words));
+        HIPCHK(ctx, hipMalloc((void**)&s->Hn, 8 * words));
         HIPCHK(ctx, hipMalloc((void**)&s->cand, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->F, 8 * words));
         HIPCHK(ctx, hipMalloc((void**)&s->C, 8 * N)); HIPCHK(ctx, hipMalloc((void**)&s->A, 4 * N));
-        HIPCHK(ctx, hipMalloc((void**)&s->zlist, 4 * N)); HIPCHK(ctx, hipMalloc((void**)&s->xlist, 4 * N));
         HIPCHK(ctx, hipMalloc((void**)&s->path_dev, 8 * (N + 1)));
         s->N = N; s->words = words;
     }
     if (!s->part_c) { HIPCHK(ctx, hipMalloc((void**)&s->part_c, 8 * WF_MAXPARTS)); HIPCHK(ctx, hipMalloc((void**)&s->part_i, 8 * WF_MAXPARTS)); }
+    if (!s->stats) HIPCHK(ctx, hipMalloc((void**)&s->stats, 8 * 4 * WF_MAXBLK));
     if (!s->ctr) { HIPCHK(ctx, hipMalloc((void**)&s->ctr, sizeof(wf_ctr))); HIPCHK(ctx, hipHostMalloc((void**)&s->ctr_host, sizeof(wf_ctr))); }
     if (world > 1) {
         if (!s->mytrips) HIPCHK(ctx, hipMalloc((void**)&s->mytrips, sizeof(wf_trip) * (size_t)N));
@@ -474,33 +513,28 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     const int nparts = s->nparts;
     hipStream_t st = ctx->stream;
     const int d = ctx->d;
-    hipLaunchKernelGGL(k_wf_apply_min, dim3(nparts), dim3(64), 0, st, words, s->H, s->Z, s->Hn, s->cand, s->C, s->part_c, s->part_i, s->ctr);
+    hipLaunchKernelGGL(k_wf_apply_min, dim3(nparts), dim3(64), 0, st, words, s->H, s->Z, s->Zp, s->Hn, s->cand, s->C, s->part_c, s->part_i, s->ctr);
     hipLaunchKernelGGL(k_wf_select, dim3(nparts), dim3(64), 0, st, words, nparts, s->H, s->Z, s->C, ctx->Xo, d, s->part_c, s->part_i, s->band,
-                       s->single, s->goal, s->zlist, s->ctr);
+                       s->single, s->goal, s->stats, s->ctr);
     const uint64_t* F = s->checkpts ? s->F : nullptr;
-    const int grid = ctx->num_cus * 8;
+    const int grid = (int)std::min<int64_t>((words + 3) / 4, (int64_t)ctx->num_cus * 8);      // one wavefront per mask word, 4 per block
     if (!s->sharded) {
-        hipLaunchKernelGGL(k_wf_mark, dim3(grid), dim3(256), 0, st, s->zlist, ctx->colptr, ctx->rowval, s->W, F,
-                           (unsigned long long*)s->cand, s->xlist, s->ctr);
+        hipLaunchKernelGGL(k_wf_mark, dim3(grid), dim3(256), 0, st, words, s->Z, ctx->colptr, ctx->rowval, s->W, F,
+                           (unsigned long long*)s->cand, s->ctr);
     } else {
         const int64_t pb = std::min<int64_t>(ctx->tile_begin * 64, ctx->N), pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
-        hipLaunchKernelGGL(k_wf_mark_owned, dim3(grid), dim3(256), 0, st, ctx->perm, pb, pe, ctx->colptr, ctx->rowval, s->W, F, s->Z,
-                           s->xlist, s->ctr);
+        hipLaunchKernelGGL(k_wf_mark_owned, dim3(ctx->num_cus * 8), dim3(256), 0, st, ctx->perm, pb, pe, ctx->colptr, ctx->rowval, s->W, F, s->Z,
+                           (unsigned long long*)s->cand, s->ctr);
     }
     const uint64_t* gfree = s->use_mask ? ctx->graph_free : nullptr;
-    const int mpad = ((ctx->M + 63) / 64) * 64 + 1;                      // odd row stride
-    const size_t box_bytes = sizeof(double) * 2 * (size_t)d * (size_t)mpad;
-    const bool lds_boxes = !gfree && ctx->M > 0 && box_bytes <= 60 * 1024;
-    const size_t lds = lds_boxes ? box_bytes : 0;
-    const int mp = lds_boxes ? mpad : 0;
     if (!s->sharded) {
-        DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 0>), dim3(grid), dim3(256), lds, st, s->xlist, ctx->colptr, ctx->rowval, ctx->nzval,
-                                         s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo, ctx->boxes, ctx->M,
-                                         mp, ctx->ss, gfree, (wf_trip*)nullptr, s->ctr));
+        DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 0>), dim3(grid), dim3(256), 0, st, words, (const unsigned long long*)s->cand, ctx->colptr,
+                                         ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo,
+                                         s->boxT, ctx->M, s->mpad, ctx->ss, gfree, (wf_trip*)nullptr, s->stats, s->ctr));
     } else {
-        DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 1>), dim3(grid), dim3(256), lds, st, s->xlist, ctx->colptr, ctx->rowval, ctx->nzval,
-                                         s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo, ctx->boxes, ctx->M,
-                                         mp, ctx->ss, gfree, s->mytrips, s->ctr));
+        DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 1>), dim3(grid), dim3(256), 0, st, words, (const unsigned long long*)s->cand, ctx->colptr,
+                                         ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo,
+                                         s->boxT, ctx->M, s->mpad, ctx->ss, gfree, s->mytrips, s->stats, s->ctr));
     }
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
@@ -518,10 +552,10 @@ static int32_t wf_exchange(mpfmt_ctx* ctx, mpfmt_wf* s)
     int32_t rc;
     for (int round = 0;; ++round) {
         wf_trip* myslot = s->xbuf + (size_t)rank * (WF_XCAP + 1);
-        hipLaunchKernelGGL(k_wf_pack, dim3((WF_XCAP + 255) / 256), dim3(256), 0, st, s->mytrips, round, myslot, s->ctr);
+        hipLaunchKernelGGL(k_wf_pack, dim3((WF_XCAP + 255) / 256), dim3(256), 0, st, s->mytrips, round, myslot, s->stats, s->ctr);
         if ((rc = mpfmt_comm_allgather_inplace(ctx, s->xbuf, slot_bytes, st))) return rc;
         hipLaunchKernelGGL(k_wf_commit, dim3(64), dim3(256), 0, st, s->xbuf, world, round, s->C, s->A, (unsigned long long*)s->W,
-                           (unsigned long long*)s->Hn, s->ctr);
+                           (unsigned long long*)s->Hn, s->stats, s->ctr);
         HIPCHK(ctx, hipMemcpy2DAsync(s->hdr_host, sizeof(wf_trip), s->xbuf, slot_bytes, sizeof(wf_trip), (size_t)world, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         int64_t mx = 0;
@@ -531,8 +565,9 @@ static int32_t wf_exchange(mpfmt_ctx* ctx, mpfmt_wf* s)
     return MPFMT_OK;
 }
 
-static int32_t wf_read_ctr(mpfmt_ctx* ctx, mpfmt_wf* s)
+static int32_t wf_read_ctr(mpfmt_ctx* ctx, mpfmt_wf* s, bool with_stats)
 {
+    if (with_stats) hipLaunchKernelGGL(k_wf_sum_stats, dim3(1), dim3(256), 0, ctx->stream, s->stats, s->ctr);
     HIPCHK(ctx, hipMemcpyAsync(s->ctr_host, s->ctr, sizeof(wf_ctr), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return MPFMT_OK;
@@ -540,16 +575,20 @@ static int32_t wf_read_ctr(mpfmt_ctx* ctx, mpfmt_wf* s)
 
 static bool wf_ended(const mpfmt_wf* s) { return s->ctr_host->done != 0 || s->ctr_host->goal_cbits != ~0ull; }
 
-static void wf_fill_info(const mpfmt_wf* s, mpfmt_wf_info* info)
+// info of the step(s) since the previous call (ctr_host must hold summed statistics)
+static void wf_fill_info(mpfmt_wf* s, mpfmt_wf_info* info)
 {
     const wf_ctr& c = *s->ctr_host;
     const bool goal = c.goal_cbits != ~0ull;
     info->done = goal ? 1 : c.done;
-    info->nz = c.done == 2 ? 0 : c.nz; info->nx = c.nx; info->nconn = c.nconn; info->ntrip = c.ntrip;
+    info->nz = (int32_t)(c.tot[WF_NZ] - s->prev_tot[WF_NZ]);
+    info->nx = (int32_t)(c.tot[WF_NX] - s->prev_tot[WF_NX]);
+    info->nconn = (int32_t)(c.tot[WF_NCONN] - s->prev_tot[WF_NCONN]);
+    info->ntrip = c.ntrip;
     info->iters = c.iters - (c.done == 2 ? 1 : 0);       // the step that found the open set empty expanded no batch
-    info->checks = c.checks; info->cmin = c.cmin;
-    // the totals on the device are brought up to date at the start of the following step
-    info->tot_z = c.tot_z + info->nz; info->tot_x = c.tot_x + c.nx; info->tot_conn = c.tot_conn + c.nconn;
+    info->checks = c.tot[WF_CHECKS]; info->cmin = c.cmin;
+    info->tot_z = c.tot[WF_NZ]; info->tot_x = c.tot[WF_NX]; info->tot_conn = c.tot[WF_NCONN];
+    for (int k = 0; k < 4; ++k) s->prev_tot[k] = c.tot[k];
 }
 
 extern "C" {
@@ -586,6 +625,7 @@ int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t check
     for (int i = 0; i < ng; ++i) s->goal.g[i] = goal_params[i];
     s->nparts = (int)std::min<int64_t>(WF_MAXPARTS, (s->words + 63) / 64);
     if (s->nparts < 1) s->nparts = 1;
+    for (int k = 0; k < 4; ++k) s->prev_tot[k] = 0;
 
     // checkpts bitmap F (fmt.jl:31-36); also answers is_free_state(init) (fmt.jl:24-29)
     auto t0 = std::chrono::steady_clock::now();
@@ -606,12 +646,23 @@ int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t check
         if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if (!s->use_mask) {                                    // obstacle table transposed for lane = obstacle reads
+        const int mpad = std::max(64, ((ctx->M + 63) / 64) * 64);
+        if (s->boxT) { HIPCHK(ctx, hipFree(s->boxT)); s->boxT = nullptr; }
+        HIPCHK(ctx, hipMalloc((void**)&s->boxT, sizeof(double) * 2 * (size_t)d * (size_t)mpad));
+        s->mpad = mpad;
+        if (ctx->M > 0)
+            hipLaunchKernelGGL(k_wf_box_transpose, dim3((unsigned)((mpad * 2 * d + 255) / 256)), dim3(256), 0, ctx->stream, ctx->boxes, ctx->M, 2 * d, mpad, s->boxT);
+        else
+            HIPCHK(ctx, hipMemsetAsync(s->boxT, 0, sizeof(double) * 2 * (size_t)d * (size_t)mpad, ctx->stream));
+    }
     auto t3 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
     s->ms_graph = ms(t1, t2); s->ms_sweep = ms(t0, t1) + ms(t2, t3);
-    hipLaunchKernelGGL(k_wf_init, dim3(256), dim3(64), 0, ctx->stream, N, s->words, s->init, s->W, s->H, s->Z, s->Hn, s->cand, s->C, s->A, s->ctr);
+    hipLaunchKernelGGL(k_wf_init, dim3(256), dim3(64), 0, ctx->stream, N, s->words, s->init, s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->C, s->A,
+                       s->stats, s->ctr);
     HIPCHK(ctx, hipGetLastError());
     s->active = true;
     return MPFMT_OK;
@@ -626,7 +677,7 @@ int32_t mpfmt_wf_step(mpfmt_ctx* ctx, mpfmt_wf_info* info)
     int32_t rc;
     if ((rc = wf_enqueue_local(ctx, s))) return rc;
     if (s->sharded && ctx->comm && (rc = wf_exchange(ctx, s))) return rc;
-    if ((rc = wf_read_ctr(ctx, s))) return rc;
+    if ((rc = wf_read_ctr(ctx, s, true))) return rc;
     if (info) wf_fill_info(s, info);
     return MPFMT_OK;
 }
@@ -665,18 +716,18 @@ int32_t mpfmt_wf_batch(mpfmt_ctx* ctx, int64_t* zs, int64_t cap, int64_t* nz)
     mpfmt_wf* s = wf_of(ctx);
     if (!s || !s->active) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no wavefront solve in progress (mpfmt_wf_begin)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int32_t rc;
-    if ((rc = wf_read_ctr(ctx, s))) return rc;
-    const int64_t n = s->ctr_host->done == 2 ? 0 : s->ctr_host->nz;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> z((size_t)s->words);
+    HIPCHK(ctx, hipMemcpy(z.data(), s->Z, 8 * s->words, hipMemcpyDeviceToHost));        // the batch mask of the last step, ascending
+    int64_t n = 0;
+    for (int64_t w = 0; w < s->words; ++w) n += __builtin_popcountll(z[w]);
     *nz = n;
     if (n > cap) return mpfmt_fail(ctx, MPFMT_ERR_CAPACITY, "batch of %lld exceeds capacity %lld", (long long)n, (long long)cap);
-    if (n > 0) {
-        if (!zs) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "zs is NULL");
-        void* scr;
-        if ((rc = mpfmt_scratch(ctx, 8 * (size_t)n, &scr))) return rc;
-        hipLaunchKernelGGL(k_wf_zs_to_i64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, s->zlist, n, (int64_t*)scr);
-        HIPCHK(ctx, hipMemcpyAsync(zs, scr, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n > 0 && !zs) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "zs is NULL");
+    int64_t o = 0;
+    for (int64_t w = 0; w < s->words; ++w) {
+        uint64_t m = z[w];
+        while (m) { const int b = __builtin_ctzll(m); m &= m - 1; zs[o++] = w * 64 + b + 1; }
     }
     return MPFMT_OK;
 }
@@ -690,7 +741,7 @@ int32_t mpfmt_wf_triples(mpfmt_ctx* ctx, int64_t cap, int64_t* x, int64_t* y, do
     if (!s || !s->active || !s->sharded) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no sharded wavefront solve in progress");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int32_t rc;
-    if ((rc = wf_read_ctr(ctx, s))) return rc;
+    if ((rc = wf_read_ctr(ctx, s, false))) return rc;
     const int64_t cnt = wf_ended(s) ? 0 : s->ctr_host->ntrip;
     *n = cnt;
     if (cnt > cap) return mpfmt_fail(ctx, MPFMT_ERR_CAPACITY, "%lld triples exceed capacity %lld", (long long)cnt, (long long)cap);
@@ -723,7 +774,7 @@ int32_t mpfmt_wf_commit(mpfmt_ctx* ctx, int64_t n, const int64_t* x, const int64
         }
         HIPCHK(ctx, hipMemcpy(s->xbuf, t.data(), sizeof(wf_trip) * (size_t)(m + 1), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_wf_commit, dim3(64), dim3(256), 0, ctx->stream, s->xbuf, 1, 0, s->C, s->A, (unsigned long long*)s->W,
-                           (unsigned long long*)s->Hn, s->ctr);
+                           (unsigned long long*)s->Hn, s->stats, s->ctr);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -738,10 +789,10 @@ int32_t mpfmt_wf_finish(mpfmt_ctx* ctx, int64_t* A, double* C, int64_t* path, mp
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t N = s->N;
     int32_t rc;
-    hipLaunchKernelGGL(k_wf_final, dim3(1), dim3(64), 0, ctx->stream, s->zlist, s->C, ctx->Xo, ctx->d, s->goal, s->ctr);
+    hipLaunchKernelGGL(k_wf_final, dim3(1), dim3(64), 0, ctx->stream, s->words, s->Z, s->Zp, s->C, ctx->Xo, ctx->d, s->goal, s->ctr);
     hipLaunchKernelGGL(k_wf_path, dim3(1), dim3(1), 0, ctx->stream, s->A, N, s->ctr, s->path_dev);
     HIPCHK(ctx, hipGetLastError());
-    if ((rc = wf_read_ctr(ctx, s))) return rc;
+    if ((rc = wf_read_ctr(ctx, s, true))) return rc;
     const wf_ctr& c = *s->ctr_host;
     int64_t plen = 0;
     HIPCHK(ctx, hipMemcpy(&plen, s->path_dev + N, 8, hipMemcpyDeviceToHost));
@@ -753,7 +804,7 @@ int32_t mpfmt_wf_finish(mpfmt_ctx* ctx, int64_t* A, double* C, int64_t* path, mp
     res->status = c.done == 1 ? 1 : 0;
     res->cost = cz;
     res->z = c.final_z + 1;
-    res->collision_checks = c.checks;
+    res->collision_checks = c.tot[WF_CHECKS];
     if (s->sharded && ctx->comm) {          // every rank counted the checks of its own samples; the headers of the last exchange hold all counts
         int rank = 0, world = 1;
         mpfmt_comm_world(ctx, &rank, &world);
@@ -778,14 +829,14 @@ int32_t mpfmt_fmtstar_wavefront(mpfmt_ctx* ctx, double r, int64_t init_idx, int3
     if (s->sharded && !ctx->comm) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "a sharded wavefront solve needs a communicator (mpfmt_comm_create), or the manual mpfmt_wf_step / _triples / _commit loop");
     // steps are enqueued in groups; the end condition voids the kernels issued after it, the host looks once per group
     // (sharded: the exchange looks at the slot headers every step anyway)
-    const int group = s->sharded ? 1 : (s->single ? 16 : 4);
+    const int group = s->sharded ? 1 : (s->single ? 32 : 8);
     const int64_t max_steps = 4 * s->N + 64;
     for (int64_t it = 0; it < max_steps; it += group) {
         for (int g = 0; g < group; ++g) {
             if ((rc = wf_enqueue_local(ctx, s))) return rc;
             if (s->sharded && (rc = wf_exchange(ctx, s))) return rc;
         }
-        if ((rc = wf_read_ctr(ctx, s))) return rc;
+        if ((rc = wf_read_ctr(ctx, s, false))) return rc;
         if (wf_ended(s)) break;
     }
     if (!wf_ended(s)) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "wavefront solve did not terminate");
