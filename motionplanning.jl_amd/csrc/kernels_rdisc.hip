@@ -697,6 +697,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         }
     }
     ctx->pool_valid = false;
+    ctx->rowpos_valid = false;
     mpfmt_timed tm3(ctx);
     if (nt > 0) {
         if (mf) {

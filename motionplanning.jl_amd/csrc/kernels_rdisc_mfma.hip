@@ -460,7 +460,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                     if (slot < a.pool_cap) {
                         const long long p = ((long long)item * 64 + ql) * a.pool_cap + slot;
                         mpfmt_hit h;
-                        h.j = a.perm[jg]; h.pad = 0; h.d = sqrt(d2);     // sample index of the row, edge cost
+                        h.j = a.perm[jg]; h.pad = (int32_t)jg; h.d = sqrt(d2);     // sample index of the row, its cell-sorted position, edge cost
                         *reinterpret_cast<uint4*>(&a.pool[p]) = *reinterpret_cast<const uint4*>(&h);   // one 16-byte store
                     } else {
                         pool_over = 1;
@@ -666,8 +666,8 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restri
                                                        int64_t capc, int S, const int32_t* __restrict__ slice_cnt, int64_t npad,
                                                        int64_t tile_begin, int64_t pos_begin, int64_t pos_end,
                                                        const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm,
-                                                       int32_t* __restrict__ rowval, double* __restrict__ nzval, uint32_t bucket_mul,
-                                                       const int32_t* __restrict__ spec_fail)
+                                                       int32_t* __restrict__ rowval, double* __restrict__ nzval, int32_t* __restrict__ rowpos,
+                                                       uint32_t bucket_mul, const int32_t* __restrict__ spec_fail)
 {
     if (spec_fail && *spec_fail) return;                     // speculative step whose capacities did not hold: redone by the host
     __shared__ __attribute__((aligned(16))) int32_t s_o[SLOT_LDS + 4];
@@ -706,19 +706,19 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restri
             }
             return col0 + (long long)sl * sstride + (e - s_pre[c][sl]);
         };
-        struct ents { int32_t ma, mb; double da, db; };
+        struct ents { int32_t ma, mb, pa, pb; double da, db; };
         auto fetch = [&](int c, ents& E) {
             const int k = __builtin_amdgcn_readlane(kk, c);
-            E.ma = E.mb = 0; E.da = E.db = 0.0;
+            E.ma = E.mb = E.pa = E.pb = 0; E.da = E.db = 0.0;
             if (k == 0 || k > 128) return;
             const long long col0 = col_base(c);
-            if (lane < k) { const mpfmt_hit h = load_hit(pool, src(c, col0, lane)); E.ma = h.j; E.da = h.d; }
-            if (64 + lane < k) { const mpfmt_hit h = load_hit(pool, src(c, col0, 64 + lane)); E.mb = h.j; E.db = h.d; }
+            if (lane < k) { const mpfmt_hit h = load_hit(pool, src(c, col0, lane)); E.ma = h.j; E.pa = h.pad; E.da = h.d; }
+            if (64 + lane < k) { const mpfmt_hit h = load_hit(pool, src(c, col0, 64 + lane)); E.mb = h.j; E.pb = h.pad; E.db = h.d; }
         };
         ents cur, nxt;
         fetch(0, cur);
         for (int c = 0; c < SLOT_TC; ++c) {
-            nxt.ma = nxt.mb = 0; nxt.da = nxt.db = 0.0;
+            nxt.ma = nxt.mb = nxt.pa = nxt.pb = 0; nxt.da = nxt.db = 0.0;
             if (c + 1 < SLOT_TC) fetch(c + 1, nxt);
             const int k = __builtin_amdgcn_readlane(kk, c);
             const int64_t out = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)outp >> 32), c) << 32) |
@@ -756,8 +756,8 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restri
                 int ra = 0, rb = 0;
                 if (ha) for (int m = 0; m < na; ++m) ra += (s_o[basea + m] < ma) ? 1 : 0;
                 if (hb) for (int m = 0; m < nb_; ++m) rb += (s_o[baseb + m] < mb) ? 1 : 0;
-                if (ha) { rowval[out + basea + ra] = ma; nzval[out + basea + ra] = cur.da; }
-                if (hb) { rowval[out + baseb + rb] = mb; nzval[out + baseb + rb] = cur.db; }
+                if (ha) { rowval[out + basea + ra] = ma; nzval[out + basea + ra] = cur.da; if (rowpos) rowpos[out + basea + ra] = cur.pa; }
+                if (hb) { rowval[out + baseb + rb] = mb; nzval[out + baseb + rb] = cur.db; if (rowpos) rowpos[out + baseb + rb] = cur.pb; }
             } else if (k > 128) {
                 // long columns: rank by counting through LDS (streamed in windows beyond SLOT_LDS hits)
                 const long long col0 = col_base(c);
@@ -770,13 +770,14 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restri
                         const int e = e0 + lane;
                         const int32_t mine = (e < k) ? s_o[e] : 0x7fffffff;
                         const double dm = (e < k) ? pool[src(c, col0, e)].d : 0.0;   // in flight during the rank loop
+                        const int32_t pm = (e < k) ? pool[src(c, col0, e)].pad : 0;
                         int32_t r = 0;
                         for (int j = 0; j < k; j += 4) {
                             const int4 v = *reinterpret_cast<const int4*>(&s_o[j]);   // wave-uniform ds_read_b128 (broadcast)
                             r += (v.x < mine) ? 1 : 0; r += (v.y < mine) ? 1 : 0;
                             r += (v.z < mine) ? 1 : 0; r += (v.w < mine) ? 1 : 0;
                         }
-                        if (e < k) { rowval[out + r] = mine; nzval[out + r] = dm; }
+                        if (e < k) { rowval[out + r] = mine; nzval[out + r] = dm; if (rowpos) rowpos[out + r] = pm; }
                     }
                 } else {
                     for (int e0 = 0; e0 < k; e0 += 64) {
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restri
                             __syncthreads();
                             for (int j = 0; j < cn; ++j) rank += (s_o[j] < mine) ? 1 : 0;
                         }
-                        if (e < k) { rowval[out + rank] = mine; nzval[out + rank] = pool[pe].d; }
+                        if (e < k) { rowval[out + rank] = mine; nzval[out + rank] = pool[pe].d; if (rowpos) rowpos[out + rank] = pool[pe].pad; }
                     }
                 }
             }
@@ -804,11 +805,15 @@ int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx, const int32_t* spec_fail)
 {
     const int64_t pb = ctx->tile_begin * 64, pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
     if (ctx->nnz == 0 || pe <= pb) return MPFMT_OK;
+    int32_t rc_;
+    // option sweep_sorted: also keep every row's cell-sorted position, so the sweep can gather from Xs (see kernels_sweep.hip)
+    if (ctx->sweep_sorted && (rc_ = mpfmt_ensure(ctx, (void**)&ctx->rowpos, sizeof(int32_t) * (size_t)std::max<int64_t>(std::max(ctx->nnz, ctx->nnz_cap), 1)))) return rc_;
     const unsigned nb = (unsigned)std::min<int64_t>((pe - pb + SLOT_TC - 1) / SLOT_TC, 1 << 20);
     hipLaunchKernelGGL(k_sortcols_slots, dim3(nb), dim3(64), 0, ctx->stream, ctx->pool, ctx->pool_cap, ctx->S,
-                       ctx->slice_cnt, ctx->ntiles * 64, ctx->tile_begin, pb, pe, ctx->colptr, ctx->perm, ctx->rowval, ctx->nzval,
+                       ctx->slice_cnt, ctx->ntiles * 64, ctx->tile_begin, pb, pe, ctx->colptr, ctx->perm, ctx->rowval, ctx->nzval, ctx->sweep_sorted ? ctx->rowpos : nullptr,
                        ctx->N > 128 ? (uint32_t)((128ull << 32) / (uint64_t)ctx->N) : 0u, spec_fail);
     HIPCHK(ctx, hipGetLastError());
+    ctx->rowpos_valid = ctx->sweep_sorted != 0;   // every entry's row is also known by its cell-sorted position (the sweep gathers from Xs)
     return MPFMT_OK;
 }
 

@@ -233,8 +233,15 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
                                                                const double* __restrict__ boxes, int M, int chunk,
                                                                mpfmt_ss ss, unsigned long long* __restrict__ mask,
                                                                int* __restrict__ task_ctr, const int32_t* __restrict__ perm,
-                                                               int64_t sp_begin, int64_t sp_end, const int32_t* __restrict__ spec_fail)
+                                                               int64_t sp_begin, int64_t sp_end, const int32_t* __restrict__ spec_fail,
+                                                               const double* __restrict__ Xrow, const int32_t* __restrict__ rowsrc, int xcd_ranges)
 {
+    // Xrow / rowsrc: where row states are gathered from -- (X, rowval) = caller order, or (Xs, rowpos) = the cell-sorted copy
+    // addressed by sorted position: the rows of a column are its spatial neighbours, which sit in a few contiguous runs of
+    // Xs (24 full 128-byte lines per cell) instead of one line per row scattered over the caller's array.  With xcd_ranges
+    // the columns are visited in cell-sorted order and every XCD (blockIdx % 8, private L2) works through its own contiguous
+    // eighth of it, so the lines one wavefront pulled in serve the neighbouring columns: the gather runs out of L2 instead
+    // of the fabric (tools/ubench/gather_variants.hip: 1.9e11 vs 5.0e10 rows/s).
     if (spec_fail && *spec_fail) return;                   // speculative step whose capacities did not hold: redone by the host
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sboxT = (double*)smem;                         // [2*D][SWEEP_CHUNK]
@@ -263,11 +270,26 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
         }
         __syncthreads();
 
-        int* ctr = task_ctr + ci;
+        int* ctr = task_ctr + ci * 8;
+        int xlive = 0;                                           // wave-uniform: XCD ranges before this one (in steal order) are exhausted
         auto grab = [&]() -> int64_t {
-            int t = 0;
-            if (lane == 0) t = atomicAdd(ctr, 1);
-            return (int64_t)__builtin_amdgcn_readfirstlane(t);
+            if (!xcd_ranges) {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(ctr, 1);
+                return (int64_t)__builtin_amdgcn_readfirstlane(t);
+            }
+            // own range first, then the next XCDs' (tail balance)
+            const int me = (int)(blockIdx.x & 7);
+            while (xlive < 8) {
+                const int x = (me + xlive) & 7;
+                const int64_t lo = ntasks * x / 8, hi = ntasks * (x + 1) / 8;
+                int t = 0;
+                if (lane == 0) t = atomicAdd(ctr + x, 1);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (lo + t < hi) return lo + t;
+                ++xlive;
+            }
+            return ntasks;
         };
         sweep_hdr<D, SWEEP_TC> H0, H1;
         auto load_hdr = [&](int64_t t, sweep_hdr<D, SWEEP_TC>& h) {
@@ -315,11 +337,11 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
         };
         auto request_rows = [&](const sweep_round& r) -> int32_t {
             const int64_t e = r.e0 + lane;
-            return (r.valid && e < r.end) ? rowval[e] : 0;
+            return (r.valid && e < r.end) ? rowsrc[e] : 0;
         };
         auto request_states = [&](int32_t y, double (&pv)[D]) {
 #pragma unroll
-            for (int i = 0; i < D; ++i) pv[i] = X[(int64_t)y * D + i];
+            for (int i = 0; i < D; ++i) pv[i] = Xrow[(int64_t)y * D + i];
         };
 
         // ---- narrow-phase queue ----
@@ -700,7 +722,7 @@ int32_t mpfmt_launch_mc_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64
 // build, small graphs): finer tasks balance the tail.  One resident set of workgroups.
 template <int D>
 static int32_t launch_graph_sweep_d(mpfmt_ctx* ctx, size_t lds, double rpad, int chunk, const int32_t* sweep_perm, int64_t sp_begin,
-                                    int64_t sp_end, const int32_t* spec_fail)
+                                    int64_t sp_end, const int32_t* spec_fail, bool sorted_rows)
 {
     constexpr auto k8 = k_graph_sweep<D, 8>;
     constexpr auto k4 = k_graph_sweep<D, 4>;
@@ -722,7 +744,8 @@ static int32_t launch_graph_sweep_d(mpfmt_ctx* ctx, size_t lds, double rpad, int
     const unsigned nb = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ntasks + waves - 1) / waves, resident));
     hipLaunchKernelGGL(tc == 4 ? k4 : k8, dim3(nb), dim3(SWEEP_GT(D)), lds, ctx->stream, ctx->Xo, ctx->colptr, ctx->rowval, ctx->N,
                        rpad, ctx->boxes, ctx->M, chunk, ctx->ss, (unsigned long long*)ctx->graph_free, ctx->sweep_ctr, sweep_perm,
-                       sp_begin, sp_end, spec_fail);
+                       sp_begin, sp_end, spec_fail, sorted_rows ? ctx->Xs : ctx->Xo, sorted_rows ? ctx->rowpos : ctx->rowval,
+                       sorted_rows ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
@@ -758,14 +781,19 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail, int64
         // persistent workgroups (one resident set): boxes are staged once per workgroup, tasks of SWEEP_TC columns
         // are claimed from a counter per obstacle chunk
         const int nchunks = std::max(1, (ctx->M + chunk - 1) / chunk);
-        if ((rc = mpfmt_ensure(ctx, (void**)&ctx->sweep_ctr, sizeof(int) * (size_t)nchunks))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->sweep_ctr, 0, sizeof(int) * (size_t)nchunks, ctx->stream));
+        if ((rc = mpfmt_ensure(ctx, (void**)&ctx->sweep_ctr, sizeof(int) * 8 * (size_t)nchunks))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->sweep_ctr, 0, sizeof(int) * 8 * (size_t)nchunks, ctx->stream));
         // unsharded: all columns in caller order; sharded: only this shard's cell-sorted positions (via perm)
+        // the single-pass build also knows every row by its cell-sorted position: rows are then gathered from Xs and the
+        // columns visited in cell-sorted order, one contiguous range per XCD
+        const bool sorted_rows = ctx->sweep_sorted && ctx->rowpos_valid && ctx->pool_valid && ctx->rdisc_path_used == 2 && ctx->rowpos && ctx->Xs &&
+                                 ctx->perm != nullptr && ctx->tile_end > ctx->tile_begin;
         const bool sharded = ctx->world > 1 && ctx->perm != nullptr && ctx->tile_end > ctx->tile_begin;
-        const int32_t* sweep_perm = sharded ? ctx->perm : nullptr;
-        const int64_t sp_begin = sharded ? ctx->tile_begin * 64 : 0;
-        const int64_t sp_end = sharded ? std::min<int64_t>(ctx->tile_end * 64, ctx->ntiles * 64) : ctx->N;
-        DISPATCH_D(d, rc = launch_graph_sweep_d<DD>(ctx, lds, rpad, chunk, sweep_perm, sp_begin, sp_end, spec_fail));
+        const bool by_perm = sharded || sorted_rows;
+        const int32_t* sweep_perm = by_perm ? ctx->perm : nullptr;
+        const int64_t sp_begin = by_perm ? ctx->tile_begin * 64 : 0;
+        const int64_t sp_end = by_perm ? std::min<int64_t>(ctx->tile_end * 64, ctx->ntiles * 64) : ctx->N;
+        DISPATCH_D(d, rc = launch_graph_sweep_d<DD>(ctx, lds, rpad, chunk, sweep_perm, sp_begin, sp_end, spec_fail, sorted_rows));
         if (rc) return rc;
         HIPCHK(ctx, hipGetLastError());
     }

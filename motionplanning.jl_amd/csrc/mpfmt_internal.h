@@ -133,6 +133,10 @@ struct mpfmt_ctx {
     double* valtmp = nullptr;
     int32_t* rowval = nullptr;           // [nnz] 0-based, ascending per column
     double* nzval = nullptr;
+    int32_t* rowpos = nullptr;           // [nnz] cell-sorted position of each entry's row (single-pass build): the sweep gathers rows from Xs
+    bool rowpos_valid = false;
+    int32_t sweep_sorted = 0;            // option: gather the sweep's rows from Xs in cell-sorted order with per-XCD task ranges (6x less HBM traffic,
+                                         // 74 % L2 hits, same time: the sweep is issue-bound -- profiles/r02_pmc_sweep_*.txt); off by default
     uint64_t* graph_free = nullptr;      // [ceil(nnz/64)]
     bool graph_swept = false;
     unsigned long long* d_pairs = nullptr;   // device counter: candidate pairs tested
