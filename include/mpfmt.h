@@ -182,7 +182,9 @@ int32_t mpfmt_mc_edges_collision(mpfmt_ctx* ctx, const int64_t* src, const int64
  *             segment tests the reference would have counted (may be NULL).
  *      dubins_steer : batch steer on explicit pairs; controls[i][3][3] = (duration, speed, signed curvature) per segment.
  *      dubins_fmtstar : fmtstar! in this space (forward / backward neighbour sets like the double integrator's).
- *      sin / cos / atan2 / acos are the device libm's: costs agree with a CPU libm to a few ulp, not bit for bit. */
+ *      sin / cos / atan2 / acos are the library's own (csrc/mp_math.h: fixed reductions and polynomials from + - * / sqrt), the
+ *      same header the CPU oracle compiles: graphs, masks and costs are bit-identical to the oracle's; against a libm-based
+ *      host (Julia) costs agree to ~1e-15 relative. */
 int32_t mpfmt_dubins_graph_count(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz);
 int32_t mpfmt_dubins_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval);
 int32_t mpfmt_dubins_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg);

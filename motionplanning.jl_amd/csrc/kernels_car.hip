@@ -6,11 +6,13 @@
 // (3) ordered compaction into the CSC the planner consumes.  The collision sweep regenerates the steering controls per edge,
 // walks the reference's collision waypoints (arcs sampled every pi/12, :68-83; target appended, statespaces.jl:135) and tests
 // consecutive pairs on (x, y) against the AABB set with the SE2 bounds on the first point (statespaces.jl:153-158).
-// Arithmetic: the reference's expressions in the written order, unfused; sin / cos / atan2 / acos / fmod are the device
+// Arithmetic: the reference's expressions in the written order, unfused; sin / cos / atan2 / acos come from mp_math.h (fixed
+// reductions and polynomials from + - * / sqrt, the SAME header the CPU oracle compiles: results are bit-identical); fmod / sqrt are the device
 // libm's, so costs agree with a CPU libm to a few ulp rather than bit for bit (the tests bound it).
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 #include "mpfmt_internal.h"
+#include "mp_math.h"
 
 #define CAR_TWOPI (2 * 3.141592653589793)
 
@@ -38,15 +40,15 @@ __host__ __device__ inline double dubins_steer(const double* s1, const double* s
 {
     const double vx = (s2[0] - s1[0]) / r, vy = (s2[1] - s1[1]) / r;
     const double d = sqrt(vx * vx + vy * vy);
-    const double th = atan2(vy, vx);
+    const double th = mp_atan2(vy, vx);
     const double a = mod2pif(s1[2] - th), b = mod2pif(s2[2] - th);
-    const double ca = cos(a), sa = sin(a), cb = cos(b), sb = sin(b);
+    const double ca = mp_cos(a), sa = mp_sin(a), cb = mp_cos(b), sb = mp_sin(b);
     double c = INFINITY;
     for (int q = 0; q < 3; ++q) { path[q].t = 0; path[q].s = 0; path[q].k = 0; }
     {
         const double tmp = 2 + d * d - 2 * (ca * cb + sa * sb - d * (sa - sb));                 // LSL
         if (!(tmp < 0)) {
-            const double t0 = atan2(cb - ca, d + sa - sb);
+            const double t0 = mp_atan2(cb - ca, d + sa - sb);
             const double t = mod2pif(-a + t0), p = sqrt(fmax(tmp, 0.0)), q = mod2pif(b - t0);
             DUB_TRY(t + p + q, 1, t, 0, p, 1, q);
         }
@@ -54,7 +56,7 @@ __host__ __device__ inline double dubins_steer(const double* s1, const double* s
     {
         const double tmp = 2 + d * d - 2 * (ca * cb + sa * sb - d * (sb - sa));                 // RSR
         if (!(tmp < 0)) {
-            const double t0 = atan2(ca - cb, d - sa + sb);
+            const double t0 = mp_atan2(ca - cb, d - sa + sb);
             const double t = mod2pif(a - t0), p = sqrt(fmax(tmp, 0.0)), q = mod2pif(-b + t0);
             DUB_TRY(t + p + q, -1, t, 0, p, -1, q);
         }
@@ -63,7 +65,7 @@ __host__ __device__ inline double dubins_steer(const double* s1, const double* s
         const double tmp = d * d - 2 + 2 * (ca * cb + sa * sb - d * (sa + sb));                 // RSL
         if (!(tmp < 0)) {
             const double p = sqrt(fmax(tmp, 0.0));
-            const double t0 = atan2(ca + cb, d - sa - sb) - atan2(2.0, p);
+            const double t0 = mp_atan2(ca + cb, d - sa - sb) - mp_atan2(2.0, p);
             const double t = mod2pif(a - t0), q = mod2pif(b - t0);
             DUB_TRY(t + p + q, -1, t, 0, p, 1, q);
         }
@@ -72,7 +74,7 @@ __host__ __device__ inline double dubins_steer(const double* s1, const double* s
         const double tmp = -2 + d * d + 2 * (ca * cb + sa * sb + d * (sa + sb));                // LSR
         if (!(tmp < 0)) {
             const double p = sqrt(fmax(tmp, 0.0));
-            const double t0 = atan2(-ca - cb, d + sa + sb) - atan2(-2.0, p);
+            const double t0 = mp_atan2(-ca - cb, d + sa + sb) - mp_atan2(-2.0, p);
             const double t = mod2pif(-a + t0), q = mod2pif(-b + t0);
             DUB_TRY(t + p + q, 1, t, 0, p, -1, q);
         }
@@ -80,8 +82,8 @@ __host__ __device__ inline double dubins_steer(const double* s1, const double* s
     {
         const double tmp = (6 - d * d + 2 * (ca * cb + sa * sb + d * (sa - sb))) / 8;           // RLR
         if (!(fabs(tmp) >= 1)) {
-            const double p = CAR_TWOPI - acos(tmp);
-            const double t0 = atan2(ca - cb, d - sa + sb);
+            const double p = CAR_TWOPI - mp_acos(tmp);
+            const double t0 = mp_atan2(ca - cb, d - sa + sb);
             const double t = mod2pif(a - t0 + p / 2), q = mod2pif(a - b - t + p);
             DUB_TRY(t + p + q, -1, t, 1, p, -1, q);
         }
@@ -89,8 +91,8 @@ __host__ __device__ inline double dubins_steer(const double* s1, const double* s
     {
         const double tmp = (6 - d * d + 2 * (ca * cb + sa * sb - d * (sa - sb))) / 8;           // LRL
         if (!(fabs(tmp) >= 1)) {
-            const double p = CAR_TWOPI - acos(tmp);
-            const double t0 = atan2(-ca + cb, d + sa - sb);
+            const double p = CAR_TWOPI - mp_acos(tmp);
+            const double t0 = mp_atan2(-ca + cb, d + sa - sb);
             const double t = mod2pif(-a + t0 + p / 2), q = mod2pif(b - a - t + p);
             DUB_TRY(t + p + q, 1, t, -1, p, 1, q);
         }
@@ -106,11 +108,11 @@ __host__ __device__ __forceinline__ void car_propagate(const double* v, const ca
 {
     const double ang = u.t * u.s * u.k;
     if (fabs(ang) > 10 * 2.220446049250313e-16) {
-        out[0] = v[0] + (sin(v[2] + ang) - sin(v[2])) / u.k;
-        out[1] = v[1] + (cos(v[2]) - cos(v[2] + ang)) / u.k;
+        out[0] = v[0] + (mp_sin(v[2] + ang) - mp_sin(v[2])) / u.k;
+        out[1] = v[1] + (mp_cos(v[2]) - mp_cos(v[2] + ang)) / u.k;
     } else {
-        out[0] = v[0] + u.t * u.s * cos(v[2]);
-        out[1] = v[1] + u.t * u.s * sin(v[2]);
+        out[0] = v[0] + u.t * u.s * mp_cos(v[2]);
+        out[1] = v[1] + u.t * u.s * mp_sin(v[2]);
     }
     out[2] = mod2pif(v[2] + ang);
 }
@@ -119,16 +121,16 @@ __host__ __device__ __forceinline__ void car_propagate(const double* v, const ca
 // backwards images in the reference's order; negative segment lengths are reverse gear -----------------------------------------
 #define CAR_PI 3.141592653589793
 struct rs_best { double c; int l, post; car_step p[5]; };
-__host__ __device__ __forceinline__ void rs_R(double x, double y, double& r, double& th) { r = sqrt(x * x + y * y); th = atan2(y, x); }
+__host__ __device__ __forceinline__ void rs_R(double x, double y, double& r, double& th) { r = sqrt(x * x + y * y); th = mp_atan2(y, x); }
 __host__ __device__ __forceinline__ double rs_M(double t) { const double m = mod2pif(t); return m > CAR_PI ? m - CAR_TWOPI : m; }
 __host__ __device__ inline double rs_Tau(double u, double v, double E, double N)
 {
     const double delta = rs_M(u - v);
-    const double A = sin(u) - sin(delta);
-    const double B = cos(u) - cos(delta) - 1;
+    const double A = mp_sin(u) - mp_sin(delta);
+    const double B = mp_cos(u) - mp_cos(delta) - 1;
     double r, th;
     rs_R(E * A + N * B, N * A - E * B, r, th);
-    const double t = 2 * cos(delta) - 2 * cos(v) - 2 * cos(u) + 3;
+    const double t = 2 * mp_cos(delta) - 2 * mp_cos(v) - 2 * mp_cos(u) + 3;
     return t < 0 ? rs_M(th + CAR_PI) : rs_M(th);
 }
 __host__ __device__ inline double rs_Omega(double u, double v, double E, double N, double t) { return rs_M(rs_Tau(u, v, E, N) - u + v - t); }
@@ -141,7 +143,7 @@ __host__ __device__ __forceinline__ void rs_accept(rs_best& b, double cnew, int 
 __host__ __device__ inline void rs_family(int f, const double* T, rs_best& b, int post)
 {
     const car_step z = car_seg(0, 0.0);
-    const double st = sin(T[2]), ct = cos(T[2]);
+    const double st = mp_sin(T[2]), ct = mp_cos(T[2]);
     if (f == 0) {                                                         // (8.1) L+ S+ L+
         double r, th; rs_R(T[0] - st, T[1] - 1 + ct, r, th);
         const double u = r, t = mod2pif(th), v = mod2pif(T[2] - t);
@@ -157,7 +159,7 @@ __host__ __device__ inline void rs_family(int f, const double* T, rs_best& b, in
         const double E = T[0] - st, N = T[1] + ct - 1;
         if (E * E + N * N > 16) return;
         double r, th; rs_R(E, N, r, th);
-        double u = acos(1 - r * r / 8);
+        double u = mp_acos(1 - r * r / 8);
         const double t = mod2pif(th - u / 2 + CAR_PI);
         double v = mod2pif(CAR_PI - u / 2 - th + T[2]);
         if (f == 3) v = v - CAR_TWOPI;
@@ -167,21 +169,21 @@ __host__ __device__ inline void rs_family(int f, const double* T, rs_best& b, in
         const double E = T[0] + st, N = T[1] - ct - 1;
         const double p = (2 + sqrt(E * E + N * N)) / 4;
         if (p < 0 || p > 1) return;
-        const double u = acos(p);
+        const double u = mp_acos(p);
         const double t = mod2pif(rs_Tau(u, -u, E, N)), v = mod2pif(rs_Omega(u, -u, E, N, T[2])) - CAR_TWOPI;
         rs_accept(b, t + 2 * u - v, 4, post, car_seg(1, t), car_seg(-1, u), car_seg(1, -u), car_seg(-1, v), z);
     } else if (f == 5) {                                                  // (8.8) L+ R-u L-u R+
         const double E = T[0] + st, N = T[1] - ct - 1;
         const double p = (20 - E * E - N * N) / 16;
         if (p < 0 || p > 1) return;
-        const double u = -acos(p);
+        const double u = -mp_acos(p);
         const double t = mod2pif(rs_Tau(u, u, E, N)), v = mod2pif(rs_Omega(u, u, E, N, T[2]));
         rs_accept(b, t - 2 * u + v, 4, post, car_seg(1, t), car_seg(-1, u), car_seg(1, u), car_seg(-1, v), z);
     } else if (f == 6) {                                                  // (8.9) L+ R- S- L-
         const double E = T[0] - st, N = T[1] + ct - 1;
         double D, be; rs_R(E, N, D, be);
         if (D < 2) return;
-        const double ga = acos(2 / D), F = sqrt(D * D / 4 - 1);
+        const double ga = mp_acos(2 / D), F = sqrt(D * D / 4 - 1);
         const double t = mod2pif(CAR_PI + be - ga), u = 2 - 2 * F;
         if (u > 0) return;
         const double v = mod2pif(-3 * CAR_PI / 2 + ga + T[2] - be) - CAR_TWOPI;
@@ -198,7 +200,7 @@ __host__ __device__ inline void rs_family(int f, const double* T, rs_best& b, in
         const double E = T[0] + st, N = T[1] - ct - 1;
         double D, be; rs_R(E, N, D, be);
         if (D < 2) return;
-        const double ga = acos(2 / D), F = sqrt(D * D / 4 - 1);
+        const double ga = mp_acos(2 / D), F = sqrt(D * D / 4 - 1);
         const double t = mod2pif(CAR_PI + be - ga), u = 4 - 2 * F;
         if (u > 0) return;
         const double v = mod2pif(CAR_PI + be - T[2] - ga);
@@ -210,14 +212,14 @@ __host__ __device__ inline void rs_family(int f, const double* T, rs_best& b, in
 __host__ __device__ inline double rs_steer(const double* s1, const double* s2, double r, double s, car_step* path, int& L)
 {
     const double dx = (s2[0] - s1[0]) / r, dy = (s2[1] - s1[1]) / r;
-    const double ct = cos(s1[2]), st = sin(s1[2]);
+    const double ct = mp_cos(s1[2]), st = mp_sin(s1[2]);
     double T[8][3];                 // images in the reference's POST numbering: 0 id, 1 T, 2 R, 3 B, 4 R_T, 5 B_T, 6 B_R, 7 B_R_T
     T[0][0] = dx * ct + dy * st; T[0][1] = -dx * st + dy * ct; T[0][2] = mod2pif(s2[2] - s1[2]);
     T[1][0] = -T[0][0]; T[1][1] = T[0][1]; T[1][2] = -T[0][2];                       // timeflip
     T[2][0] = T[0][0]; T[2][1] = -T[0][1]; T[2][2] = -T[0][2];                       // reflect
     T[4][0] = T[1][0]; T[4][1] = -T[1][1]; T[4][2] = -T[1][2];                       // reflect(timeflip)
-    T[3][0] = T[0][0] * cos(T[0][2]) + T[0][1] * sin(T[0][2]);                       // backwards (:247)
-    T[3][1] = T[0][0] * sin(T[0][2]) - T[0][1] * cos(T[0][2]);
+    T[3][0] = T[0][0] * mp_cos(T[0][2]) + T[0][1] * mp_sin(T[0][2]);                       // backwards (:247)
+    T[3][1] = T[0][0] * mp_sin(T[0][2]) - T[0][1] * mp_cos(T[0][2]);
     T[3][2] = T[0][2];
     T[5][0] = -T[3][0]; T[5][1] = T[3][1]; T[5][2] = -T[3][2];
     T[6][0] = T[3][0]; T[6][1] = -T[3][1]; T[6][2] = -T[3][2];
@@ -270,7 +272,7 @@ __device__ __forceinline__ void rs_fam_cost(const double x, const double y, cons
         const double E = x - st, N = y + ct - 1;
         if (E * E + N * N > 16) return;
         double r, a; rs_R(E, N, r, a);
-        double u = acos(1 - r * r / 8);
+        double u = mp_acos(1 - r * r / 8);
         const double t = mod2pif(a - u / 2 + CAR_PI);
         double v = mod2pif(CAR_PI - u / 2 - a + th);
         if (F == 3) v = v - CAR_TWOPI;
@@ -280,21 +282,21 @@ __device__ __forceinline__ void rs_fam_cost(const double x, const double y, cons
         const double E = x + st, N = y - ct - 1;
         const double p = (2 + sqrt(E * E + N * N)) / 4;
         if (p < 0 || p > 1) return;
-        const double u = acos(p);
+        const double u = mp_acos(p);
         const double t = mod2pif(rs_Tau(u, -u, E, N)), v = mod2pif(rs_Omega(u, -u, E, N, th)) - CAR_TWOPI;
         cnew = t + 2 * u - v;
     } else if constexpr (F == 5) {
         const double E = x + st, N = y - ct - 1;
         const double p = (20 - E * E - N * N) / 16;
         if (p < 0 || p > 1) return;
-        const double u = -acos(p);
+        const double u = -mp_acos(p);
         const double t = mod2pif(rs_Tau(u, u, E, N)), v = mod2pif(rs_Omega(u, u, E, N, th));
         cnew = t - 2 * u + v;
     } else if constexpr (F == 6) {
         const double E = x - st, N = y + ct - 1;
         double D, be; rs_R(E, N, D, be);
         if (D < 2) return;
-        const double ga = acos(2 / D), Fq = sqrt(D * D / 4 - 1);
+        const double ga = mp_acos(2 / D), Fq = sqrt(D * D / 4 - 1);
         const double t = mod2pif(CAR_PI + be - ga), u = 2 - 2 * Fq;
         if (u > 0) return;
         const double v = mod2pif(-3 * CAR_PI / 2 + ga + th - be) - CAR_TWOPI;
@@ -311,7 +313,7 @@ __device__ __forceinline__ void rs_fam_cost(const double x, const double y, cons
         const double E = x + st, N = y - ct - 1;
         double D, be; rs_R(E, N, D, be);
         if (D < 2) return;
-        const double ga = acos(2 / D), Fq = sqrt(D * D / 4 - 1);
+        const double ga = mp_acos(2 / D), Fq = sqrt(D * D / 4 - 1);
         const double t = mod2pif(CAR_PI + be - ga), u = 4 - 2 * Fq;
         if (u > 0) return;
         const double v = mod2pif(CAR_PI + be - th - ga);
@@ -359,9 +361,9 @@ __device__ __forceinline__ double rs_cost_win(const double X, const double Y, co
 __device__ inline double rs_cost(const double* s1, const double* s2, double r)
 {
     const double dx = (s2[0] - s1[0]) / r, dy = (s2[1] - s1[1]) / r;
-    const double c1 = cos(s1[2]), s1n = sin(s1[2]);
+    const double c1 = mp_cos(s1[2]), s1n = mp_sin(s1[2]);
     const double X = dx * c1 + dy * s1n, Y = -dx * s1n + dy * c1, th = mod2pif(s2[2] - s1[2]);
-    const double st = sin(th), ct = cos(th);
+    const double st = mp_sin(th), ct = mp_cos(th);
     const double Xb = X * ct + Y * st, Yb = X * st - Y * ct;              // backwards image (:247)
     int win;
     return rs_cost_win(X, Y, th, st, ct, Xb, Yb, win) * r;
@@ -373,9 +375,9 @@ __device__ inline double rs_cost(const double* s1, const double* s2, double r)
 __device__ inline double rs_steer_dev(const double* s1, const double* s2, double r, double s, car_step* path, int& L)
 {
     const double dx = (s2[0] - s1[0]) / r, dy = (s2[1] - s1[1]) / r;
-    const double c1 = cos(s1[2]), s1n = sin(s1[2]);
+    const double c1 = mp_cos(s1[2]), s1n = mp_sin(s1[2]);
     const double X = dx * c1 + dy * s1n, Y = -dx * s1n + dy * c1, th = mod2pif(s2[2] - s1[2]);
-    const double st = sin(th), ct = cos(th);
+    const double st = mp_sin(th), ct = mp_cos(th);
     const double Xb = X * ct + Y * st, Yb = X * st - Y * ct;
     int win;
     rs_cost_win(X, Y, th, st, ct, Xb, Yb, win);
@@ -492,7 +494,7 @@ __device__ inline bool car_motion_free(const double* v0, const double* w, double
         if (m != 0)
             for (long i = 1; i <= m && ok; ++i) {
                 const double ai = (double)i * thres;
-                const double p[3] = {v[0] + (sin(v[2] + ai) - sin(v[2])) / u.k, v[1] + (cos(v[2]) - cos(v[2] + ai)) / u.k, mod2pif(v[2] + ai)};
+                const double p[3] = {v[0] + (mp_sin(v[2] + ai) - mp_sin(v[2])) / u.k, v[1] + (mp_cos(v[2]) - mp_cos(v[2] + ai)) / u.k, mod2pif(v[2] + ai)};
                 visit(p);
             }
         double nv[3];

@@ -34,6 +34,7 @@
  * reference's 1-based convention where a test needs it.
  */
 #include <math.h>
+#include "../motionplanning.jl_amd/csrc/mp_math.h"
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -706,6 +707,11 @@ int32_t orc_fmtstar_graph(const double *X, int64_t N, int32_t d, int64_t init_id
     free(Wm); free(Hm); free(Hnew); free(rev); free(heap.pri); free(heap.idx);
     return 0;
 }
+
+double orc_mp_sin(double x) { return mp_sin(x); }
+double orc_mp_cos(double x) { return mp_cos(x); }
+double orc_mp_atan2(double y, double x) { return mp_atan2(y, x); }
+double orc_mp_acos(double x) { return mp_acos(x); }
 
 /* The portable input stream of the synthetic workloads: SplitMix64 (Steele, Lea, Flood, "Fast splittable
  * pseudorandom number generators", OOPSLA 2014; Vigna's splitmix64.c), used counter-based.  Draw i (0-based) of seed s:
@@ -1396,7 +1402,9 @@ void orc_2d_graph_edges_free(const double *X, int64_t N, const int64_t *colptr, 
  * States are SE2 (x, y, theta); the workspace is (x, y) (VectorView(1:2), :37).  The quasi-metric is the exact Dubins
  * length for turning radius rt and speed s; the near-neighbour sets are "chopped": candidates within Euclidean
  * (x, y) distance r (KD-tree on positions, :45-49, nearneighbors.jl:185-198), kept when the Dubins cost is <= r.
- * Arithmetic as written in the reference (unfused, operation order kept); sin/cos/atan2/acos/sqrt/fmod are libm's.
+ * Arithmetic as written in the reference (unfused, operation order kept); sin / cos / atan2 / acos are mp_math.h's -- fixed
+ * reductions and polynomials built from + - * / sqrt, the same header the device kernels compile, so both sides produce the
+ * same bits (libm's differ between glibc and the GPU's by an ulp or two, which moved threshold decisions); sqrt / fmod are libm's (exact).
  * mod2piF(x) = mod(x, 2*pi) (utils.jl:91) with Julia's mod for floats: r = rem(x, y); r == 0 ? +0 : (r < 0 ? r + y : r). */
 #define ORC_TWOPI (2 * 3.141592653589793)
 static double mod2pif(double x)
@@ -1416,15 +1424,15 @@ double orc_dubins(const double *s1, const double *s2, double r, double s, orc_st
 {
     const double vx = (s2[0] - s1[0]) / r, vy = (s2[1] - s1[1]) / r;
     const double d = sqrt(vx * vx + vy * vy);
-    const double th = atan2(vy, vx);
+    const double th = mp_atan2(vy, vx);
     const double a = mod2pif(s1[2] - th), b = mod2pif(s2[2] - th);
-    const double ca = cos(a), sa = sin(a), cb = cos(b), sb = sin(b);
+    const double ca = mp_cos(a), sa = mp_sin(a), cb = mp_cos(b), sb = mp_sin(b);
     double c = INFINITY;
     for (int q = 0; q < 3; ++q) { path[q].t = 0; path[q].s = 0; path[q].k = 0; }
     {   /* LSL :106-119 */
         const double tmp = 2 + d * d - 2 * (ca * cb + sa * sb - d * (sa - sb));
         if (!(tmp < 0)) {
-            const double t0 = atan2(cb - ca, d + sa - sb);
+            const double t0 = mp_atan2(cb - ca, d + sa - sb);
             const double t = mod2pif(-a + t0), p = sqrt(fmax(tmp, 0.0)), q = mod2pif(b - t0);
             DUB_TRY(t + p + q, 1, t, 0, p, 1, q);
         }
@@ -1432,7 +1440,7 @@ double orc_dubins(const double *s1, const double *s2, double r, double s, orc_st
     {   /* RSR :121-134 */
         const double tmp = 2 + d * d - 2 * (ca * cb + sa * sb - d * (sb - sa));
         if (!(tmp < 0)) {
-            const double t0 = atan2(ca - cb, d - sa + sb);
+            const double t0 = mp_atan2(ca - cb, d - sa + sb);
             const double t = mod2pif(a - t0), p = sqrt(fmax(tmp, 0.0)), q = mod2pif(-b + t0);
             DUB_TRY(t + p + q, -1, t, 0, p, -1, q);
         }
@@ -1441,7 +1449,7 @@ double orc_dubins(const double *s1, const double *s2, double r, double s, orc_st
         const double tmp = d * d - 2 + 2 * (ca * cb + sa * sb - d * (sa + sb));
         if (!(tmp < 0)) {
             const double p = sqrt(fmax(tmp, 0.0));
-            const double t0 = atan2(ca + cb, d - sa - sb) - atan2(2.0, p);
+            const double t0 = mp_atan2(ca + cb, d - sa - sb) - mp_atan2(2.0, p);
             const double t = mod2pif(a - t0), q = mod2pif(b - t0);
             DUB_TRY(t + p + q, -1, t, 0, p, 1, q);
         }
@@ -1450,7 +1458,7 @@ double orc_dubins(const double *s1, const double *s2, double r, double s, orc_st
         const double tmp = -2 + d * d + 2 * (ca * cb + sa * sb + d * (sa + sb));
         if (!(tmp < 0)) {
             const double p = sqrt(fmax(tmp, 0.0));
-            const double t0 = atan2(-ca - cb, d + sa + sb) - atan2(-2.0, p);
+            const double t0 = mp_atan2(-ca - cb, d + sa + sb) - mp_atan2(-2.0, p);
             const double t = mod2pif(-a + t0), q = mod2pif(-b + t0);
             DUB_TRY(t + p + q, 1, t, 0, p, -1, q);
         }
@@ -1458,8 +1466,8 @@ double orc_dubins(const double *s1, const double *s2, double r, double s, orc_st
     {   /* RLR :166-179 */
         const double tmp = (6 - d * d + 2 * (ca * cb + sa * sb + d * (sa - sb))) / 8;
         if (!(fabs(tmp) >= 1)) {
-            const double p = ORC_TWOPI - acos(tmp);
-            const double t0 = atan2(ca - cb, d - sa + sb);
+            const double p = ORC_TWOPI - mp_acos(tmp);
+            const double t0 = mp_atan2(ca - cb, d - sa + sb);
             const double t = mod2pif(a - t0 + p / 2), q = mod2pif(a - b - t + p);
             DUB_TRY(t + p + q, -1, t, 1, p, -1, q);
         }
@@ -1467,8 +1475,8 @@ double orc_dubins(const double *s1, const double *s2, double r, double s, orc_st
     {   /* LRL :181-194 */
         const double tmp = (6 - d * d + 2 * (ca * cb + sa * sb - d * (sa - sb))) / 8;
         if (!(fabs(tmp) >= 1)) {
-            const double p = ORC_TWOPI - acos(tmp);
-            const double t0 = atan2(-ca + cb, d + sa - sb);
+            const double p = ORC_TWOPI - mp_acos(tmp);
+            const double t0 = mp_atan2(-ca + cb, d + sa - sb);
             const double t = mod2pif(-a + t0 + p / 2), q = mod2pif(b - a - t + p);
             DUB_TRY(t + p + q, 1, t, -1, p, 1, q);
         }
@@ -1485,12 +1493,12 @@ static void car_propagate(const double *v, orc_step u, double *out)
 {
     const double ang = u.t * u.s * u.k;
     if (fabs(ang) > 10 * 2.220446049250313e-16) {
-        out[0] = v[0] + (sin(v[2] + ang) - sin(v[2])) / u.k;
-        out[1] = v[1] + (cos(v[2]) - cos(v[2] + ang)) / u.k;
+        out[0] = v[0] + (mp_sin(v[2] + ang) - mp_sin(v[2])) / u.k;
+        out[1] = v[1] + (mp_cos(v[2]) - mp_cos(v[2] + ang)) / u.k;
         out[2] = mod2pif(v[2] + ang);
     } else {
-        out[0] = v[0] + u.t * u.s * cos(v[2]);
-        out[1] = v[1] + u.t * u.s * sin(v[2]);
+        out[0] = v[0] + u.t * u.s * mp_cos(v[2]);
+        out[1] = v[1] + u.t * u.s * mp_sin(v[2]);
         out[2] = mod2pif(v[2] + ang);
     }
 }
@@ -1498,16 +1506,16 @@ static void car_propagate(const double *v, orc_step u, double *out)
 /* ---- Reeds-Shepp car: simplecars.jl:228-524 (ReedsSheppMetricSpace :26-31).  Nine word families, each tried on the target
  * and its time-flipped / reflected / backwards images in the reference's order; a later candidate replaces the incumbent only
  * when strictly shorter.  Negative segment lengths mean reverse gear (carsegment2stepcontrol: speed = sign(d)). */
-static void rs_R(double x, double y, double *r, double *th) { *r = sqrt(x * x + y * y); *th = atan2(y, x); }      /* :230 */
+static void rs_R(double x, double y, double *r, double *th) { *r = sqrt(x * x + y * y); *th = mp_atan2(y, x); }      /* :230 */
 static double rs_M(double t) { const double m = mod2pif(t); return m > 3.141592653589793 ? m - ORC_TWOPI : m; }      /* :232-235 */
 static double rs_Tau(double u, double v, double E, double N)                                                          /* :236-243 */
 {
     const double delta = rs_M(u - v);
-    const double A = sin(u) - sin(delta);
-    const double B = cos(u) - cos(delta) - 1;
+    const double A = mp_sin(u) - mp_sin(delta);
+    const double B = mp_cos(u) - mp_cos(delta) - 1;
     double r, th;
     rs_R(E * A + N * B, N * A - E * B, &r, &th);
-    const double t = 2 * cos(delta) - 2 * cos(v) - 2 * cos(u) + 3;
+    const double t = 2 * mp_cos(delta) - 2 * mp_cos(v) - 2 * mp_cos(u) + 3;
     return t < 0 ? rs_M(th + 3.141592653589793) : rs_M(th);
 }
 static double rs_Omega(double u, double v, double E, double N, double t) { return rs_M(rs_Tau(u, v, E, N) - u + v - t); }   /* :244 */
@@ -1519,14 +1527,14 @@ typedef struct { double c; int l; int post; orc_step p[5]; } rs_best;
 static void rs_LpSpLp(const double *T, rs_best *b, int post)                   /* (8.1) :365-376 */
 {
     double r, th;
-    rs_R(T[0] - sin(T[2]), T[1] - 1 + cos(T[2]), &r, &th);
+    rs_R(T[0] - mp_sin(T[2]), T[1] - 1 + mp_cos(T[2]), &r, &th);
     const double u = r, t = mod2pif(th), v = mod2pif(T[2] - t);
     RS_ACCEPT(b, t + u + v, 3, post, car_seg(1, t), car_seg(0, u), car_seg(1, v));
 }
 static void rs_LpSpRp(const double *T, rs_best *b, int post)                   /* (8.2) :378-391 */
 {
     double r, th, r1, th1;
-    rs_R(T[0] + sin(T[2]), T[1] - 1 - cos(T[2]), &r, &th);
+    rs_R(T[0] + mp_sin(T[2]), T[1] - 1 - mp_cos(T[2]), &r, &th);
     if (r * r < 4) return;
     const double u = sqrt(r * r - 4);
     rs_R(u, 2.0, &r1, &th1);
@@ -1535,51 +1543,51 @@ static void rs_LpSpRp(const double *T, rs_best *b, int post)                   /
 }
 static void rs_LpRmLp(const double *T, rs_best *b, int post)                   /* (8.3) :393-408 */
 {
-    const double E = T[0] - sin(T[2]), N = T[1] + cos(T[2]) - 1;
+    const double E = T[0] - mp_sin(T[2]), N = T[1] + mp_cos(T[2]) - 1;
     if (E * E + N * N > 16) return;
     double r, th;
     rs_R(E, N, &r, &th);
-    double u = acos(1 - r * r / 8);
+    double u = mp_acos(1 - r * r / 8);
     const double t = mod2pif(th - u / 2 + 3.141592653589793), v = mod2pif(3.141592653589793 - u / 2 - th + T[2]);
     u = -u;
     RS_ACCEPT(b, t - u + v, 3, post, car_seg(1, t), car_seg(-1, u), car_seg(1, v));
 }
 static void rs_LpRmLm(const double *T, rs_best *b, int post)                   /* (8.4) :410-425 */
 {
-    const double E = T[0] - sin(T[2]), N = T[1] + cos(T[2]) - 1;
+    const double E = T[0] - mp_sin(T[2]), N = T[1] + mp_cos(T[2]) - 1;
     if (E * E + N * N > 16) return;
     double r, th;
     rs_R(E, N, &r, &th);
-    double u = acos(1 - r * r / 8);
+    double u = mp_acos(1 - r * r / 8);
     const double t = mod2pif(th - u / 2 + 3.141592653589793), v = mod2pif(3.141592653589793 - u / 2 - th + T[2]) - ORC_TWOPI;
     u = -u;
     RS_ACCEPT(b, t - u - v, 3, post, car_seg(1, t), car_seg(-1, u), car_seg(1, v));
 }
 static void rs_LpRpuLmuRm(const double *T, rs_best *b, int post)               /* (8.7) :427-442 */
 {
-    const double E = T[0] + sin(T[2]), N = T[1] - cos(T[2]) - 1;
+    const double E = T[0] + mp_sin(T[2]), N = T[1] - mp_cos(T[2]) - 1;
     const double p = (2 + sqrt(E * E + N * N)) / 4;
     if (p < 0 || p > 1) return;
-    const double u = acos(p);
+    const double u = mp_acos(p);
     const double t = mod2pif(rs_Tau(u, -u, E, N)), v = mod2pif(rs_Omega(u, -u, E, N, T[2])) - ORC_TWOPI;
     RS_ACCEPT(b, t + 2 * u - v, 4, post, car_seg(1, t), car_seg(-1, u), car_seg(1, -u), car_seg(-1, v));
 }
 static void rs_LpRmuLmuRp(const double *T, rs_best *b, int post)               /* (8.8) :444-459 */
 {
-    const double E = T[0] + sin(T[2]), N = T[1] - cos(T[2]) - 1;
+    const double E = T[0] + mp_sin(T[2]), N = T[1] - mp_cos(T[2]) - 1;
     const double p = (20 - E * E - N * N) / 16;
     if (p < 0 || p > 1) return;
-    const double u = -acos(p);
+    const double u = -mp_acos(p);
     const double t = mod2pif(rs_Tau(u, u, E, N)), v = mod2pif(rs_Omega(u, u, E, N, T[2]));
     RS_ACCEPT(b, t - 2 * u + v, 4, post, car_seg(1, t), car_seg(-1, u), car_seg(1, u), car_seg(-1, v));
 }
 static void rs_LpRmSmLm(const double *T, rs_best *b, int post)                 /* (8.9) :461-479 */
 {
-    const double E = T[0] - sin(T[2]), N = T[1] + cos(T[2]) - 1;
+    const double E = T[0] - mp_sin(T[2]), N = T[1] + mp_cos(T[2]) - 1;
     double D, be;
     rs_R(E, N, &D, &be);
     if (D < 2) return;
-    const double ga = acos(2 / D), F = sqrt(D * D / 4 - 1);
+    const double ga = mp_acos(2 / D), F = sqrt(D * D / 4 - 1);
     const double t = mod2pif(3.141592653589793 + be - ga), u = 2 - 2 * F;
     if (u > 0) return;
     const double v = mod2pif(-3 * 3.141592653589793 / 2 + ga + T[2] - be) - ORC_TWOPI;
@@ -1587,7 +1595,7 @@ static void rs_LpRmSmLm(const double *T, rs_best *b, int post)                 /
 }
 static void rs_LpRmSmRm(const double *T, rs_best *b, int post)                 /* (8.10) :481-497 */
 {
-    const double E = T[0] + sin(T[2]), N = T[1] - cos(T[2]) - 1;
+    const double E = T[0] + mp_sin(T[2]), N = T[1] - mp_cos(T[2]) - 1;
     double D, be;
     rs_R(E, N, &D, &be);
     if (D < 2) return;
@@ -1598,11 +1606,11 @@ static void rs_LpRmSmRm(const double *T, rs_best *b, int post)                 /
 }
 static void rs_LpRmSmLmRp(const double *T, rs_best *b, int post)               /* (8.11) :499-518 */
 {
-    const double E = T[0] + sin(T[2]), N = T[1] - cos(T[2]) - 1;
+    const double E = T[0] + mp_sin(T[2]), N = T[1] - mp_cos(T[2]) - 1;
     double D, be;
     rs_R(E, N, &D, &be);
     if (D < 2) return;
-    const double ga = acos(2 / D), F = sqrt(D * D / 4 - 1);
+    const double ga = mp_acos(2 / D), F = sqrt(D * D / 4 - 1);
     const double t = mod2pif(3.141592653589793 + be - ga), u = 4 - 2 * F;
     if (u > 0) return;
     const double v = mod2pif(3.141592653589793 + be - T[2] - ga);
@@ -1614,7 +1622,7 @@ static void rs_LpRmSmLmRp(const double *T, rs_best *b, int post)               /
 double orc_reedsshepp(const double *s1, const double *s2, double r, double s, orc_step *path, int32_t *L)
 {
     const double dx = (s2[0] - s1[0]) / r, dy = (s2[1] - s1[1]) / r;
-    const double ct = cos(s1[2]), st = sin(s1[2]);
+    const double ct = mp_cos(s1[2]), st = mp_sin(s1[2]);
     double T[8][3];            /* POST, T, R, B, R_T, B_T, B_R, B_R_T in the reference's numbering 0..7 */
     T[0][0] = dx * ct + dy * st; T[0][1] = -dx * st + dy * ct; T[0][2] = mod2pif(s2[2] - s1[2]);
 #define RS_TIMEFLIP(D, S) do { (D)[0] = -(S)[0]; (D)[1] = (S)[1]; (D)[2] = -(S)[2]; } while (0)
@@ -1622,8 +1630,8 @@ double orc_reedsshepp(const double *s1, const double *s2, double r, double s, or
     RS_TIMEFLIP(T[1], T[0]);                       /* tTarget   */
     RS_REFLECT(T[2], T[0]);                        /* rTarget   */
     RS_REFLECT(T[4], T[1]);                        /* trTarget  */
-    T[3][0] = T[0][0] * cos(T[0][2]) + T[0][1] * sin(T[0][2]);      /* bTarget = backwards(target) :247 */
-    T[3][1] = T[0][0] * sin(T[0][2]) - T[0][1] * cos(T[0][2]);
+    T[3][0] = T[0][0] * mp_cos(T[0][2]) + T[0][1] * mp_sin(T[0][2]);      /* bTarget = backwards(target) :247 */
+    T[3][1] = T[0][0] * mp_sin(T[0][2]) - T[0][1] * mp_cos(T[0][2]);
     T[3][2] = T[0][2];
     RS_TIMEFLIP(T[5], T[3]);                       /* btTarget  */
     RS_REFLECT(T[6], T[3]);                        /* brTarget  */
@@ -1682,8 +1690,8 @@ int32_t orc_car_waypoints(int32_t kind, const double *v0, const double *w, doubl
         if (m != 0)
             for (long i = 1; i <= m && n < ORC_DUB_MAXWP - 2; ++i) {
                 const double ai = (double)i * thres;
-                wps[3 * n] = v[0] + (sin(v[2] + ai) - sin(v[2])) / u.k;
-                wps[3 * n + 1] = v[1] + (cos(v[2]) - cos(v[2] + ai)) / u.k;
+                wps[3 * n] = v[0] + (mp_sin(v[2] + ai) - mp_sin(v[2])) / u.k;
+                wps[3 * n + 1] = v[1] + (mp_cos(v[2]) - mp_cos(v[2] + ai)) / u.k;
                 wps[3 * n + 2] = mod2pif(v[2] + ai);
                 ++n;
             }

@@ -52,6 +52,8 @@ def lib():
         L.orc_kdtree_free.restype = None
         L.orc_kdtree_inball.restype = C.c_int64
         L.orc_expand.restype = C.c_int64
+        for f in (L.orc_mp_sin, L.orc_mp_cos, L.orc_mp_atan2, L.orc_mp_acos):
+            f.restype = C.c_double
         L.orc_splitmix64.restype = C.c_uint64
         L.orc_stream_uniform.restype = None
         L.orc_euclid_steer.restype = None
@@ -262,6 +264,22 @@ def fmtstar_graph(X, colptr, rowval, nzval, free_mask, Fmask, goal_kind, goal, l
                                  _d(ss_lo), _d(ss_hi), _i(A), _d(Cc), _i(path), C.byref(res))
     return dict(rc=rc, status=int(res.status), cost=float(res.cost), z=int(res.z),
                 collision_checks=int(res.collision_checks), A=A, C=Cc, path=path[:res.path_len].copy())
+
+
+def mp_sin(x):
+    return lib().orc_mp_sin(C.c_double(x))
+
+
+def mp_cos(x):
+    return lib().orc_mp_cos(C.c_double(x))
+
+
+def mp_atan2(y, x):
+    return lib().orc_mp_atan2(C.c_double(y), C.c_double(x))
+
+
+def mp_acos(x):
+    return lib().orc_mp_acos(C.c_double(x))
 
 
 def splitmix64(seed, i):

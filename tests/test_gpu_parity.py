@@ -790,17 +790,17 @@ def test_dubins_steer_batch(ctx, orc):
         cost, ctrl = ctx.dubins_steer(X0, X1, rt, 1.0)
         want = [orc.dubins(a, b, rt, 1.0) for a, b in zip(X0, X1)]
         wc = np.array([w[0] for w in want]); wu = np.array([w[1] for w in want])
-        assert np.allclose(cost, wc, rtol=1e-12, atol=0)
-        same_word = np.all(ctrl[:, :, 1:] == wu[:, :, 1:], axis=(1, 2))
-        assert same_word.mean() > 0.999                                 # ties between words can resolve differently at 1 ulp
-        assert np.allclose(ctrl[same_word], wu[same_word], rtol=1e-9, atol=1e-12)
+        # sin / cos / atan2 / acos come from ONE header on both sides (mp_math.h): costs, the winning word and its segment
+        # durations are bit-identical
+        assert np.array_equal(cost, wc)
+        assert np.array_equal(ctrl, wu)
 
 
 @pytest.mark.parametrize("N,rt,r", [(1500, 0.05, 0.25), (2500, 0.15, 0.3)])
 def test_dubins_graph_sweep_and_plan(ctx, orc, N, rt, r):
-    """Dubins backward sets, edge validity with the reference's arc waypoints, and a full plan, against the oracle.
-    Device and host libm differ by a few ulp, so costs are compared to 1e-12 and set membership / masks are required to be
-    identical except for pairs whose cost sits within 1e-9 of the radius (none expected on seeded data)."""
+    """Dubins backward sets, edge validity with the reference's arc waypoints, and a full plan, against the oracle:
+    graph, costs, masks, per-edge segment counts, tree, path and collision_checks all bit-exact (the transcendental functions
+    are mp_math.h's on both sides)."""
     rng = np.random.default_rng(70 + N)
     X, lohi, lo, hi = _car_world(rng, N, 12)
     X[0] = [0.05, 0.05, 0.6]; X[-1] = [0.95, 0.95, 0.8]
@@ -809,29 +809,20 @@ def test_dubins_graph_sweep_and_plan(ctx, orc, N, rt, r):
     colptr, rowval, nzval = ctx.dubins_graph(rt, 1.0, r)
     oc, orow, oval = orc.dubins_graph(X, rt, 1.0, r)
     c0, r0 = to0(colptr, rowval)
-    if not (np.array_equal(c0, oc) and np.array_equal(r0, orow)):
-        # tolerate only threshold-straddling pairs
-        got = set(zip(np.repeat(np.arange(N), np.diff(c0)).tolist(), r0.tolist()))
-        want = set(zip(np.repeat(np.arange(N), np.diff(oc)).tolist(), orow.tolist()))
-        for (j, i) in got ^ want:
-            assert abs(orc.dubins(X[i], X[j], rt, 1.0)[0] - r) < 1e-9 * r
-        pytest.skip("threshold-straddling pair on this seed")
-    assert np.allclose(nzval, oval, rtol=1e-12, atol=0)
+    assert np.array_equal(c0, oc) and np.array_equal(r0, orow)
+    assert np.array_equal(nzval, oval)
     assert len(r0) > 5 * N                                                # a real graph, not a trivial one
     mask, nseg = ctx.dubins_graph_edges_free()
     omask, onseg = orc.dubins_graph_edges_free(X, rt, 1.0, oc, orow, lohi, lo, hi)
-    agree = (mp._lib.unpack_bits(mask, len(r0)) == orc.unpack(omask, len(r0)))
-    assert agree.mean() > 0.9999 and (nseg == onseg)[agree].mean() > 0.9999
+    assert np.array_equal(mask, omask) and np.array_equal(nseg, onseg)
     assert 0.2 < mp._lib.unpack_bits(mask, len(r0)).mean() < 0.999
     goal = np.array([0.95, 0.95, 0.08])
     got = ctx.dubins_fmtstar(rt, 1.0, r, mp._lib.GOAL_BALL, goal)
     want = orc.dubins_fmtstar(X, rt, 1.0, oc, orow, oval, orc.GOAL_BALL, goal, lohi, lo, hi, init_idx=0)
     assert got["status"] == want["status"]
-    if agree.all():
-        assert np.array_equal(got["A"] - 1, want["A"]) and np.array_equal(got["path"] - 1, want["path"])
-        assert got["collision_checks"] == want["collision_checks"]
-        assert np.allclose(got["C"], want["C"], rtol=1e-10, atol=0)
-        assert abs(got["cost"] - want["cost"]) <= 1e-10 * max(want["cost"], 1e-300)
+    assert np.array_equal(got["A"] - 1, want["A"]) and np.array_equal(got["path"] - 1, want["path"])
+    assert got["collision_checks"] == want["collision_checks"]
+    assert np.array_equal(got["C"], want["C"]) and got["cost"] == want["cost"]
 
 
 # ---- Reeds-Shepp car -----------------------------------------------------------------------------------
@@ -849,10 +840,8 @@ def test_reedsshepp_steer_batch(ctx, orc):
         wu = np.zeros((len(want), 5, 3))
         for i, w in enumerate(want):
             wu[i, :len(w[1])] = w[1]
-        assert np.allclose(cost, wc, rtol=1e-12, atol=1e-15)
-        same_word = (nsegs == wl) & np.all(ctrl[:, :, 1:] == wu[:, :, 1:], axis=(1, 2))
-        assert same_word.mean() > 0.995                                 # ties between words can resolve differently at 1 ulp
-        assert np.allclose(ctrl[same_word], wu[same_word], rtol=1e-9, atol=1e-12)
+        assert np.array_equal(cost, wc)                                 # same transcendental functions on both sides (mp_math.h)
+        assert np.array_equal(nsegs, wl) and np.array_equal(ctrl, wu)  # ... so ties between words resolve identically
         for i in range(len(want)):                                      # segments past nsegs are zero
             assert not ctrl[i, nsegs[i]:].any()
 
@@ -860,7 +849,7 @@ def test_reedsshepp_steer_batch(ctx, orc):
 @pytest.mark.parametrize("N,rt,r", [(1500, 0.05, 0.2), (2500, 0.15, 0.25)])
 def test_reedsshepp_graph_sweep_and_plan(ctx, orc, N, rt, r):
     """Reeds-Shepp inball sets (column v holds d(v, w)), edge validity over the reference's waypoints, and a full plan
-    through the symmetric recursion, against the oracle.  Same tolerances as the Dubins test."""
+    through the symmetric recursion, against the oracle: all bit-exact, like the Dubins test."""
     rng = np.random.default_rng(90 + N)
     X, lohi, lo, hi = _car_world(rng, N, 12)
     X[0] = [0.05, 0.05, 0.6]; X[-1] = [0.95, 0.95, 0.8]
@@ -869,35 +858,22 @@ def test_reedsshepp_graph_sweep_and_plan(ctx, orc, N, rt, r):
     colptr, rowval, nzval = ctx.reedsshepp_graph(rt, 1.0, r)
     oc, orow, oval = orc.rs_graph(X, rt, 1.0, r)
     c0, r0 = to0(colptr, rowval)
-    if not (np.array_equal(c0, oc) and np.array_equal(r0, orow)):
-        got = set(zip(np.repeat(np.arange(N), np.diff(c0)).tolist(), r0.tolist()))
-        want = set(zip(np.repeat(np.arange(N), np.diff(oc)).tolist(), orow.tolist()))
-        for (j, i) in got ^ want:
-            assert abs(orc.reedsshepp(X[j], X[i], rt, 1.0)[0] - r) < 1e-9 * r
-        pytest.skip("threshold-straddling pair on this seed")
-    assert np.allclose(nzval, oval, rtol=1e-12, atol=0)
+    assert np.array_equal(c0, oc) and np.array_equal(r0, orow)
+    assert np.array_equal(nzval, oval)
     assert len(r0) > 5 * N
     mask, nseg = ctx.reedsshepp_graph_edges_free()
     omask, onseg = orc.car_graph_edges_free(2, X, rt, 1.0, oc, orow, lohi, lo, hi)
-    agree = (mp._lib.unpack_bits(mask, len(r0)) == orc.unpack(omask, len(r0)))
-    assert agree.mean() > 0.9999 and (nseg == onseg)[agree].mean() > 0.999
+    assert np.array_equal(mask, omask) and np.array_equal(nseg, onseg)
     assert 0.2 < mp._lib.unpack_bits(mask, len(r0)).mean() < 0.999
     goal = np.array([0.95, 0.95, 0.08])
     got = ctx.reedsshepp_fmtstar(rt, 1.0, r, mp._lib.GOAL_BALL, goal)
-    # Reeds-Shepp words of the C|C|C kind have length = turning radius x heading change, so two parents reached by such
-    # words give a child the SAME cost-to-come up to rounding (exact ties the reference also breaks by floating-point
-    # noise).  The recursion is therefore pinned with the device's own edge costs (identical graph, costs equal to the
-    # oracle's to 1e-12), where it must agree exactly; against the oracle's costs only the values are compared.
-    want = orc.rs_fmtstar(X, rt, 1.0, oc, orow, nzval, orc.GOAL_BALL, goal, lohi, lo, hi, init_idx=0)
+    # (Reeds-Shepp words of the C|C|C kind have length = turning radius x heading change, so two parents reached by such words
+    # tie up to rounding; with one set of transcendental functions on both sides the ties break identically.)
+    want = orc.rs_fmtstar(X, rt, 1.0, oc, orow, oval, orc.GOAL_BALL, goal, lohi, lo, hi, init_idx=0)
     assert got["status"] == want["status"] == 1
-    if agree.all() and (nseg == onseg).all():
-        assert np.array_equal(got["A"] - 1, want["A"]) and np.array_equal(got["path"] - 1, want["path"])
-        assert got["collision_checks"] == want["collision_checks"]
-        assert np.array_equal(got["C"], want["C"]) and got["cost"] == want["cost"]
-    ref = orc.rs_fmtstar(X, rt, 1.0, oc, orow, oval, orc.GOAL_BALL, goal, lohi, lo, hi, init_idx=0)
-    assert ref["status"] == 1 and abs(got["cost"] - ref["cost"]) <= 1e-9 * ref["cost"]
-    differs = (got["A"] - 1) != ref["A"]
-    assert differs.mean() < 0.02 and np.allclose(got["C"][~differs], ref["C"][~differs], rtol=1e-9, atol=0)
+    assert np.array_equal(got["A"] - 1, want["A"]) and np.array_equal(got["path"] - 1, want["path"])
+    assert got["collision_checks"] == want["collision_checks"]
+    assert np.array_equal(got["C"], want["C"]) and got["cost"] == want["cost"]
     # a dubins graph on the same context afterwards replaces the Reeds-Shepp one (and the other way round)
     ctx.dubins_graph(rt, 1.0, r)
     with pytest.raises(Exception):

@@ -513,3 +513,49 @@ def test_golden_di_pairs(orc):
     # a waypoint set starts at x0 and, for a pair within the radius, ends at x1 (to rounding)
     assert np.array_equal(z["waypoints"][ok, 0], z["X0"][ok])
     assert np.abs(z["waypoints"][inside & ok, 4] - z["X1"][inside & ok]).max() < 1e-12
+
+
+def test_mp_math_accuracy_against_mpmath(orc):
+    """mp_math.h (the fp64 sin / cos / atan2 / acos both the oracle and the device compile) against 200-bit mpmath: within
+    2 ulp on the ranges the car kernels use, exact special values, and the identities the word formulas rely on."""
+    import mpmath
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(5)
+
+    def ulps(got, want):
+        want_f = float(want)
+        if want_f == 0.0:
+            return abs(got) / 5e-324
+        return abs(mpmath.mpf(got) - want) / mpmath.mpf(np.spacing(abs(want_f)))
+    xs = np.concatenate([rng.uniform(-8 * np.pi, 8 * np.pi, 4000), rng.uniform(-1e-3, 1e-3, 500), rng.uniform(-1e4, 1e4, 500),
+                         np.arange(-16, 17) * (np.pi / 4), [0.0, 1e-300, -1e-300]])
+    worst = 0.0
+    for x in xs:
+        x = float(x)
+        for f, g in ((orc.mp_sin, mpmath.sin), (orc.mp_cos, mpmath.cos)):
+            want = g(mpmath.mpf(x))
+            if abs(float(want)) > 1e-12:                   # (near a zero of sin / cos the error is absolute: checked below)
+                worst = max(worst, float(ulps(f(x), want)))
+            assert abs(f(x) - float(want)) < 3e-16
+    assert worst <= 2.0, worst
+    worst = 0.0
+    for _ in range(5000):
+        y, x = float(rng.normal()), float(rng.normal())
+        if rng.random() < 0.2:
+            y *= 1e-8
+        if rng.random() < 0.2:
+            x *= 1e-8
+        worst = max(worst, float(ulps(orc.mp_atan2(y, x), mpmath.atan2(mpmath.mpf(y), mpmath.mpf(x)))))
+    assert worst <= 2.0, worst
+    worst = 0.0
+    for x in np.concatenate([rng.uniform(-1, 1, 4000), 1 - 10.0 ** rng.uniform(-16, -1, 300), -1 + 10.0 ** rng.uniform(-16, -1, 300)]):
+        x = float(x)
+        worst = max(worst, float(ulps(orc.mp_acos(x), mpmath.acos(mpmath.mpf(x)))))
+    assert worst <= 3.0, worst
+    import math
+    assert orc.mp_sin(0.0) == 0.0 and orc.mp_cos(0.0) == 1.0
+    assert orc.mp_atan2(0.0, 1.0) == 0.0 and orc.mp_atan2(0.0, -1.0) == math.pi and orc.mp_atan2(-0.0, -1.0) == -math.pi
+    assert orc.mp_atan2(1.0, 0.0) == math.pi / 2 and orc.mp_atan2(-1.0, 0.0) == -math.pi / 2 and orc.mp_atan2(0.0, 0.0) == 0.0
+    assert orc.mp_atan2(1.0, 1.0) == math.pi / 4 and orc.mp_atan2(2.0, -2.0) == 3 * math.pi / 4
+    assert orc.mp_acos(1.0) == 0.0 and orc.mp_acos(-1.0) == math.pi and orc.mp_acos(0.0) == math.pi / 2
+    assert math.isnan(orc.mp_acos(1.0000001)) and math.isnan(orc.mp_sin(float("inf"))) and math.isnan(orc.mp_atan2(float("nan"), 1.0))
