@@ -38,15 +38,18 @@ GATHER_CEILING_ROWS_PER_S = 4.51e10      # measured: 1e8 random 48-byte rows of 
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")      # written by tools/pmc_traffic.py from a rocprofv3 --pmc run
 
 
-def profiled_traffic(lib_version, workload, world):
+def profiled_traffic(so_path, workload, world):
     """HBM bytes per launch of the pair kernel and of the sweep from the committed PMC summary (profiles/traffic.json, made by
-    tools/pmc_traffic.py out of separate FETCH_SIZE / WRITE_SIZE passes).  None when the summary was taken on another
-    build of the library, another workload or another shard count -- a stale constant is worse than no number."""
+    tools/pmc_traffic.py out of separate FETCH_SIZE / WRITE_SIZE passes).  Empty when the summary was taken on another
+    build of the library (sha256 of libmpfmt.so), another workload or another shard count -- a stale constant is worse
+    than no number."""
+    import hashlib
     try:
         t = json.load(open(TRAFFIC_FILE))
+        sha = hashlib.sha256(open(so_path, "rb").read()).hexdigest()
     except Exception:
         return {}
-    if t.get("lib_version") != lib_version or t.get("workload") != workload or t.get("n_gpus") != world:
+    if t.get("lib_sha256") != sha or t.get("workload") != workload or t.get("n_gpus") != world:
         return {}
     return t
 
@@ -283,7 +286,7 @@ def main():
     sweep_bytes = nnz * (2 * d * 8 + 8 + 1.0 / 8.0)
     sweep_gbs = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     lib_version = mp._lib.lib().mpfmt_version().decode()
-    prof = profiled_traffic(lib_version, w.name, world)
+    prof = profiled_traffic(mp._lib.so_path(), w.name, world)
 
     out = {
         "metric": "edges checked/sec + r-disc queries/sec, FMT* N=1e6 R^6, 1/2/4/8 MI355X",
@@ -327,6 +330,7 @@ def main():
             "bound": "mfma", "achieved": ach_tflops, "peak": peak, "unit": "TFLOP/s",
             "frac": ach_tflops / peak,
             "traffic": prof.get("pair", {}).get("bytes"),
+            "traffic_gather_calibrated": prof.get("pair", {}).get("bytes_gather_calibrated"),
             "traffic_source": prof.get("source") if prof.get("pair") else None,
             "mfma_flops_issued_tflops": mfma_tflops,
             "frac_of_fp64_peak": ach_tflops / FP64_PEAK_TFLOPS,
@@ -344,6 +348,8 @@ def main():
             "kernel": "k_graph_sweep", "bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": sweep_gbs / HBM_PEAK_GBS,
             "traffic": prof.get("sweep", {}).get("bytes"),
+            "traffic_gather_calibrated": prof.get("sweep", {}).get("bytes_gather_calibrated"),
+            "l2_hit_rate": prof.get("sweep", {}).get("l2_hit_rate"),
             "traffic_source": prof.get("source") if prof.get("sweep") else None,
             "valu_frac": valu_frac,
             "gather_ceiling_edges_per_s": GATHER_CEILING_ROWS_PER_S if d == 6 else None,

@@ -152,7 +152,7 @@ __global__ void k_i32_to_i64_add1(const int32_t* __restrict__ in, int64_t n, int
 
 extern "C" {
 
-const char* mpfmt_version(void) { return "mpfmt 0.1.0 gfx950"; }
+const char* mpfmt_version(void) { return "mpfmt 0.2.0 gfx950"; }
 
 const char* mpfmt_last_error(const mpfmt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
