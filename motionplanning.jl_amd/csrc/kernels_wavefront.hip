@@ -40,6 +40,7 @@ struct wf_ctr {
     int32_t done;                 // 0 running, 2 open set exhausted, 1 goal in batch (set by k_wf_final; while running the
                                   // goal condition is goal_cbits != ~0, see wf_stop)
     int32_t ntrip;                // triples emitted this step (sharded)
+    int32_t nz, nx;               // batch nodes / candidates of this step (lists zlist / xlist)
     int64_t iters;
     unsigned long long goal_cbits;   // lowest cost (as bits) of a goal node in the batch, ~0 = none
     int64_t final_z;              // resolved by k_wf_final
@@ -60,11 +61,12 @@ struct mpfmt_wf {
     uint64_t *W = nullptr, *H = nullptr, *Z = nullptr, *Zp = nullptr, *Hn = nullptr, *cand = nullptr, *F = nullptr;
     double* C = nullptr;
     int32_t* A = nullptr;
+    int32_t *zlist = nullptr, *xlist = nullptr;                   // batch nodes / candidates of the step, compacted from the masks
     double* part_c = nullptr; int64_t* part_i = nullptr;          // per-block lexicographic minima of the open set
     double* last_c = nullptr; int64_t* last_i = nullptr;          // per-block lexicographic maxima of the batch (last node in pop order)
     int64_t* stats = nullptr;     // [WF_MAXBLK][4] per-block cumulative statistics
     double* boxT = nullptr;       // obstacle set transposed [2*d][mpad]: lane = obstacle reads are coalesced
-    int mpad = 0;
+    int mpad = 0, boxT_cap = 0;
     wf_trip* mytrips = nullptr;   // [N] connections of this rank in the current step (sharded)
     wf_trip* xbuf = nullptr;      // [world][WF_XCAP + 1] exchange slots: header (x = the rank's total count) + one round's triples
     wf_trip* hdr_host = nullptr;  // pinned [world] headers of the last exchange round
@@ -122,6 +124,24 @@ __device__ __forceinline__ void wf_lexmax_wave(double& c, int64_t& i)
     }
 }
 
+// Compaction of a bit mask into an index list, one word per lane: wave prefix sum of the popcounts, ONE atomic per wavefront
+// on the list counter, every lane then writes the indices of its own word.
+__device__ __forceinline__ void wf_append_word(unsigned long long m, int64_t w, int32_t* __restrict__ list, int32_t* counter)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = __popcll(m);
+    int inc = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+    const int total = __shfl(inc, 63);
+    if (total == 0) return;
+    int base = 0;
+    if (lane == 63) base = atomicAdd(counter, total);
+    base = __shfl(base, 63);
+    int o = base + inc - n;
+    while (m) { const int b = __ffsll((long long)m) - 1; m &= m - 1; list[o++] = (int32_t)(w * 64 + b); }
+}
+
 // statistics of one block: added to the block's own slot (the only writer of that slot; launches on a stream are ordered)
 __device__ __forceinline__ void wf_block_stat(int64_t* stats, int which, int v)
 {
@@ -156,7 +176,10 @@ __global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __
                                                      int64_t* __restrict__ part_i, wf_ctr* __restrict__ ctr)
 {
     if (wf_stop(ctr)) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr->iters += 1; ctr->ntrip = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {              // (no other thread of this kernel touches these fields)
+        ctr->tot[WF_NZ] += ctr->nz; ctr->tot[WF_NX] += ctr->nx;
+        ctr->iters += 1; ctr->ntrip = 0; ctr->nz = 0; ctr->nx = 0;
+    }
     double bc = 0.0; int64_t bi = -1;
     for (int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 64) {
         const uint64_t z = Z[w];
@@ -179,7 +202,7 @@ __global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __
 __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, const uint64_t* __restrict__ H, uint64_t* __restrict__ Z,
                                                   const double* __restrict__ C, const double* __restrict__ X, int d,
                                                   const double* __restrict__ part_c, const int64_t* __restrict__ part_i,
-                                                  double band, int single, wf_goal G, int64_t* __restrict__ stats,
+                                                  double band, int single, wf_goal G, int32_t* __restrict__ zlist,
                                                   wf_ctr* __restrict__ ctr)
 {
     if (ctr->done) return;
@@ -195,9 +218,9 @@ __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, con
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { ctr->cmin = cm; ctr->imin = im; }
     const double thr = cm + band;
-    int nsel = 0;
-    for (int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 64) {
-        uint64_t h = H[w], z = 0;
+    for (int64_t w0 = (int64_t)blockIdx.x * 64; w0 < words; w0 += (int64_t)gridDim.x * 64) {       // wave-uniform trip count
+        const int64_t w = w0 + threadIdx.x;
+        uint64_t h = (w < words) ? H[w] : 0, z = 0;
         while (h) {
             const int b = __ffsll((long long)h) - 1;
             h &= h - 1;
@@ -209,22 +232,35 @@ __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, con
             if (wf_is_goal(X + i * d, G))           // fmt.jl:68
                 atomicMin(&ctr->goal_cbits, (unsigned long long)__double_as_longlong(c));
         }
-        if (z) { Z[w] = z; nsel += __popcll(z); }
+        if (z) Z[w] = z;
+        wf_append_word(z, w, zlist, &ctr->nz);
     }
-    wf_block_stat(stats, WF_NZ, nsel);
+}
+
+// candidate mask -> candidate list (balanced work for k_wf_connect: one wavefront per candidate, whatever word it sits in)
+__global__ __launch_bounds__(64) void k_wf_compact(int64_t words, const unsigned long long* __restrict__ cand, int32_t* __restrict__ xlist,
+                                                   wf_ctr* __restrict__ ctr)
+{
+    if (wf_stop(ctr)) return;
+    for (int64_t w0 = (int64_t)blockIdx.x * 64; w0 < words; w0 += (int64_t)gridDim.x * 64) {
+        const int64_t w = w0 + threadIdx.x;
+        wf_append_word((w < words) ? cand[w] : 0ull, w, xlist, &ctr->nx);
+    }
 }
 
 // the node the reference's loop would end on: goal node of lowest (cost, index) in the batch Z, or -- open set exhausted --
 // the last node of the previous batch Zp in pop order = highest (cost, index) (fmt.jl:85-89 leaves z at the last dequeued node)
-__global__ __launch_bounds__(64) void k_wf_final(int64_t words, const uint64_t* __restrict__ Z, const uint64_t* __restrict__ Zp,
+__global__ __launch_bounds__(1024) void k_wf_final(int64_t words, const uint64_t* __restrict__ Z, const uint64_t* __restrict__ Zp,
                                                  const double* __restrict__ C, const double* __restrict__ X, int d, wf_goal G,
                                                  wf_ctr* __restrict__ ctr)
 {
     const bool goal = ctr->goal_cbits != ~0ull;
     if (!goal && ctr->done != 2) return;
     const uint64_t* S = goal ? Z : Zp;
+    __shared__ double s_c[16];
+    __shared__ long long s_i[16];
     double bc = 0.0; int64_t bi = -1;
-    for (int64_t w = threadIdx.x; w < words; w += 64) {
+    for (int64_t w = threadIdx.x; w < words; w += blockDim.x) {
         uint64_t m = S[w];
         while (m) {
             const int b = __ffsll((long long)m) - 1;
@@ -240,7 +276,15 @@ __global__ __launch_bounds__(64) void k_wf_final(int64_t words, const uint64_t* 
         }
     }
     if (goal) wf_lexmin_wave(bc, bi); else wf_lexmax_wave(bc, bi);
+    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = bc; s_i[threadIdx.x >> 6] = bi; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) {
+            const double oc = s_c[k]; const int64_t oi = s_i[k];
+            if (oi < 0) continue;
+            const bool take = bi < 0 || (goal ? (oc < bc || (oc == bc && oi < bi)) : (oc > bc || (oc == bc && oi > bi)));
+            if (take) { bc = oc; bi = oi; }
+        }
         if (bi >= 0) ctr->final_z = bi;
         if (goal) ctr->done = 1;
     }
@@ -259,12 +303,12 @@ __global__ __launch_bounds__(256) void k_wf_sum_stats(const int64_t* __restrict_
         if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)&acc[k], (unsigned long long)v[k]);
     }
     __syncthreads();
-    if (threadIdx.x < 4) ctr->tot[threadIdx.x] = acc[threadIdx.x];
+    if (threadIdx.x == WF_NCONN || threadIdx.x == WF_CHECKS) ctr->tot[threadIdx.x] = acc[threadIdx.x];
 }
 
-// mark pass: one wavefront per word of the batch mask; for every batch node of the word the wavefront walks the node's column
-// (symmetric metric: forward set == column, nearneighbors.jl:200-203) and sets the candidate bit of every unvisited valid row
-__global__ __launch_bounds__(256) void k_wf_mark(int64_t words, const uint64_t* __restrict__ Z, const int64_t* __restrict__ colptr,
+// mark pass: one wavefront per batch node walks the node's column (symmetric metric: forward set == column,
+// nearneighbors.jl:200-203) and sets the candidate bit of every unvisited valid row
+__global__ __launch_bounds__(256) void k_wf_mark(const int32_t* __restrict__ zlist, const int64_t* __restrict__ colptr,
                                                  const int32_t* __restrict__ rowval, const uint64_t* __restrict__ W,
                                                  const uint64_t* __restrict__ F, unsigned long long* __restrict__ cand,
                                                  const wf_ctr* __restrict__ ctr)
@@ -272,20 +316,16 @@ __global__ __launch_bounds__(256) void k_wf_mark(int64_t words, const uint64_t* 
     if (wf_stop(ctr)) return;
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
-    for (int64_t w = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); w < words; w += (int64_t)gridDim.x * wpb) {
-        uint64_t zm = Z[w];
-        while (zm) {
-            const int b = __ffsll((long long)zm) - 1;
-            zm &= zm - 1;
-            const int64_t z = w * 64 + b;
-            const int64_t beg = colptr[z], end = colptr[z + 1];
-            for (int64_t e = beg + lane; e < end; e += 64) {
-                const int64_t x = rowval[e];
-                if (!wf_bit(W, x) || (F && !wf_bit(F, x))) continue;          // fmt.jl:70-71
-                const unsigned long long bit = 1ull << (x & 63);
-                if (cand[x >> 6] & bit) continue;                             // seen already (a stale read only costs an atomic)
-                atomicOr(&cand[x >> 6], bit);
-            }
+    const int nz = ctr->nz;
+    for (int iz = blockIdx.x * wpb + (threadIdx.x >> 6); iz < nz; iz += gridDim.x * wpb) {
+        const int64_t z = zlist[iz];
+        const int64_t beg = colptr[z], end = colptr[z + 1];
+        for (int64_t e = beg + lane; e < end; e += 64) {
+            const int64_t x = rowval[e];
+            if (!wf_bit(W, x) || (F && !wf_bit(F, x))) continue;              // fmt.jl:70-71
+            const unsigned long long bit = 1ull << (x & 63);
+            if (cand[x >> 6] & bit) continue;                                 // seen already (a stale read only costs an atomic)
+            atomicOr(&cand[x >> 6], bit);
         }
     }
 }
@@ -333,9 +373,9 @@ __global__ void k_wf_box_transpose(const double* __restrict__ boxes, int M, int 
     bT[t] = boxes[(int64_t)min(k, M - 1) * d2 + j];               // padding repeats the last box
 }
 
-// one wavefront per word of the candidate mask, one candidate x at a time.  MODE 0: connect in place; MODE 1: emit triples
+// one wavefront per candidate x.  MODE 0: connect in place; MODE 1: emit triples
 template <int D, int MODE>
-__global__ __launch_bounds__(256) void k_wf_connect(int64_t words, const unsigned long long* __restrict__ cand, const int64_t* __restrict__ colptr,
+__global__ __launch_bounds__(256) void k_wf_connect(const int32_t* __restrict__ xlist, const int64_t* __restrict__ colptr,
                                                     const int32_t* __restrict__ rowval, const double* __restrict__ nzval,
                                                     const uint64_t* __restrict__ H, double* __restrict__ C, int32_t* __restrict__ A,
                                                     unsigned long long* __restrict__ W, unsigned long long* __restrict__ Hn,
@@ -346,13 +386,11 @@ __global__ __launch_bounds__(256) void k_wf_connect(int64_t words, const unsigne
     if (wf_stop(ctr)) return;
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
-    int my_nx = 0, my_checks = 0, my_conn = 0;                             // lane 0 counts for its wavefront
-    for (int64_t wd = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); wd < words; wd += (int64_t)gridDim.x * wpb) {
-        unsigned long long xm = cand[wd];
-        while (xm) {
-            const int xb = __ffsll((long long)xm) - 1;
-            xm &= xm - 1;
-            const int64_t x = wd * 64 + xb;
+    int my_checks = 0, my_conn = 0;                                        // lane 0 counts for its wavefront
+    const int nx = ctr->nx;
+    {
+        for (int ix = blockIdx.x * wpb + (threadIdx.x >> 6); ix < nx; ix += gridDim.x * wpb) {
+            const int64_t x = xlist[ix];
             const int64_t beg = colptr[x], end = colptr[x + 1];
             double best = 0.0;
             int64_t be = -1;
@@ -363,7 +401,6 @@ __global__ __launch_bounds__(256) void k_wf_connect(int64_t words, const unsigne
                 if (be < 0 || c < best) { best = c; be = e; }              // ascending e per lane keeps the first minimum
             }
             wf_lexmin_wave(best, be);                                      // rows ascend with e: first minimum = lowest e
-            if (lane == 0) ++my_nx;
             if (be < 0) continue;
             const int64_t y = rowval[be];
             double v[D], w[D];
@@ -401,7 +438,6 @@ __global__ __launch_bounds__(256) void k_wf_connect(int64_t words, const unsigne
             }
         }
     }
-    wf_block_stat(stats, WF_NX, my_nx);
     wf_block_stat(stats, WF_CHECKS, my_checks);
     wf_block_stat(stats, WF_NCONN, my_conn);
 }
@@ -466,7 +502,7 @@ void mpfmt_wf_free(mpfmt_ctx* ctx)
 {
     mpfmt_wf* s = wf_of(ctx);
     if (!s) return;
-    void* bufs[] = {s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->F, s->C, s->A, s->part_c, s->part_i, s->stats, s->boxT, s->mytrips, s->xbuf,
+    void* bufs[] = {s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->F, s->C, s->A, s->zlist, s->xlist, s->part_c, s->part_i, s->stats, s->boxT, s->mytrips, s->xbuf,
                     s->ctr, s->path_dev};
     for (void* b : bufs) if (b) hipFree(b);
     if (s->ctr_host) hipHostFree(s->ctr_host);
@@ -480,13 +516,14 @@ static int32_t wf_alloc(mpfmt_ctx* ctx, mpfmt_wf* s, int64_t N, int world)
     const int64_t words = (N + 63) / 64;
     if (s->N != N) {
         void** bufs[] = {(void**)&s->W, (void**)&s->H, (void**)&s->Z, (void**)&s->Zp, (void**)&s->Hn, (void**)&s->cand, (void**)&s->F,
-                         (void**)&s->C, (void**)&s->A, (void**)&s->path_dev, (void**)&s->mytrips};
+                         (void**)&s->C, (void**)&s->A, (void**)&s->zlist, (void**)&s->xlist, (void**)&s->path_dev, (void**)&s->mytrips};
         for (void** b : bufs) if (*b) { HIPCHK(ctx, hipFree(*b)); *b = nullptr; }
         HIPCHK(ctx, hipMalloc((void**)&s->W, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->H, 8 * words));
         HIPCHK(ctx, hipMalloc((void**)&s->Z, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->Zp, 8 * words));
         HIPCHK(ctx, hipMalloc((void**)&s->Hn, 8 * words));
         HIPCHK(ctx, hipMalloc((void**)&s->cand, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->F, 8 * words));
         HIPCHK(ctx, hipMalloc((void**)&s->C, 8 * N)); HIPCHK(ctx, hipMalloc((void**)&s->A, 4 * N));
+        HIPCHK(ctx, hipMalloc((void**)&s->zlist, 4 * N)); HIPCHK(ctx, hipMalloc((void**)&s->xlist, 4 * N));
         HIPCHK(ctx, hipMalloc((void**)&s->path_dev, 8 * (N + 1)));
         s->N = N; s->words = words;
     }
@@ -515,24 +552,25 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     const int d = ctx->d;
     hipLaunchKernelGGL(k_wf_apply_min, dim3(nparts), dim3(64), 0, st, words, s->H, s->Z, s->Zp, s->Hn, s->cand, s->C, s->part_c, s->part_i, s->ctr);
     hipLaunchKernelGGL(k_wf_select, dim3(nparts), dim3(64), 0, st, words, nparts, s->H, s->Z, s->C, ctx->Xo, d, s->part_c, s->part_i, s->band,
-                       s->single, s->goal, s->stats, s->ctr);
+                       s->single, s->goal, s->zlist, s->ctr);
     const uint64_t* F = s->checkpts ? s->F : nullptr;
-    const int grid = (int)std::min<int64_t>((words + 3) / 4, (int64_t)ctx->num_cus * 8);      // one wavefront per mask word, 4 per block
+    const int grid = ctx->num_cus * 8;                       // persistent: 4 wavefronts per block, one list entry per wavefront at a time
     if (!s->sharded) {
-        hipLaunchKernelGGL(k_wf_mark, dim3(grid), dim3(256), 0, st, words, s->Z, ctx->colptr, ctx->rowval, s->W, F,
+        hipLaunchKernelGGL(k_wf_mark, dim3(grid), dim3(256), 0, st, s->zlist, ctx->colptr, ctx->rowval, s->W, F,
                            (unsigned long long*)s->cand, s->ctr);
     } else {
         const int64_t pb = std::min<int64_t>(ctx->tile_begin * 64, ctx->N), pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
         hipLaunchKernelGGL(k_wf_mark_owned, dim3(ctx->num_cus * 8), dim3(256), 0, st, ctx->perm, pb, pe, ctx->colptr, ctx->rowval, s->W, F, s->Z,
                            (unsigned long long*)s->cand, s->ctr);
     }
+    hipLaunchKernelGGL(k_wf_compact, dim3(nparts), dim3(64), 0, st, words, (const unsigned long long*)s->cand, s->xlist, s->ctr);
     const uint64_t* gfree = s->use_mask ? ctx->graph_free : nullptr;
     if (!s->sharded) {
-        DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 0>), dim3(grid), dim3(256), 0, st, words, (const unsigned long long*)s->cand, ctx->colptr,
+        DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 0>), dim3(grid), dim3(256), 0, st, s->xlist, ctx->colptr,
                                          ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo,
                                          s->boxT, ctx->M, s->mpad, ctx->ss, gfree, (wf_trip*)nullptr, s->stats, s->ctr));
     } else {
-        DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 1>), dim3(grid), dim3(256), 0, st, words, (const unsigned long long*)s->cand, ctx->colptr,
+        DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 1>), dim3(grid), dim3(256), 0, st, s->xlist, ctx->colptr,
                                          ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo,
                                          s->boxT, ctx->M, s->mpad, ctx->ss, gfree, s->mytrips, s->stats, s->ctr));
     }
@@ -581,13 +619,13 @@ static void wf_fill_info(mpfmt_wf* s, mpfmt_wf_info* info)
     const wf_ctr& c = *s->ctr_host;
     const bool goal = c.goal_cbits != ~0ull;
     info->done = goal ? 1 : c.done;
-    info->nz = (int32_t)(c.tot[WF_NZ] - s->prev_tot[WF_NZ]);
-    info->nx = (int32_t)(c.tot[WF_NX] - s->prev_tot[WF_NX]);
+    info->nz = c.done == 2 ? 0 : c.nz;
+    info->nx = c.nx;
     info->nconn = (int32_t)(c.tot[WF_NCONN] - s->prev_tot[WF_NCONN]);
     info->ntrip = c.ntrip;
     info->iters = c.iters - (c.done == 2 ? 1 : 0);       // the step that found the open set empty expanded no batch
     info->checks = c.tot[WF_CHECKS]; info->cmin = c.cmin;
-    info->tot_z = c.tot[WF_NZ]; info->tot_x = c.tot[WF_NX]; info->tot_conn = c.tot[WF_NCONN];
+    info->tot_z = c.tot[WF_NZ] + info->nz; info->tot_x = c.tot[WF_NX] + c.nx; info->tot_conn = c.tot[WF_NCONN];     // (the device adds a step's nz / nx at the start of the next)
     for (int k = 0; k < 4; ++k) s->prev_tot[k] = c.tot[k];
 }
 
@@ -648,8 +686,11 @@ int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t check
     }
     if (!s->use_mask) {                                    // obstacle table transposed for lane = obstacle reads
         const int mpad = std::max(64, ((ctx->M + 63) / 64) * 64);
-        if (s->boxT) { HIPCHK(ctx, hipFree(s->boxT)); s->boxT = nullptr; }
-        HIPCHK(ctx, hipMalloc((void**)&s->boxT, sizeof(double) * 2 * (size_t)d * (size_t)mpad));
+        if (s->boxT_cap < 2 * d * mpad) {
+            if (s->boxT) { HIPCHK(ctx, hipFree(s->boxT)); s->boxT = nullptr; }
+            HIPCHK(ctx, hipMalloc((void**)&s->boxT, sizeof(double) * 2 * (size_t)d * (size_t)mpad));
+            s->boxT_cap = 2 * d * mpad;
+        }
         s->mpad = mpad;
         if (ctx->M > 0)
             hipLaunchKernelGGL(k_wf_box_transpose, dim3((unsigned)((mpad * 2 * d + 255) / 256)), dim3(256), 0, ctx->stream, ctx->boxes, ctx->M, 2 * d, mpad, s->boxT);
@@ -789,7 +830,7 @@ int32_t mpfmt_wf_finish(mpfmt_ctx* ctx, int64_t* A, double* C, int64_t* path, mp
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t N = s->N;
     int32_t rc;
-    hipLaunchKernelGGL(k_wf_final, dim3(1), dim3(64), 0, ctx->stream, s->words, s->Z, s->Zp, s->C, ctx->Xo, ctx->d, s->goal, s->ctr);
+    hipLaunchKernelGGL(k_wf_final, dim3(1), dim3(1024), 0, ctx->stream, s->words, s->Z, s->Zp, s->C, ctx->Xo, ctx->d, s->goal, s->ctr);
     hipLaunchKernelGGL(k_wf_path, dim3(1), dim3(1), 0, ctx->stream, s->A, N, s->ctr, s->path_dev);
     HIPCHK(ctx, hipGetLastError());
     if ((rc = wf_read_ctr(ctx, s, true))) return rc;
