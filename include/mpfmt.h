@@ -105,6 +105,11 @@ int32_t mpfmt_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask);
  * (sampler candidates src/sampling.jl:25, shortcut segments src/postprocessors.jl:6-39). */
 int32_t mpfmt_states_free(mpfmt_ctx* ctx, const double* P, int64_t n, uint64_t* mask);
 int32_t mpfmt_motions_free(mpfmt_ctx* ctx, const double* P, const double* Q, int64_t n, uint64_t* mask);
+/* is_free_path(p, CC, SS) = @all [is_free_motion(p[i], p[i+1], CC, SS)] (src/statespaces.jl:159-160) for a path of n states
+ * P = d x n column-major: *free_out = 1 / 0; seg_mask (may be NULL) gets the n-1 segment bits.  (The reference's box-list
+ * method iterates 1:length(BL)-1 instead of the path length, src/collisioncheckers/boxesND.jl:57 -- a bug that is not
+ * reproduced: every segment is tested.)  A path of fewer than 2 states is free. */
+int32_t mpfmt_path_free(mpfmt_ctx* ctx, const double* P, int64_t n, int32_t* free_out, uint64_t* seg_mask);
 
 /* ---- Euclidean per-edge steer, src/statespaces/geometric.jl:18-19, batched over E edges src[e] -> dst[e]
  *      (1-based sample indices):
@@ -267,9 +272,14 @@ int32_t mpfmt_graph_import(mpfmt_ctx* ctx, double r, const int64_t* colptr, cons
  *      reproducible by a scalar loop.  V[1] = init when init != NULL (sampling.jl:15-20); the last min(goal_ct, N-1)
  *      samples are free goal samples, V[N+1-i] = the i-th one (sampling.jl:37-41; sample_goal, goals.jl:97,101-108,115).
  *      The set is left uploaded in ctx (as by mpfmt_upload_samples); X_out (N*d, may be NULL) receives a copy;
- *      attempts = sample_space candidates the sequential loop would have consumed.  goal_bias is not supported (0). */
+ *      attempts = sample_space candidates the sequential loop would have consumed.
+ *      sample_free_biased adds the goal_bias keyword (sampling.jl:11,28-30): each accepted sample is replaced by a free goal
+ *      sample with probability goal_bias -- the decision for the k-th accepted sample is the uniform (seed, k) of a third
+ *      stream, the replacements take free goal samples in stream order, before the ensure_goal tail does. */
 int32_t mpfmt_sample_free(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double* init, int32_t goal_kind,
                           const double* goal_params, int32_t goal_ct, double* X_out, int64_t* attempts);
+int32_t mpfmt_sample_free_biased(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double* init, int32_t goal_kind,
+                                 const double* goal_params, int32_t goal_ct, double goal_bias, double* X_out, int64_t* attempts);
 
 /* ---- double-integrator (LinearQuadratic quasi-metric) space: DoubleIntegrator(m; vmax, r=rho)
  *      (src/statespaces/linearquadratic.jl:46-53).  Samples are states (p, v) in R^{2m} (upload_samples with

@@ -90,6 +90,9 @@ SYMBOLS = [
     ("mpfmt_upload_shapes2d", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_d_p, c_d_p, c_d_p]),
     ("mpfmt_graph_import", C.c_int32, [C.c_void_p, C.c_double, c_i64_p, c_i64_p, c_d_p]),
     ("mpfmt_sample_free", C.c_int32, [C.c_void_p, C.c_uint64, C.c_int64, c_d_p, C.c_int32, c_d_p, C.c_int32, c_d_p, c_i64_p]),
+    ("mpfmt_sample_free_biased", C.c_int32, [C.c_void_p, C.c_uint64, C.c_int64, c_d_p, C.c_int32, c_d_p, C.c_int32, C.c_double, c_d_p,
+                                             c_i64_p]),
+    ("mpfmt_path_free", C.c_int32, [C.c_void_p, c_d_p, C.c_int64, C.POINTER(C.c_int32), c_u64_p]),
     ("mpfmt_di_graph_count", C.c_int32, [C.c_void_p, C.c_double, C.c_double, c_i64_p, c_i64_p]),
     ("mpfmt_di_graph_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p, c_d_p]),
     ("mpfmt_di_graph_edges_free", C.c_int32, [C.c_void_p, c_u64_p, c_u8_p]),
@@ -621,7 +624,16 @@ class Context:
         self._chk(self._L.mpfmt_graph_import(self._h, float(r), _ip(colptr), _ip(rowval), _dp(nzval)))
         self.nnz = int(colptr[-1] - 1)
 
-    def sample_free(self, seed, N, init=None, goal_kind=0, goal_params=None, goal_ct=0):
+    def path_free(self, P):
+        """is_free_path(p, CC, SS) for the states P (n, d): (free, per-segment bits)."""
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        n = P.shape[0]
+        fr = C.c_int32()
+        mask = np.zeros(max(nwords(max(n - 1, 0)), 1), dtype=np.uint64)
+        self._chk(self._L.mpfmt_path_free(self._h, _dp(P), n, C.byref(fr), _up(mask)))
+        return bool(fr.value), unpack_bits(mask, max(n - 1, 0))
+
+    def sample_free(self, seed, N, init=None, goal_kind=0, goal_params=None, goal_ct=0, goal_bias=0.0):
         """sample_free!(P, N): N free samples drawn on the device (counter-based stream, sequential semantics), left
         uploaded in the context.  Returns (X, attempts)."""
         d = self.dw
@@ -629,8 +641,8 @@ class Context:
         att = C.c_int64()
         ini = None if init is None else np.ascontiguousarray(init, dtype=np.float64)
         g = None if goal_params is None else np.ascontiguousarray(goal_params, dtype=np.float64)
-        self._chk(self._L.mpfmt_sample_free(self._h, int(seed), int(N), None if ini is None else _dp(ini), int(goal_kind),
-                                            None if g is None else _dp(g), int(goal_ct), _dp(X), C.byref(att)))
+        self._chk(self._L.mpfmt_sample_free_biased(self._h, int(seed), int(N), None if ini is None else _dp(ini), int(goal_kind),
+                                                   None if g is None else _dp(g), int(goal_ct), float(goal_bias), _dp(X), C.byref(att)))
         self.N, self.d = int(N), d
         return X[:N], int(att.value)
 

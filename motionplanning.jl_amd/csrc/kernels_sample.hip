@@ -103,8 +103,25 @@ static bool goal_candidate(uint64_t seed, uint64_t g, int d, int kind, const dou
     return true;
 }
 
+static int32_t sample_free_impl(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double* init, int32_t goal_kind,
+                                const double* goal_params, int32_t goal_ct, double goal_bias, double* X_out, int64_t* attempts_out);
+
 int32_t mpfmt_sample_free(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double* init, int32_t goal_kind,
                           const double* goal_params, int32_t goal_ct, double* X_out, int64_t* attempts_out)
+{
+    return sample_free_impl(ctx, seed, N, init, goal_kind, goal_params, goal_ct, 0.0, X_out, attempts_out);
+}
+
+int32_t mpfmt_sample_free_biased(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double* init, int32_t goal_kind,
+                                 const double* goal_params, int32_t goal_ct, double goal_bias, double* X_out, int64_t* attempts_out)
+{
+    if (ctx && !(goal_bias >= 0.0 && goal_bias <= 1.0)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "goal_bias must lie in [0, 1]");
+    if (ctx && goal_bias > 0.0 && (!goal_params || goal_kind < 0 || goal_kind > 2)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "goal_bias needs a goal");
+    return sample_free_impl(ctx, seed, N, init, goal_kind, goal_params, goal_ct, goal_bias, X_out, attempts_out);
+}
+
+static int32_t sample_free_impl(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double* init, int32_t goal_kind,
+                                const double* goal_params, int32_t goal_ct, double goal_bias, double* X_out, int64_t* attempts_out)
 {
     if (!ctx) return MPFMT_ERR_ARG;
     if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
@@ -167,35 +184,49 @@ int32_t mpfmt_sample_free(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double
     HIPCHK(ctx, hipMemcpy(&att, d_att, sizeof(long long), hipMemcpyDeviceToHost));
     if (attempts_out) *attempts_out = (int64_t)att;
 
-    // goal samples overwrite the tail (sampling.jl:37-41): candidates generated on the host from stream 1, validity on
-    // the device in small batches
-    const int64_t ng = std::min<int64_t>(goal_ct, N - 1);
-    if (ng > 0) {
-        std::vector<double> got((size_t)ng * d);
-        int64_t found = 0;
-        uint64_t g = 0;
-        const int GB = 256;
-        std::vector<double> cand((size_t)GB * d);
-        std::vector<uint64_t> gm((GB + 63) / 64);
-        while (found < ng) {
+    // the set comes to the host once (it is handed to mpfmt_upload_samples below); goal samples are written into that copy
+    std::vector<double> host;
+    double* H = X_out;
+    if (!H) { host.resize((size_t)N * d); H = host.data(); }
+    HIPCHK(ctx, hipMemcpy(H, W, sizeof(double) * (size_t)N * d, hipMemcpyDeviceToHost));
+    // free goal samples, in the order the sequential loop draws them: candidates from stream 1 (sample_goal, goals.jl:97,
+    // 101-108,115), validity on the device in small batches
+    uint64_t g = 0;
+    const int GB = 256;
+    std::vector<double> cand((size_t)GB * d), ready;
+    size_t ready_at = 0;
+    std::vector<uint64_t> gm((GB + 63) / 64);
+    auto next_goal = [&](double* out) -> int32_t {            // sample_free_goal(P), sampling.jl:3-9
+        while (ready_at * d >= ready.size()) {
+            ready.clear(); ready_at = 0;
             int nc = 0;
             while (nc < GB && g <= 1000000ull) {
                 if (goal_candidate(seed, g++, d, goal_kind, goal_params, &cand[(size_t)nc * d])) ++nc;
             }
             if (nc == 0) return mpfmt_fail(ctx, MPFMT_ERR_INFEASIBLE, "no free goal sample among 1e6 candidates");
-            if ((rc = mpfmt_states_free(ctx, cand.data(), nc, gm.data()))) return rc;
-            for (int q = 0; q < nc && found < ng; ++q)
-                if ((gm[q >> 6] >> (q & 63)) & 1ull) { memcpy(&got[(size_t)found * d], &cand[(size_t)q * d], sizeof(double) * d); ++found; }
-            // candidates after the ng-th accepted one were never drawn by the sequential loop: harmless, they are unused
+            int32_t rc2;
+            if ((rc2 = mpfmt_states_free(ctx, cand.data(), nc, gm.data()))) return rc2;
+            for (int q = 0; q < nc; ++q)
+                if ((gm[q >> 6] >> (q & 63)) & 1ull) ready.insert(ready.end(), &cand[(size_t)q * d], &cand[(size_t)q * d] + d);
         }
-        for (int64_t i = 1; i <= ng; ++i)
-            HIPCHK(ctx, hipMemcpyAsync(W + (size_t)(N - i) * d, &got[(size_t)(i - 1) * d], sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(out, &ready[ready_at * d], sizeof(double) * d);
+        ++ready_at;
+        return MPFMT_OK;
+    };
+    // goal_bias (sampling.jl:28-30): each accepted sample is replaced by a free goal sample with probability goal_bias;
+    // the decision for the k-th accepted sample is uniform (seed, k) of stream 2 -- again a function of the sample, not of
+    // the batching -- and replacements consume the goal stream in order
+    if (goal_bias > 0.0) {
+        double u[MPFMT_MAX_DIM];
+        for (int64_t k = init ? 1 : 0; k < N; ++k) {
+            sample_uniforms(seed, (uint64_t)(k - (init ? 1 : 0)), 2u, 1, u);
+            if (u[0] < goal_bias && (rc = next_goal(H + (size_t)k * d))) return rc;
+        }
     }
+    // goal samples overwrite the tail (sampling.jl:37-41)
+    const int64_t ng = std::min<int64_t>(goal_ct, N - 1);
+    for (int64_t i = 1; i <= ng; ++i)
+        if ((rc = next_goal(H + (size_t)(N - i) * d))) return rc;
     // hand the set to the ctx exactly like mpfmt_upload_samples (bounding box, index invalidation)
-    std::vector<double> host;
-    double* H = X_out;
-    if (!H) { host.resize((size_t)N * d); H = host.data(); }
-    HIPCHK(ctx, hipMemcpy(H, W, sizeof(double) * (size_t)N * d, hipMemcpyDeviceToHost));
     return mpfmt_upload_samples(ctx, H, N, d);
 }

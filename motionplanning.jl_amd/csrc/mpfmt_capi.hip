@@ -571,6 +571,25 @@ int32_t mpfmt_motions_free(mpfmt_ctx* ctx, const double* P, const double* Q, int
     return explicit_sweep(ctx, P, Q, n, mask);
 }
 
+int32_t mpfmt_path_free(mpfmt_ctx* ctx, const double* P, int64_t n, int32_t* free_out, uint64_t* seg_mask)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!free_out) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "free_out is NULL");
+    if (n < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "n < 0");
+    *free_out = 1;
+    if (n < 2) return MPFMT_OK;
+    if (!P) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "P is NULL");
+    if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
+    const int d = ctx->dw;
+    const int64_t ns = n - 1, words = (ns + 63) / 64;
+    std::vector<uint64_t> m((size_t)words, 0);
+    int32_t rc;
+    if ((rc = explicit_sweep(ctx, P, P + d, ns, m.data()))) return rc;       // segment i = (p[i], p[i+1]): the same array, one state on
+    for (int64_t i = 0; i < ns; ++i) if (!((m[i >> 6] >> (i & 63)) & 1ull)) { *free_out = 0; break; }
+    if (seg_mask) memcpy(seg_mask, m.data(), sizeof(uint64_t) * (size_t)words);
+    return MPFMT_OK;
+}
+
 int32_t mpfmt_graph_sweep_device(mpfmt_ctx* ctx)
 {
     if (!ctx) return MPFMT_ERR_ARG;

@@ -1187,23 +1187,50 @@ static int goal_candidate(uint64_t seed, uint64_t g, int32_t d, int32_t kind, co
  * then free candidates in order (21-36), then W[N-i] = i-th free goal sample, i = 1..min(goal_ct, N-1) (37-41).
  * attempts = number of sample_space candidates consumed.  Returns 0, or -1 when the goal cannot be sampled
  * (max_goal_tries exhausted: the reference would loop forever). */
+int32_t orc_sample_free_biased(uint64_t seed, int64_t N, int32_t d, const double *init, const double *lohi, int32_t M,
+                               const double *ss_lo, const double *ss_hi, int32_t goal_kind, const double *goal_params,
+                               int32_t goal_ct, double goal_bias, double *W, int64_t *attempts);
+
 int32_t orc_sample_free(uint64_t seed, int64_t N, int32_t d, const double *init, const double *lohi, int32_t M,
                         const double *ss_lo, const double *ss_hi, int32_t goal_kind, const double *goal_params,
                         int32_t goal_ct, double *W, int64_t *attempts)
 {
+    return orc_sample_free_biased(seed, N, d, init, lohi, M, ss_lo, ss_hi, goal_kind, goal_params, goal_ct, 0.0, W, attempts);
+}
+
+/* the loop as written (sampling.jl:21-36), goal_bias included (:28-30): `rand() < goal_bias` for the k-th accepted sample is
+ * the uniform (seed, k) of stream 2; a replacement is sample_free_goal(P) (:3-9), consuming the goal stream in order */
+int32_t orc_sample_free_biased(uint64_t seed, int64_t N, int32_t d, const double *init, const double *lohi, int32_t M,
+                               const double *ss_lo, const double *ss_hi, int32_t goal_kind, const double *goal_params,
+                               int32_t goal_ct, double goal_bias, double *W, int64_t *attempts)
+{
     int64_t have = 0;
-    uint64_t c = 0;
+    uint64_t c = 0, g = 0, acc = 0;
     if (N <= 0) { if (attempts) *attempts = 0; return 0; }
     if (init) { memcpy(W, init, sizeof(double) * (size_t)d); have = 1; }
     double u[ORC_MAXD], v[ORC_MAXD];
     while (have < N) {
         orc_sample_uniforms(seed, c++, 0u, d, u);
         for (int32_t i = 0; i < d; ++i) { const double w = ss_hi[i] - ss_lo[i]; const double p = u[i] * w; v[i] = ss_lo[i] + p; }
-        if (orc_is_free_state(v, d, lohi, M, ss_lo, ss_hi)) { memcpy(W + (size_t)have * d, v, sizeof(double) * (size_t)d); ++have; }
+        if (orc_is_free_state(v, d, lohi, M, ss_lo, ss_hi)) {
+            double ub[ORC_MAXD];
+            if (0.0 < goal_bias) orc_sample_uniforms(seed, acc, 2u, 1, ub);
+            if (0.0 < goal_bias && ub[0] < goal_bias) {                         /* sampling.jl:28-29 */
+                double gv[ORC_MAXD];
+                for (;;) {
+                    if (g > 1000000u) return -1;
+                    const int ok = goal_candidate(seed, g++, d, goal_kind, goal_params, gv);
+                    if (ok && orc_is_free_state(gv, d, lohi, M, ss_lo, ss_hi)) break;
+                }
+                memcpy(W + (size_t)have * d, gv, sizeof(double) * (size_t)d);
+            } else {
+                memcpy(W + (size_t)have * d, v, sizeof(double) * (size_t)d);
+            }
+            ++have; ++acc;
+        }
     }
     if (attempts) *attempts = (int64_t)c;
     const int64_t ng = (goal_ct < N - 1) ? goal_ct : N - 1;
-    uint64_t g = 0;
     for (int64_t i = 1; i <= ng; ++i) {
         for (;;) {
             if (g > 1000000u) return -1;

@@ -421,13 +421,13 @@ def sample_uniforms(seed, c, stream, d):
     return u
 
 
-def sample_free(seed, N, d, init, lohi, ss_lo, ss_hi, goal_kind, goal, goal_ct=1):
+def sample_free(seed, N, d, init, lohi, ss_lo, ss_hi, goal_kind, goal, goal_ct=1, goal_bias=0.0):
     lohi, M = _boxes(lohi, d); ss_lo = _vec(ss_lo); ss_hi = _vec(ss_hi); goal = _vec(goal)
     init = None if init is None else _vec(init)
     W = np.empty((max(N, 0), d)); att = C.c_int64()
-    rc = lib().orc_sample_free(C.c_uint64(seed), C.c_int64(N), C.c_int32(d), None if init is None else _d(init), _d(lohi),
-                               C.c_int32(M), _d(ss_lo), _d(ss_hi), C.c_int32(goal_kind), _d(goal), C.c_int32(goal_ct),
-                               _d(W), C.byref(att))
+    rc = lib().orc_sample_free_biased(C.c_uint64(seed), C.c_int64(N), C.c_int32(d), None if init is None else _d(init), _d(lohi),
+                                      C.c_int32(M), _d(ss_lo), _d(ss_hi), C.c_int32(goal_kind), _d(goal), C.c_int32(goal_ct),
+                                      C.c_double(goal_bias), _d(W), C.byref(att))
     return rc, W, int(att.value)
 
 

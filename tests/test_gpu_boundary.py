@@ -136,3 +136,37 @@ def test_golden_di_pairs_on_the_device(orc):
     with mp.Context(0) as c:
         cost, topt = c.di_steer(z["X0"], z["X1"], float(z["rho"]), float(z["r"]))
     assert np.array_equal(cost, z["cost"]) and np.array_equal(topt, z["topt"])
+
+
+def test_sample_free_goal_bias_and_path_free(orc):
+    """sample_free!'s goal_bias keyword (sampling.jl:11,28-30) and is_free_path (statespaces.jl:159-160) -- VERDICT r1 item 7."""
+    rng = np.random.default_rng(17)
+    d, M, N = 3, 40, 20000
+    c = rng.random((M, d)); h = 0.03 + 0.07 * rng.random((M, d))
+    lohi = np.stack([c - h, c + h], axis=1)
+    lo, hi = np.zeros(d), np.ones(d)
+    init = np.full(d, 0.02)
+    goal = np.concatenate([np.full(d, 0.9), [0.08]])
+    with mp.Context(0) as cx:
+        cx.upload_samples(np.zeros((1, d))); cx.upload_boxes(lohi, lo, hi)
+        for bias in (0.0, 0.05, 0.6):
+            X, att = cx.sample_free(99, N, init, L.GOAL_BALL, goal, goal_ct=5, goal_bias=bias)
+            rc, W, oatt = orc.sample_free(99, N, d, init, lohi, lo, hi, orc.GOAL_BALL, goal, goal_ct=5, goal_bias=bias)
+            assert rc == 0 and att == oatt and np.array_equal(X, W)
+            in_goal = np.sqrt(((X - goal[:d]) ** 2).sum(1)) <= goal[d]
+            assert abs(in_goal[1:-5].mean() - bias) < 0.02 + 1e-3          # replaced samples are goal samples
+            assert orc.unpack(orc.points_free(X, lohi, lo, hi), N).all()
+        with pytest.raises(mp.MPFMTError):
+            cx.sample_free(1, 100, init, L.GOAL_BALL, goal, goal_bias=1.5)
+        # is_free_path over a random polyline and over a tree path
+        P = rng.random((200, d))
+        fr, seg = cx.path_free(P)
+        want = np.array([orc.is_free_motion(P[i], P[i + 1], lohi, lo, hi) for i in range(len(P) - 1)])
+        assert np.array_equal(seg, want) and fr == bool(want.all()) and not fr
+        w = mp.workloads.make("t", 4000, d, 0, 0.05, 0.1, seed=3, goal_radius=0.1)
+        cx.upload_samples(w.X); cx.upload_boxes(lohi, lo, hi)
+        res = cx.fmtstar_wavefront(w.r * 1.2, L.GOAL_BALL, w.goal_params(), band=0.5 * w.r)
+        if res["status"] == 1:
+            fr, seg = cx.path_free(w.X[res["path"] - 1])
+            assert fr and seg.all()                                       # every edge of the solution path is a free motion
+        assert cx.path_free(P[:1])[0] is True and cx.path_free(P[:1])[1].size == 0      # a single state: free, no segment
