@@ -275,3 +275,30 @@ def test_north_star_wavefront_solve(orc):
             assert got["cost"] >= seq["cost"] * (1 - 1e-12) and got["cost"] <= seq["cost"] * 1.10
             print("north star wavefront band %.2f r: cost %.6f (sequential %.6f), %d steps, %d checks (sequential %d), loop %.1f ms"
                   % (bandf, got["cost"], seq["cost"], got["info"]["iters"], got["collision_checks"], seq["collision_checks"], got["ms_host_loop"]))
+
+
+@pytest.mark.parametrize("N,d,M", [(1, 2, 3), (2, 2, 0), (63, 1, 2), (64, 3, 0), (65, 6, 300), (130, 12, 70), (200, 16, 5), (700, 2, 64)])
+def test_tiny_and_ragged_worlds(ctx, orc, N, d, M):
+    """Ragged sizes (N around the 64-bit mask words, one sample, no obstacles, more obstacles than one lane round, d up to 16):
+    single-node and banded solves against the oracle's loops; the init may already be a goal node."""
+    rng = np.random.default_rng(1000 + N + d)
+    X = rng.random((N, d))
+    X[0] = 0.1
+    if N > 1:
+        X[-1] = 0.9
+    c = rng.random((M, d)); h = 0.02 + 0.05 * rng.random((M, d))
+    lohi = np.stack([c - h, c + h], axis=1) if M else np.zeros((0, 2, d))
+    keep = np.array([not (np.all((lo <= X[0]) & (X[0] <= hi))) for lo, hi in lohi], dtype=bool) if M else np.zeros(0, bool)
+    lohi = lohi[keep] if M else lohi
+    lo, hi = np.zeros(d), np.ones(d)
+    r = 2.5 * (1.0 / max(N, 2)) ** (1.0 / d) if d <= 6 else 1.2
+    for goal in (np.concatenate([np.full(d, 0.9), [0.12]]), np.concatenate([np.full(d, 0.1), [0.05]])):       # far goal / the init itself
+        ctx.upload_samples(X); ctx.upload_boxes(lohi, lo, hi)
+        colptr, rowval, nzval = ctx.rdisc_graph(r)
+        F = ctx.points_free()
+        for single, bandf in ((True, 0.0), (False, 0.0), (False, 0.7)):
+            ref = orc.fmt_wavefront_graph(X, colptr - 1, rowval - 1, nzval, None, F, orc.GOAL_BALL, goal, lohi, lo, hi, band=bandf * r, single=single)
+            got = ctx.fmtstar_wavefront(r, L.GOAL_BALL, goal, band=bandf * r, single=single)
+            assert got["status"] == ref["status"] and got["z"] - 1 == ref["z"] and got["cost"] == ref["cost"]
+            assert got["collision_checks"] == ref["collision_checks"] and got["info"]["iters"] == ref["iters"]
+            assert np.array_equal(got["A"] - 1, ref["A"]) and np.array_equal(got["C"], ref["C"]) and np.array_equal(got["path"] - 1, ref["path"])
