@@ -145,8 +145,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="north_star", choices=["north_star", "cfg2", "cfg1", "cfg3"])
     ap.add_argument("--n", type=int, default=0, help="override the sample count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
