@@ -684,6 +684,33 @@ __global__ void k_entry_column(const int64_t* __restrict__ colptr, int64_t N, co
     colidx[a] = (int32_t)lo;
 }
 
+// the forward sets left on the device (rowptr [N+1], colidx [nnz]) for the wavefront driver
+int32_t mpfmt_csc_transpose_resident(mpfmt_ctx* ctx, int64_t* d_rowptr, int32_t* d_colidx)
+{
+    const int64_t N = ctx->N, nnz = ctx->nnz;
+    if (nnz >= ((int64_t)1 << 32)) return mpfmt_fail(ctx, MPFMT_ERR_CAPACITY, "graph too large for the device transpose");
+    if (nnz == 0) { HIPCHK(ctx, hipMemsetAsync(d_rowptr, 0, sizeof(int64_t) * (size_t)(N + 1), ctx->stream)); return MPFMT_OK; }
+    int bits = 1;
+    while (((int64_t)1 << bits) < N) ++bits;
+    size_t tb = 0;
+    HIPCHK(ctx, rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                          (size_t)nnz, 0, bits, ctx->stream));
+    const size_t w = sizeof(uint32_t) * (size_t)nnz;
+    const size_t off_ko = 0, off_vi = off_ko + w, off_vo = off_vi + w, off_t = (off_vo + w + 255) & ~(size_t)255;
+    void* scr;
+    int32_t rc;
+    if ((rc = mpfmt_scratch(ctx, off_t + tb + 256, &scr))) return rc;
+    uint32_t* ko = (uint32_t*)((char*)scr + off_ko); uint32_t* vi = (uint32_t*)((char*)scr + off_vi); uint32_t* vo = (uint32_t*)((char*)scr + off_vo);
+    const unsigned nb = (unsigned)((nnz + 255) / 256);
+    hipLaunchKernelGGL(k_iota_u32, dim3(nb), dim3(256), 0, ctx->stream, vi, nnz);
+    // stable sort of the entries by row: inside a row the entries keep CSC order = ascending target column
+    HIPCHK(ctx, rocprim::radix_sort_pairs((char*)scr + off_t, tb, (const uint32_t*)ctx->rowval, ko, vi, vo, (size_t)nnz, 0, bits, ctx->stream));
+    hipLaunchKernelGGL(k_lower_bound_rows, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, ctx->stream, ko, nnz, N, d_rowptr);
+    hipLaunchKernelGGL(k_entry_column, dim3(nb), dim3(256), 0, ctx->stream, ctx->colptr, N, vo, nnz, d_colidx);
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
 int32_t mpfmt_csc_transpose_device(mpfmt_ctx* ctx, mpfmt_csr_host* out)
 {
     const int64_t N = ctx->N, nnz = ctx->nnz;

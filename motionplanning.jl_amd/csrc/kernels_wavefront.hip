@@ -62,6 +62,8 @@ struct mpfmt_wf {
     double* C = nullptr;
     int32_t* A = nullptr;
     int32_t *zlist = nullptr, *xlist = nullptr;                   // batch nodes / candidates of the step, compacted from the masks
+    int64_t* rowptr = nullptr; int32_t* colidx = nullptr;         // directed cost graphs: forward sets (CSR of the resident CSC)
+    int64_t csr_nnz = 0; bool directed = false;
     double* part_c = nullptr; int64_t* part_i = nullptr;          // per-block lexicographic minima of the open set
     double* last_c = nullptr; int64_t* last_i = nullptr;          // per-block lexicographic maxima of the batch (last node in pop order)
     int64_t* stats = nullptr;     // [WF_MAXBLK][4] per-block cumulative statistics
@@ -380,9 +382,11 @@ __global__ __launch_bounds__(256) void k_wf_connect(const int32_t* __restrict__ 
                                                     const uint64_t* __restrict__ H, double* __restrict__ C, int32_t* __restrict__ A,
                                                     unsigned long long* __restrict__ W, unsigned long long* __restrict__ Hn,
                                                     const double* __restrict__ X, const double* __restrict__ bT, int M, int mpad,
-                                                    mpfmt_ss ss, const uint64_t* __restrict__ gfree, wf_trip* __restrict__ mytrips,
-                                                    int64_t* __restrict__ stats, wf_ctr* __restrict__ ctr)
+                                                    mpfmt_ss ss, const uint64_t* __restrict__ gfree, const uint8_t* __restrict__ nseg,
+                                                    wf_trip* __restrict__ mytrips, int64_t* __restrict__ stats, wf_ctr* __restrict__ ctr)
 {
+    // nseg != NULL (directed steering graphs: double integrator, cars): the edge's validity and the number of segment tests the
+    // reference would have counted for it (boxesND.jl:26 per waypoint segment) were precomputed by the space's own sweep
     if (wf_stop(ctr)) return;
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void k_wf_connect(const int32_t* __restrict__ 
 #pragma unroll
             for (int i = 0; i < D; ++i) { v[i] = X[y * D + i]; w[i] = X[x * D + i]; }
             const bool inb = in_state_space_sl<D>(v, ss);                  // statespaces.jl:155: first point of the segment
-            if (lane == 0 && inb) ++my_checks;                             // boxesND.jl:26 is reached only then
+            if (lane == 0) my_checks += nseg ? (int)nseg[be] : (inb ? 1 : 0);   // boxesND.jl:26 is reached only then
             bool fr;
             if (gfree) {
                 fr = wf_bit(gfree, be);
@@ -502,7 +506,7 @@ void mpfmt_wf_free(mpfmt_ctx* ctx)
 {
     mpfmt_wf* s = wf_of(ctx);
     if (!s) return;
-    void* bufs[] = {s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->F, s->C, s->A, s->zlist, s->xlist, s->part_c, s->part_i, s->stats, s->boxT, s->mytrips, s->xbuf,
+    void* bufs[] = {s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->F, s->C, s->A, s->zlist, s->xlist, s->rowptr, s->colidx, s->part_c, s->part_i, s->stats, s->boxT, s->mytrips, s->xbuf,
                     s->ctr, s->path_dev};
     for (void* b : bufs) if (b) hipFree(b);
     if (s->ctr_host) hipHostFree(s->ctr_host);
@@ -556,8 +560,9 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     const uint64_t* F = s->checkpts ? s->F : nullptr;
     const int grid = ctx->num_cus * 8;                       // persistent: 4 wavefronts per block, one list entry per wavefront at a time
     if (!s->sharded) {
-        hipLaunchKernelGGL(k_wf_mark, dim3(grid), dim3(256), 0, st, s->zlist, ctx->colptr, ctx->rowval, s->W, F,
-                           (unsigned long long*)s->cand, s->ctr);
+        // forward sets: the column itself for a metric (nearneighbors.jl:200-203), the row of the cost matrix otherwise
+        hipLaunchKernelGGL(k_wf_mark, dim3(grid), dim3(256), 0, st, s->zlist, s->directed ? s->rowptr : ctx->colptr,
+                           s->directed ? s->colidx : ctx->rowval, s->W, F, (unsigned long long*)s->cand, s->ctr);
     } else {
         const int64_t pb = std::min<int64_t>(ctx->tile_begin * 64, ctx->N), pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
         hipLaunchKernelGGL(k_wf_mark_owned, dim3(ctx->num_cus * 8), dim3(256), 0, st, ctx->perm, pb, pe, ctx->colptr, ctx->rowval, s->W, F, s->Z,
@@ -565,14 +570,15 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     }
     hipLaunchKernelGGL(k_wf_compact, dim3(nparts), dim3(64), 0, st, words, (const unsigned long long*)s->cand, s->xlist, s->ctr);
     const uint64_t* gfree = s->use_mask ? ctx->graph_free : nullptr;
+    const uint8_t* nseg = s->directed ? ctx->di_nseg : nullptr;
     if (!s->sharded) {
         DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 0>), dim3(grid), dim3(256), 0, st, s->xlist, ctx->colptr,
                                          ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo,
-                                         s->boxT, ctx->M, s->mpad, ctx->ss, gfree, (wf_trip*)nullptr, s->stats, s->ctr));
+                                         s->boxT, ctx->M, s->mpad, ctx->ss, gfree, nseg, (wf_trip*)nullptr, s->stats, s->ctr));
     } else {
         DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 1>), dim3(grid), dim3(256), 0, st, s->xlist, ctx->colptr,
                                          ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo,
-                                         s->boxT, ctx->M, s->mpad, ctx->ss, gfree, s->mytrips, s->stats, s->ctr));
+                                         s->boxT, ctx->M, s->mpad, ctx->ss, gfree, nseg, s->mytrips, s->stats, s->ctr));
     }
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
@@ -656,7 +662,7 @@ int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t check
     s->sharded = world > 1 || ctx->wf_force_sharded;
     if ((rc = wf_alloc(ctx, s, N, s->sharded ? std::max(world, 2) : 1))) return rc;
     s->band = band; s->single = (flags & MPFMT_WF_SINGLE) ? 1 : 0; s->checkpts = checkpts ? 1 : 0;
-    s->init = init_idx - 1; s->r = r;
+    s->init = init_idx - 1; s->r = r; s->directed = false;
     s->goal.kind = goal_kind; s->goal.gd = d;
     const int ng = goal_kind == MPFMT_GOAL_RECT ? 2 * d : goal_kind == MPFMT_GOAL_BALL ? d + 1 : d;
     memset(s->goal.g, 0, sizeof s->goal.g);
@@ -860,16 +866,14 @@ int32_t mpfmt_wf_finish(mpfmt_ctx* ctx, int64_t* A, double* C, int64_t* path, mp
     return MPFMT_OK;
 }
 
-int32_t mpfmt_fmtstar_wavefront(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind, const double* goal_params,
-                                double band, int32_t flags, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res, mpfmt_wf_info* info)
+// steps until the end condition: enqueued in groups, the end condition voids the kernels issued after it, the host looks
+// once per group (sharded: the exchange looks at the slot headers every step anyway)
+extern "C++" int32_t mpfmt_wf_run(mpfmt_ctx* ctx)
 {
-    if (!ctx || !res) return MPFMT_ERR_ARG;
-    int32_t rc;
-    if ((rc = mpfmt_wf_begin(ctx, r, init_idx, checkpts, goal_kind, goal_params, band, flags))) return rc;
     mpfmt_wf* s = wf_of(ctx);
+    if (!s || !s->active) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no wavefront solve in progress (mpfmt_wf_begin)");
     if (s->sharded && !ctx->comm) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "a sharded wavefront solve needs a communicator (mpfmt_comm_create), or the manual mpfmt_wf_step / _triples / _commit loop");
-    // steps are enqueued in groups; the end condition voids the kernels issued after it, the host looks once per group
-    // (sharded: the exchange looks at the slot headers every step anyway)
+    int32_t rc;
     const int group = s->sharded ? 1 : (s->single ? 32 : 8);
     const int64_t max_steps = 4 * s->N + 64;
     for (int64_t it = 0; it < max_steps; it += group) {
@@ -881,9 +885,70 @@ int32_t mpfmt_fmtstar_wavefront(mpfmt_ctx* ctx, double r, int64_t init_idx, int3
         if (wf_ended(s)) break;
     }
     if (!wf_ended(s)) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "wavefront solve did not terminate");
+    return MPFMT_OK;
+}
+
+// Directed steering graphs (quasi-metric spaces: double integrator, Dubins): the resident CSC holds the BACKWARD sets (column x
+// = sources y with cost(y -> x) <= r), its per-entry free bits and segment counts come from the space's own sweep
+// (mpfmt_di_sweep / mpfmt_car_sweep); the forward sets are the rows, transposed on the device here.  F: checkpts bitmap computed
+// by the caller for its space (host words); gd = coordinates the workspace goals read.
+extern "C++" int32_t mpfmt_wf_begin_directed(mpfmt_ctx* ctx, int64_t init_idx, int32_t checkpts, const uint64_t* F_host, int32_t goal_kind,
+                                const double* goal_params, int32_t gd, double band, int32_t flags)
+{
+    if (!ctx->di_filled || !ctx->di_swept) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "directed wavefront solve needs a built and swept steering graph");
+    if (ctx->world != 1) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "directed wavefront solve runs on an unsharded ctx");
+    const int64_t N = ctx->N;
+    const int d = ctx->d;
+    if (!(band >= 0.0) || !std::isfinite(band)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "band must be finite and >= 0");
+    int32_t rc;
+    if (!ctx->wf) ctx->wf = new mpfmt_wf();
+    mpfmt_wf* s = wf_of(ctx);
+    s->active = false;
+    s->t_begin = std::chrono::steady_clock::now();
+    if ((rc = wf_alloc(ctx, s, N, 1))) return rc;
+    s->sharded = 0; s->directed = true; s->use_mask = 1;
+    s->band = band; s->single = (flags & MPFMT_WF_SINGLE) ? 1 : 0; s->checkpts = checkpts ? 1 : 0;
+    s->init = init_idx - 1; s->r = ctx->di_r;
+    s->goal.kind = goal_kind; s->goal.gd = goal_kind == MPFMT_GOAL_POINT ? d : gd;
+    const int ng = goal_kind == MPFMT_GOAL_RECT ? 2 * gd : goal_kind == MPFMT_GOAL_BALL ? gd + 1 : d;
+    memset(s->goal.g, 0, sizeof s->goal.g);
+    for (int i = 0; i < ng; ++i) s->goal.g[i] = goal_params[i];
+    s->nparts = (int)std::min<int64_t>(WF_MAXPARTS, (s->words + 63) / 64);
+    if (s->nparts < 1) s->nparts = 1;
+    for (int k = 0; k < 4; ++k) s->prev_tot[k] = 0;
+    HIPCHK(ctx, hipMemcpyAsync(s->F, F_host, 8 * (size_t)s->words, hipMemcpyHostToDevice, ctx->stream));
+    // forward sets
+    const int64_t nnz = ctx->nnz;
+    if (s->csr_nnz < std::max<int64_t>(nnz, 1) || !s->rowptr) {
+        if (s->rowptr) { HIPCHK(ctx, hipFree(s->rowptr)); s->rowptr = nullptr; }
+        if (s->colidx) { HIPCHK(ctx, hipFree(s->colidx)); s->colidx = nullptr; }
+        HIPCHK(ctx, hipMalloc((void**)&s->rowptr, sizeof(int64_t) * (size_t)(N + 1)));
+        HIPCHK(ctx, hipMalloc((void**)&s->colidx, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
+        s->csr_nnz = std::max<int64_t>(nnz, 1);
+    }
+    if ((rc = mpfmt_csc_transpose_resident(ctx, s->rowptr, s->colidx))) return rc;
+    s->ms_graph = 0.0; s->ms_sweep = 0.0;
+    hipLaunchKernelGGL(k_wf_init, dim3(256), dim3(64), 0, ctx->stream, N, s->words, s->init, s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->C, s->A,
+                       s->stats, s->ctr);
+    HIPCHK(ctx, hipGetLastError());
+    s->active = true;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_fmtstar_wavefront(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind, const double* goal_params,
+                                double band, int32_t flags, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res, mpfmt_wf_info* info)
+{
+    if (!ctx || !res) return MPFMT_ERR_ARG;
+    int32_t rc;
+    if ((rc = mpfmt_wf_begin(ctx, r, init_idx, checkpts, goal_kind, goal_params, band, flags))) return rc;
+    mpfmt_wf* s = wf_of(ctx);
+    if ((rc = mpfmt_wf_run(ctx))) return rc;
     if ((rc = mpfmt_wf_finish(ctx, A, C, path, res))) return rc;
     if (info) wf_fill_info(s, info);
     return MPFMT_OK;
 }
 
 }  // extern "C"
+
+void mpfmt_wf_info_now(mpfmt_ctx* ctx, mpfmt_wf_info* info) { if (info && wf_of(ctx)) wf_fill_info(wf_of(ctx), info); }
+

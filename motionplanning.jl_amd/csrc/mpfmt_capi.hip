@@ -990,6 +990,67 @@ int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx,
     return MPFMT_OK;
 }
 
+// fmtstar! in the double-integrator space with the recursion on the device (kernels_wavefront.hip, directed form): graph,
+// 5-waypoint sweep and the transpose (forward sets) on the device, then cost-band batches; `single` reproduces
+// mpfmt_di_fmtstar / the reference's pop order exactly.
+int32_t mpfmt_di_fmtstar_wavefront(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind,
+                                   const double* goal_params, double band, int32_t flags, int64_t* A, double* C, int64_t* path,
+                                   mpfmt_fmt_result* res, mpfmt_wf_info* info)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!res || !goal_params) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "NULL output / goal pointer");
+    int32_t rc;
+    if ((rc = di_check(ctx, rho, r))) return rc;
+    if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
+    const int64_t N = ctx->N;
+    const int n = ctx->d, m = n / 2;
+    if (init_idx < 1 || init_idx > N) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "init_idx out of range");
+    if (goal_kind < 0 || goal_kind > 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown goal kind %d", goal_kind);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    auto t0 = std::chrono::steady_clock::now();
+    // checkpts bitmap: in_state_space on the state, point test on the workspace coordinates (as in mpfmt_di_fmtstar)
+    std::vector<double> X((size_t)N * n);
+    HIPCHK(ctx, hipMemcpy(X.data(), ctx->Xo, sizeof(double) * (size_t)N * n, hipMemcpyDeviceToHost));
+    std::vector<double> P((size_t)N * m);
+    for (int64_t i = 0; i < N; ++i) for (int q = 0; q < m; ++q) P[(size_t)i * m + q] = X[(size_t)i * n + q];
+    const int64_t words = (N + 63) / 64;
+    std::vector<uint64_t> F(words, 0);
+    {
+        const mpfmt_ss keep = ctx->ss;
+        ctx->ss.has = 0;
+        rc = mpfmt_states_free(ctx, P.data(), N, F.data());
+        ctx->ss = keep;
+        if (rc) return rc;
+        if (keep.has)
+            for (int64_t i = 0; i < N; ++i) {
+                bool ok = true;
+                for (int q = 0; q < n; ++q) ok = ok && (keep.lo[q] <= X[(size_t)i * n + q]) && (X[(size_t)i * n + q] <= keep.hi[q]);
+                if (!ok) F[i >> 6] &= ~(1ull << (i & 63));
+            }
+    }
+    if (!bit(F, init_idx - 1)) return mpfmt_fail(ctx, MPFMT_ERR_INFEASIBLE, "initial state is infeasible");
+    auto t1 = std::chrono::steady_clock::now();
+    if (!(ctx->di_filled && ctx->steer_kind == 1 && ctx->di_rho == rho && ctx->di_r == r)) {
+        if ((rc = mpfmt_di_count(ctx, rho, r))) return rc;
+        if ((rc = mpfmt_di_fill(ctx))) return rc;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    auto t2 = std::chrono::steady_clock::now();
+    if (!ctx->di_swept && (rc = mpfmt_di_sweep(ctx))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    auto t3 = std::chrono::steady_clock::now();
+    if ((rc = mpfmt_wf_begin_directed(ctx, init_idx, checkpts, F.data(), goal_kind, goal_params, m, band, flags))) return rc;
+    if ((rc = mpfmt_wf_run(ctx))) return rc;
+    if ((rc = mpfmt_wf_finish(ctx, A, C, path, res))) return rc;
+    auto t4 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    res->ms_graph = ms(t1, t2); res->ms_sweep = ms(t0, t1) + ms(t2, t3); res->ms_host_loop = ms(t3, t4);
+    mpfmt_wf_info_now(ctx, info);
+    return MPFMT_OK;
+}
+
 // ---- Dubins and Reeds-Shepp cars (kernels_car.hip) ------------------------------------------------------------------
 
 static int32_t car_graph_count(mpfmt_ctx* ctx, int kind, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz)

@@ -241,6 +241,7 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail = null
 #include <functional>
 #include <vector>
 int32_t mpfmt_csc_transpose_device(mpfmt_ctx* ctx, mpfmt_csr_host* out);      // kernels_di.hip; needs nnz < 2^32
+int32_t mpfmt_csc_transpose_resident(mpfmt_ctx* ctx, int64_t* d_rowptr, int32_t* d_colidx);   // the same, result left on the device
 int32_t mpfmt_car_build(mpfmt_ctx* ctx, int kind, double rt, double sp, double r);      // kind 1 Dubins, 2 Reeds-Shepp
 int32_t mpfmt_car_sweep(mpfmt_ctx* ctx);
 int32_t mpfmt_car_steer_batch(mpfmt_ctx* ctx, int kind, const double* d_X0, const double* d_X1, int64_t n, double rt, double sp, double* d_cost,
@@ -262,6 +263,10 @@ int32_t mpfmt_launch_euclid_propagate(mpfmt_ctx* ctx, const int64_t* d_src1, int
 
 // kernels_wavefront.hip -----------------------------------------------------------------------------
 void mpfmt_wf_free(mpfmt_ctx* ctx);
+int32_t mpfmt_wf_run(mpfmt_ctx* ctx);
+int32_t mpfmt_wf_begin_directed(mpfmt_ctx* ctx, int64_t init_idx, int32_t checkpts, const uint64_t* F_host, int32_t goal_kind,
+                                const double* goal_params, int32_t gd, double band, int32_t flags);
+void mpfmt_wf_info_now(mpfmt_ctx* ctx, mpfmt_wf_info* info);
 
 // kernels_expand.hip ----------------------------------------------------------------------------
 int32_t mpfmt_launch_expand(mpfmt_ctx* ctx, const uint64_t* d_W, const uint64_t* d_H, const uint64_t* d_F,

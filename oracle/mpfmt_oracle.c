@@ -759,17 +759,24 @@ void orc_euclid_propagate(const double *v, int32_t d, double t, const double *u,
  * lowest (cost, index) node) against the same (W, H, C), then the deferred update fmt.jl:83-84 for the batch, and stops when a
  * batch holds a goal node (fmt.jl:68) with z = the goal node of lowest (cost, index).  With single != 0 it is
  * orc_fmtstar_graph step for step.  iters (may be NULL) receives the number of batches, the last (unexpanded) one included. */
-int32_t orc_fmt_wavefront_graph(const double *X, int64_t N, int32_t d, int64_t init_idx,
-                                const int64_t *colptr, const int64_t *rowval, const double *nzval,
-                                const uint64_t *free_mask, const uint64_t *Fmask,
-                                int32_t goal_kind, const double *goal,
-                                const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi,
-                                double band, int32_t single,
-                                int64_t *A, double *C, int64_t *path, orc_fmt_result *res, int64_t *iters)
+/* general form: directed cost graphs too (quasi-metric spaces, fmt.jl with QuasiMetricNN): forward sets = rows of the cost
+ * matrix given as CSR (rowptr / colidx; NULL = symmetric graph, forward set = column), nseg = per-entry count of the segment
+ * tests the reference would make (NULL = one per examined edge, behind the in_state_space short circuit), gd = coordinates the
+ * goal predicate reads (POINT goals compare all d), init_free = is_free_state(init) as the caller's space defines it. */
+static int32_t wavefront_impl(const double *X, int64_t N, int32_t d, int32_t gd, int64_t init_idx, int32_t init_free,
+                              const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                              const int64_t *rowptr, const int64_t *colidx,
+                              const uint64_t *free_mask, const uint8_t *nseg, const uint64_t *Fmask,
+                              int32_t goal_kind, const double *goal,
+                              const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi,
+                              double band, int32_t single,
+                              int64_t *A, double *C, int64_t *path, orc_fmt_result *res, int64_t *iters)
 {
     memset(res, 0, sizeof *res);
     res->cost = INFINITY;
-    if (!orc_is_free_state(X + (size_t)init_idx * d, d, lohi, M, ss_lo, ss_hi)) return -1;
+    if (!init_free) return -1;
+    if (!rowptr) { rowptr = colptr; colidx = rowval; }
+#define WF_GOAL(p) ((goal_kind == 2) ? orc_is_goal_pt((p), d, 2, goal) : orc_is_goal_pt((p), gd, goal_kind, goal))
     uint8_t *Wm = (uint8_t *)malloc((size_t)N), *Hm = (uint8_t *)calloc((size_t)N, 1), *Zm = (uint8_t *)calloc((size_t)N, 1);
     uint8_t *cand = (uint8_t *)calloc((size_t)N, 1);
     memset(Wm, 1, (size_t)N);
@@ -800,14 +807,14 @@ int32_t orc_fmt_wavefront_graph(const double *X, int64_t N, int32_t d, int64_t i
         int64_t gi = -1; double gc = 0.0;
         for (int64_t k = 0; k < nz; ++k) {
             int64_t i = zs[k];
-            if (orc_is_goal_pt(X + (size_t)i * d, d, goal_kind, goal) && (gi < 0 || C[i] < gc)) { gc = C[i]; gi = i; }
+            if (WF_GOAL(X + (size_t)i * d) && (gi < 0 || C[i] < gc)) { gc = C[i]; gi = i; }
         }
         if (gi >= 0) { z_final = gi; status = 1; break; }
         /* fmt.jl:70-71: x unvisited, valid, adjacent to the batch */
         int64_t nx = 0;
         for (int64_t k = 0; k < nz; ++k)
-            for (int64_t a = colptr[zs[k]]; a < colptr[zs[k] + 1]; ++a) {
-                int64_t x = rowval[a];
+            for (int64_t a = rowptr[zs[k]]; a < rowptr[zs[k] + 1]; ++a) {
+                int64_t x = colidx[a];
                 if (!Wm[x] || cand[x]) continue;
                 if (Fmask && !get_bit(Fmask, x)) continue;
                 cand[x] = 1; xs[nx++] = x;
@@ -825,7 +832,8 @@ int32_t orc_fmt_wavefront_graph(const double *X, int64_t N, int32_t d, int64_t i
                 if (y_min < 0 || c < c_min) { y_min = y; c_min = c; e_min = b; }
             }
             if (y_min < 0) continue;
-            if (orc_in_state_space(X + (size_t)y_min * d, ss_lo, ss_hi, d)) ++count;
+            if (nseg) count += nseg[e_min];
+            else if (orc_in_state_space(X + (size_t)y_min * d, ss_lo, ss_hi, d)) ++count;
             int fr = free_mask ? get_bit(free_mask, e_min)
                                : orc_is_free_motion(X + (size_t)y_min * d, X + (size_t)x * d, d, lohi, M, ss_lo, ss_hi);
             if (fr) { cx[nconn] = x; cy[nconn] = y_min; cc[nconn] = c_min; ++nconn; }
@@ -843,7 +851,33 @@ int32_t orc_fmt_wavefront_graph(const double *X, int64_t N, int32_t d, int64_t i
     res->cost = C[z_final]; res->z = z_final; res->collision_checks = count; res->path_len = len; res->nn_queries = 0;
     if (iters) *iters = it;
     free(Wm); free(Hm); free(Zm); free(cand); free(zs); free(zprev); free(xs); free(cx); free(cy); free(cc); free(rev);
+#undef WF_GOAL
     return 0;
+}
+
+int32_t orc_fmt_wavefront_graph(const double *X, int64_t N, int32_t d, int64_t init_idx,
+                                const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                                const uint64_t *free_mask, const uint64_t *Fmask,
+                                int32_t goal_kind, const double *goal,
+                                const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi,
+                                double band, int32_t single,
+                                int64_t *A, double *C, int64_t *path, orc_fmt_result *res, int64_t *iters)
+{
+    return wavefront_impl(X, N, d, d, init_idx, orc_is_free_state(X + (size_t)init_idx * d, d, lohi, M, ss_lo, ss_hi), colptr, rowval, nzval,
+                          NULL, NULL, free_mask, NULL, Fmask, goal_kind, goal, lohi, M, ss_lo, ss_hi, band, single, A, C, path, res, iters);
+}
+
+/* the batched loop over a directed cost graph with precomputed edge bits and per-edge segment counts (double integrator,
+ * Dubins): checker of mpfmt_di_fmtstar_wavefront.  free_mask and nseg are required; Fmask NULL = checkpts false. */
+int32_t orc_fmt_wavefront_directed(const double *X, int64_t N, int32_t d, int32_t gd, int64_t init_idx, int32_t init_free,
+                                   const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                                   const int64_t *rowptr, const int64_t *colidx,
+                                   const uint64_t *free_mask, const uint8_t *nseg, const uint64_t *Fmask,
+                                   int32_t goal_kind, const double *goal, double band, int32_t single,
+                                   int64_t *A, double *C, int64_t *path, orc_fmt_result *res, int64_t *iters)
+{
+    return wavefront_impl(X, N, d, gd, init_idx, init_free, colptr, rowval, nzval, rowptr, colidx, free_mask, nseg, Fmask, goal_kind, goal,
+                          NULL, 0, NULL, NULL, band, single, A, C, path, res, iters);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -324,6 +324,31 @@ def fmt_wavefront_graph(X, colptr, rowval, nzval, free_mask, Fmask, goal_kind, g
                 collision_checks=int(res.collision_checks), A=A, C=Cc, path=path[:res.path_len].copy())
 
 
+def fmt_wavefront_directed(X, gd, colptr, rowval, nzval, free_mask, nseg, Fmask, goal_kind, goal, init_idx=0, init_free=True, band=0.0,
+                           single=False):
+    """The batched loop over a directed cost graph (CSC = backward sets; forward sets derived here), eager edge bits + nseg."""
+    X, N, d = _X(X); goal = _vec(goal)
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64); rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+    nzval = _vec(nzval)
+    nnz = int(colptr[N])
+    cols = np.repeat(np.arange(N, dtype=np.int64), np.diff(colptr))
+    order = np.lexsort((cols, rowval[:nnz]))                 # rows ascending, targets ascending inside a row
+    colidx = np.ascontiguousarray(cols[order])
+    rowptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rowval[:nnz], minlength=N), out=rowptr[1:])
+    free_mask = np.ascontiguousarray(free_mask, dtype=np.uint64)
+    nseg = np.ascontiguousarray(nseg, dtype=np.uint8)
+    Fmask = None if Fmask is None else np.ascontiguousarray(Fmask, dtype=np.uint64)
+    A = np.empty(N, dtype=np.int64); Cc = np.empty(N, dtype=np.float64); path = np.empty(N, dtype=np.int64)
+    res = FmtResult(); iters = C.c_int64()
+    rc = lib().orc_fmt_wavefront_directed(_d(X), C.c_int64(N), C.c_int32(d), C.c_int32(gd), C.c_int64(init_idx), C.c_int32(int(init_free)),
+                                          _i(colptr), _i(rowval), _d(nzval), _i(rowptr), _i(colidx), _u(free_mask),
+                                          nseg.ctypes.data_as(c_u8_p), _u(Fmask), C.c_int32(goal_kind), _d(goal), C.c_double(band),
+                                          C.c_int32(int(single)), _i(A), _d(Cc), _i(path), C.byref(res), C.byref(iters))
+    return dict(rc=rc, status=int(res.status), cost=float(res.cost), z=int(res.z), iters=int(iters.value),
+                collision_checks=int(res.collision_checks), A=A, C=Cc, path=path[:res.path_len].copy())
+
+
 def fmt_radius(rm, d, vol, N):
     return lib().orc_fmt_radius(C.c_double(rm), C.c_int32(d), C.c_double(vol), C.c_int64(N))
 

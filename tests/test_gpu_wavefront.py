@@ -302,3 +302,38 @@ def test_tiny_and_ragged_worlds(ctx, orc, N, d, M):
             assert got["status"] == ref["status"] and got["z"] - 1 == ref["z"] and got["cost"] == ref["cost"]
             assert got["collision_checks"] == ref["collision_checks"] and got["info"]["iters"] == ref["iters"]
             assert np.array_equal(got["A"] - 1, ref["A"]) and np.array_equal(got["C"], ref["C"]) and np.array_equal(got["path"] - 1, ref["path"])
+
+
+def test_di_wavefront_matches_sequential_and_oracle(ctx, orc):
+    """Kinodynamic FMT* (double integrator, BASELINE configs[3]) with the recursion on the device: the directed form (forward
+    sets = rows of the cost matrix, transposed on the device).  One node per batch = mpfmt_di_fmtstar = orc_di_fmtstar exactly;
+    with a band = the oracle's batched directed loop on the same graph, mask and segment counts."""
+    from test_gpu_parity import di_world
+    X, lohi, ss_lo, ss_hi = di_world(2500, 77)
+    ctx.upload_samples(X)
+    ctx.upload_boxes(lohi, ss_lo, ss_hi)
+    oc, orow, oval, _ = orc.di_pairwise(X, 1.0, 1.0)
+    for kind, goal, gd in ((L.GOAL_POINT, X[-1], 4), (L.GOAL_BALL, np.array([0.9, 0.9, 0.1]), 2)):
+        seq = ctx.di_fmtstar(1.0, 1.0, kind, goal)
+        ref = orc.di_fmtstar(X, 1.0, 1.0, oc, orow, oval, kind, goal, lohi, ss_lo, ss_hi)
+        one = ctx.di_fmtstar_wavefront(1.0, 1.0, kind, goal, single=True)
+        same_solution(one, seq)
+        assert one["status"] == ref["status"] and one["collision_checks"] == ref["collision_checks"]
+        assert np.array_equal(one["A"] - 1, ref["A"]) and np.array_equal(one["path"] - 1, ref["path"]) and np.array_equal(one["C"], ref["C"])
+        ctx.di_graph(1.0, 1.0)                                  # (sets the wrapper's nnz; the resident graph is reused)
+        mask, nseg = ctx.di_graph_edges_free()
+        F = orc.pack(np.array([orc.is_free_state(x[:2], lohi) and bool(np.all((ss_lo <= x) & (x <= ss_hi))) for x in X]))
+        for bandf in (0.0, 0.2, 1.0):
+            want = orc.fmt_wavefront_directed(X, 2, oc, orow, oval, mask, nseg, F, kind, goal, band=bandf)
+            got = ctx.di_fmtstar_wavefront(1.0, 1.0, kind, goal, band=bandf)
+            assert got["status"] == want["status"] and got["z"] - 1 == want["z"] and got["cost"] == want["cost"]
+            assert got["collision_checks"] == want["collision_checks"] and got["info"]["iters"] == want["iters"]
+            assert np.array_equal(got["A"] - 1, want["A"]) and np.array_equal(got["C"], want["C"]) and np.array_equal(got["path"] - 1, want["path"])
+            if seq["status"] == 1:
+                assert got["status"] == 1 and got["cost"] <= seq["cost"] * 1.3
+    # the Euclidean solve afterwards is unaffected by the directed state
+    w = world(3000, 2, 20, 5)
+    upload(ctx, w)
+    a = ctx.fmtstar_wavefront(w.r, L.GOAL_BALL, w.goal_params(), single=True)
+    b = ctx.fmtstar(w.r, L.GOAL_BALL, w.goal_params())
+    same_solution(a, b)
