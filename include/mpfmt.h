@@ -376,6 +376,13 @@ int32_t mpfmt_wf_batch(mpfmt_ctx* ctx, int64_t* zs, int64_t cap, int64_t* nz);
 int32_t mpfmt_wf_triples(mpfmt_ctx* ctx, int64_t cap, int64_t* x, int64_t* y, double* c, int64_t* n);
 int32_t mpfmt_wf_commit(mpfmt_ctx* ctx, int64_t n, const int64_t* x, const int64_t* y, const double* c);
 int32_t mpfmt_wf_finish(mpfmt_ctx* ctx, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
+/* mpfmt_dubins_fmtstar_wavefront / mpfmt_reedsshepp_fmtstar_wavefront : the car planners (simplecars.jl spaces) the same way. */
+int32_t mpfmt_dubins_fmtstar_wavefront(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+                                       int32_t goal_kind, const double* goal_params, double band, int32_t flags, int64_t* A, double* C,
+                                       int64_t* path, mpfmt_fmt_result* res, mpfmt_wf_info* info);
+int32_t mpfmt_reedsshepp_fmtstar_wavefront(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+                                           int32_t goal_kind, const double* goal_params, double band, int32_t flags, int64_t* A, double* C,
+                                           int64_t* path, mpfmt_fmt_result* res, mpfmt_wf_info* info);
 /* mpfmt_di_fmtstar_wavefront : mpfmt_di_fmtstar with the recursion on the device: the double-integrator graph is directed, so
  *        the forward sets nearF (rows of the cost matrix, linearquadratic.jl:73) are transposed on the device and the edge
  *        answers come from the 5-waypoint sweep's mask and segment counts.  MPFMT_WF_SINGLE reproduces mpfmt_di_fmtstar exactly;

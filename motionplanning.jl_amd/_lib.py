@@ -99,6 +99,10 @@ SYMBOLS = [
     ("mpfmt_di_steer", C.c_int32, [C.c_void_p, c_d_p, c_d_p, C.c_int64, C.c_int32, C.c_double, C.c_double, c_d_p, c_d_p]),
     ("mpfmt_di_fmtstar", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
                                      c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
+    ("mpfmt_dubins_fmtstar_wavefront", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
+                                                   C.c_double, C.c_int32, c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult), C.POINTER(WfInfo)]),
+    ("mpfmt_reedsshepp_fmtstar_wavefront", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
+                                                       C.c_double, C.c_int32, c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult), C.POINTER(WfInfo)]),
     ("mpfmt_di_fmtstar_wavefront", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p, C.c_double,
                                                C.c_int32, c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult), C.POINTER(WfInfo)]),
     ("mpfmt_graph_build_device", C.c_int32, [C.c_void_p, C.c_double, c_i64_p]),
@@ -687,6 +691,20 @@ class Context:
         return dict(status=int(res.status), cost=float(res.cost), z=int(res.z), collision_checks=int(res.collision_checks),
                     nnz=int(res.nnz), ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
                     A=A[:self.N], C=Cc[:self.N], path=path[:res.path_len].copy())
+
+    def car_fmtstar_wavefront(self, car, turn_radius, speed, r, goal_kind, goal_params, band=0.0, single=False, init_idx=1, checkpts=True):
+        """dubins / reedsshepp planner with the recursion on the device."""
+        g = np.ascontiguousarray(goal_params, dtype=np.float64)
+        A = np.empty(max(self.N, 1), dtype=np.int64); Cc = np.empty(max(self.N, 1), dtype=np.float64)
+        path = np.empty(max(self.N, 1), dtype=np.int64)
+        res, info = FmtResult(), WfInfo()
+        self._chk(getattr(self._L, f"mpfmt_{car}_fmtstar_wavefront")(self._h, float(turn_radius), float(speed), float(r), int(init_idx),
+                                                                     int(bool(checkpts)), int(goal_kind), _dp(g), float(band),
+                                                                     WF_SINGLE if single else 0, _ip(A), _dp(Cc), _ip(path), C.byref(res),
+                                                                     C.byref(info)))
+        out = self._fmt_out(res, A, Cc, path)
+        out["info"] = self._wf_info(info)
+        return out
 
     def di_fmtstar_wavefront(self, rho, r, goal_kind, goal_params, band=0.0, single=False, init_idx=1, checkpts=True, want_tree=True):
         """di_fmtstar with the recursion on the device (directed wavefront form)."""

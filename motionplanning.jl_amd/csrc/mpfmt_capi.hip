@@ -1225,6 +1225,69 @@ static int32_t car_fmtstar(mpfmt_ctx* ctx, int kind, double turn_radius, double 
     return MPFMT_OK;
 }
 
+// the car planners with the recursion on the device (directed wavefront form; the Reeds-Shepp graph is structurally symmetric,
+// so its rows are its columns and the same form applies): graph + waypoint sweep as in car_fmtstar, then cost-band batches
+static int32_t car_fmtstar_wavefront(mpfmt_ctx* ctx, int kind, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+                                     int32_t goal_kind, const double* goal_params, double band, int32_t flags, int64_t* A, double* C,
+                                     int64_t* path, mpfmt_fmt_result* res, mpfmt_wf_info* info)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!res || !goal_params) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "NULL output / goal pointer");
+    if (!ctx->Xo || ctx->d != 3) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car planning needs SE2 samples (d = 3)");
+    if (!ctx->have_boxes || ctx->cc_kind != 0 || ctx->dw != 2) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car planning needs 2-D boxes (mpfmt_upload_boxes, dw = 2)");
+    const int64_t N = ctx->N;
+    if (init_idx < 1 || init_idx > N) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "init_idx out of range");
+    if (goal_kind < 0 || goal_kind > 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown goal kind %d", goal_kind);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<double> X((size_t)N * 3), P((size_t)N * 2);
+    HIPCHK(ctx, hipMemcpy(X.data(), ctx->Xo, sizeof(double) * (size_t)N * 3, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < N; ++i) { P[2 * i] = X[3 * i]; P[2 * i + 1] = X[3 * i + 1]; }
+    const int64_t words = (N + 63) / 64;
+    std::vector<uint64_t> F(words, 0);
+    {
+        const mpfmt_ss keep = ctx->ss;
+        ctx->ss.has = 0;
+        rc = mpfmt_states_free(ctx, P.data(), N, F.data());
+        ctx->ss = keep;
+        if (rc) return rc;
+        if (keep.has)
+            for (int64_t i = 0; i < N; ++i) {
+                bool ok = true;
+                for (int q = 0; q < 3; ++q) ok = ok && (keep.lo[q] <= X[(size_t)i * 3 + q]) && (X[(size_t)i * 3 + q] <= keep.hi[q]);
+                if (!ok) F[i >> 6] &= ~(1ull << (i & 63));
+            }
+    }
+    if (!bit(F, init_idx - 1)) return mpfmt_fail(ctx, MPFMT_ERR_INFEASIBLE, "initial state is infeasible");
+    auto t1 = std::chrono::steady_clock::now();
+    if ((rc = mpfmt_car_build(ctx, kind, turn_radius, speed, r))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    auto t2 = std::chrono::steady_clock::now();
+    if ((rc = mpfmt_car_sweep(ctx))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    auto t3 = std::chrono::steady_clock::now();
+    if ((rc = mpfmt_wf_begin_directed(ctx, init_idx, checkpts, F.data(), goal_kind, goal_params, 2, band, flags))) return rc;
+    if ((rc = mpfmt_wf_run(ctx))) return rc;
+    if ((rc = mpfmt_wf_finish(ctx, A, C, path, res))) return rc;
+    auto t4 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    res->ms_graph = ms(t1, t2); res->ms_sweep = ms(t0, t1) + ms(t2, t3); res->ms_host_loop = ms(t3, t4);
+    mpfmt_wf_info_now(ctx, info);
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_dubins_fmtstar_wavefront(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+                                       int32_t goal_kind, const double* goal_params, double band, int32_t flags, int64_t* A, double* C,
+                                       int64_t* path, mpfmt_fmt_result* res, mpfmt_wf_info* info)
+{ return car_fmtstar_wavefront(ctx, 1, turn_radius, speed, r, init_idx, checkpts, goal_kind, goal_params, band, flags, A, C, path, res, info); }
+int32_t mpfmt_reedsshepp_fmtstar_wavefront(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+                                           int32_t goal_kind, const double* goal_params, double band, int32_t flags, int64_t* A, double* C,
+                                           int64_t* path, mpfmt_fmt_result* res, mpfmt_wf_info* info)
+{ return car_fmtstar_wavefront(ctx, 2, turn_radius, speed, r, init_idx, checkpts, goal_kind, goal_params, band, flags, A, C, path, res, info); }
+
 int32_t mpfmt_dubins_graph_count(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz)
 { return car_graph_count(ctx, 1, turn_radius, speed, r, colptr, nnz); }
 int32_t mpfmt_dubins_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval) { return car_graph_fill(ctx, 1, rowval, nzval); }

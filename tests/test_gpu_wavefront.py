@@ -337,3 +337,24 @@ def test_di_wavefront_matches_sequential_and_oracle(ctx, orc):
     a = ctx.fmtstar_wavefront(w.r, L.GOAL_BALL, w.goal_params(), single=True)
     b = ctx.fmtstar(w.r, L.GOAL_BALL, w.goal_params())
     same_solution(a, b)
+
+
+@pytest.mark.parametrize("car", ["dubins", "reedsshepp"])
+def test_car_wavefront_matches_sequential(ctx, car):
+    """Dubins (directed) and Reeds-Shepp (structurally symmetric) planners with the recursion on the device: one node per batch
+    equals the host recursion exactly (tree, costs, path, per-segment collision counts); a band still solves."""
+    from test_gpu_parity import _car_world
+    rng = np.random.default_rng(70 + 1500)
+    X, lohi, lo, hi = _car_world(rng, 1500, 12)
+    X[0] = [0.05, 0.05, 0.6]; X[-1] = [0.95, 0.95, 0.8]
+    ctx.upload_samples(X)
+    ctx.upload_boxes(lohi, lo, hi, dw=2)
+    goal = np.array([0.95, 0.95, 0.08])
+    rt, r = 0.05, (0.25 if car == "dubins" else 0.2)
+    seq = getattr(ctx, car + "_fmtstar")(rt, 1.0, r, L.GOAL_BALL, goal)
+    one = ctx.car_fmtstar_wavefront(car, rt, 1.0, r, L.GOAL_BALL, goal, single=True)
+    same_solution(one, seq)
+    band = ctx.car_fmtstar_wavefront(car, rt, 1.0, r, L.GOAL_BALL, goal, band=0.3 * r)
+    assert band["status"] == seq["status"]
+    if seq["status"] == 1:
+        assert seq["cost"] * (1 - 1e-12) <= band["cost"] <= seq["cost"] * 1.3
