@@ -446,9 +446,12 @@ def sample_free_(P, N, ensure_goal=True, ensure_goal_ct=5, rng=None, seed=None):
 
 
 # ---- planner (src/planners/fmt.jl) -------------------------------------------------------------------------------------------------
-def fmtstar_(P, N=None, rm=1.0, connections="R", r=0.0, ensure_goal_ct=1, init_idx=1, checkpts=True, rng=None, seed=None):
+def fmtstar_(P, N=None, rm=1.0, connections="R", r=0.0, ensure_goal_ct=1, init_idx=1, checkpts=True, rng=None, seed=None,
+             band=None):
     """fmtstar!(P, N; rm, connections, r, ensure_goal_ct, init_idx, checkpts)  (fmt.jl:3-119).  Returns
-    (status, cost, elapsed) and fills P.solution like the reference."""
+    (status, cost, elapsed) and fills P.solution like the reference.  band = None: the reference's sequential recursion (on the
+    host, over GPU-built arrays); band >= 0: the recursion on the device with cost-band batches of that width in units of r
+    (mpfmt_*_fmtstar_wavefront; band = 0 expands only exact cost ties together)."""
     t0 = time.time()
     N = len(P.V) if N is None else int(N)
     P.CC.count = 0
@@ -469,7 +472,17 @@ def fmtstar_(P, N=None, rm=1.0, connections="R", r=0.0, ensure_goal_ct=1, init_i
         setup_steering(P.SS, r)
     ctx = P.ctx
     P.CC._bind(ctx, P.SS)
-    if isinstance(P.SS.dist, LinearQuadratic):
+    if band is not None:
+        bw = float(band) * r
+        if isinstance(P.SS.dist, LinearQuadratic):
+            res = ctx.di_fmtstar_wavefront(P.SS.dist.rho, r, P.goal.kind, P.goal.params(), band=bw, init_idx=init_idx, checkpts=checkpts)
+        elif isinstance(P.SS.dist, (DubinsExact, ReedsSheppExact)):
+            car = "dubins" if isinstance(P.SS.dist, DubinsExact) else "reedsshepp"
+            res = ctx.car_fmtstar_wavefront(car, P.SS.dist.r, P.SS.dist.s, r, P.goal.kind, P.goal.params(), band=bw, init_idx=init_idx,
+                                            checkpts=checkpts)
+        else:
+            res = ctx.fmtstar_wavefront(r, P.goal.kind, P.goal.params(), band=bw, init_idx=init_idx, checkpts=checkpts)
+    elif isinstance(P.SS.dist, LinearQuadratic):
         res = ctx.di_fmtstar(P.SS.dist.rho, r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)
     elif isinstance(P.SS.dist, DubinsExact):
         res = ctx.dubins_fmtstar(P.SS.dist.r, P.SS.dist.s, r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)

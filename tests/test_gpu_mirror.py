@@ -200,3 +200,22 @@ def test_closest_through_the_mirror(orc):
     assert abs(d2 - 0.16) < 1e-14 and np.allclose(v, [0.3, 0.5], atol=1e-14)
     d2b, vb = mp.closest(np.array([[0.3, 0.9], [0.7, 0.0]]), C2, W)
     assert d2b.shape == (2,) and vb.shape == (2, 2)
+
+
+def test_device_recursion_through_the_mirror(orc):
+    """fmtstar_(..., band=b): the same call with the recursion on the device; a re-plan on the same samples (the reference's
+    neighbour cache persisting in P.V across fmtstar! calls) with a band gives a valid plan whose cost is within a few percent."""
+    P = mp.MPProblem(mp.UnitHypercube(2), [0.1, 0.1], mp.BallGoal([0.9, 0.9], 0.05), mp.PointRobotNDBoxes(boxes2d()))
+    rng = np.random.default_rng(5)
+    status, cost, _ = mp.fmtstar_(P, 3000, rm=1.5, rng=rng)
+    seq_tree = P.solution.metadata["tree"].copy()
+    status2, cost2, _ = mp.fmtstar_(P, 3000, rm=1.5, rng=rng, band=0.0)
+    assert status == status2 == "solved" and len(P.V) == 3000
+    assert cost2 >= cost * (1 - 1e-12) and cost2 <= cost * 1.05
+    status3, cost3, _ = mp.fmtstar_(P, 3000, rm=1.5, rng=rng, band=0.5)
+    assert status3 == "solved" and cost3 <= cost * 1.1
+    X, lohi = P.V.V, P.CC.lohi()
+    path = P.solution.metadata["path"]
+    for a, b in zip(path[:-1], path[1:]):
+        assert orc.is_free_motion(X[a - 1], X[b - 1], lohi, P.SS.lo, P.SS.hi)
+    assert (P.solution.metadata["tree"] > 0).sum() > 0.5 * (seq_tree > 0).sum()
