@@ -79,6 +79,6 @@ while time.time() - t0 < budget:
     rt = float(rng.choice([0.02, 0.1, 0.5, 3.0]))
     cost, ctrl = ctx.dubins_steer(A, B, rt, 1.0)
     want = np.array([orc.dubins(a, b, rt, 1.0)[0] for a, b in zip(A, B)])
-    assert np.allclose(cost, want, rtol=1e-11, atol=0), ("dubins", np.max(np.abs(cost - want) / want))
+    assert np.array_equal(cost, want), ("dubins", np.max(np.abs(cost - want) / want))        # mp_math.h on both sides: bit-exact
     n_dub += 1
 print("stress2 ok: sat2d %d, sampler %d, mc %d, dubins %d rounds, %.0f s" % (n_sat, n_smp, n_mc, n_dub, time.time() - t0))
