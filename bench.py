@@ -200,11 +200,13 @@ def main():
     ctx.upload_samples(w.X)                       # inputs resident in HBM before the timed region
     ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
 
-    rccl_abi = world > 1 and not one_device
+    # (one-device functional check: the library's exchange can still run when MPFMT_RCCL_LIB names the tests' shared-memory
+    # stand-in for RCCL, tests/mock_rccl -- several ranks on one GPU; never a measurement)
+    rccl_abi = world > 1 and (not one_device or bool(os.environ.get("MPFMT_RCCL_LIB")))
     gather = None
     if rccl_abi:
         # the library's own RCCL communicator: rank 0 makes the id, the control plane (torch.distributed) hands it round
-        uid = torch.zeros(mp._lib.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        uid = torch.zeros(mp._lib.COMM_ID_BYTES, dtype=torch.uint8, device="cpu" if one_device else dev)
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(mp._lib.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, src=0)
@@ -305,7 +307,8 @@ def main():
                    "parallelism": "shard%d" % world,
                    "exchange": ("none" if world == 1 else
                                 "one RCCL all-gather of the free-edge mask per step through the C ABI (mpfmt_allgather_free_mask_*), "
-                                "overlapped with the next step's index build" if rccl_abi else "gloo (one-device functional check)"),
+                                "overlapped with the next step's index build" + (" [RCCL stand-in: %s]" % os.environ["MPFMT_RCCL_LIB"] if os.environ.get("MPFMT_RCCL_LIB") else "")
+                                if rccl_abi else "gloo (one-device functional check)"),
                    "step": "r-disc graph of all N samples + collision sweep of all nnz directed edges"},
         "submetrics": {
             "rdisc_queries_per_s": w.N * args.steps / dt,

@@ -14,6 +14,7 @@
 #include "mpfmt_internal.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <mutex>
@@ -38,8 +39,10 @@ std::once_flag g_rccl_once;
 
 void rccl_load()
 {
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // MPFMT_RCCL_LIB: an explicit library (the tests put a shared-memory stand-in there to run several ranks on one GPU)
+    const char* names[] = {getenv("MPFMT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
+        if (!n || !*n) continue;
         g_rccl.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (g_rccl.dl) break;
     }
