@@ -132,7 +132,7 @@ def spawn_ranks(n):
     makes one) and exit with their status.  Rank 0 prints the JSON line on the inherited stdout."""
     import torch            # device_count() does not initialise the GPU on this image
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not os.environ.get("MPFMT_BENCH_ONE_DEVICE"):      # (the one-device functional check shares GPU 0 between the ranks)
         sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (n, have))
         sys.exit(2)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,

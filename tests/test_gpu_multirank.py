@@ -51,3 +51,16 @@ def test_bench_two_ranks_through_the_c_abi(mock_lib):
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["nnz"] == d1["config"]["nnz"]                 # the shards partition the graph
+
+
+def test_bench_starts_its_own_ranks(mock_lib):
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns the ranks (before touching the GPU) and rank 0's
+    JSON line comes back on its stdout."""
+    env = dict(os.environ, MPFMT_RCCL_LIB=mock_lib, MPFMT_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
