@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libmpfmt.so")
+_SO = os.environ.get("MPFMT_LIB_PATH") or os.path.join(_HERE, "libmpfmt.so")   # override: kernel experiments (tools/)
 _LIB = None
 
 OK, ERR_ARG, ERR_STATE, ERR_HIP, ERR_NODEVICE, ERR_CAPACITY, ERR_INFEASIBLE = 0, -1, -2, -3, -4, -5, -6

@@ -21,6 +21,8 @@
 // sample, so ~7% of the boxes survive at the north-star workload.  The 64 results of a wavefront are
 // one __ballot = one UInt64 chunk of a Julia BitVector (LSB = lowest edge index).
 #include "mpfmt_internal.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include <algorithm>
 
 #define SWEEP_THREADS 256
@@ -32,6 +34,7 @@
 #define SWEEP_LDS_BYTES (60 * 1024)
 
 #include "sweep_predicates.h"
+#include "sweep_cmpx.h"
 
 // Wave-level cull of nb (<= SWEEP_CHUNK) staged boxes against the union box [ulo, uhi] of the
 // wavefront's segments.  Survivor words stay in (wave-uniform) registers.
@@ -198,6 +201,9 @@ __device__ __forceinline__ double lane_f64(double v, int l)
 //     the blocked ones.  The queue is flushed before the task header is recycled;
 //   - predicates are the straight-line forms on register-held boxes (see above).
 #define SWEEP_QCAP 128
+#ifndef SWEEP_ABL
+#define SWEEP_ABL 0               // > 0: timing-only stage ablations for tools/ablate_sweep.sh (wrong results by construction)
+#endif
 
 struct sweep_round {
     int valid, first, hs, c;          // hs: which of the two resident task headers; c: column within the task
@@ -444,6 +450,9 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
                         for (int i = 0; i < D; ++i) out |= (int)(bx.hi[i] < ulo[i]) | (int)(bx.lo[i] > uhi[i]);
                         smask[c] = __ballot(k < nb && !out);
                     }
+#if SWEEP_ABL == 4
+                    for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] = 0;
+#endif
                 }
                 const int64_t e0 = R0.e0, end = R0.end;
                 const bool active = e0 + lane < end;
@@ -451,13 +460,22 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
 #pragma unroll
                 for (int i = 0; i < D; ++i) v[i] = pv0[i];
                 // first chunk decides in_state_space; later chunks can only clear bits
+#if SWEEP_ABL == 1
+                bool fr = active;
+#else
                 bool fr = active && (b0 > 0 || in_state_space_sl<D>(v, ss));
+#endif
                 double l[D], h[D];
                 seg_bbox<D>(v, w, l, h);
                 int p0 = -1, p1 = -1;                    // boxes whose broad phase this lane failed
+                const uint32_t eoff = (uint32_t)(e0 + lane - (R0.hs ? hdr_i64<D, SWEEP_TC>(H1, 0, R0.c) : hdr_i64<D, SWEEP_TC>(H0, 0, R0.c)));
+                hs_q = R0.hs;
 #pragma unroll
                 for (int c = 0; c < SWEEP_WORDS; ++c) {
                     unsigned long long m = smask[c];
+#if SWEEP_ABL == 3 || SWEEP_ABL == 4
+                    m = 0;
+#endif
                     while (m) {
                         const int k = c * 64 + (__ffsll((long long)m) - 1);
                         m &= m - 1;
@@ -466,14 +484,24 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
                         const bool third = pend & (p1 >= 0);
                         p1 = (pend & (p0 >= 0) & (p1 < 0)) ? k : p1;
                         p0 = (pend & (p0 < 0)) ? k : p0;
-                        if (__ballot(third)) {                                     // third pending box: rare, test in place
-                            if (third) fr = narrow_free_sl<D>(v, w, bx);
+                        const unsigned long long m3 = __ballot(third);
+                        if (m3) {
+                            // a lane's third pending box (0.5 % of the entries, but one round in four has such a lane): queued
+                            // like the other two while the p0 push below still has room; in place (a whole wave through the
+                            // exact test for one or two lanes) only when the queue is that full
+                            if constexpr (D <= 8) {
+                                if (qcount + (int)__popcll(m3) + 64 <= SWEEP_QCAP) push(third, v, eoff, ((uint32_t)R0.c << 16) | (uint32_t)k);
+                                else if (third) fr = narrow_free_sl<D>(v, w, bx);
+                            } else {
+                                if (third) fr = narrow_free_sl<D>(v, w, bx);
+                            }
                         }
                     }
                 }
                 // queue the pending exact tests (the entry counts as free until a pass says otherwise)
-                const uint32_t eoff = (uint32_t)(e0 + lane - (R0.hs ? hdr_i64<D, SWEEP_TC>(H1, 0, R0.c) : hdr_i64<D, SWEEP_TC>(H0, 0, R0.c)));
-                hs_q = R0.hs;
+#if SWEEP_ABL == 2
+                p0 = p1 = -1;
+#endif
                 if constexpr (D <= 8) {
                     push(fr && p0 >= 0, v, eoff, ((uint32_t)R0.c << 16) | (uint32_t)max(p0, 0));
                     if (__ballot(fr && p1 >= 0)) {
@@ -496,7 +524,11 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
                 // the mask starts all-ones and every obstacle chunk only clears bits, so chunks (and the waves that
                 // happen to claim a task in each of them) commute
                 const unsigned long long clr = ~bits & __ballot(active);
+#if SWEEP_ABL == 5
+                if (lane == 0 && clr == 0x123456789abcull) {
+#else
                 if (lane == 0 && clr) {
+#endif
                     atomicAnd(&mask[wd], ~(clr << sh));
                     if (sh && (clr >> (64 - sh))) atomicAnd(&mask[wd + 1], ~(clr >> (64 - sh)));
                 }
@@ -507,6 +539,321 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
         }
         if (M == 0) break;
     }
+}
+
+// ---- graph sweep over a ROUND TABLE ---------------------------------------------------------------
+// Same bits as k_graph_sweep (d <= 8, M <= SWEEP_CHUNK), a leaner skeleton.  Stage ablation of k_graph_sweep on the north
+// star (tools/ablate_sweep.sh): with the cull, the box loop and the exact tests all removed it still takes 2.29 of its 2.67 ms
+// in caller order (the random 48-byte row gather at its request-rate ceiling) and 1.90 ms with rows gathered from the
+// cell-sorted copy (L2 hits): the round sequencing itself -- two resident task headers read out by v_readlane, round
+// descriptors advanced in scalar registers across column and task boundaries (106 SGPRs, 65 of them spilled to VGPR
+// lanes) -- was the bound, not the collision arithmetic.  Here the sequence is data: a table with one entry per round
+// (column, first entry, number of entries, first-round-of-column flag) in visiting order, written by two trivial kernels
+// around a scan.  A wavefront loads 64 consecutive entries with one coalesced read (lane = round), reads round k's four
+// words out with v_readlane, fetches the column state with scalar loads (wave-uniform address), and never looks at colptr.
+// a global pointer read through the constant address space: a wave-uniform address then always takes the scalar cache
+// (s_load into SGPRs, usable directly as the scalar operand of a vector compare) -- no alias analysis involved
+typedef const __attribute__((address_space(4))) double* sweep_cptr;
+__device__ __forceinline__ sweep_cptr as_const(const double* p) { return (sweep_cptr)(uintptr_t)p; }
+
+struct sweep_rd { int32_t x; uint32_t nf; int64_t e0; };          // nf = entries (1..64) | first round of the column << 31
+
+__global__ void k_round_count(const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm, int64_t sp_begin, int64_t sp_end,
+                              int64_t* __restrict__ cnt, const int32_t* __restrict__ spec_fail)
+{
+    if (spec_fail && *spec_fail) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = sp_end - sp_begin;
+    if (i > n) return;
+    int64_t c = 0;
+    if (i < n) {
+        const int64_t x = perm ? (int64_t)perm[sp_begin + i] : sp_begin + i;       // pad positions of the sorted order hold -1
+        if (x >= 0) c = (colptr[x + 1] - colptr[x] + 63) >> 6;
+    }
+    cnt[i] = c;                                                        // cnt[n] = 0: the scan's last element is the total
+}
+
+__global__ void k_round_fill(const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm, int64_t sp_begin, int64_t sp_end,
+                             const int64_t* __restrict__ off, sweep_rd* __restrict__ table, int64_t cap, int64_t* __restrict__ total,
+                             const int32_t* __restrict__ spec_fail)
+{
+    if (spec_fail && *spec_fail) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = sp_end - sp_begin;
+    if (i > n) return;
+    if (i == n) { *total = off[n] < cap ? off[n] : cap; return; }
+    const int64_t x = perm ? (int64_t)perm[sp_begin + i] : sp_begin + i;
+    if (x < 0) return;
+    const int64_t b = colptr[x], e = colptr[x + 1];
+    int64_t o = off[i];
+    for (int64_t e0 = b; e0 < e && o < cap; e0 += 64, ++o) {
+        sweep_rd r;
+        r.x = (int32_t)x;
+        r.nf = (uint32_t)(e - e0 < 64 ? e - e0 : 64) | (e0 == b ? 0x80000000u : 0u);
+        r.e0 = e0;
+        table[o] = r;
+    }
+}
+
+#define RT_TASK 64                 // rounds per task = lanes of the descriptor register
+
+template <int D>
+__global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double* __restrict__ X, const int64_t* __restrict__ colptr, int64_t N,
+                                                                     const double* __restrict__ Xrow, const int32_t* __restrict__ rowsrc,
+                                                                     double rpad, const double* __restrict__ boxes, int M,
+                                                                     int ss_has, const double* __restrict__ ss_bounds,
+                                                                     unsigned long long* __restrict__ mask,
+                                                                     const sweep_rd* __restrict__ table, const int64_t* __restrict__ total_p,
+                                                                     int* __restrict__ task_ctr, const int32_t* __restrict__ spec_fail, int xcd_ranges)
+{
+    if (spec_fail && *spec_fail) return;                   // speculative step whose capacities did not hold: redone by the host
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sboxT = (double*)smem;                         // [2*D][SWEEP_CHUNK]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // per-wave queue of pending exact tests (SoA): row state [D][QCAP], entry (lo, hi), column, box
+    double* qv = sboxT + (int64_t)SWEEP_CHUNK * 2 * D + (int64_t)wave * (D + 2) * SWEEP_QCAP;
+    uint32_t* qel = (uint32_t*)(qv + (int64_t)D * SWEEP_QCAP);
+    uint32_t* qeh = qel + SWEEP_QCAP;
+    uint32_t* qx = qeh + SWEEP_QCAP;
+    uint32_t* qk = qx + SWEEP_QCAP;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {               // padding bits of the last word are zero
+        const int64_t nnz = colptr[N];
+        if (nnz & 63) atomicAnd(&mask[nnz >> 6], (1ull << (nnz & 63)) - 1ull);
+    }
+    for (int t = threadIdx.x; t < M * 2 * D; t += blockDim.x) {
+        const int k = t / (2 * D), i = t - k * 2 * D;
+        sboxT[i * SWEEP_CHUNK + k] = boxes[t];
+    }
+    __syncthreads();
+    const int64_t total = *total_p;
+    const int64_t ntasks = (total + RT_TASK - 1) / RT_TASK;
+
+    int xlive = 0;                                           // wave-uniform: XCD ranges before this one (in steal order) are exhausted
+    auto grab = [&]() -> int64_t {
+        if (!xcd_ranges) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(task_ctr, 1);
+            return (int64_t)__builtin_amdgcn_readfirstlane(t);
+        }
+        const int me = (int)(blockIdx.x & 7);                // own range first, then the next XCDs' (tail balance)
+        while (xlive < 8) {
+            const int x = (me + xlive) & 7;
+            const int64_t lo = ntasks * x / 8, hi = ntasks * (x + 1) / 8;
+            int t = 0;
+            if (lane == 0) t = atomicAdd(task_ctr + x, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (lo + t < hi) return lo + t;
+            ++xlive;
+        }
+        return ntasks;
+    };
+
+    // ---- queue of pending exact tests ----
+    int qcount = 0;                                          // wave-uniform
+    auto push = [&](bool pred, const double (&v)[D], int64_t e, int x, int k) {
+        const unsigned long long m = __ballot(pred);
+        if (m == 0) return;
+        const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (pred) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) qv[i * SWEEP_QCAP + pos] = v[i];
+            qel[pos] = (uint32_t)(uint64_t)e; qeh[pos] = (uint32_t)((uint64_t)e >> 32);
+            qx[pos] = (uint32_t)x; qk[pos] = (uint32_t)k;
+        }
+        qcount += __popcll(m);
+    };
+    // exact test of the last n (<= 64) queued items, lane = item; the column state is fetched again (L2-warm)
+    auto drain = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool on = lane < n;
+        const int qi = on ? qcount - n + lane : 0;
+        const int64_t x = (int64_t)qx[qi];
+        double v[D], w[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) w[i] = X[x * D + i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) v[i] = qv[i * SWEEP_QCAP + qi];
+        const int64_t e = (int64_t)(((uint64_t)qeh[qi] << 32) | (uint64_t)qel[qi]);
+        const int k = (int)qk[qi];
+        const bool free_ = narrow_free_sl<D>(v, w, load_box_T<D>(sboxT, k));
+        if (on && !free_) atomicAnd(&mask[e >> 6], ~(1ull << (e & 63)));
+        qcount -= n;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    unsigned long long smask[SWEEP_WORDS];
+#pragma unroll
+    for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] = 0;
+
+    for (int64_t t = grab(); t < ntasks; t = grab()) {
+        const int64_t g0 = t * RT_TASK;
+        const int cnt = (int)(total - g0 < RT_TASK ? total - g0 : RT_TASK);
+        // lane = round: one coalesced read of the task's descriptors
+        int dx = 0, dn = 0, del = 0, deh = 0;
+        if (lane < cnt) {
+            const sweep_rd r = table[g0 + lane];
+            dx = r.x; dn = (int)r.nf; del = (int)(uint32_t)(uint64_t)r.e0; deh = (int)(uint32_t)((uint64_t)r.e0 >> 32);
+        }
+        auto rd_x = [&](int k) -> int { return __builtin_amdgcn_readlane(dx, k); };
+        auto rd_n = [&](int k) -> int { return __builtin_amdgcn_readlane(dn, k); };
+        auto rd_e = [&](int k) -> int64_t {
+            return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(deh, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(del, k));
+        };
+        // row ids two rounds ahead, row states one round ahead (the dependent chain ids -> states is pipelined over rounds;
+        // beyond the task's last round the requests are null: the pipeline drains at the task boundary, 2 rounds in 64)
+        auto request_rows = [&](int k) -> int32_t {
+            if (k >= cnt) return 0;
+            const int n = rd_n(k) & 0x7fffffff;
+            return lane < n ? rowsrc[rd_e(k) + lane] : 0;
+        };
+        auto request_states = [&](int32_t y, double (&pv)[D]) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) pv[i] = Xrow[(int64_t)y * D + i];
+        };
+        int32_t py0 = request_rows(0);
+        int32_t py1 = request_rows(1);
+        double pv0[D], pv1[D];
+        request_states(py0, pv0);
+        int xcur = -1;
+        double w[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) w[i] = 0.0;
+
+        for (int k = 0; k < cnt; ++k) {
+            while (qcount >= 64) drain(64);                   // the one place queued exact tests run (few live registers here)
+            const int32_t py2 = request_rows(k + 2);
+            request_states(py1, pv1);
+
+            const int x = rd_x(k);
+            const int nf = rd_n(k);
+            const int n = nf & 0x7fffffff;
+            const int64_t e0 = rd_e(k);
+#if SWEEP_ABL == 4
+            if (false) {
+#else
+            if (x != xcur) {                                  // (uniform) new column: state by scalar loads, cull box, survivors
+#endif
+                xcur = x;
+                const sweep_cptr xp = as_const(X) + (int64_t)x * D;
+#pragma unroll
+                for (int i = 0; i < D; ++i) w[i] = xp[i];
+                double ulo[D], uhi[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) { ulo[i] = w[i] - rpad; uhi[i] = w[i] + rpad; }
+#pragma unroll
+                for (int c = 0; c < SWEEP_WORDS; ++c) {
+                    if (c * 64 < M) {
+                        const int kb = c * 64 + lane;
+                        const box_regs<D> bx = load_box_T<D>(sboxT, kb);      // kb < SWEEP_CHUNK: inside the staged array
+                        int out = 0;
+#pragma unroll
+                        for (int i = 0; i < D; ++i) out |= (int)(bx.hi[i] < ulo[i]) | (int)(bx.lo[i] > uhi[i]);
+                        smask[c] = __ballot(kb < M && !out);
+                    }
+                }
+            }
+            const bool active = lane < n;
+            double v[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) v[i] = pv0[i];
+#if SWEEP_ABL == 1
+            bool fr = active;
+#else
+            bool fr = active;
+            if (ss_has) {
+                // the bounds are fetched (scalar cache) where they are used: resident in SGPRs across the box loop they would
+                // take 4 D of the ~100 there are
+                const double* sq = ss_bounds; asm volatile("" : "+s"(sq));
+                const sweep_cptr sp = as_const(sq);
+                int ok = 1;
+#pragma unroll
+                for (int i = 0; i < D; ++i) ok &= (int)(sp[i] <= v[i]) & (int)(v[i] <= sp[MPFMT_MAX_DIM + i]);
+                fr = active && ok != 0;
+            }
+#endif
+            double l[D], h[D];
+            if constexpr (D <= 6) {
+                // map(min, v, w), map(max, v, w): only compared below, where a -0 / +0 difference to the reference's ternaries does not show
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    asm("v_min_f64 %0, %1, %2" : "=v"(l[i]) : "s"(w[i]), "v"(v[i]));
+                    asm("v_max_f64 %0, %1, %2" : "=v"(h[i]) : "s"(w[i]), "v"(v[i]));
+                }
+            } else {
+                seg_bbox<D>(v, w, l, h);
+            }
+            const int64_t e = e0 + lane;
+            // boxes whose broad phase this lane failed: the last four as bytes of pk (box ids < 256), their number in cnt.  For
+            // d <= 6 the whole test of one box is 2 d v_cmpx that narrow EXEC plus two lane-masked updates -- no scalar bookkeeping,
+            // no branch in the loop but its own; lanes that are out (not active / not in the state space) fail the first comparison
+            unsigned pk = 0, cnt = 0;
+            if constexpr (D <= 6) l[0] = fr ? l[0] : (double)INFINITY;
+#pragma unroll
+            for (int c = 0; c < SWEEP_WORDS; ++c) {
+                unsigned long long m = smask[c];
+#if SWEEP_ABL == 3 || SWEEP_ABL == 4
+                m = 0;
+#endif
+                while (m) {
+                    const int kb = c * 64 + (__ffsll((long long)m) - 1);
+                    m &= m - 1;
+                    // wave-uniform kb: the box comes through the scalar cache into SGPRs (the comparisons take it as their scalar
+                    // operand); an LDS broadcast read would return 64 copies through the LDS data path
+                    box_regs<D> bx;
+                    {
+                        const sweep_cptr bp = as_const(boxes) + (int64_t)kb * 2 * D;
+#pragma unroll
+                        for (int i = 0; i < D; ++i) { bx.lo[i] = bp[i]; bx.hi[i] = bp[D + i]; }
+                    }
+                    if constexpr (D <= 6) {
+                        sweep_cmpx<D>::note(bx.lo, bx.hi, l, h, pk, cnt, kb);
+                    } else {
+                        if (fr & !broadphase_free_sl<D>(l, h, bx)) { pk = (pk << 8) | (unsigned)kb; cnt += 1; }
+                    }
+                }
+            }
+#if SWEEP_ABL == 2
+            cnt = 0;
+#endif
+            if (__ballot(cnt > 4)) {
+                // (uniform, rare) lanes with more than four pending boxes: every surviving box tested exactly, in place
+                const bool o = cnt > 4;
+#pragma unroll
+                for (int c = 0; c < SWEEP_WORDS; ++c) {
+                    unsigned long long m = smask[c];
+                    while (m) {
+                        const int kb = c * 64 + (__ffsll((long long)m) - 1);
+                        m &= m - 1;
+                        const box_regs<D> bx = load_box_T<D>(sboxT, kb);
+                        if (o && fr && !broadphase_free_sl<D>(l, h, bx)) fr = narrow_free_sl<D>(v, w, bx);
+                    }
+                }
+                if (o) cnt = 0;
+            }
+            // queue the pending exact tests (the entry counts as free until a pass says otherwise); room for 64 before every push
+#pragma unroll 1
+            for (int sl = 0; sl < 4; ++sl) {
+                if (!__ballot(cnt > (unsigned)sl)) break;
+                while (qcount > SWEEP_QCAP - 64) drain(min(qcount, 64));
+                push(cnt > (unsigned)sl, v, e, x, (int)((pk >> (8 * sl)) & 255u));
+            }
+            const unsigned long long bits = __ballot(fr);
+            const int sh = (int)(e0 & 63);
+            const int64_t wd = e0 >> 6;
+            const unsigned long long clr = ~bits & __ballot(active);
+            if (lane == 0 && clr) {
+                atomicAnd(&mask[wd], ~(clr << sh));
+                if (sh && (clr >> (64 - sh))) atomicAnd(&mask[wd + 1], ~(clr >> (64 - sh)));
+            }
+            py1 = py2;
+#pragma unroll
+            for (int i = 0; i < D; ++i) pv0[i] = pv1[i];
+        }
+    }
+    while (qcount > 0) drain(min(qcount, 64));
 }
 
 // ---- launchers -------------------------------------------------------------------------------------
@@ -750,6 +1097,58 @@ static int32_t launch_graph_sweep_d(mpfmt_ctx* ctx, size_t lds, double rpad, int
     return MPFMT_OK;
 }
 
+// round table (count -> scan -> fill) + k_graph_sweep_rt; entries = nnz or, on a speculative step, the trusted capacity
+template <int D>
+static int32_t launch_sweep_rt_d(mpfmt_ctx* ctx, size_t lds, double rpad, const int32_t* spec_fail, bool sorted_rows)
+{
+    constexpr auto kk = k_graph_sweep_rt<D>;
+    if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kk, SWEEP_GT(D), lds));
+    const unsigned nb = (unsigned)(std::max(per_cu, 1) * ctx->num_cus);          // one resident set; the task count lives on the device
+    hipLaunchKernelGGL(kk, dim3(nb), dim3(SWEEP_GT(D)), lds, ctx->stream, ctx->Xo, ctx->colptr, ctx->N,
+                       sorted_rows ? ctx->Xs : ctx->Xo, sorted_rows ? ctx->rowpos : ctx->rowval, rpad, ctx->boxes, ctx->M,
+                       (int)ctx->ss.has, ctx->rt_ss, (unsigned long long*)ctx->graph_free, (const sweep_rd*)ctx->rt_table, ctx->rt_total, ctx->sweep_ctr, spec_fail,
+                       sorted_rows ? 1 : 0);
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
+static int32_t launch_graph_sweep_rt(mpfmt_ctx* ctx, double rpad, const int32_t* sweep_perm, int64_t sp_begin, int64_t sp_end,
+                                     const int32_t* spec_fail, bool sorted_rows, int64_t entries)
+{
+    int32_t rc;
+    const int d = ctx->d;
+    const int64_t ncol = sp_end - sp_begin;
+    const int64_t cap = entries / 64 + ncol + 1;                          // every column adds at most one partial round
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_cnt, sizeof(int64_t) * (size_t)(ncol + 1)))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_off, sizeof(int64_t) * (size_t)(ncol + 1)))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_table, sizeof(sweep_rd) * (size_t)cap))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_total, sizeof(int64_t)))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_ss, sizeof(double) * 2 * MPFMT_MAX_DIM))) return rc;
+    if (!ctx->rt_ss_valid || memcmp(&ctx->rt_ss_host, &ctx->ss, sizeof(mpfmt_ss)) != 0) {
+        double b[2 * MPFMT_MAX_DIM];
+        for (int i = 0; i < MPFMT_MAX_DIM; ++i) { b[i] = ctx->ss.lo[i]; b[MPFMT_MAX_DIM + i] = ctx->ss.hi[i]; }
+        HIPCHK(ctx, hipMemcpyAsync(ctx->rt_ss, b, sizeof(b), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                 // b is a stack buffer
+        ctx->rt_ss_host = ctx->ss; ctx->rt_ss_valid = true;
+    }
+    size_t tmp_bytes = 0;
+    HIPCHK(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, ctx->rt_cnt, ctx->rt_off, (int64_t)0, (size_t)(ncol + 1), rocprim::plus<int64_t>(), ctx->stream));
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_tmp, tmp_bytes))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->rt_total, 0, sizeof(int64_t), ctx->stream));
+    const unsigned nbk = (unsigned)((ncol + 1 + 255) / 256);
+    hipLaunchKernelGGL(k_round_count, dim3(nbk), dim3(256), 0, ctx->stream, ctx->colptr, sweep_perm, sp_begin, sp_end, ctx->rt_cnt, spec_fail);
+    HIPCHK(ctx, rocprim::exclusive_scan(ctx->rt_tmp, tmp_bytes, ctx->rt_cnt, ctx->rt_off, (int64_t)0, (size_t)(ncol + 1), rocprim::plus<int64_t>(), ctx->stream));
+    hipLaunchKernelGGL(k_round_fill, dim3(nbk), dim3(256), 0, ctx->stream, ctx->colptr, sweep_perm, sp_begin, sp_end, ctx->rt_off,
+                       (sweep_rd*)ctx->rt_table, cap, ctx->rt_total, spec_fail);
+    HIPCHK(ctx, hipGetLastError());
+    const int waves = SWEEP_GT(d) / 64;
+    const size_t lds = (size_t)SWEEP_CHUNK * 2 * d * sizeof(double) + (size_t)waves * (d + 2) * SWEEP_QCAP * sizeof(double);
+    DISPATCH_D(d, rc = launch_sweep_rt_d<(DD <= 8 ? DD : 8)>(ctx, lds, rpad, spec_fail, sorted_rows));
+    return rc;
+}
+
 // spec_fail / mask_entries: the speculative step (mpfmt_graph_step) sweeps before the host knows nnz -- the mask is then
 // sized and preset for mask_entries (the trusted capacity) and the kernel bails out on the device flag
 int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail, int64_t mask_entries)
@@ -793,7 +1192,10 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail, int64
         const int32_t* sweep_perm = by_perm ? ctx->perm : nullptr;
         const int64_t sp_begin = by_perm ? ctx->tile_begin * 64 : 0;
         const int64_t sp_end = by_perm ? std::min<int64_t>(ctx->tile_end * 64, ctx->ntiles * 64) : ctx->N;
-        DISPATCH_D(d, rc = launch_graph_sweep_d<DD>(ctx, lds, rpad, chunk, sweep_perm, sp_begin, sp_end, spec_fail, sorted_rows));
+        if (ctx->sweep_rounds && d <= 8 && ctx->M <= SWEEP_CHUNK)
+            rc = launch_graph_sweep_rt(ctx, rpad, sweep_perm, sp_begin, sp_end, spec_fail, sorted_rows, std::max<int64_t>(ctx->nnz, mask_entries));
+        else
+            DISPATCH_D(d, rc = launch_graph_sweep_d<DD>(ctx, lds, rpad, chunk, sweep_perm, sp_begin, sp_end, spec_fail, sorted_rows));
         if (rc) return rc;
         HIPCHK(ctx, hipGetLastError());
     }

@@ -102,6 +102,15 @@ struct mpfmt_ctx {
     int32_t mf_ablate = 0;               // timing experiments only
     int32_t num_cus = 256;               // compute units of the device (persistent-grid sizing)
     int* sweep_ctr = nullptr;            // graph sweep: one task counter per obstacle chunk
+    int32_t sweep_rounds = 1;            // option: round-table sweep (k_graph_sweep_rt) where it applies (d <= 8, M <= 256)
+    int64_t* rt_cnt = nullptr;           // [columns visited + 1] rounds per column, then (scan) first round of each column
+    int64_t* rt_off = nullptr;
+    void* rt_tmp = nullptr;              // scan temporary
+    void* rt_table = nullptr;            // [rounds] (column, entries | first << 31, first entry) in visiting order
+    int64_t* rt_total = nullptr;         // device: number of rounds
+    double* rt_ss = nullptr;             // device copy of the state-space bounds (lo[MAX_DIM], hi[MAX_DIM]) for scalar loads
+    mpfmt_ss rt_ss_host;                 // what rt_ss holds
+    bool rt_ss_valid = false;
     int64_t mf_target_items = 40000;     // work items (tile x slice) the MFMA path aims for (tools/run_shard_sweep_items.py: flat from 40k up at 1 shard, best at 2 and 4)
     float mf_negT = 0.f;
     void* lists = nullptr;               // [shard tiles][list_cap] candidate chunk ids per tile
