@@ -144,8 +144,9 @@ struct mpfmt_ctx {
     double* nzval = nullptr;
     int32_t* rowpos = nullptr;           // [nnz] cell-sorted position of each entry's row (single-pass build): the sweep gathers rows from Xs
     bool rowpos_valid = false;
-    int32_t sweep_sorted = 0;            // option: gather the sweep's rows from Xs in cell-sorted order with per-XCD task ranges (6x less HBM traffic,
-                                         // 74 % L2 hits, same time: the sweep is issue-bound -- profiles/r02_pmc_sweep_*.txt); off by default
+    int32_t sweep_sorted = 1;            // option: gather the sweep's rows from Xs in cell-sorted order with per-XCD task ranges (6x less HBM traffic,
+                                         // 74 % L2 hits): with the round-table sweep, whose instruction count no longer hides under the
+                                         // caller-order gather (2.29 ms floor), this is the faster mode (2.2 vs 2.65 ms); on by default
     uint64_t* graph_free = nullptr;      // [ceil(nnz/64)]
     bool graph_swept = false;
     unsigned long long* d_pairs = nullptr;   // device counter: candidate pairs tested

@@ -14,11 +14,12 @@ L = mp._lib
 
 # ---- (a) the timed path against the oracle ---------------------------------------------------------------------------
 
-@pytest.mark.parametrize("world,sorted_rows", [(1, 0), (3, 0), (1, 1), (3, 1)])
-def test_graph_step_device_against_oracle(orc, world, sorted_rows):
+@pytest.mark.parametrize("world,sorted_rows,rounds", [(1, 0, 1), (3, 0, 1), (1, 1, 1), (3, 1, 1), (1, 0, 0), (3, 1, 0)])
+def test_graph_step_device_against_oracle(orc, world, sorted_rows, rounds):
     """Resident CSC + free mask of mpfmt_graph_step_device vs the oracle's graph and edge predicate: the first (careful)
     call, two speculative repeats, new samples under the same (N, r), a capacity-busting cluster (device flag voids the
-    kernels, host redoes the step) and the way back (capacities far too large).  Both row-gather modes of the sweep."""
+    kernels, host redoes the step) and the way back (capacities far too large).  Both row-gather modes of the sweep, both
+    sweep kernels (round table / task headers)."""
     rng = np.random.default_rng(777)
     N, d, M = 12000, 4, 30
     X, lohi = random_world(rng, N, d, M, 0.03, 0.1)
@@ -35,6 +36,7 @@ def test_graph_step_device_against_oracle(orc, world, sorted_rows):
         with mp.Context(0) as c:
             c.set_shard(g, world); c.set_option("rebuild_index", 1)
             c.set_option("sweep_sorted", sorted_rows)        # rows gathered from the cell-sorted copy, per-XCD column ranges
+            c.set_option("sweep_rounds", rounds)             # k_graph_sweep_rt (round table) or k_graph_sweep (task headers)
             c.upload_boxes(lohi, lo, hi)
             for it, (Xi, (oc, orow, oval, omask)) in enumerate(zip(Xs, refs)):
                 c.upload_samples(Xi)
