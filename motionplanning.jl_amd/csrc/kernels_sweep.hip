@@ -547,16 +547,28 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
 // in caller order (the random 48-byte row gather at its request-rate ceiling) and 1.90 ms with rows gathered from the
 // cell-sorted copy (L2 hits): the round sequencing itself -- two resident task headers read out by v_readlane, round
 // descriptors advanced in scalar registers across column and task boundaries (106 SGPRs, 65 of them spilled to VGPR
-// lanes) -- was the bound, not the collision arithmetic.  Here the sequence is data: a table with one entry per round
-// (column, first entry, number of entries, first-round-of-column flag) in visiting order, written by two trivial kernels
-// around a scan.  A wavefront loads 64 consecutive entries with one coalesced read (lane = round), reads round k's four
-// words out with v_readlane, fetches the column state with scalar loads (wave-uniform address), and never looks at colptr.
+// lanes) -- was the bound, not the collision arithmetic (836 instructions per round, 450 of them VALU).  Here
+//   * the sequence is data: a table with one entry per 16-lane quarter of a round (column, entries, first entry), written
+//     in visiting order by two trivial kernels around a scan; a wavefront loads 64 consecutive entries = 16 rounds with one
+//     coalesced read (lane = quarter) and a lane fetches its quarter's entry by lane exchange.  Columns are packed end to
+//     end (rounded up to quarters), so rounds are full whatever the degree is;
+//   * what is wave-uniform goes through the scalar cache into SGPRs and is used as the scalar operand of the vector
+//     comparisons: the obstacle box of a broad-phase iteration, the state-space bounds, the column state for the cull;
+//   * the broad phase of one box is 2 d v_cmpx_*_f64 in a row that narrow EXEC, then two lane-masked updates of a packed
+//     per-lane list of pending boxes: 14 VALU + 9 SALU per box where the compare / s_and chain with mask bookkeeping took
+//     22 + 34 and an LDS broadcast read of the box;
+//   * exact tests never run in place on the fast path (a lane or two used to occupy the whole wave for ~270 VALU).
+// 420 instructions per round (270 VALU) in rounds of one column; with packed rounds the same total in 20 % fewer rounds.
 // a global pointer read through the constant address space: a wave-uniform address then always takes the scalar cache
 // (s_load into SGPRs, usable directly as the scalar operand of a vector compare) -- no alias analysis involved
 typedef const __attribute__((address_space(4))) double* sweep_cptr;
 __device__ __forceinline__ sweep_cptr as_const(const double* p) { return (sweep_cptr)(uintptr_t)p; }
 
-struct sweep_rd { int32_t x; uint32_t nf; int64_t e0; };          // nf = entries (1..64) | first round of the column << 31
+// One table entry per QUARTER (16 lanes) of a round: column, number of its entries in this quarter (0..16), their first entry.
+// Columns are laid end to end in visiting order, each rounded up to whole quarters, so a round of 64 lanes holds up to four
+// columns (or pieces of them) and no lane is idle but the rounding (a column of 105 entries fills 7 quarters = 1.75 rounds
+// where whole rounds per column took 2.19; a column of 14 fills a quarter instead of a round).
+struct sweep_rd { int32_t x; uint32_t nf; int64_t e0; };          // nf = entries in the quarter (0..16)
 
 __global__ void k_round_count(const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm, int64_t sp_begin, int64_t sp_end,
                               int64_t* __restrict__ cnt, const int32_t* __restrict__ spec_fail)
@@ -568,7 +580,7 @@ __global__ void k_round_count(const int64_t* __restrict__ colptr, const int32_t*
     int64_t c = 0;
     if (i < n) {
         const int64_t x = perm ? (int64_t)perm[sp_begin + i] : sp_begin + i;       // pad positions of the sorted order hold -1
-        if (x >= 0) c = (colptr[x + 1] - colptr[x] + 63) >> 6;
+        if (x >= 0) c = (colptr[x + 1] - colptr[x] + 15) >> 4;
     }
     cnt[i] = c;                                                        // cnt[n] = 0: the scan's last element is the total
 }
@@ -581,15 +593,22 @@ __global__ void k_round_fill(const int64_t* __restrict__ colptr, const int32_t* 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = sp_end - sp_begin;
     if (i > n) return;
-    if (i == n) { *total = off[n] < cap ? off[n] : cap; return; }
+    if (i == n) {
+        // the last round is padded with empty quarters; total = quarters, a multiple of 4
+        int64_t q = off[n] < cap ? off[n] : cap;
+        sweep_rd r; r.x = 0; r.nf = 0; r.e0 = 0;
+        while ((q & 3) && q < cap) table[q++] = r;
+        *total = q & ~(int64_t)3;
+        return;
+    }
     const int64_t x = perm ? (int64_t)perm[sp_begin + i] : sp_begin + i;
     if (x < 0) return;
     const int64_t b = colptr[x], e = colptr[x + 1];
     int64_t o = off[i];
-    for (int64_t e0 = b; e0 < e && o < cap; e0 += 64, ++o) {
+    for (int64_t e0 = b; e0 < e && o < cap; e0 += 16, ++o) {
         sweep_rd r;
         r.x = (int32_t)x;
-        r.nf = (uint32_t)(e - e0 < 64 ? e - e0 : 64) | (e0 == b ? 0x80000000u : 0u);
+        r.nf = (uint32_t)(e - e0 < 16 ? e - e0 : 16);
         r.e0 = e0;
         table[o] = r;
     }
@@ -684,30 +703,37 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
         __builtin_amdgcn_wave_barrier();
     };
 
-    unsigned long long smask[SWEEP_WORDS];
+    // survivors of the column cull: of the column culled last (a column usually continues into the next round) and of the
+    // round (union over its columns)
+    unsigned long long smask[SWEEP_WORDS], slast[SWEEP_WORDS];
 #pragma unroll
-    for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] = 0;
+    for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] = slast[c] = 0;
+    int xlast = -1;
 
     for (int64_t t = grab(); t < ntasks; t = grab()) {
         const int64_t g0 = t * RT_TASK;
-        const int cnt = (int)(total - g0 < RT_TASK ? total - g0 : RT_TASK);
-        // lane = round: one coalesced read of the task's descriptors
-        int dx = 0, dn = 0, del = 0, deh = 0;
-        if (lane < cnt) {
+        const int cnt = (int)(total - g0 < RT_TASK ? total - g0 : RT_TASK) >> 2;      // rounds of this task (total is a multiple of 4)
+        // lane = quarter: one coalesced read of the task's 64 quarter descriptors = 16 rounds
+        int dx = 0, del = 0, deh = 0;
+        if (lane < 4 * cnt) {
             const sweep_rd r = table[g0 + lane];
-            dx = r.x; dn = (int)r.nf; del = (int)(uint32_t)(uint64_t)r.e0; deh = (int)(uint32_t)((uint64_t)r.e0 >> 32);
+            // entries < 2^40: the count rides in bits 8..12 of the entry's high word (one lane exchange less per decode)
+            dx = r.x; del = (int)(uint32_t)(uint64_t)r.e0; deh = (int)((uint32_t)((uint64_t)r.e0 >> 32) | (r.nf << 8));
         }
-        auto rd_x = [&](int k) -> int { return __builtin_amdgcn_readlane(dx, k); };
-        auto rd_n = [&](int k) -> int { return __builtin_amdgcn_readlane(dn, k); };
-        auto rd_e = [&](int k) -> int64_t {
-            return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(deh, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(del, k));
+        // round k, this lane: the descriptor of its quarter (lane exchange), its entry, whether it has one
+        auto lane_entry = [&](int k, int& n_, int64_t& e_) {
+            const int src = 4 * k + (lane >> 4);
+            const uint32_t hn = (uint32_t)__shfl(deh, src);
+            n_ = (int)(hn >> 8);
+            e_ = (int64_t)(((uint64_t)(hn & 0xffu) << 32) | (uint32_t)__shfl(del, src)) + (lane & 15);
         };
         // row ids two rounds ahead, row states one round ahead (the dependent chain ids -> states is pipelined over rounds;
-        // beyond the task's last round the requests are null: the pipeline drains at the task boundary, 2 rounds in 64)
+        // beyond the task's last round the requests are null: the pipeline drains at the task boundary, 2 rounds in 16)
         auto request_rows = [&](int k) -> int32_t {
             if (k >= cnt) return 0;
-            const int n = rd_n(k) & 0x7fffffff;
-            return lane < n ? rowsrc[rd_e(k) + lane] : 0;
+            int n_; int64_t e_;
+            lane_entry(k, n_, e_);
+            return (lane & 15) < n_ ? rowsrc[e_] : 0;
         };
         auto request_states = [&](int32_t y, double (&pv)[D]) {
 #pragma unroll
@@ -717,45 +743,52 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
         int32_t py1 = request_rows(1);
         double pv0[D], pv1[D];
         request_states(py0, pv0);
-        int xcur = -1;
-        double w[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) w[i] = 0.0;
 
         for (int k = 0; k < cnt; ++k) {
             while (qcount >= 64) drain(64);                   // the one place queued exact tests run (few live registers here)
             const int32_t py2 = request_rows(k + 2);
             request_states(py1, pv1);
 
-            const int x = rd_x(k);
-            const int nf = rd_n(k);
-            const int n = nf & 0x7fffffff;
-            const int64_t e0 = rd_e(k);
-#if SWEEP_ABL == 4
-            if (false) {
-#else
-            if (x != xcur) {                                  // (uniform) new column: state by scalar loads, cull box, survivors
-#endif
-                xcur = x;
-                const sweep_cptr xp = as_const(X) + (int64_t)x * D;
+            int n; int64_t e;
+            lane_entry(k, n, e);
+            const int x = __shfl(dx, 4 * k + (lane >> 4));
+            const bool active = (lane & 15) < n;
+            // this lane's column state: the lanes of a quarter read the same 8 D bytes (one request)
+            double w[D];
 #pragma unroll
-                for (int i = 0; i < D; ++i) w[i] = xp[i];
-                double ulo[D], uhi[D];
+            for (int i = 0; i < D; ++i) w[i] = X[(int64_t)x * D + i];
+            // (uniform) the round's columns: cull box and survivors of each column not seen in the quarter before
+#if SWEEP_ABL != 4
 #pragma unroll
-                for (int i = 0; i < D; ++i) { ulo[i] = w[i] - rpad; uhi[i] = w[i] + rpad; }
+            for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] = 0;
+            int xprev = -1;
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                const int xq = __builtin_amdgcn_readlane(dx, 4 * k + q);
+                if (((uint32_t)__builtin_amdgcn_readlane(deh, 4 * k + q) >> 8) == 0 || xq == xprev) continue;
+                xprev = xq;
+                if (xq != xlast) {
+                    xlast = xq;
+                    const sweep_cptr xp = as_const(X) + (int64_t)xq * D;
+                    double ulo[D], uhi[D];
 #pragma unroll
-                for (int c = 0; c < SWEEP_WORDS; ++c) {
-                    if (c * 64 < M) {
-                        const int kb = c * 64 + lane;
-                        const box_regs<D> bx = load_box_T<D>(sboxT, kb);      // kb < SWEEP_CHUNK: inside the staged array
-                        int out = 0;
+                    for (int i = 0; i < D; ++i) { const double wi = xp[i]; ulo[i] = wi - rpad; uhi[i] = wi + rpad; }
 #pragma unroll
-                        for (int i = 0; i < D; ++i) out |= (int)(bx.hi[i] < ulo[i]) | (int)(bx.lo[i] > uhi[i]);
-                        smask[c] = __ballot(kb < M && !out);
+                    for (int c = 0; c < SWEEP_WORDS; ++c) {
+                        if (c * 64 < M) {
+                            const int kb = c * 64 + lane;
+                            const box_regs<D> bx = load_box_T<D>(sboxT, kb);      // kb < SWEEP_CHUNK: inside the staged array
+                            int out = 0;
+#pragma unroll
+                            for (int i = 0; i < D; ++i) out |= (int)(bx.hi[i] < ulo[i]) | (int)(bx.lo[i] > uhi[i]);
+                            slast[c] = __ballot(kb < M && !out);
+                        }
                     }
                 }
+#pragma unroll
+                for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] |= slast[c];
             }
-            const bool active = lane < n;
+#endif
             double v[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) v[i] = pv0[i];
@@ -775,21 +808,16 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
             }
 #endif
             double l[D], h[D];
-            if constexpr (D <= 6) {
-                // map(min, v, w), map(max, v, w): only compared below, where a -0 / +0 difference to the reference's ternaries does not show
+            // map(min, v, w), map(max, v, w): only compared below, where a -0 / +0 difference to the reference's ternaries does not show
 #pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    asm("v_min_f64 %0, %1, %2" : "=v"(l[i]) : "s"(w[i]), "v"(v[i]));
-                    asm("v_max_f64 %0, %1, %2" : "=v"(h[i]) : "s"(w[i]), "v"(v[i]));
-                }
-            } else {
-                seg_bbox<D>(v, w, l, h);
+            for (int i = 0; i < D; ++i) {
+                asm("v_min_f64 %0, %1, %2" : "=v"(l[i]) : "v"(w[i]), "v"(v[i]));
+                asm("v_max_f64 %0, %1, %2" : "=v"(h[i]) : "v"(w[i]), "v"(v[i]));
             }
-            const int64_t e = e0 + lane;
             // boxes whose broad phase this lane failed: the last four as bytes of pk (box ids < 256), their number in cnt.  For
             // d <= 6 the whole test of one box is 2 d v_cmpx that narrow EXEC plus two lane-masked updates -- no scalar bookkeeping,
             // no branch in the loop but its own; lanes that are out (not active / not in the state space) fail the first comparison
-            unsigned pk = 0, cnt = 0;
+            unsigned pk = 0, pc = 0;
             if constexpr (D <= 6) l[0] = fr ? l[0] : (double)INFINITY;
 #pragma unroll
             for (int c = 0; c < SWEEP_WORDS; ++c) {
@@ -809,18 +837,18 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
                         for (int i = 0; i < D; ++i) { bx.lo[i] = bp[i]; bx.hi[i] = bp[D + i]; }
                     }
                     if constexpr (D <= 6) {
-                        sweep_cmpx<D>::note(bx.lo, bx.hi, l, h, pk, cnt, kb);
+                        sweep_cmpx<D>::note(bx.lo, bx.hi, l, h, pk, pc, kb);
                     } else {
-                        if (fr & !broadphase_free_sl<D>(l, h, bx)) { pk = (pk << 8) | (unsigned)kb; cnt += 1; }
+                        if (fr & !broadphase_free_sl<D>(l, h, bx)) { pk = (pk << 8) | (unsigned)kb; pc += 1; }
                     }
                 }
             }
 #if SWEEP_ABL == 2
-            cnt = 0;
+            pc = 0;
 #endif
-            if (__ballot(cnt > 4)) {
+            if (__ballot(pc > 4)) {
                 // (uniform, rare) lanes with more than four pending boxes: every surviving box tested exactly, in place
-                const bool o = cnt > 4;
+                const bool o = pc > 4;
 #pragma unroll
                 for (int c = 0; c < SWEEP_WORDS; ++c) {
                     unsigned long long m = smask[c];
@@ -831,24 +859,31 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
                         if (o && fr && !broadphase_free_sl<D>(l, h, bx)) fr = narrow_free_sl<D>(v, w, bx);
                     }
                 }
-                if (o) cnt = 0;
+                if (o) pc = 0;
             }
             // queue the pending exact tests (the entry counts as free until a pass says otherwise); room for 64 before every push
 #pragma unroll 1
             for (int sl = 0; sl < 4; ++sl) {
-                if (!__ballot(cnt > (unsigned)sl)) break;
+                if (!__ballot(pc > (unsigned)sl)) break;
                 while (qcount > SWEEP_QCAP - 64) drain(min(qcount, 64));
-                push(cnt > (unsigned)sl, v, e, x, (int)((pk >> (8 * sl)) & 255u));
+                push(pc > (unsigned)sl, v, e, x, (int)((pk >> (8 * sl)) & 255u));
             }
-            const unsigned long long bits = __ballot(fr);
-            const int sh = (int)(e0 & 63);
-            const int64_t wd = e0 >> 6;
-            const unsigned long long clr = ~bits & __ballot(active);
-            if (lane == 0 && clr) {
-                atomicAnd(&mask[wd], ~(clr << sh));
-                if (sh && (clr >> (64 - sh))) atomicAnd(&mask[wd + 1], ~(clr >> (64 - sh)));
+            // the entries of a quarter are consecutive: its first lane clears the quarter's blocked bits in the word(s) they fall in
+            const unsigned long long bits = __ballot(fr), act = __ballot(active);
+#if SWEEP_ABL == 5
+            if (false) {
+#else
+            if ((lane & 15) == 0) {
+#endif
+                const unsigned clr = (unsigned)((~bits & act) >> (lane & 48)) & 0xffffu;
+                if (clr) {
+                    const int sh = (int)(e & 63);
+                    const unsigned long long c64 = (unsigned long long)clr << sh;
+                    atomicAnd(&mask[e >> 6], ~c64);
+                    if (sh > 48 && (clr >> (64 - sh))) atomicAnd(&mask[(e >> 6) + 1], ~(unsigned long long)(clr >> (64 - sh)));
+                }
             }
-            py1 = py2;
+            py0 = py1; py1 = py2;
 #pragma unroll
             for (int i = 0; i < D; ++i) pv0[i] = pv1[i];
         }
@@ -1120,7 +1155,7 @@ static int32_t launch_graph_sweep_rt(mpfmt_ctx* ctx, double rpad, const int32_t*
     int32_t rc;
     const int d = ctx->d;
     const int64_t ncol = sp_end - sp_begin;
-    const int64_t cap = entries / 64 + ncol + 1;                          // every column adds at most one partial round
+    const int64_t cap = entries / 16 + ncol + 8;                          // quarters: every column adds at most one partial quarter (+ padding of the last round)
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_cnt, sizeof(int64_t) * (size_t)(ncol + 1)))) return rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_off, sizeof(int64_t) * (size_t)(ncol + 1)))) return rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_table, sizeof(sweep_rd) * (size_t)cap))) return rc;
