@@ -35,6 +35,7 @@ FP64_PEAK_TFLOPS = 78.6        # fp64 vector == fp64 matrix (MFMA) dense peak, F
 FP64_VALU_LANE_OPS = 39.3e12   # unfused fp64 lane-ops/s
 FP16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense BF16/FP16 MFMA ~2.5 PFLOP/s
 GATHER_CEILING_ROWS_PER_S = 4.51e10      # measured: 1e8 random 48-byte rows of a 48 MB array in 2.219 ms (profiles/r01_ubench_fetch_calib.txt)
+GATHER_CEILING_L2_ROWS_PER_S = 1.9e11    # the same gather when the rows it touches are L2-resident (profiles/r02_ubench_gather_variants.txt)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")      # written by tools/pmc_traffic.py from a rocprofv3 --pmc run
 
 
@@ -347,21 +348,25 @@ def main():
     # Lane-ops per edge come from the PMC run (SQ_INSTS_VALU x 64 lanes / edges) when the summary matches this build.
     valu_per_edge = prof.get("sweep", {}).get("valu_lane_ops_per_edge")
     valu_frac = (valu_per_edge * nnz / (sweep_ms * 1e-3) / FP64_VALU_LANE_OPS) if (valu_per_edge and sweep_ms > 0) else None
+    sorted_rows = os.environ.get("MPFMT_OPT_SWEEP_SORTED", "1") != "0"          # library default: rows gathered from the cell-sorted copy
+    ceiling = GATHER_CEILING_L2_ROWS_PER_S if sorted_rows else GATHER_CEILING_ROWS_PER_S
     roof_sweep = {
-            "kernel": "k_graph_sweep", "bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": "k_graph_sweep_rt (+ k_round_count / scan / k_round_fill, inside the same interval)", "bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": sweep_gbs / HBM_PEAK_GBS,
             "traffic": prof.get("sweep", {}).get("bytes"),
             "traffic_gather_calibrated": prof.get("sweep", {}).get("bytes_gather_calibrated"),
             "l2_hit_rate": prof.get("sweep", {}).get("l2_hit_rate"),
             "traffic_source": prof.get("source") if prof.get("sweep") else None,
             "valu_frac": valu_frac,
-            "gather_ceiling_edges_per_s": GATHER_CEILING_ROWS_PER_S if d == 6 else None,
-            "frac_of_gather_ceiling": (nnz / (sweep_ms * 1e-3) / GATHER_CEILING_ROWS_PER_S) if (d == 6 and sweep_ms > 0) else None,
+            "row_gather": "cell-sorted copy Xs by position (L2-friendly)" if sorted_rows else "caller order",
+            "gather_ceiling_edges_per_s": ceiling if d == 6 else None,
+            "frac_of_gather_ceiling": (nnz / (sweep_ms * 1e-3) / ceiling) if (d == 6 and sweep_ms > 0) else None,
             "avg_launch_ms": sweep_ms,
             "note": "algorithmic bytes = (2*d*8 + 8 + 1/8) per edge = %.3f B; valu_frac = measured vector lane-ops per edge x edges/s over the "
-                    "39.3e12 unfused fp64 lane-op/s of SURVEY 8d; every edge needs one random 48-byte row-state gather, and a "
-                    "kernel that does nothing but such gathers reaches 4.5e10 rows/s on this GPU (tools/ubench/fetch_calib.hip, "
-                    "profiles/r01_ubench_fetch_calib.txt)" % (2 * d * 8 + 8 + 0.125),
+                    "39.3e12 unfused fp64 lane-op/s of SURVEY 8d; every edge needs one 48-byte row-state gather: a kernel that does "
+                    "nothing but such gathers reaches 4.5e10 rows/s from a caller-order array (L2 misses) and 1.9e11 when the rows are "
+                    "L2-resident (tools/ubench/, profiles/r01_ubench_fetch_calib.txt, profiles/r02_ubench_gather_variants.txt); "
+                    "stage ablation in DESIGN.md 3.3" % (2 * d * 8 + 8 + 0.125),
         }
     if sweep_ms >= pair_ms:
         out["roofline"], out["roofline_rdisc"] = roof_sweep, roof_rdisc
