@@ -424,7 +424,10 @@ int32_t mpfmt_allgather_free_mask_finish(mpfmt_ctx* ctx, void** gathered, int64_
 int32_t mpfmt_timing_reset(mpfmt_ctx* ctx);
 int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
 /* Tuning / test knobs.  "rdisc_path": 0 = auto, 1 = exact fp64 VALU pair kernel, 2 = fp16 MFMA distance-matrix
- * filter + exact fp64 refine (both give bit-identical graphs).  "timing": 0/1 event timing off/on. */
+ * filter + exact fp64 refine (both give bit-identical graphs).  "timing": 0/1 event timing off/on.
+ * "sweep_sorted" (default 1): the graph sweep gathers row states from the library's cell-sorted copy and visits the columns
+ * in cell order, 0 = from the caller-order array.  "sweep_rounds" (default 1): round-table sweep kernel where it applies
+ * (d <= 8, at most 256 boxes), 0 = the task-header kernel everywhere.  Same mask bits in every combination. */
 int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value);
 /* Counters of the last graph build: "rdisc_path_used", "pairs_tested", "survivors" (pairs that passed the
  * MFMA filter), "nnz", "slices", "cells". */
