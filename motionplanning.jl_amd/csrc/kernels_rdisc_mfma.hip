@@ -698,6 +698,15 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restri
             return (((long long)((sp >> 6) - tile_begin)) * S * 64 + (long long)(sp & 63)) * capc;
         };
         auto src = [&](int c, long long col0, int e) -> long long {
+            if (S <= 4) {
+                // (uniform) few slices -- the usual case, 3 at one shard: the column's prefix sums are wave-uniform LDS reads,
+                // the slice is a count of comparisons (no per-lane search through LDS)
+                const int p1 = s_pre[c][1], p2 = s_pre[c][S > 2 ? 2 : S], p3 = s_pre[c][S > 3 ? 3 : S];
+                const int g1 = (S > 1) & (e >= p1), g2 = (S > 2) & (e >= p2), g3 = (S > 3) & (e >= p3);
+                const int sl = g1 + g2 + g3;
+                const int first = g3 ? p3 : g2 ? p2 : g1 ? p1 : 0;
+                return col0 + (long long)sl * sstride + (e - first);
+            }
             int sl = 0;                                 // the last slice whose first entry is <= e (prefix sums: binary search)
 #pragma unroll
             for (int step = MPFMT_MAXS / 2; step > 0; step >>= 1) {
@@ -738,12 +747,15 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restri
                 {   // exclusive scan of the 128 bucket counts, two per lane
                     const int2 cc = *reinterpret_cast<const int2*>(&s_cnt[2 * lane]);
                     const int tot = cc.x + cc.y;
+                    // inclusive wave scan on the DPP network: four shifts inside the 16-lane rows (zero fill), then lane 15 of
+                    // rows 0 / 2 to rows 1 / 3, then lane 31 to rows 2 and 3 -- six adds, no LDS crossbar
                     int inc = tot;
-#pragma unroll
-                    for (int o2 = 1; o2 < 64; o2 <<= 1) {
-                        const int up = __shfl_up(inc, o2);
-                        if (lane >= o2) inc += up;
-                    }
+                    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);       // row_shr:1
+                    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);       // row_shr:2
+                    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
+                    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
+                    inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+                    inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
                     const int excl = inc - tot;
                     *reinterpret_cast<int2*>(&s_base[2 * lane]) = make_int2(excl, excl + cc.x);
                 }
