@@ -585,32 +585,62 @@ __global__ void k_round_count(const int64_t* __restrict__ colptr, const int32_t*
     cnt[i] = c;                                                        // cnt[n] = 0: the scan's last element is the total
 }
 
-__global__ void k_round_fill(const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm, int64_t sp_begin, int64_t sp_end,
-                             const int64_t* __restrict__ off, sweep_rd* __restrict__ table, int64_t cap, int64_t* __restrict__ total,
-                             const int32_t* __restrict__ spec_fail)
+// One wavefront per 64 visited columns: lane = column holds (x, first entry, entries, first quarter); the wave's quarters are
+// consecutive table entries, written 64 at a time (1 KB per store instruction) -- each lane finds the column of its quarter
+// by a 6-step search over the lanes' first quarters (lane exchange).  (A thread per column writing its own quarters one
+// after the other took 77 us for the 7e6 entries of the north star; this takes a fifth.)
+__global__ __launch_bounds__(256) void k_round_fill(const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm, int64_t sp_begin, int64_t sp_end,
+                                                    const int64_t* __restrict__ off, sweep_rd* __restrict__ table, int64_t cap, int64_t* __restrict__ total,
+                                                    const int32_t* __restrict__ spec_fail)
 {
     if (spec_fail && *spec_fail) return;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int64_t n = sp_end - sp_begin;
-    if (i > n) return;
-    if (i == n) {
-        // the last round is padded with empty quarters; total = quarters, a multiple of 4
-        int64_t q = off[n] < cap ? off[n] : cap;
-        sweep_rd r; r.x = 0; r.nf = 0; r.e0 = 0;
-        while ((q & 3) && q < cap) table[q++] = r;
-        *total = q & ~(int64_t)3;
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(int64_t)63;    // first column of this wavefront
+    if (i0 >= n) {
+        if (i0 == ((n + 63) & ~(int64_t)63) && lane == 0) {
+            // the last round is padded with empty quarters; total = quarters, a multiple of 4
+            int64_t q = off[n] < cap ? off[n] : cap;
+            sweep_rd r; r.x = 0; r.nf = 0; r.e0 = 0;
+            while ((q & 3) && q < cap) table[q++] = r;
+            *total = q & ~(int64_t)3;
+        }
         return;
     }
-    const int64_t x = perm ? (int64_t)perm[sp_begin + i] : sp_begin + i;
-    if (x < 0) return;
-    const int64_t b = colptr[x], e = colptr[x + 1];
-    int64_t o = off[i];
-    for (int64_t e0 = b; e0 < e && o < cap; e0 += 16, ++o) {
-        sweep_rd r;
-        r.x = (int32_t)x;
-        r.nf = (uint32_t)(e - e0 < 16 ? e - e0 : 16);
-        r.e0 = e0;
-        table[o] = r;
+    const int64_t i = i0 + lane;
+    int64_t x = -1, b = 0, len = 0, o = 0;
+    if (i < n) {
+        x = perm ? (int64_t)perm[sp_begin + i] : sp_begin + i;
+        o = off[i];
+        if (x >= 0) { b = colptr[x]; len = colptr[x + 1] - b; }
+    } else {
+        o = off[n];
+    }
+    const int64_t q0 = __shfl(o, 0);
+    const int64_t qend = (i0 + 64 <= n) ? off[i0 + 64] : off[n];
+    const int rel = (int)(o - q0);                                   // first quarter of this lane's column, relative (non-decreasing over lanes)
+    const int tq = (int)(qend - q0);
+    for (int j0 = 0; j0 < tq; j0 += 64) {
+        const int j = j0 + lane;
+        // the last lane whose first quarter is <= j (empty columns share their successor's first quarter: the last such lane
+        // is the one that owns quarter j)
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            const int t = lo + step;
+            const int rt = __shfl(rel, t & 63);
+            if (t < 64 && rt <= j) lo = t;
+        }
+        const int64_t cx = __shfl(x, lo), cb = __shfl(b, lo), cl = __shfl(len, lo);
+        const int cr = __shfl(rel, lo);
+        if (j < tq && q0 + j < cap) {
+            const int64_t e0 = cb + 16 * (int64_t)(j - cr);
+            sweep_rd r;
+            r.x = (int32_t)cx;
+            r.nf = (uint32_t)(cl - 16 * (int64_t)(j - cr) < 16 ? cl - 16 * (int64_t)(j - cr) : 16);
+            r.e0 = e0;
+            table[q0 + j] = r;
+        }
     }
 }
 
@@ -1175,7 +1205,8 @@ static int32_t launch_graph_sweep_rt(mpfmt_ctx* ctx, double rpad, const int32_t*
     const unsigned nbk = (unsigned)((ncol + 1 + 255) / 256);
     hipLaunchKernelGGL(k_round_count, dim3(nbk), dim3(256), 0, ctx->stream, ctx->colptr, sweep_perm, sp_begin, sp_end, ctx->rt_cnt, spec_fail);
     HIPCHK(ctx, rocprim::exclusive_scan(ctx->rt_tmp, tmp_bytes, ctx->rt_cnt, ctx->rt_off, (int64_t)0, (size_t)(ncol + 1), rocprim::plus<int64_t>(), ctx->stream));
-    hipLaunchKernelGGL(k_round_fill, dim3(nbk), dim3(256), 0, ctx->stream, ctx->colptr, sweep_perm, sp_begin, sp_end, ctx->rt_off,
+    const unsigned nbf = (unsigned)((((ncol + 63) / 64 + 1) * 64 + 255) / 256);       // one wavefront per 64 columns + the one that pads and totals
+    hipLaunchKernelGGL(k_round_fill, dim3(nbf), dim3(256), 0, ctx->stream, ctx->colptr, sweep_perm, sp_begin, sp_end, ctx->rt_off,
                        (sweep_rd*)ctx->rt_table, cap, ctx->rt_total, spec_fail);
     HIPCHK(ctx, hipGetLastError());
     const int waves = SWEEP_GT(d) / 64;
