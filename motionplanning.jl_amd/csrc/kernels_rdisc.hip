@@ -68,6 +68,20 @@ __global__ void k_cellkey(const double* __restrict__ Xo, int64_t N, int d, mpfmt
     val[p] = (int32_t)p;
 }
 
+// fp32 copy of the tiles' sub-boxes for the candidate side of k_chunk_lists: a box that contains the fp64 one (the chunk
+// lists then are a superset by a hair; the graph is decided by the exact refine)
+__global__ void k_sub32(const double* __restrict__ sub, int64_t ne, int d, float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ne) return;
+    const double x = sub[t];
+    const bool is_hi = ((t / d) & 1) != 0;
+    float f = (float)x;                                   // nearest
+    if (!is_hi && (double)f > x) f = nextafterf(f, -INFINITY);
+    if (is_hi && (double)f < x) f = nextafterf(f, INFINITY);
+    out[t] = f;
+}
+
 // sorted position s -> perm / iperm and the cell-sorted AoS copy Xs (one thread per coordinate: coalesced stores, the d
 // threads of a sample read one contiguous row); pad positions get perm = -1 and NaN coordinates (NaN never passes d2 <= r2)
 __global__ void k_sorted_perm_aos(const double* __restrict__ Xo, const int32_t* __restrict__ perm_sorted, int64_t N, int64_t npad,
@@ -265,6 +279,7 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
     if ((rc = ensure(ctx, (void**)&ctx->tile_lo, sizeof(double) * ctx->ntiles * d))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->tile_hi, sizeof(double) * ctx->ntiles * d))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->tile_sub, sizeof(double) * ctx->ntiles * 4 * d))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->tile_sub32, sizeof(float) * ctx->ntiles * 4 * d))) return rc;
 
     if (N > 0) {
         // keys / values, radix sort by cell id (stable: samples stay in index order inside a cell)
@@ -303,6 +318,10 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
             hipLaunchKernelGGL(k_tiles_from_aos, dim3((unsigned)((ne + B - 1) / B)), dim3(B), 0, ctx->stream, ctx->Xs, npad, d, ctx->Xt);
             hipLaunchKernelGGL(k_tile_bbox, dim3((unsigned)ctx->ntiles), dim3(64), 0, ctx->stream,
                                ctx->Xt, ctx->cellkey, fb, N, ctx->ntiles, d, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub);
+        }
+        {   // fp32 copy of the sub-boxes, lows rounded down and highs up (rows 0, 2 = lo; 1, 3 = hi)
+            const int64_t ne = ctx->ntiles * 4 * d;
+            hipLaunchKernelGGL(k_sub32, dim3((unsigned)((ne + B - 1) / B)), dim3(B), 0, ctx->stream, ctx->tile_sub, ne, d, ctx->tile_sub32);
         }
         HIPCHK(ctx, hipGetLastError());
     }

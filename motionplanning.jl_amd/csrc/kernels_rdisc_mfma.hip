@@ -131,7 +131,7 @@ __global__ void k_make_ops(const double* __restrict__ Xs, int64_t N, int64_t npa
 template <int D, int NW>
 __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restrict__ cellstart, const double* __restrict__ tile_lo,
                                                     const double* __restrict__ tile_hi, const double* __restrict__ tile_sub,
-                                                    mpfmt_grid G, double rpad,
+                                                    const float* __restrict__ tile_sub32, mpfmt_grid G, double rpad,
                                                     int64_t tile_begin, int64_t nt, int64_t list_cap,
                                                     uint32_t* __restrict__ lists, int32_t* __restrict__ list_len,
                                                     int32_t* __restrict__ max_len)
@@ -163,6 +163,14 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
         clo[i] = cell_of_m(wlo[i] - rpad, G.lo[i], G.inv_w[i], G.g[i]);
         chi[i] = cell_of_m(whi[i] + rpad, G.lo[i], G.inv_w[i], G.g[i]);
     }
+    // the tile's own sub-boxes in fp32, rounded outward like the candidates' (this tile's row of tile_sub32)
+    float fqal[D], fqah[D], fqbl[D], fqbh[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        fqal[i] = tile_sub32[(tile * 4 + 0) * D + i]; fqah[i] = tile_sub32[(tile * 4 + 1) * D + i];
+        fqbl[i] = tile_sub32[(tile * 4 + 2) * D + i]; fqbh[i] = tile_sub32[(tile * 4 + 3) * D + i];
+    }
+    const float frpad2 = (float)(rpad2 * (1.0 + 1e-4));
     constexpr int L = D - 1;
     uint32_t rows = 1;                                    // <= number of grid cells <= 2^24
 #pragma unroll
@@ -261,18 +269,22 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
                 }
                 keep = gap2 <= rpad2;
             } else if (keep) {
-                double gaa = 0.0, gab = 0.0, gba = 0.0, gbb = 0.0;      // query sub-box x candidate sub-box
-                const double* __restrict__ cs = tile_sub + c * 4 * D;
+                // query sub-box x candidate sub-box, in fp32 on boxes rounded outward (both sides): every gap is a lower bound of
+                // the fp64 one up to a few 1e-7 relative, which the 1e-4 on the threshold covers -- never a chunk less, and the
+                // arithmetic (the bound of this kernel: ~150 lane-ops per candidate) at the fp32 rate; candidate boxes are 16 D
+                // bytes each instead of 32 D
+                float gaa = 0.f, gab = 0.f, gba = 0.f, gbb = 0.f;
+                const float* __restrict__ cs = tile_sub32 + c * 4 * D;
 #pragma unroll
                 for (int i = 0; i < D; ++i) {
-                    const double cal = cs[i], cah = cs[D + i], cbl = cs[2 * D + i], cbh = cs[3 * D + i];
-                    const double g0 = fmax(fmax(cal - qah[i], qal[i] - cah), 0.0);
-                    const double g1 = fmax(fmax(cbl - qah[i], qal[i] - cbh), 0.0);
-                    const double g2 = fmax(fmax(cal - qbh[i], qbl[i] - cah), 0.0);
-                    const double g3 = fmax(fmax(cbl - qbh[i], qbl[i] - cbh), 0.0);
+                    const float cal = cs[i], cah = cs[D + i], cbl = cs[2 * D + i], cbh = cs[3 * D + i];
+                    const float g0 = fmaxf(fmaxf(cal - fqah[i], fqal[i] - cah), 0.f);
+                    const float g1 = fmaxf(fmaxf(cbl - fqah[i], fqal[i] - cbh), 0.f);
+                    const float g2 = fmaxf(fmaxf(cal - fqbh[i], fqbl[i] - cah), 0.f);
+                    const float g3 = fmaxf(fmaxf(cbl - fqbh[i], fqbl[i] - cbh), 0.f);
                     gaa += g0 * g0; gab += g1 * g1; gba += g2 * g2; gbb += g3 * g3;
                 }
-                keep = fmin(fmin(gaa, gab), fmin(gba, gbb)) <= rpad2;
+                keep = fminf(fminf(gaa, gab), fminf(gba, gbb)) <= frpad2;
             }
             const unsigned long long m = __ballot(keep);
             const int32_t gidx = gcount + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -850,9 +862,9 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
         // few tiles (a small shard): four wavefronts per tile, kept ids staged in LDS (4 x cap x 4 bytes)
         const bool wide = nt < 16 * (int64_t)ctx->num_cus && cap <= 3072;
 #define CASE(DD) case DD: if (wide) hipLaunchKernelGGL((k_chunk_lists<DD, 4>), dim3((unsigned)nt), dim3(256), (size_t)cap * 16, ctx->stream, ctx->cellstart, \
-            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt); \
+            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt); \
         else hipLaunchKernelGGL((k_chunk_lists<DD, 1>), dim3((unsigned)nt), dim3(64), 0, ctx->stream, ctx->cellstart, \
-            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt); break;
+            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt); break;
         switch (ctx->d) {
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
             default: return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path supports d <= 12 (got %d)", ctx->d);

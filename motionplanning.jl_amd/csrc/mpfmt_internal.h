@@ -81,6 +81,7 @@ struct mpfmt_ctx {
     double* tile_lo = nullptr;           // [ntiles][d] tight bounding box of each tile
     double* tile_hi = nullptr;
     double* tile_sub = nullptr;          // [ntiles][4][d] two sub-boxes per tile (k_tile_bbox)
+    float* tile_sub32 = nullptr;         // the same boxes in fp32, rounded outward: the candidate side of the chunk-list test (half the bytes)
 
     // ---- r-disc graph (device resident) ------------------------------------------------------------
     double graph_r = -1.0;
