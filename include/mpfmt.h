@@ -420,7 +420,8 @@ int32_t mpfmt_allgather_free_mask_finish(mpfmt_ctx* ctx, void** gathered, int64_
 
 /* ---- measurement: average device milliseconds per launch of a named kernel group since the last
  *      reset, measured with HIP events on the launch stream.  names: "rdisc_count", "rdisc_fill",
- *      "rdisc_sort", "grid", "sweep_graph", "sweep_points", "sweep_edges", "expand". */
+ *      "rdisc_sort", "grid", "sweep_graph" (mask preset + round table + kernel), "sweep_kernel" (the round-table sweep kernel alone),
+ *      "sweep_points", "sweep_edges", "expand". */
 int32_t mpfmt_timing_reset(mpfmt_ctx* ctx);
 int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
 /* Tuning / test knobs.  "rdisc_path": 0 = auto, 1 = exact fp64 VALU pair kernel, 2 = fp16 MFMA distance-matrix

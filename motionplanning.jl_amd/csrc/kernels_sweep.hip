@@ -1211,7 +1211,9 @@ static int32_t launch_graph_sweep_rt(mpfmt_ctx* ctx, double rpad, const int32_t*
     HIPCHK(ctx, hipGetLastError());
     const int waves = SWEEP_GT(d) / 64;
     const size_t lds = (size_t)SWEEP_CHUNK * 2 * d * sizeof(double) + (size_t)waves * (d + 2) * SWEEP_QCAP * sizeof(double);
+    mpfmt_timed tk(ctx);                                           // the kernel on its own, inside the caller's "sweep_graph" interval
     DISPATCH_D(d, rc = launch_sweep_rt_d<(DD <= 8 ? DD : 8)>(ctx, lds, rpad, spec_fail, sorted_rows));
+    tk.end("sweep_kernel");
     return rc;
 }
 
