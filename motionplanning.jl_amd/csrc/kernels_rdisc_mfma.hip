@@ -671,6 +671,7 @@ __device__ __forceinline__ mpfmt_hit load_hit(const mpfmt_hit* __restrict__ pool
 
 #define SLOT_LDS 1024
 #define SLOT_TC 16               // columns per wavefront
+#define SLOT_EPL 3               // hits per lane on the bucket path: columns of up to 192 hits
 // A column on its own is a chain of dependent round trips (perm -> slice counts / colptr -> slot entries -> stores), so
 // a wavefront takes SLOT_TC consecutive sorted positions: their headers are loaded together (lane = column, the
 // per-slice prefix sums go to LDS), and the slot entries of column c+1 are requested before column c is ranked.
@@ -727,34 +728,45 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restri
             }
             return col0 + (long long)sl * sstride + (e - s_pre[c][sl]);
         };
-        struct ents { int32_t ma, mb, pa, pb; double da, db; };
+        // up to SLOT_EPL entries per lane: entry q of a lane is the column's hit 64 q + lane.  (Two per lane covered columns of up to
+        // 128 hits; on the north star a third of the columns -- the interior of the cube, up to 180 neighbours -- then took the
+        // counting path, two to three times the instructions.)
+        struct ents { int32_t m[SLOT_EPL], p[SLOT_EPL]; double d[SLOT_EPL]; };
         auto fetch = [&](int c, ents& E) {
             const int k = __builtin_amdgcn_readlane(kk, c);
-            E.ma = E.mb = E.pa = E.pb = 0; E.da = E.db = 0.0;
-            if (k == 0 || k > 128) return;
+#pragma unroll
+            for (int q = 0; q < SLOT_EPL; ++q) { E.m[q] = 0; E.p[q] = 0; E.d[q] = 0.0; }
+            if (k == 0 || k > 64 * SLOT_EPL) return;
             const long long col0 = col_base(c);
-            if (lane < k) { const mpfmt_hit h = load_hit(pool, src(c, col0, lane)); E.ma = h.j; E.pa = h.pad; E.da = h.d; }
-            if (64 + lane < k) { const mpfmt_hit h = load_hit(pool, src(c, col0, 64 + lane)); E.mb = h.j; E.pb = h.pad; E.db = h.d; }
+#pragma unroll
+            for (int q = 0; q < SLOT_EPL; ++q) {
+                if (64 * q < k) {                                             // (uniform)
+                    if (64 * q + lane < k) { const mpfmt_hit h = load_hit(pool, src(c, col0, 64 * q + lane)); E.m[q] = h.j; E.p[q] = h.pad; E.d[q] = h.d; }
+                }
+            }
         };
         ents cur, nxt;
         fetch(0, cur);
         for (int c = 0; c < SLOT_TC; ++c) {
-            nxt.ma = nxt.mb = nxt.pa = nxt.pb = 0; nxt.da = nxt.db = 0.0;
+#pragma unroll
+            for (int q = 0; q < SLOT_EPL; ++q) { nxt.m[q] = 0; nxt.p[q] = 0; nxt.d[q] = 0.0; }
             if (c + 1 < SLOT_TC) fetch(c + 1, nxt);
             const int k = __builtin_amdgcn_readlane(kk, c);
             const int64_t out = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)outp >> 32), c) << 32) |
                                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)outp, c));
-            if (k > 0 && k <= 128) {
+            if (k > 0 && k <= 64 * SLOT_EPL) {
                 __syncthreads();
                 *reinterpret_cast<int2*>(&s_cnt[2 * lane]) = make_int2(0, 0);
-                const bool ha = lane < k, hb = 64 + lane < k;
-                const int32_t ma = cur.ma, mb = cur.mb;
-                // bucket_mul = floor(2^32 * 128 / N) (0: N <= 128, the id is its own bucket)
-                const int ba = bucket_mul ? min(127, (int)__umulhi((uint32_t)ma, bucket_mul)) : (ma & 127);
-                const int bb = bucket_mul ? min(127, (int)__umulhi((uint32_t)mb, bucket_mul)) : (mb & 127);
+                bool has[SLOT_EPL]; int bk[SLOT_EPL], arr[SLOT_EPL];
+#pragma unroll
+                for (int q = 0; q < SLOT_EPL; ++q) {
+                    has[q] = 64 * q + lane < k;
+                    // bucket_mul = floor(2^32 * 128 / N) (0: N <= 128, the id is its own bucket)
+                    bk[q] = bucket_mul ? min(127, (int)__umulhi((uint32_t)cur.m[q], bucket_mul)) : (cur.m[q] & 127);
+                }
                 __syncthreads();
-                const int ia = ha ? atomicAdd(&s_cnt[ba], 1) : 0;
-                const int ib = hb ? atomicAdd(&s_cnt[bb], 1) : 0;
+#pragma unroll
+                for (int q = 0; q < SLOT_EPL; ++q) arr[q] = has[q] ? atomicAdd(&s_cnt[bk[q]], 1) : 0;
                 __syncthreads();
                 {   // exclusive scan of the 128 bucket counts, two per lane
                     const int2 cc = *reinterpret_cast<const int2*>(&s_cnt[2 * lane]);
@@ -772,17 +784,25 @@ __global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restri
                     *reinterpret_cast<int2*>(&s_base[2 * lane]) = make_int2(excl, excl + cc.x);
                 }
                 __syncthreads();
-                const int basea = s_base[ba], baseb = s_base[bb];
-                const int na = s_cnt[ba], nb_ = s_cnt[bb];
-                if (ha) s_o[basea + ia] = ma;                  // ids grouped by bucket (arrival order inside)
-                if (hb) s_o[baseb + ib] = mb;
+                int base[SLOT_EPL], nin[SLOT_EPL];
+#pragma unroll
+                for (int q = 0; q < SLOT_EPL; ++q) {
+                    base[q] = s_base[bk[q]]; nin[q] = s_cnt[bk[q]];
+                    if (has[q]) s_o[base[q] + arr[q]] = cur.m[q];                  // ids grouped by bucket (arrival order inside)
+                }
                 __syncthreads();
-                int ra = 0, rb = 0;
-                if (ha) for (int m = 0; m < na; ++m) ra += (s_o[basea + m] < ma) ? 1 : 0;
-                if (hb) for (int m = 0; m < nb_; ++m) rb += (s_o[baseb + m] < mb) ? 1 : 0;
-                if (ha) { rowval[out + basea + ra] = ma; nzval[out + basea + ra] = cur.da; if (rowpos) rowpos[out + basea + ra] = cur.pa; }
-                if (hb) { rowval[out + baseb + rb] = mb; nzval[out + baseb + rb] = cur.db; if (rowpos) rowpos[out + baseb + rb] = cur.pb; }
-            } else if (k > 128) {
+#pragma unroll
+                for (int q = 0; q < SLOT_EPL; ++q) {
+                    if (64 * q < k) {                                             // (uniform)
+                        int rk = 0;
+                        if (has[q]) for (int m = 0; m < nin[q]; ++m) rk += (s_o[base[q] + m] < cur.m[q]) ? 1 : 0;
+                        if (has[q]) {
+                            const int64_t o = out + base[q] + rk;
+                            rowval[o] = cur.m[q]; nzval[o] = cur.d[q]; if (rowpos) rowpos[o] = cur.p[q];
+                        }
+                    }
+                }
+            } else if (k > 64 * SLOT_EPL) {
                 // long columns: rank by counting through LDS (streamed in windows beyond SLOT_LDS hits)
                 const long long col0 = col_base(c);
                 __syncthreads();
