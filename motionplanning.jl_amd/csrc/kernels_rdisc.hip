@@ -705,7 +705,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         // mean plus a fixed slack -- an overflow falls back to the fill pass
         const int64_t items = nt * S;
         // (a build that overflowed doubles the slack of the following ones)
-        const int64_t capc = ((int64_t)(want / ((double)items * 64.0) * 4.0) + 64) * ctx->pool_slack;
+        const int64_t capc = ((int64_t)(want / ((double)items * 64.0) * 2.5) + 32) * ctx->pool_slack;
         if ((double)capc * (double)items * 64.0 * 16.0 > 96e9) pool = false;      // cap the slot lists at 96 GB of the 288
         else {
             const size_t cap = (size_t)capc * (size_t)items * 64;
