@@ -644,6 +644,16 @@ __global__ __launch_bounds__(256) void k_round_fill(const int64_t* __restrict__ 
     }
 }
 
+// flag = 0 if any sample fails in_state_space (statespaces.jl:150); the sweep over a sample set that passes skips the test per row
+__global__ void k_all_in_ss(const double* __restrict__ X, int64_t N, int d, const double* __restrict__ ssb, int32_t* __restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    bool ok = true;
+    for (int k = 0; k < d; ++k) { const double x = X[i * d + k]; ok = ok && (ssb[k] <= x) && (x <= ssb[MPFMT_MAX_DIM + k]); }
+    if (!ok) *flag = 0;
+}
+
 #define RT_TASK 64                 // rounds per task = lanes of the descriptor register
 
 template <int D>
@@ -1173,7 +1183,7 @@ static int32_t launch_sweep_rt_d(mpfmt_ctx* ctx, size_t lds, double rpad, const 
     const unsigned nb = (unsigned)(std::max(per_cu, 1) * ctx->num_cus);          // one resident set; the task count lives on the device
     hipLaunchKernelGGL(kk, dim3(nb), dim3(SWEEP_GT(D)), lds, ctx->stream, ctx->Xo, ctx->colptr, ctx->N,
                        sorted_rows ? ctx->Xs : ctx->Xo, sorted_rows ? ctx->rowpos : ctx->rowval, rpad, ctx->boxes, ctx->M,
-                       (int)ctx->ss.has, ctx->rt_ss, (unsigned long long*)ctx->graph_free, (const sweep_rd*)ctx->rt_table, ctx->rt_total, ctx->sweep_ctr, spec_fail,
+                       (int)(ctx->ss.has && !ctx->ssflag_all_in), ctx->rt_ss, (unsigned long long*)ctx->graph_free, (const sweep_rd*)ctx->rt_table, ctx->rt_total, ctx->sweep_ctr, spec_fail,
                        sorted_rows ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
@@ -1198,10 +1208,22 @@ static int32_t launch_graph_sweep_rt(mpfmt_ctx* ctx, double rpad, const int32_t*
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                 // b is a stack buffer
         ctx->rt_ss_host = ctx->ss; ctx->rt_ss_valid = true;
     }
+    // once per (sample set, bounds): do all samples lie in the state space?  (one small kernel and a 4-byte read-back; the
+    // steady-state step pays nothing and its sweep drops 2 d comparisons per entry)
+    if (ctx->ss.has && (ctx->ssflag_epoch != ctx->samples_epoch || memcmp(&ctx->ssflag_ss, &ctx->ss, sizeof(mpfmt_ss)) != 0)) {
+        if ((rc = mpfmt_ensure(ctx, (void**)&ctx->ssflag_dev, sizeof(int32_t)))) return rc;
+        int32_t one = 1, got = 0;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->ssflag_dev, &one, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (ctx->N > 0)
+            hipLaunchKernelGGL(k_all_in_ss, dim3((unsigned)((ctx->N + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xo, ctx->N, ctx->d, ctx->rt_ss, ctx->ssflag_dev);
+        HIPCHK(ctx, hipMemcpyAsync(&got, ctx->ssflag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->ssflag_all_in = got == 1;
+        ctx->ssflag_epoch = ctx->samples_epoch; ctx->ssflag_ss = ctx->ss;
+    }
     size_t tmp_bytes = 0;
     HIPCHK(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, ctx->rt_cnt, ctx->rt_off, (int64_t)0, (size_t)(ncol + 1), rocprim::plus<int64_t>(), ctx->stream));
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_tmp, tmp_bytes))) return rc;
-    HIPCHK(ctx, hipMemsetAsync(ctx->rt_total, 0, sizeof(int64_t), ctx->stream));
     const unsigned nbk = (unsigned)((ncol + 1 + 255) / 256);
     hipLaunchKernelGGL(k_round_count, dim3(nbk), dim3(256), 0, ctx->stream, ctx->colptr, sweep_perm, sp_begin, sp_end, ctx->rt_cnt, spec_fail);
     HIPCHK(ctx, rocprim::exclusive_scan(ctx->rt_tmp, tmp_bytes, ctx->rt_cnt, ctx->rt_off, (int64_t)0, (size_t)(ncol + 1), rocprim::plus<int64_t>(), ctx->stream));

@@ -112,6 +112,11 @@ struct mpfmt_ctx {
     double* rt_ss = nullptr;             // device copy of the state-space bounds (lo[MAX_DIM], hi[MAX_DIM]) for scalar loads
     mpfmt_ss rt_ss_host;                 // what rt_ss holds
     bool rt_ss_valid = false;
+    // "every sample lies in the state space" for (samples_epoch, ss): the sweep then skips the per-row in_state_space test
+    int64_t samples_epoch = 0, ssflag_epoch = -1;
+    mpfmt_ss ssflag_ss;
+    bool ssflag_all_in = false;
+    int32_t* ssflag_dev = nullptr;
     int64_t mf_target_items = 40000;     // work items (tile x slice) the MFMA path aims for (tools/run_shard_sweep_items.py: flat from 40k up at 1 shard, best at 2 and 4)
     float mf_negT = 0.f;
     void* lists = nullptr;               // [shard tiles][list_cap] candidate chunk ids per tile
