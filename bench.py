@@ -370,7 +370,9 @@ def main():
                     "L2-resident (tools/ubench/, profiles/r01_ubench_fetch_calib.txt, profiles/r02_ubench_gather_variants.txt); "
                     "stage ablation in DESIGN.md 3.3" % (2 * d * 8 + 8 + 0.125),
         }
-    if sweep_ms >= pair_ms:
+    # dominance is decided between the two STAGES as the library times them (pair stage = "rdisc_count", sweep stage =
+    # "sweep_graph": mask preset + round table + kernel); the roofline of a stage is that of its kernel, on the kernel's own duration
+    if tm["sweep_graph"][0] >= pair_ms:
         out["roofline"], out["roofline_rdisc"] = roof_sweep, roof_rdisc
     else:
         out["roofline"], out["roofline_sweep"] = roof_rdisc, roof_sweep

@@ -21,6 +21,6 @@ cp profiles/${R}_bench_ns_${V}.json profiles/${R}_bench_ns_kernel_stats_${V}.csv
 python3 - <<PY
 import json
 d = json.load(open("profiles/${R}_bench_ns_${V}.json"))
-print("ms_per_step", d["ms_per_step"], "value", d["value"], "roofline", {k: d["roofline"][k] for k in ("kernel", "frac", "traffic", "valu_frac")},
+print("ms_per_step", d["ms_per_step"], "value", d["value"], "roofline", {k: d["roofline"].get(k) for k in ("kernel", "frac", "traffic", "valu_frac")},
       "solve", d["submetrics"].get("fmt_solve", {}).get("ms"))
 PY
