@@ -212,3 +212,37 @@ def test_cfg4_double_integrator_full_size_properties(orc):
             fr = orc.di_is_free_motion(w.X[rowval[e] - 1], w.X[cols[e] - 1], w.rho, w.r, w.lohi, w.ss_lo, w.ss_hi)
             assert bool(mask[e]) == bool(fr), e
             assert (nseg[e] == 4) or not fr                                 # a free motion has passed all 4 segment tests
+
+
+# ---- (e) the round-table sweep: packed rounds, pending lists, bounds shortcut ---------------------------------------------
+
+@pytest.mark.parametrize("N,d,M,r,box_h,bounds", [
+    (3000, 2, 25, 0.012, (0.02, 0.08), "inside"),     # degree ~1.3: a round holds four columns (or pieces of four)
+    (3000, 2, 25, 0.05, (0.02, 0.08), "cut"),         # degree ~23: columns share quarters' rounds; some samples out of bounds
+    (2500, 3, 256, 0.15, (0.03, 0.12), "inside"),     # 256 boxes = the kernel's limit (box ids fill a byte)
+    (2500, 6, 0, 0.45, (0.1, 0.2), "cut"),            # no boxes: only the in_state_space bit
+    (1500, 4, 120, 0.5, (0.15, 0.3), "inside"),       # degree ~250: columns over several rounds; dense boxes: lanes with > 4 pending
+    (1500, 8, 60, 0.9, (0.2, 0.4), "none"),           # d = 8 (generic broad phase), no state-space bounds at all
+])
+def test_round_table_sweep_cases(orc, N, d, M, r, box_h, bounds):
+    """k_graph_sweep_rt against the oracle's edge predicate over the corners of its design: rounds packed from several columns,
+    columns over several rounds, the 256-box limit, more pending boxes per lane than its packed list holds, every sample in
+    bounds (the per-row test is skipped), some out of bounds, no bounds; each with rows gathered from the cell-sorted copy and
+    from the caller's array, and against the task-header kernel."""
+    rng = np.random.default_rng(1000 + N + d + M)
+    X, lohi = random_world(rng, N, d, M, *box_h)
+    lo, hi = {"inside": (np.full(d, -0.5), np.full(d, 1.5)), "cut": (np.full(d, 0.03), np.full(d, 0.96)), "none": (None, None)}[bounds]
+    oc, orow, oval = orc.rdisc_graph(X, r)
+    want = orc.graph_edges_free(X, oc, orow, lohi, lo, hi)
+    masks = []
+    for sorted_rows, rounds in ((1, 1), (0, 1), (1, 0)):
+        with mp.Context(0) as c:
+            c.set_option("sweep_sorted", sorted_rows); c.set_option("sweep_rounds", rounds)
+            c.upload_samples(X); c.upload_boxes(lohi, lo, hi)
+            for _ in range(2):                                         # careful step, then the speculative one
+                nnz = c.graph_step_device(r)
+            colptr, rowval, nzval, free = _resident_graph(c, N)
+            assert nnz == len(orow) and np.array_equal(colptr, oc) and np.array_equal(rowval, orow)
+            masks.append(free.view(np.uint64).copy())
+    for m in masks:
+        assert np.array_equal(m, want)
