@@ -1174,13 +1174,17 @@ static int32_t launch_graph_sweep_d(mpfmt_ctx* ctx, size_t lds, double rpad, int
 
 // round table (count -> scan -> fill) + k_graph_sweep_rt; entries = nnz or, on a speculative step, the trusted capacity
 template <int D>
-static int32_t launch_sweep_rt_d(mpfmt_ctx* ctx, size_t lds, double rpad, const int32_t* spec_fail, bool sorted_rows)
+static int32_t launch_sweep_rt_d(mpfmt_ctx* ctx, size_t lds, double rpad, const int32_t* spec_fail, bool sorted_rows, int64_t table_cap)
 {
     constexpr auto kk = k_graph_sweep_rt<D>;
     if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kk, SWEEP_GT(D), lds));
-    const unsigned nb = (unsigned)(std::max(per_cu, 1) * ctx->num_cus);          // one resident set; the task count lives on the device
+    // one resident set at most; the task count lives on the device, its bound (table capacity / 64) is known here -- a small graph
+    // gets a few workgroups instead of 4096 wavefronts queueing on the task counter
+    const int64_t resident = (int64_t)std::max(per_cu, 1) * ctx->num_cus;
+    const int64_t need = (((int64_t)table_cap + RT_TASK - 1) / RT_TASK + SWEEP_GT(D) / 64 - 1) / (SWEEP_GT(D) / 64);
+    const unsigned nb = (unsigned)std::max<int64_t>(1, std::min(resident, need));
     hipLaunchKernelGGL(kk, dim3(nb), dim3(SWEEP_GT(D)), lds, ctx->stream, ctx->Xo, ctx->colptr, ctx->N,
                        sorted_rows ? ctx->Xs : ctx->Xo, sorted_rows ? ctx->rowpos : ctx->rowval, rpad, ctx->boxes, ctx->M,
                        (int)(ctx->ss.has && !ctx->ssflag_all_in), ctx->rt_ss, (unsigned long long*)ctx->graph_free, (const sweep_rd*)ctx->rt_table, ctx->rt_total, ctx->sweep_ctr, spec_fail,
@@ -1234,7 +1238,7 @@ static int32_t launch_graph_sweep_rt(mpfmt_ctx* ctx, double rpad, const int32_t*
     const int waves = SWEEP_GT(d) / 64;
     const size_t lds = (size_t)SWEEP_CHUNK * 2 * d * sizeof(double) + (size_t)waves * (d + 2) * SWEEP_QCAP * sizeof(double);
     mpfmt_timed tk(ctx);                                           // the kernel on its own, inside the caller's "sweep_graph" interval
-    DISPATCH_D(d, rc = launch_sweep_rt_d<(DD <= 8 ? DD : 8)>(ctx, lds, rpad, spec_fail, sorted_rows));
+    DISPATCH_D(d, rc = launch_sweep_rt_d<(DD <= 8 ? DD : 8)>(ctx, lds, rpad, spec_fail, sorted_rows, cap));
     tk.end("sweep_kernel");
     return rc;
 }
