@@ -479,16 +479,23 @@ __global__ __launch_bounds__(64) void k_rdisc(rdisc_args a, mpfmt_grid G)
 
 // degree of each ORIGINAL column = sum over slices of the sorted query's hits
 __global__ void k_degree(const int32_t* __restrict__ slice_cnt, const int32_t* __restrict__ perm, int S, int64_t npad,
-                         int64_t pos_begin, int64_t pos_end, int64_t* __restrict__ deg, int64_t* __restrict__ degs)
+                         int64_t pos_begin, int64_t pos_end, int64_t* __restrict__ deg, int64_t* __restrict__ degs,
+                         int32_t* __restrict__ max_deg)
 {
     int64_t s = pos_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= pos_end) return;
-    const int32_t o = perm[s];
-    if (o < 0) return;
     int64_t k = 0;
-    for (int i = 0; i < S; ++i) k += slice_cnt[(int64_t)i * npad + s];
-    deg[o] = k;
-    degs[s] = k;
+    if (s < pos_end) {
+        const int32_t o = perm[s];
+        if (o >= 0) {
+            for (int i = 0; i < S; ++i) k += slice_cnt[(int64_t)i * npad + s];
+            deg[o] = k;
+            degs[s] = k;
+        }
+    }
+    // longest column of the shard (one atomic per wavefront): the log-ordering kernel stages whole columns in LDS
+    int m = (int)min(k, (int64_t)0x7fffffff);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(max_deg, m);
 }
 
 // Per-column ordering: rank each entry by counting smaller row indices (indices in a column are
@@ -580,23 +587,24 @@ static int32_t scan_i64(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t 
 
 // device-side verdict of a speculative step: any capacity that did not hold sets the flag every later kernel checks
 __global__ void k_spec_check(const int32_t* __restrict__ pool_flag, const int32_t* __restrict__ list_max, int64_t list_cap,
-                             const int64_t* __restrict__ nnz, int64_t nnz_cap, int32_t* __restrict__ spec_fail)
+                             const int64_t* __restrict__ nnz, int64_t nnz_cap, const int32_t* __restrict__ max_deg, int32_t* __restrict__ spec_fail)
 {
-    *spec_fail = (*pool_flag != 0) || (list_max && (int64_t)*list_max > list_cap) || (*nnz >= nnz_cap);
+    *spec_fail = (*pool_flag != 0) || (list_max && (int64_t)*list_max > list_cap) || (*nnz >= nnz_cap) || (*max_deg > MPFMT_ORD_MAXDEG);
 }
 
 // everything the host wants to know after a count, gathered into one block so that ONE copy into pinned memory brings it
 // back (four separate copies into pageable host variables are four blocking round trips: ~100 us of idle GPU per step)
-struct count_readback { unsigned long long pairs[512]; long long nnz; int pool_over, list_mx; };
+struct count_readback { unsigned long long pairs[512]; long long nnz; int pool_over, list_mx, max_deg, pad_; };
 __global__ __launch_bounds__(512) void k_count_readback(const unsigned long long* __restrict__ pairs, const int64_t* __restrict__ nnz,
                                                         const int32_t* __restrict__ pool_flag, const int32_t* __restrict__ list_max,
-                                                        count_readback* __restrict__ out)
+                                                        const int32_t* __restrict__ max_deg, count_readback* __restrict__ out)
 {
     out->pairs[threadIdx.x] = pairs[threadIdx.x];
     if (threadIdx.x == 0) {
         out->nnz = *nnz;
         out->pool_over = pool_flag ? *pool_flag : 0;
         out->list_mx = list_max ? *list_max : 0;
+        out->max_deg = *max_deg;
     }
 }
 
@@ -682,8 +690,9 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     if ((rc = ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (N + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->degs, sizeof(int64_t) * (npad + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->tptr, sizeof(int64_t) * (npad + 1)))) return rc;
-    if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 512 * sizeof(unsigned long long)));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 512 * sizeof(unsigned long long), ctx->stream));
+    // 512 pair counters + one word for the longest column (k_degree)
+    if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 514 * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 514 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (N + 1), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->degs, 0, sizeof(int64_t) * (npad + 1), ctx->stream));
 
@@ -701,15 +710,16 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             want = std::min(1.0, ball / vol) * (double)N * (double)(nt * 64) * 1.15 + 64.0 * (double)N;
         }
         want = std::min(want, (double)N * (double)(nt * 64));
-        // every (tile, slice, column) owns a fixed-capacity slot list; per-list counts vary, so lists get 4x the
-        // mean plus a fixed slack -- an overflow falls back to the fill pass
+        // every (tile, slice) item owns a fixed-capacity append log; an item of the interior of the domain finds ~1.7x the
+        // mean, so logs get 2.2x the mean plus a fixed slack -- an overflow falls back to the fill pass
         const int64_t items = nt * S;
         // (a build that overflowed doubles the slack of the following ones)
-        const int64_t capc = ((int64_t)(want / ((double)items * 64.0) * 2.5) + 32) * ctx->pool_slack;
-        if ((double)capc * (double)items * 64.0 * 16.0 > 96e9) pool = false;      // cap the slot lists at 96 GB of the 288
+        const int64_t capc = (((int64_t)(want / (double)items * 2.2) + 256) * ctx->pool_slack + 3) / 4 * 4;
+        if ((double)capc * (double)items * 16.0 > 96e9) pool = false;      // cap the logs at 96 GB of the 288
         else {
-            const size_t cap = (size_t)capc * (size_t)items * 64;
+            const size_t cap = (size_t)capc * (size_t)items;
             if ((rc = ensure(ctx, (void**)&ctx->pool, sizeof(mpfmt_hit) * cap))) return rc;
+            if ((rc = ensure(ctx, (void**)&ctx->log_len, sizeof(int32_t) * (size_t)items))) return rc;
             if (!ctx->pool_flag) HIPCHK(ctx, hipMalloc((void**)&ctx->pool_flag, sizeof(int32_t)));
             HIPCHK(ctx, hipMemsetAsync(ctx->pool_flag, 0, sizeof(int32_t), ctx->stream));
             ctx->pool_cap = capc;
@@ -731,7 +741,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         const int B = 256;
         const int64_t pb = ctx->tile_begin * 64, pe = ctx->tile_end * 64;
         hipLaunchKernelGGL(k_degree, dim3((unsigned)((pe - pb + B - 1) / B)), dim3(B), 0, ctx->stream,
-                           ctx->slice_cnt, ctx->perm, S, npad, pb, pe, ctx->deg, ctx->degs);
+                           ctx->slice_cnt, ctx->perm, S, npad, pb, pe, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512));
     }
     if ((rc = scan_i64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1)))) return rc;      // columns in original order
     if ((rc = scan_i64(ctx, ctx->degs, ctx->tptr, (size_t)(npad + 1)))) return rc;    // staging in sorted order
@@ -751,7 +761,7 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     if (!ctx->rb_dev) HIPCHK(ctx, hipMalloc(&ctx->rb_dev, sizeof(count_readback)));
     if (!ctx->rb_host) HIPCHK(ctx, hipHostMalloc(&ctx->rb_host, sizeof(count_readback), hipHostMallocDefault));
     hipLaunchKernelGGL(k_count_readback, dim3(1), dim3(512), 0, ctx->stream, ctx->d_pairs, ctx->colptr + N, pool ? ctx->pool_flag : nullptr,
-                       (ctx->spec_lists && nt > 0) ? ctx->list_len + nt : nullptr, (count_readback*)ctx->rb_dev);
+                       (ctx->spec_lists && nt > 0) ? ctx->list_len + nt : nullptr, (const int32_t*)(ctx->d_pairs + 512), (count_readback*)ctx->rb_dev);
     HIPCHK(ctx, hipMemcpyAsync(ctx->rb_host, ctx->rb_dev, sizeof(count_readback), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const count_readback* rb = (const count_readback*)ctx->rb_host;
@@ -767,8 +777,11 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
         return mpfmt_launch_rdisc_count(ctx, r);
     }
     ctx->spec_lists = false;
-    if (spec_failed && pool && pool_over) *spec_failed = true;
-    ctx->pool_valid = pool && pool_over == 0;
+    ctx->max_deg = rb->max_deg;
+    // the log-ordering kernel stages whole columns in LDS: a graph with a longer column takes the two-pass build
+    const bool too_long = rb->max_deg > MPFMT_ORD_MAXDEG;
+    if (spec_failed && pool && (pool_over || too_long)) *spec_failed = true;
+    ctx->pool_valid = pool && pool_over == 0 && !too_long;
     if (pool && pool_over && ctx->pool_slack < 8) ctx->pool_slack *= 2;
     ctx->pool_hint_N = N; ctx->pool_hint_r = r; ctx->pool_hint_nnz = nnz;
     ctx->pool_hint_rank = ctx->rank; ctx->pool_hint_world = ctx->world;
@@ -800,7 +813,7 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
         if (ctx->rdisc_path_used == 2 && ctx->pool_valid) {
             // single pass: the hits are already in the slot lists; order each column straight into the final CSC
             mpfmt_timed tm4(ctx);
-            if ((rc = mpfmt_sortcols_slots(ctx))) return rc;
+            if ((rc = mpfmt_order_logs(ctx))) return rc;
             tm4.end("rdisc_sort");
             done = 1;
         }
@@ -854,13 +867,14 @@ int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r)
             if (!ctx->spec_fail) HIPCHK(ctx, hipMalloc((void**)&ctx->spec_fail, sizeof(int32_t)));
             const int64_t nt = ctx->tile_end - ctx->tile_begin;
             hipLaunchKernelGGL(k_spec_check, dim3(1), dim3(1), 0, ctx->stream, ctx->pool_flag,
-                               (ctx->spec_lists && nt > 0) ? ctx->list_len + nt : nullptr, ctx->list_cap, ctx->colptr + N, cap, ctx->spec_fail);
+                               (ctx->spec_lists && nt > 0) ? ctx->list_len + nt : nullptr, ctx->list_cap, ctx->colptr + N, cap,
+                               (const int32_t*)(ctx->d_pairs + 512), ctx->spec_fail);
             ctx->nnz = ctx->pool_hint_nnz;                          // provisional: replaced by the count's own value in _finish
             ctx->nnz_cap = cap;
             ctx->pool_valid = true; ctx->rdisc_path_used = 2;
             ctx->graph_r = r; ctx->graph_counted = true;
             mpfmt_timed tm7(ctx);
-            if ((rc = mpfmt_sortcols_slots(ctx, ctx->spec_fail))) return rc;
+            if ((rc = mpfmt_order_logs(ctx, ctx->spec_fail))) return rc;
             tm7.end("rdisc_sort");
             ctx->graph_filled = true;
             if ((rc = mpfmt_launch_graph_sweep(ctx, ctx->spec_fail, cap))) return rc;

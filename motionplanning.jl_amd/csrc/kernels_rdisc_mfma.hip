@@ -30,6 +30,8 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define NXCD 8
 #define MF_THREADS 256
@@ -48,7 +50,6 @@ struct mf_args {
     double rpad;                    // conservative radius for box pruning
     float negT;                     // -T, filter threshold in normalised squared units
     int32_t S;
-    int32_t ablate;                 // timing experiments only (results invalid): 1 skip extraction, 2 skip refine, 4 skip MFMA
     int32_t xcd_mode;               // item -> XCD placement: 0 contiguous range per XCD, 1 round robin, >=2 interleaved groups of that many items
     int64_t blk_begin;              // first 256-query block of the shard
     int64_t nitems;                 // blocks * S
@@ -63,10 +64,11 @@ struct mf_args {
     int64_t list_cap;
     unsigned long long* pairs;
     unsigned long long* survivors;
-    // MODE 2 (single pass): exact hits are appended to a pool while they are counted
-    int32_t* pool_flag;             // set to 1 when a slot list overflows (the build then falls back to a fill pass)
-    long long pool_cap;             // capacity of ONE (item, column) slot list
-    mpfmt_hit* pool;                // (sample index of the row, sqrt(d2)) records
+    // MODE 2 (single pass): exact hits are appended to the item's log while they are counted
+    int32_t* pool_flag;             // set to 1 when a log overflows (the build then falls back to a fill pass)
+    long long pool_cap;             // capacity of ONE item's log, in records
+    mpfmt_hit* pool;                // [items][pool_cap] (sample index of the row, cell-sorted position | column << 26, sqrt(d2)) records
+    int32_t* log_len;               // [items] records in each log
 };
 
 __device__ __forceinline__ int cell_of_m(double x, double lo, double inv_w, int g)
@@ -104,11 +106,17 @@ __global__ void k_make_ops(const double* __restrict__ Xs, int64_t N, int64_t npa
     const _Float16 nl = (_Float16)(n - (float)nh);
     if (d <= 6) {
         // K = 8 layout (16 B per sample): u_0..u_5, n_hi, n_lo -- the query's norm and the threshold ride in the MFMA's C
-        union { _Float16 hh[8]; uint4 v; } u8;
+        // stored [chunk][kb][col][half]: lane (kb, col) of the pair kernel's B fragment finds slots 4 kb .. 4 kb + 3 of samples
+        // col (half 0) and 32 + col (half 1) of a chunk side by side -- one 16-byte load per lane and chunk
+        union { _Float16 hh[8]; uint2 v[2]; } u8;
 #pragma unroll
         for (int k = 0; k < 6; ++k) u8.hh[k] = h[k];
         u8.hh[6] = nh; u8.hh[7] = nl;
-        ops[p] = u8.v;
+        uint2* __restrict__ o2 = reinterpret_cast<uint2*>(ops);
+        const int64_t chunk = p >> 6;
+        const int cx = (int)(p & 31), half = (int)((p >> 5) & 1);
+        o2[(chunk * 64 + cx) * 2 + half] = u8.v[0];
+        o2[(chunk * 64 + 32 + cx) * 2 + half] = u8.v[1];
         return;
     }
     h[12] = (_Float16)1.0f; h[13] = (_Float16)1.0f; h[14] = nh; h[15] = nl;
@@ -326,23 +334,35 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
 // One independent wavefront per (tile, slice of the tile's chunk list): no workgroup barriers.
-//   main loop: for each listed chunk, the two 32-candidate B fragments are 16 B/lane coalesced loads from the
-//              operand array (L2/MALL resident, 32 B per sample), prefetched two chunks ahead; 4 MFMAs
-//              (2 query row blocks x 2 candidate column blocks), sign-bit extraction, survivor queue, refine.
-#define MF_LIST 1024                // chunk ids per list round (4 KB LDS)
+//   main loop: for each listed chunk, the B fragments are ONE 16 B/lane coalesced buffer load (d <= 6; two for 7 <= d <= 12) whose
+//              address is a per-lane constant plus a SCALAR chunk offset (the chunk id comes out of a register-held block
+//              of the list with v_readlane: no LDS round trip, no vector address arithmetic), prefetched PF chunks ahead;
+//              4 MFMAs (2 query row blocks x 2 candidate column blocks), sign-bit extraction (16 v_alignbit per MFMA: the
+//              floor for reading 1024 accumulators, and on gfx950 a half-rate VALU op -- tools/ubench/extract_rates*.hip),
+//              then lanes whose 64 sign bits are not all clear push ONE record (chunk, lane, bits) to a wave-private LDS
+//              record queue -- a ballot, a prefix count and two LDS writes per chunk instead of a loop over the bits
+//   expand   : 64 records at a time (lane = record): prefix sum of the popcounts, every lane then writes its own
+//              survivors (chunk, lane, bit) into the survivor queue at its own offset -- no ballot per bit
+//   refine   : 64 survivors at a time (lane = survivor): canonical fp64 d2, membership test, and in the single-pass mode
+//              the hits of the batch are appended -- ballot-compacted, one contiguous 16 B/lane store -- to the item's LOG
+//              (full lines; k_order_logs regroups a tile's logs by column through LDS and writes the ordered CSC)
+#define MF_RCAP 128                 // record queue entries per wavefront (expanded 64 at a time)
+#define MF_QSZ 320                  // survivor queue entries per wavefront (drained 64 at a time)
+#ifndef MF_ABLATE                   // timing experiments only (results invalid): 1 skip extraction, 2 skip refine, 4 skip MFMA
+#define MF_ABLATE 0
+#endif
 
-// MODE 0: count only   1: fill the staging CSC (needs offsets from a count pass)   2: count AND append hits to the pool
-// W4: built for 4 wavefronts per SIMD (128 VGPRs): the K = 8 form then runs a B-fragment ring of 2 instead of 4 -- 2.12 vs
-// 2.20 ms on the north star (a ring of 4 at 128 VGPRs spills inside the loop: 3.7 ms; the K = 16 form is slower at 4: cfg3 58 vs 55 ms)
+// MODE 0: count only   1: fill the staging CSC (needs offsets from a count pass)   2: count AND append hits to the item's log
+// W4: built for 4 wavefronts per SIMD (128 VGPRs)
 template <int D, int MODE, bool W4>
 __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
 {
     __shared__ double s_q[64 * D];                        // fp64 query coordinates (AoS) for the refine
-    __shared__ uint32_t s_list[MF_LIST];
-    __shared__ uint32_t s_qj[MF_QCAP];                    // survivor queue: candidate chunk id
-    __shared__ uint32_t s_qq[MF_QCAP];                    //                 (finding lane << 6) | sign-bit position; decoded in drain
+    __shared__ uint32_t s_rm[MF_RCAP];                    // record queue: chunk << 6 | finding lane
+    __shared__ unsigned long long s_rh[MF_RCAP];          //               the lane's 64 sign bits of that chunk
+    __shared__ uint32_t s_qs[MF_QSZ];                     // survivor queue: chunk << 12 | finding lane << 6 | sign-bit position
     __shared__ int32_t s_cnt[64];
-    __shared__ int64_t s_base[64];
+    __shared__ int64_t s_base[MODE == 1 ? 64 : 1];
 
     const int lane = threadIdx.x;
     const int64_t nblk = gridDim.x;
@@ -376,6 +396,8 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         s_base[lane] = base;
     }
     // d <= 6: K = 8 operands (16 B per sample, v_mfma_f32_32x32x8_f16), half the operand traffic of the K = 16 form.
+    // K = 8 operand layout (k_make_ops): [chunk][kb][col][half] x 4 fp16 -- lane (kb, col) of a B fragment load gets slots
+    // 4 kb .. 4 kb + 3 of samples col and 32 + col of the chunk in ONE 16-byte load.
     constexpr bool K8 = (D <= 6);
     half8 aF[2];
     half4 aF4[2];
@@ -387,7 +409,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         const uint2* __restrict__ ops2 = reinterpret_cast<const uint2*>(a.ops);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            const uint2 raw = ops2[(tile * 64 + rb * 32 + col) * 2 + kb];
+            const uint2 raw = ops2[(tile * 64 + kb * 32 + col) * 2 + rb];
             union { uint2 u; _Float16 h[4]; } cv; cv.u = raw;
             half4 v;
             if (kb == 0) {
@@ -401,7 +423,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
-                union { uint2 u; _Float16 h[4]; } qn; qn.u = ops2[(tile * 64 + rb * 32 + row) * 2 + 1];
+                union { uint2 u; _Float16 h[4]; } qn; qn.u = ops2[(tile * 64 + 32 + row) * 2 + rb];      // slots 4..7 of sample rb*32 + row
                 cinit[rb][r] = ((float)qn.h[2] + (float)qn.h[3]) + a.negT;
             }
             aF[rb] = half8{};
@@ -432,22 +454,27 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     }
 
     // ---- refine: exact fp64 test of n queued survivors (lane = survivor) ---------------------------------------
-    int qcount = 0;                                           // wave-uniform queue length
+    int qcount = 0;                                           // wave-uniform survivor queue length
+    int rcount = 0;                                           // wave-uniform record queue length
+    int lcount = 0;                                           // hits appended to this item's log so far (wave-uniform)
     int pool_over = 0;
+    mpfmt_hit* const __restrict__ mylog = (MODE == 2) ? a.pool + (long long)item * a.pool_cap : nullptr;
     auto drain = [&](int n) {
         // takes the LAST n queue entries (order is irrelevant: columns are sorted afterwards), so nothing moves
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int first = qcount - n;
-        if (a.ablate & 2) { qcount = __builtin_amdgcn_readfirstlane(first); return; }
+        qcount = __builtin_amdgcn_readfirstlane(first);
+        if (MF_ABLATE & 2) return;
         bool hit = false;
         uint32_t jg = 0, ql = 0;
         double d2 = 0.0;
         if (lane < n) {
-            // decode (the push stores the raw coordinates of the sign bit: decoding once per drain -- 64 survivors wide -- is an
-            // order of magnitude cheaper than in the extraction loop, which runs per chunk with a handful of active lanes)
-            const uint32_t qc = s_qj[first + lane], pk = s_qq[first + lane];
-            const int bpos = (int)(pk & 63u), fl = (int)(pk >> 6);
+            // decode (the queue stores the raw coordinates of the sign bit: decoding once per drain -- 64 survivors wide -- is an
+            // order of magnitude cheaper than in the extraction, which runs per chunk with a handful of active lanes)
+            const uint32_t e = s_qs[first + lane];
+            const int bpos = (int)(e & 63u), fl = (int)((e >> 6) & 63u);
+            const uint32_t qc = e >> 12;
             const int t = bpos >> 4, r = 15 - (bpos & 15);
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (fl >> 5);
             jg = qc * 64u + (uint32_t)((t >> 1) * 32 + (fl & 31));
@@ -460,85 +487,112 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             }
             hit = (d2 <= a.r2) && ((int64_t)jg != tile * 64 + (int64_t)ql);
             if (hit) {
-                const int slot = atomicAdd(&s_cnt[ql], 1);
                 if (FILL) {
+                    const int slot = atomicAdd(&s_cnt[ql], 1);
                     const int64_t pos = s_base[ql] + slot;
                     a.rowtmp[pos] = a.perm[jg];
                     a.valtmp[pos] = sqrt(d2);
-                }
-                if (MODE == 2) {
-                    // single pass: the hit goes straight into the fixed-capacity slot list of (item, column); the
-                    // LDS counter that numbers it is the same one that counts the column's degree
-                    if (slot < a.pool_cap) {
-                        const long long p = ((long long)item * 64 + ql) * a.pool_cap + slot;
-                        mpfmt_hit h;
-                        h.j = a.perm[jg]; h.pad = (int32_t)jg; h.d = sqrt(d2);     // sample index of the row, its cell-sorted position, edge cost
-                        *reinterpret_cast<uint4*>(&a.pool[p]) = *reinterpret_cast<const uint4*>(&h);   // one 16-byte store
-                    } else {
-                        pool_over = 1;
-                    }
+                } else {
+                    atomicAdd(&s_cnt[ql], 1);                             // the column's degree (no return value needed)
                 }
             }
         }
-        qcount = __builtin_amdgcn_readfirstlane(first);
+        if (MODE == 2) {
+            // single pass: the batch's hits go to the end of the item's log, compacted -- one contiguous run of 16-byte
+            // records per drain (row sample index, cell-sorted position | column << 26, edge cost)
+            const unsigned long long mh = __ballot(hit);
+            if (hit) {
+                const int p = lcount + (int)__popcll(mh & ((1ull << lane) - 1ull));
+                if (p < a.pool_cap) {
+                    mpfmt_hit h;
+                    h.j = a.perm[jg]; h.pad = (int32_t)(jg | (ql << 26)); h.d = sqrt(d2);
+                    *reinterpret_cast<uint4*>(&mylog[p]) = *reinterpret_cast<const uint4*>(&h);   // one 16-byte store
+                } else {
+                    pool_over = 1;
+                }
+            }
+            lcount = __builtin_amdgcn_readfirstlane(lcount + (int)__popcll(mh));
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
 
-    // ---- extract the survivors of one chunk (4 accumulator tiles) into the queue ---------------------------------
-    // H: 16 sign bits per 32x32 tile t = cbk*2 + rb at bits [16t, 16t+16); bit (15 - r) <-> accumulator register r.
+    // ---- expand up to 64 records (lane = record, newest first) into the survivor queue ------------------------------
     unsigned long long surv = 0;
-    auto extract = [&](unsigned long long H, int64_t c) {
-        for (;;) {
-            const unsigned long long m = __ballot(H != 0);
-            if (!m) break;
-            if (qcount > MF_QCAP - 64) drain(64);
+    auto expand = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nrec = min(rcount, 64);
+        uint32_t meta = 0;
+        unsigned long long H = 0;
+        if (lane < nrec) { meta = s_rm[rcount - 1 - lane]; H = s_rh[rcount - 1 - lane]; }
+        const int cnt = (int)__popcll(H);
+        int incl = cnt;                                   // inclusive wave scan on the DPP network (row shifts, then row broadcasts)
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);       // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);       // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);       // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);       // row_shr:8
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+        // as many of the newest records as fit the survivor queue (a record holds at most 64 survivors; the queue is below 64 here)
+        const int room = MF_QSZ - qcount;
+        const unsigned long long fits = __ballot(lane < nrec && incl <= room);
+        const int nsub = (int)__popcll(fits);                                       // incl is monotone: the fitting lanes are 0 .. nsub - 1
+        const int total = __builtin_amdgcn_readlane(incl, nsub - 1);
+        if (lane >= nsub) H = 0;
+        int o = qcount + incl - cnt;
+        const uint32_t m6 = meta << 6;
+        while (__ballot(H != 0)) {
             if (H != 0) {
                 const int bpos = __ffsll((long long)H) - 1;
-                const int pos = qcount + (int)__popcll(m & ((1ull << lane) - 1ull));
-                s_qj[pos] = (uint32_t)c;
-                s_qq[pos] = ((uint32_t)lane << 6) | (uint32_t)bpos;
+                s_qs[o] = m6 | (uint32_t)bpos;
+                ++o;
                 H &= H - 1;
             }
-            const int np = (int)__popcll(m);
-            qcount = __builtin_amdgcn_readfirstlane(qcount + np);
-            surv += (unsigned long long)np;
         }
+        rcount = __builtin_amdgcn_readfirstlane(rcount - nsub);
+        qcount = __builtin_amdgcn_readfirstlane(qcount + total);
+        surv += (unsigned long long)total;
+        while (qcount >= 64) drain(64);
     };
 
-    // ---- main loop over a list of chunk ids ------------------------------------------------------------------------
+    // ---- main loop over the item's slice of the tile's chunk list ------------------------------------------------------
     unsigned long long tested = 0;
-    auto load_b = [&](int64_t c, uint4 (&bq)[2]) {
+    // B fragments come through a buffer descriptor: per-lane byte offset fixed for the whole kernel, chunk offset scalar
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.ops), 0, (int)(a.npad * (K8 ? 16 : 32)), 0x00020000);
+    const int voff = K8 ? lane * 16 : col * 32 + kb * 16;
+    auto load_b = [&](uint32_t c, u32x4 (&bq)[K8 ? 1 : 2]) {
         if constexpr (K8) {
-            const uint2* __restrict__ ops2 = reinterpret_cast<const uint2*>(a.ops);
-            const uint2 x0 = ops2[(c * 64 + col) * 2 + kb], x1 = ops2[(c * 64 + 32 + col) * 2 + kb];
-            bq[0] = make_uint4(x0.x, x0.y, 0u, 0u);
-            bq[1] = make_uint4(x1.x, x1.y, 0u, 0u);
+            bq[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (int)(c * 1024u), 0);
         } else {
-            bq[0] = a.ops[(c * 64 + col) * 2 + kb];
-            bq[1] = a.ops[(c * 64 + 32 + col) * 2 + kb];
+            bq[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (int)(c * 2048u), 0);
+            bq[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024, (int)(c * 2048u), 0);
         }
     };
-    // one chunk: 4 independent MFMAs back to back (2 query row blocks x 2 candidate column blocks), sign extraction
-    auto process = [&](int64_t c, const uint4 (&bq)[2]) {
+    // one chunk: 4 independent MFMAs back to back (2 query row blocks x 2 candidate column blocks), sign extraction, record push
+    // (the ring slot is refilled -- chunk cn -- as soon as the MFMAs have read it: no register copies, the load is in flight during
+    // this chunk's extraction and the following PF - 1 chunks)
+    auto process = [&](uint32_t c, u32x4 (&bq)[K8 ? 1 : 2], bool refill, uint32_t cn) {
         tested += 64ull * 64ull;
-        if (a.ablate & 4) { asm volatile("" :: "v"(bq[0].x), "v"(bq[1].x)); return; }
+        if (MF_ABLATE & 4) { asm volatile("" :: "v"(bq[0].x)); if (refill) load_b(cn, bq); return; }
         f32x16 acc0, acc1, acc2, acc3;
         if constexpr (K8) {
-            union { uint2 u; half4 h; } bf0, bf1;
-            bf0.u = make_uint2(bq[0].x, bq[0].y); bf1.u = make_uint2(bq[1].x, bq[1].y);
+            union { u32x2 u; half4 h; } bf0, bf1;
+            bf0.u = u32x2{bq[0].x, bq[0].y}; bf1.u = u32x2{bq[0].z, bq[0].w};
             acc0 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[0], bf0.h, cinit[0], 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[1], bf0.h, cinit[1], 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[0], bf1.h, cinit[0], 0, 0, 0);
             acc3 = __builtin_amdgcn_mfma_f32_32x32x8f16(aF4[1], bf1.h, cinit[1], 0, 0, 0);
         } else {
-            union { uint4 u; half8 h; } bf0, bf1;
+            union { u32x4 u; half8 h; } bf0, bf1;
             bf0.u = bq[0]; bf1.u = bq[1];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf0.h, zero16, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf0.h, zero16, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[0], bf1.h, zero16, 0, 0, 0);
             acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aF[1], bf1.h, zero16, 0, 0, 0);
         }
+        if (refill) load_b(cn, bq);
+        // H: 16 sign bits per 32x32 tile t = cbk*2 + rb at bits [16t, 16t+16); bit (15 - r) <-> accumulator register r.
         uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -548,29 +602,16 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             h3 = __builtin_amdgcn_alignbit(h3, __float_as_uint(acc3[r]), 31);
         }
         const unsigned long long H = (unsigned long long)(h0 | (h1 << 16)) | ((unsigned long long)(h2 | (h3 << 16)) << 32);
-        if (a.ablate & 1) { asm volatile("" :: "v"(H)); } else extract(H, c);
-    };
-    // B fragments are prefetched PF chunks ahead (a ring of PF register sets, statically indexed): the stream is
-    // latency x concurrency bound (L2 / MALL round trips), so more loads in flight per wavefront = more bandwidth.
-    constexpr int PF = (K8 && !W4) ? 4 : 2;
-    auto run_list = [&](int n) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (n <= 0 || (a.ablate & 8)) return;
-        uint4 ring[PF][2];
-#pragma unroll
-        for (int u = 0; u < PF; ++u) if (u < n) load_b((int64_t)s_list[u], ring[u]);
-        for (int k = 0; k < n; k += PF) {
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                if (k + u < n) {
-                    const int64_t c = (int64_t)s_list[k + u];
-                    uint4 cur[2];
-                    cur[0] = ring[u][0]; cur[1] = ring[u][1];
-                    if (k + u + PF < n) load_b((int64_t)s_list[k + u + PF], ring[u]);   // in flight during PF chunks of MFMAs
-                    process(c, cur);
-                }
+        if (MF_ABLATE & 1) { asm volatile("" :: "v"(H)); return; }
+        const unsigned long long m = __ballot(H != 0);
+        if (m) {
+            while (rcount > MF_RCAP - 64) expand();
+            if (H != 0) {
+                const int pos = rcount + (int)__popcll(m & ((1ull << lane) - 1ull));
+                s_rm[pos] = (c << 6) | (uint32_t)lane;
+                s_rh[pos] = H;
             }
+            rcount = __builtin_amdgcn_readfirstlane(rcount + (int)__popcll(m));
         }
     };
 
@@ -586,18 +627,44 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         const int64_t full = len / S;
         const int rem = (int)(len - full * S);
         auto off = [&](int64_t j) -> int { return (int)(((uint32_t)slice + (((uint32_t)j * 2654435761u) >> 24)) % (uint32_t)S); };
-        const int64_t cnt = full + ((rem > 0 && off(full) < rem) ? 1 : 0);
+        const int cnt = (int)(full + ((rem > 0 && off(full) < rem) ? 1 : 0));
         const uint32_t* __restrict__ lst = a.lists + tl * a.list_cap;
-        for (int64_t k0 = 0; k0 < cnt; k0 += MF_LIST) {
-            const int n = (int)min((int64_t)MF_LIST, cnt - k0);
-            __builtin_amdgcn_wave_barrier();
-            for (int e = lane; e < n; e += 64) s_list[e] = lst[(k0 + e) * S + off(k0 + e)];
-            run_list(n);
+        // the list is held 64 entries at a time in one VGPR (lane e = entry blk*64 + e), the following block is requested a block ahead
+        auto load_blk = [&](int blk) -> uint32_t {
+            const int e = blk * 64 + lane;
+            return (e < cnt) ? lst[(int64_t)e * S + off(e)] : 0u;
+        };
+        // B fragments are prefetched PF chunks ahead (a ring of PF register sets, statically indexed): the stream is
+        // latency x concurrency bound (L2 / MALL round trips), so more loads in flight per wavefront = more bandwidth.
+        constexpr int PF = (K8 && !W4) ? 4 : 2;
+        uint32_t lv = load_blk(0), lvn = load_blk(1);
+        u32x4 ring[PF][K8 ? 1 : 2];
+        if (!(MF_ABLATE & 8)) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) if (u < cnt) load_b((uint32_t)__builtin_amdgcn_readlane((int)lv, u), ring[u]);
+            for (int k = 0; k < cnt; k += PF) {
+                if ((k & 63) == 0 && k > 0) { lv = lvn; lvn = load_blk((k >> 6) + 1); }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int kk = k + u;
+                    if (kk < cnt) {
+                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)lv, kk & 63);
+                        const bool refill = kk + PF < cnt;
+                        const int kn = (kk + PF) & 63;
+                        const uint32_t cn = (uint32_t)((kn < PF) ? __builtin_amdgcn_readlane((int)lvn, kn) : __builtin_amdgcn_readlane((int)lv, kn));
+                        process(c, ring[u], refill, cn);
+                    }
+                }
+            }
         }
     }
+    while (rcount > 0) expand();
     while (qcount > 0) drain(min(qcount, 64));
 
-    if (MODE == 2 && pool_over) *a.pool_flag = 1;                 // overflow: the build falls back to a fill pass
+    if (MODE == 2) {
+        if (pool_over) *a.pool_flag = 1;                          // overflow: the build falls back to a fill pass
+        if (lane == 0) a.log_len[item] = min(lcount, (int)a.pool_cap);
+    }
     if (MODE != 1) {
         a.slice_cnt[(int64_t)slice * a.npad + qpos] = s_cnt[lane];
         // per-XCD-sharded counters: a single hot address saturates at ~88 atomics/us (156k items would cost 1.8 ms)
@@ -621,7 +688,8 @@ int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usab
     double ext = 0.0;
     for (int i = 0; i < d; ++i) ext = std::max(ext, ctx->bb_hi[i] - ctx->bb_lo[i]);
     *usable = false;
-    if (d > 12 || !(ext > 0.0) || !(r > 0.0)) return MPFMT_OK;
+    // (chunk ids and cell-sorted positions travel in 20 / 26 bits of the queue entries and hit records)
+    if (d > 12 || !(ext > 0.0) || !(r > 0.0) || ctx->ntiles * 64 > ((int64_t)1 << 26)) return MPFMT_OK;
     const double s = 1.0 / ext;
     const double e_c = 2.5e-4;                       // > 2^-12 (fp16 rounding on [0,1]) + fp32 conversion slack
     const double shell = 2.0 * std::sqrt((double)d) * e_c;
@@ -652,209 +720,217 @@ int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
     return MPFMT_OK;
 }
 
-// Column ordering for the single-pass build: one wavefront per sorted position.  The column's hits sit in S slot
-// lists (one per candidate slice, counts in slice_cnt); they are gathered and written to the final CSC column in
-// ascending row order -- contiguous stores, no staging CSC.
-//   - columns of up to 128 hits (an FMT* r-disc graph has a mean degree ~100) are ranked by BUCKETS: row ids are
-//     near-uniform over [0, N), so bucket = floor(id * 128 / N) (monotone in id) spreads them about one per bucket;
-//     an LDS histogram with returning atomics gives each hit its arrival slot, a 64-lane scan gives the bucket bases,
-//     and a hit's final rank is base + (number of smaller ids in its own bucket) -- a handful of LDS reads instead
-//     of a comparison against every other hit;
-//   - longer columns are ranked by counting through LDS.
-__device__ __forceinline__ mpfmt_hit load_hit(const mpfmt_hit* __restrict__ pool, long long p)
+// Column ordering for the single-pass build: one workgroup per tile.  The tile's hits sit in S logs (one per candidate
+// slice) in arrival order, columns mixed; the final CSC wants every column's rows in ascending sample index at colptr[perm[..]].
+//   1. headers: degree of each of the 64 columns (sum of the slice counts), prefix sums, output offsets;
+//   2. the logs are streamed with coalesced 16-byte loads and REGROUPED BY COLUMN in LDS (a returning LDS atomic per record
+//      gives its place inside its column's segment).  The staging area holds ORD_STG records; a tile with more hits is
+//      done in several column ranges, each streaming the logs again (L2 hits);
+//   3. one wavefront per column ranks the column's entries straight from LDS -- no dependent global round trips:
+//      columns of up to 192 hits by BUCKETS (row ids are near-uniform over [0, N), so bucket = floor(id * 128 / N), monotone
+//      in id, spreads them about one per bucket; an LDS histogram with returning atomics gives each hit its arrival slot, a
+//      64-lane scan the bucket bases, and a hit's rank is base + the number of smaller ids in its own bucket), longer
+//      ones by counting through the staged keys -- and writes rowval / nzval / rowpos of the column (one contiguous range).
+// Columns longer than ORD_STG never come here: the host checks the maximum degree (k_degree) and takes the two-pass build.
+#define ORD_THREADS 256
+#define ORD_WAVES 4
+#define ORD_STG 4096             // staged records per workgroup (64 KB of LDS)
+#define ORD_EPL 3                // hits per lane on the bucket path: columns of up to 192 hits
+struct ord_shared {
+    int32_t k[64];               // column degrees
+    int32_t cb[68];              // exclusive prefix of the degrees (cb[64] = hits of the tile)
+    int32_t cur[64];             // per-column fill cursors of the current column range
+    int32_t ln[MPFMT_MAXS + 4];  // log lengths
+    int32_t g1, pad_[3];
+    long long out[64];           // colptr of each column
+    int32_t wcnt[ORD_WAVES][128], wbase[ORD_WAVES][128];
+    int32_t wo[ORD_WAVES][64 * ORD_EPL + 8];
+};
+#define ORD_LDS_BYTES (ORD_STG * 16 + sizeof(ord_shared))
+
+__device__ __forceinline__ void wave_sync()
 {
-    const uint4 u = *reinterpret_cast<const uint4*>(&pool[p]);            // one 16-byte load
-    mpfmt_hit h;
-    *reinterpret_cast<uint4*>(&h) = u;
-    return h;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
-#define SLOT_LDS 1024
-#define SLOT_TC 16               // columns per wavefront
-#define SLOT_EPL 3               // hits per lane on the bucket path: columns of up to 192 hits
-// A column on its own is a chain of dependent round trips (perm -> slice counts / colptr -> slot entries -> stores), so
-// a wavefront takes SLOT_TC consecutive sorted positions: their headers are loaded together (lane = column, the
-// per-slice prefix sums go to LDS), and the slot entries of column c+1 are requested before column c is ranked.
-__global__ __launch_bounds__(64) void k_sortcols_slots(const mpfmt_hit* __restrict__ pool,
-                                                       int64_t capc, int S, const int32_t* __restrict__ slice_cnt, int64_t npad,
-                                                       int64_t tile_begin, int64_t pos_begin, int64_t pos_end,
-                                                       const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm,
-                                                       int32_t* __restrict__ rowval, double* __restrict__ nzval, int32_t* __restrict__ rowpos,
-                                                       uint32_t bucket_mul, const int32_t* __restrict__ spec_fail)
+__global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __restrict__ logs, int64_t capL, int S,
+                                                            const int32_t* __restrict__ slice_cnt, int64_t npad,
+                                                            const int32_t* __restrict__ log_len, int64_t tile_begin, int64_t tile_end,
+                                                            const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm,
+                                                            int32_t* __restrict__ rowval, double* __restrict__ nzval, int32_t* __restrict__ rowpos,
+                                                            uint32_t bucket_mul, const int32_t* __restrict__ spec_fail)
 {
     if (spec_fail && *spec_fail) return;                     // speculative step whose capacities did not hold: redone by the host
-    __shared__ __attribute__((aligned(16))) int32_t s_o[SLOT_LDS + 4];
-    __shared__ __attribute__((aligned(16))) int32_t s_cnt[128], s_base[128];
-    __shared__ int32_t s_pre[SLOT_TC][MPFMT_MAXS + 1];      // [column][slice] first entry of the slice's hits
-    const int lane = threadIdx.x;
-    const long long sstride = 64 * capc;
-    const int64_t ntasks = (pos_end - pos_begin + SLOT_TC - 1) / SLOT_TC;
-    for (int64_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
-        const int64_t sp0 = pos_begin + task * SLOT_TC;
+    extern __shared__ __attribute__((aligned(16))) char ord_smem[];
+    uint4* const stage = reinterpret_cast<uint4*>(ord_smem);
+    ord_shared& sh = *reinterpret_cast<ord_shared*>(ord_smem + ORD_STG * 16);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int32_t* const w_cnt = sh.wcnt[wave];
+    int32_t* const w_base = sh.wbase[wave];
+    int32_t* const w_o = sh.wo[wave];
+    for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
         __syncthreads();
-        // ---- headers, lane = column ----
-        int kk = 0;
-        int64_t outp = 0;
-        if (lane < SLOT_TC && sp0 + lane < pos_end) {
-            const int64_t sp = sp0 + lane;
+        // ---- headers ----
+        if (tid < 64) {
+            const int64_t sp = tile * 64 + tid;
             const int32_t o = perm[sp];
-            int run = 0;
-#pragma unroll 4
-            for (int sl = 0; sl < S; ++sl) { s_pre[lane][sl] = run; run += slice_cnt[(int64_t)sl * npad + sp]; }
-            s_pre[lane][S] = run;
-            if (o >= 0) { kk = run; outp = colptr[o]; }
+            int k = 0;
+            for (int sl = 0; sl < S; ++sl) k += slice_cnt[(int64_t)sl * npad + sp];
+            if (o < 0) k = 0;
+            sh.k[tid] = k;
+            sh.out[tid] = (o >= 0) ? colptr[o] : 0;
+            int inc = k;
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);       // row_shr:1
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);       // row_shr:2
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+            sh.cb[tid + 1] = inc;
+            if (tid == 0) sh.cb[0] = 0;
+        } else if (tid < 64 + S) {
+            sh.ln[tid - 64] = log_len[(tile - tile_begin) * S + (tid - 64)];
         }
         __syncthreads();
-        // entry e of column c's concatenated slot lists -> pool index
-        auto col_base = [&](int c) -> long long {
-            const int64_t sp = sp0 + c;
-            return (((long long)((sp >> 6) - tile_begin)) * S * 64 + (long long)(sp & 63)) * capc;
-        };
-        auto src = [&](int c, long long col0, int e) -> long long {
-            if (S <= 4) {
-                // (uniform) few slices -- the usual case, 3 at one shard: the column's prefix sums are wave-uniform LDS reads,
-                // the slice is a count of comparisons (no per-lane search through LDS)
-                const int p1 = s_pre[c][1], p2 = s_pre[c][S > 2 ? 2 : S], p3 = s_pre[c][S > 3 ? 3 : S];
-                const int g1 = (S > 1) & (e >= p1), g2 = (S > 2) & (e >= p2), g3 = (S > 3) & (e >= p3);
-                const int sl = g1 + g2 + g3;
-                const int first = g3 ? p3 : g2 ? p2 : g1 ? p1 : 0;
-                return col0 + (long long)sl * sstride + (e - first);
+        int g0 = 0;
+        while (g0 < 64) {
+            // ---- the next column range [g0, g1) that fits the staging area ----
+            if (tid < 64) {
+                const bool ok = tid >= g0 && (sh.cb[tid + 1] - sh.cb[g0] <= ORD_STG);
+                const unsigned long long m = __ballot(ok);
+                if (tid == 0) sh.g1 = g0 + (int)__popcll(m);
+                sh.cur[tid] = 0;
             }
-            int sl = 0;                                 // the last slice whose first entry is <= e (prefix sums: binary search)
+            __syncthreads();
+            int g1 = sh.g1;
+            const bool skip = g1 == g0;                      // a column beyond the staging area (excluded by the host): left out
+            if (skip) g1 = g0 + 1;
+            const int gb = sh.cb[g0];
+            const int ghits = sh.cb[g1] - gb;
+            // ---- stream the tile's logs, regroup the range's records by column ----
+            if (!skip && ghits > 0) {
+                for (int sl = 0; sl < S; ++sl) {
+                    const int n = sh.ln[sl];
+                    const uint4* __restrict__ lg = reinterpret_cast<const uint4*>(logs + ((tile - tile_begin) * S + sl) * capL);
+                    for (int i0 = 0; i0 < n; i0 += ORD_THREADS * 4) {
+                        uint4 rec[4];
 #pragma unroll
-            for (int step = MPFMT_MAXS / 2; step > 0; step >>= 1) {
-                const int t = sl + step;
-                if (t < S && s_pre[c][t] <= e) sl = t;
-            }
-            return col0 + (long long)sl * sstride + (e - s_pre[c][sl]);
-        };
-        // up to SLOT_EPL entries per lane: entry q of a lane is the column's hit 64 q + lane.  (Two per lane covered columns of up to
-        // 128 hits; on the north star a third of the columns -- the interior of the cube, up to 180 neighbours -- then took the
-        // counting path, two to three times the instructions.)
-        struct ents { int32_t m[SLOT_EPL], p[SLOT_EPL]; double d[SLOT_EPL]; };
-        auto fetch = [&](int c, ents& E) {
-            const int k = __builtin_amdgcn_readlane(kk, c);
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = i0 + u * ORD_THREADS + tid;
+                            rec[u] = (i < n) ? lg[i] : make_uint4(0u, 0xffffffffu, 0u, 0u);
+                        }
 #pragma unroll
-            for (int q = 0; q < SLOT_EPL; ++q) { E.m[q] = 0; E.p[q] = 0; E.d[q] = 0.0; }
-            if (k == 0 || k > 64 * SLOT_EPL) return;
-            const long long col0 = col_base(c);
-#pragma unroll
-            for (int q = 0; q < SLOT_EPL; ++q) {
-                if (64 * q < k) {                                             // (uniform)
-                    if (64 * q + lane < k) { const mpfmt_hit h = load_hit(pool, src(c, col0, 64 * q + lane)); E.m[q] = h.j; E.p[q] = h.pad; E.d[q] = h.d; }
-                }
-            }
-        };
-        ents cur, nxt;
-        fetch(0, cur);
-        for (int c = 0; c < SLOT_TC; ++c) {
-#pragma unroll
-            for (int q = 0; q < SLOT_EPL; ++q) { nxt.m[q] = 0; nxt.p[q] = 0; nxt.d[q] = 0.0; }
-            if (c + 1 < SLOT_TC) fetch(c + 1, nxt);
-            const int k = __builtin_amdgcn_readlane(kk, c);
-            const int64_t out = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)outp >> 32), c) << 32) |
-                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)outp, c));
-            if (k > 0 && k <= 64 * SLOT_EPL) {
-                __syncthreads();
-                *reinterpret_cast<int2*>(&s_cnt[2 * lane]) = make_int2(0, 0);
-                bool has[SLOT_EPL]; int bk[SLOT_EPL], arr[SLOT_EPL];
-#pragma unroll
-                for (int q = 0; q < SLOT_EPL; ++q) {
-                    has[q] = 64 * q + lane < k;
-                    // bucket_mul = floor(2^32 * 128 / N) (0: N <= 128, the id is its own bucket)
-                    bk[q] = bucket_mul ? min(127, (int)__umulhi((uint32_t)cur.m[q], bucket_mul)) : (cur.m[q] & 127);
-                }
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < SLOT_EPL; ++q) arr[q] = has[q] ? atomicAdd(&s_cnt[bk[q]], 1) : 0;
-                __syncthreads();
-                {   // exclusive scan of the 128 bucket counts, two per lane
-                    const int2 cc = *reinterpret_cast<const int2*>(&s_cnt[2 * lane]);
-                    const int tot = cc.x + cc.y;
-                    // inclusive wave scan on the DPP network: four shifts inside the 16-lane rows (zero fill), then lane 15 of
-                    // rows 0 / 2 to rows 1 / 3, then lane 31 to rows 2 and 3 -- six adds, no LDS crossbar
-                    int inc = tot;
-                    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);       // row_shr:1
-                    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);       // row_shr:2
-                    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
-                    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
-                    inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
-                    inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
-                    const int excl = inc - tot;
-                    *reinterpret_cast<int2*>(&s_base[2 * lane]) = make_int2(excl, excl + cc.x);
-                }
-                __syncthreads();
-                int base[SLOT_EPL], nin[SLOT_EPL];
-#pragma unroll
-                for (int q = 0; q < SLOT_EPL; ++q) {
-                    base[q] = s_base[bk[q]]; nin[q] = s_cnt[bk[q]];
-                    if (has[q]) s_o[base[q] + arr[q]] = cur.m[q];                  // ids grouped by bucket (arrival order inside)
-                }
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < SLOT_EPL; ++q) {
-                    if (64 * q < k) {                                             // (uniform)
-                        int rk = 0;
-                        if (has[q]) for (int m = 0; m < nin[q]; ++m) rk += (s_o[base[q] + m] < cur.m[q]) ? 1 : 0;
-                        if (has[q]) {
-                            const int64_t o = out + base[q] + rk;
-                            rowval[o] = cur.m[q]; nzval[o] = cur.d[q]; if (rowpos) rowpos[o] = cur.p[q];
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = i0 + u * ORD_THREADS + tid;
+                            const int col = (int)(rec[u].y >> 26);
+                            if (i < n && col >= g0 && col < g1) {
+                                const int pos = sh.cb[col] - gb + atomicAdd(&sh.cur[col], 1);
+                                if (pos < ORD_STG) stage[pos] = rec[u];
+                            }
                         }
                     }
                 }
-            } else if (k > 64 * SLOT_EPL) {
-                // long columns: rank by counting through LDS (streamed in windows beyond SLOT_LDS hits)
-                const long long col0 = col_base(c);
-                __syncthreads();
-                if (k <= SLOT_LDS) {
-                    for (int e = lane; e < k; e += 64) s_o[e] = pool[src(c, col0, e)].j;
-                    if (lane < 4) s_o[k + lane] = 0x7fffffff;    // pad so the rank loop can run in fours
-                    __syncthreads();
-                    for (int e0 = 0; e0 < k; e0 += 64) {
-                        const int e = e0 + lane;
-                        const int32_t mine = (e < k) ? s_o[e] : 0x7fffffff;
-                        const double dm = (e < k) ? pool[src(c, col0, e)].d : 0.0;   // in flight during the rank loop
-                        const int32_t pm = (e < k) ? pool[src(c, col0, e)].pad : 0;
-                        int32_t r = 0;
-                        for (int j = 0; j < k; j += 4) {
-                            const int4 v = *reinterpret_cast<const int4*>(&s_o[j]);   // wave-uniform ds_read_b128 (broadcast)
-                            r += (v.x < mine) ? 1 : 0; r += (v.y < mine) ? 1 : 0;
-                            r += (v.z < mine) ? 1 : 0; r += (v.w < mine) ? 1 : 0;
+            }
+            __syncthreads();
+            // ---- one wavefront per column: rank and write ----
+            if (!skip) for (int c = g0 + wave; c < g1; c += ORD_WAVES) {
+                const int k = sh.k[c];
+                if (k == 0) continue;
+                const int base = sh.cb[c] - gb;
+                const int64_t out = sh.out[c];
+                if (k <= 64 * ORD_EPL) {
+                    int32_t em[ORD_EPL], ep[ORD_EPL]; double ed[ORD_EPL];
+                    bool has[ORD_EPL]; int bk[ORD_EPL], arr[ORD_EPL];
+                    wave_sync();
+                    *reinterpret_cast<int2*>(&w_cnt[2 * lane]) = make_int2(0, 0);
+#pragma unroll
+                    for (int q = 0; q < ORD_EPL; ++q) {
+                        has[q] = 64 * q + lane < k;
+                        em[q] = 0; ep[q] = 0; ed[q] = 0.0;
+                        if (64 * q < k && has[q]) {
+                            const uint4 r = stage[base + 64 * q + lane];
+                            em[q] = (int32_t)r.x; ep[q] = (int32_t)(r.y & 0x3ffffffu);
+                            ed[q] = __hiloint2double((int)r.w, (int)r.z);
                         }
-                        if (e < k) { rowval[out + r] = mine; nzval[out + r] = dm; if (rowpos) rowpos[out + r] = pm; }
+                        // bucket_mul = floor(2^32 * 128 / N) (0: N <= 128, the id is its own bucket)
+                        bk[q] = bucket_mul ? min(127, (int)__umulhi((uint32_t)em[q], bucket_mul)) : (em[q] & 127);
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int q = 0; q < ORD_EPL; ++q) arr[q] = has[q] ? atomicAdd(&w_cnt[bk[q]], 1) : 0;
+                    wave_sync();
+                    {   // exclusive scan of the 128 bucket counts, two per lane
+                        const int2 cc = *reinterpret_cast<const int2*>(&w_cnt[2 * lane]);
+                        const int tot = cc.x + cc.y;
+                        int inc = tot;
+                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);       // row_shr:1
+                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);       // row_shr:2
+                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
+                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
+                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+                        const int excl = inc - tot;
+                        *reinterpret_cast<int2*>(&w_base[2 * lane]) = make_int2(excl, excl + cc.x);
+                    }
+                    wave_sync();
+                    int bs[ORD_EPL], nin[ORD_EPL];
+#pragma unroll
+                    for (int q = 0; q < ORD_EPL; ++q) {
+                        bs[q] = w_base[bk[q]]; nin[q] = w_cnt[bk[q]];
+                        if (has[q]) w_o[bs[q] + arr[q]] = em[q];                  // ids grouped by bucket (arrival order inside)
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int q = 0; q < ORD_EPL; ++q) {
+                        if (64 * q < k) {                                             // (uniform)
+                            int rk = 0;
+                            if (has[q]) for (int m = 0; m < nin[q]; ++m) rk += (w_o[bs[q] + m] < em[q]) ? 1 : 0;
+                            if (has[q]) {
+                                const int64_t o = out + bs[q] + rk;
+                                rowval[o] = em[q]; nzval[o] = ed[q]; if (rowpos) rowpos[o] = ep[q];
+                            }
+                        }
                     }
                 } else {
+                    // long columns: rank by counting over the staged keys (wave-uniform LDS reads)
                     for (int e0 = 0; e0 < k; e0 += 64) {
                         const int e = e0 + lane;
-                        const long long pe = (e < k) ? src(c, col0, e) : col0;
-                        const int32_t mine = (e < k) ? pool[pe].j : 0x7fffffff;
-                        int64_t rank = 0;
-                        for (int c0 = 0; c0 < k; c0 += SLOT_LDS) {
-                            const int cn = min(SLOT_LDS, k - c0);
-                            __syncthreads();
-                            for (int j = lane; j < cn; j += 64) s_o[j] = pool[src(c, col0, c0 + j)].j;
-                            __syncthreads();
-                            for (int j = 0; j < cn; ++j) rank += (s_o[j] < mine) ? 1 : 0;
+                        uint4 r = make_uint4(0x7fffffffu, 0u, 0u, 0u);
+                        if (e < k) r = stage[base + e];
+                        const int32_t mine = (int32_t)r.x;
+                        int32_t rk = 0;
+                        for (int j = 0; j < k; ++j) rk += ((int32_t)stage[base + j].x < mine) ? 1 : 0;
+                        if (e < k) {
+                            rowval[out + rk] = mine; nzval[out + rk] = __hiloint2double((int)r.w, (int)r.z);
+                            if (rowpos) rowpos[out + rk] = (int32_t)(r.y & 0x3ffffffu);
                         }
-                        if (e < k) { rowval[out + rank] = mine; nzval[out + rank] = pool[pe].d; if (rowpos) rowpos[out + rank] = pool[pe].pad; }
                     }
                 }
             }
-            cur = nxt;
+            __syncthreads();
+            g0 = g1;
         }
     }
 }
 
-int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx, const int32_t* spec_fail)
+int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail)
 {
-    const int64_t pb = ctx->tile_begin * 64, pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
-    if (ctx->nnz == 0 || pe <= pb) return MPFMT_OK;
+    const int64_t nt = ctx->tile_end - ctx->tile_begin;
+    if (ctx->nnz == 0 || nt <= 0) return MPFMT_OK;
     int32_t rc_;
     // option sweep_sorted: also keep every row's cell-sorted position, so the sweep can gather from Xs (see kernels_sweep.hip)
     if (ctx->sweep_sorted && (rc_ = mpfmt_ensure(ctx, (void**)&ctx->rowpos, sizeof(int32_t) * (size_t)std::max<int64_t>(std::max(ctx->nnz, ctx->nnz_cap), 1)))) return rc_;
-    const unsigned nb = (unsigned)std::min<int64_t>((pe - pb + SLOT_TC - 1) / SLOT_TC, 1 << 20);
-    hipLaunchKernelGGL(k_sortcols_slots, dim3(nb), dim3(64), 0, ctx->stream, ctx->pool, ctx->pool_cap, ctx->S,
-                       ctx->slice_cnt, ctx->ntiles * 64, ctx->tile_begin, pb, pe, ctx->colptr, ctx->perm, ctx->rowval, ctx->nzval, ctx->sweep_sorted ? ctx->rowpos : nullptr,
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_order_logs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORD_LDS_BYTES));
+        attr_set = true;
+    }
+    const unsigned nb = (unsigned)std::min<int64_t>(nt, 1 << 20);
+    hipLaunchKernelGGL(k_order_logs, dim3(nb), dim3(ORD_THREADS), ORD_LDS_BYTES, ctx->stream, ctx->pool, ctx->pool_cap, ctx->S,
+                       ctx->slice_cnt, ctx->ntiles * 64, ctx->log_len, ctx->tile_begin, ctx->tile_end, ctx->colptr, ctx->perm,
+                       ctx->rowval, ctx->nzval, ctx->sweep_sorted ? ctx->rowpos : nullptr,
                        ctx->N > 128 ? (uint32_t)((128ull << 32) / (uint64_t)ctx->N) : 0u, spec_fail);
     HIPCHK(ctx, hipGetLastError());
     ctx->rowpos_valid = ctx->sweep_sorted != 0;   // every entry's row is also known by its cell-sorted position (the sweep gathers from Xs)
@@ -928,7 +1004,6 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.r2 = r * r; a.rpad = r * (1.0 + 1e-9) + 1e-300; a.negT = negT;
     a.S = ctx->S;
     a.xcd_mode = ctx->mf_xcd_mode;
-    a.ablate = ctx->mf_ablate;
     a.blk_begin = ctx->tile_begin;                             // first tile of the shard
     a.nitems = (ctx->tile_end - ctx->tile_begin) * ctx->S;
     a.npad = ctx->ntiles * 64; a.ntiles = ctx->ntiles;
@@ -937,7 +1012,7 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.pairs = (MODE == 1) ? nullptr : ctx->d_pairs;              // 256 x {tested, survivors} sharded counters
     a.survivors = nullptr;
     a.pool_flag = ctx->pool_flag; a.pool_cap = ctx->pool_cap;
-    a.pool = ctx->pool;
+    a.pool = ctx->pool; a.log_len = ctx->log_len;
     if (a.nitems <= 0) return MPFMT_OK;
     const int64_t gran = NXCD * (int64_t)std::max(1, a.xcd_mode);
     const unsigned nblk = (unsigned)(((a.nitems + gran - 1) / gran) * gran);

@@ -47,6 +47,8 @@ struct wf_ctr {
     double cmin;                  // lowest open cost at this step
     int64_t imin;
     int64_t tot[4];               // sums of the per-block statistics: batch nodes, samples examined, connected, edge checks
+    int32_t ended;                // latched by the first k_wf_apply_min that finds a goal batch recorded: k_wf_select, which must not
+    int32_t pad_;                 // read goal_cbits (its own blocks write it), returns on this flag in the steps enqueued after the end
 };
 enum { WF_NZ = 0, WF_NX = 1, WF_NCONN = 2, WF_CHECKS = 3 };
 
@@ -177,7 +179,13 @@ __global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __
                                                      const double* __restrict__ C, double* __restrict__ part_c,
                                                      int64_t* __restrict__ part_i, wf_ctr* __restrict__ ctr)
 {
-    if (wf_stop(ctr)) return;
+    if (wf_stop(ctr)) {
+        // the batch of the previous step held a goal node: the steps enqueued behind it are void.  k_wf_select cannot test
+        // goal_cbits itself (see there), so the end is latched here, one kernel ahead of it on the stream (without
+        // the latch every later select of the group re-appended the same batch to zlist and counted it into nz again)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && ctr->goal_cbits != ~0ull) ctr->ended = 1;
+        return;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {              // (no other thread of this kernel touches these fields)
         ctr->tot[WF_NZ] += ctr->nz; ctr->tot[WF_NX] += ctr->nx;
         ctr->iters += 1; ctr->ntrip = 0; ctr->nz = 0; ctr->nx = 0;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, con
                                                   double band, int single, wf_goal G, int32_t* __restrict__ zlist,
                                                   wf_ctr* __restrict__ ctr)
 {
-    if (ctr->done) return;
+    if (ctr->done || ctr->ended) return;
     double cm = 0.0; int64_t im = -1;
     for (int p = threadIdx.x; p < nparts; p += 64) {
         const double c = part_c[p]; const int64_t i = part_i[p];

@@ -43,7 +43,8 @@ struct mpfmt_ss {                        // BoundedStateSpace bounds (statespace
     double hi[MPFMT_MAX_DIM];
 };
 
-// one hit of the single-pass build: row sample index + distance in ONE 16-byte record (one store, one sector)
+// one hit of the single-pass build: row sample index, (cell-sorted position of the row | column within the tile << 26), distance
+// in ONE 16-byte record
 struct __attribute__((aligned(16))) mpfmt_hit { int32_t j; int32_t pad; double d; };
 
 // 2-D SAT world (kernels_sat2d.hip): a Circle or a convex Polygon with the fields the predicates read
@@ -126,8 +127,10 @@ struct mpfmt_ctx {
     // single-pass hit pool (MFMA path): hits found by the count pass are kept, so the fill pass is a scatter
     int32_t use_pool = 1;                // option "rdisc_pool"
     int32_t* pool_flag = nullptr;        // overflow flag
-    int64_t pool_cap = 0;                // capacity of one (item, column) slot list
-    mpfmt_hit* pool = nullptr;           // [items][64 columns][pool_cap] hit records
+    int64_t pool_cap = 0;                // capacity of one item's log, in records
+    mpfmt_hit* pool = nullptr;           // [items][pool_cap] hit records: one append log per (tile, slice)
+    int32_t* log_len = nullptr;          // [items] records in each log
+    int64_t max_deg = 0;                 // longest column of the counted graph (k_degree)
     int32_t pool_slack = 1;              // doubled after a build whose slot lists overflowed
     bool pool_valid = false;             // pool holds exactly the nnz hits of the counted graph
     // speculative single-sync step (mpfmt_graph_step): capacities of the previous identical build are trusted, every kernel
@@ -236,7 +239,8 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usable);
 int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx);
 template <int MODE> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT);
-int32_t mpfmt_sortcols_slots(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr);
+int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr);
+#define MPFMT_ORD_MAXDEG 4096        // longest column the log-ordering kernel stages in LDS (ORD_STG in kernels_rdisc_mfma.hip)
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);
