@@ -710,16 +710,17 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             want = std::min(1.0, ball / vol) * (double)N * (double)(nt * 64) * 1.15 + 64.0 * (double)N;
         }
         want = std::min(want, (double)N * (double)(nt * 64));
-        // every (tile, slice) item owns a fixed-capacity append log; an item of the interior of the domain finds ~1.7x the
-        // mean, so logs get 2.2x the mean plus a fixed slack -- an overflow falls back to the fill pass
+        // every (tile, slice) item owns four fixed-capacity append logs (one per 16 columns of the tile); an item of the
+        // interior of the domain finds ~1.7x the mean, so logs get 2.3x the mean plus a fixed slack -- an overflow falls back
+        // to the fill pass
         const int64_t items = nt * S;
         // (a build that overflowed doubles the slack of the following ones)
-        const int64_t capc = (((int64_t)(want / (double)items * 2.2) + 256) * ctx->pool_slack + 3) / 4 * 4;
-        if ((double)capc * (double)items * 16.0 > 96e9) pool = false;      // cap the logs at 96 GB of the 288
+        const int64_t capc = (((int64_t)(want / ((double)items * 4.0) * 2.3) + 96) * ctx->pool_slack + 3) / 4 * 4;
+        if ((double)capc * (double)items * 64.0 > 96e9) pool = false;      // cap the logs at 96 GB of the 288
         else {
-            const size_t cap = (size_t)capc * (size_t)items;
+            const size_t cap = (size_t)capc * (size_t)items * 4;
             if ((rc = ensure(ctx, (void**)&ctx->pool, sizeof(mpfmt_hit) * cap))) return rc;
-            if ((rc = ensure(ctx, (void**)&ctx->log_len, sizeof(int32_t) * (size_t)items))) return rc;
+            if ((rc = ensure(ctx, (void**)&ctx->log_len, sizeof(int32_t) * (size_t)items * 4))) return rc;
             if (!ctx->pool_flag) HIPCHK(ctx, hipMalloc((void**)&ctx->pool_flag, sizeof(int32_t)));
             HIPCHK(ctx, hipMemsetAsync(ctx->pool_flag, 0, sizeof(int32_t), ctx->stream));
             ctx->pool_cap = capc;

@@ -66,9 +66,10 @@ struct mf_args {
     unsigned long long* survivors;
     // MODE 2 (single pass): exact hits are appended to the item's log while they are counted
     int32_t* pool_flag;             // set to 1 when a log overflows (the build then falls back to a fill pass)
-    long long pool_cap;             // capacity of ONE item's log, in records
-    mpfmt_hit* pool;                // [items][pool_cap] (sample index of the row, cell-sorted position | column << 26, sqrt(d2)) records
-    int32_t* log_len;               // [items] records in each log
+    long long pool_cap;             // capacity of ONE log, in records
+    mpfmt_hit* pool;                // [items][4][pool_cap] (sample index of the row, cell-sorted position | column << 26, sqrt(d2)) records:
+                                    // an item keeps one log per 16 columns of its tile
+    int32_t* log_len;               // [items][4] records in each log
 };
 
 __device__ __forceinline__ int cell_of_m(double x, double lo, double inv_w, int g)
@@ -362,6 +363,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     __shared__ unsigned long long s_rh[MF_RCAP];          //               the lane's 64 sign bits of that chunk
     __shared__ uint32_t s_qs[MF_QSZ];                     // survivor queue: chunk << 12 | finding lane << 6 | sign-bit position
     __shared__ int32_t s_cnt[64];
+    __shared__ int32_t s_lc[4];                           // records in the item's four logs
     __shared__ int64_t s_base[MODE == 1 ? 64 : 1];
 
     const int lane = threadIdx.x;
@@ -389,6 +391,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
 #pragma unroll
     for (int i = 0; i < D; ++i) s_q[lane * D + i] = a.Xs[qpos * D + i];
     s_cnt[lane] = 0;
+    if (lane < 4) s_lc[lane] = 0;
     constexpr bool FILL = (MODE == 1);
     if (FILL) {
         int64_t base = a.tptr[qpos];
@@ -456,9 +459,8 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     // ---- refine: exact fp64 test of n queued survivors (lane = survivor) ---------------------------------------
     int qcount = 0;                                           // wave-uniform survivor queue length
     int rcount = 0;                                           // wave-uniform record queue length
-    int lcount = 0;                                           // hits appended to this item's log so far (wave-uniform)
     int pool_over = 0;
-    mpfmt_hit* const __restrict__ mylog = (MODE == 2) ? a.pool + (long long)item * a.pool_cap : nullptr;
+    mpfmt_hit* const __restrict__ mylog = (MODE == 2) ? a.pool + (long long)item * 4 * a.pool_cap : nullptr;
     auto drain = [&](int n) {
         // takes the LAST n queue entries (order is irrelevant: columns are sorted afterwards), so nothing moves
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -497,21 +499,22 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                 }
             }
         }
-        if (MODE == 2) {
-            // single pass: the batch's hits go to the end of the item's log, compacted -- one contiguous run of 16-byte
-            // records per drain (row sample index, cell-sorted position | column << 26, edge cost)
-            const unsigned long long mh = __ballot(hit);
-            if (hit) {
-                const int p = lcount + (int)__popcll(mh & ((1ull << lane) - 1ull));
-                if (p < a.pool_cap) {
-                    mpfmt_hit h;
-                    h.j = a.perm[jg]; h.pad = (int32_t)(jg | (ql << 26)); h.d = sqrt(d2);
-                    *reinterpret_cast<uint4*>(&mylog[p]) = *reinterpret_cast<const uint4*>(&h);   // one 16-byte store
-                } else {
-                    pool_over = 1;
-                }
+        if (MODE == 2 && hit) {
+            // single pass: the hit goes to one of the item's FOUR logs, one per 16 columns of its tile, so that k_order_logs can
+            // regroup a quarter tile (about 1 700 hits) in one pass through LDS.  Its place is a returning LDS atomic on the log's
+            // counter (four addresses per wavefront: the LDS pipe serialises them beside the other wavefronts' VALU work -- four
+            // ballots with per-lane selects cost this VALU-bound kernel 50 instructions per drain), so a drain's hits still
+            // land in four contiguous runs of 16-byte records: row sample index, cell-sorted position | column << 26, d2 (the
+            // square root is taken by the ordering kernel, which has the VALU slack)
+            const int g = (int)(ql >> 4);
+            const int p = atomicAdd(&s_lc[g], 1);
+            if (p < a.pool_cap) {
+                mpfmt_hit h;
+                h.j = a.perm[jg]; h.pad = (int32_t)(jg | (ql << 26)); h.d = d2;
+                *reinterpret_cast<uint4*>(&mylog[(long long)g * a.pool_cap + p]) = *reinterpret_cast<const uint4*>(&h);   // one 16-byte store
+            } else {
+                pool_over = 1;
             }
-            lcount = __builtin_amdgcn_readfirstlane(lcount + (int)__popcll(mh));
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -663,7 +666,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
 
     if (MODE == 2) {
         if (pool_over) *a.pool_flag = 1;                          // overflow: the build falls back to a fill pass
-        if (lane == 0) a.log_len[item] = min(lcount, (int)a.pool_cap);
+        if (lane < 4) a.log_len[item * 4 + lane] = min(s_lc[lane], (int)a.pool_cap);
     }
     if (MODE != 1) {
         a.slice_cnt[(int64_t)slice * a.npad + qpos] = s_cnt[lane];
@@ -720,40 +723,57 @@ int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
     return MPFMT_OK;
 }
 
-// Column ordering for the single-pass build: one workgroup per tile.  The tile's hits sit in S logs (one per candidate
-// slice) in arrival order, columns mixed; the final CSC wants every column's rows in ascending sample index at colptr[perm[..]].
-//   1. headers: degree of each of the 64 columns (sum of the slice counts), prefix sums, output offsets;
+// Column ordering for the single-pass build: one workgroup per QUARTER TILE (16 columns).  The quarter's hits sit in S logs (one
+// per candidate slice) in arrival order, columns mixed; the final CSC wants every column's rows in ascending sample index at
+// colptr[perm[..]].
+//   1. headers: degree of each of the 16 columns (sum of the slice counts), prefix sums, output offsets;
 //   2. the logs are streamed with coalesced 16-byte loads and REGROUPED BY COLUMN in LDS (a returning LDS atomic per record
-//      gives its place inside its column's segment).  The staging area holds ORD_STG records; a tile with more hits is
-//      done in several column ranges, each streaming the logs again (L2 hits);
+//      gives its place inside its column's segment).  The staging area holds ORD_STG records; a quarter with more hits is
+//      done in several column ranges, each streaming the logs again;
 //   3. one wavefront per column ranks the column's entries straight from LDS -- no dependent global round trips:
 //      columns of up to 192 hits by BUCKETS (row ids are near-uniform over [0, N), so bucket = floor(id * 128 / N), monotone
 //      in id, spreads them about one per bucket; an LDS histogram with returning atomics gives each hit its arrival slot, a
 //      64-lane scan the bucket bases, and a hit's rank is base + the number of smaller ids in its own bucket), longer
 //      ones by counting through the staged keys -- and writes rowval / nzval / rowpos of the column (one contiguous range).
 // Columns longer than ORD_STG never come here: the host checks the maximum degree (k_degree) and takes the two-pass build.
-#define ORD_THREADS 256
-#define ORD_WAVES 4
-#define ORD_STG 4096             // staged records per workgroup (64 KB of LDS)
+#define ORD_THREADS 512
+#define ORD_WAVES 8
+#define ORD_COLS 16              // columns per workgroup = columns per log
+#define ORD_STG 3072             // staged records per workgroup (48 KB of LDS)
 #define ORD_EPL 3                // hits per lane on the bucket path: columns of up to 192 hits
-struct ord_shared {
-    int32_t k[64];               // column degrees
-    int32_t cb[68];              // exclusive prefix of the degrees (cb[64] = hits of the tile)
-    int32_t cur[64];             // per-column fill cursors of the current column range
+static_assert(ORD_STG >= MPFMT_ORD_MAXDEG, "a column the host lets through must fit the staging area");
+struct ord_hdr {
+    int32_t k[ORD_COLS];         // column degrees
+    int32_t cb[ORD_COLS + 4];    // exclusive prefix of the degrees (cb[ORD_COLS] = hits of the quarter)
     int32_t ln[MPFMT_MAXS + 4];  // log lengths
+    long long out[ORD_COLS];     // colptr of each column
+};
+struct ord_shared {
+    ord_hdr h[2];                // headers of the quarter in work and of the next one (prefetched)
+    int32_t cur[ORD_COLS];       // per-column fill cursors of the current column range
     int32_t g1, pad_[3];
-    long long out[64];           // colptr of each column
     int32_t wcnt[ORD_WAVES][128], wbase[ORD_WAVES][128];
     int32_t wo[ORD_WAVES][64 * ORD_EPL + 8];
 };
 #define ORD_LDS_BYTES (ORD_STG * 16 + sizeof(ord_shared))
+#define ORD_PRE 6                // records per thread requested ahead (6 x 512 = 3072 = the staging area)
 
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// workgroup barrier that orders LDS traffic only: __syncthreads() carries a workgroup-scope fence, i.e. s_waitcnt vmcnt(0) --
+// every barrier would wait for the global loads requested ahead for the NEXT quarter and for the stores of this one
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
+// Persistent workgroups, software pipelined: a quarter on its own is a chain of dependent round trips (perm -> colptr, counts ->
+// log lengths -> records -> LDS -> stores), and with 2 workgroups per CU nothing covers them (first version: 75 % of the wave
+// cycles waiting, 2.3 TB/s).  So while a workgroup ranks quarter q out of LDS, the records of its next quarter are already on
+// their way into registers, and the header of that quarter was requested a phase earlier still.
 __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __restrict__ logs, int64_t capL, int S,
                                                             const int32_t* __restrict__ slice_cnt, int64_t npad,
                                                             const int32_t* __restrict__ log_len, int64_t tile_begin, int64_t tile_end,
@@ -770,76 +790,129 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
     int32_t* const w_cnt = sh.wcnt[wave];
     int32_t* const w_base = sh.wbase[wave];
     int32_t* const w_o = sh.wo[wave];
-    for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
-        __syncthreads();
-        // ---- headers ----
+    const int64_t nq = (tile_end - tile_begin) * 4;
+
+    // ---- pipeline pieces ----
+    int hk = 0, ho = -1, hln = 0;                            // header values of the upcoming quarter, in the registers of the threads that fetch them
+    long long hout = 0;
+    auto hdr_fetch1 = [&](int64_t qi) {                      // perm, slice counts (threads < 16), log lengths (threads 64 .. 64 + S)
+        hk = 0; ho = -1; hln = 0;
+        if (qi >= nq) return;
+        const int64_t tl = qi >> 2; const int quarter = (int)(qi & 3);
+        if (tid < ORD_COLS) {
+            const int64_t sp = (tile_begin + tl) * 64 + quarter * ORD_COLS + tid;
+            ho = perm[sp];
+            for (int sl = 0; sl < S; ++sl) hk += slice_cnt[(int64_t)sl * npad + sp];
+        } else if (tid >= 64 && tid < 64 + S) {
+            hln = log_len[(tl * S + (tid - 64)) * 4 + quarter];
+        }
+    };
+    auto hdr_fetch2 = [&]() { hout = (tid < ORD_COLS && ho >= 0) ? colptr[ho] : 0; };
+    auto hdr_publish = [&](int hb) {                         // degrees, their prefix sums and the log lengths (the output offsets follow)
+        ord_hdr& H = sh.h[hb];
         if (tid < 64) {
-            const int64_t sp = tile * 64 + tid;
-            const int32_t o = perm[sp];
-            int k = 0;
-            for (int sl = 0; sl < S; ++sl) k += slice_cnt[(int64_t)sl * npad + sp];
-            if (o < 0) k = 0;
-            sh.k[tid] = k;
-            sh.out[tid] = (o >= 0) ? colptr[o] : 0;
-            int inc = k;
+            const int k = (tid < ORD_COLS && ho >= 0) ? hk : 0;
+            int inc = k;                                      // (lanes >= ORD_COLS carry zeros: one 16-lane row scan is enough)
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);       // row_shr:1
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);       // row_shr:2
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
-            inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
-            inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
-            sh.cb[tid + 1] = inc;
-            if (tid == 0) sh.cb[0] = 0;
+            if (tid < ORD_COLS) { H.k[tid] = k; H.cb[tid + 1] = inc; }
+            if (tid == 0) H.cb[0] = 0;
         } else if (tid < 64 + S) {
-            sh.ln[tid - 64] = log_len[(tile - tile_begin) * S + (tid - 64)];
+            H.ln[tid - 64] = hln;
         }
-        __syncthreads();
+    };
+    // prefetch registers are dealt out per (log, run of ORD_THREADS records): wave-uniform bookkeeping only.  (fsl, fc0) is where
+    // the direct streaming continues when a quarter holds more than the registers cover.
+    uint4 pre[ORD_PRE];
+    int fsl = 0, fc0 = 0;
+    auto log_ptr = [&](int64_t qi, int sl) -> const uint4* {
+        return reinterpret_cast<const uint4*>(logs + (((qi >> 2) * S + sl) * 4 + (qi & 3)) * capL);
+    };
+    auto rec_fetch = [&](const ord_hdr& H, int64_t qi) {
+        int sl = 0, c0 = 0;
+        while (sl < S && H.ln[sl] == 0) ++sl;
+#pragma unroll
+        for (int u = 0; u < ORD_PRE; ++u) {
+            pre[u] = make_uint4(0u, 0xffffffffu, 0u, 0u);
+            if (qi < nq && sl < S) {
+                const int n = H.ln[sl];
+                if (c0 + tid < n) pre[u] = log_ptr(qi, sl)[c0 + tid];
+                c0 += ORD_THREADS;
+                if (c0 >= n) { c0 = 0; ++sl; while (sl < S && H.ln[sl] == 0) ++sl; }
+            }
+        }
+        fsl = sl; fc0 = c0;
+    };
+
+    int64_t qi = blockIdx.x;
+    int hb = 0;
+    hdr_fetch1(qi);
+    hdr_fetch2();
+    hdr_publish(0);
+    if (tid < ORD_COLS) sh.h[0].out[tid] = hout;
+    lds_barrier();
+    rec_fetch(sh.h[0], qi);
+    for (; qi < nq; qi += gridDim.x, hb ^= 1) {
+        const ord_hdr& H = sh.h[hb];
+        const int64_t qn = qi + gridDim.x;                    // the workgroup's next quarter
+        const int c0 = (int)(qi & 3) * ORD_COLS;              // first column (of the tile) of this quarter
+        hdr_fetch1(qn);                                       // in flight during the scatter
         int g0 = 0;
-        while (g0 < 64) {
-            // ---- the next column range [g0, g1) that fits the staging area ----
+        bool first = true;
+        while (g0 < ORD_COLS) {
+            // ---- the next column range [g0, g1) that fits the staging area (normally the whole quarter) ----
             if (tid < 64) {
-                const bool ok = tid >= g0 && (sh.cb[tid + 1] - sh.cb[g0] <= ORD_STG);
+                const bool ok = tid >= g0 && tid < ORD_COLS && (H.cb[min(tid, ORD_COLS - 1) + 1] - H.cb[g0] <= ORD_STG);
                 const unsigned long long m = __ballot(ok);
                 if (tid == 0) sh.g1 = g0 + (int)__popcll(m);
-                sh.cur[tid] = 0;
+                if (tid < ORD_COLS) sh.cur[tid] = H.cb[tid] - H.cb[g0];
             }
-            __syncthreads();
+            lds_barrier();
             int g1 = sh.g1;
             const bool skip = g1 == g0;                      // a column beyond the staging area (excluded by the host): left out
             if (skip) g1 = g0 + 1;
-            const int gb = sh.cb[g0];
-            const int ghits = sh.cb[g1] - gb;
-            // ---- stream the tile's logs, regroup the range's records by column ----
-            if (!skip && ghits > 0) {
-                for (int sl = 0; sl < S; ++sl) {
-                    const int n = sh.ln[sl];
-                    const uint4* __restrict__ lg = reinterpret_cast<const uint4*>(logs + ((tile - tile_begin) * S + sl) * capL);
-                    for (int i0 = 0; i0 < n; i0 += ORD_THREADS * 4) {
-                        uint4 rec[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int i = i0 + u * ORD_THREADS + tid;
-                            rec[u] = (i < n) ? lg[i] : make_uint4(0u, 0xffffffffu, 0u, 0u);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int i = i0 + u * ORD_THREADS + tid;
-                            const int col = (int)(rec[u].y >> 26);
-                            if (i < n && col >= g0 && col < g1) {
-                                const int pos = sh.cb[col] - gb + atomicAdd(&sh.cur[col], 1);
-                                if (pos < ORD_STG) stage[pos] = rec[u];
-                            }
-                        }
+            const int gb = H.cb[g0];
+            // ---- regroup the range's records by column: the prefetched ones, then (quarters beyond ORD_PRE x 512 hits, or a
+            //      second column range) straight from the logs ----
+            if (!skip) {
+                auto place = [&](const uint4& r) {
+                    const int col = (int)(r.y >> 26) - c0;
+                    if (col >= g0 && col < g1) {
+                        const int pos = atomicAdd(&sh.cur[col], 1);              // (the cursor starts at the column's segment)
+                        if (pos < ORD_STG) stage[pos] = r;
                     }
+                };
+#pragma unroll
+                for (int u = 0; u < ORD_PRE; ++u) if (pre[u].y != 0xffffffffu) place(pre[u]);
+                int sl = first ? fsl : 0, cc = first ? fc0 : 0;
+                for (; sl < S; ++sl, cc = 0) {
+                    const int n = H.ln[sl];
+                    const uint4* __restrict__ lg = log_ptr(qi, sl);
+                    for (int i = cc + tid; i < n; i += ORD_THREADS) place(lg[i]);
                 }
             }
-            __syncthreads();
+            lds_barrier();
+            if (first) {
+                // the next quarter: header to LDS, output offsets and records requested -- all in flight during the ranking below
+                hdr_fetch2();
+                hdr_publish(hb ^ 1);
+#pragma unroll
+                for (int u = 0; u < ORD_PRE; ++u) pre[u].y = 0xffffffffu;      // (consumed; a further column range streams the logs itself)
+                first = false;
+            }
+            const bool last_range = g1 >= ORD_COLS;
+            if (last_range) {
+                lds_barrier();                              // (the next header's log lengths are read by every thread)
+                rec_fetch(sh.h[hb ^ 1], qn);
+            }
             // ---- one wavefront per column: rank and write ----
             if (!skip) for (int c = g0 + wave; c < g1; c += ORD_WAVES) {
-                const int k = sh.k[c];
+                const int k = H.k[c];
                 if (k == 0) continue;
-                const int base = sh.cb[c] - gb;
-                const int64_t out = sh.out[c];
+                const int base = H.cb[c] - gb;
+                const int64_t out = H.out[c];
                 if (k <= 64 * ORD_EPL) {
                     int32_t em[ORD_EPL], ep[ORD_EPL]; double ed[ORD_EPL];
                     bool has[ORD_EPL]; int bk[ORD_EPL], arr[ORD_EPL];
@@ -852,7 +925,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
                         if (64 * q < k && has[q]) {
                             const uint4 r = stage[base + 64 * q + lane];
                             em[q] = (int32_t)r.x; ep[q] = (int32_t)(r.y & 0x3ffffffu);
-                            ed[q] = __hiloint2double((int)r.w, (int)r.z);
+                            ed[q] = sqrt(__hiloint2double((int)r.w, (int)r.z));       // the log carries d2
                         }
                         // bucket_mul = floor(2^32 * 128 / N) (0: N <= 128, the id is its own bucket)
                         bk[q] = bucket_mul ? min(127, (int)__umulhi((uint32_t)em[q], bucket_mul)) : (em[q] & 127);
@@ -882,15 +955,25 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
                         if (has[q]) w_o[bs[q] + arr[q]] = em[q];                  // ids grouped by bucket (arrival order inside)
                     }
                     wave_sync();
+                    // every entry goes back to the column's own staging segment AT ITS RANK (all of them sit in registers by now),
+                    // and the segment is then written out in order: lane = consecutive CSC entries, three fully coalesced stores
+                    // per 64 entries (storing straight from the ranked registers scatters 64 lanes over the column's range:
+                    // the store issue of those permuted accesses bound the first version of this kernel)
 #pragma unroll
                     for (int q = 0; q < ORD_EPL; ++q) {
                         if (64 * q < k) {                                             // (uniform)
                             int rk = 0;
                             if (has[q]) for (int m = 0; m < nin[q]; ++m) rk += (w_o[bs[q] + m] < em[q]) ? 1 : 0;
-                            if (has[q]) {
-                                const int64_t o = out + bs[q] + rk;
-                                rowval[o] = em[q]; nzval[o] = ed[q]; if (rowpos) rowpos[o] = ep[q];
-                            }
+                            if (has[q]) stage[base + bs[q] + rk] = make_uint4((uint32_t)em[q], (uint32_t)ep[q], (uint32_t)__double2loint(ed[q]), (uint32_t)__double2hiint(ed[q]));
+                        }
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int q = 0; q < ORD_EPL; ++q) {
+                        if (64 * q < k && has[q]) {
+                            const uint4 r = stage[base + 64 * q + lane];
+                            const int64_t o = out + 64 * q + lane;
+                            rowval[o] = (int32_t)r.x; nzval[o] = __hiloint2double((int)r.w, (int)r.z); if (rowpos) rowpos[o] = (int32_t)r.y;
                         }
                     }
                 } else {
@@ -903,15 +986,16 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
                         int32_t rk = 0;
                         for (int j = 0; j < k; ++j) rk += ((int32_t)stage[base + j].x < mine) ? 1 : 0;
                         if (e < k) {
-                            rowval[out + rk] = mine; nzval[out + rk] = __hiloint2double((int)r.w, (int)r.z);
+                            rowval[out + rk] = mine; nzval[out + rk] = sqrt(__hiloint2double((int)r.w, (int)r.z));
                             if (rowpos) rowpos[out + rk] = (int32_t)(r.y & 0x3ffffffu);
                         }
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             g0 = g1;
         }
+        if (tid < ORD_COLS) sh.h[hb ^ 1].out[tid] = hout;     // the next quarter's output offsets (requested before the ranking)
     }
 }
 
@@ -927,7 +1011,8 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail)
         HIPCHK(ctx, hipFuncSetAttribute((const void*)k_order_logs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORD_LDS_BYTES));
         attr_set = true;
     }
-    const unsigned nb = (unsigned)std::min<int64_t>(nt, 1 << 20);
+    // persistent workgroups: as many as fit the chip at once (2 per CU by their LDS), each takes every nb-th quarter tile
+    const unsigned nb = (unsigned)std::min<int64_t>(nt * 4, (int64_t)ctx->num_cus * 2);
     hipLaunchKernelGGL(k_order_logs, dim3(nb), dim3(ORD_THREADS), ORD_LDS_BYTES, ctx->stream, ctx->pool, ctx->pool_cap, ctx->S,
                        ctx->slice_cnt, ctx->ntiles * 64, ctx->log_len, ctx->tile_begin, ctx->tile_end, ctx->colptr, ctx->perm,
                        ctx->rowval, ctx->nzval, ctx->sweep_sorted ? ctx->rowpos : nullptr,

@@ -127,9 +127,9 @@ struct mpfmt_ctx {
     // single-pass hit pool (MFMA path): hits found by the count pass are kept, so the fill pass is a scatter
     int32_t use_pool = 1;                // option "rdisc_pool"
     int32_t* pool_flag = nullptr;        // overflow flag
-    int64_t pool_cap = 0;                // capacity of one item's log, in records
-    mpfmt_hit* pool = nullptr;           // [items][pool_cap] hit records: one append log per (tile, slice)
-    int32_t* log_len = nullptr;          // [items] records in each log
+    int64_t pool_cap = 0;                // capacity of one log, in records
+    mpfmt_hit* pool = nullptr;           // [items][4][pool_cap] hit records: four append logs per (tile, slice), one per 16 columns
+    int32_t* log_len = nullptr;          // [items][4] records in each log
     int64_t max_deg = 0;                 // longest column of the counted graph (k_degree)
     int32_t pool_slack = 1;              // doubled after a build whose slot lists overflowed
     bool pool_valid = false;             // pool holds exactly the nnz hits of the counted graph
@@ -240,7 +240,7 @@ int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usab
 int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx);
 template <int MODE> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT);
 int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr);
-#define MPFMT_ORD_MAXDEG 4096        // longest column the log-ordering kernel stages in LDS (ORD_STG in kernels_rdisc_mfma.hip)
+#define MPFMT_ORD_MAXDEG 3072        // longest column the log-ordering kernel stages in LDS (ORD_STG in kernels_rdisc_mfma.hip)
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);
