@@ -723,25 +723,29 @@ int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
     return MPFMT_OK;
 }
 
-// Column ordering for the single-pass build: one workgroup per QUARTER TILE (16 columns).  The quarter's hits sit in S logs (one
-// per candidate slice) in arrival order, columns mixed; the final CSC wants every column's rows in ascending sample index at
-// colptr[perm[..]].
+// Column ordering for the single-pass build: one workgroup per QUARTER TILE (16 columns) at a time.  The quarter's hits sit in S
+// logs (one per candidate slice) in arrival order, columns mixed; the final CSC wants every column's rows in ascending sample
+// index at colptr[perm[..]].  A counting sort on (column, bucket of the row id) through LDS, every phase one pass over the
+// records with thread = record (no per-column serial chains):
 //   1. headers: degree of each of the 16 columns (sum of the slice counts), prefix sums, output offsets;
-//   2. the logs are streamed with coalesced 16-byte loads and REGROUPED BY COLUMN in LDS (a returning LDS atomic per record
-//      gives its place inside its column's segment).  The staging area holds ORD_STG records; a quarter with more hits is
-//      done in several column ranges, each streaming the logs again;
-//   3. one wavefront per column ranks the column's entries straight from LDS -- no dependent global round trips:
-//      columns of up to 192 hits by BUCKETS (row ids are near-uniform over [0, N), so bucket = floor(id * 128 / N), monotone
-//      in id, spreads them about one per bucket; an LDS histogram with returning atomics gives each hit its arrival slot, a
-//      64-lane scan the bucket bases, and a hit's rank is base + the number of smaller ids in its own bucket), longer
-//      ones by counting through the staged keys -- and writes rowval / nzval / rowpos of the column (one contiguous range).
-// Columns longer than ORD_STG never come here: the host checks the maximum degree (k_degree) and takes the two-pass build.
+//   2. COUNT: histogram over (column, bucket): row ids are near-uniform over [0, N), so bucket = floor(id * 128 / N) -- monotone in
+//      the id -- spreads a column's ~100 hits about one per bucket (non-returning LDS atomics);
+//   3. segmented scan of the 16 x 128 counts (32 lanes per column on the DPP network) -> a cursor per (column, bucket);
+//   4. PLACE: every record takes the next place of its (column, bucket) (returning LDS atomic) in the staging area: the quarter is
+//      now grouped by column and ordered up to the arrival order inside a bucket;
+//   5. WRITE: thread = staging position: the rank inside the bucket is a count over the bucket's other (typically 0-2) members,
+//      the square root of d2 is taken, and rowval / nzval / rowpos go out -- consecutive lanes write consecutive CSC entries.
+// The records are requested a quarter ahead into registers (ORD_PRE per thread); what a dense quarter holds beyond that is
+// streamed from the logs in phases 2 and 4.  The staging area holds ORD_STG records; a quarter with more hits is done in several
+// column ranges.  Columns longer than ORD_STG never come here: the host checks the maximum degree (k_degree) and takes the
+// two-pass build.
 #define ORD_THREADS 512
 #define ORD_WAVES 8
 #define ORD_COLS 16              // columns per workgroup = columns per log
+#define ORD_NB 128               // buckets per column
 #define ORD_STG 3072             // staged records per workgroup (48 KB of LDS)
-#define ORD_EPL 3                // hits per lane on the bucket path: columns of up to 192 hits
 static_assert(ORD_STG >= MPFMT_ORD_MAXDEG, "a column the host lets through must fit the staging area");
+static_assert(ORD_COLS * ORD_NB == ORD_THREADS * 4, "the segmented scan gives every thread four buckets");
 struct ord_hdr {
     int32_t k[ORD_COLS];         // column degrees
     int32_t cb[ORD_COLS + 4];    // exclusive prefix of the degrees (cb[ORD_COLS] = hits of the quarter)
@@ -749,11 +753,10 @@ struct ord_hdr {
     long long out[ORD_COLS];     // colptr of each column
 };
 struct ord_shared {
+    int32_t cnt[ORD_COLS][ORD_NB];   // records per (column, bucket)
+    int32_t cur[ORD_COLS][ORD_NB];   // next staging position of each (column, bucket); after the placement: the bucket's end
     ord_hdr h[2];                // headers of the quarter in work and of the next one (prefetched)
-    int32_t cur[ORD_COLS];       // per-column fill cursors of the current column range
     int32_t g1, pad_[3];
-    int32_t wcnt[ORD_WAVES][128], wbase[ORD_WAVES][128];
-    int32_t wo[ORD_WAVES][64 * ORD_EPL + 8];
 };
 #define ORD_LDS_BYTES (ORD_STG * 16 + sizeof(ord_shared))
 #define ORD_PRE 6                // records per thread requested ahead (6 x 512 = 3072 = the staging area)
@@ -772,7 +775,7 @@ __device__ __forceinline__ void lds_barrier()
 
 // Persistent workgroups, software pipelined: a quarter on its own is a chain of dependent round trips (perm -> colptr, counts ->
 // log lengths -> records -> LDS -> stores), and with 2 workgroups per CU nothing covers them (first version: 75 % of the wave
-// cycles waiting, 2.3 TB/s).  So while a workgroup ranks quarter q out of LDS, the records of its next quarter are already on
+// cycles waiting, 2.3 TB/s).  So while a workgroup writes quarter q out of LDS, the records of its next quarter are already on
 // their way into registers, and the header of that quarter was requested a phase earlier still.
 __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __restrict__ logs, int64_t capL, int S,
                                                             const int32_t* __restrict__ slice_cnt, int64_t npad,
@@ -785,12 +788,10 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
     extern __shared__ __attribute__((aligned(16))) char ord_smem[];
     uint4* const stage = reinterpret_cast<uint4*>(ord_smem);
     ord_shared& sh = *reinterpret_cast<ord_shared*>(ord_smem + ORD_STG * 16);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int32_t* const w_cnt = sh.wcnt[wave];
-    int32_t* const w_base = sh.wbase[wave];
-    int32_t* const w_o = sh.wo[wave];
+    const int tid = threadIdx.x;
     const int64_t nq = (tile_end - tile_begin) * 4;
+    // bucket_mul = floor(2^32 * 128 / N) (0: N <= 128, the id is its own bucket)
+    auto bucket = [&](uint32_t id) -> int { return bucket_mul ? min(ORD_NB - 1, (int)__umulhi(id, bucket_mul)) : (int)(id & (ORD_NB - 1)); };
 
     // ---- pipeline pieces ----
     int hk = 0, ho = -1, hln = 0;                            // header values of the upcoming quarter, in the registers of the threads that fetch them
@@ -858,44 +859,66 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
         const ord_hdr& H = sh.h[hb];
         const int64_t qn = qi + gridDim.x;                    // the workgroup's next quarter
         const int c0 = (int)(qi & 3) * ORD_COLS;              // first column (of the tile) of this quarter
-        hdr_fetch1(qn);                                       // in flight during the scatter
+        hdr_fetch1(qn);                                       // in flight during the counting sort
         int g0 = 0;
         bool first = true;
         while (g0 < ORD_COLS) {
-            // ---- the next column range [g0, g1) that fits the staging area (normally the whole quarter) ----
+            // ---- the next column range [g0, g1) that fits the staging area (normally the whole quarter); counts to zero ----
             if (tid < 64) {
                 const bool ok = tid >= g0 && tid < ORD_COLS && (H.cb[min(tid, ORD_COLS - 1) + 1] - H.cb[g0] <= ORD_STG);
                 const unsigned long long m = __ballot(ok);
                 if (tid == 0) sh.g1 = g0 + (int)__popcll(m);
-                if (tid < ORD_COLS) sh.cur[tid] = H.cb[tid] - H.cb[g0];
             }
+            *reinterpret_cast<int4*>(&sh.cnt[0][tid * 4]) = make_int4(0, 0, 0, 0);
             lds_barrier();
             int g1 = sh.g1;
             const bool skip = g1 == g0;                      // a column beyond the staging area (excluded by the host): left out
             if (skip) g1 = g0 + 1;
             const int gb = H.cb[g0];
-            // ---- regroup the range's records by column: the prefetched ones, then (quarters beyond ORD_PRE x 512 hits, or a
-            //      second column range) straight from the logs ----
-            if (!skip) {
-                auto place = [&](const uint4& r) {
-                    const int col = (int)(r.y >> 26) - c0;
-                    if (col >= g0 && col < g1) {
-                        const int pos = atomicAdd(&sh.cur[col], 1);              // (the cursor starts at the column's segment)
-                        if (pos < ORD_STG) stage[pos] = r;
-                    }
-                };
+            // every record of the quarter, phase by phase: the prefetched ones from registers, the rest (dense quarters, or a
+            // further column range) straight from the logs
+            auto for_records = [&](auto&& f) {
 #pragma unroll
-                for (int u = 0; u < ORD_PRE; ++u) if (pre[u].y != 0xffffffffu) place(pre[u]);
+                for (int u = 0; u < ORD_PRE; ++u) if (pre[u].y != 0xffffffffu) f(pre[u]);
                 int sl = first ? fsl : 0, cc = first ? fc0 : 0;
                 for (; sl < S; ++sl, cc = 0) {
                     const int n = H.ln[sl];
                     const uint4* __restrict__ lg = log_ptr(qi, sl);
-                    for (int i = cc + tid; i < n; i += ORD_THREADS) place(lg[i]);
+                    for (int i = cc + tid; i < n; i += ORD_THREADS) f(lg[i]);
                 }
+            };
+            // ---- COUNT ----
+            if (!skip) for_records([&](const uint4& r) {
+                const int col = (int)(r.y >> 26) - c0;
+                if (col >= g0 && col < g1) atomicAdd(&sh.cnt[col][bucket(r.x)], 1);
+            });
+            lds_barrier();
+            // ---- segmented scan: thread = four consecutive buckets, 32 threads per column ----
+            {
+                const int col = tid >> 5;
+                const int4 c4 = *reinterpret_cast<const int4*>(&sh.cnt[0][tid * 4]);
+                const int tot = c4.x + c4.y + c4.z + c4.w;
+                int inc = tot;
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);       // row_shr:1
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);       // row_shr:2
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3: the scan of a 32-lane half
+                const int b0 = H.cb[col] - gb + inc - tot;                               // staging position of the thread's first bucket
+                *reinterpret_cast<int4*>(&sh.cur[0][tid * 4]) = make_int4(b0, b0 + c4.x, b0 + c4.x + c4.y, b0 + c4.x + c4.y + c4.z);
             }
             lds_barrier();
+            // ---- PLACE ----
+            if (!skip) for_records([&](const uint4& r) {
+                const int col = (int)(r.y >> 26) - c0;
+                if (col >= g0 && col < g1) {
+                    const int pos = atomicAdd(&sh.cur[col][bucket(r.x)], 1);
+                    if (pos >= 0 && pos < ORD_STG) stage[pos] = r;
+                }
+            });
+            lds_barrier();
             if (first) {
-                // the next quarter: header to LDS, output offsets and records requested -- all in flight during the ranking below
+                // the next quarter: header to LDS, output offsets and records requested -- all in flight during the write-out below
                 hdr_fetch2();
                 hdr_publish(hb ^ 1);
 #pragma unroll
@@ -904,98 +927,32 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
             }
             const bool last_range = g1 >= ORD_COLS;
             if (last_range) {
-                lds_barrier();                              // (the next header's log lengths are read by every thread)
+                lds_barrier();                                // (the next header's log lengths are read by every thread)
                 rec_fetch(sh.h[hb ^ 1], qn);
             }
-            // ---- one wavefront per column: rank and write ----
-            if (!skip) for (int c = g0 + wave; c < g1; c += ORD_WAVES) {
-                const int k = H.k[c];
-                if (k == 0) continue;
-                const int base = H.cb[c] - gb;
-                const int64_t out = H.out[c];
-                if (k <= 64 * ORD_EPL) {
-                    int32_t em[ORD_EPL], ep[ORD_EPL]; double ed[ORD_EPL];
-                    bool has[ORD_EPL]; int bk[ORD_EPL], arr[ORD_EPL];
-                    wave_sync();
-                    *reinterpret_cast<int2*>(&w_cnt[2 * lane]) = make_int2(0, 0);
-#pragma unroll
-                    for (int q = 0; q < ORD_EPL; ++q) {
-                        has[q] = 64 * q + lane < k;
-                        em[q] = 0; ep[q] = 0; ed[q] = 0.0;
-                        if (64 * q < k && has[q]) {
-                            const uint4 r = stage[base + 64 * q + lane];
-                            em[q] = (int32_t)r.x; ep[q] = (int32_t)(r.y & 0x3ffffffu);
-                            ed[q] = sqrt(__hiloint2double((int)r.w, (int)r.z));       // the log carries d2
-                        }
-                        // bucket_mul = floor(2^32 * 128 / N) (0: N <= 128, the id is its own bucket)
-                        bk[q] = bucket_mul ? min(127, (int)__umulhi((uint32_t)em[q], bucket_mul)) : (em[q] & 127);
-                    }
-                    wave_sync();
-#pragma unroll
-                    for (int q = 0; q < ORD_EPL; ++q) arr[q] = has[q] ? atomicAdd(&w_cnt[bk[q]], 1) : 0;
-                    wave_sync();
-                    {   // exclusive scan of the 128 bucket counts, two per lane
-                        const int2 cc = *reinterpret_cast<const int2*>(&w_cnt[2 * lane]);
-                        const int tot = cc.x + cc.y;
-                        int inc = tot;
-                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);       // row_shr:1
-                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);       // row_shr:2
-                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
-                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
-                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
-                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
-                        const int excl = inc - tot;
-                        *reinterpret_cast<int2*>(&w_base[2 * lane]) = make_int2(excl, excl + cc.x);
-                    }
-                    wave_sync();
-                    int bs[ORD_EPL], nin[ORD_EPL];
-#pragma unroll
-                    for (int q = 0; q < ORD_EPL; ++q) {
-                        bs[q] = w_base[bk[q]]; nin[q] = w_cnt[bk[q]];
-                        if (has[q]) w_o[bs[q] + arr[q]] = em[q];                  // ids grouped by bucket (arrival order inside)
-                    }
-                    wave_sync();
-                    // every entry goes back to the column's own staging segment AT ITS RANK (all of them sit in registers by now),
-                    // and the segment is then written out in order: lane = consecutive CSC entries, three fully coalesced stores
-                    // per 64 entries (storing straight from the ranked registers scatters 64 lanes over the column's range:
-                    // the store issue of those permuted accesses bound the first version of this kernel)
-#pragma unroll
-                    for (int q = 0; q < ORD_EPL; ++q) {
-                        if (64 * q < k) {                                             // (uniform)
-                            int rk = 0;
-                            if (has[q]) for (int m = 0; m < nin[q]; ++m) rk += (w_o[bs[q] + m] < em[q]) ? 1 : 0;
-                            if (has[q]) stage[base + bs[q] + rk] = make_uint4((uint32_t)em[q], (uint32_t)ep[q], (uint32_t)__double2loint(ed[q]), (uint32_t)__double2hiint(ed[q]));
-                        }
-                    }
-                    wave_sync();
-#pragma unroll
-                    for (int q = 0; q < ORD_EPL; ++q) {
-                        if (64 * q < k && has[q]) {
-                            const uint4 r = stage[base + 64 * q + lane];
-                            const int64_t o = out + 64 * q + lane;
-                            rowval[o] = (int32_t)r.x; nzval[o] = __hiloint2double((int)r.w, (int)r.z); if (rowpos) rowpos[o] = (int32_t)r.y;
-                        }
-                    }
-                } else {
-                    // long columns: rank by counting over the staged keys (wave-uniform LDS reads)
-                    for (int e0 = 0; e0 < k; e0 += 64) {
-                        const int e = e0 + lane;
-                        uint4 r = make_uint4(0x7fffffffu, 0u, 0u, 0u);
-                        if (e < k) r = stage[base + e];
-                        const int32_t mine = (int32_t)r.x;
-                        int32_t rk = 0;
-                        for (int j = 0; j < k; ++j) rk += ((int32_t)stage[base + j].x < mine) ? 1 : 0;
-                        if (e < k) {
-                            rowval[out + rk] = mine; nzval[out + rk] = sqrt(__hiloint2double((int)r.w, (int)r.z));
-                            if (rowpos) rowpos[out + rk] = (int32_t)(r.y & 0x3ffffffu);
-                        }
+            // ---- WRITE: thread = staging position ----
+            if (!skip) {
+                const int nst = min(H.cb[g1] - gb, ORD_STG);
+                for (int p = tid; p < nst; p += ORD_THREADS) {
+                    const uint4 r = stage[p];
+                    const int col = min(max((int)(r.y >> 26) - c0, 0), ORD_COLS - 1);
+                    const int bk = bucket(r.x);
+                    const int e = sh.cur[col][bk], n = sh.cnt[col][bk];            // the bucket occupies [e - n, e)
+                    int rk = e - n;
+                    for (int m = e - n; m < e; ++m) rk += ((int32_t)stage[m].x < (int32_t)r.x) ? 1 : 0;
+                    const int rel = rk - (H.cb[col] - gb);                          // rank inside the column
+                    if (rel >= 0 && rel < H.k[col]) {                               // (always, unless a log overflowed: that build is void, but stays in bounds)
+                        const int64_t o = H.out[col] + rel;
+                        rowval[o] = (int32_t)r.x;
+                        nzval[o] = sqrt(__hiloint2double((int)r.w, (int)r.z));      // the log carries d2
+                        if (rowpos) rowpos[o] = (int32_t)(r.y & 0x3ffffffu);
                     }
                 }
             }
             lds_barrier();
             g0 = g1;
         }
-        if (tid < ORD_COLS) sh.h[hb ^ 1].out[tid] = hout;     // the next quarter's output offsets (requested before the ranking)
+        if (tid < ORD_COLS) sh.h[hb ^ 1].out[tid] = hout;     // the next quarter's output offsets (requested before the write-out)
     }
 }
 
