@@ -797,7 +797,7 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     return MPFMT_OK;
 }
 
-int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
+int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r, bool fuse_sweep)
 {
     if (!ctx->graph_counted || ctx->graph_r != r)
         return mpfmt_fail(ctx, MPFMT_ERR_STATE, "rdisc_fill without a matching rdisc_count");
@@ -814,8 +814,9 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
         if (ctx->rdisc_path_used == 2 && ctx->pool_valid) {
             // single pass: the hits are already in the slot lists; order each column straight into the final CSC
             mpfmt_timed tm4(ctx);
-            if ((rc = mpfmt_order_logs(ctx))) return rc;
-            tm4.end("rdisc_sort");
+            const bool fuse = fuse_sweep && mpfmt_order_can_fuse(ctx);
+            if ((rc = mpfmt_order_logs(ctx, nullptr, fuse))) return rc;
+            tm4.end(fuse ? "order_sweep" : "rdisc_sort");
             done = 1;
         }
         if (!done) {
@@ -875,23 +876,24 @@ int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r)
             ctx->pool_valid = true; ctx->rdisc_path_used = 2;
             ctx->graph_r = r; ctx->graph_counted = true;
             mpfmt_timed tm7(ctx);
-            if ((rc = mpfmt_order_logs(ctx, ctx->spec_fail))) return rc;
-            tm7.end("rdisc_sort");
+            const bool fuse = mpfmt_order_can_fuse(ctx);
+            if ((rc = mpfmt_order_logs(ctx, ctx->spec_fail, fuse, cap))) return rc;
+            tm7.end(fuse ? "order_sweep" : "rdisc_sort");
             ctx->graph_filled = true;
-            if ((rc = mpfmt_launch_graph_sweep(ctx, ctx->spec_fail, cap))) return rc;
+            if (!fuse && (rc = mpfmt_launch_graph_sweep(ctx, ctx->spec_fail, cap))) return rc;
             ctx->step_state = 1;                                    // speculative kernels in flight
             return MPFMT_OK;
         }
         if ((rc = mpfmt_rdisc_count_finish(ctx, r, nullptr))) return rc;
-        if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
-        if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+        if ((rc = mpfmt_launch_rdisc_fill(ctx, r, true))) return rc;
+        if (!ctx->graph_swept && (rc = mpfmt_launch_graph_sweep(ctx))) return rc;
         ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
         ctx->step_state = 2;
         return MPFMT_OK;
     }
     if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
-    if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
-    if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+    if ((rc = mpfmt_launch_rdisc_fill(ctx, r, true))) return rc;
+    if (!ctx->graph_swept && (rc = mpfmt_launch_graph_sweep(ctx))) return rc;
     ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
     ctx->step_state = 2;
     return MPFMT_OK;
@@ -914,8 +916,8 @@ int32_t mpfmt_graph_step_finish_impl(mpfmt_ctx* ctx)
         ctx->spec_ready = false;
         ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
         if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
-        if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
-        if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+        if ((rc = mpfmt_launch_rdisc_fill(ctx, r, true))) return rc;
+        if (!ctx->graph_swept && (rc = mpfmt_launch_graph_sweep(ctx))) return rc;
         ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
         return MPFMT_OK;
     }

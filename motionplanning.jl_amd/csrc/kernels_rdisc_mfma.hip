@@ -723,262 +723,6 @@ int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
     return MPFMT_OK;
 }
 
-// Column ordering for the single-pass build: one workgroup per QUARTER TILE (16 columns) at a time.  The quarter's hits sit in S
-// logs (one per candidate slice) in arrival order, columns mixed; the final CSC wants every column's rows in ascending sample
-// index at colptr[perm[..]].  A counting sort on (column, bucket of the row id) through LDS, every phase one pass over the
-// records with thread = record (no per-column serial chains):
-//   1. headers: degree of each of the 16 columns (sum of the slice counts), prefix sums, output offsets;
-//   2. COUNT: histogram over (column, bucket): row ids are near-uniform over [0, N), so bucket = floor(id * 128 / N) -- monotone in
-//      the id -- spreads a column's ~100 hits about one per bucket (non-returning LDS atomics);
-//   3. segmented scan of the 16 x 128 counts (32 lanes per column on the DPP network) -> a cursor per (column, bucket);
-//   4. PLACE: every record takes the next place of its (column, bucket) (returning LDS atomic) in the staging area: the quarter is
-//      now grouped by column and ordered up to the arrival order inside a bucket;
-//   5. WRITE: thread = staging position: the rank inside the bucket is a count over the bucket's other (typically 0-2) members,
-//      the square root of d2 is taken, and rowval / nzval / rowpos go out -- consecutive lanes write consecutive CSC entries.
-// The records are requested a quarter ahead into registers (ORD_PRE per thread); what a dense quarter holds beyond that is
-// streamed from the logs in phases 2 and 4.  The staging area holds ORD_STG records; a quarter with more hits is done in several
-// column ranges.  Columns longer than ORD_STG never come here: the host checks the maximum degree (k_degree) and takes the
-// two-pass build.
-#define ORD_THREADS 512
-#define ORD_WAVES 8
-#define ORD_COLS 16              // columns per workgroup = columns per log
-#define ORD_NB 128               // buckets per column
-#define ORD_STG 3072             // staged records per workgroup (48 KB of LDS)
-static_assert(ORD_STG >= MPFMT_ORD_MAXDEG, "a column the host lets through must fit the staging area");
-static_assert(ORD_COLS * ORD_NB == ORD_THREADS * 4, "the segmented scan gives every thread four buckets");
-struct ord_hdr {
-    int32_t k[ORD_COLS];         // column degrees
-    int32_t cb[ORD_COLS + 4];    // exclusive prefix of the degrees (cb[ORD_COLS] = hits of the quarter)
-    int32_t ln[MPFMT_MAXS + 4];  // log lengths
-    long long out[ORD_COLS];     // colptr of each column
-};
-struct ord_shared {
-    int32_t cnt[ORD_COLS][ORD_NB];   // records per (column, bucket)
-    int32_t cur[ORD_COLS][ORD_NB];   // next staging position of each (column, bucket); after the placement: the bucket's end
-    ord_hdr h[2];                // headers of the quarter in work and of the next one (prefetched)
-    int32_t g1, pad_[3];
-};
-#define ORD_LDS_BYTES (ORD_STG * 16 + sizeof(ord_shared))
-#define ORD_PRE 6                // records per thread requested ahead (6 x 512 = 3072 = the staging area)
-
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-// workgroup barrier that orders LDS traffic only: __syncthreads() carries a workgroup-scope fence, i.e. s_waitcnt vmcnt(0) --
-// every barrier would wait for the global loads requested ahead for the NEXT quarter and for the stores of this one
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// Persistent workgroups, software pipelined: a quarter on its own is a chain of dependent round trips (perm -> colptr, counts ->
-// log lengths -> records -> LDS -> stores), and with 2 workgroups per CU nothing covers them (first version: 75 % of the wave
-// cycles waiting, 2.3 TB/s).  So while a workgroup writes quarter q out of LDS, the records of its next quarter are already on
-// their way into registers, and the header of that quarter was requested a phase earlier still.
-__global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __restrict__ logs, int64_t capL, int S,
-                                                            const int32_t* __restrict__ slice_cnt, int64_t npad,
-                                                            const int32_t* __restrict__ log_len, int64_t tile_begin, int64_t tile_end,
-                                                            const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm,
-                                                            int32_t* __restrict__ rowval, double* __restrict__ nzval, int32_t* __restrict__ rowpos,
-                                                            uint32_t bucket_mul, const int32_t* __restrict__ spec_fail)
-{
-    if (spec_fail && *spec_fail) return;                     // speculative step whose capacities did not hold: redone by the host
-    extern __shared__ __attribute__((aligned(16))) char ord_smem[];
-    uint4* const stage = reinterpret_cast<uint4*>(ord_smem);
-    ord_shared& sh = *reinterpret_cast<ord_shared*>(ord_smem + ORD_STG * 16);
-    const int tid = threadIdx.x;
-    const int64_t nq = (tile_end - tile_begin) * 4;
-    // bucket_mul = floor(2^32 * 128 / N) (0: N <= 128, the id is its own bucket)
-    auto bucket = [&](uint32_t id) -> int { return bucket_mul ? min(ORD_NB - 1, (int)__umulhi(id, bucket_mul)) : (int)(id & (ORD_NB - 1)); };
-
-    // ---- pipeline pieces ----
-    int hk = 0, ho = -1, hln = 0;                            // header values of the upcoming quarter, in the registers of the threads that fetch them
-    long long hout = 0;
-    auto hdr_fetch1 = [&](int64_t qi) {                      // perm, slice counts (threads < 16), log lengths (threads 64 .. 64 + S)
-        hk = 0; ho = -1; hln = 0;
-        if (qi >= nq) return;
-        const int64_t tl = qi >> 2; const int quarter = (int)(qi & 3);
-        if (tid < ORD_COLS) {
-            const int64_t sp = (tile_begin + tl) * 64 + quarter * ORD_COLS + tid;
-            ho = perm[sp];
-            for (int sl = 0; sl < S; ++sl) hk += slice_cnt[(int64_t)sl * npad + sp];
-        } else if (tid >= 64 && tid < 64 + S) {
-            hln = log_len[(tl * S + (tid - 64)) * 4 + quarter];
-        }
-    };
-    auto hdr_fetch2 = [&]() { hout = (tid < ORD_COLS && ho >= 0) ? colptr[ho] : 0; };
-    auto hdr_publish = [&](int hb) {                         // degrees, their prefix sums and the log lengths (the output offsets follow)
-        ord_hdr& H = sh.h[hb];
-        if (tid < 64) {
-            const int k = (tid < ORD_COLS && ho >= 0) ? hk : 0;
-            int inc = k;                                      // (lanes >= ORD_COLS carry zeros: one 16-lane row scan is enough)
-            inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);       // row_shr:1
-            inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);       // row_shr:2
-            inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
-            inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
-            if (tid < ORD_COLS) { H.k[tid] = k; H.cb[tid + 1] = inc; }
-            if (tid == 0) H.cb[0] = 0;
-        } else if (tid < 64 + S) {
-            H.ln[tid - 64] = hln;
-        }
-    };
-    // prefetch registers are dealt out per (log, run of ORD_THREADS records): wave-uniform bookkeeping only.  (fsl, fc0) is where
-    // the direct streaming continues when a quarter holds more than the registers cover.
-    uint4 pre[ORD_PRE];
-    int fsl = 0, fc0 = 0;
-    auto log_ptr = [&](int64_t qi, int sl) -> const uint4* {
-        return reinterpret_cast<const uint4*>(logs + (((qi >> 2) * S + sl) * 4 + (qi & 3)) * capL);
-    };
-    auto rec_fetch = [&](const ord_hdr& H, int64_t qi) {
-        int sl = 0, c0 = 0;
-        while (sl < S && H.ln[sl] == 0) ++sl;
-#pragma unroll
-        for (int u = 0; u < ORD_PRE; ++u) {
-            pre[u] = make_uint4(0u, 0xffffffffu, 0u, 0u);
-            if (qi < nq && sl < S) {
-                const int n = H.ln[sl];
-                if (c0 + tid < n) pre[u] = log_ptr(qi, sl)[c0 + tid];
-                c0 += ORD_THREADS;
-                if (c0 >= n) { c0 = 0; ++sl; while (sl < S && H.ln[sl] == 0) ++sl; }
-            }
-        }
-        fsl = sl; fc0 = c0;
-    };
-
-    int64_t qi = blockIdx.x;
-    int hb = 0;
-    hdr_fetch1(qi);
-    hdr_fetch2();
-    hdr_publish(0);
-    if (tid < ORD_COLS) sh.h[0].out[tid] = hout;
-    lds_barrier();
-    rec_fetch(sh.h[0], qi);
-    for (; qi < nq; qi += gridDim.x, hb ^= 1) {
-        const ord_hdr& H = sh.h[hb];
-        const int64_t qn = qi + gridDim.x;                    // the workgroup's next quarter
-        const int c0 = (int)(qi & 3) * ORD_COLS;              // first column (of the tile) of this quarter
-        hdr_fetch1(qn);                                       // in flight during the counting sort
-        int g0 = 0;
-        bool first = true;
-        while (g0 < ORD_COLS) {
-            // ---- the next column range [g0, g1) that fits the staging area (normally the whole quarter); counts to zero ----
-            if (tid < 64) {
-                const bool ok = tid >= g0 && tid < ORD_COLS && (H.cb[min(tid, ORD_COLS - 1) + 1] - H.cb[g0] <= ORD_STG);
-                const unsigned long long m = __ballot(ok);
-                if (tid == 0) sh.g1 = g0 + (int)__popcll(m);
-            }
-            *reinterpret_cast<int4*>(&sh.cnt[0][tid * 4]) = make_int4(0, 0, 0, 0);
-            lds_barrier();
-            int g1 = sh.g1;
-            const bool skip = g1 == g0;                      // a column beyond the staging area (excluded by the host): left out
-            if (skip) g1 = g0 + 1;
-            const int gb = H.cb[g0];
-            // every record of the quarter, phase by phase: the prefetched ones from registers, the rest (dense quarters, or a
-            // further column range) straight from the logs
-            auto for_records = [&](auto&& f) {
-#pragma unroll
-                for (int u = 0; u < ORD_PRE; ++u) if (pre[u].y != 0xffffffffu) f(pre[u]);
-                int sl = first ? fsl : 0, cc = first ? fc0 : 0;
-                for (; sl < S; ++sl, cc = 0) {
-                    const int n = H.ln[sl];
-                    const uint4* __restrict__ lg = log_ptr(qi, sl);
-                    for (int i = cc + tid; i < n; i += ORD_THREADS) f(lg[i]);
-                }
-            };
-            // ---- COUNT ----
-            if (!skip) for_records([&](const uint4& r) {
-                const int col = (int)(r.y >> 26) - c0;
-                if (col >= g0 && col < g1) atomicAdd(&sh.cnt[col][bucket(r.x)], 1);
-            });
-            lds_barrier();
-            // ---- segmented scan: thread = four consecutive buckets, 32 threads per column ----
-            {
-                const int col = tid >> 5;
-                const int4 c4 = *reinterpret_cast<const int4*>(&sh.cnt[0][tid * 4]);
-                const int tot = c4.x + c4.y + c4.z + c4.w;
-                int inc = tot;
-                inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);       // row_shr:1
-                inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);       // row_shr:2
-                inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
-                inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
-                inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3: the scan of a 32-lane half
-                const int b0 = H.cb[col] - gb + inc - tot;                               // staging position of the thread's first bucket
-                *reinterpret_cast<int4*>(&sh.cur[0][tid * 4]) = make_int4(b0, b0 + c4.x, b0 + c4.x + c4.y, b0 + c4.x + c4.y + c4.z);
-            }
-            lds_barrier();
-            // ---- PLACE ----
-            if (!skip) for_records([&](const uint4& r) {
-                const int col = (int)(r.y >> 26) - c0;
-                if (col >= g0 && col < g1) {
-                    const int pos = atomicAdd(&sh.cur[col][bucket(r.x)], 1);
-                    if (pos >= 0 && pos < ORD_STG) stage[pos] = r;
-                }
-            });
-            lds_barrier();
-            if (first) {
-                // the next quarter: header to LDS, output offsets and records requested -- all in flight during the write-out below
-                hdr_fetch2();
-                hdr_publish(hb ^ 1);
-#pragma unroll
-                for (int u = 0; u < ORD_PRE; ++u) pre[u].y = 0xffffffffu;      // (consumed; a further column range streams the logs itself)
-                first = false;
-            }
-            const bool last_range = g1 >= ORD_COLS;
-            if (last_range) {
-                lds_barrier();                                // (the next header's log lengths are read by every thread)
-                rec_fetch(sh.h[hb ^ 1], qn);
-            }
-            // ---- WRITE: thread = staging position ----
-            if (!skip) {
-                const int nst = min(H.cb[g1] - gb, ORD_STG);
-                for (int p = tid; p < nst; p += ORD_THREADS) {
-                    const uint4 r = stage[p];
-                    const int col = min(max((int)(r.y >> 26) - c0, 0), ORD_COLS - 1);
-                    const int bk = bucket(r.x);
-                    const int e = sh.cur[col][bk], n = sh.cnt[col][bk];            // the bucket occupies [e - n, e)
-                    int rk = e - n;
-                    for (int m = e - n; m < e; ++m) rk += ((int32_t)stage[m].x < (int32_t)r.x) ? 1 : 0;
-                    const int rel = rk - (H.cb[col] - gb);                          // rank inside the column
-                    if (rel >= 0 && rel < H.k[col]) {                               // (always, unless a log overflowed: that build is void, but stays in bounds)
-                        const int64_t o = H.out[col] + rel;
-                        rowval[o] = (int32_t)r.x;
-                        nzval[o] = sqrt(__hiloint2double((int)r.w, (int)r.z));      // the log carries d2
-                        if (rowpos) rowpos[o] = (int32_t)(r.y & 0x3ffffffu);
-                    }
-                }
-            }
-            lds_barrier();
-            g0 = g1;
-        }
-        if (tid < ORD_COLS) sh.h[hb ^ 1].out[tid] = hout;     // the next quarter's output offsets (requested before the write-out)
-    }
-}
-
-int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail)
-{
-    const int64_t nt = ctx->tile_end - ctx->tile_begin;
-    if (ctx->nnz == 0 || nt <= 0) return MPFMT_OK;
-    int32_t rc_;
-    // option sweep_sorted: also keep every row's cell-sorted position, so the sweep can gather from Xs (see kernels_sweep.hip)
-    if (ctx->sweep_sorted && (rc_ = mpfmt_ensure(ctx, (void**)&ctx->rowpos, sizeof(int32_t) * (size_t)std::max<int64_t>(std::max(ctx->nnz, ctx->nnz_cap), 1)))) return rc_;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_order_logs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORD_LDS_BYTES));
-        attr_set = true;
-    }
-    // persistent workgroups: as many as fit the chip at once (2 per CU by their LDS), each takes every nb-th quarter tile
-    const unsigned nb = (unsigned)std::min<int64_t>(nt * 4, (int64_t)ctx->num_cus * 2);
-    hipLaunchKernelGGL(k_order_logs, dim3(nb), dim3(ORD_THREADS), ORD_LDS_BYTES, ctx->stream, ctx->pool, ctx->pool_cap, ctx->S,
-                       ctx->slice_cnt, ctx->ntiles * 64, ctx->log_len, ctx->tile_begin, ctx->tile_end, ctx->colptr, ctx->perm,
-                       ctx->rowval, ctx->nzval, ctx->sweep_sorted ? ctx->rowpos : nullptr,
-                       ctx->N > 128 ? (uint32_t)((128ull << 32) / (uint64_t)ctx->N) : 0u, spec_fail);
-    HIPCHK(ctx, hipGetLastError());
-    ctx->rowpos_valid = ctx->sweep_sorted != 0;   // every entry's row is also known by its cell-sorted position (the sweep gathers from Xs)
-    return MPFMT_OK;
-}
-
 // (re)build the per-tile candidate chunk lists of this ctx's shard for radius r; grows the list capacity until every
 // list fits.  *usable = false when the lists would need more than 32 GB (caller then takes the exact VALU path).
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec)

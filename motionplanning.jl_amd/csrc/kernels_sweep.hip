@@ -1193,17 +1193,11 @@ static int32_t launch_sweep_rt_d(mpfmt_ctx* ctx, size_t lds, double rpad, const 
     return MPFMT_OK;
 }
 
-static int32_t launch_graph_sweep_rt(mpfmt_ctx* ctx, double rpad, const int32_t* sweep_perm, int64_t sp_begin, int64_t sp_end,
-                                     const int32_t* spec_fail, bool sorted_rows, int64_t entries)
+// device copy of the state-space bounds (scalar loads in the sweep kernels) and, once per (sample set, bounds), the answer to
+// "do all samples lie in the state space?" (the sweeps then skip the per-row in_state_space test)
+int32_t mpfmt_sweep_prepare_ss(mpfmt_ctx* ctx)
 {
     int32_t rc;
-    const int d = ctx->d;
-    const int64_t ncol = sp_end - sp_begin;
-    const int64_t cap = entries / 16 + ncol + 8;                          // quarters: every column adds at most one partial quarter (+ padding of the last round)
-    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_cnt, sizeof(int64_t) * (size_t)(ncol + 1)))) return rc;
-    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_off, sizeof(int64_t) * (size_t)(ncol + 1)))) return rc;
-    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_table, sizeof(sweep_rd) * (size_t)cap))) return rc;
-    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_total, sizeof(int64_t)))) return rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_ss, sizeof(double) * 2 * MPFMT_MAX_DIM))) return rc;
     if (!ctx->rt_ss_valid || memcmp(&ctx->rt_ss_host, &ctx->ss, sizeof(mpfmt_ss)) != 0) {
         double b[2 * MPFMT_MAX_DIM];
@@ -1225,6 +1219,21 @@ static int32_t launch_graph_sweep_rt(mpfmt_ctx* ctx, double rpad, const int32_t*
         ctx->ssflag_all_in = got == 1;
         ctx->ssflag_epoch = ctx->samples_epoch; ctx->ssflag_ss = ctx->ss;
     }
+    return MPFMT_OK;
+}
+
+static int32_t launch_graph_sweep_rt(mpfmt_ctx* ctx, double rpad, const int32_t* sweep_perm, int64_t sp_begin, int64_t sp_end,
+                                     const int32_t* spec_fail, bool sorted_rows, int64_t entries)
+{
+    int32_t rc;
+    const int d = ctx->d;
+    const int64_t ncol = sp_end - sp_begin;
+    const int64_t cap = entries / 16 + ncol + 8;                          // quarters: every column adds at most one partial quarter (+ padding of the last round)
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_cnt, sizeof(int64_t) * (size_t)(ncol + 1)))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_off, sizeof(int64_t) * (size_t)(ncol + 1)))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_table, sizeof(sweep_rd) * (size_t)cap))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_total, sizeof(int64_t)))) return rc;
+    if ((rc = mpfmt_sweep_prepare_ss(ctx))) return rc;
     size_t tmp_bytes = 0;
     HIPCHK(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, ctx->rt_cnt, ctx->rt_off, (int64_t)0, (size_t)(ncol + 1), rocprim::plus<int64_t>(), ctx->stream));
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_tmp, tmp_bytes))) return rc;

@@ -153,6 +153,8 @@ struct mpfmt_ctx {
     double* nzval = nullptr;
     int32_t* rowpos = nullptr;           // [nnz] cell-sorted position of each entry's row (single-pass build): the sweep gathers rows from Xs
     bool rowpos_valid = false;
+    int32_t fuse_sweep = 0;              // option (off: measured slower): mpfmt_graph_step evaluates the edge tests inside the column-ordering
+                                         // kernel (kernels_order.hip, k_order_logs<D, true>) instead of the separate sweep kernel
     int32_t sweep_sorted = 1;            // option: gather the sweep's rows from Xs in cell-sorted order with per-XCD task ranges (6x less HBM traffic,
                                          // 74 % L2 hits): with the round-table sweep, whose instruction count no longer hides under the
                                          // caller-order gather (2.29 ms floor), this is the faster mode (2.2 vs 2.65 ms); on by default
@@ -235,11 +237,13 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed);
 int32_t mpfmt_graph_step(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_graph_step_finish_impl(mpfmt_ctx* ctx);
-int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r);
+int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r, bool fuse_sweep = false);
 int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usable);
 int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx);
 template <int MODE> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT);
-int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr);
+int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr, bool fuse = false, int64_t mask_entries = -1);      // kernels_order.hip
+bool mpfmt_order_can_fuse(const mpfmt_ctx* ctx);
+int32_t mpfmt_sweep_prepare_ss(mpfmt_ctx* ctx);          // kernels_sweep.hip: device copy of the state-space bounds + the all-samples-inside flag
 #define MPFMT_ORD_MAXDEG 3072        // longest column the log-ordering kernel stages in LDS (ORD_STG in kernels_rdisc_mfma.hip)
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
