@@ -274,10 +274,11 @@ def main():
     path_used = ctx.stat("rdisc_path_used")
     survivors = ctx.stat("survivors")
     single_pass = ctx.stat("pool_used") == 1
-    tm = {k: ctx.timing(k) for k in ("grid", "rdisc_count", "rdisc_fill", "rdisc_sort", "sweep_graph", "sweep_kernel")}
+    tm = {k: ctx.timing(k) for k in ("grid", "rdisc_count", "pair_kernel", "rdisc_fill", "rdisc_sort", "order_sweep", "sweep_graph", "sweep_kernel")}
     d = w.d
-    # dominant kernel: the r-disc pair sweep k_rdisc_mfma (single pass) -- or count + fill in the two-pass forms
-    pair_ms = tm["rdisc_count"][0] + tm["rdisc_fill"][0]
+    fused = tm["order_sweep"][1] > 0                 # option fuse_sweep: the edge tests ride in the ordering kernel
+    # the r-disc pair kernel k_rdisc_mfma on its own launch duration (single pass) -- or count + fill in the two-pass forms
+    pair_ms = (tm["pair_kernel"][0] if tm["pair_kernel"][1] > 0 else tm["rdisc_count"][0]) + tm["rdisc_fill"][0]
     passes = 1 if single_pass else 2
     pairs_per_pass = stats["pairs_tested"]
     # algorithmic flops: 2*d per tested pair; MFMA flops actually issued: K = 16 slots -> 32 per pair
@@ -290,8 +291,17 @@ def main():
     sweep_ms = tm["sweep_kernel"][0] if tm["sweep_kernel"][1] > 0 else tm["sweep_graph"][0]
     sweep_bytes = nnz * (2 * d * 8 + 8 + 1.0 / 8.0)
     sweep_gbs = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    # the column-ordering kernel (k_order_logs): algorithmic bytes = one 16-byte hit record in, rowval (4) + nzval (8) + rowpos (4) out
+    sort_ms = tm["order_sweep"][0] if fused else tm["rdisc_sort"][0]
+    sort_bytes_per_edge = 16.0 + 4.0 + 8.0 + (0.0 if fused else 4.0) + ((2 * d * 8 + 1.0 / 8.0) if fused else 0.0)
+    sort_gbs = nnz * sort_bytes_per_edge / (sort_ms * 1e-3) / 1e9 if sort_ms > 0 else 0.0
+    # algorithmic HBM bytes of the pair kernel: 8 d (N + Q) in + 12 nnz out
+    pair_alg_bytes = 8.0 * d * (2 * stats["tiles"] * 64) + 12.0 * nnz
     lib_version = mp._lib.lib().mpfmt_version().decode()
     prof = profiled_traffic(mp._lib.so_path(), w.name, world)
+
+    def ratio(bytes_measured, bytes_alg):
+        return (bytes_measured / bytes_alg) if (bytes_measured and bytes_alg) else None
 
     out = {
         "metric": "edges checked/sec + r-disc queries/sec, FMT* N=1e6 R^6, 1/2/4/8 MI355X",
@@ -312,11 +322,13 @@ def main():
                                 "one RCCL all-gather of the free-edge mask per step through the C ABI (mpfmt_allgather_free_mask_*), "
                                 "overlapped with the next step's index build" + (" [RCCL stand-in: %s]" % os.environ["MPFMT_RCCL_LIB"] if os.environ.get("MPFMT_RCCL_LIB") else "")
                                 if rccl_abi else "gloo (one-device functional check)"),
-                   "step": "r-disc graph of all N samples + collision sweep of all nnz directed edges"},
+                   "step": "index build (cell grid, sorted copies, MFMA operands, chunk lists) + r-disc graph of all N samples as an ordered CSC "
+                           "+ collision sweep of all nnz directed edges; the one thing not redone per step is the all-samples-in-state-space "
+                           "flag (k_all_in_ss, 25 us, once per upload)"},
         "submetrics": {
             "rdisc_queries_per_s": w.N * args.steps / dt,
             "edges_checked_per_s_sweep_kernel": (nnz / (sweep_ms * 1e-3)) if sweep_ms > 0 else None,
-            "rdisc_queries_per_s_graph_kernels": ((stats["tiles"] * 64) / ((pair_ms + tm["rdisc_sort"][0] + tm["grid"][0]) * 1e-3))
+            "rdisc_queries_per_s_graph_kernels": ((stats["tiles"] * 64) / ((tm["rdisc_count"][0] + tm["rdisc_fill"][0] + sort_ms + tm["grid"][0]) * 1e-3))
             if pair_ms > 0 else None,
             "kernel_ms": {k: v[0] for k, v in tm.items()},
             "pairs_tested_per_pass": pairs_per_pass,
@@ -327,39 +339,52 @@ def main():
             "lib_version": lib_version,
         }
     }
-    # `roofline` describes the DOMINANT kernel = the one with the larger measured average launch duration in this run;
-    # the other one is kept beside it.  `traffic` comes from profiles/traffic.json (rocprofv3 --pmc, tools/pmc_traffic.py)
-    # and is null whenever that summary was not taken on this build / workload / shard count.
+    # Three roofline objects, one per kernel of the step; `roofline` is the one of the DOMINANT kernel = the largest average launch
+    # duration measured in this run by the library's HIP-event timers around the kernel launches themselves (pair_kernel,
+    # rdisc_sort / order_sweep, sweep_kernel) -- the same timers each object's `achieved` divides by.  `traffic` comes from
+    # profiles/traffic.json (rocprofv3 --pmc, tools/pmc_traffic.py) and is null whenever that summary was not taken on this
+    # build / workload / shard count; traffic_ratio = counter traffic / algorithmic bytes.
+    pk = prof.get("pair", {})
     roof_rdisc = {
-            "kernel": "k_rdisc_mfma_w4 (single pass: fp16 MFMA distance-matrix filter + exact fp64 refine + hit emit)"
+            "kernel": "k_rdisc_mfma_w4 (single pass: fp16 MFMA distance-matrix filter + exact fp64 refine + hit logs)"
             if single_pass else "k_rdisc (count + fill passes)",
             "bound": "mfma", "achieved": ach_tflops, "peak": peak, "unit": "TFLOP/s",
             "frac": ach_tflops / peak,
-            "traffic": prof.get("pair", {}).get("bytes"),
-            "traffic_gather_calibrated": prof.get("pair", {}).get("bytes_gather_calibrated"),
-            "traffic_source": prof.get("source") if prof.get("pair") else None,
+            "traffic": pk.get("bytes"),
+            "traffic_ratio": ratio(pk.get("bytes"), pair_alg_bytes),
+            "algorithmic_bytes": pair_alg_bytes,
+            "traffic_gather_calibrated": pk.get("bytes_gather_calibrated"),
+            "traffic_source": prof.get("source") if pk else None,
             "mfma_flops_issued_tflops": mfma_tflops,
             "frac_of_fp64_peak": ach_tflops / FP64_PEAK_TFLOPS,
-            "valu_per_mfma": prof.get("pair", {}).get("valu_per_mfma"),
+            "valu_per_mfma": pk.get("valu_per_mfma"),
+            "valu_busy": pk.get("valu_busy"),
             "avg_launch_ms": pair_ms,
             "note": "achieved = pairs_tested x 2d algorithmic flop (SURVEY 8d) / kernel time; peak = dense fp16 MFMA "
                     "(the filter runs v_mfma_f32_32x32x%d_f16, %d flop per pair with the norm slots); the kernel is " % (mfma_k, 2 * mfma_k) +
-                    "VALU-issue bound on sign-bit extraction, not MFMA bound; the result is the exact fp64 graph"
+                    "VALU-issue bound: 16 v_alignbit per MFMA read the 1024 accumulator signs (a half-rate VALU class on gfx950, "
+                    "profiles/r03_ubench_valu_classes.txt), the matrix pipe is busy 1/6 of the time; the result is the exact fp64 graph"
         }
     # SURVEY 8d asks for both fractions of the sweep: algorithmic bytes/s over 8 TB/s and fp64 lane-ops/s over 39.3e12.
     # Lane-ops per edge come from the PMC run (SQ_INSTS_VALU x 64 lanes / edges) when the summary matches this build.
-    valu_per_edge = prof.get("sweep", {}).get("valu_lane_ops_per_edge")
+    sk = prof.get("sweep", {})
+    valu_per_edge = sk.get("valu_lane_ops_per_edge")
     valu_frac = (valu_per_edge * nnz / (sweep_ms * 1e-3) / FP64_VALU_LANE_OPS) if (valu_per_edge and sweep_ms > 0) else None
     sorted_rows = os.environ.get("MPFMT_OPT_SWEEP_SORTED", "1") != "0"          # library default: rows gathered from the cell-sorted copy
     ceiling = GATHER_CEILING_L2_ROWS_PER_S if sorted_rows else GATHER_CEILING_ROWS_PER_S
     roof_sweep = {
             "kernel": "k_graph_sweep_rt" if tm["sweep_kernel"][1] > 0 else "k_graph_sweep", "bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": sweep_gbs / HBM_PEAK_GBS,
-            "traffic": prof.get("sweep", {}).get("bytes"),
-            "traffic_gather_calibrated": prof.get("sweep", {}).get("bytes_gather_calibrated"),
-            "l2_hit_rate": prof.get("sweep", {}).get("l2_hit_rate"),
-            "traffic_source": prof.get("source") if prof.get("sweep") else None,
+            "traffic": sk.get("bytes"),
+            "traffic_ratio": ratio(sk.get("bytes"), sweep_bytes),
+            "algorithmic_bytes": sweep_bytes,
+            "traffic_gather_calibrated": sk.get("bytes_gather_calibrated"),
+            "l2_hit_rate": sk.get("l2_hit_rate"),
+            "traffic_source": prof.get("source") if sk else None,
             "valu_frac": valu_frac,
+            "wait_frac": sk.get("wait_frac"),
+            "real_bound": "instruction issue / latency, not HBM: the counters see a fraction of the algorithmic bytes (traffic_ratio; rows come "
+                          "out of L2), the vector ALU issues valu_frac of the unfused fp64 lane-op rate and wait_frac of the wave cycles sit in s_waitcnt",
             "row_gather": "cell-sorted copy Xs by position (L2-friendly)" if sorted_rows else "caller order",
             "gather_ceiling_edges_per_s": ceiling if d == 6 else None,
             "frac_of_gather_ceiling": (nnz / (sweep_ms * 1e-3) / ceiling) if (d == 6 and sweep_ms > 0) else None,
@@ -370,12 +395,26 @@ def main():
                     "L2-resident (tools/ubench/, profiles/r01_ubench_fetch_calib.txt, profiles/r02_ubench_gather_variants.txt); "
                     "stage ablation in DESIGN.md 3.3" % (2 * d * 8 + 8 + 0.125),
         }
-    # dominance is decided between the two STAGES as the library times them (pair stage = "rdisc_count", sweep stage =
-    # "sweep_graph": mask preset + round table + kernel); the roofline of a stage is that of its kernel, on the kernel's own duration
-    if tm["sweep_graph"][0] >= pair_ms:
-        out["roofline"], out["roofline_rdisc"] = roof_sweep, roof_rdisc
-    else:
-        out["roofline"], out["roofline_sweep"] = roof_rdisc, roof_sweep
+    ok_ = prof.get("sort", {})
+    roof_sort = {
+            "kernel": "k_order_logs (hit logs -> ordered CSC%s)" % (" + fused edge tests" if fused else ""),
+            "bound": "hbm", "achieved": sort_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": sort_gbs / HBM_PEAK_GBS,
+            "traffic": ok_.get("bytes"),
+            "traffic_ratio": ratio(ok_.get("bytes"), nnz * sort_bytes_per_edge),
+            "algorithmic_bytes": nnz * sort_bytes_per_edge,
+            "traffic_source": prof.get("source") if ok_ else None,
+            "wait_frac": ok_.get("wait_frac"),
+            "avg_launch_ms": sort_ms,
+            "note": "algorithmic bytes per edge = %.3f: one 16-byte hit record in, rowval + nzval%s out" % (sort_bytes_per_edge, " + free bit, both endpoints" if fused else " + rowpos"),
+        }
+    roofs = {"roofline_rdisc": (pair_ms, roof_rdisc), "roofline_sort": (sort_ms, roof_sort)}
+    if not fused:
+        roofs["roofline_sweep"] = (sweep_ms, roof_sweep)
+    dom = max(roofs, key=lambda k: roofs[k][0])
+    out["roofline"] = dict(roofs[dom][1], dominant_by="largest average kernel launch duration in this run (%s)" % dom)
+    for k, (_, obj) in roofs.items():
+        out[k] = obj
 
     # whole solve (outside the timed region): fmtstar! with the recursion on the device (mpfmt_fmtstar_wavefront) --
     # what a planner call costs end to end, next to the eager step above

@@ -39,6 +39,8 @@ extern "C" {
 #define MPFMT_ERR_NODEVICE   -4   /* no gfx950 device visible: the library has NO CPU fallback */
 #define MPFMT_ERR_CAPACITY   -5   /* caller buffer too small */
 #define MPFMT_ERR_INFEASIBLE -6   /* fmtstar: initial state infeasible (src/planners/fmt.jl:24-29) */
+#define MPFMT_RETRY            1   /* not an error: mpfmt_allgather_free_mask_finish on a ctx driven inside mpfmt_group_begin / _end -- a shard
+                                      outgrew the agreed capacity; call _relaunch for every ctx (in a group), then _finish again */
 
 #define MPFMT_MAX_DIM 16
 
@@ -407,7 +409,15 @@ int32_t mpfmt_di_fmtstar_wavefront(mpfmt_ctx* ctx, double rho, double r, int64_t
  *                       _launch / _finish split the call: the gather runs on the ctx's communication stream and overlaps
  *                       whatever is enqueued next (the following step's index build); cap_hint > 0 = capacity in words
  *                       the caller guarantees to be identical on all ranks (needed by a single-thread driver on the
- *                       first step, when the blocking lengths exchange would wait on a peer it has yet to launch). */
+ *                       first step, when the blocking lengths exchange would wait on a peer it has yet to launch).
+ *                       _launch snapshots the rank's mask, so the next step may overwrite the ctx's mask before _finish.
+ *                       Calls that may sit inside mpfmt_group_begin / _end: mpfmt_comm_create, mpfmt_allgather_free_mask_launch
+ *                       (with cap_hint > 0 the first time) and _relaunch; _finish must come after mpfmt_group_end.  A ctx
+ *                       launched inside a group never repeats a gather on its own (its peers hang off the same thread): _finish
+ *                       returns MPFMT_RETRY on every ctx instead, the driver calls _relaunch for all of them in a group and
+ *                       _finish again.  (Verified with the tests' RCCL stand-in, which defers collectives to the end of
+ *                       the group like RCCL does; a multi-GPU box has not been available.)
+ *                       MPFMT_RCCL_LIB (tests: a stand-in library) is honoured only with MPFMT_ALLOW_RCCL_OVERRIDE=1. */
 #define MPFMT_COMM_ID_BYTES 128
 int32_t mpfmt_comm_unique_id(uint8_t* id128);
 int32_t mpfmt_comm_create(mpfmt_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id128);
@@ -417,6 +427,7 @@ int32_t mpfmt_group_end(void);
 int32_t mpfmt_allgather_free_mask(mpfmt_ctx* ctx, void** gathered, int64_t* stride_words, int64_t* words_each, int64_t* nnz_each);
 int32_t mpfmt_allgather_free_mask_launch(mpfmt_ctx* ctx, int64_t cap_hint);
 int32_t mpfmt_allgather_free_mask_finish(mpfmt_ctx* ctx, void** gathered, int64_t* stride_words, int64_t* words_each, int64_t* nnz_each);
+int32_t mpfmt_allgather_free_mask_relaunch(mpfmt_ctx* ctx);
 
 /* ---- measurement: average device milliseconds per launch of a named kernel group since the last
  *      reset, measured with HIP events on the launch stream.  names: "rdisc_count", "rdisc_fill",

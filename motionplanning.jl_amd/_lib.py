@@ -13,6 +13,7 @@ _SO = os.environ.get("MPFMT_LIB_PATH") or os.path.join(_HERE, "libmpfmt.so")   #
 _LIB = None
 
 OK, ERR_ARG, ERR_STATE, ERR_HIP, ERR_NODEVICE, ERR_CAPACITY, ERR_INFEASIBLE = 0, -1, -2, -3, -4, -5, -6
+RETRY = 1            # mpfmt_allgather_free_mask_finish on a ctx driven inside a group: relaunch every ctx, then finish again
 GOAL_RECT, GOAL_BALL, GOAL_POINT = 0, 1, 2
 MAX_DIM = 16
 
@@ -130,6 +131,7 @@ SYMBOLS = [
     ("mpfmt_allgather_free_mask", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), c_i64_p, c_i64_p, c_i64_p]),
     ("mpfmt_allgather_free_mask_launch", C.c_int32, [C.c_void_p, C.c_int64]),
     ("mpfmt_allgather_free_mask_finish", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), c_i64_p, c_i64_p, c_i64_p]),
+    ("mpfmt_allgather_free_mask_relaunch", C.c_int32, [C.c_void_p]),
     ("mpfmt_timing_reset", C.c_int32, [C.c_void_p]),
     ("mpfmt_timing_get", C.c_int32, [C.c_void_p, C.c_char_p, c_d_p, c_i64_p]),
     ("mpfmt_set_option", C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
@@ -170,6 +172,19 @@ def comm_unique_id():
     if rc != OK:
         raise MPFMTError(rc, lib().mpfmt_last_error(None).decode())
     return u.tobytes()
+
+
+def group_begin():
+    """ncclGroupStart: one host thread driving several ctxs brackets every round of *_launch calls (include/mpfmt.h)."""
+    rc = lib().mpfmt_group_begin()
+    if rc != OK:
+        raise MPFMTError(rc, lib().mpfmt_last_error(None).decode())
+
+
+def group_end():
+    rc = lib().mpfmt_group_end()
+    if rc != OK:
+        raise MPFMTError(rc, lib().mpfmt_last_error(None).decode())
 
 
 def nwords(n):
@@ -507,11 +522,19 @@ class Context:
     def allgather_free_mask_launch(self, cap_hint=0):
         self._chk(self._L.mpfmt_allgather_free_mask_launch(self._h, int(cap_hint)))
 
-    def allgather_free_mask_finish(self, world):
+    def allgather_free_mask_finish(self, world, allow_retry=False):
+        """(device ptr, stride in words, words per rank, nnz per rank); with allow_retry (single-thread drivers of several ctxs)
+        None when the library asks for a relaunch of every ctx (MPFMT_RETRY)."""
         ptr, stride = C.c_void_p(), C.c_int64()
         words = np.zeros(world, dtype=np.int64); nnz = np.zeros(world, dtype=np.int64)
-        self._chk(self._L.mpfmt_allgather_free_mask_finish(self._h, C.byref(ptr), C.byref(stride), _ip(words), _ip(nnz)))
+        rc = self._L.mpfmt_allgather_free_mask_finish(self._h, C.byref(ptr), C.byref(stride), _ip(words), _ip(nnz))
+        if rc == RETRY and allow_retry:
+            return None
+        self._chk(rc)
         return ptr.value, stride.value, words, nnz
+
+    def allgather_free_mask_relaunch(self):
+        self._chk(self._L.mpfmt_allgather_free_mask_relaunch(self._h))
 
     def allgather_free_mask(self, world):
         """One RCCL all-gather of the per-shard free-edge masks: (device ptr, stride in words, words per rank, nnz per rank)."""

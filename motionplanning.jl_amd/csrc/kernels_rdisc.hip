@@ -489,13 +489,15 @@ __global__ void k_degree(const int32_t* __restrict__ slice_cnt, const int32_t* _
         if (o >= 0) {
             for (int i = 0; i < S; ++i) k += slice_cnt[(int64_t)i * npad + s];
             deg[o] = k;
-            degs[s] = k;
         }
+        degs[s] = k;                                           // (pad positions: 0 -- nothing else clears them on an unsharded ctx)
     }
-    // longest column of the shard (one atomic per wavefront): the log-ordering kernel stages whole columns in LDS
+    // longest column of the shard: the log-ordering kernel stages whole columns in LDS.  A wavefront only goes to the atomic
+    // when it beats the maximum it can see (a stale read at worst costs a redundant atomic): one atomic per wavefront on the
+    // single address took 0.18 ms at N = 1e6 (~88 atomics / us)
     int m = (int)min(k, (int64_t)0x7fffffff);
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(max_deg, m);
+    if ((threadIdx.x & 63) == 0 && m > *(volatile int32_t*)max_deg) atomicMax(max_deg, m);
 }
 
 // Per-column ordering: rank each entry by counting smaller row indices (indices in a column are
@@ -693,8 +695,15 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     // 512 pair counters + one word for the longest column (k_degree)
     if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 514 * sizeof(unsigned long long)));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 514 * sizeof(unsigned long long), ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (N + 1), ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->degs, 0, sizeof(int64_t) * (npad + 1), ctx->stream));
+    if (ctx->world > 1 || nt <= 0) {
+        // a shard's k_degree visits its own positions only: everything else must read zero
+        HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (N + 1), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->degs, 0, sizeof(int64_t) * (npad + 1), ctx->stream));
+    } else {
+        // unsharded: k_degree writes every entry but the scans' extra last one
+        HIPCHK(ctx, hipMemsetAsync(ctx->deg + N, 0, sizeof(int64_t), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->degs + npad, 0, sizeof(int64_t), ctx->stream));
+    }
 
     // single-pass pool: capacity from the last build of the same (N, r), else from the ball-volume estimate
     bool pool = mf && ctx->use_pool && nt > 0;
@@ -731,8 +740,10 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     mpfmt_timed tm3(ctx);
     if (nt > 0) {
         if (mf) {
+            mpfmt_timed tk(ctx);                                   // the pair kernel on its own, inside the "rdisc_count" interval
             if (pool) { if ((rc = mpfmt_launch_rdisc_mfma<2>(ctx, r, negT))) return rc; }
             else if ((rc = mpfmt_launch_rdisc_mfma<0>(ctx, r, negT))) return rc;
+            tk.end("pair_kernel");
         } else {
             rdisc_args a;
             fill_args(ctx, r, a);

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <algorithm>
 #include <mutex>
+#include <vector>
 
 namespace {
 
@@ -39,8 +40,16 @@ std::once_flag g_rccl_once;
 
 void rccl_load()
 {
-    // MPFMT_RCCL_LIB: an explicit library (the tests put a shared-memory stand-in there to run several ranks on one GPU)
-    const char* names[] = {getenv("MPFMT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // MPFMT_RCCL_LIB: an explicit library (the tests put a shared-memory stand-in there to run several ranks on one GPU).  An
+    // environment variable must not be able to swap the collective library of a production process by accident: it is
+    // honoured only together with MPFMT_ALLOW_RCCL_OVERRIDE=1
+    const char* over = getenv("MPFMT_RCCL_LIB");
+    const char* allow = getenv("MPFMT_ALLOW_RCCL_OVERRIDE");
+    if (over && *over && !(allow && allow[0] == '1' && allow[1] == 0)) {
+        g_rccl.err = "MPFMT_RCCL_LIB is set without MPFMT_ALLOW_RCCL_OVERRIDE=1: refusing to substitute the collective library";
+        return;
+    }
+    const char* names[] = {over, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         if (!n || !*n) continue;
         g_rccl.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -92,7 +101,11 @@ struct mpfmt_comm {
     int64_t* hdr_host = nullptr;             // pinned [world][2]
     int64_t* hdr_dev = nullptr;              // [world][2] staging of the first (lengths only) exchange
     bool pending = false;
+    bool grouped = false;                    // the gather in flight was launched inside mpfmt_group_begin / _end (one thread, several ctxs)
+    bool post_due = false;                   // its header copy + completion event are still to be enqueued (by mpfmt_group_end)
     int64_t my_words = 0, my_nnz = 0;
+    uint64_t* snap = nullptr;                // this rank's mask as it was at _launch: a repeat at a larger capacity re-sends THAT step
+    int64_t snap_words = 0;
     // generic all-gather staging (wavefront triples): [world][slot]
     void* abuf = nullptr;
     size_t abuf_bytes = 0;
@@ -131,6 +144,48 @@ int32_t mpfmt_comm_world(const mpfmt_ctx* ctx, int* rank, int* world)
     return 0;
 }
 
+static int g_group_depth = 0;                          // mpfmt_group_begin nesting (the single driving thread)
+static std::vector<mpfmt_ctx*> g_group_post;           // ctxs whose gather was launched inside the open group
+
+// what follows the collective on the communication stream: slot headers (lengths) to pinned host memory, completion event
+static int32_t gather_post(mpfmt_ctx* ctx, mpfmt_comm* c)
+{
+    if (!c || !c->post_due) return MPFMT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpy2DAsync(c->hdr_host, 2 * sizeof(int64_t), c->gbuf, (size_t)c->slot_last * sizeof(uint64_t), 2 * sizeof(int64_t),
+                                 (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(ctx, hipEventRecord(c->ev_done, c->stream));
+    c->post_due = false;
+    return MPFMT_OK;
+}
+
+// pack this rank's snapshot into its slot (compute stream) and run the all-gather at capacity c->cap (communication stream)
+static int32_t gather_issue(mpfmt_ctx* ctx, mpfmt_comm* c)
+{
+    const int64_t slot = c->cap + 2;
+    if (c->gbuf_words < slot * c->world) {
+        if (c->gbuf) { HIPCHK(ctx, hipStreamSynchronize(c->stream)); HIPCHK(ctx, hipFree(c->gbuf)); c->gbuf = nullptr; }
+        HIPCHK(ctx, hipMalloc((void**)&c->gbuf, sizeof(uint64_t) * (size_t)(slot * c->world)));
+        c->gbuf_words = slot * c->world;
+    }
+    // pack on the compute stream (after the sweep and the snapshot), exchange on the communication stream
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done, 0));        // the previous gather has left the buffer
+    uint64_t* mine = c->gbuf + (size_t)c->rank * slot;
+    hipLaunchKernelGGL(k_pack_mask, dim3((unsigned)((std::max<int64_t>(c->cap, 1) + 255) / 256)), dim3(256), 0, ctx->stream,
+                       c->snap, c->my_words, c->my_nnz, c->cap, mine);
+    HIPCHK(ctx, hipGetLastError());
+    c->slot_last = slot;
+    HIPCHK(ctx, hipEventRecord(c->ev_compute, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(c->stream, c->ev_compute, 0));
+    NCCLCHK(ctx, g_rccl.AllGather(mine, c->gbuf, (size_t)slot, ncclUint64, c->comm, c->stream));
+    c->post_due = true;
+    c->grouped = g_group_depth > 0;
+    if (c->grouped) g_group_post.push_back(ctx);                        // the collective is enqueued at mpfmt_group_end: so is what follows it
+    else { int32_t rc; if ((rc = gather_post(ctx, c))) return rc; }
+    c->pending = true;
+    return MPFMT_OK;
+}
+
 extern "C" {
 
 int32_t mpfmt_comm_unique_id(uint8_t* id128)
@@ -150,14 +205,24 @@ int32_t mpfmt_group_begin(void)
     int32_t rc;
     if ((rc = rccl_ready(nullptr))) return rc;
     NCCLCHK(nullptr, g_rccl.GroupStart());
+    ++g_group_depth;
     return MPFMT_OK;
 }
 
+// Inside ncclGroupStart / ncclGroupEnd a collective is only ENQUEUED at ncclGroupEnd: whatever must follow it on the stream (the
+// copy of the slot headers to the host, the completion event) is enqueued here, after the group has closed -- issued right
+// behind the ncclAllGather call it would run BEFORE the collective.
 int32_t mpfmt_group_end(void)
 {
     int32_t rc;
     if ((rc = rccl_ready(nullptr))) return rc;
+    if (g_group_depth > 0) --g_group_depth;
     NCCLCHK(nullptr, g_rccl.GroupEnd());
+    if (g_group_depth == 0) {
+        std::vector<mpfmt_ctx*> due;
+        due.swap(g_group_post);
+        for (mpfmt_ctx* ctx : due) if ((rc = gather_post(ctx, (mpfmt_comm*)ctx->comm))) return rc;
+    }
     return MPFMT_OK;
 }
 
@@ -201,6 +266,7 @@ int32_t mpfmt_comm_destroy(mpfmt_ctx* ctx)
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->gbuf) hipFree(c->gbuf);
+    if (c->snap) hipFree(c->snap);
     if (c->abuf) hipFree(c->abuf);
     if (c->hdr_dev) hipFree(c->hdr_dev);
     if (c->hdr_host) hipHostFree(c->hdr_host);
@@ -226,10 +292,12 @@ int32_t mpfmt_allgather_free_mask_launch(mpfmt_ctx* ctx, int64_t cap_hint)
     if (cap_hint < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "cap_hint < 0");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t words = (ctx->nnz + 63) / 64;
-    c->my_words = words; c->my_nnz = ctx->nnz;
     if (cap_hint > 0) {
         c->cap = cap_hint;
     } else if (c->cap < 0) {
+        if (g_group_depth > 0)
+            return mpfmt_fail(ctx, MPFMT_ERR_STATE, "inside mpfmt_group_begin / _end the first mask gather needs cap_hint > 0 (the blocking "
+                                                    "lengths exchange would wait on a peer this thread has yet to launch)");
         int64_t mine[2] = {words, ctx->nnz};
         HIPCHK(ctx, hipMemcpyAsync(c->hdr_dev + 2 * c->rank, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
         NCCLCHK(ctx, g_rccl.AllGather(c->hdr_dev + 2 * c->rank, c->hdr_dev, 2, ncclInt64, c->comm, c->stream));
@@ -239,27 +307,30 @@ int32_t mpfmt_allgather_free_mask_launch(mpfmt_ctx* ctx, int64_t cap_hint)
         for (int g = 0; g < c->world; ++g) mx = std::max(mx, c->hdr_host[2 * g]);
         c->cap = mx + mx / 20 + 8;
     }
-    const int64_t slot = c->cap + 2;
-    if (c->gbuf_words < slot * c->world) {
-        if (c->gbuf) { HIPCHK(ctx, hipStreamSynchronize(c->stream)); HIPCHK(ctx, hipFree(c->gbuf)); c->gbuf = nullptr; }
-        HIPCHK(ctx, hipMalloc((void**)&c->gbuf, sizeof(uint64_t) * (size_t)(slot * c->world)));
-        c->gbuf_words = slot * c->world;
+    // snapshot of this rank's mask and lengths: the overlap protocol runs the NEXT step's kernels before _finish, so a repeat at a
+    // larger capacity must not read the ctx's live mask (it would gather step k+1 under step k's name)
+    c->my_words = words; c->my_nnz = ctx->nnz;
+    if (c->snap_words < std::max<int64_t>(words, 1)) {
+        if (c->snap) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(c->snap)); c->snap = nullptr; }
+        const int64_t want = std::max<int64_t>(words + words / 8, 64);
+        HIPCHK(ctx, hipMalloc((void**)&c->snap, sizeof(uint64_t) * (size_t)want));
+        c->snap_words = want;
     }
-    // pack on the compute stream (after the sweep), exchange on the communication stream
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done, 0));        // the previous gather has left the buffer
-    uint64_t* mine = c->gbuf + (size_t)c->rank * slot;
-    hipLaunchKernelGGL(k_pack_mask, dim3((unsigned)((std::max<int64_t>(c->cap, 1) + 255) / 256)), dim3(256), 0, ctx->stream,
-                       ctx->graph_free, words, ctx->nnz, c->cap, mine);
-    HIPCHK(ctx, hipGetLastError());
-    c->slot_last = slot;
-    HIPCHK(ctx, hipEventRecord(c->ev_compute, ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(c->stream, c->ev_compute, 0));
-    NCCLCHK(ctx, g_rccl.AllGather(mine, c->gbuf, (size_t)slot, ncclUint64, c->comm, c->stream));
-    HIPCHK(ctx, hipMemcpy2DAsync(c->hdr_host, 2 * sizeof(int64_t), c->gbuf, (size_t)slot * sizeof(uint64_t), 2 * sizeof(int64_t),
-                                 (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(ctx, hipEventRecord(c->ev_done, c->stream));
-    c->pending = true;
-    return MPFMT_OK;
+    if (words > 0) HIPCHK(ctx, hipMemcpyAsync(c->snap, ctx->graph_free, sizeof(uint64_t) * (size_t)words, hipMemcpyDeviceToDevice, ctx->stream));
+    return gather_issue(ctx, c);
+}
+
+// the second half of a repeat for single-thread drivers: _finish returned MPFMT_RETRY on every ctx (all saw the same lengths and
+// adopted the same larger capacity); the driver calls this for every ctx inside mpfmt_group_begin / _end, then _finish again
+int32_t mpfmt_allgather_free_mask_relaunch(mpfmt_ctx* ctx)
+{
+    mpfmt_comm* c;
+    int32_t rc;
+    if ((rc = comm_of(ctx, &c))) return rc;
+    if (c->pending) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "a mask gather is already in flight (call _finish)");
+    if (c->cap < 0 || !c->snap) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "nothing to relaunch (no mask gather has been launched)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return gather_issue(ctx, c);
 }
 
 int32_t mpfmt_allgather_free_mask_finish(mpfmt_ctx* ctx, void** gathered, int64_t* stride_words, int64_t* words_each, int64_t* nnz_each)
@@ -268,17 +339,23 @@ int32_t mpfmt_allgather_free_mask_finish(mpfmt_ctx* ctx, void** gathered, int64_
     int32_t rc;
     if ((rc = comm_of(ctx, &c))) return rc;
     if (!c->pending) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no mask gather in flight");
+    if (c->post_due) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "mask gather launched inside a group that is still open (mpfmt_group_end first)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipEventSynchronize(c->ev_done));
     c->pending = false;
     int64_t mx = 0;
     for (int g = 0; g < c->world; ++g) mx = std::max(mx, c->hdr_host[2 * g]);
     if (mx > c->cap) {
-        // a shard outgrew the agreed capacity: every rank sees the same lengths, so all of them repeat at the exact size
+        // a shard outgrew the agreed capacity: every rank sees the same lengths, so all of them repeat at the exact size -- from
+        // the snapshots taken at _launch, i.e. the same step's masks
         c->cap = mx + mx / 20 + 8;
-        if ((rc = mpfmt_allgather_free_mask_launch(ctx, c->cap))) return rc;
+        if (c->grouped) return MPFMT_RETRY;                             // single-thread driver: relaunch all ctxs in a group, then _finish
+        if ((rc = gather_issue(ctx, c))) return rc;
         HIPCHK(ctx, hipEventSynchronize(c->ev_done));
         c->pending = false;
+        mx = 0;
+        for (int g = 0; g < c->world; ++g) mx = std::max(mx, c->hdr_host[2 * g]);
+        if (mx > c->cap) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "mask gather: a rank reports %lld words after the repeat at capacity %lld", (long long)mx, (long long)c->cap);
     } else if (mx < c->cap / 2) {
         c->cap = mx + mx / 20 + 8;            // shards shrank a lot: tighten for the next step (same decision on every rank)
     }

@@ -51,7 +51,7 @@ def main():
     out = {"lib_sha256": lib_sha(), "workload": workload, "n_gpus": 1, "source": os.path.relpath(out_txt, ROOT),
            "method": "bytes = (FETCH_SIZE x 2 + WRITE_SIZE) KiB x 1024 (MI355X_MICROARCH.md HBM section: gfx950 FETCH_SIZE is half the bytes of a "
                      "coalesced read); bytes_gather_calibrated = (FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gathers: FETCH_SIZE = 64 B x read requests)"}
-    for tag, sub in (("pair", "k_rdisc_mfma"), ("sweep", "k_graph_sweep"), ("sort", "k_sortcols_slots")):
+    for tag, sub in (("pair", "k_rdisc_mfma"), ("sweep", "k_graph_sweep"), ("sort", "k_order_logs")):
         p = pick(sub)
         if not p:
             continue
@@ -62,6 +62,11 @@ def main():
              "l2_hit_rate": (p.get("TCC_HIT_sum", 0) / max(p.get("TCC_HIT_sum", 0) + p.get("TCC_MISS_sum", 0), 1))}
         if p.get("SQ_INSTS_MFMA"):
             e["valu_per_mfma"] = p["SQ_INSTS_VALU"] / p["SQ_INSTS_MFMA"]
+        if p.get("SQ_WAVE_CYCLES"):
+            e["wait_frac"] = p.get("SQ_WAIT_ANY", 0) / p["SQ_WAVE_CYCLES"]          # wave cycles parked in s_waitcnt / barriers
+        if p.get("SQ_ACTIVE_INST_VALU") and p.get("GRBM_GUI_ACTIVE"):
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE cycles summed over the 8 XCDs
+            e["valu_busy"] = p["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (p["GRBM_GUI_ACTIVE"] / 8.0)
         if tag == "sweep" and nnz:
             e["valu_lane_ops_per_edge"] = p.get("SQ_INSTS_VALU", 0) * 64.0 / nnz
         out[tag] = e
