@@ -1,8 +1,11 @@
 # MPFmtHIP.jl -- libmpfmt.so (MI355X) under MotionPlanning.jl's own dispatch.  `include` after `using MotionPlanning`.
 # Julia 0.5/0.6 dialect like the reference (type / immutable / Ptr{Void}).  Julia is not installed where this repository is
-# built: every ccall below is executed, with exactly these argument widths, by tests/abi_c/abi_caller.c (gcc, -m gpu).
-import MotionPlanning: helper_data_structures, inball, is_free_state, is_free_motion, DistanceDataStructure,
-                       SweptCollisionChecker, EmptyControlCache, BoxBounds, ImmutableNNC, MetricNN, statevec2mat
+# built: every ccall below is executed, with exactly these argument widths, by tests/abi_c/abi_caller.c and abi_caller2.c (gcc,
+# -m gpu; a width that differs from include/mpfmt.h fails their build), and what they return is compared with the oracle.
+import MotionPlanning: helper_data_structures, inball, is_free_state, is_free_motion, closest, closeR, sample_free!,
+                       DistanceDataStructure, SweptCollisionChecker, EmptyControlCache, BruteDistanceDS, BoxBounds, ImmutableNNC,
+                       MetricNN, statevec2mat, LinearQuadratic, ChoppedMetric, ChoppedQuasiMetric, ReedsSheppExact, DubinsExact,
+                       SE2State, PointRobot2D, Circle, Polygon, Compound2D, Shape2D
 const libmpfmt = "libmpfmt"                      # motionplanning.jl_amd/libmpfmt.so on LD_LIBRARY_PATH
 lasterr(ctx) = unsafe_string(ccall((:mpfmt_last_error, libmpfmt), Cstring, (Ptr{Void},), ctx))
 chk(ctx::Ptr{Void}, rc::Int32) = rc == 0 || error(lasterr(ctx))
@@ -119,4 +122,134 @@ function hip_comm_create!(ctxs::Vector{Ptr{Void}})
         chk(c, ccall((:mpfmt_comm_create, libmpfmt), Int32, (Ptr{Void}, Int32, Int32, Ptr{UInt8}), c, g - 1, length(ctxs), id))
     end
     ccall((:mpfmt_group_end, libmpfmt), Int32, ())
+end
+
+
+# One thread, G ctxs, one step of the eager hot path on every GPU and the free-edge masks of all shards on each of them
+# (what `bench.py --gpus G` does with one process per GPU).  Launch everything, then finish everything: no call blocks on a
+# peer this thread has yet to launch.  `first` = true on the first step (the thread has seen every shard's nnz: it agrees the
+# capacity itself instead of the blocking lengths exchange).  Returns per-ctx (device pointer, stride in words, words, nnz).
+function hip_graph_step!(ctxs::Vector{Ptr{Void}}, r::Float64; first::Bool = false)
+    G = length(ctxs); nnz = Vector{Int64}(G)
+    for c in ctxs
+        chk(c, ccall((:mpfmt_graph_step_launch, libmpfmt), Int32, (Ptr{Void}, Float64), c, r))
+    end
+    for (g, c) in enumerate(ctxs)
+        n = Ref{Int64}(0)
+        chk(c, ccall((:mpfmt_graph_step_finish, libmpfmt), Int32, (Ptr{Void}, Ptr{Int64}), c, n)); nnz[g] = n[]
+    end
+    hint = first ? div(maximum(nnz) + 63, 64) + 64 : 0
+    ccall((:mpfmt_group_begin, libmpfmt), Int32, ())
+    for c in ctxs
+        chk(c, ccall((:mpfmt_allgather_free_mask_launch, libmpfmt), Int32, (Ptr{Void}, Int64), c, hint))
+    end
+    ccall((:mpfmt_group_end, libmpfmt), Int32, ())
+    hip_gather_finish!(ctxs)
+end
+function hip_gather_finish!(ctxs::Vector{Ptr{Void}})
+    G = length(ctxs)
+    out = Vector{Any}(G)
+    while true
+        again = false
+        for (g, c) in enumerate(ctxs)
+            ptr = Ref{Ptr{Void}}(C_NULL); stride = Ref{Int64}(0); words = Vector{Int64}(G); nnzs = Vector{Int64}(G)
+            rc = ccall((:mpfmt_allgather_free_mask_finish, libmpfmt), Int32,
+                       (Ptr{Void}, Ptr{Ptr{Void}}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}), c, ptr, stride, words, nnzs)
+            rc == 1 ? (again = true) : chk(c, rc)             # MPFMT_RETRY: a shard outgrew the capacity (every ctx reports it)
+            out[g] = (ptr[], stride[], words, nnzs)
+        end
+        again || return out
+        ccall((:mpfmt_group_begin, libmpfmt), Int32, ())
+        for c in ctxs
+            chk(c, ccall((:mpfmt_allgather_free_mask_relaunch, libmpfmt), Int32, (Ptr{Void},), c))
+        end
+        ccall((:mpfmt_group_end, libmpfmt), Int32, ())
+    end
+end
+
+# ---- LinearQuadratic (double integrator): helper_data_structures(V, M::LinearQuadratic) (linearquadratic.jl:68-77) ----------
+# States are uploaded with mpfmt_upload_samples(ctx, X, N, 2m), obstacles with mpfmt_upload_boxes(ctx, lohi, M, m, lo, hi, 2m)
+# (workspace = first m coordinates, OutputMatrix([I 0]), linearquadratic.jl:51-52).
+function helper_data_structures{S}(V::Vector{S}, M::LinearQuadratic, DS::HIPDistanceDS)
+    N = length(V); colptr = Vector{Int}(N + 1); nnz = Ref{Int64}(0)
+    chk(DS.ctx, ccall((:mpfmt_di_graph_count, libmpfmt), Int32, (Ptr{Void}, Float64, Float64, Ptr{Int64}, Ptr{Int64}),
+                      DS.ctx, M.bvp.R[1,1], M.cmax, colptr, nnz))
+    rowval = Vector{Int}(nnz[]); nzval = Vector{Float64}(nnz[]); tval = Vector{Float64}(nnz[])
+    chk(DS.ctx, ccall((:mpfmt_di_graph_fill, libmpfmt), Int32, (Ptr{Void}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}),
+                      DS.ctx, rowval, nzval, tval))
+    Dmat = SparseMatrixCSC(N, N, colptr, rowval, nzval)
+    BruteDistanceDS(Dmat'), EmptyControlCache(), BruteDistanceDS(Dmat), EmptyControlCache()   # DSF, USF, DSB, USB
+end
+# every is_free_motion(V[y], V[x], CC, SS) of the steering graph (5 collision waypoints, linearquadratic.jl:85-88) and the
+# number of workspace segment tests the reference would have made for it (its CC.count increments)
+function hip_di_edges_free(DS::HIPDistanceDS, nnz::Int)
+    free = falses(nnz); nseg = Vector{UInt8}(nnz)
+    chk(DS.ctx, ccall((:mpfmt_di_graph_edges_free, libmpfmt), Int32, (Ptr{Void}, Ptr{UInt64}, Ptr{UInt8}), DS.ctx, free.chunks, nseg))
+    free, nseg
+end
+
+# ---- simple cars (simplecars.jl:42-49): chopped Reeds-Shepp metric / Dubins quasi-metric ---------------------------------------
+function helper_data_structures{S<:SE2State,R<:ReedsSheppExact}(V::Vector{S}, M::ChoppedMetric{R}, DS::HIPDistanceDS)
+    N = length(V); colptr = Vector{Int}(N + 1); nnz = Ref{Int64}(0)
+    chk(DS.ctx, ccall((:mpfmt_reedsshepp_graph_count, libmpfmt), Int32, (Ptr{Void}, Float64, Float64, Float64, Ptr{Int64}, Ptr{Int64}),
+                      DS.ctx, M.m.r, M.m.s, M.chopval, colptr, nnz))
+    rowval = Vector{Int}(nnz[]); nzval = Vector{Float64}(nnz[])
+    chk(DS.ctx, ccall((:mpfmt_reedsshepp_graph_fill, libmpfmt), Int32, (Ptr{Void}, Ptr{Int64}, Ptr{Float64}), DS.ctx, rowval, nzval))
+    BruteDistanceDS(SparseMatrixCSC(N, N, colptr, rowval, nzval)), EmptyControlCache()      # column v = inball(v), ds = d(v, w)
+end
+function helper_data_structures{S<:SE2State,R<:DubinsExact}(V::Vector{S}, M::ChoppedQuasiMetric{R}, DS::HIPDistanceDS)
+    N = length(V); colptr = Vector{Int}(N + 1); nnz = Ref{Int64}(0)
+    chk(DS.ctx, ccall((:mpfmt_dubins_graph_count, libmpfmt), Int32, (Ptr{Void}, Float64, Float64, Float64, Ptr{Int64}, Ptr{Int64}),
+                      DS.ctx, M.m.r, M.m.s, M.chopval, colptr, nnz))
+    rowval = Vector{Int}(nnz[]); nzval = Vector{Float64}(nnz[])
+    chk(DS.ctx, ccall((:mpfmt_dubins_graph_fill, libmpfmt), Int32, (Ptr{Void}, Ptr{Int64}, Ptr{Float64}), DS.ctx, rowval, nzval))
+    Dmat = SparseMatrixCSC(N, N, colptr, rowval, nzval)                                      # column x = backward set of x
+    BruteDistanceDS(Dmat'), EmptyControlCache(), BruteDistanceDS(Dmat), EmptyControlCache()
+end
+
+# ---- closest / closeR (boxesND.jl:33-34,61-86; robots2D.jl:25-26), one call for a batch of query points (columns of P) ----------
+function closest(P::Matrix{Float64}, CC::HIPBoxes, W::Matrix{Float64})
+    n = size(P, 2); d2 = Vector{Float64}(n); v = similar(P); k = Vector{Int}(n); fails = Ref{Int64}(0)
+    chk(CC.ctx, ccall((:mpfmt_closest, libmpfmt), Int32,
+                      (Ptr{Void}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}),
+                      CC.ctx, P, n, W, d2, v, k, fails))
+    fails[] == 0 || error("bvls returned nothing for $(fails[]) (point, box) pair(s)")     # what bvls.jl:67 leads to in the reference
+    d2, v
+end
+function closeR(P::Matrix{Float64}, CC::HIPBoxes, W::Matrix{Float64}, r2::Float64)
+    n = size(P, 2); dw = size(P, 1); ptr = Vector{Int}(n + 1); total = Ref{Int64}(0); fails = Ref{Int64}(0)
+    cap = n * length(CC.boxes)                   # every (point, obstacle) pair at most
+    obstacle = Vector{Int}(cap); d2 = Vector{Float64}(cap); v = Matrix{Float64}(dw, cap)
+    chk(CC.ctx, ccall((:mpfmt_closeR, libmpfmt), Int32,
+                      (Ptr{Void}, Ptr{Float64}, Int64, Ptr{Float64}, Float64, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Float64},
+                       Ptr{Int64}, Ptr{Int64}),
+                      CC.ctx, P, n, W, r2, ptr, cap, obstacle, d2, v, total, fails))
+    ptr, obstacle[1:total[]], d2[1:total[]], v[:, 1:total[]]
+end
+
+# ---- 2-D SAT world: PointRobot2D(Compound2D(parts)) (robots2D.jl:5-14) -----------------------------------------------------------
+# kinds 0 = Circle (cx, cy, r), 1 = Polygon (x1, y1, x2, y2, ...); afterwards every validity entry point of the ctx answers with
+# the SAT predicates (SAT2D.jl:119-178) until mpfmt_upload_boxes switches back
+function hip_upload_shapes!(ctx::Ptr{Void}, parts::Vector, lo::Vector{Float64}, hi::Vector{Float64})
+    kinds = Int32[]; nverts = Int32[]; data = Float64[]
+    for s in parts
+        if isa(s, Circle)
+            push!(kinds, 0); push!(nverts, 0); append!(data, [s.c[1], s.c[2], s.r])
+        else
+            push!(kinds, 1); push!(nverts, length(s.points)); for p in s.points; append!(data, [p[1], p[2]]); end
+        end
+    end
+    chk(ctx, ccall((:mpfmt_upload_shapes2d, libmpfmt), Int32,
+                   (Ptr{Void}, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                   ctx, length(kinds), kinds, nverts, data, lo, hi))
+end
+
+# ---- sample_free!(P, N) (sampling.jl:11-45): the rejection loop in device batches (counter-based stream, sequential semantics) ----
+function hip_sample_free!(ctx::Ptr{Void}, seed::UInt64, N::Int, init::Vector{Float64}, goal_kind::Int32, goal_params::Vector{Float64},
+                          goal_ct::Int32)
+    X = Matrix{Float64}(length(init), N); attempts = Ref{Int64}(0)
+    chk(ctx, ccall((:mpfmt_sample_free, libmpfmt), Int32,
+                   (Ptr{Void}, UInt64, Int64, Ptr{Float64}, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Int64}),
+                   ctx, seed, N, init, goal_kind, goal_params, goal_ct, X, attempts))
+    X, attempts[]
 end

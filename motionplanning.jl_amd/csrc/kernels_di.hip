@@ -485,7 +485,7 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->slice_cnt, sizeof(int32_t) * (size_t)S * std::max<int64_t>(npad, 1)))) return rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->deg, sizeof(int64_t) * (N + 1)))) return rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (N + 1)))) return rc;
-    if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 512 * sizeof(unsigned long long)));
+    if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 514 * sizeof(unsigned long long)));     // (512 pair counters + the Euclidean build's longest-column word: one size everywhere)
     HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 2 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (N + 1), ctx->stream));
     di_args a;

@@ -1,8 +1,10 @@
 /* A C caller of libmpfmt.so that makes every call julia/MPFmtHIP.jl makes, with exactly the argument widths of its `ccall`
  * signatures (Int32 -> int32_t, Int64 / Int -> int64_t, Float64 -> double, Ptr{T} -> T*, Ptr{Void} -> void*).  The typedefs
- * below are written from the Julia file, NOT from mpfmt.h; assigning the library's symbols to them is a compile-time check
- * (-Werror=incompatible-pointer-types) that the glue's widths are the header's.  tests/test_gpu_boundary.py builds this with
- * gcc, runs it on the GPU box and compares what it wrote with the oracle.
+ * below are written from the Julia file, NOT from mpfmt.h; casting the library's symbols to them under -Wcast-function-type -Werror
+ * is a compile-time check that the glue's widths are the header's (pointer parameters match any pointer, integer and float
+ * widths and the argument count must agree -- tests/test_gpu_boundary.py also checks that a wrong width does fail the build).
+ * tests/test_gpu_boundary.py builds this with gcc, runs it on the GPU box and compares what it wrote with the oracle.
+ * (abi_caller2.c does the same for the glue of the other spaces and checkers.)
  * usage: abi_caller <input.bin> <output.bin> */
 #include <stdio.h>
 #include <stdlib.h>

@@ -19,7 +19,9 @@ def test_c_caller_with_ccall_widths(orc, tmp_path):
     w = mp.workloads.make("t", 2500, 3, 30, 0.05, 0.12, seed=5, goal_radius=0.1)
     exe = str(tmp_path / "abi_caller")
     pkg = os.path.join(ROOT, "motionplanning.jl_amd")
-    subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Werror=incompatible-pointer-types", "-I", os.path.join(ROOT, "include"),
+    # -Wcast-function-type -Werror: the typedefs are written from the Julia file's ccall signatures; a cast of the library's symbol to
+    # one of them with a different integer / float width, or another argument count, fails the build (pointers match any pointer)
+    subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Wextra", "-Wcast-function-type", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "abi_c", "abi_caller.c"), "-o", exe, "-L", pkg, "-lmpfmt", "-Wl,-rpath," + pkg])
     N, d, M = w.N, w.d, w.M
     band = 0.4 * w.r
@@ -63,6 +65,104 @@ def test_c_caller_with_ccall_widths(orc, tmp_path):
         assert np.array_equal(A - 1, ref["A"]) and np.array_equal(C, ref["C"]) and np.array_equal(path - 1, ref["path"])
     nnz2, stride, wcount, ncount = take(np.int64, 4)
     assert nnz2 == nnz and ncount == nnz and wcount == (nnz + 63) // 64 and stride == wcount + 16 + 2
+    assert pos[0] == len(buf)
+
+
+def test_a_wrong_ccall_width_fails_the_build(tmp_path):
+    """The guard the C callers rely on: the same cast with one Int64 turned into an Int32 must not compile."""
+    src = tmp_path / "bad.c"
+    src.write_text('#include "mpfmt.h"\ntypedef int32_t (*f_bad)(void*, const double*, int32_t, int32_t);\n'
+                   'int main(void) { f_bad f = (f_bad)mpfmt_upload_samples; return f == 0; }\n')
+    p = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Wcast-function-type", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                        "-o", str(tmp_path / "bad.o")], capture_output=True, text=True)
+    assert p.returncode != 0 and "cast-function-type" in p.stderr
+
+
+def test_c_caller_of_the_other_spaces(orc, tmp_path):
+    """julia/MPFmtHIP.jl beyond Euclidean + boxes: double integrator, Dubins / Reeds-Shepp, closest / closeR, the 2-D SAT world, the
+    sampler and the single-thread step loop (launch / finish, grouped gather, relaunch) -- called from C with the ccall widths
+    (tests/abi_c/abi_caller2.c) and compared with the oracle."""
+    import json
+    exe = str(tmp_path / "abi_caller2")
+    pkg = os.path.join(ROOT, "motionplanning.jl_amd")
+    subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Wextra", "-Wcast-function-type", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_c", "abi_caller2.c"), "-o", exe, "-L", pkg, "-lmpfmt", "-Wl,-rpath," + pkg])
+    rng = np.random.default_rng(12)
+    N4, N3, Mb, nq, Ns, seed = 500, 700, 12, 300, 2000, 4242
+    rho, r_di, rt, sp, r_car, r2, r_e = 1.0, 0.8, 0.1, 1.0, 0.25, 0.05, 0.06
+    c = rng.uniform(0.2, 0.8, (Mb, 2)); hw = rng.uniform(0.03, 0.07, (Mb, 2))
+    lohi2 = np.stack([c - hw, c + hw], axis=1)                                  # (M, 2, dw)
+    X4 = np.concatenate([rng.uniform(0, 1, (N4, 2)), rng.uniform(-0.5, 0.5, (N4, 2))], axis=1)
+    X3 = np.concatenate([rng.uniform(0, 1, (N3, 2)), rng.uniform(0, 2 * np.pi, (N3, 1))], axis=1)
+    lo4, hi4 = np.array([0, 0, -0.5, -0.5]), np.array([1, 1, 0.5, 0.5])
+    lo3, hi3 = np.array([0, 0, 0.0]), np.array([1, 1, 2 * np.pi])
+    lo2, hi2 = np.zeros(2), np.ones(2)
+    Pq = rng.uniform(0, 1, (nq, 2))
+    A_ = rng.normal(size=(2, 2)); W = A_ @ A_.T + 0.5 * np.eye(2)
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "shapes_2d.json")))["worlds"]["ISRR_POLY_WITH_SPIKE"]
+    kinds = np.array([0 if s[0] == "circle" else 1 for s in fx], dtype=np.int32)
+    nverts = np.array([0 if s[0] == "circle" else len(s[1]) for s in fx], dtype=np.int32)
+    data = np.concatenate([np.array([s[1][0], s[1][1], s[2]]) if s[0] == "circle" else np.asarray(s[1], dtype=np.float64).ravel() for s in fx])
+    init2 = np.array([0.05, 0.05]); goal = np.array([0.9, 0.9, 0.05])
+    with open(tmp_path / "in2.bin", "wb") as f:
+        f.write(np.array([N4, N3, Mb, nq, len(kinds), len(data), Ns, seed], dtype=np.int64).tobytes())
+        f.write(np.array([rho, r_di, rt, sp, r_car, r2, r_e, 0.0], dtype=np.float64).tobytes())
+        for a in (X4, X3, lohi2, lo4, hi4, lo3, hi3, lo2, hi2, Pq, W):
+            f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+        f.write(kinds.tobytes()); f.write(nverts.tobytes()); f.write(np.ascontiguousarray(data, dtype=np.float64).tobytes())
+        f.write(init2.tobytes()); f.write(goal.tobytes())
+    env = dict(os.environ)
+    import torch
+    env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(os.path.dirname(torch.__file__), "lib"), "/opt/rocm/lib", env.get("LD_LIBRARY_PATH", "")])
+    p = subprocess.run([exe, str(tmp_path / "in2.bin"), str(tmp_path / "out2.bin")], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    buf = open(tmp_path / "out2.bin", "rb").read()
+    pos = [0]
+
+    def take(dtype, n):
+        a = np.frombuffer(buf, dtype=dtype, count=int(n), offset=pos[0])
+        pos[0] += a.nbytes
+        return a
+    # double integrator
+    nnz = int(take(np.int64, 1)[0])
+    colptr, rowval, nzval, tval = take(np.int64, N4 + 1), take(np.int64, nnz), take(np.float64, nnz), take(np.float64, nnz)
+    fr, nseg = take(np.uint64, (nnz + 63) // 64), take(np.uint8, nnz)
+    oc, orow, oval, otv = orc.di_pairwise(X4, rho, r_di)
+    assert nnz == len(orow) and np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow)
+    assert np.array_equal(nzval, oval) and np.array_equal(tval, otv)
+    assert np.array_equal(fr, orc.di_graph_edges_free(X4, rho, r_di, oc, orow, lohi2, lo4, hi4))
+    assert nseg.max() <= 4
+    # cars
+    for name, graph in (("dubins", orc.dubins_graph), ("reedsshepp", orc.rs_graph)):
+        nnz = int(take(np.int64, 1)[0])
+        colptr, rowval, nzval = take(np.int64, N3 + 1), take(np.int64, nnz), take(np.float64, nnz)
+        oc, orow, oval = graph(X3, rt, sp, r_car)
+        assert nnz == len(orow) and np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow), name
+        assert np.array_equal(nzval, oval), name
+    # closest / closeR
+    d2, v, k, fails = take(np.float64, nq), take(np.float64, nq * 2).reshape(nq, 2), take(np.int64, nq), int(take(np.int64, 1)[0])
+    od2, ov, ok, obad = orc.closest_boxes(Pq, lohi2, W)
+    assert fails == obad and np.array_equal(k - 1, ok)
+    assert np.allclose(d2, od2, rtol=1e-9, atol=1e-15) and np.allclose(v, ov, rtol=1e-9, atol=1e-12)
+    total = int(take(np.int64, 1)[0])
+    ptr, ob, dd, vv = take(np.int64, nq + 1), take(np.int64, total), take(np.float64, total), take(np.float64, total * 2).reshape(total, 2)
+    optr, oidx, odd, ovv = orc.closeR_boxes(Pq, lohi2, W, r2)
+    assert total == len(oidx) and np.array_equal(ptr - 1, optr) and np.array_equal(ob - 1, oidx)
+    assert np.allclose(dd, odd, rtol=1e-9, atol=1e-15) and np.allclose(vv, ovv, rtol=1e-9, atol=1e-12)
+    # sampler + the step loop on the sampled set
+    Xs, attempts = take(np.float64, Ns * 2).reshape(Ns, 2), int(take(np.int64, 1)[0])
+    rc, Wo, oatt = orc.sample_free(seed, Ns, 2, init2, lohi2, lo2, hi2, mp._lib.GOAL_BALL, goal, goal_ct=3)
+    assert rc == 0 and np.array_equal(Xs, Wo) and attempts == oatt
+    for step in range(2):
+        nnz, words, nn, retried = take(np.int64, 4)
+        oc, orow, _ = orc.rdisc_graph(Xs, r_e * (1.5 if step else 1.0))
+        assert nnz == len(orow) == nn and words == (nnz + 63) // 64
+        assert retried == (1 if step else 0)                     # the larger radius outgrew the agreed capacity: MPFMT_RETRY -> relaunch
+    # 2-D SAT world
+    S = orc.Shapes2D([("circle", tuple(s[1]), s[2]) if s[0] == "circle" else ("polygon", [tuple(q) for q in s[1]]) for s in fx])
+    mpt, mseg = take(np.uint64, (nq + 63) // 64), take(np.uint64, (nq - 1 + 63) // 64)
+    assert np.array_equal(mpt, orc.points_free_2d(Pq, S, lo2, hi2))
+    assert np.array_equal(mseg, orc.motions_free_2d(Pq[:-1], Pq[1:], S, lo2, hi2))
     assert pos[0] == len(buf)
 
 

@@ -358,3 +358,32 @@ def test_car_wavefront_matches_sequential(ctx, car):
     assert band["status"] == seq["status"]
     if seq["status"] == 1:
         assert seq["cost"] * (1 - 1e-12) <= band["cost"] <= seq["cost"] * 1.3
+
+
+@pytest.mark.parametrize("N,d,M,seed,bandf,single", [(3000, 2, 25, 5, 0.3, False), (3000, 2, 25, 5, 50.0, False), (20, 2, 3, 6, 0.0, True),
+                                                      (6000, 3, 40, 7, 2.0, False)])
+def test_run_path_counts_equal_the_stepwise_loop(ctx, N, d, M, seed, bandf, single):
+    """mpfmt_wf_run enqueues steps in groups (8; 32 in single-node mode); the steps enqueued behind the goal batch must be
+    void -- batch size, batch total and the batch list of the run path equal the one-step-at-a-time loop, also when the band
+    takes the whole open set (|Z| > N / 8) and when N is smaller than a group (single mode, N < 32)."""
+    w = world(N, d, M, seed, goal_radius=0.2)
+    upload(ctx, w)
+    ctx.wf_begin(w.r, L.GOAL_BALL, w.goal_params(), band=bandf * w.r, single=single)
+    infos = []
+    while True:
+        info = ctx.wf_step()
+        infos.append(info)
+        if info["done"]:
+            break
+    zs_step = np.sort(ctx.wf_batch())
+    res_step = ctx.wf_finish()
+    got = ctx.fmtstar_wavefront(w.r, L.GOAL_BALL, w.goal_params(), band=bandf * w.r, single=single)
+    zs_run = np.sort(ctx.wf_batch())
+    gi, si = got["info"], infos[-1]
+    assert gi["done"] == si["done"] and gi["iters"] == si["iters"]
+    assert gi["nz"] == si["nz"] and gi["tot_z"] == si["tot_z"], (gi, si)
+    assert gi["nx"] == si["nx"] and gi["tot_x"] == si["tot_x"] and gi["tot_conn"] == si["tot_conn"]
+    assert np.array_equal(zs_run, zs_step) and len(zs_run) == gi["nz"]
+    assert got["status"] == res_step["status"] and got["z"] == res_step["z"] and got["cost"] == res_step["cost"]
+    assert got["collision_checks"] == res_step["collision_checks"]
+    assert np.array_equal(got["A"], res_step["A"])
