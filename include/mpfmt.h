@@ -256,6 +256,12 @@ int32_t mpfmt_closeR(mpfmt_ctx* ctx, const double* P, int64_t n, const double* W
 #define MPFMT_SHAPE_POLYGON 1
 int32_t mpfmt_upload_shapes2d(mpfmt_ctx* ctx, int32_t n_shapes, const int32_t* kinds, const int32_t* nverts, const double* data,
                               const double* ss_lo, const double* ss_hi);
+/* The 2-D SAT world under a steering space (the notebook's double-integrator and Dubins examples, docs/MotionPlanning.ipynb cells 7-11:
+ * PointRobot2D with DoubleIntegrator(2) / DubinsQuasiMetricSpace): upload the shapes (workspace bounds), then the state-space
+ * bounds of the steering space (4 for the double integrator, 3 for SE2; src/statespaces.jl:29-34, in_state_space :150).  The
+ * steering sweeps (mpfmt_di_graph_edges_free, mpfmt_dubins_ / mpfmt_reedsshepp_graph_edges_free, the *_fmtstar calls) then test
+ * their workspace segments with is_free_motion(v, w, CC::PointRobot2D) (robots2D.jl:13-14). */
+int32_t mpfmt_set_state_bounds(mpfmt_ctx* ctx, const double* ss_lo, const double* ss_hi, int32_t d_state);
 
 /* ---- graph persistence: install a graph exported earlier by mpfmt_rdisc_count / mpfmt_rdisc_fill (same
  *      1-based CSC: colptr[N+1], rowval[nnz] strictly ascending per column, nzval[nnz]) for the samples now uploaded --

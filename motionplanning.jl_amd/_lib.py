@@ -132,6 +132,7 @@ SYMBOLS = [
     ("mpfmt_allgather_free_mask_launch", C.c_int32, [C.c_void_p, C.c_int64]),
     ("mpfmt_allgather_free_mask_finish", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), c_i64_p, c_i64_p, c_i64_p]),
     ("mpfmt_allgather_free_mask_relaunch", C.c_int32, [C.c_void_p]),
+    ("mpfmt_set_state_bounds", C.c_int32, [C.c_void_p, c_d_p, c_d_p, C.c_int32]),
     ("mpfmt_timing_reset", C.c_int32, [C.c_void_p]),
     ("mpfmt_timing_get", C.c_int32, [C.c_void_p, C.c_char_p, c_d_p, c_i64_p]),
     ("mpfmt_set_option", C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
@@ -283,6 +284,11 @@ class Context:
     # ---- setup ----------------------------------------------------------------------------------
     def set_stream(self, stream_handle):
         self._chk(self._L.mpfmt_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def set_state_bounds(self, ss_lo, ss_hi):
+        """BoundedStateSpace lo / hi of any state dimension (after upload_shapes2d: the bounds of a steering space over the 2-D world)."""
+        lo = np.ascontiguousarray(ss_lo, dtype=np.float64); hi = np.ascontiguousarray(ss_hi, dtype=np.float64)
+        self._chk(self._L.mpfmt_set_state_bounds(self._h, _dp(lo), _dp(hi), len(lo)))
 
     def set_shard(self, rank, world):
         self._chk(self._L.mpfmt_set_shard(self._h, int(rank), int(world)))

@@ -13,6 +13,7 @@
 #include <rocprim/rocprim.hpp>
 #include "mpfmt_internal.h"
 #include "mp_math.h"
+#include "sat2d_predicates.h"
 
 #define CAR_TWOPI (2 * 3.141592653589793)
 
@@ -468,7 +469,7 @@ __device__ __forceinline__ bool in_ss3(const double* p, const mpfmt_ss& ss)
 
 // is_free_motion(v, w, CC, SS) over the reference's collision waypoints; *nseg = segment tests made (CC.count)
 template <int KIND>
-__device__ inline bool car_motion_free(const double* v0, const double* w, double rt, double sp, const double* __restrict__ boxes, int M,
+__device__ inline bool car_motion_free(const double* v0, const double* w, double rt, double sp, const mpfmt_ws2d& cc,
                                        const mpfmt_ss& ss, int* nseg)
 {
     car_step path[5];
@@ -482,7 +483,12 @@ __device__ inline bool car_motion_free(const double* v0, const double* w, double
     auto visit = [&](const double* p) {               // p is the next waypoint: test the pair (prev, p)
         if (ok && have_prev) {
             if (!in_ss3(prev, ss)) ok = false;
-            else { ++cnt; if (!seg_free_boxes2(prev[0], prev[1], p[0], p[1], boxes, M)) ok = false; }
+            else {
+                ++cnt;                                     // boxesND.jl:26 / robots2D.jl:13: one count per segment asked for
+                const bool fr = cc.kind == 1 ? motion_free_2d(prev[0], prev[1], p[0], p[1], cc.shapes, cc.ns, cc.aabb)
+                                             : seg_free_boxes2(prev[0], prev[1], p[0], p[1], cc.boxes, cc.M);
+                if (!fr) ok = false;
+            }
         }
         prev[0] = p[0]; prev[1] = p[1]; prev[2] = p[2]; have_prev = true;
     };
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(64) void k_car_compact(const int64_t* __restrict__ 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_car_sweep(const double* __restrict__ X, int64_t N, const int64_t* __restrict__ colptr,
                                                    const int32_t* __restrict__ rowval, int64_t nnz, double rt, double sp,
-                                                   const double* __restrict__ boxes, int M, mpfmt_ss ss, uint64_t* __restrict__ mask,
+                                                   mpfmt_ws2d cc, mpfmt_ss ss, uint64_t* __restrict__ mask,
                                                    uint8_t* __restrict__ nseg)
 {
     const int lane = threadIdx.x & 63;
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(256) void k_car_sweep(const double* __restrict__ X,
         while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (colptr[mid] <= e) lo = mid; else hi = mid; }
         const int64_t x = lo, y = rowval[e];
         int ns = 0;
-        fr = car_motion_free<KIND>(X + 3 * y, X + 3 * x, rt, sp, boxes, M, ss, &ns);
+        fr = car_motion_free<KIND>(X + 3 * y, X + 3 * x, rt, sp, cc, ss, &ns);
         nseg[e] = (uint8_t)min(ns, 255);
     }
     const unsigned long long bits = __ballot(fr);
@@ -702,8 +708,11 @@ int32_t mpfmt_car_build(mpfmt_ctx* ctx, int kind, double rt, double sp, double r
 int32_t mpfmt_car_sweep(mpfmt_ctx* ctx)
 {
     if (!(ctx->di_filled && (ctx->steer_kind == 2 || ctx->steer_kind == 3))) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car sweep before the car graph is built");
-    if (!ctx->have_boxes || ctx->cc_kind != 0 || ctx->dw != 2)
-        return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the Dubins sweep needs 2-D boxes (mpfmt_upload_boxes with dw = 2 and the 3 SE2 bounds)");
+    if (!ctx->have_boxes || ctx->dw != 2)
+        return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the car sweep needs a 2-D workspace checker (mpfmt_upload_boxes with dw = 2, or mpfmt_upload_shapes2d) and the 3 SE2 bounds");
+    mpfmt_ws2d cc;
+    cc.kind = ctx->cc_kind; cc.boxes = ctx->boxes; cc.M = ctx->cc_kind == 0 ? ctx->M : 0;
+    cc.shapes = ctx->shapes2d; cc.ns = ctx->cc_kind == 1 ? ctx->M : 0; cc.aabb = ctx->aabb2d;
     if (ctx->ss.has && ctx->ss.d != 3) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "state-space bounds must have 3 dims for SE2 states");
     int32_t rc;
     const int64_t nnz = ctx->nnz, words = (nnz + 63) / 64;
@@ -714,10 +723,10 @@ int32_t mpfmt_car_sweep(mpfmt_ctx* ctx)
     if (nnz > 0) {
         if (ctx->steer_kind == 3)
             hipLaunchKernelGGL(k_car_sweep<2>, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xo, ctx->N, ctx->colptr,
-                               ctx->rowval, nnz, ctx->car_rt, ctx->car_sp, ctx->boxes, ctx->M, ctx->ss, ctx->graph_free, ctx->di_nseg);
+                               ctx->rowval, nnz, ctx->car_rt, ctx->car_sp, cc, ctx->ss, ctx->graph_free, ctx->di_nseg);
         else
             hipLaunchKernelGGL(k_car_sweep<1>, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xo, ctx->N, ctx->colptr,
-                               ctx->rowval, nnz, ctx->car_rt, ctx->car_sp, ctx->boxes, ctx->M, ctx->ss, ctx->graph_free, ctx->di_nseg);
+                               ctx->rowval, nnz, ctx->car_rt, ctx->car_sp, cc, ctx->ss, ctx->graph_free, ctx->di_nseg);
         HIPCHK(ctx, hipGetLastError());
     }
     tm2.end("car_sweep");

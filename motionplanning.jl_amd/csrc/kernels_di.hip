@@ -15,6 +15,7 @@
 // ~6 % candidates are queued (ballot compaction) and refined 64 at a time with all lanes busy: exact
 // dcost(r) test, safeguarded Newton (data-dependent trip count), cost <= r.
 #include "mpfmt_internal.h"
+#include "sat2d_predicates.h"
 #include <algorithm>
 #include <cmath>
 
@@ -368,8 +369,9 @@ template <int M>
 __global__ __launch_bounds__(256) void k_di_sweep(const double* __restrict__ X, int64_t N, const int64_t* __restrict__ colptr,
                                                   const int32_t* __restrict__ rowval, const double* __restrict__ tval,
                                                   int64_t nnz, double rho, const double* __restrict__ boxes, int nbox,
-                                                  mpfmt_ss ss, uint64_t* __restrict__ mask, uint8_t* __restrict__ nseg)
+                                                  mpfmt_ss ss, uint64_t* __restrict__ mask, uint8_t* __restrict__ nseg, mpfmt_ws2d cc)
 {
+    // cc.kind == 1 (M == 2 only): the workspace checker is the 2-D SAT world (PointRobot2D), nbox = 0
     constexpr int NS = 2 * M;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sbox = (double*)smem;
@@ -403,6 +405,9 @@ __global__ __launch_bounds__(256) void k_di_sweep(const double* __restrict__ X, 
                 pv[i] = wp[i]; pw[i] = wn[i];
                 l[i] = (pw[i] < pv[i]) ? pw[i] : pv[i];
                 h[i] = (pv[i] < pw[i]) ? pw[i] : pv[i];
+            }
+            if constexpr (M == 2) {
+                if (cc.kind == 1 && !motion_free_2d(pv[0], pv[1], pw[0], pw[1], cc.shapes, cc.ns, cc.aabb)) fr = false;      // robots2D.jl:13-14
             }
             for (int k = 0; k < nbox && fr; ++k) {
                 // box in registers, comparisons combined without control flow (an LDS operand behind && / || becomes
@@ -611,11 +616,15 @@ int32_t mpfmt_di_sweep(mpfmt_ctx* ctx)
 {
     if (!ctx->di_filled) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "di sweep before the di graph is filled");
     if (!ctx->have_boxes) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no obstacle set uploaded (mpfmt_upload_boxes)");
-    if (ctx->cc_kind != 0) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the double-integrator sweep runs against the AABB checker (mpfmt_upload_boxes)");
     const int m = ctx->d / 2;
+    if (ctx->cc_kind != 0 && m != 2) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the 2-D SAT world needs a 2-D workspace (states in R^4)");
     if (ctx->dw != m) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "workspace dim %d != state dim / 2 = %d", ctx->dw, m);
     if (ctx->ss.has && ctx->ss.d != ctx->d) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "state-space bounds have %d dims, states %d", ctx->ss.d, ctx->d);
-    const size_t lds = (size_t)ctx->M * 2 * m * sizeof(double) + 16;
+    mpfmt_ws2d cc;
+    cc.kind = ctx->cc_kind; cc.boxes = ctx->boxes; cc.M = ctx->cc_kind == 0 ? ctx->M : 0;
+    cc.shapes = ctx->shapes2d; cc.ns = ctx->cc_kind == 1 ? ctx->M : 0; cc.aabb = ctx->aabb2d;
+    const int nbox = ctx->cc_kind == 0 ? ctx->M : 0;
+    const size_t lds = (size_t)nbox * 2 * m * sizeof(double) + 16;
     if (lds > 60 * 1024) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "double-integrator sweep supports at most %d boxes", (int)(60 * 1024 / (16 * m)));
     const int64_t nnz = ctx->nnz, words = (nnz + 63) / 64;
     int32_t rc;
@@ -625,8 +634,8 @@ int32_t mpfmt_di_sweep(mpfmt_ctx* ctx)
         mpfmt_timed tm3(ctx);
         const unsigned nb = (unsigned)((nnz + 255) / 256);
         DISPATCH_M(m, hipLaunchKernelGGL((k_di_sweep<DM>), dim3(nb), dim3(256), lds, ctx->stream, ctx->Xo, ctx->N, ctx->colptr,
-                                         ctx->rowval, ctx->tval, nnz, ctx->di_rho, ctx->boxes, ctx->M, ctx->ss, ctx->graph_free,
-                                         ctx->di_nseg));
+                                         ctx->rowval, ctx->tval, nnz, ctx->di_rho, ctx->boxes, nbox, ctx->ss, ctx->graph_free,
+                                         ctx->di_nseg, cc));
         HIPCHK(ctx, hipGetLastError());
         tm3.end("di_sweep");
     }

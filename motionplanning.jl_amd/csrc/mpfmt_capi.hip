@@ -258,6 +258,21 @@ int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t
     return MPFMT_OK;
 }
 
+// state-space bounds on their own: the BoundedStateSpace lo / hi for any state dimension (src/statespaces.jl:29-34).  The 2-D SAT
+// world's upload takes the two workspace bounds only; a steering space over it (double integrator R^4, SE2 cars) sets its own.
+int32_t mpfmt_set_state_bounds(mpfmt_ctx* ctx, const double* ss_lo, const double* ss_hi, int32_t d_state)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if ((ss_lo == nullptr) != (ss_hi == nullptr)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "ss_lo / ss_hi must both be given or both NULL");
+    if (ss_lo && (d_state < 1 || d_state > MPFMT_MAX_DIM)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "d_state out of range");
+    ctx->ss.has = ss_lo ? 1 : 0;
+    ctx->ss.d = ss_lo ? d_state : 0;
+    for (int i = 0; i < MPFMT_MAX_DIM; ++i) { ctx->ss.lo[i] = -INFINITY; ctx->ss.hi[i] = INFINITY; }
+    if (ss_lo) for (int i = 0; i < d_state; ++i) { ctx->ss.lo[i] = ss_lo[i]; ctx->ss.hi[i] = ss_hi[i]; }
+    ctx->graph_swept = false; ctx->di_swept = false;
+    return MPFMT_OK;
+}
+
 int32_t mpfmt_upload_boxes(mpfmt_ctx* ctx, const double* lohi, int32_t M, int32_t dw,
                            const double* ss_lo, const double* ss_hi, int32_t d_state)
 {
@@ -1145,7 +1160,7 @@ static int32_t car_fmtstar(mpfmt_ctx* ctx, int kind, double turn_radius, double 
     if (!ctx) return MPFMT_ERR_ARG;
     if (!A || !C || !path || !res || !goal_params) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "NULL output / goal pointer");
     if (!ctx->Xo || ctx->d != 3) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car planning needs SE2 samples (d = 3)");
-    if (!ctx->have_boxes || ctx->cc_kind != 0 || ctx->dw != 2) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car planning needs 2-D boxes (mpfmt_upload_boxes, dw = 2)");
+    if (!ctx->have_boxes || ctx->dw != 2) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car planning needs a 2-D workspace checker (mpfmt_upload_boxes with dw = 2, or mpfmt_upload_shapes2d)");
     const int64_t N = ctx->N;
     if (init_idx < 1 || init_idx > N) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "init_idx out of range");
     if (goal_kind < 0 || goal_kind > 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown goal kind %d", goal_kind);
@@ -1235,7 +1250,7 @@ static int32_t car_fmtstar_wavefront(mpfmt_ctx* ctx, int kind, double turn_radiu
     if (!ctx) return MPFMT_ERR_ARG;
     if (!res || !goal_params) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "NULL output / goal pointer");
     if (!ctx->Xo || ctx->d != 3) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car planning needs SE2 samples (d = 3)");
-    if (!ctx->have_boxes || ctx->cc_kind != 0 || ctx->dw != 2) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car planning needs 2-D boxes (mpfmt_upload_boxes, dw = 2)");
+    if (!ctx->have_boxes || ctx->dw != 2) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "car planning needs a 2-D workspace checker (mpfmt_upload_boxes with dw = 2, or mpfmt_upload_shapes2d)");
     const int64_t N = ctx->N;
     if (init_idx < 1 || init_idx > N) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "init_idx out of range");
     if (goal_kind < 0 || goal_kind > 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown goal kind %d", goal_kind);

@@ -83,6 +83,10 @@ def ReedsSheppMetricSpace(r, s=1.0, lo=(0.0, 0.0), hi=(1.0, 1.0)):
     return BoundedStateSpace(np.array([lo[0], lo[1], 0.0]), np.array([hi[0], hi[1], 2 * math.pi]), ReedsSheppExact(r, s), workspace_dim=2)
 
 
+def SS_WS(SS):
+    return SS.workspace_dim
+
+
 def volume(SS):
     return float(np.prod(SS.hi - SS.lo))
 
@@ -130,6 +134,10 @@ class PointRobotNDBoxes:
         lohi = self.lohi() if self.boxes else np.zeros((0, 2, dw))
         ctx.upload_boxes(lohi, SS.lo, SS.hi, dw=dw)
         self._ctx, self._ss = ctx, SS
+
+    def _bind_workspace(self, ctx, SS):
+        ctx.upload_boxes(self.lohi() if self.boxes else np.zeros((0, 2, SS.workspace_dim)), None, None, dw=SS.workspace_dim)
+        self._ctx = None
 
     def inflate(self, eps):
         return PointRobotNDBoxes([BoxBounds(b.lo - eps, b.hi + eps) for b in self.boxes]) if eps > 0 else self
@@ -189,10 +197,16 @@ class PointRobot2D:
         self._ss = None
 
     def _bind(self, ctx, SS):
-        if SS.workspace_dim != 2 or dim(SS) != 2:
-            raise ValueError("PointRobot2D needs a 2-D state space")
-        ctx.upload_shapes2d(self.obstacles.parts(), SS.lo, SS.hi)
+        if SS.workspace_dim != 2:
+            raise ValueError("PointRobot2D needs a 2-D workspace")
+        ctx.upload_shapes2d(self.obstacles.parts(), SS.lo[:2], SS.hi[:2])
+        if dim(SS) != 2:                                     # a steering space over the 2-D world (double integrator, SE2 cars)
+            ctx.set_state_bounds(SS.lo, SS.hi)
         self._ctx, self._ss = ctx, SS
+
+    def _bind_workspace(self, ctx, SS):
+        ctx.upload_shapes2d(self.obstacles.parts(), None, None)
+        self._ctx = None
 
     def addobstacle(self, o):                                                 # robots2D.jl:23
         return PointRobot2D(Compound2D(self.obstacles, o))
@@ -210,7 +224,7 @@ def is_free_state(v, CC, SS, ctx):
         out = _lib.unpack_bits(ctx.states_free(V), len(V))
     else:                                                   # workspace = leading coordinates (OutputMatrix [I 0])
         inb = np.all((SS.lo <= V) & (V <= SS.hi), axis=1)
-        ctx.upload_boxes(CC.lohi(), None, None, dw=SS.workspace_dim)
+        CC._bind_workspace(ctx, SS)                           # the checker alone, no state-space bounds (they were applied above)
         out = _lib.unpack_bits(ctx.states_free(np.ascontiguousarray(V[:, :SS.workspace_dim])), len(V)) & inb
         CC._bind(ctx, SS)
     return bool(out[0]) if np.ndim(v) == 1 else out
@@ -472,24 +486,29 @@ def fmtstar_(P, N=None, rm=1.0, connections="R", r=0.0, ensure_goal_ct=1, init_i
         setup_steering(P.SS, r)
     ctx = P.ctx
     P.CC._bind(ctx, P.SS)
+    gkind, gpar = P.goal.kind, P.goal.params()
+    if isinstance(P.SS.dist, (DubinsExact, ReedsSheppExact)) and gkind == _lib.GOAL_POINT and len(gpar) == SS_WS(P.SS):
+        # PointGoal(pt) is a WORKSPACE goal (goals.jl:45,111-114: state2workspace(v) == pt); for SE2 states the library's POINT kind
+        # means an exact state, so the workspace point goes down as the ball of radius 0 around it (norm(v_ws - pt) <= 0)
+        gkind, gpar = _lib.GOAL_BALL, np.concatenate([gpar, [0.0]])
     if band is not None:
         bw = float(band) * r
         if isinstance(P.SS.dist, LinearQuadratic):
-            res = ctx.di_fmtstar_wavefront(P.SS.dist.rho, r, P.goal.kind, P.goal.params(), band=bw, init_idx=init_idx, checkpts=checkpts)
+            res = ctx.di_fmtstar_wavefront(P.SS.dist.rho, r, gkind, gpar, band=bw, init_idx=init_idx, checkpts=checkpts)
         elif isinstance(P.SS.dist, (DubinsExact, ReedsSheppExact)):
             car = "dubins" if isinstance(P.SS.dist, DubinsExact) else "reedsshepp"
-            res = ctx.car_fmtstar_wavefront(car, P.SS.dist.r, P.SS.dist.s, r, P.goal.kind, P.goal.params(), band=bw, init_idx=init_idx,
+            res = ctx.car_fmtstar_wavefront(car, P.SS.dist.r, P.SS.dist.s, r, gkind, gpar, band=bw, init_idx=init_idx,
                                             checkpts=checkpts)
         else:
-            res = ctx.fmtstar_wavefront(r, P.goal.kind, P.goal.params(), band=bw, init_idx=init_idx, checkpts=checkpts)
+            res = ctx.fmtstar_wavefront(r, gkind, gpar, band=bw, init_idx=init_idx, checkpts=checkpts)
     elif isinstance(P.SS.dist, LinearQuadratic):
-        res = ctx.di_fmtstar(P.SS.dist.rho, r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)
+        res = ctx.di_fmtstar(P.SS.dist.rho, r, gkind, gpar, init_idx=init_idx, checkpts=checkpts)
     elif isinstance(P.SS.dist, DubinsExact):
-        res = ctx.dubins_fmtstar(P.SS.dist.r, P.SS.dist.s, r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)
+        res = ctx.dubins_fmtstar(P.SS.dist.r, P.SS.dist.s, r, gkind, gpar, init_idx=init_idx, checkpts=checkpts)
     elif isinstance(P.SS.dist, ReedsSheppExact):
-        res = ctx.reedsshepp_fmtstar(P.SS.dist.r, P.SS.dist.s, r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)
+        res = ctx.reedsshepp_fmtstar(P.SS.dist.r, P.SS.dist.s, r, gkind, gpar, init_idx=init_idx, checkpts=checkpts)
     else:
-        res = ctx.fmtstar(r, P.goal.kind, P.goal.params(), init_idx=init_idx, checkpts=checkpts)
+        res = ctx.fmtstar(r, gkind, gpar, init_idx=init_idx, checkpts=checkpts)
     P.CC.count = res["collision_checks"]
     P.status = "solved" if res["status"] == 1 else "failed"
     path = res["path"]
