@@ -218,12 +218,20 @@ def main():
             gather = mp.distributed.MaskGather(dist, world, dev)
 
     pending = [False]
+    exposed = [0.0, 0.0]                              # host seconds spent waiting in _finish / in the step call, timed region only
+
+    def finish_gather():
+        t = time.perf_counter()
+        ctx.allgather_free_mask_finish(world)
+        exposed[0] += time.perf_counter() - t
 
     def step():
         if rccl_abi:
+            t = time.perf_counter()
             nnz = ctx.graph_step_device(w.r)      # graph + sweep of this rank's shard
+            exposed[1] += time.perf_counter() - t
             if pending[0]:
-                ctx.allgather_free_mask_finish(world)      # the previous step's gather ran beside this step's kernels
+                finish_gather()                   # the previous step's gather ran beside this step's kernels
             ctx.allgather_free_mask_launch()      # ONE all-gather per step, on the communication stream
             pending[0] = True
         elif world > 1:
@@ -234,7 +242,7 @@ def main():
 
     def drain():
         if pending[0]:
-            ctx.allgather_free_mask_finish(world)
+            finish_gather()
             pending[0] = False
 
     if dist is not None:
@@ -250,6 +258,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ctx.timing_reset()
+    exposed[0] = exposed[1] = 0.0
     t0 = time.perf_counter()
     nnz = 0
     for _ in range(args.steps):
@@ -415,6 +424,19 @@ def main():
     out["roofline"] = dict(roofs[dom][1], dominant_by="largest average kernel launch duration in this run (%s)" % dom)
     for k, (_, obj) in roofs.items():
         out[k] = obj
+
+    if dist is not None:
+        # one line to diagnose a scaling curve from: every rank's kernel intervals, its shard, and how long its host sat in the
+        # gather's _finish (the part of the exchange that did NOT hide behind the next step's kernels)
+        keys = ["grid", "rdisc_count", "pair_kernel", "rdisc_sort", "sweep_graph", "sweep_kernel"]
+        mine = torch.tensor([tm[k][0] for k in keys] + [1e3 * exposed[0] / max(args.steps, 1), 1e3 * exposed[1] / max(args.steps, 1),
+                             float(nnz), float(stats["pairs_tested"])], dtype=torch.float64, device=dev)
+        allv = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allv, mine)
+        allv = allv.cpu().numpy().reshape(world, -1)
+        names = keys + ["gather_exposed_ms", "step_call_ms", "nnz", "pairs_tested"]
+        out["per_rank"] = {n: {"min": float(allv[:, i].min()), "max": float(allv[:, i].max()), "all": [float(x) for x in allv[:, i]]}
+                           for i, n in enumerate(names)}
 
     # whole solve (outside the timed region): fmtstar! with the recursion on the device (mpfmt_fmtstar_wavefront) --
     # what a planner call costs end to end, next to the eager step above

@@ -884,6 +884,36 @@ extern "C++" int32_t mpfmt_wf_run(mpfmt_ctx* ctx)
     int32_t rc;
     const int group = s->sharded ? 1 : (s->single ? 32 : 8);
     const int64_t max_steps = 4 * s->N + 64;
+    if (!s->sharded && ctx->wf_graphs) {
+        // The kernels of a step take no host-side argument that changes from step to step (the sets, the lists and the counters live
+        // on the device), so a group of steps is captured ONCE into a hipGraph and replayed: one launch per 8 wavefronts instead of
+        // 48 (a wavefront's kernels are a few microseconds each -- the solve was launch-bound).  Anything that goes wrong with the
+        // capture falls through to the plain loop below.
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            for (int g = 0; g < group && ok; ++g) ok = wf_enqueue_local(ctx, s) == MPFMT_OK;
+            ok = (hipStreamEndCapture(ctx->stream, &graph) == hipSuccess) && ok && graph != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (ok) {
+            rc = MPFMT_OK;
+            for (int64_t it = 0; it < max_steps && rc == MPFMT_OK; it += group) {
+                if (hipGraphLaunch(exec, ctx->stream) != hipSuccess) { rc = mpfmt_fail(ctx, MPFMT_ERR_HIP, "hipGraphLaunch failed in the wavefront solve"); break; }
+                if ((rc = wf_read_ctr(ctx, s, false))) break;
+                if (wf_ended(s)) break;
+            }
+        }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ok) {
+            if (rc) return rc;
+            if (!wf_ended(s)) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "wavefront solve did not terminate");
+            return MPFMT_OK;
+        }
+        (void)hipGetLastError();                              // capture not available: plain launches
+    }
     for (int64_t it = 0; it < max_steps; it += group) {
         for (int g = 0; g < group; ++g) {
             if ((rc = wf_enqueue_local(ctx, s))) return rc;

@@ -1360,6 +1360,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "rebuild_index") == 0) { ctx->rebuild_index = value != 0; return MPFMT_OK; }
     if (strcmp(name, "rdisc_pool") == 0) { ctx->use_pool = value != 0; return MPFMT_OK; }
     if (strcmp(name, "fuse_sweep") == 0) { ctx->fuse_sweep = value != 0; return MPFMT_OK; }
+    if (strcmp(name, "wf_graphs") == 0) { ctx->wf_graphs = value != 0; return MPFMT_OK; }
     if (strcmp(name, "mf_ablate") == 0) { ctx->mf_ablate = (int32_t)value; return MPFMT_OK; }
     if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }
     if (strcmp(name, "mf_target_items") == 0) { ctx->mf_target_items = value; return MPFMT_OK; }

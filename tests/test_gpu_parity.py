@@ -913,6 +913,28 @@ def test_mc_one_edge_many_rollouts(ctx, orc):
     assert ctx.mc_edges_collision([1], [2], 0.03, 20000, seed=1)[0] == orc.mc_edges(X, [0], [1], 0.03, 20000, 1, lohi, np.zeros(2), np.ones(2))[0]
 
 
+def test_mc_one_edge_many_rollouts_in_r6_among_200_boxes(ctx, orc):
+    """BASELINE configs[4] at its own size on the north-star world: 1e6 rollouts of one graph edge in R^6 among the 200 AABBs.  Two
+    edges of the workload's graph (one the deterministic check finds free, one it finds blocked); the estimate is stable across
+    seeds to the binomial error, a 20k-rollout prefix equals the scalar loop, and sigma = 0 reproduces the deterministic answer."""
+    w = mp.workloads.north_star(20000)
+    ctx.upload_samples(w.X); ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+    colptr, rowval, _ = ctx.rdisc_graph(w.r * 1.6)
+    free = mp._lib.unpack_bits(ctx.graph_edges_free(), len(rowval))
+    cols = np.repeat(np.arange(1, w.N + 1), np.diff(colptr))
+    picks = [int(np.flatnonzero(free)[len(rowval) // 7]), int(np.flatnonzero(~free)[5])]
+    sigma = 0.02
+    for e in picks:
+        src, dst = [int(rowval[e])], [int(cols[e])]
+        p = [ctx.mc_edges_collision(src, dst, sigma, 1_000_000, seed=s)[0] / 1e6 for s in (11, 12, 13)]
+        assert max(p) - min(p) <= 6 * np.sqrt(max(p[0] * (1 - p[0]), 1e-6) / 1e6) + 1e-6, p
+        pre = ctx.mc_edges_collision(src, dst, sigma, 20000, seed=11)[0]
+        assert pre == orc.mc_edges(w.X, [src[0] - 1], [dst[0] - 1], sigma, 20000, 11, w.lohi, w.ss_lo, w.ss_hi)[0]
+        det = ctx.mc_edges_collision(src, dst, 0.0, 5, seed=1)[0]
+        assert det == (0 if free[e] else 5)
+    assert p[0] > 0.3                                            # the blocked edge collides in a large share of its perturbed copies
+
+
 # ---- closest obstacle points in a Mahalanobis metric (SURVEY 8f N4) ---------------------------------------------------
 
 def _spd(rng, d):
