@@ -50,7 +50,7 @@ template <int DX>
 struct ord_hdr {
     int32_t k[ORD_COLS];         // column degrees
     int32_t cb[ORD_COLS + 4];    // exclusive prefix of the degrees (cb[ORD_COLS] = hits of the quarter)
-    int32_t ln[MPFMT_MAXS + 4];  // log lengths
+    int32_t lp[MPFMT_MAXS + 4];  // exclusive prefix of the S log lengths: lp[sl] = records before log sl, lp[S] = records of the quarter
     long long out[ORD_COLS];     // colptr of each column
     double xc[ORD_COLS][DX];     // column states (fused sweep)
 };
@@ -158,31 +158,46 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
                 }
             }
             if (tid == 0) H.cb[0] = 0;
-        } else if (tid < 64 + S) {
-            H.ln[tid - 64] = hln;
+        } else if (tid < 128) {
+            // (second wavefront, lanes 0 .. S - 1 hold the log lengths, S <= 16: one 16-lane row scan)
+            int inc = (tid - 64 < S) ? hln : 0;
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);       // row_shr:1
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);       // row_shr:2
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
+            if (tid - 64 < S) H.lp[tid - 64 + 1] = inc;
+            if (tid == 64) H.lp[0] = 0;
         }
     };
-    // prefetch registers are dealt out per (log, run of ORD_THREADS records): wave-uniform bookkeeping only.  (fsl, fc0) is where
-    // the direct streaming continues when a quarter holds more than the registers cover.
+    // The quarter's S logs are read as ONE sequence of lp[S] records: record i lives in the log sl with lp[sl] <= i < lp[sl + 1] (a
+    // binary search over <= 17 prefix sums in LDS).  Dealing registers out per (log, run of records) instead left most lanes
+    // idle on small shards, where a tile has 16 slices with ~100 records each.
     uint4 pre[ORD_PRE];
-    int fsl = 0, fc0 = 0;
-    auto log_ptr = [&](int64_t qi, int sl) -> const uint4* {
-        return reinterpret_cast<const uint4*>(logs + (((qi >> 2) * S + sl) * 4 + (qi & 3)) * capL);
+    auto rec_ptr = [&](const hdr_t& H, int64_t qi, int i) -> const uint4* {
+        int lo = 0, base = 0;
+        if (S <= 4) {
+            // (uniform) few slices -- the usual case, 3 at one shard: the prefix sums are wave-uniform LDS reads kept in scalar
+            // registers, the log is a count of comparisons
+            const int p1 = __builtin_amdgcn_readfirstlane(H.lp[1]), p2 = __builtin_amdgcn_readfirstlane(H.lp[S > 2 ? 2 : S]),
+                      p3 = __builtin_amdgcn_readfirstlane(H.lp[S > 3 ? 3 : S]);
+            const int g1 = (S > 1) & (i >= p1), g2 = (S > 2) & (i >= p2), g3 = (S > 3) & (i >= p3);
+            lo = g1 + g2 + g3;
+            base = g3 ? p3 : g2 ? p2 : g1 ? p1 : 0;
+        } else {
+            int hi = S;                                      // lp[lo] <= i < lp[hi]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (H.lp[mid] <= i) lo = mid; else hi = mid; }
+            base = H.lp[lo];
+        }
+        return reinterpret_cast<const uint4*>(logs + (((qi >> 2) * S + lo) * 4 + (qi & 3)) * capL) + (i - base);
     };
     auto rec_fetch = [&](const hdr_t& H, int64_t qi) {
-        int sl = 0, c0 = 0;
-        while (sl < S && H.ln[sl] == 0) ++sl;
+        const int total = (qi < nq) ? H.lp[S] : 0;
 #pragma unroll
         for (int u = 0; u < ORD_PRE; ++u) {
+            const int i = u * ORD_THREADS + tid;
             pre[u] = make_uint4(0u, 0xffffffffu, 0u, 0u);
-            if (qi < nq && sl < S) {
-                const int n = H.ln[sl];
-                if (c0 + tid < n) pre[u] = log_ptr(qi, sl)[c0 + tid];
-                c0 += ORD_THREADS;
-                if (c0 >= n) { c0 = 0; ++sl; while (sl < S && H.ln[sl] == 0) ++sl; }
-            }
+            if (u * ORD_THREADS < total) { if (i < total) pre[u] = *rec_ptr(H, qi, i); }
         }
-        fsl = sl; fc0 = c0;
     };
 
     int64_t qi = blockIdx.x;
@@ -218,12 +233,8 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
             auto for_records = [&](auto&& f) {
 #pragma unroll
                 for (int u = 0; u < ORD_PRE; ++u) if (pre[u].y != 0xffffffffu) f(pre[u]);
-                int sl = first ? fsl : 0, cc = first ? fc0 : 0;
-                for (; sl < S; ++sl, cc = 0) {
-                    const int n = H.ln[sl];
-                    const uint4* __restrict__ lg = log_ptr(qi, sl);
-                    for (int i = cc + tid; i < n; i += ORD_THREADS) f(lg[i]);
-                }
+                const int total = H.lp[S];
+                for (int i = (first ? ORD_PRE * ORD_THREADS : 0) + tid; i < total; i += ORD_THREADS) f(*rec_ptr(H, qi, i));
             };
             // ---- COUNT ----
             if (!skip) for_records([&](const uint4& r) {
