@@ -492,12 +492,18 @@ __global__ void k_degree(const int32_t* __restrict__ slice_cnt, const int32_t* _
         }
         degs[s] = k;                                           // (pad positions: 0 -- nothing else clears them on an unsharded ctx)
     }
-    // longest column of the shard: the log-ordering kernel stages whole columns in LDS.  A wavefront only goes to the atomic
-    // when it beats the maximum it can see (a stale read at worst costs a redundant atomic): one atomic per wavefront on the
-    // single address took 0.18 ms at N = 1e6 (~88 atomics / us)
+    // longest column of the shard: the log-ordering kernel stages whole columns in LDS.  One candidate per workgroup, and it only
+    // goes to the atomic when it beats the maximum it can see (a stale read at worst costs a redundant atomic): one atomic per
+    // wavefront on the single address took 0.18 ms at N = 1e6 (~88 atomics / us), the pre-checked per-wavefront form 0.08
+    __shared__ int s_m[4];
     int m = (int)min(k, (int64_t)0x7fffffff);
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0 && m > *(volatile int32_t*)max_deg) atomicMax(max_deg, m);
+    if ((threadIdx.x & 63) == 0) s_m[(threadIdx.x >> 6) & 3] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < (int)(blockDim.x >> 6) && q < 4; ++q) m = max(m, s_m[q]);
+        if (m > *(volatile int32_t*)max_deg) atomicMax(max_deg, m);
+    }
 }
 
 // Per-column ordering: rank each entry by counting smaller row indices (indices in a column are
@@ -756,7 +762,10 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
                            ctx->slice_cnt, ctx->perm, S, npad, pb, pe, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512));
     }
     if ((rc = scan_i64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1)))) return rc;      // columns in original order
-    if ((rc = scan_i64(ctx, ctx->degs, ctx->tptr, (size_t)(npad + 1)))) return rc;    // staging in sorted order
+    // staging offsets in sorted order: only the two-pass forms read them (the single-pass build orders its logs straight into the
+    // CSC) -- made here for those, and on demand by mpfmt_launch_rdisc_fill when a single-pass build has to fall back
+    ctx->tptr_valid = false;
+    if (!pool) { if ((rc = scan_i64(ctx, ctx->degs, ctx->tptr, (size_t)(npad + 1)))) return rc; ctx->tptr_valid = true; }
     tm3.end("rdisc_count");
     ctx->cnt_pool = pool; ctx->cnt_mf = mf;
     return MPFMT_OK;
@@ -831,6 +840,10 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r, bool fuse_sweep)
             done = 1;
         }
         if (!done) {
+            if (!ctx->tptr_valid) {
+                if ((rc = scan_i64(ctx, ctx->degs, ctx->tptr, (size_t)(ctx->ntiles * 64 + 1)))) return rc;
+                ctx->tptr_valid = true;
+            }
             mpfmt_timed tm5(ctx);
             if (ctx->rdisc_path_used == 2) {
                 if ((rc = mpfmt_launch_rdisc_mfma<1>(ctx, r, ctx->mf_negT))) return rc;

@@ -93,6 +93,7 @@ struct mpfmt_ctx {
     int64_t* deg = nullptr;              // [N+1] degree by original index
     int64_t* degs = nullptr;             // [npad+1] degree by sorted position
     int64_t* tptr = nullptr;             // [npad+1] offsets of the sorted-order staging CSC (rowtmp/valtmp)
+    bool tptr_valid = false;             // tptr holds the scan of the counted graph's degs (the single-pass build leaves it undone)
     // MFMA filter path (kernels_rdisc_mfma.hip)
     double* Xs = nullptr;                // [npad][d] cell-sorted AoS fp64 (NaN padded): exact refine gathers
     void* ops = nullptr;                 // [npad] 16 fp16 slots (32 B) per sorted sample: MFMA operands
