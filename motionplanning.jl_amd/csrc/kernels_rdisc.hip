@@ -195,9 +195,14 @@ __global__ __launch_bounds__(256) void k_build_tiles(const double* __restrict__ 
     }
     const int split = (jump > 0) ? where + 1 : 64;
     double* rows = s_rows[wave];
+    // the row's d coordinates are requested together (a runtime-d loop that loads and reduces in turn sat out d gather latencies)
+    double xr[BT_MAXD];
+#pragma unroll
+    for (int i = 0; i < BT_MAXD; ++i) xr[i] = (i < d && o >= 0) ? Xo[(int64_t)o * d + i] : __builtin_nan("");
+#pragma unroll
+    for (int i = 0; i < BT_MAXD; ++i) if (i < d) rows[lane * d + i] = xr[i];
     for (int i = 0; i < d; ++i) {
-        const double x = (o >= 0) ? Xo[(int64_t)o * d + i] : __builtin_nan("");
-        rows[lane * d + i] = x;
+        const double x = rows[lane * d + i];                 // (own row: no barrier needed)
         Xt[(tile * d + i) * 64 + lane] = x;
         double amn = lane < split ? x : NAN, amx = amn, bmn = lane < split ? NAN : x, bmx = bmn;   // fmin/fmax ignore NaN (pads too)
         for (int off = 32; off > 0; off >>= 1) {

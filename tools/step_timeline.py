@@ -1,12 +1,17 @@
-"""Kernel timeline of the last step in a rocprofv3 kernel-trace DB (gaps between kernels = host round trips / launch latency).
-usage: step_timeline.py results.db"""
+#!/usr/bin/env python3
+"""One step's kernel timeline out of a rocprofv3 rocpd database: start offset, duration and the gap to the previous kernel's end.
+Usage: step_timeline.py results.db [which_step_from_the_end]"""
 import sqlite3, sys
-c = sqlite3.connect(sys.argv[1])
-rows = list(c.execute("select name, start, end from kernels order by start"))
-idx = [i for i, r in enumerate(rows) if 'k_graph_sweep' in r[0]]
-a, b = idx[-2] + 1, idx[-1]
-t0 = rows[a][1]; prev_end = rows[a - 1][2]; tot = 0
-for r in rows[a:b + 1]:
-    print("%8.1f us  +%6.1f gap  dur %7.1f  %s" % ((r[1] - t0) / 1e3, (r[1] - prev_end) / 1e3, (r[2] - r[1]) / 1e3, r[0][:60]))
-    prev_end = r[2]; tot += r[2] - r[1]
-print("step span %.1f us, kernel sum %.1f us, launches %d" % ((rows[b][2] - rows[idx[-2]][2]) / 1e3, tot / 1e3, b - a + 1))
+db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+rows = list(cur.execute("select %s, start, end from kernels order by start" % name_col))
+# a step starts at the first kernel after a k_graph_sweep* kernel
+starts = [0] + [i + 1 for i, r in enumerate(rows) if "k_graph_sweep" in r[0]]
+a, b = starts[-back - 1], starts[-back]
+t0 = rows[a][1]; prev_end = t0
+print("%-58s %10s %10s %9s" % ("kernel", "start us", "dur us", "gap us"))
+for n, s, e in rows[a:b]:
+    print("%-58s %10.1f %10.1f %9.1f" % (n[:58], (s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3)); prev_end = e
+print("step span %.1f us; next step's first kernel starts %.1f us after this step's last ends" % ((prev_end - t0) / 1e3, (rows[b][1] - prev_end) / 1e3 if b < len(rows) else -1))
