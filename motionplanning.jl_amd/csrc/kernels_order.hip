@@ -99,9 +99,14 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
                                                             const int32_t* __restrict__ log_len, int64_t tile_begin, int64_t tile_end,
                                                             const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm,
                                                             int32_t* __restrict__ rowval, double* __restrict__ nzval, int32_t* __restrict__ rowpos,
-                                                            uint32_t bucket_mul, const int32_t* __restrict__ spec_fail, ord_sweep sw)
+                                                            uint32_t bucket_mul, const int32_t* __restrict__ spec_fail, ord_sweep sw,
+                                                            const mpfmt_hit* __restrict__ flogs, int64_t fcapL, const int32_t* __restrict__ flen)
 {
     if (spec_fail && *spec_fail) return;                     // speculative step whose capacities did not hold: redone by the host
+    // half build (flogs != nullptr): every pair was found once, by the tile of its lower cell-sorted end, which also wrote the
+    // record of the OTHER column into that column's tile's FOREIGN log (one per quarter tile, appended to by many tiles; its
+    // per-column counts are row S of slice_cnt).  Here it is simply one more log of the quarter: source S of SS = S + 1.
+    const int SS = S + (flogs ? 1 : 0);
     constexpr int DX = SWEEP ? D : 1;
     typedef ord_hdr<DX> hdr_t;
     typedef ord_shared<DX, SWEEP> shared_t;
@@ -131,13 +136,15 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
         if (tid < ORD_COLS) {
             const int64_t sp = (tile_begin + tl) * 64 + quarter * ORD_COLS + tid;
             ho = perm[sp];
-            for (int sl = 0; sl < S; ++sl) hk += slice_cnt[(int64_t)sl * npad + sp];
+            for (int sl = 0; sl < SS; ++sl) hk += slice_cnt[(int64_t)sl * npad + sp];
             if (SWEEP) {
 #pragma unroll
                 for (int i = 0; i < DX; ++i) hx[i] = sw.Xs[sp * D + i];
             }
         } else if (tid >= 64 && tid < 64 + S) {
             hln = log_len[(tl * S + (tid - 64)) * 4 + quarter];
+        } else if (tid == 64 + S && flogs) {
+            hln = min(flen[(tile_begin + tl) * 4 + quarter], (int32_t)fcapL);
         }
     };
     auto hdr_fetch2 = [&]() { hout = (tid < ORD_COLS && ho >= 0) ? colptr[ho] : 0; };
@@ -159,13 +166,13 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
             }
             if (tid == 0) H.cb[0] = 0;
         } else if (tid < 128) {
-            // (second wavefront, lanes 0 .. S - 1 hold the log lengths, S <= 16: one 16-lane row scan)
-            int inc = (tid - 64 < S) ? hln : 0;
+            // (second wavefront, lanes 0 .. SS - 1 hold the log lengths, SS <= 16: one 16-lane row scan)
+            int inc = (tid - 64 < SS) ? hln : 0;
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);       // row_shr:1
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);       // row_shr:2
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
-            if (tid - 64 < S) H.lp[tid - 64 + 1] = inc;
+            if (tid - 64 < SS) H.lp[tid - 64 + 1] = inc;
             if (tid == 64) H.lp[0] = 0;
         }
     };
@@ -175,23 +182,25 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
     uint4 pre[ORD_PRE];
     auto rec_ptr = [&](const hdr_t& H, int64_t qi, int i) -> const uint4* {
         int lo = 0, base = 0;
-        if (S <= 4) {
-            // (uniform) few slices -- the usual case, 3 at one shard: the prefix sums are wave-uniform LDS reads kept in scalar
-            // registers, the log is a count of comparisons
-            const int p1 = __builtin_amdgcn_readfirstlane(H.lp[1]), p2 = __builtin_amdgcn_readfirstlane(H.lp[S > 2 ? 2 : S]),
-                      p3 = __builtin_amdgcn_readfirstlane(H.lp[S > 3 ? 3 : S]);
-            const int g1 = (S > 1) & (i >= p1), g2 = (S > 2) & (i >= p2), g3 = (S > 3) & (i >= p3);
-            lo = g1 + g2 + g3;
-            base = g3 ? p3 : g2 ? p2 : g1 ? p1 : 0;
+        if (SS <= 5) {
+            // (uniform) few logs -- the usual case: the prefix sums are wave-uniform LDS reads kept in scalar registers, the log
+            // is a count of comparisons
+            const int p1 = __builtin_amdgcn_readfirstlane(H.lp[1]), p2 = __builtin_amdgcn_readfirstlane(H.lp[SS > 2 ? 2 : SS]),
+                      p3 = __builtin_amdgcn_readfirstlane(H.lp[SS > 3 ? 3 : SS]), p4 = __builtin_amdgcn_readfirstlane(H.lp[SS > 4 ? 4 : SS]);
+            const int g1 = (SS > 1) & (i >= p1), g2 = (SS > 2) & (i >= p2), g3 = (SS > 3) & (i >= p3), g4 = (SS > 4) & (i >= p4);
+            lo = g1 + g2 + g3 + g4;
+            base = g4 ? p4 : g3 ? p3 : g2 ? p2 : g1 ? p1 : 0;
         } else {
-            int hi = S;                                      // lp[lo] <= i < lp[hi]
+            int hi = SS;                                     // lp[lo] <= i < lp[hi]
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (H.lp[mid] <= i) lo = mid; else hi = mid; }
             base = H.lp[lo];
         }
-        return reinterpret_cast<const uint4*>(logs + (((qi >> 2) * S + lo) * 4 + (qi & 3)) * capL) + (i - base);
+        const mpfmt_hit* const src = (lo == S) ? flogs + ((tile_begin + (qi >> 2)) * 4 + (qi & 3)) * fcapL
+                                               : logs + (((qi >> 2) * S + lo) * 4 + (qi & 3)) * capL;
+        return reinterpret_cast<const uint4*>(src) + (i - base);
     };
     auto rec_fetch = [&](const hdr_t& H, int64_t qi) {
-        const int total = (qi < nq) ? H.lp[S] : 0;
+        const int total = (qi < nq) ? H.lp[SS] : 0;
 #pragma unroll
         for (int u = 0; u < ORD_PRE; ++u) {
             const int i = u * ORD_THREADS + tid;
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
             auto for_records = [&](auto&& f) {
 #pragma unroll
                 for (int u = 0; u < ORD_PRE; ++u) if (pre[u].y != 0xffffffffu) f(pre[u]);
-                const int total = H.lp[S];
+                const int total = H.lp[SS];
                 for (int i = (first ? ORD_PRE * ORD_THREADS : 0) + tid; i < total; i += ORD_THREADS) f(*rec_ptr(H, qi, i));
             };
             // ---- COUNT ----
@@ -510,7 +519,8 @@ static int32_t launch_order(mpfmt_ctx* ctx, const int32_t* spec_fail, const ord_
     hipLaunchKernelGGL(kk, dim3(nb), dim3(ORD_THREADS), lds, ctx->stream, ctx->pool, ctx->pool_cap, ctx->S,
                        ctx->slice_cnt, ctx->ntiles * 64, ctx->log_len, ctx->tile_begin, ctx->tile_end, ctx->colptr, ctx->perm,
                        ctx->rowval, ctx->nzval, (!SWEEP && ctx->sweep_sorted) ? ctx->rowpos : nullptr,
-                       ctx->N > 128 ? (uint32_t)((128ull << 32) / (uint64_t)ctx->N) : 0u, spec_fail, sw);
+                       ctx->N > 128 ? (uint32_t)((128ull << 32) / (uint64_t)ctx->N) : 0u, spec_fail, sw,
+                       ctx->half_used ? ctx->fpool : nullptr, ctx->fcap, ctx->flen);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }

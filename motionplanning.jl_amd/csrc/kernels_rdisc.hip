@@ -294,6 +294,7 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
         while (((int64_t)1 << bits) < G.ncells) ++bits;
         const int fb = std::min(8, 32 - bits);                         // position bits inside the cell (see k_cellkey)
         bits += fb;
+        ctx->cell_fb = fb;
         // rocprim's default takes its merge sort (about 20 launches) up to 2^20 items; the cell key has few bits, so the
         // onesweep radix sort (histogram + one pass per 8 bits) is the shorter pipeline from a few thousand samples on
         using sort_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
@@ -666,7 +667,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     const int64_t nt = ctx->tile_end - ctx->tile_begin;
 
     // path: MFMA fp16 filter + exact refine when it is usable, else the exact fp64 VALU kernel
-    bool mf = false;
+    bool mf = false, half = false;
     float negT = 0.f;
     if (ctx->rdisc_path != 1) {
         if ((rc = mpfmt_mfma_prepare(ctx, r, &negT, &mf))) return rc;
@@ -681,7 +682,9 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             ctx->lists_r = -1.0;
         }
         bool ok = true;
-        if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok, spec))) return rc;    // per-tile candidate chunk lists
+        // half build: the whole graph on this ctx, through the single-pass logs (decided before the lists, which differ)
+        half = ctx->use_half && !ctx->half_off && ctx->use_pool && ctx->world == 1 && nt == ctx->ntiles && nt > 0;
+        if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok, spec, half))) return rc;    // per-tile candidate chunk lists
         tm2.end("grid");
         if (!ok) {
             if (ctx->rdisc_path == 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path requested but its chunk lists exceed 32 GB");
@@ -696,9 +699,12 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     // (the K = 16 form, d > 6, prefers more and shorter items: cfg3 55.0 vs 57.4 ms at 5 vs 3 slices)
     const int64_t target = mf ? (ctx->d <= 6 ? ctx->mf_target_items : ctx->mf_target_items * 7 / 4) : 32768;
     if (units > 0) S = (int)std::min<int64_t>(MPFMT_MAXS, std::max<int64_t>(1, (target + units - 1) / units));
+    if (!mf) half = false;
+    if (half) S = std::min(S, MPFMT_MAXS - 1);                 // (the foreign log is one more log of a quarter tile: S + 1 <= 16)
     ctx->S = S;
     const int64_t npad = ctx->ntiles * 64;
-    if ((rc = ensure(ctx, (void**)&ctx->slice_cnt, sizeof(int32_t) * (size_t)S * npad))) return rc;
+    // (one more row for the half build: the foreign hits of each cell-sorted position)
+    if ((rc = ensure(ctx, (void**)&ctx->slice_cnt, sizeof(int32_t) * (size_t)(S + 1) * npad))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->deg, sizeof(int64_t) * (N + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (N + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->degs, sizeof(int64_t) * (npad + 1)))) return rc;
@@ -736,7 +742,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         const int64_t items = nt * S;
         // (a build that overflowed doubles the slack of the following ones)
         const int64_t capc = (((int64_t)(want / ((double)items * 4.0) * 2.3) + 96) * ctx->pool_slack + 3) / 4 * 4;
-        if ((double)capc * (double)items * 64.0 > 96e9) pool = false;      // cap the logs at 96 GB of the 288
+        if ((double)capc * (double)items * 64.0 * (half ? 2.0 : 1.0) > 96e9) pool = false;      // cap the logs at 96 GB of the 288
         else {
             const size_t cap = (size_t)capc * (size_t)items * 4;
             if ((rc = ensure(ctx, (void**)&ctx->pool, sizeof(mpfmt_hit) * cap))) return rc;
@@ -744,8 +750,24 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             if (!ctx->pool_flag) HIPCHK(ctx, hipMalloc((void**)&ctx->pool_flag, sizeof(int32_t)));
             HIPCHK(ctx, hipMemsetAsync(ctx->pool_flag, 0, sizeof(int32_t), ctx->stream));
             ctx->pool_cap = capc;
+            if (half) {
+                // a foreign log can receive up to all the hits of its 16 columns (the last tile finds none itself): S item logs' worth
+                ctx->fcap = (capc * S + 15) / 16 * 16;           // (k_foreign_degrees reads the column bytes 16 at a time)
+                if ((rc = ensure(ctx, (void**)&ctx->fpool, sizeof(mpfmt_hit) * (size_t)ctx->fcap * (size_t)nt * 4))) return rc;
+                if ((rc = ensure(ctx, (void**)&ctx->flen, sizeof(int32_t) * (size_t)nt * 4))) return rc;
+                if ((rc = ensure(ctx, (void**)&ctx->fcol, (size_t)ctx->fcap * (size_t)nt * 4))) return rc;
+                HIPCHK(ctx, hipMemsetAsync(ctx->flen, 0, sizeof(int32_t) * (size_t)nt * 4, ctx->stream));
+            }
         }
     }
+    if (half && !pool) {
+        // (no room for the logs after all: the two-pass kernels need whole lists)
+        half = false;
+        bool ok = true;
+        if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok, spec, false))) return rc;
+        if (!ok) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "chunk lists do not fit");
+    }
+    ctx->half_used = half;
     ctx->pool_valid = false;
     ctx->rowpos_valid = false;
     mpfmt_timed tm3(ctx);
@@ -763,8 +785,9 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         }
         const int B = 256;
         const int64_t pb = ctx->tile_begin * 64, pe = ctx->tile_end * 64;
+        if (half && (rc = mpfmt_launch_foreign_degrees(ctx))) return rc;
         hipLaunchKernelGGL(k_degree, dim3((unsigned)((pe - pb + B - 1) / B)), dim3(B), 0, ctx->stream,
-                           ctx->slice_cnt, ctx->perm, S, npad, pb, pe, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512));
+                           ctx->slice_cnt, ctx->perm, S + (half ? 1 : 0), npad, pb, pe, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512));
     }
     if ((rc = scan_i64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1)))) return rc;      // columns in original order
     // staging offsets in sorted order: only the two-pass forms read them (the single-pass build orders its logs straight into the
@@ -806,6 +829,15 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     ctx->max_deg = rb->max_deg;
     // the log-ordering kernel stages whole columns in LDS: a graph with a longer column takes the two-pass build
     const bool too_long = rb->max_deg > MPFMT_ORD_MAXDEG;
+    if (ctx->half_used && pool && (pool_over || too_long)) {
+        // a half build cannot fall back to the fill pass (its counts and lists cover half the pairs): count again, whole
+        ctx->half_off = true; ctx->half_used = false;
+        ctx->lists_r = -1.0;
+        if (pool_over && ctx->pool_slack < 8) ctx->pool_slack *= 2;
+        ctx->graph_counted = false;
+        if (spec_failed) { *spec_failed = true; return MPFMT_OK; }
+        return mpfmt_launch_rdisc_count(ctx, r);
+    }
     if (spec_failed && pool && (pool_over || too_long)) *spec_failed = true;
     ctx->pool_valid = pool && pool_over == 0 && !too_long;
     if (pool && pool_over && ctx->pool_slack < 8) ctx->pool_slack *= 2;

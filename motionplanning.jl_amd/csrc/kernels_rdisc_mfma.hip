@@ -70,6 +70,13 @@ struct mf_args {
     mpfmt_hit* pool;                // [items][4][pool_cap] (sample index of the row, cell-sorted position | column << 26, sqrt(d2)) records:
                                     // an item keeps one log per 16 columns of its tile
     int32_t* log_len;               // [items][4] records in each log
+    // half build (unsharded single pass): the chunk lists hold only chunks >= the tile, every pair is found once, and the hit of a
+    // chunk beyond the tile is also written as the record of the OTHER column into that column's tile's foreign log
+    int32_t half;
+    mpfmt_hit* fpool;               // [tiles][4][fcap] foreign logs, one per 16 columns of a tile, appended to by the tiles before it
+    int32_t* flen;                  // [tiles][4] their lengths (global cursors)
+    long long fcap;
+    uint8_t* fcol;                  // [tiles][4][fcap] column (0..15 of the quarter) of every foreign record: what k_foreign_degrees reads
 };
 
 __device__ __forceinline__ int cell_of_m(double x, double lo, double inv_w, int g)
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
                                                     const float* __restrict__ tile_sub32, mpfmt_grid G, double rpad,
                                                     int64_t tile_begin, int64_t nt, int64_t list_cap,
                                                     uint32_t* __restrict__ lists, int32_t* __restrict__ list_len,
-                                                    int32_t* __restrict__ max_len)
+                                                    int32_t* __restrict__ max_len, int half, const uint32_t* __restrict__ cellkey, int fb)
 {
     __shared__ int32_t s_sega_[NW][64];                   // first chunk of each row's run
     __shared__ int32_t s_segp_[NW][64];                   // exclusive prefix of the runs' chunk counts
@@ -190,8 +197,22 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
     int32_t gcount = 0;              // unique surviving chunks so far (uniform)
     int64_t carry = -1;              // last chunk id of the previous flattened batch (dedupe)
     int64_t firstkept = -1, lastkept = -1;
-    const uint32_t nbatch = (rows + 63) / 64, bq = (nbatch + NW - 1) / NW;
-    const uint32_t row_begin = (uint32_t)wave * bq * 64, row_end = min(rows, (uint32_t)(wave + 1) * bq * 64);
+    // half build: only chunks >= the tile are wanted.  Rows come in ascending cell order, so every row before the one that holds
+    // the tile's first sample lies wholly before the tile: the enumeration starts at that row
+    uint32_t rows_lo = 0;
+    if (half) {
+        int64_t cid = (int64_t)(cellkey[tile * 64] >> fb);    // (a tile's first sample is never a pad)
+        uint32_t mul = 1;
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            const int ci = (int)((cid / G.stride[i]) % G.g[i]);
+            rows_lo += (uint32_t)max(0, min(ci, chi[i]) - clo[i]) * mul;
+            mul *= (uint32_t)(chi[i] - clo[i] + 1);
+        }
+        rows_lo = min(rows_lo, rows);
+    }
+    const uint32_t nbatch = (rows - rows_lo + 63) / 64, bq = (nbatch + NW - 1) / NW;
+    const uint32_t row_begin = rows_lo + (uint32_t)wave * bq * 64, row_end = min(rows, rows_lo + (uint32_t)(wave + 1) * bq * 64);
     for (uint32_t row0 = row_begin; row0 < row_end; row0 += 64) {
         // lane = one row: candidate run [ca, ca+n) in chunk units
         const uint32_t row = row0 + lane;
@@ -268,7 +289,7 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
             if (lane == 0) prevc = carry;
             const int lastl = min(63, T - t0 - 1);
             carry = __shfl(c, lastl);
-            bool keep = act && (c != prevc);
+            bool keep = act && (c != prevc) && (!half || c >= tile);     // half build: the chunks before the tile find these pairs
             if (keep && !use_sub) {                       // coarse grid (<= 2 cells per dimension): every cell neighbours every other
                 double gap2 = 0.0;                        // one, a tile running over a row end loses nothing -- hull against hull
 #pragma unroll
@@ -311,7 +332,9 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
     }
     // the stored length never exceeds what was written (a truncated list voids the build: max_len tells the host / k_spec_check)
     if (NW == 1) {
-        if (lane == 0) { list_len[tl] = min(gcount, (int32_t)list_cap); atomicMax(max_len, gcount); }
+        // (the maximum goes to the atomic only when it beats what is there: one atomic per tile on the one address took most of this
+        // kernel's time -- ~88 atomics per microsecond)
+        if (lane == 0) { list_len[tl] = min(gcount, (int32_t)list_cap); if (gcount > *(volatile int32_t*)max_len) atomicMax(max_len, gcount); }
         return;
     }
     if (lane == 0) { s_wcnt[wave] = gcount; s_wfirst[wave] = (int32_t)firstkept; s_wlast[wave] = (int32_t)lastkept; }
@@ -330,7 +353,7 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
         const int32_t o = off + i - mydrop;
         if (o < list_cap) out[o] = stage[i];
     }
-    if (threadIdx.x == 0) { list_len[tl] = min(total, (int32_t)list_cap); atomicMax(max_len, total); }
+    if (threadIdx.x == 0) { list_len[tl] = min(total, (int32_t)list_cap); if (total > *(volatile int32_t*)max_len) atomicMax(max_len, total); }
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
@@ -365,6 +388,8 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     __shared__ int32_t s_cnt[64];
     __shared__ int32_t s_lc[4];                           // records in the item's four logs
     __shared__ int64_t s_base[MODE == 1 ? 64 : 1];
+    __shared__ uint4 s_pend[MODE == 2 ? 64 : 1];          // half build: the foreign records of the last drain, stored by the next one
+    __shared__ int32_t s_pfq[MODE == 2 ? 64 : 1];         //             ... and the foreign log each belongs to
 
     const int lane = threadIdx.x;
     const int64_t nblk = gridDim.x;
@@ -461,10 +486,31 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     int rcount = 0;                                           // wave-uniform record queue length
     int pool_over = 0;
     mpfmt_hit* const __restrict__ mylog = (MODE == 2) ? a.pool + (long long)item * 4 * a.pool_cap : nullptr;
+    // half build: the places a drain reserves in the foreign logs come back from the L2 a microsecond or two later; its records
+    // wait in LDS and are stored by the NEXT drain (or at the end of the item), so nobody waits for that round trip
+    int pend_base = 0;                                        // what the reserving atomic returned (lanes that led a log's group)
+    int pend_meta = 0;                                        // bit 31: this lane has a record pending; bits 0..5 leader lane, 6..12 place in the group
+    auto flush_pending = [&]() {
+        if (__ballot(pend_meta < 0) == 0) return;
+        const int base = __shfl(pend_base, pend_meta & 63);
+        if (pend_meta < 0) {
+            const int fp = base + ((pend_meta >> 6) & 127);
+            const int fq = s_pfq[lane];
+            if (fp < a.fcap) {
+                const uint4 rec = s_pend[lane];
+                *reinterpret_cast<uint4*>(&a.fpool[(long long)fq * a.fcap + fp]) = rec;
+                a.fcol[(long long)fq * a.fcap + fp] = (uint8_t)((rec.y >> 26) & 15u);
+            } else {
+                pool_over = 1;
+            }
+        }
+        pend_meta = 0;
+    };
     auto drain = [&](int n) {
         // takes the LAST n queue entries (order is irrelevant: columns are sorted afterwards), so nothing moves
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (MODE == 2 && a.half) flush_pending();
         const int first = qcount - n;
         qcount = __builtin_amdgcn_readfirstlane(first);
         if (MF_ABLATE & 2) return;
@@ -514,6 +560,36 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                 *reinterpret_cast<uint4*>(&mylog[(long long)g * a.pool_cap + p]) = *reinterpret_cast<const uint4*>(&h);   // one 16-byte store
             } else {
                 pool_over = 1;
+            }
+        }
+        if (MODE == 2 && a.half) {
+            // the same pair seen from the other end: column jg, row = this query -- a record for the FOREIGN log of jg's quarter tile.
+            // The hits of a drain fall into a handful of such logs (its survivors come from two or three chunks): the lanes of each
+            // log are found with one ballot per log, the first of them reserves the places of all with ONE returning atomic (a
+            // returning atomic per hit ran at 2e10 / s: 4.7 ms for the 1e8 of the north star), the others read it by lane exchange.
+            // The column lane of every record also goes to a compact side array, from which k_foreign_degrees counts the columns'
+            // foreign hits (the CSC offsets need every column's degree before the logs are ordered).
+            const bool fh = hit && (int64_t)(jg >> 6) != tile;
+            const int fq = (int)((jg >> 6) * 4u + ((jg & 63u) >> 4));
+            unsigned long long rem = __ballot(fh);
+            int leader = lane, pre = 0, cnt_l = 0;
+            while (rem) {
+                const int L = __builtin_ctzll(rem);
+                const int key = __builtin_amdgcn_readlane(fq, L);
+                const bool mine = fh && fq == key;
+                const unsigned long long mm = __ballot(mine);
+                if (mine) { leader = L; pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u)); }
+                if (lane == L) cnt_l = (int)__popcll(mm);
+                rem &= ~mm;
+            }
+            if (fh) {
+                const uint32_t qs = (uint32_t)(tile * 64) + ql;
+                mpfmt_hit h;
+                h.j = a.perm[qs]; h.pad = (int32_t)(qs | ((jg & 63u) << 26)); h.d = d2;
+                s_pend[lane] = *reinterpret_cast<const uint4*>(&h);
+                s_pfq[lane] = fq;
+                if (lane == leader) pend_base = atomicAdd(&a.flen[fq], cnt_l);
+                pend_meta = (int)(0x80000000u | (uint32_t)leader | ((uint32_t)pre << 6));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -663,6 +739,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     }
     while (rcount > 0) expand();
     while (qcount > 0) drain(min(qcount, 64));
+    if (MODE == 2 && a.half) flush_pending();
 
     if (MODE == 2) {
         if (pool_over) *a.pool_flag = 1;                          // overflow: the build falls back to a fill pass
@@ -725,13 +802,14 @@ int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
 
 // (re)build the per-tile candidate chunk lists of this ctx's shard for radius r; grows the list capacity until every
 // list fits.  *usable = false when the lists would need more than 32 GB (caller then takes the exact VALU path).
-int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec)
+int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec, bool half)
 {
     *usable = true;
     ctx->spec_lists = false;
     const int64_t nt = ctx->tile_end - ctx->tile_begin;
     if (nt <= 0) return MPFMT_OK;
-    if (ctx->lists_r == r && ctx->lists_begin == ctx->tile_begin && ctx->lists_end == ctx->tile_end && ctx->lists) return MPFMT_OK;
+    if (ctx->lists_r == r && ctx->lists_begin == ctx->tile_begin && ctx->lists_end == ctx->tile_end && ctx->lists && ctx->lists_half == half) return MPFMT_OK;
+    if (ctx->lists_half != half) { ctx->lists_cap_trusted = -1; ctx->lists_half = half; }       // (a capacity learnt in the other form says nothing)
     int32_t rc;
     int64_t cap = std::min<int64_t>(ctx->ntiles, std::max<int64_t>(ctx->list_cap, 2048));
     const double rpad = r * (1.0 + 1e-9) + 1e-300;
@@ -744,9 +822,9 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
         // few tiles (a small shard): four wavefronts per tile, kept ids staged in LDS (4 x cap x 4 bytes)
         const bool wide = nt < 16 * (int64_t)ctx->num_cus && cap <= 3072;
 #define CASE(DD) case DD: if (wide) hipLaunchKernelGGL((k_chunk_lists<DD, 4>), dim3((unsigned)nt), dim3(256), (size_t)cap * 16, ctx->stream, ctx->cellstart, \
-            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt); \
+            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt, half ? 1 : 0, ctx->cellkey, ctx->cell_fb); \
         else hipLaunchKernelGGL((k_chunk_lists<DD, 1>), dim3((unsigned)nt), dim3(64), 0, ctx->stream, ctx->cellstart, \
-            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt); break;
+            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt, half ? 1 : 0, ctx->cellkey, ctx->cell_fb); break;
         switch (ctx->d) {
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
             default: return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path supports d <= 12 (got %d)", ctx->d);
@@ -771,6 +849,41 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
         cap = std::min<int64_t>(ctx->ntiles, ((int64_t)mx + 255) / 256 * 256);
     }
     *usable = false;
+    return MPFMT_OK;
+}
+
+// half build: foreign hits of every column = a count over the compact column array of its quarter tile's foreign log (one
+// wavefront per quarter tile; the counts are row S of slice_cnt, where k_degree and the ordering kernel add them to the own ones)
+__global__ __launch_bounds__(256) void k_foreign_degrees(const uint8_t* __restrict__ fcol, const int32_t* __restrict__ flen, long long fcap,
+                                                         int64_t nq, int32_t* __restrict__ fdeg)
+{
+    __shared__ int s_c[4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;
+    if (lane < 16) s_c[wave][lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n = (int)min((long long)flen[q], fcap);
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(fcol + q * fcap);           // (fcap is a multiple of 16)
+    for (int i0 = lane * 16; i0 < n; i0 += 64 * 16) {
+        const uint4 v = src[i0 >> 4];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (i0 + k < n) atomicAdd(&s_c[wave][(w[k >> 2] >> (8 * (k & 3))) & 15u], 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16) fdeg[q * 16 + lane] = s_c[wave][lane];
+}
+
+int32_t mpfmt_launch_foreign_degrees(mpfmt_ctx* ctx)
+{
+    const int64_t nq = (ctx->tile_end - ctx->tile_begin) * 4;
+    if (nq <= 0) return MPFMT_OK;
+    hipLaunchKernelGGL(k_foreign_degrees, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ctx->stream, ctx->fcol, ctx->flen, (long long)ctx->fcap, nq,
+                       ctx->slice_cnt + (int64_t)ctx->S * (ctx->ntiles * 64));
+    HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
 
@@ -799,6 +912,9 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.survivors = nullptr;
     a.pool_flag = ctx->pool_flag; a.pool_cap = ctx->pool_cap;
     a.pool = ctx->pool; a.log_len = ctx->log_len;
+    a.half = (MODE == 2 && ctx->half_used) ? 1 : 0;
+    a.fpool = ctx->fpool; a.flen = ctx->flen; a.fcap = ctx->fcap; a.fcol = ctx->fcol;
+    if (MODE != 2 && ctx->lists_half) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "two-pass r-disc kernels need whole chunk lists");
     if (a.nitems <= 0) return MPFMT_OK;
     const int64_t gran = NXCD * (int64_t)std::max(1, a.xcd_mode);
     const unsigned nblk = (unsigned)(((a.nitems + gran - 1) / gran) * gran);

@@ -131,6 +131,17 @@ struct mpfmt_ctx {
     int64_t pool_cap = 0;                // capacity of one log, in records
     mpfmt_hit* pool = nullptr;           // [items][4][pool_cap] hit records: four append logs per (tile, slice), one per 16 columns
     int32_t* log_len = nullptr;          // [items][4] records in each log
+    // half build of the single-pass r-disc graph (kernels_rdisc_mfma.hip: every pair found once, the other column's record goes
+    // to a foreign log of that column's tile)
+    int use_half = 1;                    // option rdisc_half
+    bool half_used = false;              // the counted graph was built that way
+    bool half_off = false;               // a half build overflowed / met a column too long for the ordering kernel: whole builds from now on
+    bool lists_half = false;             // the cached chunk lists hold only chunks >= the tile
+    int cell_fb = 0;                     // position bits below the cell id in cellkey (k_cellkey)
+    mpfmt_hit* fpool = nullptr;          // [tiles][4][fcap] foreign logs
+    int32_t* flen = nullptr;             // [tiles][4] their lengths
+    uint8_t* fcol = nullptr;             // [tiles][4][fcap] column (within the quarter) of every foreign record
+    int64_t fcap = 0;
     int64_t max_deg = 0;                 // longest column of the counted graph (k_degree)
     int32_t pool_slack = 1;              // doubled after a build whose slot lists overflowed
     bool pool_valid = false;             // pool holds exactly the nnz hits of the counted graph
@@ -248,7 +259,8 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr, boo
 bool mpfmt_order_can_fuse(const mpfmt_ctx* ctx);
 int32_t mpfmt_sweep_prepare_ss(mpfmt_ctx* ctx);          // kernels_sweep.hip: device copy of the state-space bounds + the all-samples-inside flag
 #define MPFMT_ORD_MAXDEG 3072        // longest column the log-ordering kernel stages in LDS (ORD_STG in kernels_rdisc_mfma.hip)
-int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false);
+int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false, bool half = false);
+int32_t mpfmt_launch_foreign_degrees(mpfmt_ctx* ctx);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);
 
