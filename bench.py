@@ -284,6 +284,10 @@ def main():
     survivors = ctx.stat("survivors")
     single_pass = ctx.stat("pool_used") == 1
     tm = {k: ctx.timing(k) for k in ("grid", "rdisc_count", "pair_kernel", "rdisc_fill", "rdisc_sort", "order_sweep", "sweep_graph", "sweep_kernel")}
+    # per STEP: an interval name can be timed more than once in a step ("grid" is the cell grid + sorted copies, and again the MFMA
+    # operands + chunk lists), timing() returns the mean per interval
+    per_step = {k: (v[0] * v[1] / max(args.steps, 1)) for k, v in tm.items()}
+    half_build = ctx.stat("rdisc_half_used") == 1
     d = w.d
     fused = tm["order_sweep"][1] > 0                 # option fuse_sweep: the edge tests ride in the ordering kernel
     # the r-disc pair kernel k_rdisc_mfma on its own launch duration (single pass) -- or count + fill in the two-pass forms
@@ -333,13 +337,15 @@ def main():
                                 if rccl_abi else "gloo (one-device functional check)"),
                    "step": "index build (cell grid, sorted copies, MFMA operands, chunk lists) + r-disc graph of all N samples as an ordered CSC "
                            "+ collision sweep of all nnz directed edges; the one thing not redone per step is the all-samples-in-state-space "
-                           "flag (k_all_in_ss, 25 us, once per upload)"},
+                           "flag (k_all_in_ss, 25 us, once per upload)" +
+                           ("; half build: every pair of samples is tested once by the pair kernel, which writes the hit records of both columns" if half_build else "")},
         "submetrics": {
             "rdisc_queries_per_s": w.N * args.steps / dt,
             "edges_checked_per_s_sweep_kernel": (nnz / (sweep_ms * 1e-3)) if sweep_ms > 0 else None,
-            "rdisc_queries_per_s_graph_kernels": ((stats["tiles"] * 64) / ((tm["rdisc_count"][0] + tm["rdisc_fill"][0] + sort_ms + tm["grid"][0]) * 1e-3))
+            "rdisc_queries_per_s_graph_kernels": ((stats["tiles"] * 64) / ((tm["rdisc_count"][0] + tm["rdisc_fill"][0] + sort_ms + per_step["grid"]) * 1e-3))
             if pair_ms > 0 else None,
-            "kernel_ms": {k: v[0] for k, v in tm.items()},
+            "kernel_ms": per_step,
+            "rdisc_half_build": half_build,
             "pairs_tested_per_pass": pairs_per_pass,
             "pair_passes": passes,
             "rdisc_pair_kernel": "fp16 MFMA filter + exact fp64 refine" if path_used == 2 else "exact fp64 VALU",
@@ -366,13 +372,18 @@ def main():
             "traffic_source": prof.get("source") if pk else None,
             "mfma_flops_issued_tflops": mfma_tflops,
             "frac_of_fp64_peak": ach_tflops / FP64_PEAK_TFLOPS,
+            "half_build": half_build,
+            "ordered_pairs_served_tflops": ach_tflops * (2.0 if half_build else 1.0),
             "valu_per_mfma": pk.get("valu_per_mfma"),
             "valu_busy": pk.get("valu_busy"),
             "avg_launch_ms": pair_ms,
             "note": "achieved = pairs_tested x 2d algorithmic flop (SURVEY 8d) / kernel time; peak = dense fp16 MFMA "
                     "(the filter runs v_mfma_f32_32x32x%d_f16, %d flop per pair with the norm slots); the kernel is " % (mfma_k, 2 * mfma_k) +
                     "VALU-issue bound: 16 v_alignbit per MFMA read the 1024 accumulator signs (a half-rate VALU class on gfx950, "
-                    "profiles/r03_ubench_valu_classes.txt), the matrix pipe is busy 1/6 of the time; the result is the exact fp64 graph"
+                    "profiles/r03_ubench_valu_classes.txt), the matrix pipe is busy 1/6 of the time; the result is the exact fp64 graph" +
+                    ("; half build: pairs_tested counts every unordered (tile, chunk) block once -- the kernel does half the distance "
+                     "work of the whole build and writes the records of both columns (ordered_pairs_served_tflops = what a whole build "
+                     "would have had to evaluate in the same time)" if half_build else "")
         }
     # SURVEY 8d asks for both fractions of the sweep: algorithmic bytes/s over 8 TB/s and fp64 lane-ops/s over 39.3e12.
     # Lane-ops per edge come from the PMC run (SQ_INSTS_VALU x 64 lanes / edges) when the summary matches this build.

@@ -831,6 +831,8 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     const bool too_long = rb->max_deg > MPFMT_ORD_MAXDEG;
     if (ctx->half_used && pool && (pool_over || too_long)) {
         // a half build cannot fall back to the fill pass (its counts and lists cover half the pairs): count again, whole
+        // (an overflow may have been a first, unsized estimate: half builds get one more try once a whole build has left its hint)
+        ctx->half_fail += too_long ? 2 : 1;
         ctx->half_off = true; ctx->half_used = false;
         ctx->lists_r = -1.0;
         if (pool_over && ctx->pool_slack < 8) ctx->pool_slack *= 2;
@@ -840,6 +842,7 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     }
     if (spec_failed && pool && (pool_over || too_long)) *spec_failed = true;
     ctx->pool_valid = pool && pool_over == 0 && !too_long;
+    if (ctx->pool_valid && ctx->half_off && ctx->half_fail < 2) ctx->half_off = false;
     if (pool && pool_over && ctx->pool_slack < 8) ctx->pool_slack *= 2;
     ctx->pool_hint_N = N; ctx->pool_hint_r = r; ctx->pool_hint_nnz = nnz;
     ctx->pool_hint_rank = ctx->rank; ctx->pool_hint_world = ctx->world;

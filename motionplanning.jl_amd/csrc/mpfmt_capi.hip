@@ -1362,7 +1362,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "fuse_sweep") == 0) { ctx->fuse_sweep = value != 0; return MPFMT_OK; }
     if (strcmp(name, "wf_graphs") == 0) { ctx->wf_graphs = value != 0; return MPFMT_OK; }
     if (strcmp(name, "rdisc_half") == 0) {
-        ctx->use_half = value != 0; ctx->half_off = false;
+        ctx->use_half = value != 0; ctx->half_off = false; ctx->half_fail = 0;
         ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false; ctx->spec_ready = false; ctx->lists_r = -1.0;
         return MPFMT_OK;
     }

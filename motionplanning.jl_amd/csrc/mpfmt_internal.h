@@ -135,6 +135,7 @@ struct mpfmt_ctx {
     // to a foreign log of that column's tile)
     int use_half = 1;                    // option rdisc_half
     bool half_used = false;              // the counted graph was built that way
+    int half_fail = 0;                   // half builds that had to be redone whole (2: no more tries)
     bool half_off = false;               // a half build overflowed / met a column too long for the ordering kernel: whole builds from now on
     bool lists_half = false;             // the cached chunk lists hold only chunks >= the tile
     int cell_fb = 0;                     // position bits below the cell id in cellkey (k_cellkey)

@@ -57,6 +57,55 @@ def test_graph_step_device_against_oracle(orc, world, sorted_rows, rounds):
                 assert nnz == deg.sum()
 
 
+@pytest.mark.parametrize("d,N,r", [(2, 6000, 0.03), (3, 7001, 0.09), (6, 20000, 0.42)])
+def test_half_build_equals_whole_build_and_the_oracle(orc, d, N, r):
+    """The single-pass build in its half form (every pair tested once, the other column's record written to a foreign log) against
+    the whole form and the oracle: graph, costs, free mask, over a careful first step, speculative repeats and new samples."""
+    rng = np.random.default_rng(4000 + d)
+    X, lohi = random_world(rng, N, d, 12, 0.05, 0.2)
+    lo, hi = np.full(d, 0.0), np.full(d, 1.0)
+    sets = [X, X, rng.random((N, d))]
+    got = {}
+    used = 0
+    for half in (1, 0):
+        with mp.Context(0) as c:
+            c.set_option("rdisc_half", half); c.set_option("rebuild_index", 1)
+            c.upload_boxes(lohi, lo, hi)
+            for it, Xi in enumerate(sets):
+                c.upload_samples(Xi)
+                nnz = c.graph_step_device(r)
+                assert half == 1 or c.stat("rdisc_half_used") == 0
+                used = used + c.stat("rdisc_half_used")     # (new samples may outgrow a trusted capacity: that step is redone whole)
+                got[(half, it)] = _resident_graph(c, N)
+                assert nnz == got[(half, it)][0][-1]
+    assert used >= 1                                          # the half form did run (a first estimate that overflows is redone whole)
+    for it, Xi in enumerate(sets):
+        a, b = got[(1, it)], got[(0, it)]
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v), it
+        if it != 1:
+            oc, orow, oval = orc.rdisc_graph(Xi, r)
+            assert np.array_equal(a[0], oc) and np.array_equal(a[1], orow) and np.array_equal(a[2], oval)
+            assert np.array_equal(a[3].view(np.uint64), orc.graph_edges_free(Xi, oc, orow, lohi, lo, hi))
+
+
+def test_half_build_overflow_is_redone_whole(orc):
+    """A cluster the capacity estimate does not expect: the half build's logs overflow, the count is redone whole (a half build
+    has no fill pass to fall back to), and once a build has left its size hint the half form is tried again."""
+    rng = np.random.default_rng(91)
+    X = np.concatenate([0.5 + 0.004 * rng.standard_normal((3000, 3)), rng.random((900, 3))])
+    oc, orow, oval = orc.rdisc_graph(X, 0.2)
+    with mp.Context(0) as c:
+        c.upload_samples(X)
+        seen = []
+        for _ in range(3):
+            colptr, rowval, nzval = c.rdisc_graph(0.2)
+            assert np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow) and np.array_equal(nzval, oval)
+            seen.append((c.stat("pool_used"), c.stat("rdisc_half_used")))
+        assert seen[0] == (0, 0)                              # estimate too small: two-pass build
+        assert seen[1][0] == 1                                # sized by the first build's count
+
+
 def test_trimmed_stress_in_suite(orc):
     """tools/stress.py with fixed seeds and a bounded budget: random sizes / dimensions / radii / obstacle counts / shards,
     both pair kernels, graph + costs + masks + the three-call graph_step_device sequence, all against the oracle."""
