@@ -35,6 +35,7 @@ __device__ __forceinline__ ord_cptr ord_const(const double* p) { return (ord_cpt
 // streamed from the logs in phases 2 and 4.  The staging area holds ORD_STG records; a quarter with more hits is done in several
 // column ranges.  Columns longer than ORD_STG never come here: the host checks the maximum degree (k_degree) and takes the
 // two-pass build.
+#define ORD_ID(x) ((x) & 0x3fffffffu)      // a record's row index; bit 30 = the pair kernel's broad-phase flag (edge needs an exact test)
 #define ORD_THREADS 512
 #define ORD_WAVES 8
 #define ORD_COLS 16              // columns per workgroup = columns per log
@@ -52,6 +53,7 @@ struct ord_hdr {
     int32_t cb[ORD_COLS + 4];    // exclusive prefix of the degrees (cb[ORD_COLS] = hits of the quarter)
     int32_t lp[MPFMT_MAXS + 4];  // exclusive prefix of the S log lengths: lp[sl] = records before log sl, lp[S] = records of the quarter
     long long out[ORD_COLS];     // colptr of each column
+    int32_t ho[ORD_COLS];        // sample index of each column (pending-entry items)
     double xc[ORD_COLS][DX];     // column states (fused sweep)
 };
 template <int DX, bool SWEEP>
@@ -59,7 +61,7 @@ struct ord_shared {
     int32_t cnt[ORD_COLS][ORD_NB];   // records per (column, bucket)
     int32_t cur[ORD_COLS][ORD_NB];   // next staging position of each (column, bucket); after the placement: the bucket's end
     ord_hdr<DX> h[2];            // headers of the quarter in work and of the next one (prefetched)
-    int32_t g1, pad_[3];
+    int32_t g1, pcount, pad_[2];     // pcount: pending-entry items this workgroup has appended
     unsigned long long cm[SWEEP ? ORD_COLS : 1][ORD_MAXM / 64];     // obstacles that survive each column's cull
     uint32_t bits[SWEEP ? ORD_STG / 32 : 1];                         // free bit of every staged entry, by rank position
     uint32_t qa[SWEEP ? ORD_WAVES : 1][SWEEP ? ORD_QCAP : 1];        // pending exact tests: rank position | box << 12 | column << 20
@@ -100,7 +102,9 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
                                                             const int64_t* __restrict__ colptr, const int32_t* __restrict__ perm,
                                                             int32_t* __restrict__ rowval, double* __restrict__ nzval, int32_t* __restrict__ rowpos,
                                                             uint32_t bucket_mul, const int32_t* __restrict__ spec_fail, ord_sweep sw,
-                                                            const mpfmt_hit* __restrict__ flogs, int64_t fcapL, const int32_t* __restrict__ flen)
+                                                            const mpfmt_hit* __restrict__ flogs, int64_t fcapL, const int32_t* __restrict__ flen,
+                                                            uint4* __restrict__ pend_items, int64_t pend_wcap, int32_t* __restrict__ pend_cnt,
+                                                            int32_t* __restrict__ pend_over)
 {
     if (spec_fail && *spec_fail) return;                     // speculative step whose capacities did not hold: redone by the host
     // half build (flogs != nullptr): every pair was found once, by the tile of its lower cell-sorted end, which also wrote the
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
             if (tid < ORD_COLS) {
-                H.k[tid] = k; H.cb[tid + 1] = inc;
+                H.k[tid] = k; H.cb[tid + 1] = inc; H.ho[tid] = ho;
                 if (SWEEP) {
 #pragma unroll
                     for (int i = 0; i < DX; ++i) H.xc[tid][i] = hx[i];
@@ -209,6 +213,10 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
         }
     };
 
+    // Entries whose record carries the pair kernel's broad-phase flag (bit 30 of the row index: the segment's box meets an
+    // obstacle's) are listed for k_sweep_pending -- (entry, column sample, row position) -- in this workgroup's own segment of the
+    // item array; every other entry is free and stays set in the preset mask.
+    if (tid == 0) sh.pcount = 0;
     int64_t qi = blockIdx.x;
     int hb = 0;
     hdr_fetch1(qi);
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
             // ---- COUNT ----
             if (!skip) for_records([&](const uint4& r) {
                 const int col = (int)(r.y >> 26) - c0;
-                if (col >= g0 && col < g1) atomicAdd(&sh.cnt[col][bucket(r.x)], 1);
+                if (col >= g0 && col < g1) atomicAdd(&sh.cnt[col][bucket(ORD_ID(r.x))], 1);
             });
             lds_barrier();
             // ---- segmented scan: thread = four consecutive buckets, 32 threads per column ----
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
             if (!skip) for_records([&](const uint4& r) {
                 const int col = (int)(r.y >> 26) - c0;
                 if (col >= g0 && col < g1) {
-                    const int pos = atomicAdd(&sh.cur[col][bucket(r.x)], 1);
+                    const int pos = atomicAdd(&sh.cur[col][bucket(ORD_ID(r.x))], 1);
                     if (pos >= 0 && pos < ORD_STG) stage[pos] = r;
                 }
             });
@@ -369,17 +377,32 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
                     // (idle lanes of the last round carry the range's last column: the wave's column span below stays an interval)
                     const uint4 r = act ? stage[p] : make_uint4(0u, (uint32_t)(c0 + g1 - 1) << 26, 0u, 0u);
                     const int col = min(max((int)(r.y >> 26) - c0, 0), ORD_COLS - 1);
-                    const int bk = bucket(r.x);
+                    const int bk = bucket(ORD_ID(r.x));
                     const int e = sh.cur[col][bk], n = sh.cnt[col][bk];            // the bucket occupies [e - n, e)
                     int rk = e - n;
-                    if (act) for (int m = e - n; m < e; ++m) rk += ((int32_t)stage[m].x < (int32_t)r.x) ? 1 : 0;
+                    if (act) for (int m = e - n; m < e; ++m) rk += ((int32_t)ORD_ID(stage[m].x) < (int32_t)ORD_ID(r.x)) ? 1 : 0;
                     const int rel = rk - (H.cb[col] - gb);                          // rank inside the column
                     const bool valid = act && rel >= 0 && rel < H.k[col];          // (always, unless a log overflowed: that build is void, but stays in bounds)
+                    const int64_t o = H.out[col] + rel;
                     if (valid) {
-                        const int64_t o = H.out[col] + rel;
-                        rowval[o] = (int32_t)r.x;
+                        rowval[o] = (int32_t)ORD_ID(r.x);
                         nzval[o] = sqrt(__hiloint2double((int)r.w, (int)r.z));      // the log carries d2
                         if (rowpos) rowpos[o] = (int32_t)(r.y & 0x3ffffffu);
+                    }
+                    if (pend_items) {
+                        const bool pd = valid && ((r.x >> 30) & 1u);
+                        const unsigned long long pm = __ballot(pd);
+                        if (pm) {
+                            int base = 0;
+                            if (lane == 0) base = atomicAdd(&sh.pcount, (int)__popcll(pm));
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            if (pd) {
+                                const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                                if (pos < pend_wcap)
+                                    pend_items[(int64_t)blockIdx.x * pend_wcap + pos] =
+                                        make_uint4((uint32_t)(uint64_t)o, (uint32_t)((uint64_t)o >> 32), (uint32_t)H.ho[col], r.y & 0x3ffffffu);
+                            }
+                        }
                     }
                     if constexpr (SWEEP) {
                         const uint32_t jg = r.y & 0x3ffffffu;
@@ -496,6 +519,14 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
         }
         if (tid < ORD_COLS) sh.h[hb ^ 1].out[tid] = hout;     // the next quarter's output offsets (requested before the write-out)
     }
+    if (pend_items) {
+        lds_barrier();
+        if (tid == 0) {
+            const int c = sh.pcount;
+            pend_cnt[blockIdx.x] = (int32_t)min((int64_t)c, pend_wcap);
+            if (c > pend_wcap) *pend_over = 1;                // a segment was too short: the host sweeps the whole graph instead
+        }
+    }
 }
 
 template <int D, bool SWEEP>
@@ -516,11 +547,25 @@ static int32_t launch_order(mpfmt_ctx* ctx, const int32_t* spec_fail, const ord_
         per_cu = std::max(1, std::min(per_cu, 2));
     }
     const unsigned nb = (unsigned)std::min<int64_t>(nt * 4, (int64_t)ctx->num_cus * per_cu);
+    // records flagged by the pair kernel's broad phase (step APIs, half build): their entries are listed for k_sweep_pending, one
+    // segment of the item array per workgroup.  Workgroups take every nb-th quarter tile, so their shares are even: 1.5x the mean + 4096
+    const bool pend = !SWEEP && ctx->broad_in_drain;
+    if (pend) {
+        int32_t rc;
+        const int64_t entries = std::max<int64_t>(ctx->nnz, ctx->nnz_cap);
+        ctx->pend_wcap = entries * 3 / (2 * (int64_t)nb) + 4096;
+        if ((rc = mpfmt_ensure(ctx, (void**)&ctx->pend_items, sizeof(uint4) * (size_t)ctx->pend_wcap * nb))) return rc;
+        if ((rc = mpfmt_ensure(ctx, (void**)&ctx->pend_cnt, sizeof(int32_t) * (size_t)(nb + 1)))) return rc;
+        ctx->pend_over = ctx->pend_cnt + nb;
+        HIPCHK(ctx, hipMemsetAsync(ctx->pend_over, 0, sizeof(int32_t), ctx->stream));
+    }
     hipLaunchKernelGGL(kk, dim3(nb), dim3(ORD_THREADS), lds, ctx->stream, ctx->pool, ctx->pool_cap, ctx->S,
                        ctx->slice_cnt, ctx->ntiles * 64, ctx->log_len, ctx->tile_begin, ctx->tile_end, ctx->colptr, ctx->perm,
-                       ctx->rowval, ctx->nzval, (!SWEEP && ctx->sweep_sorted) ? ctx->rowpos : nullptr,
+                       ctx->rowval, ctx->nzval, (!SWEEP && ctx->sweep_sorted && !pend) ? ctx->rowpos : nullptr,      // (the pending list carries its own row positions)
                        ctx->N > 128 ? (uint32_t)((128ull << 32) / (uint64_t)ctx->N) : 0u, spec_fail, sw,
-                       ctx->half_used ? ctx->fpool : nullptr, ctx->fcap, ctx->flen);
+                       ctx->half_used ? ctx->fpool : nullptr, ctx->fcap, ctx->flen,
+                       pend ? (uint4*)ctx->pend_items : nullptr, ctx->pend_wcap, ctx->pend_cnt, ctx->pend_over);
+    if (pend) ctx->pend_nseg = (int)nb;
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
@@ -555,7 +600,8 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail, bool fuse, in
         // option sweep_sorted: also keep every row's cell-sorted position, so the sweep can gather from Xs (see kernels_sweep.hip)
         if (ctx->sweep_sorted && (rc = mpfmt_ensure(ctx, (void**)&ctx->rowpos, sizeof(int32_t) * (size_t)std::max<int64_t>(std::max(ctx->nnz, ctx->nnz_cap), 1)))) return rc;
         if ((rc = launch_order<1, false>(ctx, spec_fail, sw))) return rc;
-        ctx->rowpos_valid = ctx->sweep_sorted != 0;   // every entry's row is also known by its cell-sorted position (the sweep gathers from Xs)
+        ctx->pend_valid = ctx->broad_in_drain;        // ... or the flagged entries have been listed for k_sweep_pending
+        ctx->rowpos_valid = ctx->sweep_sorted != 0 && !ctx->pend_valid;   // every entry's row is also known by its cell-sorted position (the sweep gathers from Xs)
         return MPFMT_OK;
     }
     switch (ctx->d) {

@@ -611,10 +611,12 @@ __global__ void k_spec_check(const int32_t* __restrict__ pool_flag, const int32_
 struct count_readback { unsigned long long pairs[512]; long long nnz; int pool_over, list_mx, max_deg, pad_; };
 __global__ __launch_bounds__(512) void k_count_readback(const unsigned long long* __restrict__ pairs, const int64_t* __restrict__ nnz,
                                                         const int32_t* __restrict__ pool_flag, const int32_t* __restrict__ list_max,
-                                                        const int32_t* __restrict__ max_deg, count_readback* __restrict__ out)
+                                                        const int32_t* __restrict__ max_deg, count_readback* __restrict__ out,
+                                                        const int32_t* __restrict__ pend_over)
 {
     out->pairs[threadIdx.x] = pairs[threadIdx.x];
     if (threadIdx.x == 0) {
+        out->pad_ = pend_over ? *pend_over : 0;               // (speculative step: a segment of the pending-entry list overflowed)
         out->nnz = *nnz;
         out->pool_over = pool_flag ? *pool_flag : 0;
         out->list_mx = list_max ? *list_max : 0;
@@ -768,8 +770,10 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         if (!ok) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "chunk lists do not fit");
     }
     ctx->half_used = half;
+    ctx->broad_in_drain = half && ctx->want_broad;
     ctx->pool_valid = false;
     ctx->rowpos_valid = false;
+    ctx->pend_valid = false;
     mpfmt_timed tm3(ctx);
     if (nt > 0) {
         if (mf) {
@@ -810,11 +814,13 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     if (!ctx->rb_dev) HIPCHK(ctx, hipMalloc(&ctx->rb_dev, sizeof(count_readback)));
     if (!ctx->rb_host) HIPCHK(ctx, hipHostMalloc(&ctx->rb_host, sizeof(count_readback), hipHostMallocDefault));
     hipLaunchKernelGGL(k_count_readback, dim3(1), dim3(512), 0, ctx->stream, ctx->d_pairs, ctx->colptr + N, pool ? ctx->pool_flag : nullptr,
-                       (ctx->spec_lists && nt > 0) ? ctx->list_len + nt : nullptr, (const int32_t*)(ctx->d_pairs + 512), (count_readback*)ctx->rb_dev);
+                       (ctx->spec_lists && nt > 0) ? ctx->list_len + nt : nullptr, (const int32_t*)(ctx->d_pairs + 512), (count_readback*)ctx->rb_dev,
+                       (ctx->pend_valid && ctx->sweep_pending_used) ? (const int32_t*)ctx->pend_over : nullptr);
     HIPCHK(ctx, hipMemcpyAsync(ctx->rb_host, ctx->rb_dev, sizeof(count_readback), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const count_readback* rb = (const count_readback*)ctx->rb_host;
     const int64_t nnz = rb->nnz;
+    ctx->pend_overflowed = rb->pad_ != 0;
     const int32_t pool_over = rb->pool_over, list_mx = rb->list_mx;
     unsigned long long pairs[512];
     memcpy(pairs, rb->pairs, sizeof pairs);
@@ -908,6 +914,22 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r, bool fuse_sweep)
     return MPFMT_OK;
 }
 
+// the sweep visited the pending-entry list only (mpfmt_launch_graph_sweep): had a segment of that list overflowed, the kernel has
+// done nothing -- found out here, behind a synchronisation the careful path can afford, and answered with the whole sweep
+static int32_t sweep_checked(mpfmt_ctx* ctx)
+{
+    int32_t rc;
+    if (ctx->graph_swept) return MPFMT_OK;
+    if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+    if (!ctx->sweep_pending_used) return MPFMT_OK;
+    int32_t over = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&over, ctx->pend_over, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!over) return MPFMT_OK;
+    ctx->pend_valid = false; ctx->graph_swept = false;
+    return mpfmt_launch_graph_sweep(ctx);
+}
+
 // One whole step -- index, r-disc graph, column order, collision sweep -- with a single host synchronisation.
 // mpfmt_launch_rdisc_count + _fill + mpfmt_launch_graph_sweep need the host between them (nnz sizes the CSC and the mask,
 // the list maximum and the pool flag decide the path).  When the previous build of the same (N, r, shard) went through the
@@ -917,11 +939,22 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r, bool fuse_sweep)
 // The step is split in two so that ONE host thread can keep several ctxs (GPUs) busy: _launch issues the kernels of the
 // speculative form without waiting (or, when nothing can be trusted yet, runs the careful form to completion), _finish makes
 // the one synchronisation, validates, and redoes the step the careful way if a trusted capacity did not hold.
+// can the broad phase of the step's edge tests ride in the pair kernel's drain?  (PointRobotNDBoxes in the state space's own
+// coordinates, d <= 6 -- the K = 8 pair kernel --, <= 256 boxes, no sample outside the state space: the one-sided in_state_space test of
+// statespaces.jl:155 is then true for every entry)
+static bool step_wants_broad(mpfmt_ctx* ctx)
+{
+    if (!ctx->fuse_broad || ctx->cc_kind != 0 || !ctx->have_boxes || ctx->dw != ctx->d || ctx->d > 6 || ctx->M > 256 || ctx->world != 1) return false;
+    if (mpfmt_sweep_prepare_ss(ctx) != MPFMT_OK) return false;
+    return !(ctx->ss.has && !ctx->ssflag_all_in);
+}
+
 int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r)
 {
     int32_t rc;
     const int64_t N = ctx->N;
     ctx->step_state = 0; ctx->step_r = r;
+    ctx->want_broad = step_wants_broad(ctx);
     const bool spec = ctx->spec_ready && ctx->use_pool && ctx->pool_hint_N == N && ctx->pool_hint_r == r && ctx->pool_hint_rank == ctx->rank &&
                       ctx->pool_hint_world == ctx->world && ctx->pool_hint_nnz > 0 && ctx->cc_kind == 0 && ctx->have_boxes && ctx->dw == ctx->d;
     if (spec) {
@@ -950,20 +983,28 @@ int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r)
         }
         if ((rc = mpfmt_rdisc_count_finish(ctx, r, nullptr))) return rc;
         if ((rc = mpfmt_launch_rdisc_fill(ctx, r, true))) return rc;
-        if (!ctx->graph_swept && (rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+        if ((rc = sweep_checked(ctx))) return rc;
         ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
         ctx->step_state = 2;
         return MPFMT_OK;
     }
     if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
     if ((rc = mpfmt_launch_rdisc_fill(ctx, r, true))) return rc;
-    if (!ctx->graph_swept && (rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+    if ((rc = sweep_checked(ctx))) return rc;
     ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
     ctx->step_state = 2;
     return MPFMT_OK;
 }
 
+static int32_t step_finish_inner(mpfmt_ctx* ctx);
 int32_t mpfmt_graph_step_finish_impl(mpfmt_ctx* ctx)
+{
+    const int32_t rc = step_finish_inner(ctx);
+    ctx->want_broad = false;                                  // (builds outside a step never flag their records)
+    return rc;
+}
+
+static int32_t step_finish_inner(mpfmt_ctx* ctx)
 {
     int32_t rc;
     const double r = ctx->step_r;
@@ -974,6 +1015,10 @@ int32_t mpfmt_graph_step_finish_impl(mpfmt_ctx* ctx)
         if ((rc = mpfmt_rdisc_count_finish(ctx, r, &failed))) return rc;
         if (!failed && ctx->nnz < ctx->nnz_cap && ctx->pool_valid) {
             ctx->graph_filled = true; ctx->graph_swept = true;      // (finish resets the flags it owns)
+            if (ctx->pend_overflowed) {                             // the pending-entry list was cut short: sweep the whole graph
+                ctx->pend_valid = false; ctx->graph_swept = false;
+                return mpfmt_launch_graph_sweep(ctx);
+            }
             return MPFMT_OK;
         }
         // the trust was misplaced: redo the step the careful way (capacities have been corrected by finish)
@@ -981,7 +1026,7 @@ int32_t mpfmt_graph_step_finish_impl(mpfmt_ctx* ctx)
         ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
         if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
         if ((rc = mpfmt_launch_rdisc_fill(ctx, r, true))) return rc;
-        if (!ctx->graph_swept && (rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+        if ((rc = sweep_checked(ctx))) return rc;
         ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
         return MPFMT_OK;
     }

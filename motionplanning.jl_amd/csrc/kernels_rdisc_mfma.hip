@@ -24,6 +24,7 @@
 // prefetched two chunks ahead; chunks farther than r from the tile's tight box are pruned by a lane-parallel prologue.
 // MODE 2 (single pass) also writes every exact hit into the fixed-capacity slot list of its (tile, slice, column).
 #include "mpfmt_internal.h"
+#include "sweep_cmpx.h"
 #include <algorithm>
 #include <cmath>
 
@@ -38,6 +39,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define MF_WAVES 4
 #define MF_QCAP 256                 // survivor queue entries per wavefront (drained in batches of 64)
 #define MF_PAD_NORM 60000.0f        // |u|^2 stand-in for padding samples: never below any threshold
+
+// a global pointer read through the constant address space: a wave-uniform address then always takes the scalar cache
+typedef const __attribute__((address_space(4))) double* mf_cptr;
+__device__ __forceinline__ mf_cptr mf_const(const double* p) { return (mf_cptr)(uintptr_t)p; }
 
 struct mf_args {
     const uint4* ops;               // [npad][2] 16 fp16 slots per sorted sample (candidate role)
@@ -77,6 +82,11 @@ struct mf_args {
     int32_t* flen;                  // [tiles][4] their lengths (global cursors)
     long long fcap;
     uint8_t* fcol;                  // [tiles][4][fcap] column (0..15 of the quarter) of every foreign record: what k_foreign_degrees reads
+    // broad phase of the edge tests in the drain (half build, d <= 6, <= 256 boxes in the state space's own coordinates, every
+    // sample inside the state space): bit 30 of a record's row index = "the segment's box meets an obstacle's: exact test needed"
+    int32_t fb;
+    int32_t M;
+    const double* boxes;            // [M][2][D]
 };
 
 __device__ __forceinline__ int cell_of_m(double x, double lo, double inv_w, int g)
@@ -412,6 +422,31 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     const int64_t qpos = tile * 64 + lane;
     const int kb = lane >> 5, col = lane & 31;
 
+    // ---- broad phase in the drain: the obstacles that can meet a segment out of this tile at all (lane = box).  Both ends of such a
+    // segment lie within r of the tile's hull (the candidate is within r of a query of the tile), so a box farther than that from
+    // the hull in some axis is out for the whole item
+    unsigned long long bsurv[4] = {0ull, 0ull, 0ull, 0ull};
+    if constexpr (MODE == 2 && D <= 6) {
+        if (a.fb) {
+            double ulo[D], uhi[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { ulo[i] = a.tile_lo[tile * D + i] - a.rpad; uhi[i] = a.tile_hi[tile * D + i] + a.rpad; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c * 64 < a.M) {
+                    const int kbx = c * 64 + lane;
+                    int out = 0;
+                    if (kbx < a.M) {
+                        const double* bp = a.boxes + (int64_t)kbx * 2 * D;
+#pragma unroll
+                        for (int i = 0; i < D; ++i) out |= (int)(bp[D + i] < ulo[i]) | (int)(bp[i] > uhi[i]);
+                    }
+                    bsurv[c] = __ballot(kbx < a.M && !out);
+                }
+            }
+        }
+    }
+
     // ---- setup: fp64 query coordinates to LDS, A fragments to VGPRs, counters --------------------------------
 #pragma unroll
     for (int i = 0; i < D; ++i) s_q[lane * D + i] = a.Xs[qpos * D + i];
@@ -517,6 +552,11 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         bool hit = false;
         uint32_t jg = 0, ql = 0;
         double d2 = 0.0;
+        [[maybe_unused]] double sl[D <= 6 ? D : 1], sh[D <= 6 ? D : 1];
+        if constexpr (MODE == 2 && D <= 6) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) { sl[i] = (double)INFINITY; sh[i] = -(double)INFINITY; }
+        }
         if (lane < n) {
             // decode (the queue stores the raw coordinates of the sign bit: decoding once per drain -- 64 survivors wide -- is an
             // order of magnitude cheaper than in the extraction, which runs per chunk with a handful of active lanes)
@@ -529,7 +569,12 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             ql = (uint32_t)((t & 1) * 32 + row);
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                const double t = s_q[ql * D + i] - a.Xs[(int64_t)jg * D + i];
+                const double qi = s_q[ql * D + i], ci = a.Xs[(int64_t)jg * D + i];
+                if constexpr (MODE == 2 && D <= 6) {
+                    asm("v_min_f64 %0, %1, %2" : "=v"(sl[i]) : "v"(qi), "v"(ci));     // the segment's box (only compared: -0 / +0 do not show)
+                    asm("v_max_f64 %0, %1, %2" : "=v"(sh[i]) : "v"(qi), "v"(ci));
+                }
+                const double t = qi - ci;
                 const double tt = t * t;
                 d2 = (i == 0) ? tt : d2 + tt;
             }
@@ -545,6 +590,29 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                 }
             }
         }
+        // broad phase of is_free_motion for the hits of this drain (boxesND.jl:44-45, symmetric in the two end points, so one test
+        // serves both records of a pair): the boxes that survived the tile's cull, each through the scalar cache, 2 D v_cmpx in a row
+        uint32_t pendflag = 0;
+        if constexpr (MODE == 2 && D <= 6) {
+            if (a.fb) {
+                unsigned pk = 0, pc = 0;
+                sl[0] = hit ? sl[0] : (double)INFINITY;       // lanes without a hit fail the first comparison
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned long long mb = bsurv[c];
+                    while (mb) {
+                        const int kbx = c * 64 + (__ffsll((long long)mb) - 1);
+                        mb &= mb - 1;
+                        double blo[D], bhi[D];
+                        const mf_cptr bp = mf_const(a.boxes) + (int64_t)kbx * 2 * D;
+#pragma unroll
+                        for (int i = 0; i < D; ++i) { blo[i] = bp[i]; bhi[i] = bp[D + i]; }
+                        sweep_cmpx<D>::note(blo, bhi, sl, sh, pk, pc, kbx);
+                    }
+                }
+                pendflag = pc ? (1u << 30) : 0u;
+            }
+        }
         if (MODE == 2 && hit) {
             // single pass: the hit goes to one of the item's FOUR logs, one per 16 columns of its tile, so that k_order_logs can
             // regroup a quarter tile (about 1 700 hits) in one pass through LDS.  Its place is a returning LDS atomic on the log's
@@ -556,7 +624,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             const int p = atomicAdd(&s_lc[g], 1);
             if (p < a.pool_cap) {
                 mpfmt_hit h;
-                h.j = a.perm[jg]; h.pad = (int32_t)(jg | (ql << 26)); h.d = d2;
+                h.j = (int32_t)((uint32_t)a.perm[jg] | pendflag); h.pad = (int32_t)(jg | (ql << 26)); h.d = d2;
                 *reinterpret_cast<uint4*>(&mylog[(long long)g * a.pool_cap + p]) = *reinterpret_cast<const uint4*>(&h);   // one 16-byte store
             } else {
                 pool_over = 1;
@@ -585,7 +653,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             if (fh) {
                 const uint32_t qs = (uint32_t)(tile * 64) + ql;
                 mpfmt_hit h;
-                h.j = a.perm[qs]; h.pad = (int32_t)(qs | ((jg & 63u) << 26)); h.d = d2;
+                h.j = (int32_t)((uint32_t)a.perm[qs] | pendflag); h.pad = (int32_t)(qs | ((jg & 63u) << 26)); h.d = d2;
                 s_pend[lane] = *reinterpret_cast<const uint4*>(&h);
                 s_pfq[lane] = fq;
                 if (lane == leader) pend_base = atomicAdd(&a.flen[fq], cnt_l);
@@ -914,6 +982,7 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.pool = ctx->pool; a.log_len = ctx->log_len;
     a.half = (MODE == 2 && ctx->half_used) ? 1 : 0;
     a.fpool = ctx->fpool; a.flen = ctx->flen; a.fcap = ctx->fcap; a.fcol = ctx->fcol;
+    a.fb = (a.half && ctx->broad_in_drain) ? 1 : 0; a.M = ctx->M; a.boxes = ctx->boxes;
     if (MODE != 2 && ctx->lists_half) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "two-pass r-disc kernels need whole chunk lists");
     if (a.nitems <= 0) return MPFMT_OK;
     const int64_t gran = NXCD * (int64_t)std::max(1, a.xcd_mode);

@@ -931,6 +931,139 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
     while (qcount > 0) drain(min(qcount, 64));
 }
 
+// ---- exact tests of the entries the pair kernel's broad phase flagged ---------------------------------------------------
+// The half build's drain tests every hit's segment box against the obstacles that survive its tile's cull (symmetric: once per
+// pair, kernels_rdisc_mfma.hip) and flags the records of a pair whose box meets one; k_order_logs lists the flagged entries --
+// (entry, column sample, row position) -- in column order, one segment of the item array per ordering workgroup.  Everything not
+// listed is free (the mask is preset to ones).  Here lane = listed entry: both states are gathered (the column's from the caller's
+// array: consecutive items share it; the row's from the cell-sorted copy), the obstacle set is culled against the r-balls of the
+// (few) distinct columns of the 64 items, the broad phase runs once more to find WHICH boxes (2 D v_cmpx each, per-lane packed list
+// of up to four), and the slab tests run in place -- nearly every lane has one to run.  is_free_motion(V[row], V[col], CC, SS)
+// with every sample inside the state space (statespaces.jl:153-158, boxesND.jl:26,44-56).
+template <int D>
+__global__ __launch_bounds__(256) void k_sweep_pending(const uint4* __restrict__ items, const int32_t* __restrict__ cnt, int64_t wcap,
+                                                       const int32_t* __restrict__ pend_over, const double* __restrict__ X,
+                                                       const double* __restrict__ Xs, double rpad, const double* __restrict__ boxes, int M,
+                                                       unsigned long long* __restrict__ mask, const int64_t* __restrict__ nnz_dev,
+                                                       const int32_t* __restrict__ spec_fail)
+{
+    if (spec_fail && *spec_fail) return;
+    if (*pend_over) return;                                   // the list is incomplete: the host sweeps the whole graph instead
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sboxT = (double*)smem;                            // [2*D][SWEEP_CHUNK]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {      // padding bits of the last word are zero
+        const int64_t nnz = *nnz_dev;
+        if (nnz & 63) atomicAnd(&mask[nnz >> 6], (1ull << (nnz & 63)) - 1ull);
+    }
+    for (int t = threadIdx.x; t < M * 2 * D; t += blockDim.x) {
+        const int k = t / (2 * D), i = t - k * 2 * D;
+        sboxT[i * SWEEP_CHUNK + k] = boxes[t];
+    }
+    __syncthreads();
+    const int n = cnt[blockIdx.x];
+    const uint4* __restrict__ seg = items + (int64_t)blockIdx.x * wcap;
+    const int wstride = (int)gridDim.y * 4;
+    for (int b0 = ((int)blockIdx.y * 4 + wave) * 64; b0 < n; b0 += wstride * 64) {
+        const int idx = b0 + lane;
+        const bool active = idx < n;
+        const uint4 it = seg[min(idx, n - 1)];
+        const int64_t e = (int64_t)(((uint64_t)it.y << 32) | (uint64_t)it.x);
+        const int x = (int)it.z;
+        double v[D], w[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) w[i] = X[(int64_t)x * D + i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) v[i] = Xs[(int64_t)it.w * D + i];
+        // obstacles within reach of the columns of these 64 items (lane = box), column by column
+        unsigned long long smask[SWEEP_WORDS];
+#pragma unroll
+        for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] = 0;
+        unsigned long long rem = __ballot(active);
+        while (rem) {
+            const int L = __builtin_ctzll(rem);
+            const int xq = __builtin_amdgcn_readlane(x, L);
+            const sweep_cptr xp = as_const(X) + (int64_t)xq * D;
+            double ulo[D], uhi[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { const double wi = xp[i]; ulo[i] = wi - rpad; uhi[i] = wi + rpad; }
+#pragma unroll
+            for (int c = 0; c < SWEEP_WORDS; ++c) {
+                if (c * 64 < M) {
+                    const int kb = c * 64 + lane;
+                    const box_regs<D> bx = load_box_T<D>(sboxT, kb);
+                    int out = 0;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) out |= (int)(bx.hi[i] < ulo[i]) | (int)(bx.lo[i] > uhi[i]);
+                    smask[c] |= __ballot(kb < M && !out);
+                }
+            }
+            rem &= ~__ballot(active && x == xq);
+        }
+        double l[D], h[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            asm("v_min_f64 %0, %1, %2" : "=v"(l[i]) : "v"(w[i]), "v"(v[i]));
+            asm("v_max_f64 %0, %1, %2" : "=v"(h[i]) : "v"(w[i]), "v"(v[i]));
+        }
+        unsigned pk = 0, pc = 0;
+        bool fr = active;
+        if constexpr (D <= 6) {
+            l[0] = active ? l[0] : (double)INFINITY;
+#pragma unroll
+            for (int c = 0; c < SWEEP_WORDS; ++c) {
+                unsigned long long mb = smask[c];
+                while (mb) {
+                    const int kb = c * 64 + (__ffsll((long long)mb) - 1);
+                    mb &= mb - 1;
+                    box_regs<D> bx;
+                    const sweep_cptr bp = as_const(boxes) + (int64_t)kb * 2 * D;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) { bx.lo[i] = bp[i]; bx.hi[i] = bp[D + i]; }
+                    sweep_cmpx<D>::note(bx.lo, bx.hi, l, h, pk, pc, kb);
+                }
+            }
+            // the slab tests of the listed boxes, most recent first; a lane with more than four takes every surviving box below
+#pragma unroll 1
+            for (int sl = 0; sl < 4; ++sl) {
+                const bool go = fr && pc > (unsigned)sl && pc <= 4u;
+                if (!__ballot(go)) continue;
+                const box_regs<D> bx = load_box_T<D>(sboxT, (int)((pk >> (8 * sl)) & 255u));
+                const bool f = narrow_free_sl<D>(v, w, bx);
+                if (go) fr = f;
+            }
+        } else {
+            pc = 5;
+        }
+        if (__ballot(fr && pc > 4u)) {
+            const bool o = pc > 4u;
+#pragma unroll
+            for (int c = 0; c < SWEEP_WORDS; ++c) {
+                unsigned long long mb = smask[c];
+                while (mb) {
+                    const int kb = c * 64 + (__ffsll((long long)mb) - 1);
+                    mb &= mb - 1;
+                    const box_regs<D> bx = load_box_T<D>(sboxT, kb);
+                    if (o && fr && !broadphase_free_sl<D>(l, h, bx)) fr = narrow_free_sl<D>(v, w, bx);
+                }
+            }
+        }
+        if (active && !fr) atomicAnd(&mask[e >> 6], ~(1ull << (e & 63)));
+    }
+}
+
+template <int D>
+static int32_t launch_sweep_pending_d(mpfmt_ctx* ctx, double rpad, const int32_t* spec_fail)
+{
+    const size_t lds = (size_t)SWEEP_CHUNK * 2 * D * sizeof(double);
+    hipLaunchKernelGGL((k_sweep_pending<D>), dim3((unsigned)ctx->pend_nseg, 8), dim3(256), lds, ctx->stream, (const uint4*)ctx->pend_items,
+                       (const int32_t*)ctx->pend_cnt, ctx->pend_wcap, (const int32_t*)ctx->pend_over, ctx->Xo, ctx->Xs, rpad, ctx->boxes, ctx->M,
+                       (unsigned long long*)ctx->graph_free, ctx->colptr + ctx->N, spec_fail);
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
 // ---- launchers -------------------------------------------------------------------------------------
 static int box_chunk(int M, int D, bool culled)
 {
@@ -1273,6 +1406,21 @@ int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail, int64
     mpfmt_timed tm7(ctx);
     // preset to ones (the sweep clears blocked entries); an empty graph keeps one zero word
     HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, ctx->nnz > 0 ? 0xFF : 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
+    if (ctx->nnz > 0 && ctx->pend_valid && ctx->d <= 6 && ctx->M <= SWEEP_CHUNK) {
+        // the step's pair kernel has done the broad phase and the ordering pass has listed what it flagged: only those entries
+        // are visited.  (Should a segment of the list have overflowed, the kernel returns at once and the caller -- who reads the
+        // flag behind its next synchronisation -- sweeps the whole graph.)
+        const double rpad = ctx->graph_r * (1.0 + 1e-9) + 1e-300;
+        mpfmt_timed tk(ctx);
+        DISPATCH_D(ctx->d, rc = launch_sweep_pending_d<(DD <= 6 ? DD : 6)>(ctx, rpad, spec_fail));
+        tk.end("sweep_kernel");
+        if (rc) return rc;
+        tm7.end("sweep_graph");
+        ctx->graph_swept = true;
+        ctx->sweep_pending_used = true;
+        return MPFMT_OK;
+    }
+    ctx->sweep_pending_used = false;
     if (ctx->nnz > 0) {
         const int d = ctx->d;
         const int waves = SWEEP_GT(d) / 64;

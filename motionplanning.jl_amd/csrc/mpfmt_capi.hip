@@ -194,7 +194,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
-                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->pool, ctx->log_len, ctx->fpool, ctx->flen, ctx->fcol, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev};
+                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->pool, ctx->log_len, ctx->fpool, ctx->flen, ctx->fcol, ctx->pend_items, ctx->pend_cnt, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev};
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
     mpfmt_comm_destroy(ctx);
     mpfmt_wf_free(ctx);
@@ -269,7 +269,7 @@ int32_t mpfmt_set_state_bounds(mpfmt_ctx* ctx, const double* ss_lo, const double
     ctx->ss.d = ss_lo ? d_state : 0;
     for (int i = 0; i < MPFMT_MAX_DIM; ++i) { ctx->ss.lo[i] = -INFINITY; ctx->ss.hi[i] = INFINITY; }
     if (ss_lo) for (int i = 0; i < d_state; ++i) { ctx->ss.lo[i] = ss_lo[i]; ctx->ss.hi[i] = ss_hi[i]; }
-    ctx->graph_swept = false; ctx->di_swept = false;
+    ctx->graph_swept = false; ctx->di_swept = false; ctx->pend_valid = false;     // (a pending list belongs to the obstacle set it was made against)
     return MPFMT_OK;
 }
 
@@ -292,7 +292,7 @@ int32_t mpfmt_upload_boxes(mpfmt_ctx* ctx, const double* lohi, int32_t M, int32_
     ctx->ss.d = ss_lo ? d_state : 0;
     for (int i = 0; i < MPFMT_MAX_DIM; ++i) { ctx->ss.lo[i] = -INFINITY; ctx->ss.hi[i] = INFINITY; }
     if (ss_lo) for (int i = 0; i < d_state; ++i) { ctx->ss.lo[i] = ss_lo[i]; ctx->ss.hi[i] = ss_hi[i]; }
-    ctx->graph_swept = false;
+    ctx->graph_swept = false; ctx->pend_valid = false;
     ctx->di_swept = false;
     return MPFMT_OK;
 }
@@ -436,7 +436,7 @@ int32_t mpfmt_graph_import(mpfmt_ctx* ctx, double r, const int64_t* colptr, cons
     ctx->nnz = nnz;
     ctx->graph_r = r;
     ctx->graph_counted = ctx->graph_filled = true;
-    ctx->graph_swept = false;
+    ctx->graph_swept = false; ctx->pend_valid = false;
     ctx->pool_valid = false;
     ctx->rowpos_valid = false;
     ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
@@ -1361,6 +1361,11 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "rdisc_pool") == 0) { ctx->use_pool = value != 0; return MPFMT_OK; }
     if (strcmp(name, "fuse_sweep") == 0) { ctx->fuse_sweep = value != 0; return MPFMT_OK; }
     if (strcmp(name, "wf_graphs") == 0) { ctx->wf_graphs = value != 0; return MPFMT_OK; }
+    if (strcmp(name, "fuse_broad") == 0) {
+        ctx->fuse_broad = value != 0;
+        ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false; ctx->spec_ready = false;
+        return MPFMT_OK;
+    }
     if (strcmp(name, "rdisc_half") == 0) {
         ctx->use_half = value != 0; ctx->half_off = false; ctx->half_fail = 0;
         ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false; ctx->spec_ready = false; ctx->lists_r = -1.0;

@@ -134,6 +134,17 @@ struct mpfmt_ctx {
     // half build of the single-pass r-disc graph (kernels_rdisc_mfma.hip: every pair found once, the other column's record goes
     // to a foreign log of that column's tile)
     int use_half = 1;                    // option rdisc_half
+    int fuse_broad = 1;                  // option: broad phase of the edge tests in the half build's drain (step APIs only)
+    void* pend_items = nullptr;          // [segments][pend_wcap] (entry, column sample, row position) of the entries that need an exact test
+    int64_t pend_wcap = 0;
+    int32_t* pend_cnt = nullptr;         // [segments] items per segment, then the overflow flag
+    int32_t* pend_over = nullptr;
+    int pend_nseg = 0;
+    bool sweep_pending_used = false;     // the last graph sweep visited the pending list only
+    bool pend_overflowed = false;        // read back behind the speculative step's synchronisation
+    bool pend_valid = false;             // the resident graph has its pending list (made by this step's ordering pass)
+    bool want_broad = false;             // set by the step APIs around their count
+    bool broad_in_drain = false;         // this count's records carry the broad-phase flag (bit 30 of the row index)
     bool half_used = false;              // the counted graph was built that way
     int half_fail = 0;                   // half builds that had to be redone whole (2: no more tries)
     bool half_off = false;               // a half build overflowed / met a column too long for the ordering kernel: whole builds from now on
