@@ -63,7 +63,7 @@ struct ord_shared {
     ord_hdr<DX> h[2];            // headers of the quarter in work and of the next one (prefetched)
     int32_t g1, pcount, pad_[2];     // pcount: pending-entry items this workgroup has appended
     unsigned long long cm[SWEEP ? ORD_COLS : 1][ORD_MAXM / 64];     // obstacles that survive each column's cull
-    uint32_t bits[SWEEP ? ORD_STG / 32 : 1];                         // free bit of every staged entry, by rank position
+    uint32_t bits[ORD_STG / 32];                                     // free bit of every staged entry, by rank position (fused sweep; blocked bits out of the records)
     uint32_t qa[SWEEP ? ORD_WAVES : 1][SWEEP ? ORD_QCAP : 1];        // pending exact tests: rank position | box << 12 | column << 20
     uint32_t qb[SWEEP ? ORD_WAVES : 1][SWEEP ? ORD_QCAP : 1];        //                      cell-sorted position of the row
 };
@@ -104,8 +104,10 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
                                                             uint32_t bucket_mul, const int32_t* __restrict__ spec_fail, ord_sweep sw,
                                                             const mpfmt_hit* __restrict__ flogs, int64_t fcapL, const int32_t* __restrict__ flen,
                                                             uint4* __restrict__ pend_items, int64_t pend_wcap, int32_t* __restrict__ pend_cnt,
-                                                            int32_t* __restrict__ pend_over)
+                                                            int32_t* __restrict__ pend_over, int rec_bits)
 {
+    // rec_bits: k_exact_pairs has marked the records of blocked edges (bit 31 of the row index); their entries' bits are cleared in
+    // the mask (sw.mask, preset to ones) the way the fused sweep's are: an LDS bitmap by rank position, copied to CSC positions
     if (spec_fail && *spec_fail) return;                     // speculative step whose capacities did not hold: redone by the host
     // half build (flogs != nullptr): every pair was found once, by the tile of its lower cell-sorted end, which also wrote the
     // record of the OTHER column into that column's tile's FOREIGN log (one per quarter tile, appended to by many tiles; its
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
     const int64_t nq = (tile_end - tile_begin) * 4;
     // bucket_mul = floor(2^32 * 128 / N) (0: N <= 128, the id is its own bucket)
     auto bucket = [&](uint32_t id) -> int { return bucket_mul ? min(ORD_NB - 1, (int)__umulhi(id, bucket_mul)) : (int)(id & (ORD_NB - 1)); };
-    if (SWEEP && blockIdx.x == 0 && tid == 0) {              // padding bits of the mask's last word are zero
+    if ((SWEEP || rec_bits) && blockIdx.x == 0 && tid == 0) {              // padding bits of the mask's last word are zero
         const int64_t nnz = *sw.nnz_dev;
         if (nnz & 63) atomicAnd(&sw.mask[nnz >> 6], (1ull << (nnz & 63)) - 1ull);
     }
@@ -306,6 +308,8 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
                     }
                 }
                 if (tid < ORD_STG / 32) sh.bits[tid] = 0xffffffffu;
+            } else {
+                if (rec_bits && tid < ORD_STG / 32) sh.bits[tid] = 0xffffffffu;
             }
             lds_barrier();
             if (first) {
@@ -389,6 +393,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
                         nzval[o] = sqrt(__hiloint2double((int)r.w, (int)r.z));      // the log carries d2
                         if (rowpos) rowpos[o] = (int32_t)(r.y & 0x3ffffffu);
                     }
+                    if constexpr (!SWEEP) { if (rec_bits && valid && (r.x >> 31)) atomicAnd(&sh.bits[rk >> 5], ~(1u << (rk & 31))); }
                     if (pend_items) {
                         const bool pd = valid && ((r.x >> 30) & 1u);
                         const unsigned long long pm = __ballot(pd);
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
                 if constexpr (SWEEP) { while (qcount > 0) drain(min(qcount, 64)); }
             }
             lds_barrier();
-            if constexpr (SWEEP) {
+            if (SWEEP || rec_bits) {
                 // ---- the free bits of the range's columns, from rank positions to CSC positions (wavefront w: columns 2 w, 2 w + 1) ----
                 if (!skip) for (int c = g0 + 2 * wave; c < min(g1, g0 + 2 * wave + 2); ++c) {
                     const int k = H.k[c];
@@ -549,11 +554,12 @@ static int32_t launch_order(mpfmt_ctx* ctx, const int32_t* spec_fail, const ord_
     const unsigned nb = (unsigned)std::min<int64_t>(nt * 4, (int64_t)ctx->num_cus * per_cu);
     // records flagged by the pair kernel's broad phase (step APIs, half build): their entries are listed for k_sweep_pending, one
     // segment of the item array per workgroup.  Workgroups take every nb-th quarter tile, so their shares are even: 1.5x the mean + 4096
-    const bool pend = !SWEEP && ctx->broad_in_drain;
+    const bool recbits = !SWEEP && ctx->bits_in_records;      // form 2: the blocked edges are marked in the records, nothing to list
+    const bool pend = !SWEEP && ctx->broad_in_drain && !recbits;
     if (pend) {
         int32_t rc;
         const int64_t entries = std::max<int64_t>(ctx->nnz, ctx->nnz_cap);
-        ctx->pend_wcap = entries * 3 / (2 * (int64_t)nb) + 4096;
+        ctx->pend_wcap = ctx->debug_small_lists ? 8 : entries * 3 / (2 * (int64_t)nb) + 4096;
         if ((rc = mpfmt_ensure(ctx, (void**)&ctx->pend_items, sizeof(uint4) * (size_t)ctx->pend_wcap * nb))) return rc;
         if ((rc = mpfmt_ensure(ctx, (void**)&ctx->pend_cnt, sizeof(int32_t) * (size_t)(nb + 1)))) return rc;
         ctx->pend_over = ctx->pend_cnt + nb;
@@ -561,10 +567,10 @@ static int32_t launch_order(mpfmt_ctx* ctx, const int32_t* spec_fail, const ord_
     }
     hipLaunchKernelGGL(kk, dim3(nb), dim3(ORD_THREADS), lds, ctx->stream, ctx->pool, ctx->pool_cap, ctx->S,
                        ctx->slice_cnt, ctx->ntiles * 64, ctx->log_len, ctx->tile_begin, ctx->tile_end, ctx->colptr, ctx->perm,
-                       ctx->rowval, ctx->nzval, (!SWEEP && ctx->sweep_sorted && !pend) ? ctx->rowpos : nullptr,      // (the pending list carries its own row positions)
+                       ctx->rowval, ctx->nzval, (!SWEEP && ctx->sweep_sorted && !pend && !recbits) ? ctx->rowpos : nullptr,      // (the pending list carries its own row positions)
                        ctx->N > 128 ? (uint32_t)((128ull << 32) / (uint64_t)ctx->N) : 0u, spec_fail, sw,
                        ctx->half_used ? ctx->fpool : nullptr, ctx->fcap, ctx->flen,
-                       pend ? (uint4*)ctx->pend_items : nullptr, ctx->pend_wcap, ctx->pend_cnt, ctx->pend_over);
+                       pend ? (uint4*)ctx->pend_items : nullptr, ctx->pend_wcap, ctx->pend_cnt, ctx->pend_over, recbits ? 1 : 0);
     if (pend) ctx->pend_nseg = (int)nb;
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
@@ -595,13 +601,22 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail, bool fuse, in
         sw.mask = (unsigned long long*)ctx->graph_free; sw.nnz_dev = ctx->colptr + ctx->N;
     }
     ctx->rowpos_valid = false;
-    if (ctx->nnz == 0 || nt <= 0) { if (fuse) ctx->graph_swept = true; return MPFMT_OK; }
+    const bool recbits = !fuse && ctx->bits_in_records;
+    if (recbits) {
+        // the records carry the blocked bits (k_exact_pairs): this pass also writes the mask
+        const int64_t words = (std::max<int64_t>(ctx->nnz, mask_entries) + 63) / 64;
+        if ((rc = mpfmt_ensure(ctx, (void**)&ctx->graph_free, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1)))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, ctx->nnz > 0 ? 0xFF : 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
+        sw.mask = (unsigned long long*)ctx->graph_free; sw.nnz_dev = ctx->colptr + ctx->N;
+    }
+    if (ctx->nnz == 0 || nt <= 0) { if (fuse || recbits) ctx->graph_swept = true; return MPFMT_OK; }
     if (!fuse) {
         // option sweep_sorted: also keep every row's cell-sorted position, so the sweep can gather from Xs (see kernels_sweep.hip)
         if (ctx->sweep_sorted && (rc = mpfmt_ensure(ctx, (void**)&ctx->rowpos, sizeof(int32_t) * (size_t)std::max<int64_t>(std::max(ctx->nnz, ctx->nnz_cap), 1)))) return rc;
         if ((rc = launch_order<1, false>(ctx, spec_fail, sw))) return rc;
-        ctx->pend_valid = ctx->broad_in_drain;        // ... or the flagged entries have been listed for k_sweep_pending
-        ctx->rowpos_valid = ctx->sweep_sorted != 0 && !ctx->pend_valid;   // every entry's row is also known by its cell-sorted position (the sweep gathers from Xs)
+        ctx->pend_valid = ctx->broad_in_drain && !recbits;        // ... or the flagged entries have been listed for k_sweep_pending
+        ctx->rowpos_valid = ctx->sweep_sorted != 0 && !ctx->pend_valid && !recbits;   // every entry's row is also known by its cell-sorted position (the sweep gathers from Xs)
+        if (recbits) { ctx->graph_swept = true; ctx->sweep_in_order = true; }
         return MPFMT_OK;
     }
     switch (ctx->d) {

@@ -771,6 +771,20 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     }
     ctx->half_used = half;
     ctx->broad_in_drain = half && ctx->want_broad;
+    ctx->bits_in_records = false; ctx->sweep_in_order = false;
+    if (ctx->broad_in_drain && ctx->fuse_broad == 2) {
+        // form 2: the pairs flagged by the drain's broad phase are listed for k_exact_pairs in 1024 dense regions (an item appends to
+        // region item mod 1024 with one reservation per drain); room for three quarters of all pairs being flagged -- beyond that the
+        // flag is raised and the host sweeps the whole graph
+        const int64_t items = nt * S;
+        const double pairs_est = 0.5 * (double)ctx->pool_cap * 4.0 * (double)items / 2.3;        // (the logs' capacity is 2.3x the expected hits)
+        ctx->pair_icap = ctx->debug_small_lists ? 8 : (int64_t)(0.75 * pairs_est / 1024.0) + 4096;      // (option debug_small_lists: the overflow path, for the tests)
+        if ((rc = ensure(ctx, (void**)&ctx->pair_items, 32 * (size_t)ctx->pair_icap * 1024))) return rc;
+        if ((rc = ensure(ctx, (void**)&ctx->pair_cnt, sizeof(int32_t) * (1024 + 1)))) return rc;
+        ctx->pair_over = ctx->pair_cnt + 1024;
+        HIPCHK(ctx, hipMemsetAsync(ctx->pair_cnt, 0, sizeof(int32_t) * (1024 + 1), ctx->stream));
+        ctx->bits_in_records = true;
+    }
     ctx->pool_valid = false;
     ctx->rowpos_valid = false;
     ctx->pend_valid = false;
@@ -778,7 +792,10 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     if (nt > 0) {
         if (mf) {
             mpfmt_timed tk(ctx);                                   // the pair kernel on its own, inside the "rdisc_count" interval
-            if (pool) { if ((rc = mpfmt_launch_rdisc_mfma<2>(ctx, r, negT))) return rc; }
+            if (pool) {
+                if ((rc = mpfmt_launch_rdisc_mfma<2>(ctx, r, negT))) return rc;
+                if (ctx->bits_in_records && (rc = mpfmt_launch_exact_pairs(ctx, nullptr))) return rc;
+            }
             else if ((rc = mpfmt_launch_rdisc_mfma<0>(ctx, r, negT))) return rc;
             tk.end("pair_kernel");
         } else {
@@ -815,7 +832,7 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     if (!ctx->rb_host) HIPCHK(ctx, hipHostMalloc(&ctx->rb_host, sizeof(count_readback), hipHostMallocDefault));
     hipLaunchKernelGGL(k_count_readback, dim3(1), dim3(512), 0, ctx->stream, ctx->d_pairs, ctx->colptr + N, pool ? ctx->pool_flag : nullptr,
                        (ctx->spec_lists && nt > 0) ? ctx->list_len + nt : nullptr, (const int32_t*)(ctx->d_pairs + 512), (count_readback*)ctx->rb_dev,
-                       (ctx->pend_valid && ctx->sweep_pending_used) ? (const int32_t*)ctx->pend_over : nullptr);
+                       ctx->sweep_in_order ? (const int32_t*)ctx->pair_over : (ctx->pend_valid && ctx->sweep_pending_used) ? (const int32_t*)ctx->pend_over : nullptr);
     HIPCHK(ctx, hipMemcpyAsync(ctx->rb_host, ctx->rb_dev, sizeof(count_readback), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const count_readback* rb = (const count_readback*)ctx->rb_host;
@@ -919,6 +936,14 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r, bool fuse_sweep)
 static int32_t sweep_checked(mpfmt_ctx* ctx)
 {
     int32_t rc;
+    if (ctx->graph_swept && ctx->sweep_in_order) {            // form 2: the ordering pass wrote the mask out of the records' bits
+        int32_t over = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&over, ctx->pair_over, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!over) return MPFMT_OK;
+        ctx->sweep_in_order = false; ctx->graph_swept = false;
+        return mpfmt_launch_graph_sweep(ctx);
+    }
     if (ctx->graph_swept) return MPFMT_OK;
     if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
     if (!ctx->sweep_pending_used) return MPFMT_OK;
@@ -974,10 +999,12 @@ int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r)
             ctx->graph_r = r; ctx->graph_counted = true;
             mpfmt_timed tm7(ctx);
             const bool fuse = mpfmt_order_can_fuse(ctx);
+            ctx->graph_swept = false;
             if ((rc = mpfmt_order_logs(ctx, ctx->spec_fail, fuse, cap))) return rc;
             tm7.end(fuse ? "order_sweep" : "rdisc_sort");
             ctx->graph_filled = true;
-            if (!fuse && (rc = mpfmt_launch_graph_sweep(ctx, ctx->spec_fail, cap))) return rc;
+            // (form 2 of the fused edge tests: the ordering pass has written the mask already)
+            if (!fuse && !ctx->graph_swept && (rc = mpfmt_launch_graph_sweep(ctx, ctx->spec_fail, cap))) return rc;
             ctx->step_state = 1;                                    // speculative kernels in flight
             return MPFMT_OK;
         }
@@ -1015,8 +1042,8 @@ static int32_t step_finish_inner(mpfmt_ctx* ctx)
         if ((rc = mpfmt_rdisc_count_finish(ctx, r, &failed))) return rc;
         if (!failed && ctx->nnz < ctx->nnz_cap && ctx->pool_valid) {
             ctx->graph_filled = true; ctx->graph_swept = true;      // (finish resets the flags it owns)
-            if (ctx->pend_overflowed) {                             // the pending-entry list was cut short: sweep the whole graph
-                ctx->pend_valid = false; ctx->graph_swept = false;
+            if (ctx->pend_overflowed) {                             // the pending-entry / pending-pair list was cut short: sweep the whole graph
+                ctx->pend_valid = false; ctx->sweep_in_order = false; ctx->graph_swept = false;
                 return mpfmt_launch_graph_sweep(ctx);
             }
             return MPFMT_OK;

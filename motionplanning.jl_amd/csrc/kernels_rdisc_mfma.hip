@@ -87,6 +87,12 @@ struct mf_args {
     int32_t fb;
     int32_t M;
     const double* boxes;            // [M][2][D]
+    // fb == 2: the pairs whose segment box met an obstacle's are listed (MF_NREG regions of icap 32-byte items) for
+    // k_exact_pairs, which runs the slab tests in both directions and sets bit 31 of the blocked records' row index
+    uint4* pitems;
+    int32_t* pcnt;                  // [MF_NREG] items in each region (zeroed per build; may exceed icap: the reader clamps)
+    long long icap;
+    int32_t* pend_over;
 };
 
 __device__ __forceinline__ int cell_of_m(double x, double lo, double inv_w, int g)
@@ -380,6 +386,7 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
 //   refine   : 64 survivors at a time (lane = survivor): canonical fp64 d2, membership test, and in the single-pass mode
 //              the hits of the batch are appended -- ballot-compacted, one contiguous 16 B/lane store -- to the item's LOG
 //              (full lines; k_order_logs regroups a tile's logs by column through LDS and writes the ordered CSC)
+#define MF_NREG 1024                // regions of the pending-pair list (fb == 2)
 #define MF_RCAP 128                 // record queue entries per wavefront (expanded 64 at a time)
 #define MF_QSZ 320                  // survivor queue entries per wavefront (drained 64 at a time)
 #ifndef MF_ABLATE                   // timing experiments only (results invalid): 1 skip extraction, 2 skip refine, 4 skip MFMA
@@ -398,8 +405,6 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     __shared__ int32_t s_cnt[64];
     __shared__ int32_t s_lc[4];                           // records in the item's four logs
     __shared__ int64_t s_base[MODE == 1 ? 64 : 1];
-    __shared__ uint4 s_pend[MODE == 2 ? 64 : 1];          // half build: the foreign records of the last drain, stored by the next one
-    __shared__ int32_t s_pfq[MODE == 2 ? 64 : 1];         //             ... and the foreign log each belongs to
 
     const int lane = threadIdx.x;
     const int64_t nblk = gridDim.x;
@@ -521,31 +526,10 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     int rcount = 0;                                           // wave-uniform record queue length
     int pool_over = 0;
     mpfmt_hit* const __restrict__ mylog = (MODE == 2) ? a.pool + (long long)item * 4 * a.pool_cap : nullptr;
-    // half build: the places a drain reserves in the foreign logs come back from the L2 a microsecond or two later; its records
-    // wait in LDS and are stored by the NEXT drain (or at the end of the item), so nobody waits for that round trip
-    int pend_base = 0;                                        // what the reserving atomic returned (lanes that led a log's group)
-    int pend_meta = 0;                                        // bit 31: this lane has a record pending; bits 0..5 leader lane, 6..12 place in the group
-    auto flush_pending = [&]() {
-        if (__ballot(pend_meta < 0) == 0) return;
-        const int base = __shfl(pend_base, pend_meta & 63);
-        if (pend_meta < 0) {
-            const int fp = base + ((pend_meta >> 6) & 127);
-            const int fq = s_pfq[lane];
-            if (fp < a.fcap) {
-                const uint4 rec = s_pend[lane];
-                *reinterpret_cast<uint4*>(&a.fpool[(long long)fq * a.fcap + fp]) = rec;
-                a.fcol[(long long)fq * a.fcap + fp] = (uint8_t)((rec.y >> 26) & 15u);
-            } else {
-                pool_over = 1;
-            }
-        }
-        pend_meta = 0;
-    };
     auto drain = [&](int n) {
         // takes the LAST n queue entries (order is irrelevant: columns are sorted afterwards), so nothing moves
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (MODE == 2 && a.half) flush_pending();
         const int first = qcount - n;
         qcount = __builtin_amdgcn_readfirstlane(first);
         if (MF_ABLATE & 2) return;
@@ -593,6 +577,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         // broad phase of is_free_motion for the hits of this drain (boxesND.jl:44-45, symmetric in the two end points, so one test
         // serves both records of a pair): the boxes that survived the tile's cull, each through the scalar cache, 2 D v_cmpx in a row
         uint32_t pendflag = 0;
+        [[maybe_unused]] unsigned pk_keep = 0, pc_keep = 0;
         if constexpr (MODE == 2 && D <= 6) {
             if (a.fb) {
                 unsigned pk = 0, pc = 0;
@@ -611,8 +596,11 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                     }
                 }
                 pendflag = pc ? (1u << 30) : 0u;
+                pk_keep = pk; pc_keep = pc;
             }
         }
+        [[maybe_unused]] long long own_idx = -1, for_idx = -1;      // where the two records of this lane's pair went (pending-pair items)
+        [[maybe_unused]] uint32_t own_j = 0, for_j = 0;
         if (MODE == 2 && hit) {
             // single pass: the hit goes to one of the item's FOUR logs, one per 16 columns of its tile, so that k_order_logs can
             // regroup a quarter tile (about 1 700 hits) in one pass through LDS.  Its place is a returning LDS atomic on the log's
@@ -624,10 +612,26 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             const int p = atomicAdd(&s_lc[g], 1);
             if (p < a.pool_cap) {
                 mpfmt_hit h;
-                h.j = (int32_t)((uint32_t)a.perm[jg] | pendflag); h.pad = (int32_t)(jg | (ql << 26)); h.d = d2;
+                own_j = (uint32_t)a.perm[jg] | pendflag;
+                h.j = (int32_t)own_j; h.pad = (int32_t)(jg | (ql << 26)); h.d = d2;
+                own_idx = ((long long)item * 4 + g) * a.pool_cap + p;
                 *reinterpret_cast<uint4*>(&mylog[(long long)g * a.pool_cap + p]) = *reinterpret_cast<const uint4*>(&h);   // one 16-byte store
             } else {
                 pool_over = 1;
+            }
+        }
+        // fb == 2: the pairs whose box met an obstacle's are listed for k_exact_pairs in one of MF_NREG dense regions (this item's:
+        // item mod MF_NREG) -- one reservation per drain on the region's counter, requested here, used after the foreign records
+        // below are out (per-item segments sized for the worst case left the list scattered over 9 GB in 6 KB pieces: the kernel that
+        // reads it spent 1.3 ms on address translation alone)
+        [[maybe_unused]] int ibase = 0;
+        [[maybe_unused]] unsigned long long ipm = 0;
+        [[maybe_unused]] bool iem = false;
+        if constexpr (MODE == 2 && D <= 6) {
+            if (a.fb == 2) {
+                iem = hit && pendflag != 0 && own_idx >= 0;
+                ipm = __ballot(iem);
+                if (ipm && lane == 0) ibase = atomicAdd(&a.pcnt[item & (MF_NREG - 1)], (int)__popcll(ipm));
             }
         }
         if (MODE == 2 && a.half) {
@@ -650,14 +654,45 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                 if (lane == L) cnt_l = (int)__popcll(mm);
                 rem &= ~mm;
             }
-            if (fh) {
-                const uint32_t qs = (uint32_t)(tile * 64) + ql;
-                mpfmt_hit h;
-                h.j = (int32_t)((uint32_t)a.perm[qs] | pendflag); h.pad = (int32_t)(qs | ((jg & 63u) << 26)); h.d = d2;
-                s_pend[lane] = *reinterpret_cast<const uint4*>(&h);
-                s_pfq[lane] = fq;
-                if (lane == leader) pend_base = atomicAdd(&a.flen[fq], cnt_l);
-                pend_meta = (int)(0x80000000u | (uint32_t)leader | ((uint32_t)pre << 6));
+            if (__ballot(fh)) {
+                // (storing these from the NEXT drain, so that nobody waits for the reservation's round trip, was measured: 1.305 ->
+                // 1.29 ms; not worth the LDS and the second code path)
+                int base = 0;
+                if (fh && lane == leader) base = atomicAdd(&a.flen[fq], cnt_l);
+                base = __shfl(base, leader);
+                const int fp = base + pre;
+                if (fh) {
+                    if (fp < a.fcap) {
+                        const uint32_t qs = (uint32_t)(tile * 64) + ql;
+                        mpfmt_hit h;
+                        for_j = (uint32_t)a.perm[qs] | pendflag;
+                        h.j = (int32_t)for_j; h.pad = (int32_t)(qs | ((jg & 63u) << 26)); h.d = d2;
+                        for_idx = (long long)fq * a.fcap + fp;
+                        *reinterpret_cast<uint4*>(&a.fpool[for_idx]) = *reinterpret_cast<const uint4*>(&h);
+                        a.fcol[for_idx] = (uint8_t)(jg & 15u);
+                    } else {
+                        pool_over = 1;
+                    }
+                }
+            }
+        }
+        if constexpr (MODE == 2 && D <= 6) {
+            if (a.fb == 2 && ipm) {
+                // pending-pair items: where the pair's record(s) are, their first words, both cell-sorted positions and the boxes its
+                // segment box met (the last four as bytes; 7 = more than four: every box is tried)
+                const int base = __builtin_amdgcn_readfirstlane(ibase);
+                const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ipm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ipm, 0u));
+                if (iem) {
+                    if (pos < a.icap) {
+                        uint4* const dst = a.pitems + ((long long)(item & (MF_NREG - 1)) * a.icap + pos) * 2;
+                        const uint32_t fhi = for_idx >= 0 ? (uint32_t)((unsigned long long)for_idx >> 32) & 0xffu : 0xffu;
+                        dst[0] = make_uint4((uint32_t)(unsigned long long)own_idx, (uint32_t)(unsigned long long)for_idx,
+                                            ((uint32_t)((unsigned long long)own_idx >> 32) & 0xffu) | (fhi << 8) | ((pc_keep > 4u ? 7u : pc_keep) << 16), pk_keep);
+                        dst[1] = make_uint4((uint32_t)(tile * 64) + ql, jg, own_j, for_j);
+                    } else {
+                        *a.pend_over = 1;
+                    }
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -807,7 +842,6 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     }
     while (rcount > 0) expand();
     while (qcount > 0) drain(min(qcount, 64));
-    if (MODE == 2 && a.half) flush_pending();
 
     if (MODE == 2) {
         if (pool_over) *a.pool_flag = 1;                          // overflow: the build falls back to a fill pass
@@ -982,7 +1016,8 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.pool = ctx->pool; a.log_len = ctx->log_len;
     a.half = (MODE == 2 && ctx->half_used) ? 1 : 0;
     a.fpool = ctx->fpool; a.flen = ctx->flen; a.fcap = ctx->fcap; a.fcol = ctx->fcol;
-    a.fb = (a.half && ctx->broad_in_drain) ? 1 : 0; a.M = ctx->M; a.boxes = ctx->boxes;
+    a.fb = (a.half && ctx->broad_in_drain) ? (ctx->fuse_broad == 2 ? 2 : 1) : 0; a.M = ctx->M; a.boxes = ctx->boxes;
+    a.pitems = (uint4*)ctx->pair_items; a.pcnt = ctx->pair_cnt; a.icap = ctx->pair_icap; a.pend_over = ctx->pair_over;
     if (MODE != 2 && ctx->lists_half) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "two-pass r-disc kernels need whole chunk lists");
     if (a.nitems <= 0) return MPFMT_OK;
     const int64_t gran = NXCD * (int64_t)std::max(1, a.xcd_mode);

@@ -1053,6 +1053,136 @@ __global__ __launch_bounds__(256) void k_sweep_pending(const uint4* __restrict__
     }
 }
 
+// ---- exact tests of the PAIRS the pair kernel's broad phase flagged, before the logs are ordered ------------------------------------
+// Form 2 of the fused edge tests (option fuse_broad = 2).  The drain knows which obstacles a pair's segment box met; it lists the pair
+// with those box ids, the cell-sorted positions of its two ends and the places of its record(s) in the logs.  Here lane = pair: both
+// states are gathered from the cell-sorted copy, the slab test (boxesND.jl:46-51) runs for each listed box in BOTH directions -- it is
+// not symmetric bit for bit -- and a blocked direction sets bit 31 of its record's row index: (v = candidate -> w = query) is the
+// query's column's entry = the own record, (query -> candidate) the foreign one.  k_order_logs then clears the mask bits of the
+// entries whose record carries the bit.  No gather of rows by entry, no obstacle cull, no box loop.
+template <int D>
+__global__ __launch_bounds__(256, 4) void k_exact_pairs(const uint4* __restrict__ pitems, const int32_t* __restrict__ pcnt, long long icap, int64_t nitems,
+                                                     const int32_t* __restrict__ pend_over, const double* __restrict__ Xs,
+                                                     const double* __restrict__ boxes, int M, mpfmt_hit* __restrict__ pool,
+                                                     mpfmt_hit* __restrict__ fpool, const int32_t* __restrict__ spec_fail)
+{
+    if (spec_fail && *spec_fail) return;
+    if (*pend_over) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sboxT = (double*)smem;                            // [2*D][SWEEP_CHUNK]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int t = threadIdx.x; t < M * 2 * D; t += blockDim.x) {
+        const int k = t / (2 * D), i = t - k * 2 * D;
+        sboxT[i * SWEEP_CHUNK + k] = boxes[t];
+    }
+    __syncthreads();
+    {
+        // region blockIdx.x of the list, this workgroup's wavefronts taking every (4 gridDim.y)-th block of 64 pairs
+        const int64_t it = blockIdx.x;
+        const int n = (int)min((long long)pcnt[it], icap);
+        for (int b0 = ((int)blockIdx.y * 4 + wave) * 64; b0 < n; b0 += (int)gridDim.y * 4 * 64) {
+            // 64 pairs at a time (lane = pair); their (pair, box) work units -- one to four per pair -- are laid end to end and taken 64
+            // at a time (lane = unit), so that every lane of a slab test has one to run (a loop over "the k-th box of every pair" ran
+            // at a third of the lanes: 1.5 ms instead of 0.4)
+            const bool on = b0 + lane < n;
+            const uint4* __restrict__ src = pitems + (it * icap + min(b0 + lane, n - 1)) * 2;
+            const uint4 i0 = src[0], i1 = src[1];
+            const unsigned pc = on ? ((i0.z >> 16) & 7u) : 0u;
+            const int units = (pc <= 4u) ? (int)pc : 0;
+            int incl = units;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+            const int total = __shfl(incl, 63);
+            const int excl = incl - units;
+            // (the kernel is built for 4 wavefronts per SIMD -- __launch_bounds__(256, 4): left alone the compiler took 150-210 VGPRs for
+            // the slab test's six divisions and the kernel ran latency-bound at two wavefronts per SIMD, 1.6 ms; requesting the next
+            // units' states ahead of the tests cost 24 more registers and gained nothing)
+            struct unit_t { int p; int kb; bool act; };
+            auto request = [&](int t0, unit_t& u, double (&q)[D], double (&c)[D]) {
+                const int t = t0 + lane;
+                u.act = t < total;
+                int p = 0;                                    // the pair lane of unit t: the last lane whose first unit is <= t
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) { const int c2 = p + step; const int e2 = __shfl(excl, c2 & 63); if (c2 < 64 && e2 <= t) p = c2; }
+                u.p = p;
+                const int sl = t - __shfl(excl, p);
+                const uint32_t pk = (uint32_t)__shfl((int)i0.w, p);
+                u.kb = u.act ? (int)((pk >> (8 * (sl & 3))) & 255u) : 0;
+                const uint32_t qpos = (uint32_t)__shfl((int)i1.x, p), cpos = (uint32_t)__shfl((int)i1.y, p);
+#pragma unroll
+                for (int i = 0; i < D; ++i) q[i] = Xs[(int64_t)qpos * D + i];
+#pragma unroll
+                for (int i = 0; i < D; ++i) c[i] = Xs[(int64_t)cpos * D + i];
+            };
+            auto test = [&](const unit_t& u, double (&q)[D], double (&c)[D]) {
+                const box_regs<D> bx = load_box_T<D>(sboxT, u.kb);
+                bool fwd = true, rev = true;                  // own entry: is_free_motion(c, q); foreign entry: is_free_motion(q, c)
+#pragma unroll 1
+                for (int dir = 0; dir < 2; ++dir) {           // (one copy of the slab test: the ends change places between the passes)
+                    const bool f = narrow_free_sl<D>(c, q, bx);
+                    if (dir == 0) fwd = f; else rev = f;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) { const double tt = c[i]; c[i] = q[i]; q[i] = tt; }
+                }
+                const int p = u.p;
+                const uint32_t pz = (uint32_t)__shfl((int)i0.z, p);
+                const uint32_t olo = (uint32_t)__shfl((int)i0.x, p), flo = (uint32_t)__shfl((int)i0.y, p);
+                const uint32_t oj = (uint32_t)__shfl((int)i1.z, p), fj = (uint32_t)__shfl((int)i1.w, p);
+                if (u.act && !fwd) pool[(long long)(((unsigned long long)(pz & 0xffu) << 32) | olo)].j = (int32_t)(oj | 0x80000000u);
+                const unsigned fhi = (pz >> 8) & 0xffu;
+                if (u.act && !rev && fhi != 0xffu) fpool[(long long)(((unsigned long long)fhi << 32) | flo)].j = (int32_t)(fj | 0x80000000u);
+            };
+            for (int t0 = 0; t0 < total; t0 += 64) {
+                unit_t ua;
+                double qa[D], ca[D];
+                request(t0, ua, qa, ca);
+                test(ua, qa, ca);
+            }
+            if (__ballot(on && pc > 4u)) {
+                // (rare) more than four boxes met: every box, broad phase first, as the reference loops (boxesND.jl:44-51)
+                const bool o = on && pc > 4u;
+                double q[D], c[D], l[D], h[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) { q[i] = Xs[(int64_t)i1.x * D + i]; c[i] = Xs[(int64_t)i1.y * D + i]; l[i] = fmin(q[i], c[i]); h[i] = fmax(q[i], c[i]); }
+                bool fwd = true, rev = true;
+                for (int kb = 0; kb < M; ++kb) {
+                    const box_regs<D> bx = load_box_T<D>(sboxT, kb);
+                    const bool meet = o && !broadphase_free_sl<D>(l, h, bx);
+                    if (__ballot(meet)) {
+#pragma unroll 1
+                        for (int dir = 0; dir < 2; ++dir) {
+                            const bool f = narrow_free_sl<D>(c, q, bx);
+                            if (meet) { if (dir == 0) fwd = fwd && f; else rev = rev && f; }
+#pragma unroll
+                            for (int i = 0; i < D; ++i) { const double tt = c[i]; c[i] = q[i]; q[i] = tt; }
+                        }
+                    }
+                }
+                if (o && !fwd) pool[(long long)(((unsigned long long)(i0.z & 0xffu) << 32) | (unsigned long long)i0.x)].j = (int32_t)(i1.z | 0x80000000u);
+                const unsigned fhi = (i0.z >> 8) & 0xffu;
+                if (o && !rev && fhi != 0xffu) fpool[(long long)(((unsigned long long)fhi << 32) | (unsigned long long)i0.y)].j = (int32_t)(i1.w | 0x80000000u);
+            }
+        }
+    }
+}
+
+int32_t mpfmt_launch_exact_pairs(mpfmt_ctx* ctx, const int32_t* spec_fail)
+{
+    const int d = ctx->d;
+    const int64_t nitems = 1024;                             // regions of the list (MF_NREG in kernels_rdisc_mfma.hip)
+    if (ctx->tile_end <= ctx->tile_begin || d > 6) return MPFMT_OK;
+    const size_t lds = (size_t)SWEEP_CHUNK * 2 * d * sizeof(double);
+    mpfmt_timed tk(ctx);
+#define CASE(DD) case DD: hipLaunchKernelGGL((k_exact_pairs<DD>), dim3(1024, 4), dim3(256), lds, ctx->stream, (const uint4*)ctx->pair_items, (const int32_t*)ctx->pair_cnt, \
+        (long long)ctx->pair_icap, nitems, (const int32_t*)ctx->pair_over, ctx->Xs, ctx->boxes, ctx->M, (mpfmt_hit*)ctx->pool, (mpfmt_hit*)ctx->fpool, spec_fail); break;
+    switch (d) { CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) default: break; }
+#undef CASE
+    tk.end("exact_pairs");
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
 template <int D>
 static int32_t launch_sweep_pending_d(mpfmt_ctx* ctx, double rpad, const int32_t* spec_fail)
 {

@@ -695,7 +695,7 @@ int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t check
     const bool lazy_ok = ctx->cc_kind == 0 && ctx->dw == d;
     s->use_mask = ((flags & MPFMT_WF_EAGER) || !lazy_ok) ? 1 : 0;
     if (s->use_mask && !ctx->graph_swept) {
-        if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
+        ctx->pend_valid = false; if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (!s->use_mask) {                                    // obstacle table transposed for lane = obstacle reads

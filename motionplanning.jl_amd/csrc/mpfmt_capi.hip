@@ -194,7 +194,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
-                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->pool, ctx->log_len, ctx->fpool, ctx->flen, ctx->fcol, ctx->pend_items, ctx->pend_cnt, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev};
+                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->pool, ctx->log_len, ctx->fpool, ctx->flen, ctx->fcol, ctx->pend_items, ctx->pend_cnt, ctx->pair_items, ctx->pair_cnt, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev};
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
     mpfmt_comm_destroy(ctx);
     mpfmt_wf_free(ctx);
@@ -610,6 +610,7 @@ int32_t mpfmt_graph_sweep_device(mpfmt_ctx* ctx)
 {
     if (!ctx) return MPFMT_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->pend_valid = false;                                 // (outside a step: the whole sweep -- nobody checks a pending list's overflow flag here)
     return mpfmt_launch_graph_sweep(ctx);
 }
 
@@ -620,6 +621,7 @@ int32_t mpfmt_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask)
     int32_t rc;
     if (!ctx->graph_counted) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "graph_edges_free before rdisc_count");
     if (!ctx->graph_filled && (rc = mpfmt_launch_rdisc_fill(ctx, ctx->graph_r))) return rc;
+    ctx->pend_valid = false;
     if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
     const int64_t words = (ctx->nnz + 63) / 64;
     if (words > 0) {
@@ -793,6 +795,7 @@ int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkp
     // previous plan, or mpfmt_graph_import) is reused: only the obstacle-dependent sweep is redone.
     if (!(ctx->graph_filled && ctx->graph_r == r) && (rc = mpfmt_graph_build_device(ctx, r, nullptr))) return rc;
     auto t2 = std::chrono::steady_clock::now();
+    ctx->pend_valid = false;
     if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     auto t3 = std::chrono::steady_clock::now();
@@ -1361,8 +1364,9 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "rdisc_pool") == 0) { ctx->use_pool = value != 0; return MPFMT_OK; }
     if (strcmp(name, "fuse_sweep") == 0) { ctx->fuse_sweep = value != 0; return MPFMT_OK; }
     if (strcmp(name, "wf_graphs") == 0) { ctx->wf_graphs = value != 0; return MPFMT_OK; }
+    if (strcmp(name, "debug_small_lists") == 0) { ctx->debug_small_lists = value != 0; return MPFMT_OK; }
     if (strcmp(name, "fuse_broad") == 0) {
-        ctx->fuse_broad = value != 0;
+        ctx->fuse_broad = (int)value;                           // 0 off, 1 flagged entries listed by the ordering pass (k_sweep_pending), 2 flagged pairs tested before it (k_exact_pairs)
         ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false; ctx->spec_ready = false;
         return MPFMT_OK;
     }
@@ -1393,6 +1397,21 @@ int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value)
     if (!ctx || !name || !value) return MPFMT_ERR_ARG;
     if (strcmp(name, "rdisc_path_used") == 0) { *value = ctx->rdisc_path_used; return MPFMT_OK; }
     if (strcmp(name, "rdisc_half_used") == 0) { *value = ctx->half_used ? 1 : 0; return MPFMT_OK; }
+    if (strcmp(name, "sweep_form") == 0) {                   // how the resident mask was made: 0 whole sweep, 1 pending entries, 2 pairs before the ordering
+        *value = ctx->sweep_in_order ? 2 : (ctx->sweep_pending_used && ctx->pend_valid) ? 1 : 0; return MPFMT_OK;
+    }
+    if (strcmp(name, "pair_items") == 0) {                   // (a synchronising read) pending pairs the last half build listed for k_exact_pairs
+        *value = 0;
+        const int64_t items = 1024;
+        if (ctx->bits_in_records && ctx->pair_cnt && items > 0) {
+            std::vector<int32_t> h((size_t)items);
+            HIPCHK(ctx, hipMemcpyAsync(h.data(), ctx->pair_cnt, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            for (int32_t v : h) *value += v;
+        }
+        return MPFMT_OK;
+    }
+    if (strcmp(name, "pend_overflowed") == 0) { *value = ctx->pend_overflowed ? 1 : 0; return MPFMT_OK; }
     if (strcmp(name, "pool_used") == 0) { *value = ctx->pool_valid ? 1 : 0; return MPFMT_OK; }
     if (strcmp(name, "list_cap") == 0) { *value = ctx->list_cap; return MPFMT_OK; }
     if (strcmp(name, "survivors") == 0) { *value = ctx->survivors; return MPFMT_OK; }

@@ -134,7 +134,7 @@ struct mpfmt_ctx {
     // half build of the single-pass r-disc graph (kernels_rdisc_mfma.hip: every pair found once, the other column's record goes
     // to a foreign log of that column's tile)
     int use_half = 1;                    // option rdisc_half
-    int fuse_broad = 1;                  // option: broad phase of the edge tests in the half build's drain (step APIs only)
+    int fuse_broad = 2;                  // option: broad phase of the edge tests in the half build's drain (step APIs only)
     void* pend_items = nullptr;          // [segments][pend_wcap] (entry, column sample, row position) of the entries that need an exact test
     int64_t pend_wcap = 0;
     int32_t* pend_cnt = nullptr;         // [segments] items per segment, then the overflow flag
@@ -143,6 +143,13 @@ struct mpfmt_ctx {
     bool sweep_pending_used = false;     // the last graph sweep visited the pending list only
     bool pend_overflowed = false;        // read back behind the speculative step's synchronisation
     bool pend_valid = false;             // the resident graph has its pending list (made by this step's ordering pass)
+    void* pair_items = nullptr;          // fuse_broad = 2: [items][pair_icap] 32-byte pending-pair items (k_exact_pairs)
+    int32_t* pair_cnt = nullptr;         // [items], then the overflow flag
+    int32_t* pair_over = nullptr;
+    int64_t pair_icap = 0;
+    bool sweep_in_order = false;         // the mask of the resident graph was written by the ordering pass (form 2)
+    bool bits_in_records = false;        // this count's blocked edges are marked in the records (bit 31 of the row index)
+    int debug_small_lists = 0;           // option (tests): pending lists of 8 items, so that their overflow path runs
     bool want_broad = false;             // set by the step APIs around their count
     bool broad_in_drain = false;         // this count's records carry the broad-phase flag (bit 30 of the row index)
     bool half_used = false;              // the counted graph was built that way
@@ -273,6 +280,7 @@ int32_t mpfmt_sweep_prepare_ss(mpfmt_ctx* ctx);          // kernels_sweep.hip: d
 #define MPFMT_ORD_MAXDEG 3072        // longest column the log-ordering kernel stages in LDS (ORD_STG in kernels_rdisc_mfma.hip)
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false, bool half = false);
 int32_t mpfmt_launch_foreign_degrees(mpfmt_ctx* ctx);
+int32_t mpfmt_launch_exact_pairs(mpfmt_ctx* ctx, const int32_t* spec_fail);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);
 

@@ -89,6 +89,56 @@ def test_half_build_equals_whole_build_and_the_oracle(orc, d, N, r):
             assert np.array_equal(a[3].view(np.uint64), orc.graph_edges_free(Xi, oc, orow, lohi, lo, hi))
 
 
+@pytest.mark.parametrize("form", [2, 1, 0])
+@pytest.mark.parametrize("d,N,r,M", [(2, 6000, 0.03, 12), (3, 7001, 0.09, 40), (6, 20000, 0.42, 200)])
+def test_edge_tests_fused_into_the_half_build(orc, form, d, N, r, M):
+    """The step's edge tests in their three forms -- 2: broad phase in the pair kernel's drain, flagged PAIRS tested before the logs are
+    ordered, the ordering pass writes the mask; 1: flagged ENTRIES listed by the ordering pass and tested afterwards; 0: the whole
+    sweep -- against the oracle's graph and mask, over a careful step, speculative repeats, new samples and new obstacles."""
+    rng = np.random.default_rng(6000 + d)
+    X, lohi = random_world(rng, N, d, M, 0.05, 0.25)
+    lohi2 = mp.workloads.make_boxes(rng, max(M // 2, 1), d, 0.1, 0.3, [])
+    lo, hi = np.full(d, 0.0), np.full(d, 1.0)
+    seen = []
+    with mp.Context(0) as c:
+        c.set_option("fuse_broad", form); c.set_option("rebuild_index", 1)
+        for Xi, boxes in ((X, lohi), (X, lohi), (rng.random((N, d)), lohi), (X, lohi2), (X, lohi2)):
+            c.upload_samples(Xi); c.upload_boxes(boxes, lo, hi)
+            nnz = c.graph_step_device(r)
+            seen.append(c.stat("sweep_form"))
+            colptr, rowval, nzval, free = _resident_graph(c, N)
+            oc, orow, oval = orc.rdisc_graph(Xi, r)
+            assert np.array_equal(colptr, oc) and np.array_equal(rowval, orow) and np.array_equal(nzval, oval)
+            assert np.array_equal(free.view(np.uint64), orc.graph_edges_free(Xi, oc, orow, boxes, lo, hi))
+        # a sweep of the resident graph on its own, after the obstacles changed, is the whole sweep whatever the step did
+        c.upload_boxes(lohi, lo, hi)
+        c.graph_sweep_device()
+        free = _resident_graph(c, N)[3]
+        assert np.array_equal(free.view(np.uint64), orc.graph_edges_free(X, oc, orow, lohi, lo, hi))
+    assert all(s in (0, form) for s in seen), seen             # (0: the build was not a half build, or a trusted capacity did not hold)
+    if d == 6: assert form == 0 or form in seen, seen
+
+
+@pytest.mark.parametrize("form", [2, 1])
+def test_fused_edge_tests_survive_a_list_overflow(orc, form):
+    """Option debug_small_lists shrinks the pending lists to 8 items: the kernels that read them return at once, the host finds the
+    flag behind its synchronisation and sweeps the whole graph."""
+    rng = np.random.default_rng(77)
+    N, d, r = 9000, 3, 0.08
+    X, lohi = random_world(rng, N, d, 30, 0.05, 0.25)
+    lo, hi = np.full(d, 0.0), np.full(d, 1.0)
+    oc, orow, oval = orc.rdisc_graph(X, r)
+    want = orc.graph_edges_free(X, oc, orow, lohi, lo, hi)
+    with mp.Context(0) as c:
+        c.set_option("fuse_broad", form); c.set_option("debug_small_lists", 1); c.set_option("rebuild_index", 1)
+        c.upload_samples(X); c.upload_boxes(lohi, lo, hi)
+        for it in range(3):                                   # careful, then speculative
+            c.graph_step_device(r)
+            colptr, rowval, nzval, free = _resident_graph(c, N)
+            assert np.array_equal(rowval, orow) and np.array_equal(free.view(np.uint64), want), it
+            assert c.stat("sweep_form") == 0
+
+
 def test_half_build_overflow_is_redone_whole(orc):
     """A cluster the capacity estimate does not expect: the half build's logs overflow, the count is redone whole (a half build
     has no fill pass to fall back to), and once a build has left its size hint the half form is tried again."""
