@@ -283,7 +283,9 @@ def main():
     path_used = ctx.stat("rdisc_path_used")
     survivors = ctx.stat("survivors")
     single_pass = ctx.stat("pool_used") == 1
-    tm = {k: ctx.timing(k) for k in ("grid", "rdisc_count", "pair_kernel", "rdisc_fill", "rdisc_sort", "order_sweep", "sweep_graph", "sweep_kernel")}
+    tm = {k: ctx.timing(k) for k in ("grid", "rdisc_count", "pair_kernel", "exact_pairs", "rdisc_fill", "rdisc_sort", "order_sweep", "sweep_graph", "sweep_kernel")}
+    edge_form = ctx.stat("sweep_form")               # 0 whole sweep kernel; 1 flagged entries after the ordering; 2 flagged pairs before it
+    pending_pairs = ctx.stat("pair_items") if edge_form == 2 else 0
     # per STEP: an interval name can be timed more than once in a step ("grid" is the cell grid + sorted copies, and again the MFMA
     # operands + chunk lists), timing() returns the mean per interval
     per_step = {k: (v[0] * v[1] / max(args.steps, 1)) for k, v in tm.items()}
@@ -291,7 +293,8 @@ def main():
     d = w.d
     fused = tm["order_sweep"][1] > 0                 # option fuse_sweep: the edge tests ride in the ordering kernel
     # the r-disc pair kernel k_rdisc_mfma on its own launch duration (single pass) -- or count + fill in the two-pass forms
-    pair_ms = (tm["pair_kernel"][0] if tm["pair_kernel"][1] > 0 else tm["rdisc_count"][0]) + tm["rdisc_fill"][0]
+    # ("pair_kernel" spans k_exact_pairs too when the edge tests are fused in form 2: that kernel has its own timer)
+    pair_ms = (tm["pair_kernel"][0] - tm["exact_pairs"][0] if tm["pair_kernel"][1] > 0 else tm["rdisc_count"][0]) + tm["rdisc_fill"][0]
     passes = 1 if single_pass else 2
     pairs_per_pass = stats["pairs_tested"]
     # algorithmic flops: 2*d per tested pair; MFMA flops actually issued: K = 16 slots -> 32 per pair
@@ -302,7 +305,11 @@ def main():
     # the sweep kernel's own launch duration where the library times it (round-table kernel); "sweep_graph" is the whole interval
     # (mask preset + round table + kernel) and stays in kernel_ms
     sweep_ms = tm["sweep_kernel"][0] if tm["sweep_kernel"][1] > 0 else tm["sweep_graph"][0]
+    if edge_form == 2:
+        sweep_ms = tm["exact_pairs"][0]              # the only kernel that is edge tests alone; the broad phase rides in the pair kernel
     sweep_bytes = nnz * (2 * d * 8 + 8 + 1.0 / 8.0)
+    if edge_form == 2:
+        sweep_bytes = pending_pairs * (32.0 + 2 * d * 8 + 8.0)       # one 32-byte item, two states, up to two record words marked
     sweep_gbs = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     # the column-ordering kernel (k_order_logs): algorithmic bytes = one 16-byte hit record in, rowval (4) + nzval (8) + rowpos (4) out
     sort_ms = tm["order_sweep"][0] if fused else tm["rdisc_sort"][0]
@@ -338,7 +345,9 @@ def main():
                    "step": "index build (cell grid, sorted copies, MFMA operands, chunk lists) + r-disc graph of all N samples as an ordered CSC "
                            "+ collision sweep of all nnz directed edges; the one thing not redone per step is the all-samples-in-state-space "
                            "flag (k_all_in_ss, 25 us, once per upload)" +
-                           ("; half build: every pair of samples is tested once by the pair kernel, which writes the hit records of both columns" if half_build else "")},
+                           ("; half build: every pair of samples is tested once by the pair kernel, which writes the hit records of both columns" if half_build else "") +
+                           ("; edge tests fused: the broad phase of a pair's segment runs in the pair kernel's drain (once for both directions), "
+                            "the flagged pairs' slab tests in k_exact_pairs, the mask is written by the ordering pass -- no separate sweep kernel" if edge_form == 2 else "")},
         "submetrics": {
             "rdisc_queries_per_s": w.N * args.steps / dt,
             "edges_checked_per_s_sweep_kernel": (nnz / (sweep_ms * 1e-3)) if sweep_ms > 0 else None,
@@ -346,6 +355,9 @@ def main():
             if pair_ms > 0 else None,
             "kernel_ms": per_step,
             "rdisc_half_build": half_build,
+            "edge_test_form": {0: "whole sweep kernel (k_graph_sweep_rt)", 1: "broad phase in the pair kernel's drain, flagged entries listed by the ordering pass, k_sweep_pending",
+                               2: "broad phase in the pair kernel's drain, flagged pairs tested in both directions by k_exact_pairs before the ordering pass, which writes the mask"}.get(edge_form),
+            "pending_pairs": pending_pairs if edge_form == 2 else None,
             "pairs_tested_per_pass": pairs_per_pass,
             "pair_passes": passes,
             "rdisc_pair_kernel": "fp16 MFMA filter + exact fp64 refine" if path_used == 2 else "exact fp64 VALU",
@@ -373,6 +385,7 @@ def main():
             "mfma_flops_issued_tflops": mfma_tflops,
             "frac_of_fp64_peak": ach_tflops / FP64_PEAK_TFLOPS,
             "half_build": half_build,
+            "edge_broad_phase_in_drain": edge_form > 0,      # the kernel's time then includes 2 d v_cmpx per surviving box and hit (0.7 ms at the north star)
             "ordered_pairs_served_tflops": ach_tflops * (2.0 if half_build else 1.0),
             "valu_per_mfma": pk.get("valu_per_mfma"),
             "valu_busy": pk.get("valu_busy"),
@@ -387,13 +400,15 @@ def main():
         }
     # SURVEY 8d asks for both fractions of the sweep: algorithmic bytes/s over 8 TB/s and fp64 lane-ops/s over 39.3e12.
     # Lane-ops per edge come from the PMC run (SQ_INSTS_VALU x 64 lanes / edges) when the summary matches this build.
-    sk = prof.get("sweep", {})
+    sk = prof.get("exact" if edge_form == 2 else "pending" if edge_form == 1 else "sweep", {})
     valu_per_edge = sk.get("valu_lane_ops_per_edge")
     valu_frac = (valu_per_edge * nnz / (sweep_ms * 1e-3) / FP64_VALU_LANE_OPS) if (valu_per_edge and sweep_ms > 0) else None
     sorted_rows = os.environ.get("MPFMT_OPT_SWEEP_SORTED", "1") != "0"          # library default: rows gathered from the cell-sorted copy
     ceiling = GATHER_CEILING_L2_ROWS_PER_S if sorted_rows else GATHER_CEILING_ROWS_PER_S
     roof_sweep = {
-            "kernel": "k_graph_sweep_rt" if tm["sweep_kernel"][1] > 0 else "k_graph_sweep", "bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": ("k_exact_pairs (slab tests of the flagged pairs, both directions; the broad phase of ALL pairs is in the pair kernel's drain)" if edge_form == 2
+                       else "k_sweep_pending" if edge_form == 1 else "k_graph_sweep_rt" if tm["sweep_kernel"][1] > 0 else "k_graph_sweep"),
+            "bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": sweep_gbs / HBM_PEAK_GBS,
             "traffic": sk.get("bytes"),
             "traffic_ratio": ratio(sk.get("bytes"), sweep_bytes),
@@ -409,7 +424,9 @@ def main():
             "gather_ceiling_edges_per_s": ceiling if d == 6 else None,
             "frac_of_gather_ceiling": (nnz / (sweep_ms * 1e-3) / ceiling) if (d == 6 and sweep_ms > 0) else None,
             "avg_launch_ms": sweep_ms,
-            "note": "algorithmic bytes = (2*d*8 + 8 + 1/8) per edge = %.3f B; valu_frac = measured vector lane-ops per edge x edges/s over the "
+            "note": ("edge tests fused into the half build: algorithmic bytes here = pending pairs x (32-byte item + two states + marks) -- a kernel of "
+                     "dependent gathers and fp64 divisions, not a stream; the whole sweep it replaces: " if edge_form == 2 else "") +
+                    "algorithmic bytes = (2*d*8 + 8 + 1/8) per edge = %.3f B; valu_frac = measured vector lane-ops per edge x edges/s over the "
                     "39.3e12 unfused fp64 lane-op/s of SURVEY 8d; every edge needs one 48-byte row-state gather: a kernel that does "
                     "nothing but such gathers reaches 4.5e10 rows/s from a caller-order array (L2 misses) and 1.9e11 when the rows are "
                     "L2-resident (tools/ubench/, profiles/r01_ubench_fetch_calib.txt, profiles/r02_ubench_gather_variants.txt); "

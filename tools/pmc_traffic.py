@@ -51,7 +51,7 @@ def main():
     out = {"lib_sha256": lib_sha(), "workload": workload, "n_gpus": 1, "source": os.path.relpath(out_txt, ROOT),
            "method": "bytes = (FETCH_SIZE x 2 + WRITE_SIZE) KiB x 1024 (MI355X_MICROARCH.md HBM section: gfx950 FETCH_SIZE is half the bytes of a "
                      "coalesced read); bytes_gather_calibrated = (FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gathers: FETCH_SIZE = 64 B x read requests)"}
-    for tag, sub in (("pair", "k_rdisc_mfma"), ("sweep", "k_graph_sweep"), ("sort", "k_order_logs")):
+    for tag, sub in (("pair", "k_rdisc_mfma"), ("sweep", "k_graph_sweep"), ("sort", "k_order_logs"), ("exact", "k_exact_pairs"), ("pending", "k_sweep_pending")):
         p = pick(sub)
         if not p:
             continue
