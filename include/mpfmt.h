@@ -438,6 +438,7 @@ int32_t mpfmt_allgather_free_mask_relaunch(mpfmt_ctx* ctx);
 /* ---- measurement: average device milliseconds per launch of a named kernel group since the last
  *      reset, measured with HIP events on the launch stream.  names: "rdisc_count", "rdisc_fill",
  *      "rdisc_sort", "grid", "sweep_graph" (mask preset + round table + kernel), "sweep_kernel" (the round-table sweep kernel alone),
+ *      "pair_kernel" (the pair kernel, and k_exact_pairs behind it when the edge tests are fused), "exact_pairs",
  *      "sweep_points", "sweep_edges", "expand". */
 int32_t mpfmt_timing_reset(mpfmt_ctx* ctx);
 int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
@@ -445,10 +446,20 @@ int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64
  * filter + exact fp64 refine (both give bit-identical graphs).  "timing": 0/1 event timing off/on.
  * "sweep_sorted" (default 1): the graph sweep gathers row states from the library's cell-sorted copy and visits the columns
  * in cell order, 0 = from the caller-order array.  "sweep_rounds" (default 1): round-table sweep kernel where it applies
- * (d <= 8, at most 256 boxes), 0 = the task-header kernel everywhere.  Same mask bits in every combination. */
+ * (d <= 8, at most 256 boxes), 0 = the task-header kernel everywhere.  Same mask bits in every combination.
+ * "rdisc_half" (default 1): the single-pass build of an unsharded ctx tests every pair of samples once and writes the hit
+ * records of both columns (same CSC bit for bit; a build that overflows its logs is counted again whole).
+ * "fuse_broad" (default 2): in mpfmt_graph_step* on such a build (AABB checker in the state space's own coordinates, d <= 6,
+ * <= 256 boxes, every sample inside the state space) the edge tests ride in the graph kernels: 2 = broad phase in the pair
+ * kernel, slab tests of the flagged pairs before the columns are ordered, the ordering pass writes the mask; 1 = flagged entries
+ * tested after the ordering; 0 = the separate sweep kernel.  Same graph and mask bits in every combination; a sweep called on
+ * its own (mpfmt_graph_sweep_device, mpfmt_graph_edges_free) is always the whole sweep.
+ * "fuse_sweep", "wf_graphs" (default 0): measured alternatives kept for the record.
+ * "debug_small_lists": test knob, shrinks the pending lists of the fused edge tests so that their overflow path runs. */
 int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value);
 /* Counters of the last graph build: "rdisc_path_used", "pairs_tested", "survivors" (pairs that passed the
- * MFMA filter), "nnz", "slices", "cells". */
+ * MFMA filter), "nnz", "slices", "cells", "rdisc_half_used", "pool_used"; of the last step's edge tests: "sweep_form"
+ * (0 / 1 / 2 as "fuse_broad"), "pair_items" (pairs listed for the exact tests; a synchronising read). */
 int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value);
 /* work counters of the last graph build: candidate pairs distance-tested, tiles, slices. */
 int32_t mpfmt_graph_stats(mpfmt_ctx* ctx, int64_t* pairs_tested, int64_t* tiles, int64_t* slices, int64_t* cells);
