@@ -770,9 +770,11 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         if (!ok) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "chunk lists do not fit");
     }
     ctx->half_used = half;
-    ctx->broad_in_drain = half && ctx->want_broad;
+    // the broad phase of the step's edge tests rides in any single-pass build (whole builds -- shards -- flag each entry's own record
+    // and take form 1: the ordering pass lists the flagged entries); the pair form needs the half build
+    ctx->broad_in_drain = pool && mf && ctx->d <= 6 && ctx->want_broad;
     ctx->bits_in_records = false; ctx->sweep_in_order = false;
-    if (ctx->broad_in_drain && ctx->fuse_broad == 2) {
+    if (ctx->broad_in_drain && half && ctx->fuse_broad == 2) {
         // form 2: the pairs flagged by the drain's broad phase are listed for k_exact_pairs in 1024 dense regions (an item appends to
         // region item mod 1024 with one reservation per drain); room for three quarters of all pairs being flagged -- beyond that the
         // flag is raised and the host sweeps the whole graph
@@ -969,7 +971,7 @@ static int32_t sweep_checked(mpfmt_ctx* ctx)
 // statespaces.jl:155 is then true for every entry)
 static bool step_wants_broad(mpfmt_ctx* ctx)
 {
-    if (!ctx->fuse_broad || ctx->cc_kind != 0 || !ctx->have_boxes || ctx->dw != ctx->d || ctx->d > 6 || ctx->M > 256 || ctx->world != 1) return false;
+    if (!ctx->fuse_broad || ctx->cc_kind != 0 || !ctx->have_boxes || ctx->dw != ctx->d || ctx->d > 6 || ctx->M > 256) return false;
     if (mpfmt_sweep_prepare_ss(ctx) != MPFMT_OK) return false;
     return !(ctx->ss.has && !ctx->ssflag_all_in);
 }

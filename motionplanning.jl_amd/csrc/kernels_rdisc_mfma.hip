@@ -1016,7 +1016,7 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.pool = ctx->pool; a.log_len = ctx->log_len;
     a.half = (MODE == 2 && ctx->half_used) ? 1 : 0;
     a.fpool = ctx->fpool; a.flen = ctx->flen; a.fcap = ctx->fcap; a.fcol = ctx->fcol;
-    a.fb = (a.half && ctx->broad_in_drain) ? (ctx->fuse_broad == 2 ? 2 : 1) : 0; a.M = ctx->M; a.boxes = ctx->boxes;
+    a.fb = (MODE == 2 && ctx->broad_in_drain) ? (ctx->bits_in_records ? 2 : 1) : 0; a.M = ctx->M; a.boxes = ctx->boxes;
     a.pitems = (uint4*)ctx->pair_items; a.pcnt = ctx->pair_cnt; a.icap = ctx->pair_icap; a.pend_over = ctx->pair_over;
     if (MODE != 2 && ctx->lists_half) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "two-pass r-disc kernels need whole chunk lists");
     if (a.nitems <= 0) return MPFMT_OK;
