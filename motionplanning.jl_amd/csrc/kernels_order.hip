@@ -40,8 +40,8 @@ __device__ __forceinline__ ord_cptr ord_const(const double* p) { return (ord_cpt
 #define ORD_WAVES 8
 #define ORD_COLS 16              // columns per workgroup = columns per log
 #define ORD_NB 128               // buckets per column
-#define ORD_STG 3072             // staged records per workgroup (48 KB of LDS)
-#define ORD_PRE 6                // records per thread requested ahead (6 x 512 = 3072 = the staging area)
+#define ORD_STG 2048             // staged records per workgroup (32 KB of LDS; with the counters 49.5 KB: THREE workgroups per CU -- 3072 allowed two: 1.18 -> 1.14 ms)
+#define ORD_PRE 4                // records per thread requested ahead (4 x 512 = 2048 = the staging area)
 #define ORD_QCAP 128             // pending exact tests per wavefront
 #define ORD_MAXM 256             // obstacles the fused sweep handles (4 survivor words per column)
 static_assert(ORD_STG >= MPFMT_ORD_MAXDEG, "a column the host lets through must fit the staging area");
@@ -545,11 +545,11 @@ static int32_t launch_order(mpfmt_ctx* ctx, const int32_t* spec_fail, const ord_
         HIPCHK(ctx, hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    // persistent workgroups: as many as fit the chip at once (2 per CU by their LDS), each takes every nb-th quarter tile
+    // persistent workgroups: as many as fit the chip at once (3 per CU by their LDS and their 82 VGPRs), each takes every nb-th quarter tile
     static int per_cu = 0;
     if (per_cu == 0) {
         HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kk, ORD_THREADS, lds));
-        per_cu = std::max(1, std::min(per_cu, 2));
+        per_cu = std::max(1, std::min(per_cu, 3));
     }
     const unsigned nb = (unsigned)std::min<int64_t>(nt * 4, (int64_t)ctx->num_cus * per_cu);
     // records flagged by the pair kernel's broad phase (step APIs, half build): their entries are listed for k_sweep_pending, one

@@ -277,7 +277,7 @@ template <int MODE> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, fl
 int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr, bool fuse = false, int64_t mask_entries = -1);      // kernels_order.hip
 bool mpfmt_order_can_fuse(const mpfmt_ctx* ctx);
 int32_t mpfmt_sweep_prepare_ss(mpfmt_ctx* ctx);          // kernels_sweep.hip: device copy of the state-space bounds + the all-samples-inside flag
-#define MPFMT_ORD_MAXDEG 3072        // longest column the log-ordering kernel stages in LDS (ORD_STG in kernels_rdisc_mfma.hip)
+#define MPFMT_ORD_MAXDEG 2048        // longest column the log-ordering kernel stages in LDS (ORD_STG in kernels_order.hip)
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false, bool half = false);
 int32_t mpfmt_launch_foreign_degrees(mpfmt_ctx* ctx);
 int32_t mpfmt_launch_exact_pairs(mpfmt_ctx* ctx, const int32_t* spec_fail);

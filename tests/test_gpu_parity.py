@@ -150,7 +150,7 @@ def test_rdisc_clustered_and_duplicates(ctx, orc):
 def test_rdisc_pool_overflow_falls_back(orc):
     """A dense cluster defeats the pool's capacity estimate: the build must notice the overflow and run the fill pass."""
     rng = np.random.default_rng(81)
-    X = np.concatenate([0.5 + 0.004 * rng.standard_normal((3000, 3)), rng.random((500, 3))])
+    X = np.concatenate([0.5 + 0.004 * rng.standard_normal((1800, 3)), rng.random((500, 3))])      # (every pair of the cluster is an edge: columns of 1800+, under the ordering kernel's 2048)
     c = mp.Context(0)
     c.upload_samples(X)
     used = []

@@ -144,7 +144,7 @@ def test_half_build_overflow_is_redone_whole(orc):
     """A cluster the capacity estimate does not expect: the half build's logs overflow, the count is redone whole (a half build
     has no fill pass to fall back to), and once a build has left its size hint the half form is tried again."""
     rng = np.random.default_rng(91)
-    X = np.concatenate([0.5 + 0.004 * rng.standard_normal((3000, 3)), rng.random((900, 3))])
+    X = np.concatenate([0.5 + 0.004 * rng.standard_normal((1800, 3)), rng.random((900, 3))])      # (every pair of the cluster is an edge: columns of 1800+, under the ordering kernel's 2048)
     oc, orow, oval = orc.rdisc_graph(X, 0.2)
     with mp.Context(0) as c:
         c.upload_samples(X)
