@@ -385,7 +385,7 @@ __global__ void k_wf_box_transpose(const double* __restrict__ boxes, int M, int 
 
 // one wavefront per candidate x.  MODE 0: connect in place; MODE 1: emit triples
 template <int D, int MODE>
-__global__ __launch_bounds__(256) void k_wf_connect(const int32_t* __restrict__ xlist, const int64_t* __restrict__ colptr,
+__global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict__ xlist, const int64_t* __restrict__ colptr,
                                                     const int32_t* __restrict__ rowval, const double* __restrict__ nzval,
                                                     const uint64_t* __restrict__ H, double* __restrict__ C, int32_t* __restrict__ A,
                                                     unsigned long long* __restrict__ W, unsigned long long* __restrict__ Hn,
