@@ -150,7 +150,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
         } else if (tid >= 64 && tid < 64 + S) {
             hln = log_len[(tl * S + (tid - 64)) * 4 + quarter];
         } else if (tid == 64 + S && flogs) {
-            hln = min(flen[(tile_begin + tl) * 4 + quarter], (int32_t)fcapL);
+            hln = min(flen[tl * 4 + quarter], (int32_t)fcapL);
         }
     };
     auto hdr_fetch2 = [&]() { hout = (tid < ORD_COLS && ho >= 0) ? colptr[ho] : 0; };
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(const mpfmt_hit* __r
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (H.lp[mid] <= i) lo = mid; else hi = mid; }
             base = H.lp[lo];
         }
-        const mpfmt_hit* const src = (lo == S) ? flogs + ((tile_begin + (qi >> 2)) * 4 + (qi & 3)) * fcapL
+        const mpfmt_hit* const src = (lo == S) ? flogs + qi * fcapL
                                                : logs + (((qi >> 2) * S + lo) * 4 + (qi & 3)) * capL;
         return reinterpret_cast<const uint4*>(src) + (i - base);
     };

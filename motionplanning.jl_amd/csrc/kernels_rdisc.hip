@@ -685,7 +685,8 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         }
         bool ok = true;
         // half build: the whole graph on this ctx, through the single-pass logs (decided before the lists, which differ)
-        half = ctx->use_half && !ctx->half_off && ctx->use_pool && ctx->world == 1 && nt == ctx->ntiles && nt > 0;
+        // (a shard does the same for the pairs inside it; its pairs with other shards' samples are found from its own side only)
+        half = ctx->use_half && !ctx->half_off && ctx->use_pool && nt > 0;
         if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok, spec, half))) return rc;    // per-tile candidate chunk lists
         tm2.end("grid");
         if (!ok) {

@@ -78,6 +78,7 @@ struct mf_args {
     // half build (unsharded single pass): the chunk lists hold only chunks >= the tile, every pair is found once, and the hit of a
     // chunk beyond the tile is also written as the record of the OTHER column into that column's tile's foreign log
     int32_t half;
+    int64_t ntiles_shard;           // tiles of this shard: the other column's record is written for candidates in [blk_begin, blk_begin + ntiles_shard)
     mpfmt_hit* fpool;               // [tiles][4][fcap] foreign logs, one per 16 columns of a tile, appended to by the tiles before it
     int32_t* flen;                  // [tiles][4] their lengths (global cursors)
     long long fcap;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
     // half build: only chunks >= the tile are wanted.  Rows come in ascending cell order, so every row before the one that holds
     // the tile's first sample lies wholly before the tile: the enumeration starts at that row
     uint32_t rows_lo = 0;
-    if (half) {
+    if (half && tile_begin == 0) {                            // (a shard keeps the chunks of the shards before it: every row is enumerated)
         int64_t cid = (int64_t)(cellkey[tile * 64] >> fb);    // (a tile's first sample is never a pad)
         uint32_t mul = 1;
 #pragma unroll
@@ -305,7 +306,8 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
             if (lane == 0) prevc = carry;
             const int lastl = min(63, T - t0 - 1);
             carry = __shfl(c, lastl);
-            bool keep = act && (c != prevc) && (!half || c >= tile);     // half build: the chunks before the tile find these pairs
+            // half build: the chunks before the tile find these pairs -- inside the shard; a chunk of another shard is nobody's but ours
+            bool keep = act && (c != prevc) && (!half || c >= tile || c < tile_begin || c >= tile_begin + nt);
             if (keep && !use_sub) {                       // coarse grid (<= 2 cells per dimension): every cell neighbours every other
                 double gap2 = 0.0;                        // one, a tile running over a row end loses nothing -- hull against hull
 #pragma unroll
@@ -641,8 +643,9 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             // returning atomic per hit ran at 2e10 / s: 4.7 ms for the 1e8 of the north star), the others read it by lane exchange.
             // The column lane of every record also goes to a compact side array, from which k_foreign_degrees counts the columns'
             // foreign hits (the CSC offsets need every column's degree before the logs are ordered).
-            const bool fh = hit && (int64_t)(jg >> 6) != tile;
-            const int fq = (int)((jg >> 6) * 4u + ((jg & 63u) >> 4));
+            const int64_t fc = (int64_t)(jg >> 6) - a.blk_begin;        // the candidate's tile, counted from the shard's first
+            const bool fh = hit && (int64_t)(jg >> 6) != tile && fc >= 0 && fc < a.ntiles_shard;
+            const int fq = (int)(fc * 4 + (int64_t)((jg & 63u) >> 4));
             unsigned long long rem = __ballot(fh);
             int leader = lane, pre = 0, cnt_l = 0;
             while (rem) {
@@ -957,7 +960,7 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
 // half build: foreign hits of every column = a count over the compact column array of its quarter tile's foreign log (one
 // wavefront per quarter tile; the counts are row S of slice_cnt, where k_degree and the ordering kernel add them to the own ones)
 __global__ __launch_bounds__(256) void k_foreign_degrees(const uint8_t* __restrict__ fcol, const int32_t* __restrict__ flen, long long fcap,
-                                                         int64_t nq, int32_t* __restrict__ fdeg)
+                                                         int64_t nq, int32_t* __restrict__ fdeg, int64_t pos0)
 {
     __shared__ int s_c[4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -976,7 +979,7 @@ __global__ __launch_bounds__(256) void k_foreign_degrees(const uint8_t* __restri
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < 16) fdeg[q * 16 + lane] = s_c[wave][lane];
+    if (lane < 16) fdeg[pos0 + q * 16 + lane] = s_c[wave][lane];
 }
 
 int32_t mpfmt_launch_foreign_degrees(mpfmt_ctx* ctx)
@@ -984,7 +987,7 @@ int32_t mpfmt_launch_foreign_degrees(mpfmt_ctx* ctx)
     const int64_t nq = (ctx->tile_end - ctx->tile_begin) * 4;
     if (nq <= 0) return MPFMT_OK;
     hipLaunchKernelGGL(k_foreign_degrees, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ctx->stream, ctx->fcol, ctx->flen, (long long)ctx->fcap, nq,
-                       ctx->slice_cnt + (int64_t)ctx->S * (ctx->ntiles * 64));
+                       ctx->slice_cnt + (int64_t)ctx->S * (ctx->ntiles * 64), ctx->tile_begin * 64);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
@@ -1015,6 +1018,7 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.pool_flag = ctx->pool_flag; a.pool_cap = ctx->pool_cap;
     a.pool = ctx->pool; a.log_len = ctx->log_len;
     a.half = (MODE == 2 && ctx->half_used) ? 1 : 0;
+    a.ntiles_shard = ctx->tile_end - ctx->tile_begin;
     a.fpool = ctx->fpool; a.flen = ctx->flen; a.fcap = ctx->fcap; a.fcol = ctx->fcol;
     a.fb = (MODE == 2 && ctx->broad_in_drain) ? (ctx->bits_in_records ? 2 : 1) : 0; a.M = ctx->M; a.boxes = ctx->boxes;
     a.pitems = (uint4*)ctx->pair_items; a.pcnt = ctx->pair_cnt; a.icap = ctx->pair_icap; a.pend_over = ctx->pair_over;

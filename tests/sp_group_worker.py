@@ -27,7 +27,7 @@ w = mp.workloads.north_star(N) if big else mp.workloads.make("t", N, d, 40, 0.05
 
 ref = mp.Context(0)
 ref.upload_samples(w.X); ref.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
-radii = [w.r, w.r, w.r * (1.2 if big else 1.45), w.r * 0.8, w.r]         # steady, growth, shrink, back
+radii = [w.r, w.r, w.r * (1.12 if big else 1.45), w.r * 0.8, w.r]        # steady, growth (x2 entries at the north star), shrink, back
 want = {}
 for r in sorted(set(radii)):
     if big:
@@ -40,6 +40,7 @@ for r in sorted(set(radii)):
         colptr, rowval, nzval = ref.rdisc_graph(r)
         want[r] = (colptr - 1, ref.graph_edges_free(), len(rowval))
 
+ref.close()                                                  # (its logs at the largest radius are tens of GB: the shards need the room)
 uid = L.comm_unique_id()
 ctxs = [mp.Context(0) for _ in range(world)]
 L.group_begin()
@@ -100,5 +101,4 @@ for k in range(len(radii)):
 assert retries >= 1, "the growth step must have gone through MPFMT_RETRY"
 for c in ctxs:
     c.close()
-ref.close()
 print("group ok: world %d, N %d, %d retries" % (world, w.N, retries))
