@@ -447,8 +447,8 @@ int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64
  * "sweep_sorted" (default 1): the graph sweep gathers row states from the library's cell-sorted copy and visits the columns
  * in cell order, 0 = from the caller-order array.  "sweep_rounds" (default 1): round-table sweep kernel where it applies
  * (d <= 8, at most 256 boxes), 0 = the task-header kernel everywhere.  Same mask bits in every combination.
- * "rdisc_half" (default 1): the single-pass build of an unsharded ctx tests every pair of samples once and writes the hit
- * records of both columns (same CSC bit for bit; a build that overflows its logs is counted again whole).
+ * "rdisc_half" (default 1): the single-pass build tests every pair of the ctx's own samples once and writes the hit records
+ * of both columns (same CSC bit for bit; a build that overflows its logs is counted again whole).
  * "fuse_broad" (default 2): in mpfmt_graph_step* on such a build (AABB checker in the state space's own coordinates, d <= 6,
  * <= 256 boxes, every sample inside the state space) the edge tests ride in the graph kernels: 2 = broad phase in the pair
  * kernel, slab tests of the flagged pairs before the columns are ordered, the ordering pass writes the mask; 1 = flagged entries
