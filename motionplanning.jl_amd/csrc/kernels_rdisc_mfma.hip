@@ -626,14 +626,28 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         // item mod MF_NREG) -- one reservation per drain on the region's counter, requested here, used after the foreign records
         // below are out (per-item segments sized for the worst case left the list scattered over 9 GB in 6 KB pieces: the kernel that
         // reads it spent 1.3 ms on address translation alone)
-        [[maybe_unused]] int ibase = 0;
+        // One item per (pair, box) UNIT -- a pair that met k <= 4 boxes writes k items, one that met more a single item with bit 8 of the box word set
+        // ("every box"): the reader's lanes are then units with nothing to look up among each other.
+        [[maybe_unused]] int ibase = 0, iexcl = 0, iunits = 0;
         [[maybe_unused]] unsigned long long ipm = 0;
         [[maybe_unused]] bool iem = false;
         if constexpr (MODE == 2 && D <= 6) {
             if (a.fb == 2) {
                 iem = hit && pendflag != 0 && own_idx >= 0;
                 ipm = __ballot(iem);
-                if (ipm && lane == 0) ibase = atomicAdd(&a.pcnt[item & (MF_NREG - 1)], (int)__popcll(ipm));
+                if (ipm) {
+                    iunits = iem ? (pc_keep > 4u ? 1 : (int)pc_keep) : 0;
+                    int incl = iunits;                                        // inclusive scan over the lanes (DPP)
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);       // row_shr:1
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);       // row_shr:2
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);       // row_shr:4
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);       // row_shr:8
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);      // row_bcast:15
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);      // row_bcast:31
+                    iexcl = incl - iunits;
+                    const int total = __builtin_amdgcn_readlane(incl, 63);
+                    if (lane == 0) ibase = atomicAdd(&a.pcnt[item & (MF_NREG - 1)], total);
+                }
             }
         }
         if (MODE == 2 && a.half) {
@@ -681,19 +695,21 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         }
         if constexpr (MODE == 2 && D <= 6) {
             if (a.fb == 2 && ipm) {
-                // pending-pair items: where the pair's record(s) are, their first words, both cell-sorted positions and the boxes its
-                // segment box met (the last four as bytes; 7 = more than four: every box is tried)
+                // items: where the pair's record(s) are, their first words, both cell-sorted positions and ONE box its segment box met
                 const int base = __builtin_amdgcn_readfirstlane(ibase);
-                const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ipm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ipm, 0u));
                 if (iem) {
-                    if (pos < a.icap) {
-                        uint4* const dst = a.pitems + ((long long)(item & (MF_NREG - 1)) * a.icap + pos) * 2;
-                        const uint32_t fhi = for_idx >= 0 ? (uint32_t)((unsigned long long)for_idx >> 32) & 0xffu : 0xffu;
-                        dst[0] = make_uint4((uint32_t)(unsigned long long)own_idx, (uint32_t)(unsigned long long)for_idx,
-                                            ((uint32_t)((unsigned long long)own_idx >> 32) & 0xffu) | (fhi << 8) | ((pc_keep > 4u ? 7u : pc_keep) << 16), pk_keep);
-                        dst[1] = make_uint4((uint32_t)(tile * 64) + ql, jg, own_j, for_j);
-                    } else {
-                        *a.pend_over = 1;
+                    const uint32_t fhi = for_idx >= 0 ? (uint32_t)((unsigned long long)for_idx >> 32) & 0xffu : 0xffu;
+                    const uint32_t w2 = ((uint32_t)((unsigned long long)own_idx >> 32) & 0xffu) | (fhi << 8);
+                    for (int u = 0; u < iunits; ++u) {
+                        const int pos = base + iexcl + u;
+                        if (pos < a.icap) {
+                            uint4* const dst = a.pitems + ((long long)(item & (MF_NREG - 1)) * a.icap + pos) * 2;
+                            const uint32_t kbx = pc_keep > 4u ? 256u : ((pk_keep >> (8 * u)) & 255u);        // (bit 8: every box)
+                            dst[0] = make_uint4((uint32_t)(unsigned long long)own_idx, (uint32_t)(unsigned long long)for_idx, w2, kbx);
+                            dst[1] = make_uint4((uint32_t)(tile * 64) + ql, jg, own_j, for_j);
+                        } else {
+                            *a.pend_over = 1;
+                        }
                     }
                 }
             }

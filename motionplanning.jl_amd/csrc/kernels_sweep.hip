@@ -1082,73 +1082,38 @@ __global__ __launch_bounds__(256, 4) void k_exact_pairs(const uint4* __restrict_
         const int64_t it = blockIdx.x;
         const int n = (int)min((long long)pcnt[it], icap);
         for (int b0 = ((int)blockIdx.y * 4 + wave) * 64; b0 < n; b0 += (int)gridDim.y * 4 * 64) {
-            // 64 pairs at a time (lane = pair); their (pair, box) work units -- one to four per pair -- are laid end to end and taken 64
-            // at a time (lane = unit), so that every lane of a slab test has one to run (a loop over "the k-th box of every pair" ran
-            // at a third of the lanes: 1.5 ms instead of 0.4)
+            // lane = (pair, box) unit: the pair kernel writes one item per box a pair's segment box met (bit 8 of the box word: it met more
+            // than four -- every box is tried).  (Items per PAIR with up to four boxes, their units laid end to end here by a scan and a
+            // search among the lanes, cost 15 dependent lane exchanges per 64 units.)
             const bool on = b0 + lane < n;
             const uint4* __restrict__ src = pitems + (it * icap + min(b0 + lane, n - 1)) * 2;
             const uint4 i0 = src[0], i1 = src[1];
-            const unsigned pc = on ? ((i0.z >> 16) & 7u) : 0u;
-            const int units = (pc <= 4u) ? (int)pc : 0;
-            int incl = units;
+            const int kb = (int)(i0.w & 255u);
+            const bool all = on && (i0.w & 256u) != 0;
+            double q[D], c[D];
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-            const int total = __shfl(incl, 63);
-            const int excl = incl - units;
-            // (the kernel is built for 4 wavefronts per SIMD -- __launch_bounds__(256, 4): left alone the compiler took 150-210 VGPRs for
-            // the slab test's six divisions and the kernel ran latency-bound at two wavefronts per SIMD, 1.6 ms; requesting the next
-            // units' states ahead of the tests cost 24 more registers and gained nothing)
-            struct unit_t { int p; int kb; bool act; };
-            auto request = [&](int t0, unit_t& u, double (&q)[D], double (&c)[D]) {
-                const int t = t0 + lane;
-                u.act = t < total;
-                int p = 0;                                    // the pair lane of unit t: the last lane whose first unit is <= t
+            for (int i = 0; i < D; ++i) q[i] = Xs[(int64_t)i1.x * D + i];
 #pragma unroll
-                for (int step = 32; step > 0; step >>= 1) { const int c2 = p + step; const int e2 = __shfl(excl, c2 & 63); if (c2 < 64 && e2 <= t) p = c2; }
-                u.p = p;
-                const int sl = t - __shfl(excl, p);
-                const uint32_t pk = (uint32_t)__shfl((int)i0.w, p);
-                u.kb = u.act ? (int)((pk >> (8 * (sl & 3))) & 255u) : 0;
-                const uint32_t qpos = (uint32_t)__shfl((int)i1.x, p), cpos = (uint32_t)__shfl((int)i1.y, p);
-#pragma unroll
-                for (int i = 0; i < D; ++i) q[i] = Xs[(int64_t)qpos * D + i];
-#pragma unroll
-                for (int i = 0; i < D; ++i) c[i] = Xs[(int64_t)cpos * D + i];
-            };
-            auto test = [&](const unit_t& u, double (&q)[D], double (&c)[D]) {
-                const box_regs<D> bx = load_box_T<D>(sboxT, u.kb);
-                bool fwd = true, rev = true;                  // own entry: is_free_motion(c, q); foreign entry: is_free_motion(q, c)
+            for (int i = 0; i < D; ++i) c[i] = Xs[(int64_t)i1.y * D + i];
+            bool fwd = true, rev = true;                      // own entry: is_free_motion(c, q); foreign entry: is_free_motion(q, c)
+            {
+                const box_regs<D> bx = load_box_T<D>(sboxT, (on && !all) ? kb : 0);
 #pragma unroll 1
                 for (int dir = 0; dir < 2; ++dir) {           // (one copy of the slab test: the ends change places between the passes)
                     const bool f = narrow_free_sl<D>(c, q, bx);
-                    if (dir == 0) fwd = f; else rev = f;
+                    if (on && !all) { if (dir == 0) fwd = f; else rev = f; }
 #pragma unroll
                     for (int i = 0; i < D; ++i) { const double tt = c[i]; c[i] = q[i]; q[i] = tt; }
                 }
-                const int p = u.p;
-                const uint32_t pz = (uint32_t)__shfl((int)i0.z, p);
-                const uint32_t olo = (uint32_t)__shfl((int)i0.x, p), flo = (uint32_t)__shfl((int)i0.y, p);
-                const uint32_t oj = (uint32_t)__shfl((int)i1.z, p), fj = (uint32_t)__shfl((int)i1.w, p);
-                if (u.act && !fwd) pool[(long long)(((unsigned long long)(pz & 0xffu) << 32) | olo)].j = (int32_t)(oj | 0x80000000u);
-                const unsigned fhi = (pz >> 8) & 0xffu;
-                if (u.act && !rev && fhi != 0xffu) fpool[(long long)(((unsigned long long)fhi << 32) | flo)].j = (int32_t)(fj | 0x80000000u);
-            };
-            for (int t0 = 0; t0 < total; t0 += 64) {
-                unit_t ua;
-                double qa[D], ca[D];
-                request(t0, ua, qa, ca);
-                test(ua, qa, ca);
             }
-            if (__ballot(on && pc > 4u)) {
+            if (__ballot(all)) {
                 // (rare) more than four boxes met: every box, broad phase first, as the reference loops (boxesND.jl:44-51)
-                const bool o = on && pc > 4u;
-                double q[D], c[D], l[D], h[D];
+                double l[D], h[D];
 #pragma unroll
-                for (int i = 0; i < D; ++i) { q[i] = Xs[(int64_t)i1.x * D + i]; c[i] = Xs[(int64_t)i1.y * D + i]; l[i] = fmin(q[i], c[i]); h[i] = fmax(q[i], c[i]); }
-                bool fwd = true, rev = true;
-                for (int kb = 0; kb < M; ++kb) {
-                    const box_regs<D> bx = load_box_T<D>(sboxT, kb);
-                    const bool meet = o && !broadphase_free_sl<D>(l, h, bx);
+                for (int i = 0; i < D; ++i) { l[i] = fmin(q[i], c[i]); h[i] = fmax(q[i], c[i]); }
+                for (int k2 = 0; k2 < M; ++k2) {
+                    const box_regs<D> bx = load_box_T<D>(sboxT, k2);
+                    const bool meet = all && !broadphase_free_sl<D>(l, h, bx);
                     if (__ballot(meet)) {
 #pragma unroll 1
                         for (int dir = 0; dir < 2; ++dir) {
@@ -1159,10 +1124,10 @@ __global__ __launch_bounds__(256, 4) void k_exact_pairs(const uint4* __restrict_
                         }
                     }
                 }
-                if (o && !fwd) pool[(long long)(((unsigned long long)(i0.z & 0xffu) << 32) | (unsigned long long)i0.x)].j = (int32_t)(i1.z | 0x80000000u);
-                const unsigned fhi = (i0.z >> 8) & 0xffu;
-                if (o && !rev && fhi != 0xffu) fpool[(long long)(((unsigned long long)fhi << 32) | (unsigned long long)i0.y)].j = (int32_t)(i1.w | 0x80000000u);
             }
+            if (on && !fwd) pool[(long long)(((unsigned long long)(i0.z & 0xffu) << 32) | (unsigned long long)i0.x)].j = (int32_t)(i1.z | 0x80000000u);
+            const unsigned fhi = (i0.z >> 8) & 0xffu;
+            if (on && !rev && fhi != 0xffu) fpool[(long long)(((unsigned long long)fhi << 32) | (unsigned long long)i0.y)].j = (int32_t)(i1.w | 0x80000000u);
         }
     }
 }

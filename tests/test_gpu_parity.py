@@ -1042,6 +1042,7 @@ def _resident_graph(ctx, N):
     import torch
     from motionplanning_jl_amd.distributed import DevArray
     cp, rv, nz, fr = ctx.graph_device_ptrs()
+    torch.cuda.synchronize()                  # (graph_sweep_device only enqueues on the ctx's own stream; torch copies on another)
     colptr = torch.as_tensor(DevArray(cp, N + 1, "<i8"), device="cuda:0").cpu().numpy()
     nnz = int(colptr[-1])
     if nnz == 0:

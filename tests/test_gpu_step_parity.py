@@ -121,6 +121,29 @@ def test_edge_tests_fused_into_the_half_build(orc, form, d, N, r, M):
 
 
 @pytest.mark.parametrize("form", [2, 1])
+def test_fused_edge_tests_among_many_overlapping_obstacles(orc, form):
+    """256 large boxes (the last id is 255, the most the packed per-lane lists can name): most segments meet more than four of them,
+    which sends them down the every-box paths of k_exact_pairs / k_sweep_pending."""
+    rng = np.random.default_rng(4321)
+    N, d, r, M = 9000, 3, 0.07, 256
+    X = rng.random((N, d))
+    lohi = mp.workloads.make_boxes(rng, M, d, 0.15, 0.35, [])
+    lo, hi = np.full(d, 0.0), np.full(d, 1.0)
+    oc, orow, oval = orc.rdisc_graph(X, r)
+    want = orc.graph_edges_free(X, oc, orow, lohi, lo, hi)
+    with mp.Context(0) as c:
+        c.set_option("fuse_broad", form); c.set_option("rebuild_index", 1)
+        c.upload_samples(X); c.upload_boxes(lohi, lo, hi)
+        forms = []
+        for it in range(3):
+            c.graph_step_device(r)
+            forms.append(c.stat("sweep_form"))
+            colptr, rowval, nzval, free = _resident_graph(c, N)
+            assert np.array_equal(rowval, orow) and np.array_equal(free.view(np.uint64), want), it
+    assert form in forms, forms
+
+
+@pytest.mark.parametrize("form", [2, 1])
 def test_fused_edge_tests_survive_a_list_overflow(orc, form):
     """Option debug_small_lists shrinks the pending lists to 8 items: the kernels that read them return at once, the host finds the
     flag behind its synchronisation and sweeps the whole graph."""
