@@ -456,13 +456,13 @@ def main():
     if dist is not None:
         # one line to diagnose a scaling curve from: every rank's kernel intervals, its shard, and how long its host sat in the
         # gather's _finish (the part of the exchange that did NOT hide behind the next step's kernels)
-        keys = ["grid", "rdisc_count", "pair_kernel", "rdisc_sort", "sweep_graph", "sweep_kernel"]
-        mine = torch.tensor([tm[k][0] for k in keys] + [1e3 * exposed[0] / max(args.steps, 1), 1e3 * exposed[1] / max(args.steps, 1),
-                             float(nnz), float(stats["pairs_tested"])], dtype=torch.float64, device=dev)
+        keys = ["grid", "rdisc_count", "pair_kernel", "exact_pairs", "rdisc_sort", "sweep_graph", "sweep_kernel"]
+        mine = torch.tensor([per_step[k] for k in keys] + [1e3 * exposed[0] / max(args.steps, 1), 1e3 * exposed[1] / max(args.steps, 1),
+                             float(nnz), float(stats["pairs_tested"]), float(edge_form)], dtype=torch.float64, device=dev)
         allv = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(allv, mine)
         allv = allv.cpu().numpy().reshape(world, -1)
-        names = keys + ["gather_exposed_ms", "step_call_ms", "nnz", "pairs_tested"]
+        names = keys + ["gather_exposed_ms", "step_call_ms", "nnz", "pairs_tested", "edge_test_form"]
         out["per_rank"] = {n: {"min": float(allv[:, i].min()), "max": float(allv[:, i].max()), "all": [float(x) for x in allv[:, i]]}
                            for i, n in enumerate(names)}
 
