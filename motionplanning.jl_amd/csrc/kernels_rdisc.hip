@@ -486,8 +486,10 @@ __global__ __launch_bounds__(64) void k_rdisc(rdisc_args a, mpfmt_grid G)
 // degree of each ORIGINAL column = sum over slices of the sorted query's hits
 __global__ void k_degree(const int32_t* __restrict__ slice_cnt, const int32_t* __restrict__ perm, int S, int64_t npad,
                          int64_t pos_begin, int64_t pos_end, int64_t* __restrict__ deg, int64_t* __restrict__ degs,
-                         int32_t* __restrict__ max_deg)
+                         int32_t* __restrict__ max_deg, int64_t N_tail)
 {
+    // (unsharded: the scans' extra last elements are zeroed here instead of by two fill launches)
+    if (N_tail >= 0 && blockIdx.x == 0 && threadIdx.x == 0) { deg[N_tail] = 0; degs[npad] = 0; }
     int64_t s = pos_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t k = 0;
     if (s < pos_end) {
@@ -712,18 +714,27 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     if ((rc = ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (N + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->degs, sizeof(int64_t) * (npad + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->tptr, sizeof(int64_t) * (npad + 1)))) return rc;
-    // 512 pair counters + one word for the longest column (k_degree)
-    if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 514 * sizeof(unsigned long long)));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 514 * sizeof(unsigned long long), ctx->stream));
+    // The small per-build counters live in ONE arena zeroed by ONE fill: 512 pair counters + the longest column's
+    // word (k_degree), the logs' overflow flag, the pending-pair list's region counters + its overflow flag.  (A ctx whose counters
+    // were allocated one by one before -- by the steering spaces' builds -- keeps them and their separate fills.)
+    constexpr size_t ZA_PAIRS = 0, ZA_FLAG = 4128, ZA_PCNT = 4160, ZA_BYTES = 4160 + 4112;
+    if (!ctx->zarena && !ctx->d_pairs && !ctx->pool_flag && !ctx->pair_cnt) {
+        HIPCHK(ctx, hipMalloc((void**)&ctx->zarena, ZA_BYTES));
+        ctx->d_pairs = (unsigned long long*)((char*)ctx->zarena + ZA_PAIRS);
+        ctx->pool_flag = (int32_t*)((char*)ctx->zarena + ZA_FLAG);
+        ctx->pair_cnt = (int32_t*)((char*)ctx->zarena + ZA_PCNT);
+    }
+    if (ctx->zarena) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->zarena, 0, ZA_BYTES, ctx->stream));
+    } else {
+        if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 514 * sizeof(unsigned long long)));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 514 * sizeof(unsigned long long), ctx->stream));
+    }
     if (ctx->world > 1 || nt <= 0) {
         // a shard's k_degree visits its own positions only: everything else must read zero
         HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (N + 1), ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->degs, 0, sizeof(int64_t) * (npad + 1), ctx->stream));
-    } else {
-        // unsharded: k_degree writes every entry but the scans' extra last one
-        HIPCHK(ctx, hipMemsetAsync(ctx->deg + N, 0, sizeof(int64_t), ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->degs + npad, 0, sizeof(int64_t), ctx->stream));
-    }
+    }                                                          // (unsharded: k_degree writes every entry, the scans' extra last ones too)
 
     // single-pass pool: capacity from the last build of the same (N, r), else from the ball-volume estimate
     bool pool = mf && ctx->use_pool && nt > 0;
@@ -751,7 +762,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             if ((rc = ensure(ctx, (void**)&ctx->pool, sizeof(mpfmt_hit) * cap))) return rc;
             if ((rc = ensure(ctx, (void**)&ctx->log_len, sizeof(int32_t) * (size_t)items * 4))) return rc;
             if (!ctx->pool_flag) HIPCHK(ctx, hipMalloc((void**)&ctx->pool_flag, sizeof(int32_t)));
-            HIPCHK(ctx, hipMemsetAsync(ctx->pool_flag, 0, sizeof(int32_t), ctx->stream));
+            if (!ctx->zarena) HIPCHK(ctx, hipMemsetAsync(ctx->pool_flag, 0, sizeof(int32_t), ctx->stream));
             ctx->pool_cap = capc;
             if (half) {
                 // a foreign log can receive up to all the hits of its 16 columns (the last tile finds none itself): S item logs' worth
@@ -783,9 +794,11 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         const double pairs_est = 0.5 * (double)ctx->pool_cap * 4.0 * (double)items / 2.3;        // (the logs' capacity is 2.3x the expected hits)
         ctx->pair_icap = ctx->debug_small_lists ? 8 : (int64_t)(0.75 * pairs_est / 1024.0) + 4096;      // (option debug_small_lists: the overflow path, for the tests)
         if ((rc = ensure(ctx, (void**)&ctx->pair_items, 32 * (size_t)ctx->pair_icap * 1024))) return rc;
-        if ((rc = ensure(ctx, (void**)&ctx->pair_cnt, sizeof(int32_t) * (1024 + 1)))) return rc;
+        if (!ctx->zarena) {
+            if ((rc = ensure(ctx, (void**)&ctx->pair_cnt, sizeof(int32_t) * (1024 + 1)))) return rc;
+            HIPCHK(ctx, hipMemsetAsync(ctx->pair_cnt, 0, sizeof(int32_t) * (1024 + 1), ctx->stream));
+        }
         ctx->pair_over = ctx->pair_cnt + 1024;
-        HIPCHK(ctx, hipMemsetAsync(ctx->pair_cnt, 0, sizeof(int32_t) * (1024 + 1), ctx->stream));
         ctx->bits_in_records = true;
     }
     ctx->pool_valid = false;
@@ -811,7 +824,8 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         const int64_t pb = ctx->tile_begin * 64, pe = ctx->tile_end * 64;
         if (half && (rc = mpfmt_launch_foreign_degrees(ctx))) return rc;
         hipLaunchKernelGGL(k_degree, dim3((unsigned)((pe - pb + B - 1) / B)), dim3(B), 0, ctx->stream,
-                           ctx->slice_cnt, ctx->perm, S + (half ? 1 : 0), npad, pb, pe, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512));
+                           ctx->slice_cnt, ctx->perm, S + (half ? 1 : 0), npad, pb, pe, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512),
+                           (ctx->world > 1 || nt <= 0) ? (int64_t)-1 : N);
     }
     if ((rc = scan_i64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1)))) return rc;      // columns in original order
     // staging offsets in sorted order: only the two-pass forms read them (the single-pass build orders its logs straight into the

@@ -191,6 +191,7 @@ struct mpfmt_ctx {
                                          // caller-order gather (2.29 ms floor), this is the faster mode (2.2 vs 2.65 ms); on by default
     uint64_t* graph_free = nullptr;      // [ceil(nnz/64)]
     bool graph_swept = false;
+    void* zarena = nullptr;              // one arena for d_pairs, pool_flag, pair_cnt (one fill per build); they point into it when it exists
     unsigned long long* d_pairs = nullptr;   // device counter: candidate pairs tested
     int64_t pairs_tested = 0;
 
