@@ -177,6 +177,14 @@ int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const in
  *      Needs the AABB checker; E and rollouts < 2^32. */
 int32_t mpfmt_mc_edges_collision(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double sigma, int64_t rollouts,
                                  uint64_t seed, int64_t* hits);
+/*      Importance-sampling estimator of the same probability (the approach of the papers README.md:9-10 cites): rollouts are drawn from
+ *      an equal mixture of the nominal noise and the noise shifted -- both end points alike, at most 3 sigma per coordinate -- towards
+ *      the closest obstacle point of the segment's midpoint (closest(p, BB, I) of boxesND.jl:61-86 with W = I: a clamp); a colliding
+ *      rollout counts with weight f(y) / (0.5 f(y) + 0.5 f(y - s)), f the product of Irwin-Hall(8) densities.  Weights are quantised to
+ *      2^-40 and summed as integers: estimate = wsum[e] / (rollouts * 2^40), which a scalar loop reproduces exactly (the arithmetic is
+ *      spelled out at k_mc_is_edges, csrc/kernels_sweep.hip).  rollouts < 2^22; the whole obstacle set must fit one LDS stage (M <= 256 at d <= 8). */
+int32_t mpfmt_mc_edges_collision_is(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double sigma, int64_t rollouts,
+                                    uint64_t seed, uint64_t* wsum);
 
 /* ---- Dubins car: DubinsQuasiMetricSpace(r_turn, s, lo, hi) of src/statespaces/simplecars.jl:32-38.
  *      Samples are SE2 states (x, y, theta) (upload_samples with d = 3); obstacles live in the workspace (x, y)

@@ -72,6 +72,7 @@ SYMBOLS = [
                                              c_d_p, c_d_p, C.c_int64, C.c_int32, c_d_p, c_i64_p, c_d_p, c_i64_p,
                                              C.POINTER(FmtResult)]),
     ("mpfmt_mc_edges_collision", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, C.c_int64, C.c_double, C.c_int64, C.c_uint64, c_i64_p]),
+    ("mpfmt_mc_edges_collision_is", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, C.c_int64, C.c_double, C.c_int64, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("mpfmt_dubins_graph_count", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, c_i64_p, c_i64_p]),
     ("mpfmt_dubins_graph_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p]),
     ("mpfmt_dubins_graph_edges_free", C.c_int32, [C.c_void_p, c_u64_p, c_u8_p]),
@@ -553,6 +554,16 @@ class Context:
         hits = np.zeros(max(len(src), 1), dtype=np.int64)
         self._chk(self._L.mpfmt_mc_edges_collision(self._h, _ip(src), _ip(dst), len(src), float(sigma), int(rollouts), int(seed), _ip(hits)))
         return hits[:len(src)]
+
+    def mc_edges_collision_is(self, src, dst, sigma, rollouts, seed=0):
+        """Importance-sampling estimate of the collision probability per edge (1-based src / dst): (probabilities, raw uint64 sums of
+        the colliding rollouts' weights at 2^-40 -- what the scalar loop reproduces exactly)."""
+        src = np.ascontiguousarray(src, dtype=np.int64); dst = np.ascontiguousarray(dst, dtype=np.int64)
+        wsum = np.zeros(max(len(src), 1), dtype=np.uint64)
+        self._chk(self._L.mpfmt_mc_edges_collision_is(self._h, _ip(src), _ip(dst), len(src), float(sigma), int(rollouts), int(seed),
+                                                      wsum.ctypes.data_as(C.POINTER(C.c_uint64))))
+        wsum = wsum[:len(src)]
+        return wsum.astype(np.float64) / (2.0 ** 40) / max(int(rollouts), 1), wsum
 
     # ---- Dubins and Reeds-Shepp cars --------------------------------------------------------------
     def _car_graph(self, car, turn_radius, speed, r):

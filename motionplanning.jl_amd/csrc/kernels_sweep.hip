@@ -1368,6 +1368,170 @@ int32_t mpfmt_launch_mc_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64
     return MPFMT_OK;
 }
 
+// ---- importance-sampling estimator of the same probability (the approach of the papers README.md:9-10 cites) -------------------------
+// Rollouts come from an equal MIXTURE of the nominal noise and the noise shifted towards the closest obstacle point; a colliding
+// rollout counts with its likelihood ratio.  Declared so that a scalar loop reproduces the sums bit for bit (tests/):
+//   m = 0.5 (v + w);  c = clamp(m, lo_k, hi_k) of the box k with the smallest sum_i (c_i - m_i)^2 (first minimum; closest(p, BB, I) of
+//   boxesND.jl:61-86 with W = I);  shift in noise units s_i = clip((c_i - m_i) / sigma, -3, 3), the same for both end points;
+//   rollout k: noise z as above; component bit = Philox(key = seed, counter = (k, e, 2 d, 3)) word 0 & 1;  y = z + bit s;
+//   v' = v + sigma y_v, w' = w + sigma y_w;  hit = !is_free_motion(v', w', CC, SS);
+//   weight = f(y) / (0.5 f(y) + 0.5 f(y - s)),  f = product over the 2 d coordinates of the Irwin-Hall(8) density g at
+//   x = (y * 53509.92 + 262140) / 65536,  g(x) = (1 / 5040) sum_{k<4} (-1)^k C(8, k) max(t - k, 0)^7 at t = min(x, 8 - x);
+//   weights are quantised to 2^-40 and summed as integers (wsum[e]): the order of the sum does not matter.
+#define MC_INV 53509.91992145008
+__device__ __forceinline__ double mc_ih8_pdf(double x)
+{
+    const double t = (x < 8.0 - x) ? x : 8.0 - x;
+    if (!(t > 0.0)) return 0.0;
+    double acc = 0.0;
+    const double cf[4] = {1.0, -8.0, 28.0, -56.0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double u = t - (double)k;
+        if (u > 0.0) {
+            const double u2 = u * u, u4 = u2 * u2, u3 = u2 * u;
+            const double u7 = u4 * u3;
+            const double term = cf[k] * u7;
+            acc = acc + term;
+        }
+    }
+    return acc * (1.0 / 5040.0);
+}
+
+template <int D>
+__global__ __launch_bounds__(SWEEP_THREADS) void k_mc_is_edges(const double* __restrict__ X, const int64_t* __restrict__ src1,
+                                                               const int64_t* __restrict__ dst1, double sigma, int64_t rollouts,
+                                                               int64_t per_block, uint64_t seed, const double* __restrict__ boxes, int M,
+                                                               mpfmt_ss ss, unsigned long long* __restrict__ wsum, int64_t e_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sbox = (double*)smem;
+    __shared__ unsigned long long s_sum;
+    const int lane = threadIdx.x & 63;
+    const int64_t e = blockIdx.x;
+    const int64_t k_begin = (int64_t)blockIdx.y * per_block, k_end = min(rollouts, k_begin + per_block);
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    stage_boxes<D>(sbox, boxes, 0, M);
+    __syncthreads();
+    double v0[D], w0[D], sh[D];
+    const int64_t s = src1[e] - 1, t = dst1[e] - 1;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { v0[i] = X[s * D + i]; w0[i] = X[t * D + i]; sh[i] = 0.0; }
+    // the shift: towards the closest obstacle point of the midpoint (every thread walks the boxes: wave-uniform, first minimum)
+    double best = 0.0; int kbest = -1;
+    for (int k = 0; k < M; ++k) {
+        const double* lo = sbox + (int64_t)k * 2 * D; const double* hi = lo + D;
+        double d2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double sum = v0[i] + w0[i];
+            const double m = 0.5 * sum;
+            const double c = (m < lo[i]) ? lo[i] : ((m > hi[i]) ? hi[i] : m);
+            const double tt0 = c - m, tt = tt0 * tt0;
+            d2 = (i == 0) ? tt : d2 + tt;
+        }
+        if (kbest < 0 || d2 < best) { best = d2; kbest = k; }
+    }
+    if (kbest >= 0 && sigma > 0.0) {
+        const double* lo = sbox + (int64_t)kbest * 2 * D; const double* hi = lo + D;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double sum = v0[i] + w0[i];
+            const double m = 0.5 * sum;
+            const double c = (m < lo[i]) ? lo[i] : ((m > hi[i]) ? hi[i] : m);
+            double q = (c - m) / sigma;
+            q = (q < -3.0) ? -3.0 : ((q > 3.0) ? 3.0 : q);
+            sh[i] = q;
+        }
+    }
+    double ulo[D], uhi[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double reach = (MC_ZMAX + fabs(sh[i])) * sigma;
+        ulo[i] = ((w0[i] < v0[i]) ? w0[i] : v0[i]) - reach;
+        uhi[i] = ((v0[i] < w0[i]) ? w0[i] : v0[i]) + reach;
+    }
+    unsigned long long smask[SWEEP_WORDS];
+    cull_boxes<D>(sbox, M, ulo, uhi, smask, lane);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    unsigned long long mine = 0;
+    for (int64_t kb = k_begin; kb < k_end; kb += SWEEP_THREADS) {
+        const int64_t k = kb + threadIdx.x;
+        const bool act = k < k_end;
+        // component bit: Philox(key = seed, counter = (k, e, 2 D, 3)) word 0 & 1
+        uint32_t c0 = (uint32_t)k, c1 = (uint32_t)(e_off + e), c2 = (uint32_t)(2 * D), c3 = 3u, q0 = k0, q1 = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ q0, n1 = (uint32_t)p1;
+            const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ q1, n3 = (uint32_t)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            q0 += 0x9E3779B9u; q1 += 0xBB67AE85u;
+        }
+        const double bit = (double)(c0 & 1u);
+        double v[D], w[D], yv[D], yw[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double zv = mc_normal(k0, k1, (uint32_t)k, (uint32_t)(e_off + e), (uint32_t)i);
+            const double zw = mc_normal(k0, k1, (uint32_t)k, (uint32_t)(e_off + e), (uint32_t)(D + i));
+            const double shf = bit * sh[i];
+            yv[i] = zv + shf; yw[i] = zw + shf;
+            const double pv = sigma * yv[i], pw = sigma * yw[i];
+            v[i] = v0[i] + pv; w[i] = w0[i] + pw;
+        }
+        bool fr = act && in_state_space_sl<D>(v, ss);
+        if (M > 0) fr = sweep_segment<D>(sbox, smask, v, w, fr);
+        if (act && !fr) {
+            double a = 1.0, b = 1.0;
+#pragma unroll
+            for (int c = 0; c < 2 * D; ++c) {
+                const double yc = (c < D) ? yv[c < D ? c : 0] : yw[c < D ? 0 : c - D];
+                const double sc = sh[c < D ? c : c - D];
+                const double xa = (yc * MC_INV + 262140.0) * (1.0 / 65536.0);
+                const double yb = yc - sc;
+                const double xb = (yb * MC_INV + 262140.0) * (1.0 / 65536.0);
+                a = a * mc_ih8_pdf(xa); b = b * mc_ih8_pdf(xb);
+            }
+            const double den = 0.5 * a + 0.5 * b;
+            const double wgt = (den > 0.0) ? a / den : 0.0;
+            mine += (unsigned long long)(wgt * 1099511627776.0);
+        }
+    }
+    // integer sum: lanes -> wavefront -> workgroup -> edge
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0 && mine) atomicAdd(&s_sum, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum) atomicAdd(&wsum[e], s_sum);
+}
+
+int32_t mpfmt_launch_mc_is_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, double sigma, int64_t rollouts,
+                                 uint64_t seed, unsigned long long* d_wsum)
+{
+    int32_t rc;
+    if ((rc = check_boxes(ctx, ctx->d))) return rc;
+    if (ctx->cc_kind != 0) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the Monte-Carlo evaluator runs against the AABB checker");
+    if (E == 0 || rollouts == 0) return MPFMT_OK;
+    const int d = ctx->d;
+    const int chunk = box_chunk(ctx->M, d, true);
+    if (ctx->M > chunk) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "the importance-sampling estimator stages the whole obstacle set: M <= %d at d = %d", chunk, d);
+    const size_t lds = sweep_lds(std::max(chunk, 1), d);
+    int64_t slices = std::max<int64_t>(1, std::min<int64_t>((rollouts + 4 * SWEEP_THREADS - 1) / (4 * SWEEP_THREADS),
+                                                            std::max<int64_t>(1, (int64_t)ctx->num_cus * 8 / std::max<int64_t>(E, 1))));
+    slices = std::min<int64_t>(slices, 65535);
+    const int64_t per_block = ((rollouts + slices - 1) / slices + SWEEP_THREADS - 1) / SWEEP_THREADS * SWEEP_THREADS;
+    slices = (rollouts + per_block - 1) / per_block;
+    mpfmt_timed tm5(ctx);
+    for (int64_t e0 = 0; e0 < E; e0 += 1 << 20) {
+        const int64_t ne = std::min<int64_t>(E - e0, 1 << 20);
+        DISPATCH_D(d, hipLaunchKernelGGL((k_mc_is_edges<DD>), dim3((unsigned)ne, (unsigned)slices), dim3(SWEEP_THREADS), lds, ctx->stream,
+                                         ctx->Xo, d_src1 + e0, d_dst1 + e0, sigma, rollouts, per_block, seed, ctx->boxes, ctx->M, ctx->ss, d_wsum + e0, e0));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    tm5.end("mc_is_edges");
+    return MPFMT_OK;
+}
+
 // tasks of 16 columns; of 8 when that would leave fewer than ~6 tasks per resident wavefront (a shard of a multi-GPU
 // build, small graphs): finer tasks balance the tail.  One resident set of workgroups.
 template <int D>

@@ -295,6 +295,8 @@ int32_t mpfmt_launch_edges_free(mpfmt_ctx* ctx, const int64_t* d_src1, const int
 int32_t mpfmt_launch_motions_free(mpfmt_ctx* ctx, const double* d_P, const double* d_Q, int64_t n, uint64_t* d_mask);
 int32_t mpfmt_launch_mc_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, double sigma, int64_t rollouts,
                               uint64_t seed, unsigned long long* d_hits);
+int32_t mpfmt_launch_mc_is_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, double sigma, int64_t rollouts,
+                                 uint64_t seed, unsigned long long* d_wsum);
 int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr, int64_t mask_entries = -1);
 
 // kernels_di.hip ----------------------------------------------------------------------------------

@@ -570,6 +570,17 @@ def mc_edges(X, src, dst, sigma, rollouts, seed, lohi, ss_lo=None, ss_hi=None):
     return hits[:len(src)]
 
 
+def mc_is_edges(X, src, dst, sigma, rollouts, seed, lohi, ss_lo=None, ss_hi=None):
+    """Importance-sampling estimator of the same probability: sum of the colliding rollouts' weights, quantised to 2^-40 (uint64)."""
+    X, N, d = _X(X); lohi, M = _boxes(lohi, d)
+    src = np.ascontiguousarray(src, dtype=np.int64); dst = np.ascontiguousarray(dst, dtype=np.int64)
+    wsum = np.zeros(max(len(src), 1), dtype=np.uint64)
+    lib().orc_mc_is_edges(_d(X), C.c_int32(d), _i(src), _i(dst), C.c_int64(len(src)), C.c_double(sigma), C.c_int64(rollouts),
+                          C.c_uint64(seed), _d(lohi), C.c_int32(M), _d(_vec(ss_lo)), _d(_vec(ss_hi)),
+                          wsum.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return wsum[:len(src)]
+
+
 # ---- Reeds-Shepp car (SURVEY 8f N5, second half) ---------------------------------------------------------------------
 def reedsshepp(s1, s2, rt=1.0, sp=1.0):
     """(cost, controls[L][3] = (t, speed, curvature)) of simplecars.jl:265-363."""
