@@ -178,11 +178,12 @@ int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const in
 int32_t mpfmt_mc_edges_collision(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double sigma, int64_t rollouts,
                                  uint64_t seed, int64_t* hits);
 /*      Importance-sampling estimator of the same probability (the approach of the papers README.md:9-10 cites): rollouts are drawn from
- *      an equal mixture of the nominal noise and the noise shifted -- both end points alike, at most 3 sigma per coordinate -- towards
- *      the closest obstacle point of the segment's midpoint (closest(p, BB, I) of boxesND.jl:61-86 with W = I: a clamp); a colliding
- *      rollout counts with weight f(y) / (0.5 f(y) + 0.5 f(y - s)), f the product of Irwin-Hall(8) densities.  Weights are quantised to
- *      2^-40 and summed as integers: estimate = wsum[e] / (rollouts * 2^40), which a scalar loop reproduces exactly (the arithmetic is
- *      spelled out at k_mc_is_edges, csrc/kernels_sweep.hip).  rollouts < 2^22; the whole obstacle set must fit one LDS stage (M <= 256 at d <= 8). */
+ *      a mixture -- half of them from the nominal noise, the rest from the noise shifted (both end points alike, at most 3 sigma per
+ *      coordinate) towards the closest points of the up to three obstacles nearest to the nominal segment (closest(p, BB, I) of
+ *      boxesND.jl:61-86 with W = I -- a clamp -- at five points of the segment); a colliding rollout counts with weight
+ *      f(y) / (0.5 f(y) + sum_j (0.5 / K) f(y - s_j)), f the product of Irwin-Hall(8) densities.  Weights are quantised to 2^-40 and
+ *      summed as integers: estimate = wsum[e] / (rollouts * 2^40), which a scalar loop reproduces exactly (the arithmetic is spelled out
+ *      at k_mc_is_edges, csrc/kernels_sweep.hip).  rollouts < 2^22; the whole obstacle set must fit one LDS stage (M <= 256 at d <= 8). */
 int32_t mpfmt_mc_edges_collision_is(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double sigma, int64_t rollouts,
                                     uint64_t seed, uint64_t* wsum);
 

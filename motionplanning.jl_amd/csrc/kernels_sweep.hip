@@ -1369,16 +1369,19 @@ int32_t mpfmt_launch_mc_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64
 }
 
 // ---- importance-sampling estimator of the same probability (the approach of the papers README.md:9-10 cites) -------------------------
-// Rollouts come from an equal MIXTURE of the nominal noise and the noise shifted towards the closest obstacle point; a colliding
-// rollout counts with its likelihood ratio.  Declared so that a scalar loop reproduces the sums bit for bit (tests/):
-//   m = 0.5 (v + w);  c = clamp(m, lo_k, hi_k) of the box k with the smallest sum_i (c_i - m_i)^2 (first minimum; closest(p, BB, I) of
-//   boxesND.jl:61-86 with W = I);  shift in noise units s_i = clip((c_i - m_i) / sigma, -3, 3), the same for both end points;
-//   rollout k: noise z as above; component bit = Philox(key = seed, counter = (k, e, 2 d, 3)) word 0 & 1;  y = z + bit s;
-//   v' = v + sigma y_v, w' = w + sigma y_w;  hit = !is_free_motion(v', w', CC, SS);
-//   weight = f(y) / (0.5 f(y) + 0.5 f(y - s)),  f = product over the 2 d coordinates of the Irwin-Hall(8) density g at
-//   x = (y * 53509.92 + 262140) / 65536,  g(x) = (1 / 5040) sum_{k<4} (-1)^k C(8, k) max(t - k, 0)^7 at t = min(x, 8 - x);
+// Rollouts come from a MIXTURE of the nominal noise and the noise shifted towards the closest obstacle points; a colliding rollout
+// counts with its likelihood ratio.  Declared so that a scalar loop reproduces the sums bit for bit (tests/):
+//   closest points: for every box k and the five points p_t = v + t (w - v), t = 0, 1/4, 1/2, 3/4, 1, of the nominal segment,
+//     c = clamp(p_t, lo_k, hi_k) (closest(p, BB, I) of boxesND.jl:61-86 with W = I) and d2 = sum_i (c_i - p_t,i)^2; the box keeps its
+//     smallest d2 (first minimum over t); the K = min(3, M) boxes with the smallest d2 (first minima over k) give the shifts, in noise
+//     units and the same for both end points: s_j,i = clip((c_i - p_t,i) / sigma, -3, 3);
+//   rollout k: noise z as above;  Philox(key = seed, counter = (k, e, 2 d, 3)) -> words x0, x1: nominal when x0 & 1 == 0, else shift
+//     j = x1 mod K;  y = z (+ s_j);  v' = v + sigma y_v, w' = w + sigma y_w;  hit = !is_free_motion(v', w', CC, SS);
+//   weight = f(y) / (0.5 f(y) + sum_j (0.5 / K) f(y - s_j)),  f = product over the 2 d coordinates of the Irwin-Hall(8) density g at
+//     x = (y * 53509.92 + 262140) / 65536,  g(x) = (1 / 5040) sum_{k<4} (-1)^k C(8, k) max(t - k, 0)^7 at t = min(x, 8 - x);
 //   weights are quantised to 2^-40 and summed as integers (wsum[e]): the order of the sum does not matter.
 #define MC_INV 53509.91992145008
+#define MC_IS_K 3
 __device__ __forceinline__ double mc_ih8_pdf(double x)
 {
     const double t = (x < 8.0 - x) ? x : 8.0 - x;
@@ -1407,6 +1410,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_mc_is_edges(const double* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sbox = (double*)smem;
     __shared__ unsigned long long s_sum;
+    __shared__ double s_d2[SWEEP_CHUNK];
+    __shared__ int s_bt[SWEEP_CHUNK], s_ch[MC_IS_K];
     const int lane = threadIdx.x & 63;
     const int64_t e = blockIdx.x;
     const int64_t k_begin = (int64_t)blockIdx.y * per_block, k_end = min(rollouts, k_begin + per_block);
@@ -1414,41 +1419,75 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_mc_is_edges(const double* __r
     __syncthreads();
     stage_boxes<D>(sbox, boxes, 0, M);
     __syncthreads();
-    double v0[D], w0[D], sh[D];
+    double v0[D], w0[D];
     const int64_t s = src1[e] - 1, t = dst1[e] - 1;
 #pragma unroll
-    for (int i = 0; i < D; ++i) { v0[i] = X[s * D + i]; w0[i] = X[t * D + i]; sh[i] = 0.0; }
-    // the shift: towards the closest obstacle point of the midpoint (every thread walks the boxes: wave-uniform, first minimum)
-    double best = 0.0; int kbest = -1;
-    for (int k = 0; k < M; ++k) {
+    for (int i = 0; i < D; ++i) { v0[i] = X[s * D + i]; w0[i] = X[t * D + i]; }
+    // every box's closest approach to the five points of the nominal segment (thread = box), then the K closest boxes (thread 0)
+    for (int k = threadIdx.x; k < M; k += blockDim.x) {
         const double* lo = sbox + (int64_t)k * 2 * D; const double* hi = lo + D;
-        double d2 = 0.0;
+        double best = 0.0; int tb = -1;
+        for (int tq = 0; tq < 5; ++tq) {
+            const double tt = 0.25 * (double)tq;
+            double d2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const double sum = v0[i] + w0[i];
-            const double m = 0.5 * sum;
-            const double c = (m < lo[i]) ? lo[i] : ((m > hi[i]) ? hi[i] : m);
-            const double tt0 = c - m, tt = tt0 * tt0;
-            d2 = (i == 0) ? tt : d2 + tt;
+            for (int i = 0; i < D; ++i) {
+                const double df = w0[i] - v0[i], pr = tt * df;
+                const double p = v0[i] + pr;
+                const double c = (p < lo[i]) ? lo[i] : ((p > hi[i]) ? hi[i] : p);
+                const double g = c - p, gg = g * g;
+                d2 = (i == 0) ? gg : d2 + gg;
+            }
+            if (tb < 0 || d2 < best) { best = d2; tb = tq; }
         }
-        if (kbest < 0 || d2 < best) { best = d2; kbest = k; }
+        s_d2[k] = best; s_bt[k] = tb;
     }
-    if (kbest >= 0 && sigma > 0.0) {
-        const double* lo = sbox + (int64_t)kbest * 2 * D; const double* hi = lo + D;
+    __syncthreads();
+    const int K = (M < MC_IS_K) ? M : MC_IS_K;
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < K; ++j) {
+            int kb = -1;
+            for (int k = 0; k < M; ++k) {
+                bool taken = false;
+                for (int q = 0; q < j; ++q) taken = taken || (s_ch[q] == k);
+                if (taken) continue;
+                if (kb < 0 || s_d2[k] < s_d2[kb]) kb = k;
+            }
+            s_ch[j] = kb;
+        }
+    }
+    __syncthreads();
+    double sj[MC_IS_K][D];
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const double sum = v0[i] + w0[i];
-            const double m = 0.5 * sum;
-            const double c = (m < lo[i]) ? lo[i] : ((m > hi[i]) ? hi[i] : m);
-            double q = (c - m) / sigma;
-            q = (q < -3.0) ? -3.0 : ((q > 3.0) ? 3.0 : q);
-            sh[i] = q;
+    for (int j = 0; j < MC_IS_K; ++j) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) sj[j][i] = 0.0;
+        if (j < K) {
+            const int kb = s_ch[j];
+            const double* lo = sbox + (int64_t)kb * 2 * D; const double* hi = lo + D;
+            const double tt = 0.25 * (double)s_bt[kb];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double df = w0[i] - v0[i], pr = tt * df;
+                const double p = v0[i] + pr;
+                const double c = (p < lo[i]) ? lo[i] : ((p > hi[i]) ? hi[i] : p);
+                double q = 0.0;
+                if (sigma > 0.0) {
+                    q = (c - p) / sigma;
+                    q = (q < -3.0) ? -3.0 : ((q > 3.0) ? 3.0 : q);
+                }
+                sj[j][i] = q;
+            }
         }
     }
+    const double cj = (K > 0) ? 0.5 / (double)K : 0.0;
     double ulo[D], uhi[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        const double reach = (MC_ZMAX + fabs(sh[i])) * sigma;
+        double mx = 0.0;
+#pragma unroll
+        for (int j = 0; j < MC_IS_K; ++j) mx = fmax(mx, fabs(sj[j][i]));
+        const double reach = (MC_ZMAX + mx) * sigma;
         ulo[i] = ((w0[i] < v0[i]) ? w0[i] : v0[i]) - reach;
         uhi[i] = ((v0[i] < w0[i]) ? w0[i] : v0[i]) + reach;
     }
@@ -1459,7 +1498,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_mc_is_edges(const double* __r
     for (int64_t kb = k_begin; kb < k_end; kb += SWEEP_THREADS) {
         const int64_t k = kb + threadIdx.x;
         const bool act = k < k_end;
-        // component bit: Philox(key = seed, counter = (k, e, 2 D, 3)) word 0 & 1
+        // component: Philox(key = seed, counter = (k, e, 2 D, 3)) words 0, 1
         uint32_t c0 = (uint32_t)k, c1 = (uint32_t)(e_off + e), c2 = (uint32_t)(2 * D), c3 = 3u, q0 = k0, q1 = k1;
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
@@ -1469,13 +1508,13 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_mc_is_edges(const double* __r
             c0 = n0; c1 = n1; c2 = n2; c3 = n3;
             q0 += 0x9E3779B9u; q1 += 0xBB67AE85u;
         }
-        const double bit = (double)(c0 & 1u);
+        const int comp = (K > 0 && (c0 & 1u)) ? (int)(c1 % (uint32_t)max(K, 1)) : -1;
         double v[D], w[D], yv[D], yw[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             const double zv = mc_normal(k0, k1, (uint32_t)k, (uint32_t)(e_off + e), (uint32_t)i);
             const double zw = mc_normal(k0, k1, (uint32_t)k, (uint32_t)(e_off + e), (uint32_t)(D + i));
-            const double shf = bit * sh[i];
+            const double shf = (comp == 0) ? sj[0][i] : (comp == 1) ? sj[1][i] : (comp == 2) ? sj[2][i] : 0.0;
             yv[i] = zv + shf; yw[i] = zw + shf;
             const double pv = sigma * yv[i], pw = sigma * yw[i];
             v[i] = v0[i] + pv; w[i] = w0[i] + pw;
@@ -1483,17 +1522,30 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_mc_is_edges(const double* __r
         bool fr = act && in_state_space_sl<D>(v, ss);
         if (M > 0) fr = sweep_segment<D>(sbox, smask, v, w, fr);
         if (act && !fr) {
-            double a = 1.0, b = 1.0;
+            double a = 1.0;
 #pragma unroll
             for (int c = 0; c < 2 * D; ++c) {
                 const double yc = (c < D) ? yv[c < D ? c : 0] : yw[c < D ? 0 : c - D];
-                const double sc = sh[c < D ? c : c - D];
                 const double xa = (yc * MC_INV + 262140.0) * (1.0 / 65536.0);
-                const double yb = yc - sc;
-                const double xb = (yb * MC_INV + 262140.0) * (1.0 / 65536.0);
-                a = a * mc_ih8_pdf(xa); b = b * mc_ih8_pdf(xb);
+                a = a * mc_ih8_pdf(xa);
             }
-            const double den = 0.5 * a + 0.5 * b;
+            double den = 0.5 * a;
+#pragma unroll
+            for (int j = 0; j < MC_IS_K; ++j) {
+                if (j < K) {
+                    double b = 1.0;
+#pragma unroll
+                    for (int c = 0; c < 2 * D; ++c) {
+                        const double yc = (c < D) ? yv[c < D ? c : 0] : yw[c < D ? 0 : c - D];
+                        const double yb = yc - sj[j][c < D ? c : c - D];
+                        const double xb = (yb * MC_INV + 262140.0) * (1.0 / 65536.0);
+                        b = b * mc_ih8_pdf(xb);
+                    }
+                    const double tb = cj * b;
+                    den = den + tb;
+                }
+            }
+            if (K == 0) den = a;
             const double wgt = (den > 0.0) ? a / den : 0.0;
             mine += (unsigned long long)(wgt * 1099511627776.0);
         }

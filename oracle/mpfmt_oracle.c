@@ -1928,18 +1928,21 @@ void orc_mc_edges(const double *X, int32_t d, const int64_t *src, const int64_t 
 
 /* ---- Importance-sampling estimator of the same probability ---------------------------------------------
  * The papers README.md:9-10 cites estimate the collision probability of a trajectory under Gaussian-like tracking error by sampling
- * from a MIXTURE: the nominal noise and the noise shifted towards the closest obstacle point, with likelihood-ratio weights.  Declared
- * here so that the scalar loop and the device kernel agree bit for bit:
- *   m = 0.5 (v + w);  closest obstacle point c = clamp(m, lo_k, hi_k) of the box k with the smallest sum_i (c_i - m_i)^2 (first
- *   minimum; closest(p, BB, I) of boxesND.jl:61-86 with W = I is that clamp);  shift in noise units s_i = clip((c_i - m_i) / sigma,
- *   -3, 3), the same for both end points;
- *   rollout k: noise z as in orc_mc_edges;  component bit = Philox(key = seed, counter = (k, e, 2 d, 3)) word 0 & 1;
- *   sample y = z + bit * s;  v' = v + sigma y_v, w' = w + sigma y_w;  hit = !is_free_motion(v', w', CC, SS);
- *   weight = f(y) / (0.5 f(y) + 0.5 f(y - s)),  f = product over the 2 d coordinates of the Irwin-Hall(8) density g at
- *   x = (y * 53509.92 + 262140) / 65536,  g(x) = (1 / 5040) sum_k (-1)^k C(8, k) max(t - k, 0)^7 at t = min(x, 8 - x) (k = 0..3);
+ * from a MIXTURE: the nominal noise and the noise shifted towards the closest obstacle points, with likelihood-ratio weights.
+ * Declared here so that the scalar loop and the device kernel agree bit for bit:
+ *   closest points: for every box k and the five points p_t = v + t (w - v), t = 0, 1/4, 1/2, 3/4, 1, of the nominal segment,
+ *     c = clamp(p_t, lo_k, hi_k) (closest(p, BB, I) of boxesND.jl:61-86 with W = I) and d2 = sum_i (c_i - p_t,i)^2; the box keeps its
+ *     smallest d2 (first minimum over t); the K = min(3, M) boxes with the smallest d2 (first minima over k) give the shifts, in noise
+ *     units and the same for both end points: s_j,i = clip((c_i - p_t,i) / sigma, -3, 3);
+ *   rollout k: noise z as in orc_mc_edges;  Philox(key = seed, counter = (k, e, 2 d, 3)) -> words x0, x1: the rollout is nominal when
+ *     x0 & 1 == 0, else it takes shift j = x1 mod K;  y = z (+ s_j);  v' = v + sigma y_v, w' = w + sigma y_w;
+ *     hit = !is_free_motion(v', w', CC, SS);
+ *   weight = f(y) / (0.5 f(y) + sum_j (0.5 / K) f(y - s_j)),  f = product over the 2 d coordinates of the Irwin-Hall(8) density g at
+ *     x = (y * 53509.92 + 262140) / 65536,  g(x) = (1 / 5040) sum_{k<4} (-1)^k C(8, k) max(t - k, 0)^7 at t = min(x, 8 - x);
  *   the estimate is sum_k hit_k weight_k / rollouts; weights are quantised to 2^-40 and summed as integers (wsum[e]), so the order of
  *   the sum does not matter. */
 #define ORC_MC_INV 53509.91992145008
+#define ORC_IS_K 3
 static double ih8_pdf(double x)
 {
     const double t = (x < 8.0 - x) ? x : 8.0 - x;
@@ -1960,64 +1963,93 @@ static double ih8_pdf(double x)
 void orc_mc_is_edges(const double *X, int32_t d, const int64_t *src, const int64_t *dst, int64_t E, double sigma, int64_t rollouts,
                      uint64_t seed, const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi, uint64_t *wsum)
 {
-    double v[ORC_MAXD], w[ORC_MAXD], s[ORC_MAXD], y[2 * ORC_MAXD];
+    double v[ORC_MAXD], w[ORC_MAXD], s[ORC_IS_K][ORC_MAXD], y[2 * ORC_MAXD];
+    double *bd2 = (double *)malloc(sizeof(double) * (size_t)(M > 0 ? M : 1));
+    int32_t *bt = (int32_t *)malloc(sizeof(int32_t) * (size_t)(M > 0 ? M : 1));
     for (int64_t e = 0; e < E; ++e) {
         const double *v0 = X + (size_t)src[e] * d, *w0 = X + (size_t)dst[e] * d;
-        /* the shift: towards the closest obstacle point of the segment's midpoint */
-        double best = 0.0; int32_t kb = -1;
+        /* every box's closest approach to the five points of the nominal segment */
         for (int32_t k = 0; k < M; ++k) {
             const double *lo = lohi + (size_t)k * 2 * d, *hi = lo + d;
-            double d2 = 0.0;
+            double best = 0.0; int32_t tb = -1;
+            for (int32_t t = 0; t < 5; ++t) {
+                const double tt = 0.25 * (double)t;
+                double d2 = 0.0;
+                for (int32_t i = 0; i < d; ++i) {
+                    const double df = w0[i] - v0[i], pr = tt * df;
+                    const double p = v0[i] + pr;
+                    const double c = (p < lo[i]) ? lo[i] : ((p > hi[i]) ? hi[i] : p);
+                    const double g = c - p, gg = g * g;
+                    d2 = (i == 0) ? gg : d2 + gg;
+                }
+                if (tb < 0 || d2 < best) { best = d2; tb = t; }
+            }
+            bd2[k] = best; bt[k] = tb;
+        }
+        const int32_t K = (M < ORC_IS_K) ? M : ORC_IS_K;
+        int32_t chosen[ORC_IS_K];
+        for (int32_t j = 0; j < K; ++j) {
+            int32_t kb = -1;
+            for (int32_t k = 0; k < M; ++k) {
+                int taken = 0;
+                for (int32_t q = 0; q < j; ++q) taken |= (chosen[q] == k);
+                if (taken) continue;
+                if (kb < 0 || bd2[k] < bd2[kb]) kb = k;
+            }
+            chosen[j] = kb;
+            const double *lo = lohi + (size_t)kb * 2 * d, *hi = lo + d;
+            const double tt = 0.25 * (double)bt[kb];
             for (int32_t i = 0; i < d; ++i) {
-                const double sum = v0[i] + w0[i];
-                const double m = 0.5 * sum;
-                const double c = (m < lo[i]) ? lo[i] : ((m > hi[i]) ? hi[i] : m);
-                const double t = c - m, tt = t * t;
-                d2 = (i == 0) ? tt : d2 + tt;
-            }
-            if (kb < 0 || d2 < best) { best = d2; kb = k; }
-        }
-        for (int32_t i = 0; i < d; ++i) {
-            s[i] = 0.0;
-            if (kb >= 0 && sigma > 0.0) {
-                const double *lo = lohi + (size_t)kb * 2 * d, *hi = lo + d;
-                const double sum = v0[i] + w0[i];
-                const double m = 0.5 * sum;
-                const double c = (m < lo[i]) ? lo[i] : ((m > hi[i]) ? hi[i] : m);
-                double q = (c - m) / sigma;
-                q = (q < -3.0) ? -3.0 : ((q > 3.0) ? 3.0 : q);
-                s[i] = q;
+                const double df = w0[i] - v0[i], pr = tt * df;
+                const double p = v0[i] + pr;
+                const double c = (p < lo[i]) ? lo[i] : ((p > hi[i]) ? hi[i] : p);
+                double q = 0.0;
+                if (sigma > 0.0) {
+                    q = (c - p) / sigma;
+                    q = (q < -3.0) ? -3.0 : ((q > 3.0) ? 3.0 : q);
+                }
+                s[j][i] = q;
             }
         }
+        const double cj = (K > 0) ? 0.5 / (double)K : 0.0;
         uint64_t acc = 0;
         for (int64_t k = 0; k < rollouts; ++k) {
             const uint32_t ctr[4] = {(uint32_t)k, (uint32_t)e, (uint32_t)(2 * d), 3u}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
             uint32_t xw[4];
             orc_philox4x32_10(ctr, key, xw);
-            const double bit = (double)(xw[0] & 1u);
+            const int32_t comp = (K > 0 && (xw[0] & 1u)) ? (int32_t)(xw[1] % (uint32_t)K) : -1;
             for (int32_t c = 0; c < d; ++c) {
                 const double zv = mc_normal(seed, (uint32_t)k, (uint32_t)e, (uint32_t)c);
                 const double zw = mc_normal(seed, (uint32_t)k, (uint32_t)e, (uint32_t)(d + c));
-                const double sh = bit * s[c];
+                const double sh = (comp >= 0) ? s[comp][c] : 0.0;
                 y[c] = zv + sh; y[d + c] = zw + sh;
                 const double pv = sigma * y[c], pw = sigma * y[d + c];
                 v[c] = v0[c] + pv; w[c] = w0[c] + pw;
             }
             if (orc_is_free_motion(v, w, d, lohi, M, ss_lo, ss_hi)) continue;
-            double a = 1.0, b = 1.0;                         /* f(y), f(y - s) up to the common constant */
+            double a = 1.0;                                  /* f(y) up to the common constant */
             for (int32_t c = 0; c < 2 * d; ++c) {
-                const double sc = s[c < d ? c : c - d];
                 const double xa = (y[c] * ORC_MC_INV + 262140.0) * (1.0 / 65536.0);
-                const double yb = y[c] - sc;
-                const double xb = (yb * ORC_MC_INV + 262140.0) * (1.0 / 65536.0);
-                a = a * ih8_pdf(xa); b = b * ih8_pdf(xb);
+                a = a * ih8_pdf(xa);
             }
-            const double den = 0.5 * a + 0.5 * b;
+            double den = 0.5 * a;
+            for (int32_t j = 0; j < K; ++j) {
+                double b = 1.0;                              /* f(y - s_j) */
+                for (int32_t c = 0; c < 2 * d; ++c) {
+                    const double yb = y[c] - s[j][c < d ? c : c - d];
+                    const double xb = (yb * ORC_MC_INV + 262140.0) * (1.0 / 65536.0);
+                    b = b * ih8_pdf(xb);
+                }
+                const double tb = cj * b;
+                den = den + tb;
+            }
+            if (K == 0) den = a;                             /* no obstacle: plain Monte Carlo (nothing can collide anyway) */
             const double wgt = (den > 0.0) ? a / den : 0.0;
             acc += (uint64_t)(wgt * 1099511627776.0);          /* 2^40 */
         }
         wsum[e] = acc;
     }
+    free(bd2); free(bt);
 }
 
 /* ---- Reeds-Shepp space: chopped METRIC (ChoppedMetric, MetricNN): inball(v) = { w : |xy_v - xy_w| <= r, rs(v -> w) <= r } with
