@@ -7,6 +7,7 @@ import torch
 import motionplanning_jl_amd as mp
 from motionplanning_jl_amd.distributed import DevArray
 from oracle import oracle as orc
+FORMS = {}                                                                       # steps by the form of their edge tests (include/mpfmt.h, stat sweep_form)
 def run(budget=60.0, seed=0, maxd=8, max_cases=None):
     rng = np.random.default_rng(seed)
     t0 = time.time(); cases = 0; edges = 0
@@ -21,7 +22,8 @@ def run(budget=60.0, seed=0, maxd=8, max_cases=None):
             X = 0.5 + 0.05 * (X - 0.5)                                          # a tight cluster
         c = rng.random((M, d)); h = 0.02 + 0.2 * rng.random((M, d)) * rng.random()
         lohi = np.stack([c - h, c + h], axis=1) if M else np.zeros((0, 2, d))
-        lo, hi = np.full(d, 0.05 * rng.random()), np.full(d, 1 - 0.05 * rng.random())
+        inset = (rng.random() < 0.5)                                            # (a sample outside the state space keeps the edge tests out of the pair kernel)
+        lo, hi = np.full(d, 0.05 * rng.random() * inset), np.full(d, 1 - 0.05 * rng.random() * inset)
         # radius for a target mean degree
         deg = float(rng.choice([0.5, 5, 40, 150, N]))
         span = X.max(0) - X.min(0) if N > 1 else np.ones(d)
@@ -67,6 +69,7 @@ def run(budget=60.0, seed=0, maxd=8, max_cases=None):
             for rep in range(3):
                 nnz = ctx.graph_step_device(r)
                 assert nnz == len(rowval), ("step nnz", d, N, r, world, rank, rep)
+                FORMS[ctx.stat("sweep_form")] = FORMS.get(ctx.stat("sweep_form"), 0) + 1
                 cp, rv, nz, fr = ctx.graph_device_ptrs()
                 dev = lambda ptr, n, ts: torch.as_tensor(DevArray(ptr, n, ts), device="cuda:0").cpu().numpy()
                 assert np.array_equal(dev(cp, N + 1, "<i8"), colptr - 1), ("step colptr", d, N, r, world, rank, rep)
@@ -84,4 +87,4 @@ if __name__ == "__main__":
     t0 = time.time()
     cases, edges = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
                        int(sys.argv[3]) if len(sys.argv) > 3 else 8)
-    print("stress ok: %d cases, %d edges, %.0f s" % (cases, edges, time.time() - t0))
+    print("stress ok: %d cases, %d edges, %.0f s; steps by edge-test form: %s" % (cases, edges, time.time() - t0, sorted(FORMS.items())))
