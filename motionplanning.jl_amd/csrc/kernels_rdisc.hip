@@ -792,7 +792,8 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         // flag is raised and the host sweeps the whole graph
         const int64_t items = nt * S;
         const double pairs_est = 0.5 * (double)ctx->pool_cap * 4.0 * (double)items / 2.3;        // (the logs' capacity is 2.3x the expected hits)
-        ctx->pair_icap = ctx->debug_small_lists ? 8 : (int64_t)(0.75 * pairs_est / 1024.0) + 4096;      // (option debug_small_lists: the overflow path, for the tests)
+        // (a list that overflowed -- obstacles crowd the flagged pairs into few regions -- doubles the room of the following builds)
+        ctx->pair_icap = ctx->debug_small_lists ? 8 : (int64_t)(0.75 * pairs_est / 1024.0) * ctx->pair_slack + 4096;      // (option debug_small_lists: the overflow path, for the tests)
         if ((rc = ensure(ctx, (void**)&ctx->pair_items, 32 * (size_t)ctx->pair_icap * 1024))) return rc;
         if (!ctx->zarena) {
             if ((rc = ensure(ctx, (void**)&ctx->pair_cnt, sizeof(int32_t) * (1024 + 1)))) return rc;
@@ -871,8 +872,10 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     const bool too_long = rb->max_deg > MPFMT_ORD_MAXDEG;
     if (ctx->half_used && pool && (pool_over || too_long)) {
         // a half build cannot fall back to the fill pass (its counts and lists cover half the pairs): count again, whole
-        // (an overflow may have been a first, unsized estimate: half builds get one more try once a whole build has left its hint)
-        ctx->half_fail += too_long ? 2 : 1;
+        // (an overflow doubles the logs' slack -- the first slices of a half build's lists, the tile's own neighbourhood, find several
+        // times the mean when the lists are cut into many slices -- and the half form is tried again once a whole build has left
+        // its hint; a column too long, or an overflow at the widest slack, ends the tries)
+        if (too_long || ctx->pool_slack >= 8) ctx->half_fail = 2;
         ctx->half_off = true; ctx->half_used = false;
         ctx->lists_r = -1.0;
         if (pool_over && ctx->pool_slack < 8) ctx->pool_slack *= 2;
@@ -958,6 +961,7 @@ static int32_t sweep_checked(mpfmt_ctx* ctx)
         HIPCHK(ctx, hipMemcpyAsync(&over, ctx->pair_over, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (!over) return MPFMT_OK;
+        if (ctx->pair_slack < 8) ctx->pair_slack *= 2;
         ctx->sweep_in_order = false; ctx->graph_swept = false;
         return mpfmt_launch_graph_sweep(ctx);
     }
@@ -1060,6 +1064,7 @@ static int32_t step_finish_inner(mpfmt_ctx* ctx)
         if (!failed && ctx->nnz < ctx->nnz_cap && ctx->pool_valid) {
             ctx->graph_filled = true; ctx->graph_swept = true;      // (finish resets the flags it owns)
             if (ctx->pend_overflowed) {                             // the pending-entry / pending-pair list was cut short: sweep the whole graph
+                if (ctx->sweep_in_order && ctx->pair_slack < 8) ctx->pair_slack *= 2;
                 ctx->pend_valid = false; ctx->sweep_in_order = false; ctx->graph_swept = false;
                 return mpfmt_launch_graph_sweep(ctx);
             }

@@ -147,13 +147,14 @@ struct mpfmt_ctx {
     int32_t* pair_cnt = nullptr;         // [items], then the overflow flag
     int32_t* pair_over = nullptr;
     int64_t pair_icap = 0;
+    int pair_slack = 1;                  // doubled (to 8) by a step whose pending-pair list overflowed
     bool sweep_in_order = false;         // the mask of the resident graph was written by the ordering pass (form 2)
     bool bits_in_records = false;        // this count's blocked edges are marked in the records (bit 31 of the row index)
     int debug_small_lists = 0;           // option (tests): pending lists of 8 items, so that their overflow path runs
     bool want_broad = false;             // set by the step APIs around their count
     bool broad_in_drain = false;         // this count's records carry the broad-phase flag (bit 30 of the row index)
     bool half_used = false;              // the counted graph was built that way
-    int half_fail = 0;                   // half builds that had to be redone whole (2: no more tries)
+    int half_fail = 0;                   // 2: no more half builds (a column too long for the ordering kernel, or an overflow at the widest slack)
     bool half_off = false;               // a half build overflowed / met a column too long for the ordering kernel: whole builds from now on
     bool lists_half = false;             // the cached chunk lists hold only chunks >= the tile
     int cell_fb = 0;                     // position bits below the cell id in cellkey (k_cellkey)
