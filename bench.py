@@ -152,6 +152,10 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="override the sample count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the whole-solve submetric (wavefront FMT*)")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-call submetrics (fresh contexts, outside the timed region)")
+    ap.add_argument("--sample-sets", type=int, default=4,
+                    help="distinct sample sets (same N, r, obstacles; resident in HBM) the steps cycle through: every step builds the "
+                         "graph of NEW samples, as a planner's calls do; 1 = the same samples every step")
     args = ap.parse_args()
 
     one_device = bool(os.environ.get("MPFMT_BENCH_ONE_DEVICE"))
@@ -200,6 +204,13 @@ def main():
             ctx.set_option(opt, int(v))
     ctx.upload_samples(w.X)                       # inputs resident in HBM before the timed region
     ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+    # K sample sets of the same problem, all resident in HBM before the clock starts; step k hands set k mod K to the library by
+    # device pointer (mpfmt_upload_samples_device: one device-to-device copy + the bounding box, inside the timed step) -- a planner
+    # builds one graph per sample set, so no timed step sees the samples of the step before it
+    nsets = max(1, args.sample_sets)
+    sets = [torch.from_numpy(mp.workloads.resample(w, k)).to(dev) for k in range(nsets)] if nsets > 1 else []
+    torch.cuda.synchronize()
+    step_no = [0]
 
     # (one-device functional check: the library's exchange can still run when MPFMT_RCCL_LIB names the tests' shared-memory
     # stand-in for RCCL, tests/mock_rccl -- several ranks on one GPU; never a measurement)
@@ -226,6 +237,10 @@ def main():
         exposed[0] += time.perf_counter() - t
 
     def step():
+        if sets:
+            t_ = sets[step_no[0] % nsets]
+            step_no[0] += 1
+            ctx.upload_samples_device(t_.data_ptr(), w.N, w.d)
         if rccl_abi:
             t = time.perf_counter()
             nnz = ctx.graph_step_device(w.r)      # graph + sweep of this rank's shard
@@ -261,8 +276,10 @@ def main():
     exposed[0] = exposed[1] = 0.0
     t0 = time.perf_counter()
     nnz = 0
+    nnz_sum = 0
     for _ in range(args.steps):
         nnz = step()
+        nnz_sum += nnz
     drain()                                        # the last step's mask is assembled on every rank before the clock stops
     torch.cuda.synchronize()
     if dist is not None:
@@ -272,13 +289,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tn = torch.tensor([nnz], dtype=torch.int64, device=dev)
+        tn = torch.tensor([nnz, nnz_sum], dtype=torch.int64, device=dev)
         dist.all_reduce(tn, op=dist.ReduceOp.SUM)
-        nnz_total = int(tn.item())
+        nnz_total, nnz_sum_total = int(tn[0].item()), int(tn[1].item())
     else:
-        nnz_total = nnz
+        nnz_total, nnz_sum_total = nnz, nnz_sum
 
     ms_step = 1e3 * dt / max(args.steps, 1)
+    nnz_last = nnz
+    nnz = nnz_sum / max(args.steps, 1)               # this rank's mean entries per step: what the per-kernel averages below belong to
     stats = ctx.graph_stats()
     path_used = ctx.stat("rdisc_path_used")
     survivors = ctx.stat("survivors")
@@ -325,7 +344,7 @@ def main():
 
     out = {
         "metric": "edges checked/sec + r-disc queries/sec, FMT* N=1e6 R^6, 1/2/4/8 MI355X",
-        "value": nnz_total * args.steps / dt,
+        "value": nnz_sum_total / dt,                  # edges of every timed step (each step has its own sample set, hence its own nnz)
         "unit": "edges checked/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -336,7 +355,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": w.name, "N": w.N, "d": w.d, "M": w.M, "r": w.r, "nnz": nnz_total,
+        "config": {"workload": w.name, "N": w.N, "d": w.d, "M": w.M, "r": w.r, "nnz": nnz_total, "nnz_mean_per_step": nnz_sum_total / max(args.steps, 1),
+                   "sample_sets": ("%d sets of N i.i.d. samples (stream seeds %d + 1000 k), resident in HBM, one per step in turn "
+                                   "(mpfmt_upload_samples_device inside the timed step); nnz = the last step's" % (nsets, w.seed)) if sets else "the same samples every step",
                    "parallelism": "shard%d" % world,
                    "exchange": ("none" if world == 1 else
                                 "one RCCL all-gather of the free-edge mask per step through the C ABI (mpfmt_allgather_free_mask_*), "
@@ -350,7 +371,10 @@ def main():
                             "the flagged pairs' slab tests in k_exact_pairs, the mask is written by the ordering pass -- no separate sweep kernel" if edge_form == 2 else "")},
         "submetrics": {
             "rdisc_queries_per_s": w.N * args.steps / dt,
-            "edges_checked_per_s_sweep_kernel": (nnz / (sweep_ms * 1e-3)) if sweep_ms > 0 else None,
+            # (form 2: no kernel is "the sweep" -- every edge's broad phase runs inside the pair kernel and k_exact_pairs visits the
+            # flagged (pair, box) units only; dividing all nnz by its time would credit it with work it does not do: ADVICE r3)
+            "edges_checked_per_s_sweep_kernel": ((nnz / (sweep_ms * 1e-3)) if sweep_ms > 0 else None) if edge_form != 2 else None,
+            "exact_pair_units_per_s": (pending_pairs / (tm["exact_pairs"][0] * 1e-3)) if (edge_form == 2 and tm["exact_pairs"][0] > 0) else None,
             "rdisc_queries_per_s_graph_kernels": ((stats["tiles"] * 64) / ((tm["rdisc_count"][0] + tm["rdisc_fill"][0] + sort_ms + per_step["grid"]) * 1e-3))
             if pair_ms > 0 else None,
             "kernel_ms": per_step,
@@ -389,11 +413,12 @@ def main():
             "ordered_pairs_served_tflops": ach_tflops * (2.0 if half_build else 1.0),
             "valu_per_mfma": pk.get("valu_per_mfma"),
             "valu_busy": pk.get("valu_busy"),
+            "mfma_busy": pk.get("mfma_busy"),                # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), from the same PMC run
             "avg_launch_ms": pair_ms,
             "note": "achieved = pairs_tested x 2d algorithmic flop (SURVEY 8d) / kernel time; peak = dense fp16 MFMA "
                     "(the filter runs v_mfma_f32_32x32x%d_f16, %d flop per pair with the norm slots); the kernel is " % (mfma_k, 2 * mfma_k) +
                     "VALU-issue bound: 16 v_alignbit per MFMA read the 1024 accumulator signs (a half-rate VALU class on gfx950, "
-                    "profiles/r03_ubench_valu_classes.txt), the matrix pipe is busy 1/6 of the time; the result is the exact fp64 graph" +
+                    "profiles/r03_ubench_valu_classes.txt), the matrix pipe is busy mfma_busy of the time" + (" (%.3f)" % pk["mfma_busy"] if pk.get("mfma_busy") else " (null: no PMC summary of this build)") + "; the result is the exact fp64 graph" +
                     ("; half build: pairs_tested counts every unordered (tile, chunk) block once -- the kernel does half the distance "
                      "work of the whole build and writes the records of both columns (ordered_pairs_served_tflops = what a whole build "
                      "would have had to evaluate in the same time)" if half_build else "")
@@ -402,7 +427,7 @@ def main():
     # Lane-ops per edge come from the PMC run (SQ_INSTS_VALU x 64 lanes / edges) when the summary matches this build.
     sk = prof.get("exact" if edge_form == 2 else "pending" if edge_form == 1 else "sweep", {})
     valu_per_edge = sk.get("valu_lane_ops_per_edge")
-    valu_frac = (valu_per_edge * nnz / (sweep_ms * 1e-3) / FP64_VALU_LANE_OPS) if (valu_per_edge and sweep_ms > 0) else None
+    valu_frac = (valu_per_edge * nnz / (sweep_ms * 1e-3) / FP64_VALU_LANE_OPS) if (valu_per_edge and sweep_ms > 0 and edge_form != 2) else None
     sorted_rows = os.environ.get("MPFMT_OPT_SWEEP_SORTED", "1") != "0"          # library default: rows gathered from the cell-sorted copy
     ceiling = GATHER_CEILING_L2_ROWS_PER_S if sorted_rows else GATHER_CEILING_ROWS_PER_S
     roof_sweep = {
@@ -421,8 +446,8 @@ def main():
             "real_bound": "instruction issue / latency, not HBM: the counters see a fraction of the algorithmic bytes (traffic_ratio; rows come "
                           "out of L2), the vector ALU issues valu_frac of the unfused fp64 lane-op rate and wait_frac of the wave cycles sit in s_waitcnt",
             "row_gather": "cell-sorted copy Xs by position (L2-friendly)" if sorted_rows else "caller order",
-            "gather_ceiling_edges_per_s": ceiling if d == 6 else None,
-            "frac_of_gather_ceiling": (nnz / (sweep_ms * 1e-3) / ceiling) if (d == 6 and sweep_ms > 0) else None,
+            "gather_ceiling_edges_per_s": ceiling if (d == 6 and edge_form != 2) else None,
+            "frac_of_gather_ceiling": (nnz / (sweep_ms * 1e-3) / ceiling) if (d == 6 and sweep_ms > 0 and edge_form != 2) else None,      # (k_exact_pairs does not gather nnz rows)
             "avg_launch_ms": sweep_ms,
             "note": ("edge tests fused into the half build: algorithmic bytes here = pending pairs x (32-byte item + two states + marks) -- a kernel of "
                      "dependent gathers and fp64 divisions, not a stream; the whole sweep it replaces: " if edge_form == 2 else "") +
@@ -445,6 +470,19 @@ def main():
             "avg_launch_ms": sort_ms,
             "note": "algorithmic bytes per edge = %.3f: one 16-byte hit record in, rowval + nzval%s out" % (sort_bytes_per_edge, " + free bit, both endpoints" if fused else " + rowpos"),
         }
+    # the whole step against HBM: what has to cross it at least once (samples in, CSC + mask out) over the step time, and what the
+    # counters saw cross it summed over EVERY kernel of a step (the hit records alone cross three times: written by the pair kernel,
+    # read and written again by the ordering pass)
+    step_alg_bytes = 8.0 * d * w.N + 16.0 * d * w.M + 8.0 * (w.N + 1) + 12.0 * nnz + nnz / 8.0
+    st = prof.get("step", {})
+    out["roofline_step"] = {
+        "bound": "hbm", "achieved": step_alg_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": step_alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "algorithmic_bytes": step_alg_bytes, "traffic": st.get("bytes"), "traffic_ratio": ratio(st.get("bytes"), step_alg_bytes),
+        "traffic_frac_of_peak": (st["bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if st.get("bytes") else None,
+        "traffic_by_kernel": st.get("by_kernel"), "traffic_source": prof.get("source") if st else None,
+        "note": "algorithmic bytes = samples in (8 d N) + boxes + colptr + 12 B per CSC entry + 1 bit per entry out; traffic = sum over all "
+                "kernels of one step of (FETCH_SIZE x 2 + WRITE_SIZE) from the PMC run, null unless profiles/traffic.json was taken on this build"}
     roofs = {"roofline_rdisc": (pair_ms, roof_rdisc), "roofline_sort": (sort_ms, roof_sort)}
     if not fused:
         roofs["roofline_sweep"] = (sweep_ms, roof_sweep)
@@ -465,6 +503,59 @@ def main():
         names = keys + ["gather_exposed_ms", "step_call_ms", "nnz", "pairs_tested", "edge_test_form"]
         out["per_rank"] = {n: {"min": float(allv[:, i].min()), "max": float(allv[:, i].max()), "all": [float(x) for x in allv[:, i]]}
                            for i, n in enumerate(names)}
+
+    # cold calls (outside the timed region, fresh contexts): what the FIRST call of a planner costs -- every device buffer is
+    # allocated inside it, no size of an earlier build can be taken on trust -- next to the steady-state step above
+    if world == 1 and not args.no_cold and args.workload != "cfg3":
+        try:
+            def wall(f):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                v = f()
+                torch.cuda.synchronize()
+                return 1e3 * (time.perf_counter() - t1), v
+
+            def form_of(c):
+                return {"pair_kernel": c.stat("rdisc_path_used"), "half_build": c.stat("rdisc_half_used"), "edge_test_form": c.stat("sweep_form")}
+            cold = {"what": "fresh mpfmt_ctx each: first_step = the first mpfmt_graph_step_device after the uploads (allocations, careful sizes); "
+                            "second_step = the same call again; new_samples_step = mpfmt_upload_samples_device of another sample set + the step; "
+                            "fmtstar_cold = mpfmt_upload_samples (PCIe) + mpfmt_upload_boxes + mpfmt_fmtstar_wavefront (index, graph, lazy edge tests, "
+                            "recursion on the device, band 0.25 r) -> path; wall clock, one run each (best of 2 fresh contexts)"}
+            best = None
+            for _ in range(2):
+                c2 = mp.Context(0)
+                c2.set_stream(stream.cuda_stream); c2.set_option("rebuild_index", 1)
+                c2.upload_samples(w.X); c2.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+                row = {}
+                row["first_step_ms"], _ = wall(lambda: c2.graph_step_device(w.r)); row["first_step_form"] = form_of(c2)
+                row["second_step_ms"], _ = wall(lambda: c2.graph_step_device(w.r)); row["second_step_form"] = form_of(c2)
+                if sets:
+                    def newstep():
+                        c2.upload_samples_device(sets[1].data_ptr(), w.N, w.d)
+                        return c2.graph_step_device(w.r)
+                    row["new_samples_step_ms"], _ = wall(newstep); row["new_samples_step_form"] = form_of(c2)
+                    row["new_samples_step2_ms"], _ = wall(lambda: (c2.upload_samples_device(sets[2 % nsets].data_ptr(), w.N, w.d), c2.graph_step_device(w.r)))
+                c2.close()
+                if best is None or row["first_step_ms"] < best["first_step_ms"]:
+                    best = row
+            cold.update(best)
+            bs = None
+            for _ in range(2):
+                c3 = mp.Context(0)
+                c3.set_stream(stream.cuda_stream)
+
+                def solve():
+                    c3.upload_samples(w.X); c3.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+                    return c3.fmtstar_wavefront(w.r, mp._lib.GOAL_BALL, w.goal_params(), band=0.25 * w.r, want_tree=False)
+                ms_c, res_c = wall(solve)
+                c3.close()
+                if bs is None or ms_c < bs[0]:
+                    bs = (ms_c, res_c)
+            cold["fmtstar_cold_ms"] = bs[0]; cold["fmtstar_cold_cost"] = bs[1]["cost"]; cold["fmtstar_cold_status"] = bs[1]["status"]
+            cold["first_step_over_steady_step"] = cold["first_step_ms"] / ms_step
+            out["submetrics"]["cold"] = cold
+        except mp.MPFMTError as e:
+            out["submetrics"]["cold"] = {"error": str(e)}
 
     # whole solve (outside the timed region): fmtstar! with the recursion on the device (mpfmt_fmtstar_wavefront) --
     # what a planner call costs end to end, next to the eager step above

@@ -32,6 +32,10 @@
 extern "C" {
 #endif
 
+/* every export carries default visibility; the library itself is built with -fvisibility=hidden, so nothing else (C++ helpers,
+ * kernel launch stubs) is visible to a process that loads it beside other HIP libraries */
+#define MPFMT_API __attribute__((visibility("default")))
+
 #define MPFMT_OK              0
 #define MPFMT_ERR_ARG        -1   /* bad argument (null pointer, dimension out of range, index out of range) */
 #define MPFMT_ERR_STATE      -2   /* call out of order (e.g. fill before count, sweep before boxes) */
@@ -54,27 +58,32 @@ typedef struct mpfmt_ctx mpfmt_ctx;
 /* ---- context ------------------------------------------------------------------------------------- */
 
 /* device = HIP device ordinal (one ctx per GPU; one process per GPU in multi-GPU runs). */
-int32_t mpfmt_ctx_create(int32_t device, mpfmt_ctx** out);
-int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx);
-const char* mpfmt_last_error(const mpfmt_ctx* ctx);
+MPFMT_API int32_t mpfmt_ctx_create(int32_t device, mpfmt_ctx** out);
+MPFMT_API int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx);
+MPFMT_API const char* mpfmt_last_error(const mpfmt_ctx* ctx);
 /* Version string of the library build ("mpfmt <semver> gfx950"). */
-const char* mpfmt_version(void);
+MPFMT_API const char* mpfmt_version(void);
 /* Launch on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream. */
-int32_t mpfmt_set_stream(mpfmt_ctx* ctx, void* hip_stream);
+MPFMT_API int32_t mpfmt_set_stream(mpfmt_ctx* ctx, void* hip_stream);
 /* Multi-GPU: this ctx owns shard `rank` of `world` (contiguous ranges of the library's cell-sorted
  * sample order).  Graph build / sweep then only produce the columns of the shard.  Default (0,1). */
-int32_t mpfmt_set_shard(mpfmt_ctx* ctx, int32_t rank, int32_t world);
+MPFMT_API int32_t mpfmt_set_shard(mpfmt_ctx* ctx, int32_t rank, int32_t world);
 
 /* ---- index build: helper_data_structures(V, dist) (src/nearneighbors.jl:95-100,
  *      src/statespaces/geometric.jl:14) called by MetricNN(V, dist, init) (src/nearneighbors.jl:70-74)
  *      every time addpoints runs (src/sampling.jl:43). --------------------------------------------- */
-int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t d);
+MPFMT_API int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t d);
+/* The same for a sample set that already lives in HBM of ctx's device (dX = device pointer, same d x N column-major layout): a batch
+ * produced on the device -- the library's sampler (mpfmt_sample_free leaves its set in ctx already), a ROCArray -- becomes the
+ * SampleSet of the next index build (addpoints, src/nearneighbors.jl:108-109) without crossing PCIe.  One device-to-device copy;
+ * the set's bounding box and the finiteness check run on the device. */
+MPFMT_API int32_t mpfmt_upload_samples_device(mpfmt_ctx* ctx, const double* dX, int64_t N, int32_t d);
 
 /* ---- collision checker: PointRobotNDBoxes(boxes) (src/collisioncheckers/boxesND.jl:15-23) and the
  *      BoundedStateSpace bounds used by in_state_space (src/statespaces.jl:29-34,150).
  *      ss_lo/ss_hi: d_state doubles each, or both NULL (no bounds test).
  *      dw = workspace dimension (Identity s2w: dw == d). ------------------------------------------- */
-int32_t mpfmt_upload_boxes(mpfmt_ctx* ctx, const double* lohi, int32_t M, int32_t dw,
+MPFMT_API int32_t mpfmt_upload_boxes(mpfmt_ctx* ctx, const double* lohi, int32_t M, int32_t dw,
                            const double* ss_lo, const double* ss_hi, int32_t d_state);
 
 /* ---- r-disc neighbour graph = ImmutableNNC(D::SparseMatrixCSC, r) (src/nearneighbors.jl:23-27):
@@ -83,13 +92,13 @@ int32_t mpfmt_upload_boxes(mpfmt_ctx* ctx, const double* lohi, int32_t M, int32_
  *        count: colptr[N+1] (1-based, colptr[1] == 1), *nnz = colptr[N+1]-1
  *        fill : rowval[nnz] (1-based, strictly ascending inside a column, self excluded), nzval[nnz].
  *      With a shard set, only the shard's columns are non-empty. ------------------------------------ */
-int32_t mpfmt_rdisc_count(mpfmt_ctx* ctx, double r, int64_t* colptr, int64_t* nnz);
-int32_t mpfmt_rdisc_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval);
+MPFMT_API int32_t mpfmt_rdisc_count(mpfmt_ctx* ctx, double r, int64_t* colptr, int64_t* nnz);
+MPFMT_API int32_t mpfmt_rdisc_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval);
 
 /* One query = inball(V, dist, DS, v, r, forwards) (src/nearneighbors.jl:179-183), the MutableNNC
  * cache-miss path (src/nearneighbors.jl:129-135).  v 1-based.  *k = neighbour count; at most cap
  * entries are written (MPFMT_ERR_CAPACITY if k > cap, *k still set). */
-int32_t mpfmt_rdisc_query(mpfmt_ctx* ctx, int64_t v, double r, int64_t* inds, double* ds, int64_t cap, int64_t* k);
+MPFMT_API int32_t mpfmt_rdisc_query(mpfmt_ctx* ctx, int64_t v, double r, int64_t* inds, double* ds, int64_t cap, int64_t* k);
 
 /* ---- batch validity ------------------------------------------------------------------------------
  * points_free: bit e = is_free_state(V[idx[e]], CC, SS) (src/statespaces.jl:151-152,
@@ -99,19 +108,19 @@ int32_t mpfmt_rdisc_query(mpfmt_ctx* ctx, int64_t v, double r, int64_t* inds, do
  *              src/collisioncheckers/boxesND.jl:26,44-56); src = parent first (src/planners/fmt.jl:75).
  * graph_edges_free: the same over every stored graph entry, CSC order: entry e in column x with
  *              row y  <->  is_free_motion(V[y], V[x]).  mask has ceil(nnz/64) words. */
-int32_t mpfmt_points_free(mpfmt_ctx* ctx, const int64_t* idx, int64_t n, uint64_t* mask);
-int32_t mpfmt_edges_free(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, uint64_t* mask);
-int32_t mpfmt_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask);
+MPFMT_API int32_t mpfmt_points_free(mpfmt_ctx* ctx, const int64_t* idx, int64_t n, uint64_t* mask);
+MPFMT_API int32_t mpfmt_edges_free(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, uint64_t* mask);
+MPFMT_API int32_t mpfmt_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask);
 /* Same three on explicit points (not sample indices): P = d x n column-major; Q likewise (segment ends).
  * is_free_state(v, CC, SS) / is_free_motion(v, w, CC, SS) for states that are not samples
  * (sampler candidates src/sampling.jl:25, shortcut segments src/postprocessors.jl:6-39). */
-int32_t mpfmt_states_free(mpfmt_ctx* ctx, const double* P, int64_t n, uint64_t* mask);
-int32_t mpfmt_motions_free(mpfmt_ctx* ctx, const double* P, const double* Q, int64_t n, uint64_t* mask);
+MPFMT_API int32_t mpfmt_states_free(mpfmt_ctx* ctx, const double* P, int64_t n, uint64_t* mask);
+MPFMT_API int32_t mpfmt_motions_free(mpfmt_ctx* ctx, const double* P, const double* Q, int64_t n, uint64_t* mask);
 /* is_free_path(p, CC, SS) = @all [is_free_motion(p[i], p[i+1], CC, SS)] (src/statespaces.jl:159-160) for a path of n states
  * P = d x n column-major: *free_out = 1 / 0; seg_mask (may be NULL) gets the n-1 segment bits.  (The reference's box-list
  * method iterates 1:length(BL)-1 instead of the path length, src/collisioncheckers/boxesND.jl:57 -- a bug that is not
  * reproduced: every segment is tested.)  A path of fewer than 2 states is free. */
-int32_t mpfmt_path_free(mpfmt_ctx* ctx, const double* P, int64_t n, int32_t* free_out, uint64_t* seg_mask);
+MPFMT_API int32_t mpfmt_path_free(mpfmt_ctx* ctx, const double* P, int64_t n, int32_t* free_out, uint64_t* seg_mask);
 
 /* ---- Euclidean per-edge steer, src/statespaces/geometric.jl:18-19, batched over E edges src[e] -> dst[e]
  *      (1-based sample indices):
@@ -121,8 +130,8 @@ int32_t mpfmt_path_free(mpfmt_ctx* ctx, const double* P, int64_t n, int32_t* fre
  *        euclid_propagate : propagate(M::Euclidean, v, u::StepControl) = v + u.t * u.u from v = V[src[e]]; with s != NULL the
  *                           partial form of src/statespaces.jl:79-81: s[e] <= 0 -> v, s[e] >= t[e] -> full step, else v + s[e] * u.
  *      collision_waypoints(::Euclidean, v, w) = (v, w) (geometric.jl:20) is what mpfmt_edges_free sweeps. */
-int32_t mpfmt_euclid_steer(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double* t, double* u);
-int32_t mpfmt_euclid_propagate(mpfmt_ctx* ctx, const int64_t* src, int64_t E, const double* t, const double* u, const double* s,
+MPFMT_API int32_t mpfmt_euclid_steer(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double* t, double* u);
+MPFMT_API int32_t mpfmt_euclid_propagate(mpfmt_ctx* ctx, const int64_t* src, int64_t E, const double* t, const double* u, const double* s,
                                double* out);
 
 /* ---- batch expand: the body of the FMT* loop (src/planners/fmt.jl:70-82) for a set of z.
@@ -131,7 +140,7 @@ int32_t mpfmt_euclid_propagate(mpfmt_ctx* ctx, const int64_t* src, int64_t E, co
  *        free  = is_free_motion(V[y_min], V[x], CC, SS)                              (fmt.jl:75)
  *      Results are reported sorted by x ascending.  W,H,F: N-bit masks; C: N doubles; zs 1-based.
  *      Requires a built graph (mpfmt_rdisc_count).  xs/ymin/cmin/free_out need capacity cap. */
-int32_t mpfmt_expand(mpfmt_ctx* ctx, const uint64_t* W, const uint64_t* H, const uint64_t* F, const double* C,
+MPFMT_API int32_t mpfmt_expand(mpfmt_ctx* ctx, const uint64_t* W, const uint64_t* H, const uint64_t* F, const double* C,
                      const int64_t* zs, int64_t nz,
                      int64_t* xs, int64_t* ymin, double* cmin, uint8_t* free_out, int64_t cap, int64_t* nx);
 
@@ -153,7 +162,7 @@ typedef struct {
     double  ms_host_loop;      /* host time: sequential FMT* recursion */
 } mpfmt_fmt_result;
 
-int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts,
+MPFMT_API int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts,
                       int32_t goal_kind, const double* goal_params,
                       int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
@@ -163,7 +172,7 @@ int32_t mpfmt_fmtstar(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkp
  * bitmap over samples (NULL: checkpts = false), ss_lo/ss_hi = state-space bounds (both NULL: none).  init_idx is 1-based;
  * A / path are 1-based like mpfmt_fmtstar's; res gets status, cost, z, collision_checks, path_len, nnz.
  * mpfmt_fmtstar = graph_build_device + graph_sweep_device + this. */
-int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const int64_t* colptr, const int32_t* rowval,
+MPFMT_API int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const int64_t* colptr, const int32_t* rowval,
                                  const double* nzval, const uint64_t* efree, const uint64_t* F, const double* ss_lo,
                                  const double* ss_hi, int64_t init_idx, int32_t goal_kind, const double* goal_params,
                                  int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
@@ -175,7 +184,7 @@ int32_t mpfmt_host_fmt_recursion(int64_t N, int32_t d, const double* X, const in
  *      Irwin-Hall(8) variate built from the halfwords of Philox4x32-10(key = seed, counter = (rollout, edge, coordinate, 2))
  *      -- integer sums and unfused fp64 only, so a scalar loop reproduces hits[e] (colliding rollouts) exactly.
  *      Needs the AABB checker; E and rollouts < 2^32. */
-int32_t mpfmt_mc_edges_collision(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double sigma, int64_t rollouts,
+MPFMT_API int32_t mpfmt_mc_edges_collision(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double sigma, int64_t rollouts,
                                  uint64_t seed, int64_t* hits);
 /*      Importance-sampling estimator of the same probability (the approach of the papers README.md:9-10 cites): rollouts are drawn from
  *      a mixture -- half of them from the nominal noise, the rest from the noise shifted (both end points alike, at most 3 sigma per
@@ -184,7 +193,7 @@ int32_t mpfmt_mc_edges_collision(mpfmt_ctx* ctx, const int64_t* src, const int64
  *      f(y) / (0.5 f(y) + sum_j (0.5 / K) f(y - s_j)), f the product of Irwin-Hall(8) densities.  Weights are quantised to 2^-40 and
  *      summed as integers: estimate = wsum[e] / (rollouts * 2^40), which a scalar loop reproduces exactly (the arithmetic is spelled out
  *      at k_mc_is_edges, csrc/kernels_sweep.hip).  rollouts < 2^22; the whole obstacle set must fit one LDS stage (M <= 256 at d <= 8). */
-int32_t mpfmt_mc_edges_collision_is(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double sigma, int64_t rollouts,
+MPFMT_API int32_t mpfmt_mc_edges_collision_is(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double sigma, int64_t rollouts,
                                     uint64_t seed, uint64_t* wsum);
 
 /* ---- Dubins car: DubinsQuasiMetricSpace(r_turn, s, lo, hi) of src/statespaces/simplecars.jl:32-38.
@@ -201,12 +210,12 @@ int32_t mpfmt_mc_edges_collision_is(mpfmt_ctx* ctx, const int64_t* src, const in
  *      sin / cos / atan2 / acos are the library's own (csrc/mp_math.h: fixed reductions and polynomials from + - * / sqrt), the
  *      same header the CPU oracle compiles: graphs, masks and costs are bit-identical to the oracle's; against a libm-based
  *      host (Julia) costs agree to ~1e-15 relative. */
-int32_t mpfmt_dubins_graph_count(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz);
-int32_t mpfmt_dubins_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval);
-int32_t mpfmt_dubins_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg);
-int32_t mpfmt_dubins_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, double turn_radius, double speed,
+MPFMT_API int32_t mpfmt_dubins_graph_count(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz);
+MPFMT_API int32_t mpfmt_dubins_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval);
+MPFMT_API int32_t mpfmt_dubins_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg);
+MPFMT_API int32_t mpfmt_dubins_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, double turn_radius, double speed,
                            double* cost, double* controls);
-int32_t mpfmt_dubins_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+MPFMT_API int32_t mpfmt_dubins_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
                              int32_t goal_kind, const double* goal_params, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
 /* ---- Reeds-Shepp car: ReedsSheppMetricSpace(r_turn, s, lo, hi) of src/statespaces/simplecars.jl:29-34 --
@@ -222,12 +231,12 @@ int32_t mpfmt_dubins_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, d
  *             are zero (nsegs may be NULL).
  *      reedsshepp_fmtstar : fmtstar! in this space (the symmetric recursion of fmt.jl:36-100); workspace goals act on
  *             (x, y), MPFMT_GOAL_POINT takes a whole state (3 doubles). */
-int32_t mpfmt_reedsshepp_graph_count(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz);
-int32_t mpfmt_reedsshepp_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval);
-int32_t mpfmt_reedsshepp_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg);
-int32_t mpfmt_reedsshepp_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, double turn_radius, double speed,
+MPFMT_API int32_t mpfmt_reedsshepp_graph_count(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t* colptr, int64_t* nnz);
+MPFMT_API int32_t mpfmt_reedsshepp_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval);
+MPFMT_API int32_t mpfmt_reedsshepp_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg);
+MPFMT_API int32_t mpfmt_reedsshepp_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, double turn_radius, double speed,
                                double* cost, double* controls, int32_t* nsegs);
-int32_t mpfmt_reedsshepp_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+MPFMT_API int32_t mpfmt_reedsshepp_fmtstar(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
                                  int32_t goal_kind, const double* goal_params, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
 /* ---- Closest obstacle points in a Mahalanobis metric: closest(p, CC, W) / closeR(p, CC, W, r2) of
@@ -246,9 +255,9 @@ int32_t mpfmt_reedsshepp_fmtstar(mpfmt_ctx* ctx, double turn_radius, double spee
  *             left out of the minimum / the lists; for circles, pairs whose multiplier iteration (SAT2D.jl:222-235,
  *             unbounded in the reference) has not ended after 200 Newton steps.
  *      Values agree with the reference's LAPACK route (QR least squares, eigfact) to rounding, not bit for bit. */
-int32_t mpfmt_closest(mpfmt_ctx* ctx, const double* P, int64_t n, const double* W, double* d2min, double* vmin, int64_t* kmin,
+MPFMT_API int32_t mpfmt_closest(mpfmt_ctx* ctx, const double* P, int64_t n, const double* W, double* d2min, double* vmin, int64_t* kmin,
                       int64_t* failures);
-int32_t mpfmt_closeR(mpfmt_ctx* ctx, const double* P, int64_t n, const double* W, double r2, int64_t* ptr, int64_t cap,
+MPFMT_API int32_t mpfmt_closeR(mpfmt_ctx* ctx, const double* P, int64_t n, const double* W, double r2, int64_t* ptr, int64_t cap,
                      int64_t* obstacle, double* d2, double* v, int64_t* total, int64_t* failures);
 
 /* ---- 2-D SAT world: PointRobot2D(Compound2D(parts)) of src/collisioncheckers/robots2D.jl:12-14 and
@@ -263,14 +272,14 @@ int32_t mpfmt_closeR(mpfmt_ctx* ctx, const double* P, int64_t n, const double* W
  *      Nested Compound2D parts are not represented: flatten them (every basic test starts with its own AABB check). */
 #define MPFMT_SHAPE_CIRCLE  0
 #define MPFMT_SHAPE_POLYGON 1
-int32_t mpfmt_upload_shapes2d(mpfmt_ctx* ctx, int32_t n_shapes, const int32_t* kinds, const int32_t* nverts, const double* data,
+MPFMT_API int32_t mpfmt_upload_shapes2d(mpfmt_ctx* ctx, int32_t n_shapes, const int32_t* kinds, const int32_t* nverts, const double* data,
                               const double* ss_lo, const double* ss_hi);
 /* The 2-D SAT world under a steering space (the notebook's double-integrator and Dubins examples, docs/MotionPlanning.ipynb cells 7-11:
  * PointRobot2D with DoubleIntegrator(2) / DubinsQuasiMetricSpace): upload the shapes (workspace bounds), then the state-space
  * bounds of the steering space (4 for the double integrator, 3 for SE2; src/statespaces.jl:29-34, in_state_space :150).  The
  * steering sweeps (mpfmt_di_graph_edges_free, mpfmt_dubins_ / mpfmt_reedsshepp_graph_edges_free, the *_fmtstar calls) then test
  * their workspace segments with is_free_motion(v, w, CC::PointRobot2D) (robots2D.jl:13-14). */
-int32_t mpfmt_set_state_bounds(mpfmt_ctx* ctx, const double* ss_lo, const double* ss_hi, int32_t d_state);
+MPFMT_API int32_t mpfmt_set_state_bounds(mpfmt_ctx* ctx, const double* ss_lo, const double* ss_hi, int32_t d_state);
 
 /* ---- graph persistence: install a graph exported earlier by mpfmt_rdisc_count / mpfmt_rdisc_fill (same
  *      1-based CSC: colptr[N+1], rowval[nnz] strictly ascending per column, nzval[nnz]) for the samples now uploaded --
@@ -278,7 +287,7 @@ int32_t mpfmt_set_state_bounds(mpfmt_ctx* ctx, const double* ss_lo, const double
  *      Afterwards mpfmt_graph_edges_free / mpfmt_graph_sweep_device / mpfmt_expand / mpfmt_fmtstar(r) use it without
  *      running the pair phase (mpfmt_fmtstar reuses any filled graph of the same radius).  The arrays are validated
  *      (monotone colptr, rows in range, ascending, no self loops); distances are taken as given. */
-int32_t mpfmt_graph_import(mpfmt_ctx* ctx, double r, const int64_t* colptr, const int64_t* rowval, const double* nzval);
+MPFMT_API int32_t mpfmt_graph_import(mpfmt_ctx* ctx, double r, const int64_t* colptr, const int64_t* rowval, const double* nzval);
 
 /* ---- batch free-space sampler: sample_free!(P, N, true; ensure_goal_ct) of src/sampling.jl:11-45 with
  *      the rejection loop (sample_space, statespaces.jl:40; is_free_state, statespaces.jl:151-152) run in batches on the
@@ -293,9 +302,9 @@ int32_t mpfmt_graph_import(mpfmt_ctx* ctx, double r, const int64_t* colptr, cons
  *      sample_free_biased adds the goal_bias keyword (sampling.jl:11,28-30): each accepted sample is replaced by a free goal
  *      sample with probability goal_bias -- the decision for the k-th accepted sample is the uniform (seed, k) of a third
  *      stream, the replacements take free goal samples in stream order, before the ensure_goal tail does. */
-int32_t mpfmt_sample_free(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double* init, int32_t goal_kind,
+MPFMT_API int32_t mpfmt_sample_free(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double* init, int32_t goal_kind,
                           const double* goal_params, int32_t goal_ct, double* X_out, int64_t* attempts);
-int32_t mpfmt_sample_free_biased(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double* init, int32_t goal_kind,
+MPFMT_API int32_t mpfmt_sample_free_biased(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const double* init, int32_t goal_kind,
                                  const double* goal_params, int32_t goal_ct, double goal_bias, double* X_out, int64_t* attempts);
 
 /* ---- double-integrator (LinearQuadratic quasi-metric) space: DoubleIntegrator(m; vmax, r=rho)
@@ -314,12 +323,12 @@ int32_t mpfmt_sample_free_biased(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const
  *      di_steer : batch steer(L, x0, x1, r) -> (cost, t*) (:191-195) on explicit pairs, X0/X1 = 2m x n col-major.
  *      di_fmtstar : fmtstar! (src/planners/fmt.jl:3-119) over that graph; POINT goal = StateGoal (exact state,
  *             src/goals.jl:128-131), RECT/BALL act on the workspace coordinates. */
-int32_t mpfmt_di_graph_count(mpfmt_ctx* ctx, double rho, double r, int64_t* colptr, int64_t* nnz);
-int32_t mpfmt_di_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval, double* tval);
-int32_t mpfmt_di_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg);
-int32_t mpfmt_di_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, int32_t m, double rho, double r,
+MPFMT_API int32_t mpfmt_di_graph_count(mpfmt_ctx* ctx, double rho, double r, int64_t* colptr, int64_t* nnz);
+MPFMT_API int32_t mpfmt_di_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* nzval, double* tval);
+MPFMT_API int32_t mpfmt_di_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg);
+MPFMT_API int32_t mpfmt_di_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, int32_t m, double rho, double r,
                        double* cost, double* topt);
-int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx, int32_t checkpts,
+MPFMT_API int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx, int32_t checkpts,
                          int32_t goal_kind, const double* goal_params,
                          int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 
@@ -329,8 +338,8 @@ int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx,
  * graph_sweep_device: per-edge free mask of the resident graph into HBM.
  * Pointers to the resident arrays (device addresses, valid until the next build / ctx destroy):
  *   colptr int64[N+1] 0-based offsets, rowval int32[nnz] 0-based, nzval double[nnz], free uint64[ceil(nnz/64)]. */
-int32_t mpfmt_graph_build_device(mpfmt_ctx* ctx, double r, int64_t* nnz);
-int32_t mpfmt_graph_sweep_device(mpfmt_ctx* ctx);
+MPFMT_API int32_t mpfmt_graph_build_device(mpfmt_ctx* ctx, double r, int64_t* nnz);
+MPFMT_API int32_t mpfmt_graph_sweep_device(mpfmt_ctx* ctx);
 /* graph_step_device: graph_build_device + graph_sweep_device as ONE call with one host synchronisation -- the planner's
  * whole step (fmt.jl:70-75's neighbour sets and edge checks for every sample).  The two-call form needs the host between
  * its kernels (nnz sizes the CSC and the mask).  When the previous step of the same (N, r, shard) took the single-pass
@@ -338,17 +347,17 @@ int32_t mpfmt_graph_sweep_device(mpfmt_ctx* ctx);
  * that did not hold, validates after the synchronisation and transparently redoes the step the careful way if needed.
  * Results are identical to the two-call form and complete in HBM when the call returns (graph_sweep_device, by contrast,
  * only enqueues its kernel on the ctx's stream). */
-int32_t mpfmt_graph_step_device(mpfmt_ctx* ctx, double r, int64_t* nnz);
+MPFMT_API int32_t mpfmt_graph_step_device(mpfmt_ctx* ctx, double r, int64_t* nnz);
 /* The same step in two calls, for ONE host thread that drives several ctxs (a Julia process holding one ctx per GPU, SURVEY
  * 8e): _launch issues the step's kernels and returns without waiting when the previous step's sizes can be trusted (otherwise
  * it runs the careful form to completion), _finish makes the one synchronisation, validates and repairs.  graph_step_device
  * = _launch + _finish. */
-int32_t mpfmt_graph_step_launch(mpfmt_ctx* ctx, double r);
-int32_t mpfmt_graph_step_finish(mpfmt_ctx* ctx, int64_t* nnz);
-int32_t mpfmt_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** rowval, void** nzval, void** free_mask);
+MPFMT_API int32_t mpfmt_graph_step_launch(mpfmt_ctx* ctx, double r);
+MPFMT_API int32_t mpfmt_graph_step_finish(mpfmt_ctx* ctx, int64_t* nnz);
+MPFMT_API int32_t mpfmt_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** rowval, void** nzval, void** free_mask);
 /* Shard bookkeeping for the all-gather: column range (in the library's sorted order) and the number
  * of edges this shard produced. */
-int32_t mpfmt_shard_info(mpfmt_ctx* ctx, int64_t* col_begin, int64_t* col_end, int64_t* shard_nnz);
+MPFMT_API int32_t mpfmt_shard_info(mpfmt_ctx* ctx, int64_t* col_begin, int64_t* col_end, int64_t* shard_nnz);
 
 /* ---- wavefront solve: fmtstar! (src/planners/fmt.jl:3-119) with the dynamic-programming recursion ON THE DEVICE.
  *      mpfmt_fmtstar runs the loop fmt.jl:68-90 on one host core over GPU-built arrays; here W / H / C / A live in HBM and
@@ -383,28 +392,28 @@ typedef struct {
     double  cmin;              /* lowest open cost at the last step */
     int64_t tot_z, tot_x, tot_conn;   /* sums over the steps */
 } mpfmt_wf_info;
-int32_t mpfmt_fmtstar_wavefront(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind, const double* goal_params,
+MPFMT_API int32_t mpfmt_fmtstar_wavefront(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind, const double* goal_params,
                                 double band, int32_t flags, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res, mpfmt_wf_info* info);
-int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind, const double* goal_params,
+MPFMT_API int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind, const double* goal_params,
                        double band, int32_t flags);
-int32_t mpfmt_wf_step(mpfmt_ctx* ctx, mpfmt_wf_info* info);
-int32_t mpfmt_wf_state(mpfmt_ctx* ctx, uint64_t* W, uint64_t* H, double* C, int64_t* A);
-int32_t mpfmt_wf_batch(mpfmt_ctx* ctx, int64_t* zs, int64_t cap, int64_t* nz);
-int32_t mpfmt_wf_triples(mpfmt_ctx* ctx, int64_t cap, int64_t* x, int64_t* y, double* c, int64_t* n);
-int32_t mpfmt_wf_commit(mpfmt_ctx* ctx, int64_t n, const int64_t* x, const int64_t* y, const double* c);
-int32_t mpfmt_wf_finish(mpfmt_ctx* ctx, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
+MPFMT_API int32_t mpfmt_wf_step(mpfmt_ctx* ctx, mpfmt_wf_info* info);
+MPFMT_API int32_t mpfmt_wf_state(mpfmt_ctx* ctx, uint64_t* W, uint64_t* H, double* C, int64_t* A);
+MPFMT_API int32_t mpfmt_wf_batch(mpfmt_ctx* ctx, int64_t* zs, int64_t cap, int64_t* nz);
+MPFMT_API int32_t mpfmt_wf_triples(mpfmt_ctx* ctx, int64_t cap, int64_t* x, int64_t* y, double* c, int64_t* n);
+MPFMT_API int32_t mpfmt_wf_commit(mpfmt_ctx* ctx, int64_t n, const int64_t* x, const int64_t* y, const double* c);
+MPFMT_API int32_t mpfmt_wf_finish(mpfmt_ctx* ctx, int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);
 /* mpfmt_dubins_fmtstar_wavefront / mpfmt_reedsshepp_fmtstar_wavefront : the car planners (simplecars.jl spaces) the same way. */
-int32_t mpfmt_dubins_fmtstar_wavefront(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+MPFMT_API int32_t mpfmt_dubins_fmtstar_wavefront(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
                                        int32_t goal_kind, const double* goal_params, double band, int32_t flags, int64_t* A, double* C,
                                        int64_t* path, mpfmt_fmt_result* res, mpfmt_wf_info* info);
-int32_t mpfmt_reedsshepp_fmtstar_wavefront(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
+MPFMT_API int32_t mpfmt_reedsshepp_fmtstar_wavefront(mpfmt_ctx* ctx, double turn_radius, double speed, double r, int64_t init_idx, int32_t checkpts,
                                            int32_t goal_kind, const double* goal_params, double band, int32_t flags, int64_t* A, double* C,
                                            int64_t* path, mpfmt_fmt_result* res, mpfmt_wf_info* info);
 /* mpfmt_di_fmtstar_wavefront : mpfmt_di_fmtstar with the recursion on the device: the double-integrator graph is directed, so
  *        the forward sets nearF (rows of the cost matrix, linearquadratic.jl:73) are transposed on the device and the edge
  *        answers come from the 5-waypoint sweep's mask and segment counts.  MPFMT_WF_SINGLE reproduces mpfmt_di_fmtstar exactly;
  *        A / C / path may be NULL. */
-int32_t mpfmt_di_fmtstar_wavefront(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind,
+MPFMT_API int32_t mpfmt_di_fmtstar_wavefront(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx, int32_t checkpts, int32_t goal_kind,
                                    const double* goal_params, double band, int32_t flags, int64_t* A, double* C, int64_t* path,
                                    mpfmt_fmt_result* res, mpfmt_wf_info* info);
 
@@ -434,23 +443,23 @@ int32_t mpfmt_di_fmtstar_wavefront(mpfmt_ctx* ctx, double rho, double r, int64_t
  *                       the group like RCCL does; a multi-GPU box has not been available.)
  *                       MPFMT_RCCL_LIB (tests: a stand-in library) is honoured only with MPFMT_ALLOW_RCCL_OVERRIDE=1. */
 #define MPFMT_COMM_ID_BYTES 128
-int32_t mpfmt_comm_unique_id(uint8_t* id128);
-int32_t mpfmt_comm_create(mpfmt_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id128);
-int32_t mpfmt_comm_destroy(mpfmt_ctx* ctx);
-int32_t mpfmt_group_begin(void);
-int32_t mpfmt_group_end(void);
-int32_t mpfmt_allgather_free_mask(mpfmt_ctx* ctx, void** gathered, int64_t* stride_words, int64_t* words_each, int64_t* nnz_each);
-int32_t mpfmt_allgather_free_mask_launch(mpfmt_ctx* ctx, int64_t cap_hint);
-int32_t mpfmt_allgather_free_mask_finish(mpfmt_ctx* ctx, void** gathered, int64_t* stride_words, int64_t* words_each, int64_t* nnz_each);
-int32_t mpfmt_allgather_free_mask_relaunch(mpfmt_ctx* ctx);
+MPFMT_API int32_t mpfmt_comm_unique_id(uint8_t* id128);
+MPFMT_API int32_t mpfmt_comm_create(mpfmt_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id128);
+MPFMT_API int32_t mpfmt_comm_destroy(mpfmt_ctx* ctx);
+MPFMT_API int32_t mpfmt_group_begin(void);
+MPFMT_API int32_t mpfmt_group_end(void);
+MPFMT_API int32_t mpfmt_allgather_free_mask(mpfmt_ctx* ctx, void** gathered, int64_t* stride_words, int64_t* words_each, int64_t* nnz_each);
+MPFMT_API int32_t mpfmt_allgather_free_mask_launch(mpfmt_ctx* ctx, int64_t cap_hint);
+MPFMT_API int32_t mpfmt_allgather_free_mask_finish(mpfmt_ctx* ctx, void** gathered, int64_t* stride_words, int64_t* words_each, int64_t* nnz_each);
+MPFMT_API int32_t mpfmt_allgather_free_mask_relaunch(mpfmt_ctx* ctx);
 
 /* ---- measurement: average device milliseconds per launch of a named kernel group since the last
  *      reset, measured with HIP events on the launch stream.  names: "rdisc_count", "rdisc_fill",
  *      "rdisc_sort", "grid", "sweep_graph" (mask preset + round table + kernel), "sweep_kernel" (the round-table sweep kernel alone),
  *      "pair_kernel" (the pair kernel, and k_exact_pairs behind it when the edge tests are fused), "exact_pairs",
  *      "sweep_points", "sweep_edges", "expand". */
-int32_t mpfmt_timing_reset(mpfmt_ctx* ctx);
-int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
+MPFMT_API int32_t mpfmt_timing_reset(mpfmt_ctx* ctx);
+MPFMT_API int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
 /* Tuning / test knobs.  "rdisc_path": 0 = auto, 1 = exact fp64 VALU pair kernel, 2 = fp16 MFMA distance-matrix
  * filter + exact fp64 refine (both give bit-identical graphs).  "timing": 0/1 event timing off/on.
  * "sweep_sorted" (default 1): the graph sweep gathers row states from the library's cell-sorted copy and visits the columns
@@ -465,13 +474,13 @@ int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64
  * its own (mpfmt_graph_sweep_device, mpfmt_graph_edges_free) is always the whole sweep.
  * "fuse_sweep", "wf_graphs" (default 0): measured alternatives kept for the record.
  * "debug_small_lists": test knob, shrinks the pending lists of the fused edge tests so that their overflow path runs. */
-int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value);
+MPFMT_API int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value);
 /* Counters of the last graph build: "rdisc_path_used", "pairs_tested", "survivors" (pairs that passed the
  * MFMA filter), "nnz", "slices", "cells", "rdisc_half_used", "pool_used"; of the last step's edge tests: "sweep_form"
  * (0 / 1 / 2 as "fuse_broad"), "pair_items" (pairs listed for the exact tests; a synchronising read). */
-int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value);
+MPFMT_API int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value);
 /* work counters of the last graph build: candidate pairs distance-tested, tiles, slices. */
-int32_t mpfmt_graph_stats(mpfmt_ctx* ctx, int64_t* pairs_tested, int64_t* tiles, int64_t* slices, int64_t* cells);
+MPFMT_API int32_t mpfmt_graph_stats(mpfmt_ctx* ctx, int64_t* pairs_tested, int64_t* tiles, int64_t* slices, int64_t* cells);
 
 #ifdef __cplusplus
 }

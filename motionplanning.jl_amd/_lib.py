@@ -53,6 +53,7 @@ SYMBOLS = [
     ("mpfmt_set_stream", C.c_int32, [C.c_void_p, C.c_void_p]),
     ("mpfmt_set_shard", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
     ("mpfmt_upload_samples", C.c_int32, [C.c_void_p, c_d_p, C.c_int64, C.c_int32]),
+    ("mpfmt_upload_samples_device", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     ("mpfmt_upload_boxes", C.c_int32, [C.c_void_p, c_d_p, C.c_int32, C.c_int32, c_d_p, c_d_p, C.c_int32]),
     ("mpfmt_rdisc_count", C.c_int32, [C.c_void_p, C.c_double, c_i64_p, c_i64_p]),
     ("mpfmt_rdisc_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p]),
@@ -301,6 +302,12 @@ class Context:
             raise ValueError("X must be (N, d)")
         self._chk(self._L.mpfmt_upload_samples(self._h, _dp(X), X.shape[0], X.shape[1]))
         self.N, self.d = X.shape
+        self.nnz = None
+
+    def upload_samples_device(self, ptr, N, d):
+        """The same from a device pointer (N x d float64, C-contiguous, on this ctx's GPU): no PCIe crossing."""
+        self._chk(self._L.mpfmt_upload_samples_device(self._h, C.c_void_p(int(ptr)), int(N), int(d)))
+        self.N, self.d = int(N), int(d)
         self.nnz = None
 
     def upload_boxes(self, lohi, ss_lo=None, ss_hi=None, dw=None):

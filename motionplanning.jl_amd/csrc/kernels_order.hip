@@ -540,13 +540,12 @@ static int32_t launch_order(mpfmt_ctx* ctx, const int32_t* spec_fail, const ord_
     const int64_t nt = ctx->tile_end - ctx->tile_begin;
     constexpr auto kk = k_order_logs<D, SWEEP>;
     const size_t lds = (size_t)ORD_STG * 16 + sizeof(ord_shared<SWEEP ? D : 1, SWEEP>);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    // (the attribute belongs to the kernel ON A DEVICE: set per launch -- a cached flag would cover the first device of a process
+    // that drives several, and be written by concurrent ctx threads)
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent workgroups: as many as fit the chip at once (3 per CU by their LDS and their 82 VGPRs), each takes every nb-th quarter tile
-    static int per_cu = 0;
+    if (ctx->ord_d != D) { ctx->ord_per_cu[0] = ctx->ord_per_cu[1] = 0; ctx->ord_d = D; }
+    int& per_cu = ctx->ord_per_cu[SWEEP ? 1 : 0];
     if (per_cu == 0) {
         HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kk, ORD_THREADS, lds));
         per_cu = std::max(1, std::min(per_cu, 3));

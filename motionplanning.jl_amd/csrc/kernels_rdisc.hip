@@ -670,6 +670,11 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     ctx->tile_end = std::min<int64_t>(ctx->ntiles, 4 * shard_cut(ctx->rank + 1));
     const int64_t nt = ctx->tile_end - ctx->tile_begin;
 
+    // the last build of the same (N, r, shard) met a column longer than the ordering kernel stages: the logs would be written for
+    // nothing (every such build ends in the fill pass), so the two-pass form is taken at once -- until a build reports a shorter
+    // longest column again (k_degree measures it in every form)
+    const bool hint_match = ctx->pool_hint_N == N && ctx->pool_hint_r == r && ctx->pool_hint_rank == ctx->rank && ctx->pool_hint_world == ctx->world;
+    const bool too_long_hint = hint_match && ctx->pool_hint_maxdeg > MPFMT_ORD_MAXDEG;
     // path: MFMA fp16 filter + exact refine when it is usable, else the exact fp64 VALU kernel
     bool mf = false, half = false;
     float negT = 0.f;
@@ -688,7 +693,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         bool ok = true;
         // half build: the whole graph on this ctx, through the single-pass logs (decided before the lists, which differ)
         // (a shard does the same for the pairs inside it; its pairs with other shards' samples are found from its own side only)
-        half = ctx->use_half && !ctx->half_off && ctx->use_pool && nt > 0;
+        half = ctx->use_half && !ctx->half_off && ctx->use_pool && nt > 0 && !too_long_hint;
         if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok, spec, half))) return rc;    // per-tile candidate chunk lists
         tm2.end("grid");
         if (!ok) {
@@ -737,10 +742,10 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     }                                                          // (unsharded: k_degree writes every entry, the scans' extra last ones too)
 
     // single-pass pool: capacity from the last build of the same (N, r), else from the ball-volume estimate
-    bool pool = mf && ctx->use_pool && nt > 0;
+    bool pool = mf && ctx->use_pool && nt > 0 && !too_long_hint;
     if (pool) {
         double want;
-        if (ctx->pool_hint_N == N && ctx->pool_hint_r == r && ctx->pool_hint_rank == ctx->rank && ctx->pool_hint_world == ctx->world) {
+        if (hint_match) {
             want = (double)ctx->pool_hint_nnz * 1.02 + 4096.0;
         } else {
             const int d = ctx->d;
@@ -875,7 +880,7 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
         // (an overflow doubles the logs' slack -- the first slices of a half build's lists, the tile's own neighbourhood, find several
         // times the mean when the lists are cut into many slices -- and the half form is tried again once a whole build has left
         // its hint; a column too long, or an overflow at the widest slack, ends the tries)
-        if (too_long || ctx->pool_slack >= 8) ctx->half_fail = 2;
+        if (pool_over && ctx->pool_slack >= 8) ctx->half_fail = 2;      // (a column too long is remembered by the size hint instead: the logs come back with shorter columns)
         ctx->half_off = true; ctx->half_used = false;
         ctx->lists_r = -1.0;
         if (pool_over && ctx->pool_slack < 8) ctx->pool_slack *= 2;
@@ -887,7 +892,7 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     ctx->pool_valid = pool && pool_over == 0 && !too_long;
     if (ctx->pool_valid && ctx->half_off && ctx->half_fail < 2) ctx->half_off = false;
     if (pool && pool_over && ctx->pool_slack < 8) ctx->pool_slack *= 2;
-    ctx->pool_hint_N = N; ctx->pool_hint_r = r; ctx->pool_hint_nnz = nnz;
+    ctx->pool_hint_N = N; ctx->pool_hint_r = r; ctx->pool_hint_nnz = nnz; ctx->pool_hint_maxdeg = rb->max_deg;
     ctx->pool_hint_rank = ctx->rank; ctx->pool_hint_world = ctx->world;
     ctx->nnz = nnz;
     for (int i = 1; i < 256; ++i) { pairs[0] += pairs[2 * i]; pairs[1] += pairs[2 * i + 1]; }

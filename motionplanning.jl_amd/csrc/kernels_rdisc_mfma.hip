@@ -890,7 +890,8 @@ int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usab
     for (int i = 0; i < d; ++i) ext = std::max(ext, ctx->bb_hi[i] - ctx->bb_lo[i]);
     *usable = false;
     // (chunk ids and cell-sorted positions travel in 20 / 26 bits of the queue entries and hit records)
-    if (d > 12 || !(ext > 0.0) || !(r > 0.0) || ctx->ntiles * 64 > ((int64_t)1 << 26)) return MPFMT_OK;
+    // (strictly below 2^26: position 2^26 - 1 with column 63 would make a record word of all ones, the ordering kernel's "no record" mark)
+    if (d > 12 || !(ext > 0.0) || !(r > 0.0) || ctx->ntiles * 64 >= ((int64_t)1 << 26)) return MPFMT_OK;
     const double s = 1.0 / ext;
     const double e_c = 2.5e-4;                       // > 2^-12 (fp16 rounding on [0,1]) + fp32 conversion slack
     const double shell = 2.0 * std::sqrt((double)d) * e_c;

@@ -644,16 +644,6 @@ __global__ __launch_bounds__(256) void k_round_fill(const int64_t* __restrict__ 
     }
 }
 
-// flag = 0 if any sample fails in_state_space (statespaces.jl:150); the sweep over a sample set that passes skips the test per row
-__global__ void k_all_in_ss(const double* __restrict__ X, int64_t N, int d, const double* __restrict__ ssb, int32_t* __restrict__ flag)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    bool ok = true;
-    for (int k = 0; k < d; ++k) { const double x = X[i * d + k]; ok = ok && (ssb[k] <= x) && (x <= ssb[MPFMT_MAX_DIM + k]); }
-    if (!ok) *flag = 0;
-}
-
 #define RT_TASK 64                 // rounds per task = lanes of the descriptor register
 
 template <int D>
@@ -1650,17 +1640,13 @@ int32_t mpfmt_sweep_prepare_ss(mpfmt_ctx* ctx)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                 // b is a stack buffer
         ctx->rt_ss_host = ctx->ss; ctx->rt_ss_valid = true;
     }
-    // once per (sample set, bounds): do all samples lie in the state space?  (one small kernel and a 4-byte read-back; the
-    // steady-state step pays nothing and its sweep drops 2 d comparisons per entry)
+    // once per (sample set, bounds): do all samples lie in the state space?  (the sweep then drops 2 d comparisons per entry)
     if (ctx->ss.has && (ctx->ssflag_epoch != ctx->samples_epoch || memcmp(&ctx->ssflag_ss, &ctx->ss, sizeof(mpfmt_ss)) != 0)) {
-        if ((rc = mpfmt_ensure(ctx, (void**)&ctx->ssflag_dev, sizeof(int32_t)))) return rc;
-        int32_t one = 1, got = 0;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->ssflag_dev, &one, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        if (ctx->N > 0)
-            hipLaunchKernelGGL(k_all_in_ss, dim3((unsigned)((ctx->N + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xo, ctx->N, ctx->d, ctx->rt_ss, ctx->ssflag_dev);
-        HIPCHK(ctx, hipMemcpyAsync(&got, ctx->ssflag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->ssflag_all_in = got == 1;
+        // (every sample is finite and the uploads keep the set's bounding box: all samples pass in_state_space, statespaces.jl:150,
+        // exactly when the box does -- no kernel, no read-back; new samples every step then cost the step nothing here)
+        bool all_in = true;
+        if (ctx->N > 0) for (int k = 0; k < ctx->d; ++k) all_in = all_in && (ctx->ss.lo[k] <= ctx->bb_lo[k]) && (ctx->bb_hi[k] <= ctx->ss.hi[k]);
+        ctx->ssflag_all_in = all_in;
         ctx->ssflag_epoch = ctx->samples_epoch; ctx->ssflag_ss = ctx->ss;
     }
     return MPFMT_OK;

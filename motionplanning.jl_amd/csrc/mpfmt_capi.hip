@@ -195,8 +195,9 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
-                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->pool, ctx->log_len, ctx->fpool, ctx->flen, ctx->fcol, ctx->pend_items, ctx->pend_cnt, ctx->pair_items, ctx->pair_cnt, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev};
+                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->pool, ctx->log_len, ctx->fpool, ctx->flen, ctx->fcol, ctx->pend_items, ctx->pend_cnt, ctx->pair_items, ctx->pair_cnt, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev, ctx->bb_dev};
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
+    if (ctx->bb_host) hipHostFree(ctx->bb_host);
     mpfmt_comm_destroy(ctx);
     mpfmt_wf_free(ctx);
     if (ctx->aux) { mpfmt_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
@@ -251,6 +252,77 @@ int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t
     ctx->samples_epoch += 1;
     if (N > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->Xo, X, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->N = N; ctx->d = d;
+    ctx->grid_r = -1.0; ctx->graph_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0;
+    ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
+    ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
+    ctx->nnz = 0;
+    return MPFMT_OK;
+}
+
+// per-block partial bounding boxes of a device-resident sample set + a count of non-finite coordinates (mpfmt_upload_samples_device)
+__global__ __launch_bounds__(256) void k_bbox_partials(const double* __restrict__ X, int64_t N, int d, double* __restrict__ part, int32_t* __restrict__ bad)
+{
+    __shared__ double s_lo[4][MPFMT_MAX_DIM], s_hi[4][MPFMT_MAX_DIM];
+    double lo[MPFMT_MAX_DIM], hi[MPFMT_MAX_DIM];
+    for (int i = 0; i < MPFMT_MAX_DIM; ++i) { lo[i] = INFINITY; hi[i] = -INFINITY; }
+    int nbad = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x)
+        for (int i = 0; i < d; ++i) {
+            const double a = X[p * d + i];
+            if (!(fabs(a) <= 1.7976931348623157e308)) ++nbad;
+            lo[i] = fmin(lo[i], a); hi[i] = fmax(hi[i], a);
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = 0; i < d; ++i) {
+        for (int off = 32; off > 0; off >>= 1) { lo[i] = fmin(lo[i], __shfl_xor(lo[i], off)); hi[i] = fmax(hi[i], __shfl_xor(hi[i], off)); }
+        if (lane == 0) { s_lo[wave][i] = lo[i]; s_hi[wave][i] = hi[i]; }
+    }
+    if (__ballot(nbad != 0) && lane == 0) atomicAdd(bad, 1);
+    __syncthreads();
+    if (threadIdx.x < d) {
+        const int i = threadIdx.x;
+        part[((int64_t)blockIdx.x * 2 + 0) * MPFMT_MAX_DIM + i] = fmin(fmin(s_lo[0][i], s_lo[1][i]), fmin(s_lo[2][i], s_lo[3][i]));
+        part[((int64_t)blockIdx.x * 2 + 1) * MPFMT_MAX_DIM + i] = fmax(fmax(s_hi[0][i], s_hi[1][i]), fmax(s_hi[2][i], s_hi[3][i]));
+    }
+}
+
+// The same as mpfmt_upload_samples for a sample set that already lives in HBM (a batch made on the device: the library's own sampler,
+// a ROCArray, a torch tensor): one device-to-device copy, the bounding box by a reduction on the device, one small read-back.
+int32_t mpfmt_upload_samples_device(mpfmt_ctx* ctx, const double* dX, int64_t N, int32_t d)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (N < 0 || N >= ((int64_t)1 << 31) - 64) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "N = %lld out of range", (long long)N);
+    if (d < 1 || d > MPFMT_MAX_DIM) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "d = %d out of range [1,%d]", d, MPFMT_MAX_DIM);
+    if (N > 0 && !dX) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "dX is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    constexpr int NB = 256;
+    struct bb_block { double part[NB][2][MPFMT_MAX_DIM]; int32_t bad; int32_t pad_; };
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->bb_dev, sizeof(bb_block)))) return rc;
+    if (!ctx->bb_host) HIPCHK(ctx, hipHostMalloc(&ctx->bb_host, sizeof(bb_block), hipHostMallocDefault));
+    bb_block* dev = (bb_block*)ctx->bb_dev;
+    const int nb = (int)std::min<int64_t>(NB, (N + 255) / 256);
+    double lo[MPFMT_MAX_DIM], hi[MPFMT_MAX_DIM];
+    for (int i = 0; i < d; ++i) { lo[i] = 0.0; hi[i] = 0.0; }
+    if (N > 0) {
+        HIPCHK(ctx, hipMemsetAsync(&dev->bad, 0, sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(k_bbox_partials, dim3(nb), dim3(256), 0, ctx->stream, dX, N, d, &dev->part[0][0][0], &dev->bad);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(ctx->bb_host, dev, sizeof(bb_block), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->Xo, sizeof(double) * (size_t)N * d))) return rc;
+    if (N > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->Xo, dX, sizeof(double) * (size_t)N * d, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (N > 0) {
+        const bb_block* h = (const bb_block*)ctx->bb_host;
+        if (h->bad) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "the sample set has a non-finite coordinate");
+        for (int i = 0; i < d; ++i) { lo[i] = INFINITY; hi[i] = -INFINITY; }
+        for (int b = 0; b < nb; ++b)
+            for (int i = 0; i < d; ++i) { lo[i] = std::min(lo[i], h->part[b][0][i]); hi[i] = std::max(hi[i], h->part[b][1][i]); }
+    }
+    for (int i = 0; i < d; ++i) { ctx->bb_lo[i] = lo[i]; ctx->bb_hi[i] = hi[i]; }
+    ctx->samples_epoch += 1;
     ctx->N = N; ctx->d = d;
     ctx->grid_r = -1.0; ctx->graph_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0;
     ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;

@@ -144,8 +144,10 @@ int32_t mpfmt_comm_world(const mpfmt_ctx* ctx, int* rank, int* world)
     return 0;
 }
 
-static int g_group_depth = 0;                          // mpfmt_group_begin nesting (the single driving thread)
-static std::vector<mpfmt_ctx*> g_group_post;           // ctxs whose gather was launched inside the open group
+// A group belongs to the host thread that opened it (ncclGroupStart / End are per thread too): both are thread_local, so one thread
+// per ctx beside a grouping thread cannot race on them
+static thread_local int g_group_depth = 0;                          // mpfmt_group_begin nesting of this thread
+static thread_local std::vector<mpfmt_ctx*> g_group_post;           // ctxs whose gather was launched inside this thread's open group
 
 // what follows the collective on the communication stream: slot headers (lengths) to pinned host memory, completion event
 static int32_t gather_post(mpfmt_ctx* ctx, mpfmt_comm* c)
@@ -217,13 +219,23 @@ int32_t mpfmt_group_end(void)
     int32_t rc;
     if ((rc = rccl_ready(nullptr))) return rc;
     if (g_group_depth > 0) --g_group_depth;
-    NCCLCHK(nullptr, g_rccl.GroupEnd());
-    if (g_group_depth == 0) {
-        std::vector<mpfmt_ctx*> due;
-        due.swap(g_group_post);
-        for (mpfmt_ctx* ctx : due) if ((rc = gather_post(ctx, (mpfmt_comm*)ctx->comm))) return rc;
+    const ncclResult_t gr = g_rccl.GroupEnd();
+    if (g_group_depth > 0 && gr == ncclSuccess) return MPFMT_OK;
+    // the outermost group has closed (or RCCL refused it): the list is emptied on EVERY path, every ctx is posted -- a failure on one
+    // must not leave the others with post_due set for good -- and the first error is what the caller sees
+    std::vector<mpfmt_ctx*> due;
+    due.swap(g_group_post);
+    if (gr != ncclSuccess) {
+        g_group_depth = 0;
+        for (mpfmt_ctx* ctx : due) { mpfmt_comm* c = (mpfmt_comm*)ctx->comm; if (c) { c->post_due = false; c->pending = false; } }
+        return mpfmt_fail(nullptr, MPFMT_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(gr));
     }
-    return MPFMT_OK;
+    int32_t first = MPFMT_OK;
+    for (mpfmt_ctx* ctx : due) {
+        rc = gather_post(ctx, (mpfmt_comm*)ctx->comm);
+        if (rc && !first) first = rc;
+    }
+    return first;
 }
 
 int32_t mpfmt_comm_create(mpfmt_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id128)
@@ -262,6 +274,8 @@ int32_t mpfmt_comm_destroy(mpfmt_ctx* ctx)
 {
     if (!ctx || !ctx->comm) return MPFMT_OK;
     mpfmt_comm* c = (mpfmt_comm*)ctx->comm;
+    // (a ctx destroyed inside an open group must not be posted at group_end)
+    g_group_post.erase(std::remove(g_group_post.begin(), g_group_post.end(), ctx), g_group_post.end());
     hipSetDevice(ctx->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);

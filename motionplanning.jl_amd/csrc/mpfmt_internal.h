@@ -69,6 +69,8 @@ struct mpfmt_ctx {
     int32_t d = 0;
     double* Xo = nullptr;                // [N][d] original order (AoS = the caller's layout)
     double bb_lo[MPFMT_MAX_DIM], bb_hi[MPFMT_MAX_DIM];
+    void* bb_dev = nullptr;              // mpfmt_upload_samples_device: per-block partial boxes, and their pinned host mirror
+    void* bb_host = nullptr;
 
     // ---- cell grid for radius grid_r --------------------------------------------------------------
     double grid_r = -1.0;
@@ -104,6 +106,8 @@ struct mpfmt_ctx {
     int32_t mf_xcd_mode = 512;
     int32_t mf_ablate = 0;               // timing experiments only
     int32_t num_cus = 256;               // compute units of the device (persistent-grid sizing)
+    int ord_d = -1;
+    int ord_per_cu[2] = {0, 0};          // k_order_logs<., false / true>: resident workgroups per CU on THIS ctx's device
     int* sweep_ctr = nullptr;            // graph sweep: one task counter per obstacle chunk
     int32_t sweep_rounds = 1;            // option: round-table sweep (k_graph_sweep_rt) where it applies (d <= 8, M <= 256)
     int64_t* rt_cnt = nullptr;           // [columns visited + 1] rounds per column, then (scan) first round of each column
@@ -175,7 +179,7 @@ struct mpfmt_ctx {
     void* rb_dev = nullptr;              // count read-back block (device) and its pinned host mirror
     void* rb_host = nullptr;
     int64_t lists_cap_trusted = -1;      // list capacity that a verified build found sufficient
-    int64_t pool_hint_N = -1; double pool_hint_r = -1.0; int64_t pool_hint_nnz = 0; int pool_hint_rank = -1, pool_hint_world = -1;   // capacity hint from the last build
+    int64_t pool_hint_N = -1; double pool_hint_r = -1.0; int64_t pool_hint_nnz = 0; int64_t pool_hint_maxdeg = 0; int pool_hint_rank = -1, pool_hint_world = -1;   // capacity hint from the last build
     int64_t survivors = 0;
     int64_t* colptr = nullptr;           // [N+1] 0-based offsets by original index
     int64_t nnz = 0;

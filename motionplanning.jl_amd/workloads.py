@@ -24,6 +24,7 @@ class Workload:
     goal_radius: float
     ss_lo: np.ndarray
     ss_hi: np.ndarray
+    seed: int = 0
 
     @property
     def N(self):
@@ -100,7 +101,18 @@ def make(name, N, d, M, h_lo, h_hi, seed, init_v=0.1, goal_v=0.9, goal_radius=0.
     X[-1] = goal
     if r is None:
         r = fmt_radius(rm, d, 1.0, N)
-    return Workload(name, X, lohi, float(r), init, goal, goal_radius, np.zeros(d), np.ones(d))
+    return Workload(name, X, lohi, float(r), init, goal, goal_radius, np.zeros(d), np.ones(d), seed)
+
+
+def resample(w, k):
+    """Sample set k of the same problem (k = 0: w.X itself): what a planner's k-th call on this world draws -- new i.i.d. samples of
+    the same N, init first, goal centre last, same obstacles and radius.  Stream seed = w.seed + 1000 k (pinned like every other)."""
+    if k == 0:
+        return w.X
+    X = Stream(w.seed + 1000 * k).random((w.N, w.d))
+    X[0] = w.init
+    X[-1] = w.goal_center
+    return X
 
 
 def cfg1(N=1000):

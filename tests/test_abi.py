@@ -27,6 +27,18 @@ def test_library_exports_every_declared_symbol():
     assert sorted(n for n, _, _ in mp._lib.SYMBOLS) == syms
 
 
+def test_library_exports_nothing_but_the_abi():
+    """Built with -fvisibility=hidden + MPFMT_API: the dynamic symbol table holds the header's functions and nothing else (no C++
+    helper, no kernel launch stub that another HIP library in the same process could interpose)."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", mp._lib.so_path()]).decode()
+    defined = sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "TtWwVvBbDdRr")
+    funcs = sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T")
+    assert funcs == header_symbols(), sorted(set(funcs) ^ set(header_symbols()))
+    extra = [s for s in defined if s not in funcs]
+    assert all(not s.startswith(("_Z", "mpfmt")) for s in extra), extra
+
+
 def test_version_string():
     assert mp._lib.lib().mpfmt_version().decode().endswith("gfx950")
 

@@ -1,0 +1,125 @@
+"""GPU parity tests (-m gpu) of the step bench.py TIMES, at the size it is timed at.
+
+bench.py runs mpfmt_graph_step_device with rebuild_index = 1 on the north star (N = 1e6 in R^6, 200 boxes): half build of the r-disc
+graph (every pair tested once, both columns' records written by the pair kernel) + the edge tests fused into it (broad phase in the pair
+kernel's drain, flagged pairs through k_exact_pairs, mask written by the ordering pass).  At this size the oracle cannot build the
+whole graph, so the resident CSC + mask are compared
+  * with the ORACLE on sampled columns (KD-tree inball: rows and costs) and sampled edges (is_free_motion, parent first,
+    src/planners/fmt.jl:75), and
+  * entry for entry with the two-phase ABI forms (mpfmt_rdisc_count / _fill + mpfmt_graph_edges_free: the whole sweep) on a second
+    ctx -- which tests/test_gpu_parity.py::test_north_star_full_size_properties compares with the oracle the same way,
+on a cold first call, on repeats, and on NEW samples of the same (N, r) handed over from a device pointer
+(mpfmt_upload_samples_device) -- the call sequence of the bench's timed loop.
+"""
+import numpy as np
+import pytest
+
+import motionplanning_jl_amd as mp
+from test_gpu_parity import _resident_graph
+
+pytestmark = pytest.mark.gpu
+L = mp._lib
+
+
+def _check_against_oracle(orc, X, r, lohi, ss_lo, ss_hi, colptr, rowval, nzval, free_words, rng, ncols=400, nedges=300000):
+    N = len(X)
+    nnz = int(colptr[-1])
+    kd = orc.KDTree(X)
+    for v in rng.integers(0, N, size=ncols):
+        oi, od = kd.inball(int(v), r)
+        a, b = int(colptr[v]), int(colptr[v + 1])
+        assert np.array_equal(rowval[a:b], oi), "column %d: rows differ from the oracle" % v
+        assert np.array_equal(nzval[a:b], od), "column %d: costs differ from the oracle" % v
+    deg = np.diff(colptr)
+    es = np.sort(rng.integers(0, nnz, size=nedges))
+    cols = np.searchsorted(colptr, es, side="right") - 1
+    assert np.all(colptr[cols] <= es) and np.all(es < colptr[cols + 1]) and deg.min() >= 0
+    bits = L.unpack_bits(free_words.view(np.uint64), nnz)
+    want = orc.unpack(orc.edges_free(X, rowval[es].astype(np.int64), cols.astype(np.int64), lohi, ss_lo, ss_hi), len(es))
+    assert np.array_equal(bits[es], want), "sampled free bits differ from the oracle"
+
+
+def test_north_star_step_path(orc):
+    import torch
+    w = mp.workloads.north_star()
+    N = w.N
+    rng = np.random.default_rng(41)
+    # reference of the whole arrays: the two-phase forms on a second ctx (the whole sweep kernel)
+    with mp.Context(0) as b:
+        b.upload_samples(w.X); b.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+        colptr_b, rowval_b, nzval_b = b.rdisc_graph(w.r)
+        mask_b = b.graph_edges_free()
+    nnz_ref = len(rowval_b)
+    assert nnz_ref == 107492200                               # (the workload stream is pinned: tests/golden/stream_heads.json)
+    colptr_b = colptr_b - 1
+    rowval_b = (rowval_b - 1).astype(np.int32)
+    with mp.Context(0) as c:
+        c.set_option("rebuild_index", 1)
+        c.upload_samples(w.X); c.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+        forms = []
+        for it in range(3):                                   # cold, then two calls that take the previous sizes on trust
+            nnz = c.graph_step_device(w.r)
+            forms.append((c.stat("rdisc_path_used"), c.stat("rdisc_half_used"), c.stat("sweep_form")))
+            assert nnz == nnz_ref, it
+            colptr, rowval, nzval, free = _resident_graph(c, N)
+            assert np.array_equal(colptr, colptr_b), it
+            assert np.array_equal(rowval, rowval_b), it
+            assert np.array_equal(nzval, nzval_b), it
+            assert np.array_equal(free.view(np.uint64), mask_b), it
+            _check_against_oracle(orc, w.X, w.r, w.lohi, w.ss_lo, w.ss_hi, colptr, rowval, nzval, free, rng)
+            del colptr, rowval, nzval, free
+        assert forms[1] == (2, 1, 2) and forms[2] == (2, 1, 2), forms      # the timed form: MFMA pair kernel, half build, fused edge tests
+        assert forms[0] == (2, 1, 2), forms                                # ... and the cold call takes it too
+        del rowval_b, nzval_b, mask_b, colptr_b
+        # new samples of the same (N, r), resident in HBM: what a planner's next call looks like (and bench.py's timed loop)
+        for seed in (101, 102):
+            X2 = np.random.default_rng(seed).random((N, w.d))
+            X2[0] = w.X[0]; X2[-1] = w.X[-1]
+            t = torch.from_numpy(X2).to("cuda:0")
+            torch.cuda.synchronize()
+            c.upload_samples_device(t.data_ptr(), N, w.d)
+            nnz = c.graph_step_device(w.r)
+            assert (c.stat("rdisc_path_used"), c.stat("rdisc_half_used"), c.stat("sweep_form")) == (2, 1, 2), seed
+            colptr, rowval, nzval, free = _resident_graph(c, N)
+            assert nnz == colptr[-1]
+            _check_against_oracle(orc, X2, w.r, w.lohi, w.ss_lo, w.ss_hi, colptr, rowval, nzval, free, rng, ncols=300, nedges=200000)
+            # symmetry of the whole graph: sum and xor checksums of the directed keys and of their transposes
+            cols = np.repeat(np.arange(N, dtype=np.int64), np.diff(colptr))
+            k1 = cols * N + rowval
+            k2 = rowval.astype(np.int64) * N + cols
+            assert int(k1.sum()) == int(k2.sum()) and int(np.bitwise_xor.reduce(k1)) == int(np.bitwise_xor.reduce(k2))
+            d = np.diff(rowval.astype(np.int64))
+            assert np.all(d[cols[1:] == cols[:-1]] > 0)                          # ascending inside every column
+            del cols, k1, k2, d, colptr, rowval, nzval, free, t
+
+
+def test_upload_samples_device_equals_host_upload(orc):
+    """mpfmt_upload_samples_device against mpfmt_upload_samples: same bounding box (hence the same grid), same graph and mask;
+    a non-finite coordinate is refused."""
+    import torch
+    rng = np.random.default_rng(5)
+    N, d, r = 30011, 3, 0.06
+    X = rng.random((N, d)) * np.array([1.0, 0.5, 2.0]) - 0.25
+    lohi = mp.workloads.make_boxes(rng, 25, d, 0.05, 0.2, [])
+    lo, hi = np.full(d, -0.3), np.full(d, 2.0)
+    got = []
+    for dev in (False, True):
+        with mp.Context(0) as c:
+            c.upload_boxes(lohi, lo, hi)
+            if dev:
+                t = torch.from_numpy(X).to("cuda:0"); torch.cuda.synchronize()
+                c.upload_samples_device(t.data_ptr(), N, d)
+            else:
+                c.upload_samples(X)
+            c.graph_step_device(r)
+            got.append(_resident_graph(c, N) + (c.graph_stats()["cells"],))
+    for u, v in zip(*got):
+        assert np.array_equal(u, v)
+    oc, orow, oval = orc.rdisc_graph(X, r)
+    assert np.array_equal(got[1][0], oc) and np.array_equal(got[1][1], orow) and np.array_equal(got[1][2], oval)
+    assert np.array_equal(got[1][3].view(np.uint64), orc.graph_edges_free(X, oc, orow, lohi, lo, hi))
+    X[123, 1] = np.nan
+    with mp.Context(0) as c:
+        t = torch.from_numpy(X).to("cuda:0"); torch.cuda.synchronize()
+        with pytest.raises(mp.MPFMTError):
+            c.upload_samples_device(t.data_ptr(), N, d)

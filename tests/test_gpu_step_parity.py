@@ -369,3 +369,16 @@ def test_round_table_sweep_cases(orc, N, d, M, r, box_h, bounds):
             masks.append(free.view(np.uint64).copy())
     for m in masks:
         assert np.array_equal(m, want)
+
+
+def test_large_stress_of_the_timed_form_in_suite(orc):
+    """tools/stress_large.py inside the suite: random worlds of 2e4 .. 2.5e5 samples in R^2 .. R^6 (clumps, density
+    gradients, 0 .. 400 boxes) through the default step -- cold call, repeat, re-upload -- against scipy's kd-tree graph and the
+    oracle's sweep of it, bit for bit; most of the steps must have run in the form bench.py times (half build, edge-test form 2)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_large
+    cases, edges, forms = stress_large.run(budget=100.0, seed=12, timed_form_only=True, max_pairs=4e7, sizes=(20000, 50000, 110000, 250000))
+    steps = sum(forms.values())
+    assert cases >= 3 and edges > 1e7, (cases, edges)
+    assert forms.get((1, 2), 0) * 2 >= steps, forms

@@ -67,9 +67,23 @@ def main():
         if p.get("SQ_ACTIVE_INST_VALU") and p.get("GRBM_GUI_ACTIVE"):
             # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE cycles summed over the 8 XCDs
             e["valu_busy"] = p["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (p["GRBM_GUI_ACTIVE"] / 8.0)
+        if p.get("SQ_VALU_MFMA_BUSY_CYCLES") and p.get("GRBM_GUI_ACTIVE"):
+            # matrix-pipe busy cycles summed over the 1024 SIMDs over the kernel's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+            e["mfma_busy"] = p["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (p["GRBM_GUI_ACTIVE"] / 8.0)
         if tag == "sweep" and nnz:
             e["valu_lane_ops_per_edge"] = p.get("SQ_INSTS_VALU", 0) * 64.0 / nnz
         out[tag] = e
+    # the whole step: every kernel's traffic, per step (steps = dispatches of the pair kernel in the run)
+    pk = [k for k in per if "k_rdisc_mfma" in k]
+    if pk:
+        steps = max(cnt[max(pk, key=lambda k: per[k].get("SQ_BUSY_CYCLES", 0))].get("FETCH_SIZE", 0), 1)
+        by = {}
+        for k in per:
+            b = (acc[k].get("FETCH_SIZE", 0.0) * 2 + acc[k].get("WRITE_SIZE", 0.0)) * 1024 / steps
+            if b > 0:
+                by[k.split("(")[0][:60]] = by.get(k.split("(")[0][:60], 0.0) + b
+        out["step"] = {"steps_in_run": steps, "bytes": sum(by.values()),
+                       "by_kernel": {k: v for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:12]}}
     json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

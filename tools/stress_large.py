@@ -14,14 +14,16 @@ from motionplanning_jl_amd.distributed import DevArray
 from oracle import oracle as orc
 
 
-def run(budget=60.0, seed=0):
+def run(budget=60.0, seed=0, timed_form_only=False, max_pairs=1.2e8, sizes=(20000, 50000, 110000, 250000, 400000)):
+    """timed_form_only: every case runs the DEFAULT options only (what bench.py times: half build + fused edge tests, form 2) over a
+    cold step, a repeat and a re-upload -- the in-suite form (tests/test_gpu_step_parity.py), where most steps must be (1, 2)."""
     rng = np.random.default_rng(seed)
     t0 = time.time(); cases = 0; edges = 0; forms = {}
     dev = lambda ptr, n, ts: torch.as_tensor(DevArray(ptr, n, ts), device="cuda:0").cpu().numpy()
     while time.time() - t0 < budget:
         d = int(rng.integers(2, 7))
-        N = int(rng.choice([20000, 50000, 110000, 250000, 400000]))
-        M = int(rng.choice([0, 30, 200, 256, 400]))
+        N = int(rng.choice(list(sizes)))
+        M = int(rng.choice([30, 200, 256] if timed_form_only else [0, 30, 200, 256, 400]))      # (form 2 takes <= 256 boxes)
         deg = float(rng.choice([6, 25, 60]))
         X = rng.random((N, d))
         kind = rng.random()
@@ -32,10 +34,10 @@ def run(budget=60.0, seed=0):
         r = float((deg / N) ** (1.0 / d) * 0.62)
         c = rng.random((M, d)); h = 0.02 + 0.15 * rng.random((M, d)) * rng.random()
         lohi = np.stack([c - h, c + h], axis=1) if M else np.zeros((0, 2, d))
-        inset = 0.03 * rng.random() * (rng.random() < 0.3)                     # (a sample outside the state space keeps the edge tests out of the pair kernel)
+        inset = 0.0 if timed_form_only else 0.03 * rng.random() * (rng.random() < 0.3)                     # (a sample outside the state space keeps the edge tests out of the pair kernel)
         lo, hi = np.full(d, inset), np.full(d, 1 - inset)
         tree = cKDTree(X)
-        if tree.count_neighbors(tree, r) > 1.2e8:
+        if tree.count_neighbors(tree, r) > max_pairs:
             continue                                                            # keeps one case under half a minute of host work
         pairs = tree.query_pairs(r, output_type="ndarray")
         col = np.concatenate([pairs[:, 0], pairs[:, 1]]); row = np.concatenate([pairs[:, 1], pairs[:, 0]])
@@ -54,10 +56,12 @@ def run(budget=60.0, seed=0):
         assert np.all(np.abs(nzval - dd) <= 1e-15 * dd + 1e-300), ("costs", d, N, r)
         for half in (1, 0):
             for form in (2, 1, 0):
+                if timed_form_only and (half, form) != (1, 2):
+                    continue
                 if half == 0 and form != int(rng.integers(0, 3)):
                     continue                                                    # the whole build: one form per case
                 ctx.set_option("rdisc_half", half); ctx.set_option("fuse_broad", form); ctx.set_option("rebuild_index", 1)
-                for rep in range(2):
+                for rep in range(3 if timed_form_only else 2):
                     ctx.upload_samples(X); ctx.upload_boxes(lohi, lo, hi)       # new samples: the step builds its graph again
                     nnz = ctx.graph_step_device(r)
                     assert nnz == len(rowval), ("step nnz", d, N, M, r, half, form, rep)
