@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64) void k_rdisc(rdisc_args a, mpfmt_grid G)
 // degree of each ORIGINAL column = sum over slices of the sorted query's hits
 __global__ void k_degree(const int32_t* __restrict__ slice_cnt, const int32_t* __restrict__ perm, int S, int64_t npad,
                          int64_t pos_begin, int64_t pos_end, int64_t* __restrict__ deg, int64_t* __restrict__ degs,
-                         int32_t* __restrict__ max_deg, int64_t N_tail)
+                         int32_t* __restrict__ max_deg, int64_t N_tail, int32_t* __restrict__ qmax)
 {
     // (unsharded: the scans' extra last elements are zeroed here instead of by two fill launches)
     if (N_tail >= 0 && blockIdx.x == 0 && threadIdx.x == 0) { deg[N_tail] = 0; degs[npad] = 0; }
@@ -503,14 +503,18 @@ __global__ void k_degree(const int32_t* __restrict__ slice_cnt, const int32_t* _
     // longest column of the shard: the log-ordering kernel stages whole columns in LDS.  One candidate per workgroup, and it only
     // goes to the atomic when it beats the maximum it can see (a stale read at worst costs a redundant atomic): one atomic per
     // wavefront on the single address took 0.18 ms at N = 1e6 (~88 atomics / us), the pre-checked per-wavefront form 0.08
-    __shared__ int s_m[4];
+    // ... and the fullest quarter (16 consecutive positions: what one log of the single-pass build has to hold)
+    __shared__ int s_m[4], s_q[4];
     int m = (int)min(k, (int64_t)0x7fffffff);
-    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) s_m[(threadIdx.x >> 6) & 3] = m;
+    int qs = m;
+    for (int off = 8; off > 0; off >>= 1) qs += __shfl_xor(qs, off);
+    for (int off = 32; off > 0; off >>= 1) { m = max(m, __shfl_xor(m, off)); qs = max(qs, __shfl_xor(qs, off)); }
+    if ((threadIdx.x & 63) == 0) { s_m[(threadIdx.x >> 6) & 3] = m; s_q[(threadIdx.x >> 6) & 3] = qs; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int q = 1; q < (int)(blockDim.x >> 6) && q < 4; ++q) m = max(m, s_m[q]);
+        for (int q = 1; q < (int)(blockDim.x >> 6) && q < 4; ++q) { m = max(m, s_m[q]); qs = max(qs, s_q[q]); }
         if (m > *(volatile int32_t*)max_deg) atomicMax(max_deg, m);
+        if (qs > *(volatile int32_t*)qmax) atomicMax(qmax, qs);
     }
 }
 
@@ -610,7 +614,7 @@ __global__ void k_spec_check(const int32_t* __restrict__ pool_flag, const int32_
 
 // everything the host wants to know after a count, gathered into one block so that ONE copy into pinned memory brings it
 // back (four separate copies into pageable host variables are four blocking round trips: ~100 us of idle GPU per step)
-struct count_readback { unsigned long long pairs[512]; long long nnz; int pool_over, list_mx, max_deg, pad_; };
+struct count_readback { unsigned long long pairs[512]; long long nnz; int pool_over, list_mx, max_deg, pad_, qmax, pad2_; };
 __global__ __launch_bounds__(512) void k_count_readback(const unsigned long long* __restrict__ pairs, const int64_t* __restrict__ nnz,
                                                         const int32_t* __restrict__ pool_flag, const int32_t* __restrict__ list_max,
                                                         const int32_t* __restrict__ max_deg, count_readback* __restrict__ out,
@@ -623,6 +627,7 @@ __global__ __launch_bounds__(512) void k_count_readback(const unsigned long long
         out->pool_over = pool_flag ? *pool_flag : 0;
         out->list_mx = list_max ? *list_max : 0;
         out->max_deg = *max_deg;
+        out->qmax = max_deg[2];                               // (the word behind the longest column's: the fullest quarter)
     }
 }
 
@@ -693,7 +698,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         bool ok = true;
         // half build: the whole graph on this ctx, through the single-pass logs (decided before the lists, which differ)
         // (a shard does the same for the pairs inside it; its pairs with other shards' samples are found from its own side only)
-        half = ctx->use_half && !ctx->half_off && ctx->use_pool && nt > 0 && !too_long_hint;
+        half = ctx->use_half && ctx->use_pool && nt > 0 && !too_long_hint && !ctx->pool_skip_once;
         if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok, spec, half))) return rc;    // per-tile candidate chunk lists
         tm2.end("grid");
         if (!ok) {
@@ -710,11 +715,9 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     const int64_t target = mf ? (ctx->d <= 6 ? ctx->mf_target_items : ctx->mf_target_items * 7 / 4) : 32768;
     if (units > 0) S = (int)std::min<int64_t>(MPFMT_MAXS, std::max<int64_t>(1, (target + units - 1) / units));
     if (!mf) half = false;
-    if (half) S = std::min(S, MPFMT_MAXS - 1);                 // (the foreign log is one more log of a quarter tile: S + 1 <= 16)
     ctx->S = S;
     const int64_t npad = ctx->ntiles * 64;
-    // (one more row for the half build: the foreign hits of each cell-sorted position)
-    if ((rc = ensure(ctx, (void**)&ctx->slice_cnt, sizeof(int32_t) * (size_t)(S + 1) * npad))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->slice_cnt, sizeof(int32_t) * (size_t)S * npad))) return rc;      // (per-slice counts: the two-pass forms)
     if ((rc = ensure(ctx, (void**)&ctx->deg, sizeof(int64_t) * (N + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (N + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->degs, sizeof(int64_t) * (npad + 1)))) return rc;
@@ -741,42 +744,42 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         HIPCHK(ctx, hipMemsetAsync(ctx->degs, 0, sizeof(int64_t) * (npad + 1), ctx->stream));
     }                                                          // (unsharded: k_degree writes every entry, the scans' extra last ones too)
 
-    // single-pass pool: capacity from the last build of the same (N, r), else from the ball-volume estimate
-    bool pool = mf && ctx->use_pool && nt > 0 && !too_long_hint;
+    // single-pass logs: ONE log per quarter tile (16 consecutive cell-sorted columns) that receives every record of its columns,
+    // whoever finds the hit.  What a log must hold is the sum of 16 neighbouring columns' degrees -- a quantity with little spread
+    // (no share of a tile's hits by slice or by finder enters it) -- so its capacity is the fullest quarter of the last build of the same
+    // (N, r, shard) plus slack, or, on a cold ctx, the quarter of an INTERIOR column of a uniform sample set: 16 x (ball volume x
+    // density) plus six standard deviations of that sum with its 16 terms taken as one.  Samples denser than uniform somewhere overflow
+    // the cold estimate: that build is redone in the two-pass form, which leaves the true maximum for the next one.
+    bool pool = mf && ctx->use_pool && nt > 0 && !too_long_hint && !ctx->pool_skip_once;
+    ctx->pool_skip_once = false;
+    double nnz_est = 0.0;
     if (pool) {
-        double want;
-        if (hint_match) {
-            want = (double)ctx->pool_hint_nnz * 1.02 + 4096.0;
+        double qwant;
+        const int d = ctx->d;
+        if (hint_match && ctx->pool_hint_qmax > 0) {
+            const double qm = (double)ctx->pool_hint_qmax;
+            qwant = qm * 1.12 + 96.0 * std::sqrt(std::max(qm / 16.0, 1.0)) + 64.0;
+            nnz_est = (double)ctx->pool_hint_nnz;
         } else {
-            const int d = ctx->d;
             double vol = 1.0;
             for (int i = 0; i < d; ++i) vol *= std::max(ctx->bb_hi[i] - ctx->bb_lo[i], 1e-300);
             const double ball = std::pow(M_PI, d / 2.0) / std::tgamma(d / 2.0 + 1.0) * std::pow(r, (double)d);
-            want = std::min(1.0, ball / vol) * (double)N * (double)(nt * 64) * 1.15 + 64.0 * (double)N;
+            const double lam = std::min(1.0, ball / vol) * (double)N;          // neighbours of an interior sample
+            qwant = 16.0 * lam * 1.1 + 96.0 * std::sqrt(std::max(lam, 1.0)) + 64.0;
+            nnz_est = lam * (double)(nt * 64);
         }
-        want = std::min(want, (double)N * (double)(nt * 64));
-        // every (tile, slice) item owns four fixed-capacity append logs (one per 16 columns of the tile); an item of the
-        // interior of the domain finds ~1.7x the mean, so logs get 2.3x the mean plus a fixed slack -- an overflow falls back
-        // to the fill pass
-        const int64_t items = nt * S;
-        // (a build that overflowed doubles the slack of the following ones)
-        const int64_t capc = (((int64_t)(want / ((double)items * 4.0) * 2.3) + 96) * ctx->pool_slack + 3) / 4 * 4;
-        if ((double)capc * (double)items * 64.0 * (half ? 2.0 : 1.0) > 96e9) pool = false;      // cap the logs at 96 GB of the 288
+        qwant = std::min(qwant * (double)ctx->pool_slack, 16.0 * (double)std::min<int64_t>(N, MPFMT_ORD_MAXDEG + 1));   // (16 columns of the longest the ordering kernel takes)
+        const int64_t qcap = std::max<int64_t>(64, ((int64_t)qwant + 15) / 16 * 16);
+        if ((double)qcap * (double)nt * 4.0 * 12.0 > 96e9) pool = false;      // cap the logs at 96 GB of the 288
         else {
-            const size_t cap = (size_t)capc * (size_t)items * 4;
-            if ((rc = ensure(ctx, (void**)&ctx->pool, sizeof(mpfmt_hit) * cap))) return rc;
-            if ((rc = ensure(ctx, (void**)&ctx->log_len, sizeof(int32_t) * (size_t)items * 4))) return rc;
+            const size_t nq = (size_t)nt * 4;
+            if ((rc = ensure(ctx, (void**)&ctx->qkey, sizeof(uint32_t) * (size_t)qcap * nq))) return rc;
+            if ((rc = ensure(ctx, (void**)&ctx->qd2, sizeof(double) * (size_t)qcap * nq))) return rc;
+            if ((rc = ensure(ctx, (void**)&ctx->qlen, sizeof(int32_t) * nq))) return rc;
             if (!ctx->pool_flag) HIPCHK(ctx, hipMalloc((void**)&ctx->pool_flag, sizeof(int32_t)));
             if (!ctx->zarena) HIPCHK(ctx, hipMemsetAsync(ctx->pool_flag, 0, sizeof(int32_t), ctx->stream));
-            ctx->pool_cap = capc;
-            if (half) {
-                // a foreign log can receive up to all the hits of its 16 columns (the last tile finds none itself): S item logs' worth
-                ctx->fcap = (capc * S + 15) / 16 * 16;           // (k_foreign_degrees reads the column bytes 16 at a time)
-                if ((rc = ensure(ctx, (void**)&ctx->fpool, sizeof(mpfmt_hit) * (size_t)ctx->fcap * (size_t)nt * 4))) return rc;
-                if ((rc = ensure(ctx, (void**)&ctx->flen, sizeof(int32_t) * (size_t)nt * 4))) return rc;
-                if ((rc = ensure(ctx, (void**)&ctx->fcol, (size_t)ctx->fcap * (size_t)nt * 4))) return rc;
-                HIPCHK(ctx, hipMemsetAsync(ctx->flen, 0, sizeof(int32_t) * (size_t)nt * 4, ctx->stream));
-            }
+            HIPCHK(ctx, hipMemsetAsync(ctx->qlen, 0, sizeof(int32_t) * nq, ctx->stream));
+            ctx->qcap = qcap;
         }
     }
     if (half && !pool) {
@@ -795,11 +798,10 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         // form 2: the pairs flagged by the drain's broad phase are listed for k_exact_pairs in 1024 dense regions (an item appends to
         // region item mod 1024 with one reservation per drain); room for three quarters of all pairs being flagged -- beyond that the
         // flag is raised and the host sweeps the whole graph
-        const int64_t items = nt * S;
-        const double pairs_est = 0.5 * (double)ctx->pool_cap * 4.0 * (double)items / 2.3;        // (the logs' capacity is 2.3x the expected hits)
+        const double pairs_est = 0.5 * nnz_est;
         // (a list that overflowed -- obstacles crowd the flagged pairs into few regions -- doubles the room of the following builds)
         ctx->pair_icap = ctx->debug_small_lists ? 8 : (int64_t)(0.75 * pairs_est / 1024.0) * ctx->pair_slack + 4096;      // (option debug_small_lists: the overflow path, for the tests)
-        if ((rc = ensure(ctx, (void**)&ctx->pair_items, 32 * (size_t)ctx->pair_icap * 1024))) return rc;
+        if ((rc = ensure(ctx, (void**)&ctx->pair_items, 16 * (size_t)ctx->pair_icap * 1024))) return rc;
         if (!ctx->zarena) {
             if ((rc = ensure(ctx, (void**)&ctx->pair_cnt, sizeof(int32_t) * (1024 + 1)))) return rc;
             HIPCHK(ctx, hipMemsetAsync(ctx->pair_cnt, 0, sizeof(int32_t) * (1024 + 1), ctx->stream));
@@ -828,10 +830,10 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         }
         const int B = 256;
         const int64_t pb = ctx->tile_begin * 64, pe = ctx->tile_end * 64;
-        if (half && (rc = mpfmt_launch_foreign_degrees(ctx))) return rc;
-        hipLaunchKernelGGL(k_degree, dim3((unsigned)((pe - pb + B - 1) / B)), dim3(B), 0, ctx->stream,
-                           ctx->slice_cnt, ctx->perm, S + (half ? 1 : 0), npad, pb, pe, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512),
-                           (ctx->world > 1 || nt <= 0) ? (int64_t)-1 : N);
+        if (pool) { if ((rc = mpfmt_launch_log_degrees(ctx))) return rc; }         // single pass: the columns' degrees are counts over the logs' keys
+        else hipLaunchKernelGGL(k_degree, dim3((unsigned)((pe - pb + B - 1) / B)), dim3(B), 0, ctx->stream,
+                                ctx->slice_cnt, ctx->perm, S, npad, pb, pe, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512),
+                                (ctx->world > 1 || nt <= 0) ? (int64_t)-1 : N, (int32_t*)(ctx->d_pairs + 513));
     }
     if ((rc = scan_i64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1)))) return rc;      // columns in original order
     // staging offsets in sorted order: only the two-pass forms read them (the single-pass build orders its logs straight into the
@@ -865,6 +867,7 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     unsigned long long pairs[512];
     memcpy(pairs, rb->pairs, sizeof pairs);
     if (ctx->spec_lists && list_mx > ctx->list_cap) {             // lists were truncated: everything after them is void
+        ctx->redo_reason |= 1; ctx->redo_count += 1;
         ctx->lists_r = -1.0; ctx->lists_cap_trusted = -1;
         ctx->list_cap = std::min<int64_t>(ctx->ntiles, ((int64_t)list_mx + 255) / 256 * 256);
         ctx->spec_lists = false;
@@ -875,24 +878,22 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     ctx->max_deg = rb->max_deg;
     // the log-ordering kernel stages whole columns in LDS: a graph with a longer column takes the two-pass build
     const bool too_long = rb->max_deg > MPFMT_ORD_MAXDEG;
-    if (ctx->half_used && pool && (pool_over || too_long)) {
-        // a half build cannot fall back to the fill pass (its counts and lists cover half the pairs): count again, whole
-        // (an overflow doubles the logs' slack -- the first slices of a half build's lists, the tile's own neighbourhood, find several
-        // times the mean when the lists are cut into many slices -- and the half form is tried again once a whole build has left
-        // its hint; a column too long, or an overflow at the widest slack, ends the tries)
-        if (pool_over && ctx->pool_slack >= 8) ctx->half_fail = 2;      // (a column too long is remembered by the size hint instead: the logs come back with shorter columns)
-        ctx->half_off = true; ctx->half_used = false;
-        ctx->lists_r = -1.0;
+    if (pool && (pool_over || too_long)) {
+        // a log overflowed (samples denser somewhere than the capacity assumed) or a column is too long for the ordering kernel: the
+        // single pass has no per-slice counts to fill from (and a half build's lists cover half the pairs) -- the graph is counted
+        // again in the two-pass form.  That count leaves the fullest quarter and the longest column in the size hint, so the next
+        // build of the same (N, r, shard) is a single pass again with logs that hold (or goes straight to two passes while a column
+        // stays too long); an overflow also doubles the slack of the following builds, up to 8x.
         if (pool_over && ctx->pool_slack < 8) ctx->pool_slack *= 2;
+        ctx->redo_reason |= pool_over ? 2 : 4; ctx->redo_count += 1;
+        ctx->pool_skip_once = true;
+        ctx->lists_r = -1.0;
         ctx->graph_counted = false;
         if (spec_failed) { *spec_failed = true; return MPFMT_OK; }
         return mpfmt_launch_rdisc_count(ctx, r);
     }
-    if (spec_failed && pool && (pool_over || too_long)) *spec_failed = true;
-    ctx->pool_valid = pool && pool_over == 0 && !too_long;
-    if (ctx->pool_valid && ctx->half_off && ctx->half_fail < 2) ctx->half_off = false;
-    if (pool && pool_over && ctx->pool_slack < 8) ctx->pool_slack *= 2;
-    ctx->pool_hint_N = N; ctx->pool_hint_r = r; ctx->pool_hint_nnz = nnz; ctx->pool_hint_maxdeg = rb->max_deg;
+    ctx->pool_valid = pool;
+    ctx->pool_hint_N = N; ctx->pool_hint_r = r; ctx->pool_hint_nnz = nnz; ctx->pool_hint_maxdeg = rb->max_deg; ctx->pool_hint_qmax = rb->qmax;
     ctx->pool_hint_rank = ctx->rank; ctx->pool_hint_world = ctx->world;
     ctx->nnz = nnz;
     for (int i = 1; i < 256; ++i) { pairs[0] += pairs[2 * i]; pairs[1] += pairs[2 * i + 1]; }
@@ -905,7 +906,7 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     return MPFMT_OK;
 }
 
-int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r, bool fuse_sweep)
+int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
 {
     if (!ctx->graph_counted || ctx->graph_r != r)
         return mpfmt_fail(ctx, MPFMT_ERR_STATE, "rdisc_fill without a matching rdisc_count");
@@ -922,9 +923,8 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r, bool fuse_sweep)
         if (ctx->rdisc_path_used == 2 && ctx->pool_valid) {
             // single pass: the hits are already in the slot lists; order each column straight into the final CSC
             mpfmt_timed tm4(ctx);
-            const bool fuse = fuse_sweep && mpfmt_order_can_fuse(ctx);
-            if ((rc = mpfmt_order_logs(ctx, nullptr, fuse))) return rc;
-            tm4.end(fuse ? "order_sweep" : "rdisc_sort");
+            if ((rc = mpfmt_order_logs(ctx, nullptr))) return rc;
+            tm4.end("rdisc_sort");
             done = 1;
         }
         if (!done) {
@@ -1024,25 +1024,24 @@ int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r)
             ctx->pool_valid = true; ctx->rdisc_path_used = 2;
             ctx->graph_r = r; ctx->graph_counted = true;
             mpfmt_timed tm7(ctx);
-            const bool fuse = mpfmt_order_can_fuse(ctx);
             ctx->graph_swept = false;
-            if ((rc = mpfmt_order_logs(ctx, ctx->spec_fail, fuse, cap))) return rc;
-            tm7.end(fuse ? "order_sweep" : "rdisc_sort");
+            if ((rc = mpfmt_order_logs(ctx, ctx->spec_fail, cap))) return rc;
+            tm7.end("rdisc_sort");
             ctx->graph_filled = true;
             // (form 2 of the fused edge tests: the ordering pass has written the mask already)
-            if (!fuse && !ctx->graph_swept && (rc = mpfmt_launch_graph_sweep(ctx, ctx->spec_fail, cap))) return rc;
+            if (!ctx->graph_swept && (rc = mpfmt_launch_graph_sweep(ctx, ctx->spec_fail, cap))) return rc;
             ctx->step_state = 1;                                    // speculative kernels in flight
             return MPFMT_OK;
         }
         if ((rc = mpfmt_rdisc_count_finish(ctx, r, nullptr))) return rc;
-        if ((rc = mpfmt_launch_rdisc_fill(ctx, r, true))) return rc;
+        if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
         if ((rc = sweep_checked(ctx))) return rc;
         ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
         ctx->step_state = 2;
         return MPFMT_OK;
     }
     if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
-    if ((rc = mpfmt_launch_rdisc_fill(ctx, r, true))) return rc;
+    if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
     if ((rc = sweep_checked(ctx))) return rc;
     ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
     ctx->step_state = 2;
@@ -1069,6 +1068,7 @@ static int32_t step_finish_inner(mpfmt_ctx* ctx)
         if (!failed && ctx->nnz < ctx->nnz_cap && ctx->pool_valid) {
             ctx->graph_filled = true; ctx->graph_swept = true;      // (finish resets the flags it owns)
             if (ctx->pend_overflowed) {                             // the pending-entry / pending-pair list was cut short: sweep the whole graph
+                ctx->redo_reason |= 16; ctx->redo_count += 1;
                 if (ctx->sweep_in_order && ctx->pair_slack < 8) ctx->pair_slack *= 2;
                 ctx->pend_valid = false; ctx->sweep_in_order = false; ctx->graph_swept = false;
                 return mpfmt_launch_graph_sweep(ctx);
@@ -1076,10 +1076,11 @@ static int32_t step_finish_inner(mpfmt_ctx* ctx)
             return MPFMT_OK;
         }
         // the trust was misplaced: redo the step the careful way (capacities have been corrected by finish)
+        if (!failed) { ctx->redo_reason |= 8; ctx->redo_count += 1; }       // (nnz beyond the trusted allocation)
         ctx->spec_ready = false;
         ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
         if ((rc = mpfmt_launch_rdisc_count(ctx, r))) return rc;
-        if ((rc = mpfmt_launch_rdisc_fill(ctx, r, true))) return rc;
+        if ((rc = mpfmt_launch_rdisc_fill(ctx, r))) return rc;
         if ((rc = sweep_checked(ctx))) return rc;
         ctx->spec_ready = ctx->rdisc_path_used == 2 && ctx->pool_valid;
         return MPFMT_OK;

@@ -69,27 +69,27 @@ struct mf_args {
     int64_t list_cap;
     unsigned long long* pairs;
     unsigned long long* survivors;
-    // MODE 2 (single pass): exact hits are appended to the item's log while they are counted
-    int32_t* pool_flag;             // set to 1 when a log overflows (the build then falls back to a fill pass)
-    long long pool_cap;             // capacity of ONE log, in records
-    mpfmt_hit* pool;                // [items][4][pool_cap] (sample index of the row, cell-sorted position | column << 26, sqrt(d2)) records:
-                                    // an item keeps one log per 16 columns of its tile
-    int32_t* log_len;               // [items][4] records in each log
-    // half build (unsharded single pass): the chunk lists hold only chunks >= the tile, every pair is found once, and the hit of a
-    // chunk beyond the tile is also written as the record of the OTHER column into that column's tile's foreign log
+    // MODE 2 (single pass): every exact hit is appended -- while it is found -- to the LOG OF ITS COLUMN'S QUARTER TILE (16 consecutive
+    // cell-sorted columns): one log per quarter whoever finds the hit (any slice of the column's own tile; in a half build also the
+    // tiles before it, which see the pair from the other end).  A record is 12 bytes in two arrays: a key word -- row sample index
+    // (26 bits) | column within the quarter << 26 | broad-phase flag << 30 (bit 31: set later by k_exact_pairs on a blocked edge) --
+    // and the squared distance.  Places are reserved on the log's global cursor, one returning atomic per (drain, log).
+    int32_t* pool_flag;             // set to 1 when a log overflows (the build is then redone in the two-pass form)
+    long long qcap;                 // capacity of ONE quarter log, in records
+    uint32_t* qkey;                 // [quarters of the shard][qcap]
+    double* qd2;                    // [quarters of the shard][qcap]
+    int32_t* qlen;                  // [quarters of the shard] cursors (zeroed per build; may run past qcap: readers clamp)
+    // half build: the chunk lists hold only chunks >= the tile (inside the shard), every pair is found once, and the hit of a chunk
+    // beyond the tile is also written as the record of the OTHER column into that column's quarter log
     int32_t half;
     int64_t ntiles_shard;           // tiles of this shard: the other column's record is written for candidates in [blk_begin, blk_begin + ntiles_shard)
-    mpfmt_hit* fpool;               // [tiles][4][fcap] foreign logs, one per 16 columns of a tile, appended to by the tiles before it
-    int32_t* flen;                  // [tiles][4] their lengths (global cursors)
-    long long fcap;
-    uint8_t* fcol;                  // [tiles][4][fcap] column (0..15 of the quarter) of every foreign record: what k_foreign_degrees reads
     // broad phase of the edge tests in the drain (half build, d <= 6, <= 256 boxes in the state space's own coordinates, every
     // sample inside the state space): bit 30 of a record's row index = "the segment's box meets an obstacle's: exact test needed"
     int32_t fb;
     int32_t M;
     const double* boxes;            // [M][2][D]
-    // fb == 2: the pairs whose segment box met an obstacle's are listed (MF_NREG regions of icap 32-byte items) for
-    // k_exact_pairs, which runs the slab tests in both directions and sets bit 31 of the blocked records' row index
+    // fb == 2: the pairs whose segment box met an obstacle's are listed (MF_NREG regions of icap 16-byte items, one per (pair, box)
+    // unit) for k_exact_pairs, which runs the slab tests in both directions and sets bit 31 of the blocked records' key
     uint4* pitems;
     int32_t* pcnt;                  // [MF_NREG] items in each region (zeroed per build; may exceed icap: the reader clamps)
     long long icap;
@@ -405,7 +405,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     __shared__ unsigned long long s_rh[MF_RCAP];          //               the lane's 64 sign bits of that chunk
     __shared__ uint32_t s_qs[MF_QSZ];                     // survivor queue: chunk << 12 | finding lane << 6 | sign-bit position
     __shared__ int32_t s_cnt[64];
-    __shared__ int32_t s_lc[4];                           // records in the item's four logs
+    __shared__ int32_t s_lc[4];                           // own hits of the drain in work, per quarter of the tile (zero between drains)
     __shared__ int64_t s_base[MODE == 1 ? 64 : 1];
 
     const int lane = threadIdx.x;
@@ -527,7 +527,6 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     int qcount = 0;                                           // wave-uniform survivor queue length
     int rcount = 0;                                           // wave-uniform record queue length
     int pool_over = 0;
-    mpfmt_hit* const __restrict__ mylog = (MODE == 2) ? a.pool + (long long)item * 4 * a.pool_cap : nullptr;
     auto drain = [&](int n) {
         // takes the LAST n queue entries (order is irrelevant: columns are sorted afterwards), so nothing moves
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -571,8 +570,8 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                     const int64_t pos = s_base[ql] + slot;
                     a.rowtmp[pos] = a.perm[jg];
                     a.valtmp[pos] = sqrt(d2);
-                } else {
-                    atomicAdd(&s_cnt[ql], 1);                             // the column's degree (no return value needed)
+                } else if (MODE == 0) {
+                    atomicAdd(&s_cnt[ql], 1);                             // the column's degree (no return value needed; the single pass counts from the logs)
                 }
             }
         }
@@ -601,114 +600,104 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                 pk_keep = pk; pc_keep = pc;
             }
         }
-        [[maybe_unused]] long long own_idx = -1, for_idx = -1;      // where the two records of this lane's pair went (pending-pair items)
-        [[maybe_unused]] uint32_t own_j = 0, for_j = 0;
-        if (MODE == 2 && hit) {
-            // single pass: the hit goes to one of the item's FOUR logs, one per 16 columns of its tile, so that k_order_logs can
-            // regroup a quarter tile (about 1 700 hits) in one pass through LDS.  Its place is a returning LDS atomic on the log's
-            // counter (four addresses per wavefront: the LDS pipe serialises them beside the other wavefronts' VALU work -- four
-            // ballots with per-lane selects cost this VALU-bound kernel 50 instructions per drain), so a drain's hits still
-            // land in four contiguous runs of 16-byte records: row sample index, cell-sorted position | column << 26, d2 (the
-            // square root is taken by the ordering kernel, which has the VALU slack)
+        if constexpr (MODE == 2) {
+            // ---- single pass: the records of this drain's hits go to the quarter logs ------------------------------------------------
+            // own record: column = the query ql of this tile, row = the candidate -> log (tile, ql >> 4); the place inside the drain's
+            // group is a returning LDS atomic on a per-drain counter (four addresses; the counters are left at zero again)
             const int g = (int)(ql >> 4);
-            const int p = atomicAdd(&s_lc[g], 1);
-            if (p < a.pool_cap) {
-                mpfmt_hit h;
-                own_j = (uint32_t)a.perm[jg] | pendflag;
-                h.j = (int32_t)own_j; h.pad = (int32_t)(jg | (ql << 26)); h.d = d2;
-                own_idx = ((long long)item * 4 + g) * a.pool_cap + p;
-                *reinterpret_cast<uint4*>(&mylog[(long long)g * a.pool_cap + p]) = *reinterpret_cast<const uint4*>(&h);   // one 16-byte store
-            } else {
-                pool_over = 1;
-            }
-        }
-        // fb == 2: the pairs whose box met an obstacle's are listed for k_exact_pairs in one of MF_NREG dense regions (this item's:
-        // item mod MF_NREG) -- one reservation per drain on the region's counter, requested here, used after the foreign records
-        // below are out (per-item segments sized for the worst case left the list scattered over 9 GB in 6 KB pieces: the kernel that
-        // reads it spent 1.3 ms on address translation alone)
-        // One item per (pair, box) UNIT -- a pair that met k <= 4 boxes writes k items, one that met more a single item with bit 8 of the box word set
-        // ("every box"): the reader's lanes are then units with nothing to look up among each other.
-        [[maybe_unused]] int ibase = 0, iexcl = 0, iunits = 0;
-        [[maybe_unused]] unsigned long long ipm = 0;
-        [[maybe_unused]] bool iem = false;
-        if constexpr (MODE == 2 && D <= 6) {
-            if (a.fb == 2) {
-                iem = hit && pendflag != 0 && own_idx >= 0;
-                ipm = __ballot(iem);
-                if (ipm) {
-                    iunits = iem ? (pc_keep > 4u ? 1 : (int)pc_keep) : 0;
-                    int incl = iunits;                                        // inclusive scan over the lanes (DPP)
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);       // row_shr:1
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);       // row_shr:2
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);       // row_shr:4
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);       // row_shr:8
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);      // row_bcast:15
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);      // row_bcast:31
-                    iexcl = incl - iunits;
-                    const int total = __builtin_amdgcn_readlane(incl, 63);
-                    if (lane == 0) ibase = atomicAdd(&a.pcnt[item & (MF_NREG - 1)], total);
+            int pin = 0;
+            if (hit) pin = atomicAdd(&s_lc[g], 1);
+            // the same pair seen from the other end (half build): column jg, row = this query -> the log of jg's quarter tile.  The hits
+            // of a drain fall into a handful of such logs (its survivors come from two or three chunks): the lanes of each are found with
+            // one ballot per log, the first of them reserves the places of all
+            const int64_t fc = (int64_t)(jg >> 6) - a.blk_begin;        // the candidate's tile, counted from the shard's first
+            const bool fh = a.half && hit && (int64_t)(jg >> 6) != tile && fc >= 0 && fc < a.ntiles_shard;
+            const int fq = (int)(fc * 4 + (int64_t)((jg & 63u) >> 4));
+            int leader = lane, pre = 0, cnt_l = 0;
+            {
+                unsigned long long rem = __ballot(fh);
+                while (rem) {
+                    const int L = __builtin_ctzll(rem);
+                    const int key = __builtin_amdgcn_readlane(fq, L);
+                    const bool mine = fh && fq == key;
+                    const unsigned long long mm = __ballot(mine);
+                    if (mine) { leader = L; pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u)); }
+                    if (lane == L) cnt_l = (int)__popcll(mm);
+                    rem &= ~mm;
                 }
             }
-        }
-        if (MODE == 2 && a.half) {
-            // the same pair seen from the other end: column jg, row = this query -- a record for the FOREIGN log of jg's quarter tile.
-            // The hits of a drain fall into a handful of such logs (its survivors come from two or three chunks): the lanes of each
-            // log are found with one ballot per log, the first of them reserves the places of all with ONE returning atomic (a
-            // returning atomic per hit ran at 2e10 / s: 4.7 ms for the 1e8 of the north star), the others read it by lane exchange.
-            // The column lane of every record also goes to a compact side array, from which k_foreign_degrees counts the columns'
-            // foreign hits (the CSC offsets need every column's degree before the logs are ordered).
-            const int64_t fc = (int64_t)(jg >> 6) - a.blk_begin;        // the candidate's tile, counted from the shard's first
-            const bool fh = hit && (int64_t)(jg >> 6) != tile && fc >= 0 && fc < a.ntiles_shard;
-            const int fq = (int)(fc * 4 + (int64_t)((jg & 63u) >> 4));
-            unsigned long long rem = __ballot(fh);
-            int leader = lane, pre = 0, cnt_l = 0;
-            while (rem) {
-                const int L = __builtin_ctzll(rem);
-                const int key = __builtin_amdgcn_readlane(fq, L);
-                const bool mine = fh && fq == key;
-                const unsigned long long mm = __ballot(mine);
-                if (mine) { leader = L; pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u)); }
-                if (lane == L) cnt_l = (int)__popcll(mm);
-                rem &= ~mm;
-            }
-            if (__ballot(fh)) {
-                // (storing these from the NEXT drain, so that nobody waits for the reservation's round trip, was measured: 1.305 ->
-                // 1.29 ms; not worth the LDS and the second code path)
-                int base = 0;
-                if (fh && lane == leader) base = atomicAdd(&a.flen[fq], cnt_l);
-                base = __shfl(base, leader);
-                const int fp = base + pre;
-                if (fh) {
-                    if (fp < a.fcap) {
-                        const uint32_t qs = (uint32_t)(tile * 64) + ql;
-                        mpfmt_hit h;
-                        for_j = (uint32_t)a.perm[qs] | pendflag;
-                        h.j = (int32_t)for_j; h.pad = (int32_t)(qs | ((jg & 63u) << 26)); h.d = d2;
-                        for_idx = (long long)fq * a.fcap + fp;
-                        *reinterpret_cast<uint4*>(&a.fpool[for_idx]) = *reinterpret_cast<const uint4*>(&h);
-                        a.fcol[for_idx] = (uint8_t)(jg & 15u);
-                    } else {
-                        pool_over = 1;
+            // fb == 2: one item per (pair, box) unit of the pairs whose box met an obstacle's -- a pair that met k <= 4 boxes writes k
+            // items, one that met more a single item that stands for "every box" -- in one of MF_NREG dense regions (this item's: item
+            // mod MF_NREG), one reservation per drain
+            [[maybe_unused]] int ibase = 0, iexcl = 0, iunits = 0;
+            [[maybe_unused]] unsigned long long ipm = 0;
+            [[maybe_unused]] bool iem = false;
+            if constexpr (D <= 6) {
+                if (a.fb == 2) {
+                    iem = hit && pendflag != 0;
+                    ipm = __ballot(iem);
+                    if (ipm) {
+                        iunits = iem ? (pc_keep > 4u ? 1 : (int)pc_keep) : 0;
+                        int incl = iunits;                                        // inclusive scan over the lanes (DPP)
+                        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);       // row_shr:1
+                        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);       // row_shr:2
+                        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);       // row_shr:4
+                        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);       // row_shr:8
+                        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);      // row_bcast:15
+                        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);      // row_bcast:31
+                        iexcl = incl - iunits;
+                        const int total = __builtin_amdgcn_readlane(incl, 63);
+                        if (lane == 0) ibase = atomicAdd(&a.pcnt[item & (MF_NREG - 1)], total);
                     }
                 }
             }
-        }
-        if constexpr (MODE == 2 && D <= 6) {
-            if (a.fb == 2 && ipm) {
-                // items: where the pair's record(s) are, their first words, both cell-sorted positions and ONE box its segment box met
-                const int base = __builtin_amdgcn_readfirstlane(ibase);
-                if (iem) {
-                    const uint32_t fhi = for_idx >= 0 ? (uint32_t)((unsigned long long)for_idx >> 32) & 0xffu : 0xffu;
-                    const uint32_t w2 = ((uint32_t)((unsigned long long)own_idx >> 32) & 0xffu) | (fhi << 8);
-                    for (int u = 0; u < iunits; ++u) {
-                        const int pos = base + iexcl + u;
-                        if (pos < a.icap) {
-                            uint4* const dst = a.pitems + ((long long)(item & (MF_NREG - 1)) * a.icap + pos) * 2;
-                            const uint32_t kbx = pc_keep > 4u ? 256u : ((pk_keep >> (8 * u)) & 255u);        // (bit 8: every box)
-                            dst[0] = make_uint4((uint32_t)(unsigned long long)own_idx, (uint32_t)(unsigned long long)for_idx, w2, kbx);
-                            dst[1] = make_uint4((uint32_t)(tile * 64) + ql, jg, own_j, for_j);
-                        } else {
-                            *a.pend_over = 1;
+            // the reservations of the drain are requested back to back -- own logs (lanes 0..3), the other columns' logs (group leaders),
+            // the pending-pair region above -- and consumed after the keys are built: one L2 round trip for all of them
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int obase = 0;
+            if (lane < 4) {
+                const int c = s_lc[lane];
+                if (c) { s_lc[lane] = 0; obase = atomicAdd(&a.qlen[(tile - a.blk_begin) * 4 + lane], c); }
+            }
+            int fbase = 0;
+            if (fh && lane == leader) fbase = atomicAdd(&a.qlen[fq], cnt_l);
+            uint32_t own_key = 0, for_key = 0;
+            const uint32_t qs = (uint32_t)(tile * 64) + ql;
+            if (hit) own_key = (uint32_t)a.perm[jg] | ((ql & 15u) << 26) | pendflag;
+            if (fh) for_key = (uint32_t)a.perm[qs] | ((jg & 15u) << 26) | pendflag;
+            const int own_p = __shfl(obase, g) + pin;
+            const int for_p = __shfl(fbase, leader) + pre;
+            [[maybe_unused]] uint32_t own_w = 0xffffffffu, for_w = 0xffffffffu;      // places of the two records (pending-pair items)
+            if (hit) {
+                if (own_p < a.qcap) {
+                    const long long o = ((long long)(tile - a.blk_begin) * 4 + g) * a.qcap + own_p;
+                    a.qkey[o] = own_key; a.qd2[o] = d2;
+                    own_w = (uint32_t)own_p;
+                } else pool_over = 1;
+            }
+            if (fh) {
+                if (for_p < a.qcap) {
+                    const long long o = (long long)fq * a.qcap + for_p;
+                    a.qkey[o] = for_key; a.qd2[o] = d2;
+                    for_w = (uint32_t)for_p;
+                } else pool_over = 1;
+            }
+            if constexpr (D <= 6) {
+                if (a.fb == 2 && ipm) {
+                    // item: both cell-sorted positions (their quarters are the records' logs), ONE box the segment's box met (9 bits split
+                    // over the two position words; 256 = every box), the places of the two records in their logs
+                    const int base = __builtin_amdgcn_readfirstlane(ibase);
+                    if (iem && own_w != 0xffffffffu) {
+                        for (int u = 0; u < iunits; ++u) {
+                            const int pos = base + iexcl + u;
+                            if (pos < a.icap) {
+                                const uint32_t kbx = pc_keep > 4u ? 256u : ((pk_keep >> (8 * u)) & 255u);        // (bit 8: every box)
+                                a.pitems[(long long)(item & (MF_NREG - 1)) * a.icap + pos] =
+                                    make_uint4(qs | ((kbx & 63u) << 26), jg | ((kbx >> 6) << 26), own_w, for_w);
+                            } else {
+                                *a.pend_over = 1;
+                            }
                         }
                     }
                 }
@@ -863,11 +852,10 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     while (qcount > 0) drain(min(qcount, 64));
 
     if (MODE == 2) {
-        if (pool_over) *a.pool_flag = 1;                          // overflow: the build falls back to a fill pass
-        if (lane < 4) a.log_len[item * 4 + lane] = min(s_lc[lane], (int)a.pool_cap);
+        if (pool_over) *a.pool_flag = 1;                          // a quarter log overflowed: the build is redone in the two-pass form
     }
     if (MODE != 1) {
-        a.slice_cnt[(int64_t)slice * a.npad + qpos] = s_cnt[lane];
+        if (MODE == 0) a.slice_cnt[(int64_t)slice * a.npad + qpos] = s_cnt[lane];
         // per-XCD-sharded counters: a single hot address saturates at ~88 atomics/us (156k items would cost 1.8 ms)
         if (lane == 0 && a.pairs) { atomicAdd(a.pairs + 2 * (blockIdx.x & 255), tested); atomicAdd(a.pairs + 2 * (blockIdx.x & 255) + 1, surv); }
     }
@@ -974,37 +962,63 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
     return MPFMT_OK;
 }
 
-// half build: foreign hits of every column = a count over the compact column array of its quarter tile's foreign log (one
-// wavefront per quarter tile; the counts are row S of slice_cnt, where k_degree and the ordering kernel add them to the own ones)
-__global__ __launch_bounds__(256) void k_foreign_degrees(const uint8_t* __restrict__ fcol, const int32_t* __restrict__ flen, long long fcap,
-                                                         int64_t nq, int32_t* __restrict__ fdeg, int64_t pos0)
+// single pass: the degree of every column = a count over the keys of its quarter tile's log (one wavefront per quarter log), written
+// straight to the two degree arrays the scans read (by original index and by cell-sorted position); the longest column (the ordering
+// kernel stages whole columns) and the fullest log (the next build's capacity) go to two words behind the pair counters
+__global__ __launch_bounds__(256) void k_log_degrees(const uint32_t* __restrict__ qkey, const int32_t* __restrict__ qlen, long long qcap, int64_t nq,
+                                                     int64_t pos0, const int32_t* __restrict__ perm, int64_t* __restrict__ deg,
+                                                     int64_t* __restrict__ degs, int32_t* __restrict__ max_deg, int32_t* __restrict__ qmax,
+                                                     int64_t N_tail, int64_t npad)
 {
     __shared__ int s_c[4][16];
+    __shared__ int s_m[4], s_q[4];
+    // (unsharded: the scans' extra last elements are zeroed here instead of by two fill launches)
+    if (N_tail >= 0 && blockIdx.x == 0 && threadIdx.x == 0) { deg[N_tail] = 0; degs[npad] = 0; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
-    if (q >= nq) return;
-    if (lane < 16) s_c[wave][lane] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int n = (int)min((long long)flen[q], fcap);
-    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(fcol + q * fcap);           // (fcap is a multiple of 16)
-    for (int i0 = lane * 16; i0 < n; i0 += 64 * 16) {
-        const uint4 v = src[i0 >> 4];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    int kmax = 0, n = 0;
+    if (q < nq) {
+        if (lane < 16) s_c[wave][lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        n = (int)min((long long)qlen[q], qcap);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(qkey + q * qcap);           // (qcap is a multiple of 4)
+        for (int i0 = lane * 4; i0 < n; i0 += 64 * 4) {
+            const uint4 v = src[i0 >> 2];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) if (i0 + k < n) atomicAdd(&s_c[wave][(w[k >> 2] >> (8 * (k & 3))) & 15u], 1);
+            for (int k = 0; k < 4; ++k) if (i0 + k < n) atomicAdd(&s_c[wave][(w[k] >> 26) & 15u], 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 16) {
+            const int k = s_c[wave][lane];
+            const int64_t pos = pos0 + q * 16 + lane;
+            const int32_t o = perm[pos];
+            if (o >= 0) deg[o] = k;
+            degs[pos] = k;                                     // (pad positions: 0 -- nothing else clears them on an unsharded ctx)
+            kmax = k;
+        }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 16) fdeg[pos0 + q * 16 + lane] = s_c[wave][lane];
+    for (int off = 8; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
+    if (lane == 0) { s_m[wave] = kmax; s_q[wave] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (one candidate per workgroup, and it only goes to the atomic when it beats what is there: ~88 atomics / us on one address)
+        const int m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])), qm = max(max(s_q[0], s_q[1]), max(s_q[2], s_q[3]));
+        if (m > *(volatile int32_t*)max_deg) atomicMax(max_deg, m);
+        if (qm > *(volatile int32_t*)qmax) atomicMax(qmax, qm);
+    }
 }
 
-int32_t mpfmt_launch_foreign_degrees(mpfmt_ctx* ctx)
+int32_t mpfmt_launch_log_degrees(mpfmt_ctx* ctx)
 {
     const int64_t nq = (ctx->tile_end - ctx->tile_begin) * 4;
     if (nq <= 0) return MPFMT_OK;
-    hipLaunchKernelGGL(k_foreign_degrees, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ctx->stream, ctx->fcol, ctx->flen, (long long)ctx->fcap, nq,
-                       ctx->slice_cnt + (int64_t)ctx->S * (ctx->ntiles * 64), ctx->tile_begin * 64);
+    const bool whole = !(ctx->world > 1);
+    hipLaunchKernelGGL(k_log_degrees, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ctx->stream, ctx->qkey, ctx->qlen, (long long)ctx->qcap, nq,
+                       ctx->tile_begin * 64, ctx->perm, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512), (int32_t*)(ctx->d_pairs + 513),
+                       whole ? ctx->N : (int64_t)-1, ctx->ntiles * 64);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
@@ -1032,11 +1046,10 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.lists = (const uint32_t*)ctx->lists; a.list_len = ctx->list_len; a.list_cap = ctx->list_cap;
     a.pairs = (MODE == 1) ? nullptr : ctx->d_pairs;              // 256 x {tested, survivors} sharded counters
     a.survivors = nullptr;
-    a.pool_flag = ctx->pool_flag; a.pool_cap = ctx->pool_cap;
-    a.pool = ctx->pool; a.log_len = ctx->log_len;
+    a.pool_flag = ctx->pool_flag; a.qcap = ctx->qcap;
+    a.qkey = ctx->qkey; a.qd2 = ctx->qd2; a.qlen = ctx->qlen;
     a.half = (MODE == 2 && ctx->half_used) ? 1 : 0;
     a.ntiles_shard = ctx->tile_end - ctx->tile_begin;
-    a.fpool = ctx->fpool; a.flen = ctx->flen; a.fcap = ctx->fcap; a.fcol = ctx->fcol;
     a.fb = (MODE == 2 && ctx->broad_in_drain) ? (ctx->bits_in_records ? 2 : 1) : 0; a.M = ctx->M; a.boxes = ctx->boxes;
     a.pitems = (uint4*)ctx->pair_items; a.pcnt = ctx->pair_cnt; a.icap = ctx->pair_icap; a.pend_over = ctx->pair_over;
     if (MODE != 2 && ctx->lists_half) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "two-pass r-disc kernels need whole chunk lists");

@@ -1044,17 +1044,18 @@ __global__ __launch_bounds__(256) void k_sweep_pending(const uint4* __restrict__
 }
 
 // ---- exact tests of the PAIRS the pair kernel's broad phase flagged, before the logs are ordered ------------------------------------
-// Form 2 of the fused edge tests (option fuse_broad = 2).  The drain knows which obstacles a pair's segment box met; it lists the pair
-// with those box ids, the cell-sorted positions of its two ends and the places of its record(s) in the logs.  Here lane = pair: both
-// states are gathered from the cell-sorted copy, the slab test (boxesND.jl:46-51) runs for each listed box in BOTH directions -- it is
-// not symmetric bit for bit -- and a blocked direction sets bit 31 of its record's row index: (v = candidate -> w = query) is the
-// query's column's entry = the own record, (query -> candidate) the foreign one.  k_order_logs then clears the mask bits of the
-// entries whose record carries the bit.  No gather of rows by entry, no obstacle cull, no box loop.
+// Form 2 of the fused edge tests (option fuse_broad = 2).  The drain knows which obstacles a pair's segment box met; it lists one 16-byte
+// item per (pair, box) unit: the cell-sorted positions of the pair's two ends (their quarter tiles are the logs of its two records),
+// the box, and the records' places in those logs.  Here lane = unit: both states are gathered from the cell-sorted copy, the slab
+// test (boxesND.jl:46-51) runs in BOTH directions -- it is not symmetric bit for bit -- and a blocked direction sets bit 31 of its
+// record's key: (v = candidate -> w = query) is the query's column's entry = the own record, (query -> candidate) the other
+// column's.  k_order_logs then clears the mask bits of the entries whose key carries the bit.  No gather of rows by entry, no obstacle
+// cull, no box loop.
 template <int D>
 __global__ __launch_bounds__(256, 4) void k_exact_pairs(const uint4* __restrict__ pitems, const int32_t* __restrict__ pcnt, long long icap, int64_t nitems,
                                                      const int32_t* __restrict__ pend_over, const double* __restrict__ Xs,
-                                                     const double* __restrict__ boxes, int M, mpfmt_hit* __restrict__ pool,
-                                                     mpfmt_hit* __restrict__ fpool, const int32_t* __restrict__ spec_fail)
+                                                     const double* __restrict__ boxes, int M, uint32_t* __restrict__ qkey, long long qcap,
+                                                     int64_t qbase, const int32_t* __restrict__ spec_fail)
 {
     if (spec_fail && *spec_fail) return;
     if (*pend_over) return;
@@ -1076,15 +1077,16 @@ __global__ __launch_bounds__(256, 4) void k_exact_pairs(const uint4* __restrict_
             // than four -- every box is tried).  (Items per PAIR with up to four boxes, their units laid end to end here by a scan and a
             // search among the lanes, cost 15 dependent lane exchanges per 64 units.)
             const bool on = b0 + lane < n;
-            const uint4* __restrict__ src = pitems + (it * icap + min(b0 + lane, n - 1)) * 2;
-            const uint4 i0 = src[0], i1 = src[1];
-            const int kb = (int)(i0.w & 255u);
-            const bool all = on && (i0.w & 256u) != 0;
+            const uint4 i0 = pitems[it * icap + min(b0 + lane, n - 1)];
+            const uint32_t qs = i0.x & 0x03ffffffu, jg = i0.y & 0x03ffffffu;
+            const uint32_t kbw = (i0.x >> 26) | ((i0.y >> 26) << 6);
+            const int kb = (int)(kbw & 255u);
+            const bool all = on && (kbw & 256u) != 0;
             double q[D], c[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) q[i] = Xs[(int64_t)i1.x * D + i];
+            for (int i = 0; i < D; ++i) q[i] = Xs[(int64_t)qs * D + i];
 #pragma unroll
-            for (int i = 0; i < D; ++i) c[i] = Xs[(int64_t)i1.y * D + i];
+            for (int i = 0; i < D; ++i) c[i] = Xs[(int64_t)jg * D + i];
             bool fwd = true, rev = true;                      // own entry: is_free_motion(c, q); foreign entry: is_free_motion(q, c)
             {
                 const box_regs<D> bx = load_box_T<D>(sboxT, (on && !all) ? kb : 0);
@@ -1115,9 +1117,9 @@ __global__ __launch_bounds__(256, 4) void k_exact_pairs(const uint4* __restrict_
                     }
                 }
             }
-            if (on && !fwd) pool[(long long)(((unsigned long long)(i0.z & 0xffu) << 32) | (unsigned long long)i0.x)].j = (int32_t)(i1.z | 0x80000000u);
-            const unsigned fhi = (i0.z >> 8) & 0xffu;
-            if (on && !rev && fhi != 0xffu) fpool[(long long)(((unsigned long long)fhi << 32) | (unsigned long long)i0.y)].j = (int32_t)(i1.w | 0x80000000u);
+            // (a key has several writers now -- one unit per box the pair met: the mark is an OR, with no return value)
+            if (on && !fwd) atomicOr(&qkey[((long long)(qs >> 4) - qbase) * qcap + (long long)i0.z], 0x80000000u);
+            if (on && !rev && i0.w != 0xffffffffu) atomicOr(&qkey[((long long)(jg >> 4) - qbase) * qcap + (long long)i0.w], 0x80000000u);
         }
     }
 }
@@ -1130,7 +1132,7 @@ int32_t mpfmt_launch_exact_pairs(mpfmt_ctx* ctx, const int32_t* spec_fail)
     const size_t lds = (size_t)SWEEP_CHUNK * 2 * d * sizeof(double);
     mpfmt_timed tk(ctx);
 #define CASE(DD) case DD: hipLaunchKernelGGL((k_exact_pairs<DD>), dim3(1024, 4), dim3(256), lds, ctx->stream, (const uint4*)ctx->pair_items, (const int32_t*)ctx->pair_cnt, \
-        (long long)ctx->pair_icap, nitems, (const int32_t*)ctx->pair_over, ctx->Xs, ctx->boxes, ctx->M, (mpfmt_hit*)ctx->pool, (mpfmt_hit*)ctx->fpool, spec_fail); break;
+        (long long)ctx->pair_icap, nitems, (const int32_t*)ctx->pair_over, ctx->Xs, ctx->boxes, ctx->M, ctx->qkey, (long long)ctx->qcap, ctx->tile_begin * 4, spec_fail); break;
     switch (d) { CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) default: break; }
 #undef CASE
     tk.end("exact_pairs");

@@ -195,7 +195,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
-                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->pool, ctx->log_len, ctx->fpool, ctx->flen, ctx->fcol, ctx->pend_items, ctx->pend_cnt, ctx->pair_items, ctx->pair_cnt, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev, ctx->bb_dev};
+                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->qkey, ctx->qd2, ctx->qlen, ctx->pend_items, ctx->pend_cnt, ctx->pair_items, ctx->pair_cnt, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev, ctx->bb_dev};
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
     if (ctx->bb_host) hipHostFree(ctx->bb_host);
     mpfmt_comm_destroy(ctx);
@@ -1460,7 +1460,6 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "rebuild_index") == 0) { ctx->rebuild_index = value != 0; return MPFMT_OK; }
     if (strcmp(name, "rdisc_pool") == 0) { ctx->use_pool = value != 0; return MPFMT_OK; }
-    if (strcmp(name, "fuse_sweep") == 0) { ctx->fuse_sweep = value != 0; return MPFMT_OK; }
     if (strcmp(name, "wf_graphs") == 0) { ctx->wf_graphs = value != 0; return MPFMT_OK; }
     if (strcmp(name, "debug_small_lists") == 0) { ctx->debug_small_lists = value != 0; return MPFMT_OK; }
     if (strcmp(name, "fuse_broad") == 0) {
@@ -1469,7 +1468,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
         return MPFMT_OK;
     }
     if (strcmp(name, "rdisc_half") == 0) {
-        ctx->use_half = value != 0; ctx->half_off = false; ctx->half_fail = 0;
+        ctx->use_half = value != 0;
         ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false; ctx->spec_ready = false; ctx->lists_r = -1.0;
         return MPFMT_OK;
     }
@@ -1510,6 +1509,9 @@ int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value)
         return MPFMT_OK;
     }
     if (strcmp(name, "pend_overflowed") == 0) { *value = ctx->pend_overflowed ? 1 : 0; return MPFMT_OK; }
+    if (strcmp(name, "redo_count") == 0) { *value = ctx->redo_count; return MPFMT_OK; }
+    if (strcmp(name, "redo_reason") == 0) { *value = ctx->redo_reason; ctx->redo_reason = 0; return MPFMT_OK; }      // (bits since the last read)
+    if (strcmp(name, "qcap") == 0) { *value = ctx->qcap; return MPFMT_OK; }
     if (strcmp(name, "pool_used") == 0) { *value = ctx->pool_valid ? 1 : 0; return MPFMT_OK; }
     if (strcmp(name, "list_cap") == 0) { *value = ctx->list_cap; return MPFMT_OK; }
     if (strcmp(name, "survivors") == 0) { *value = ctx->survivors; return MPFMT_OK; }

@@ -43,10 +43,6 @@ struct mpfmt_ss {                        // BoundedStateSpace bounds (statespace
     double hi[MPFMT_MAX_DIM];
 };
 
-// one hit of the single-pass build: row sample index, (cell-sorted position of the row | column within the tile << 26), distance
-// in ONE 16-byte record
-struct __attribute__((aligned(16))) mpfmt_hit { int32_t j; int32_t pad; double d; };
-
 // 2-D SAT world (kernels_sat2d.hip): a Circle or a convex Polygon with the fields the predicates read
 #define MPFMT_MAX_POLY 16
 struct mpfmt_shape2d {
@@ -106,8 +102,7 @@ struct mpfmt_ctx {
     int32_t mf_xcd_mode = 512;
     int32_t mf_ablate = 0;               // timing experiments only
     int32_t num_cus = 256;               // compute units of the device (persistent-grid sizing)
-    int ord_d = -1;
-    int ord_per_cu[2] = {0, 0};          // k_order_logs<., false / true>: resident workgroups per CU on THIS ctx's device
+    int ord_per_cu = 0;          // k_order_logs: resident workgroups per CU on THIS ctx's device
     int* sweep_ctr = nullptr;            // graph sweep: one task counter per obstacle chunk
     int32_t sweep_rounds = 1;            // option: round-table sweep (k_graph_sweep_rt) where it applies (d <= 8, M <= 256)
     int64_t* rt_cnt = nullptr;           // [columns visited + 1] rounds per column, then (scan) first round of each column
@@ -132,9 +127,11 @@ struct mpfmt_ctx {
     // single-pass hit pool (MFMA path): hits found by the count pass are kept, so the fill pass is a scatter
     int32_t use_pool = 1;                // option "rdisc_pool"
     int32_t* pool_flag = nullptr;        // overflow flag
-    int64_t pool_cap = 0;                // capacity of one log, in records
-    mpfmt_hit* pool = nullptr;           // [items][4][pool_cap] hit records: four append logs per (tile, slice), one per 16 columns
-    int32_t* log_len = nullptr;          // [items][4] records in each log
+    int64_t qcap = 0;                    // capacity of one quarter log, in records (a multiple of 16)
+    uint32_t* qkey = nullptr;            // [quarter tiles of the shard][qcap] record keys: row sample index | column within the quarter << 26 | flags
+    double* qd2 = nullptr;               // [quarter tiles of the shard][qcap] squared distances
+    int32_t* qlen = nullptr;             // [quarter tiles of the shard] the logs' cursors
+    int64_t pool_hint_qmax = 0;          // records in the fullest quarter (16 consecutive cell-sorted columns) of the last build: sizes the next one's logs
     // half build of the single-pass r-disc graph (kernels_rdisc_mfma.hip: every pair found once, the other column's record goes
     // to a foreign log of that column's tile)
     int use_half = 1;                    // option rdisc_half
@@ -158,14 +155,10 @@ struct mpfmt_ctx {
     bool want_broad = false;             // set by the step APIs around their count
     bool broad_in_drain = false;         // this count's records carry the broad-phase flag (bit 30 of the row index)
     bool half_used = false;              // the counted graph was built that way
-    int half_fail = 0;                   // 2: no more half builds (a column too long for the ordering kernel, or an overflow at the widest slack)
-    bool half_off = false;               // a half build overflowed / met a column too long for the ordering kernel: whole builds from now on
+    int64_t redo_count = 0; int32_t redo_reason = 0;      // stats: builds redone because a capacity did not hold (1 chunk list cut, 2 log overflow, 4 column too long, 8 nnz beyond the allocation, 16 pending list cut)
+    bool pool_skip_once = false;         // the next count runs in the two-pass form (a log of the single pass overflowed, or a column was too long)
     bool lists_half = false;             // the cached chunk lists hold only chunks >= the tile
     int cell_fb = 0;                     // position bits below the cell id in cellkey (k_cellkey)
-    mpfmt_hit* fpool = nullptr;          // [tiles][4][fcap] foreign logs
-    int32_t* flen = nullptr;             // [tiles][4] their lengths
-    uint8_t* fcol = nullptr;             // [tiles][4][fcap] column (within the quarter) of every foreign record
-    int64_t fcap = 0;
     int64_t max_deg = 0;                 // longest column of the counted graph (k_degree)
     int32_t pool_slack = 1;              // doubled after a build whose slot lists overflowed
     bool pool_valid = false;             // pool holds exactly the nnz hits of the counted graph
@@ -189,8 +182,6 @@ struct mpfmt_ctx {
     double* nzval = nullptr;
     int32_t* rowpos = nullptr;           // [nnz] cell-sorted position of each entry's row (single-pass build): the sweep gathers rows from Xs
     bool rowpos_valid = false;
-    int32_t fuse_sweep = 0;              // option (off: measured slower): mpfmt_graph_step evaluates the edge tests inside the column-ordering
-                                         // kernel (kernels_order.hip, k_order_logs<D, true>) instead of the separate sweep kernel
     int32_t sweep_sorted = 1;            // option: gather the sweep's rows from Xs in cell-sorted order with per-XCD task ranges (6x less HBM traffic,
                                          // 74 % L2 hits): with the round-table sweep, whose instruction count no longer hides under the
                                          // caller-order gather (2.29 ms floor), this is the faster mode (2.2 vs 2.65 ms); on by default
@@ -276,16 +267,15 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed);
 int32_t mpfmt_graph_step(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_graph_step_finish_impl(mpfmt_ctx* ctx);
-int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r, bool fuse_sweep = false);
+int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usable);
 int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx);
 template <int MODE> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT);
-int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr, bool fuse = false, int64_t mask_entries = -1);      // kernels_order.hip
-bool mpfmt_order_can_fuse(const mpfmt_ctx* ctx);
+int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr, int64_t mask_entries = -1);      // kernels_order.hip
 int32_t mpfmt_sweep_prepare_ss(mpfmt_ctx* ctx);          // kernels_sweep.hip: device copy of the state-space bounds + the all-samples-inside flag
 #define MPFMT_ORD_MAXDEG 2048        // longest column the log-ordering kernel stages in LDS (ORD_STG in kernels_order.hip)
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false, bool half = false);
-int32_t mpfmt_launch_foreign_degrees(mpfmt_ctx* ctx);
+int32_t mpfmt_launch_log_degrees(mpfmt_ctx* ctx);
 int32_t mpfmt_launch_exact_pairs(mpfmt_ctx* ctx, const int32_t* spec_fail);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);

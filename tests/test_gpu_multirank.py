@@ -46,7 +46,7 @@ def test_bench_two_ranks_through_the_c_abi(mock_lib):
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "shard2" and "C ABI" in d["config"]["exchange"]
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "cfg2", "--no-cpu-baseline", "--no-solve"],
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--workload", "cfg2", "--no-cpu-baseline", "--no-solve", "--no-cold"],
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])

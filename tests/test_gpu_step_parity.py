@@ -382,3 +382,18 @@ def test_large_stress_of_the_timed_form_in_suite(orc):
     steps = sum(forms.values())
     assert cases >= 3 and edges > 1e7, (cases, edges)
     assert forms.get((1, 2), 0) * 2 >= steps, forms
+
+
+def test_form_grid():
+    """A cold ctx takes the timed form on its FIRST step, and keeps it: 2-, 3-, 4- and 6-dimensional worlds of 2e4 and
+    1.1e5 uniform samples, 30 and 256 boxes, mean degree 6 and 60 -- cold step, repeat, new samples: wherever the MFMA pair kernel runs,
+    every step is (half build, edge-test form 2) and no build is redone because a capacity did not hold."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_form_grid
+    bad = []
+    for d, N, M, deg, nnz, out in run_form_grid.grid(sizes=(20000, 110000)):
+        for it, (path, half, form, over, redone, why) in enumerate(out):
+            if path == 2 and ((half, form) != (1, 2) or over or redone):
+                bad.append((d, N, M, deg, it, half, form, over, redone, why))
+    assert not bad, bad
