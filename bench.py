@@ -516,7 +516,8 @@ def main():
                 return 1e3 * (time.perf_counter() - t1), v
 
             def form_of(c):
-                return {"pair_kernel": c.stat("rdisc_path_used"), "half_build": c.stat("rdisc_half_used"), "edge_test_form": c.stat("sweep_form")}
+                return {"pair_kernel": c.stat("rdisc_path_used"), "half_build": c.stat("rdisc_half_used"), "edge_test_form": c.stat("sweep_form"),
+                        "builds_redone": c.stat("redo_count"), "why": c.stat("redo_reason")}
             cold = {"what": "fresh mpfmt_ctx each: first_step = the first mpfmt_graph_step_device after the uploads (allocations, careful sizes); "
                             "second_step = the same call again; new_samples_step = mpfmt_upload_samples_device of another sample set + the step; "
                             "fmtstar_cold = mpfmt_upload_samples (PCIe) + mpfmt_upload_boxes + mpfmt_fmtstar_wavefront (index, graph, lazy edge tests, "

@@ -31,11 +31,18 @@
 #define ORD_WAVES 8
 #define ORD_COLS 16              // columns per workgroup = columns per log
 #define ORD_NB 128               // buckets per column
-#define ORD_STG 3072             // staged records per workgroup: 12 bytes each (36 KB of LDS; with the counters 53 KB: three workgroups per CU)
-#define ORD_PRE 6                // records per thread requested ahead (6 x 512 = the staging area)
+#ifndef ORD_STG
+#define ORD_STG 3008             // staged records per workgroup: 12 bytes each (35.3 KB of LDS; with the counters 52.3 KB -- three workgroups per CU
+#endif                           // need <= 53 KB each: LDS is handed out in 512-byte pieces, 3072 records were 48 bytes too many)
+#ifndef ORD_PRE
+#define ORD_PRE 6                // records per thread requested ahead (6 x 512 >= the staging area)
+#endif
 static_assert(ORD_STG >= MPFMT_ORD_MAXDEG, "a column the host lets through must fit the staging area");
 static_assert(ORD_COLS * ORD_NB == ORD_THREADS * 4, "the segmented scan gives every thread four buckets");
-static_assert(ORD_PRE * ORD_THREADS == ORD_STG, "the prefetched records are what the staging area holds");
+static_assert(ORD_PRE * ORD_THREADS >= ORD_STG && ORD_STG % 32 == 0, "the prefetched records cover what the staging area holds");
+#ifndef ORD_OPT                  // A/B switches (tools/build_variant.sh): 1 the bucket's members read together in the write-out; 8 squared
+#define ORD_OPT 1                // distances requested when the counting sort begins instead of a quarter ahead
+#endif
 
 struct ord_hdr {
     int32_t k[ORD_COLS];         // column degrees
@@ -130,27 +137,25 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
             H.n = hln;
         }
     };
-    // keys: requested a quarter ahead (during the write-out of the quarter before).  Squared distances: requested when the quarter's
-    // counting sort begins and placed two barriers later -- their 12 registers are then dead during the write-out, the phase that needs
-    // the most (both at once: 103 VGPRs, two workgroups per CU instead of three)
+    // keys and squared distances: requested a quarter ahead (during the write-out of the quarter before)
     uint32_t pk[ORD_PRE];
     double pd[ORD_PRE];
+    // (buffer loads: one per-lane byte offset for all six, the slot's offset and the log's base scalar, reads past the log's end
+    // return zero -- six flat loads keep six 64-bit addresses alive per array)
     auto rec_fetch = [&](const ord_hdr& H, int64_t qi) {
         const int total = (qi < nq) ? H.n : 0;
-        const long long base = qi * a.qcap;
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.qkey + (qi < nq ? qi : 0) * a.qcap), 0, total * 4, 0x00020000);
 #pragma unroll
-        for (int u = 0; u < ORD_PRE; ++u) {
-            const int i = u * ORD_THREADS + tid;
-            pk[u] = 0u;
-            if (u * ORD_THREADS < total) { if (i < total) pk[u] = a.qkey[base + i]; }
-        }
+        for (int u = 0; u < ORD_PRE; ++u) pk[u] = __builtin_amdgcn_raw_buffer_load_b32(rk, tid * 4, u * ORD_THREADS * 4, 0);
     };
-    auto d2_fetch = [&](int total, long long base) {
+    typedef uint32_t ord_u32x2 __attribute__((ext_vector_type(2)));
+    auto d2_fetch = [&](int total, int64_t qi) {
+        const long long base = (qi < nq ? qi : 0) * a.qcap;
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.qd2 + base), 0, total * 8, 0x00020000);
 #pragma unroll
         for (int u = 0; u < ORD_PRE; ++u) {
-            const int i = u * ORD_THREADS + tid;
-            pd[u] = 0.0;
-            if (u * ORD_THREADS < total) { if (i < total) pd[u] = a.qd2[base + i]; }
+            const ord_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rd, tid * 8, u * ORD_THREADS * 8, 0);
+            pd[u] = __hiloint2double((int)v.y, (int)v.x);
         }
     };
 
@@ -163,13 +168,14 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
     if (tid < ORD_COLS) sh.h[0].out[tid] = hout;
     lds_barrier();
     rec_fetch(sh.h[0], qi);
+    if (!(ORD_OPT & 8)) d2_fetch(sh.h[0].n, qi);
     for (; qi < nq; qi += gridDim.x, hb ^= 1) {
         const ord_hdr& H = sh.h[hb];
         const int64_t qn = qi + gridDim.x;                    // the workgroup's next quarter
         const int total = H.n;
         const long long lbase = qi * a.qcap;
         hdr_fetch1(qn);                                       // in flight during the counting sort
-        d2_fetch(total, lbase);
+        if (ORD_OPT & 8) d2_fetch(total, qi);
         int g0 = 0;
         bool first = true;
         while (g0 < ORD_COLS) {
@@ -243,6 +249,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
             if (last_range) {
                 lds_barrier();                                // (the next header's log length is read by every thread)
                 rec_fetch(sh.h[hb ^ 1], qn);
+                if (!(ORD_OPT & 8)) d2_fetch(qn < nq ? sh.h[hb ^ 1].n : 0, qn);
             }
             // ---- WRITE: thread = staging position ----
             if (!skip) {
@@ -257,7 +264,18 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
                     const int bk = bucket(id);
                     const int e = sh.cur[col][bk], n = sh.cnt[col][bk];            // the bucket occupies [e - n, e)
                     int rk = e - n;
+#if ORD_OPT & 1
+                    if (act) {
+                        // (the bucket holds the record itself and typically 0-2 others: four independent reads, then the rare rest)
+                        const int b0 = e - n, bl = e - 1;
+                        const uint32_t m0 = ORD_ID(stage_key[b0]), m1 = ORD_ID(stage_key[min(b0 + 1, bl)]), m2 = ORD_ID(stage_key[min(b0 + 2, bl)]),
+                                       m3 = ORD_ID(stage_key[min(b0 + 3, bl)]);
+                        rk += (int)(m0 < id) + (int)(n > 1 && m1 < id) + (int)(n > 2 && m2 < id) + (int)(n > 3 && m3 < id);
+                        for (int m = b0 + 4; m < e; ++m) rk += (ORD_ID(stage_key[m]) < id) ? 1 : 0;
+                    }
+#else
                     if (act) for (int m = e - n; m < e; ++m) rk += (ORD_ID(stage_key[m]) < id) ? 1 : 0;
+#endif
                     const int rel = rk - (H.cb[col] - gb);                          // rank inside the column
                     const bool valid = act && rel >= 0 && rel < H.k[col];          // (always, unless a log overflowed: that build is void, but stays in bounds)
                     const int64_t o = H.out[col] + rel;
@@ -339,8 +357,10 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail, int64_t mask_
     const bool recbits = ctx->bits_in_records;                // form 2: the blocked edges are marked in the keys, this pass also writes the mask
     const bool pend = ctx->broad_in_drain && !recbits;        // form 1: the flagged entries are listed for k_sweep_pending
     if (recbits) {
+        // (sized with the slack a following speculative step asks for, so that it finds the mask in place)
         const int64_t words = (std::max<int64_t>(ctx->nnz, mask_entries) + 63) / 64;
-        if ((rc = mpfmt_ensure(ctx, (void**)&ctx->graph_free, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1)))) return rc;
+        const int64_t words_alloc = (std::max<int64_t>((int64_t)((double)ctx->nnz * 1.02) + 4096, mask_entries) + 63) / 64 + 1;
+        if ((rc = mpfmt_ensure(ctx, (void**)&ctx->graph_free, sizeof(uint64_t) * (size_t)words_alloc))) return rc;
         // preset to ones (blocked entries are cleared); an empty graph keeps one zero word
         HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, ctx->nnz > 0 ? 0xFF : 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
     }

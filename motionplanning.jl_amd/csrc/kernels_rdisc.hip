@@ -796,11 +796,11 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     ctx->bits_in_records = false; ctx->sweep_in_order = false;
     if (ctx->broad_in_drain && half && ctx->fuse_broad == 2) {
         // form 2: the pairs flagged by the drain's broad phase are listed for k_exact_pairs in 1024 dense regions (an item appends to
-        // region item mod 1024 with one reservation per drain); room for three quarters of all pairs being flagged -- beyond that the
-        // flag is raised and the host sweeps the whole graph
+        // region item mod 1024 with one reservation per drain), one 16-byte item per (pair, box) unit -- up to four per pair.  Room for
+        // two units per pair of the estimate (few large obstacles in a low-dimensional world flag most pairs, several times each);
+        // beyond that the flag is raised, the host sweeps the whole graph and the following builds get twice the room
         const double pairs_est = 0.5 * nnz_est;
-        // (a list that overflowed -- obstacles crowd the flagged pairs into few regions -- doubles the room of the following builds)
-        ctx->pair_icap = ctx->debug_small_lists ? 8 : (int64_t)(0.75 * pairs_est / 1024.0) * ctx->pair_slack + 4096;      // (option debug_small_lists: the overflow path, for the tests)
+        ctx->pair_icap = ctx->debug_small_lists ? 8 : (int64_t)(2.0 * pairs_est / 1024.0) * ctx->pair_slack + 4096;      // (option debug_small_lists: the overflow path, for the tests)
         if ((rc = ensure(ctx, (void**)&ctx->pair_items, 16 * (size_t)ctx->pair_icap * 1024))) return rc;
         if (!ctx->zarena) {
             if ((rc = ensure(ctx, (void**)&ctx->pair_cnt, sizeof(int32_t) * (1024 + 1)))) return rc;
@@ -869,7 +869,7 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     if (ctx->spec_lists && list_mx > ctx->list_cap) {             // lists were truncated: everything after them is void
         ctx->redo_reason |= 1; ctx->redo_count += 1;
         ctx->lists_r = -1.0; ctx->lists_cap_trusted = -1;
-        ctx->list_cap = std::min<int64_t>(ctx->ntiles, ((int64_t)list_mx + 255) / 256 * 256);
+        ctx->list_cap = std::min<int64_t>(ctx->ntiles, ((int64_t)list_mx + list_mx / 8 + 64 + 255) / 256 * 256);
         ctx->spec_lists = false;
         if (spec_failed) { *spec_failed = true; return MPFMT_OK; }
         return mpfmt_launch_rdisc_count(ctx, r);
@@ -916,8 +916,10 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
         if ((rc = ensure(ctx, (void**)&ctx->rowtmp, sizeof(int32_t) * (size_t)nnz))) return rc;
         if ((rc = ensure(ctx, (void**)&ctx->valtmp, sizeof(double) * (size_t)nnz))) return rc;
     }
-    if ((rc = ensure(ctx, (void**)&ctx->rowval, sizeof(int32_t) * (size_t)nnz))) return rc;
-    if ((rc = ensure(ctx, (void**)&ctx->nzval, sizeof(double) * (size_t)nnz))) return rc;
+    // (with the slack a following speculative step of the same (N, r) allocates for -- it then finds its arrays in place)
+    const size_t nnz_alloc = (size_t)((double)nnz * 1.02) + 4096;
+    if ((rc = ensure(ctx, (void**)&ctx->rowval, sizeof(int32_t) * nnz_alloc))) return rc;
+    if ((rc = ensure(ctx, (void**)&ctx->nzval, sizeof(double) * nnz_alloc))) return rc;
     if (ctx->tile_end > ctx->tile_begin && nnz > 0) {
         int done = 0;
         if (ctx->rdisc_path_used == 2 && ctx->pool_valid) {
@@ -967,6 +969,7 @@ static int32_t sweep_checked(mpfmt_ctx* ctx)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (!over) return MPFMT_OK;
         if (ctx->pair_slack < 8) ctx->pair_slack *= 2;
+        ctx->redo_reason |= 16; ctx->redo_count += 1; ctx->pend_overflowed = true;
         ctx->sweep_in_order = false; ctx->graph_swept = false;
         return mpfmt_launch_graph_sweep(ctx);
     }

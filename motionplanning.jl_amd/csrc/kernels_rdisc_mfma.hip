@@ -527,6 +527,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     int qcount = 0;                                           // wave-uniform survivor queue length
     int rcount = 0;                                           // wave-uniform record queue length
     int pool_over = 0;
+    [[maybe_unused]] int ndrain = 0;                          // drains of this item so far (wave-uniform): spreads its pending-pair items over the regions
     auto drain = [&](int n) {
         // takes the LAST n queue entries (order is irrelevant: columns are sorted afterwards), so nothing moves
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -632,6 +633,10 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             [[maybe_unused]] int ibase = 0, iexcl = 0, iunits = 0;
             [[maybe_unused]] unsigned long long ipm = 0;
             [[maybe_unused]] bool iem = false;
+            // (the region changes from drain to drain: in a low-dimensional world ONE item -- the slice that holds the tile's own chunk --
+            // finds most of a tile's pairs, and by item alone its units overflowed a region sized for the mean)
+            [[maybe_unused]] const int iregion = (int)((item + (int64_t)ndrain * 131) & (MF_NREG - 1));
+            ndrain = __builtin_amdgcn_readfirstlane(ndrain + 1);
             if constexpr (D <= 6) {
                 if (a.fb == 2) {
                     iem = hit && pendflag != 0;
@@ -647,7 +652,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                         incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);      // row_bcast:31
                         iexcl = incl - iunits;
                         const int total = __builtin_amdgcn_readlane(incl, 63);
-                        if (lane == 0) ibase = atomicAdd(&a.pcnt[item & (MF_NREG - 1)], total);
+                        if (lane == 0) ibase = atomicAdd(&a.pcnt[iregion], total);
                     }
                 }
             }
@@ -693,7 +698,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                             const int pos = base + iexcl + u;
                             if (pos < a.icap) {
                                 const uint32_t kbx = pc_keep > 4u ? 256u : ((pk_keep >> (8 * u)) & 255u);        // (bit 8: every box)
-                                a.pitems[(long long)(item & (MF_NREG - 1)) * a.icap + pos] =
+                                a.pitems[(long long)iregion * a.icap + pos] =
                                     make_uint4(qs | ((kbx & 63u) << 26), jg | ((kbx >> 6) << 26), own_w, for_w);
                             } else {
                                 *a.pend_over = 1;
@@ -921,7 +926,7 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
     if (ctx->lists_r == r && ctx->lists_begin == ctx->tile_begin && ctx->lists_end == ctx->tile_end && ctx->lists && ctx->lists_half == half) return MPFMT_OK;
     if (ctx->lists_half != half) { ctx->lists_cap_trusted = -1; ctx->lists_half = half; }       // (a capacity learnt in the other form says nothing)
     int32_t rc;
-    int64_t cap = std::min<int64_t>(ctx->ntiles, std::max<int64_t>(ctx->list_cap, 2048));
+    int64_t cap = std::min<int64_t>(ctx->ntiles, std::max<int64_t>(ctx->list_cap, 3072));      // (the north star's longest list is ~2000 entries, and differs by sample set)
     const double rpad = r * (1.0 + 1e-9) + 1e-300;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->list_len, sizeof(int32_t) * (size_t)(nt + 1)))) return rc;
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -956,7 +961,7 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
             ctx->list_cap = cap; ctx->lists_r = r; ctx->lists_begin = ctx->tile_begin; ctx->lists_end = ctx->tile_end;
             return MPFMT_OK;
         }
-        cap = std::min<int64_t>(ctx->ntiles, ((int64_t)mx + 255) / 256 * 256);
+        cap = std::min<int64_t>(ctx->ntiles, ((int64_t)mx + mx / 8 + 64 + 255) / 256 * 256);       // (room for the longest list of the NEXT sample set too)
     }
     *usable = false;
     return MPFMT_OK;
@@ -983,11 +988,22 @@ __global__ __launch_bounds__(256) void k_log_degrees(const uint32_t* __restrict_
         __builtin_amdgcn_wave_barrier();
         n = (int)min((long long)qlen[q], qcap);
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(qkey + q * qcap);           // (qcap is a multiple of 4)
-        for (int i0 = lane * 4; i0 < n; i0 += 64 * 4) {
-            const uint4 v = src[i0 >> 2];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        // (four 16-byte loads in flight per lane: one wavefront per log with one load at a time was a chain of ~10 round trips, 84 % of
+        // its cycles waiting)
+        for (int b0 = 0; b0 < n; b0 += 4 * 256) {
+            uint4 v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (i0 + k < n) atomicAdd(&s_c[wave][(w[k] >> 26) & 15u], 1);
+            for (int j = 0; j < 4; ++j) {
+                const int i0 = b0 + j * 256 + lane * 4;
+                v[j] = (i0 < n) ? src[i0 >> 2] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i0 = b0 + j * 256 + lane * 4;
+                const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (i0 + k < n) atomicAdd(&s_c[wave][(w[k] >> 26) & 15u], 1);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

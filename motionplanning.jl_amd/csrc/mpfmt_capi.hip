@@ -1511,6 +1511,7 @@ int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value)
     if (strcmp(name, "pend_overflowed") == 0) { *value = ctx->pend_overflowed ? 1 : 0; return MPFMT_OK; }
     if (strcmp(name, "redo_count") == 0) { *value = ctx->redo_count; return MPFMT_OK; }
     if (strcmp(name, "redo_reason") == 0) { *value = ctx->redo_reason; ctx->redo_reason = 0; return MPFMT_OK; }      // (bits since the last read)
+    if (strcmp(name, "ord_per_cu") == 0) { *value = ctx->ord_per_cu; return MPFMT_OK; }
     if (strcmp(name, "qcap") == 0) { *value = ctx->qcap; return MPFMT_OK; }
     if (strcmp(name, "pool_used") == 0) { *value = ctx->pool_valid ? 1 : 0; return MPFMT_OK; }
     if (strcmp(name, "list_cap") == 0) { *value = ctx->list_cap; return MPFMT_OK; }

@@ -6,5 +6,5 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 rm -rf /tmp/pmcq
-(cd /tmp && timeout 400 rocprofv3 -i $OLDPWD/$CF --kernel-trace --output-format csv -d /tmp/pmcq -o p -- python3 $OLDPWD/bench.py --no-cpu-baseline --no-solve --steps 3 --warmup 1 > /tmp/pmcq.log 2>&1)
+(cd /tmp && timeout 400 rocprofv3 -i $OLDPWD/$CF --kernel-trace --output-format csv -d /tmp/pmcq -o p -- python3 $OLDPWD/bench.py --no-cpu-baseline --no-solve --no-cold --steps 3 --warmup 1 > /tmp/pmcq.log 2>&1)
 python3 tools/pmc_summary.py /tmp/pmcq > gpurun_out/pmc_${TAG}.txt
