@@ -553,6 +553,21 @@ def main():
                 if bs is None or ms_c < bs[0]:
                     bs = (ms_c, res_c)
             cold["fmtstar_cold_ms"] = bs[0]; cold["fmtstar_cold_cost"] = bs[1]["cost"]; cold["fmtstar_cold_status"] = bs[1]["status"]
+            # the drop-in precompute! of julia/MPFmtHIP.jl (hip_precompute_step!): uploads + ONE step + ONE export of colptr / rowval /
+            # nzval / mask (1-based Int64, BitVector chunks) into page-locked host arrays -- what the unmodified fmtstar! needs before
+            # its loop (its lookups afterwards are host work the library does not see)
+            c4 = mp.Context(0)
+            c4.set_stream(stream.cuda_stream)
+            t1 = time.perf_counter()
+            c4.upload_samples(w.X); c4.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+            c4.graph_step_device(w.r)
+            t2 = time.perf_counter()
+            _, er, _, _, rate = c4.graph_export(pinned=True)
+            t3 = time.perf_counter()
+            c4.close()
+            cold["julia_precompute_cold"] = {"upload_and_step_ms": 1e3 * (t2 - t1), "export_ms_incl_pinned_alloc_and_host_copy": 1e3 * (t3 - t2),
+                                            "export_gb_per_s": rate, "exported_bytes": 8.0 * (w.N + 1) + 16.125 * len(er)}
+            del er
             cold["first_step_over_steady_step"] = cold["first_step_ms"] / ms_step
             out["submetrics"]["cold"] = cold
         except mp.MPFMTError as e:

@@ -355,6 +355,16 @@ MPFMT_API int32_t mpfmt_graph_step_device(mpfmt_ctx* ctx, double r, int64_t* nnz
 MPFMT_API int32_t mpfmt_graph_step_launch(mpfmt_ctx* ctx, double r);
 MPFMT_API int32_t mpfmt_graph_step_finish(mpfmt_ctx* ctx, int64_t* nnz);
 MPFMT_API int32_t mpfmt_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** rowval, void** nzval, void** free_mask);
+/* The graph and mask a step left resident, to the host in the format of mpfmt_rdisc_count / _fill / mpfmt_graph_edges_free -- colptr[N+1]
+ * and rowval[nnz] 1-based Int64, nzval[nnz], mask[(nnz+63)/64] BitVector chunks (mask may be NULL) -- WITHOUT rebuilding or re-sweeping:
+ * the drop-in precompute! of julia/MPFmtHIP.jl is mpfmt_graph_step_device + this call, after which the unmodified fmtstar!
+ * (src/planners/fmt.jl:68-90) reads ImmutableNNC columns (src/nearneighbors.jl:23-27,128) and answers is_free_motion from the mask.
+ * Index conversion runs on the device ahead of two copy streams; *gb_per_s (may be NULL) reports the rate.  The copies run at link
+ * speed when the destinations are page-locked: mpfmt_pinned_alloc hands out such memory (Julia wraps it with unsafe_wrap /
+ * pointer_to_array, own = false, and returns it with mpfmt_pinned_free). */
+MPFMT_API int32_t mpfmt_graph_export(mpfmt_ctx* ctx, int64_t* colptr, int64_t* rowval, double* nzval, uint64_t* mask, double* gb_per_s);
+MPFMT_API int32_t mpfmt_pinned_alloc(int64_t bytes, void** out);
+MPFMT_API int32_t mpfmt_pinned_free(void* p);
 /* Shard bookkeeping for the all-gather: column range (in the library's sorted order) and the number
  * of edges this shard produced. */
 MPFMT_API int32_t mpfmt_shard_info(mpfmt_ctx* ctx, int64_t* col_begin, int64_t* col_end, int64_t* shard_nnz);

@@ -54,13 +54,14 @@ type HIPBoxes{N,T} <: SweptCollisionChecker
     index::Dict{Any,Int}                         # sample -> 1-based index
     D::SparseMatrixCSC{Float64,Int}              # the r-disc graph the edge bits refer to
     free::BitVector                              # bit e <-> is_free_motion(V[rowval[e]], V[column of e])
+    pinned::Vector{Ptr{Void}}                    # page-locked arrays behind D and free (hip_precompute_step!)
 end
 function HIPBoxes{N,T}(boxes::Vector{BoxBounds{N,T}}, DS::HIPDistanceDS, SS)
     lohi = reinterpret(T, boxes, (2N, length(boxes)))          # [lo(N); hi(N)] per box, zero copy
     chk(DS.ctx, ccall((:mpfmt_upload_boxes, libmpfmt), Int32,
                       (Ptr{Void}, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Int32),
                       DS.ctx, lohi, length(boxes), N, collect(SS.lo), collect(SS.hi), length(SS.lo)))
-    HIPBoxes(boxes, 0, DS.ctx, Dict{Any,Int}(), spzeros(0, 0), falses(0))
+    HIPBoxes(boxes, 0, DS.ctx, Dict{Any,Int}(), spzeros(0, 0), falses(0), Ptr{Void}[])
 end
 # graph + every edge bit in one go, and the reference's own neighbour cache installed: inball! becomes viewcol (nearneighbors.jl:128)
 function precompute!(P::MPProblem, r::Float64)
@@ -71,6 +72,40 @@ function precompute!(P::MPProblem, r::Float64)
     CC.index = Dict{Any,Int}(zip(P.V.V, 1:N))
     P.V = MetricNN(P.V.V, P.V.dist, P.V.init, ImmutableNNC(CC.D, fill(r, N)), P.V.DS, P.V.US)
     P
+end
+# The same precompute! without a second build, a second sweep or a pageable copy: ONE mpfmt_graph_step_device (index, half build of the
+# graph, edge tests fused into it, mask written by the ordering pass -- the path bench.py times), then ONE mpfmt_graph_export into
+# page-locked arrays the library hands out (2.6 GB at the north star, at link speed).  The arrays back the SparseMatrixCSC and the
+# BitVector directly (pointer_to_array, own = false); hip_release!(CC) returns them.
+function hip_precompute_step!(P::MPProblem, r::Float64)
+    CC = P.CC; N = length(P.V); ctx = CC.ctx
+    nnz = Ref{Int64}(0)
+    chk(ctx, ccall((:mpfmt_graph_step_device, libmpfmt), Int32, (Ptr{Void}, Float64, Ptr{Int64}), ctx, r, nnz))
+    words = (nnz[] + 63) >> 6
+    ptrs = [Ref{Ptr{Void}}(C_NULL) for k in 1:4]
+    for (k, bytes) in enumerate((8(N + 1), 8max(nnz[], 1), 8max(nnz[], 1), 8max(words, 1)))
+        ccall((:mpfmt_pinned_alloc, libmpfmt), Int32, (Int64, Ptr{Ptr{Void}}), bytes, ptrs[k]) == 0 || error("mpfmt_pinned_alloc")
+    end
+    rate = Ref{Float64}(0.0)
+    chk(ctx, ccall((:mpfmt_graph_export, libmpfmt), Int32, (Ptr{Void}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{UInt64}, Ptr{Float64}),
+                   ctx, ptrs[1][], ptrs[2][], ptrs[3][], ptrs[4][], rate))
+    colptr = pointer_to_array(convert(Ptr{Int64}, ptrs[1][]), N + 1, false)
+    rowval = pointer_to_array(convert(Ptr{Int64}, ptrs[2][]), nnz[], false)
+    nzval = pointer_to_array(convert(Ptr{Float64}, ptrs[3][]), nnz[], false)
+    CC.D = SparseMatrixCSC(N, N, colptr, rowval, nzval)
+    CC.free = falses(0)
+    CC.free.chunks = pointer_to_array(convert(Ptr{UInt64}, ptrs[4][]), words, false); CC.free.len = nnz[]; CC.free.dims = (nnz[],)
+    CC.pinned = [p[] for p in ptrs]
+    CC.index = Dict{Any,Int}(zip(P.V.V, 1:N))
+    P.V = MetricNN(P.V.V, P.V.dist, P.V.init, ImmutableNNC(CC.D, fill(r, N)), P.V.DS, P.V.US)
+    rate[]                                       # GB/s of the export
+end
+function hip_release!(CC::HIPBoxes)
+    CC.D = spzeros(0, 0); CC.free = falses(0)
+    for p in CC.pinned
+        ccall((:mpfmt_pinned_free, libmpfmt), Int32, (Ptr{Void},), p)
+    end
+    CC.pinned = Ptr{Void}[]
 end
 function is_free_motion(v::AbstractVector, w::AbstractVector, CC::HIPBoxes)
     CC.count += 1                                # boxesND.jl:26

@@ -115,6 +115,9 @@ SYMBOLS = [
     ("mpfmt_graph_sweep_device", C.c_int32, [C.c_void_p]),
     ("mpfmt_graph_device_ptrs", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("mpfmt_graph_export", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, c_d_p, c_u64_p, c_d_p]),
+    ("mpfmt_pinned_alloc", C.c_int32, [C.c_int64, C.POINTER(C.c_void_p)]),
+    ("mpfmt_pinned_free", C.c_int32, [C.c_void_p]),
     ("mpfmt_shard_info", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, c_i64_p]),
     ("mpfmt_fmtstar_wavefront", C.c_int32, [C.c_void_p, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p, C.c_double, C.c_int32,
                                             c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult), C.POINTER(WfInfo)]),
@@ -797,6 +800,39 @@ class Context:
         p = [C.c_void_p() for _ in range(4)]
         self._chk(self._L.mpfmt_graph_device_ptrs(self._h, *[C.byref(x) for x in p]))
         return tuple(x.value for x in p)
+
+    def graph_export(self, pinned=True, want_mask=True):
+        """The resident graph + mask (as a step left them) in the ABI's host format: (colptr, rowval, nzval, mask, GB/s).  pinned: the
+        destinations come from mpfmt_pinned_alloc (the copies then run at link speed); the arrays returned are copies."""
+        N = self.N
+        nnz = self.stat("nnz")
+        words = (nnz + 63) // 64
+        sizes = [8 * (N + 1), 8 * max(nnz, 1), 8 * max(nnz, 1), 8 * max(words, 1)]
+        rate = C.c_double()
+        if pinned:
+            ptrs = []
+            for b in sizes:
+                p = C.c_void_p()
+                rc = self._L.mpfmt_pinned_alloc(b, C.byref(p))
+                if rc != 0:
+                    raise MPFMTError(rc, "mpfmt_pinned_alloc failed")
+                ptrs.append(p)
+            try:
+                self._chk(self._L.mpfmt_graph_export(self._h, C.cast(ptrs[0], c_i64_p), C.cast(ptrs[1], c_i64_p), C.cast(ptrs[2], c_d_p),
+                                                     C.cast(ptrs[3], c_u64_p) if want_mask else None, C.byref(rate)))
+                colptr = np.ctypeslib.as_array(C.cast(ptrs[0], c_i64_p), shape=(N + 1,)).copy()
+                rowval = np.ctypeslib.as_array(C.cast(ptrs[1], c_i64_p), shape=(max(nnz, 1),))[:nnz].copy()
+                nzval = np.ctypeslib.as_array(C.cast(ptrs[2], c_d_p), shape=(max(nnz, 1),))[:nnz].copy()
+                mask = np.ctypeslib.as_array(C.cast(ptrs[3], c_u64_p), shape=(max(words, 1),))[:words].copy() if want_mask else None
+            finally:
+                for p in ptrs:
+                    self._L.mpfmt_pinned_free(p)
+        else:
+            colptr = np.empty(N + 1, dtype=np.int64); rowval = np.empty(max(nnz, 1), dtype=np.int64)
+            nzval = np.empty(max(nnz, 1), dtype=np.float64); mask = np.zeros(max(words, 1), dtype=np.uint64)
+            self._chk(self._L.mpfmt_graph_export(self._h, _ip(colptr), _ip(rowval), _dp(nzval), _up(mask) if want_mask else None, C.byref(rate)))
+            rowval, nzval, mask = rowval[:nnz], nzval[:nnz], (mask[:words] if want_mask else None)
+        return colptr, rowval, nzval, mask, rate.value
 
     def shard_info(self):
         a, b, n = C.c_int64(), C.c_int64(), C.c_int64()

@@ -800,7 +800,27 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         // two units per pair of the estimate (few large obstacles in a low-dimensional world flag most pairs, several times each);
         // beyond that the flag is raised, the host sweeps the whole graph and the following builds get twice the room
         const double pairs_est = 0.5 * nnz_est;
-        ctx->pair_icap = ctx->debug_small_lists ? 8 : (int64_t)(2.0 * pairs_est / 1024.0) * ctx->pair_slack + 4096;      // (option debug_small_lists: the overflow path, for the tests)
+        // units per pair: the expected number of boxes an edge's box meets, from the obstacles' extents -- box k meets a segment of
+        // extent ~r/2 per axis placed uniformly in the samples' bounding box with probability prod_i min(1, (w_ki + r/2) / L_i) -- times
+        // 1.5 + 0.25, at most 4 (a pair that meets more writes one item): 1.4 at the north star (0.25 measured), 4 among the 30 large
+        // boxes of a 2-D world of the form grid, where two units per pair overflowed
+        double units = 0.0;
+        if ((int64_t)ctx->boxes_host.size() == (int64_t)ctx->M * 2 * ctx->dw && ctx->dw == ctx->d) {
+            for (int k = 0; k < ctx->M; ++k) {
+                double p = 1.0;
+                for (int i = 0; i < ctx->d; ++i) {
+                    const double L = std::max(ctx->bb_hi[i] - ctx->bb_lo[i], 1e-300);
+                    const double lo = std::max(ctx->boxes_host[(size_t)k * 2 * ctx->d + i], ctx->bb_lo[i] - 0.5 * r);
+                    const double hi = std::min(ctx->boxes_host[(size_t)k * 2 * ctx->d + ctx->d + i], ctx->bb_hi[i] + 0.5 * r);
+                    const double wdt = hi - lo;
+                    p *= (wdt >= 0.0) ? std::min(1.0, (wdt + 0.5 * r) / L) : 0.0;      // (NaN bounds: counted as meeting)
+                    if (!(wdt == wdt)) p = 1.0;
+                }
+                units += p;
+            }
+        } else units = 4.0;
+        units = std::min(4.0, units * 1.5 + 0.25);
+        ctx->pair_icap = ctx->debug_small_lists ? 8 : (int64_t)(std::min(6.0, units * (double)ctx->pair_slack) * pairs_est / 1024.0) + 4096;      // (option debug_small_lists: the overflow path, for the tests)
         if ((rc = ensure(ctx, (void**)&ctx->pair_items, 16 * (size_t)ctx->pair_icap * 1024))) return rc;
         if (!ctx->zarena) {
             if ((rc = ensure(ctx, (void**)&ctx->pair_cnt, sizeof(int32_t) * (1024 + 1)))) return rc;
@@ -817,6 +837,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         if (mf) {
             mpfmt_timed tk(ctx);                                   // the pair kernel on its own, inside the "rdisc_count" interval
             if (pool) {
+                if (ctx->broad_in_drain && (rc = mpfmt_launch_sample_masks(ctx, r))) return rc;
                 if ((rc = mpfmt_launch_rdisc_mfma<2>(ctx, r, negT))) return rc;
                 if (ctx->bits_in_records && (rc = mpfmt_launch_exact_pairs(ctx, nullptr))) return rc;
             }

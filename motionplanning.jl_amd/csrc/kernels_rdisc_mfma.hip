@@ -88,6 +88,8 @@ struct mf_args {
     int32_t fb;
     int32_t M;
     const double* boxes;            // [M][2][D]
+    const unsigned long long* smask;   // [npad] per cell-sorted sample: bit (k & 63) set when box k lies within r (per axis) of the sample
+                                    // (k_sample_masks): a segment's box can only meet boxes in the masks of BOTH its ends
     // fb == 2: the pairs whose segment box met an obstacle's are listed (MF_NREG regions of icap 16-byte items, one per (pair, box)
     // unit) for k_exact_pairs, which runs the slab tests in both directions and sets bit 31 of the blocked records' key
     uint4* pitems;
@@ -374,6 +376,68 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
     if (threadIdx.x == 0) { list_len[tl] = min(total, (int32_t)list_cap); if (total > *(volatile int32_t*)max_len) atomicMax(max_len, total); }
 }
 
+// ---- per-sample obstacle masks for the broad phase in the drain ------------------------------------------------------
+// One wavefront per tile, lane = sample: bit (k & 63) of a sample's mask is set unless box k is farther than r from the sample along
+// some axis (the negated comparisons of boxesND.jl:44-45, so a NaN bound keeps the bit).  Both ends of an edge lie within r of each
+// other, hence the edge's box [min, max] lies within r of either end along every axis: a box that meets it has its bit in BOTH ends'
+// masks.  The drain ORs (mask_q & mask_c) over its 64 pairs and walks only those boxes of the tile's cull -- 12 instead of 20 at
+// the north star (measured on the host, tools/sim_drain_masks.py).
+template <int D>
+__global__ __launch_bounds__(256) void k_sample_masks(const double* __restrict__ Xs, const double* __restrict__ tile_lo, const double* __restrict__ tile_hi,
+                                                      int64_t tile_begin, int64_t nt, double rpad, const double* __restrict__ boxes, int M,
+                                                      unsigned long long* __restrict__ smask)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tl >= nt) return;
+    const int64_t tile = tile_begin + tl;
+    const double rm = rpad * (1.0 + 1e-6) + 1e-300;
+    double xl[D], xh[D], ulo[D], uhi[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double x = Xs[(tile * 64 + lane) * D + i];
+        xl[i] = x - rm; xh[i] = x + rm;
+        ulo[i] = tile_lo[tile * D + i] - rm; uhi[i] = tile_hi[tile * D + i] + rm;
+    }
+    unsigned long long mask = 0;
+    for (int c = 0; c * 64 < M; ++c) {
+        const int kbx = c * 64 + lane;
+        int out = 0;
+        if (kbx < M) {
+            const double* bp = boxes + (int64_t)kbx * 2 * D;
+#pragma unroll
+            for (int i = 0; i < D; ++i) out |= (int)(bp[D + i] < ulo[i]) | (int)(bp[i] > uhi[i]);
+        }
+        unsigned long long mb = __ballot(kbx < M && !out);
+        while (mb) {
+            const int b = __ffsll((long long)mb) - 1;
+            mb &= mb - 1;
+            const mf_cptr bp = mf_const(boxes) + (int64_t)(c * 64 + b) * 2 * D;
+            int o2 = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) o2 |= (int)(bp[D + i] < xl[i]) | (int)(bp[i] > xh[i]);
+            if (!o2) mask |= 1ull << b;
+        }
+    }
+    smask[tile * 64 + lane] = mask;                           // (pad samples: NaN coordinates, every comparison false -- every surviving bit set; never read for a hit)
+}
+
+int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r)
+{
+    // (every tile, not the shard's own: a shard's candidates come from all of them)
+    const int64_t nt = ctx->ntiles;
+    int32_t rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->smask, sizeof(unsigned long long) * (size_t)std::max<int64_t>(ctx->ntiles * 64, 1)))) return rc;
+    if (nt <= 0 || ctx->tile_end <= ctx->tile_begin) return MPFMT_OK;
+    const double rpad = r * (1.0 + 1e-9) + 1e-300;
+#define CASE(DD) case DD: hipLaunchKernelGGL((k_sample_masks<DD>), dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, ctx->stream, ctx->Xs, ctx->tile_lo, ctx->tile_hi, \
+        (int64_t)0, nt, rpad, ctx->boxes, ctx->M, (unsigned long long*)ctx->smask); break;
+    switch (ctx->d) { CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) default: break; }
+#undef CASE
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------------------
 // One independent wavefront per (tile, slice of the tile's chunk list): no workgroup barriers.
 //   main loop: for each listed chunk, the B fragments are ONE 16 B/lane coalesced buffer load (d <= 6; two for 7 <= d <= 12) whose
@@ -406,6 +470,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     __shared__ uint32_t s_qs[MF_QSZ];                     // survivor queue: chunk << 12 | finding lane << 6 | sign-bit position
     __shared__ int32_t s_cnt[64];
     __shared__ int32_t s_lc[4];                           // own hits of the drain in work, per quarter of the tile (zero between drains)
+    __shared__ unsigned long long s_qm[(MODE == 2 && D <= 6) ? 64 : 1];      // the queries' obstacle masks (broad phase in the drain)
     __shared__ int64_t s_base[MODE == 1 ? 64 : 1];
 
     const int lane = threadIdx.x;
@@ -459,6 +524,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     for (int i = 0; i < D; ++i) s_q[lane * D + i] = a.Xs[qpos * D + i];
     s_cnt[lane] = 0;
     if (lane < 4) s_lc[lane] = 0;
+    if constexpr (MODE == 2 && D <= 6) { if (a.fb) s_qm[lane] = a.smask[qpos]; }
     constexpr bool FILL = (MODE == 1);
     if (FILL) {
         int64_t base = a.tptr[qpos];
@@ -584,9 +650,28 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             if (a.fb) {
                 unsigned pk = 0, pc = 0;
                 sl[0] = hit ? sl[0] : (double)INFINITY;       // lanes without a hit fail the first comparison
+                // the boxes some pair of this drain can meet at all: OR over the lanes of (mask of the query & mask of the candidate)
+                unsigned long long um = 0;
+#if !(MF_ABLATE & 16)
+                if (hit) um = s_qm[ql] & a.smask[jg];
+                {
+                    uint32_t ul = (uint32_t)um, uh = (uint32_t)(um >> 32);
+#define MF_OR_DPP(x, ctrl, rm_, bc) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rm_, 0xf, bc)
+                    MF_OR_DPP(ul, 0x111, 0xf, true); MF_OR_DPP(uh, 0x111, 0xf, true);        // row_shr:1
+                    MF_OR_DPP(ul, 0x112, 0xf, true); MF_OR_DPP(uh, 0x112, 0xf, true);        // row_shr:2
+                    MF_OR_DPP(ul, 0x114, 0xf, true); MF_OR_DPP(uh, 0x114, 0xf, true);        // row_shr:4
+                    MF_OR_DPP(ul, 0x118, 0xf, true); MF_OR_DPP(uh, 0x118, 0xf, true);        // row_shr:8
+                    MF_OR_DPP(ul, 0x142, 0xa, false); MF_OR_DPP(uh, 0x142, 0xa, false);      // row_bcast:15
+                    MF_OR_DPP(ul, 0x143, 0xc, false); MF_OR_DPP(uh, 0x143, 0xc, false);      // row_bcast:31
+#undef MF_OR_DPP
+                    um = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)uh, 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)ul, 63);
+                }
+#else
+                um = ~0ull;
+#endif
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    unsigned long long mb = bsurv[c];
+                    unsigned long long mb = bsurv[c] & um;
                     while (mb) {
                         const int kbx = c * 64 + (__ffsll((long long)mb) - 1);
                         mb &= mb - 1;
@@ -1067,6 +1152,7 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.half = (MODE == 2 && ctx->half_used) ? 1 : 0;
     a.ntiles_shard = ctx->tile_end - ctx->tile_begin;
     a.fb = (MODE == 2 && ctx->broad_in_drain) ? (ctx->bits_in_records ? 2 : 1) : 0; a.M = ctx->M; a.boxes = ctx->boxes;
+    a.smask = (const unsigned long long*)ctx->smask;
     a.pitems = (uint4*)ctx->pair_items; a.pcnt = ctx->pair_cnt; a.icap = ctx->pair_icap; a.pend_over = ctx->pair_over;
     if (MODE != 2 && ctx->lists_half) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "two-pass r-disc kernels need whole chunk lists");
     if (a.nitems <= 0) return MPFMT_OK;

@@ -195,9 +195,10 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
-                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->qkey, ctx->qd2, ctx->qlen, ctx->pend_items, ctx->pend_cnt, ctx->pair_items, ctx->pair_cnt, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev, ctx->bb_dev};
+                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->qkey, ctx->qd2, ctx->qlen, ctx->smask, ctx->pend_items, ctx->pend_cnt, ctx->pair_items, ctx->pair_cnt, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev, ctx->bb_dev};
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
     if (ctx->bb_host) hipHostFree(ctx->bb_host);
+    for (int k = 0; k < 2; ++k) { if (ctx->copy_stream[k]) hipStreamDestroy(ctx->copy_stream[k]); if (ctx->ev_conv[k]) hipEventDestroy(ctx->ev_conv[k]); if (ctx->ev_copy[k]) hipEventDestroy(ctx->ev_copy[k]); }
     mpfmt_comm_destroy(ctx);
     mpfmt_wf_free(ctx);
     if (ctx->aux) { mpfmt_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
@@ -361,6 +362,7 @@ int32_t mpfmt_upload_boxes(mpfmt_ctx* ctx, const double* lohi, int32_t M, int32_
     if (M > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->boxes, lohi, sizeof(double) * (size_t)M * 2 * dw, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->M = M; ctx->dw = dw; ctx->have_boxes = true; ctx->cc_kind = 0;
+    ctx->boxes_host.assign(lohi, lohi + (size_t)M * 2 * dw);      // (a host copy: sizes the pending-pair list from the obstacles' extents)
     ctx->ss.has = ss_lo ? 1 : 0;
     ctx->ss.d = ss_lo ? d_state : 0;
     for (int i = 0; i < MPFMT_MAX_DIM; ++i) { ctx->ss.lo[i] = -INFINITY; ctx->ss.hi[i] = INFINITY; }
@@ -727,6 +729,81 @@ int32_t mpfmt_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask)
         HIPCHK(ctx, hipMemcpyAsync(mask, ctx->graph_free, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return MPFMT_OK;
+}
+
+// ---- the resident graph + mask to the host in the ABI's format, at link speed ----------------------------------------------------------
+// mpfmt_rdisc_count / _fill / mpfmt_graph_edges_free rebuild or re-sweep what a step has already left in HBM, and copy slab by slab with
+// a synchronisation each.  This call hands out what mpfmt_graph_step_device left resident -- colptr and rowval as 1-based Int64, nzval,
+// the free mask (BitVector chunks) -- with the index conversion on the compute stream two slabs ahead of two copy streams, so the link
+// is the only thing waited for when the destinations are page-locked (mpfmt_pinned_alloc).
+int32_t mpfmt_pinned_alloc(int64_t bytes, void** out)
+{
+    if (!out || bytes < 0) return MPFMT_ERR_ARG;
+    *out = nullptr;
+    if (bytes == 0) return MPFMT_OK;
+    return hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault) == hipSuccess ? MPFMT_OK : MPFMT_ERR_HIP;
+}
+
+int32_t mpfmt_pinned_free(void* p)
+{
+    if (!p) return MPFMT_OK;
+    return hipHostFree(p) == hipSuccess ? MPFMT_OK : MPFMT_ERR_HIP;
+}
+
+int32_t mpfmt_graph_export(mpfmt_ctx* ctx, int64_t* colptr, int64_t* rowval, double* nzval, uint64_t* mask, double* gb_per_s)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->graph_filled) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no resident graph (mpfmt_graph_step_device / mpfmt_graph_build_device)");
+    if (mask && !ctx->graph_swept) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the resident graph has not been swept");
+    const int64_t N = ctx->N, nnz = ctx->nnz;
+    if (!colptr || (nnz > 0 && (!rowval || !nzval))) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "colptr / rowval / nzval is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_stream[0]) {
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream[k], hipStreamNonBlocking));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_conv[k], hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_copy[k], hipEventDisableTiming));
+        }
+    }
+    int32_t rc;
+    const int64_t slab = (int64_t)1 << 24;                    // entries per conversion slab: 128 MB of Int64, two in flight
+    void* scr;
+    if ((rc = mpfmt_scratch(ctx, sizeof(int64_t) * (size_t)(2 * slab + N + 1), &scr))) return rc;
+    int64_t* stg[2] = {(int64_t*)scr, (int64_t*)scr + slab};
+    int64_t* cp1 = (int64_t*)scr + 2 * slab;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));            // the step's kernels are done: the clock below sees the export alone
+    const auto t0 = std::chrono::steady_clock::now();
+    // stream B: nzval, mask; stream A: colptr, rowval slabs as they are converted
+    hipLaunchKernelGGL(k_add1_i64, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->colptr, N + 1, cp1);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_conv[0], ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream[0], ctx->ev_conv[0], 0));
+    HIPCHK(ctx, hipMemcpyAsync(colptr, cp1, sizeof(int64_t) * (size_t)(N + 1), hipMemcpyDeviceToHost, ctx->copy_stream[0]));
+    if (nnz > 0) {
+        const int64_t half = nnz / 2;
+        // (the distances in two pieces, one per copy stream, so both engines stay busy while the row indices are converted)
+        HIPCHK(ctx, hipMemcpyAsync(nzval, ctx->nzval, sizeof(double) * (size_t)half, hipMemcpyDeviceToHost, ctx->copy_stream[1]));
+        int k = 0;
+        for (int64_t o = 0; o < nnz; o += slab, ++k) {
+            const int64_t n = std::min(slab, nnz - o);
+            const int b = k & 1;
+            if (k >= 2) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copy[b], 0));      // the slab's staging buffer has been copied out
+            hipLaunchKernelGGL(k_i32_to_i64_add1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rowval + o, n, stg[b]);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_conv[b], ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream[0], ctx->ev_conv[b], 0));
+            HIPCHK(ctx, hipMemcpyAsync(rowval + o, stg[b], sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->copy_stream[0]));
+            HIPCHK(ctx, hipEventRecord(ctx->ev_copy[b], ctx->copy_stream[0]));
+        }
+        HIPCHK(ctx, hipMemcpyAsync(nzval + half, ctx->nzval + half, sizeof(double) * (size_t)(nnz - half), hipMemcpyDeviceToHost, ctx->copy_stream[1]));
+        if (mask) HIPCHK(ctx, hipMemcpyAsync(mask, ctx->graph_free, sizeof(uint64_t) * (size_t)((nnz + 63) / 64), hipMemcpyDeviceToHost, ctx->copy_stream[1]));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream[0]));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream[1]));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double bytes = 8.0 * (double)(N + 1) + 16.0 * (double)nnz + (mask ? (double)((nnz + 63) / 64) * 8.0 : 0.0);
+    if (gb_per_s) *gb_per_s = sec > 0.0 ? bytes / sec / 1e9 : 0.0;
     return MPFMT_OK;
 }
 

@@ -57,6 +57,8 @@ struct mpfmt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
+    hipStream_t copy_stream[2] = {nullptr, nullptr};      // mpfmt_graph_export: two device-to-host streams and their hand-over events
+    hipEvent_t ev_conv[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
     std::string err;
     int rank = 0, world = 1;
 
@@ -131,6 +133,7 @@ struct mpfmt_ctx {
     uint32_t* qkey = nullptr;            // [quarter tiles of the shard][qcap] record keys: row sample index | column within the quarter << 26 | flags
     double* qd2 = nullptr;               // [quarter tiles of the shard][qcap] squared distances
     int32_t* qlen = nullptr;             // [quarter tiles of the shard] the logs' cursors
+    void* smask = nullptr;               // [npad] per-sample obstacle masks (k_sample_masks): the drain's broad phase walks the boxes in (mask_q & mask_c) only
     int64_t pool_hint_qmax = 0;          // records in the fullest quarter (16 consecutive cell-sorted columns) of the last build: sizes the next one's logs
     // half build of the single-pass r-disc graph (kernels_rdisc_mfma.hip: every pair found once, the other column's record goes
     // to a foreign log of that column's tile)
@@ -207,6 +210,7 @@ struct mpfmt_ctx {
 
     // ---- obstacles -----------------------------------------------------------------------------
     double* boxes = nullptr;             // [M][2][dw]
+    std::vector<double> boxes_host;      // the same on the host
     int32_t M = 0, dw = 0;
     bool have_boxes = false;
     int32_t cc_kind = 0;                 // collision checker: 0 = PointRobotNDBoxes, 1 = PointRobot2D (SAT)
@@ -276,6 +280,7 @@ int32_t mpfmt_sweep_prepare_ss(mpfmt_ctx* ctx);          // kernels_sweep.hip: d
 #define MPFMT_ORD_MAXDEG 2048        // longest column the log-ordering kernel stages in LDS (ORD_STG in kernels_order.hip)
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false, bool half = false);
 int32_t mpfmt_launch_log_degrees(mpfmt_ctx* ctx);
+int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_launch_exact_pairs(mpfmt_ctx* ctx, const int32_t* spec_fail);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);

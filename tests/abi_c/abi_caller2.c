@@ -19,6 +19,10 @@ typedef int32_t (*f_gather_launch)(void*, int64_t);                             
 typedef int32_t (*f_gather_finish)(void*, void**, int64_t*, int64_t*, int64_t*);   /* (Ptr{Void}, Ptr{Ptr{Void}}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}) */
 typedef int32_t (*f_gather_relaunch)(void*);                                       /* (Ptr{Void},) */
 typedef int32_t (*f_group)(void);
+typedef int32_t (*f_step_device)(void*, double, int64_t*);                         /* (Ptr{Void}, Float64, Ptr{Int64}) */
+typedef int32_t (*f_pinned_alloc)(int64_t, void**);                                /* (Int64, Ptr{Ptr{Void}}) */
+typedef int32_t (*f_pinned_free)(void*);                                           /* (Ptr{Void},) */
+typedef int32_t (*f_export)(void*, int64_t*, int64_t*, double*, uint64_t*, double*);   /* (Ptr{Void}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{UInt64}, Ptr{Float64}) */
 /* helper_data_structures(V, ::LinearQuadratic), hip_di_edges_free */
 typedef int32_t (*f_di_count)(void*, double, double, int64_t*, int64_t*);          /* (Ptr{Void}, Float64, Float64, Ptr{Int64}, Ptr{Int64}) */
 typedef int32_t (*f_di_fill)(void*, int64_t*, double*, double*);                   /* (Ptr{Void}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}) */
@@ -58,6 +62,10 @@ int main(int argc, char** argv)
     f_closeR closeR = (f_closeR)mpfmt_closeR;
     f_upload_shapes upload_shapes = (f_upload_shapes)mpfmt_upload_shapes2d;
     f_sample_free sample_free = (f_sample_free)mpfmt_sample_free;
+    f_step_device step_device = (f_step_device)mpfmt_graph_step_device;
+    f_pinned_alloc pinned_alloc = (f_pinned_alloc)mpfmt_pinned_alloc;
+    f_pinned_free pinned_free = (f_pinned_free)mpfmt_pinned_free;
+    f_export graph_export = (f_export)mpfmt_graph_export;
 
     FILE* in = fopen(argv[1], "rb");
     if (!in) { perror(argv[1]); return 2; }
@@ -149,6 +157,19 @@ int main(int argc, char** argv)
             put(out, &nnz, 8); put(out, &words, 8); put(out, &nn, 8); put(out, &retried, 8);
         }
         CHECK(mpfmt_comm_destroy(ctx));
+        /* ---- hip_precompute_step!: one step, one export into page-locked arrays (the sampled set is still uploaded) ---- */
+        {
+            int64_t nnz = 0;
+            CHECK(step_device(ctx, p[6], &nnz));
+            const int64_t words = (nnz + 63) / 64;
+            void* pp[4] = {NULL, NULL, NULL, NULL};
+            const int64_t bytes[4] = {8 * (Ns + 1), 8 * (nnz ? nnz : 1), 8 * (nnz ? nnz : 1), 8 * (words ? words : 1)};
+            for (int k = 0; k < 4; ++k) if (pinned_alloc(bytes[k], &pp[k]) != 0) { fprintf(stderr, "pinned_alloc failed\n"); return 3; }
+            double rate = 0.0;
+            CHECK(graph_export(ctx, (int64_t*)pp[0], (int64_t*)pp[1], (double*)pp[2], (uint64_t*)pp[3], &rate));
+            put(out, &nnz, 8); put(out, pp[0], 8 * (Ns + 1)); put(out, pp[1], 8 * nnz); put(out, pp[2], 8 * nnz); put(out, pp[3], 8 * words);
+            for (int k = 0; k < 4; ++k) if (pinned_free(pp[k]) != 0) { fprintf(stderr, "pinned_free failed\n"); return 3; }
+        }
     }
     /* ---- 2-D SAT world: shapes uploaded, point and segment validity on the query points ---- */
     {

@@ -62,3 +62,15 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in txt and "mpfmt_oracle" not in txt and "from oracle" not in txt \
                     and "import oracle" not in txt, os.path.join(dp, f)
+
+
+def test_every_ccall_of_the_julia_glue_is_executed_by_a_c_caller():
+    """julia/MPFmtHIP.jl cannot run here (no Julia): every symbol it ccalls must be called by tests/abi_c/abi_caller.c or abi_caller2.c,
+    which the GPU suite builds with the ccall argument widths and runs."""
+    jl = open(os.path.join(ROOT, "julia", "MPFmtHIP.jl")).read()
+    used = set(re.findall(r"ccall\(\(:(mpfmt_[A-Za-z0-9_]+)", jl))
+    csrc = open(os.path.join(ROOT, "tests", "abi_c", "abi_caller.c")).read() + open(os.path.join(ROOT, "tests", "abi_c", "abi_caller2.c")).read()
+    called = set(re.findall(r"\b(mpfmt_[A-Za-z0-9_]+)\b", csrc))
+    assert len(used) >= 30
+    assert not (used - called), sorted(used - called)
+    assert used <= set(header_symbols())

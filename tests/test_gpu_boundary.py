@@ -158,6 +158,12 @@ def test_c_caller_of_the_other_spaces(orc, tmp_path):
         oc, orow, _ = orc.rdisc_graph(Xs, r_e * (1.5 if step else 1.0))
         assert nnz == len(orow) == nn and words == (nnz + 63) // 64
         assert retried == (1 if step else 0)                     # the larger radius outgrew the agreed capacity: MPFMT_RETRY -> relaunch
+    # hip_precompute_step!: the step's resident graph + mask exported in the ABI's format
+    nnz = int(take(np.int64, 1)[0])
+    colptr, rowval, nzval, fr = take(np.int64, Ns + 1), take(np.int64, nnz), take(np.float64, nnz), take(np.uint64, (nnz + 63) // 64)
+    oc, orow, oval = orc.rdisc_graph(Xs, r_e)
+    assert nnz == len(orow) and np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow) and np.array_equal(nzval, oval)
+    assert np.array_equal(fr, orc.graph_edges_free(Xs, oc, orow, lohi2, lo2, hi2))
     # 2-D SAT world
     S = orc.Shapes2D([("circle", tuple(s[1]), s[2]) if s[0] == "circle" else ("polygon", [tuple(q) for q in s[1]]) for s in fx])
     mpt, mseg = take(np.uint64, (nq + 63) // 64), take(np.uint64, (nq - 1 + 63) // 64)

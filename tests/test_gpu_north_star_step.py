@@ -67,6 +67,14 @@ def test_north_star_step_path(orc):
             assert np.array_equal(nzval, nzval_b), it
             assert np.array_equal(free.view(np.uint64), mask_b), it
             _check_against_oracle(orc, w.X, w.r, w.lohi, w.ss_lo, w.ss_hi, colptr, rowval, nzval, free, rng)
+            if it == 2:
+                # the drop-in precompute! of julia/MPFmtHIP.jl: the same arrays through mpfmt_graph_export (1-based Int64, page-locked destinations)
+                ec, er, ev, em, rate = c.graph_export(pinned=True)
+                assert np.array_equal(ec - 1, colptr) and np.array_equal(er - 1, rowval) and np.array_equal(ev, nzval)
+                assert np.array_equal(em, free.view(np.uint64))
+                assert rate > 3.0, rate                       # GB/s (PCIe Gen4 x16 would give ~25, Gen5 ~50; pageable copies ~3)
+                print("mpfmt_graph_export: %.1f GB/s" % rate)
+                del ec, er, ev, em
             del colptr, rowval, nzval, free
         assert forms[1] == (2, 1, 2) and forms[2] == (2, 1, 2), forms      # the timed form: MFMA pair kernel, half build, fused edge tests
         assert forms[0] == (2, 1, 2), forms                                # ... and the cold call takes it too
