@@ -120,6 +120,51 @@ def cpu_baseline(w, mp, seconds=14.0):
                       % (t_build, nq, w.N, t_q, nb, t_b, ne, t_e, nthr, ne_all, t_all, cores)}
 
 
+def stream_bench(args):
+    """BASELINE configs[2] at the radius of src/planners/fmt.jl:39 (R^12, N = 1e6, r = 0.625, E[deg] ~ 4 700: 57 GB as a CSC) in the
+    streaming mode: one step = one mpfmt_rdisc_stream -- degrees of all columns and the best open parent of each for a given cost
+    vector (the reductions one FMT* expand step takes from the graph), nothing stored.  Single GPU; not the headline workload."""
+    import torch
+    import motionplanning_jl_amd as mp
+    torch.cuda.set_device(0)
+    w = mp.workloads.cfg3(args.n) if args.n else mp.workloads.cfg3()
+    r = mp.workloads.fmt_radius(1.0, w.d, 1.0, w.N)
+    rng = np.random.default_rng(1)
+    Cc = rng.random(w.N) * 3.0
+    H = mp._lib.pack_bits(rng.random(w.N) < 0.25)
+    ctx = mp.Context(0)
+    ctx.upload_samples(w.X); ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+    steps, warm = max(1, min(args.steps, 5)), max(1, min(args.warmup, 1))
+    for _ in range(warm):
+        got = ctx.rdisc_stream(r, Cc, H)
+    torch.cuda.synchronize()
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        got = ctx.rdisc_stream(r, Cc, H)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = 1e3 * dt / steps
+    kms = ctx.timing("stream_kernel")[0]
+    pairs = ctx.stat("pairs_tested")
+    mfma_tflops = pairs * 2.0 * 16 / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    out = {"metric": "r-disc queries/sec, streaming reductions (BASELINE configs[2] at the fmt.jl:39 radius; not the headline metric)",
+           "value": w.N * steps / dt, "unit": "r-disc queries/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "cfg3_full_r12_n%d" % w.N, "N": w.N, "d": w.d, "r": r, "nnz": got["nnz"], "mean_degree": got["nnz"] / w.N,
+                      "step": "mpfmt_rdisc_stream: degree of every column + best open parent argmin C[y] + d(y, x) over a 25 % open set; "
+                              "host arrays in, host arrays out (40 MB over PCIe inside the step)"},
+           "submetrics": {"stream_kernel_ms": kms, "pairs_tested": pairs, "pairs_per_s": pairs / (kms * 1e-3) if kms > 0 else None,
+                          "edges_reduced_per_s": got["nnz"] / (kms * 1e-3) if kms > 0 else None,
+                          "csc_bytes_never_stored": 12.0 * got["nnz"] + 8.0 * (w.N + 1)},
+           "roofline": {"kernel": "k_rdisc_mfma<12, 3> (fp16 MFMA filter + exact fp64 refine + per-column reductions in LDS)", "bound": "mfma",
+                        "achieved": pairs * 2.0 * w.d / (kms * 1e-3) / 1e12 if kms > 0 else 0.0, "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": (pairs * 2.0 * w.d / (kms * 1e-3) / 1e12 / FP16_MFMA_PEAK_TFLOPS) if kms > 0 else 0.0,
+                        "mfma_flops_issued_tflops": mfma_tflops, "mfma_issued_frac_of_peak": mfma_tflops / FP16_MFMA_PEAK_TFLOPS, "traffic": None}}
+    print(json.dumps(out))
+    ctx.close()
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -148,7 +193,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="north_star", choices=["north_star", "cfg2", "cfg1", "cfg3"])
+    ap.add_argument("--workload", default="north_star", choices=["north_star", "cfg2", "cfg1", "cfg3", "cfg3_full"])
     ap.add_argument("--n", type=int, default=0, help="override the sample count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the whole-solve submetric (wavefront FMT*)")
@@ -158,6 +203,8 @@ def main():
                          "graph of NEW samples, as a planner's calls do; 1 = the same samples every step")
     args = ap.parse_args()
 
+    if args.workload == "cfg3_full":
+        return stream_bench(args)
     one_device = bool(os.environ.get("MPFMT_BENCH_ONE_DEVICE"))
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
@@ -295,6 +342,22 @@ def main():
     else:
         nnz_total, nnz_sum_total = nnz, nnz_sum
 
+    # consistency of a sharded run with the unsharded one (tools/first_8gpu_run.sh): free edges over all shards of the LAST step
+    free_edges = None
+    try:
+        from motionplanning_jl_amd.distributed import DevArray
+        fr = ctx.graph_device_ptrs()[3]
+        if fr and nnz > 0:
+            wds = torch.as_tensor(DevArray(fr, (nnz + 63) // 64), device=dev).cpu().numpy().view(np.uint8)
+            free_edges = int(np.unpackbits(wds, bitorder="little")[:nnz].sum())
+        else:
+            free_edges = 0
+        if dist is not None:
+            tf = torch.tensor([free_edges], dtype=torch.int64, device=dev)
+            dist.all_reduce(tf, op=dist.ReduceOp.SUM)
+            free_edges = int(tf.item())
+    except Exception:
+        free_edges = None
     ms_step = 1e3 * dt / max(args.steps, 1)
     nnz_last = nnz
     nnz = nnz_sum / max(args.steps, 1)               # this rank's mean entries per step: what the per-kernel averages below belong to
@@ -369,6 +432,7 @@ def main():
                            ("; half build: every pair of samples is tested once by the pair kernel, which writes the hit records of both columns" if half_build else "") +
                            ("; edge tests fused: the broad phase of a pair's segment runs in the pair kernel's drain (once for both directions), "
                             "the flagged pairs' slab tests in k_exact_pairs, the mask is written by the ordering pass -- no separate sweep kernel" if edge_form == 2 else "")},
+        "consistency": {"free_edges": free_edges, "of_entries": nnz_total, "what": "set bits of the free-edge mask of the last step, summed over the shards"},
         "submetrics": {
             "rdisc_queries_per_s": w.N * args.steps / dt,
             # (form 2: no kernel is "the sweep" -- every edge's broad phase runs inside the pair kernel and k_exact_pairs visits the

@@ -365,6 +365,20 @@ MPFMT_API int32_t mpfmt_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** 
 MPFMT_API int32_t mpfmt_graph_export(mpfmt_ctx* ctx, int64_t* colptr, int64_t* rowval, double* nzval, uint64_t* mask, double* gb_per_s);
 MPFMT_API int32_t mpfmt_pinned_alloc(int64_t bytes, void** out);
 MPFMT_API int32_t mpfmt_pinned_free(void* p);
+
+/* ---- streaming r-disc: per-column reductions WITHOUT the stored graph.  BASELINE configs[2] at the radius of src/planners/fmt.jl:39
+ *      (R^12, N = 1e6: ~4 700 neighbours per sample, 57 GB of CSC) cannot keep ImmutableNNC resident; what the loop body
+ *      src/planners/fmt.jl:70-82 needs of column x is a reduction over inball(x) (src/nearneighbors.jl:179-183):
+ *        deg[x]      = |inball(x)|                                        (PRM*-style degree; *nnz = their sum)
+ *        parent[x]   = argmin over y in inball(x), y in H, of C[y] + d(y, x), FIRST minimum in ascending y (findmin, fmt.jl:73),
+ *                      1-based, 0 when no open neighbour; cost[x] = that minimum (Inf when none) -- C = NULL skips both;
+ *                      H = NULL: every sample is open.  The caller then makes the ONE lazy edge test of fmt.jl:75 (mpfmt_edges_free).
+ *        free_deg[x] = number of y in inball(x) with is_free_motion(V[y], V[x]) (src/statespaces.jl:153-158) when want_free != 0
+ *      C: N doubles by sample index; H: BitVector chunks over the samples.  Outputs: N entries each, caller-owned.  Needs an
+ *      unsharded ctx, d <= 12 and a radius the fp16 filter can take (the MFMA pair kernel does the work); membership and costs are
+ *      the canonical fp64 arithmetic of every other entry point. ---------------------------------------------------------------- */
+MPFMT_API int32_t mpfmt_rdisc_stream(mpfmt_ctx* ctx, double r, const double* C, const uint64_t* H, int32_t want_free,
+                                     int64_t* deg, int64_t* free_deg, int64_t* parent, double* cost, int64_t* nnz);
 /* Shard bookkeeping for the all-gather: column range (in the library's sorted order) and the number
  * of edges this shard produced. */
 MPFMT_API int32_t mpfmt_shard_info(mpfmt_ctx* ctx, int64_t* col_begin, int64_t* col_end, int64_t* shard_nnz);

@@ -118,6 +118,7 @@ SYMBOLS = [
     ("mpfmt_graph_export", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, c_d_p, c_u64_p, c_d_p]),
     ("mpfmt_pinned_alloc", C.c_int32, [C.c_int64, C.POINTER(C.c_void_p)]),
     ("mpfmt_pinned_free", C.c_int32, [C.c_void_p]),
+    ("mpfmt_rdisc_stream", C.c_int32, [C.c_void_p, C.c_double, c_d_p, c_u64_p, C.c_int32, c_i64_p, c_i64_p, c_i64_p, c_d_p, c_i64_p]),
     ("mpfmt_shard_info", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, c_i64_p]),
     ("mpfmt_fmtstar_wavefront", C.c_int32, [C.c_void_p, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p, C.c_double, C.c_int32,
                                             c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult), C.POINTER(WfInfo)]),
@@ -833,6 +834,23 @@ class Context:
             self._chk(self._L.mpfmt_graph_export(self._h, _ip(colptr), _ip(rowval), _dp(nzval), _up(mask) if want_mask else None, C.byref(rate)))
             rowval, nzval, mask = rowval[:nnz], nzval[:nnz], (mask[:words] if want_mask else None)
         return colptr, rowval, nzval, mask, rate.value
+
+    def rdisc_stream(self, r, Cc=None, H=None, want_free=False):
+        """Per-column reductions of the r-disc graph without storing it: dict(deg, nnz[, parent (1-based, 0 = none), cost][, free_deg])."""
+        N = self.N
+        deg = np.zeros(max(N, 1), dtype=np.int64); fdeg = np.zeros(max(N, 1), dtype=np.int64)
+        par = np.zeros(max(N, 1), dtype=np.int64); cost = np.zeros(max(N, 1), dtype=np.float64)
+        nnz = C.c_int64()
+        Cc_ = None if Cc is None else np.ascontiguousarray(Cc, dtype=np.float64)
+        H_ = None if H is None else np.ascontiguousarray(H, dtype=np.uint64)
+        self._chk(self._L.mpfmt_rdisc_stream(self._h, float(r), _dp(Cc_), _up(H_), int(bool(want_free)), _ip(deg), _ip(fdeg), _ip(par), _dp(cost),
+                                             C.byref(nnz)))
+        out = {"deg": deg[:N], "nnz": nnz.value}
+        if Cc is not None:
+            out["parent"], out["cost"] = par[:N], cost[:N]
+        if want_free:
+            out["free_deg"] = fdeg[:N]
+        return out
 
     def shard_info(self):
         a, b, n = C.c_int64(), C.c_int64(), C.c_int64()

@@ -25,6 +25,7 @@
 // MODE 2 (single pass) also writes every exact hit into the fixed-capacity slot list of its (tile, slice, column).
 #include "mpfmt_internal.h"
 #include "sweep_cmpx.h"
+#include "sweep_predicates.h"
 #include <algorithm>
 #include <cmath>
 
@@ -92,6 +93,16 @@ struct mf_args {
                                     // (k_sample_masks): a segment's box can only meet boxes in the masks of BOTH its ends
     // fb == 2: the pairs whose segment box met an obstacle's are listed (MF_NREG regions of icap 16-byte items, one per (pair, box)
     // unit) for k_exact_pairs, which runs the slab tests in both directions and sets bit 31 of the blocked records' key
+    // MODE 3 (streaming, mpfmt_rdisc_stream): no graph is stored; per column the degree, the best open parent argmin_y C[y] + d(y, x)
+    // (first minimum in ascending y: fmt.jl:73) and, on request, the number of free edges, as per-slice partials
+    const double* st_C;             // [N] cost-to-come by sample index (or nullptr: no parent search)
+    const unsigned long long* st_H; // [N bits] open set by sample index (nullptr: every sample is open)
+    int32_t st_free;                // count is_free_motion(V[y], V[x]) over the column's entries
+    int32_t st_ss_has;
+    const double* st_ss;            // state-space bounds lo[MPFMT_MAX_DIM], hi[MPFMT_MAX_DIM] (in_state_space of the first point)
+    unsigned long long* st_best;    // [S][npad] bits of the best cost (~0: none)
+    int32_t* st_besti;              // [S][npad] its sample index
+    int32_t* st_nfree;              // [S][npad]
     uint4* pitems;
     int32_t* pcnt;                  // [MF_NREG] items in each region (zeroed per build; may exceed icap: the reader clamps)
     long long icap;
@@ -472,6 +483,8 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     __shared__ int32_t s_lc[4];                           // own hits of the drain in work, per quarter of the tile (zero between drains)
     __shared__ unsigned long long s_qm[(MODE == 2 && D <= 6) ? 64 : 1];      // the queries' obstacle masks (broad phase in the drain)
     __shared__ int64_t s_base[MODE == 1 ? 64 : 1];
+    __shared__ unsigned long long s_best[MODE == 3 ? 64 : 1];
+    __shared__ int32_t s_besti[MODE == 3 ? 64 : 1], s_nfree[MODE == 3 ? 64 : 1];
 
     const int lane = threadIdx.x;
     const int64_t nblk = gridDim.x;
@@ -525,6 +538,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     s_cnt[lane] = 0;
     if (lane < 4) s_lc[lane] = 0;
     if constexpr (MODE == 2 && D <= 6) { if (a.fb) s_qm[lane] = a.smask[qpos]; }
+    if constexpr (MODE == 3) { s_best[lane] = ~0ull; s_besti[lane] = 0x7fffffff; s_nfree[lane] = 0; }
     constexpr bool FILL = (MODE == 1);
     if (FILL) {
         int64_t base = a.tptr[qpos];
@@ -605,6 +619,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         uint32_t jg = 0, ql = 0;
         double d2 = 0.0;
         [[maybe_unused]] double sl[D <= 6 ? D : 1], sh[D <= 6 ? D : 1];
+        [[maybe_unused]] double qv[MODE == 3 ? D : 1], cv[MODE == 3 ? D : 1];
         if constexpr (MODE == 2 && D <= 6) {
 #pragma unroll
             for (int i = 0; i < D; ++i) { sl[i] = (double)INFINITY; sh[i] = -(double)INFINITY; }
@@ -622,6 +637,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 const double qi = s_q[ql * D + i], ci = a.Xs[(int64_t)jg * D + i];
+                if constexpr (MODE == 3) { qv[i] = qi; cv[i] = ci; }
                 if constexpr (MODE == 2 && D <= 6) {
                     asm("v_min_f64 %0, %1, %2" : "=v"(sl[i]) : "v"(qi), "v"(ci));     // the segment's box (only compared: -0 / +0 do not show)
                     asm("v_max_f64 %0, %1, %2" : "=v"(sh[i]) : "v"(qi), "v"(ci));
@@ -637,9 +653,58 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                     const int64_t pos = s_base[ql] + slot;
                     a.rowtmp[pos] = a.perm[jg];
                     a.valtmp[pos] = sqrt(d2);
-                } else if (MODE == 0) {
+                } else if (MODE == 0 || MODE == 3) {
                     atomicAdd(&s_cnt[ql], 1);                             // the column's degree (no return value needed; the single pass counts from the logs)
                 }
+            }
+        }
+        if constexpr (MODE == 3) {
+            // ---- streaming reductions of the column ql over this drain's hits ----
+            if (a.st_C) {
+                // best open parent: lexicographic minimum of (C[y] + dist, y) -- findmin returns the FIRST minimum of the ascending
+                // neighbourhood (fmt.jl:73).  Costs are non-negative doubles: their bit patterns order like the values.
+                unsigned long long mine = ~0ull, old = ~0ull;
+                int y = -1;
+                if (hit) {
+                    y = a.perm[jg];
+                    const bool open = a.st_H ? ((a.st_H[y >> 6] >> (y & 63)) & 1ull) != 0 : true;
+                    if (open) {
+                        const double cost = a.st_C[y] + sqrt(d2);
+                        if (cost >= 0.0) mine = (unsigned long long)__double_as_longlong(cost);      // (NaN: no candidate)
+                    }
+                    old = s_best[ql];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                if (mine != ~0ull) atomicMin(&s_best[ql], mine);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const unsigned long long now = hit ? s_best[ql] : ~0ull;
+                if (hit && now < old) s_besti[ql] = 0x7fffffff;       // the minimum moved in this drain: the index of the old one is out
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                if (mine != ~0ull && mine == now) atomicMin(&s_besti[ql], y);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            }
+            if (a.st_free) {
+                // is_free_motion(V[y], V[x], CC, SS) (statespaces.jl:153-158): in_state_space of the first point, then the segment against
+                // every box -- broad phase, exact slab test where the boxes meet (boxesND.jl:44-56); boxes through the scalar cache
+                bool fr = hit;
+                if (a.st_ss_has) {
+                    const mf_cptr sp = mf_const(a.st_ss);
+                    int ok = 1;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) ok &= (int)(sp[i] <= cv[i]) & (int)(cv[i] <= sp[MPFMT_MAX_DIM + i]);
+                    fr = fr && ok != 0;
+                }
+                double l[D], h[D];
+                seg_bbox<D>(cv, qv, l, h);
+                for (int k = 0; k < a.M; ++k) {
+                    box_regs<D> bx;
+                    const mf_cptr bp = mf_const(a.boxes) + (int64_t)k * 2 * D;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) { bx.lo[i] = bp[i]; bx.hi[i] = bp[D + i]; }
+                    const bool meet = fr && !broadphase_free_sl<D>(l, h, bx);
+                    if (__ballot(meet)) { const bool f = narrow_free_sl<D>(cv, qv, bx); if (meet) fr = f; }
+                }
+                if (fr) atomicAdd(&s_nfree[ql], 1);
             }
         }
         // broad phase of is_free_motion for the hits of this drain (boxesND.jl:44-45, symmetric in the two end points, so one test
@@ -944,6 +1009,12 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     if (MODE == 2) {
         if (pool_over) *a.pool_flag = 1;                          // a quarter log overflowed: the build is redone in the two-pass form
     }
+    if constexpr (MODE == 3) {
+        a.slice_cnt[(int64_t)slice * a.npad + qpos] = s_cnt[lane];
+        a.st_best[(int64_t)slice * a.npad + qpos] = s_best[lane];
+        a.st_besti[(int64_t)slice * a.npad + qpos] = s_besti[lane];
+        a.st_nfree[(int64_t)slice * a.npad + qpos] = s_nfree[lane];
+    }
     if (MODE != 1) {
         if (MODE == 0) a.slice_cnt[(int64_t)slice * a.npad + qpos] = s_cnt[lane];
         // per-XCD-sharded counters: a single hot address saturates at ~88 atomics/us (156k items would cost 1.8 ms)
@@ -1011,7 +1082,10 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
     if (ctx->lists_r == r && ctx->lists_begin == ctx->tile_begin && ctx->lists_end == ctx->tile_end && ctx->lists && ctx->lists_half == half) return MPFMT_OK;
     if (ctx->lists_half != half) { ctx->lists_cap_trusted = -1; ctx->lists_half = half; }       // (a capacity learnt in the other form says nothing)
     int32_t rc;
-    int64_t cap = std::min<int64_t>(ctx->ntiles, std::max<int64_t>(ctx->list_cap, 3072));      // (the north star's longest list is ~2000 entries, and differs by sample set)
+    // (the north star's longest list is ~2 250 entries for most sample sets and 6 257 for one of five -- a tile of three sparse cells
+    // across a row end: large index builds start with room for that; small shards keep the capacity their 4-wavefront list kernel stages)
+    const bool small = (ctx->tile_end - ctx->tile_begin) < 16 * (int64_t)ctx->num_cus;
+    int64_t cap = std::min<int64_t>(ctx->ntiles, std::max<int64_t>(ctx->list_cap, small ? 3072 : 8192));
     const double rpad = r * (1.0 + 1e-9) + 1e-300;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->list_len, sizeof(int32_t) * (size_t)(nt + 1)))) return rc;
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -1153,6 +1227,9 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.ntiles_shard = ctx->tile_end - ctx->tile_begin;
     a.fb = (MODE == 2 && ctx->broad_in_drain) ? (ctx->bits_in_records ? 2 : 1) : 0; a.M = ctx->M; a.boxes = ctx->boxes;
     a.smask = (const unsigned long long*)ctx->smask;
+    a.st_C = ctx->st_C; a.st_H = (const unsigned long long*)ctx->st_H; a.st_free = ctx->st_free;
+    a.st_ss_has = (int32_t)(ctx->ss.has != 0); a.st_ss = ctx->rt_ss;
+    a.st_best = (unsigned long long*)ctx->st_best; a.st_besti = ctx->st_besti; a.st_nfree = ctx->st_nfree;
     a.pitems = (uint4*)ctx->pair_items; a.pcnt = ctx->pair_cnt; a.icap = ctx->pair_icap; a.pend_over = ctx->pair_over;
     if (MODE != 2 && ctx->lists_half) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "two-pass r-disc kernels need whole chunk lists");
     if (a.nitems <= 0) return MPFMT_OK;
@@ -1172,3 +1249,115 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
 template int32_t mpfmt_launch_rdisc_mfma<0>(mpfmt_ctx*, double, float);
 template int32_t mpfmt_launch_rdisc_mfma<1>(mpfmt_ctx*, double, float);
 template int32_t mpfmt_launch_rdisc_mfma<2>(mpfmt_ctx*, double, float);
+template int32_t mpfmt_launch_rdisc_mfma<3>(mpfmt_ctx*, double, float);
+
+// ---- streaming mode: per-column reductions without a stored graph (mpfmt_rdisc_stream) -------------------------------------------------
+// BASELINE configs[2] at the radius of fmt.jl:39 (R^12, N = 1e6, r = 0.625) has ~4 700 neighbours per sample: 57 GB of CSC.  What an
+// FMT* expand step (fmt.jl:70-82) or a PRM*-style count needs of it per column x is a reduction: the degree, the best open parent
+// argmin_y C[y] + d(y, x) (then ONE lazy edge test of that parent, fmt.jl:75), optionally the number of free edges.  The pair kernel
+// in MODE 3 (filter on the matrix cores, exact fp64 refine, reductions in LDS per (tile, slice)) leaves per-slice partials; this
+// kernel folds the slices and writes by sample index.
+__global__ void k_stream_reduce(const int32_t* __restrict__ slice_cnt, const unsigned long long* __restrict__ st_best, const int32_t* __restrict__ st_besti,
+                                const int32_t* __restrict__ st_nfree, int S, int64_t npad, int64_t pos_begin, int64_t pos_end,
+                                const int32_t* __restrict__ perm, int64_t* __restrict__ deg, int64_t* __restrict__ nfree,
+                                int64_t* __restrict__ parent, double* __restrict__ cost, unsigned long long* __restrict__ total)
+{
+    const int64_t s = pos_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    long long k = 0;
+    if (s < pos_end) {
+        const int32_t o = perm[s];
+        if (o >= 0) {
+            long long f = 0;
+            unsigned long long b = ~0ull;
+            int32_t bi = 0x7fffffff;
+            for (int i = 0; i < S; ++i) {
+                k += slice_cnt[(int64_t)i * npad + s];
+                f += st_nfree[(int64_t)i * npad + s];
+                const unsigned long long c = st_best[(int64_t)i * npad + s];
+                const int32_t ci = st_besti[(int64_t)i * npad + s];
+                if (c < b || (c == b && ci < bi)) { b = c; bi = ci; }
+            }
+            deg[o] = k; nfree[o] = f;
+            parent[o] = (b != ~0ull) ? (int64_t)bi + 1 : 0;                      // 1-based sample index, 0 = no open neighbour
+            cost[o] = (b != ~0ull) ? __longlong_as_double((long long)b) : (double)INFINITY;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) k += __shfl_xor(k, off);
+    if ((threadIdx.x & 63) == 0 && k) atomicAdd(total, (unsigned long long)k);
+}
+
+int32_t mpfmt_rdisc_stream_impl(mpfmt_ctx* ctx, double r, const double* C_host, const uint64_t* H_host, int32_t want_free,
+                                int64_t* deg, int64_t* nfree, int64_t* parent, double* cost, int64_t* nnz_out)
+{
+    int32_t rc;
+    const int64_t N = ctx->N;
+    if (ctx->world != 1) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "mpfmt_rdisc_stream needs an unsharded ctx");
+    if (want_free && !(ctx->have_boxes && ctx->cc_kind == 0 && ctx->dw == ctx->d))
+        return mpfmt_fail(ctx, MPFMT_ERR_STATE, "free-edge counts need PointRobotNDBoxes obstacles in the state space's own coordinates");
+    if ((rc = mpfmt_build_grid(ctx, r))) return rc;
+    ctx->tile_begin = 0; ctx->tile_end = ctx->ntiles;
+    const int64_t nt = ctx->ntiles, npad = nt * 64;
+    bool mf = false;
+    float negT = 0.f;
+    if ((rc = mpfmt_mfma_prepare(ctx, r, &negT, &mf))) return rc;
+    if (!mf) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "mpfmt_rdisc_stream runs on the MFMA pair kernel: d <= 12 and a radius above the fp16 shell");
+    if (ctx->ops_r != ctx->grid_r) {
+        if ((rc = mpfmt_mfma_build_operands(ctx))) return rc;
+        ctx->ops_r = ctx->grid_r; ctx->lists_r = -1.0;
+    }
+    bool ok = true;
+    if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok, false, false))) return rc;
+    if (!ok) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "chunk lists exceed 32 GB");
+    const int64_t target = ctx->d <= 6 ? ctx->mf_target_items : ctx->mf_target_items * 7 / 4;
+    const int S = nt > 0 ? (int)std::min<int64_t>(MPFMT_MAXS, std::max<int64_t>(1, (target + nt - 1) / nt)) : 1;
+    ctx->S = S;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->slice_cnt, sizeof(int32_t) * (size_t)S * std::max<int64_t>(npad, 1)))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->st_best, sizeof(uint64_t) * (size_t)S * std::max<int64_t>(npad, 1)))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->st_besti, sizeof(int32_t) * (size_t)S * std::max<int64_t>(npad, 1)))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->st_nfree, sizeof(int32_t) * (size_t)S * std::max<int64_t>(npad, 1)))) return rc;
+    // scratch: C[N], H words, deg[N], nfree[N], parent[N], cost[N], total
+    const size_t w = (size_t)(N + 63) / 64;
+    const size_t o_C = 0, o_H = o_C + 8 * (size_t)std::max<int64_t>(N, 1), o_deg = o_H + 8 * std::max<size_t>(w, 1), o_nf = o_deg + 8 * (size_t)std::max<int64_t>(N, 1),
+                 o_par = o_nf + 8 * (size_t)std::max<int64_t>(N, 1), o_cost = o_par + 8 * (size_t)std::max<int64_t>(N, 1), o_tot = o_cost + 8 * (size_t)std::max<int64_t>(N, 1);
+    void* scr;
+    if ((rc = mpfmt_scratch(ctx, o_tot + 16, &scr))) return rc;
+    char* sc = (char*)scr;
+    if (C_host && N > 0) HIPCHK(ctx, hipMemcpyAsync(sc + o_C, C_host, 8 * (size_t)N, hipMemcpyHostToDevice, ctx->stream));
+    if (H_host && N > 0) HIPCHK(ctx, hipMemcpyAsync(sc + o_H, H_host, 8 * w, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(sc + o_tot, 0, 16, ctx->stream));
+    if (want_free && (rc = mpfmt_sweep_prepare_ss(ctx))) return rc;
+    if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 514 * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 512 * sizeof(unsigned long long), ctx->stream));
+    ctx->st_C = C_host ? (const double*)(sc + o_C) : nullptr;
+    ctx->st_H = (C_host && H_host) ? (const uint64_t*)(sc + o_H) : nullptr;
+    ctx->st_free = want_free ? 1 : 0;
+    ctx->half_used = false; ctx->broad_in_drain = false; ctx->bits_in_records = false;
+    // the resident graph (if any) keeps its arrays, but the index now belongs to this radius
+    if (ctx->graph_r != r) { ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false; ctx->graph_r = -1.0; }
+    ctx->spec_ready = false;
+    if (nt > 0) {
+        mpfmt_timed tk(ctx);
+        if ((rc = mpfmt_launch_rdisc_mfma<3>(ctx, r, negT))) return rc;
+        tk.end("stream_kernel");
+        const int B = 256;
+        hipLaunchKernelGGL(k_stream_reduce, dim3((unsigned)((npad + B - 1) / B)), dim3(B), 0, ctx->stream, ctx->slice_cnt, (const unsigned long long*)ctx->st_best,
+                           ctx->st_besti, ctx->st_nfree, S, npad, (int64_t)0, npad, ctx->perm, (int64_t*)(sc + o_deg), (int64_t*)(sc + o_nf), (int64_t*)(sc + o_par),
+                           (double*)(sc + o_cost), (unsigned long long*)(sc + o_tot));
+        HIPCHK(ctx, hipGetLastError());
+    }
+    unsigned long long tot = 0, pairs[512];
+    if (N > 0) {
+        if (deg) HIPCHK(ctx, hipMemcpyAsync(deg, sc + o_deg, 8 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+        if (nfree && want_free) HIPCHK(ctx, hipMemcpyAsync(nfree, sc + o_nf, 8 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+        if (parent && C_host) HIPCHK(ctx, hipMemcpyAsync(parent, sc + o_par, 8 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+        if (cost && C_host) HIPCHK(ctx, hipMemcpyAsync(cost, sc + o_cost, 8 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(&tot, sc + o_tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pairs, ctx->d_pairs, sizeof pairs, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 1; i < 256; ++i) { pairs[0] += pairs[2 * i]; pairs[1] += pairs[2 * i + 1]; }
+    ctx->pairs_tested = (int64_t)pairs[0]; ctx->survivors = (int64_t)pairs[1];
+    ctx->st_C = nullptr; ctx->st_H = nullptr; ctx->st_free = 0;
+    if (nnz_out) *nnz_out = (int64_t)tot;
+    return MPFMT_OK;
+}

@@ -195,7 +195,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
-                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->qkey, ctx->qd2, ctx->qlen, ctx->smask, ctx->pend_items, ctx->pend_cnt, ctx->pair_items, ctx->pair_cnt, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev, ctx->bb_dev};
+                    ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->qkey, ctx->qd2, ctx->qlen, ctx->smask, ctx->st_best, ctx->st_besti, ctx->st_nfree, ctx->pend_items, ctx->pend_cnt, ctx->pair_items, ctx->pair_cnt, ctx->lists, ctx->list_len, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev, ctx->bb_dev};
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
     if (ctx->bb_host) hipHostFree(ctx->bb_host);
     for (int k = 0; k < 2; ++k) { if (ctx->copy_stream[k]) hipStreamDestroy(ctx->copy_stream[k]); if (ctx->ev_conv[k]) hipEventDestroy(ctx->ev_conv[k]); if (ctx->ev_copy[k]) hipEventDestroy(ctx->ev_copy[k]); }
@@ -730,6 +730,20 @@ int32_t mpfmt_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return MPFMT_OK;
+}
+
+// per-column reductions of the r-disc graph without storing it (kernels_rdisc_mfma.hip, MODE 3)
+int32_t mpfmt_rdisc_stream(mpfmt_ctx* ctx, double r, const double* C, const uint64_t* H, int32_t want_free,
+                           int64_t* deg, int64_t* free_deg, int64_t* parent, double* cost, int64_t* nnz)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->Xo && ctx->N > 0) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    if (!(r >= 0.0) || !std::isfinite(r)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "radius must be finite and >= 0");
+    if (H && !C) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "an open set without costs");
+    if (C && (!parent || !cost)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "parent / cost is NULL");
+    if (want_free && !free_deg) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "free_deg is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return mpfmt_rdisc_stream_impl(ctx, r, C, H, want_free, deg, free_deg, parent, cost, nnz);
 }
 
 // ---- the resident graph + mask to the host in the ABI's format, at link speed ----------------------------------------------------------
@@ -1592,6 +1606,17 @@ int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value)
     if (strcmp(name, "qcap") == 0) { *value = ctx->qcap; return MPFMT_OK; }
     if (strcmp(name, "pool_used") == 0) { *value = ctx->pool_valid ? 1 : 0; return MPFMT_OK; }
     if (strcmp(name, "list_cap") == 0) { *value = ctx->list_cap; return MPFMT_OK; }
+    if (strcmp(name, "list_max") == 0) {                     // (a synchronising read) longest chunk list of the last list build
+        *value = 0;
+        const int64_t nt = ctx->tile_end - ctx->tile_begin;
+        if (ctx->list_len && nt > 0) {
+            int32_t v = 0;
+            HIPCHK(ctx, hipMemcpyAsync(&v, ctx->list_len + nt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            *value = v;
+        }
+        return MPFMT_OK;
+    }
     if (strcmp(name, "survivors") == 0) { *value = ctx->survivors; return MPFMT_OK; }
     if (strcmp(name, "pairs_tested") == 0) { *value = ctx->pairs_tested; return MPFMT_OK; }
     if (strcmp(name, "nnz") == 0) { *value = ctx->nnz; return MPFMT_OK; }

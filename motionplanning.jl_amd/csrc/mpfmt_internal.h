@@ -133,6 +133,8 @@ struct mpfmt_ctx {
     uint32_t* qkey = nullptr;            // [quarter tiles of the shard][qcap] record keys: row sample index | column within the quarter << 26 | flags
     double* qd2 = nullptr;               // [quarter tiles of the shard][qcap] squared distances
     int32_t* qlen = nullptr;             // [quarter tiles of the shard] the logs' cursors
+    const double* st_C = nullptr; const uint64_t* st_H = nullptr; int st_free = 0;      // streaming mode (mpfmt_rdisc_stream): inputs of the launch in flight
+    void* st_best = nullptr; int32_t* st_besti = nullptr; int32_t* st_nfree = nullptr;  //   and its per-slice partials [S][npad]
     void* smask = nullptr;               // [npad] per-sample obstacle masks (k_sample_masks): the drain's broad phase walks the boxes in (mask_q & mask_c) only
     int64_t pool_hint_qmax = 0;          // records in the fullest quarter (16 consecutive cell-sorted columns) of the last build: sizes the next one's logs
     // half build of the single-pass r-disc graph (kernels_rdisc_mfma.hip: every pair found once, the other column's record goes
@@ -281,6 +283,8 @@ int32_t mpfmt_sweep_prepare_ss(mpfmt_ctx* ctx);          // kernels_sweep.hip: d
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false, bool half = false);
 int32_t mpfmt_launch_log_degrees(mpfmt_ctx* ctx);
 int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r);
+int32_t mpfmt_rdisc_stream_impl(mpfmt_ctx* ctx, double r, const double* C_host, const uint64_t* H_host, int32_t want_free,
+                                int64_t* deg, int64_t* nfree, int64_t* parent, double* cost, int64_t* nnz_out);
 int32_t mpfmt_launch_exact_pairs(mpfmt_ctx* ctx, const int32_t* spec_fail);
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);
