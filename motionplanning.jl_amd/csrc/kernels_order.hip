@@ -91,7 +91,11 @@ struct ord_args {
 // log length -> records -> LDS -> stores), and with 3 workgroups per CU nothing covers them.  So while a workgroup writes quarter q out
 // of LDS, the records of its next quarter are already on their way into registers, and the header of that quarter was requested a
 // phase earlier still.
+#ifdef ORD_W6
+__global__ __launch_bounds__(ORD_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_order_logs(ord_args a)
+#else
 __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
+#endif
 {
     if (a.spec_fail && *a.spec_fail) return;                 // speculative step whose capacities did not hold: redone by the host
     extern __shared__ __attribute__((aligned(16))) char ord_smem[];
@@ -142,12 +146,12 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
     double pd[ORD_PRE];
     // (buffer loads: one per-lane byte offset for all six, the slot's offset and the log's base scalar, reads past the log's end
     // return zero -- six flat loads keep six 64-bit addresses alive per array)
-    auto rec_fetch = [&](const ord_hdr& H, int64_t qi) {
-        const int total = (qi < nq) ? H.n : 0;
+    auto rec_fetch_n = [&](int total, int64_t qi) {
         const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.qkey + (qi < nq ? qi : 0) * a.qcap), 0, total * 4, 0x00020000);
 #pragma unroll
         for (int u = 0; u < ORD_PRE; ++u) pk[u] = __builtin_amdgcn_raw_buffer_load_b32(rk, tid * 4, u * ORD_THREADS * 4, 0);
     };
+    auto rec_fetch = [&](const ord_hdr& H, int64_t qi) { rec_fetch_n((qi < nq) ? H.n : 0, qi); };
     typedef uint32_t ord_u32x2 __attribute__((ext_vector_type(2)));
     auto d2_fetch = [&](int total, int64_t qi) {
         const long long base = (qi < nq ? qi : 0) * a.qcap;
@@ -247,13 +251,91 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
             }
             const bool last_range = g1 >= ORD_COLS;
             if (last_range) {
+#if ORD_OPT & 4
+                // (the next log's length straight from its cursor -- a wave-uniform load: no barrier for the header's copy of it)
+                const int ntot = (qn < nq) ? (int)min((long long)a.qlen[qn], a.qcap) : 0;
+                rec_fetch_n(ntot, qn);
+                if (!(ORD_OPT & 8)) d2_fetch(ntot, qn);
+#else
                 lds_barrier();                                // (the next header's log length is read by every thread)
                 rec_fetch(sh.h[hb ^ 1], qn);
                 if (!(ORD_OPT & 8)) d2_fetch(qn < nq ? sh.h[hb ^ 1].n : 0, qn);
+#endif
             }
             // ---- WRITE: thread = staging position ----
             if (!skip) {
                 const int nst = min(H.cb[g1] - gb, ORD_STG);
+#if ORD_OPT & 2
+                // three positions per thread at a time, level by level: the keys, then their buckets' ends and sizes, then the buckets'
+                // members and the distances -- each level's LDS reads are in flight together (one position at a time is a chain of four
+                // dependent LDS round trips, and a thread has up to six positions)
+#ifndef ORD_GW
+#define ORD_GW 2
+#endif
+                constexpr int GW = ORD_GW;
+                for (int p0 = 0; p0 < nst; p0 += GW * ORD_THREADS) {
+                    if (p0 + wave * 64 >= nst) break;                        // (no barrier inside: a wavefront without positions is done)
+                    int pj[GW], col[GW], e[GW], n[GW];
+                    bool act[GW];
+                    uint32_t key[GW], id[GW], m[GW][4];
+                    double dd[GW];
+#pragma unroll
+                    for (int j = 0; j < GW; ++j) {
+                        pj[j] = p0 + j * ORD_THREADS + tid;
+                        act[j] = pj[j] < nst;
+                        key[j] = stage_key[min(pj[j], ORD_STG - 1)];
+                        dd[j] = stage_d2[min(pj[j], ORD_STG - 1)];
+                    }
+#pragma unroll
+                    for (int j = 0; j < GW; ++j) {
+                        if (!act[j]) key[j] = (uint32_t)(g1 - 1) << 26;
+                        col[j] = (int)ORD_COL(key[j]); id[j] = ORD_ID(key[j]);
+                        const int bk = bucket(id[j]);
+                        e[j] = sh.cur[col[j]][bk]; n[j] = sh.cnt[col[j]][bk];    // the bucket occupies [e - n, e)
+                    }
+#pragma unroll
+                    for (int j = 0; j < GW; ++j) {
+                        const int b0 = min(max(e[j] - n[j], 0), ORD_STG - 1), bl = min(max(e[j] - 1, b0), ORD_STG - 1);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) m[j][t] = ORD_ID(stage_key[min(b0 + t, bl)]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < GW; ++j) {
+                        int rk = e[j] - n[j];
+                        if (act[j]) {
+                            rk += (int)(m[j][0] < id[j]) + (int)(n[j] > 1 && m[j][1] < id[j]) + (int)(n[j] > 2 && m[j][2] < id[j]) + (int)(n[j] > 3 && m[j][3] < id[j]);
+                            for (int mm = e[j] - n[j] + 4; mm < e[j]; ++mm) rk += (ORD_ID(stage_key[mm]) < id[j]) ? 1 : 0;
+                        }
+                        const int rel = rk - (H.cb[col[j]] - gb);                    // rank inside the column
+                        const bool valid = act[j] && rel >= 0 && rel < H.k[col[j]];  // (always, unless a log overflowed: that build is void, but stays in bounds)
+                        const int64_t o = H.out[col[j]] + rel;
+                        int32_t rp = 0;
+                        const bool pd_ = valid && a.pend_items && ((key[j] >> 30) & 1u);
+                        if ((valid && a.rowpos) || pd_) rp = a.iperm[id[j]];
+                        if (valid) {
+                            a.rowval[o] = (int32_t)id[j];
+                            a.nzval[o] = sqrt(dd[j]);                                // the log carries d2
+                            if (a.rowpos) a.rowpos[o] = rp;
+                        }
+                        if (a.rec_bits && valid && (key[j] >> 31)) atomicAnd(&sh.bits[rk >> 5], ~(1u << (rk & 31)));
+                        if (a.pend_items && p0 + j * ORD_THREADS + wave * 64 < nst) {
+                            const unsigned long long pm = __ballot(pd_);
+                            if (pm) {
+                                int base = 0;
+                                if (lane == 0) base = atomicAdd(&sh.pcount, (int)__popcll(pm));
+                                base = __builtin_amdgcn_readfirstlane(base);
+                                if (pd_) {
+                                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                                    if (pos < a.pend_wcap)
+                                        a.pend_items[(int64_t)blockIdx.x * a.pend_wcap + pos] =
+                                            make_uint4((uint32_t)(uint64_t)o, (uint32_t)((uint64_t)o >> 32), (uint32_t)H.ho[col[j]], (uint32_t)rp);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#else
                 for (int p0 = 0; p0 < nst; p0 += ORD_THREADS) {
                     const int p = p0 + tid;
                     const bool act = p < nst;
@@ -306,6 +388,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
                     }
                 }
             }
+#endif
             lds_barrier();
             if (a.rec_bits) {
                 // ---- the free bits of the range's columns, from rank positions to CSC positions (wavefront w: columns 2 w, 2 w + 1) ----
