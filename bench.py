@@ -391,11 +391,12 @@ def main():
         sweep_ms = tm["exact_pairs"][0]              # the only kernel that is edge tests alone; the broad phase rides in the pair kernel
     sweep_bytes = nnz * (2 * d * 8 + 8 + 1.0 / 8.0)
     if edge_form == 2:
-        sweep_bytes = pending_pairs * (32.0 + 2 * d * 8 + 8.0)       # one 32-byte item, two states, up to two record words marked
+        sweep_bytes = pending_pairs * (16.0 + 2 * d * 8 + 8.0)       # one 16-byte item, two states, up to two key words marked
     sweep_gbs = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-    # the column-ordering kernel (k_order_logs): algorithmic bytes = one 16-byte hit record in, rowval (4) + nzval (8) + rowpos (4) out
+    # the column-ordering kernel (k_order_logs): algorithmic bytes = one 12-byte hit record in, rowval (4) + nzval (8) out
     sort_ms = tm["order_sweep"][0] if fused else tm["rdisc_sort"][0]
-    sort_bytes_per_edge = 16.0 + 4.0 + 8.0 + (0.0 if fused else 4.0) + ((2 * d * 8 + 1.0 / 8.0) if fused else 0.0)
+    rowpos_out = edge_form == 0 and single_pass            # (the whole sweep gathers rows by cell-sorted position: the ordering pass then writes them too)
+    sort_bytes_per_edge = 12.0 + 4.0 + 8.0 + (4.0 if rowpos_out else 0.0) + (1.0 / 8.0 if edge_form == 2 else 0.0)
     sort_gbs = nnz * sort_bytes_per_edge / (sort_ms * 1e-3) / 1e9 if sort_ms > 0 else 0.0
     # algorithmic HBM bytes of the pair kernel: 8 d (N + Q) in + 12 nnz out
     pair_alg_bytes = 8.0 * d * (2 * stats["tiles"] * 64) + 12.0 * nnz
@@ -513,7 +514,7 @@ def main():
             "gather_ceiling_edges_per_s": ceiling if (d == 6 and edge_form != 2) else None,
             "frac_of_gather_ceiling": (nnz / (sweep_ms * 1e-3) / ceiling) if (d == 6 and sweep_ms > 0 and edge_form != 2) else None,      # (k_exact_pairs does not gather nnz rows)
             "avg_launch_ms": sweep_ms,
-            "note": ("edge tests fused into the half build: algorithmic bytes here = pending pairs x (32-byte item + two states + marks) -- a kernel of "
+            "note": ("edge tests fused into the half build: algorithmic bytes here = pending (pair, box) units x (16-byte item + two states + marks) -- a kernel of "
                      "dependent gathers and fp64 divisions, not a stream; the whole sweep it replaces: " if edge_form == 2 else "") +
                     "algorithmic bytes = (2*d*8 + 8 + 1/8) per edge = %.3f B; valu_frac = measured vector lane-ops per edge x edges/s over the "
                     "39.3e12 unfused fp64 lane-op/s of SURVEY 8d; every edge needs one 48-byte row-state gather: a kernel that does "
@@ -532,7 +533,8 @@ def main():
             "traffic_source": prof.get("source") if ok_ else None,
             "wait_frac": ok_.get("wait_frac"),
             "avg_launch_ms": sort_ms,
-            "note": "algorithmic bytes per edge = %.3f: one 16-byte hit record in, rowval + nzval%s out" % (sort_bytes_per_edge, " + free bit, both endpoints" if fused else " + rowpos"),
+            "note": "algorithmic bytes per edge = %.3f: one 12-byte hit record (key + d2) in, rowval + nzval%s out" % (
+                sort_bytes_per_edge, " + the free bit" if edge_form == 2 else " + rowpos" if rowpos_out else ""),
         }
     # the whole step against HBM: what has to cross it at least once (samples in, CSC + mask out) over the step time, and what the
     # counters saw cross it summed over EVERY kernel of a step (the hit records alone cross three times: written by the pair kernel,
