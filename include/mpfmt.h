@@ -195,6 +195,18 @@ MPFMT_API int32_t mpfmt_mc_edges_collision(mpfmt_ctx* ctx, const int64_t* src, c
  *      at k_mc_is_edges, csrc/kernels_sweep.hip).  rollouts < 2^22; the whole obstacle set must fit one LDS stage (M <= 256 at d <= 8). */
 MPFMT_API int32_t mpfmt_mc_edges_collision_is(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double sigma, int64_t rollouts,
                                     uint64_t seed, uint64_t* wsum);
+/*      The ADAPTIVE estimator (BASELINE configs[4]: "adaptive-importance-sampling"): per edge a pilot of 4096 rollouts with the noise
+ *      inflated by 1.625 finds colliding perturbations; their likelihood-ratio-weighted mean -- the mean of the nominal noise GIVEN a
+ *      collision, one cross-entropy update of the proposal's mean in all 2 d noise coordinates -- becomes the shift of a two-component
+ *      mixture (half nominal, half shifted); weights f(y) / (0.5 f(y) + 0.5 f(y - mu)) as above.  An edge whose pilot sees no collision
+ *      is estimated by plain Monte Carlo (mu = 0, every weight 1).  shifts (may be NULL): E x 2 d doubles, the mu of every edge in
+ *      noise units.  Spelled out: pilot rollout k, coordinate c < 2 d: Irwin-Hall integer S from Philox(key = seed, counter = (k, e,
+ *      64 + c, 2)), Z = S - 262140, z = Z / 53509.92, y = 1.625 z; a colliding rollout's likelihood ratio lr = prod g(x(y_c)) /
+ *      prod g(x(z_c)) (g, x as above), Wq = (uint64)(lr 2^30); SW = sum Wq, A_c = sum Wq Z_c over the hits; mu_c = clip(1.625 (A_c /
+ *      53509.92) / SW, -3, 3).  Main rollouts: noise as in mpfmt_mc_edges_collision, shifted by mu when word 0 of Philox(counter = (k,
+ *      e, 2 d, 3)) is odd.  Integer sums throughout: a scalar loop reproduces wsum and shifts exactly; same limits as above. */
+MPFMT_API int32_t mpfmt_mc_edges_collision_ais(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double sigma, int64_t rollouts,
+                                     uint64_t seed, uint64_t* wsum, double* shifts);
 
 /* ---- Dubins car: DubinsQuasiMetricSpace(r_turn, s, lo, hi) of src/statespaces/simplecars.jl:32-38.
  *      Samples are SE2 states (x, y, theta) (upload_samples with d = 3); obstacles live in the workspace (x, y)

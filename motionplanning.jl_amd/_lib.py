@@ -74,6 +74,8 @@ SYMBOLS = [
                                              C.POINTER(FmtResult)]),
     ("mpfmt_mc_edges_collision", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, C.c_int64, C.c_double, C.c_int64, C.c_uint64, c_i64_p]),
     ("mpfmt_mc_edges_collision_is", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, C.c_int64, C.c_double, C.c_int64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("mpfmt_mc_edges_collision_ais", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, C.c_int64, C.c_double, C.c_int64, C.c_uint64, C.POINTER(C.c_uint64),
+                                                 c_d_p]),
     ("mpfmt_dubins_graph_count", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_double, c_i64_p, c_i64_p]),
     ("mpfmt_dubins_graph_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p]),
     ("mpfmt_dubins_graph_edges_free", C.c_int32, [C.c_void_p, c_u64_p, c_u8_p]),
@@ -575,6 +577,17 @@ class Context:
                                                       wsum.ctypes.data_as(C.POINTER(C.c_uint64))))
         wsum = wsum[:len(src)]
         return wsum.astype(np.float64) / (2.0 ** 40) / max(int(rollouts), 1), wsum
+
+    def mc_edges_collision_ais(self, src, dst, sigma, rollouts, seed=0):
+        """ADAPTIVE importance sampling (pilot -> cross-entropy mean shift -> mixture): (probabilities, raw uint64 weight sums at 2^-40,
+        shifts (E, 2 d) in noise units)."""
+        src = np.ascontiguousarray(src, dtype=np.int64); dst = np.ascontiguousarray(dst, dtype=np.int64)
+        wsum = np.zeros(max(len(src), 1), dtype=np.uint64)
+        sh = np.zeros((max(len(src), 1), 2 * self.d))
+        self._chk(self._L.mpfmt_mc_edges_collision_ais(self._h, _ip(src), _ip(dst), len(src), float(sigma), int(rollouts), int(seed),
+                                                       wsum.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(sh)))
+        wsum = wsum[:len(src)]
+        return wsum.astype(np.float64) / (2.0 ** 40) / max(int(rollouts), 1), wsum, sh[:len(src)]
 
     # ---- Dubins and Reeds-Shepp cars --------------------------------------------------------------
     def _car_graph(self, car, turn_radius, speed, r):

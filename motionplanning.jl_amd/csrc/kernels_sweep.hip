@@ -1549,6 +1549,228 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_mc_is_edges(const double* __r
     if (threadIdx.x == 0 && s_sum) atomicAdd(&wsum[e], s_sum);
 }
 
+// ---- ADAPTIVE importance sampling (BASELINE configs[4]): a pilot estimates, per edge, the mean of the nominal noise
+// GIVEN a collision (a cross-entropy update of the proposal's mean), the main run samples from the mixture 0.5 nominal + 0.5 nominal
+// shifted by that mean.  include/mpfmt.h (mpfmt_mc_edges_collision_ais) spells the arithmetic out; all sums are integers, so a scalar
+// loop reproduces the shifts and the weight sums exactly.
+#define MC_AIS_NP 4096
+#define MC_AIS_ALPHA 1.625
+__device__ __forceinline__ int mc_normal_int(uint32_t k0, uint32_t k1, uint32_t k, uint32_t e, uint32_t c)
+{
+    uint32_t c0 = k, c1 = e, c2 = c, c3 = 2u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint32_t S = (c0 & 0xffffu) + (c0 >> 16) + (c1 & 0xffffu) + (c1 >> 16) + (c2 & 0xffffu) + (c2 >> 16) + (c3 & 0xffffu) + (c3 >> 16);
+    return (int)S - 262140;
+}
+
+// pilot: one workgroup per edge, thread = pilot rollout (16 each); integer sums of the hits' quantised likelihood ratios and of
+// their products with the noise integers; threads c < 2 D turn them into the shift mu[e][c]
+template <int D>
+__global__ __launch_bounds__(SWEEP_THREADS) void k_mc_ais_pilot(const double* __restrict__ X, const int64_t* __restrict__ src1,
+                                                                const int64_t* __restrict__ dst1, double sigma, uint64_t seed,
+                                                                const double* __restrict__ boxes, int M, mpfmt_ss ss,
+                                                                double* __restrict__ mu, int64_t e_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sbox = (double*)smem;
+    __shared__ unsigned long long s_sw;
+    __shared__ long long s_a[2 * D];
+    const int lane = threadIdx.x & 63;
+    const int64_t e = blockIdx.x;
+    if (threadIdx.x == 0) s_sw = 0;
+    if (threadIdx.x < 2 * D) s_a[threadIdx.x] = 0;
+    __syncthreads();
+    stage_boxes<D>(sbox, boxes, 0, M);
+    __syncthreads();
+    double v0[D], w0[D];
+    const int64_t s = src1[e] - 1, t = dst1[e] - 1;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { v0[i] = X[s * D + i]; w0[i] = X[t * D + i]; }
+    double ulo[D], uhi[D];
+    const double reach = (MC_ZMAX * MC_AIS_ALPHA) * sigma;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        ulo[i] = ((w0[i] < v0[i]) ? w0[i] : v0[i]) - reach;
+        uhi[i] = ((v0[i] < w0[i]) ? w0[i] : v0[i]) + reach;
+    }
+    unsigned long long smask[SWEEP_WORDS];
+    cull_boxes<D>(sbox, M, ulo, uhi, smask, lane);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    unsigned long long sw = 0;
+    long long acc[2 * D];
+#pragma unroll
+    for (int c = 0; c < 2 * D; ++c) acc[c] = 0;
+    for (int k = threadIdx.x; k < MC_AIS_NP; k += SWEEP_THREADS) {
+        int Z[2 * D];
+        double y[2 * D];
+        double num = 1.0, den = 1.0;
+#pragma unroll
+        for (int c = 0; c < 2 * D; ++c) {
+            Z[c] = mc_normal_int(k0, k1, (uint32_t)k, (uint32_t)(e_off + e), (uint32_t)(64 + c));
+            const double z = (double)Z[c] * MC_SCALE;
+            y[c] = MC_AIS_ALPHA * z;
+            const double xy = (y[c] * MC_INV + 262140.0) * (1.0 / 65536.0), xz = (z * MC_INV + 262140.0) * (1.0 / 65536.0);
+            num = num * mc_ih8_pdf(xy); den = den * mc_ih8_pdf(xz);
+        }
+        double v[D], w[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double pv = sigma * y[i], pw = sigma * y[D + i];
+            v[i] = v0[i] + pv; w[i] = w0[i] + pw;
+        }
+        bool fr = in_state_space_sl<D>(v, ss);
+        if (M > 0) fr = sweep_segment<D>(sbox, smask, v, w, fr);
+        if (!fr) {
+            const double lr = (den > 0.0) ? num / den : 0.0;
+            const unsigned long long Wq = (unsigned long long)(lr * 1073741824.0);
+            sw += Wq;
+#pragma unroll
+            for (int c = 0; c < 2 * D; ++c) acc[c] += (long long)Wq * (long long)Z[c];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) sw += __shfl_xor(sw, off);
+    if (lane == 0 && sw) atomicAdd(&s_sw, sw);
+#pragma unroll
+    for (int c = 0; c < 2 * D; ++c) {
+        long long a = acc[c];
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+        if (lane == 0 && a) atomicAdd((unsigned long long*)&s_a[c], (unsigned long long)a);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * D) {
+        double m = 0.0;
+        const unsigned long long SW = s_sw;
+        if (SW > 0) {
+            const double tt = (double)s_a[threadIdx.x] * MC_SCALE;
+            m = MC_AIS_ALPHA * tt / (double)SW;
+            m = (m < -3.0) ? -3.0 : ((m > 3.0) ? 3.0 : m);
+        }
+        mu[(e_off + e) * (2 * MPFMT_MAX_DIM) + threadIdx.x] = m;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(SWEEP_THREADS) void k_mc_ais_edges(const double* __restrict__ X, const int64_t* __restrict__ src1,
+                                                                const int64_t* __restrict__ dst1, double sigma, int64_t rollouts,
+                                                                int64_t per_block, uint64_t seed, const double* __restrict__ boxes, int M,
+                                                                mpfmt_ss ss, const double* __restrict__ mu_all,
+                                                                unsigned long long* __restrict__ wsum, int64_t e_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sbox = (double*)smem;
+    __shared__ unsigned long long s_sum;
+    const int lane = threadIdx.x & 63;
+    const int64_t e = blockIdx.x;
+    const int64_t k_begin = (int64_t)blockIdx.y * per_block, k_end = min(rollouts, k_begin + per_block);
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    stage_boxes<D>(sbox, boxes, 0, M);
+    __syncthreads();
+    double v0[D], w0[D], mu[2 * D];
+    const int64_t s = src1[e] - 1, t = dst1[e] - 1;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { v0[i] = X[s * D + i]; w0[i] = X[t * D + i]; }
+#pragma unroll
+    for (int c = 0; c < 2 * D; ++c) mu[c] = mu_all[(e_off + e) * (2 * MPFMT_MAX_DIM) + c];
+    double ulo[D], uhi[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double mx = fmax(fabs(mu[i]), fabs(mu[D + i]));
+        const double reach = (MC_ZMAX + mx) * sigma;
+        ulo[i] = ((w0[i] < v0[i]) ? w0[i] : v0[i]) - reach;
+        uhi[i] = ((v0[i] < w0[i]) ? w0[i] : v0[i]) + reach;
+    }
+    unsigned long long smask[SWEEP_WORDS];
+    cull_boxes<D>(sbox, M, ulo, uhi, smask, lane);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    unsigned long long mine = 0;
+    for (int64_t kb = k_begin; kb < k_end; kb += SWEEP_THREADS) {
+        const int64_t k = kb + threadIdx.x;
+        const bool act = k < k_end;
+        // selector: Philox(key = seed, counter = (k, e, 2 D, 3)) word 0
+        uint32_t c0 = (uint32_t)k, c1 = (uint32_t)(e_off + e), c2 = (uint32_t)(2 * D), c3 = 3u, q0 = k0, q1 = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ q0, n1 = (uint32_t)p1;
+            const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ q1, n3 = (uint32_t)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            q0 += 0x9E3779B9u; q1 += 0xBB67AE85u;
+        }
+        const bool shifted = (c0 & 1u) != 0;
+        double y[2 * D], v[D], w[D];
+#pragma unroll
+        for (int c = 0; c < 2 * D; ++c) {
+            const double z = mc_normal(k0, k1, (uint32_t)k, (uint32_t)(e_off + e), (uint32_t)c);
+            y[c] = shifted ? z + mu[c] : z;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double pv = sigma * y[i], pw = sigma * y[D + i];
+            v[i] = v0[i] + pv; w[i] = w0[i] + pw;
+        }
+        bool fr = act && in_state_space_sl<D>(v, ss);
+        if (M > 0) fr = sweep_segment<D>(sbox, smask, v, w, fr);
+        if (act && !fr) {
+            double a = 1.0, b = 1.0;
+#pragma unroll
+            for (int c = 0; c < 2 * D; ++c) {
+                const double xa = (y[c] * MC_INV + 262140.0) * (1.0 / 65536.0);
+                a = a * mc_ih8_pdf(xa);
+                const double yb = y[c] - mu[c];
+                const double xb = (yb * MC_INV + 262140.0) * (1.0 / 65536.0);
+                b = b * mc_ih8_pdf(xb);
+            }
+            const double ha = 0.5 * a, hb = 0.5 * b;
+            const double dn = ha + hb;
+            const double wgt = (dn > 0.0) ? a / dn : 0.0;
+            mine += (unsigned long long)(wgt * 1099511627776.0);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0 && mine) atomicAdd(&s_sum, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum) atomicAdd(&wsum[e], s_sum);
+}
+
+int32_t mpfmt_launch_mc_ais_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, double sigma, int64_t rollouts,
+                                  uint64_t seed, unsigned long long* d_wsum, double* d_mu)
+{
+    int32_t rc;
+    if ((rc = check_boxes(ctx, ctx->d))) return rc;
+    if (ctx->cc_kind != 0) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the Monte-Carlo evaluator runs against the AABB checker");
+    if (E == 0) return MPFMT_OK;
+    const int d = ctx->d;
+    const int chunk = box_chunk(ctx->M, d, true);
+    if (ctx->M > chunk) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "the importance-sampling estimator stages the whole obstacle set: M <= %d at d = %d", chunk, d);
+    const size_t lds = sweep_lds(std::max(chunk, 1), d);
+    int64_t slices = std::max<int64_t>(1, std::min<int64_t>((rollouts + 4 * SWEEP_THREADS - 1) / (4 * SWEEP_THREADS),
+                                                            std::max<int64_t>(1, (int64_t)ctx->num_cus * 8 / std::max<int64_t>(E, 1))));
+    slices = std::min<int64_t>(slices, 65535);
+    const int64_t per_block = ((std::max<int64_t>(rollouts, 1) + slices - 1) / slices + SWEEP_THREADS - 1) / SWEEP_THREADS * SWEEP_THREADS;
+    slices = (std::max<int64_t>(rollouts, 1) + per_block - 1) / per_block;
+    mpfmt_timed tm5(ctx);
+    for (int64_t e0 = 0; e0 < E; e0 += 1 << 20) {
+        const int64_t ne = std::min<int64_t>(E - e0, 1 << 20);
+        DISPATCH_D(d, hipLaunchKernelGGL((k_mc_ais_pilot<DD>), dim3((unsigned)ne), dim3(SWEEP_THREADS), lds, ctx->stream,
+                                         ctx->Xo, d_src1 + e0, d_dst1 + e0, sigma, seed, ctx->boxes, ctx->M, ctx->ss, d_mu, e0));
+        if (rollouts > 0)
+            DISPATCH_D(d, hipLaunchKernelGGL((k_mc_ais_edges<DD>), dim3((unsigned)ne, (unsigned)slices), dim3(SWEEP_THREADS), lds, ctx->stream,
+                                             ctx->Xo, d_src1 + e0, d_dst1 + e0, sigma, rollouts, per_block, seed, ctx->boxes, ctx->M, ctx->ss,
+                                             (const double*)d_mu, d_wsum + e0, e0));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    tm5.end("mc_ais_edges");
+    return MPFMT_OK;
+}
+
 int32_t mpfmt_launch_mc_is_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, double sigma, int64_t rollouts,
                                  uint64_t seed, unsigned long long* d_wsum)
 {

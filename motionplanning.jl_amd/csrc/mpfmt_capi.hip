@@ -650,6 +650,36 @@ int32_t mpfmt_mc_edges_collision_is(mpfmt_ctx* ctx, const int64_t* src, const in
     return MPFMT_OK;
 }
 
+// the ADAPTIVE estimator: pilot (4096 rollouts per edge, inflated noise) -> cross-entropy mean shift per edge -> mixture run
+int32_t mpfmt_mc_edges_collision_ais(mpfmt_ctx* ctx, const int64_t* src, const int64_t* dst, int64_t E, double sigma, int64_t rollouts,
+                                     uint64_t seed, uint64_t* wsum, double* shifts)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->Xo) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no samples uploaded");
+    if (E < 0 || E >= ((int64_t)1 << 32)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "E out of range");
+    if (rollouts < 0 || rollouts >= ((int64_t)1 << 22)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "rollouts out of range [0, 2^22): the weights are summed in 64 bits at 2^-40");
+    if (!(sigma >= 0.0) || !std::isfinite(sigma)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "sigma must be finite and >= 0");
+    if (E == 0) return MPFMT_OK;
+    if (!src || !dst || !wsum) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "src / dst / wsum is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = check_idx(ctx, src, E, "src")) || (rc = check_idx(ctx, dst, E, "dst"))) return rc;
+    DevTmp tmp;
+    int64_t *d_s = nullptr, *d_t = nullptr; unsigned long long* d_h = nullptr; double* d_mu = nullptr;
+    if ((rc = up_i64(ctx, tmp, src, E, &d_s))) return rc;
+    if ((rc = up_i64(ctx, tmp, dst, E, &d_t))) return rc;
+    HIPCHK(ctx, tmp.get(&d_h, sizeof(unsigned long long) * E));
+    HIPCHK(ctx, tmp.get(&d_mu, sizeof(double) * (size_t)E * 2 * MPFMT_MAX_DIM));
+    HIPCHK(ctx, hipMemsetAsync(d_h, 0, sizeof(unsigned long long) * E, ctx->stream));
+    if ((rc = mpfmt_launch_mc_ais_edges(ctx, d_s, d_t, E, sigma, rollouts, seed, d_h, d_mu))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(wsum, d_h, sizeof(uint64_t) * E, hipMemcpyDeviceToHost, ctx->stream));
+    if (shifts)       // [E][2 d] out of the [E][2 MPFMT_MAX_DIM] device rows
+        HIPCHK(ctx, hipMemcpy2DAsync(shifts, sizeof(double) * 2 * ctx->d, d_mu, sizeof(double) * 2 * MPFMT_MAX_DIM, sizeof(double) * 2 * ctx->d, (size_t)E,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MPFMT_OK;
+}
+
 static int32_t explicit_sweep(mpfmt_ctx* ctx, const double* P, const double* Q, int64_t n, uint64_t* mask)
 {
     if (!ctx) return MPFMT_ERR_ARG;

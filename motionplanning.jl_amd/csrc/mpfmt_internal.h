@@ -301,6 +301,8 @@ int32_t mpfmt_launch_mc_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64
                               uint64_t seed, unsigned long long* d_hits);
 int32_t mpfmt_launch_mc_is_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, double sigma, int64_t rollouts,
                                  uint64_t seed, unsigned long long* d_wsum);
+int32_t mpfmt_launch_mc_ais_edges(mpfmt_ctx* ctx, const int64_t* d_src1, const int64_t* d_dst1, int64_t E, double sigma, int64_t rollouts,
+                                  uint64_t seed, unsigned long long* d_wsum, double* d_mu);
 int32_t mpfmt_launch_graph_sweep(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr, int64_t mask_entries = -1);
 
 // kernels_di.hip ----------------------------------------------------------------------------------

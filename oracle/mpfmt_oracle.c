@@ -2052,6 +2052,101 @@ void orc_mc_is_edges(const double *X, int32_t d, const int64_t *src, const int64
     free(bd2); free(bt);
 }
 
+/* ---- ADAPTIVE importance sampling of the same probability (BASELINE configs[4]: "adaptive-importance-sampling") ----
+ * Two stages per edge, a cross-entropy update of the proposal's mean from a pilot:
+ *   pilot: ORC_AIS_NP = 4096 rollouts with the noise INFLATED by ALPHA = 1.625: rollout k, coordinate c < 2 d: Irwin-Hall integer S from
+ *     Philox(key = seed, counter = (k, e, 64 + c, 2)), Z = S - 262140, z = Z * ORC_MC_SCALE, y = ALPHA * z; v' = v + sigma y_v,
+ *     w' = w + sigma y_w; hit = !is_free_motion(v', w', CC, SS).  A hit's likelihood ratio against the nominal noise, up to the
+ *     factor ALPHA^(2 d) common to all rollouts:  lr = prod_c g(x(y_c)) / prod_c g(x(z_c))  (g, x as in orc_mc_is_edges; each factor
+ *     is <= 1), quantised Wq = (uint64)(lr * 2^30).  Integer sums over the hits: SW = sum Wq, A_c = sum Wq * Z_c.
+ *   shift (the mean of the nominal noise GIVEN a collision, in noise units):  mu_c = clip(ALPHA * ((double)A_c * ORC_MC_SCALE) /
+ *     (double)SW, -3, 3), 0 when the pilot saw no collision (the estimator is then plain Monte Carlo).
+ *   main: rollout k: z as in orc_mc_edges; shifted when Philox(key = seed, counter = (k, e, 2 d, 3)) word 0 is odd: y = z (+ mu);
+ *     weight = a / (0.5 a + 0.5 b), a = prod_c g(x(y_c)), b = prod_c g(x(y_c - mu_c)); wsum[e] = sum over colliding rollouts of
+ *     (uint64)(weight * 2^40); estimate = wsum / (rollouts * 2^40).  All sums are integers: any order gives the same result. */
+#define ORC_AIS_NP 4096
+#define ORC_AIS_ALPHA 1.625
+static int32_t mc_normal_int(uint64_t seed, uint32_t k, uint32_t e, uint32_t c)
+{
+    const uint32_t ctr[4] = {k, e, c, 2u}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t x[4];
+    orc_philox4x32_10(ctr, key, x);
+    uint32_t S = 0;
+    for (int i = 0; i < 4; ++i) S += (x[i] & 0xffffu) + (x[i] >> 16);
+    return (int32_t)S - 262140;
+}
+
+void orc_mc_ais_edges(const double *X, int32_t d, const int64_t *src, const int64_t *dst, int64_t E, double sigma, int64_t rollouts,
+                      uint64_t seed, const double *lohi, int32_t M, const double *ss_lo, const double *ss_hi, uint64_t *wsum, double *shifts)
+{
+    double v[ORC_MAXD], w[ORC_MAXD], y[2 * ORC_MAXD], mu[2 * ORC_MAXD];
+    int32_t Z[2 * ORC_MAXD];
+    for (int64_t e = 0; e < E; ++e) {
+        const double *v0 = X + (size_t)src[e] * d, *w0 = X + (size_t)dst[e] * d;
+        uint64_t SW = 0;
+        int64_t A[2 * ORC_MAXD];
+        for (int32_t c = 0; c < 2 * d; ++c) A[c] = 0;
+        for (int64_t k = 0; k < ORC_AIS_NP; ++k) {
+            double num = 1.0, den = 1.0;
+            for (int32_t c = 0; c < 2 * d; ++c) {
+                Z[c] = mc_normal_int(seed, (uint32_t)k, (uint32_t)e, (uint32_t)(64 + c));
+                const double z = (double)Z[c] * ORC_MC_SCALE;
+                y[c] = ORC_AIS_ALPHA * z;
+                const double xy = (y[c] * ORC_MC_INV + 262140.0) * (1.0 / 65536.0), xz = (z * ORC_MC_INV + 262140.0) * (1.0 / 65536.0);
+                num = num * ih8_pdf(xy); den = den * ih8_pdf(xz);
+            }
+            for (int32_t c = 0; c < d; ++c) {
+                const double pv = sigma * y[c], pw = sigma * y[d + c];
+                v[c] = v0[c] + pv; w[c] = w0[c] + pw;
+            }
+            if (orc_is_free_motion(v, w, d, lohi, M, ss_lo, ss_hi)) continue;
+            const double lr = (den > 0.0) ? num / den : 0.0;
+            const uint64_t Wq = (uint64_t)(lr * 1073741824.0);               /* 2^30 */
+            SW += Wq;
+            for (int32_t c = 0; c < 2 * d; ++c) A[c] += (int64_t)Wq * (int64_t)Z[c];
+        }
+        for (int32_t c = 0; c < 2 * d; ++c) {
+            double m = 0.0;
+            if (SW > 0) {
+                const double t = (double)A[c] * ORC_MC_SCALE;
+                m = ORC_AIS_ALPHA * t / (double)SW;
+                m = (m < -3.0) ? -3.0 : ((m > 3.0) ? 3.0 : m);
+            }
+            mu[c] = m;
+            if (shifts) shifts[(size_t)e * 2 * d + c] = m;
+        }
+        uint64_t acc = 0;
+        for (int64_t k = 0; k < rollouts; ++k) {
+            const uint32_t ctr[4] = {(uint32_t)k, (uint32_t)e, (uint32_t)(2 * d), 3u}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+            uint32_t xw[4];
+            orc_philox4x32_10(ctr, key, xw);
+            const int shifted = (int)(xw[0] & 1u);
+            for (int32_t c = 0; c < 2 * d; ++c) {
+                const double z = mc_normal(seed, (uint32_t)k, (uint32_t)e, (uint32_t)c);
+                y[c] = shifted ? z + mu[c] : z;
+            }
+            for (int32_t c = 0; c < d; ++c) {
+                const double pv = sigma * y[c], pw = sigma * y[d + c];
+                v[c] = v0[c] + pv; w[c] = w0[c] + pw;
+            }
+            if (orc_is_free_motion(v, w, d, lohi, M, ss_lo, ss_hi)) continue;
+            double a = 1.0, b = 1.0;
+            for (int32_t c = 0; c < 2 * d; ++c) {
+                const double xa = (y[c] * ORC_MC_INV + 262140.0) * (1.0 / 65536.0);
+                a = a * ih8_pdf(xa);
+                const double yb = y[c] - mu[c];
+                const double xb = (yb * ORC_MC_INV + 262140.0) * (1.0 / 65536.0);
+                b = b * ih8_pdf(xb);
+            }
+            const double ha = 0.5 * a, hb = 0.5 * b;
+            const double dn = ha + hb;
+            const double wgt = (dn > 0.0) ? a / dn : 0.0;
+            acc += (uint64_t)(wgt * 1099511627776.0);          /* 2^40 */
+        }
+        wsum[e] = acc;
+    }
+}
+
 /* ---- Reeds-Shepp space: chopped METRIC (ChoppedMetric, MetricNN): inball(v) = { w : |xy_v - xy_w| <= r, rs(v -> w) <= r } with
  * ds = rs(v -> w) (colwise(dist, V[v], V[inds]), nearneighbors.jl:185-198); forward and backward sets coincide (:200-203).
  * CSC: column v = inball(v).  Two-phase like orc_dubins_graph. */

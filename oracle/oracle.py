@@ -581,6 +581,18 @@ def mc_is_edges(X, src, dst, sigma, rollouts, seed, lohi, ss_lo=None, ss_hi=None
     return wsum[:len(src)]
 
 
+def mc_ais_edges(X, src, dst, sigma, rollouts, seed, lohi, ss_lo=None, ss_hi=None):
+    """ADAPTIVE importance sampling (pilot -> cross-entropy mean shift -> mixture): (wsum uint64 2^-40, shifts (E, 2 d) in noise units)."""
+    X, N, d = _X(X); lohi, M = _boxes(lohi, d)
+    src = np.ascontiguousarray(src, dtype=np.int64); dst = np.ascontiguousarray(dst, dtype=np.int64)
+    wsum = np.zeros(max(len(src), 1), dtype=np.uint64)
+    sh = np.zeros((max(len(src), 1), 2 * d))
+    lib().orc_mc_ais_edges(_d(X), C.c_int32(d), _i(src), _i(dst), C.c_int64(len(src)), C.c_double(sigma), C.c_int64(rollouts),
+                           C.c_uint64(seed), _d(lohi), C.c_int32(M), _d(_vec(ss_lo)), _d(_vec(ss_hi)),
+                           wsum.ctypes.data_as(C.POINTER(C.c_uint64)), _d(sh))
+    return wsum[:len(src)], sh[:len(src)]
+
+
 # ---- Reeds-Shepp car (SURVEY 8f N5, second half) ---------------------------------------------------------------------
 def reedsshepp(s1, s2, rt=1.0, sp=1.0):
     """(cost, controls[L][3] = (t, speed, curvature)) of simplecars.jl:265-363."""
