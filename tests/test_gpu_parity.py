@@ -955,7 +955,7 @@ def test_adaptive_importance_sampling_in_r6_among_200_boxes(ctx):
     w = mp.workloads.north_star(20000)
     ctx.upload_samples(w.X); ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
     colptr, rowval, _ = ctx.rdisc_graph(w.r * 1.6)
-    free = L.unpack_bits(ctx.graph_edges_free(), len(rowval))
+    free = mp._lib.unpack_bits(ctx.graph_edges_free(), len(rowval))
     cols = np.repeat(np.arange(1, w.N + 1), np.diff(colptr))
     rng = np.random.default_rng(6)
     pick = rng.choice(np.flatnonzero(free), 192, replace=False)
