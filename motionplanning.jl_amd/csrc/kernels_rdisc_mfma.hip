@@ -410,25 +410,42 @@ __global__ __launch_bounds__(256) void k_sample_masks(const double* __restrict__
         xl[i] = x - rm; xh[i] = x + rm;
         ulo[i] = tile_lo[tile * D + i] - rm; uhi[i] = tile_hi[tile * D + i] + rm;
     }
+    // the boxes that survive the tile's cull (lane = box) are staged in LDS, then every lane (= sample) walks them with broadcast reads
+    // (wave-uniform scalar loads were a chain of ~20 scalar-cache round trips per wavefront: 46 us for the 15 625 tiles)
+    __shared__ double s_bx[4][64][2 * D];
+    const int wv = threadIdx.x >> 6;
     unsigned long long mask = 0;
     for (int c = 0; c * 64 < M; ++c) {
         const int kbx = c * 64 + lane;
         int out = 0;
+        double bl[D], bh[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) { bl[i] = 0.0; bh[i] = 0.0; }
         if (kbx < M) {
             const double* bp = boxes + (int64_t)kbx * 2 * D;
 #pragma unroll
-            for (int i = 0; i < D; ++i) out |= (int)(bp[D + i] < ulo[i]) | (int)(bp[i] > uhi[i]);
+            for (int i = 0; i < D; ++i) { bl[i] = bp[i]; bh[i] = bp[D + i]; out |= (int)(bh[i] < ulo[i]) | (int)(bl[i] > uhi[i]); }
         }
-        unsigned long long mb = __ballot(kbx < M && !out);
-        while (mb) {
-            const int b = __ffsll((long long)mb) - 1;
-            mb &= mb - 1;
-            const mf_cptr bp = mf_const(boxes) + (int64_t)(c * 64 + b) * 2 * D;
+        const bool sv = kbx < M && !out;
+        const unsigned long long mb = __ballot(sv);
+        const int slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+        if (sv) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) { s_bx[wv][slot][i] = bl[i]; s_bx[wv][slot][D + i] = bh[i]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long rem = mb;
+        for (int k = 0; rem; ++k) {
+            const int b = __ffsll((long long)rem) - 1;
+            rem &= rem - 1;
             int o2 = 0;
 #pragma unroll
-            for (int i = 0; i < D; ++i) o2 |= (int)(bp[D + i] < xl[i]) | (int)(bp[i] > xh[i]);
+            for (int i = 0; i < D; ++i) o2 |= (int)(s_bx[wv][k][D + i] < xl[i]) | (int)(s_bx[wv][k][i] > xh[i]);
             if (!o2) mask |= 1ull << b;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     smask[tile * 64 + lane] = mask;                           // (pad samples: NaN coordinates, every comparison false -- every surviving bit set; never read for a hit)
 }
