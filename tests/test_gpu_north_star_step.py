@@ -131,3 +131,41 @@ def test_upload_samples_device_equals_host_upload(orc):
         t = torch.from_numpy(X).to("cuda:0"); torch.cuda.synchronize()
         with pytest.raises(mp.MPFMTError):
             c.upload_samples_device(t.data_ptr(), N, d)
+
+
+def test_four_million_samples_step(orc):
+    """Four times the north star (N = 4e6 in R^6, r from the fmt.jl:39 rule, 5.0e8 directed edges, 6 GB of CSC): the timed step's form on a
+    cold ctx, sampled columns of the resident graph against the oracle's KD-tree, sampled free bits against the oracle's edge predicate
+    (only the sampled slices cross PCIe)."""
+    import torch
+    from motionplanning_jl_amd.distributed import DevArray
+    w = mp.workloads.north_star(4_000_000)
+    N = w.N
+    rng = np.random.default_rng(77)
+    with mp.Context(0) as c:
+        c.set_option("rebuild_index", 1)
+        c.upload_samples(w.X); c.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+        nnz = c.graph_step_device(w.r)
+        assert (c.stat("rdisc_path_used"), c.stat("rdisc_half_used"), c.stat("sweep_form")) == (2, 1, 2)
+        assert c.stat("redo_count") == 0
+        assert 4.5e8 < nnz < 5.5e8 and nnz % 2 == 0
+        cp, rv, nz, fr = c.graph_device_ptrs()
+        torch.cuda.synchronize()
+        colptr = torch.as_tensor(DevArray(cp, N + 1, "<i8"), device="cuda:0").cpu().numpy()
+        assert colptr[0] == 0 and colptr[-1] == nnz and np.all(np.diff(colptr) >= 0)
+        rowval_d = torch.as_tensor(DevArray(rv, nnz, "<i4"), device="cuda:0")
+        nzval_d = torch.as_tensor(DevArray(nz, nnz, "<f8"), device="cuda:0")
+        free_d = torch.as_tensor(DevArray(fr, (nnz + 63) // 64, "<i8"), device="cuda:0")
+        kd = orc.KDTree(w.X)
+        for v in rng.integers(0, N, size=250):
+            oi, od = kd.inball(int(v), w.r)
+            a, b = int(colptr[v]), int(colptr[v + 1])
+            rows = rowval_d[a:b].cpu().numpy()
+            assert np.array_equal(rows, oi), v
+            assert np.array_equal(nzval_d[a:b].cpu().numpy(), od), v
+            want = orc.unpack(orc.edges_free(w.X, oi, np.full(len(oi), v), w.lohi, w.ss_lo, w.ss_hi), len(oi))
+            words = free_d[a // 64:(b + 63) // 64 + 1].cpu().numpy().view(np.uint64)
+            bits = L.unpack_bits(words, len(words) * 64)[a - (a // 64) * 64:][:b - a]
+            assert np.array_equal(bits, want), v
+        # a second step on the first one's sizes (speculative): same graph size, same form, nothing redone
+        assert c.graph_step_device(w.r) == nnz and c.stat("redo_count") == 0 and c.stat("sweep_form") == 2
