@@ -180,7 +180,8 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
                                                     const float* __restrict__ tile_sub32, mpfmt_grid G, double rpad,
                                                     int64_t tile_begin, int64_t nt, int64_t list_cap,
                                                     uint32_t* __restrict__ lists, int32_t* __restrict__ list_len,
-                                                    int32_t* __restrict__ max_len, int half, const uint32_t* __restrict__ cellkey, int fb)
+                                                    int32_t* __restrict__ max_len, int half, const uint32_t* __restrict__ cellkey, int fb,
+                                                    uint32_t* __restrict__ gstage)
 {
     __shared__ int32_t s_sega_[NW][64];                   // first chunk of each row's run
     __shared__ int32_t s_segp_[NW][64];                   // exclusive prefix of the runs' chunk counts
@@ -223,7 +224,8 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
     for (int i = 0; i < L; ++i) rows *= (uint32_t)(chi[i] - clo[i] + 1);
 
     uint32_t* __restrict__ out = lists + tl * list_cap;
-    uint32_t* const stage = (NW > 1) ? s_stage + (int64_t)wave * list_cap : nullptr;
+    // (NW > 1: the wavefront's kept ids are staged in LDS -- or, when the lists are too long for it, in a global scratch area)
+    uint32_t* const stage = (NW > 1) ? (gstage ? gstage + ((int64_t)blockIdx.x * NW + wave) * list_cap : s_stage + (int64_t)wave * list_cap) : nullptr;
     int32_t gcount = 0;              // unique surviving chunks so far (uniform)
     int64_t carry = -1;              // last chunk id of the previous flattened batch (dedupe)
     int64_t firstkept = -1, lastkept = -1;
@@ -1110,12 +1112,16 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
         if ((rc = mpfmt_ensure(ctx, (void**)&ctx->lists, sizeof(uint32_t) * (size_t)cap * (size_t)nt))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->list_len + nt, 0, sizeof(int32_t), ctx->stream));
         const mpfmt_grid& G = ctx->grid;
-        // few tiles (a small shard): four wavefronts per tile, kept ids staged in LDS (4 x cap x 4 bytes)
-        const bool wide = nt < 16 * (int64_t)ctx->num_cus && cap <= 3072;
-#define CASE(DD) case DD: if (wide) hipLaunchKernelGGL((k_chunk_lists<DD, 4>), dim3((unsigned)nt), dim3(256), (size_t)cap * 16, ctx->stream, ctx->cellstart, \
-            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt, half ? 1 : 0, ctx->cellkey, ctx->cell_fb); \
+        // few tiles (a small shard): four wavefronts per tile, kept ids staged in LDS (4 x cap x 4 bytes) -- in a global scratch area when
+        // the lists are longer than LDS takes at a useful occupancy (a shard's lists hold every chunk of the OTHER shards: ~4 500 entries)
+        const bool wide = nt < 16 * (int64_t)ctx->num_cus;
+        const bool gst = wide && cap > 3072;
+        if (gst && (rc = mpfmt_ensure(ctx, (void**)&ctx->lists_stage, sizeof(uint32_t) * (size_t)cap * 4 * (size_t)nt))) return rc;
+        uint32_t* const gstage = gst ? (uint32_t*)ctx->lists_stage : nullptr;
+#define CASE(DD) case DD: if (wide) hipLaunchKernelGGL((k_chunk_lists<DD, 4>), dim3((unsigned)nt), dim3(256), gst ? (size_t)0 : (size_t)cap * 16, ctx->stream, ctx->cellstart, \
+            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt, half ? 1 : 0, ctx->cellkey, ctx->cell_fb, gstage); \
         else hipLaunchKernelGGL((k_chunk_lists<DD, 1>), dim3((unsigned)nt), dim3(64), 0, ctx->stream, ctx->cellstart, \
-            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt, half ? 1 : 0, ctx->cellkey, ctx->cell_fb); break;
+            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt, half ? 1 : 0, ctx->cellkey, ctx->cell_fb, (uint32_t*)nullptr); break;
         switch (ctx->d) {
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
             default: return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path supports d <= 12 (got %d)", ctx->d);

@@ -124,6 +124,7 @@ struct mpfmt_ctx {
     float mf_negT = 0.f;
     void* lists = nullptr;               // [shard tiles][list_cap] candidate chunk ids per tile
     int32_t* list_len = nullptr;         // [shard tiles + 1] lengths, last = max
+    void* lists_stage = nullptr;         // small shards with long lists: [tiles][4][list_cap] staging of the 4-wavefront list kernel
     int64_t list_cap = 0;
     double lists_r = -1.0; int64_t lists_begin = -1, lists_end = -1;
     // single-pass hit pool (MFMA path): hits found by the count pass are kept, so the fill pass is a scatter
