@@ -762,6 +762,9 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         if (hint_match && ctx->pool_hint_qmax > 0) {
             const double qm = (double)ctx->pool_hint_qmax;
             qwant = qm * 1.12 + 96.0 * std::sqrt(std::max(qm / 16.0, 1.0)) + 64.0;
+            // (logs that held the last build with a tenth to spare are kept as they are: growing them by a few per cent means freeing
+            // and allocating gigabytes, which the allocator sometimes answers in 100+ ms)
+            if (ctx->pool_slack == 1 && (double)ctx->qcap >= qm * 1.10 + 64.0 && (double)ctx->qcap <= qwant) qwant = (double)ctx->qcap;
             nnz_est = (double)ctx->pool_hint_nnz;
         } else {
             double vol = 1.0;
