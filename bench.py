@@ -363,6 +363,7 @@ def main():
     nnz = nnz_sum / max(args.steps, 1)               # this rank's mean entries per step: what the per-kernel averages below belong to
     stats = ctx.graph_stats()
     path_used = ctx.stat("rdisc_path_used")
+    launch_stats = {k: ctx.stat(k) for k in ("ord_per_cu", "qcap", "list_max", "redo_count", "redo_reason")}
     survivors = ctx.stat("survivors")
     single_pass = ctx.stat("pool_used") == 1
     tm = {k: ctx.timing(k) for k in ("grid", "rdisc_count", "pair_kernel", "exact_pairs", "rdisc_fill", "rdisc_sort", "order_sweep", "sweep_graph", "sweep_kernel")}
@@ -428,8 +429,7 @@ def main():
                                 "overlapped with the next step's index build" + (" [RCCL stand-in: %s]" % os.environ["MPFMT_RCCL_LIB"] if os.environ.get("MPFMT_RCCL_LIB") else "")
                                 if rccl_abi else "gloo (one-device functional check)"),
                    "step": "index build (cell grid, sorted copies, MFMA operands, chunk lists) + r-disc graph of all N samples as an ordered CSC "
-                           "+ collision sweep of all nnz directed edges; the one thing not redone per step is the all-samples-in-state-space "
-                           "flag (k_all_in_ss, 25 us, once per upload)" +
+                           "+ collision sweep of all nnz directed edges (nothing is kept from one step to the next but the buffers and their sizes)" +
                            ("; half build: every pair of samples is tested once by the pair kernel, which writes the hit records of both columns" if half_build else "") +
                            ("; edge tests fused: the broad phase of a pair's segment runs in the pair kernel's drain (once for both directions), "
                             "the flagged pairs' slab tests in k_exact_pairs, the mask is written by the ordering pass -- no separate sweep kernel" if edge_form == 2 else "")},
@@ -453,6 +453,8 @@ def main():
             "filter_survivors_per_pass": survivors,
             "grid_cells": stats["cells"], "tiles": stats["tiles"], "slices": stats["slices"],
             "lib_version": lib_version,
+            # ordering-pass workgroups per CU (3 by their LDS), records a quarter log holds, longest chunk list, builds redone in the run (and why)
+            "launch": launch_stats,
         }
     }
     # Three roofline objects, one per kernel of the step; `roofline` is the one of the DOMINANT kernel = the largest average launch
