@@ -716,12 +716,24 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                 double l[D], h[D];
                 seg_bbox<D>(cv, qv, l, h);
                 for (int k = 0; k < a.M; ++k) {
-                    box_regs<D> bx;
                     const mf_cptr bp = mf_const(a.boxes) + (int64_t)k * 2 * D;
+                    if constexpr (D > 6) {
+                        // the axes six at a time; the rest of the box is fetched only where a lane's segment box meets it so far
+                        const unsigned long long pend = sweep_cmpx_groups<D>(__ballot(fr), bp, l, h);
+                        if (pend) {
+                            box_regs<D> bx;
 #pragma unroll
-                    for (int i = 0; i < D; ++i) { bx.lo[i] = bp[i]; bx.hi[i] = bp[D + i]; }
-                    const bool meet = fr && !broadphase_free_sl<D>(l, h, bx);
-                    if (__ballot(meet)) { const bool f = narrow_free_sl<D>(cv, qv, bx); if (meet) fr = f; }
+                            for (int i = 0; i < D; ++i) { bx.lo[i] = bp[i]; bx.hi[i] = bp[D + i]; }
+                            const bool f = narrow_free_sl<D>(cv, qv, bx);
+                            if ((pend >> lane) & 1ull) fr = f;
+                        }
+                    } else {
+                        box_regs<D> bx;
+#pragma unroll
+                        for (int i = 0; i < D; ++i) { bx.lo[i] = bp[i]; bx.hi[i] = bp[D + i]; }
+                        const bool meet = fr && !broadphase_free_sl<D>(l, h, bx);
+                        if (__ballot(meet)) { const bool f = narrow_free_sl<D>(cv, qv, bx); if (meet) fr = f; }
+                    }
                 }
                 if (fr) atomicAdd(&s_nfree[ql], 1);
             }

@@ -35,6 +35,13 @@
 
 #include "sweep_predicates.h"
 #include "sweep_cmpx.h"
+// a global pointer read through the constant address space: a wave-uniform address then always takes the scalar cache
+// (s_load into SGPRs, usable directly as the scalar operand of a vector compare) -- no alias analysis involved
+typedef const __attribute__((address_space(4))) double* sweep_cptr;
+__device__ __forceinline__ sweep_cptr as_const(const double* p) { return (sweep_cptr)(uintptr_t)p; }
+#ifndef SWEEP_GROUPS             // A/B: 0 = the d > 6 broad phase as one run of 2 d compares (round 3)
+#define SWEEP_GROUPS 1
+#endif
 
 // Wave-level cull of nb (<= SWEEP_CHUNK) staged boxes against the union box [ulo, uhi] of the
 // wavefront's segments.  Survivor words stay in (wave-uniform) registers.
@@ -479,8 +486,13 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
                     while (m) {
                         const int k = c * 64 + (__ffsll((long long)m) - 1);
                         m &= m - 1;
-                        const box_regs<D> bx = load_box_T<D>(sboxT, k);           // wave-uniform k: broadcast reads
-                        const bool pend = fr & !broadphase_free_sl<D>(l, h, bx);
+                        bool pend;
+                        if constexpr (D > 8 && SWEEP_GROUPS) {
+                            // the axes six at a time, the box through the scalar cache (sweep_cmpx.h): in R^12 few (segment, box) pairs
+                            // are left after six axes, and then neither the other bounds are fetched nor their comparisons run
+                            const unsigned long long pm = sweep_cmpx_groups<D>(__ballot(fr), as_const(boxes) + (int64_t)(b0 + k) * 2 * D, l, h);
+                            pend = (pm >> lane) & 1ull;
+                        } else pend = fr & !broadphase_free_sl<D>(l, h, load_box_T<D>(sboxT, k));      // wave-uniform k: broadcast reads
                         const bool third = pend & (p1 >= 0);
                         p1 = (pend & (p0 >= 0) & (p1 < 0)) ? k : p1;
                         p0 = (pend & (p0 < 0)) ? k : p0;
@@ -491,9 +503,9 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
                             // exact test for one or two lanes) only when the queue is that full
                             if constexpr (D <= 8) {
                                 if (qcount + (int)__popcll(m3) + 64 <= SWEEP_QCAP) push(third, v, eoff, ((uint32_t)R0.c << 16) | (uint32_t)k);
-                                else if (third) fr = narrow_free_sl<D>(v, w, bx);
+                                else if (third) fr = narrow_free_sl<D>(v, w, load_box_T<D>(sboxT, k));
                             } else {
-                                if (third) fr = narrow_free_sl<D>(v, w, bx);
+                                if (third) fr = narrow_free_sl<D>(v, w, load_box_T<D>(sboxT, k));
                             }
                         }
                     }
@@ -559,10 +571,6 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
 //     22 + 34 and an LDS broadcast read of the box;
 //   * exact tests never run in place on the fast path (a lane or two used to occupy the whole wave for ~270 VALU).
 // 420 instructions per round (270 VALU) in rounds of one column; with packed rounds the same total in 20 % fewer rounds.
-// a global pointer read through the constant address space: a wave-uniform address then always takes the scalar cache
-// (s_load into SGPRs, usable directly as the scalar operand of a vector compare) -- no alias analysis involved
-typedef const __attribute__((address_space(4))) double* sweep_cptr;
-__device__ __forceinline__ sweep_cptr as_const(const double* p) { return (sweep_cptr)(uintptr_t)p; }
 
 // One table entry per QUARTER (16 lanes) of a round: column, number of its entries in this quarter (0..16), their first entry.
 // Columns are laid end to end in visiting order, each rounded up to whole quarters, so a round of 64 lanes holds up to four
@@ -849,6 +857,7 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
             // no branch in the loop but its own; lanes that are out (not active / not in the state space) fail the first comparison
             unsigned pk = 0, pc = 0;
             if constexpr (D <= 6) l[0] = fr ? l[0] : (double)INFINITY;
+            [[maybe_unused]] const unsigned long long frm = __ballot(fr);
 #pragma unroll
             for (int c = 0; c < SWEEP_WORDS; ++c) {
                 unsigned long long m = smask[c];
@@ -860,16 +869,17 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
                     m &= m - 1;
                     // wave-uniform kb: the box comes through the scalar cache into SGPRs (the comparisons take it as their scalar
                     // operand); an LDS broadcast read would return 64 copies through the LDS data path
-                    box_regs<D> bx;
-                    {
-                        const sweep_cptr bp = as_const(boxes) + (int64_t)kb * 2 * D;
+                    const sweep_cptr bp = as_const(boxes) + (int64_t)kb * 2 * D;
+                    if constexpr (D <= 6 || !SWEEP_GROUPS) {
+                        box_regs<D> bx;
 #pragma unroll
                         for (int i = 0; i < D; ++i) { bx.lo[i] = bp[i]; bx.hi[i] = bp[D + i]; }
-                    }
-                    if constexpr (D <= 6) {
-                        sweep_cmpx<D>::note(bx.lo, bx.hi, l, h, pk, pc, kb);
+                        if constexpr (D <= 6) sweep_cmpx<D>::note(bx.lo, bx.hi, l, h, pk, pc, kb);
+                        else if (fr & !broadphase_free_sl<D>(l, h, bx)) { pk = (pk << 8) | (unsigned)kb; pc += 1; }
                     } else {
-                        if (fr & !broadphase_free_sl<D>(l, h, bx)) { pk = (pk << 8) | (unsigned)kb; pc += 1; }
+                        // d > 6: the axes six at a time, the later bounds fetched only while a lane is left (sweep_cmpx.h)
+                        const unsigned long long pend = sweep_cmpx_groups<D>(frm, bp, l, h);
+                        if ((pend >> lane) & 1ull) { pk = (pk << 8) | (unsigned)kb; pc += 1; }
                     }
                 }
             }
