@@ -712,11 +712,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     ctx->rdisc_path_used = mf ? 2 : 1;
     ctx->mf_negT = negT;
 
-    int S = 1;
-    const int64_t units = nt;                                   // work items before slicing (one wavefront each)
-    // (the K = 16 form, d > 6, prefers more and shorter items: cfg3 55.0 vs 57.4 ms at 5 vs 3 slices)
-    const int64_t target = mf ? (ctx->d <= 6 ? ctx->mf_target_items : ctx->mf_target_items * 7 / 4) : 32768;
-    if (units > 0) S = (int)std::min<int64_t>(MPFMT_MAXS, std::max<int64_t>(1, (target + units - 1) / units));
+    const int S = mpfmt_slices_for(ctx, nt, mf);                // work items = tiles x slices (one wavefront each)
     if (!mf) half = false;
     ctx->S = S;
     const int64_t npad = ctx->ntiles * 64;

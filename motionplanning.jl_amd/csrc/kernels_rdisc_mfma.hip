@@ -522,7 +522,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     }
     if (item >= a.nitems) return;
     const int64_t tile = a.blk_begin + item / a.S;
-    const int slice = (int)(item % a.S);
+    const int slice = (int)(item % a.S);                    // (S is odd: mpfmt_slices_for)
     const int64_t qpos = tile * 64 + lane;
     const int kb = lane >> 5, col = lane & 31;
 
@@ -1062,6 +1062,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
+// Slices per tile (work items = tiles x slices, one wavefront each).  The count is ODD: slice 0 of a tile holds the tile's own chunk --
+// the block with by far the most hits, ~1.7x the drain work of the other slices -- and single-wavefront workgroups go to the SIMDs of a
+// CU in turn, so with an even count the heavy items pile up on the same SIMDs (S = 4, 8: every heavy item on one SIMD in four -- pair
+// kernel 2.8-2.9 ms at the north star against 2.02 at S = 3; S = 2, 6: on two -- 2.2-2.3 ms).  With an odd count the heavy items sit
+// S apart and visit every residue modulo a power of two equally.  (tools/opt_sweep.sh mf_target_items; LABNOTES round 4.)
+int mpfmt_slices_for(const mpfmt_ctx* ctx, int64_t units, bool mfma)
+{
+    if (units <= 0) return 1;
+    // (the K = 16 form, d > 6, prefers more and shorter items: cfg3 55.0 vs 57.4 ms at 5 vs 3 slices)
+    const int64_t target = mfma ? (ctx->d <= 6 ? ctx->mf_target_items : ctx->mf_target_items * 7 / 4) : 32768;
+    int S = (int)std::min<int64_t>(MPFMT_MAXS, std::max<int64_t>(1, (target + units - 1) / units));
+    if (mfma && S > 1 && (S & 1) == 0) S = (S + 1 <= MPFMT_MAXS) ? S + 1 : S - 1;
+    return S;
+}
 int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usable)
 {
     // normalisation: one common scale so that every coordinate lies in [0,1]
@@ -1343,8 +1357,7 @@ int32_t mpfmt_rdisc_stream_impl(mpfmt_ctx* ctx, double r, const double* C_host, 
     bool ok = true;
     if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok, false, false))) return rc;
     if (!ok) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "chunk lists exceed 32 GB");
-    const int64_t target = ctx->d <= 6 ? ctx->mf_target_items : ctx->mf_target_items * 7 / 4;
-    const int S = nt > 0 ? (int)std::min<int64_t>(MPFMT_MAXS, std::max<int64_t>(1, (target + nt - 1) / nt)) : 1;
+    const int S = mpfmt_slices_for(ctx, nt, true);
     ctx->S = S;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->slice_cnt, sizeof(int32_t) * (size_t)S * std::max<int64_t>(npad, 1)))) return rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->st_best, sizeof(uint64_t) * (size_t)S * std::max<int64_t>(npad, 1)))) return rc;

@@ -101,7 +101,7 @@ struct mpfmt_ctx {
     double ops_r = -1.0;                 // grid radius the operands were built for
     int32_t rdisc_path = 0;              // 0 auto, 1 exact fp64 VALU kernel, 2 MFMA filter + exact refine
     int32_t rdisc_path_used = 0;
-    int32_t mf_xcd_mode = 512;
+    int32_t mf_xcd_mode = 64;            // work items go to the XCDs in interleaved groups of this many (tools/xcd_sweep.sh: 64 2.02 ms, 512 2.05, one contiguous range per XCD 2.41)
     int32_t mf_ablate = 0;               // timing experiments only
     int32_t num_cus = 256;               // compute units of the device (persistent-grid sizing)
     int ord_per_cu = 0;          // k_order_logs: resident workgroups per CU on THIS ctx's device
@@ -282,6 +282,7 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr, int
 int32_t mpfmt_sweep_prepare_ss(mpfmt_ctx* ctx);          // kernels_sweep.hip: device copy of the state-space bounds + the all-samples-inside flag
 #define MPFMT_ORD_MAXDEG 2048        // longest column the log-ordering kernel stages in LDS (ORD_STG in kernels_order.hip)
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false, bool half = false);
+int mpfmt_slices_for(const mpfmt_ctx* ctx, int64_t units, bool mfma);      // slices per tile of the pair kernels (odd: kernels_rdisc_mfma.hip)
 int32_t mpfmt_launch_log_degrees(mpfmt_ctx* ctx);
 int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_rdisc_stream_impl(mpfmt_ctx* ctx, double r, const double* C_host, const uint64_t* H_host, int32_t want_free,
