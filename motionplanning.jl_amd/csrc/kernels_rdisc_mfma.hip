@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
 template <int D>
 __global__ __launch_bounds__(256) void k_sample_masks(const double* __restrict__ Xs, const double* __restrict__ tile_lo, const double* __restrict__ tile_hi,
                                                       int64_t tile_begin, int64_t nt, double rpad, const double* __restrict__ boxes, int M,
-                                                      unsigned long long* __restrict__ smask)
+                                                      unsigned long long* __restrict__ smask, unsigned long long* __restrict__ tile_bs)
 {
     const int lane = threadIdx.x & 63;
     const int64_t tl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -430,6 +430,7 @@ __global__ __launch_bounds__(256) void k_sample_masks(const double* __restrict__
         }
         const bool sv = kbx < M && !out;
         const unsigned long long mb = __ballot(sv);
+        if (lane == 0) tile_bs[tile * 4 + c] = mb;            // the tile's surviving boxes: what the pair kernel's items of this tile walk
         const int slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
         if (sv) {
 #pragma unroll
@@ -449,6 +450,7 @@ __global__ __launch_bounds__(256) void k_sample_masks(const double* __restrict__
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    if (lane < 4 && lane * 64 >= M) tile_bs[tile * 4 + lane] = 0ull;
     smask[tile * 64 + lane] = mask;                           // (pad samples: NaN coordinates, every comparison false -- every surviving bit set; never read for a hit)
 }
 
@@ -457,11 +459,12 @@ int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r)
     // (every tile, not the shard's own: a shard's candidates come from all of them)
     const int64_t nt = ctx->ntiles;
     int32_t rc;
-    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->smask, sizeof(unsigned long long) * (size_t)std::max<int64_t>(ctx->ntiles * 64, 1)))) return rc;
+    // (per-sample masks [npad], then the four survivor words of every tile)
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->smask, sizeof(unsigned long long) * (size_t)std::max<int64_t>(ctx->ntiles * 68, 1)))) return rc;
     if (nt <= 0 || ctx->tile_end <= ctx->tile_begin) return MPFMT_OK;
     const double rpad = r * (1.0 + 1e-9) + 1e-300;
 #define CASE(DD) case DD: hipLaunchKernelGGL((k_sample_masks<DD>), dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, ctx->stream, ctx->Xs, ctx->tile_lo, ctx->tile_hi, \
-        (int64_t)0, nt, rpad, ctx->boxes, ctx->M, (unsigned long long*)ctx->smask); break;
+        (int64_t)0, nt, rpad, ctx->boxes, ctx->M, (unsigned long long*)ctx->smask, (unsigned long long*)ctx->smask + ctx->ntiles * 64); break;
     switch (ctx->d) { CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) default: break; }
 #undef CASE
     HIPCHK(ctx, hipGetLastError());
@@ -532,22 +535,11 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     unsigned long long bsurv[4] = {0ull, 0ull, 0ull, 0ull};
     if constexpr (MODE == 2 && D <= 6) {
         if (a.fb) {
-            double ulo[D], uhi[D];
+            // (culled once per tile by k_sample_masks -- with its slightly wider margin, a superset of the boxes within rpad of the hull;
+            // the comparisons of the drain decide -- instead of once per item here: 4 x 12 loads and 24 comparisons per lane)
+            const unsigned long long* tb = a.smask + a.npad + tile * 4;
 #pragma unroll
-            for (int i = 0; i < D; ++i) { ulo[i] = a.tile_lo[tile * D + i] - a.rpad; uhi[i] = a.tile_hi[tile * D + i] + a.rpad; }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c * 64 < a.M) {
-                    const int kbx = c * 64 + lane;
-                    int out = 0;
-                    if (kbx < a.M) {
-                        const double* bp = a.boxes + (int64_t)kbx * 2 * D;
-#pragma unroll
-                        for (int i = 0; i < D; ++i) out |= (int)(bp[D + i] < ulo[i]) | (int)(bp[i] > uhi[i]);
-                    }
-                    bsurv[c] = __ballot(kbx < a.M && !out);
-                }
-            }
+            for (int c = 0; c < 4; ++c) bsurv[c] = tb[c];
         }
     }
 

@@ -1082,12 +1082,21 @@ __global__ __launch_bounds__(256, 4) void k_exact_pairs(const uint4* __restrict_
         // region blockIdx.x of the list, this workgroup's wavefronts taking every (4 gridDim.y)-th block of 64 pairs
         const int64_t it = blockIdx.x;
         const int n = (int)min((long long)pcnt[it], icap);
-        for (int b0 = ((int)blockIdx.y * 4 + wave) * 64; b0 < n; b0 += (int)gridDim.y * 4 * 64) {
+        const int bstep = (int)gridDim.y * 4 * 64;
+        const int bfirst = ((int)blockIdx.y * 4 + wave) * 64;
+        // (the next block's items are requested while this block's states are on their way: one dependent round trip per block, not two)
+        uint4 inext = make_uint4(0u, 0u, 0u, 0u);
+        if (bfirst < n) inext = pitems[it * icap + min(bfirst + lane, n - 1)];
+        // (and a block's marks go out after the NEXT block's states are requested: the atomics' round trip runs beside the gather's instead
+        // of in front of it -- the wait before the first use of a state is a wait for everything outstanding)
+        long long mark0 = -1, mark1 = -1;
+        for (int b0 = bfirst; b0 < n; b0 += bstep) {
             // lane = (pair, box) unit: the pair kernel writes one item per box a pair's segment box met (bit 8 of the box word: it met more
             // than four -- every box is tried).  (Items per PAIR with up to four boxes, their units laid end to end here by a scan and a
             // search among the lanes, cost 15 dependent lane exchanges per 64 units.)
             const bool on = b0 + lane < n;
-            const uint4 i0 = pitems[it * icap + min(b0 + lane, n - 1)];
+            const uint4 i0 = inext;
+            if (b0 + bstep < n) inext = pitems[it * icap + min(b0 + bstep + lane, n - 1)];
             const uint32_t qs = i0.x & 0x03ffffffu, jg = i0.y & 0x03ffffffu;
             const uint32_t kbw = (i0.x >> 26) | ((i0.y >> 26) << 6);
             const int kb = (int)(kbw & 255u);
@@ -1097,6 +1106,9 @@ __global__ __launch_bounds__(256, 4) void k_exact_pairs(const uint4* __restrict_
             for (int i = 0; i < D; ++i) q[i] = Xs[(int64_t)qs * D + i];
 #pragma unroll
             for (int i = 0; i < D; ++i) c[i] = Xs[(int64_t)jg * D + i];
+            // (a key has several writers -- one unit per box the pair met: the mark is an OR, with no return value)
+            if (mark0 >= 0) atomicOr(&qkey[mark0], 0x80000000u);
+            if (mark1 >= 0) atomicOr(&qkey[mark1], 0x80000000u);
             bool fwd = true, rev = true;                      // own entry: is_free_motion(c, q); foreign entry: is_free_motion(q, c)
             {
                 const box_regs<D> bx = load_box_T<D>(sboxT, (on && !all) ? kb : 0);
@@ -1127,10 +1139,11 @@ __global__ __launch_bounds__(256, 4) void k_exact_pairs(const uint4* __restrict_
                     }
                 }
             }
-            // (a key has several writers now -- one unit per box the pair met: the mark is an OR, with no return value)
-            if (on && !fwd) atomicOr(&qkey[((long long)(qs >> 4) - qbase) * qcap + (long long)i0.z], 0x80000000u);
-            if (on && !rev && i0.w != 0xffffffffu) atomicOr(&qkey[((long long)(jg >> 4) - qbase) * qcap + (long long)i0.w], 0x80000000u);
+            mark0 = (on && !fwd) ? ((long long)(qs >> 4) - qbase) * qcap + (long long)i0.z : -1ll;
+            mark1 = (on && !rev && i0.w != 0xffffffffu) ? ((long long)(jg >> 4) - qbase) * qcap + (long long)i0.w : -1ll;
         }
+        if (mark0 >= 0) atomicOr(&qkey[mark0], 0x80000000u);
+        if (mark1 >= 0) atomicOr(&qkey[mark1], 0x80000000u);
     }
 }
 
