@@ -543,6 +543,26 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         }
     }
 
+    // half build, the tile's own chunk: the 64 x 64 block holds every pair of the tile's samples twice.  Only the sign bits of (query ql,
+    // candidate cj) with cj > ql are kept -- the pair is refined, its segment's box tested and its item written once, and the record of
+    // the other column goes to the tile's own logs like any other "same pair from the other end".  Bit 16 t + 15 - r of a lane's word
+    // is query (t & 1) 32 + g(r) + 4 (lane >> 5), g(r) = (r & 3) + 8 (r >> 2) increasing in r, candidate (t >> 1) 32 + (lane & 31): per
+    // 16-bit group the kept r are those below a count.
+    [[maybe_unused]] unsigned long long own_keep = ~0ull;
+    if constexpr (MODE == 2) {
+        if (a.half) {
+            own_keep = 0ull;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int A = (t >> 1) * 32 + (lane & 31) - (t & 1) * 32 - 4 * (lane >> 5);      // keep g(r) < A
+                const int Ac = min(max(A, 0), 32);
+                const int R = min(16, 4 * (Ac >> 3) + min(Ac & 7, 4));                              // number of r with g(r) < A
+                const unsigned long long m16 = R ? ((0xFFFFull << (16 - R)) & 0xFFFFull) : 0ull;
+                own_keep |= m16 << (16 * t);
+            }
+        }
+    }
+
     // ---- setup: fp64 query coordinates to LDS, A fragments to VGPRs, counters --------------------------------
 #pragma unroll
     for (int i = 0; i < D; ++i) s_q[lane * D + i] = a.Xs[qpos * D + i];
@@ -785,7 +805,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             // of a drain fall into a handful of such logs (its survivors come from two or three chunks): the lanes of each are found with
             // one ballot per log, the first of them reserves the places of all
             const int64_t fc = (int64_t)(jg >> 6) - a.blk_begin;        // the candidate's tile, counted from the shard's first
-            const bool fh = a.half && hit && (int64_t)(jg >> 6) != tile && fc >= 0 && fc < a.ntiles_shard;
+            const bool fh = a.half && hit && fc >= 0 && fc < a.ntiles_shard;      // (the tile's own chunk too: its pairs are kept once, own_keep)
             const int fq = (int)(fc * 4 + (int64_t)((jg & 63u) >> 4));
             int leader = lane, pre = 0, cnt_l = 0;
             {
@@ -969,7 +989,8 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             h2 = __builtin_amdgcn_alignbit(h2, __float_as_uint(acc2[r]), 31);
             h3 = __builtin_amdgcn_alignbit(h3, __float_as_uint(acc3[r]), 31);
         }
-        const unsigned long long H = (unsigned long long)(h0 | (h1 << 16)) | ((unsigned long long)(h2 | (h3 << 16)) << 32);
+        unsigned long long H = (unsigned long long)(h0 | (h1 << 16)) | ((unsigned long long)(h2 | (h3 << 16)) << 32);
+        if constexpr (MODE == 2) { if (c == (uint32_t)tile) H &= own_keep; }
         if (MF_ABLATE & 1) { asm volatile("" :: "v"(H)); return; }
         const unsigned long long m = __ballot(H != 0);
         if (m) {
@@ -1254,9 +1275,10 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.tile_lo = ctx->tile_lo; a.tile_hi = ctx->tile_hi;
     a.r2 = r * r; a.rpad = r * (1.0 + 1e-9) + 1e-300; a.negT = negT;
     a.S = ctx->S;
-    a.xcd_mode = ctx->mf_xcd_mode;
     a.blk_begin = ctx->tile_begin;                             // first tile of the shard
     a.nitems = (ctx->tile_end - ctx->tile_begin) * ctx->S;
+    // (small groups spread a small launch evenly; large ones keep neighbouring tiles -- which read the same candidate chunks -- on one L2)
+    a.xcd_mode = ctx->mf_xcd_mode >= 0 ? ctx->mf_xcd_mode : (a.nitems >= 32768 ? 256 : 64);
     a.npad = ctx->ntiles * 64; a.ntiles = ctx->ntiles;
     a.slice_cnt = ctx->slice_cnt; a.tptr = ctx->tptr; a.rowtmp = ctx->rowtmp; a.valtmp = ctx->valtmp;
     a.lists = (const uint32_t*)ctx->lists; a.list_len = ctx->list_len; a.list_cap = ctx->list_cap;

@@ -101,7 +101,8 @@ struct mpfmt_ctx {
     double ops_r = -1.0;                 // grid radius the operands were built for
     int32_t rdisc_path = 0;              // 0 auto, 1 exact fp64 VALU kernel, 2 MFMA filter + exact refine
     int32_t rdisc_path_used = 0;
-    int32_t mf_xcd_mode = 64;            // work items go to the XCDs in interleaved groups of this many (tools/xcd_sweep.sh: 64 2.02 ms, 512 2.05, one contiguous range per XCD 2.41)
+    int32_t mf_xcd_mode = -1;            // work items go to the XCDs in interleaved groups of this many; -1: 256 for launches of >= 32768 items, else 64
+                                         // (north star: groups of 64 2.02 ms / 5.6 GB of counter traffic, 256 2.04 / 4.6, 512 2.05 / 4.4; one range per XCD 2.41 ms)
     int32_t mf_ablate = 0;               // timing experiments only
     int32_t num_cus = 256;               // compute units of the device (persistent-grid sizing)
     int ord_per_cu = 0;          // k_order_logs: resident workgroups per CU on THIS ctx's device
