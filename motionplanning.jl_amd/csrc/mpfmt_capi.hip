@@ -1647,6 +1647,25 @@ int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value)
         }
         return MPFMT_OK;
     }
+    if (strncmp(name, "list_q", 6) == 0 || strcmp(name, "list_argmax") == 0 || strcmp(name, "list_sum") == 0) {
+        // (synchronising reads, diagnostics) list_q<permille>: that quantile of the tiles' chunk-list lengths; list_argmax: the tile (counted
+        // from the shard's first) with the longest list; list_sum: all entries
+        *value = 0;
+        const int64_t nt = ctx->tile_end - ctx->tile_begin;
+        if (ctx->list_len && nt > 0) {
+            std::vector<int32_t> h((size_t)nt);
+            HIPCHK(ctx, hipMemcpyAsync(h.data(), ctx->list_len, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (strcmp(name, "list_argmax") == 0) *value = (int64_t)(std::max_element(h.begin(), h.end()) - h.begin());
+            else if (strcmp(name, "list_sum") == 0) { int64_t t = 0; for (int32_t v : h) t += v; *value = t; }
+            else {
+                const int64_t q = std::min<int64_t>(1000, std::max<int64_t>(0, atoll(name + 6)));
+                std::sort(h.begin(), h.end());
+                *value = h[(size_t)std::min<int64_t>(nt - 1, nt * q / 1000)];
+            }
+        }
+        return MPFMT_OK;
+    }
     if (strcmp(name, "survivors") == 0) { *value = ctx->survivors; return MPFMT_OK; }
     if (strcmp(name, "pairs_tested") == 0) { *value = ctx->pairs_tested; return MPFMT_OK; }
     if (strcmp(name, "nnz") == 0) { *value = ctx->nnz; return MPFMT_OK; }
