@@ -89,6 +89,32 @@ def test_half_build_equals_whole_build_and_the_oracle(orc, d, N, r):
             assert np.array_equal(a[3].view(np.uint64), orc.graph_edges_free(Xi, oc, orow, lohi, lo, hi))
 
 
+@pytest.mark.parametrize("d,N,r,dup", [(2, 50, 0.3, 0), (3, 64, 0.5, 7), (6, 65, 0.9, 0), (2, 200, 0.4, 40), (6, 1000, 0.7, 100), (4, 5000, 0.2, 0)])
+def test_pairs_inside_one_tile_are_found_once(orc, d, N, r, dup):
+    """The half build keeps the pairs of a tile's OWN chunk once (sign bits of (query, candidate <= query) masked off, the other column's
+    record sent to the tile's own logs): worlds where most or all edges join two samples of one 64-sample tile -- a single tile, a tile
+    and one sample, repeated samples (distance 0, distinct indices) -- under the fused edge tests, against the oracle; and the slice
+    count of the pair kernel's work items is odd (kernels_rdisc_mfma.hip, mpfmt_slices_for)."""
+    rng = np.random.default_rng(900 + N)
+    X, lohi = random_world(rng, N, d, 9, 0.05, 0.25)
+    if dup:
+        X[rng.integers(0, N, size=dup)] = X[rng.integers(0, N, size=dup)]       # repeated samples
+    lo, hi = np.full(d, 0.0), np.full(d, 1.0)
+    oc, orow, oval = orc.rdisc_graph(X, r)
+    omask = orc.graph_edges_free(X, oc, orow, lohi, lo, hi)
+    with mp.Context(0) as c:
+        c.set_option("rebuild_index", 1)
+        c.upload_samples(X); c.upload_boxes(lohi, lo, hi)
+        for it in range(3):
+            nnz = c.graph_step_device(r)
+            colptr, rowval, nzval, free = _resident_graph(c, N)
+            assert nnz == len(orow) and np.array_equal(colptr, oc) and np.array_equal(rowval, orow) and np.array_equal(nzval, oval), it
+            assert np.array_equal(free.view(np.uint64), omask), it
+            if c.stat("rdisc_path_used") == 2:
+                assert c.graph_stats()["slices"] % 2 == 1
+        assert c.stat("rdisc_half_used") == 1 and c.stat("sweep_form") == 2
+
+
 @pytest.mark.parametrize("form", [2, 1, 0])
 @pytest.mark.parametrize("d,N,r,M", [(2, 6000, 0.03, 12), (3, 7001, 0.09, 40), (6, 20000, 0.42, 200)])
 def test_edge_tests_fused_into_the_half_build(orc, form, d, N, r, M):
