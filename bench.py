@@ -245,7 +245,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_option("rebuild_index", 1)           # every step rebuilds the cell grid + MFMA operands (the index build)
-    for opt in ("sweep_sorted", "mf_target_items", "rdisc_half", "fuse_broad", "mf_xcd_mode", "cell_fb_max"):             # tuning experiments (tools/): MPFMT_OPT_<NAME>=<int>
+    for opt in ("sweep_sorted", "mf_target_items", "rdisc_half", "fuse_broad", "mf_xcd_mode", "cell_fb_max", "lists_wide"):             # tuning experiments (tools/): MPFMT_OPT_<NAME>=<int>
         v = os.environ.get("MPFMT_OPT_" + opt.upper())
         if v is not None:
             ctx.set_option(opt, int(v))

@@ -1153,7 +1153,7 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
         const mpfmt_grid& G = ctx->grid;
         // few tiles (a small shard): four wavefronts per tile, kept ids staged in LDS (4 x cap x 4 bytes) -- in a global scratch area when
         // the lists are longer than LDS takes at a useful occupancy (a shard's lists hold every chunk of the OTHER shards: ~4 500 entries)
-        const bool wide = nt < 16 * (int64_t)ctx->num_cus;
+        const bool wide = ctx->lists_wide >= 0 ? ctx->lists_wide != 0 : nt < 16 * (int64_t)ctx->num_cus;
         const bool gst = wide && cap > 3072;
         if (gst && (rc = mpfmt_ensure(ctx, (void**)&ctx->lists_stage, sizeof(uint32_t) * (size_t)cap * 4 * (size_t)nt))) return rc;
         uint32_t* const gstage = gst ? (uint32_t*)ctx->lists_stage : nullptr;

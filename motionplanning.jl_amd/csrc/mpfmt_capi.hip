@@ -1595,6 +1595,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "mf_ablate") == 0) { ctx->mf_ablate = (int32_t)value; return MPFMT_OK; }
     if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }
+    if (strcmp(name, "lists_wide") == 0) { ctx->lists_wide = (int32_t)value; ctx->lists_r = -1.0; return MPFMT_OK; }
     if (strcmp(name, "cell_fb_max") == 0) { ctx->cell_fb_max = (int32_t)std::min<int64_t>(8, std::max<int64_t>(0, value)); ctx->grid_r = -1.0; return MPFMT_OK; }
     if (strcmp(name, "mf_target_items") == 0) { ctx->mf_target_items = value; return MPFMT_OK; }
     if (strcmp(name, "timing") == 0) { ctx->timing_enabled = value != 0; return MPFMT_OK; }

@@ -101,6 +101,7 @@ struct mpfmt_ctx {
     double ops_r = -1.0;                 // grid radius the operands were built for
     int32_t rdisc_path = 0;              // 0 auto, 1 exact fp64 VALU kernel, 2 MFMA filter + exact refine
     int32_t rdisc_path_used = 0;
+    int32_t lists_wide = -1;             // chunk lists built by four wavefronts per tile (1), one (0), or by the number of tiles (-1)
     int32_t cell_fb_max = 8;             // position bits inside a cell that the sort key carries (k_cellkey)
     int32_t mf_xcd_mode = -1;            // work items go to the XCDs in interleaved groups of this many; -1: 256 for launches of >= 32768 items, else 64
                                          // (north star: groups of 64 2.02 ms / 5.6 GB of counter traffic, 256 2.04 / 4.6, 512 2.05 / 4.4; one range per XCD 2.41 ms)
