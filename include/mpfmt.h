@@ -508,12 +508,21 @@ MPFMT_API int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg
  * kernel, slab tests of the flagged pairs before the columns are ordered, the ordering pass writes the mask; 1 = flagged entries
  * tested after the ordering; 0 = the separate sweep kernel.  Same graph and mask bits in every combination; a sweep called on
  * its own (mpfmt_graph_sweep_device, mpfmt_graph_edges_free) is always the whole sweep.
- * "fuse_sweep", "wf_graphs" (default 0): measured alternatives kept for the record.
+ * "wf_graphs" (default 0): a measured alternative kept for the record (LABNOTES.md).
+ * "mf_target_items" (default 40000): work items (tile x slice of its chunk list, one wavefront each) the MFMA pair kernel aims for; the
+ * slice count is made odd.  "mf_xcd_mode" (default -1 = by launch size): items reach the XCDs in interleaved groups of this many
+ * (0 = one contiguous range per XCD, 1 = round robin).  "cell_fb_max" (default 8): position bits inside a cell that the cell sort's key
+ * carries.  "lists_wide" (default -1 = by the number of tiles): chunk lists built by four wavefronts per tile (1) or one (0).
+ * Tuning knobs only: the graph and the masks are the same bit for bit whatever their values.
  * "debug_small_lists": test knob, shrinks the pending lists of the fused edge tests so that their overflow path runs. */
 MPFMT_API int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value);
 /* Counters of the last graph build: "rdisc_path_used", "pairs_tested", "survivors" (pairs that passed the
  * MFMA filter), "nnz", "slices", "cells", "rdisc_half_used", "pool_used"; of the last step's edge tests: "sweep_form"
- * (0 / 1 / 2 as "fuse_broad"), "pair_items" (pairs listed for the exact tests; a synchronising read). */
+ * (0 / 1 / 2 as "fuse_broad"), "pair_items" (pairs listed for the exact tests; a synchronising read); diagnostics: "redo_count" /
+ * "redo_reason" (builds redone since the ctx was made and why: 1 a chunk list was cut, 2 a log overflowed, 4 a column too long for the
+ * ordering pass, 8 more entries than allocated, 16 the pending-pair list was cut), "qcap" (records a quarter log holds), "ord_per_cu"
+ * (ordering-pass workgroups per CU), "list_cap" / "list_max" / "list_q<permille>" / "list_argmax" / "list_sum" (chunk-list lengths of
+ * the last list build; synchronising reads). */
 MPFMT_API int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value);
 /* work counters of the last graph build: candidate pairs distance-tested, tiles, slices. */
 MPFMT_API int32_t mpfmt_graph_stats(mpfmt_ctx* ctx, int64_t* pairs_tested, int64_t* tiles, int64_t* slices, int64_t* cells);
