@@ -11,18 +11,18 @@
 //            u^ are EXACT coordinates of slightly moved points (|u^ - u| <= 2^-12 per coordinate), so
 //            | |u^_q-u^_c| - s|q-c| | <= 2 sqrt(d) 2^-12 and the threshold
 //                T = (s r + 2 sqrt(d) e_c)^2 + accumulation margin
-//            can never reject a true neighbour (proof in DESIGN.md section 3).  It passes a few per cent of
-//            extra pairs in a thin shell around the r-ball.
+//            can never reject a true neighbour (proof in LABNOTES.md section 3.1).  It passes a few per cent of extra pairs in a
+//            thin shell around the r-ball.  (d <= 6: the K = 8 form, v_mfma_f32_32x32x8_f16, norm and threshold in the C input.)
 //   extract: the sign bits of the 16 accumulators are funnelled into one 16-bit word per lane
 //            (v_alignbit_b32), lanes with survivors append (query, candidate) to a wave-private LDS queue
 //            (__ballot + mbcnt prefix), ~0.3 % of the pairs.
 //   refine : when 64 survivors are queued, lane = survivor: exact canonical fp64 d2 from the fp64
 //            coordinates, membership test, count or emit (row index, sqrt(d2)).  All 64 lanes busy.
 //
-// Work mapping: one independent wavefront per (64-query tile, slice of its candidate chunks), no workgroup barriers;
-// the tile's two 32-row A fragments stay in VGPRs; B fragments are 1 KB coalesced loads from the operand array,
-// prefetched two chunks ahead; chunks farther than r from the tile's tight box are pruned by a lane-parallel prologue.
-// MODE 2 (single pass) also writes every exact hit into the fixed-capacity slot list of its (tile, slice, column).
+// Work mapping: one independent wavefront per (64-query tile, slice of its candidate chunks), no workgroup barriers; the tile's two
+// 32-row A fragments stay in VGPRs; B fragments are 1 KB coalesced loads, prefetched two chunks ahead; the chunks within r of the tile's
+// sub-boxes are listed once per index build (k_chunk_lists).  MODE 2 (single pass) appends every exact hit to the log of its column's
+// quarter tile (in a half build both columns' records, from the lane that holds both ends) and runs the edge tests' broad phase in the drain.
 #include "mpfmt_internal.h"
 #include "sweep_cmpx.h"
 #include "sweep_predicates.h"
