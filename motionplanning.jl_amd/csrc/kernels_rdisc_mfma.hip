@@ -502,6 +502,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     __shared__ unsigned long long s_rh[MF_RCAP];          //               the lane's 64 sign bits of that chunk
     __shared__ uint32_t s_qs[MF_QSZ];                     // survivor queue: chunk << 12 | finding lane << 6 | sign-bit position
     __shared__ int32_t s_cnt[64];
+    __shared__ int32_t s_operm[MODE == 2 ? 64 : 1];       // caller indices of the tile's own samples (the other column's record carries the query's)
     __shared__ int32_t s_lc[4];                           // own hits of the drain in work, per quarter of the tile (zero between drains)
     __shared__ unsigned long long s_qm[(MODE == 2 && D <= 6) ? 64 : 1];      // the queries' obstacle masks (broad phase in the drain)
     __shared__ int64_t s_base[MODE == 1 ? 64 : 1];
@@ -568,6 +569,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     for (int i = 0; i < D; ++i) s_q[lane * D + i] = a.Xs[qpos * D + i];
     s_cnt[lane] = 0;
     if (lane < 4) s_lc[lane] = 0;
+    if constexpr (MODE == 2) s_operm[lane] = a.perm[qpos];
     if constexpr (MODE == 2 && D <= 6) { if (a.fb) s_qm[lane] = a.smask[qpos]; }
     if constexpr (MODE == 3) { s_best[lane] = ~0ull; s_besti[lane] = 0x7fffffff; s_nfree[lane] = 0; }
     constexpr bool FILL = (MODE == 1);
@@ -649,6 +651,11 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         bool hit = false;
         uint32_t jg = 0, ql = 0;
         double d2 = 0.0;
+#ifndef MF_EARLY
+#define MF_EARLY 1
+#endif
+        [[maybe_unused]] uint32_t e_pj = 0;
+        [[maybe_unused]] unsigned long long e_sm = 0;
         [[maybe_unused]] double sl[D <= 6 ? D : 1], sh[D <= 6 ? D : 1];
         [[maybe_unused]] double qv[MODE == 3 ? D : 1], cv[MODE == 3 ? D : 1];
         if constexpr (MODE == 2 && D <= 6) {
@@ -665,6 +672,13 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (fl >> 5);
             jg = qc * 64u + (uint32_t)((t >> 1) * 32 + (fl & 31));
             ql = (uint32_t)((t & 1) * 32 + row);
+#if MF_EARLY
+            // (requested with the candidate's coordinates, not after the membership test: one dependent round trip less per drain)
+            if constexpr (MODE == 2) {
+                e_pj = (uint32_t)a.perm[jg];
+                if constexpr (D <= 6) { if (a.fb) e_sm = a.smask[jg]; }
+            }
+#endif
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 const double qi = s_q[ql * D + i], ci = a.Xs[(int64_t)jg * D + i];
@@ -761,7 +775,11 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                 // the boxes some pair of this drain can meet at all: OR over the lanes of (mask of the query & mask of the candidate)
                 unsigned long long um = 0;
 #if !(MF_ABLATE & 16)
+#if MF_EARLY
+                if (hit) um = s_qm[ql] & e_sm;
+#else
                 if (hit) um = s_qm[ql] & a.smask[jg];
+#endif
                 {
                     uint32_t ul = (uint32_t)um, uh = (uint32_t)(um >> 32);
 #define MF_OR_DPP(x, ctrl, rm_, bc) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rm_, 0xf, bc)
@@ -862,8 +880,16 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             if (fh && lane == leader) fbase = atomicAdd(&a.qlen[fq], cnt_l);
             uint32_t own_key = 0, for_key = 0;
             const uint32_t qs = (uint32_t)(tile * 64) + ql;
+#if MF_EARLY
+            if (hit) own_key = e_pj | ((ql & 15u) << 26) | pendflag;
+#else
             if (hit) own_key = (uint32_t)a.perm[jg] | ((ql & 15u) << 26) | pendflag;
+#endif
+#if MF_EARLY
+            if (fh) for_key = (uint32_t)s_operm[ql] | ((jg & 15u) << 26) | pendflag;
+#else
             if (fh) for_key = (uint32_t)a.perm[qs] | ((jg & 15u) << 26) | pendflag;
+#endif
             const int own_p = __shfl(obase, g) + pin;
             const int for_p = __shfl(fbase, leader) + pre;
             [[maybe_unused]] uint32_t own_w = 0xffffffffu, for_w = 0xffffffffu;      // places of the two records (pending-pair items)
