@@ -651,8 +651,8 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         bool hit = false;
         uint32_t jg = 0, ql = 0;
         double d2 = 0.0;
-#ifndef MF_EARLY
-#define MF_EARLY 1
+#ifndef MF_EARLY                 // A/B: 0 = loads and reservations where their results are first needed; 1 = loads hoisted; 2 = reservations too
+#define MF_EARLY 2
 #endif
         [[maybe_unused]] uint32_t e_pj = 0;
         [[maybe_unused]] unsigned long long e_sm = 0;
@@ -764,6 +764,48 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                 if (fr) atomicAdd(&s_nfree[ql], 1);
             }
         }
+#if MF_EARLY >= 2
+        // (MODE 2) the places of this drain's records are reserved BEFORE the broad phase: the returning atomics on the logs' cursors -- a
+        // device-scope round trip -- run beside the ~170 comparisons of the box walk instead of after it; only the pending-pair region
+        // (whose size the walk decides) is reserved afterwards
+        [[maybe_unused]] int g = 0, pin = 0, fq = 0, leader = 0, pre = 0, cnt_l = 0, obase = 0, fbase = 0;
+        [[maybe_unused]] int64_t fc = 0;
+        [[maybe_unused]] bool fh = false;
+        if constexpr (MODE == 2) {
+            // own record: column = the query ql of this tile, row = the candidate -> log (tile, ql >> 4); the place inside the drain's
+            // group is a returning LDS atomic on a per-drain counter (four addresses; the counters are left at zero again)
+            g = (int)(ql >> 4);
+            if (hit) pin = atomicAdd(&s_lc[g], 1);
+            // the same pair seen from the other end (half build): column jg, row = this query -> the log of jg's quarter tile.  The hits
+            // of a drain fall into a handful of such logs (its survivors come from two or three chunks): the lanes of each are found with
+            // one ballot per log, the first of them reserves the places of all
+            fc = (int64_t)(jg >> 6) - a.blk_begin;        // the candidate's tile, counted from the shard's first
+            fh = a.half && hit && fc >= 0 && fc < a.ntiles_shard;      // (the tile's own chunk too: its pairs are kept once, own_keep)
+            fq = (int)(fc * 4 + (int64_t)((jg & 63u) >> 4));
+            leader = lane;
+            {
+                unsigned long long rem = __ballot(fh);
+                while (rem) {
+                    const int L = __builtin_ctzll(rem);
+                    const int key = __builtin_amdgcn_readlane(fq, L);
+                    const bool mine = fh && fq == key;
+                    const unsigned long long mm = __ballot(mine);
+                    if (mine) { leader = L; pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u)); }
+                    if (lane == L) cnt_l = (int)__popcll(mm);
+                    rem &= ~mm;
+                }
+            }
+            // the reservations of the drain are requested back to back -- own logs (lanes 0..3), the other columns' logs (group leaders),
+            // and consumed after the box walk
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 4) {
+                const int c = s_lc[lane];
+                if (c) { s_lc[lane] = 0; obase = atomicAdd(&a.qlen[(tile - a.blk_begin) * 4 + lane], c); }
+            }
+            if (fh && lane == leader) fbase = atomicAdd(&a.qlen[fq], cnt_l);
+        }
+#endif
         // broad phase of is_free_motion for the hits of this drain (boxesND.jl:44-45, symmetric in the two end points, so one test
         // serves both records of a pair): the boxes that survived the tile's cull, each through the scalar cache, 2 D v_cmpx in a row
         uint32_t pendflag = 0;
@@ -814,6 +856,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         }
         if constexpr (MODE == 2) {
             // ---- single pass: the records of this drain's hits go to the quarter logs ------------------------------------------------
+#if MF_EARLY < 2
             // own record: column = the query ql of this tile, row = the candidate -> log (tile, ql >> 4); the place inside the drain's
             // group is a returning LDS atomic on a per-drain counter (four addresses; the counters are left at zero again)
             const int g = (int)(ql >> 4);
@@ -838,6 +881,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                     rem &= ~mm;
                 }
             }
+#endif
             // fb == 2: one item per (pair, box) unit of the pairs whose box met an obstacle's -- a pair that met k <= 4 boxes writes k
             // items, one that met more a single item that stands for "every box" -- in one of MF_NREG dense regions (this item's: item
             // mod MF_NREG), one reservation per drain
@@ -867,6 +911,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                     }
                 }
             }
+#if MF_EARLY < 2
             // the reservations of the drain are requested back to back -- own logs (lanes 0..3), the other columns' logs (group leaders),
             // the pending-pair region above -- and consumed after the keys are built: one L2 round trip for all of them
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -878,6 +923,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             }
             int fbase = 0;
             if (fh && lane == leader) fbase = atomicAdd(&a.qlen[fq], cnt_l);
+#endif
             uint32_t own_key = 0, for_key = 0;
             const uint32_t qs = (uint32_t)(tile * 64) + ql;
 #if MF_EARLY
