@@ -74,3 +74,19 @@ def test_every_ccall_of_the_julia_glue_is_executed_by_a_c_caller():
     assert len(used) >= 30
     assert not (used - called), sorted(used - called)
     assert used <= set(header_symbols())
+
+
+def test_committed_counter_summary_belongs_to_this_build():
+    """profiles/traffic.json (rocprofv3 --pmc, tools/pmc_traffic.py) is keyed to the sha256 of the library it was taken on; bench.py
+    prints `roofline.traffic` only when that is the library it runs.  The committed summary must be the one of the library built from
+    the committed sources (the build is reproducible: same compiler, same flags, same bytes)."""
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "motionplanning.jl_amd", "libmpfmt.so")
+    tj = os.path.join(root, "profiles", "traffic.json")
+    if not (os.path.exists(so) and os.path.exists(tj)):
+        pytest.skip("no built library or no counter summary")
+    sha = hashlib.sha256(open(so, "rb").read()).hexdigest()
+    t = json.load(open(tj))
+    assert t["lib_sha256"] == sha, "profiles/traffic.json was taken on another build: run tools/final_profiles.sh on the GPU box"
