@@ -76,7 +76,11 @@ MPFMT_API int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t 
 /* The same for a sample set that already lives in HBM of ctx's device (dX = device pointer, same d x N column-major layout): a batch
  * produced on the device -- the library's sampler (mpfmt_sample_free leaves its set in ctx already), a ROCArray -- becomes the
  * SampleSet of the next index build (addpoints, src/nearneighbors.jl:108-109) without crossing PCIe.  One device-to-device copy;
- * the set's bounding box and the finiteness check run on the device. */
+ * the set's bounding box and the finiteness check run on the device.
+ * Ordering: dX is read on ctx's stream.  Whatever produced it must be complete on that stream -- hand the producer's stream to
+ * mpfmt_set_stream first, or synchronise it before the call.  On return the copy is complete (dX may be reused).
+ * A non-finite coordinate returns MPFMT_ERR_ARG and leaves the ctx WITHOUT a sample set (N = 0, no index, no graph): the copy runs
+ * beside the check, so the previous set is gone either way and nothing of it is served afterwards. */
 MPFMT_API int32_t mpfmt_upload_samples_device(mpfmt_ctx* ctx, const double* dX, int64_t N, int32_t d);
 
 /* ---- collision checker: PointRobotNDBoxes(boxes) (src/collisioncheckers/boxesND.jl:15-23) and the

@@ -767,17 +767,18 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             qwant = qm * 1.12 + 96.0 * std::sqrt(std::max(qm / 16.0, 1.0)) + 64.0;
             // (logs that held the last build with a tenth to spare are kept as they are: growing them by a few per cent means freeing
             // and allocating gigabytes, which the allocator sometimes answers in 100+ ms)
-            if (ctx->pool_slack == 1 && (double)ctx->qcap >= qm * 1.10 + 64.0 && (double)ctx->qcap <= qwant) qwant = (double)ctx->qcap;
+            if ((double)ctx->qcap >= qm * 1.10 + 64.0 && (double)ctx->qcap <= qwant) qwant = (double)ctx->qcap;
             nnz_est = (double)ctx->pool_hint_nnz;
         } else {
             double vol = 1.0;
             for (int i = 0; i < d; ++i) vol *= std::max(ctx->bb_hi[i] - ctx->bb_lo[i], 1e-300);
             const double ball = std::pow(M_PI, d / 2.0) / std::tgamma(d / 2.0 + 1.0) * std::pow(r, (double)d);
             const double lam = std::min(1.0, ball / vol) * (double)N;          // neighbours of an interior sample
-            qwant = 16.0 * lam * 1.1 + 96.0 * std::sqrt(std::max(lam, 1.0)) + 64.0;
+            // (the slack an overflow doubles belongs to this estimate only: a hint carries the true fullest quarter of the last build)
+            qwant = (16.0 * lam * 1.1 + 96.0 * std::sqrt(std::max(lam, 1.0)) + 64.0) * (double)ctx->pool_slack;
             nnz_est = lam * (double)(nt * 64);
         }
-        qwant = std::min(qwant * (double)ctx->pool_slack, 16.0 * (double)std::min<int64_t>(N, MPFMT_ORD_MAXDEG + 1));   // (16 columns of the longest the ordering kernel takes)
+        qwant = std::min(qwant, 16.0 * (double)std::min<int64_t>(N, MPFMT_ORD_MAXDEG + 1));   // (16 columns of the longest the ordering kernel takes)
         const int64_t qcap = std::max<int64_t>(64, ((int64_t)qwant + 15) / 16 * 16);
         if ((double)qcap * (double)nt * 4.0 * 12.0 > 96e9) pool = false;      // cap the logs at 96 GB of the 288
         else {
@@ -923,6 +924,7 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
         return mpfmt_launch_rdisc_count(ctx, r);
     }
     ctx->pool_valid = pool;
+    if (pool) ctx->pool_slack = 1;                                // (a single pass whose logs held: the next cold estimate starts from its own margin again)
     ctx->pool_hint_N = N; ctx->pool_hint_r = r; ctx->pool_hint_nnz = nnz; ctx->pool_hint_maxdeg = rb->max_deg; ctx->pool_hint_qmax = rb->qmax;
     ctx->pool_hint_rank = ctx->rank; ctx->pool_hint_world = ctx->world;
     ctx->nnz = nnz;

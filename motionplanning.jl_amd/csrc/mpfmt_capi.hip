@@ -191,6 +191,8 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     if (!ctx) return MPFMT_OK;
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
+    // (refused while another thread's open group still has to post this ctx's gather: the ctx stays whole and usable)
+    { const int32_t rc = mpfmt_comm_destroy(ctx); if (rc) return rc; }
     if (ctx->zarena) { hipFree(ctx->zarena); ctx->d_pairs = nullptr; ctx->pool_flag = nullptr; ctx->pair_cnt = nullptr; }      // (they point into it)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
@@ -199,7 +201,6 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
     if (ctx->bb_host) hipHostFree(ctx->bb_host);
     for (int k = 0; k < 2; ++k) { if (ctx->copy_stream[k]) hipStreamDestroy(ctx->copy_stream[k]); if (ctx->ev_conv[k]) hipEventDestroy(ctx->ev_conv[k]); if (ctx->ev_copy[k]) hipEventDestroy(ctx->ev_copy[k]); }
-    mpfmt_comm_destroy(ctx);
     mpfmt_wf_free(ctx);
     if (ctx->aux) { mpfmt_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
     for (void* b : bufs) if (b) hipFree(b);
@@ -317,7 +318,18 @@ int32_t mpfmt_upload_samples_device(mpfmt_ctx* ctx, const double* dX, int64_t N,
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (N > 0) {
         const bb_block* h = (const bb_block*)ctx->bb_host;
-        if (h->bad) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "the sample set has a non-finite coordinate");
+        if (h->bad) {
+            // Xo has been overwritten beside the check (one synchronisation for both): the ctx holds NO sample set now -- nothing of the
+            // previous one (index, graph, hints) may be served after this error
+            ctx->samples_epoch += 1;
+            ctx->N = 0; ctx->d = d; ctx->ntiles = 0; ctx->nnz = 0;
+            ctx->grid_r = -1.0; ctx->graph_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0;
+            ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
+            ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
+            ctx->spec_ready = false; ctx->pool_valid = false; ctx->pend_valid = false; ctx->rowpos_valid = false;
+            for (int i = 0; i < d; ++i) { ctx->bb_lo[i] = 0.0; ctx->bb_hi[i] = 0.0; }
+            return mpfmt_fail(ctx, MPFMT_ERR_ARG, "the sample set has a non-finite coordinate (the ctx now holds no samples)");
+        }
         for (int i = 0; i < d; ++i) { lo[i] = INFINITY; hi[i] = -INFINITY; }
         for (int b = 0; b < nb; ++b)
             for (int i = 0; i < d; ++i) { lo[i] = std::min(lo[i], h->part[b][0][i]); hi[i] = std::max(hi[i], h->part[b][1][i]); }

@@ -218,7 +218,8 @@ int32_t mpfmt_group_end(void)
 {
     int32_t rc;
     if ((rc = rccl_ready(nullptr))) return rc;
-    if (g_group_depth > 0) --g_group_depth;
+    if (g_group_depth <= 0) return mpfmt_fail(nullptr, MPFMT_ERR_STATE, "mpfmt_group_end without mpfmt_group_begin on this thread");
+    --g_group_depth;
     const ncclResult_t gr = g_rccl.GroupEnd();
     if (g_group_depth > 0 && gr == ncclSuccess) return MPFMT_OK;
     // the outermost group has closed (or RCCL refused it): the list is emptied on EVERY path, every ctx is posted -- a failure on one
@@ -274,8 +275,12 @@ int32_t mpfmt_comm_destroy(mpfmt_ctx* ctx)
 {
     if (!ctx || !ctx->comm) return MPFMT_OK;
     mpfmt_comm* c = (mpfmt_comm*)ctx->comm;
-    // (a ctx destroyed inside an open group must not be posted at group_end)
+    // a ctx destroyed inside an open group must not be posted at group_end: the opener's list is thread-local, so only the opening
+    // thread can take the ctx out of it -- from any other thread the destroy is refused while the group's post is due
+    const size_t before = g_group_post.size();
     g_group_post.erase(std::remove(g_group_post.begin(), g_group_post.end(), ctx), g_group_post.end());
+    if (c->post_due && c->grouped && g_group_post.size() == before)
+        return mpfmt_fail(ctx, MPFMT_ERR_STATE, "communicator destroyed from another thread while its gather waits in an open group (close the group first)");
     hipSetDevice(ctx->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
