@@ -628,21 +628,27 @@ def main():
             # the drop-in precompute! of julia/MPFmtHIP.jl (hip_precompute_step!): uploads + ONE step + ONE export of colptr / rowval /
             # nzval / mask (1-based Int64, BitVector chunks) into page-locked host arrays -- what the unmodified fmtstar! needs before
             # its loop (its lookups afterwards are host work the library does not see)
-            jp = None
-            for _ in range(2):
-                c4 = mp.Context(0)
-                c4.set_stream(stream.cuda_stream)
-                t1 = time.perf_counter()
-                c4.upload_samples(w.X); c4.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+            # (export_first_ms: the first export of a ctx, which page-locks the ctx's export arena -- ~0.2 s per GB; export_repeat_ms:
+            # every later export of the same ctx -- the arena is kept -- i.e. what a re-plan on new samples or obstacles pays)
+            c4 = mp.Context(0)
+            c4.set_stream(stream.cuda_stream)
+            t1 = time.perf_counter()
+            c4.upload_samples(w.X); c4.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+            c4.graph_step_device(w.r)
+            t2 = time.perf_counter()
+            _, er, _, _, rate1 = c4.graph_export_arena(copy=False)
+            t3 = time.perf_counter()
+            nb = 8.0 * (w.N + 1) + 16.125 * len(er)
+            rep = []
+            for _ in range(3):
                 c4.graph_step_device(w.r)
-                t2 = time.perf_counter()
-                _, er, _, _, rate = c4.graph_export(pinned=True)
-                t3 = time.perf_counter()
-                c4.close()
-                row = {"upload_and_step_ms": 1e3 * (t2 - t1), "export_ms_incl_pinned_alloc_and_host_copy": 1e3 * (t3 - t2),
-                       "export_gb_per_s": rate, "exported_bytes": 8.0 * (w.N + 1) + 16.125 * len(er)}
-                del er
-                jp = row if jp is None else {k_: (min(jp[k_], row[k_]) if k_.endswith("_ms") else max(jp[k_], row[k_])) for k_ in row}
+                t4 = time.perf_counter()
+                _, er, _, _, rate2 = c4.graph_export_arena(copy=False)
+                rep.append((1e3 * (time.perf_counter() - t4), rate2))
+            del er
+            c4.close()
+            jp = {"upload_and_step_ms": 1e3 * (t2 - t1), "export_first_ms": 1e3 * (t3 - t2), "export_first_gb_per_s": rate1,
+                  "export_repeat_ms": min(x[0] for x in rep), "export_repeat_gb_per_s": max(x[1] for x in rep), "exported_bytes": nb}
             cold["julia_precompute_cold"] = jp
             cold["first_step_over_steady_step"] = cold["first_step_ms"] / ms_step
             out["submetrics"]["cold"] = cold

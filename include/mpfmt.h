@@ -381,6 +381,16 @@ MPFMT_API int32_t mpfmt_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** 
 MPFMT_API int32_t mpfmt_graph_export(mpfmt_ctx* ctx, int64_t* colptr, int64_t* rowval, double* nzval, uint64_t* mask, double* gb_per_s);
 MPFMT_API int32_t mpfmt_pinned_alloc(int64_t bytes, void** out);
 MPFMT_API int32_t mpfmt_pinned_free(void* p);
+/* Page-locking is the expensive part of a page-locked export (hipHostMalloc: ~0.2 s per GB, several times the copy it speeds up), so the
+ * ctx keeps ONE page-locked arena for it: grow-only, valid until it has to grow or the ctx is destroyed (mpfmt_ctx_destroy frees it).
+ * mpfmt_export_arena returns at least `bytes` of it.  mpfmt_graph_export_pinned is mpfmt_graph_export into that arena: it returns the
+ * four arrays (64-byte aligned; *mask may be asked for or NULL; *nnz_out their length) -- the memory behind the SparseMatrixCSC of
+ * ImmutableNNC(D, r) (src/nearneighbors.jl:23-28) and the BitVector of free edges in julia/MPFmtHIP.jl hip_precompute_step!, which
+ * every later call of the same ctx reuses: the second graph of a problem costs the copy alone.  The arrays are overwritten by the
+ * next export of this ctx. */
+MPFMT_API int32_t mpfmt_export_arena(mpfmt_ctx* ctx, int64_t bytes, void** out);
+MPFMT_API int32_t mpfmt_graph_export_pinned(mpfmt_ctx* ctx, int64_t** colptr, int64_t** rowval, double** nzval, uint64_t** mask,
+                                            int64_t* nnz_out, double* gb_per_s);
 
 /* ---- streaming r-disc: per-column reductions WITHOUT the stored graph.  BASELINE configs[2] at the radius of src/planners/fmt.jl:39
  *      (R^12, N = 1e6: ~4 700 neighbours per sample, 57 GB of CSC) cannot keep ImmutableNNC resident; what the loop body

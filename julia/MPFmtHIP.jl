@@ -74,31 +74,50 @@ function precompute!(P::MPProblem, r::Float64)
     P
 end
 # The same precompute! without a second build, a second sweep or a pageable copy: ONE mpfmt_graph_step_device (index, half build of the
-# graph, edge tests fused into it, mask written by the ordering pass -- the path bench.py times), then ONE mpfmt_graph_export into
-# page-locked arrays the library hands out (2.6 GB at the north star, at link speed).  The arrays back the SparseMatrixCSC and the
-# BitVector directly (pointer_to_array, own = false); hip_release!(CC) returns them.
+# graph, edge tests fused into it, mask written by the ordering pass -- the path bench.py times), then ONE mpfmt_graph_export_pinned into
+# the ctx's page-locked export arena (2.6 GB at the north star, at link speed).  The arena lives as long as the ctx: page-locking it
+# (~0.2 s per GB) is paid by the first graph of a ctx only, every later precompute of the same problem costs the copy alone.  The
+# arrays back the SparseMatrixCSC and the BitVector directly (pointer_to_array, own = false) and are overwritten by the next export of
+# the ctx; hip_release!(CC) drops the references (the library frees the arena with the ctx).
 function hip_precompute_step!(P::MPProblem, r::Float64)
     CC = P.CC; N = length(P.V); ctx = CC.ctx
     nnz = Ref{Int64}(0)
     chk(ctx, ccall((:mpfmt_graph_step_device, libmpfmt), Int32, (Ptr{Void}, Float64, Ptr{Int64}), ctx, r, nnz))
-    words = (nnz[] + 63) >> 6
-    ptrs = [Ref{Ptr{Void}}(C_NULL) for k in 1:4]
-    for (k, bytes) in enumerate((8(N + 1), 8max(nnz[], 1), 8max(nnz[], 1), 8max(words, 1)))
-        ccall((:mpfmt_pinned_alloc, libmpfmt), Int32, (Int64, Ptr{Ptr{Void}}), bytes, ptrs[k]) == 0 || error("mpfmt_pinned_alloc")
-    end
+    pc = Ref{Ptr{Int64}}(C_NULL); pr = Ref{Ptr{Int64}}(C_NULL); pv = Ref{Ptr{Float64}}(C_NULL); pm = Ref{Ptr{UInt64}}(C_NULL)
     rate = Ref{Float64}(0.0)
-    chk(ctx, ccall((:mpfmt_graph_export, libmpfmt), Int32, (Ptr{Void}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{UInt64}, Ptr{Float64}),
-                   ctx, ptrs[1][], ptrs[2][], ptrs[3][], ptrs[4][], rate))
-    colptr = pointer_to_array(convert(Ptr{Int64}, ptrs[1][]), N + 1, false)
-    rowval = pointer_to_array(convert(Ptr{Int64}, ptrs[2][]), nnz[], false)
-    nzval = pointer_to_array(convert(Ptr{Float64}, ptrs[3][]), nnz[], false)
+    chk(ctx, ccall((:mpfmt_graph_export_pinned, libmpfmt), Int32,
+                   (Ptr{Void}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{UInt64}}, Ptr{Int64}, Ptr{Float64}),
+                   ctx, pc, pr, pv, pm, nnz, rate))
+    words = (nnz[] + 63) >> 6
+    colptr = pointer_to_array(pc[], N + 1, false)
+    rowval = pointer_to_array(pr[], nnz[], false)
+    nzval = pointer_to_array(pv[], nnz[], false)
     CC.D = SparseMatrixCSC(N, N, colptr, rowval, nzval)
     CC.free = falses(0)
-    CC.free.chunks = pointer_to_array(convert(Ptr{UInt64}, ptrs[4][]), words, false); CC.free.len = nnz[]; CC.free.dims = (nnz[],)
-    CC.pinned = [p[] for p in ptrs]
+    CC.free.chunks = pointer_to_array(pm[], words, false); CC.free.len = nnz[]; CC.free.dims = (nnz[],)
     CC.index = Dict{Any,Int}(zip(P.V.V, 1:N))
     P.V = MetricNN(P.V.V, P.V.dist, P.V.init, ImmutableNNC(CC.D, fill(r, N)), P.V.DS, P.V.US)
     rate[]                                       # GB/s of the export
+end
+# The same export into page-locked arrays that outlive the ctx (mpfmt_pinned_alloc per array -- page-locking paid per call -- returned
+# by hip_release!): for a graph that is kept while the ctx goes on to other sample sets.
+function hip_export_owned!(CC::HIPBoxes, N::Int, nnz::Int)
+    words = (nnz + 63) >> 6
+    ptrs = Ptr{Void}[]
+    for bytes in (8(N + 1), 8max(nnz, 1), 8max(nnz, 1), 8max(words, 1))
+        p = Ref{Ptr{Void}}(C_NULL)
+        ccall((:mpfmt_pinned_alloc, libmpfmt), Int32, (Int64, Ptr{Ptr{Void}}), bytes, p) == 0 || error("mpfmt_pinned_alloc")
+        push!(ptrs, p[])
+    end
+    rate = Ref{Float64}(0.0)
+    chk(CC.ctx, ccall((:mpfmt_graph_export, libmpfmt), Int32, (Ptr{Void}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{UInt64}, Ptr{Float64}),
+                      CC.ctx, ptrs[1], ptrs[2], ptrs[3], ptrs[4], rate))
+    CC.D = SparseMatrixCSC(N, N, pointer_to_array(convert(Ptr{Int64}, ptrs[1]), N + 1, false),
+                           pointer_to_array(convert(Ptr{Int64}, ptrs[2]), nnz, false), pointer_to_array(convert(Ptr{Float64}, ptrs[3]), nnz, false))
+    CC.free = falses(0)
+    CC.free.chunks = pointer_to_array(convert(Ptr{UInt64}, ptrs[4]), words, false); CC.free.len = nnz; CC.free.dims = (nnz,)
+    CC.pinned = ptrs
+    rate[]
 end
 function hip_release!(CC::HIPBoxes)
     CC.D = spzeros(0, 0); CC.free = falses(0)

@@ -120,6 +120,9 @@ SYMBOLS = [
     ("mpfmt_graph_export", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, c_d_p, c_u64_p, c_d_p]),
     ("mpfmt_pinned_alloc", C.c_int32, [C.c_int64, C.POINTER(C.c_void_p)]),
     ("mpfmt_pinned_free", C.c_int32, [C.c_void_p]),
+    ("mpfmt_export_arena", C.c_int32, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
+    ("mpfmt_graph_export_pinned", C.c_int32, [C.c_void_p, C.POINTER(c_i64_p), C.POINTER(c_i64_p), C.POINTER(c_d_p), C.POINTER(c_u64_p),
+                                              c_i64_p, C.POINTER(C.c_double)]),
     ("mpfmt_rdisc_stream", C.c_int32, [C.c_void_p, C.c_double, c_d_p, c_u64_p, C.c_int32, c_i64_p, c_i64_p, c_i64_p, c_d_p, c_i64_p]),
     ("mpfmt_shard_info", C.c_int32, [C.c_void_p, c_i64_p, c_i64_p, c_i64_p]),
     ("mpfmt_fmtstar_wavefront", C.c_int32, [C.c_void_p, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p, C.c_double, C.c_int32,
@@ -846,6 +849,23 @@ class Context:
             nzval = np.empty(max(nnz, 1), dtype=np.float64); mask = np.zeros(max(words, 1), dtype=np.uint64)
             self._chk(self._L.mpfmt_graph_export(self._h, _ip(colptr), _ip(rowval), _dp(nzval), _up(mask) if want_mask else None, C.byref(rate)))
             rowval, nzval, mask = rowval[:nnz], nzval[:nnz], (mask[:words] if want_mask else None)
+        return colptr, rowval, nzval, mask, rate.value
+
+    def graph_export_arena(self, want_mask=True, copy=True):
+        """mpfmt_graph_export_pinned: the resident graph + mask into the ctx's own page-locked arena (kept across calls: only the first
+        export of a ctx pays for page-locking).  copy=False returns views of the arena, valid until the next export / close."""
+        cp, rv, nz, mk = c_i64_p(), c_i64_p(), c_d_p(), c_u64_p()
+        nnz = C.c_int64(); rate = C.c_double()
+        self._chk(self._L.mpfmt_graph_export_pinned(self._h, C.byref(cp), C.byref(rv), C.byref(nz), C.byref(mk) if want_mask else None,
+                                                    C.byref(nnz), C.byref(rate)))
+        n = nnz.value; words = (n + 63) // 64
+        colptr = np.ctypeslib.as_array(cp, shape=(self.N + 1,))
+        rowval = np.ctypeslib.as_array(rv, shape=(max(n, 1),))[:n]
+        nzval = np.ctypeslib.as_array(nz, shape=(max(n, 1),))[:n]
+        mask = np.ctypeslib.as_array(mk, shape=(max(words, 1),))[:words] if want_mask else None
+        if copy:
+            colptr, rowval, nzval = colptr.copy(), rowval.copy(), nzval.copy()
+            mask = mask.copy() if mask is not None else None
         return colptr, rowval, nzval, mask, rate.value
 
     def rdisc_stream(self, r, Cc=None, H=None, want_free=False):

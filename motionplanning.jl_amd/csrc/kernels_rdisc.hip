@@ -22,8 +22,8 @@
 // sequential slots, no atomics), then a per-column rank sort puts row indices in ascending order
 // (the SparseVector contract of nearneighbors.jl:138-198).
 #include "mpfmt_internal.h"
+#include "mf_operand.h"
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #include <cmath>
 #include <algorithm>
 #include <vector>
@@ -42,19 +42,28 @@ __device__ __forceinline__ int cell_of(double x, double lo, double inv_w, int g)
     return c;
 }
 
-// Sort key = cell id (row-major, last dimension fastest) followed by fb bits of the sample's position INSIDE its cell along
-// the last dimension.  A tile is 64 consecutive samples of the sorted order and usually takes the tail of one cell and the
-// head of the next one in the row; with the samples of a cell in index order both parts span their whole cells (tile extent
-// two cells along the last dimension), with this key they are the upper end of one cell and the lower end of the next --
-// one cell width.  Any order inside a cell is valid (columns are sorted afterwards); ties keep the index order (stable).
-__global__ void k_cellkey(const double* __restrict__ Xo, int64_t N, int d, mpfmt_grid G, int fb,
-                          uint32_t* __restrict__ key, int32_t* __restrict__ val)
+// ------------------------------------------------------------------------------------------------
+// The cell sort (hand-written: a counting sort by cell id, then an ordering pass inside each cell).
+// Sort key = cell id (mpfmt_grid: row-major, or block-major on a sharded ctx) followed by fb bits of the sample's position INSIDE
+// its cell along the last dimension, then the sample index.  A tile is 64 consecutive samples of the sorted order and usually takes
+// the tail of one cell and the head of the next one in the row; with the samples of a cell in index order both parts span their
+// whole cells (tile extent two cells along the last dimension), with this key they are the upper end of one cell and the lower end
+// of the next -- one cell width.  The order is a total one (index last), so every rank of a sharded run derives the SAME order, and
+// with it the same shards, from the samples alone.
+//   k_cellkey_count : key of every sample, its arrival number in its cell (the returning atomic that counts the cell)
+//   k_scan_*        : exclusive scan of the cell counts in place -> cellstart
+//   k_cell_need     : (sharded) the tiles this rank reads: its own and those of the cells next to its own cells
+//   k_cell_scatter  : (fine bits, sample index) of every sample to cellstart[cell] + arrival number
+//   k_cell_order    : one wavefront per cell puts the cell's items in ascending order
+// ------------------------------------------------------------------------------------------------
+__global__ void k_cellkey_count(const double* __restrict__ Xo, int64_t N, int d, mpfmt_grid G, int fb,
+                                uint32_t* __restrict__ key, uint32_t* __restrict__ slot, int32_t* __restrict__ cellcnt)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     int64_t id = 0;
     for (int i = 0; i < d; ++i)
-        id += (int64_t)cell_of(Xo[p * d + i], G.lo[i], G.inv_w[i], G.g[i]) * G.stride[i];
+        id += mpfmt_cell_term(G, i, cell_of(Xo[p * d + i], G.lo[i], G.inv_w[i], G.g[i]));
     uint32_t fine = 0;
     if (fb > 0) {
         const int L = d - 1;
@@ -65,78 +74,275 @@ __global__ void k_cellkey(const double* __restrict__ Xo, int64_t N, int d, mpfmt
         if (!(t == t)) fine = 0;
     }
     key[p] = ((uint32_t)id << fb) | fine;
-    val[p] = (int32_t)p;
+    slot[p] = (uint32_t)atomicAdd(&cellcnt[id], 1);
 }
 
-// fp32 copy of the tiles' sub-boxes for the candidate side of k_chunk_lists: a box that contains the fp64 one (the chunk
-// lists then are a superset by a hair; the graph is decided by the exact refine)
-__global__ void k_sub32(const double* __restrict__ sub, int64_t ne, int d, float* __restrict__ out)
+// exclusive scan of up to 4096 consecutive items per call of a 1024-thread workgroup (thread = 4 items); returns the block's total.
+// (hand-written: the cell counts -> cellstart and the degrees -> colptr; in == out allowed)
+template <typename T>
+__device__ __forceinline__ T scan4096(const T* in, T* out, int64_t base, int64_t n, T carry, T* s_w)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ne) return;
-    const double x = sub[t];
-    const bool is_hi = ((t / d) & 1) != 0;
-    float f = (float)x;                                   // nearest
-    if (!is_hi && (double)f > x) f = nextafterf(f, -INFINITY);
-    if (is_hi && (double)f < x) f = nextafterf(f, INFINITY);
-    out[t] = f;
-}
-
-// sorted position s -> perm / iperm and the cell-sorted AoS copy Xs (one thread per coordinate: coalesced stores, the d
-// threads of a sample read one contiguous row); pad positions get perm = -1 and NaN coordinates (NaN never passes d2 <= r2)
-__global__ void k_sorted_perm_aos(const double* __restrict__ Xo, const int32_t* __restrict__ perm_sorted, int64_t N, int64_t npad,
-                                  int d, int32_t* __restrict__ perm, int32_t* __restrict__ iperm, double* __restrict__ Xs)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= npad * d) return;
-    const int64_t s = t / d;
-    const int i = (int)(t - s * d);
-    const int32_t o = (s < N) ? perm_sorted[s] : -1;
-    if (i == 0) {
-        perm[s] = o;
-        if (o >= 0) iperm[o] = (int32_t)s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i0 = base + (int64_t)tid * 4;
+    T v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? in[i0 + k] : (T)0;
+    const T t = v[0] + v[1] + v[2] + v[3];
+    T inc = t;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const T u = __shfl_up(inc, off); if (lane >= off) inc += u; }
+    __syncthreads();                                       // (s_w of the previous call has been read)
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        T x = lane < 16 ? s_w[lane] : (T)0;
+        const T own = x;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { const T u = __shfl_up(x, off); if (lane >= off) x += u; }
+        if (lane < 16) s_w[lane] = x - own;                // exclusive over the wavefronts
+        if (lane == 15) s_w[16] = x;                       // the block's total
     }
-    Xs[t] = (o >= 0) ? Xo[(int64_t)o * d + i] : __builtin_nan("");
+    __syncthreads();
+    T o = carry + s_w[wave] + inc - t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (i0 + k < n) out[i0 + k] = o; o += v[k]; }
+    return s_w[16];
 }
-
-// tiled SoA copy Xt[tile][i][lane] from the sorted AoS copy (coalesced stores; the exact VALU pair kernel and the tile boxes read it)
-__global__ void k_tiles_from_aos(const double* __restrict__ Xs, int64_t npad, int d, double* __restrict__ Xt)
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scan_single(const T* in, T* out, int64_t n)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= npad * d) return;
-    const int64_t tile = t / (64 * d);
-    const int rem = (int)(t - tile * 64 * d);
-    const int i = rem >> 6, lane = rem & 63;
-    Xt[t] = Xs[(tile * 64 + lane) * d + i];
+    __shared__ T s_w[17];
+    T carry = 0;
+    for (int64_t base = 0; base < n; base += 4096) carry += scan4096<T>(in, out, base, n, carry, s_w);
 }
-
-__global__ void k_cellstart(const uint32_t* __restrict__ key_sorted, int fb, int64_t N, int64_t ncells,
-                            int32_t* __restrict__ cellstart)
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scan_block(const T* in, T* out, int64_t n, T* __restrict__ bsum)
 {
-    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > ncells) return;
-    int64_t lo = 0, hi = N;                 // lower_bound(key_sorted, c)
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)(key_sorted[mid] >> fb) < c) lo = mid + 1; else hi = mid;
+    __shared__ T s_w[17];
+    const T tot = scan4096<T>(in, out, (int64_t)blockIdx.x * 4096, n, (T)0, s_w);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scan_add(T* __restrict__ a, int64_t n, const T* __restrict__ bsum)
+{
+    const T add = bsum[blockIdx.x];
+    const int64_t i0 = (int64_t)blockIdx.x * 4096 + (int64_t)threadIdx.x * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (i0 + k < n) a[i0 + k] += add;
+}
+// out = exclusive scan of in (n items; in == out allowed); bsum: room for ceil(n / 4096) + 1 items
+template <typename T>
+static void launch_scan(hipStream_t st, const T* in, T* out, int64_t n, T* bsum)
+{
+    const int64_t nsb = (n + 4095) / 4096;
+    if (nsb <= 16) {
+        hipLaunchKernelGGL((k_scan_single<T>), dim3(1), dim3(1024), 0, st, in, out, n);
+    } else {
+        hipLaunchKernelGGL((k_scan_block<T>), dim3((unsigned)nsb), dim3(1024), 0, st, in, out, n, bsum);
+        hipLaunchKernelGGL((k_scan_single<T>), dim3(1), dim3(1024), 0, st, (const T*)bsum, bsum, nsb);
+        hipLaunchKernelGGL((k_scan_add<T>), dim3((unsigned)nsb), dim3(1024), 0, st, out, n, (const T*)bsum);
     }
-    cellstart[c] = (int32_t)lo;
 }
 
-// Tight box of each 64-sample tile, plus TWO sub-boxes.  A tile is 64 consecutive samples of the cell-sorted order, so one
-// in g_last tiles runs over the end of a grid row (one in g_last * g_prev over the end of two, ...): its hull then spans the
-// whole extent of the minor dimensions although its samples sit in two compact groups.  The samples are split where the
-// cell key jumps the most and each side gets its own box (tile_sub [tile][A lo, A hi, B lo, B hi][d]; B is an empty box
-// (+1e300, -1e300) when the tile lies in one cell) -- the candidate lists test sub-box against sub-box, which keeps them
-// ~30 % shorter than hull against hull.  Any split is valid: every sample lies in A or in B.
-__global__ __launch_bounds__(64) void k_tile_bbox(const double* __restrict__ Xt, const uint32_t* __restrict__ cellkey, int fb, int64_t N,
-                                                  int64_t ntiles, int d, double* __restrict__ tile_lo, double* __restrict__ tile_hi,
-                                                  double* __restrict__ tile_sub)
+// does the cell [cs, ce) of the sorted order touch a tile this rank reads?  (tileneed == nullptr: the index is whole)
+__device__ __forceinline__ bool cell_wanted(const uint8_t* __restrict__ tileneed, int64_t cs, int64_t ce)
 {
-    int64_t tile = blockIdx.x;
+    if (!tileneed) return true;
+    const int64_t t0 = cs >> 6, t1 = (ce - 1) >> 6;
+    if (t1 - t0 >= 4) return true;
+    bool w = false;
+    for (int64_t t = t0; t <= t1; ++t) w = w || tileneed[t] != 0;
+    return w;
+}
+
+// Sharded ctx: which tiles does this rank read at all?  Its own (positions [pos_b, pos_e) of the sorted order) and those that hold a
+// sample within r of an own sample: such a sample lies in a cell next to (Chebyshev distance <= 1) the own sample's cell, cells
+// being at least r wide.  One workgroup per cell id; the workgroups of own cells mark the tiles of all their neighbours (thread =
+// neighbour offset).  Tiles left unmarked are never built: they get empty boxes, which every candidate test rejects.
+__global__ __launch_bounds__(256) void k_cell_need(const int32_t* __restrict__ cellstart, mpfmt_grid G, int d, int64_t pos_b, int64_t pos_e,
+                                                   int64_t noff, uint8_t* __restrict__ tileneed)
+{
+    const int64_t id = blockIdx.x;
+    const int64_t cs = cellstart[id], ce = cellstart[id + 1];
+    // own cell <=> it holds a position of [pos_b, pos_e)
+    if (ce <= cs || ce <= pos_b || cs >= pos_e) return;
+    int c[MPFMT_MAX_DIM];
+    for (int i = 0; i < d; ++i) c[i] = mpfmt_cell_coord(G, i, id);
+    for (int64_t t = threadIdx.x; t < noff; t += blockDim.x) {
+        int64_t rem = t, nid = 0;
+        bool ok = true;
+        for (int i = d - 1; i >= 0; --i) {
+            int o = 0;
+            if (G.g[i] > 1) { o = (int)(rem % 3) - 1; rem /= 3; }
+            const int cc = c[i] + o;
+            ok = ok && cc >= 0 && cc < G.g[i];
+            nid += mpfmt_cell_term(G, i, min(max(cc, 0), G.g[i] - 1));
+        }
+        if (!ok) continue;
+        const int64_t ns = cellstart[nid], ne = cellstart[nid + 1];
+        for (int64_t tl = ns >> 6; tl <= ((ne - 1) >> 6) && ne > ns; ++tl) tileneed[tl] = 1;
+    }
+}
+
+__global__ void k_cell_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot, int64_t N, int fb,
+                               const int32_t* __restrict__ cellstart, const uint8_t* __restrict__ tileneed, unsigned long long* __restrict__ items)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const uint32_t k = key[p];
+    const int64_t id = (int64_t)(k >> fb);
+    const int64_t cs = cellstart[id];
+    if (tileneed && !cell_wanted(tileneed, cs, cellstart[id + 1])) return;
+    items[cs + slot[p]] = ((unsigned long long)(k & ((1u << fb) - 1u)) << 32) | (unsigned long long)(uint32_t)p;
+}
+
+// One wavefront per cell: the cell's items (fine bits << 32 | sample index -- all different) into ascending order, written as the
+// sorted order's sample index and cell key of each position.  <= 64 items: in registers (rank = items below mine, v_readlane
+// broadcasts).  <= 1024: the same count over an LDS copy.  More (clustered or duplicated samples): a stable LSD radix sort, eight
+// bits a pass, between the item array and a second one -- O(n) per pass whatever the cell holds.
+#define CO_LDS 1024
+__global__ __launch_bounds__(256) void k_cell_order(const int32_t* __restrict__ cellstart, int64_t ncells, int fb, int pbits,
+                                                    const uint8_t* __restrict__ tileneed, unsigned long long* items, unsigned long long* items2,
+                                                    int32_t* __restrict__ val_out, uint32_t* __restrict__ cellkey)
+{
+    __shared__ unsigned long long s_it[4][CO_LDS];
+    __shared__ int32_t s_cnt[4][256];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t id = (int64_t)blockIdx.x * 4 + wave;
+    if (id >= ncells) return;
+    const int64_t cs = cellstart[id], ce = cellstart[id + 1];
+    const int64_t n = (int64_t)__builtin_amdgcn_readfirstlane((int)(ce - cs));      // (wave-uniform: one cell per wavefront)
+    if (n <= 0 || !cell_wanted(tileneed, cs, ce)) return;
+    const uint32_t keyhi = (uint32_t)id << fb;
+    if (n <= 64) {
+        const unsigned long long mine = lane < n ? items[cs + lane] : ~0ull;
+        int rank = 0;
+        for (int j = 0; j < (int)n; ++j) {
+            const unsigned long long o = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), j) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
+            rank += (o < mine) ? 1 : 0;
+        }
+        if (lane < n) { val_out[cs + rank] = (int32_t)(uint32_t)mine; cellkey[cs + rank] = keyhi | (uint32_t)(mine >> 32); }
+        return;
+    }
+    if (n <= CO_LDS) {
+        unsigned long long* const it = s_it[wave];
+        for (int i = lane; i < (int)n; i += 64) it[i] = items[cs + i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < (int)n; base += 256) {
+            unsigned long long m[4];
+            int rk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int i = base + k * 64 + lane; m[k] = i < (int)n ? it[i] : ~0ull; rk[k] = 0; }
+            for (int j = 0; j < (int)n; ++j) {
+                const unsigned long long o = it[j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rk[k] += (o < m[k]) ? 1 : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = base + k * 64 + lane;
+                if (i < (int)n) { val_out[cs + rk[k]] = (int32_t)(uint32_t)m[k]; cellkey[cs + rk[k]] = keyhi | (uint32_t)(m[k] >> 32); }
+            }
+        }
+        return;
+    }
+    // ---- stable LSD radix sort of a large cell ----
+    int32_t* const cnt = s_cnt[wave];
+    unsigned long long* src = items + cs;
+    unsigned long long* dst = items2 + cs;
+    const int npass = (pbits + 7) / 8 + (fb > 0 ? 1 : 0);
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = (pass < (pbits + 7) / 8) ? pass * 8 : 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cnt[lane + 64 * k] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t i = lane; i < n; i += 64) atomicAdd(&cnt[(int)((src[i] >> shift) & 255ull)], 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {   // exclusive scan of the 256 counts (lane = four consecutive digits)
+            const int c0 = cnt[lane * 4], c1 = cnt[lane * 4 + 1], c2 = cnt[lane * 4 + 2], c3 = cnt[lane * 4 + 3];
+            const int t = c0 + c1 + c2 + c3;
+            int inc = t;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(inc, off); if (lane >= off) inc += u; }
+            const int b0 = inc - t;
+            cnt[lane * 4] = b0; cnt[lane * 4 + 1] = b0 + c0; cnt[lane * 4 + 2] = b0 + c0 + c1; cnt[lane * 4 + 3] = b0 + c0 + c1 + c2;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t base = 0; base < n; base += 64) {
+            const int64_t i = base + lane;
+            const bool act = i < n;
+            const unsigned long long item = act ? src[i] : 0ull;
+            const int dg = act ? (int)((item >> shift) & 255ull) : 256;
+            unsigned long long rem = __ballot(act);
+            while (rem) {                                    // the lanes of one digit at a time, in lane order: stable
+                const int L = __builtin_ctzll(rem);
+                const int dv = __builtin_amdgcn_readlane(dg, L);
+                const bool mine = dg == dv;
+                const unsigned long long mm = __ballot(mine);
+                const int pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                const int b = cnt[dv];
+                if (mine) dst[b + pre] = item;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == L) cnt[dv] = b + (int)__popcll(mm);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                rem &= ~mm;
+            }
+        }
+        __threadfence();                                     // this pass's stores before the next pass's loads (other lanes' addresses)
+        unsigned long long* const sw = src; src = dst; dst = sw;
+    }
+    for (int64_t i = lane; i < n; i += 64) {
+        const unsigned long long item = src[i];
+        val_out[cs + i] = (int32_t)(uint32_t)item;
+        cellkey[cs + i] = keyhi | (uint32_t)(item >> 32);
+    }
+}
+
+// One pass over the tiles this rank reads (one wavefront per tile, lane = sample): the row is gathered once from the caller's array and
+// leaves as the sorted AoS row (through LDS: coalesced stores), the tile's SoA slice, perm / iperm, the hull, the two sub-boxes (fp64,
+// and fp32 rounded outward: the candidate side of the chunk-list test) and -- when the matrix-core pair kernel will run -- the fp16
+// operand.  A tile is 64 consecutive samples of the cell-sorted order, so one in g_last tiles runs over the end of a grid row (one in
+// g_last * g_prev over the end of two, ...): its hull then spans the whole extent of the minor dimensions although its samples sit in
+// two compact groups.  The samples are split where the cell key jumps the most and each side gets its own box (tile_sub [tile][A lo,
+// A hi, B lo, B hi][d]; B is an empty box (+1e300, -1e300) when the tile lies in one cell) -- the candidate lists test sub-box against
+// sub-box, which keeps them ~30 % shorter than hull against hull.  Any split is valid: every sample lies in A or in B.
+// A tile the rank does not read (tileneed) gets empty boxes and nothing else.
+#define BT_MAXD 16
+__device__ __forceinline__ float f32_down(double x) { float f = (float)x; if ((double)f > x) f = nextafterf(f, -INFINITY); return f; }
+__device__ __forceinline__ float f32_up(double x) { float f = (float)x; if ((double)f < x) f = nextafterf(f, INFINITY); return f; }
+struct bt_ops { void* ops; double scale; };               // ops == nullptr: no operands
+__global__ __launch_bounds__(256) void k_build_tiles(const double* __restrict__ Xo, const int32_t* __restrict__ perm_sorted,
+                                                     const uint32_t* __restrict__ cellkey, int fb, int64_t N, int64_t ntiles, int d,
+                                                     int32_t* __restrict__ perm, int32_t* __restrict__ iperm, double* __restrict__ Xs,
+                                                     double* __restrict__ Xt, double* __restrict__ tile_lo, double* __restrict__ tile_hi,
+                                                     double* __restrict__ tile_sub, float* __restrict__ tile_sub32,
+                                                     const uint8_t* __restrict__ tileneed, bt_ops ops, mpfmt_grid G)
+{
+    __shared__ double s_rows[4][64 * BT_MAXD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     if (tile >= ntiles) return;
-    int lane = threadIdx.x;
+    if (tileneed && !tileneed[tile]) {
+        for (int i = lane; i < d; i += 64) { tile_lo[tile * d + i] = 1e300; tile_hi[tile * d + i] = -1e300; }
+        for (int i = lane; i < 4 * d; i += 64) {
+            const bool hi = ((i / d) & 1) != 0;
+            tile_sub[tile * 4 * d + i] = hi ? -1e300 : 1e300;
+            tile_sub32[tile * 4 * d + i] = hi ? -INFINITY : INFINITY;
+        }
+        return;
+    }
     const int64_t sp = tile * 64 + lane;
+    const int32_t o = (sp < N) ? perm_sorted[sp] : -1;
+    perm[sp] = o;
+    if (o >= 0) iperm[o] = (int32_t)sp;
+    // cut where the cell key jumps the most
     const int64_t key = (int64_t)(cellkey[min(sp, N - 1)] >> fb);
     const int64_t nxt = __shfl_down(key, 1);
     int64_t jump = (lane < 63 && sp + 1 < N) ? llabs(nxt - key) : 0;
@@ -147,53 +353,6 @@ __global__ __launch_bounds__(64) void k_tile_bbox(const double* __restrict__ Xt,
         if (oj > jump || (oj == jump && ow < where)) { jump = oj; where = ow; }
     }
     const int split = (jump > 0) ? where + 1 : 64;         // A = lanes [0, split), B = lanes [split, 64)
-    for (int i = 0; i < d; ++i) {
-        const double x = Xt[(tile * d + i) * 64 + lane];
-        double amn = lane < split ? x : NAN, amx = amn, bmn = lane < split ? NAN : x, bmx = bmn;   // fmin/fmax ignore NaN (pads too)
-        for (int off = 32; off > 0; off >>= 1) {
-            amn = fmin(amn, __shfl_xor(amn, off));
-            amx = fmax(amx, __shfl_xor(amx, off));
-            bmn = fmin(bmn, __shfl_xor(bmn, off));
-            bmx = fmax(bmx, __shfl_xor(bmx, off));
-        }
-        if (lane == 0) {
-            tile_lo[tile * d + i] = fmin(amn, bmn); tile_hi[tile * d + i] = fmax(amx, bmx);      // the hull
-            double* t = tile_sub + tile * 4 * d;
-            t[i] = (amn == amn) ? amn : 1e300; t[d + i] = (amx == amx) ? amx : -1e300;
-            t[2 * d + i] = (bmn == bmn) ? bmn : 1e300; t[3 * d + i] = (bmx == bmx) ? bmx : -1e300;
-        }
-    }
-}
-
-// k_sorted_perm_aos + k_tiles_from_aos + k_tile_bbox in one pass over the samples (one wavefront per tile, lane = sample): the
-// row is gathered once from the caller's array and leaves as the sorted AoS row (through LDS: coalesced stores), the tile's SoA
-// slice, perm / iperm, the hull and the two sub-boxes.  Three launches and two re-reads of 8dN bytes less per index build.
-#define BT_MAXD 16
-__global__ __launch_bounds__(256) void k_build_tiles(const double* __restrict__ Xo, const int32_t* __restrict__ perm_sorted,
-                                                     const uint32_t* __restrict__ cellkey, int fb, int64_t N, int64_t ntiles, int d,
-                                                     int32_t* __restrict__ perm, int32_t* __restrict__ iperm, double* __restrict__ Xs,
-                                                     double* __restrict__ Xt, double* __restrict__ tile_lo, double* __restrict__ tile_hi,
-                                                     double* __restrict__ tile_sub)
-{
-    __shared__ double s_rows[4][64 * BT_MAXD];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    if (tile >= ntiles) return;
-    const int64_t sp = tile * 64 + lane;
-    const int32_t o = (sp < N) ? perm_sorted[sp] : -1;
-    perm[sp] = o;
-    if (o >= 0) iperm[o] = (int32_t)sp;
-    // cut where the cell key jumps the most (see k_tile_bbox)
-    const int64_t key = (int64_t)(cellkey[min(sp, N - 1)] >> fb);
-    const int64_t nxt = __shfl_down(key, 1);
-    int64_t jump = (lane < 63 && sp + 1 < N) ? llabs(nxt - key) : 0;
-    int where = lane;
-    for (int off = 32; off > 0; off >>= 1) {
-        const int64_t oj = __shfl_xor(jump, off);
-        const int ow = __shfl_xor(where, off);
-        if (oj > jump || (oj == jump && ow < where)) { jump = oj; where = ow; }
-    }
-    const int split = (jump > 0) ? where + 1 : 64;
     double* rows = s_rows[wave];
     // the row's d coordinates are requested together (a runtime-d loop that loads and reduces in turn sat out d gather latencies)
     double xr[BT_MAXD];
@@ -201,6 +360,7 @@ __global__ __launch_bounds__(256) void k_build_tiles(const double* __restrict__ 
     for (int i = 0; i < BT_MAXD; ++i) xr[i] = (i < d && o >= 0) ? Xo[(int64_t)o * d + i] : __builtin_nan("");
 #pragma unroll
     for (int i = 0; i < BT_MAXD; ++i) if (i < d) rows[lane * d + i] = xr[i];
+    if (ops.ops) mf_write_operand(ops.ops, G, d, ops.scale, sp, o >= 0, xr);
     for (int i = 0; i < d; ++i) {
         const double x = rows[lane * d + i];                 // (own row: no barrier needed)
         Xt[(tile * d + i) * 64 + lane] = x;
@@ -212,10 +372,13 @@ __global__ __launch_bounds__(256) void k_build_tiles(const double* __restrict__ 
             bmx = fmax(bmx, __shfl_xor(bmx, off));
         }
         if (lane == 0) {
-            tile_lo[tile * d + i] = fmin(amn, bmn); tile_hi[tile * d + i] = fmax(amx, bmx);
+            tile_lo[tile * d + i] = fmin(amn, bmn); tile_hi[tile * d + i] = fmax(amx, bmx);      // the hull
             double* t = tile_sub + tile * 4 * d;
-            t[i] = (amn == amn) ? amn : 1e300; t[d + i] = (amx == amx) ? amx : -1e300;
-            t[2 * d + i] = (bmn == bmn) ? bmn : 1e300; t[3 * d + i] = (bmx == bmx) ? bmx : -1e300;
+            float* t32 = tile_sub32 + tile * 4 * d;
+            const double al = (amn == amn) ? amn : 1e300, ah = (amx == amx) ? amx : -1e300;
+            const double bl = (bmn == bmn) ? bmn : 1e300, bh = (bmx == bmx) ? bmx : -1e300;
+            t[i] = al; t[d + i] = ah; t[2 * d + i] = bl; t[3 * d + i] = bh;
+            t32[i] = f32_down(al); t32[d + i] = f32_up(ah); t32[2 * d + i] = f32_down(bl); t32[3 * d + i] = f32_up(bh);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -226,9 +389,60 @@ __global__ __launch_bounds__(256) void k_build_tiles(const double* __restrict__ 
 
 static inline int32_t ensure(mpfmt_ctx* ctx, void** p, size_t bytes) { return mpfmt_ensure(ctx, p, bytes); }
 
-int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
+
+// shard boundaries as fractions of the cell-sorted order, at equal ESTIMATED WORK rather than equal sample counts: a column's work
+// (candidate pairs, edges) goes with the number of grid cells around its own -- 2 instead of 3 per dimension at the faces of the
+// domain -- so the face shards of an equal-count split would idle while the interior ones finish (30 % at 8 slabs of the north star).
+// The cells of the leading axes are walked in id order (the order the samples are sorted in) with weight prod_i (cells within +-1
+// along i); the cut positions assume a uniform density -- only the balance depends on that, never the result -- and every rank
+// derives the same cuts from the grid alone.
+// (a face cell sees 2 of 3 neighbouring cells -- two thirds of the candidate pairs -- but its columns keep more than two thirds of
+// their hits, and since the half build the per-hit work of the drain outweighs the per-pair work of the filter: measured over the
+// shards of the north star a face column costs 0.84 of an interior one, not 0.67 -- weight 2.35 / 3)
+static void shard_cuts(mpfmt_ctx* ctx)
 {
-    if (ctx->grid_r == r && ctx->Xt) return MPFMT_OK;
+    const mpfmt_grid& G = ctx->grid;
+    const int d = ctx->d, world = ctx->world;
+    std::vector<int64_t> key = {(int64_t)world, (int64_t)d, (int64_t)G.nsplit};
+    for (int i = 0; i < d; ++i) { key.push_back(G.g[i]); key.push_back(G.split[i]); }
+    if (key == ctx->cut_key && (int)ctx->cut_frac.size() == world + 1) return;
+    ctx->cut_frac.assign((size_t)world + 1, 0.0);
+    ctx->cut_frac[(size_t)world] = 1.0;
+    // the leading axes whose cells are walked one by one: at least the cut ones, then more while the walk stays short
+    int m = std::max(1, G.nsplit);
+    int64_t units = 1;
+    for (int i = 0; i < m; ++i) units *= G.g[i];
+    while (m < d - 1 && units * G.g[m] <= 4096) { units *= G.g[m]; ++m; }
+    struct unit { int64_t id; double w; };
+    std::vector<unit> u((size_t)units);
+    std::vector<int> c((size_t)m, 0);
+    auto nb = [](int cc, int n) { return n == 1 ? 1.0 : ((cc == 0 || cc == n - 1) ? 2.35 : 3.0); };
+    for (int64_t k = 0; k < units; ++k) {
+        int64_t id = 0; double w = 1.0;
+        for (int i = 0; i < m; ++i) { id += mpfmt_cell_term(G, i, c[i]); w *= nb(c[i], G.g[i]); }
+        u[(size_t)k] = {id, w};
+        for (int i = m - 1; i >= 0; --i) { if (++c[i] < G.g[i]) break; c[i] = 0; }
+    }
+    std::sort(u.begin(), u.end(), [](const unit& a, const unit& b) { return a.id < b.id; });
+    double total = 0.0;
+    for (const unit& x : u) total += x.w;
+    double acc = 0.0;
+    int g = 1;
+    for (int64_t k = 0; k < units && g < world; ++k) {
+        const double w = u[(size_t)k].w;
+        while (g < world && acc + w >= total * (double)g / (double)world) {
+            ctx->cut_frac[(size_t)g] = ((double)k + (total * (double)g / (double)world - acc) / w) / (double)units;
+            ++g;
+        }
+        acc += w;
+    }
+    for (; g < world; ++g) ctx->cut_frac[(size_t)g] = 1.0;
+    ctx->cut_key = key;
+}
+
+int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r, bool whole)
+{
+    if (ctx->grid_r == r && ctx->Xt && ctx->index_rank == ctx->rank && ctx->index_world == ctx->world && !(whole && ctx->tileneed)) return MPFMT_OK;
     const int64_t N = ctx->N;
     const int d = ctx->d;
     mpfmt_timed tm1(ctx);
@@ -259,26 +473,62 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
         if (prod <= cmax || gcap == 1) break;
         gcap = (gcap > 2) ? gcap - std::max(1, gcap / 8) : 1;
     }
+    // ---- cell ids: block-major on a sharded ctx (one cut axis per factor of two of the world, at most three, never the last axis) ----
+    for (int i = 0; i < MPFMT_MAX_DIM; ++i) { G.split[i] = 0; G.hstride[i] = 0; G.ext[i] = 1; }
+    G.nsplit = 0;
+    if (ctx->world > 1) {
+        int want = 0;
+        while ((1 << want) < ctx->world && want < 3) ++want;
+        int64_t lead = 1;
+        for (int i = 0; i < d - 1 && G.nsplit < want; ++i) {
+            if (i != G.nsplit) break;                          // (the cut axes are the leading ones)
+            if (G.g[i] < 2 || lead * G.g[i] > ((int64_t)1 << 20)) break;
+            lead *= G.g[i];
+            G.split[i] = (G.g[i] + 1) / 2;
+            ++G.nsplit;
+        }
+    }
     int64_t stride = 1;
     for (int i = d - 1; i >= 0; --i) {
+        G.ext[i] = G.split[i] > 0 ? G.split[i] : G.g[i];
         G.stride[i] = stride;
-        stride *= G.g[i];
+        stride *= G.ext[i];
         double ext = ctx->bb_hi[i] - ctx->bb_lo[i];
         G.lo[i] = ctx->bb_lo[i];
         G.w[i] = (G.g[i] > 1) ? ext / (double)G.g[i] : (ext > 0 ? ext : 1.0);
         G.inv_w[i] = (G.g[i] > 1) ? (double)G.g[i] / ext : 0.0;
     }
-    G.ncells = stride;
+    G.inner = stride;
+    for (int i = 0; i < G.nsplit; ++i) G.hstride[i] = G.inner << (G.nsplit - 1 - i);
+    G.ncells = G.inner << G.nsplit;
     for (int i = d; i < MPFMT_MAX_DIM; ++i) { G.g[i] = 1; G.stride[i] = 0; G.lo[i] = 0; G.w[i] = 1; G.inv_w[i] = 0; }
 
     ctx->ntiles = (N + 63) / 64;
     const int64_t npad = ctx->ntiles * 64;
 
+    // ---- the shard: a contiguous range of 256-sample blocks (4 tiles) of the cell-sorted order ----
+    {
+        shard_cuts(ctx);
+        const int64_t nblocks4 = (ctx->ntiles + 3) / 4;
+        auto cut = [&](int g) -> int64_t {
+            if (g <= 0) return 0;
+            if (g >= ctx->world) return nblocks4;
+            return std::min<int64_t>(nblocks4, std::max<int64_t>(0, (int64_t)std::llround(ctx->cut_frac[(size_t)g] * (double)nblocks4)));
+        };
+        ctx->tile_begin = std::min<int64_t>(ctx->ntiles, 4 * cut(ctx->rank));
+        ctx->tile_end = std::min<int64_t>(ctx->ntiles, 4 * cut(ctx->rank + 1));
+    }
+
     int32_t rc;
     if ((rc = ensure(ctx, (void**)&ctx->perm, sizeof(int32_t) * npad))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->iperm, sizeof(int32_t) * N))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->cellkey, sizeof(uint32_t) * N))) return rc;
-    if ((rc = ensure(ctx, (void**)&ctx->cellstart, sizeof(int32_t) * (G.ncells + 1)))) return rc;
+    const size_t arena_cells = sizeof(int32_t) * (size_t)(G.ncells + 2);
+    const size_t arena_bytes = arena_cells + (size_t)std::max<int64_t>(ctx->ntiles, 1);
+    if ((rc = ensure(ctx, (void**)&ctx->idx_arena, arena_bytes))) return rc;
+    ctx->cellstart = (int32_t*)ctx->idx_arena;
+    ctx->list_max = ctx->cellstart + (G.ncells + 1);
+    ctx->tileneed_buf = (uint8_t*)ctx->idx_arena + arena_cells;
     if ((rc = ensure(ctx, (void**)&ctx->Xt, sizeof(double) * npad * d))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->Xs, sizeof(double) * std::max<int64_t>(npad, 1) * d))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->tile_lo, sizeof(double) * ctx->ntiles * d))) return rc;
@@ -286,60 +536,66 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r)
     if ((rc = ensure(ctx, (void**)&ctx->tile_sub, sizeof(double) * ctx->ntiles * 4 * d))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->tile_sub32, sizeof(float) * ctx->ntiles * 4 * d))) return rc;
 
+    // the matrix-core pair kernel's operands are written by the tile pass when that kernel is going to run
+    bool mf = false;
+    float negT = 0.f;
+    if (ctx->rdisc_path != 1 && (rc = mpfmt_mfma_prepare(ctx, r, &negT, &mf))) return rc;
+    if (mf && (rc = ensure(ctx, (void**)&ctx->ops, 32 * (size_t)std::max<int64_t>(npad, 1)))) return rc;
+
+    // shard + halo index: the matrix-core path reads candidates only through its chunk lists, which the empty boxes of unbuilt tiles
+    // keep them out of; the exact VALU kernel walks cell runs directly and needs every tile.  The halo search visits 3^(gridded
+    // dimensions) neighbours of every own cell: past 1e8 visits the whole index is cheaper than the search.
+    ctx->tileneed = nullptr;
+    int64_t noff = 1;
+    if (ctx->world > 1 && !whole && mf && ctx->index_halo && N > 0) {
+        double v = 1.0;
+        for (int i = 0; i < d; ++i) if (G.g[i] > 1) { noff *= 3; v *= 3.0; }
+        if (v * (double)G.ncells / (double)ctx->world <= 1e8 && ctx->tile_end > ctx->tile_begin) ctx->tileneed = ctx->tileneed_buf;
+    }
+
     if (N > 0) {
-        // keys / values, radix sort by cell id (stable: samples stay in index order inside a cell)
-        uint32_t* key_in; int32_t* val_in; int32_t* val_out;
-        size_t tmp_bytes = 0;
         int bits = 1;
         while (((int64_t)1 << bits) < G.ncells) ++bits;
-        int fb = std::max(0, std::min(ctx->cell_fb_max, 32 - bits));         // position bits inside the cell (see k_cellkey)
-        // (the sort runs one pass per 8 key bits: when four or more position bits still fit a pass fewer, the rest are not worth a
-        // pass -- cfg2: 2 passes instead of 3, index 0.156 -> 0.130 ms, pair kernel unchanged; the north star's 14 cell bits leave 2: kept at 8)
-        if (fb > 4 && bits > 0) {
-            const int passes = (bits + fb + 7) / 8;
-            const int fit = 8 * (passes - 1) - bits;
-            if (fit >= 4 && fit < fb) fb = fit;
-        }
-        bits += fb;
+        const int fb = std::max(0, std::min(ctx->cell_fb_max, 32 - bits));       // position bits inside the cell (k_cellkey_count)
         ctx->cell_fb = fb;
-        // rocprim's default takes its merge sort (about 20 launches) up to 2^20 items; the cell key has few bits, so the
-        // onesweep radix sort (histogram + one pass per 8 bits) is the shorter pipeline from a few thousand samples on
-        using sort_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
-        HIPCHK(ctx, rocprim::radix_sort_pairs<sort_cfg>(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                              (int32_t*)nullptr, (int32_t*)nullptr, (size_t)N, 0, bits, ctx->stream));
-        size_t off_key = 0, off_val = off_key + sizeof(uint32_t) * N, off_vout = off_val + sizeof(int32_t) * N;
-        size_t off_tmp = (off_vout + sizeof(int32_t) * N + 255) & ~(size_t)255;
+        int pbits = 1;
+        while (((int64_t)1 << pbits) < N) ++pbits;
+        // scratch: key[N] slot[N] val_out[N] (4 bytes each), items[N] items2[N] (8 bytes each), block sums of the scan
+        const int64_t nsb = (G.ncells + 1 + 4095) / 4096;
+        const size_t o_key = 0, o_slot = o_key + 4 * (size_t)N, o_val = o_slot + 4 * (size_t)N;
+        const size_t o_it = (o_val + 4 * (size_t)N + 15) & ~(size_t)15, o_it2 = o_it + 8 * (size_t)N, o_bs = o_it2 + 8 * (size_t)N;
         void* scr;
-        if ((rc = mpfmt_scratch(ctx, off_tmp + tmp_bytes, &scr))) return rc;
-        key_in = (uint32_t*)((char*)scr + off_key);
-        val_in = (int32_t*)((char*)scr + off_val);
-        val_out = (int32_t*)((char*)scr + off_vout);
-        void* tmp = (char*)scr + off_tmp;
+        if ((rc = mpfmt_scratch(ctx, o_bs + 4 * (size_t)(nsb + 1), &scr))) return rc;
+        uint32_t* key = (uint32_t*)((char*)scr + o_key);
+        uint32_t* slot = (uint32_t*)((char*)scr + o_slot);
+        int32_t* val_out = (int32_t*)((char*)scr + o_val);
+        unsigned long long* items = (unsigned long long*)((char*)scr + o_it);
+        unsigned long long* items2 = (unsigned long long*)((char*)scr + o_it2);
+        int32_t* bsum = (int32_t*)((char*)scr + o_bs);
+        HIPCHK(ctx, hipMemsetAsync(ctx->idx_arena, 0, ctx->tileneed ? arena_bytes : arena_cells, ctx->stream));
+        ctx->list_max_clean = true;
         const int B = 256;
-        hipLaunchKernelGGL(k_cellkey, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream,
-                           ctx->Xo, N, d, G, fb, key_in, val_in);
-        HIPCHK(ctx, rocprim::radix_sort_pairs<sort_cfg>(tmp, tmp_bytes, key_in, ctx->cellkey, val_in, val_out, (size_t)N, 0, bits, ctx->stream));
-        hipLaunchKernelGGL(k_cellstart, dim3((unsigned)((G.ncells + 1 + B - 1) / B)), dim3(B), 0, ctx->stream,
-                           ctx->cellkey, fb, N, G.ncells, ctx->cellstart);
-        if (d <= BT_MAXD) {
-            hipLaunchKernelGGL(k_build_tiles, dim3((unsigned)((ctx->ntiles + 3) / 4)), dim3(256), 0, ctx->stream, ctx->Xo, val_out, ctx->cellkey, fb,
-                               N, ctx->ntiles, d, ctx->perm, ctx->iperm, ctx->Xs, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub);
-        } else {
-            const int64_t ne = npad * d;
-            hipLaunchKernelGGL(k_sorted_perm_aos, dim3((unsigned)((ne + B - 1) / B)), dim3(B), 0, ctx->stream,
-                               ctx->Xo, val_out, N, npad, d, ctx->perm, ctx->iperm, ctx->Xs);
-            hipLaunchKernelGGL(k_tiles_from_aos, dim3((unsigned)((ne + B - 1) / B)), dim3(B), 0, ctx->stream, ctx->Xs, npad, d, ctx->Xt);
-            hipLaunchKernelGGL(k_tile_bbox, dim3((unsigned)ctx->ntiles), dim3(64), 0, ctx->stream,
-                               ctx->Xt, ctx->cellkey, fb, N, ctx->ntiles, d, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub);
-        }
-        {   // fp32 copy of the sub-boxes, lows rounded down and highs up (rows 0, 2 = lo; 1, 3 = hi)
-            const int64_t ne = ctx->ntiles * 4 * d;
-            hipLaunchKernelGGL(k_sub32, dim3((unsigned)((ne + B - 1) / B)), dim3(B), 0, ctx->stream, ctx->tile_sub, ne, d, ctx->tile_sub32);
-        }
+        hipLaunchKernelGGL(k_cellkey_count, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream,
+                           ctx->Xo, N, d, G, fb, key, slot, ctx->cellstart);
+        launch_scan<int32_t>(ctx->stream, (const int32_t*)ctx->cellstart, ctx->cellstart, G.ncells + 1, bsum);
+        if (ctx->tileneed)
+            hipLaunchKernelGGL(k_cell_need, dim3((unsigned)G.ncells), dim3(256), 0, ctx->stream, (const int32_t*)ctx->cellstart, G, d,
+                               ctx->tile_begin * 64, std::min<int64_t>(ctx->tile_end * 64, N), noff, ctx->tileneed);
+        hipLaunchKernelGGL(k_cell_scatter, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream, (const uint32_t*)key, (const uint32_t*)slot, N, fb,
+                           (const int32_t*)ctx->cellstart, (const uint8_t*)ctx->tileneed, items);
+        hipLaunchKernelGGL(k_cell_order, dim3((unsigned)((G.ncells + 3) / 4)), dim3(256), 0, ctx->stream, (const int32_t*)ctx->cellstart, G.ncells, fb, pbits,
+                           (const uint8_t*)ctx->tileneed, items, items2, val_out, ctx->cellkey);
+        bt_ops bo{mf ? ctx->ops : nullptr, ctx->mf_scale};
+        hipLaunchKernelGGL(k_build_tiles, dim3((unsigned)((ctx->ntiles + 3) / 4)), dim3(256), 0, ctx->stream, ctx->Xo, (const int32_t*)val_out,
+                           (const uint32_t*)ctx->cellkey, fb, N, ctx->ntiles, d, ctx->perm, ctx->iperm, ctx->Xs, ctx->Xt, ctx->tile_lo, ctx->tile_hi,
+                           ctx->tile_sub, ctx->tile_sub32, (const uint8_t*)ctx->tileneed, bo, G);
         HIPCHK(ctx, hipGetLastError());
     }
     tm1.end("grid");
     ctx->grid_r = r;
+    ctx->index_rank = ctx->rank; ctx->index_world = ctx->world;
+    ctx->ops_r = mf ? r : -1.0;
+    ctx->lists_r = -1.0;
     ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
     return MPFMT_OK;
 }
@@ -425,7 +681,7 @@ __global__ __launch_bounds__(64) void k_rdisc(rdisc_args a, mpfmt_grid G)
             const int span = chi[i] - clo[i] + 1;
             const int c = clo[i] + (int)(rem % span);
             rem /= span;
-            cbase += (int64_t)c * G.stride[i];
+            cbase += mpfmt_cell_term(G, i, c);
             const double eps = G.w[i] * 1e-9;
             const double blo = G.lo[i] + (double)c * G.w[i] - eps;
             const double bhi = G.lo[i] + (double)(c + 1) * G.w[i] + eps;
@@ -603,12 +859,11 @@ static void fill_args(mpfmt_ctx* ctx, double r, rdisc_args& a)
 
 static int32_t scan_i64(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t n)
 {
-    size_t tmp_bytes = 0;
-    HIPCHK(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (int64_t)0, n, rocprim::plus<int64_t>(), ctx->stream));
     void* tmp;
     int32_t rc;
-    if ((rc = mpfmt_scratch(ctx, tmp_bytes, &tmp))) return rc;
-    HIPCHK(ctx, rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (int64_t)0, n, rocprim::plus<int64_t>(), ctx->stream));
+    if ((rc = mpfmt_scratch(ctx, sizeof(int64_t) * ((n + 4095) / 4096 + 1), &tmp))) return rc;
+    launch_scan<int64_t>(ctx->stream, in, out, (int64_t)n, (int64_t*)tmp);
+    HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
 
@@ -650,39 +905,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     int32_t rc;
     if ((rc = mpfmt_build_grid(ctx, r))) return rc;
     const int64_t N = ctx->N;
-    // shard: contiguous range of 256-sample blocks (4 tiles) of the cell-sorted order
-    const int64_t nblocks4 = (ctx->ntiles + 3) / 4;
-    // Boundaries at equal ESTIMATED WORK rather than equal sample counts: a column's work (candidate pairs, edges) goes
-    // with the number of grid cells around its own -- 2 instead of 3 per dimension at the faces of the domain -- so the
-    // first and last shards of an equal-count split would idle while the interior ones finish (30 % at 8 shards on the
-    // north star).  Weight of a cell = prod_i (cells within +-1 along i); the cut positions assume a uniform density
-    // (only the balance depends on that, never the result), and every rank derives the same cuts from the grid alone.
-    auto shard_cut = [&](int g) -> int64_t {                       // first 256-sample block of shard g
-        if (g <= 0) return 0;
-        if (g >= ctx->world) return nblocks4;
-        const mpfmt_grid& G = ctx->grid;
-        const int d = ctx->d;
-        // cells are sorted with dimension 0 most significant: weight prefix over (c0, c1) slabs is enough resolution
-        // (finer dimensions only matter inside one slab, where the weights of the remaining dimensions average out)
-        const int g0 = std::max(1, G.g[0]), g1 = d > 1 ? std::max(1, G.g[1]) : 1;
-        // (a face cell sees 2 of 3 neighbouring cells -- two thirds of the candidate pairs -- but its columns keep more than two thirds
-        // of their hits, and since the half build the per-hit work of the drain outweighs the per-pair work of the filter: measured
-        // over the 8 shards of the north star a face column costs 0.84 of an interior one, not 0.67 -- weight 2.35 / 3, between what 8 and 4 shards ask for)
-        auto nb = [](int c, int n) { return n == 1 ? 1.0 : ((c == 0 || c == n - 1) ? 2.35 : 3.0); };
-        double total = 0.0;
-        for (int a = 0; a < g0; ++a) for (int b = 0; b < g1; ++b) total += (double)nb(a, g0) * (double)nb(b, g1);
-        const double want = total * (double)g / (double)ctx->world;
-        double acc = 0.0, frac = 1.0;
-        for (int a = 0; a < g0 && frac == 1.0; ++a)
-            for (int b = 0; b < g1; ++b) {
-                const double w = (double)nb(a, g0) * (double)nb(b, g1);
-                if (acc + w >= want) { frac = ((double)(a * g1 + b) + (want - acc) / w) / (double)(g0 * g1); break; }
-                acc += w;
-            }
-        return std::min<int64_t>(nblocks4, std::max<int64_t>(0, (int64_t)std::llround(frac * (double)nblocks4)));
-    };
-    ctx->tile_begin = std::min<int64_t>(ctx->ntiles, 4 * shard_cut(ctx->rank));
-    ctx->tile_end = std::min<int64_t>(ctx->ntiles, 4 * shard_cut(ctx->rank + 1));
+    // (the shard -- tile_begin, tile_end -- is cut by the index build: mpfmt_build_grid)
     const int64_t nt = ctx->tile_end - ctx->tile_begin;
 
     // the last build of the same (N, r, shard) met a column longer than the ordering kernel stages: the logs would be written for
@@ -716,6 +939,8 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             mf = false;
         }
     }
+    // (the exact VALU kernel walks cell runs directly: it needs every tile, not the shard + halo index of the matrix-core path)
+    if (!mf && ctx->tileneed && (rc = mpfmt_build_grid(ctx, r, true))) return rc;
     ctx->rdisc_path_used = mf ? 2 : 1;
     ctx->mf_negT = negT;
 
@@ -887,7 +1112,7 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     if (!ctx->rb_dev) HIPCHK(ctx, hipMalloc(&ctx->rb_dev, sizeof(count_readback)));
     if (!ctx->rb_host) HIPCHK(ctx, hipHostMalloc(&ctx->rb_host, sizeof(count_readback), hipHostMallocDefault));
     hipLaunchKernelGGL(k_count_readback, dim3(1), dim3(512), 0, ctx->stream, ctx->d_pairs, ctx->colptr + N, pool ? ctx->pool_flag : nullptr,
-                       (ctx->spec_lists && nt > 0) ? ctx->list_len + nt : nullptr, (const int32_t*)(ctx->d_pairs + 512), (count_readback*)ctx->rb_dev,
+                       (ctx->spec_lists && nt > 0) ? ctx->list_max : nullptr, (const int32_t*)(ctx->d_pairs + 512), (count_readback*)ctx->rb_dev,
                        ctx->sweep_in_order ? (const int32_t*)ctx->pair_over : (ctx->pend_valid && ctx->sweep_pending_used) ? (const int32_t*)ctx->pend_over : nullptr);
     HIPCHK(ctx, hipMemcpyAsync(ctx->rb_host, ctx->rb_dev, sizeof(count_readback), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1052,7 +1277,7 @@ int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r)
             if (!ctx->spec_fail) HIPCHK(ctx, hipMalloc((void**)&ctx->spec_fail, sizeof(int32_t)));
             const int64_t nt = ctx->tile_end - ctx->tile_begin;
             hipLaunchKernelGGL(k_spec_check, dim3(1), dim3(1), 0, ctx->stream, ctx->pool_flag,
-                               (ctx->spec_lists && nt > 0) ? ctx->list_len + nt : nullptr, ctx->list_cap, ctx->colptr + N, cap,
+                               (ctx->spec_lists && nt > 0) ? ctx->list_max : nullptr, ctx->list_cap, ctx->colptr + N, cap,
                                (const int32_t*)(ctx->d_pairs + 512), ctx->spec_fail);
             ctx->nnz = ctx->pool_hint_nnz;                          // provisional: replaced by the count's own value in _finish
             ctx->nnz_cap = cap;
@@ -1165,7 +1390,7 @@ __global__ __launch_bounds__(256) void k_rdisc_query(const double* __restrict__ 
 #pragma unroll
         for (int i = L - 1; i >= 0; --i) {
             const int span = chi[i] - clo[i] + 1;
-            cbase += (int64_t)(clo[i] + (int)(rem % span)) * G.stride[i];
+            cbase += mpfmt_cell_term(G, i, clo[i] + (int)(rem % span));
             rem /= span;
         }
         const int64_t ra = cellstart[cbase + clo[L]], rb = cellstart[cbase + chi[L] + 1];
@@ -1200,7 +1425,7 @@ int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* 
                                  int64_t* inds_host, double* ds_host, int64_t cap)
 {
     int32_t rc;
-    if ((rc = mpfmt_build_grid(ctx, r))) return rc;
+    if ((rc = mpfmt_build_grid(ctx, r, true))) return rc;      // (any sample may be asked for: the whole index, also on a sharded ctx)
     const int64_t N = ctx->N;
     // scratch: hit_idx[N] hit_val[N] out_idx[N] out_val[N] k
     size_t o_hi = 0, o_hv = o_hi + ((sizeof(int32_t) * N + 15) & ~(size_t)15), o_oi = o_hv + sizeof(double) * N,

@@ -26,6 +26,7 @@
 #include "mpfmt_internal.h"
 #include "sweep_cmpx.h"
 #include "sweep_predicates.h"
+#include "mf_operand.h"
 #include <algorithm>
 #include <cmath>
 
@@ -39,7 +40,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define MF_THREADS 256
 #define MF_WAVES 4
 #define MF_QCAP 256                 // survivor queue entries per wavefront (drained in batches of 64)
-#define MF_PAD_NORM 60000.0f        // |u|^2 stand-in for padding samples: never below any threshold
 
 // a global pointer read through the constant address space: a wave-uniform address then always takes the scalar cache
 typedef const __attribute__((address_space(4))) double* mf_cptr;
@@ -119,50 +119,17 @@ __device__ __forceinline__ int cell_of_m(double x, double lo, double inv_w, int 
 }
 
 // ---- operand construction --------------------------------------------------------------------------------
-// one thread per sorted position; writes the candidate-role operand (32 B).
+// one thread per sorted position; writes the candidate-role operand (mf_operand.h).  The index build writes the operands itself
+// (k_build_tiles); this kernel serves a ctx whose index was built before the matrix-core path was asked for.
 __global__ void k_make_ops(const double* __restrict__ Xs, int64_t N, int64_t npad, int d,
-                           mpfmt_grid G, double scale, uint4* __restrict__ ops)
+                           mpfmt_grid G, double scale, void* __restrict__ ops)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npad) return;
-    _Float16 h[16];
+    double x[12];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) h[k] = (_Float16)0.0f;
-    float n = 0.0f;
-    if (p < N) {
-        for (int i = 0; i < d; ++i) {
-            const float u = (float)((Xs[p * d + i] - G.lo[i]) * scale);
-            const _Float16 q = (_Float16)u;                 // round to nearest even
-            h[i] = q;
-            const float qf = (float)q;
-            n += qf * qf;                                   // exact products, fp32 sum
-        }
-    } else {
-        n = MF_PAD_NORM;
-    }
-    const _Float16 nh = (_Float16)n;
-    const _Float16 nl = (_Float16)(n - (float)nh);
-    if (d <= 6) {
-        // K = 8 layout (16 B per sample): u_0..u_5, n_hi, n_lo -- the query's norm and the threshold ride in the MFMA's C
-        // stored [chunk][kb][col][half]: lane (kb, col) of the pair kernel's B fragment finds slots 4 kb .. 4 kb + 3 of samples
-        // col (half 0) and 32 + col (half 1) of a chunk side by side -- one 16-byte load per lane and chunk
-        union { _Float16 hh[8]; uint2 v[2]; } u8;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) u8.hh[k] = h[k];
-        u8.hh[6] = nh; u8.hh[7] = nl;
-        uint2* __restrict__ o2 = reinterpret_cast<uint2*>(ops);
-        const int64_t chunk = p >> 6;
-        const int cx = (int)(p & 31), half = (int)((p >> 5) & 1);
-        o2[(chunk * 64 + cx) * 2 + half] = u8.v[0];
-        o2[(chunk * 64 + 32 + cx) * 2 + half] = u8.v[1];
-        return;
-    }
-    h[12] = (_Float16)1.0f; h[13] = (_Float16)1.0f; h[14] = nh; h[15] = nl;
-    union { _Float16 hh[16]; uint4 v[2]; } u;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) u.hh[k] = h[k];
-    ops[p * 2] = u.v[0];
-    ops[p * 2 + 1] = u.v[1];
+    for (int i = 0; i < 12; ++i) x[i] = (i < d && p < N) ? Xs[p * d + i] : 0.0;
+    mf_write_operand(ops, G, d, scale, p, p < N, x);
 }
 
 // ---- candidate chunk lists -------------------------------------------------------------------------------------
@@ -219,9 +186,25 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
     }
     const float frpad2 = (float)(rpad2 * (1.0 + 1e-4));
     constexpr int L = D - 1;
-    uint32_t rows = 1;                                    // <= number of grid cells <= 2^24
+    // The rows (cells of the dimensions before the last) around the tile, in ASCENDING CELL-ID ORDER -- consecutive rows' runs are then
+    // consecutive ranges of the sorted order, and a chunk that straddles two runs is seen twice in a row (the dedupe below).  Row-major
+    // ids: the mixed-radix count over [clo, chi].  Block-major ids (sharded ctx): the half-block combinations first (axis 0 the most
+    // significant), inside each the mixed-radix count over the part of [clo, chi] that lies in that half.
+    const int ncombo = 1 << G.nsplit;
+    auto part = [&](int i, int cb, int& lo, int& hi) {        // the cells of axis i < L in half-block combination cb
+        lo = clo[i]; hi = chi[i];
+        if (i < G.nsplit) {
+            if ((cb >> (G.nsplit - 1 - i)) & 1) lo = max(lo, G.split[i]); else hi = min(hi, G.split[i] - 1);
+        }
+    };
+    auto combo_rows = [&](int cb) -> uint32_t {
+        uint32_t n = 1;
 #pragma unroll
-    for (int i = 0; i < L; ++i) rows *= (uint32_t)(chi[i] - clo[i] + 1);
+        for (int i = 0; i < L; ++i) { int lo, hi; part(i, cb, lo, hi); n *= (uint32_t)max(hi - lo + 1, 0); }
+        return n;
+    };
+    uint32_t rows = 0;                                    // <= number of grid cells <= 2^24
+    for (int cb = 0; cb < ncombo; ++cb) rows += combo_rows(cb);
 
     uint32_t* __restrict__ out = lists + tl * list_cap;
     // (NW > 1: the wavefront's kept ids are staged in LDS -- or, when the lists are too long for it, in a global scratch area)
@@ -232,7 +215,7 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
     // half build: only chunks >= the tile are wanted.  Rows come in ascending cell order, so every row before the one that holds
     // the tile's first sample lies wholly before the tile: the enumeration starts at that row
     uint32_t rows_lo = 0;
-    if (half && tile_begin == 0) {                            // (a shard keeps the chunks of the shards before it: every row is enumerated)
+    if (half && tile_begin == 0 && G.nsplit == 0) {           // (a shard keeps the chunks of the shards before it: every row is enumerated)
         int64_t cid = (int64_t)(cellkey[tile * 64] >> fb);    // (a tile's first sample is never a pad)
         uint32_t mul = 1;
 #pragma unroll
@@ -251,15 +234,19 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
         int32_t ca = 0, n = 0;
         if (row < row_end) {
             uint32_t rem = row;
+            int cbi = 0;
+            for (; cbi < ncombo - 1; ++cbi) { const uint32_t n = combo_rows(cbi); if (rem < n) break; rem -= n; }
             int64_t cbase = 0;
             double partial = 0.0, pa = 0.0, pb = 0.0;      // row cell vs the hull / sub-box A / sub-box B
 #pragma unroll
             for (int i = L - 1; i >= 0; --i) {
-                const uint32_t span = (uint32_t)(chi[i] - clo[i] + 1);
+                int plo, phi;
+                part(i, cbi, plo, phi);
+                const uint32_t span = (uint32_t)max(phi - plo + 1, 1);
                 const uint32_t qd = rem / span;
-                const int c = clo[i] + (int)(rem - qd * span);
+                const int c = plo + (int)(rem - qd * span);
                 rem = qd;
-                cbase += (int64_t)c * G.stride[i];
+                cbase += mpfmt_cell_term(G, i, c);
                 const double eps = G.w[i] * 1e-9;
                 const double lo = G.lo[i] + (double)c * G.w[i] - eps;
                 const double hi = G.lo[i] + (double)(c + 1) * G.w[i] + eps;
@@ -398,12 +385,14 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
 template <int D>
 __global__ __launch_bounds__(256) void k_sample_masks(const double* __restrict__ Xs, const double* __restrict__ tile_lo, const double* __restrict__ tile_hi,
                                                       int64_t tile_begin, int64_t nt, double rpad, const double* __restrict__ boxes, int M,
-                                                      unsigned long long* __restrict__ smask, unsigned long long* __restrict__ tile_bs)
+                                                      unsigned long long* __restrict__ smask, unsigned long long* __restrict__ tile_bs,
+                                                      const uint8_t* __restrict__ tileneed)
 {
     const int lane = threadIdx.x & 63;
     const int64_t tl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tl >= nt) return;
     const int64_t tile = tile_begin + tl;
+    if (tileneed && !tileneed[tile]) return;                  // (a tile this rank never reads: shard + halo index)
     const double rm = rpad * (1.0 + 1e-6) + 1e-300;
     double xl[D], xh[D], ulo[D], uhi[D];
 #pragma unroll
@@ -464,7 +453,7 @@ int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r)
     if (nt <= 0 || ctx->tile_end <= ctx->tile_begin) return MPFMT_OK;
     const double rpad = r * (1.0 + 1e-9) + 1e-300;
 #define CASE(DD) case DD: hipLaunchKernelGGL((k_sample_masks<DD>), dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, ctx->stream, ctx->Xs, ctx->tile_lo, ctx->tile_hi, \
-        (int64_t)0, nt, rpad, ctx->boxes, ctx->M, (unsigned long long*)ctx->smask, (unsigned long long*)ctx->smask + ctx->ntiles * 64); break;
+        (int64_t)0, nt, rpad, ctx->boxes, ctx->M, (unsigned long long*)ctx->smask, (unsigned long long*)ctx->smask + ctx->ntiles * 64, (const uint8_t*)ctx->tileneed); break;
     switch (ctx->d) { CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) default: break; }
 #undef CASE
     HIPCHK(ctx, hipGetLastError());
@@ -1196,7 +1185,7 @@ int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx)
     if (npad == 0) return MPFMT_OK;
     const int B = 256;
     hipLaunchKernelGGL(k_make_ops, dim3((unsigned)((npad + B - 1) / B)), dim3(B), 0, ctx->stream,
-                       ctx->Xs, ctx->N, npad, ctx->d, ctx->grid, ctx->mf_scale, (uint4*)ctx->ops);
+                       ctx->Xs, ctx->N, npad, ctx->d, ctx->grid, ctx->mf_scale, ctx->ops);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
@@ -1221,7 +1210,9 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
     for (int attempt = 0; attempt < 4; ++attempt) {
         if ((double)cap * (double)nt * 4.0 > 32e9) { *usable = false; return MPFMT_OK; }
         if ((rc = mpfmt_ensure(ctx, (void**)&ctx->lists, sizeof(uint32_t) * (size_t)cap * (size_t)nt))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->list_len + nt, 0, sizeof(int32_t), ctx->stream));
+        // (the longest list's word lives in the index arena: zeroed by the index build's one fill, again here only when used since)
+        if (!ctx->list_max_clean) HIPCHK(ctx, hipMemsetAsync(ctx->list_max, 0, sizeof(int32_t), ctx->stream));
+        ctx->list_max_clean = false;
         const mpfmt_grid& G = ctx->grid;
         // few tiles (a small shard): four wavefronts per tile, kept ids staged in LDS (4 x cap x 4 bytes) -- in a global scratch area when
         // the lists are longer than LDS takes at a useful occupancy (a shard's lists hold every chunk of the OTHER shards: ~4 500 entries)
@@ -1230,9 +1221,9 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
         if (gst && (rc = mpfmt_ensure(ctx, (void**)&ctx->lists_stage, sizeof(uint32_t) * (size_t)cap * 4 * (size_t)nt))) return rc;
         uint32_t* const gstage = gst ? (uint32_t*)ctx->lists_stage : nullptr;
 #define CASE(DD) case DD: if (wide) hipLaunchKernelGGL((k_chunk_lists<DD, 4>), dim3((unsigned)nt), dim3(256), gst ? (size_t)0 : (size_t)cap * 16, ctx->stream, ctx->cellstart, \
-            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt, half ? 1 : 0, ctx->cellkey, ctx->cell_fb, gstage); \
+            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_max, half ? 1 : 0, ctx->cellkey, ctx->cell_fb, gstage); \
         else hipLaunchKernelGGL((k_chunk_lists<DD, 1>), dim3((unsigned)nt), dim3(64), 0, ctx->stream, ctx->cellstart, \
-            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_len + nt, half ? 1 : 0, ctx->cellkey, ctx->cell_fb, (uint32_t*)nullptr); break;
+            ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32, G, rpad, ctx->tile_begin, nt, cap, (uint32_t*)ctx->lists, ctx->list_len, ctx->list_max, half ? 1 : 0, ctx->cellkey, ctx->cell_fb, (uint32_t*)nullptr); break;
         switch (ctx->d) {
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
             default: return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path supports d <= 12 (got %d)", ctx->d);
@@ -1247,7 +1238,7 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
             return MPFMT_OK;
         }
         int32_t mx = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&mx, ctx->list_len + nt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(&mx, ctx->list_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (mx <= cap) {
             ctx->lists_cap_trusted = cap;

@@ -194,11 +194,12 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     // (refused while another thread's open group still has to post this ctx's gather: the ctx stays whole and usable)
     { const int32_t rc = mpfmt_comm_destroy(ctx); if (rc) return rc; }
     if (ctx->zarena) { hipFree(ctx->zarena); ctx->d_pairs = nullptr; ctx->pool_flag = nullptr; ctx->pair_cnt = nullptr; }      // (they point into it)
-    void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->cellstart, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32,
+    void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->idx_arena, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
                     ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->qkey, ctx->qd2, ctx->qlen, ctx->smask, ctx->st_best, ctx->st_besti, ctx->st_nfree, ctx->pend_items, ctx->pend_cnt, ctx->pair_items, ctx->pair_cnt, ctx->lists, ctx->list_len, ctx->lists_stage, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev, ctx->bb_dev};
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
+    if (ctx->export_arena) hipHostFree(ctx->export_arena);
     if (ctx->bb_host) hipHostFree(ctx->bb_host);
     for (int k = 0; k < 2; ++k) { if (ctx->copy_stream[k]) hipStreamDestroy(ctx->copy_stream[k]); if (ctx->ev_conv[k]) hipEventDestroy(ctx->ev_conv[k]); if (ctx->ev_copy[k]) hipEventDestroy(ctx->ev_copy[k]); }
     mpfmt_wf_free(ctx);
@@ -229,6 +230,7 @@ int32_t mpfmt_set_shard(mpfmt_ctx* ctx, int32_t rank, int32_t world)
     if (!ctx) return MPFMT_ERR_ARG;
     if (world < 1 || rank < 0 || rank >= world) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "bad shard %d of %d", rank, world);
     ctx->rank = rank; ctx->world = world;
+    ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0;      // (the cell order and the built part of the index belong to the shard)
     ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
     return MPFMT_OK;
 }
@@ -861,6 +863,46 @@ int32_t mpfmt_graph_export(mpfmt_ctx* ctx, int64_t* colptr, int64_t* rowval, dou
     const double bytes = 8.0 * (double)(N + 1) + 16.0 * (double)nnz + (mask ? (double)((nnz + 63) / 64) * 8.0 : 0.0);
     if (gb_per_s) *gb_per_s = sec > 0.0 ? bytes / sec / 1e9 : 0.0;
     return MPFMT_OK;
+}
+
+// Page-locked export arena that lives as long as the ctx (grow-only, freed by mpfmt_ctx_destroy): page-locking gigabytes costs
+// ~0.2 s per GB (hipHostMalloc), far more than the copy it speeds up -- paid once per ctx here, not once per graph.
+int32_t mpfmt_export_arena(mpfmt_ctx* ctx, int64_t bytes, void** out)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!out || bytes < 0) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "mpfmt_export_arena: bad arguments");
+    *out = nullptr;
+    if ((size_t)bytes > ctx->export_arena_bytes) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        if (ctx->export_arena) { HIPCHK(ctx, hipHostFree(ctx->export_arena)); ctx->export_arena = nullptr; ctx->export_arena_bytes = 0; }
+        // (an eighth of slack: the next graph of the same problem -- new samples, new obstacles -- finds its room in place)
+        const size_t want = (size_t)bytes + (size_t)bytes / 8 + 4096;
+        HIPCHK(ctx, hipHostMalloc(&ctx->export_arena, want, hipHostMallocDefault));
+        ctx->export_arena_bytes = want;
+    }
+    *out = ctx->export_arena;
+    return MPFMT_OK;
+}
+
+// mpfmt_graph_export into the ctx's own arena: the four arrays are carved out of it (64-byte aligned) and stay valid until the next
+// export of this ctx or its destruction -- the drop-in precompute! of julia/MPFmtHIP.jl wraps them without a copy.
+int32_t mpfmt_graph_export_pinned(mpfmt_ctx* ctx, int64_t** colptr, int64_t** rowval, double** nzval, uint64_t** mask, int64_t* nnz_out, double* gb_per_s)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!colptr || !rowval || !nzval) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "colptr / rowval / nzval is NULL");
+    if (!ctx->graph_filled) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no resident graph (mpfmt_graph_step_device / mpfmt_graph_build_device)");
+    const int64_t N = ctx->N, nnz = ctx->nnz, words = (nnz + 63) / 64;
+    auto al = [](size_t b) { return (b + 63) & ~(size_t)63; };
+    const size_t o_cp = 0, o_rv = al(8 * (size_t)(N + 1)), o_nz = o_rv + al(8 * (size_t)std::max<int64_t>(nnz, 1));
+    const size_t o_mk = o_nz + al(8 * (size_t)std::max<int64_t>(nnz, 1)), total = o_mk + al(8 * (size_t)std::max<int64_t>(words, 1));
+    void* base = nullptr;
+    int32_t rc;
+    if ((rc = mpfmt_export_arena(ctx, (int64_t)total, &base))) return rc;
+    char* b = (char*)base;
+    *colptr = (int64_t*)(b + o_cp); *rowval = (int64_t*)(b + o_rv); *nzval = (double*)(b + o_nz);
+    if (mask) *mask = (uint64_t*)(b + o_mk);
+    if (nnz_out) *nnz_out = nnz;
+    return mpfmt_graph_export(ctx, *colptr, *rowval, *nzval, mask ? *mask : nullptr, gb_per_s);
 }
 
 int32_t mpfmt_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** rowval, void** nzval, void** free_mask)
@@ -1607,6 +1649,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
     }
     if (strcmp(name, "mf_ablate") == 0) { ctx->mf_ablate = (int32_t)value; return MPFMT_OK; }
     if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }
+    if (strcmp(name, "index_halo") == 0) { ctx->index_halo = value != 0; ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; return MPFMT_OK; }
     if (strcmp(name, "lists_wide") == 0) { ctx->lists_wide = (int32_t)value; ctx->lists_r = -1.0; return MPFMT_OK; }
     if (strcmp(name, "cell_fb_max") == 0) { ctx->cell_fb_max = (int32_t)std::min<int64_t>(8, std::max<int64_t>(0, value)); ctx->grid_r = -1.0; return MPFMT_OK; }
     if (strcmp(name, "mf_target_items") == 0) { ctx->mf_target_items = value; return MPFMT_OK; }
@@ -1655,7 +1698,7 @@ int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value)
         const int64_t nt = ctx->tile_end - ctx->tile_begin;
         if (ctx->list_len && nt > 0) {
             int32_t v = 0;
-            HIPCHK(ctx, hipMemcpyAsync(&v, ctx->list_len + nt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(&v, ctx->list_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             *value = v;
         }

@@ -18,17 +18,42 @@ struct mpfmt_timer {
 
 // Geometry of the uniform cell grid that bins the samples for one radius (host copy; passed by value
 // to kernels).  Cells are at least r wide in every gridded dimension, so the neighbours of a point in
-// cell c lie in cells c-1..c+1.  Linear cell id is row-major with the LAST gridded dimension fastest,
-// so a run of cells along that dimension is a contiguous range of the cell-sorted sample array.
+// cell c lie in cells c-1..c+1.
+// Cell ids.  Unsharded: row-major with the LAST dimension fastest, so a run of cells along that dimension is a contiguous
+// range of the cell-sorted sample array.  Sharded (world > 1): BLOCK-MAJOR -- the leading nsplit axes are cut in two at a cell
+// boundary (cells [0, split) | [split, g)), the id's most significant digits say which half of each cut axis a cell lies in
+// (axis 0 first), and inside such a half-block the order is the row-major one above.  An index range of the cell-sorted order
+// is then a compact block of space (0.5^3 x 1^3 at 8 shards in R^6) instead of a slab thinner than r, which is what decides
+// how many edges join two shards.  The last axis is never cut (runs along it stay contiguous); a cut axis with an odd cell
+// count leaves holes in the id range (ids of cells that do not exist: empty).
 struct mpfmt_grid {
     int32_t gd;                          // dims are all gridded; g[i] == 1 means "not split"
     int32_t g[MPFMT_MAX_DIM];            // cells per dimension
     double  lo[MPFMT_MAX_DIM];           // lower corner of the sample bounding box
     double  w[MPFMT_MAX_DIM];            // cell width
     double  inv_w[MPFMT_MAX_DIM];
-    int64_t stride[MPFMT_MAX_DIM];       // linear-id stride per dimension
-    int64_t ncells;
+    int64_t stride[MPFMT_MAX_DIM];       // id stride per dimension inside a half-block
+    int32_t split[MPFMT_MAX_DIM];        // 0: the axis is not cut; else the first cell of its upper half
+    int32_t ext[MPFMT_MAX_DIM];          // cells per dimension of a half-block's id range (split, or g when not cut)
+    int64_t hstride[MPFMT_MAX_DIM];      // id offset of the upper half of a cut axis
+    int32_t nsplit;                      // cut axes (the leading ones: 0 .. nsplit-1)
+    int64_t inner;                       // ids per half-block
+    int64_t ncells;                      // id range = inner << nsplit
 };
+// contribution of cell coordinate c of axis i to the cell id
+__host__ __device__ __forceinline__ int64_t mpfmt_cell_term(const mpfmt_grid& G, int i, int c)
+{
+    const int s = G.split[i];
+    return (s > 0 && c >= s) ? G.hstride[i] + (int64_t)(c - s) * G.stride[i] : (int64_t)c * G.stride[i];
+}
+// cell coordinate of axis i out of a cell id (may be >= g[i] for a hole of the block-major id range)
+__host__ __device__ __forceinline__ int mpfmt_cell_coord(const mpfmt_grid& G, int i, int64_t id)
+{
+    const int64_t in = id % G.inner;
+    int c = (int)((in / G.stride[i]) % G.ext[i]);
+    if (G.split[i] > 0 && ((id / G.hstride[i]) & 1)) c += G.split[i];
+    return c;
+}
 
 struct mpfmt_boxes_dev {                 // obstacle set in HBM: [M][2][dw] (lo then hi per box)
     const double* lohi;
@@ -59,6 +84,8 @@ struct mpfmt_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t copy_stream[2] = {nullptr, nullptr};      // mpfmt_graph_export: two device-to-host streams and their hand-over events
     hipEvent_t ev_conv[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
+    void* export_arena = nullptr;        // page-locked host memory of mpfmt_graph_export_pinned (grow-only, lives as long as the ctx)
+    size_t export_arena_bytes = 0;
     std::string err;
     int rank = 0, world = 1;
 
@@ -77,7 +104,20 @@ struct mpfmt_ctx {
     int32_t* perm = nullptr;             // [ntiles*64] sorted position -> original index (pad = -1)
     int32_t* iperm = nullptr;            // [N] original index -> sorted position
     uint32_t* cellkey = nullptr;         // [N] cell id of each sorted position
-    int32_t* cellstart = nullptr;        // [ncells+1]
+    // one arena, one fill per index build: cellstart [ncells + 1] (the cells' counters, scanned in place) | list_max (longest chunk list,
+    // k_chunk_lists) | tileneed [ntiles] bytes
+    void* idx_arena = nullptr;
+    int32_t* cellstart = nullptr;        // [ncells+1] (inside idx_arena)
+    int32_t* list_max = nullptr;         // (inside idx_arena)
+    bool list_max_clean = false;         // zeroed by the index build's fill and not written since
+    // sharded ctx on the matrix-core path: only the tiles this rank reads are built -- its own and the halo (the tiles of the cells next
+    // to its own cells); tileneed [ntiles] marks them (nullptr: the index is whole)
+    uint8_t* tileneed = nullptr;
+    uint8_t* tileneed_buf = nullptr;     // (inside idx_arena)
+    int32_t index_halo = 1;              // option: allow the shard + halo index
+    int index_rank = 0, index_world = 1; // the shard the index was built for
+    std::vector<double> cut_frac;        // shard boundaries as fractions of the cell-sorted order (cut_key: the geometry they belong to)
+    std::vector<int64_t> cut_key;
     double* Xt = nullptr;                // [ntiles][d][64] tiled SoA, cell-sorted, NaN padded
     double* tile_lo = nullptr;           // [ntiles][d] tight bounding box of each tile
     double* tile_hi = nullptr;
@@ -270,7 +310,7 @@ struct mpfmt_timed {
 };
 
 // kernels_rdisc.hip -----------------------------------------------------------------------------
-int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r);
+int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r, bool whole = false);      // whole: every tile is built even on a sharded ctx
 int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r);
 int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec);
 int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed);

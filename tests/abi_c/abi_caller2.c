@@ -22,6 +22,8 @@ typedef int32_t (*f_group)(void);
 typedef int32_t (*f_step_device)(void*, double, int64_t*);                         /* (Ptr{Void}, Float64, Ptr{Int64}) */
 typedef int32_t (*f_pinned_alloc)(int64_t, void**);                                /* (Int64, Ptr{Ptr{Void}}) */
 typedef int32_t (*f_pinned_free)(void*);                                           /* (Ptr{Void},) */
+typedef int32_t (*f_export_pinned)(void*, int64_t**, int64_t**, double**, uint64_t**, int64_t*, double*);
+                                                                                 /* (Ptr{Void}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{UInt64}}, Ptr{Int64}, Ptr{Float64}) */
 typedef int32_t (*f_export)(void*, int64_t*, int64_t*, double*, uint64_t*, double*);   /* (Ptr{Void}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{UInt64}, Ptr{Float64}) */
 /* helper_data_structures(V, ::LinearQuadratic), hip_di_edges_free */
 typedef int32_t (*f_di_count)(void*, double, double, int64_t*, int64_t*);          /* (Ptr{Void}, Float64, Float64, Ptr{Int64}, Ptr{Int64}) */
@@ -66,6 +68,7 @@ int main(int argc, char** argv)
     f_pinned_alloc pinned_alloc = (f_pinned_alloc)mpfmt_pinned_alloc;
     f_pinned_free pinned_free = (f_pinned_free)mpfmt_pinned_free;
     f_export graph_export = (f_export)mpfmt_graph_export;
+    f_export_pinned graph_export_pinned = (f_export_pinned)mpfmt_graph_export_pinned;
 
     FILE* in = fopen(argv[1], "rb");
     if (!in) { perror(argv[1]); return 2; }
@@ -169,6 +172,18 @@ int main(int argc, char** argv)
             CHECK(graph_export(ctx, (int64_t*)pp[0], (int64_t*)pp[1], (double*)pp[2], (uint64_t*)pp[3], &rate));
             put(out, &nnz, 8); put(out, pp[0], 8 * (Ns + 1)); put(out, pp[1], 8 * nnz); put(out, pp[2], 8 * nnz); put(out, pp[3], 8 * words);
             for (int k = 0; k < 4; ++k) if (pinned_free(pp[k]) != 0) { fprintf(stderr, "pinned_free failed\n"); return 3; }
+            /* hip_precompute_step!: the same export into the ctx's own page-locked arena, twice -- the second call must hand out the
+             * same memory (the arena lives as long as the ctx) and the same graph */
+            int64_t *ac = NULL, *ar = NULL; double* av = NULL; uint64_t* am = NULL; int64_t annz = -1;
+            CHECK(graph_export_pinned(ctx, &ac, &ar, &av, &am, &annz, &rate));
+            int64_t *bc = NULL, *br = NULL; double* bv = NULL; uint64_t* bm = NULL; int64_t bnnz = -1;
+            CHECK(graph_export_pinned(ctx, &bc, &br, &bv, &bm, &bnnz, &rate));
+            const int64_t same = (ac == bc && ar == br && av == bv && am == bm && annz == nnz && bnnz == nnz) ? 1 : 0;
+            void* arena = NULL;
+            CHECK(mpfmt_export_arena(ctx, 64, &arena));
+            const int64_t base_same = ((void*)ac == arena) ? 1 : 0;
+            put(out, &same, 8); put(out, &base_same, 8);
+            put(out, bc, 8 * (Ns + 1)); put(out, br, 8 * nnz); put(out, bv, 8 * nnz); put(out, bm, 8 * words);
         }
     }
     /* ---- 2-D SAT world: shapes uploaded, point and segment validity on the query points ---- */

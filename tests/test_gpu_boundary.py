@@ -164,6 +164,11 @@ def test_c_caller_of_the_other_spaces(orc, tmp_path):
     oc, orow, oval = orc.rdisc_graph(Xs, r_e)
     assert nnz == len(orow) and np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow) and np.array_equal(nzval, oval)
     assert np.array_equal(fr, orc.graph_edges_free(Xs, oc, orow, lohi2, lo2, hi2))
+    # ... and the same through mpfmt_graph_export_pinned, twice: the ctx's page-locked arena is handed out again, not allocated again
+    same, base_same = take(np.int64, 2)
+    assert same == 1 and base_same == 1
+    c2, r2, v2, f2 = take(np.int64, Ns + 1), take(np.int64, nnz), take(np.float64, nnz), take(np.uint64, (nnz + 63) // 64)
+    assert np.array_equal(c2, colptr) and np.array_equal(r2, rowval) and np.array_equal(v2, nzval) and np.array_equal(f2, fr)
     # 2-D SAT world
     S = orc.Shapes2D([("circle", tuple(s[1]), s[2]) if s[0] == "circle" else ("polygon", [tuple(q) for q in s[1]]) for s in fx])
     mpt, mseg = take(np.uint64, (nq + 63) // 64), take(np.uint64, (nq - 1 + 63) // 64)
