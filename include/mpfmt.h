@@ -421,6 +421,9 @@ MPFMT_API int32_t mpfmt_shard_info(mpfmt_ctx* ctx, int64_t* col_begin, int64_t* 
  *              FMT* tree of the same graph whose cost can exceed the sequential one slightly (reported by the tests / bench).
  *        flags & MPFMT_WF_EAGER  : answer edge tests from the swept graph mask (mpfmt_graph_step_device) instead of testing
  *              lazily; forced for checkers without a lane-per-obstacle form here (2-D SAT world, non-identity workspace).
+ *              Without the flag the mask is still USED when a step left one for this graph and obstacle set (an edge's bit is a
+ *              pure function of the edge: tree, costs and collision_checks are the lazy loop's) -- never computed for the solve.
+ *        flags & MPFMT_WF_LAZY   : test every asked-for edge against the obstacle set even when a mask is resident (measurements).
  *      mpfmt_fmtstar_wavefront = begin + steps until done + finish.  A / C / path may be NULL (skips the 12 N-byte copy).
  *      Step-wise form (tests, drivers that interleave other work): wf_begin, wf_step ... until info.done, wf_finish;
  *      wf_state copies the sets out (W, H as the next step will see them; A 1-based, 0 = none), wf_batch the z of the
@@ -431,6 +434,7 @@ MPFMT_API int32_t mpfmt_shard_info(mpfmt_ctx* ctx, int64_t* col_begin, int64_t* 
  *      made by the caller: wf_step on every ctx, wf_triples from each, wf_commit of all of them to each. */
 #define MPFMT_WF_SINGLE 1
 #define MPFMT_WF_EAGER  2
+#define MPFMT_WF_LAZY   4
 typedef struct {
     int32_t done;              /* 0 running, 1 goal reached (:solved), 2 open set exhausted (:failed) */
     int32_t nz;                /* batch size of the last step */

@@ -41,7 +41,7 @@ class WfInfo(C.Structure):
                 ("tot_conn", C.c_int64)]
 
 
-WF_SINGLE, WF_EAGER = 1, 2
+WF_SINGLE, WF_EAGER, WF_LAZY = 1, 2, 4
 COMM_ID_BYTES = 128
 
 # every symbol include/mpfmt.h declares: (name, restype, argtypes)
@@ -474,7 +474,7 @@ class Context:
                     nnz=int(res.nnz), ms_graph=res.ms_graph, ms_sweep=res.ms_sweep, ms_host_loop=res.ms_host_loop,
                     A=None if A is None else A[:self.N], C=None if Cc is None else Cc[:self.N], path=path[:res.path_len].copy())
 
-    def fmtstar_wavefront(self, r, goal_kind, goal_params, band=0.0, single=False, eager=False, init_idx=1, checkpts=True,
+    def fmtstar_wavefront(self, r, goal_kind, goal_params, band=0.0, single=False, eager=False, lazy=False, init_idx=1, checkpts=True,
                           want_tree=True):
         """fmtstar! with the recursion on the device (include/mpfmt.h): band = cost width of a batch; single = one node per
         step (the reference's order exactly)."""
@@ -483,16 +483,16 @@ class Context:
         Cc = np.empty(max(self.N, 1), dtype=np.float64) if want_tree else None
         path = np.empty(max(self.N, 1), dtype=np.int64)
         res, info = FmtResult(), WfInfo()
-        flags = (WF_SINGLE if single else 0) | (WF_EAGER if eager else 0)
+        flags = (WF_SINGLE if single else 0) | (WF_EAGER if eager else 0) | (WF_LAZY if lazy else 0)
         self._chk(self._L.mpfmt_fmtstar_wavefront(self._h, float(r), int(init_idx), int(bool(checkpts)), int(goal_kind), _dp(g), float(band),
                                                   flags, _ip(A), _dp(Cc), _ip(path), C.byref(res), C.byref(info)))
         out = self._fmt_out(res, A, Cc, path)
         out["info"] = self._wf_info(info)
         return out
 
-    def wf_begin(self, r, goal_kind, goal_params, band=0.0, single=False, eager=False, init_idx=1, checkpts=True):
+    def wf_begin(self, r, goal_kind, goal_params, band=0.0, single=False, eager=False, init_idx=1, checkpts=True, lazy=False):
         g = np.ascontiguousarray(goal_params, dtype=np.float64)
-        flags = (WF_SINGLE if single else 0) | (WF_EAGER if eager else 0)
+        flags = (WF_SINGLE if single else 0) | (WF_EAGER if eager else 0) | (WF_LAZY if lazy else 0)
         self._chk(self._L.mpfmt_wf_begin(self._h, float(r), int(init_idx), int(bool(checkpts)), int(goal_kind), _dp(g), float(band), flags))
 
     def wf_step(self):

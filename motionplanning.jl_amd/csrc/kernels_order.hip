@@ -84,6 +84,7 @@ struct ord_args {
     unsigned long long* mask;    // rec_bits: free bit per CSC entry, preset to ones
     const int64_t* nnz_dev;      // colptr + N
     uint4* pend_items; int64_t pend_wcap; int32_t* pend_cnt; int32_t* pend_over;
+    int64_t* deg_clear;          // sharded ctx: the degree array by sample index, whose entries of this shard are put back to zero here
     int rec_bits;                // k_exact_pairs has marked the keys of blocked edges (bit 31): their entries' bits are cleared in the mask
 };
 
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
             const int64_t sp = a.tile_begin * 64 + qi * ORD_COLS + tid;
             ho = a.perm[sp];
             hk = (int)a.degs[sp];
+            if (a.deg_clear && ho >= 0) a.deg_clear[ho] = 0;      // (read by the colptr scan before this kernel; zero again for the next step)
         } else if (tid == 64) {
             hln = (int)min((long long)a.qlen[qi], a.qcap);
         }
@@ -480,6 +482,7 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail, int64_t mask_
     a.mask = (unsigned long long*)ctx->graph_free; a.nnz_dev = ctx->colptr + ctx->N;
     a.pend_items = pend ? (uint4*)ctx->pend_items : nullptr; a.pend_wcap = ctx->pend_wcap; a.pend_cnt = ctx->pend_cnt; a.pend_over = ctx->pend_over;
     a.rec_bits = recbits ? 1 : 0;
+    a.deg_clear = ctx->world > 1 ? ctx->deg : nullptr;
     hipLaunchKernelGGL(k_order_logs, dim3(nb), dim3(ORD_THREADS), lds, ctx->stream, a);
     HIPCHK(ctx, hipGetLastError());
     if (pend) ctx->pend_nseg = (int)nb;

@@ -56,6 +56,9 @@ __device__ __forceinline__ int cell_of(double x, double lo, double inv_w, int g)
 //   k_cell_scatter  : (fine bits, sample index) of every sample to cellstart[cell] + arrival number
 //   k_cell_order    : one wavefront per cell puts the cell's items in ascending order
 // ------------------------------------------------------------------------------------------------
+// (the counting atomic returns the sample's arrival number in its cell: the scatter needs no atomic of its own.  A plain count with
+// the scatter drawing its own numbers -- only a third of the samples is scattered on a rank of eight -- measured slower at every
+// shard count: 1.12 vs 1.07 ms per step at 8 ranks, 3.66 vs 3.62 unsharded)
 __global__ void k_cellkey_count(const double* __restrict__ Xo, int64_t N, int d, mpfmt_grid G, int fb,
                                 uint32_t* __restrict__ key, uint32_t* __restrict__ slot, int32_t* __restrict__ cellcnt)
 {
@@ -108,12 +111,32 @@ __device__ __forceinline__ T scan4096(const T* in, T* out, int64_t base, int64_t
     for (int k = 0; k < 4; ++k) { if (i0 + k < n) out[i0 + k] = o; o += v[k]; }
     return s_w[16];
 }
+// one workgroup, one pass: thread = a contiguous segment of ceil(n / 1024) items (summed, then written behind the scanned thread totals)
+// -- the few thousand cell counters / block sums this serves sit in L2; a loop of 4096-item rounds cost a barrier chain per round
 template <typename T>
 __global__ __launch_bounds__(1024) void k_scan_single(const T* in, T* out, int64_t n)
 {
     __shared__ T s_w[17];
-    T carry = 0;
-    for (int64_t base = 0; base < n; base += 4096) carry += scan4096<T>(in, out, base, n, carry, s_w);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t seg = (n + 1023) / 1024;
+    const int64_t i0 = (int64_t)tid * seg, i1 = min(n, i0 + seg);
+    T t = 0;
+    for (int64_t i = i0; i < i1; ++i) t += in[i];
+    T inc = t;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const T u = __shfl_up(inc, off); if (lane >= off) inc += u; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        T x = lane < 16 ? s_w[lane] : (T)0;
+        const T own = x;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { const T u = __shfl_up(x, off); if (lane >= off) x += u; }
+        if (lane < 16) s_w[lane] = x - own;
+    }
+    __syncthreads();
+    T o = s_w[wave] + inc - t;
+    for (int64_t i = i0; i < i1; ++i) { const T v = in[i]; out[i] = o; o += v; }
 }
 template <typename T>
 __global__ __launch_bounds__(1024) void k_scan_block(const T* in, T* out, int64_t n, T* __restrict__ bsum)
@@ -135,7 +158,7 @@ template <typename T>
 static void launch_scan(hipStream_t st, const T* in, T* out, int64_t n, T* bsum)
 {
     const int64_t nsb = (n + 4095) / 4096;
-    if (nsb <= 16) {
+    if (nsb <= 32) {
         hipLaunchKernelGGL((k_scan_single<T>), dim3(1), dim3(1024), 0, st, in, out, n);
     } else {
         hipLaunchKernelGGL((k_scan_block<T>), dim3((unsigned)nsb), dim3(1024), 0, st, in, out, n, bsum);
@@ -160,15 +183,17 @@ __device__ __forceinline__ bool cell_wanted(const uint8_t* __restrict__ tileneed
 // being at least r wide.  One workgroup per cell id; the workgroups of own cells mark the tiles of all their neighbours (thread =
 // neighbour offset).  Tiles left unmarked are never built: they get empty boxes, which every candidate test rejects.
 __global__ __launch_bounds__(256) void k_cell_need(const int32_t* __restrict__ cellstart, mpfmt_grid G, int d, int64_t pos_b, int64_t pos_e,
-                                                   int64_t noff, uint8_t* __restrict__ tileneed)
+                                                   int64_t noff, int64_t ncells, uint8_t* __restrict__ tileneed)
 {
-    const int64_t id = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);             // one wavefront per cell id
+    if (id >= ncells) return;
     const int64_t cs = cellstart[id], ce = cellstart[id + 1];
     // own cell <=> it holds a position of [pos_b, pos_e)
     if (ce <= cs || ce <= pos_b || cs >= pos_e) return;
     int c[MPFMT_MAX_DIM];
     for (int i = 0; i < d; ++i) c[i] = mpfmt_cell_coord(G, i, id);
-    for (int64_t t = threadIdx.x; t < noff; t += blockDim.x) {
+    for (int64_t t = lane; t < noff; t += 64) {
         int64_t rem = t, nid = 0;
         bool ok = true;
         for (int i = d - 1; i >= 0; --i) {
@@ -575,12 +600,11 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r, bool whole)
         HIPCHK(ctx, hipMemsetAsync(ctx->idx_arena, 0, ctx->tileneed ? arena_bytes : arena_cells, ctx->stream));
         ctx->list_max_clean = true;
         const int B = 256;
-        hipLaunchKernelGGL(k_cellkey_count, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream,
-                           ctx->Xo, N, d, G, fb, key, slot, ctx->cellstart);
+        hipLaunchKernelGGL(k_cellkey_count, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream, ctx->Xo, N, d, G, fb, key, slot, ctx->cellstart);
         launch_scan<int32_t>(ctx->stream, (const int32_t*)ctx->cellstart, ctx->cellstart, G.ncells + 1, bsum);
         if (ctx->tileneed)
-            hipLaunchKernelGGL(k_cell_need, dim3((unsigned)G.ncells), dim3(256), 0, ctx->stream, (const int32_t*)ctx->cellstart, G, d,
-                               ctx->tile_begin * 64, std::min<int64_t>(ctx->tile_end * 64, N), noff, ctx->tileneed);
+            hipLaunchKernelGGL(k_cell_need, dim3((unsigned)((G.ncells + 3) / 4)), dim3(256), 0, ctx->stream, (const int32_t*)ctx->cellstart, G, d,
+                               ctx->tile_begin * 64, std::min<int64_t>(ctx->tile_end * 64, N), noff, G.ncells, ctx->tileneed);
         hipLaunchKernelGGL(k_cell_scatter, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream, (const uint32_t*)key, (const uint32_t*)slot, N, fb,
                            (const int32_t*)ctx->cellstart, (const uint8_t*)ctx->tileneed, items);
         hipLaunchKernelGGL(k_cell_order, dim3((unsigned)((G.ncells + 3) / 4)), dim3(256), 0, ctx->stream, (const int32_t*)ctx->cellstart, G.ncells, fb, pbits,
@@ -949,31 +973,39 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     ctx->S = S;
     const int64_t npad = ctx->ntiles * 64;
     if ((rc = ensure(ctx, (void**)&ctx->slice_cnt, sizeof(int32_t) * (size_t)S * npad))) return rc;      // (per-slice counts: the two-pass forms)
-    if ((rc = ensure(ctx, (void**)&ctx->deg, sizeof(int64_t) * (N + 1)))) return rc;
+    { const int64_t* was = ctx->deg; if ((rc = ensure(ctx, (void**)&ctx->deg, sizeof(int64_t) * (N + 1)))) return rc; if (ctx->deg != was) ctx->deg_zero_valid = false; }
     if ((rc = ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (N + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->degs, sizeof(int64_t) * (npad + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->tptr, sizeof(int64_t) * (npad + 1)))) return rc;
     // The small per-build counters live in ONE arena zeroed by ONE fill: 512 pair counters + the longest column's
     // word (k_degree), the logs' overflow flag, the pending-pair list's region counters + its overflow flag.  (A ctx whose counters
     // were allocated one by one before -- by the steering spaces' builds -- keeps them and their separate fills.)
-    constexpr size_t ZA_PAIRS = 0, ZA_FLAG = 4128, ZA_PCNT = 4160, ZA_BYTES = 4160 + 4112;
-    if (!ctx->zarena && !ctx->d_pairs && !ctx->pool_flag && !ctx->pair_cnt) {
-        HIPCHK(ctx, hipMalloc((void**)&ctx->zarena, ZA_BYTES));
+    // (... and the quarter logs' cursors behind them)
+    constexpr size_t ZA_PAIRS = 0, ZA_FLAG = 4128, ZA_PCNT = 4160, ZA_QLEN = 4160 + 4112, ZA_BYTES = ZA_QLEN;
+    const size_t za_need = ZA_BYTES + sizeof(int32_t) * (size_t)std::max<int64_t>(nt * 4, 1);
+    if ((!ctx->zarena && !ctx->d_pairs && !ctx->pool_flag && !ctx->pair_cnt && !ctx->qlen) || (ctx->zarena && ctx->zarena_bytes < za_need)) {
+        if (ctx->zarena) HIPCHK(ctx, hipFree(ctx->zarena));
+        ctx->zarena = nullptr;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->zarena, za_need));
+        ctx->zarena_bytes = za_need;
         ctx->d_pairs = (unsigned long long*)((char*)ctx->zarena + ZA_PAIRS);
         ctx->pool_flag = (int32_t*)((char*)ctx->zarena + ZA_FLAG);
         ctx->pair_cnt = (int32_t*)((char*)ctx->zarena + ZA_PCNT);
+        ctx->qlen = (int32_t*)((char*)ctx->zarena + ZA_QLEN);
     }
     if (ctx->zarena) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->zarena, 0, ZA_BYTES, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->zarena, 0, za_need, ctx->stream));
     } else {
         if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 514 * sizeof(unsigned long long)));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 514 * sizeof(unsigned long long), ctx->stream));
     }
-    if (ctx->world > 1 || nt <= 0) {
-        // a shard's k_degree visits its own positions only: everything else must read zero
-        HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (N + 1), ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->degs, 0, sizeof(int64_t) * (npad + 1), ctx->stream));
-    }                                                          // (unsharded: k_degree writes every entry, the scans' extra last ones too)
+    const bool sparse_deg = ctx->world > 1 || nt <= 0;         // (unsharded: the degree kernels write every entry, the scans' extra last ones too)
+    if (sparse_deg) {
+        // a shard's degree kernel visits its own positions only: everything else must read zero.  The ordering pass puts the zeros
+        // back where a step wrote (ord_args.deg_clear), so a sharded ctx pays this 8 N-byte fill once, not every step
+        if (!ctx->deg_zero_valid) HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (N + 1), ctx->stream));
+    }
+    ctx->deg_zero_valid = false;
 
     // single-pass logs: ONE log per quarter tile (16 consecutive cell-sorted columns) that receives every record of its columns,
     // whoever finds the hit.  What a log must hold is the sum of 16 neighbouring columns' degrees -- a quantity with little spread
@@ -1010,10 +1042,12 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             const size_t nq = (size_t)nt * 4;
             if ((rc = ensure(ctx, (void**)&ctx->qkey, sizeof(uint32_t) * (size_t)qcap * nq))) return rc;
             if ((rc = ensure(ctx, (void**)&ctx->qd2, sizeof(double) * (size_t)qcap * nq))) return rc;
-            if ((rc = ensure(ctx, (void**)&ctx->qlen, sizeof(int32_t) * nq))) return rc;
-            if (!ctx->pool_flag) HIPCHK(ctx, hipMalloc((void**)&ctx->pool_flag, sizeof(int32_t)));
-            if (!ctx->zarena) HIPCHK(ctx, hipMemsetAsync(ctx->pool_flag, 0, sizeof(int32_t), ctx->stream));
-            HIPCHK(ctx, hipMemsetAsync(ctx->qlen, 0, sizeof(int32_t) * nq, ctx->stream));
+            if (!ctx->zarena) {                                    // (a ctx with separately allocated counters: their own fills)
+                if ((rc = ensure(ctx, (void**)&ctx->qlen, sizeof(int32_t) * nq))) return rc;
+                if (!ctx->pool_flag) HIPCHK(ctx, hipMalloc((void**)&ctx->pool_flag, sizeof(int32_t)));
+                HIPCHK(ctx, hipMemsetAsync(ctx->pool_flag, 0, sizeof(int32_t), ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(ctx->qlen, 0, sizeof(int32_t) * nq, ctx->stream));
+            }
             ctx->qcap = qcap;
         }
     }
@@ -1067,6 +1101,8 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     ctx->pool_valid = false;
     ctx->rowpos_valid = false;
     ctx->pend_valid = false;
+    // (the degrees by cell-sorted position feed the staging offsets of the two-pass forms only: a single-pass build reads its own positions)
+    if (sparse_deg && !pool) HIPCHK(ctx, hipMemsetAsync(ctx->degs, 0, sizeof(int64_t) * (npad + 1), ctx->stream));
     mpfmt_timed tm3(ctx);
     if (nt > 0) {
         if (mf) {
@@ -1184,6 +1220,7 @@ int32_t mpfmt_launch_rdisc_fill(mpfmt_ctx* ctx, double r)
             mpfmt_timed tm4(ctx);
             if ((rc = mpfmt_order_logs(ctx, nullptr))) return rc;
             tm4.end("rdisc_sort");
+            ctx->deg_zero_valid = ctx->world > 1;                  // (the ordering pass has put the zeros back)
             done = 1;
         }
         if (!done) {
@@ -1327,6 +1364,7 @@ static int32_t step_finish_inner(mpfmt_ctx* ctx)
         if ((rc = mpfmt_rdisc_count_finish(ctx, r, &failed))) return rc;
         if (!failed && ctx->nnz < ctx->nnz_cap && ctx->pool_valid) {
             ctx->graph_filled = true; ctx->graph_swept = true;      // (finish resets the flags it owns)
+            ctx->deg_zero_valid = ctx->world > 1;                   // (the ordering pass ran: the shard's degree entries are zero again)
             if (ctx->pend_overflowed) {                             // the pending-entry / pending-pair list was cut short: sweep the whole graph
                 ctx->redo_reason |= 16; ctx->redo_count += 1;
                 if (ctx->sweep_in_order && ctx->pair_slack < 8) ctx->pair_slack *= 2;

@@ -1254,6 +1254,9 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
 // single pass: the degree of every column = a count over the keys of its quarter tile's log (one wavefront per quarter log), written
 // straight to the two degree arrays the scans read (by original index and by cell-sorted position); the longest column (the ordering
 // kernel stages whole columns) and the fullest log (the next build's capacity) go to two words behind the pair counters
+// LPB = 4: one wavefront per log (a whole build: bandwidth-bound on the keys).  LPB = 1: the four wavefronts of a workgroup share one
+// log (a shard: too few logs to fill the chip, each a chain of dependent round trips -- four times the loads in flight per log)
+template <int LPB>
 __global__ __launch_bounds__(256) void k_log_degrees(const uint32_t* __restrict__ qkey, const int32_t* __restrict__ qlen, long long qcap, int64_t nq,
                                                      int64_t pos0, const int32_t* __restrict__ perm, int64_t* __restrict__ deg,
                                                      int64_t* __restrict__ degs, int32_t* __restrict__ max_deg, int32_t* __restrict__ qmax,
@@ -1264,17 +1267,21 @@ __global__ __launch_bounds__(256) void k_log_degrees(const uint32_t* __restrict_
     // (unsharded: the scans' extra last elements are zeroed here instead of by two fill launches)
     if (N_tail >= 0 && blockIdx.x == 0 && threadIdx.x == 0) { deg[N_tail] = 0; degs[npad] = 0; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t q = (LPB == 4) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
+    int* const cnt = s_c[LPB == 4 ? wave : 0];
     int kmax = 0, n = 0;
+    if (LPB == 1) { if (threadIdx.x < 16) cnt[threadIdx.x] = 0; __syncthreads(); }
     if (q < nq) {
-        if (lane < 16) s_c[wave][lane] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if (LPB == 4) {
+            if (lane < 16) cnt[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         n = (int)min((long long)qlen[q], qcap);
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(qkey + q * qcap);           // (qcap is a multiple of 4)
         // (four 16-byte loads in flight per lane: one wavefront per log with one load at a time was a chain of ~10 round trips, 84 % of
         // its cycles waiting)
-        for (int b0 = 0; b0 < n; b0 += 4 * 256) {
+        for (int b0 = (LPB == 4 ? 0 : wave * 4 * 256); b0 < n; b0 += (LPB == 4 ? 1 : 4) * 4 * 256) {
             uint4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1286,19 +1293,19 @@ __global__ __launch_bounds__(256) void k_log_degrees(const uint32_t* __restrict_
                 const int i0 = b0 + j * 256 + lane * 4;
                 const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) if (i0 + k < n) atomicAdd(&s_c[wave][(w[k] >> 26) & 15u], 1);
+                for (int k = 0; k < 4; ++k) if (i0 + k < n) atomicAdd(&cnt[(w[k] >> 26) & 15u], 1);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 16) {
-            const int k = s_c[wave][lane];
-            const int64_t pos = pos0 + q * 16 + lane;
-            const int32_t o = perm[pos];
-            if (o >= 0) deg[o] = k;
-            degs[pos] = k;                                     // (pad positions: 0 -- nothing else clears them on an unsharded ctx)
-            kmax = k;
-        }
+    }
+    if (LPB == 1) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    if (q < nq && lane < 16 && (LPB == 4 || wave == 0)) {
+        const int k = cnt[lane];
+        const int64_t pos = pos0 + q * 16 + lane;
+        const int32_t o = perm[pos];
+        if (o >= 0) deg[o] = k;
+        degs[pos] = k;                                     // (pad positions: 0 -- nothing else clears them on an unsharded ctx)
+        kmax = k;
     }
     for (int off = 8; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
     if (lane == 0) { s_m[wave] = kmax; s_q[wave] = n; }
@@ -1316,9 +1323,14 @@ int32_t mpfmt_launch_log_degrees(mpfmt_ctx* ctx)
     const int64_t nq = (ctx->tile_end - ctx->tile_begin) * 4;
     if (nq <= 0) return MPFMT_OK;
     const bool whole = !(ctx->world > 1);
-    hipLaunchKernelGGL(k_log_degrees, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ctx->stream, ctx->qkey, ctx->qlen, (long long)ctx->qcap, nq,
-                       ctx->tile_begin * 64, ctx->perm, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512), (int32_t*)(ctx->d_pairs + 513),
-                       whole ? ctx->N : (int64_t)-1, ctx->ntiles * 64);
+    if (nq >= 16 * (int64_t)ctx->num_cus * 4)
+        hipLaunchKernelGGL((k_log_degrees<4>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ctx->stream, ctx->qkey, ctx->qlen, (long long)ctx->qcap, nq,
+                           ctx->tile_begin * 64, ctx->perm, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512), (int32_t*)(ctx->d_pairs + 513),
+                           whole ? ctx->N : (int64_t)-1, ctx->ntiles * 64);
+    else
+        hipLaunchKernelGGL((k_log_degrees<1>), dim3((unsigned)nq), dim3(256), 0, ctx->stream, ctx->qkey, ctx->qlen, (long long)ctx->qcap, nq,
+                           ctx->tile_begin * 64, ctx->perm, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512), (int32_t*)(ctx->d_pairs + 513),
+                           whole ? ctx->N : (int64_t)-1, ctx->ntiles * 64);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }

@@ -82,6 +82,7 @@ struct mpfmt_wf {
     wf_goal goal;
     double band = 0.0;
     int32_t single = 0, checkpts = 1, use_mask = 0, sharded = 0;
+    int32_t all_in = 0;           // every sample lies inside the state space (the first-point test of statespaces.jl:155 is true for every edge)
     int64_t init = 0;
     double r = 0.0;
     bool active = false;
@@ -117,6 +118,16 @@ __device__ __forceinline__ void wf_lexmin_wave(double& c, int64_t& i)
         const double oc = __shfl_xor(c, off);
         const int64_t oi = __shfl_xor(i, off);
         if (oi >= 0 && (i < 0 || oc < c || (oc == c && oi < i))) { c = oc; i = oi; }
+    }
+}
+// the same, carrying a payload with the winner (the entry's row: no reload of rowval[be] after the reduce)
+__device__ __forceinline__ void wf_lexmin_wave_y(double& c, int64_t& i, int32_t& y)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oc = __shfl_xor(c, off);
+        const int64_t oi = __shfl_xor(i, off);
+        const int32_t oy = __shfl_xor(y, off);
+        if (oi >= 0 && (i < 0 || oc < c || (oc == c && oi < i))) { c = oc; i = oi; y = oy; }
     }
 }
 __device__ __forceinline__ void wf_lexmax_wave(double& c, int64_t& i)
@@ -174,11 +185,32 @@ __global__ __launch_bounds__(64) void k_wf_init(int64_t N, int64_t words, int64_
     }
 }
 
+// The open set is a bit mask; what a step needs of it is a cost per open node -- a gather of C[i] behind every set bit.  Walking a
+// word's bits in one lane makes those gathers a dependent chain per lane (k_wf_select took 19 us a step that way, a fifth of the
+// solve).  Instead a wavefront takes 64 words (lane = word), lays their set bits out as a node list in LDS (prefix sum of the
+// popcounts; 12-bit positions inside the 64-word group) and then works lane = node: every round of 64 gathers is in flight at once.
+#define WF_GRP_CAP 4096           // nodes of one 64-word group (every bit set)
+__device__ __forceinline__ int wf_expand_group(unsigned long long m, uint16_t* __restrict__ s_list)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = __popcll(m);
+    int inc = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+    const int total = __shfl(inc, 63);
+    int o = inc - n;
+    while (m) { const int b = __ffsll((long long)m) - 1; m &= m - 1; s_list[o++] = (uint16_t)(lane * 64 + b); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return total;
+}
+
 __global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __restrict__ H, uint64_t* __restrict__ Z, uint64_t* __restrict__ Zp,
                                                      uint64_t* __restrict__ Hn, uint64_t* __restrict__ cand,
                                                      const double* __restrict__ C, double* __restrict__ part_c,
                                                      int64_t* __restrict__ part_i, wf_ctr* __restrict__ ctr)
 {
+    __shared__ uint16_t s_list[WF_GRP_CAP];
     if (wf_stop(ctr)) {
         // the batch of the previous step held a goal node: the steps enqueued behind it are void.  k_wf_select cannot test
         // goal_cbits itself (see there), so the end is latched here, one kernel ahead of it on the stream (without
@@ -191,17 +223,21 @@ __global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __
         ctr->iters += 1; ctr->ntrip = 0; ctr->nz = 0; ctr->nx = 0;
     }
     double bc = 0.0; int64_t bi = -1;
-    for (int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 64) {
-        const uint64_t z = Z[w];
-        uint64_t h = (H[w] & ~z) | Hn[w];                     // fmt.jl:83-84 for the batch of the previous step
-        H[w] = h; Zp[w] = z; Z[w] = 0; Hn[w] = 0; cand[w] = 0;
-        while (h) {
-            const int b = __ffsll((long long)h) - 1;
-            h &= h - 1;
-            const int64_t i = w * 64 + b;
-            const double c = C[i];
-            if (bi < 0 || c < bc) { bc = c; bi = i; }         // ascending i per thread: first minimum
+    for (int64_t w0 = (int64_t)blockIdx.x * 64; w0 < words; w0 += (int64_t)gridDim.x * 64) {       // wave-uniform trip count
+        const int64_t w = w0 + threadIdx.x;
+        uint64_t h = 0;
+        if (w < words) {
+            const uint64_t z = Z[w];
+            h = (H[w] & ~z) | Hn[w];                          // fmt.jl:83-84 for the batch of the previous step
+            H[w] = h; Zp[w] = z; Z[w] = 0; Hn[w] = 0; cand[w] = 0;
         }
+        const int total = wf_expand_group(h, s_list);
+        for (int k = threadIdx.x; k < total; k += 64) {
+            const int64_t i = w0 * 64 + (int64_t)s_list[k];
+            const double c = C[i];
+            if (bi < 0 || c < bc || (c == bc && i < bi)) { bc = c; bi = i; }
+        }
+        __builtin_amdgcn_wave_barrier();                      // (the list is rewritten by the next group)
     }
     wf_lexmin_wave(bc, bi);
     if (threadIdx.x == 0) { part_c[blockIdx.x] = bc; part_i[blockIdx.x] = bi; }
@@ -215,6 +251,8 @@ __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, con
                                                   double band, int single, wf_goal G, int32_t* __restrict__ zlist,
                                                   wf_ctr* __restrict__ ctr)
 {
+    __shared__ uint16_t s_list[WF_GRP_CAP];
+    __shared__ unsigned long long s_z[64];
     if (ctr->done || ctr->ended) return;
     double cm = 0.0; int64_t im = -1;
     for (int p = threadIdx.x; p < nparts; p += 64) {
@@ -230,20 +268,25 @@ __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, con
     const double thr = cm + band;
     for (int64_t w0 = (int64_t)blockIdx.x * 64; w0 < words; w0 += (int64_t)gridDim.x * 64) {       // wave-uniform trip count
         const int64_t w = w0 + threadIdx.x;
-        uint64_t h = (w < words) ? H[w] : 0, z = 0;
-        while (h) {
-            const int b = __ffsll((long long)h) - 1;
-            h &= h - 1;
-            const int64_t i = w * 64 + b;
+        const uint64_t h = (w < words) ? H[w] : 0;
+        s_z[threadIdx.x] = 0ull;
+        const int total = wf_expand_group(h, s_list);
+        for (int k = threadIdx.x; k < total; k += 64) {
+            const int p = (int)s_list[k];
+            const int64_t i = w0 * 64 + p;
             const double c = C[i];
             const bool sel = single ? (i == im) : (c <= thr);
             if (!sel) continue;
-            z |= 1ull << b;
+            atomicOr(&s_z[p >> 6], 1ull << (p & 63));
             if (wf_is_goal(X + i * d, G))           // fmt.jl:68
                 atomicMin(&ctr->goal_cbits, (unsigned long long)__double_as_longlong(c));
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t z = s_z[threadIdx.x];
         if (z) Z[w] = z;
         wf_append_word(z, w, zlist, &ctr->nz);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -327,9 +370,18 @@ __global__ __launch_bounds__(256) void k_wf_mark(const int32_t* __restrict__ zli
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int nz = ctr->nz;
-    for (int iz = blockIdx.x * wpb + (threadIdx.x >> 6); iz < nz; iz += gridDim.x * wpb) {
-        const int64_t z = zlist[iz];
-        const int64_t beg = colptr[z], end = colptr[z + 1];
+    // A node is a chain of dependent round trips (list entry -> column bounds -> rows -> set words -> atomic) and a wavefront has a
+    // handful of nodes per step: the list entry is fetched two nodes ahead and the column bounds one node ahead, so a node's own
+    // chain starts at its rows.
+    const int st = gridDim.x * wpb;
+    const int i0 = blockIdx.x * wpb + (threadIdx.x >> 6);
+    int64_t za = (i0 < nz) ? zlist[i0] : -1, zb = (i0 + st < nz) ? zlist[i0 + st] : -1;
+    int64_t ba = za >= 0 ? colptr[za] : 0, ea = za >= 0 ? colptr[za + 1] : 0;
+    for (int iz = i0; iz < nz; iz += st) {
+        const int64_t beg = ba, end = ea;
+        const int64_t zc = (iz + 2 * st < nz) ? zlist[iz + 2 * st] : -1;
+        ba = zb >= 0 ? colptr[zb] : 0; ea = zb >= 0 ? colptr[zb + 1] : 0;
+        zb = zc;
         for (int64_t e = beg + lane; e < end; e += 64) {
             const int64_t x = rowval[e];
             if (!wf_bit(W, x) || (F && !wf_bit(F, x))) continue;              // fmt.jl:70-71
@@ -391,7 +443,7 @@ __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict
                                                     unsigned long long* __restrict__ W, unsigned long long* __restrict__ Hn,
                                                     const double* __restrict__ X, const double* __restrict__ bT, int M, int mpad,
                                                     mpfmt_ss ss, const uint64_t* __restrict__ gfree, const uint8_t* __restrict__ nseg,
-                                                    wf_trip* __restrict__ mytrips, int64_t* __restrict__ stats, wf_ctr* __restrict__ ctr)
+                                                    wf_trip* __restrict__ mytrips, int64_t* __restrict__ stats, wf_ctr* __restrict__ ctr, int all_in)
 {
     // nseg != NULL (directed steering graphs: double integrator, cars): the edge's validity and the number of segment tests the
     // reference would have counted for it (boxesND.jl:26 per waypoint segment) were precomputed by the space's own sweep
@@ -400,53 +452,69 @@ __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict
     const int wpb = blockDim.x >> 6;
     int my_checks = 0, my_conn = 0;                                        // lane 0 counts for its wavefront
     const int nx = ctr->nx;
-    {
-        for (int ix = blockIdx.x * wpb + (threadIdx.x >> 6); ix < nx; ix += gridDim.x * wpb) {
-            const int64_t x = xlist[ix];
-            const int64_t beg = colptr[x], end = colptr[x + 1];
-            double best = 0.0;
-            int64_t be = -1;
-            for (int64_t e = beg + lane; e < end; e += 64) {               // nearB(V, x, r, H) + findmin, fmt.jl:72-74
-                const int64_t y = rowval[e];
-                if (!wf_bit(H, y)) continue;
-                const double c = C[y] + nzval[e];
-                if (be < 0 || c < best) { best = c; be = e; }              // ascending e per lane keeps the first minimum
-            }
-            wf_lexmin_wave(best, be);                                      // rows ascend with e: first minimum = lowest e
-            if (be < 0) continue;
-            const int64_t y = rowval[be];
-            double v[D], w[D];
+    // (the candidate and its column bounds are fetched ahead, like k_wf_mark's nodes; the winner's row rides through the reduce, the
+    // candidate's own state is requested with its rows: what is left of the chain is rows -> open bits -> costs -> parent state / mask bit)
+    const int st = gridDim.x * wpb;
+    const int i0 = blockIdx.x * wpb + (threadIdx.x >> 6);
+    int64_t xa = (i0 < nx) ? xlist[i0] : -1, xb = (i0 + st < nx) ? xlist[i0 + st] : -1;
+    int64_t ba = xa >= 0 ? colptr[xa] : 0, ea = xa >= 0 ? colptr[xa + 1] : 0;
+    for (int ix = i0; ix < nx; ix += st) {
+        const int64_t x = xa, beg = ba, end = ea;
+        const int64_t xc = (ix + 2 * st < nx) ? xlist[ix + 2 * st] : -1;
+        ba = xb >= 0 ? colptr[xb] : 0; ea = xb >= 0 ? colptr[xb + 1] : 0;
+        xa = xb; xb = xc;
+        double w[D];
+        const bool need_w = !(gfree || nseg);                              // (the lazy edge test reads both ends)
+        if (need_w) {
 #pragma unroll
-            for (int i = 0; i < D; ++i) { v[i] = X[y * D + i]; w[i] = X[x * D + i]; }
-            const bool inb = in_state_space_sl<D>(v, ss);                  // statespaces.jl:155: first point of the segment
-            if (lane == 0) my_checks += nseg ? (int)nseg[be] : (inb ? 1 : 0);   // boxesND.jl:26 is reached only then
-            bool fr;
-            if (gfree) {
-                fr = wf_bit(gfree, be);
-            } else {
-                double l[D], h[D];
-                seg_bbox<D>(v, w, l, h);
-                bool blocked = false;
-                for (int k0 = 0; k0 < M; k0 += 64) {                       // lane = obstacle (boxesND.jl:52-56; @all in any order)
-                    const int k = k0 + lane;
-                    const box_regs<D> b = wf_load_box_T<D>(bT, mpad, k);   // k < mpad always: the table is padded to 64 lanes
-                    const bool pend = (k < M) && !broadphase_free_sl<D>(l, h, b);
-                    if (__ballot(pend)) {
-                        if (pend) blocked = blocked || !narrow_free_sl<D>(v, w, b);
-                    }
+            for (int i = 0; i < D; ++i) w[i] = X[x * D + i];
+        }
+        double best = 0.0;
+        int64_t be = -1;
+        int32_t by = -1;
+        for (int64_t e = beg + lane; e < end; e += 64) {                   // nearB(V, x, r, H) + findmin, fmt.jl:72-74
+            const int32_t y = rowval[e];
+            if (!wf_bit(H, y)) continue;
+            const double c = C[y] + nzval[e];
+            if (be < 0 || c < best) { best = c; be = e; by = y; }          // ascending e per lane keeps the first minimum
+        }
+        wf_lexmin_wave_y(best, be, by);                                    // rows ascend with e: first minimum = lowest e
+        if (be < 0) continue;
+        const int64_t y = by;
+        bool inb = true;
+        double v[D];
+        if (!all_in || need_w) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) v[i] = X[y * D + i];
+            inb = in_state_space_sl<D>(v, ss);                             // statespaces.jl:155: first point of the segment
+        }
+        if (lane == 0) my_checks += nseg ? (int)nseg[be] : (inb ? 1 : 0);  // boxesND.jl:26 is reached only then
+        bool fr;
+        if (gfree) {
+            fr = wf_bit(gfree, be);
+        } else {
+            double l[D], h[D];
+            seg_bbox<D>(v, w, l, h);
+            bool blocked = false;
+            for (int k0 = 0; k0 < M; k0 += 64) {                           // lane = obstacle (boxesND.jl:52-56; @all in any order)
+                const int k = k0 + lane;
+                const box_regs<D> b = wf_load_box_T<D>(bT, mpad, k);       // k < mpad always: the table is padded to 64 lanes
+                const bool pend = (k < M) && !broadphase_free_sl<D>(l, h, b);
+                if (__ballot(pend)) {
+                    if (pend) blocked = blocked || !narrow_free_sl<D>(v, w, b);
                 }
-                fr = inb && (__ballot(blocked) == 0);
             }
-            if (fr && lane == 0) {                                         // fmt.jl:76-80
-                if (MODE == 0) {
-                    A[x] = (int32_t)y; C[x] = best;
-                    atomicAnd(&W[x >> 6], ~(1ull << (x & 63)));
-                    atomicOr(&Hn[x >> 6], 1ull << (x & 63));
-                    ++my_conn;
-                } else {
-                    wf_trip r; r.x = (int32_t)x; r.y = (int32_t)y; r.c = best;
-                    mytrips[atomicAdd(&ctr->ntrip, 1)] = r;                // at most one per owned candidate: capacity N holds
-                }
+            fr = inb && (__ballot(blocked) == 0);
+        }
+        if (fr && lane == 0) {                                             // fmt.jl:76-80
+            if (MODE == 0) {
+                A[x] = (int32_t)y; C[x] = best;
+                atomicAnd(&W[x >> 6], ~(1ull << (x & 63)));
+                atomicOr(&Hn[x >> 6], 1ull << (x & 63));
+                ++my_conn;
+            } else {
+                wf_trip r; r.x = (int32_t)x; r.y = (int32_t)y; r.c = best;
+                mytrips[atomicAdd(&ctr->ntrip, 1)] = r;                    // at most one per owned candidate: capacity N holds
             }
         }
     }
@@ -582,11 +650,11 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     if (!s->sharded) {
         DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 0>), dim3(grid), dim3(256), 0, st, s->xlist, ctx->colptr,
                                          ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo,
-                                         s->boxT, ctx->M, s->mpad, ctx->ss, gfree, nseg, (wf_trip*)nullptr, s->stats, s->ctr));
+                                         s->boxT, ctx->M, s->mpad, ctx->ss, gfree, nseg, (wf_trip*)nullptr, s->stats, s->ctr, s->all_in));
     } else {
         DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 1>), dim3(grid), dim3(256), 0, st, s->xlist, ctx->colptr,
                                          ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo,
-                                         s->boxT, ctx->M, s->mpad, ctx->ss, gfree, nseg, s->mytrips, s->stats, s->ctr));
+                                         s->boxT, ctx->M, s->mpad, ctx->ss, gfree, nseg, s->mytrips, s->stats, s->ctr, s->all_in));
     }
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
@@ -693,7 +761,11 @@ int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t check
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     auto t2 = std::chrono::steady_clock::now();
     const bool lazy_ok = ctx->cc_kind == 0 && ctx->dw == d;
-    s->use_mask = ((flags & MPFMT_WF_EAGER) || !lazy_ok) ? 1 : 0;
+    // (a mask a step left for this graph and this obstacle set is used, not recomputed: upload_boxes / set_state_bounds void graph_swept)
+    const bool resident = ctx->graph_swept && ctx->graph_filled && ctx->graph_r == r && ctx->graph_free && !(flags & MPFMT_WF_LAZY);
+    s->use_mask = ((flags & MPFMT_WF_EAGER) || !lazy_ok || resident) ? 1 : 0;
+    if ((rc = mpfmt_sweep_prepare_ss(ctx))) return rc;
+    s->all_in = (!ctx->ss.has || ctx->ssflag_all_in) ? 1 : 0;
     if (s->use_mask && !ctx->graph_swept) {
         ctx->pend_valid = false; if ((rc = mpfmt_launch_graph_sweep(ctx))) return rc;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -944,7 +1016,7 @@ extern "C++" int32_t mpfmt_wf_begin_directed(mpfmt_ctx* ctx, int64_t init_idx, i
     s->active = false;
     s->t_begin = std::chrono::steady_clock::now();
     if ((rc = wf_alloc(ctx, s, N, 1))) return rc;
-    s->sharded = 0; s->directed = true; s->use_mask = 1;
+    s->sharded = 0; s->directed = true; s->use_mask = 1; s->all_in = 0;
     s->band = band; s->single = (flags & MPFMT_WF_SINGLE) ? 1 : 0; s->checkpts = checkpts ? 1 : 0;
     s->init = init_idx - 1; s->r = ctx->di_r;
     s->goal.kind = goal_kind; s->goal.gd = goal_kind == MPFMT_GOAL_POINT ? d : gd;

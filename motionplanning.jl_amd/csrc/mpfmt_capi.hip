@@ -193,7 +193,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     hipDeviceSynchronize();
     // (refused while another thread's open group still has to post this ctx's gather: the ctx stays whole and usable)
     { const int32_t rc = mpfmt_comm_destroy(ctx); if (rc) return rc; }
-    if (ctx->zarena) { hipFree(ctx->zarena); ctx->d_pairs = nullptr; ctx->pool_flag = nullptr; ctx->pair_cnt = nullptr; }      // (they point into it)
+    if (ctx->zarena) { hipFree(ctx->zarena); ctx->d_pairs = nullptr; ctx->pool_flag = nullptr; ctx->pair_cnt = nullptr; ctx->qlen = nullptr; }      // (they point into it)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->idx_arena, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
                     ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops,
@@ -230,6 +230,7 @@ int32_t mpfmt_set_shard(mpfmt_ctx* ctx, int32_t rank, int32_t world)
     if (!ctx) return MPFMT_ERR_ARG;
     if (world < 1 || rank < 0 || rank >= world) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "bad shard %d of %d", rank, world);
     ctx->rank = rank; ctx->world = world;
+    ctx->deg_zero_valid = false;
     ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0;      // (the cell order and the built part of the index belong to the shard)
     ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
     return MPFMT_OK;

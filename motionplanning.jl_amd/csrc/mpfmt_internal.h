@@ -236,6 +236,8 @@ struct mpfmt_ctx {
                                          // caller-order gather (2.29 ms floor), this is the faster mode (2.2 vs 2.65 ms); on by default
     uint64_t* graph_free = nullptr;      // [ceil(nnz/64)]
     bool graph_swept = false;
+    size_t zarena_bytes = 0;
+    bool deg_zero_valid = false;         // sharded ctx: deg[] is all zeros (the ordering pass cleared what the last step wrote)
     void* zarena = nullptr;              // one arena for d_pairs, pool_flag, pair_cnt (one fill per build); they point into it when it exists
     unsigned long long* d_pairs = nullptr;   // device counter: candidate pairs tested
     int64_t pairs_tested = 0;

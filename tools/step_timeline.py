@@ -8,7 +8,7 @@ cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
 name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
 rows = list(cur.execute("select %s, start, end from kernels order by start" % name_col))
 # a step starts at its k_cellkey (the index build); the read-back of the step before it comes first in the listing
-starts = [i for i, r in enumerate(rows) if r[0].startswith("k_cellkey")]
+starts = [i for i, r in enumerate(rows) if "k_cellkey" in r[0]]
 a, b = starts[-back - 1], starts[-back]
 t0 = rows[a][1]; prev_end = t0
 print("%-58s %10s %10s %9s" % ("kernel", "start us", "dur us", "gap us"))
