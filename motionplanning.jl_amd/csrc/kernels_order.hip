@@ -32,17 +32,17 @@
 #define ORD_COLS 16              // columns per workgroup = columns per log
 #define ORD_NB 128               // buckets per column
 #ifndef ORD_STG
-#define ORD_STG 3008             // staged records per workgroup: 12 bytes each (35.3 KB of LDS; with the counters 52.3 KB -- three workgroups per CU
-#endif                           // need <= 53 KB each: LDS is handed out in 512-byte pieces, 3072 records were 48 bytes too many)
+#define ORD_STG 2560             // staged records per workgroup: 12 bytes each (30 KB of LDS; with the 16-bit counters 39 KB -- FOUR workgroups per CU
+#endif                           // need <= 40 KB each)
 #ifndef ORD_PRE
-#define ORD_PRE 6                // records per thread requested ahead (6 x 512 >= the staging area)
+#define ORD_PRE 5                // records per thread requested ahead (5 x 512 = the staging area)
+#endif
+#ifndef ORD_WAVES_EU
+#define ORD_WAVES_EU 8           // wavefronts per SIMD the kernel is built for (8: 64 VGPRs -- four 512-thread workgroups per CU)
 #endif
 static_assert(ORD_STG >= MPFMT_ORD_MAXDEG, "a column the host lets through must fit the staging area");
 static_assert(ORD_COLS * ORD_NB == ORD_THREADS * 4, "the segmented scan gives every thread four buckets");
-static_assert(ORD_PRE * ORD_THREADS >= ORD_STG && ORD_STG % 32 == 0, "the prefetched records cover what the staging area holds");
-#ifndef ORD_OPT                  // A/B switches (tools/build_variant.sh): 1 the bucket's members read together in the write-out; 8 squared
-#define ORD_OPT 1                // distances requested when the counting sort begins instead of a quarter ahead
-#endif
+static_assert(ORD_PRE * ORD_THREADS >= ORD_STG && ORD_STG % 32 == 0 && ORD_STG < 65536, "the prefetched records cover what the staging area holds; positions fit 16 bits");
 
 struct ord_hdr {
     int32_t k[ORD_COLS];         // column degrees
@@ -52,8 +52,10 @@ struct ord_hdr {
     int32_t n, pad_[3];          // records in the quarter's log
 };
 struct ord_shared {
-    int32_t cnt[ORD_COLS][ORD_NB];   // records per (column, bucket)
-    int32_t cur[ORD_COLS][ORD_NB];   // next staging position of each (column, bucket); after the placement: the bucket's end
+    // 16-bit counters, two per word (low half = the even bucket): a count or a staging position never reaches 65536, so the halves
+    // never carry into each other and one 32-bit LDS atomic serves either
+    uint32_t cnt[ORD_COLS][ORD_NB / 2];   // records per (column, bucket)
+    uint32_t cur[ORD_COLS][ORD_NB / 2];   // next staging position of each (column, bucket); after the placement: the bucket's end
     ord_hdr h[2];                    // headers of the quarter in work and of the next one (prefetched)
     int32_t g1, pcount, pad_[2];     // pcount: pending-entry items this workgroup has appended
     uint32_t bits[ORD_STG / 32];     // free bit of every staged entry, by rank position (blocked bits out of the keys)
@@ -92,8 +94,8 @@ struct ord_args {
 // log length -> records -> LDS -> stores), and with 3 workgroups per CU nothing covers them.  So while a workgroup writes quarter q out
 // of LDS, the records of its next quarter are already on their way into registers, and the header of that quarter was requested a
 // phase earlier still.
-#ifdef ORD_W6
-__global__ __launch_bounds__(ORD_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_order_logs(ord_args a)
+#if ORD_WAVES_EU
+__global__ __launch_bounds__(ORD_THREADS) __attribute__((amdgpu_waves_per_eu(ORD_WAVES_EU, ORD_WAVES_EU))) void k_order_logs(ord_args a)
 #else
 __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
 #endif
@@ -174,15 +176,14 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
     if (tid < ORD_COLS) sh.h[0].out[tid] = hout;
     lds_barrier();
     rec_fetch(sh.h[0], qi);
-    if (!(ORD_OPT & 8)) d2_fetch(sh.h[0].n, qi);
+    d2_fetch(sh.h[0].n, qi);
     for (; qi < nq; qi += gridDim.x, hb ^= 1) {
         const ord_hdr& H = sh.h[hb];
         const int64_t qn = qi + gridDim.x;                    // the workgroup's next quarter
         const int total = H.n;
         const long long lbase = qi * a.qcap;
         hdr_fetch1(qn);                                       // in flight during the counting sort
-        if (ORD_OPT & 8) d2_fetch(total, qi);
-        int g0 = 0;
+            int g0 = 0;
         bool first = true;
         while (g0 < ORD_COLS) {
             // ---- the next column range [g0, g1) that fits the staging area (normally the whole quarter); counts to zero ----
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
                 const unsigned long long m = __ballot(ok);
                 if (tid == 0) sh.g1 = g0 + (int)__popcll(m);
             }
-            *reinterpret_cast<int4*>(&sh.cnt[0][tid * 4]) = make_int4(0, 0, 0, 0);
+            *reinterpret_cast<uint2*>(&sh.cnt[0][tid * 2]) = make_uint2(0u, 0u);
             lds_barrier();
             int g1 = sh.g1;
             const bool skip = g1 == g0;                      // a column beyond the staging area (excluded by the host): left out
@@ -213,29 +214,34 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
             // ---- COUNT ----
             if (!skip) for_records([&](uint32_t key, int, int) {
                 const int col = (int)ORD_COL(key);
-                if (col >= g0 && col < g1) atomicAdd(&sh.cnt[col][bucket(ORD_ID(key))], 1);
+                if (col >= g0 && col < g1) { const int bk = bucket(ORD_ID(key)); atomicAdd(&sh.cnt[col][bk >> 1], 1u << ((bk & 1) * 16)); }
             });
             lds_barrier();
             // ---- segmented scan: thread = four consecutive buckets, 32 threads per column ----
             {
                 const int col = tid >> 5;
-                const int4 c4 = *reinterpret_cast<const int4*>(&sh.cnt[0][tid * 4]);
-                const int tot = c4.x + c4.y + c4.z + c4.w;
+                const uint2 cw = *reinterpret_cast<const uint2*>(&sh.cnt[0][tid * 2]);
+                const int c0 = (int)(cw.x & 0xffffu), c1 = (int)(cw.x >> 16), c2 = (int)(cw.y & 0xffffu), c3 = (int)(cw.y >> 16);
+                const int tot = c0 + c1 + c2 + c3;
                 int inc = tot;
                 inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);       // row_shr:1
                 inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);       // row_shr:2
                 inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);       // row_shr:4
                 inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);       // row_shr:8
                 inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3: the scan of a 32-lane half
-                const int b0 = H.cb[col] - gb + inc - tot;                               // staging position of the thread's first bucket
-                *reinterpret_cast<int4*>(&sh.cur[0][tid * 4]) = make_int4(b0, b0 + c4.x, b0 + c4.x + c4.y, b0 + c4.x + c4.y + c4.z);
+                // staging position of the thread's first bucket (a void build -- an overflowed log -- may run past the area: clamped, the
+                // 16-bit halves must not carry)
+                const int b0 = min(max(H.cb[col] - gb + inc - tot, 0), ORD_STG);
+                const int b1 = min(b0 + c0, ORD_STG), b2 = min(b1 + c1, ORD_STG), b3 = min(b2 + c2, ORD_STG);
+                *reinterpret_cast<uint2*>(&sh.cur[0][tid * 2]) = make_uint2((uint32_t)b0 | ((uint32_t)b1 << 16), (uint32_t)b2 | ((uint32_t)b3 << 16));
             }
             lds_barrier();
             // ---- PLACE ----
             if (!skip) for_records([&](uint32_t key, int u, int i) {
                 const int col = (int)ORD_COL(key);
                 if (col >= g0 && col < g1) {
-                    const int pos = atomicAdd(&sh.cur[col][bucket(ORD_ID(key))], 1);
+                    const int bk = bucket(ORD_ID(key));
+                    const int pos = (int)((atomicAdd(&sh.cur[col][bk >> 1], 1u << ((bk & 1) * 16)) >> ((bk & 1) * 16)) & 0xffffu);
                     double d2 = 0.0;
                     if (u < 0) d2 = a.qd2[lbase + i];
 #pragma unroll
@@ -253,91 +259,13 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
             }
             const bool last_range = g1 >= ORD_COLS;
             if (last_range) {
-#if ORD_OPT & 4
-                // (the next log's length straight from its cursor -- a wave-uniform load: no barrier for the header's copy of it)
-                const int ntot = (qn < nq) ? (int)min((long long)a.qlen[qn], a.qcap) : 0;
-                rec_fetch_n(ntot, qn);
-                if (!(ORD_OPT & 8)) d2_fetch(ntot, qn);
-#else
                 lds_barrier();                                // (the next header's log length is read by every thread)
                 rec_fetch(sh.h[hb ^ 1], qn);
-                if (!(ORD_OPT & 8)) d2_fetch(qn < nq ? sh.h[hb ^ 1].n : 0, qn);
-#endif
+                d2_fetch(qn < nq ? sh.h[hb ^ 1].n : 0, qn);
             }
             // ---- WRITE: thread = staging position ----
             if (!skip) {
                 const int nst = min(H.cb[g1] - gb, ORD_STG);
-#if ORD_OPT & 2
-                // three positions per thread at a time, level by level: the keys, then their buckets' ends and sizes, then the buckets'
-                // members and the distances -- each level's LDS reads are in flight together (one position at a time is a chain of four
-                // dependent LDS round trips, and a thread has up to six positions)
-#ifndef ORD_GW
-#define ORD_GW 2
-#endif
-                constexpr int GW = ORD_GW;
-                for (int p0 = 0; p0 < nst; p0 += GW * ORD_THREADS) {
-                    if (p0 + wave * 64 >= nst) break;                        // (no barrier inside: a wavefront without positions is done)
-                    int pj[GW], col[GW], e[GW], n[GW];
-                    bool act[GW];
-                    uint32_t key[GW], id[GW], m[GW][4];
-                    double dd[GW];
-#pragma unroll
-                    for (int j = 0; j < GW; ++j) {
-                        pj[j] = p0 + j * ORD_THREADS + tid;
-                        act[j] = pj[j] < nst;
-                        key[j] = stage_key[min(pj[j], ORD_STG - 1)];
-                        dd[j] = stage_d2[min(pj[j], ORD_STG - 1)];
-                    }
-#pragma unroll
-                    for (int j = 0; j < GW; ++j) {
-                        if (!act[j]) key[j] = (uint32_t)(g1 - 1) << 26;
-                        col[j] = (int)ORD_COL(key[j]); id[j] = ORD_ID(key[j]);
-                        const int bk = bucket(id[j]);
-                        e[j] = sh.cur[col[j]][bk]; n[j] = sh.cnt[col[j]][bk];    // the bucket occupies [e - n, e)
-                    }
-#pragma unroll
-                    for (int j = 0; j < GW; ++j) {
-                        const int b0 = min(max(e[j] - n[j], 0), ORD_STG - 1), bl = min(max(e[j] - 1, b0), ORD_STG - 1);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) m[j][t] = ORD_ID(stage_key[min(b0 + t, bl)]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < GW; ++j) {
-                        int rk = e[j] - n[j];
-                        if (act[j]) {
-                            rk += (int)(m[j][0] < id[j]) + (int)(n[j] > 1 && m[j][1] < id[j]) + (int)(n[j] > 2 && m[j][2] < id[j]) + (int)(n[j] > 3 && m[j][3] < id[j]);
-                            for (int mm = e[j] - n[j] + 4; mm < e[j]; ++mm) rk += (ORD_ID(stage_key[mm]) < id[j]) ? 1 : 0;
-                        }
-                        const int rel = rk - (H.cb[col[j]] - gb);                    // rank inside the column
-                        const bool valid = act[j] && rel >= 0 && rel < H.k[col[j]];  // (always, unless a log overflowed: that build is void, but stays in bounds)
-                        const int64_t o = H.out[col[j]] + rel;
-                        int32_t rp = 0;
-                        const bool pd_ = valid && a.pend_items && ((key[j] >> 30) & 1u);
-                        if ((valid && a.rowpos) || pd_) rp = a.iperm[id[j]];
-                        if (valid) {
-                            a.rowval[o] = (int32_t)id[j];
-                            a.nzval[o] = sqrt(dd[j]);                                // the log carries d2
-                            if (a.rowpos) a.rowpos[o] = rp;
-                        }
-                        if (a.rec_bits && valid && (key[j] >> 31)) atomicAnd(&sh.bits[rk >> 5], ~(1u << (rk & 31)));
-                        if (a.pend_items && p0 + j * ORD_THREADS + wave * 64 < nst) {
-                            const unsigned long long pm = __ballot(pd_);
-                            if (pm) {
-                                int base = 0;
-                                if (lane == 0) base = atomicAdd(&sh.pcount, (int)__popcll(pm));
-                                base = __builtin_amdgcn_readfirstlane(base);
-                                if (pd_) {
-                                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                                    if (pos < a.pend_wcap)
-                                        a.pend_items[(int64_t)blockIdx.x * a.pend_wcap + pos] =
-                                            make_uint4((uint32_t)(uint64_t)o, (uint32_t)((uint64_t)o >> 32), (uint32_t)H.ho[col[j]], (uint32_t)rp);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-#else
                 for (int p0 = 0; p0 < nst; p0 += ORD_THREADS) {
                     const int p = p0 + tid;
                     const bool act = p < nst;
@@ -346,9 +274,8 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
                     const int col = (int)ORD_COL(key);
                     const uint32_t id = ORD_ID(key);
                     const int bk = bucket(id);
-                    const int e = sh.cur[col][bk], n = sh.cnt[col][bk];            // the bucket occupies [e - n, e)
+                    const int e = (int)((sh.cur[col][bk >> 1] >> ((bk & 1) * 16)) & 0xffffu), n = (int)((sh.cnt[col][bk >> 1] >> ((bk & 1) * 16)) & 0xffffu);   // the bucket occupies [e - n, e)
                     int rk = e - n;
-#if ORD_OPT & 1
                     if (act) {
                         // (the bucket holds the record itself and typically 0-2 others: four independent reads, then the rare rest)
                         const int b0 = e - n, bl = e - 1;
@@ -357,9 +284,6 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
                         rk += (int)(m0 < id) + (int)(n > 1 && m1 < id) + (int)(n > 2 && m2 < id) + (int)(n > 3 && m3 < id);
                         for (int m = b0 + 4; m < e; ++m) rk += (ORD_ID(stage_key[m]) < id) ? 1 : 0;
                     }
-#else
-                    if (act) for (int m = e - n; m < e; ++m) rk += (ORD_ID(stage_key[m]) < id) ? 1 : 0;
-#endif
                     const int rel = rk - (H.cb[col] - gb);                          // rank inside the column
                     const bool valid = act && rel >= 0 && rel < H.k[col];          // (always, unless a log overflowed: that build is void, but stays in bounds)
                     const int64_t o = H.out[col] + rel;
@@ -390,7 +314,6 @@ __global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
                     }
                 }
             }
-#endif
             lds_barrier();
             if (a.rec_bits) {
                 // ---- the free bits of the range's columns, from rank positions to CSC positions (wavefront w: columns 2 w, 2 w + 1) ----
@@ -457,11 +380,11 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail, int64_t mask_
     // (the attribute belongs to the kernel ON A DEVICE: set per launch -- a cached flag would cover the first device of a process
     // that drives several, and be written by concurrent ctx threads)
     HIPCHK(ctx, hipFuncSetAttribute((const void*)k_order_logs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // persistent workgroups: as many as fit the chip at once (3 per CU by their LDS), each takes every nb-th quarter tile
+    // persistent workgroups: as many as fit the chip at once (4 per CU by their LDS and registers), each takes every nb-th quarter tile
     if (ctx->ord_per_cu == 0) {
         int per_cu = 0;
         HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_order_logs, ORD_THREADS, lds));
-        ctx->ord_per_cu = std::max(1, std::min(per_cu, 3));
+        ctx->ord_per_cu = std::max(1, std::min(per_cu, 4));
     }
     const unsigned nb = (unsigned)std::min<int64_t>(nt * 4, (int64_t)ctx->num_cus * ctx->ord_per_cu);
     if (pend) {

@@ -111,32 +111,45 @@ __device__ __forceinline__ T scan4096(const T* in, T* out, int64_t base, int64_t
     for (int k = 0; k < 4; ++k) { if (i0 + k < n) out[i0 + k] = o; o += v[k]; }
     return s_w[16];
 }
-// one workgroup, one pass: thread = a contiguous segment of ceil(n / 1024) items (summed, then written behind the scanned thread totals)
-// -- the few thousand cell counters / block sums this serves sit in L2; a loop of 4096-item rounds cost a barrier chain per round
+// one workgroup, chunk by chunk (the block sums of the long scans)
 template <typename T>
 __global__ __launch_bounds__(1024) void k_scan_single(const T* in, T* out, int64_t n)
 {
     __shared__ T s_w[17];
+    T carry = 0;
+    for (int64_t base = 0; base < n; base += 4096) carry += scan4096<T>(in, out, base, n, carry, s_w);
+}
+// one workgroup, ONE pass over up to 36 K items staged in LDS (the cell counters of an index build: 15 625 at the north star): loaded
+// and stored coalesced, summed by thread = a contiguous run of an ODD number of items (no bank conflicts), one barrier chain instead
+// of one per 4096 items
+#define SCAN_LDS_MAX 36864
+__global__ __launch_bounds__(1024) void k_scan_lds_i32(const int32_t* in, int32_t* out, int n)
+{
+    extern __shared__ int32_t s_a[];
+    __shared__ int32_t s_w[17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t seg = (n + 1023) / 1024;
-    const int64_t i0 = (int64_t)tid * seg, i1 = min(n, i0 + seg);
-    T t = 0;
-    for (int64_t i = i0; i < i1; ++i) t += in[i];
-    T inc = t;
+    const int seg = ((n + 1023) / 1024) | 1;
+    for (int i = tid; i < seg * 1024; i += 1024) s_a[i] = (i < n) ? in[i] : 0;
+    __syncthreads();
+    int32_t t = 0;
+    for (int k = 0; k < seg; ++k) t += s_a[tid * seg + k];
+    int32_t inc = t;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const T u = __shfl_up(inc, off); if (lane >= off) inc += u; }
+    for (int off = 1; off < 64; off <<= 1) { const int32_t u = __shfl_up(inc, off); if (lane >= off) inc += u; }
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
     if (wave == 0) {
-        T x = lane < 16 ? s_w[lane] : (T)0;
-        const T own = x;
+        int32_t x = lane < 16 ? s_w[lane] : 0;
+        const int32_t own = x;
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) { const T u = __shfl_up(x, off); if (lane >= off) x += u; }
+        for (int off = 1; off < 16; off <<= 1) { const int32_t u = __shfl_up(x, off); if (lane >= off) x += u; }
         if (lane < 16) s_w[lane] = x - own;
     }
     __syncthreads();
-    T o = s_w[wave] + inc - t;
-    for (int64_t i = i0; i < i1; ++i) { const T v = in[i]; out[i] = o; o += v; }
+    int32_t o = s_w[wave] + inc - t;
+    for (int k = 0; k < seg; ++k) { const int32_t v = s_a[tid * seg + k]; s_a[tid * seg + k] = o; o += v; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) out[i] = s_a[i];
 }
 template <typename T>
 __global__ __launch_bounds__(1024) void k_scan_block(const T* in, T* out, int64_t n, T* __restrict__ bsum)
@@ -158,7 +171,7 @@ template <typename T>
 static void launch_scan(hipStream_t st, const T* in, T* out, int64_t n, T* bsum)
 {
     const int64_t nsb = (n + 4095) / 4096;
-    if (nsb <= 32) {
+    if (nsb <= 16) {
         hipLaunchKernelGGL((k_scan_single<T>), dim3(1), dim3(1024), 0, st, in, out, n);
     } else {
         hipLaunchKernelGGL((k_scan_block<T>), dim3((unsigned)nsb), dim3(1024), 0, st, in, out, n, bsum);
@@ -183,17 +196,15 @@ __device__ __forceinline__ bool cell_wanted(const uint8_t* __restrict__ tileneed
 // being at least r wide.  One workgroup per cell id; the workgroups of own cells mark the tiles of all their neighbours (thread =
 // neighbour offset).  Tiles left unmarked are never built: they get empty boxes, which every candidate test rejects.
 __global__ __launch_bounds__(256) void k_cell_need(const int32_t* __restrict__ cellstart, mpfmt_grid G, int d, int64_t pos_b, int64_t pos_e,
-                                                   int64_t noff, int64_t ncells, uint8_t* __restrict__ tileneed)
+                                                   int64_t noff, uint8_t* __restrict__ tileneed)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);             // one wavefront per cell id
-    if (id >= ncells) return;
+    const int64_t id = blockIdx.x;                           // (one workgroup per cell id: one wavefront per cell measured 40 us against 20)
     const int64_t cs = cellstart[id], ce = cellstart[id + 1];
     // own cell <=> it holds a position of [pos_b, pos_e)
     if (ce <= cs || ce <= pos_b || cs >= pos_e) return;
     int c[MPFMT_MAX_DIM];
     for (int i = 0; i < d; ++i) c[i] = mpfmt_cell_coord(G, i, id);
-    for (int64_t t = lane; t < noff; t += 64) {
+    for (int64_t t = threadIdx.x; t < noff; t += blockDim.x) {
         int64_t rem = t, nid = 0;
         bool ok = true;
         for (int i = d - 1; i >= 0; --i) {
@@ -601,10 +612,17 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r, bool whole)
         ctx->list_max_clean = true;
         const int B = 256;
         hipLaunchKernelGGL(k_cellkey_count, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream, ctx->Xo, N, d, G, fb, key, slot, ctx->cellstart);
-        launch_scan<int32_t>(ctx->stream, (const int32_t*)ctx->cellstart, ctx->cellstart, G.ncells + 1, bsum);
+        if (G.ncells + 1 <= SCAN_LDS_MAX) {
+            const int seg = (int)(((G.ncells + 1 + 1023) / 1024) | 1);
+            const size_t lds = sizeof(int32_t) * (size_t)seg * 1024;
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)k_scan_lds_i32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_scan_lds_i32, dim3(1), dim3(1024), lds, ctx->stream, (const int32_t*)ctx->cellstart, ctx->cellstart, (int)(G.ncells + 1));
+        } else {
+            launch_scan<int32_t>(ctx->stream, (const int32_t*)ctx->cellstart, ctx->cellstart, G.ncells + 1, bsum);
+        }
         if (ctx->tileneed)
-            hipLaunchKernelGGL(k_cell_need, dim3((unsigned)((G.ncells + 3) / 4)), dim3(256), 0, ctx->stream, (const int32_t*)ctx->cellstart, G, d,
-                               ctx->tile_begin * 64, std::min<int64_t>(ctx->tile_end * 64, N), noff, G.ncells, ctx->tileneed);
+            hipLaunchKernelGGL(k_cell_need, dim3((unsigned)G.ncells), dim3(256), 0, ctx->stream, (const int32_t*)ctx->cellstart, G, d,
+                               ctx->tile_begin * 64, std::min<int64_t>(ctx->tile_end * 64, N), noff, ctx->tileneed);
         hipLaunchKernelGGL(k_cell_scatter, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream, (const uint32_t*)key, (const uint32_t*)slot, N, fb,
                            (const int32_t*)ctx->cellstart, (const uint8_t*)ctx->tileneed, items);
         hipLaunchKernelGGL(k_cell_order, dim3((unsigned)((G.ncells + 3) / 4)), dim3(256), 0, ctx->stream, (const int32_t*)ctx->cellstart, G.ncells, fb, pbits,
@@ -1061,7 +1079,8 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     ctx->half_used = half;
     // the broad phase of the step's edge tests rides in any single-pass build (whole builds -- shards -- flag each entry's own record
     // and take form 1: the ordering pass lists the flagged entries); the pair form needs the half build
-    ctx->broad_in_drain = pool && mf && ctx->d <= 6 && ctx->want_broad;
+    // (7 <= d <= 12: only as form 2 below -- the pending-entry form's exact kernel, k_sweep_pending, is built for d <= 6)
+    ctx->broad_in_drain = pool && mf && ctx->want_broad && (ctx->d <= 6 || (ctx->d <= 12 && half && ctx->fuse_broad == 2));
     ctx->bits_in_records = false; ctx->sweep_in_order = false;
     if (ctx->broad_in_drain && half && ctx->fuse_broad == 2) {
         // form 2: the pairs flagged by the drain's broad phase are listed for k_exact_pairs in 1024 dense regions (an item appends to
@@ -1288,11 +1307,11 @@ static int32_t sweep_checked(mpfmt_ctx* ctx)
 // speculative form without waiting (or, when nothing can be trusted yet, runs the careful form to completion), _finish makes
 // the one synchronisation, validates, and redoes the step the careful way if a trusted capacity did not hold.
 // can the broad phase of the step's edge tests ride in the pair kernel's drain?  (PointRobotNDBoxes in the state space's own
-// coordinates, d <= 6 -- the K = 8 pair kernel --, <= 256 boxes, no sample outside the state space: the one-sided in_state_space test of
+// coordinates, d <= 12 -- the matrix-core pair kernels --, <= 256 boxes, no sample outside the state space: the one-sided in_state_space test of
 // statespaces.jl:155 is then true for every entry)
 static bool step_wants_broad(mpfmt_ctx* ctx)
 {
-    if (!ctx->fuse_broad || ctx->cc_kind != 0 || !ctx->have_boxes || ctx->dw != ctx->d || ctx->d > 6 || ctx->M > 256) return false;
+    if (!ctx->fuse_broad || ctx->cc_kind != 0 || !ctx->have_boxes || ctx->dw != ctx->d || ctx->d > 12 || ctx->M > 256) return false;
     if (mpfmt_sweep_prepare_ss(ctx) != MPFMT_OK) return false;
     return !(ctx->ss.has && !ctx->ssflag_all_in);
 }

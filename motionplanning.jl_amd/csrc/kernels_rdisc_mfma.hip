@@ -84,7 +84,7 @@ struct mf_args {
     // beyond the tile is also written as the record of the OTHER column into that column's quarter log
     int32_t half;
     int64_t ntiles_shard;           // tiles of this shard: the other column's record is written for candidates in [blk_begin, blk_begin + ntiles_shard)
-    // broad phase of the edge tests in the drain (half build, d <= 6, <= 256 boxes in the state space's own coordinates, every
+    // broad phase of the edge tests in the drain (half build, d <= 12, <= 256 boxes in the state space's own coordinates, every
     // sample inside the state space): bit 30 of a record's row index = "the segment's box meets an obstacle's: exact test needed"
     int32_t fb;
     int32_t M;
@@ -454,7 +454,7 @@ int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r)
     const double rpad = r * (1.0 + 1e-9) + 1e-300;
 #define CASE(DD) case DD: hipLaunchKernelGGL((k_sample_masks<DD>), dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, ctx->stream, ctx->Xs, ctx->tile_lo, ctx->tile_hi, \
         (int64_t)0, nt, rpad, ctx->boxes, ctx->M, (unsigned long long*)ctx->smask, (unsigned long long*)ctx->smask + ctx->ntiles * 64, (const uint8_t*)ctx->tileneed); break;
-    switch (ctx->d) { CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) default: break; }
+    switch (ctx->d) { CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) default: break; }
 #undef CASE
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
@@ -493,7 +493,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     __shared__ int32_t s_cnt[64];
     __shared__ int32_t s_operm[MODE == 2 ? 64 : 1];       // caller indices of the tile's own samples (the other column's record carries the query's)
     __shared__ int32_t s_lc[4];                           // own hits of the drain in work, per quarter of the tile (zero between drains)
-    __shared__ unsigned long long s_qm[(MODE == 2 && D <= 6) ? 64 : 1];      // the queries' obstacle masks (broad phase in the drain)
+    __shared__ unsigned long long s_qm[MODE == 2 ? 64 : 1];      // the queries' obstacle masks (broad phase in the drain)
     __shared__ int64_t s_base[MODE == 1 ? 64 : 1];
     __shared__ unsigned long long s_best[MODE == 3 ? 64 : 1];
     __shared__ int32_t s_besti[MODE == 3 ? 64 : 1], s_nfree[MODE == 3 ? 64 : 1];
@@ -523,7 +523,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     // segment lie within r of the tile's hull (the candidate is within r of a query of the tile), so a box farther than that from
     // the hull in some axis is out for the whole item
     unsigned long long bsurv[4] = {0ull, 0ull, 0ull, 0ull};
-    if constexpr (MODE == 2 && D <= 6) {
+    if constexpr (MODE == 2) {
         if (a.fb) {
             // (culled once per tile by k_sample_masks -- with its slightly wider margin, a superset of the boxes within rpad of the hull;
             // the comparisons of the drain decide -- instead of once per item here: 4 x 12 loads and 24 comparisons per lane)
@@ -559,7 +559,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     s_cnt[lane] = 0;
     if (lane < 4) s_lc[lane] = 0;
     if constexpr (MODE == 2) s_operm[lane] = a.perm[qpos];
-    if constexpr (MODE == 2 && D <= 6) { if (a.fb) s_qm[lane] = a.smask[qpos]; }
+    if constexpr (MODE == 2) { if (a.fb) s_qm[lane] = a.smask[qpos]; }
     if constexpr (MODE == 3) { s_best[lane] = ~0ull; s_besti[lane] = 0x7fffffff; s_nfree[lane] = 0; }
     constexpr bool FILL = (MODE == 1);
     if (FILL) {
@@ -640,14 +640,11 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         bool hit = false;
         uint32_t jg = 0, ql = 0;
         double d2 = 0.0;
-#ifndef MF_EARLY                 // A/B: 0 = loads and reservations where their results are first needed; 1 = loads hoisted; 2 = reservations too
-#define MF_EARLY 2
-#endif
         [[maybe_unused]] uint32_t e_pj = 0;
         [[maybe_unused]] unsigned long long e_sm = 0;
-        [[maybe_unused]] double sl[D <= 6 ? D : 1], sh[D <= 6 ? D : 1];
+        [[maybe_unused]] double sl[MODE == 2 ? D : 1], sh[MODE == 2 ? D : 1];
         [[maybe_unused]] double qv[MODE == 3 ? D : 1], cv[MODE == 3 ? D : 1];
-        if constexpr (MODE == 2 && D <= 6) {
+        if constexpr (MODE == 2) {
 #pragma unroll
             for (int i = 0; i < D; ++i) { sl[i] = (double)INFINITY; sh[i] = -(double)INFINITY; }
         }
@@ -661,18 +658,16 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (fl >> 5);
             jg = qc * 64u + (uint32_t)((t >> 1) * 32 + (fl & 31));
             ql = (uint32_t)((t & 1) * 32 + row);
-#if MF_EARLY
             // (requested with the candidate's coordinates, not after the membership test: one dependent round trip less per drain)
             if constexpr (MODE == 2) {
                 e_pj = (uint32_t)a.perm[jg];
-                if constexpr (D <= 6) { if (a.fb) e_sm = a.smask[jg]; }
+                if (a.fb) e_sm = a.smask[jg];
             }
-#endif
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 const double qi = s_q[ql * D + i], ci = a.Xs[(int64_t)jg * D + i];
                 if constexpr (MODE == 3) { qv[i] = qi; cv[i] = ci; }
-                if constexpr (MODE == 2 && D <= 6) {
+                if constexpr (MODE == 2) {
                     asm("v_min_f64 %0, %1, %2" : "=v"(sl[i]) : "v"(qi), "v"(ci));     // the segment's box (only compared: -0 / +0 do not show)
                     asm("v_max_f64 %0, %1, %2" : "=v"(sh[i]) : "v"(qi), "v"(ci));
                 }
@@ -753,7 +748,6 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                 if (fr) atomicAdd(&s_nfree[ql], 1);
             }
         }
-#if MF_EARLY >= 2
         // (MODE 2) the places of this drain's records are reserved BEFORE the broad phase: the returning atomics on the logs' cursors -- a
         // device-scope round trip -- run beside the ~170 comparisons of the box walk instead of after it; only the pending-pair region
         // (whose size the walk decides) is reserved afterwards
@@ -794,23 +788,19 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             }
             if (fh && lane == leader) fbase = atomicAdd(&a.qlen[fq], cnt_l);
         }
-#endif
         // broad phase of is_free_motion for the hits of this drain (boxesND.jl:44-45, symmetric in the two end points, so one test
         // serves both records of a pair): the boxes that survived the tile's cull, each through the scalar cache, 2 D v_cmpx in a row
         uint32_t pendflag = 0;
         [[maybe_unused]] unsigned pk_keep = 0, pc_keep = 0;
-        if constexpr (MODE == 2 && D <= 6) {
+        if constexpr (MODE == 2) {
             if (a.fb) {
                 unsigned pk = 0, pc = 0;
                 sl[0] = hit ? sl[0] : (double)INFINITY;       // lanes without a hit fail the first comparison
+                [[maybe_unused]] const unsigned long long hitm = __ballot(hit);
                 // the boxes some pair of this drain can meet at all: OR over the lanes of (mask of the query & mask of the candidate)
                 unsigned long long um = 0;
 #if !(MF_ABLATE & 16)
-#if MF_EARLY
                 if (hit) um = s_qm[ql] & e_sm;
-#else
-                if (hit) um = s_qm[ql] & a.smask[jg];
-#endif
                 {
                     uint32_t ul = (uint32_t)um, uh = (uint32_t)(um >> 32);
 #define MF_OR_DPP(x, ctrl, rm_, bc) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rm_, 0xf, bc)
@@ -832,11 +822,22 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                     while (mb) {
                         const int kbx = c * 64 + (__ffsll((long long)mb) - 1);
                         mb &= mb - 1;
-                        double blo[D], bhi[D];
                         const mf_cptr bp = mf_const(a.boxes) + (int64_t)kbx * 2 * D;
+                        if constexpr (D <= 6) {
+                            double blo[D], bhi[D];
 #pragma unroll
-                        for (int i = 0; i < D; ++i) { blo[i] = bp[i]; bhi[i] = bp[D + i]; }
-                        sweep_cmpx<D>::note(blo, bhi, sl, sh, pk, pc, kbx);
+                            for (int i = 0; i < D; ++i) { blo[i] = bp[i]; bhi[i] = bp[D + i]; }
+                            sweep_cmpx<D>::note(blo, bhi, sl, sh, pk, pc, kbx);
+                        } else {
+                            // 7 <= d <= 12: the axes six at a time (sweep_cmpx.h), the later bounds fetched only while a lane is left -- in
+                            // R^12 few (segment, box) pairs survive six axes.  The same list of the last four boxes met and their number.
+                            const unsigned long long pend = sweep_cmpx_groups<D>(hitm, bp, sl, sh);
+                            if (pend) {
+                                const bool pl = (pend >> lane) & 1ull;
+                                pk = pl ? ((pk << 8) | (unsigned)kbx) : pk;
+                                pc += pl ? 1u : 0u;
+                            }
+                        }
                     }
                 }
                 pendflag = pc ? (1u << 30) : 0u;
@@ -845,32 +846,6 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         }
         if constexpr (MODE == 2) {
             // ---- single pass: the records of this drain's hits go to the quarter logs ------------------------------------------------
-#if MF_EARLY < 2
-            // own record: column = the query ql of this tile, row = the candidate -> log (tile, ql >> 4); the place inside the drain's
-            // group is a returning LDS atomic on a per-drain counter (four addresses; the counters are left at zero again)
-            const int g = (int)(ql >> 4);
-            int pin = 0;
-            if (hit) pin = atomicAdd(&s_lc[g], 1);
-            // the same pair seen from the other end (half build): column jg, row = this query -> the log of jg's quarter tile.  The hits
-            // of a drain fall into a handful of such logs (its survivors come from two or three chunks): the lanes of each are found with
-            // one ballot per log, the first of them reserves the places of all
-            const int64_t fc = (int64_t)(jg >> 6) - a.blk_begin;        // the candidate's tile, counted from the shard's first
-            const bool fh = a.half && hit && fc >= 0 && fc < a.ntiles_shard;      // (the tile's own chunk too: its pairs are kept once, own_keep)
-            const int fq = (int)(fc * 4 + (int64_t)((jg & 63u) >> 4));
-            int leader = lane, pre = 0, cnt_l = 0;
-            {
-                unsigned long long rem = __ballot(fh);
-                while (rem) {
-                    const int L = __builtin_ctzll(rem);
-                    const int key = __builtin_amdgcn_readlane(fq, L);
-                    const bool mine = fh && fq == key;
-                    const unsigned long long mm = __ballot(mine);
-                    if (mine) { leader = L; pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u)); }
-                    if (lane == L) cnt_l = (int)__popcll(mm);
-                    rem &= ~mm;
-                }
-            }
-#endif
             // fb == 2: one item per (pair, box) unit of the pairs whose box met an obstacle's -- a pair that met k <= 4 boxes writes k
             // items, one that met more a single item that stands for "every box" -- in one of MF_NREG dense regions (this item's: item
             // mod MF_NREG), one reservation per drain
@@ -881,7 +856,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
             // finds most of a tile's pairs, and by item alone its units overflowed a region sized for the mean)
             [[maybe_unused]] const int iregion = (int)((item + (int64_t)ndrain * 131) & (MF_NREG - 1));
             ndrain = __builtin_amdgcn_readfirstlane(ndrain + 1);
-            if constexpr (D <= 6) {
+            {
                 if (a.fb == 2) {
                     iem = hit && pendflag != 0;
                     ipm = __ballot(iem);
@@ -900,31 +875,10 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                     }
                 }
             }
-#if MF_EARLY < 2
-            // the reservations of the drain are requested back to back -- own logs (lanes 0..3), the other columns' logs (group leaders),
-            // the pending-pair region above -- and consumed after the keys are built: one L2 round trip for all of them
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            int obase = 0;
-            if (lane < 4) {
-                const int c = s_lc[lane];
-                if (c) { s_lc[lane] = 0; obase = atomicAdd(&a.qlen[(tile - a.blk_begin) * 4 + lane], c); }
-            }
-            int fbase = 0;
-            if (fh && lane == leader) fbase = atomicAdd(&a.qlen[fq], cnt_l);
-#endif
             uint32_t own_key = 0, for_key = 0;
             const uint32_t qs = (uint32_t)(tile * 64) + ql;
-#if MF_EARLY
             if (hit) own_key = e_pj | ((ql & 15u) << 26) | pendflag;
-#else
-            if (hit) own_key = (uint32_t)a.perm[jg] | ((ql & 15u) << 26) | pendflag;
-#endif
-#if MF_EARLY
             if (fh) for_key = (uint32_t)s_operm[ql] | ((jg & 15u) << 26) | pendflag;
-#else
-            if (fh) for_key = (uint32_t)a.perm[qs] | ((jg & 15u) << 26) | pendflag;
-#endif
             const int own_p = __shfl(obase, g) + pin;
             const int for_p = __shfl(fbase, leader) + pre;
             [[maybe_unused]] uint32_t own_w = 0xffffffffu, for_w = 0xffffffffu;      // places of the two records (pending-pair items)
@@ -942,7 +896,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                     for_w = (uint32_t)for_p;
                 } else pool_over = 1;
             }
-            if constexpr (D <= 6) {
+            {
                 if (a.fb == 2 && ipm) {
                     // item: both cell-sorted positions (their quarters are the records' logs), ONE box the segment's box met (9 bits split
                     // over the two position words; 256 = every box), the places of the two records in their logs
@@ -1254,9 +1208,7 @@ int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec
 // single pass: the degree of every column = a count over the keys of its quarter tile's log (one wavefront per quarter log), written
 // straight to the two degree arrays the scans read (by original index and by cell-sorted position); the longest column (the ordering
 // kernel stages whole columns) and the fullest log (the next build's capacity) go to two words behind the pair counters
-// LPB = 4: one wavefront per log (a whole build: bandwidth-bound on the keys).  LPB = 1: the four wavefronts of a workgroup share one
-// log (a shard: too few logs to fill the chip, each a chain of dependent round trips -- four times the loads in flight per log)
-template <int LPB>
+// (a shard has too few logs to fill the chip; four wavefronts per log there measured slower -- 59 against 40 us at 8 ranks)
 __global__ __launch_bounds__(256) void k_log_degrees(const uint32_t* __restrict__ qkey, const int32_t* __restrict__ qlen, long long qcap, int64_t nq,
                                                      int64_t pos0, const int32_t* __restrict__ perm, int64_t* __restrict__ deg,
                                                      int64_t* __restrict__ degs, int32_t* __restrict__ max_deg, int32_t* __restrict__ qmax,
@@ -1267,21 +1219,17 @@ __global__ __launch_bounds__(256) void k_log_degrees(const uint32_t* __restrict_
     // (unsharded: the scans' extra last elements are zeroed here instead of by two fill launches)
     if (N_tail >= 0 && blockIdx.x == 0 && threadIdx.x == 0) { deg[N_tail] = 0; degs[npad] = 0; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t q = (LPB == 4) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
-    int* const cnt = s_c[LPB == 4 ? wave : 0];
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
     int kmax = 0, n = 0;
-    if (LPB == 1) { if (threadIdx.x < 16) cnt[threadIdx.x] = 0; __syncthreads(); }
     if (q < nq) {
-        if (LPB == 4) {
-            if (lane < 16) cnt[lane] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
+        if (lane < 16) s_c[wave][lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         n = (int)min((long long)qlen[q], qcap);
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(qkey + q * qcap);           // (qcap is a multiple of 4)
         // (four 16-byte loads in flight per lane: one wavefront per log with one load at a time was a chain of ~10 round trips, 84 % of
         // its cycles waiting)
-        for (int b0 = (LPB == 4 ? 0 : wave * 4 * 256); b0 < n; b0 += (LPB == 4 ? 1 : 4) * 4 * 256) {
+        for (int b0 = 0; b0 < n; b0 += 4 * 256) {
             uint4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1293,19 +1241,19 @@ __global__ __launch_bounds__(256) void k_log_degrees(const uint32_t* __restrict_
                 const int i0 = b0 + j * 256 + lane * 4;
                 const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) if (i0 + k < n) atomicAdd(&cnt[(w[k] >> 26) & 15u], 1);
+                for (int k = 0; k < 4; ++k) if (i0 + k < n) atomicAdd(&s_c[wave][(w[k] >> 26) & 15u], 1);
             }
         }
-    }
-    if (LPB == 1) __syncthreads();
-    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-    if (q < nq && lane < 16 && (LPB == 4 || wave == 0)) {
-        const int k = cnt[lane];
-        const int64_t pos = pos0 + q * 16 + lane;
-        const int32_t o = perm[pos];
-        if (o >= 0) deg[o] = k;
-        degs[pos] = k;                                     // (pad positions: 0 -- nothing else clears them on an unsharded ctx)
-        kmax = k;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 16) {
+            const int k = s_c[wave][lane];
+            const int64_t pos = pos0 + q * 16 + lane;
+            const int32_t o = perm[pos];
+            if (o >= 0) deg[o] = k;
+            degs[pos] = k;                                     // (pad positions: 0 -- nothing else clears them on an unsharded ctx)
+            kmax = k;
+        }
     }
     for (int off = 8; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
     if (lane == 0) { s_m[wave] = kmax; s_q[wave] = n; }
@@ -1323,14 +1271,9 @@ int32_t mpfmt_launch_log_degrees(mpfmt_ctx* ctx)
     const int64_t nq = (ctx->tile_end - ctx->tile_begin) * 4;
     if (nq <= 0) return MPFMT_OK;
     const bool whole = !(ctx->world > 1);
-    if (nq >= 16 * (int64_t)ctx->num_cus * 4)
-        hipLaunchKernelGGL((k_log_degrees<4>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ctx->stream, ctx->qkey, ctx->qlen, (long long)ctx->qcap, nq,
-                           ctx->tile_begin * 64, ctx->perm, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512), (int32_t*)(ctx->d_pairs + 513),
-                           whole ? ctx->N : (int64_t)-1, ctx->ntiles * 64);
-    else
-        hipLaunchKernelGGL((k_log_degrees<1>), dim3((unsigned)nq), dim3(256), 0, ctx->stream, ctx->qkey, ctx->qlen, (long long)ctx->qcap, nq,
-                           ctx->tile_begin * 64, ctx->perm, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512), (int32_t*)(ctx->d_pairs + 513),
-                           whole ? ctx->N : (int64_t)-1, ctx->ntiles * 64);
+    hipLaunchKernelGGL(k_log_degrees, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, ctx->stream, ctx->qkey, ctx->qlen, (long long)ctx->qcap, nq,
+                       ctx->tile_begin * 64, ctx->perm, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512), (int32_t*)(ctx->d_pairs + 513),
+                       whole ? ctx->N : (int64_t)-1, ctx->ntiles * 64);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }

@@ -39,9 +39,6 @@
 // (s_load into SGPRs, usable directly as the scalar operand of a vector compare) -- no alias analysis involved
 typedef const __attribute__((address_space(4))) double* sweep_cptr;
 __device__ __forceinline__ sweep_cptr as_const(const double* p) { return (sweep_cptr)(uintptr_t)p; }
-#ifndef SWEEP_GROUPS             // A/B: 0 = the d > 6 broad phase as one run of 2 d compares (round 3)
-#define SWEEP_GROUPS 1
-#endif
 
 // Wave-level cull of nb (<= SWEEP_CHUNK) staged boxes against the union box [ulo, uhi] of the
 // wavefront's segments.  Survivor words stay in (wave-uniform) registers.
@@ -208,9 +205,6 @@ __device__ __forceinline__ double lane_f64(double v, int l)
 //     the blocked ones.  The queue is flushed before the task header is recycled;
 //   - predicates are the straight-line forms on register-held boxes (see above).
 #define SWEEP_QCAP 128
-#ifndef SWEEP_ABL
-#define SWEEP_ABL 0               // > 0: timing-only stage ablations for tools/ablate_sweep.sh (wrong results by construction)
-#endif
 
 struct sweep_round {
     int valid, first, hs, c;          // hs: which of the two resident task headers; c: column within the task
@@ -457,9 +451,6 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
                         for (int i = 0; i < D; ++i) out |= (int)(bx.hi[i] < ulo[i]) | (int)(bx.lo[i] > uhi[i]);
                         smask[c] = __ballot(k < nb && !out);
                     }
-#if SWEEP_ABL == 4
-                    for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] = 0;
-#endif
                 }
                 const int64_t e0 = R0.e0, end = R0.end;
                 const bool active = e0 + lane < end;
@@ -467,11 +458,7 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
 #pragma unroll
                 for (int i = 0; i < D; ++i) v[i] = pv0[i];
                 // first chunk decides in_state_space; later chunks can only clear bits
-#if SWEEP_ABL == 1
-                bool fr = active;
-#else
                 bool fr = active && (b0 > 0 || in_state_space_sl<D>(v, ss));
-#endif
                 double l[D], h[D];
                 seg_bbox<D>(v, w, l, h);
                 int p0 = -1, p1 = -1;                    // boxes whose broad phase this lane failed
@@ -480,14 +467,11 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
 #pragma unroll
                 for (int c = 0; c < SWEEP_WORDS; ++c) {
                     unsigned long long m = smask[c];
-#if SWEEP_ABL == 3 || SWEEP_ABL == 4
-                    m = 0;
-#endif
                     while (m) {
                         const int k = c * 64 + (__ffsll((long long)m) - 1);
                         m &= m - 1;
                         bool pend;
-                        if constexpr (D > 8 && SWEEP_GROUPS) {
+                        if constexpr (D > 8) {
                             // the axes six at a time, the box through the scalar cache (sweep_cmpx.h): in R^12 few (segment, box) pairs
                             // are left after six axes, and then neither the other bounds are fetched nor their comparisons run
                             const unsigned long long pm = sweep_cmpx_groups<D>(__ballot(fr), as_const(boxes) + (int64_t)(b0 + k) * 2 * D, l, h);
@@ -511,9 +495,6 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
                     }
                 }
                 // queue the pending exact tests (the entry counts as free until a pass says otherwise)
-#if SWEEP_ABL == 2
-                p0 = p1 = -1;
-#endif
                 if constexpr (D <= 8) {
                     push(fr && p0 >= 0, v, eoff, ((uint32_t)R0.c << 16) | (uint32_t)max(p0, 0));
                     if (__ballot(fr && p1 >= 0)) {
@@ -536,11 +517,7 @@ __global__ __launch_bounds__(SWEEP_GT(D), (D <= 8 ? 1 : 2)) void k_graph_sweep(c
                 // the mask starts all-ones and every obstacle chunk only clears bits, so chunks (and the waves that
                 // happen to claim a task in each of them) commute
                 const unsigned long long clr = ~bits & __ballot(active);
-#if SWEEP_ABL == 5
-                if (lane == 0 && clr == 0x123456789abcull) {
-#else
                 if (lane == 0 && clr) {
-#endif
                     atomicAnd(&mask[wd], ~(clr << sh));
                     if (sh && (clr >> (64 - sh))) atomicAnd(&mask[wd + 1], ~(clr >> (64 - sh)));
                 }
@@ -796,7 +773,6 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
 #pragma unroll
             for (int i = 0; i < D; ++i) w[i] = X[(int64_t)x * D + i];
             // (uniform) the round's columns: cull box and survivors of each column not seen in the quarter before
-#if SWEEP_ABL != 4
 #pragma unroll
             for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] = 0;
             int xprev = -1;
@@ -826,13 +802,9 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
 #pragma unroll
                 for (int c = 0; c < SWEEP_WORDS; ++c) smask[c] |= slast[c];
             }
-#endif
             double v[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) v[i] = pv0[i];
-#if SWEEP_ABL == 1
-            bool fr = active;
-#else
             bool fr = active;
             if (ss_has) {
                 // the bounds are fetched (scalar cache) where they are used: resident in SGPRs across the box loop they would
@@ -844,7 +816,6 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
                 for (int i = 0; i < D; ++i) ok &= (int)(sp[i] <= v[i]) & (int)(v[i] <= sp[MPFMT_MAX_DIM + i]);
                 fr = active && ok != 0;
             }
-#endif
             double l[D], h[D];
             // map(min, v, w), map(max, v, w): only compared below, where a -0 / +0 difference to the reference's ternaries does not show
 #pragma unroll
@@ -861,16 +832,13 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
 #pragma unroll
             for (int c = 0; c < SWEEP_WORDS; ++c) {
                 unsigned long long m = smask[c];
-#if SWEEP_ABL == 3 || SWEEP_ABL == 4
-                m = 0;
-#endif
                 while (m) {
                     const int kb = c * 64 + (__ffsll((long long)m) - 1);
                     m &= m - 1;
                     // wave-uniform kb: the box comes through the scalar cache into SGPRs (the comparisons take it as their scalar
                     // operand); an LDS broadcast read would return 64 copies through the LDS data path
                     const sweep_cptr bp = as_const(boxes) + (int64_t)kb * 2 * D;
-                    if constexpr (D <= 6 || !SWEEP_GROUPS) {
+                    if constexpr (D <= 6) {
                         box_regs<D> bx;
 #pragma unroll
                         for (int i = 0; i < D; ++i) { bx.lo[i] = bp[i]; bx.hi[i] = bp[D + i]; }
@@ -883,9 +851,6 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
                     }
                 }
             }
-#if SWEEP_ABL == 2
-            pc = 0;
-#endif
             if (__ballot(pc > 4)) {
                 // (uniform, rare) lanes with more than four pending boxes: every surviving box tested exactly, in place
                 const bool o = pc > 4;
@@ -910,11 +875,7 @@ __global__ __launch_bounds__(SWEEP_GT(D), 1) void k_graph_sweep_rt(const double*
             }
             // the entries of a quarter are consecutive: its first lane clears the quarter's blocked bits in the word(s) they fall in
             const unsigned long long bits = __ballot(fr), act = __ballot(active);
-#if SWEEP_ABL == 5
-            if (false) {
-#else
             if ((lane & 15) == 0) {
-#endif
                 const unsigned clr = (unsigned)((~bits & act) >> (lane & 48)) & 0xffffu;
                 if (clr) {
                     const int sh = (int)(e & 63);
@@ -1151,12 +1112,12 @@ int32_t mpfmt_launch_exact_pairs(mpfmt_ctx* ctx, const int32_t* spec_fail)
 {
     const int d = ctx->d;
     const int64_t nitems = 1024;                             // regions of the list (MF_NREG in kernels_rdisc_mfma.hip)
-    if (ctx->tile_end <= ctx->tile_begin || d > 6) return MPFMT_OK;
+    if (ctx->tile_end <= ctx->tile_begin || d > 12) return MPFMT_OK;
     const size_t lds = (size_t)SWEEP_CHUNK * 2 * d * sizeof(double);
     mpfmt_timed tk(ctx);
 #define CASE(DD) case DD: hipLaunchKernelGGL((k_exact_pairs<DD>), dim3(1024, 4), dim3(256), lds, ctx->stream, (const uint4*)ctx->pair_items, (const int32_t*)ctx->pair_cnt, \
         (long long)ctx->pair_icap, nitems, (const int32_t*)ctx->pair_over, ctx->Xs, ctx->boxes, ctx->M, ctx->qkey, (long long)ctx->qcap, ctx->tile_begin * 4, spec_fail); break;
-    switch (d) { CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) default: break; }
+    switch (d) { CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) default: break; }
 #undef CASE
     tk.end("exact_pairs");
     HIPCHK(ctx, hipGetLastError());

@@ -60,7 +60,7 @@ struct wf_trip { int32_t x, y; double c; };
 
 struct mpfmt_wf {
     int64_t N = 0, words = 0;
-    uint64_t *W = nullptr, *H = nullptr, *Z = nullptr, *Zp = nullptr, *Hn = nullptr, *cand = nullptr, *F = nullptr;
+    uint64_t *W = nullptr, *H = nullptr, *Z = nullptr, *Zp = nullptr, *Hn = nullptr, *cand = nullptr, *F = nullptr, *WF = nullptr;
     double* C = nullptr;
     int32_t* A = nullptr;
     int32_t *zlist = nullptr, *xlist = nullptr;                   // batch nodes / candidates of the step, compacted from the masks
@@ -187,9 +187,10 @@ __global__ __launch_bounds__(64) void k_wf_init(int64_t N, int64_t words, int64_
 
 // The open set is a bit mask; what a step needs of it is a cost per open node -- a gather of C[i] behind every set bit.  Walking a
 // word's bits in one lane makes those gathers a dependent chain per lane (k_wf_select took 19 us a step that way, a fifth of the
-// solve).  Instead a wavefront takes 64 words (lane = word), lays their set bits out as a node list in LDS (prefix sum of the
-// popcounts; 12-bit positions inside the 64-word group) and then works lane = node: every round of 64 gathers is in flight at once.
-#define WF_GRP_CAP 4096           // nodes of one 64-word group (every bit set)
+// solve).  Instead a wavefront takes WF_GW words (lane = word), lays their set bits out as a node list in LDS (prefix sum of the
+// popcounts; positions inside the group) and then works lane = node: every round of 64 gathers is in flight at once.
+#define WF_GW 16                  // words per wavefront group (lanes 0 .. 15 hold one each): ~1000 groups at N = 1e6 instead of ~250 -- four times the gathers in flight
+#define WF_GRP_CAP (WF_GW * 64)   // nodes of one group (every bit set)
 __device__ __forceinline__ int wf_expand_group(unsigned long long m, uint16_t* __restrict__ s_list)
 {
     const int lane = threadIdx.x & 63;
@@ -207,6 +208,7 @@ __device__ __forceinline__ int wf_expand_group(unsigned long long m, uint16_t* _
 
 __global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __restrict__ H, uint64_t* __restrict__ Z, uint64_t* __restrict__ Zp,
                                                      uint64_t* __restrict__ Hn, uint64_t* __restrict__ cand,
+                                                     const uint64_t* __restrict__ W, const uint64_t* __restrict__ F, uint64_t* __restrict__ WF,
                                                      const double* __restrict__ C, double* __restrict__ part_c,
                                                      int64_t* __restrict__ part_i, wf_ctr* __restrict__ ctr)
 {
@@ -223,13 +225,14 @@ __global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __
         ctr->iters += 1; ctr->ntrip = 0; ctr->nz = 0; ctr->nx = 0;
     }
     double bc = 0.0; int64_t bi = -1;
-    for (int64_t w0 = (int64_t)blockIdx.x * 64; w0 < words; w0 += (int64_t)gridDim.x * 64) {       // wave-uniform trip count
+    for (int64_t w0 = (int64_t)blockIdx.x * WF_GW; w0 < words; w0 += (int64_t)gridDim.x * WF_GW) {       // wave-uniform trip count
         const int64_t w = w0 + threadIdx.x;
         uint64_t h = 0;
-        if (w < words) {
+        if (w < words && threadIdx.x < WF_GW) {
             const uint64_t z = Z[w];
             h = (H[w] & ~z) | Hn[w];                          // fmt.jl:83-84 for the batch of the previous step
             H[w] = h; Zp[w] = z; Z[w] = 0; Hn[w] = 0; cand[w] = 0;
+            WF[w] = W[w] & (F ? F[w] : ~0ull);                // unvisited and valid: the one word k_wf_mark gathers per entry
         }
         const int total = wf_expand_group(h, s_list);
         for (int k = threadIdx.x; k < total; k += 64) {
@@ -266,9 +269,10 @@ __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, con
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { ctr->cmin = cm; ctr->imin = im; }
     const double thr = cm + band;
-    for (int64_t w0 = (int64_t)blockIdx.x * 64; w0 < words; w0 += (int64_t)gridDim.x * 64) {       // wave-uniform trip count
+    for (int64_t w0 = (int64_t)blockIdx.x * WF_GW; w0 < words; w0 += (int64_t)gridDim.x * WF_GW) {       // wave-uniform trip count
         const int64_t w = w0 + threadIdx.x;
-        const uint64_t h = (w < words) ? H[w] : 0;
+        const bool own = w < words && threadIdx.x < WF_GW;
+        const uint64_t h = own ? H[w] : 0;
         s_z[threadIdx.x] = 0ull;
         const int total = wf_expand_group(h, s_list);
         for (int k = threadIdx.x; k < total; k += 64) {
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, con
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint64_t z = s_z[threadIdx.x];
+        const uint64_t z = own ? s_z[threadIdx.x] : 0ull;
         if (z) Z[w] = z;
         wf_append_word(z, w, zlist, &ctr->nz);
         __builtin_amdgcn_wave_barrier();
@@ -362,29 +366,22 @@ __global__ __launch_bounds__(256) void k_wf_sum_stats(const int64_t* __restrict_
 // mark pass: one wavefront per batch node walks the node's column (symmetric metric: forward set == column,
 // nearneighbors.jl:200-203) and sets the candidate bit of every unvisited valid row
 __global__ __launch_bounds__(256) void k_wf_mark(const int32_t* __restrict__ zlist, const int64_t* __restrict__ colptr,
-                                                 const int32_t* __restrict__ rowval, const uint64_t* __restrict__ W,
-                                                 const uint64_t* __restrict__ F, unsigned long long* __restrict__ cand,
-                                                 const wf_ctr* __restrict__ ctr)
+                                                 const int32_t* __restrict__ rowval, const uint64_t* __restrict__ WF,
+                                                 unsigned long long* __restrict__ cand, const wf_ctr* __restrict__ ctr)
 {
     if (wf_stop(ctr)) return;
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int nz = ctr->nz;
-    // A node is a chain of dependent round trips (list entry -> column bounds -> rows -> set words -> atomic) and a wavefront has a
-    // handful of nodes per step: the list entry is fetched two nodes ahead and the column bounds one node ahead, so a node's own
-    // chain starts at its rows.
-    const int st = gridDim.x * wpb;
-    const int i0 = blockIdx.x * wpb + (threadIdx.x >> 6);
-    int64_t za = (i0 < nz) ? zlist[i0] : -1, zb = (i0 + st < nz) ? zlist[i0 + st] : -1;
-    int64_t ba = za >= 0 ? colptr[za] : 0, ea = za >= 0 ? colptr[za + 1] : 0;
-    for (int iz = i0; iz < nz; iz += st) {
-        const int64_t beg = ba, end = ea;
-        const int64_t zc = (iz + 2 * st < nz) ? zlist[iz + 2 * st] : -1;
-        ba = zb >= 0 ? colptr[zb] : 0; ea = zb >= 0 ? colptr[zb + 1] : 0;
-        zb = zc;
+    // (per entry ONE gathered word -- WF = unvisited and valid, combined by k_wf_apply_min -- and the candidate word only for the entries
+    // that pass it: the kernel moves a 64-byte line from L2 per gathered word, and three gathers per entry ran at the L2's bandwidth.
+    // Fetching list entries and column bounds ahead, or keeping several chunks in flight, did not help: 24 us either way, or worse)
+    for (int iz = blockIdx.x * wpb + (threadIdx.x >> 6); iz < nz; iz += gridDim.x * wpb) {
+        const int64_t z = zlist[iz];
+        const int64_t beg = colptr[z], end = colptr[z + 1];
         for (int64_t e = beg + lane; e < end; e += 64) {
             const int64_t x = rowval[e];
-            if (!wf_bit(W, x) || (F && !wf_bit(F, x))) continue;              // fmt.jl:70-71
+            if (!wf_bit(WF, x)) continue;                                     // fmt.jl:70-71
             const unsigned long long bit = 1ull << (x & 63);
             if (cand[x >> 6] & bit) continue;                                 // seen already (a stale read only costs an atomic)
             atomicOr(&cand[x >> 6], bit);
@@ -472,11 +469,15 @@ __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict
         double best = 0.0;
         int64_t be = -1;
         int32_t by = -1;
-        for (int64_t e = beg + lane; e < end; e += 64) {                   // nearB(V, x, r, H) + findmin, fmt.jl:72-74
-            const int32_t y = rowval[e];
-            if (!wf_bit(H, y)) continue;
-            const double c = C[y] + nzval[e];
-            if (be < 0 || c < best) { best = c; be = e; by = y; }          // ascending e per lane keeps the first minimum
+        for (int64_t e0 = beg + lane; e0 < end + lane; e0 += 128) {        // nearB(V, x, r, H) + findmin, fmt.jl:72-74
+            // (two 64-entry chunks per pass: their rows, then their open-set words, then their costs are in flight together)
+            const int64_t e1 = e0 + 64;
+            const int32_t y0 = e0 < end ? rowval[e0] : -1, y1 = e1 < end ? rowval[e1] : -1;
+            const double d0 = e0 < end ? nzval[e0] : 0.0, d1 = e1 < end ? nzval[e1] : 0.0;
+            const bool o0 = y0 >= 0 && wf_bit(H, y0), o1 = y1 >= 0 && wf_bit(H, y1);
+            const double c0 = o0 ? C[y0] + d0 : 0.0, c1 = o1 ? C[y1] + d1 : 0.0;
+            if (o0 && (be < 0 || c0 < best)) { best = c0; be = e0; by = y0; }     // ascending e per lane keeps the first minimum
+            if (o1 && (be < 0 || c1 < best)) { best = c1; be = e1; by = y1; }
         }
         wf_lexmin_wave_y(best, be, by);                                    // rows ascend with e: first minimum = lowest e
         if (be < 0) continue;
@@ -582,7 +583,7 @@ void mpfmt_wf_free(mpfmt_ctx* ctx)
 {
     mpfmt_wf* s = wf_of(ctx);
     if (!s) return;
-    void* bufs[] = {s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->F, s->C, s->A, s->zlist, s->xlist, s->rowptr, s->colidx, s->part_c, s->part_i, s->stats, s->boxT, s->mytrips, s->xbuf,
+    void* bufs[] = {s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->F, s->WF, s->C, s->A, s->zlist, s->xlist, s->rowptr, s->colidx, s->part_c, s->part_i, s->stats, s->boxT, s->mytrips, s->xbuf,
                     s->ctr, s->path_dev};
     for (void* b : bufs) if (b) hipFree(b);
     if (s->ctr_host) hipHostFree(s->ctr_host);
@@ -595,13 +596,13 @@ static int32_t wf_alloc(mpfmt_ctx* ctx, mpfmt_wf* s, int64_t N, int world)
 {
     const int64_t words = (N + 63) / 64;
     if (s->N != N) {
-        void** bufs[] = {(void**)&s->W, (void**)&s->H, (void**)&s->Z, (void**)&s->Zp, (void**)&s->Hn, (void**)&s->cand, (void**)&s->F,
+        void** bufs[] = {(void**)&s->W, (void**)&s->H, (void**)&s->Z, (void**)&s->Zp, (void**)&s->Hn, (void**)&s->cand, (void**)&s->F, (void**)&s->WF,
                          (void**)&s->C, (void**)&s->A, (void**)&s->zlist, (void**)&s->xlist, (void**)&s->path_dev, (void**)&s->mytrips};
         for (void** b : bufs) if (*b) { HIPCHK(ctx, hipFree(*b)); *b = nullptr; }
         HIPCHK(ctx, hipMalloc((void**)&s->W, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->H, 8 * words));
         HIPCHK(ctx, hipMalloc((void**)&s->Z, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->Zp, 8 * words));
         HIPCHK(ctx, hipMalloc((void**)&s->Hn, 8 * words));
-        HIPCHK(ctx, hipMalloc((void**)&s->cand, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->F, 8 * words));
+        HIPCHK(ctx, hipMalloc((void**)&s->cand, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->F, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->WF, 8 * words));
         HIPCHK(ctx, hipMalloc((void**)&s->C, 8 * N)); HIPCHK(ctx, hipMalloc((void**)&s->A, 4 * N));
         HIPCHK(ctx, hipMalloc((void**)&s->zlist, 4 * N)); HIPCHK(ctx, hipMalloc((void**)&s->xlist, 4 * N));
         HIPCHK(ctx, hipMalloc((void**)&s->path_dev, 8 * (N + 1)));
@@ -630,7 +631,8 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     const int nparts = s->nparts;
     hipStream_t st = ctx->stream;
     const int d = ctx->d;
-    hipLaunchKernelGGL(k_wf_apply_min, dim3(nparts), dim3(64), 0, st, words, s->H, s->Z, s->Zp, s->Hn, s->cand, s->C, s->part_c, s->part_i, s->ctr);
+    hipLaunchKernelGGL(k_wf_apply_min, dim3(nparts), dim3(64), 0, st, words, s->H, s->Z, s->Zp, s->Hn, s->cand, s->W, s->checkpts ? s->F : nullptr, s->WF, s->C,
+                       s->part_c, s->part_i, s->ctr);
     hipLaunchKernelGGL(k_wf_select, dim3(nparts), dim3(64), 0, st, words, nparts, s->H, s->Z, s->C, ctx->Xo, d, s->part_c, s->part_i, s->band,
                        s->single, s->goal, s->zlist, s->ctr);
     const uint64_t* F = s->checkpts ? s->F : nullptr;
@@ -638,7 +640,7 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     if (!s->sharded) {
         // forward sets: the column itself for a metric (nearneighbors.jl:200-203), the row of the cost matrix otherwise
         hipLaunchKernelGGL(k_wf_mark, dim3(grid), dim3(256), 0, st, s->zlist, s->directed ? s->rowptr : ctx->colptr,
-                           s->directed ? s->colidx : ctx->rowval, s->W, F, (unsigned long long*)s->cand, s->ctr);
+                           s->directed ? s->colidx : ctx->rowval, s->WF, (unsigned long long*)s->cand, s->ctr);
     } else {
         const int64_t pb = std::min<int64_t>(ctx->tile_begin * 64, ctx->N), pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
         hipLaunchKernelGGL(k_wf_mark_owned, dim3(ctx->num_cus * 8), dim3(256), 0, st, ctx->perm, pb, pe, ctx->colptr, ctx->rowval, s->W, F, s->Z,
@@ -743,7 +745,7 @@ int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t check
     const int ng = goal_kind == MPFMT_GOAL_RECT ? 2 * d : goal_kind == MPFMT_GOAL_BALL ? d + 1 : d;
     memset(s->goal.g, 0, sizeof s->goal.g);
     for (int i = 0; i < ng; ++i) s->goal.g[i] = goal_params[i];
-    s->nparts = (int)std::min<int64_t>(WF_MAXPARTS, (s->words + 63) / 64);
+    s->nparts = (int)std::min<int64_t>(WF_MAXPARTS, (s->words + WF_GW - 1) / WF_GW);
     if (s->nparts < 1) s->nparts = 1;
     for (int k = 0; k < 4; ++k) s->prev_tot[k] = 0;
 
@@ -1023,7 +1025,7 @@ extern "C++" int32_t mpfmt_wf_begin_directed(mpfmt_ctx* ctx, int64_t init_idx, i
     const int ng = goal_kind == MPFMT_GOAL_RECT ? 2 * gd : goal_kind == MPFMT_GOAL_BALL ? gd + 1 : d;
     memset(s->goal.g, 0, sizeof s->goal.g);
     for (int i = 0; i < ng; ++i) s->goal.g[i] = goal_params[i];
-    s->nparts = (int)std::min<int64_t>(WF_MAXPARTS, (s->words + 63) / 64);
+    s->nparts = (int)std::min<int64_t>(WF_MAXPARTS, (s->words + WF_GW - 1) / WF_GW);
     if (s->nparts < 1) s->nparts = 1;
     for (int k = 0; k < 4; ++k) s->prev_tot[k] = 0;
     HIPCHK(ctx, hipMemcpyAsync(s->F, F_host, 8 * (size_t)s->words, hipMemcpyHostToDevice, ctx->stream));

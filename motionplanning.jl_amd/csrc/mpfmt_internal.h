@@ -145,7 +145,6 @@ struct mpfmt_ctx {
     int32_t cell_fb_max = 8;             // position bits inside a cell that the sort key carries (k_cellkey)
     int32_t mf_xcd_mode = -1;            // work items go to the XCDs in interleaved groups of this many; -1: 256 for launches of >= 32768 items, else 64
                                          // (north star: groups of 64 2.02 ms / 5.6 GB of counter traffic, 256 2.04 / 4.6, 512 2.05 / 4.4; one range per XCD 2.41 ms)
-    int32_t mf_ablate = 0;               // timing experiments only
     int32_t num_cus = 256;               // compute units of the device (persistent-grid sizing)
     int ord_per_cu = 0;          // k_order_logs: resident workgroups per CU on THIS ctx's device
     int* sweep_ctr = nullptr;            // graph sweep: one task counter per obstacle chunk

@@ -116,7 +116,8 @@ def test_pairs_inside_one_tile_are_found_once(orc, d, N, r, dup):
 
 
 @pytest.mark.parametrize("form", [2, 1, 0])
-@pytest.mark.parametrize("d,N,r,M", [(2, 6000, 0.03, 12), (3, 7001, 0.09, 40), (6, 20000, 0.42, 200)])
+@pytest.mark.parametrize("d,N,r,M", [(2, 6000, 0.03, 12), (3, 7001, 0.09, 40), (6, 20000, 0.42, 200),
+                                     (7, 20000, 0.40, 200), (9, 16000, 0.50, 200), (12, 16000, 0.66, 200)])
 def test_edge_tests_fused_into_the_half_build(orc, form, d, N, r, M):
     """The step's edge tests in their three forms -- 2: broad phase in the pair kernel's drain, flagged PAIRS tested before the logs are
     ordered, the ordering pass writes the mask; 1: flagged ENTRIES listed by the ordering pass and tested afterwards; 0: the whole
@@ -143,7 +144,9 @@ def test_edge_tests_fused_into_the_half_build(orc, form, d, N, r, M):
         assert np.array_equal(free.view(np.uint64), orc.graph_edges_free(X, oc, orow, lohi, lo, hi))
     ok = {0, form} | ({1} if form == 2 else set())            # (0: not a single-pass build, or a trusted capacity did not hold; 1 under 2: not a half build)
     assert all(s in ok for s in seen), seen
-    if d == 6: assert form == 0 or form in seen, seen
+    # (7 <= d <= 12: the drain's broad phase runs as chains of six axes and exists as form 2 only -- form 1's exact kernel is built for d <= 6)
+    if d >= 6 and not (d > 6 and form == 1): assert form == 0 or form in seen, seen
+    if d > 6 and form == 1: assert set(seen) == {0}, seen
 
 
 @pytest.mark.parametrize("form", [2, 1])
@@ -322,6 +325,17 @@ def test_cfg3_r12_full_size_properties(orc):
         want = orc.unpack(orc.edges_free(w.X, rowval[es] - 1, cols[es] - 1, w.lohi, w.ss_lo, w.ss_hi), len(es))
         assert np.array_equal(mask[es], want)
         assert np.array_equal(c.points_free(), orc.points_free(w.X, w.lohi, w.ss_lo, w.ss_hi))
+        # the STEP on the same world (what `bench.py --workload cfg3` times): half build with the edge tests fused into it (form 2: the
+        # drain's broad phase in chains of six axes, flagged pairs through k_exact_pairs<12>, mask written by the ordering pass) -- the
+        # same graph and the same mask, bit for bit, as the two-phase build and the whole sweep above
+        whole_mask = c.graph_edges_free()
+        c.set_option("rebuild_index", 1)
+        for it in range(2):
+            assert c.graph_step_device(w.r) == nnz
+            assert c.stat("rdisc_half_used") == 1 and c.stat("sweep_form") == 2, (it, c.stat("sweep_form"))
+            cp2, rv2, nz2, fr2 = _resident_graph(c, N)
+            assert np.array_equal(cp2 + 1, colptr) and np.array_equal(rv2.astype(np.int64) + 1, rowval) and np.array_equal(nz2, nzval)
+            assert np.array_equal(fr2.view(np.uint64), whole_mask)
 
 
 def test_cfg4_double_integrator_full_size_properties(orc):

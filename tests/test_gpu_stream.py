@@ -71,7 +71,7 @@ def test_cfg3_at_the_fmt_radius_streams(orc):
     Hbits = rng.random(N) < 0.25
     with mp.Context(0) as c:
         c.upload_samples(w.X); c.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
-        got = c.rdisc_stream(r, Cc, L.pack_bits(Hbits))
+        got = c.rdisc_stream(r, Cc, L.pack_bits(Hbits), want_free=True)
     deg = got["deg"]
     assert got["nnz"] == int(deg.sum()) and got["nnz"] % 2 == 0
     # (E[deg] = 4 716 for an INTERIOR sample; in the unit cube of R^12 nearly every sample is within r of several faces: the mean is ~770)
@@ -80,6 +80,9 @@ def test_cfg3_at_the_fmt_radius_streams(orc):
     for v in rng.integers(0, N, size=60):
         oi, od = kd.inball(int(v), r)
         assert deg[v] == len(oi), v
+        # free edges of the column: is_free_motion(V[y], V[v]) over its rows (statespaces.jl:153-158), against the oracle's edge test
+        fb = orc.unpack(orc.edges_free(w.X, oi, np.full(len(oi), v, dtype=np.int64), w.lohi, w.ss_lo, w.ss_hi), len(oi))
+        assert got["free_deg"][v] == int(fb.sum()), v
         keep = Hbits[oi]
         if keep.any():
             cst = Cc[oi[keep]] + od[keep]
