@@ -963,9 +963,20 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         if (ctx->rdisc_path == 2 && !mf)
             return mpfmt_fail(ctx, MPFMT_ERR_ARG, "MFMA r-disc path requested but not usable (d > 12 or radius too small for the fp16 shell)");
     }
+    // a radius below the fp16 shell (large low-dimensional worlds): the same single-pass pipeline -- chunk lists, half build, logs, fused
+    // edge tests -- with the exact fp64 test itself as the filter (k_rdisc_vf_w4) instead of the two-pass exact kernel and a whole sweep
+    bool vf = false;
+    if (ctx->rdisc_path == 0 && !mf) {
+        double ext = 0.0;
+        for (int i = 0; i < ctx->d; ++i) ext = std::max(ext, ctx->bb_hi[i] - ctx->bb_lo[i]);
+        vf = ctx->d <= 3 && r > 0.0 && ext > 0.0 && ctx->ntiles * 64 < ((int64_t)1 << 26) && ctx->use_pool && ctx->use_half && nt > 0 &&
+             !too_long_hint && !ctx->pool_skip_once && ctx->world == 1;
+    }
+    ctx->filter_valu = vf;
+    if (vf) mf = true;                                        // (the pair-kernel pipeline from here on)
     if (mf) {
         mpfmt_timed tm2(ctx);
-        if (ctx->ops_r != ctx->grid_r) {
+        if (!vf && ctx->ops_r != ctx->grid_r) {
             if ((rc = mpfmt_mfma_build_operands(ctx))) return rc;
             ctx->ops_r = ctx->grid_r;
             ctx->lists_r = -1.0;
@@ -1069,6 +1080,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             ctx->qcap = qcap;
         }
     }
+    if (vf && !pool) { vf = false; mf = false; half = false; ctx->filter_valu = false; ctx->rdisc_path_used = 1; }      // (no room for the logs: the exact two-pass kernel)
     if (half && !pool) {
         // (no room for the logs after all: the two-pass kernels need whole lists)
         half = false;

@@ -483,7 +483,10 @@ int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r)
 
 // MODE 0: count only   1: fill the staging CSC (needs offsets from a count pass)   2: count AND append hits to the item's log
 // W4: built for 4 wavefronts per SIMD (128 VGPRs)
-template <int D, int MODE, bool W4>
+// VF: the filter is the canonical fp64 test itself on the vector ALUs instead of the fp16 matrix-core one -- for worlds whose radius lies
+// below the fp16 shell of globally normalised coordinates (large low-dimensional worlds: 2-D, N >= 1e5 at small degrees).  The same
+// pipeline otherwise: chunk lists, the 64-bit hit word per lane in the accumulator layout, record queue, drain, logs, fused edge tests.
+template <int D, int MODE, bool W4, bool VF = false>
 __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
 {
     __shared__ double s_q[64 * D];                        // fp64 query coordinates (AoS) for the refine
@@ -577,7 +580,10 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     f32x16 zero16;
 #pragma unroll
     for (int k = 0; k < 16; ++k) zero16[k] = 0.0f;
-    if constexpr (K8) {
+    if constexpr (VF) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) { aF[rb] = half8{}; aF4[rb] = half4{}; cinit[rb] = zero16; }
+    } else if constexpr (K8) {
         const uint2* __restrict__ ops2 = reinterpret_cast<const uint2*>(a.ops);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
@@ -964,7 +970,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     // B fragments come through a buffer descriptor: per-lane byte offset fixed for the whole kernel, chunk offset scalar
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.ops), 0, (int)(a.npad * (K8 ? 16 : 32)), 0x00020000);
     const int voff = K8 ? lane * 16 : col * 32 + kb * 16;
-    auto load_b = [&](uint32_t c, u32x4 (&bq)[K8 ? 1 : 2]) {
+    [[maybe_unused]] auto load_b = [&](uint32_t c, u32x4 (&bq)[K8 ? 1 : 2]) {
         if constexpr (K8) {
             bq[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (int)(c * 1024u), 0);
         } else {
@@ -975,7 +981,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
     // one chunk: 4 independent MFMAs back to back (2 query row blocks x 2 candidate column blocks), sign extraction, record push
     // (the ring slot is refilled -- chunk cn -- as soon as the MFMAs have read it: no register copies, the load is in flight during
     // this chunk's extraction and the following PF - 1 chunks)
-    auto process = [&](uint32_t c, u32x4 (&bq)[K8 ? 1 : 2], bool refill, uint32_t cn) {
+    [[maybe_unused]] auto process = [&](uint32_t c, u32x4 (&bq)[K8 ? 1 : 2], bool refill, uint32_t cn) {
         tested += 64ull * 64ull;
         if (MF_ABLATE & 4) { asm volatile("" :: "v"(bq[0].x)); if (refill) load_b(cn, bq); return; }
         f32x16 acc0, acc1, acc2, acc3;
@@ -1019,6 +1025,55 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         }
     };
 
+    // ---- VF: one chunk on the vector ALUs: this lane's two candidates (columns col and 32 + col of the chunk) against its 2 x 16 query
+    // rows, canonical fp64 d2 <= r2, bits laid out like the accumulators' signs (bit 16 t + 15 - r: t = candidate half * 2 + row block)
+    [[maybe_unused]] auto load_c = [&](uint32_t c, double (&cb)[2 * D]) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            cb[i] = a.Xs[((int64_t)c * 64 + col) * D + i];
+            cb[D + i] = a.Xs[((int64_t)c * 64 + 32 + col) * D + i];
+        }
+    };
+    [[maybe_unused]] auto process_vf = [&](uint32_t c, double (&cb)[2 * D], bool refill, uint32_t cn) {
+        tested += 64ull * 64ull;
+        double c0[D], c1[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) { c0[i] = cb[i]; c1[i] = cb[D + i]; }
+        if (refill) load_c(cn, cb);
+        unsigned long long H = 0;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            uint32_t h0 = 0, h1 = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+                double d20 = 0.0, d21 = 0.0;
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    const double qi = s_q[row * D + i];
+                    const double t0 = qi - c0[i], t1 = qi - c1[i];
+                    const double tt0 = t0 * t0, tt1 = t1 * t1;
+                    d20 = (i == 0) ? tt0 : d20 + tt0;
+                    d21 = (i == 0) ? tt1 : d21 + tt1;
+                }
+                h0 |= (d20 <= a.r2) ? (1u << (15 - r)) : 0u;
+                h1 |= (d21 <= a.r2) ? (1u << (15 - r)) : 0u;
+            }
+            H |= ((unsigned long long)h0 << (16 * rb)) | ((unsigned long long)h1 << (16 * (2 + rb)));
+        }
+        if constexpr (MODE == 2) { if (c == (uint32_t)tile) H &= own_keep; }
+        const unsigned long long m = __ballot(H != 0);
+        if (m) {
+            while (rcount > MF_RCAP - 64) expand();
+            if (H != 0) {
+                const int pos = rcount + (int)__popcll(m & ((1ull << lane) - 1ull));
+                s_rm[pos] = (c << 6) | (uint32_t)lane;
+                s_rh[pos] = H;
+            }
+            rcount = __builtin_amdgcn_readfirstlane(rcount + (int)__popcll(m));
+        }
+    };
+
     // ---- this item's slice of the tile's candidate chunk list (built once per tile by k_chunk_lists) ------------------
     {
         const int64_t tl = tile - a.blk_begin;
@@ -1042,10 +1097,14 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         // latency x concurrency bound (L2 / MALL round trips), so more loads in flight per wavefront = more bandwidth.
         constexpr int PF = (K8 && !W4) ? 4 : 2;
         uint32_t lv = load_blk(0), lvn = load_blk(1);
-        u32x4 ring[PF][K8 ? 1 : 2];
+        [[maybe_unused]] u32x4 ring[PF][K8 ? 1 : 2];
+        [[maybe_unused]] double cring[VF ? PF : 1][2 * D];
         if (!(MF_ABLATE & 8)) {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) if (u < cnt) load_b((uint32_t)__builtin_amdgcn_readlane((int)lv, u), ring[u]);
+            for (int u = 0; u < PF; ++u) if (u < cnt) {
+                if constexpr (VF) load_c((uint32_t)__builtin_amdgcn_readlane((int)lv, u), cring[u]);
+                else load_b((uint32_t)__builtin_amdgcn_readlane((int)lv, u), ring[u]);
+            }
             for (int k = 0; k < cnt; k += PF) {
                 if ((k & 63) == 0 && k > 0) { lv = lvn; lvn = load_blk((k >> 6) + 1); }
 #pragma unroll
@@ -1056,7 +1115,8 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
                         const bool refill = kk + PF < cnt;
                         const int kn = (kk + PF) & 63;
                         const uint32_t cn = (uint32_t)((kn < PF) ? __builtin_amdgcn_readlane((int)lvn, kn) : __builtin_amdgcn_readlane((int)lv, kn));
-                        process(c, ring[u], refill, cn);
+                        if constexpr (VF) process_vf(c, cring[u], refill, cn);
+                        else process(c, ring[u], refill, cn);
                     }
                 }
             }
@@ -1087,6 +1147,12 @@ template <int D, int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rdisc_mfma_w4(mf_args a, mpfmt_grid G)
 {
     rdisc_mfma_body<D, MODE, true>(a, G);
+}
+// the single-pass pipeline with the exact fp64 filter on the vector ALUs (d <= 3: large low-dimensional worlds)
+template <int D>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rdisc_vf_w4(mf_args a, mpfmt_grid G)
+{
+    rdisc_mfma_body<D, 2, true, true>(a, G);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
@@ -1317,6 +1383,19 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     const int64_t gran = NXCD * (int64_t)std::max(1, a.xcd_mode);
     const unsigned nblk = (unsigned)(((a.nitems + gran - 1) / gran) * gran);
     const mpfmt_grid& G = ctx->grid;
+    if (ctx->filter_valu) {
+        if constexpr (MODE == 2) {
+            switch (ctx->d) {
+                case 1: hipLaunchKernelGGL((k_rdisc_vf_w4<1>), dim3(nblk), dim3(64), 0, ctx->stream, a, G); break;
+                case 2: hipLaunchKernelGGL((k_rdisc_vf_w4<2>), dim3(nblk), dim3(64), 0, ctx->stream, a, G); break;
+                case 3: hipLaunchKernelGGL((k_rdisc_vf_w4<3>), dim3(nblk), dim3(64), 0, ctx->stream, a, G); break;
+                default: return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the vector-ALU filter is built for d <= 3");
+            }
+            HIPCHK(ctx, hipGetLastError());
+            return MPFMT_OK;
+        }
+        return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the vector-ALU filter exists for the single-pass build only");
+    }
 #define CASE(DD) case DD: launch_pair_kernel<DD, MODE>(ctx, nblk, a, G); break;
     switch (ctx->d) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)

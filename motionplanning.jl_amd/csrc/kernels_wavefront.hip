@@ -48,7 +48,7 @@ struct wf_ctr {
     int64_t imin;
     int64_t tot[4];               // sums of the per-block statistics: batch nodes, samples examined, connected, edge checks
     int32_t ended;                // latched by the first k_wf_apply_min that finds a goal batch recorded: k_wf_select, which must not
-    int32_t pad_;                 // read goal_cbits (its own blocks write it), returns on this flag in the steps enqueued after the end
+    int32_t ticket;               // k_wf_apply_min: blocks that have written their partial minimum (the last one reduces them all)
 };
 enum { WF_NZ = 0, WF_NX = 1, WF_NCONN = 2, WF_CHECKS = 3 };
 
@@ -243,7 +243,24 @@ __global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __
         __builtin_amdgcn_wave_barrier();                      // (the list is rewritten by the next group)
     }
     wf_lexmin_wave(bc, bi);
-    if (threadIdx.x == 0) { part_c[blockIdx.x] = bc; part_i[blockIdx.x] = bi; }
+    // the block that finishes last folds the partial minima into ctr->cmin / imin (imin < 0: the open set is empty): k_wf_select reads two
+    // words instead of every block reducing every partial (977 blocks x 977 partials: 25 of its 25 us a step)
+    int last = 0;
+    if (threadIdx.x == 0) {
+        part_c[blockIdx.x] = bc; part_i[blockIdx.x] = bi;
+        __threadfence();
+        last = atomicAdd(&ctr->ticket, 1) == (int)gridDim.x - 1;
+    }
+    last = __shfl(last, 0);
+    if (!last) return;
+    __threadfence();
+    double cm = 0.0; int64_t im = -1;
+    for (int p = threadIdx.x; p < (int)gridDim.x; p += 64) {
+        const double c = ((volatile double*)part_c)[p]; const int64_t i = ((volatile int64_t*)part_i)[p];
+        if (i >= 0 && (im < 0 || c < cm || (c == cm && i < im))) { cm = c; im = i; }
+    }
+    wf_lexmin_wave(cm, im);
+    if (threadIdx.x == 0) { ctr->cmin = cm; ctr->imin = im; ctr->ticket = 0; }
 }
 
 // goal_cbits is written (atomicMin) only by blocks that have passed the entry test, which therefore reads `done` alone: a
@@ -257,17 +274,11 @@ __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, con
     __shared__ uint16_t s_list[WF_GRP_CAP];
     __shared__ unsigned long long s_z[64];
     if (ctr->done || ctr->ended) return;
-    double cm = 0.0; int64_t im = -1;
-    for (int p = threadIdx.x; p < nparts; p += 64) {
-        const double c = part_c[p]; const int64_t i = part_i[p];
-        if (i >= 0 && (im < 0 || c < cm || (c == cm && i < im))) { cm = c; im = i; }
-    }
-    wf_lexmin_wave(cm, im);
+    const double cm = ctr->cmin; const int64_t im = ctr->imin;      // (folded by the last block of k_wf_apply_min)
     if (im < 0) {                                   // H is empty: fmt.jl:85-89 `break`
         if (blockIdx.x == 0 && threadIdx.x == 0) ctr->done = 2;
         return;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr->cmin = cm; ctr->imin = im; }
     const double thr = cm + band;
     for (int64_t w0 = (int64_t)blockIdx.x * WF_GW; w0 < words; w0 += (int64_t)gridDim.x * WF_GW) {       // wave-uniform trip count
         const int64_t w = w0 + threadIdx.x;
@@ -432,8 +443,9 @@ __global__ void k_wf_box_transpose(const double* __restrict__ boxes, int M, int 
     bT[t] = boxes[(int64_t)min(k, M - 1) * d2 + j];               // padding repeats the last box
 }
 
-// one wavefront per candidate x.  MODE 0: connect in place; MODE 1: emit triples
-template <int D, int MODE>
+// one wavefront per candidate x.  MODE 0: connect in place; MODE 1: emit triples.  GEOM: the edge tests run against the obstacle set here
+// (the lazy form); without it they are a bit of the resident mask and the kernel holds no geometry at all (four candidates in flight)
+template <int D, int MODE, bool GEOM>
 __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict__ xlist, const int64_t* __restrict__ colptr,
                                                     const int32_t* __restrict__ rowval, const double* __restrict__ nzval,
                                                     const uint64_t* __restrict__ H, double* __restrict__ C, int32_t* __restrict__ A,
@@ -449,73 +461,97 @@ __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict
     const int wpb = blockDim.x >> 6;
     int my_checks = 0, my_conn = 0;                                        // lane 0 counts for its wavefront
     const int nx = ctr->nx;
-    // (the candidate and its column bounds are fetched ahead, like k_wf_mark's nodes; the winner's row rides through the reduce, the
-    // candidate's own state is requested with its rows: what is left of the chain is rows -> open bits -> costs -> parent state / mask bit)
+    // A candidate is a chain of dependent round trips (list entry -> column bounds -> rows -> open-set words -> costs -> [reduce] ->
+    // mask bit / parent state -> stores) and a wavefront has a handful of candidates per step: one at a time the kernel sat out every
+    // trip (15 us of wavefront time per candidate).  NB candidates are taken per pass and every stage is issued for all of them before
+    // the next stage's first use: the trips of the NB chains overlap.  The winner's row rides through the reduce (no reload of rowval).
+    constexpr int NB = GEOM ? 1 : 4;
     const int st = gridDim.x * wpb;
-    const int i0 = blockIdx.x * wpb + (threadIdx.x >> 6);
-    int64_t xa = (i0 < nx) ? xlist[i0] : -1, xb = (i0 + st < nx) ? xlist[i0 + st] : -1;
-    int64_t ba = xa >= 0 ? colptr[xa] : 0, ea = xa >= 0 ? colptr[xa + 1] : 0;
-    for (int ix = i0; ix < nx; ix += st) {
-        const int64_t x = xa, beg = ba, end = ea;
-        const int64_t xc = (ix + 2 * st < nx) ? xlist[ix + 2 * st] : -1;
-        ba = xb >= 0 ? colptr[xb] : 0; ea = xb >= 0 ? colptr[xb + 1] : 0;
-        xa = xb; xb = xc;
-        double w[D];
-        const bool need_w = !(gfree || nseg);                              // (the lazy edge test reads both ends)
-        if (need_w) {
+    for (int ix0 = blockIdx.x * wpb + (threadIdx.x >> 6); ix0 < nx; ix0 += NB * st) {
+        int64_t x[NB], beg[NB], end[NB];
 #pragma unroll
-            for (int i = 0; i < D; ++i) w[i] = X[x * D + i];
-        }
-        double best = 0.0;
-        int64_t be = -1;
-        int32_t by = -1;
-        for (int64_t e0 = beg + lane; e0 < end + lane; e0 += 128) {        // nearB(V, x, r, H) + findmin, fmt.jl:72-74
-            // (two 64-entry chunks per pass: their rows, then their open-set words, then their costs are in flight together)
-            const int64_t e1 = e0 + 64;
-            const int32_t y0 = e0 < end ? rowval[e0] : -1, y1 = e1 < end ? rowval[e1] : -1;
-            const double d0 = e0 < end ? nzval[e0] : 0.0, d1 = e1 < end ? nzval[e1] : 0.0;
-            const bool o0 = y0 >= 0 && wf_bit(H, y0), o1 = y1 >= 0 && wf_bit(H, y1);
-            const double c0 = o0 ? C[y0] + d0 : 0.0, c1 = o1 ? C[y1] + d1 : 0.0;
-            if (o0 && (be < 0 || c0 < best)) { best = c0; be = e0; by = y0; }     // ascending e per lane keeps the first minimum
-            if (o1 && (be < 0 || c1 < best)) { best = c1; be = e1; by = y1; }
-        }
-        wf_lexmin_wave_y(best, be, by);                                    // rows ascend with e: first minimum = lowest e
-        if (be < 0) continue;
-        const int64_t y = by;
-        bool inb = true;
-        double v[D];
-        if (!all_in || need_w) {
+        for (int k = 0; k < NB; ++k) x[k] = (ix0 + k * st < nx) ? (int64_t)xlist[ix0 + k * st] : -1;
 #pragma unroll
-            for (int i = 0; i < D; ++i) v[i] = X[y * D + i];
-            inb = in_state_space_sl<D>(v, ss);                             // statespaces.jl:155: first point of the segment
-        }
-        if (lane == 0) my_checks += nseg ? (int)nseg[be] : (inb ? 1 : 0);  // boxesND.jl:26 is reached only then
-        bool fr;
-        if (gfree) {
-            fr = wf_bit(gfree, be);
-        } else {
-            double l[D], h[D];
-            seg_bbox<D>(v, w, l, h);
-            bool blocked = false;
-            for (int k0 = 0; k0 < M; k0 += 64) {                           // lane = obstacle (boxesND.jl:52-56; @all in any order)
-                const int k = k0 + lane;
-                const box_regs<D> b = wf_load_box_T<D>(bT, mpad, k);       // k < mpad always: the table is padded to 64 lanes
-                const bool pend = (k < M) && !broadphase_free_sl<D>(l, h, b);
-                if (__ballot(pend)) {
-                    if (pend) blocked = blocked || !narrow_free_sl<D>(v, w, b);
-                }
+        for (int k = 0; k < NB; ++k) { beg[k] = x[k] >= 0 ? colptr[x[k]] : 0; end[k] = x[k] >= 0 ? colptr[x[k] + 1] : 0; }
+        double best[NB];
+        int64_t be[NB];
+        int32_t by[NB];
+        int64_t span = 0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { best[k] = 0.0; be[k] = -1; by[k] = -1; span = max(span, end[k] - beg[k]); }
+        for (int64_t off = lane; off < span + lane; off += 64) {           // nearB(V, x, r, H) + findmin, fmt.jl:72-74 (wave-uniform trips)
+            int32_t y0[NB];
+            double d0[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int64_t e0 = beg[k] + off;
+                y0[k] = e0 < end[k] ? rowval[e0] : -1;
+                d0[k] = e0 < end[k] ? nzval[e0] : 0.0;
             }
-            fr = inb && (__ballot(blocked) == 0);
+            unsigned long long h0[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) h0[k] = y0[k] >= 0 ? H[y0[k] >> 6] : 0ull;
+            double c0[NB];
+            bool o0[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                o0[k] = y0[k] >= 0 && ((h0[k] >> (y0[k] & 63)) & 1ull);
+                c0[k] = o0[k] ? C[y0[k]] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const double s0 = c0[k] + d0[k];
+                if (o0[k] && (be[k] < 0 || s0 < best[k])) { best[k] = s0; be[k] = beg[k] + off; by[k] = y0[k]; }     // ascending e per lane keeps the first minimum
+            }
         }
-        if (fr && lane == 0) {                                             // fmt.jl:76-80
-            if (MODE == 0) {
-                A[x] = (int32_t)y; C[x] = best;
-                atomicAnd(&W[x >> 6], ~(1ull << (x & 63)));
-                atomicOr(&Hn[x >> 6], 1ull << (x & 63));
-                ++my_conn;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) wf_lexmin_wave_y(best[k], be[k], by[k]);    // rows ascend with e: first minimum = lowest e
+        // the edge tests of the NB winners: their mask words requested together (resident mask), or one lazy test after the other
+        unsigned long long gw[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) gw[k] = (gfree && be[k] >= 0) ? gfree[be[k] >> 6] : 0ull;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            if (be[k] < 0) continue;                                           // (wave-uniform: be is the reduced value)
+            const int64_t y = by[k];
+            bool inb = true;
+            double v[D];
+            [[maybe_unused]] double w[D];
+            if (!all_in || GEOM) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) v[i] = X[y * D + i];
+                inb = in_state_space_sl<D>(v, ss);                             // statespaces.jl:155: first point of the segment
+            }
+            if (lane == 0) my_checks += nseg ? (int)nseg[be[k]] : (inb ? 1 : 0);   // boxesND.jl:26 is reached only then
+            bool fr;
+            if (!GEOM) {
+                fr = (gw[k] >> (be[k] & 63)) & 1ull;
             } else {
-                wf_trip r; r.x = (int32_t)x; r.y = (int32_t)y; r.c = best;
-                mytrips[atomicAdd(&ctr->ntrip, 1)] = r;                    // at most one per owned candidate: capacity N holds
+#pragma unroll
+                for (int i = 0; i < D; ++i) w[i] = X[x[k] * D + i];
+                double l[D], h[D];
+                seg_bbox<D>(v, w, l, h);
+                bool blocked = false;
+                for (int k0 = 0; k0 < M; k0 += 64) {                           // lane = obstacle (boxesND.jl:52-56; @all in any order)
+                    const int kk = k0 + lane;
+                    const box_regs<D> b = wf_load_box_T<D>(bT, mpad, kk);      // kk < mpad always: the table is padded to 64 lanes
+                    const bool pend = (kk < M) && !broadphase_free_sl<D>(l, h, b);
+                    if (__ballot(pend)) {
+                        if (pend) blocked = blocked || !narrow_free_sl<D>(v, w, b);
+                    }
+                }
+                fr = inb && (__ballot(blocked) == 0);
+            }
+            if (fr && lane == 0) {                                             // fmt.jl:76-80
+                if (MODE == 0) {
+                    A[x[k]] = (int32_t)y; C[x[k]] = best[k];
+                    atomicAnd(&W[x[k] >> 6], ~(1ull << (x[k] & 63)));
+                    atomicOr(&Hn[x[k] >> 6], 1ull << (x[k] & 63));
+                    ++my_conn;
+                } else {
+                    wf_trip r; r.x = (int32_t)x[k]; r.y = (int32_t)y; r.c = best[k];
+                    mytrips[atomicAdd(&ctr->ntrip, 1)] = r;                    // at most one per owned candidate: capacity N holds
+                }
             }
         }
     }
@@ -649,15 +685,14 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     hipLaunchKernelGGL(k_wf_compact, dim3(nparts), dim3(64), 0, st, words, (const unsigned long long*)s->cand, s->xlist, s->ctr);
     const uint64_t* gfree = s->use_mask ? ctx->graph_free : nullptr;
     const uint8_t* nseg = s->directed ? ctx->di_nseg : nullptr;
-    if (!s->sharded) {
-        DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 0>), dim3(grid), dim3(256), 0, st, s->xlist, ctx->colptr,
-                                         ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo,
-                                         s->boxT, ctx->M, s->mpad, ctx->ss, gfree, nseg, (wf_trip*)nullptr, s->stats, s->ctr, s->all_in));
-    } else {
-        DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, 1>), dim3(grid), dim3(256), 0, st, s->xlist, ctx->colptr,
-                                         ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo,
-                                         s->boxT, ctx->M, s->mpad, ctx->ss, gfree, nseg, s->mytrips, s->stats, s->ctr, s->all_in));
-    }
+    // (a directed steering graph's validity bits are its own sweep's: gfree is set there too -- the mask form)
+    const bool geom = gfree == nullptr;
+#define WF_CONNECT(MODE_, GEOM_, TRIPS_) DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, MODE_, GEOM_>), dim3(grid), dim3(256), 0, st, s->xlist, ctx->colptr, \
+        ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo, s->boxT, ctx->M, s->mpad, ctx->ss, gfree, nseg, \
+        TRIPS_, s->stats, s->ctr, s->all_in))
+    if (!s->sharded) { if (geom) { WF_CONNECT(0, true, (wf_trip*)nullptr); } else { WF_CONNECT(0, false, (wf_trip*)nullptr); } }
+    else { if (geom) { WF_CONNECT(1, true, s->mytrips); } else { WF_CONNECT(1, false, s->mytrips); } }
+#undef WF_CONNECT
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }

@@ -1728,6 +1728,7 @@ int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value)
     if (strcmp(name, "nnz") == 0) { *value = ctx->nnz; return MPFMT_OK; }
     if (strcmp(name, "slices") == 0) { *value = ctx->S; return MPFMT_OK; }
     if (strcmp(name, "cells") == 0) { *value = ctx->grid.ncells; return MPFMT_OK; }
+    if (strcmp(name, "filter_valu") == 0) { *value = ctx->filter_valu ? 1 : 0; return MPFMT_OK; }
     return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown stat %s", name);
 }
 

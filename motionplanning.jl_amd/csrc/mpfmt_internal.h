@@ -141,6 +141,7 @@ struct mpfmt_ctx {
     double ops_r = -1.0;                 // grid radius the operands were built for
     int32_t rdisc_path = 0;              // 0 auto, 1 exact fp64 VALU kernel, 2 MFMA filter + exact refine
     int32_t rdisc_path_used = 0;
+    bool filter_valu = false;            // the counted graph's pair kernel ran the exact fp64 filter on the vector ALUs (k_rdisc_vf_w4) instead of the fp16 matrix-core one
     int32_t lists_wide = -1;             // chunk lists built by four wavefronts per tile (1), one (0), or by the number of tiles (-1)
     int32_t cell_fb_max = 8;             // position bits inside a cell that the sort key carries (k_cellkey)
     int32_t mf_xcd_mode = -1;            // work items go to the XCDs in interleaved groups of this many; -1: 256 for launches of >= 32768 items, else 64

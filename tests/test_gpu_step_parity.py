@@ -424,16 +424,47 @@ def test_large_stress_of_the_timed_form_in_suite(orc):
     assert forms.get((1, 2), 0) * 2 >= steps, forms
 
 
+@pytest.mark.parametrize("d,N,deg", [(2, 150000, 6), (2, 90001, 3), (3, 200000, 0.7), (1, 5000, 4)])
+def test_large_low_dimensional_world_takes_the_pipeline_with_the_exact_filter(orc, d, N, deg):
+    """Worlds whose radius lies below the fp16 shell of globally normalised coordinates (the notebook's 2-D world scaled up,
+    docs/MotionPlanning.ipynb cell 4): the step is still the single-pass pipeline -- half build, logs, edge tests fused (form 2) -- with
+    the canonical fp64 test as the filter (k_rdisc_vf_w4).  Graph, costs and mask against the oracle over a cold step, a speculative
+    repeat and new samples; duplicates and a ragged last tile included."""
+    rng = np.random.default_rng(700 + d + N)
+    r = float((deg / N) ** (1.0 / d) * 0.62) if d > 1 else 2e-5
+    M = 40
+    lo, hi = np.zeros(d), np.ones(d)
+    lohi = mp.workloads.make_boxes(rng, M, d, 0.02, 0.12, [])
+    X = rng.random((N, d)); X[77] = X[5]; X[N - 1] = X[N - 2]                  # exact duplicates: distance 0 is a neighbour
+    X2 = rng.random((N, d))
+    with mp.Context(0) as c:
+        c.set_option("rebuild_index", 1)
+        for Xi in (X, X, X2):
+            c.upload_samples(Xi); c.upload_boxes(lohi, lo, hi)
+            c.graph_step_device(r)
+            assert c.stat("rdisc_path_used") == 2 and c.stat("filter_valu") == 1, (c.stat("rdisc_path_used"), c.stat("filter_valu"))
+            assert c.stat("rdisc_half_used") == 1 and c.stat("sweep_form") == 2
+            colptr, rowval, nzval, free = _resident_graph(c, N)
+            oc, orow, oval = orc.rdisc_graph(Xi, r)
+            assert np.array_equal(colptr, oc) and np.array_equal(rowval, orow) and np.array_equal(nzval, oval)
+            assert np.array_equal(free.view(np.uint64), orc.graph_edges_free(Xi, oc, orow, lohi, lo, hi))
+        assert c.stat("redo_count") == 0
+
+
 def test_form_grid():
     """A cold ctx takes the timed form on its FIRST step, and keeps it: 2-, 3-, 4- and 6-dimensional worlds of 2e4 and
-    1.1e5 uniform samples, 30 and 256 boxes, mean degree 6 and 60 -- cold step, repeat, new samples: wherever the MFMA pair kernel runs,
-    every step is (half build, edge-test form 2) and no build is redone because a capacity did not hold."""
+    1.1e5 uniform samples, 30 and 256 boxes, mean degree 6 and 60 -- cold step, repeat, new samples: EVERY world runs the pair-kernel
+    pipeline (half build, edge-test form 2) and no build is redone because a capacity did not hold.  Where the radius lies below the
+    fp16 shell of the matrix-core filter (2-D, N = 1.1e5 at degree 6: VERDICT r4 item 6) the filter is the exact fp64 one on the vector
+    ALUs, the pipeline the same."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import run_form_grid
-    bad = []
-    for d, N, M, deg, nnz, out in run_form_grid.grid(sizes=(20000, 110000)):
+    bad, valu = [], []
+    for d, N, M, deg, nnz, out, flt, ms in run_form_grid.grid(sizes=(20000, 110000)):
+        if flt: valu.append((d, N, deg))
         for it, (path, half, form, over, redone, why) in enumerate(out):
-            if path == 2 and ((half, form) != (1, 2) or over or redone):
-                bad.append((d, N, M, deg, it, half, form, over, redone, why))
+            if path != 2 or (half, form) != (1, 2) or over or redone:
+                bad.append((d, N, M, deg, it, path, half, form, over, redone, why))
     assert not bad, bad
+    assert (2, 110000, 6) in valu and all(d <= 3 for d, _, _ in valu), valu

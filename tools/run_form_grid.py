@@ -10,7 +10,7 @@ import motionplanning_jl_amd as mp
 
 
 def grid(dims=(2, 3, 4, 6), sizes=(20000, 110000, 400000), boxes=(30, 256), degs=(6, 60), seed=5):
-    """yields (d, N, M, deg, nnz, [(path, half, form, overflow, redone, reason) per step])"""
+    """yields (d, N, M, deg, nnz, [(path, half, form, overflow, redone, reason) per step], vector-ALU filter used, kernel ms of the steps)"""
     rng = np.random.default_rng(seed)
     for d in dims:
         for N in sizes:
@@ -27,9 +27,12 @@ def grid(dims=(2, 3, 4, 6), sizes=(20000, 110000, 400000), boxes=(30, 256), degs
                             nnz = c.graph_step_device(r)
                             out.append((c.stat("rdisc_path_used"), c.stat("rdisc_half_used"), c.stat("sweep_form"), c.stat("pend_overflowed"),
                                         c.stat("redo_count"), c.stat("redo_reason")))
-                    yield d, N, M, deg, nnz, out
+                            flt = c.stat("filter_valu")
+                            ms = c.timing("grid")[0] + c.timing("rdisc_count")[0] + c.timing("rdisc_sort")[0] + c.timing("sweep_graph")[0]
+                    yield d, N, M, deg, nnz, out, flt, ms
 
 
 if __name__ == "__main__":
-    for d, N, M, deg, nnz, out in grid():
-        print("d %d N %6d M %3d deg %2d nnz %9d: (path, half, form, overflow, redone, why) %s" % (d, N, M, deg, nnz, out), flush=True)
+    for d, N, M, deg, nnz, out, flt, ms in grid():
+        print("d %d N %6d M %3d deg %2d nnz %9d: (path, half, form, overflow, redone, why) %s  filter %s  %.3f ms (timers, 3 steps)"
+              % (d, N, M, deg, nnz, out, "fp64 VALU" if flt else "fp16 MFMA", ms), flush=True)
