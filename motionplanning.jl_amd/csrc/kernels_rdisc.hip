@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_build_tiles(const double* __restrict__ 
                                                      double* __restrict__ tile_sub, float* __restrict__ tile_sub32,
                                                      const uint8_t* __restrict__ tileneed, bt_ops ops, mpfmt_grid G)
 {
-    __shared__ double s_rows[4][64 * BT_MAXD];
+    extern __shared__ double s_rows_dyn[];                  // [4][64 * d]: sized by the dimension (12 KB at d = 6, where the 32 KB of d = 16 would halve the residency)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     if (tile >= ntiles) return;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void k_build_tiles(const double* __restrict__ 
         if (oj > jump || (oj == jump && ow < where)) { jump = oj; where = ow; }
     }
     const int split = (jump > 0) ? where + 1 : 64;         // A = lanes [0, split), B = lanes [split, 64)
-    double* rows = s_rows[wave];
+    double* rows = s_rows_dyn + (size_t)wave * 64 * d;
     // the row's d coordinates are requested together (a runtime-d loop that loads and reduces in turn sat out d gather latencies)
     double xr[BT_MAXD];
 #pragma unroll
@@ -628,7 +628,7 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r, bool whole)
         hipLaunchKernelGGL(k_cell_order, dim3((unsigned)((G.ncells + 3) / 4)), dim3(256), 0, ctx->stream, (const int32_t*)ctx->cellstart, G.ncells, fb, pbits,
                            (const uint8_t*)ctx->tileneed, items, items2, val_out, ctx->cellkey);
         bt_ops bo{mf ? ctx->ops : nullptr, ctx->mf_scale};
-        hipLaunchKernelGGL(k_build_tiles, dim3((unsigned)((ctx->ntiles + 3) / 4)), dim3(256), 0, ctx->stream, ctx->Xo, (const int32_t*)val_out,
+        hipLaunchKernelGGL(k_build_tiles, dim3((unsigned)((ctx->ntiles + 3) / 4)), dim3(256), sizeof(double) * 4 * 64 * (size_t)d, ctx->stream, ctx->Xo, (const int32_t*)val_out,
                            (const uint32_t*)ctx->cellkey, fb, N, ctx->ntiles, d, ctx->perm, ctx->iperm, ctx->Xs, ctx->Xt, ctx->tile_lo, ctx->tile_hi,
                            ctx->tile_sub, ctx->tile_sub32, (const uint8_t*)ctx->tileneed, bo, G);
         HIPCHK(ctx, hipGetLastError());

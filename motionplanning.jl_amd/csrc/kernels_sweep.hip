@@ -89,8 +89,6 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_points_free(const double* __r
                                                                int64_t n, const double* __restrict__ boxes, int M, int chunk,
                                                                mpfmt_ss ss, uint64_t* __restrict__ mask)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sbox = (double*)smem;
     const int lane = threadIdx.x & 63;
     const int64_t e = (int64_t)blockIdx.x * SWEEP_THREADS + threadIdx.x;
     const bool active = e < n;
@@ -100,18 +98,14 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_points_free(const double* __r
 #pragma unroll
     for (int i = 0; i < D; ++i) v[i] = active ? X[src * D + i] : 0.0;
     bool fr = active && in_state_space_sl<D>(v, ss);
-    for (int b0 = 0; b0 < M; b0 += chunk) {
-        const int nb = min(chunk, M - b0);
-        __syncthreads();
-        stage_boxes<D>(sbox, boxes, b0, nb);
-        __syncthreads();
-        for (int k = 0; k < nb; ++k) {
-            const box_regs<D> b = load_box<D>(sbox, k);
-            int outside = 0;                                     // @any [!(lo[i] <= v[i] <= hi[i])]
+    // the boxes through the scalar cache (wave-uniform addresses): staged in LDS every box cost 2 D broadcast reads per wavefront, which
+    // run at the LDS's full-width rate -- 0.22 ms for the checkpts sweep of 1e6 samples against 200 boxes, all of it LDS time
+    for (int k = 0; k < M; ++k) {
+        const sweep_cptr bp = as_const(boxes) + (int64_t)k * 2 * D;
+        int outside = 0;                                     // @any [!(lo[i] <= v[i] <= hi[i])]
 #pragma unroll
-            for (int i = 0; i < D; ++i) outside |= (int)!(b.lo[i] <= v[i]) | (int)!(v[i] <= b.hi[i]);
-            fr = fr & (outside != 0);
-        }
+        for (int i = 0; i < D; ++i) outside |= (int)!(bp[i] <= v[i]) | (int)!(v[i] <= bp[D + i]);
+        fr = fr & (outside != 0);
     }
     const unsigned long long bits = __ballot(fr);
     if (lane == 0 && (e - lane) < n) mask[(e - lane) >> 6] = bits;
@@ -1163,11 +1157,9 @@ static int32_t launch_points(mpfmt_ctx* ctx, const double* X, const int64_t* idx
 {
     if (n == 0) return MPFMT_OK;
     if (ctx->cc_kind == 1) return mpfmt_2d_launch_points(ctx, X, idx1, n, d_mask);
-    const int chunk = box_chunk(ctx->M, d, false);
-    const size_t lds = sweep_lds(chunk, d);
     const unsigned nb = (unsigned)((n + SWEEP_THREADS - 1) / SWEEP_THREADS);
-    DISPATCH_D(d, hipLaunchKernelGGL((k_points_free<DD>), dim3(nb), dim3(SWEEP_THREADS), lds, ctx->stream,
-                                     X, idx1, n, ctx->boxes, ctx->M, chunk, ctx->ss, d_mask));
+    DISPATCH_D(d, hipLaunchKernelGGL((k_points_free<DD>), dim3(nb), dim3(SWEEP_THREADS), 0, ctx->stream,
+                                     X, idx1, n, ctx->boxes, ctx->M, 0, ctx->ss, d_mask));
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }

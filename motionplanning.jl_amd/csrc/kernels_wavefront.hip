@@ -48,7 +48,7 @@ struct wf_ctr {
     int64_t imin;
     int64_t tot[4];               // sums of the per-block statistics: batch nodes, samples examined, connected, edge checks
     int32_t ended;                // latched by the first k_wf_apply_min that finds a goal batch recorded: k_wf_select, which must not
-    int32_t ticket;               // k_wf_apply_min: blocks that have written their partial minimum (the last one reduces them all)
+    int32_t pad_;
 };
 enum { WF_NZ = 0, WF_NX = 1, WF_NCONN = 2, WF_CHECKS = 3 };
 
@@ -206,13 +206,21 @@ __device__ __forceinline__ int wf_expand_group(unsigned long long m, uint16_t* _
     return total;
 }
 
-__global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __restrict__ H, uint64_t* __restrict__ Z, uint64_t* __restrict__ Zp,
+// One workgroup = four wavefronts = one 64-word slab of the masks; each wavefront takes WF_GW = 16 of its words.  One partial minimum per
+// workgroup (k_wf_select reduces ~250 of them, every workgroup for itself) and ONE atomic per workgroup on a list counter: a counter
+// takes ~90 atomics per microsecond, so a thousand wavefronts appending one by one cost more than the gathers they were split up for.
+#define WF_BLK_WORDS (4 * WF_GW)
+__global__ __launch_bounds__(256) void k_wf_apply_min(int64_t words, uint64_t* __restrict__ H, uint64_t* __restrict__ Z, uint64_t* __restrict__ Zp,
                                                      uint64_t* __restrict__ Hn, uint64_t* __restrict__ cand,
                                                      const uint64_t* __restrict__ W, const uint64_t* __restrict__ F, uint64_t* __restrict__ WF,
                                                      const double* __restrict__ C, double* __restrict__ part_c,
                                                      int64_t* __restrict__ part_i, wf_ctr* __restrict__ ctr)
 {
-    __shared__ uint16_t s_list[WF_GRP_CAP];
+    __shared__ uint16_t s_list_[4][WF_GRP_CAP];
+    __shared__ double s_c[4];
+    __shared__ long long s_i[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint16_t* const s_list = s_list_[wave];
     if (wf_stop(ctr)) {
         // the batch of the previous step held a goal node: the steps enqueued behind it are void.  k_wf_select cannot test
         // goal_cbits itself (see there), so the end is latched here, one kernel ahead of it on the stream (without
@@ -225,17 +233,18 @@ __global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __
         ctr->iters += 1; ctr->ntrip = 0; ctr->nz = 0; ctr->nx = 0;
     }
     double bc = 0.0; int64_t bi = -1;
-    for (int64_t w0 = (int64_t)blockIdx.x * WF_GW; w0 < words; w0 += (int64_t)gridDim.x * WF_GW) {       // wave-uniform trip count
-        const int64_t w = w0 + threadIdx.x;
+    for (int64_t b0 = (int64_t)blockIdx.x * WF_BLK_WORDS; b0 < words; b0 += (int64_t)gridDim.x * WF_BLK_WORDS) {     // uniform trip count
+        const int64_t w0 = b0 + wave * WF_GW;
+        const int64_t w = w0 + lane;
         uint64_t h = 0;
-        if (w < words && threadIdx.x < WF_GW) {
+        if (w < words && lane < WF_GW) {
             const uint64_t z = Z[w];
             h = (H[w] & ~z) | Hn[w];                          // fmt.jl:83-84 for the batch of the previous step
             H[w] = h; Zp[w] = z; Z[w] = 0; Hn[w] = 0; cand[w] = 0;
             WF[w] = W[w] & (F ? F[w] : ~0ull);                // unvisited and valid: the one word k_wf_mark gathers per entry
         }
         const int total = wf_expand_group(h, s_list);
-        for (int k = threadIdx.x; k < total; k += 64) {
+        for (int k = lane; k < total; k += 64) {
             const int64_t i = w0 * 64 + (int64_t)s_list[k];
             const double c = C[i];
             if (bi < 0 || c < bc || (c == bc && i < bi)) { bc = c; bi = i; }
@@ -243,50 +252,52 @@ __global__ __launch_bounds__(64) void k_wf_apply_min(int64_t words, uint64_t* __
         __builtin_amdgcn_wave_barrier();                      // (the list is rewritten by the next group)
     }
     wf_lexmin_wave(bc, bi);
-    // the block that finishes last folds the partial minima into ctr->cmin / imin (imin < 0: the open set is empty): k_wf_select reads two
-    // words instead of every block reducing every partial (977 blocks x 977 partials: 25 of its 25 us a step)
-    int last = 0;
+    if (lane == 0) { s_c[wave] = bc; s_i[wave] = bi; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            const double oc = s_c[k]; const int64_t oi = s_i[k];
+            if (oi >= 0 && (bi < 0 || oc < bc || (oc == bc && oi < bi))) { bc = oc; bi = oi; }
+        }
         part_c[blockIdx.x] = bc; part_i[blockIdx.x] = bi;
-        __threadfence();
-        last = atomicAdd(&ctr->ticket, 1) == (int)gridDim.x - 1;
     }
-    last = __shfl(last, 0);
-    if (!last) return;
-    __threadfence();
-    double cm = 0.0; int64_t im = -1;
-    for (int p = threadIdx.x; p < (int)gridDim.x; p += 64) {
-        const double c = ((volatile double*)part_c)[p]; const int64_t i = ((volatile int64_t*)part_i)[p];
-        if (i >= 0 && (im < 0 || c < cm || (c == cm && i < im))) { cm = c; im = i; }
-    }
-    wf_lexmin_wave(cm, im);
-    if (threadIdx.x == 0) { ctr->cmin = cm; ctr->imin = im; ctr->ticket = 0; }
 }
 
 // goal_cbits is written (atomicMin) only by blocks that have passed the entry test, which therefore reads `done` alone: a
 // block starting late must still select its words.  done = 2 is decided identically by every block from the partials.
-__global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, const uint64_t* __restrict__ H, uint64_t* __restrict__ Z,
+__global__ __launch_bounds__(256) void k_wf_select(int64_t words, int nparts, const uint64_t* __restrict__ H, uint64_t* __restrict__ Z,
                                                   const double* __restrict__ C, const double* __restrict__ X, int d,
                                                   const double* __restrict__ part_c, const int64_t* __restrict__ part_i,
                                                   double band, int single, wf_goal G, int32_t* __restrict__ zlist,
                                                   wf_ctr* __restrict__ ctr)
 {
-    __shared__ uint16_t s_list[WF_GRP_CAP];
-    __shared__ unsigned long long s_z[64];
+    __shared__ uint16_t s_list_[4][WF_GRP_CAP];
+    __shared__ unsigned long long s_z_[4][WF_GW];
+    __shared__ int s_tot[4], s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint16_t* const s_list = s_list_[wave];
+    unsigned long long* const s_z = s_z_[wave];
     if (ctr->done || ctr->ended) return;
-    const double cm = ctr->cmin; const int64_t im = ctr->imin;      // (folded by the last block of k_wf_apply_min)
+    double cm = 0.0; int64_t im = -1;
+    for (int p = lane; p < nparts; p += 64) {                 // (every wavefront reduces the ~250 partials for itself)
+        const double c = part_c[p]; const int64_t i = part_i[p];
+        if (i >= 0 && (im < 0 || c < cm || (c == cm && i < im))) { cm = c; im = i; }
+    }
+    wf_lexmin_wave(cm, im);
     if (im < 0) {                                   // H is empty: fmt.jl:85-89 `break`
         if (blockIdx.x == 0 && threadIdx.x == 0) ctr->done = 2;
         return;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr->cmin = cm; ctr->imin = im; }
     const double thr = cm + band;
-    for (int64_t w0 = (int64_t)blockIdx.x * WF_GW; w0 < words; w0 += (int64_t)gridDim.x * WF_GW) {       // wave-uniform trip count
-        const int64_t w = w0 + threadIdx.x;
-        const bool own = w < words && threadIdx.x < WF_GW;
+    for (int64_t b0 = (int64_t)blockIdx.x * WF_BLK_WORDS; b0 < words; b0 += (int64_t)gridDim.x * WF_BLK_WORDS) {     // uniform trip count
+        const int64_t w0 = b0 + wave * WF_GW;
+        const int64_t w = w0 + lane;
+        const bool own = w < words && lane < WF_GW;
         const uint64_t h = own ? H[w] : 0;
-        s_z[threadIdx.x] = 0ull;
+        if (lane < WF_GW) s_z[lane] = 0ull;
         const int total = wf_expand_group(h, s_list);
-        for (int k = threadIdx.x; k < total; k += 64) {
+        for (int k = lane; k < total; k += 64) {
             const int p = (int)s_list[k];
             const int64_t i = w0 * 64 + p;
             const double c = C[i];
@@ -298,10 +309,25 @@ __global__ __launch_bounds__(64) void k_wf_select(int64_t words, int nparts, con
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint64_t z = own ? s_z[threadIdx.x] : 0ull;
+        const uint64_t z = own ? s_z[lane] : 0ull;
         if (z) Z[w] = z;
-        wf_append_word(z, w, zlist, &ctr->nz);
-        __builtin_amdgcn_wave_barrier();
+        // the batch list: the four wavefronts' counts are summed, ONE atomic on the list counter, every lane writes its own word's nodes
+        const int n = __popcll(z);
+        int inc = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+        if (lane == 63) s_tot[wave] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+            s_base = tot ? atomicAdd(&ctr->nz, tot) : 0;
+        }
+        __syncthreads();
+        int o = s_base + inc - n;
+        for (int k = 0; k < wave; ++k) o += s_tot[k];
+        uint64_t m = z;
+        while (m) { const int bb = __ffsll((long long)m) - 1; m &= m - 1; zlist[o++] = (int32_t)(w * 64 + bb); }
+        __syncthreads();                                      // (s_tot / s_base are rewritten by the next slab)
     }
 }
 
@@ -667,9 +693,9 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     const int nparts = s->nparts;
     hipStream_t st = ctx->stream;
     const int d = ctx->d;
-    hipLaunchKernelGGL(k_wf_apply_min, dim3(nparts), dim3(64), 0, st, words, s->H, s->Z, s->Zp, s->Hn, s->cand, s->W, s->checkpts ? s->F : nullptr, s->WF, s->C,
+    hipLaunchKernelGGL(k_wf_apply_min, dim3(nparts), dim3(256), 0, st, words, s->H, s->Z, s->Zp, s->Hn, s->cand, s->W, s->checkpts ? s->F : nullptr, s->WF, s->C,
                        s->part_c, s->part_i, s->ctr);
-    hipLaunchKernelGGL(k_wf_select, dim3(nparts), dim3(64), 0, st, words, nparts, s->H, s->Z, s->C, ctx->Xo, d, s->part_c, s->part_i, s->band,
+    hipLaunchKernelGGL(k_wf_select, dim3(nparts), dim3(256), 0, st, words, nparts, s->H, s->Z, s->C, ctx->Xo, d, s->part_c, s->part_i, s->band,
                        s->single, s->goal, s->zlist, s->ctr);
     const uint64_t* F = s->checkpts ? s->F : nullptr;
     const int grid = ctx->num_cus * 8;                       // persistent: 4 wavefronts per block, one list entry per wavefront at a time
@@ -780,7 +806,7 @@ int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t check
     const int ng = goal_kind == MPFMT_GOAL_RECT ? 2 * d : goal_kind == MPFMT_GOAL_BALL ? d + 1 : d;
     memset(s->goal.g, 0, sizeof s->goal.g);
     for (int i = 0; i < ng; ++i) s->goal.g[i] = goal_params[i];
-    s->nparts = (int)std::min<int64_t>(WF_MAXPARTS, (s->words + WF_GW - 1) / WF_GW);
+    s->nparts = (int)std::min<int64_t>(WF_MAXPARTS, (s->words + WF_BLK_WORDS - 1) / WF_BLK_WORDS);
     if (s->nparts < 1) s->nparts = 1;
     for (int k = 0; k < 4; ++k) s->prev_tot[k] = 0;
 
@@ -794,10 +820,17 @@ int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t check
     auto t1 = std::chrono::steady_clock::now();
     // r-disc graph (reused when one of this radius is resident); the edge tests stay lazy unless the checker has no
     // lane-per-obstacle form here (2-D SAT world, non-identity workspace) or the caller asks for the eager mask
-    if (!(ctx->graph_filled && ctx->graph_r == r) && (rc = mpfmt_graph_build_device(ctx, r, nullptr))) return rc;
+    const bool lazy_ok = ctx->cc_kind == 0 && ctx->dw == d;
+    if (!(ctx->graph_filled && ctx->graph_r == r)) {
+        // no graph of this radius is resident: the STEP builds it with every edge's bit (edge tests fused into the build: ~0.4 ms more
+        // than the graph alone at the north star), and the recursion then reads bits instead of testing ~1e6 edges one wavefront at a
+        // time (2.4 ms); MPFMT_WF_LAZY keeps the graph-only build and the lazy tests
+        if (lazy_ok && !(flags & MPFMT_WF_LAZY)) rc = mpfmt_graph_step_device(ctx, r, nullptr);
+        else rc = mpfmt_graph_build_device(ctx, r, nullptr);
+        if (rc) return rc;
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     auto t2 = std::chrono::steady_clock::now();
-    const bool lazy_ok = ctx->cc_kind == 0 && ctx->dw == d;
     // (a mask a step left for this graph and this obstacle set is used, not recomputed: upload_boxes / set_state_bounds void graph_swept)
     const bool resident = ctx->graph_swept && ctx->graph_filled && ctx->graph_r == r && ctx->graph_free && !(flags & MPFMT_WF_LAZY);
     s->use_mask = ((flags & MPFMT_WF_EAGER) || !lazy_ok || resident) ? 1 : 0;
@@ -1060,7 +1093,7 @@ extern "C++" int32_t mpfmt_wf_begin_directed(mpfmt_ctx* ctx, int64_t init_idx, i
     const int ng = goal_kind == MPFMT_GOAL_RECT ? 2 * gd : goal_kind == MPFMT_GOAL_BALL ? gd + 1 : d;
     memset(s->goal.g, 0, sizeof s->goal.g);
     for (int i = 0; i < ng; ++i) s->goal.g[i] = goal_params[i];
-    s->nparts = (int)std::min<int64_t>(WF_MAXPARTS, (s->words + WF_GW - 1) / WF_GW);
+    s->nparts = (int)std::min<int64_t>(WF_MAXPARTS, (s->words + WF_BLK_WORDS - 1) / WF_BLK_WORDS);
     if (s->nparts < 1) s->nparts = 1;
     for (int k = 0; k < 4; ++k) s->prev_tot[k] = 0;
     HIPCHK(ctx, hipMemcpyAsync(s->F, F_host, 8 * (size_t)s->words, hipMemcpyHostToDevice, ctx->stream));
