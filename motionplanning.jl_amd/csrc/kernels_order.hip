@@ -31,15 +31,9 @@
 #define ORD_WAVES 8
 #define ORD_COLS 16              // columns per workgroup = columns per log
 #define ORD_NB 128               // buckets per column
-#ifndef ORD_STG
-#define ORD_STG 2560             // staged records per workgroup: 12 bytes each (30 KB of LDS; with the 16-bit counters 39 KB -- FOUR workgroups per CU
-#endif                           // need <= 40 KB each)
-#ifndef ORD_PRE
+#define ORD_STG 2560             // staged records per workgroup: 12 bytes each (30 KB of LDS; with the 16-bit counters 39 KB -- FOUR workgroups per CU need <= 40 KB each)
 #define ORD_PRE 5                // records per thread requested ahead (5 x 512 = the staging area)
-#endif
-#ifndef ORD_WAVES_EU
-#define ORD_WAVES_EU 8           // wavefronts per SIMD the kernel is built for (8: 64 VGPRs -- four 512-thread workgroups per CU)
-#endif
+#define ORD_WAVES_EU 8           // wavefronts per SIMD the kernel is built for (8: 64 VGPRs, 4 of them spilled -- four 512-thread workgroups per CU)
 static_assert(ORD_STG >= MPFMT_ORD_MAXDEG, "a column the host lets through must fit the staging area");
 static_assert(ORD_COLS * ORD_NB == ORD_THREADS * 4, "the segmented scan gives every thread four buckets");
 static_assert(ORD_PRE * ORD_THREADS >= ORD_STG && ORD_STG % 32 == 0 && ORD_STG < 65536, "the prefetched records cover what the staging area holds; positions fit 16 bits");
@@ -94,11 +88,7 @@ struct ord_args {
 // log length -> records -> LDS -> stores), and with 3 workgroups per CU nothing covers them.  So while a workgroup writes quarter q out
 // of LDS, the records of its next quarter are already on their way into registers, and the header of that quarter was requested a
 // phase earlier still.
-#if ORD_WAVES_EU
 __global__ __launch_bounds__(ORD_THREADS) __attribute__((amdgpu_waves_per_eu(ORD_WAVES_EU, ORD_WAVES_EU))) void k_order_logs(ord_args a)
-#else
-__global__ __launch_bounds__(ORD_THREADS) void k_order_logs(ord_args a)
-#endif
 {
     if (a.spec_fail && *a.spec_fail) return;                 // speculative step whose capacities did not hold: redone by the host
     extern __shared__ __attribute__((aligned(16))) char ord_smem[];

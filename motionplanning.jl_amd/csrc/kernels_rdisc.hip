@@ -512,7 +512,7 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r, bool whole)
     // ---- cell ids: block-major on a sharded ctx (one cut axis per factor of two of the world, at most three, never the last axis) ----
     for (int i = 0; i < MPFMT_MAX_DIM; ++i) { G.split[i] = 0; G.hstride[i] = 0; G.ext[i] = 1; }
     G.nsplit = 0;
-    if (ctx->world > 1) {
+    if (ctx->world > 1 && ctx->shard_blocks) {
         int want = 0;
         while ((1 << want) < ctx->world && want < 3) ++want;
         int64_t lead = 1;

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict
     // mask bit / parent state -> stores) and a wavefront has a handful of candidates per step: one at a time the kernel sat out every
     // trip (15 us of wavefront time per candidate).  NB candidates are taken per pass and every stage is issued for all of them before
     // the next stage's first use: the trips of the NB chains overlap.  The winner's row rides through the reduce (no reload of rowval).
-    constexpr int NB = GEOM ? 1 : 4;
+    constexpr int NB = GEOM ? 1 : 2;                                       // (one at a time 4.55 ms per solve, two 4.13, four 4.25: registers)
     const int st = gridDim.x * wpb;
     for (int ix0 = blockIdx.x * wpb + (threadIdx.x >> 6); ix0 < nx; ix0 += NB * st) {
         int64_t x[NB], beg[NB], end[NB];
@@ -713,9 +713,14 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     const uint8_t* nseg = s->directed ? ctx->di_nseg : nullptr;
     // (a directed steering graph's validity bits are its own sweep's: gfree is set there too -- the mask form)
     const bool geom = gfree == nullptr;
-#define WF_CONNECT(MODE_, GEOM_, TRIPS_) DISPATCH_D(d, hipLaunchKernelGGL((k_wf_connect<DD, MODE_, GEOM_>), dim3(grid), dim3(256), 0, st, s->xlist, ctx->colptr, \
+    // (persistent workgroups: exactly as many as are resident at once -- the kernel's loops stride by the grid, so a workgroup that has to
+    // wait for a slot starts its share of the candidates when the others are done with theirs)
+#define WF_CONNECT(MODE_, GEOM_, TRIPS_) DISPATCH_D(d, { int per_cu = 0; \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_connect<DD, MODE_, GEOM_>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4; \
+        const int cgrid = ctx->num_cus * std::min(per_cu, 8); \
+        hipLaunchKernelGGL((k_wf_connect<DD, MODE_, GEOM_>), dim3(cgrid), dim3(256), 0, st, s->xlist, ctx->colptr, \
         ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo, s->boxT, ctx->M, s->mpad, ctx->ss, gfree, nseg, \
-        TRIPS_, s->stats, s->ctr, s->all_in))
+        TRIPS_, s->stats, s->ctr, s->all_in); })
     if (!s->sharded) { if (geom) { WF_CONNECT(0, true, (wf_trip*)nullptr); } else { WF_CONNECT(0, false, (wf_trip*)nullptr); } }
     else { if (geom) { WF_CONNECT(1, true, s->mytrips); } else { WF_CONNECT(1, false, s->mytrips); } }
 #undef WF_CONNECT

@@ -115,6 +115,7 @@ struct mpfmt_ctx {
     uint8_t* tileneed = nullptr;
     uint8_t* tileneed_buf = nullptr;     // (inside idx_arena)
     int32_t index_halo = 1;              // option: allow the shard + halo index
+    int32_t shard_blocks = 1;            // option: block-major cell ids on a sharded ctx (0: row-major -- shards are slabs; measurements)
     int index_rank = 0, index_world = 1; // the shard the index was built for
     std::vector<double> cut_frac;        // shard boundaries as fractions of the cell-sorted order (cut_key: the geometry they belong to)
     std::vector<int64_t> cut_key;

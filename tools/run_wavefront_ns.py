@@ -1,4 +1,5 @@
-"""North-star whole solve on the device (mpfmt_fmtstar_wavefront) with and without the captured hipGraph of a step group, per band."""
+"""North-star whole solve on the device (mpfmt_fmtstar_wavefront) on the graph and mask a step left resident: per band, reading the
+resident mask (the default) and testing every asked-for edge against the obstacle set (MPFMT_WF_LAZY)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import motionplanning_jl_amd as mp
@@ -6,14 +7,13 @@ w = mp.workloads.north_star()
 ctx = mp.Context(0)
 ctx.upload_samples(w.X); ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
 ctx.graph_step_device(w.r)
-for graphs in (0, 1):
-    ctx.set_option("wf_graphs", graphs)
+for lazy in (False, True):
     for bandf in (0.05, 0.25, 2.0):
         best = None
-        for _ in range(4):
+        for _ in range(3):
             t = time.perf_counter()
-            res = ctx.fmtstar_wavefront(w.r, mp._lib.GOAL_BALL, w.goal_params(), band=bandf * w.r, want_tree=False)
+            res = ctx.fmtstar_wavefront(w.r, mp._lib.GOAL_BALL, w.goal_params(), band=bandf * w.r, lazy=lazy, want_tree=False)
             ms = 1e3 * (time.perf_counter() - t)
             best = ms if best is None else min(best, ms)
-        print("graphs %d band %.2f r: %.2f ms  cost %.6f  wavefronts %d  checks %d  (Group-Marching batches, not the reference's pop order)"
-              % (graphs, bandf, best, res["cost"], res["info"]["iters"], res["collision_checks"]))
+        print("edge tests %s band %.2f r: %.2f ms  cost %.6f  wavefronts %d  checks %d  (Group-Marching batches, not the reference's pop order)"
+              % ("lazy" if lazy else "from the resident mask", bandf, best, res["cost"], res["info"]["iters"], res["collision_checks"]), flush=True)
