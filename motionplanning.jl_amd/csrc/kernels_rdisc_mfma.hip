@@ -292,12 +292,7 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
         s_segp[lane] = incl - n;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // Software pipelined over the batches of 64 flattened candidates: a batch's chunk ids and its candidates' boxes (one gather of 16 D
-        // bytes per lane: D 16-byte loads) are requested while the batch before it is tested -- one dependent round trip per batch
-        // instead of two (the kernel is a chain of such trips: ~30 us per tile at one wavefront per tile).
-        int64_t cN = -2; bool keepN = false;
-        float4 bxN[D];
-        auto stage1 = [&](int32_t t0, int64_t& c, bool& keep, float4 (&bx)[D]) {
+        for (int32_t t0 = 0; t0 < T; t0 += 64) {
             const int32_t t = t0 + lane;
             const bool act = t < T;
             // run owning flattened index t: the largest j with s_segp[j] <= t
@@ -307,28 +302,14 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
                 const int jj = j + step;
                 if (jj < 64 && s_segp[jj] <= t) j = jj;
             }
-            c = act ? (int64_t)s_sega[j] + (t - s_segp[j]) : -2;
+            int64_t c = act ? (int64_t)s_sega[j] + (t - s_segp[j]) : -2;
             // dedupe: consecutive runs may share their boundary chunk
             int64_t prevc = __shfl_up(c, 1);
             if (lane == 0) prevc = carry;
             const int lastl = min(63, T - t0 - 1);
             carry = __shfl(c, lastl);
             // half build: the chunks before the tile find these pairs -- inside the shard; a chunk of another shard is nobody's but ours
-            keep = act && (c != prevc) && (!half || c >= tile || c < tile_begin || c >= tile_begin + nt);
-            if (use_sub) {
-                const float4* __restrict__ cs4 = reinterpret_cast<const float4*>(tile_sub32 + (keep ? c : 0) * 4 * D);      // (16 D bytes per tile: 16-byte aligned)
-#pragma unroll
-                for (int i = 0; i < D; ++i) bx[i] = cs4[i];
-            }
-        };
-        if (T > 0) stage1(0, cN, keepN, bxN);
-        for (int32_t t0 = 0; t0 < T; t0 += 64) {
-            const int64_t c = cN;
-            bool keep = keepN;
-            float4 bx[D];
-#pragma unroll
-            for (int i = 0; i < D; ++i) bx[i] = bxN[i];
-            if (t0 + 64 < T) stage1(t0 + 64, cN, keepN, bxN);
+            bool keep = act && (c != prevc) && (!half || c >= tile || c < tile_begin || c >= tile_begin + nt);
             if (keep && !use_sub) {                       // coarse grid (<= 2 cells per dimension): every cell neighbours every other
                 double gap2 = 0.0;                        // one, a tile running over a row end loses nothing -- hull against hull
 #pragma unroll
@@ -341,9 +322,10 @@ __global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restri
                 // query sub-box x candidate sub-box, in fp32 on boxes rounded outward (both sides): every gap is a lower bound of
                 // the fp64 one up to a few 1e-7 relative, which the 1e-4 on the threshold covers -- never a chunk less, and the
                 // arithmetic (the bound of this kernel: ~150 lane-ops per candidate) at the fp32 rate; candidate boxes are 16 D
-                // bytes each instead of 32 D
+                // bytes each instead of 32 D.  (Requesting the next 64 candidates' boxes before these are tested was measured: no
+                // gain -- the registers it takes cost the residency it was meant to cover for.)
                 float gaa = 0.f, gab = 0.f, gba = 0.f, gbb = 0.f;
-                const float* cs = reinterpret_cast<const float*>(bx);          // [A lo (D), A hi (D), B lo (D), B hi (D)]
+                const float* __restrict__ cs = tile_sub32 + c * 4 * D;
 #pragma unroll
                 for (int i = 0; i < D; ++i) {
                     const float cal = cs[i], cah = cs[D + i], cbl = cs[2 * D + i], cbh = cs[3 * D + i];

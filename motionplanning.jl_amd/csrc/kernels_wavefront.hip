@@ -47,8 +47,8 @@ struct wf_ctr {
     double cmin;                  // lowest open cost at this step
     int64_t imin;
     int64_t tot[4];               // sums of the per-block statistics: batch nodes, samples examined, connected, edge checks
+    int32_t nz_prev;              // batch size of the step before (k_wf_compact): k_wf_apply_min takes those nodes out of Hs
     int32_t ended;                // latched by the first k_wf_apply_min that finds a goal batch recorded: k_wf_select, which must not
-    int32_t pad_;
 };
 enum { WF_NZ = 0, WF_NX = 1, WF_NCONN = 2, WF_CHECKS = 3 };
 
@@ -61,6 +61,14 @@ struct wf_trip { int32_t x, y; double c; };
 struct mpfmt_wf {
     int64_t N = 0, words = 0;
     uint64_t *W = nullptr, *H = nullptr, *Z = nullptr, *Zp = nullptr, *Hn = nullptr, *cand = nullptr, *F = nullptr, *WF = nullptr;
+    // The sets the mark / connect passes GATHER from, kept a second time by CELL-SORTED POSITION (unsharded Euclidean graphs): a column's
+    // rows are spatial neighbours, so by position their bits sit in ~14 cache lines instead of ~103 by caller index (north star, measured
+    // on the host) and their costs in ~60 instead of ~106.  WFs: unvisited and valid; Hs: open (Hns: opened during this step); cands:
+    // candidates of this step; Cs: cost-to-come.  The graph's rows by position: ctx->rowpos.
+    uint64_t *WFs = nullptr, *Hs = nullptr, *Hns = nullptr, *cands = nullptr;
+    double* Cs = nullptr;
+    int64_t pwords = 0;
+    int32_t pos_space = 0;
     double* C = nullptr;
     int32_t* A = nullptr;
     int32_t *zlist = nullptr, *xlist = nullptr;                   // batch nodes / candidates of the step, compacted from the masks
@@ -206,6 +214,27 @@ __device__ __forceinline__ int wf_expand_group(unsigned long long m, uint16_t* _
     return total;
 }
 
+// start of a step, position side: the nodes opened during the step before join Hs, its batch leaves it, the candidate mask is cleared
+// (part of k_wf_apply_min's launch)
+struct wf_pos { int64_t pwords; unsigned long long* Hs; uint64_t* Hns; uint64_t* cands; const int32_t* zlist; const int32_t* iperm; };
+__device__ __forceinline__ void wf_apply_pos(const wf_pos& P, const wf_ctr* __restrict__ ctr)
+{
+    const int64_t pwords = P.pwords;
+    unsigned long long* __restrict__ Hs = P.Hs; uint64_t* __restrict__ Hns = P.Hns; uint64_t* __restrict__ cands = P.cands;
+    const int32_t* __restrict__ zlist = P.zlist; const int32_t* __restrict__ iperm = P.iperm;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t w = t; w < pwords; w += nt) {
+        const uint64_t hn = Hns[w];
+        if (hn) { atomicOr(&Hs[w], (unsigned long long)hn); Hns[w] = 0; }
+        cands[w] = 0;
+    }
+    const int nzp = ctr->nz_prev;
+    for (int64_t k = t; k < nzp; k += nt) {
+        const int64_t p = iperm[zlist[k]];
+        atomicAnd(&Hs[p >> 6], ~(1ull << (p & 63)));
+    }
+}
+
 // One workgroup = four wavefronts = one 64-word slab of the masks; each wavefront takes WF_GW = 16 of its words.  One partial minimum per
 // workgroup (k_wf_select reduces ~250 of them, every workgroup for itself) and ONE atomic per workgroup on a list counter: a counter
 // takes ~90 atomics per microsecond, so a thousand wavefronts appending one by one cost more than the gathers they were split up for.
@@ -214,7 +243,7 @@ __global__ __launch_bounds__(256) void k_wf_apply_min(int64_t words, uint64_t* _
                                                      uint64_t* __restrict__ Hn, uint64_t* __restrict__ cand,
                                                      const uint64_t* __restrict__ W, const uint64_t* __restrict__ F, uint64_t* __restrict__ WF,
                                                      const double* __restrict__ C, double* __restrict__ part_c,
-                                                     int64_t* __restrict__ part_i, wf_ctr* __restrict__ ctr)
+                                                     int64_t* __restrict__ part_i, wf_ctr* __restrict__ ctr, wf_pos P)
 {
     __shared__ uint16_t s_list_[4][WF_GRP_CAP];
     __shared__ double s_c[4];
@@ -232,6 +261,7 @@ __global__ __launch_bounds__(256) void k_wf_apply_min(int64_t words, uint64_t* _
         ctr->tot[WF_NZ] += ctr->nz; ctr->tot[WF_NX] += ctr->nx;
         ctr->iters += 1; ctr->ntrip = 0; ctr->nz = 0; ctr->nx = 0;
     }
+    if (P.pwords) wf_apply_pos(P, ctr);                       // (reads nz_prev and the batch list of the step before: k_wf_select rewrites both later)
     double bc = 0.0; int64_t bi = -1;
     for (int64_t b0 = (int64_t)blockIdx.x * WF_BLK_WORDS; b0 < words; b0 += (int64_t)gridDim.x * WF_BLK_WORDS) {     // uniform trip count
         const int64_t w0 = b0 + wave * WF_GW;
@@ -240,8 +270,8 @@ __global__ __launch_bounds__(256) void k_wf_apply_min(int64_t words, uint64_t* _
         if (w < words && lane < WF_GW) {
             const uint64_t z = Z[w];
             h = (H[w] & ~z) | Hn[w];                          // fmt.jl:83-84 for the batch of the previous step
-            H[w] = h; Zp[w] = z; Z[w] = 0; Hn[w] = 0; cand[w] = 0;
-            WF[w] = W[w] & (F ? F[w] : ~0ull);                // unvisited and valid: the one word k_wf_mark gathers per entry
+            H[w] = h; Zp[w] = z; Z[w] = 0; Hn[w] = 0;
+            if (!P.pwords) { cand[w] = 0; WF[w] = W[w] & (F ? F[w] : ~0ull); }     // unvisited and valid: the one word k_wf_mark gathers per entry
         }
         const int total = wf_expand_group(h, s_list);
         for (int k = lane; k < total; k += 64) {
@@ -336,12 +366,36 @@ __global__ __launch_bounds__(64) void k_wf_compact(int64_t words, const unsigned
                                                    wf_ctr* __restrict__ ctr)
 {
     if (wf_stop(ctr)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->nz_prev = ctr->nz;      // (k_wf_select is done, the next k_wf_apply_min has not begun)
     for (int64_t w0 = (int64_t)blockIdx.x * 64; w0 < words; w0 += (int64_t)gridDim.x * 64) {
         const int64_t w = w0 + threadIdx.x;
         wf_append_word((w < words) ? cand[w] : 0ull, w, xlist, &ctr->nx);
     }
 }
 
+// ---- position space -----------------------------------------------------------------------------------------------------
+// the graph's rows as cell-sorted positions (once per graph: the ordering pass writes them itself only for the unfused sweeps)
+__global__ void k_wf_rowpos(const int32_t* __restrict__ rowval, const int32_t* __restrict__ iperm, int64_t nnz, int32_t* __restrict__ rowpos)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) rowpos[e] = iperm[rowval[e]];
+}
+// start of a solve: unvisited-and-valid by position (pads and the initial state out), the initial state open at cost 0
+__global__ __launch_bounds__(256) void k_wf_init_pos(int64_t pwords, const int32_t* __restrict__ perm, const int32_t* __restrict__ iperm, int64_t init,
+                                                     const uint64_t* __restrict__ F, uint64_t* __restrict__ WFs, uint64_t* __restrict__ Hs,
+                                                     uint64_t* __restrict__ Hns, uint64_t* __restrict__ cands, double* __restrict__ Cs)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t pinit = iperm[init];
+    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < pwords; w += (int64_t)gridDim.x * 4) {
+        const int64_t p = w * 64 + lane;
+        const int32_t o = perm[p];
+        const bool ok = o >= 0 && o != init && (!F || wf_bit(F, o));
+        const unsigned long long m = __ballot(ok);
+        Cs[p] = 0.0;
+        if (lane == 0) { WFs[w] = m; Hs[w] = (w == (pinit >> 6)) ? 1ull << (pinit & 63) : 0ull; Hns[w] = 0; cands[w] = 0; }
+    }
+}
 // the node the reference's loop would end on: goal node of lowest (cost, index) in the batch Z, or -- open set exhausted --
 // the last node of the previous batch Zp in pop order = highest (cost, index) (fmt.jl:85-89 leaves z at the last dequeued node)
 __global__ __launch_bounds__(1024) void k_wf_final(int64_t words, const uint64_t* __restrict__ Z, const uint64_t* __restrict__ Zp,
@@ -471,14 +525,17 @@ __global__ void k_wf_box_transpose(const double* __restrict__ boxes, int M, int 
 
 // one wavefront per candidate x.  MODE 0: connect in place; MODE 1: emit triples.  GEOM: the edge tests run against the obstacle set here
 // (the lazy form); without it they are a bit of the resident mask and the kernel holds no geometry at all (four candidates in flight)
-template <int D, int MODE, bool GEOM>
+// POS: the candidate list holds cell-sorted positions (in ascending order: neighbouring candidates are neighbours in space), the open set and
+// the costs are gathered by position (Hs, Cs, rows = rowsrc = the graph's rows as positions) and every connection is recorded on both sides
+struct wf_posc { const int32_t* perm; const int32_t* rowpos; const unsigned long long* Hs; double* Cs; unsigned long long* WFs; unsigned long long* Hns; };
+template <int D, int MODE, bool GEOM, bool POS>
 __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict__ xlist, const int64_t* __restrict__ colptr,
                                                     const int32_t* __restrict__ rowval, const double* __restrict__ nzval,
                                                     const uint64_t* __restrict__ H, double* __restrict__ C, int32_t* __restrict__ A,
                                                     unsigned long long* __restrict__ W, unsigned long long* __restrict__ Hn,
                                                     const double* __restrict__ X, const double* __restrict__ bT, int M, int mpad,
                                                     mpfmt_ss ss, const uint64_t* __restrict__ gfree, const uint8_t* __restrict__ nseg,
-                                                    wf_trip* __restrict__ mytrips, int64_t* __restrict__ stats, wf_ctr* __restrict__ ctr, int all_in)
+                                                    wf_trip* __restrict__ mytrips, int64_t* __restrict__ stats, wf_ctr* __restrict__ ctr, int all_in, wf_posc P)
 {
     // nseg != NULL (directed steering graphs: double integrator, cars): the edge's validity and the number of segment tests the
     // reference would have counted for it (boxesND.jl:26 per waypoint segment) were precomputed by the space's own sweep
@@ -492,11 +549,23 @@ __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict
     // trip (15 us of wavefront time per candidate).  NB candidates are taken per pass and every stage is issued for all of them before
     // the next stage's first use: the trips of the NB chains overlap.  The winner's row rides through the reduce (no reload of rowval).
     constexpr int NB = GEOM ? 1 : 2;                                       // (one at a time 4.55 ms per solve, two 4.13, four 4.25: registers)
-    const int st = gridDim.x * wpb;
-    for (int ix0 = blockIdx.x * wpb + (threadIdx.x >> 6); ix0 < nx; ix0 += NB * st) {
+    // candidates per wavefront: round robin (caller labels), or -- POS -- one contiguous run of the position-ordered list each, so that a
+    // wavefront's consecutive candidates are neighbours in space and their gathers meet the lines the last one pulled in
+    const int nwv = gridDim.x * wpb, gwv = blockIdx.x * wpb + (threadIdx.x >> 6);
+    const int per = POS ? (nx + nwv - 1) / nwv : 0;
+    const int ix_lo = POS ? gwv * per : gwv, ix_hi = POS ? min(nx, (gwv + 1) * per) : nx;
+    const int st = POS ? 1 : nwv;
+    const int32_t* __restrict__ rowsrc = POS ? P.rowpos : rowval;
+    const unsigned long long* __restrict__ Hg = POS ? P.Hs : (const unsigned long long*)H;
+    const double* __restrict__ Cg = POS ? P.Cs : C;
+    for (int ix0 = ix_lo; ix0 < ix_hi; ix0 += NB * st) {
         int64_t x[NB], beg[NB], end[NB];
+        [[maybe_unused]] int64_t px[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) x[k] = (ix0 + k * st < nx) ? (int64_t)xlist[ix0 + k * st] : -1;
+        for (int k = 0; k < NB; ++k) {
+            const int64_t v = (ix0 + k * st < ix_hi) ? (int64_t)xlist[ix0 + k * st] : -1;
+            if constexpr (POS) { px[k] = v; x[k] = v >= 0 ? (int64_t)P.perm[v] : -1; } else x[k] = v;
+        }
 #pragma unroll
         for (int k = 0; k < NB; ++k) { beg[k] = x[k] >= 0 ? colptr[x[k]] : 0; end[k] = x[k] >= 0 ? colptr[x[k] + 1] : 0; }
         double best[NB];
@@ -511,18 +580,18 @@ __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const int64_t e0 = beg[k] + off;
-                y0[k] = e0 < end[k] ? rowval[e0] : -1;
+                y0[k] = e0 < end[k] ? rowsrc[e0] : -1;
                 d0[k] = e0 < end[k] ? nzval[e0] : 0.0;
             }
             unsigned long long h0[NB];
 #pragma unroll
-            for (int k = 0; k < NB; ++k) h0[k] = y0[k] >= 0 ? H[y0[k] >> 6] : 0ull;
+            for (int k = 0; k < NB; ++k) h0[k] = y0[k] >= 0 ? Hg[y0[k] >> 6] : 0ull;
             double c0[NB];
             bool o0[NB];
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 o0[k] = y0[k] >= 0 && ((h0[k] >> (y0[k] & 63)) & 1ull);
-                c0[k] = o0[k] ? C[y0[k]] : 0.0;
+                c0[k] = o0[k] ? Cg[y0[k]] : 0.0;
             }
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
@@ -539,7 +608,7 @@ __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             if (be[k] < 0) continue;                                           // (wave-uniform: be is the reduced value)
-            const int64_t y = by[k];
+            const int64_t y = POS ? (int64_t)rowval[be[k]] : (int64_t)by[k];   // (POS: the reduce carried the row's position)
             bool inb = true;
             double v[D];
             [[maybe_unused]] double w[D];
@@ -573,6 +642,11 @@ __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict
                     A[x[k]] = (int32_t)y; C[x[k]] = best[k];
                     atomicAnd(&W[x[k] >> 6], ~(1ull << (x[k] & 63)));
                     atomicOr(&Hn[x[k] >> 6], 1ull << (x[k] & 63));
+                    if constexpr (POS) {
+                        P.Cs[px[k]] = best[k];
+                        atomicAnd(&P.WFs[px[k] >> 6], ~(1ull << (px[k] & 63)));
+                        atomicOr(&P.Hns[px[k] >> 6], 1ull << (px[k] & 63));
+                    }
                     ++my_conn;
                 } else {
                     wf_trip r; r.x = (int32_t)x[k]; r.y = (int32_t)y; r.c = best[k];
@@ -645,7 +719,7 @@ void mpfmt_wf_free(mpfmt_ctx* ctx)
 {
     mpfmt_wf* s = wf_of(ctx);
     if (!s) return;
-    void* bufs[] = {s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->F, s->WF, s->C, s->A, s->zlist, s->xlist, s->rowptr, s->colidx, s->part_c, s->part_i, s->stats, s->boxT, s->mytrips, s->xbuf,
+    void* bufs[] = {s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->F, s->WF, s->WFs, s->Hs, s->Hns, s->cands, s->Cs, s->C, s->A, s->zlist, s->xlist, s->rowptr, s->colidx, s->part_c, s->part_i, s->stats, s->boxT, s->mytrips, s->xbuf,
                     s->ctr, s->path_dev};
     for (void* b : bufs) if (b) hipFree(b);
     if (s->ctr_host) hipHostFree(s->ctr_host);
@@ -659,6 +733,7 @@ static int32_t wf_alloc(mpfmt_ctx* ctx, mpfmt_wf* s, int64_t N, int world)
     const int64_t words = (N + 63) / 64;
     if (s->N != N) {
         void** bufs[] = {(void**)&s->W, (void**)&s->H, (void**)&s->Z, (void**)&s->Zp, (void**)&s->Hn, (void**)&s->cand, (void**)&s->F, (void**)&s->WF,
+                         (void**)&s->WFs, (void**)&s->Hs, (void**)&s->Hns, (void**)&s->cands, (void**)&s->Cs,
                          (void**)&s->C, (void**)&s->A, (void**)&s->zlist, (void**)&s->xlist, (void**)&s->path_dev, (void**)&s->mytrips};
         for (void** b : bufs) if (*b) { HIPCHK(ctx, hipFree(*b)); *b = nullptr; }
         HIPCHK(ctx, hipMalloc((void**)&s->W, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->H, 8 * words));
@@ -668,6 +743,9 @@ static int32_t wf_alloc(mpfmt_ctx* ctx, mpfmt_wf* s, int64_t N, int world)
         HIPCHK(ctx, hipMalloc((void**)&s->C, 8 * N)); HIPCHK(ctx, hipMalloc((void**)&s->A, 4 * N));
         HIPCHK(ctx, hipMalloc((void**)&s->zlist, 4 * N)); HIPCHK(ctx, hipMalloc((void**)&s->xlist, 4 * N));
         HIPCHK(ctx, hipMalloc((void**)&s->path_dev, 8 * (N + 1)));
+        HIPCHK(ctx, hipMalloc((void**)&s->WFs, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->Hs, 8 * words));      // (ceil(N / 64) words = one per tile)
+        HIPCHK(ctx, hipMalloc((void**)&s->Hns, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->cands, 8 * words));
+        HIPCHK(ctx, hipMalloc((void**)&s->Cs, 8 * 64 * words));
         s->N = N; s->words = words;
     }
     if (!s->part_c) { HIPCHK(ctx, hipMalloc((void**)&s->part_c, 8 * WF_MAXPARTS)); HIPCHK(ctx, hipMalloc((void**)&s->part_i, 8 * WF_MAXPARTS)); }
@@ -693,36 +771,45 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     const int nparts = s->nparts;
     hipStream_t st = ctx->stream;
     const int d = ctx->d;
+    const bool pos = s->pos_space != 0;
+    wf_pos PA{pos ? s->pwords : 0, (unsigned long long*)s->Hs, s->Hns, s->cands, s->zlist, ctx->iperm};
     hipLaunchKernelGGL(k_wf_apply_min, dim3(nparts), dim3(256), 0, st, words, s->H, s->Z, s->Zp, s->Hn, s->cand, s->W, s->checkpts ? s->F : nullptr, s->WF, s->C,
-                       s->part_c, s->part_i, s->ctr);
+                       s->part_c, s->part_i, s->ctr, PA);
     hipLaunchKernelGGL(k_wf_select, dim3(nparts), dim3(256), 0, st, words, nparts, s->H, s->Z, s->C, ctx->Xo, d, s->part_c, s->part_i, s->band,
                        s->single, s->goal, s->zlist, s->ctr);
     const uint64_t* F = s->checkpts ? s->F : nullptr;
     const int grid = ctx->num_cus * 8;                       // persistent: 4 wavefronts per block, one list entry per wavefront at a time
     if (!s->sharded) {
-        // forward sets: the column itself for a metric (nearneighbors.jl:200-203), the row of the cost matrix otherwise
-        hipLaunchKernelGGL(k_wf_mark, dim3(grid), dim3(256), 0, st, s->zlist, s->directed ? s->rowptr : ctx->colptr,
-                           s->directed ? s->colidx : ctx->rowval, s->WF, (unsigned long long*)s->cand, s->ctr);
+        // forward sets: the column itself for a metric (nearneighbors.jl:200-203), the row of the cost matrix otherwise.  Position space:
+        // the same kernel over the rows as positions, the position-indexed unvisited-and-valid and candidate masks
+        if (pos) hipLaunchKernelGGL(k_wf_mark, dim3(grid), dim3(256), 0, st, s->zlist, ctx->colptr, (const int32_t*)ctx->rowpos, s->WFs,
+                                    (unsigned long long*)s->cands, s->ctr);
+        else hipLaunchKernelGGL(k_wf_mark, dim3(grid), dim3(256), 0, st, s->zlist, s->directed ? s->rowptr : ctx->colptr,
+                                s->directed ? s->colidx : ctx->rowval, s->WF, (unsigned long long*)s->cand, s->ctr);
     } else {
         const int64_t pb = std::min<int64_t>(ctx->tile_begin * 64, ctx->N), pe = std::min<int64_t>(ctx->tile_end * 64, ctx->N);
         hipLaunchKernelGGL(k_wf_mark_owned, dim3(ctx->num_cus * 8), dim3(256), 0, st, ctx->perm, pb, pe, ctx->colptr, ctx->rowval, s->W, F, s->Z,
                            (unsigned long long*)s->cand, s->ctr);
     }
-    hipLaunchKernelGGL(k_wf_compact, dim3(nparts), dim3(64), 0, st, words, (const unsigned long long*)s->cand, s->xlist, s->ctr);
+    if (pos) hipLaunchKernelGGL(k_wf_compact, dim3(nparts), dim3(64), 0, st, s->pwords, (const unsigned long long*)s->cands, s->xlist, s->ctr);
+    else hipLaunchKernelGGL(k_wf_compact, dim3(nparts), dim3(64), 0, st, words, (const unsigned long long*)s->cand, s->xlist, s->ctr);
     const uint64_t* gfree = s->use_mask ? ctx->graph_free : nullptr;
     const uint8_t* nseg = s->directed ? ctx->di_nseg : nullptr;
     // (a directed steering graph's validity bits are its own sweep's: gfree is set there too -- the mask form)
     const bool geom = gfree == nullptr;
     // (persistent workgroups: exactly as many as are resident at once -- the kernel's loops stride by the grid, so a workgroup that has to
     // wait for a slot starts its share of the candidates when the others are done with theirs)
-#define WF_CONNECT(MODE_, GEOM_, TRIPS_) DISPATCH_D(d, { int per_cu = 0; \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_connect<DD, MODE_, GEOM_>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4; \
+    wf_posc PC{ctx->perm, ctx->rowpos, (const unsigned long long*)s->Hs, s->Cs, (unsigned long long*)s->WFs, (unsigned long long*)s->Hns};
+#define WF_CONNECT(MODE_, GEOM_, POS_, TRIPS_) DISPATCH_D(d, { int per_cu = 0; \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_connect<DD, MODE_, GEOM_, POS_>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4; \
         const int cgrid = ctx->num_cus * std::min(per_cu, 8); \
-        hipLaunchKernelGGL((k_wf_connect<DD, MODE_, GEOM_>), dim3(cgrid), dim3(256), 0, st, s->xlist, ctx->colptr, \
+        hipLaunchKernelGGL((k_wf_connect<DD, MODE_, GEOM_, POS_>), dim3(cgrid), dim3(256), 0, st, s->xlist, ctx->colptr, \
         ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo, s->boxT, ctx->M, s->mpad, ctx->ss, gfree, nseg, \
-        TRIPS_, s->stats, s->ctr, s->all_in); })
-    if (!s->sharded) { if (geom) { WF_CONNECT(0, true, (wf_trip*)nullptr); } else { WF_CONNECT(0, false, (wf_trip*)nullptr); } }
-    else { if (geom) { WF_CONNECT(1, true, s->mytrips); } else { WF_CONNECT(1, false, s->mytrips); } }
+        TRIPS_, s->stats, s->ctr, s->all_in, PC); })
+    if (!s->sharded) {
+        if (pos) { if (geom) { WF_CONNECT(0, true, true, (wf_trip*)nullptr); } else { WF_CONNECT(0, false, true, (wf_trip*)nullptr); } }
+        else { if (geom) { WF_CONNECT(0, true, false, (wf_trip*)nullptr); } else { WF_CONNECT(0, false, false, (wf_trip*)nullptr); } }
+    } else { if (geom) { WF_CONNECT(1, true, false, s->mytrips); } else { WF_CONNECT(1, false, false, s->mytrips); } }
 #undef WF_CONNECT
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
@@ -865,6 +952,20 @@ int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t check
     s->ms_graph = ms(t1, t2); s->ms_sweep = ms(t0, t1) + ms(t2, t3);
     hipLaunchKernelGGL(k_wf_init, dim3(256), dim3(64), 0, ctx->stream, N, s->words, s->init, s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->C, s->A,
                        s->stats, s->ctr);
+    // position space (see mpfmt_wf): an unsharded ctx whose WHOLE index belongs to the resident graph (built here, not imported)
+    s->pos_space = (!s->sharded && ctx->wf_pos_space && ctx->grid_r == r && ctx->perm && ctx->iperm && !ctx->tileneed && ctx->ntiles == s->words &&
+                    ctx->nnz > 0 && ctx->nnz < ((int64_t)1 << 31)) ? 1 : 0;
+    if (s->pos_space) {
+        s->pwords = s->words;
+        if (!ctx->rowpos_valid) {
+            if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rowpos, sizeof(int32_t) * (size_t)std::max<int64_t>(std::max(ctx->nnz, ctx->nnz_cap), 1)))) return rc;
+            hipLaunchKernelGGL(k_wf_rowpos, dim3((unsigned)((ctx->nnz + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t*)ctx->rowval, (const int32_t*)ctx->iperm,
+                               ctx->nnz, ctx->rowpos);
+            ctx->rowpos_valid = true;
+        }
+        hipLaunchKernelGGL(k_wf_init_pos, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, s->pwords, (const int32_t*)ctx->perm, (const int32_t*)ctx->iperm, s->init,
+                           (const uint64_t*)(s->checkpts ? s->F : nullptr), s->WFs, s->Hs, s->Hns, s->cands, s->Cs);
+    }
     HIPCHK(ctx, hipGetLastError());
     s->active = true;
     return MPFMT_OK;
@@ -1091,7 +1192,7 @@ extern "C++" int32_t mpfmt_wf_begin_directed(mpfmt_ctx* ctx, int64_t init_idx, i
     s->active = false;
     s->t_begin = std::chrono::steady_clock::now();
     if ((rc = wf_alloc(ctx, s, N, 1))) return rc;
-    s->sharded = 0; s->directed = true; s->use_mask = 1; s->all_in = 0;
+    s->sharded = 0; s->directed = true; s->use_mask = 1; s->all_in = 0; s->pos_space = 0;
     s->band = band; s->single = (flags & MPFMT_WF_SINGLE) ? 1 : 0; s->checkpts = checkpts ? 1 : 0;
     s->init = init_idx - 1; s->r = ctx->di_r;
     s->goal.kind = goal_kind; s->goal.gd = goal_kind == MPFMT_GOAL_POINT ? d : gd;

@@ -1649,6 +1649,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
         return MPFMT_OK;
     }
     if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }
+    if (strcmp(name, "wf_pos_space") == 0) { ctx->wf_pos_space = value != 0; return MPFMT_OK; }
     if (strcmp(name, "shard_blocks") == 0) { ctx->shard_blocks = value != 0; ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; ctx->cut_key.clear(); return MPFMT_OK; }
     if (strcmp(name, "index_halo") == 0) { ctx->index_halo = value != 0; ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; return MPFMT_OK; }
     if (strcmp(name, "lists_wide") == 0) { ctx->lists_wide = (int32_t)value; ctx->lists_r = -1.0; return MPFMT_OK; }
