@@ -464,18 +464,25 @@ __global__ __launch_bounds__(256) void k_wf_mark(const int32_t* __restrict__ zli
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int nz = ctr->nz;
-    // (per entry ONE gathered word -- WF = unvisited and valid, combined by k_wf_apply_min -- and the candidate word only for the entries
-    // that pass it: the kernel moves a 64-byte line from L2 per gathered word, and three gathers per entry ran at the L2's bandwidth.
-    // Fetching list entries and column bounds ahead, or keeping several chunks in flight, did not help: 24 us either way, or worse)
-    for (int iz = blockIdx.x * wpb + (threadIdx.x >> 6); iz < nz; iz += gridDim.x * wpb) {
+    // Per entry ONE gathered word (WF = unvisited and valid) and the candidate word only for the entries that pass it.  The kernel is
+    // bound by the latency of a node's chain (rows -> WF words -> candidate words -> atomic) at full residency: 54 000 nodes take 37 us =
+    // 32 nodes in flight per CU x ~5.6 us each.  Both 64-entry chunks of a column (mean degree 107) are therefore requested together:
+    // half the trips per node.  (Written with scalars: an earlier form with small arrays ran 2.7 x slower.)
+    for (int iz = blockIdx.x * wpb + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); iz < nz; iz += gridDim.x * wpb) {
         const int64_t z = zlist[iz];
         const int64_t beg = colptr[z], end = colptr[z + 1];
-        for (int64_t e = beg + lane; e < end; e += 64) {
-            const int64_t x = rowval[e];
-            if (!wf_bit(WF, x)) continue;                                     // fmt.jl:70-71
-            const unsigned long long bit = 1ull << (x & 63);
-            if (cand[x >> 6] & bit) continue;                                 // seen already (a stale read only costs an atomic)
-            atomicOr(&cand[x >> 6], bit);
+        for (int64_t e0 = beg + lane; e0 < end + lane; e0 += 128) {         // (wave-uniform trip count)
+            const int64_t e1 = e0 + 64;
+            const int64_t xa = e0 < end ? (int64_t)rowval[e0] : -1;
+            const int64_t xb = e1 < end ? (int64_t)rowval[e1] : -1;
+            const unsigned long long wa = xa >= 0 ? WF[xa >> 6] : 0ull;
+            const unsigned long long wb = xb >= 0 ? WF[xb >> 6] : 0ull;
+            const unsigned long long ba = 1ull << (xa & 63), bb = 1ull << (xb & 63);
+            const bool pa = (wa & ba) != 0, pb = (wb & bb) != 0;            // fmt.jl:70-71
+            const unsigned long long ca = pa ? cand[xa >> 6] : ~0ull;       // seen already? (a stale read only costs an atomic)
+            const unsigned long long cb = pb ? cand[xb >> 6] : ~0ull;
+            if (pa && !(ca & ba)) atomicOr(&cand[xa >> 6], ba);
+            if (pb && !(cb & bb)) atomicOr(&cand[xb >> 6], bb);
         }
     }
 }
@@ -551,23 +558,54 @@ __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict
     constexpr int NB = GEOM ? 1 : 2;                                       // (one at a time 4.55 ms per solve, two 4.13, four 4.25: registers)
     // candidates per wavefront: round robin (caller labels), or -- POS -- one contiguous run of the position-ordered list each, so that a
     // wavefront's consecutive candidates are neighbours in space and their gathers meet the lines the last one pulled in
-    const int nwv = gridDim.x * wpb, gwv = blockIdx.x * wpb + (threadIdx.x >> 6);
+    // (the wavefront's index as a scalar: list entries, sample indices and column bounds are then scalar loads into SGPRs)
+    const int nwv = gridDim.x * wpb, gwv = blockIdx.x * wpb + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int per = POS ? (nx + nwv - 1) / nwv : 0;
     const int ix_lo = POS ? gwv * per : gwv, ix_hi = POS ? min(nx, (gwv + 1) * per) : nx;
     const int st = POS ? 1 : nwv;
     const int32_t* __restrict__ rowsrc = POS ? P.rowpos : rowval;
     const unsigned long long* __restrict__ Hg = POS ? P.Hs : (const unsigned long long*)H;
     const double* __restrict__ Cg = POS ? P.Cs : C;
+    // POS: a candidate's header is itself a chain (list entry -> sample index -> column bounds); it is walked one link per pass for the
+    // candidates three, two and one pass ahead, so that a pass starts at its rows
+    [[maybe_unused]] int64_t pxA[NB], pxB[NB], xB[NB], pxC[NB], xC[NB], begC[NB], endC[NB];
+    [[maybe_unused]] auto linkA = [&](int ix, int64_t (&q)[NB]) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) q[k] = (ix + k < ix_hi) ? (int64_t)xlist[ix + k] : -1;
+    };
+    [[maybe_unused]] auto linkB = [&](const int64_t (&q)[NB], int64_t (&xx)[NB]) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) xx[k] = q[k] >= 0 ? (int64_t)P.perm[q[k]] : -1;
+    };
+    [[maybe_unused]] auto linkC = [&](const int64_t (&xx)[NB], int64_t (&b)[NB], int64_t (&e)[NB]) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { b[k] = xx[k] >= 0 ? colptr[xx[k]] : 0; e[k] = xx[k] >= 0 ? colptr[xx[k] + 1] : 0; }
+    };
+    if constexpr (POS) {
+        linkA(ix_lo, pxC); linkB(pxC, xC); linkC(xC, begC, endC);
+        linkA(ix_lo + NB, pxB); linkB(pxB, xB);
+        linkA(ix_lo + 2 * NB, pxA);
+    }
     for (int ix0 = ix_lo; ix0 < ix_hi; ix0 += NB * st) {
         int64_t x[NB], beg[NB], end[NB];
         [[maybe_unused]] int64_t px[NB];
+        if constexpr (POS) {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int64_t v = (ix0 + k * st < ix_hi) ? (int64_t)xlist[ix0 + k * st] : -1;
-            if constexpr (POS) { px[k] = v; x[k] = v >= 0 ? (int64_t)P.perm[v] : -1; } else x[k] = v;
+            for (int k = 0; k < NB; ++k) { px[k] = pxC[k]; x[k] = xC[k]; beg[k] = begC[k]; end[k] = endC[k]; }
+            // one link further for the passes to come (consumed at the top of the next pass)
+#pragma unroll
+            for (int k = 0; k < NB; ++k) { pxC[k] = pxB[k]; xC[k] = xB[k]; }
+            linkC(xC, begC, endC);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) pxB[k] = pxA[k];
+            linkB(pxB, xB);
+            linkA(ix0 + 3 * NB, pxA);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) x[k] = (ix0 + k * st < ix_hi) ? (int64_t)xlist[ix0 + k * st] : -1;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) { beg[k] = x[k] >= 0 ? colptr[x[k]] : 0; end[k] = x[k] >= 0 ? colptr[x[k] + 1] : 0; }
         }
-#pragma unroll
-        for (int k = 0; k < NB; ++k) { beg[k] = x[k] >= 0 ? colptr[x[k]] : 0; end[k] = x[k] >= 0 ? colptr[x[k] + 1] : 0; }
         double best[NB];
         int64_t be[NB];
         int32_t by[NB];
