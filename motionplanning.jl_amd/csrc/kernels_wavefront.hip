@@ -47,7 +47,7 @@ struct wf_ctr {
     double cmin;                  // lowest open cost at this step
     int64_t imin;
     int64_t tot[4];               // sums of the per-block statistics: batch nodes, samples examined, connected, edge checks
-    int32_t pad_;
+    int32_t nz_prev;              // batch size of the step before (k_wf_compact): k_wf_apply_min takes those nodes out of Hs
     int32_t ended;                // latched by the first k_wf_apply_min that finds a goal batch recorded: k_wf_select, which must not
 };
 enum { WF_NZ = 0, WF_NX = 1, WF_NCONN = 2, WF_CHECKS = 3 };
@@ -65,7 +65,7 @@ struct mpfmt_wf {
     // rows are spatial neighbours, so by position their bits sit in ~14 cache lines instead of ~103 by caller index (north star, measured
     // on the host) and their costs in ~60 instead of ~106.  WFs: unvisited and valid; Hs: open (Hns: opened during this step); cands:
     // candidates of this step; Cs: cost-to-come.  The graph's rows by position: ctx->rowpos.
-    uint64_t *WFs = nullptr, *Hs = nullptr, *Hns = nullptr, *cands = nullptr, *Zs = nullptr, *Zps = nullptr;
+    uint64_t *WFs = nullptr, *Hs = nullptr, *Hns = nullptr, *cands = nullptr;
     double* Cs = nullptr;
     int64_t pwords = 0;
     int32_t pos_space = 0;
@@ -214,6 +214,27 @@ __device__ __forceinline__ int wf_expand_group(unsigned long long m, uint16_t* _
     return total;
 }
 
+// start of a step, position side: the nodes opened during the step before join Hs, its batch leaves it, the candidate mask is cleared
+// (part of k_wf_apply_min's launch)
+struct wf_pos { int64_t pwords; unsigned long long* Hs; uint64_t* Hns; uint64_t* cands; const int32_t* zlist; const int32_t* iperm; };
+__device__ __forceinline__ void wf_apply_pos(const wf_pos& P, const wf_ctr* __restrict__ ctr)
+{
+    const int64_t pwords = P.pwords;
+    unsigned long long* __restrict__ Hs = P.Hs; uint64_t* __restrict__ Hns = P.Hns; uint64_t* __restrict__ cands = P.cands;
+    const int32_t* __restrict__ zlist = P.zlist; const int32_t* __restrict__ iperm = P.iperm;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t w = t; w < pwords; w += nt) {
+        const uint64_t hn = Hns[w];
+        if (hn) { atomicOr(&Hs[w], (unsigned long long)hn); Hns[w] = 0; }
+        cands[w] = 0;
+    }
+    const int nzp = ctr->nz_prev;
+    for (int64_t k = t; k < nzp; k += nt) {
+        const int64_t p = iperm[zlist[k]];
+        atomicAnd(&Hs[p >> 6], ~(1ull << (p & 63)));
+    }
+}
+
 // One workgroup = four wavefronts = one 64-word slab of the masks; each wavefront takes WF_GW = 16 of its words.  One partial minimum per
 // workgroup (k_wf_select reduces ~250 of them, every workgroup for itself) and ONE atomic per workgroup on a list counter: a counter
 // takes ~90 atomics per microsecond, so a thousand wavefronts appending one by one cost more than the gathers they were split up for.
@@ -222,10 +243,8 @@ __global__ __launch_bounds__(256) void k_wf_apply_min(int64_t words, uint64_t* _
                                                      uint64_t* __restrict__ Hn, uint64_t* __restrict__ cand,
                                                      const uint64_t* __restrict__ W, const uint64_t* __restrict__ F, uint64_t* __restrict__ WF,
                                                      const double* __restrict__ C, double* __restrict__ part_c,
-                                                     int64_t* __restrict__ part_i, wf_ctr* __restrict__ ctr, const int32_t* __restrict__ perm)
+                                                     int64_t* __restrict__ part_i, wf_ctr* __restrict__ ctr, wf_pos P)
 {
-    // perm != nullptr: the sets are indexed by cell-sorted position (mpfmt_wf: position space); a node's sample index -- what ties are
-    // broken by and what leaves the kernel -- is perm[position]
     __shared__ uint16_t s_list_[4][WF_GRP_CAP];
     __shared__ double s_c[4];
     __shared__ long long s_i[4];
@@ -242,6 +261,7 @@ __global__ __launch_bounds__(256) void k_wf_apply_min(int64_t words, uint64_t* _
         ctr->tot[WF_NZ] += ctr->nz; ctr->tot[WF_NX] += ctr->nx;
         ctr->iters += 1; ctr->ntrip = 0; ctr->nz = 0; ctr->nx = 0;
     }
+    if (P.pwords) wf_apply_pos(P, ctr);                       // (reads nz_prev and the batch list of the step before: k_wf_select rewrites both later)
     double bc = 0.0; int64_t bi = -1;
     for (int64_t b0 = (int64_t)blockIdx.x * WF_BLK_WORDS; b0 < words; b0 += (int64_t)gridDim.x * WF_BLK_WORDS) {     // uniform trip count
         const int64_t w0 = b0 + wave * WF_GW;
@@ -250,14 +270,13 @@ __global__ __launch_bounds__(256) void k_wf_apply_min(int64_t words, uint64_t* _
         if (w < words && lane < WF_GW) {
             const uint64_t z = Z[w];
             h = (H[w] & ~z) | Hn[w];                          // fmt.jl:83-84 for the batch of the previous step
-            H[w] = h; Zp[w] = z; Z[w] = 0; Hn[w] = 0; cand[w] = 0;
-            if (WF) WF[w] = W[w] & (F ? F[w] : ~0ull);       // unvisited and valid: the one word k_wf_mark gathers per entry (position space: kept by k_wf_connect)
+            H[w] = h; Zp[w] = z; Z[w] = 0; Hn[w] = 0;
+            if (!P.pwords) { cand[w] = 0; WF[w] = W[w] & (F ? F[w] : ~0ull); }     // unvisited and valid: the one word k_wf_mark gathers per entry
         }
         const int total = wf_expand_group(h, s_list);
         for (int k = lane; k < total; k += 64) {
-            const int64_t p = w0 * 64 + (int64_t)s_list[k];
-            const double c = C[p];
-            const int64_t i = perm ? (int64_t)perm[p] : p;
+            const int64_t i = w0 * 64 + (int64_t)s_list[k];
+            const double c = C[i];
             if (bi < 0 || c < bc || (c == bc && i < bi)) { bc = c; bi = i; }
         }
         __builtin_amdgcn_wave_barrier();                      // (the list is rewritten by the next group)
@@ -280,7 +299,7 @@ __global__ __launch_bounds__(256) void k_wf_select(int64_t words, int nparts, co
                                                   const double* __restrict__ C, const double* __restrict__ X, int d,
                                                   const double* __restrict__ part_c, const int64_t* __restrict__ part_i,
                                                   double band, int single, wf_goal G, int32_t* __restrict__ zlist,
-                                                  wf_ctr* __restrict__ ctr, const int32_t* __restrict__ perm)
+                                                  wf_ctr* __restrict__ ctr)
 {
     __shared__ uint16_t s_list_[4][WF_GRP_CAP];
     __shared__ unsigned long long s_z_[4][WF_GW];
@@ -310,9 +329,9 @@ __global__ __launch_bounds__(256) void k_wf_select(int64_t words, int nparts, co
         const int total = wf_expand_group(h, s_list);
         for (int k = lane; k < total; k += 64) {
             const int p = (int)s_list[k];
-            const int64_t i = w0 * 64 + p;                   // (position space: X is the cell-sorted copy, the test reads the same coordinates)
+            const int64_t i = w0 * 64 + p;
             const double c = C[i];
-            const bool sel = single ? ((perm ? (int64_t)perm[i] : i) == im) : (c <= thr);
+            const bool sel = single ? (i == im) : (c <= thr);
             if (!sel) continue;
             atomicOr(&s_z[p >> 6], 1ull << (p & 63));
             if (wf_is_goal(X + i * d, G))           // fmt.jl:68
@@ -337,7 +356,7 @@ __global__ __launch_bounds__(256) void k_wf_select(int64_t words, int nparts, co
         int o = s_base + inc - n;
         for (int k = 0; k < wave; ++k) o += s_tot[k];
         uint64_t m = z;
-        while (m) { const int bb = __ffsll((long long)m) - 1; m &= m - 1; zlist[o++] = perm ? perm[w * 64 + bb] : (int32_t)(w * 64 + bb); }      // (the batch list holds sample indices)
+        while (m) { const int bb = __ffsll((long long)m) - 1; m &= m - 1; zlist[o++] = (int32_t)(w * 64 + bb); }
         __syncthreads();                                      // (s_tot / s_base are rewritten by the next slab)
     }
 }
@@ -347,6 +366,7 @@ __global__ __launch_bounds__(64) void k_wf_compact(int64_t words, const unsigned
                                                    wf_ctr* __restrict__ ctr)
 {
     if (wf_stop(ctr)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->nz_prev = ctr->nz;      // (k_wf_select is done, the next k_wf_apply_min has not begun)
     for (int64_t w0 = (int64_t)blockIdx.x * 64; w0 < words; w0 += (int64_t)gridDim.x * 64) {
         const int64_t w = w0 + threadIdx.x;
         wf_append_word((w < words) ? cand[w] : 0ull, w, xlist, &ctr->nx);
@@ -363,8 +383,7 @@ __global__ void k_wf_rowpos(const int32_t* __restrict__ rowval, const int32_t* _
 // start of a solve: unvisited-and-valid by position (pads and the initial state out), the initial state open at cost 0
 __global__ __launch_bounds__(256) void k_wf_init_pos(int64_t pwords, const int32_t* __restrict__ perm, const int32_t* __restrict__ iperm, int64_t init,
                                                      const uint64_t* __restrict__ F, uint64_t* __restrict__ WFs, uint64_t* __restrict__ Hs,
-                                                     uint64_t* __restrict__ Hns, uint64_t* __restrict__ cands, double* __restrict__ Cs,
-                                                     uint64_t* __restrict__ Zs, uint64_t* __restrict__ Zps)
+                                                     uint64_t* __restrict__ Hns, uint64_t* __restrict__ cands, double* __restrict__ Cs)
 {
     const int lane = threadIdx.x & 63;
     const int64_t pinit = iperm[init];
@@ -374,14 +393,14 @@ __global__ __launch_bounds__(256) void k_wf_init_pos(int64_t pwords, const int32
         const bool ok = o >= 0 && o != init && (!F || wf_bit(F, o));
         const unsigned long long m = __ballot(ok);
         Cs[p] = 0.0;
-        if (lane == 0) { WFs[w] = m; Hs[w] = (w == (pinit >> 6)) ? 1ull << (pinit & 63) : 0ull; Hns[w] = 0; cands[w] = 0; Zs[w] = 0; Zps[w] = 0; }
+        if (lane == 0) { WFs[w] = m; Hs[w] = (w == (pinit >> 6)) ? 1ull << (pinit & 63) : 0ull; Hns[w] = 0; cands[w] = 0; }
     }
 }
 // the node the reference's loop would end on: goal node of lowest (cost, index) in the batch Z, or -- open set exhausted --
 // the last node of the previous batch Zp in pop order = highest (cost, index) (fmt.jl:85-89 leaves z at the last dequeued node)
 __global__ __launch_bounds__(1024) void k_wf_final(int64_t words, const uint64_t* __restrict__ Z, const uint64_t* __restrict__ Zp,
                                                  const double* __restrict__ C, const double* __restrict__ X, int d, wf_goal G,
-                                                 wf_ctr* __restrict__ ctr, const int32_t* __restrict__ perm)
+                                                 wf_ctr* __restrict__ ctr)
 {
     const bool goal = ctr->goal_cbits != ~0ull;
     if (!goal && ctr->done != 2) return;
@@ -394,11 +413,10 @@ __global__ __launch_bounds__(1024) void k_wf_final(int64_t words, const uint64_t
         while (m) {
             const int b = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const int64_t p = w * 64 + b;
-            const double c = C[p];
-            const int64_t i = perm ? (int64_t)perm[p] : p;
+            const int64_t i = w * 64 + b;
+            const double c = C[i];
             if (goal) {
-                if (!wf_is_goal(X + p * d, G)) continue;
+                if (!wf_is_goal(X + i * d, G)) continue;
                 if (bi < 0 || c < bc || (c == bc && i < bi)) { bc = c; bi = i; }
             } else {
                 if (bi < 0 || c > bc || (c == bc && i > bi)) { bc = c; bi = i; }
@@ -448,8 +466,8 @@ __global__ __launch_bounds__(256) void k_wf_mark(const int32_t* __restrict__ zli
     const int nz = ctr->nz;
     // Per entry ONE gathered word (WF = unvisited and valid) and the candidate word only for the entries that pass it.  The kernel is
     // bound by the latency of a node's chain (rows -> WF words -> candidate words -> atomic) at full residency: 54 000 nodes take 37 us =
-    // 32 nodes in flight per CU x ~5.6 us each.  Both 64-entry chunks of a column (mean degree 107) are therefore requested together:
-    // half the trips per node.  (Written with scalars: an earlier form with small arrays ran 2.7 x slower.)
+    // 32 nodes in flight per CU x ~5.6 us each.  Both 64-entry chunks of a column (mean degree 107) are therefore requested together
+    // (37 -> 33 us at the widest wavefront).  (Written with scalars: an earlier form with small arrays ran 2.7 x slower.)
     for (int iz = blockIdx.x * wpb + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); iz < nz; iz += gridDim.x * wpb) {
         const int64_t z = zlist[iz];
         const int64_t beg = colptr[z], end = colptr[z + 1];
@@ -547,8 +565,6 @@ __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict
     const int32_t* __restrict__ rowsrc = POS ? P.rowpos : rowval;
     const unsigned long long* __restrict__ Hg = POS ? P.Hs : (const unsigned long long*)H;
     const double* __restrict__ Cg = POS ? P.Cs : C;
-    // (Walking the header chain -- list entry -> sample index -> column bounds -- a link per pass ahead of the candidates was measured: as
-    // vector loads its registers cost the residency (105 VGPRs), as scalar loads every wait is lgkmcnt(0) and the links serialise: 70 -> 91 us.)
     for (int ix0 = ix_lo; ix0 < ix_hi; ix0 += NB * st) {
         int64_t x[NB], beg[NB], end[NB];
         [[maybe_unused]] int64_t px[NB];
@@ -631,13 +647,12 @@ __global__ __launch_bounds__(256, 4) void k_wf_connect(const int32_t* __restrict
             if (fr && lane == 0) {                                             // fmt.jl:76-80
                 if (MODE == 0) {
                     A[x[k]] = (int32_t)y; C[x[k]] = best[k];
-                    if constexpr (POS) {                     // (the sets live by position; the caller-order views are made on request)
+                    atomicAnd(&W[x[k] >> 6], ~(1ull << (x[k] & 63)));
+                    atomicOr(&Hn[x[k] >> 6], 1ull << (x[k] & 63));
+                    if constexpr (POS) {
                         P.Cs[px[k]] = best[k];
                         atomicAnd(&P.WFs[px[k] >> 6], ~(1ull << (px[k] & 63)));
                         atomicOr(&P.Hns[px[k] >> 6], 1ull << (px[k] & 63));
-                    } else {
-                        atomicAnd(&W[x[k] >> 6], ~(1ull << (x[k] & 63)));
-                        atomicOr(&Hn[x[k] >> 6], 1ull << (x[k] & 63));
                     }
                     ++my_conn;
                 } else {
@@ -697,30 +712,6 @@ __global__ void k_wf_path(const int32_t* __restrict__ A, int64_t N, const wf_ctr
     for (int64_t k = n - 1; k >= 0; --k) { path[k] = cur + 1; if (k) cur = A[cur]; }
 }
 
-// position space -> the caller-order views the step-wise API hands out: bit i of a set = bit iperm[i] of its position-indexed form
-__global__ __launch_bounds__(256) void k_wf_mask_to_orig(const uint64_t* __restrict__ Ms, const uint64_t* __restrict__ Ms_minus, const uint64_t* __restrict__ Ms_plus,
-                                                         const int32_t* __restrict__ iperm, int64_t N, uint64_t* __restrict__ Mo)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool b = false;
-    if (i < N) {
-        const int64_t p = iperm[i];
-        b = wf_bit(Ms, p);
-        if (Ms_minus && wf_bit(Ms_minus, p)) b = false;
-        if (Ms_plus && wf_bit(Ms_plus, p)) b = true;
-    }
-    const unsigned long long m = __ballot(b);
-    if ((threadIdx.x & 63) == 0 && i < N) Mo[i >> 6] = m;
-}
-// W in position space is not kept (WFs = unvisited AND valid): unvisited <=> no parent and not the initial state
-__global__ __launch_bounds__(256) void k_wf_unvisited(const int32_t* __restrict__ A, int64_t init, int64_t N, uint64_t* __restrict__ Wo)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool b = i < N && A[i] < 0 && i != init;
-    const unsigned long long m = __ballot(b);
-    if ((threadIdx.x & 63) == 0 && i < N) Wo[i >> 6] = m;
-}
-
 __global__ void k_wf_A_to_i64(const int32_t* __restrict__ A, int64_t N, int64_t* __restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -735,7 +726,7 @@ void mpfmt_wf_free(mpfmt_ctx* ctx)
 {
     mpfmt_wf* s = wf_of(ctx);
     if (!s) return;
-    void* bufs[] = {s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->F, s->WF, s->WFs, s->Hs, s->Hns, s->cands, s->Zs, s->Zps, s->Cs, s->C, s->A, s->zlist, s->xlist, s->rowptr, s->colidx, s->part_c, s->part_i, s->stats, s->boxT, s->mytrips, s->xbuf,
+    void* bufs[] = {s->W, s->H, s->Z, s->Zp, s->Hn, s->cand, s->F, s->WF, s->WFs, s->Hs, s->Hns, s->cands, s->Cs, s->C, s->A, s->zlist, s->xlist, s->rowptr, s->colidx, s->part_c, s->part_i, s->stats, s->boxT, s->mytrips, s->xbuf,
                     s->ctr, s->path_dev};
     for (void* b : bufs) if (b) hipFree(b);
     if (s->ctr_host) hipHostFree(s->ctr_host);
@@ -749,7 +740,7 @@ static int32_t wf_alloc(mpfmt_ctx* ctx, mpfmt_wf* s, int64_t N, int world)
     const int64_t words = (N + 63) / 64;
     if (s->N != N) {
         void** bufs[] = {(void**)&s->W, (void**)&s->H, (void**)&s->Z, (void**)&s->Zp, (void**)&s->Hn, (void**)&s->cand, (void**)&s->F, (void**)&s->WF,
-                         (void**)&s->WFs, (void**)&s->Hs, (void**)&s->Hns, (void**)&s->cands, (void**)&s->Zs, (void**)&s->Zps, (void**)&s->Cs,
+                         (void**)&s->WFs, (void**)&s->Hs, (void**)&s->Hns, (void**)&s->cands, (void**)&s->Cs,
                          (void**)&s->C, (void**)&s->A, (void**)&s->zlist, (void**)&s->xlist, (void**)&s->path_dev, (void**)&s->mytrips};
         for (void** b : bufs) if (*b) { HIPCHK(ctx, hipFree(*b)); *b = nullptr; }
         HIPCHK(ctx, hipMalloc((void**)&s->W, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->H, 8 * words));
@@ -761,7 +752,6 @@ static int32_t wf_alloc(mpfmt_ctx* ctx, mpfmt_wf* s, int64_t N, int world)
         HIPCHK(ctx, hipMalloc((void**)&s->path_dev, 8 * (N + 1)));
         HIPCHK(ctx, hipMalloc((void**)&s->WFs, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->Hs, 8 * words));      // (ceil(N / 64) words = one per tile)
         HIPCHK(ctx, hipMalloc((void**)&s->Hns, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->cands, 8 * words));
-        HIPCHK(ctx, hipMalloc((void**)&s->Zs, 8 * words)); HIPCHK(ctx, hipMalloc((void**)&s->Zps, 8 * words));
         HIPCHK(ctx, hipMalloc((void**)&s->Cs, 8 * 64 * words));
         s->N = N; s->words = words;
     }
@@ -789,18 +779,11 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     hipStream_t st = ctx->stream;
     const int d = ctx->d;
     const bool pos = s->pos_space != 0;
-    if (pos) {
-        // position space: the same kernels over the position-indexed sets, sample indices through perm
-        hipLaunchKernelGGL(k_wf_apply_min, dim3(nparts), dim3(256), 0, st, s->pwords, s->Hs, s->Zs, s->Zps, s->Hns, s->cands, (const uint64_t*)nullptr,
-                           (const uint64_t*)nullptr, (uint64_t*)nullptr, (const double*)s->Cs, s->part_c, s->part_i, s->ctr, (const int32_t*)ctx->perm);
-        hipLaunchKernelGGL(k_wf_select, dim3(nparts), dim3(256), 0, st, s->pwords, nparts, (const uint64_t*)s->Hs, s->Zs, (const double*)s->Cs, (const double*)ctx->Xs, d,
-                           s->part_c, s->part_i, s->band, s->single, s->goal, s->zlist, s->ctr, (const int32_t*)ctx->perm);
-    } else {
-        hipLaunchKernelGGL(k_wf_apply_min, dim3(nparts), dim3(256), 0, st, words, s->H, s->Z, s->Zp, s->Hn, s->cand, s->W, s->checkpts ? s->F : nullptr, s->WF, s->C,
-                           s->part_c, s->part_i, s->ctr, (const int32_t*)nullptr);
-        hipLaunchKernelGGL(k_wf_select, dim3(nparts), dim3(256), 0, st, words, nparts, s->H, s->Z, s->C, ctx->Xo, d, s->part_c, s->part_i, s->band,
-                           s->single, s->goal, s->zlist, s->ctr, (const int32_t*)nullptr);
-    }
+    wf_pos PA{pos ? s->pwords : 0, (unsigned long long*)s->Hs, s->Hns, s->cands, s->zlist, ctx->iperm};
+    hipLaunchKernelGGL(k_wf_apply_min, dim3(nparts), dim3(256), 0, st, words, s->H, s->Z, s->Zp, s->Hn, s->cand, s->W, s->checkpts ? s->F : nullptr, s->WF, s->C,
+                       s->part_c, s->part_i, s->ctr, PA);
+    hipLaunchKernelGGL(k_wf_select, dim3(nparts), dim3(256), 0, st, words, nparts, s->H, s->Z, s->C, ctx->Xo, d, s->part_c, s->part_i, s->band,
+                       s->single, s->goal, s->zlist, s->ctr);
     const uint64_t* F = s->checkpts ? s->F : nullptr;
     const int grid = ctx->num_cus * 8;                       // persistent: 4 wavefronts per block, one list entry per wavefront at a time
     if (!s->sharded) {
@@ -988,7 +971,7 @@ int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t check
             ctx->rowpos_valid = true;
         }
         hipLaunchKernelGGL(k_wf_init_pos, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, s->pwords, (const int32_t*)ctx->perm, (const int32_t*)ctx->iperm, s->init,
-                           (const uint64_t*)(s->checkpts ? s->F : nullptr), s->WFs, s->Hs, s->Hns, s->cands, s->Cs, s->Zs, s->Zps);
+                           (const uint64_t*)(s->checkpts ? s->F : nullptr), s->WFs, s->Hs, s->Hns, s->cands, s->Cs);
     }
     HIPCHK(ctx, hipGetLastError());
     s->active = true;
@@ -1017,21 +1000,6 @@ int32_t mpfmt_wf_state(mpfmt_ctx* ctx, uint64_t* W, uint64_t* H, double* C, int6
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t N = s->N, words = s->words;
-    if (s->pos_space) {
-        // (the sets live by position: the caller-order views are made here, in the scratch words of the caller-order sets)
-        const unsigned nb = (unsigned)((N + 255) / 256);
-        if (W) {
-            hipLaunchKernelGGL(k_wf_unvisited, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t*)s->A, s->init, N, s->W);
-            HIPCHK(ctx, hipMemcpyAsync(W, s->W, 8 * words, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        if (H) {   // as the NEXT step will see it: (H \ Z) + Hnew
-            hipLaunchKernelGGL(k_wf_mask_to_orig, dim3(nb), dim3(256), 0, ctx->stream, (const uint64_t*)s->Hs, (const uint64_t*)s->Zs, (const uint64_t*)s->Hns,
-                               (const int32_t*)ctx->iperm, N, s->H);
-            HIPCHK(ctx, hipMemcpyAsync(H, s->H, 8 * words, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        W = nullptr; H = nullptr;
-    }
     if (W) HIPCHK(ctx, hipMemcpy(W, s->W, 8 * words, hipMemcpyDeviceToHost));
     if (H) {   // the open set as the NEXT step will see it: H = (H \ Z) + Hnew is applied at the start of a step
         std::vector<uint64_t> h(words), z(words), hn(words);
@@ -1060,11 +1028,6 @@ int32_t mpfmt_wf_batch(mpfmt_ctx* ctx, int64_t* zs, int64_t cap, int64_t* nz)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<uint64_t> z((size_t)s->words);
-    if (s->pos_space) {
-        hipLaunchKernelGGL(k_wf_mask_to_orig, dim3((unsigned)((s->N + 255) / 256)), dim3(256), 0, ctx->stream, (const uint64_t*)s->Zs, (const uint64_t*)nullptr,
-                           (const uint64_t*)nullptr, (const int32_t*)ctx->iperm, s->N, s->Z);
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    }
     HIPCHK(ctx, hipMemcpy(z.data(), s->Z, 8 * s->words, hipMemcpyDeviceToHost));        // the batch mask of the last step, ascending
     int64_t n = 0;
     for (int64_t w = 0; w < s->words; ++w) n += __builtin_popcountll(z[w]);
@@ -1136,9 +1099,7 @@ int32_t mpfmt_wf_finish(mpfmt_ctx* ctx, int64_t* A, double* C, int64_t* path, mp
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t N = s->N;
     int32_t rc;
-    if (s->pos_space) hipLaunchKernelGGL(k_wf_final, dim3(1), dim3(1024), 0, ctx->stream, s->pwords, (const uint64_t*)s->Zs, (const uint64_t*)s->Zps, (const double*)s->Cs,
-                                         (const double*)ctx->Xs, ctx->d, s->goal, s->ctr, (const int32_t*)ctx->perm);
-    else hipLaunchKernelGGL(k_wf_final, dim3(1), dim3(1024), 0, ctx->stream, s->words, s->Z, s->Zp, s->C, ctx->Xo, ctx->d, s->goal, s->ctr, (const int32_t*)nullptr);
+    hipLaunchKernelGGL(k_wf_final, dim3(1), dim3(1024), 0, ctx->stream, s->words, s->Z, s->Zp, s->C, ctx->Xo, ctx->d, s->goal, s->ctr);
     hipLaunchKernelGGL(k_wf_path, dim3(1), dim3(1), 0, ctx->stream, s->A, N, s->ctr, s->path_dev);
     HIPCHK(ctx, hipGetLastError());
     if ((rc = wf_read_ctr(ctx, s, true))) return rc;
