@@ -433,7 +433,7 @@ def test_large_stress_of_the_timed_form_in_suite(orc):
     assert forms.get((1, 2), 0) * 2 >= steps, forms
 
 
-@pytest.mark.parametrize("d,N,deg", [(2, 150000, 6), (2, 90001, 3), (3, 200000, 0.7), (1, 5000, 4)])
+@pytest.mark.parametrize("d,N,deg", [(2, 30000, 4), (2, 20001, 2), (3, 40000, 0.15), (1, 5000, 4)])
 def test_large_low_dimensional_world_takes_the_pipeline_with_the_exact_filter(orc, d, N, deg):
     """Worlds whose radius lies below the fp16 shell of globally normalised coordinates (the notebook's 2-D world scaled up,
     docs/MotionPlanning.ipynb cell 4): the step is still the single-pass pipeline -- half build, logs, edge tests fused (form 2) -- with

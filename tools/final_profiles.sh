@@ -43,9 +43,14 @@ for spec in "3 8" "0 1"; do
 done
 # the device FMT* solve on the resident north-star graph: per-kernel durations and counters
 rm -rf /tmp/prof_wf /tmp/pmc_wf
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_wf -o s -- python3 $ROOT/tools/run_wavefront_ns.py > profiles/${R}_wavefront_ns.txt 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_wf -o s -- python3 $ROOT/tools/run_wavefront_ns.py > $ROOT/profiles/${R}_wavefront_ns.txt 2>&1)
 DB=$(find /tmp/prof_wf -name "*_results.db" | head -1)
 [ -n "$DB" ] && python3 tools/rocpd_stats.py "$DB" profiles/${R}_wavefront_kernel_stats_${V}.csv > /dev/null
 (cd /tmp && timeout 600 rocprofv3 -i $ROOT/tools/pmc_mem.txt --kernel-trace --output-format csv -d /tmp/pmc_wf -o p -- python3 $ROOT/tools/run_wavefront_ns.py > /tmp/pmc_wf.log 2>&1)
 python3 tools/pmc_summary.py /tmp/pmc_wf k_wf > profiles/${R}_pmc_wavefront_${V}.txt 2>&1
+cp profiles/${R}_* gpurun_out/ 2>/dev/null
+rm -rf /tmp/prof_ws
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_ws -o s -- python3 $ROOT/tools/run_wavefront_steps.py > /tmp/ws.log 2>&1)
+DB=$(find /tmp/prof_ws -name "*_results.db" | head -1)
+[ -n "$DB" ] && { grep "per wavefront" /tmp/ws.log; python3 tools/wavefront_steps.py $DB 1; } > profiles/${R}_wavefront_steps.txt 2>&1
 cp profiles/${R}_* gpurun_out/ 2>/dev/null
