@@ -72,6 +72,10 @@ MPFMT_API int32_t mpfmt_set_shard(mpfmt_ctx* ctx, int32_t rank, int32_t world);
 /* ---- index build: helper_data_structures(V, dist) (src/nearneighbors.jl:95-100,
  *      src/statespaces/geometric.jl:14) called by MetricNN(V, dist, init) (src/nearneighbors.jl:70-74)
  *      every time addpoints runs (src/sampling.jl:43). --------------------------------------------- */
+/* X: d x N column-major host doubles (Julia's Vector{SVector{d,Float64}} as it lies in memory).  One PCIe copy; the set's bounding
+ * box and the finiteness check run on the device beside it (one reduction over the uploaded copy -- a host loop over the coordinates
+ * would cost more than the copy).  A non-finite coordinate returns MPFMT_ERR_ARG naming the first such sample (1-based) and leaves
+ * the ctx WITHOUT a sample set, as for mpfmt_upload_samples_device below. */
 MPFMT_API int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t d);
 /* The same for a sample set that already lives in HBM of ctx's device (dX = device pointer, same d x N column-major layout): a batch
  * produced on the device -- the library's sampler (mpfmt_sample_free leaves its set in ctx already), a ROCArray -- becomes the

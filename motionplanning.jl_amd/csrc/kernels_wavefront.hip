@@ -962,6 +962,14 @@ int32_t mpfmt_wf_begin(mpfmt_ctx* ctx, double r, int64_t init_idx, int32_t check
     // position space (see mpfmt_wf): an unsharded ctx whose WHOLE index belongs to the resident graph (built here, not imported)
     s->pos_space = (!s->sharded && ctx->wf_pos_space && ctx->grid_r == r && ctx->perm && ctx->iperm && !ctx->tileneed && ctx->ntiles == s->words &&
                     ctx->nnz > 0 && ctx->nnz < ((int64_t)1 << 31)) ? 1 : 0;
+    if (s->pos_space && !ctx->rowpos_valid) {
+        // the entries' positions cost one gather over the whole graph (0.7 ms at the north star) and save a quarter of that per solve:
+        // the FIRST solve on a graph runs by caller index, the positions are made when a second one asks for the same graph
+        const bool again = ctx->wf_seen_epoch == ctx->samples_epoch && ctx->wf_seen_r == r && ctx->wf_seen_nnz == ctx->nnz;
+        ctx->wf_seen_epoch = ctx->samples_epoch; ctx->wf_seen_r = r; ctx->wf_seen_nnz = ctx->nnz;
+        if (!again && ctx->wf_pos_space < 2) s->pos_space = 0;
+    }
+    ctx->wf_pos_used = s->pos_space;
     if (s->pos_space) {
         s->pwords = s->words;
         if (!ctx->rowpos_valid) {

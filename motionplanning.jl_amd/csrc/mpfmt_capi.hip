@@ -236,36 +236,7 @@ int32_t mpfmt_set_shard(mpfmt_ctx* ctx, int32_t rank, int32_t world)
     return MPFMT_OK;
 }
 
-int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t d)
-{
-    if (!ctx) return MPFMT_ERR_ARG;
-    if (N < 0 || N >= ((int64_t)1 << 31) - 64) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "N = %lld out of range", (long long)N);
-    if (d < 1 || d > MPFMT_MAX_DIM) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "d = %d out of range [1,%d]", d, MPFMT_MAX_DIM);
-    if (N > 0 && !X) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "X is NULL");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    for (int i = 0; i < d; ++i) { ctx->bb_lo[i] = INFINITY; ctx->bb_hi[i] = -INFINITY; }
-    for (int64_t p = 0; p < N; ++p)
-        for (int i = 0; i < d; ++i) {
-            const double a = X[p * d + i];
-            if (!std::isfinite(a)) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "sample %lld has a non-finite coordinate", (long long)(p + 1));
-            if (a < ctx->bb_lo[i]) ctx->bb_lo[i] = a;
-            if (a > ctx->bb_hi[i]) ctx->bb_hi[i] = a;
-        }
-    if (N == 0) for (int i = 0; i < d; ++i) { ctx->bb_lo[i] = 0; ctx->bb_hi[i] = 0; }
-    int32_t rc;
-    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->Xo, sizeof(double) * (size_t)N * d))) return rc;
-    ctx->samples_epoch += 1;
-    if (N > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->Xo, X, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->N = N; ctx->d = d;
-    ctx->grid_r = -1.0; ctx->graph_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0;
-    ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
-    ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
-    ctx->nnz = 0;
-    return MPFMT_OK;
-}
-
-// per-block partial bounding boxes of a device-resident sample set + a count of non-finite coordinates (mpfmt_upload_samples_device)
+// per-block partial bounding boxes of a device-resident sample set + a count of non-finite coordinates
 __global__ __launch_bounds__(256) void k_bbox_partials(const double* __restrict__ X, int64_t N, int d, double* __restrict__ part, int32_t* __restrict__ bad)
 {
     __shared__ double s_lo[4][MPFMT_MAX_DIM], s_hi[4][MPFMT_MAX_DIM];
@@ -292,14 +263,15 @@ __global__ __launch_bounds__(256) void k_bbox_partials(const double* __restrict_
     }
 }
 
-// The same as mpfmt_upload_samples for a sample set that already lives in HBM (a batch made on the device: the library's own sampler,
-// a ROCArray, a torch tensor): one device-to-device copy, the bounding box by a reduction on the device, one small read-back.
-int32_t mpfmt_upload_samples_device(mpfmt_ctx* ctx, const double* dX, int64_t N, int32_t d)
+// Both uploads: the copy into the ctx's sample buffer (host-to-device or device-to-device) and, beside it on the same stream, the
+// finiteness check and the bounding box as ONE reduction on the device (a host loop over 6e6 coordinates costs 3 ms -- more than the
+// PCIe copy of them), one small read-back, one synchronisation.  A non-finite coordinate is found after the buffer has been
+// overwritten: the ctx then holds NO sample set -- nothing of the previous one (index, graph, hints) may be served after the error.
+static int32_t adopt_samples(mpfmt_ctx* ctx, const double* src, bool src_on_host, int64_t N, int32_t d)
 {
-    if (!ctx) return MPFMT_ERR_ARG;
     if (N < 0 || N >= ((int64_t)1 << 31) - 64) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "N = %lld out of range", (long long)N);
     if (d < 1 || d > MPFMT_MAX_DIM) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "d = %d out of range [1,%d]", d, MPFMT_MAX_DIM);
-    if (N > 0 && !dX) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "dX is NULL");
+    if (N > 0 && !src) return mpfmt_fail(ctx, MPFMT_ERR_ARG, src_on_host ? "X is NULL" : "dX is NULL");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int32_t rc;
     constexpr int NB = 256;
@@ -310,27 +282,31 @@ int32_t mpfmt_upload_samples_device(mpfmt_ctx* ctx, const double* dX, int64_t N,
     const int nb = (int)std::min<int64_t>(NB, (N + 255) / 256);
     double lo[MPFMT_MAX_DIM], hi[MPFMT_MAX_DIM];
     for (int i = 0; i < d; ++i) { lo[i] = 0.0; hi[i] = 0.0; }
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->Xo, sizeof(double) * (size_t)N * d))) return rc;
     if (N > 0) {
         HIPCHK(ctx, hipMemsetAsync(&dev->bad, 0, sizeof(int32_t), ctx->stream));
-        hipLaunchKernelGGL(k_bbox_partials, dim3(nb), dim3(256), 0, ctx->stream, dX, N, d, &dev->part[0][0][0], &dev->bad);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->Xo, src, sizeof(double) * (size_t)N * d, src_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_bbox_partials, dim3(nb), dim3(256), 0, ctx->stream, ctx->Xo, N, d, &dev->part[0][0][0], &dev->bad);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(ctx->bb_host, dev, sizeof(bb_block), hipMemcpyDeviceToHost, ctx->stream));
     }
-    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->Xo, sizeof(double) * (size_t)N * d))) return rc;
-    if (N > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->Xo, dX, sizeof(double) * (size_t)N * d, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->samples_epoch += 1;
+    ctx->grid_r = -1.0; ctx->graph_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0;
+    ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
+    ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
+    ctx->nnz = 0;
     if (N > 0) {
         const bb_block* h = (const bb_block*)ctx->bb_host;
         if (h->bad) {
-            // Xo has been overwritten beside the check (one synchronisation for both): the ctx holds NO sample set now -- nothing of the
-            // previous one (index, graph, hints) may be served after this error
-            ctx->samples_epoch += 1;
-            ctx->N = 0; ctx->d = d; ctx->ntiles = 0; ctx->nnz = 0;
-            ctx->grid_r = -1.0; ctx->graph_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0;
-            ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
-            ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
+            ctx->N = 0; ctx->d = d; ctx->ntiles = 0;
             ctx->spec_ready = false; ctx->pool_valid = false; ctx->pend_valid = false; ctx->rowpos_valid = false;
             for (int i = 0; i < d; ++i) { ctx->bb_lo[i] = 0.0; ctx->bb_hi[i] = 0.0; }
+            if (src_on_host)                                         // (name the sample, as the host check used to)
+                for (int64_t p = 0; p < N; ++p)
+                    for (int i = 0; i < d; ++i)
+                        if (!std::isfinite(src[p * d + i]))
+                            return mpfmt_fail(ctx, MPFMT_ERR_ARG, "sample %lld has a non-finite coordinate (the ctx now holds no samples)", (long long)(p + 1));
             return mpfmt_fail(ctx, MPFMT_ERR_ARG, "the sample set has a non-finite coordinate (the ctx now holds no samples)");
         }
         for (int i = 0; i < d; ++i) { lo[i] = INFINITY; hi[i] = -INFINITY; }
@@ -338,13 +314,22 @@ int32_t mpfmt_upload_samples_device(mpfmt_ctx* ctx, const double* dX, int64_t N,
             for (int i = 0; i < d; ++i) { lo[i] = std::min(lo[i], h->part[b][0][i]); hi[i] = std::max(hi[i], h->part[b][1][i]); }
     }
     for (int i = 0; i < d; ++i) { ctx->bb_lo[i] = lo[i]; ctx->bb_hi[i] = hi[i]; }
-    ctx->samples_epoch += 1;
     ctx->N = N; ctx->d = d;
-    ctx->grid_r = -1.0; ctx->graph_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0;
-    ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
-    ctx->di_counted = ctx->di_filled = ctx->di_swept = false;
-    ctx->nnz = 0;
     return MPFMT_OK;
+}
+
+int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t d)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    return adopt_samples(ctx, X, true, N, d);
+}
+
+// The same for a sample set that already lives in HBM (a batch made on the device: the library's own sampler, a ROCArray, a torch
+// tensor): one device-to-device copy instead of the PCIe one.
+int32_t mpfmt_upload_samples_device(mpfmt_ctx* ctx, const double* dX, int64_t N, int32_t d)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    return adopt_samples(ctx, dX, false, N, d);
 }
 
 // state-space bounds on their own: the BoundedStateSpace lo / hi for any state dimension (src/statespaces.jl:29-34).  The 2-D SAT
@@ -1649,7 +1634,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
         return MPFMT_OK;
     }
     if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }
-    if (strcmp(name, "wf_pos_space") == 0) { ctx->wf_pos_space = value != 0; return MPFMT_OK; }
+    if (strcmp(name, "wf_pos_space") == 0) { ctx->wf_pos_space = value < 0 ? 0 : (value > 2 ? 2 : (int32_t)value); return MPFMT_OK; }
     if (strcmp(name, "shard_blocks") == 0) { ctx->shard_blocks = value != 0; ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; ctx->cut_key.clear(); return MPFMT_OK; }
     if (strcmp(name, "index_halo") == 0) { ctx->index_halo = value != 0; ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; return MPFMT_OK; }
     if (strcmp(name, "lists_wide") == 0) { ctx->lists_wide = (int32_t)value; ctx->lists_r = -1.0; return MPFMT_OK; }
@@ -1731,6 +1716,7 @@ int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value)
     if (strcmp(name, "slices") == 0) { *value = ctx->S; return MPFMT_OK; }
     if (strcmp(name, "cells") == 0) { *value = ctx->grid.ncells; return MPFMT_OK; }
     if (strcmp(name, "filter_valu") == 0) { *value = ctx->filter_valu ? 1 : 0; return MPFMT_OK; }
+    if (strcmp(name, "wf_pos_space_used") == 0) { *value = ctx->wf_pos_used; return MPFMT_OK; }
     return mpfmt_fail(ctx, MPFMT_ERR_ARG, "unknown stat %s", name);
 }
 

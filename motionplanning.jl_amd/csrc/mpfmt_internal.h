@@ -281,7 +281,10 @@ struct mpfmt_ctx {
     int32_t step_state = 0; double step_r = 0.0;   // graph_step_launch / _finish: 0 none, 1 speculative kernels in flight, 2 complete
     int32_t wf_graphs = 0;               // option (off: measured, no gain -- the solve is bound by k_wf_connect, 3.2 of 5.4 ms, not by launches): replay a captured
                                          // hipGraph of a group of 8 steps instead of launching its ~48 kernels
-    int32_t wf_pos_space = 1;            // option: the device solve gathers its sets by cell-sorted position (0: by caller index -- measurements)
+    int32_t wf_pos_space = 1;            // option: the device solve gathers its sets by cell-sorted position from the second solve on a graph
+                                         // on (0: always by caller index, 2: from the first solve -- measurements, tests)
+    int64_t wf_seen_epoch = -1; double wf_seen_r = -1.0; int64_t wf_seen_nnz = -1;      // the graph the last device solve ran on
+    int32_t wf_pos_used = 0;             // stat: the last device solve gathered by position
     int32_t wf_force_sharded = 0;        // option: run the sharded form of the wavefront step (own-column marking, triples, exchange) at world = 1
     void* wf = nullptr;                  // mpfmt_wf: W / H / C / A and the batch lists of a running wavefront solve
 };

@@ -131,6 +131,20 @@ def test_upload_samples_device_equals_host_upload(orc):
         t = torch.from_numpy(X).to("cuda:0"); torch.cuda.synchronize()
         with pytest.raises(mp.MPFMTError):
             c.upload_samples_device(t.data_ptr(), N, d)
+        # the host upload checks on the device too: the error names the sample (1-based), the ctx then holds none, and a good set
+        # uploaded afterwards is served as if nothing had happened
+        c.upload_boxes(lohi, lo, hi)
+        with pytest.raises(mp.MPFMTError, match="sample 124 "):
+            c.upload_samples(X)
+        assert c.graph_step_device(r) == 0                                       # (an empty sample set: the empty graph)
+        X[123, 1] = 0.5; X[7, 2] = np.inf
+        with pytest.raises(mp.MPFMTError, match="sample 8 "):
+            c.upload_samples(X)
+        X[7, 2] = 0.25
+        c.upload_samples(X); c.graph_step_device(r)
+        oc, orow, oval = orc.rdisc_graph(X, r)
+        colptr, rowval, nzval, free = _resident_graph(c, N)
+        assert np.array_equal(colptr, oc) and np.array_equal(rowval, orow) and np.array_equal(nzval, oval)
 
 
 def test_four_million_samples_step(orc):

@@ -162,6 +162,29 @@ def test_band_solve_equals_oracle_wavefront(ctx, orc, N, d, M, seed):
     assert np.array_equal(got["A"] - 1, ref["A"]) and got["collision_checks"] == ref["collision_checks"]
 
 
+def test_position_space_from_the_second_solve_on_a_graph(orc):
+    """The device solve keeps its sets a second time by cell-sorted position once a graph is solved on AGAIN (the entries' positions cost a
+    pass over the whole graph, which a first -- cold -- solve does not pay): first solve by caller index, later ones by position, a new
+    sample set starts over; options 0 / 2 pin either form.  Every solve equals the oracle's batched loop exactly."""
+    w = world(30000, 6, 150, 21)
+    w2 = world(30000, 6, 150, 22)
+    with mp.Context(0) as c:
+        for opt, want in ((1, (0, 1, 1)), (2, (1, 1, 1)), (0, (0, 0, 0))):
+            c.set_option("wf_pos_space", opt)
+            for wi in (w, w2):
+                upload(c, wi)
+                ref = None
+                for k in range(3):
+                    got = c.fmtstar_wavefront(wi.r, L.GOAL_BALL, wi.goal_params(), band=0.25 * wi.r)
+                    assert c.stat("wf_pos_space_used") == want[k], (opt, k)
+                    if ref is None:
+                        colptr, rowval, nzval = c.graph_export()[:3]
+                        ref = orc.fmt_wavefront_graph(wi.X, colptr - 1, rowval - 1, nzval, None, c.points_free(), orc.GOAL_BALL, wi.goal_params(),
+                                                      wi.lohi, wi.ss_lo, wi.ss_hi, band=0.25 * wi.r)
+                    assert got["status"] == ref["status"] and got["z"] - 1 == ref["z"] and got["collision_checks"] == ref["collision_checks"]
+                    assert np.array_equal(got["A"] - 1, ref["A"]) and np.array_equal(got["C"], ref["C"]) and np.array_equal(got["path"] - 1, ref["path"])
+
+
 def test_wavefront_in_the_sat2d_world(ctx, orc):
     """Checkers without a lane-per-obstacle form answer from the swept mask: same result as the host recursion."""
     rng = np.random.default_rng(3)
