@@ -362,7 +362,7 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail, int64_t mask_
         // preset to ones (blocked entries are cleared); an empty graph keeps one zero word
         HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, ctx->nnz > 0 ? 0xFF : 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
     }
-    if (ctx->nnz == 0 || nt <= 0) { if (recbits) { ctx->graph_swept = true; ctx->sweep_in_order = true; } return MPFMT_OK; }
+    if (ctx->nnz == 0 || nt <= 0) { if ((rc = mpfmt_side_join(ctx))) return rc; if (recbits) { ctx->graph_swept = true; ctx->sweep_in_order = true; } return MPFMT_OK; }
     // option sweep_sorted: also keep every row's cell-sorted position, so the whole sweep can gather from Xs (see kernels_sweep.hip)
     const bool want_rowpos = ctx->sweep_sorted && !pend && !recbits;
     if (want_rowpos && (rc = mpfmt_ensure(ctx, (void**)&ctx->rowpos, sizeof(int32_t) * (size_t)std::max<int64_t>(std::max(ctx->nnz, ctx->nnz_cap), 1)))) return rc;
@@ -396,6 +396,7 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail, int64_t mask_
     a.pend_items = pend ? (uint4*)ctx->pend_items : nullptr; a.pend_wcap = ctx->pend_wcap; a.pend_cnt = ctx->pend_cnt; a.pend_over = ctx->pend_over;
     a.rec_bits = recbits ? 1 : 0;
     a.deg_clear = ctx->world > 1 ? ctx->deg : nullptr;
+    if ((rc = mpfmt_side_join(ctx))) return rc;               // k_exact_pairs' marks (on the side stream since the pair kernel ended)
     hipLaunchKernelGGL(k_order_logs, dim3(nb), dim3(ORD_THREADS), lds, ctx->stream, a);
     HIPCHK(ctx, hipGetLastError());
     if (pend) ctx->pend_nseg = (int)nb;

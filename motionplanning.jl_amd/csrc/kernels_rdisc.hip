@@ -945,6 +945,8 @@ int32_t mpfmt_launch_rdisc_count(mpfmt_ctx* ctx, double r)
 int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
 {
     int32_t rc;
+    if ((rc = mpfmt_side_join(ctx))) return rc;               // (whatever an abandoned build left on the side stream)
+    ctx->masks_early = false;
     if ((rc = mpfmt_build_grid(ctx, r))) return rc;
     const int64_t N = ctx->N;
     // (the shard -- tile_begin, tile_end -- is cut by the index build: mpfmt_build_grid)
@@ -985,6 +987,17 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         // half build: the whole graph on this ctx, through the single-pass logs (decided before the lists, which differ)
         // (a shard does the same for the pairs inside it; its pairs with other shards' samples are found from its own side only)
         half = ctx->use_half && ctx->use_pool && nt > 0 && !too_long_hint && !ctx->pool_skip_once;
+        // the per-sample obstacle masks of the fused broad phase need the tiles only: beside the chunk lists, on the side stream (the
+        // condition is broad_in_drain's below as far as it is known here; masks made for a build that does not use them cost nothing
+        // on this stream)
+        if (ctx->overlap && ctx->want_broad && ctx->use_pool && nt > 0 && !too_long_hint && !ctx->pool_skip_once &&
+            (ctx->d <= 6 || (ctx->d <= 12 && half && ctx->fuse_broad == 2))) {
+            hipStream_t main_s;
+            if ((rc = mpfmt_side_fork(ctx, &main_s))) return rc;
+            const int32_t rc2 = mpfmt_launch_sample_masks(ctx, r);
+            if ((rc = mpfmt_side_back(ctx, main_s)) || (rc = rc2)) return rc;
+            ctx->masks_early = true;
+        }
         if ((rc = mpfmt_mfma_build_lists(ctx, r, &ok, spec, half))) return rc;    // per-tile candidate chunk lists
         tm2.end("grid");
         if (!ok) {
@@ -1135,13 +1148,15 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     // (the degrees by cell-sorted position feed the staging offsets of the two-pass forms only: a single-pass build reads its own positions)
     if (sparse_deg && !pool) HIPCHK(ctx, hipMemsetAsync(ctx->degs, 0, sizeof(int64_t) * (npad + 1), ctx->stream));
     mpfmt_timed tm3(ctx);
+    bool side_count = false;
     if (nt > 0) {
         if (mf) {
             mpfmt_timed tk(ctx);                                   // the pair kernel on its own, inside the "rdisc_count" interval
             if (pool) {
-                if (ctx->broad_in_drain && (rc = mpfmt_launch_sample_masks(ctx, r))) return rc;
+                if (ctx->masks_early) { if ((rc = mpfmt_side_join(ctx))) return rc; }
+                else if (ctx->broad_in_drain && (rc = mpfmt_launch_sample_masks(ctx, r))) return rc;
                 if ((rc = mpfmt_launch_rdisc_mfma<2>(ctx, r, negT))) return rc;
-                if (ctx->bits_in_records && (rc = mpfmt_launch_exact_pairs(ctx, nullptr))) return rc;
+                tk.end("pair_kernel");
             }
             else if ((rc = mpfmt_launch_rdisc_mfma<0>(ctx, r, negT))) return rc;
             tk.end("pair_kernel");
@@ -1153,12 +1168,26 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         }
         const int B = 256;
         const int64_t pb = ctx->tile_begin * 64, pe = ctx->tile_end * 64;
-        if (pool) { if ((rc = mpfmt_launch_log_degrees(ctx))) return rc; }         // single pass: the columns' degrees are counts over the logs' keys
+        if (pool) {
+            // single pass: the columns' degrees are counts over the logs' keys.  The flagged pairs' exact tests (form 2) MARK keys (bit 31,
+            // read by the ordering pass) while the count reads other bits of them: the count and the scan of the degrees go to the side
+            // stream, the tests -- the longer of the two -- stay here; joined before the first reader of colptr
+            side_count = ctx->overlap && ctx->bits_in_records;
+            hipStream_t main_s = nullptr;
+            if (side_count && (rc = mpfmt_side_fork(ctx, &main_s))) return rc;
+            int32_t rc2 = mpfmt_launch_log_degrees(ctx);
+            if (side_count) {
+                if (!rc2) rc2 = scan_i64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1));
+                if ((rc = mpfmt_side_back(ctx, main_s))) return rc;
+            }
+            if (rc2) return rc2;
+            if (ctx->bits_in_records && (rc = mpfmt_launch_exact_pairs(ctx, nullptr))) return rc;
+        }
         else hipLaunchKernelGGL(k_degree, dim3((unsigned)((pe - pb + B - 1) / B)), dim3(B), 0, ctx->stream,
                                 ctx->slice_cnt, ctx->perm, S, npad, pb, pe, ctx->deg, ctx->degs, (int32_t*)(ctx->d_pairs + 512),
                                 (ctx->world > 1 || nt <= 0) ? (int64_t)-1 : N, (int32_t*)(ctx->d_pairs + 513));
     }
-    if ((rc = scan_i64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1)))) return rc;      // columns in original order
+    if (!side_count && (rc = scan_i64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1)))) return rc;      // columns in original order
     // staging offsets in sorted order: only the two-pass forms read them (the single-pass build orders its logs straight into the
     // CSC) -- made here for those, and on demand by mpfmt_launch_rdisc_fill when a single-pass build has to fall back
     ctx->tptr_valid = false;
@@ -1176,6 +1205,7 @@ int32_t mpfmt_rdisc_count_finish(mpfmt_ctx* ctx, double r, bool* spec_failed)
     const bool pool = ctx->cnt_pool;
     const int64_t nt = ctx->tile_end - ctx->tile_begin;
     if (spec_failed) *spec_failed = false;
+    { int32_t rcj; if ((rcj = mpfmt_side_join(ctx))) return rcj; }
     if (!ctx->rb_dev) HIPCHK(ctx, hipMalloc(&ctx->rb_dev, sizeof(count_readback)));
     if (!ctx->rb_host) HIPCHK(ctx, hipHostMalloc(&ctx->rb_host, sizeof(count_readback), hipHostMallocDefault));
     hipLaunchKernelGGL(k_count_readback, dim3(1), dim3(512), 0, ctx->stream, ctx->d_pairs, ctx->colptr + N, pool ? ctx->pool_flag : nullptr,
@@ -1344,6 +1374,7 @@ int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r)
             if ((rc = ensure(ctx, (void**)&ctx->nzval, sizeof(double) * (size_t)cap))) return rc;
             if (!ctx->spec_fail) HIPCHK(ctx, hipMalloc((void**)&ctx->spec_fail, sizeof(int32_t)));
             const int64_t nt = ctx->tile_end - ctx->tile_begin;
+            if ((rc = mpfmt_side_join(ctx))) return rc;             // (the degree count and its scan: colptr)
             hipLaunchKernelGGL(k_spec_check, dim3(1), dim3(1), 0, ctx->stream, ctx->pool_flag,
                                (ctx->spec_lists && nt > 0) ? ctx->list_max : nullptr, ctx->list_cap, ctx->colptr + N, cap,
                                (const int32_t*)(ctx->d_pairs + 512), ctx->spec_fail);

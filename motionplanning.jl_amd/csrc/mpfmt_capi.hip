@@ -91,6 +91,42 @@ static void timer_resolve(mpfmt_ctx* ctx)
     t.pending.clear();
 }
 
+int32_t mpfmt_side_fork(mpfmt_ctx* ctx, hipStream_t* main_out)
+{
+    if (!ctx->side_stream) {
+        // (lowest priority: what runs there is never the longer of the two sides)
+        int prio_lo = 0, prio_hi = 0;
+        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_lo));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    int32_t rc;
+    if ((rc = mpfmt_side_join(ctx))) return rc;               // (one fork at a time)
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+    *main_out = ctx->stream;
+    ctx->stream = ctx->side_stream;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_side_back(mpfmt_ctx* ctx, hipStream_t main)
+{
+    const hipError_t e = hipEventRecord(ctx->ev_join, ctx->side_stream);
+    ctx->stream = main;
+    ctx->side_pending = true;
+    HIPCHK(ctx, e);
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_side_join(mpfmt_ctx* ctx)
+{
+    if (!ctx->side_pending) return MPFMT_OK;
+    ctx->side_pending = false;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return MPFMT_OK;
+}
+
 void mpfmt_time_begin(mpfmt_ctx* ctx)
 {
     if (!ctx->timing_enabled) return;
@@ -201,6 +237,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
     if (ctx->export_arena) hipHostFree(ctx->export_arena);
     if (ctx->bb_host) hipHostFree(ctx->bb_host);
+    if (ctx->side_stream) { hipStreamSynchronize(ctx->side_stream); hipStreamDestroy(ctx->side_stream); hipEventDestroy(ctx->ev_fork); hipEventDestroy(ctx->ev_join); }
     for (int k = 0; k < 2; ++k) { if (ctx->copy_stream[k]) hipStreamDestroy(ctx->copy_stream[k]); if (ctx->ev_conv[k]) hipEventDestroy(ctx->ev_conv[k]); if (ctx->ev_copy[k]) hipEventDestroy(ctx->ev_copy[k]); }
     mpfmt_wf_free(ctx);
     if (ctx->aux) { mpfmt_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
@@ -1634,6 +1671,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
         return MPFMT_OK;
     }
     if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }
+    if (strcmp(name, "overlap") == 0) { ctx->overlap = value != 0; return MPFMT_OK; }
     if (strcmp(name, "wf_pos_space") == 0) { ctx->wf_pos_space = value < 0 ? 0 : (value > 2 ? 2 : (int32_t)value); return MPFMT_OK; }
     if (strcmp(name, "shard_blocks") == 0) { ctx->shard_blocks = value != 0; ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; ctx->cut_key.clear(); return MPFMT_OK; }
     if (strcmp(name, "index_halo") == 0) { ctx->index_halo = value != 0; ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; return MPFMT_OK; }

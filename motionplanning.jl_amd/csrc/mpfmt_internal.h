@@ -82,6 +82,14 @@ struct mpfmt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
+    // A second stream for the two kernels of a step that have nothing to wait for on the first but one predecessor: the per-sample obstacle
+    // masks (beside the chunk lists) and the flagged pairs' exact tests (beside the logs' degree count and its scans).  Forked and joined
+    // with events; side_pending: work is in flight there that ctx->stream has not waited for yet.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_pending = false;
+    bool masks_early = false;            // this build's sample masks were launched beside its chunk lists
+    int32_t overlap = 1;                 // option: 0 keeps every kernel of the step on ctx->stream (measurements)
     hipStream_t copy_stream[2] = {nullptr, nullptr};      // mpfmt_graph_export: two device-to-host streams and their hand-over events
     hipEvent_t ev_conv[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
     void* export_arena = nullptr;        // page-locked host memory of mpfmt_graph_export_pinned (grow-only, lives as long as the ctx)
@@ -315,6 +323,11 @@ struct mpfmt_timed {
     mpfmt_timed(const mpfmt_timed&) = delete;
     mpfmt_timed& operator=(const mpfmt_timed&) = delete;
 };
+
+// mpfmt_capi.hip: the side stream (see mpfmt_ctx::side_stream)
+int32_t mpfmt_side_fork(mpfmt_ctx* ctx, hipStream_t* main_out);      // ctx->stream := the side stream, ordered after everything issued so far
+int32_t mpfmt_side_back(mpfmt_ctx* ctx, hipStream_t main);           // ctx->stream := main again; the side work is pending
+int32_t mpfmt_side_join(mpfmt_ctx* ctx);                             // ctx->stream waits for the pending side work (no-op without)
 
 // kernels_rdisc.hip -----------------------------------------------------------------------------
 int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r, bool whole = false);      // whole: every tile is built even on a sharded ctx
