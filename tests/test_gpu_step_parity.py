@@ -158,6 +158,44 @@ def test_edge_tests_fused_into_the_half_build(orc, form, d, N, r, M):
     if d > 6 and form == 1: assert set(seen) == {0}, seen
 
 
+@pytest.mark.parametrize("d,N,r,M", [(3, 7001, 0.09, 40), (6, 20000, 0.42, 200), (9, 10000, 0.55, 200)])
+def test_step_with_and_without_the_side_stream(orc, d, N, r, M):
+    """The step's two side-stream forks (sample masks beside the chunk lists; degree count and scan beside the flagged pairs' exact
+    tests) against the same step with every kernel on one stream (option overlap = 0) and against the oracle: careful step, speculative
+    repeats, new samples, on the ctx's own stream and on a caller's."""
+    import torch
+    rng = np.random.default_rng(6000 + d)
+    X, lohi = random_world(rng, N, d, M, 0.05, 0.25)
+    lo, hi = np.full(d, 0.0), np.full(d, 1.0)
+    X2 = rng.random((N, d))
+    user = torch.cuda.Stream(device="cuda:0")
+    got = {}
+    for ov, st in ((1, None), (0, None), (1, user)):
+        with mp.Context(0) as c:
+            c.set_option("overlap", ov); c.set_option("rebuild_index", 1)
+            if st is not None: c.set_stream(st.cuda_stream)
+            outs = []
+            for Xi in (X, X, X2, X2, X):
+                c.upload_samples(Xi); c.upload_boxes(lohi, lo, hi)
+                c.graph_step_device(r)
+                assert c.stat("sweep_form") == 2 and c.stat("rdisc_half_used") == 1
+                outs.append(_resident_graph(c, N))
+            got[(ov, st is not None)] = outs
+    for k in range(5):
+        for key in ((0, False), (1, True)):
+            for u, v in zip(got[(1, False)][k], got[key][k]):
+                assert np.array_equal(u, v)
+    for k, Xi in ((0, X), (2, X2)):
+        kg = (d, N, r, Xi is X)
+        if kg not in _ORACLE_GRAPHS: _ORACLE_GRAPHS[kg] = orc.rdisc_graph(Xi, r)
+        oc, orow, oval = _ORACLE_GRAPHS[kg]
+        km = kg + (True,)
+        if km not in _ORACLE_MASKS: _ORACLE_MASKS[km] = orc.graph_edges_free(Xi, oc, orow, lohi, lo, hi)
+        colptr, rowval, nzval, free = got[(1, False)][k]
+        assert np.array_equal(colptr, oc) and np.array_equal(rowval, orow) and np.array_equal(nzval, oval)
+        assert np.array_equal(free.view(np.uint64), _ORACLE_MASKS[km])
+
+
 @pytest.mark.parametrize("form", [2, 1])
 def test_fused_edge_tests_among_many_overlapping_obstacles(orc, form):
     """256 large boxes (the last id is 255, the most the packed per-lane lists can name): most segments meet more than four of them,
