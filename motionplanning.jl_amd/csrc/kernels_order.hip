@@ -346,6 +346,18 @@ __global__ __launch_bounds__(ORD_THREADS) __attribute__((amdgpu_waves_per_eu(ORD
     }
 }
 
+// The mask of a speculative step preset ahead of the ordering pass (entries = the trusted capacity): issued on the side stream beside the
+// exact pair tests instead of between them and the ordering kernel.  mpfmt_order_logs recognises it by its word count.
+int32_t mpfmt_mask_preset(mpfmt_ctx* ctx, int64_t entries)
+{
+    int32_t rc;
+    const int64_t words = (entries + 63) / 64;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->graph_free, sizeof(uint64_t) * (size_t)(words + 1)))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, 0xFF, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
+    ctx->mask_preset_words = words;
+    return MPFMT_OK;
+}
+
 // order the logs of the counted graph into the CSC (mask_entries: entries the mask is sized for, as in mpfmt_launch_graph_sweep)
 int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail, int64_t mask_entries)
 {
@@ -360,8 +372,10 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail, int64_t mask_
         const int64_t words_alloc = (std::max<int64_t>((int64_t)((double)ctx->nnz * 1.02) + 4096, mask_entries) + 63) / 64 + 1;
         if ((rc = mpfmt_ensure(ctx, (void**)&ctx->graph_free, sizeof(uint64_t) * (size_t)words_alloc))) return rc;
         // preset to ones (blocked entries are cleared); an empty graph keeps one zero word
-        HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, ctx->nnz > 0 ? 0xFF : 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
+        if (!(ctx->mask_preset_words == words && ctx->nnz > 0))
+            HIPCHK(ctx, hipMemsetAsync(ctx->graph_free, ctx->nnz > 0 ? 0xFF : 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(words, 1), ctx->stream));
     }
+    ctx->mask_preset_words = -1;
     if (ctx->nnz == 0 || nt <= 0) { if ((rc = mpfmt_side_join(ctx))) return rc; if (recbits) { ctx->graph_swept = true; ctx->sweep_in_order = true; } return MPFMT_OK; }
     // option sweep_sorted: also keep every row's cell-sorted position, so the whole sweep can gather from Xs (see kernels_sweep.hip)
     const bool want_rowpos = ctx->sweep_sorted && !pend && !recbits;

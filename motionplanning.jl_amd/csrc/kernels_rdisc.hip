@@ -952,6 +952,36 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     // (the shard -- tile_begin, tile_end -- is cut by the index build: mpfmt_build_grid)
     const int64_t nt = ctx->tile_end - ctx->tile_begin;
 
+    // The small per-build counters live in ONE arena zeroed by ONE fill (VERDICT r2 item 7): 512 pair counters + the longest column's
+    // word (k_degree), the logs' overflow flag, the pending-pair list's region counters + its overflow flag.  (A ctx whose counters
+    // were allocated one by one before -- by the steering spaces' builds -- keeps them and their separate fills.)
+    // (... and the quarter logs' cursors behind them)
+    // The fill is issued beside the chunk lists when the step forks there (a fill between two kernels of one stream costs ~15 us of
+    // dispatch gaps on top of its 3), else in front of the pair kernel.
+    constexpr size_t ZA_PAIRS = 0, ZA_FLAG = 4128, ZA_PCNT = 4160, ZA_QLEN = 4160 + 4112, ZA_BYTES = ZA_QLEN;
+    const size_t za_need = ZA_BYTES + sizeof(int32_t) * (size_t)std::max<int64_t>(nt * 4, 1);
+    bool counters_zeroed = false;
+    auto zero_counters = [&]() -> int32_t {
+        if ((!ctx->zarena && !ctx->d_pairs && !ctx->pool_flag && !ctx->pair_cnt && !ctx->qlen) || (ctx->zarena && ctx->zarena_bytes < za_need)) {
+            if (ctx->zarena) HIPCHK(ctx, hipFree(ctx->zarena));
+            ctx->zarena = nullptr;
+            HIPCHK(ctx, hipMalloc((void**)&ctx->zarena, za_need));
+            ctx->zarena_bytes = za_need;
+            ctx->d_pairs = (unsigned long long*)((char*)ctx->zarena + ZA_PAIRS);
+            ctx->pool_flag = (int32_t*)((char*)ctx->zarena + ZA_FLAG);
+            ctx->pair_cnt = (int32_t*)((char*)ctx->zarena + ZA_PCNT);
+            ctx->qlen = (int32_t*)((char*)ctx->zarena + ZA_QLEN);
+        }
+        if (ctx->zarena) {
+            HIPCHK(ctx, hipMemsetAsync(ctx->zarena, 0, za_need, ctx->stream));
+        } else {
+            if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 514 * sizeof(unsigned long long)));
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 514 * sizeof(unsigned long long), ctx->stream));
+        }
+        counters_zeroed = true;
+        return MPFMT_OK;
+    };
+
     // the last build of the same (N, r, shard) met a column longer than the ordering kernel stages: the logs would be written for
     // nothing (every such build ends in the fill pass), so the two-pass form is taken at once -- until a build reports a shorter
     // longest column again (k_degree measures it in every form)
@@ -994,7 +1024,8 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             (ctx->d <= 6 || (ctx->d <= 12 && half && ctx->fuse_broad == 2))) {
             hipStream_t main_s;
             if ((rc = mpfmt_side_fork(ctx, &main_s))) return rc;
-            const int32_t rc2 = mpfmt_launch_sample_masks(ctx, r);
+            int32_t rc2 = mpfmt_launch_sample_masks(ctx, r);
+            if (!rc2 && ctx->zarena && ctx->zarena_bytes >= za_need) rc2 = zero_counters();      // (an arena in place: nothing is freed under the lists)
             if ((rc = mpfmt_side_back(ctx, main_s)) || (rc = rc2)) return rc;
             ctx->masks_early = true;
         }
@@ -1019,28 +1050,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     if ((rc = ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (N + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->degs, sizeof(int64_t) * (npad + 1)))) return rc;
     if ((rc = ensure(ctx, (void**)&ctx->tptr, sizeof(int64_t) * (npad + 1)))) return rc;
-    // The small per-build counters live in ONE arena zeroed by ONE fill (VERDICT r2 item 7): 512 pair counters + the longest column's
-    // word (k_degree), the logs' overflow flag, the pending-pair list's region counters + its overflow flag.  (A ctx whose counters
-    // were allocated one by one before -- by the steering spaces' builds -- keeps them and their separate fills.)
-    // (... and the quarter logs' cursors behind them)
-    constexpr size_t ZA_PAIRS = 0, ZA_FLAG = 4128, ZA_PCNT = 4160, ZA_QLEN = 4160 + 4112, ZA_BYTES = ZA_QLEN;
-    const size_t za_need = ZA_BYTES + sizeof(int32_t) * (size_t)std::max<int64_t>(nt * 4, 1);
-    if ((!ctx->zarena && !ctx->d_pairs && !ctx->pool_flag && !ctx->pair_cnt && !ctx->qlen) || (ctx->zarena && ctx->zarena_bytes < za_need)) {
-        if (ctx->zarena) HIPCHK(ctx, hipFree(ctx->zarena));
-        ctx->zarena = nullptr;
-        HIPCHK(ctx, hipMalloc((void**)&ctx->zarena, za_need));
-        ctx->zarena_bytes = za_need;
-        ctx->d_pairs = (unsigned long long*)((char*)ctx->zarena + ZA_PAIRS);
-        ctx->pool_flag = (int32_t*)((char*)ctx->zarena + ZA_FLAG);
-        ctx->pair_cnt = (int32_t*)((char*)ctx->zarena + ZA_PCNT);
-        ctx->qlen = (int32_t*)((char*)ctx->zarena + ZA_QLEN);
-    }
-    if (ctx->zarena) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->zarena, 0, za_need, ctx->stream));
-    } else {
-        if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 514 * sizeof(unsigned long long)));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 514 * sizeof(unsigned long long), ctx->stream));
-    }
+    if (!counters_zeroed && (rc = zero_counters())) return rc;
     const bool sparse_deg = ctx->world > 1 || nt <= 0;         // (unsharded: the degree kernels write every entry, the scans' extra last ones too)
     if (sparse_deg) {
         // a shard's degree kernel visits its own positions only: everything else must read zero.  The ordering pass puts the zeros
@@ -1178,6 +1188,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             int32_t rc2 = mpfmt_launch_log_degrees(ctx);
             if (side_count) {
                 if (!rc2) rc2 = scan_i64(ctx, ctx->deg, ctx->colptr, (size_t)(N + 1));
+                if (!rc2 && ctx->preset_entries > 0) rc2 = mpfmt_mask_preset(ctx, ctx->preset_entries);
                 if ((rc = mpfmt_side_back(ctx, main_s))) return rc;
             }
             if (rc2) return rc2;
@@ -1367,17 +1378,21 @@ int32_t mpfmt_graph_step_launch_impl(mpfmt_ctx* ctx, double r)
     const bool spec = ctx->spec_ready && ctx->use_pool && ctx->pool_hint_N == N && ctx->pool_hint_r == r && ctx->pool_hint_rank == ctx->rank &&
                       ctx->pool_hint_world == ctx->world && ctx->pool_hint_nnz > 0 && ctx->cc_kind == 0 && ctx->have_boxes && ctx->dw == ctx->d;
     if (spec) {
-        if ((rc = mpfmt_rdisc_count_launch(ctx, r, true))) return rc;
+        const int64_t cap = (int64_t)((double)ctx->pool_hint_nnz * 1.02) + 4096;
+        ctx->preset_entries = cap; ctx->mask_preset_words = -1;
+        rc = mpfmt_rdisc_count_launch(ctx, r, true);
+        ctx->preset_entries = -1;
+        if (rc) return rc;
         if (ctx->cnt_mf && ctx->cnt_pool) {
-            const int64_t cap = (int64_t)((double)ctx->pool_hint_nnz * 1.02) + 4096;
             if ((rc = ensure(ctx, (void**)&ctx->rowval, sizeof(int32_t) * (size_t)cap))) return rc;
             if ((rc = ensure(ctx, (void**)&ctx->nzval, sizeof(double) * (size_t)cap))) return rc;
             if (!ctx->spec_fail) HIPCHK(ctx, hipMalloc((void**)&ctx->spec_fail, sizeof(int32_t)));
             const int64_t nt = ctx->tile_end - ctx->tile_begin;
-            if ((rc = mpfmt_side_join(ctx))) return rc;             // (the degree count and its scan: colptr)
-            hipLaunchKernelGGL(k_spec_check, dim3(1), dim3(1), 0, ctx->stream, ctx->pool_flag,
+            // (behind the degree count and its scan -- colptr -- on whichever stream they ran; the join then covers the check too)
+            hipLaunchKernelGGL(k_spec_check, dim3(1), dim3(1), 0, ctx->side_pending ? ctx->side_stream : ctx->stream, ctx->pool_flag,
                                (ctx->spec_lists && nt > 0) ? ctx->list_max : nullptr, ctx->list_cap, ctx->colptr + N, cap,
                                (const int32_t*)(ctx->d_pairs + 512), ctx->spec_fail);
+            if (ctx->side_pending) HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
             ctx->nnz = ctx->pool_hint_nnz;                          // provisional: replaced by the count's own value in _finish
             ctx->nnz_cap = cap;
             ctx->pool_valid = true; ctx->rdisc_path_used = 2;

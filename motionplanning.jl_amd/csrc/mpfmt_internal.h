@@ -88,6 +88,8 @@ struct mpfmt_ctx {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_pending = false;
+    int64_t preset_entries = -1;         // speculative step: the mask's trusted capacity, for the preset beside the exact pair tests
+    int64_t mask_preset_words = -1;      // words of graph_free preset to ones ahead of mpfmt_order_logs (-1: none)
     bool masks_early = false;            // this build's sample masks were launched beside its chunk lists
     int32_t overlap = 1;                 // option: 0 keeps every kernel of the step on ctx->stream (measurements)
     hipStream_t copy_stream[2] = {nullptr, nullptr};      // mpfmt_graph_export: two device-to-host streams and their hand-over events
@@ -342,6 +344,7 @@ int32_t mpfmt_mfma_prepare(mpfmt_ctx* ctx, double r, float* negT_out, bool* usab
 int32_t mpfmt_mfma_build_operands(mpfmt_ctx* ctx);
 template <int MODE> int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT);
 int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail = nullptr, int64_t mask_entries = -1);      // kernels_order.hip
+int32_t mpfmt_mask_preset(mpfmt_ctx* ctx, int64_t entries);
 int32_t mpfmt_sweep_prepare_ss(mpfmt_ctx* ctx);          // kernels_sweep.hip: device copy of the state-space bounds + the all-samples-inside flag
 #define MPFMT_ORD_MAXDEG 2048        // longest column the log-ordering kernel stages in LDS (ORD_STG in kernels_order.hip)
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false, bool half = false);

@@ -186,14 +186,20 @@ def test_step_with_and_without_the_side_stream(orc, d, N, r, M):
             for u, v in zip(got[(1, False)][k], got[key][k]):
                 assert np.array_equal(u, v)
     for k, Xi in ((0, X), (2, X2)):
-        kg = (d, N, r, Xi is X)
-        if kg not in _ORACLE_GRAPHS: _ORACLE_GRAPHS[kg] = orc.rdisc_graph(Xi, r)
-        oc, orow, oval = _ORACLE_GRAPHS[kg]
-        km = kg + (True,)
-        if km not in _ORACLE_MASKS: _ORACLE_MASKS[km] = orc.graph_edges_free(Xi, oc, orow, lohi, lo, hi)
+        # (X and lohi are the fused test's first world -- same seed --, its oracle results are shared; X2 is this test's own)
+        kg = (d, N, r, True) if Xi is X else None
+        if kg is None: oc, orow, oval = orc.rdisc_graph(Xi, r)
+        else:
+            if kg not in _ORACLE_GRAPHS: _ORACLE_GRAPHS[kg] = orc.rdisc_graph(Xi, r)
+            oc, orow, oval = _ORACLE_GRAPHS[kg]
+        if kg is None: omask = orc.graph_edges_free(Xi, oc, orow, lohi, lo, hi)
+        else:
+            km = kg + (True,)
+            if km not in _ORACLE_MASKS: _ORACLE_MASKS[km] = orc.graph_edges_free(Xi, oc, orow, lohi, lo, hi)
+            omask = _ORACLE_MASKS[km]
         colptr, rowval, nzval, free = got[(1, False)][k]
         assert np.array_equal(colptr, oc) and np.array_equal(rowval, orow) and np.array_equal(nzval, oval)
-        assert np.array_equal(free.view(np.uint64), _ORACLE_MASKS[km])
+        assert np.array_equal(free.view(np.uint64), omask)
 
 
 @pytest.mark.parametrize("form", [2, 1])
