@@ -273,30 +273,40 @@ int32_t mpfmt_set_shard(mpfmt_ctx* ctx, int32_t rank, int32_t world)
     return MPFMT_OK;
 }
 
-// per-block partial bounding boxes of a device-resident sample set + a count of non-finite coordinates
-__global__ __launch_bounds__(256) void k_bbox_partials(const double* __restrict__ X, int64_t N, int d, double* __restrict__ part, int32_t* __restrict__ bad)
+// per-block partial bounding boxes of a device-resident sample set + a count of non-finite coordinates; with dst the same pass is the
+// copy into the ctx's sample buffer (thread = one coordinate: coalesced whatever d is; the box per axis needs d | the stride, so a
+// thread's coordinates are those of ONE axis when the block's stride is a multiple of d -- the launch rounds it)
+#define BBOX_THREADS 1024
+__global__ __launch_bounds__(BBOX_THREADS) void k_bbox_partials(const double* __restrict__ X, double* __restrict__ dst, int64_t N, int d, int64_t stride,
+                                                                double* __restrict__ part, int32_t* __restrict__ bad)
 {
-    __shared__ double s_lo[4][MPFMT_MAX_DIM], s_hi[4][MPFMT_MAX_DIM];
-    double lo[MPFMT_MAX_DIM], hi[MPFMT_MAX_DIM];
-    for (int i = 0; i < MPFMT_MAX_DIM; ++i) { lo[i] = INFINITY; hi[i] = -INFINITY; }
+    __shared__ double s_lo[MPFMT_MAX_DIM], s_hi[MPFMT_MAX_DIM];
+    __shared__ unsigned long long s_lob[MPFMT_MAX_DIM], s_hib[MPFMT_MAX_DIM];
+    (void)s_lo; (void)s_hi;
+    // total order of doubles as unsigned integers (sign flip), so that the per-axis minimum / maximum are LDS atomics
+    auto enc = [](double a) -> unsigned long long { const unsigned long long u = (unsigned long long)__double_as_longlong(a); return (u >> 63) ? ~u : (u | 0x8000000000000000ull); };
+    auto dec = [](unsigned long long e) -> double { const unsigned long long u = (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e; return __longlong_as_double((long long)u); };
+    if (threadIdx.x < MPFMT_MAX_DIM) { s_lob[threadIdx.x] = ~0ull; s_hib[threadIdx.x] = 0ull; }
+    __syncthreads();
+    const int64_t total = N * d;
+    // stride (a multiple of d) coordinates apart: this thread's coordinates all belong to axis (first index) mod d
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int axis = (int)(first % d);
+    double lo = INFINITY, hi = -INFINITY;
     int nbad = 0;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x)
-        for (int i = 0; i < d; ++i) {
-            const double a = X[p * d + i];
-            if (!(fabs(a) <= 1.7976931348623157e308)) ++nbad;
-            lo[i] = fmin(lo[i], a); hi[i] = fmax(hi[i], a);
-        }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = 0; i < d; ++i) {
-        for (int off = 32; off > 0; off >>= 1) { lo[i] = fmin(lo[i], __shfl_xor(lo[i], off)); hi[i] = fmax(hi[i], __shfl_xor(hi[i], off)); }
-        if (lane == 0) { s_lo[wave][i] = lo[i]; s_hi[wave][i] = hi[i]; }
+    for (int64_t t = (first < stride) ? first : total; t < total; t += stride) {
+        const double a = X[t];
+        if (dst) dst[t] = a;
+        if (!(fabs(a) <= 1.7976931348623157e308)) ++nbad;
+        lo = fmin(lo, a); hi = fmax(hi, a);
     }
-    if (__ballot(nbad != 0) && lane == 0) atomicAdd(bad, 1);
+    if (lo <= hi) { atomicMin(&s_lob[axis], enc(lo)); atomicMax(&s_hib[axis], enc(hi)); }
+    if (__ballot(nbad != 0) && (threadIdx.x & 63) == 0) atomicAdd(bad, 1);
     __syncthreads();
     if (threadIdx.x < d) {
         const int i = threadIdx.x;
-        part[((int64_t)blockIdx.x * 2 + 0) * MPFMT_MAX_DIM + i] = fmin(fmin(s_lo[0][i], s_lo[1][i]), fmin(s_lo[2][i], s_lo[3][i]));
-        part[((int64_t)blockIdx.x * 2 + 1) * MPFMT_MAX_DIM + i] = fmax(fmax(s_hi[0][i], s_hi[1][i]), fmax(s_hi[2][i], s_hi[3][i]));
+        part[((int64_t)blockIdx.x * 2 + 0) * MPFMT_MAX_DIM + i] = (s_lob[i] == ~0ull) ? INFINITY : dec(s_lob[i]);
+        part[((int64_t)blockIdx.x * 2 + 1) * MPFMT_MAX_DIM + i] = (s_hib[i] == 0ull) ? -INFINITY : dec(s_hib[i]);
     }
 }
 
@@ -316,14 +326,18 @@ static int32_t adopt_samples(mpfmt_ctx* ctx, const double* src, bool src_on_host
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->bb_dev, sizeof(bb_block)))) return rc;
     if (!ctx->bb_host) HIPCHK(ctx, hipHostMalloc(&ctx->bb_host, sizeof(bb_block), hipHostMallocDefault));
     bb_block* dev = (bb_block*)ctx->bb_dev;
-    const int nb = (int)std::min<int64_t>(NB, (N + 255) / 256);
+    // blocks x threads rounded up to a multiple of d: a thread then stays on one axis (k_bbox_partials)
+    const int nb = (int)std::min<int64_t>(NB, (N * d + BBOX_THREADS - 1) / BBOX_THREADS);
+    const int64_t stride = std::max<int64_t>(((int64_t)std::max(nb, 1) * BBOX_THREADS / d) * d, d);      // (rounded DOWN: every residue below it has a thread)
     double lo[MPFMT_MAX_DIM], hi[MPFMT_MAX_DIM];
     for (int i = 0; i < d; ++i) { lo[i] = 0.0; hi[i] = 0.0; }
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->Xo, sizeof(double) * (size_t)N * d))) return rc;
     if (N > 0) {
         HIPCHK(ctx, hipMemsetAsync(&dev->bad, 0, sizeof(int32_t), ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->Xo, src, sizeof(double) * (size_t)N * d, src_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_bbox_partials, dim3(nb), dim3(256), 0, ctx->stream, ctx->Xo, N, d, &dev->part[0][0][0], &dev->bad);
+        // host samples: the PCIe copy, then the reduction over the copy; device samples: the reduction IS the copy
+        if (src_on_host) HIPCHK(ctx, hipMemcpyAsync(ctx->Xo, src, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_bbox_partials, dim3(nb), dim3(BBOX_THREADS), 0, ctx->stream, src_on_host ? (const double*)ctx->Xo : src, src_on_host ? (double*)nullptr : ctx->Xo,
+                           N, d, stride, &dev->part[0][0][0], &dev->bad);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(ctx->bb_host, dev, sizeof(bb_block), hipMemcpyDeviceToHost, ctx->stream));
     }
