@@ -1024,8 +1024,8 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             (ctx->d <= 6 || (ctx->d <= 12 && half && ctx->fuse_broad == 2))) {
             hipStream_t main_s;
             if ((rc = mpfmt_side_fork(ctx, &main_s))) return rc;
-            int32_t rc2 = mpfmt_launch_sample_masks(ctx, r);
-            if (!rc2 && ctx->zarena && ctx->zarena_bytes >= za_need) rc2 = zero_counters();      // (an arena in place: nothing is freed under the lists)
+            int32_t rc2 = (ctx->zarena && ctx->zarena_bytes >= za_need) ? zero_counters() : MPFMT_OK;      // (an arena in place: nothing is freed under the lists)
+            if (!rc2) rc2 = mpfmt_launch_sample_masks(ctx, r);
             if ((rc = mpfmt_side_back(ctx, main_s)) || (rc = rc2)) return rc;
             ctx->masks_early = true;
         }
