@@ -1157,14 +1157,15 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     ctx->pend_valid = false;
     // (the degrees by cell-sorted position feed the staging offsets of the two-pass forms only: a single-pass build reads its own positions)
     if (sparse_deg && !pool) HIPCHK(ctx, hipMemsetAsync(ctx->degs, 0, sizeof(int64_t) * (npad + 1), ctx->stream));
+    // (whatever went beside the chunk lists -- sample masks, the counters' fill -- is waited for by every form of the pair kernel)
+    if (ctx->masks_early && (rc = mpfmt_side_join(ctx))) return rc;
     mpfmt_timed tm3(ctx);
     bool side_count = false;
     if (nt > 0) {
         if (mf) {
             mpfmt_timed tk(ctx);                                   // the pair kernel on its own, inside the "rdisc_count" interval
             if (pool) {
-                if (ctx->masks_early) { if ((rc = mpfmt_side_join(ctx))) return rc; }
-                else if (ctx->broad_in_drain && (rc = mpfmt_launch_sample_masks(ctx, r))) return rc;
+                if (!ctx->masks_early && ctx->broad_in_drain && (rc = mpfmt_launch_sample_masks(ctx, r))) return rc;
                 if ((rc = mpfmt_launch_rdisc_mfma<2>(ctx, r, negT))) return rc;
                 tk.end("pair_kernel");
             }
