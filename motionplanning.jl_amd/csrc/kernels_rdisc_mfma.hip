@@ -58,7 +58,12 @@ struct mf_args {
     int32_t S;
     int32_t xcd_mode;               // item -> XCD placement: 0 contiguous range per XCD, 1 round robin, >=2 interleaved groups of that many items
     int64_t blk_begin;              // first 256-query block of the shard
-    int64_t nitems;                 // blocks * S
+    int64_t nitems;                 // tiles x slices (items_head + the tail tiles x S_tail)
+    // The LAST tiles of the launch are cut into more, shorter items (single-pass build): blocks are dispatched in item order, so the
+    // kernel ends when the last-dispatched items end -- with every other wave slot already idle for up to an item's duration (~150 us
+    // of a 1.7 ms launch at three slices per tile; measured by launching the kernel in two parts: +140 us at a 90 % split).
+    int64_t items_head;             // items of the tiles cut into S slices; the tiles after them are cut into S_tail
+    int32_t S_tail;
     int64_t npad;
     int64_t ntiles;
     int32_t* slice_cnt;             // [S][npad]
@@ -518,8 +523,11 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         item = ((k / gsz) * NXCD + x) * gsz + (k % gsz);
     }
     if (item >= a.nitems) return;
-    const int64_t tile = a.blk_begin + item / a.S;
-    const int slice = (int)(item % a.S);                    // (S is odd: mpfmt_slices_for)
+    const bool tail_item = item >= a.items_head;
+    const int Scur = tail_item ? a.S_tail : a.S;             // (odd: mpfmt_slices_for)
+    const int64_t irel = tail_item ? item - a.items_head : item;
+    const int64_t tile = a.blk_begin + (tail_item ? a.items_head / a.S : 0) + irel / Scur;
+    const int slice = (int)(irel % Scur);
     const int64_t qpos = tile * 64 + lane;
     const int kb = lane >> 5, col = lane & 31;
 
@@ -1083,7 +1091,7 @@ __device__ __forceinline__ void rdisc_mfma_body(mf_args a, mpfmt_grid G)
         // h a multiplicative hash of j.  Every slice sees the same near/far mix of chunks, and -- unlike a plain k mod S --
         // a periodic structure in the list (rows of the cell grid are ~3 chunks each) cannot line its hits up in one
         // slice (seen: 90 of a column's 155 hits in one of 16 slices, overflowing that slot list on every build).
-        const int S = a.S;
+        const int S = Scur;
         const int64_t full = len / S;
         const int rem = (int)(len - full * S);
         auto off = [&](int64_t j) -> int { return (int)(((uint32_t)slice + (((uint32_t)j * 2654435761u) >> 24)) % (uint32_t)S); };
@@ -1362,6 +1370,15 @@ int32_t mpfmt_launch_rdisc_mfma(mpfmt_ctx* ctx, double r, float negT)
     a.S = ctx->S;
     a.blk_begin = ctx->tile_begin;                             // first tile of the shard
     a.nitems = (ctx->tile_end - ctx->tile_begin) * ctx->S;
+    a.items_head = a.nitems; a.S_tail = ctx->S;
+    if (MODE == 2 && ctx->mf_tail_slices > ctx->S && ctx->mf_tail_permille > 0 && a.nitems >= ctx->mf_tail_min_items) {
+        // (the per-slice arrays of the other modes are laid out for S slices: only the single-pass build, which has none, cuts its tail finer)
+        const int64_t nt_all = ctx->tile_end - ctx->tile_begin;
+        const int64_t tail_tiles = std::min<int64_t>(nt_all, nt_all * ctx->mf_tail_permille / 1000);
+        a.items_head = (nt_all - tail_tiles) * ctx->S;
+        a.S_tail = ctx->mf_tail_slices | 1;
+        a.nitems = a.items_head + tail_tiles * a.S_tail;
+    }
     // (small groups spread a small launch evenly; large ones keep neighbouring tiles -- which read the same candidate chunks -- on one L2)
     a.xcd_mode = ctx->mf_xcd_mode >= 0 ? ctx->mf_xcd_mode : (a.nitems >= 32768 ? 256 : 64);
     a.npad = ctx->ntiles * 64; a.ntiles = ctx->ntiles;

@@ -162,7 +162,7 @@ def test_edge_tests_fused_into_the_half_build(orc, form, d, N, r, M):
 def test_step_with_and_without_the_side_stream(orc, d, N, r, M):
     """The step's two side-stream forks (sample masks beside the chunk lists; degree count and scan beside the flagged pairs' exact
     tests) against the same step with every kernel on one stream (option overlap = 0) and against the oracle: careful step, speculative
-    repeats, new samples, on the ctx's own stream and on a caller's."""
+    repeats, new samples, on the ctx's own stream and on a caller's; and with the launch's last tiles cut into more slices than the rest."""
     import torch
     rng = np.random.default_rng(6000 + d)
     X, lohi = random_world(rng, N, d, M, 0.05, 0.25)
@@ -170,9 +170,11 @@ def test_step_with_and_without_the_side_stream(orc, d, N, r, M):
     X2 = rng.random((N, d))
     user = torch.cuda.Stream(device="cuda:0")
     got = {}
-    for ov, st in ((1, None), (0, None), (1, user)):
+    for ov, st in ((1, None), (0, None), (1, user), (2, None)):
         with mp.Context(0) as c:
-            c.set_option("overlap", ov); c.set_option("rebuild_index", 1)
+            c.set_option("overlap", min(ov, 1)); c.set_option("rebuild_index", 1)
+            if ov == 2:           # the last third of the tiles cut into 7 slices instead of the launch's own (forced: these launches are small)
+                c.set_option("mf_tail_min_items", 0); c.set_option("mf_tail_permille", 333); c.set_option("mf_tail_slices", 7)
             if st is not None: c.set_stream(st.cuda_stream)
             outs = []
             for Xi in (X, X, X2, X2, X):
@@ -182,7 +184,7 @@ def test_step_with_and_without_the_side_stream(orc, d, N, r, M):
                 outs.append(_resident_graph(c, N))
             got[(ov, st is not None)] = outs
     for k in range(5):
-        for key in ((0, False), (1, True)):
+        for key in ((0, False), (1, True), (2, False)):
             for u, v in zip(got[(1, False)][k], got[key][k]):
                 assert np.array_equal(u, v)
     for k, Xi in ((0, X), (2, X2)):
