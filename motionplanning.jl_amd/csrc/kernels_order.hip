@@ -51,7 +51,7 @@ struct ord_shared {
     uint32_t cnt[ORD_COLS][ORD_NB / 2];   // records per (column, bucket)
     uint32_t cur[ORD_COLS][ORD_NB / 2];   // next staging position of each (column, bucket); after the placement: the bucket's end
     ord_hdr h[2];                    // headers of the quarter in work and of the next one (prefetched)
-    int32_t g1, pcount, pad_[2];     // pcount: pending-entry items this workgroup has appended
+    int32_t g1, pcount, nextk, pad_; // pcount: pending-entry items this workgroup has appended; nextk: the draw for the quarter after next
     uint32_t bits[ORD_STG / 32];     // free bit of every staged entry, by rank position (blocked bits out of the keys)
 };
 
@@ -82,8 +82,15 @@ struct ord_args {
     uint4* pend_items; int64_t pend_wcap; int32_t* pend_cnt; int32_t* pend_over;
     int64_t* deg_clear;          // sharded ctx: the degree array by sample index, whose entries of this shard are put back to zero here
     int rec_bits;                // k_exact_pairs has marked the keys of blocked edges (bit 31): their entries' bits are cleared in the mask
+    int32_t* qctr;               // [8] (zeroed per launch) or nullptr: counters the workgroups draw their quarters from, one per XCD
 };
 
+// Which quarters a workgroup takes: its first two by its index (b, b + nb), every further one from a COUNTER (one per XCD -- a counter
+// takes ~90 atomics per microsecond, the launch draws 62 500 quarters in 0.7 ms -- XCD x handing out the quarters = x mod 8 in order).
+// With a fixed share (every nb-th quarter) the four workgroups of a CU finish 570 / 650 / 760 / 880 us after the launch although their
+// shares are equal: the wave scheduler serves the oldest wavefronts first, so the CU's first workgroup runs ahead, and the last one ends
+// alone on a CU whose other slots are idle (measured with the device clock at entry and exit of every workgroup).  Drawn from a counter,
+// the quarters go to whoever is done.
 // Persistent workgroups, software pipelined: a quarter on its own is a chain of dependent round trips (perm -> colptr, degrees ->
 // log length -> records -> LDS -> stores), and with 3 workgroups per CU nothing covers them.  So while a workgroup writes quarter q out
 // of LDS, the records of its next quarter are already on their way into registers, and the header of that quarter was requested a
@@ -159,6 +166,8 @@ __global__ __launch_bounds__(ORD_THREADS) __attribute__((amdgpu_waves_per_eu(ORD
 
     if (tid == 0) sh.pcount = 0;
     int64_t qi = blockIdx.x;
+    int64_t qn = qi + gridDim.x;                              // the quarter after qi (its header and records are requested while qi is in work)
+    const int xcd = (int)(blockIdx.x & 7u);
     int hb = 0;
     hdr_fetch1(qi);
     hdr_fetch2();
@@ -167,9 +176,8 @@ __global__ __launch_bounds__(ORD_THREADS) __attribute__((amdgpu_waves_per_eu(ORD
     lds_barrier();
     rec_fetch(sh.h[0], qi);
     d2_fetch(sh.h[0].n, qi);
-    for (; qi < nq; qi += gridDim.x, hb ^= 1) {
+    for (; qi < nq; hb ^= 1) {
         const ord_hdr& H = sh.h[hb];
-        const int64_t qn = qi + gridDim.x;                    // the workgroup's next quarter
         const int total = H.n;
         const long long lbase = qi * a.qcap;
         hdr_fetch1(qn);                                       // in flight during the counting sort
@@ -245,6 +253,8 @@ __global__ __launch_bounds__(ORD_THREADS) __attribute__((amdgpu_waves_per_eu(ORD
                 // the next quarter: header to LDS, output offsets and records requested -- all in flight during the write-out below
                 hdr_fetch2();
                 hdr_publish(hb ^ 1);
+                // ... and the draw for the one after it (read behind the barriers of the write-out)
+                if (a.qctr && tid == 0) sh.nextk = atomicAdd(&a.qctr[xcd], 1);
                 first = false;
             }
             const bool last_range = g1 >= ORD_COLS;
@@ -335,6 +345,8 @@ __global__ __launch_bounds__(ORD_THREADS) __attribute__((amdgpu_waves_per_eu(ORD
             g0 = g1;
         }
         if (tid < ORD_COLS) sh.h[hb ^ 1].out[tid] = hout;     // the next quarter's output offsets (requested before the write-out)
+        qi = qn;
+        qn = a.qctr ? 2 * (int64_t)gridDim.x + xcd + 8 * (int64_t)sh.nextk : qn + gridDim.x;      // (gridDim.x is a multiple of 4 with a counter: 2 nb = 0 mod 8)
     }
     if (a.pend_items) {
         lds_barrier();
@@ -390,7 +402,10 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail, int64_t mask_
         HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_order_logs, ORD_THREADS, lds));
         ctx->ord_per_cu = std::max(1, std::min(per_cu, 4));
     }
-    const unsigned nb = (unsigned)std::min<int64_t>(nt * 4, (int64_t)ctx->num_cus * ctx->ord_per_cu);
+    unsigned nb = (unsigned)std::min<int64_t>(nt * 4, (int64_t)ctx->num_cus * ctx->ord_per_cu);
+    // quarters drawn from the per-XCD counters (zeroed with the step's counter arena) when the launch is a whole number of draws' strides
+    const bool draw = ctx->ord_draw && ctx->ord_ctr && nb >= 8;
+    if (draw) nb &= ~3u;
     if (pend) {
         // one segment of the item array per workgroup; workgroups take every nb-th quarter tile, so their shares are even: 1.5x the mean + 4096
         const int64_t entries = std::max<int64_t>(ctx->nnz, ctx->nnz_cap);
@@ -410,6 +425,7 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail, int64_t mask_
     a.pend_items = pend ? (uint4*)ctx->pend_items : nullptr; a.pend_wcap = ctx->pend_wcap; a.pend_cnt = ctx->pend_cnt; a.pend_over = ctx->pend_over;
     a.rec_bits = recbits ? 1 : 0;
     a.deg_clear = ctx->world > 1 ? ctx->deg : nullptr;
+    a.qctr = draw ? ctx->ord_ctr : nullptr;
     if ((rc = mpfmt_side_join(ctx))) return rc;               // k_exact_pairs' marks (on the side stream since the pair kernel ended)
     hipLaunchKernelGGL(k_order_logs, dim3(nb), dim3(ORD_THREADS), lds, ctx->stream, a);
     HIPCHK(ctx, hipGetLastError());

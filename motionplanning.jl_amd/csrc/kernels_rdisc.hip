@@ -958,7 +958,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     // (... and the quarter logs' cursors behind them)
     // The fill is issued beside the chunk lists when the step forks there (a fill between two kernels of one stream costs ~15 us of
     // dispatch gaps on top of its 3), else in front of the pair kernel.
-    constexpr size_t ZA_PAIRS = 0, ZA_FLAG = 4128, ZA_PCNT = 4160, ZA_QLEN = 4160 + 4112, ZA_BYTES = ZA_QLEN;
+    constexpr size_t ZA_PAIRS = 0, ZA_FLAG = 4128, ZA_PCNT = 4160, ZA_OCTR = 4160 + 4112, ZA_QLEN = ZA_OCTR + 32, ZA_BYTES = ZA_QLEN;
     const size_t za_need = ZA_BYTES + sizeof(int32_t) * (size_t)std::max<int64_t>(nt * 4, 1);
     bool counters_zeroed = false;
     auto zero_counters = [&]() -> int32_t {
@@ -971,6 +971,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             ctx->pool_flag = (int32_t*)((char*)ctx->zarena + ZA_FLAG);
             ctx->pair_cnt = (int32_t*)((char*)ctx->zarena + ZA_PCNT);
             ctx->qlen = (int32_t*)((char*)ctx->zarena + ZA_QLEN);
+            ctx->ord_ctr = (int32_t*)((char*)ctx->zarena + ZA_OCTR);
         }
         if (ctx->zarena) {
             HIPCHK(ctx, hipMemsetAsync(ctx->zarena, 0, za_need, ctx->stream));
