@@ -514,7 +514,7 @@ MPFMT_API int32_t mpfmt_allgather_free_mask_relaunch(mpfmt_ctx* ctx);
 /* ---- measurement: average device milliseconds per launch of a named kernel group since the last
  *      reset, measured with HIP events on the launch stream.  names: "rdisc_count", "rdisc_fill",
  *      "rdisc_sort", "grid", "sweep_graph" (mask preset + round table + kernel), "sweep_kernel" (the round-table sweep kernel alone),
- *      "pair_kernel" (the pair kernel, and k_exact_pairs behind it when the edge tests are fused), "exact_pairs",
+ *      "pair_kernel" (the pair kernel alone), "exact_pairs" (k_exact_pairs, edge-test form 2),
  *      "sweep_points", "sweep_edges", "expand". */
 MPFMT_API int32_t mpfmt_timing_reset(mpfmt_ctx* ctx);
 MPFMT_API int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
@@ -535,6 +535,15 @@ MPFMT_API int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg
  * slice count is made odd.  "mf_xcd_mode" (default -1 = by launch size): items reach the XCDs in interleaved groups of this many
  * (0 = one contiguous range per XCD, 1 = round robin).  "cell_fb_max" (default 8): position bits inside a cell that the cell sort's key
  * carries.  "lists_wide" (default -1 = by the number of tiles): chunk lists built by four wavefronts per tile (1) or one (0).
+ * "overlap" (default 1): the step runs its per-sample obstacle masks and the counter fill beside the chunk lists, and the degree count,
+ * its scan, the mask preset and the capacity check beside the exact pair tests, on a second (lowest-priority) stream of the ctx forked
+ * and joined with events; 0 = every kernel on the ctx's stream.  "ord_draw" (default 1): the ordering kernel's workgroups draw their
+ * quarter tiles from per-XCD counters; 0 = every nb-th quarter each.  "mf_tail_slices" / "mf_tail_permille" / "mf_tail_min_items"
+ * (defaults 9 / 80 / 32768): the last permille of a single-pass launch's tiles are cut into that many (odd) slices instead of the
+ * launch's own, in launches of at least that many items.  "index_halo" / "shard_blocks" (default 1 / 1, sharded ctxs): the index is
+ * built for the shard's tiles and their neighbour cells only; cell ids are block-major so that a shard is a compact block.
+ * "wf_pos_space" (default 1): the device solve keeps its sets a second time by cell-sorted position from the SECOND solve on a graph on
+ * (2: from the first, 0: never).
  * Tuning knobs only: the graph and the masks are the same bit for bit whatever their values.
  * "debug_small_lists": test knob, shrinks the pending lists of the fused edge tests so that their overflow path runs. */
 MPFMT_API int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value);
@@ -543,7 +552,8 @@ MPFMT_API int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t val
  * (0 / 1 / 2 as "fuse_broad"), "pair_items" (pairs listed for the exact tests; a synchronising read); diagnostics: "redo_count" /
  * "redo_reason" (builds redone since the ctx was made and why: 1 a chunk list was cut, 2 a log overflowed, 4 a column too long for the
  * ordering pass, 8 more entries than allocated, 16 the pending-pair list was cut), "qcap" (records a quarter log holds), "ord_per_cu"
- * (ordering-pass workgroups per CU), "list_cap" / "list_max" / "list_q<permille>" / "list_argmax" / "list_sum" (chunk-list lengths of
+ * (ordering-pass workgroups per CU), "filter_valu" (1: the last single-pass build filtered with the exact fp64 test on the vector ALUs),
+ * "wf_pos_space_used" (1: the last device solve gathered by cell-sorted position), "list_cap" / "list_max" / "list_q<permille>" / "list_argmax" / "list_sum" (chunk-list lengths of
  * the last list build; synchronising reads). */
 MPFMT_API int32_t mpfmt_get_stat(mpfmt_ctx* ctx, const char* name, int64_t* value);
 /* work counters of the last graph build: candidate pairs distance-tested, tiles, slices. */
