@@ -146,8 +146,10 @@ __global__ void k_make_ops(const double* __restrict__ Xs, int64_t N, int64_t npa
 // one long latency chain): the tile's rows are split into NW contiguous ranges, one per wavefront; each stages its kept
 // ids in LDS, and the ranges are concatenated in order -- a chunk straddling two ranges is kept by both or by neither
 // (same box test), so dropping a range's first id when it equals the previous range's last restores the dedupe exactly.
+// (built for six wavefronts per SIMD -- 80 registers, no spills: left alone the compiler takes 106, and the sample masks that run beside
+// this kernel on the step's side stream then find room for one wavefront per SIMD: 122 us for them instead of 59; eight per SIMD spill)
 template <int D, int NW>
-__global__ __launch_bounds__(64 * NW) void k_chunk_lists(const int32_t* __restrict__ cellstart, const double* __restrict__ tile_lo,
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_chunk_lists(const int32_t* __restrict__ cellstart, const double* __restrict__ tile_lo,
                                                     const double* __restrict__ tile_hi, const double* __restrict__ tile_sub,
                                                     const float* __restrict__ tile_sub32, mpfmt_grid G, double rpad,
                                                     int64_t tile_begin, int64_t nt, int64_t list_cap,
