@@ -1025,8 +1025,9 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             (ctx->d <= 6 || (ctx->d <= 12 && half && ctx->fuse_broad == 2))) {
             hipStream_t main_s;
             if ((rc = mpfmt_side_fork(ctx, &main_s))) return rc;
-            int32_t rc2 = (ctx->zarena && ctx->zarena_bytes >= za_need) ? zero_counters() : MPFMT_OK;      // (an arena in place: nothing is freed under the lists)
-            if (!rc2) rc2 = mpfmt_launch_sample_masks(ctx, r);
+            // (an arena in place -- nothing is freed under the lists -- is cleared by the masks' kernel itself)
+            const bool arena = ctx->zarena && ctx->zarena_bytes >= za_need;
+            const int32_t rc2 = mpfmt_launch_sample_masks(ctx, r, arena ? ctx->zarena : nullptr, arena ? za_need : 0, &counters_zeroed);
             if ((rc = mpfmt_side_back(ctx, main_s)) || (rc = rc2)) return rc;
             ctx->masks_early = true;
         }

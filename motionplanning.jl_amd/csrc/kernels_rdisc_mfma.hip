@@ -394,8 +394,15 @@ template <int D>
 __global__ __launch_bounds__(256) void k_sample_masks(const double* __restrict__ Xs, const double* __restrict__ tile_lo, const double* __restrict__ tile_hi,
                                                       int64_t tile_begin, int64_t nt, double rpad, const double* __restrict__ boxes, int M,
                                                       unsigned long long* __restrict__ smask, unsigned long long* __restrict__ tile_bs,
-                                                      const uint8_t* __restrict__ tileneed)
+                                                      const uint8_t* __restrict__ tileneed, unsigned long long* __restrict__ zero, int64_t zero_words)
 {
+    // (beside the chunk lists this kernel also clears the step's counter arena, a slice per workgroup: as a fill of its own on the
+    // lowest-priority stream the 260 KB waited up to 70 us for a wave slot)
+    if (zero) {
+        const int64_t per = (zero_words + gridDim.x - 1) / gridDim.x;
+        const int64_t z0 = (int64_t)blockIdx.x * per, z1 = min(zero_words, z0 + per);
+        for (int64_t z = z0 + threadIdx.x; z < z1; z += blockDim.x) zero[z] = 0ull;
+    }
     const int lane = threadIdx.x & 63;
     const int64_t tl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tl >= nt) return;
@@ -451,8 +458,9 @@ __global__ __launch_bounds__(256) void k_sample_masks(const double* __restrict__
     smask[tile * 64 + lane] = mask;                           // (pad samples: NaN coordinates, every comparison false -- every surviving bit set; never read for a hit)
 }
 
-int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r)
+int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r, void* zero, size_t zero_bytes, bool* zeroed)
 {
+    if (zeroed) *zeroed = false;
     // (every tile, not the shard's own: a shard's candidates come from all of them)
     const int64_t nt = ctx->ntiles;
     int32_t rc;
@@ -460,11 +468,14 @@ int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r)
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->smask, sizeof(unsigned long long) * (size_t)std::max<int64_t>(ctx->ntiles * 68, 1)))) return rc;
     if (nt <= 0 || ctx->tile_end <= ctx->tile_begin) return MPFMT_OK;
     const double rpad = r * (1.0 + 1e-9) + 1e-300;
+    void* const zp = (zero && zero_bytes % 8 == 0 && ctx->d >= 1 && ctx->d <= 12) ? zero : nullptr;
 #define CASE(DD) case DD: hipLaunchKernelGGL((k_sample_masks<DD>), dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, ctx->stream, ctx->Xs, ctx->tile_lo, ctx->tile_hi, \
-        (int64_t)0, nt, rpad, ctx->boxes, ctx->M, (unsigned long long*)ctx->smask, (unsigned long long*)ctx->smask + ctx->ntiles * 64, (const uint8_t*)ctx->tileneed); break;
+        (int64_t)0, nt, rpad, ctx->boxes, ctx->M, (unsigned long long*)ctx->smask, (unsigned long long*)ctx->smask + ctx->ntiles * 64, (const uint8_t*)ctx->tileneed, \
+        (unsigned long long*)zp, (int64_t)(zero_bytes / 8)); break;
     switch (ctx->d) { CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) default: break; }
 #undef CASE
     HIPCHK(ctx, hipGetLastError());
+    if (zeroed) *zeroed = zp != nullptr;
     return MPFMT_OK;
 }
 

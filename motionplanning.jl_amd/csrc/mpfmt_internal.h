@@ -354,7 +354,7 @@ int32_t mpfmt_sweep_prepare_ss(mpfmt_ctx* ctx);          // kernels_sweep.hip: d
 int32_t mpfmt_mfma_build_lists(mpfmt_ctx* ctx, double r, bool* usable, bool spec = false, bool half = false);
 int mpfmt_slices_for(const mpfmt_ctx* ctx, int64_t units, bool mfma);      // slices per tile of the pair kernels (odd: kernels_rdisc_mfma.hip)
 int32_t mpfmt_launch_log_degrees(mpfmt_ctx* ctx);
-int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r);
+int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r, void* zero = nullptr, size_t zero_bytes = 0, bool* zeroed = nullptr);      // (zero: a buffer the kernel clears on the side)
 int32_t mpfmt_rdisc_stream_impl(mpfmt_ctx* ctx, double r, const double* C_host, const uint64_t* H_host, int32_t want_free,
                                 int64_t* deg, int64_t* nfree, int64_t* parent, double* cost, int64_t* nnz_out);
 int32_t mpfmt_launch_exact_pairs(mpfmt_ctx* ctx, const int32_t* spec_fail);
