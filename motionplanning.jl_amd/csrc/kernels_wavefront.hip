@@ -805,10 +805,15 @@ static int32_t wf_enqueue_local(mpfmt_ctx* ctx, mpfmt_wf* s)
     // (a directed steering graph's validity bits are its own sweep's: gfree is set there too -- the mask form)
     const bool geom = gfree == nullptr;
     // (persistent workgroups: exactly as many as are resident at once -- the kernel's loops stride by the grid, so a workgroup that has to
-    // wait for a slot starts its share of the candidates when the others are done with theirs)
+    // wait for a slot starts its share of the candidates when the others are done with theirs.  The runtime's occupancy query counts
+    // registers in eights; the device clock at the entry of every wavefront says sixteens: the mask form's 71 registers fit six to a
+    // SIMD, not the seven the query answers -- one workgroup per CU started 40 us late and the widest launch took 80 us instead of 60)
     wf_posc PC{ctx->perm, ctx->rowpos, (const unsigned long long*)s->Hs, s->Cs, (unsigned long long*)s->WFs, (unsigned long long*)s->Hns};
 #define WF_CONNECT(MODE_, GEOM_, POS_, TRIPS_) DISPATCH_D(d, { int per_cu = 0; \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_connect<DD, MODE_, GEOM_, POS_>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4; \
+        hipFuncAttributes fa_; \
+        if (hipFuncGetAttributes(&fa_, (const void*)k_wf_connect<DD, MODE_, GEOM_, POS_>) == hipSuccess && fa_.numRegs > 0) \
+            per_cu = std::max(1, std::min(per_cu, 512 / (((fa_.numRegs + 15) / 16) * 16))); \
         const int cgrid = ctx->num_cus * std::min(per_cu, 8); \
         hipLaunchKernelGGL((k_wf_connect<DD, MODE_, GEOM_, POS_>), dim3(cgrid), dim3(256), 0, st, s->xlist, ctx->colptr, \
         ctx->rowval, ctx->nzval, s->H, s->C, s->A, (unsigned long long*)s->W, (unsigned long long*)s->Hn, ctx->Xo, s->boxT, ctx->M, s->mpad, ctx->ss, gfree, nseg, \
