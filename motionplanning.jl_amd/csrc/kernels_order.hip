@@ -404,7 +404,10 @@ int32_t mpfmt_order_logs(mpfmt_ctx* ctx, const int32_t* spec_fail, int64_t mask_
     }
     unsigned nb = (unsigned)std::min<int64_t>(nt * 4, (int64_t)ctx->num_cus * ctx->ord_per_cu);
     // quarters drawn from the per-XCD counters (zeroed with the step's counter arena) when the launch is a whole number of draws' strides
-    const bool draw = ctx->ord_draw && ctx->ord_ctr && nb >= 8;
+    // (... and the quarters are long: a counter hands out ~90 draws per microsecond, workgroups that finish a 400-record quarter every
+    // few microseconds wait for it -- 2-D N = 1e6 at 440 records per quarter: 1.27 -> 1.47 ms per step; cfg2 at 1240: +2 %; the north
+    // star at 1720: -9 % of the kernel)
+    const bool draw = ctx->ord_draw && ctx->ord_ctr && nb >= 8 && (ctx->ord_draw > 1 || ctx->nnz >= (int64_t)1536 * nt * 4);
     if (draw) nb &= ~3u;
     if (pend) {
         // one segment of the item array per workgroup; workgroups take every nb-th quarter tile, so their shares are even: 1.5x the mean + 4096

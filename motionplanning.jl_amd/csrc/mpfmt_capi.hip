@@ -1685,7 +1685,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
         return MPFMT_OK;
     }
     if (strcmp(name, "mf_tail_permille") == 0) { ctx->mf_tail_permille = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1000); return MPFMT_OK; }
-    if (strcmp(name, "ord_draw") == 0) { ctx->ord_draw = value != 0; return MPFMT_OK; }
+    if (strcmp(name, "ord_draw") == 0) { ctx->ord_draw = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return MPFMT_OK; }
     if (strcmp(name, "mf_tail_min_items") == 0) { ctx->mf_tail_min_items = std::max<int64_t>(value, 0); return MPFMT_OK; }
     if (strcmp(name, "mf_tail_slices") == 0) { ctx->mf_tail_slices = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 63); return MPFMT_OK; }
     if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }

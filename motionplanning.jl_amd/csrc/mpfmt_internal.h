@@ -157,7 +157,7 @@ struct mpfmt_ctx {
     int32_t cell_fb_max = 8;             // position bits inside a cell that the sort key carries (k_cellkey)
     int64_t mf_tail_min_items = 32768;   // ... in launches of at least this many items (smaller ones do not fill the chip: nothing to even out)
     int32_t* ord_ctr = nullptr;          // [8] inside the counter arena: the ordering kernel's per-XCD quarter counters (zeroed with the arena)
-    int32_t ord_draw = 1;                // option: 0 = every workgroup of the ordering kernel takes every nb-th quarter (measurements)
+    int32_t ord_draw = 1;                // option: 1 = the ordering kernel's workgroups draw their quarters when those are long (>= 1536 records on average), 2 = always, 0 = every nb-th quarter each
     int32_t mf_tail_permille = 80, mf_tail_slices = 9;      // options: the last tiles of a single-pass pair-kernel launch are cut into this many slices (0: off)
     int32_t mf_xcd_mode = -1;            // work items go to the XCDs in interleaved groups of this many; -1: 256 for launches of >= 32768 items, else 64
                                          // (north star: groups of 64 2.02 ms / 5.6 GB of counter traffic, 256 2.04 / 4.6, 512 2.05 / 4.4; one range per XCD 2.41 ms)

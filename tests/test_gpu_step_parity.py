@@ -175,6 +175,8 @@ def test_step_with_and_without_the_side_stream(orc, d, N, r, M):
             c.set_option("overlap", min(ov, 1)); c.set_option("rebuild_index", 1)
             if ov == 2:           # the last third of the tiles cut into 7 slices instead of the launch's own (forced: these launches are small)
                 c.set_option("mf_tail_min_items", 0); c.set_option("mf_tail_permille", 333); c.set_option("mf_tail_slices", 7)
+            # (the ordering kernel's quarters: drawn from the counters whatever their length / by the default rule / a fixed share each)
+            c.set_option("ord_draw", 2 if ov == 1 and st is None else (1 if ov == 2 else 0))
             if st is not None: c.set_stream(st.cuda_stream)
             outs = []
             for Xi in (X, X, X2, X2, X):
