@@ -537,7 +537,8 @@ MPFMT_API int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg
  * carries.  "lists_wide" (default -1 = by the number of tiles): chunk lists built by four wavefronts per tile (1) or one (0).
  * "overlap" (default 1): the step runs its per-sample obstacle masks and the counter fill beside the chunk lists, and the degree count,
  * its scan, the mask preset and the capacity check beside the exact pair tests, on a second (lowest-priority) stream of the ctx forked
- * and joined with events; 0 = every kernel on the ctx's stream.  "ord_draw" (default 1): the ordering kernel's workgroups draw their
+ * and joined with events -- from 65536 samples on (smaller steps are shorter than the events' latencies); 2 = always; 0 = every kernel
+ * on the ctx's stream.  "ord_draw" (default 1): the ordering kernel's workgroups draw their
  * quarter tiles from per-XCD counters when a quarter holds >= 1536 records on average; 2 = always; 0 = every nb-th quarter each.  "mf_tail_slices" / "mf_tail_permille" / "mf_tail_min_items"
  * (defaults 9 / 80 / 32768): the last permille of a single-pass launch's tiles are cut into that many (odd) slices instead of the
  * launch's own, in launches of at least that many items.  "index_halo" / "shard_blocks" (default 1 / 1, sharded ctxs): the index is

@@ -951,6 +951,9 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
     const int64_t N = ctx->N;
     // (the shard -- tile_begin, tile_end -- is cut by the index build: mpfmt_build_grid)
     const int64_t nt = ctx->tile_end - ctx->tile_begin;
+    // the side stream pays from ~1e5 samples on: every fork and join is an event's latency (~15 us), the kernels they let run side by
+    // side take 5-10 us each in a world of 2e4 samples (0.19 -> 0.22 ms per step there; cfg2, N = 1e5: 0.70 -> 0.68)
+    const bool use_side = ctx->overlap > 1 || (ctx->overlap == 1 && N >= 65536);
 
     // The small per-build counters live in ONE arena zeroed by ONE fill: 512 pair counters + the longest column's
     // word (k_degree), the logs' overflow flag, the pending-pair list's region counters + its overflow flag.  (A ctx whose counters
@@ -1021,7 +1024,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
         // the per-sample obstacle masks of the fused broad phase need the tiles only: beside the chunk lists, on the side stream (the
         // condition is broad_in_drain's below as far as it is known here; masks made for a build that does not use them cost nothing
         // on this stream)
-        if (ctx->overlap && ctx->want_broad && ctx->use_pool && nt > 0 && !too_long_hint && !ctx->pool_skip_once &&
+        if (use_side && ctx->want_broad && ctx->use_pool && nt > 0 && !too_long_hint && !ctx->pool_skip_once &&
             (ctx->d <= 6 || (ctx->d <= 12 && half && ctx->fuse_broad == 2))) {
             hipStream_t main_s;
             if ((rc = mpfmt_side_fork(ctx, &main_s))) return rc;
@@ -1185,7 +1188,7 @@ int32_t mpfmt_rdisc_count_launch(mpfmt_ctx* ctx, double r, bool spec)
             // single pass: the columns' degrees are counts over the logs' keys.  The flagged pairs' exact tests (form 2) MARK keys (bit 31,
             // read by the ordering pass) while the count reads other bits of them: the count and the scan of the degrees go to the side
             // stream, the tests -- the longer of the two -- stay here; joined before the first reader of colptr
-            side_count = ctx->overlap && ctx->bits_in_records;
+            side_count = use_side && ctx->bits_in_records;
             hipStream_t main_s = nullptr;
             if (side_count && (rc = mpfmt_side_fork(ctx, &main_s))) return rc;
             int32_t rc2 = mpfmt_launch_log_degrees(ctx);

@@ -1689,7 +1689,7 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "mf_tail_min_items") == 0) { ctx->mf_tail_min_items = std::max<int64_t>(value, 0); return MPFMT_OK; }
     if (strcmp(name, "mf_tail_slices") == 0) { ctx->mf_tail_slices = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 63); return MPFMT_OK; }
     if (strcmp(name, "mf_xcd_mode") == 0) { ctx->mf_xcd_mode = (int32_t)value; return MPFMT_OK; }
-    if (strcmp(name, "overlap") == 0) { ctx->overlap = value != 0; return MPFMT_OK; }
+    if (strcmp(name, "overlap") == 0) { ctx->overlap = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return MPFMT_OK; }
     if (strcmp(name, "wf_pos_space") == 0) { ctx->wf_pos_space = value < 0 ? 0 : (value > 2 ? 2 : (int32_t)value); return MPFMT_OK; }
     if (strcmp(name, "shard_blocks") == 0) { ctx->shard_blocks = value != 0; ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; ctx->cut_key.clear(); return MPFMT_OK; }
     if (strcmp(name, "index_halo") == 0) { ctx->index_halo = value != 0; ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; return MPFMT_OK; }

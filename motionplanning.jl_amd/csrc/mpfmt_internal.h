@@ -91,7 +91,7 @@ struct mpfmt_ctx {
     int64_t preset_entries = -1;         // speculative step: the mask's trusted capacity, for the preset beside the exact pair tests
     int64_t mask_preset_words = -1;      // words of graph_free preset to ones ahead of mpfmt_order_logs (-1: none)
     bool masks_early = false;            // this build's sample masks were launched beside its chunk lists
-    int32_t overlap = 1;                 // option: 0 keeps every kernel of the step on ctx->stream (measurements)
+    int32_t overlap = 1;                 // option: 1 = the side stream from 65536 samples on, 2 = always, 0 = every kernel of the step on ctx->stream
     hipStream_t copy_stream[2] = {nullptr, nullptr};      // mpfmt_graph_export: two device-to-host streams and their hand-over events
     hipEvent_t ev_conv[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
     void* export_arena = nullptr;        // page-locked host memory of mpfmt_graph_export_pinned (grow-only, lives as long as the ctx)

@@ -172,7 +172,7 @@ def test_step_with_and_without_the_side_stream(orc, d, N, r, M):
     got = {}
     for ov, st in ((1, None), (0, None), (1, user), (2, None)):
         with mp.Context(0) as c:
-            c.set_option("overlap", min(ov, 1)); c.set_option("rebuild_index", 1)
+            c.set_option("overlap", 2 if ov else 0); c.set_option("rebuild_index", 1)      # (2: forced -- by default only from 65536 samples on)
             if ov == 2:           # the last third of the tiles cut into 7 slices instead of the launch's own (forced: these launches are small)
                 c.set_option("mf_tail_min_items", 0); c.set_option("mf_tail_permille", 333); c.set_option("mf_tail_slices", 7)
             # (the ordering kernel's quarters: drawn from the counters whatever their length / by the default rule / a fixed share each)
