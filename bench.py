@@ -245,7 +245,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_option("rebuild_index", 1)           # every step rebuilds the cell grid + MFMA operands (the index build)
-    for opt in ("sweep_sorted", "mf_target_items", "rdisc_half", "fuse_broad", "mf_xcd_mode", "cell_fb_max", "lists_wide"):             # tuning experiments (tools/): MPFMT_OPT_<NAME>=<int>
+    for opt in ("mf_target_items", "rdisc_half", "fuse_broad", "mf_xcd_mode", "cell_fb_max"):             # tuning experiments (tools/): MPFMT_OPT_<NAME>=<int>
         v = os.environ.get("MPFMT_OPT_" + opt.upper())
         if v is not None:
             ctx.set_option(opt, int(v))
@@ -522,7 +522,7 @@ def main():
                     "39.3e12 unfused fp64 lane-op/s of SURVEY 8d; every edge needs one 48-byte row-state gather: a kernel that does "
                     "nothing but such gathers reaches 4.5e10 rows/s from a caller-order array (L2 misses) and 1.9e11 when the rows are "
                     "L2-resident (tools/ubench/, profiles/r01_ubench_fetch_calib.txt, profiles/r02_ubench_gather_variants.txt); "
-                    "stage ablation in DESIGN.md 3.3" % (2 * d * 8 + 8 + 0.125),
+                    "the kernel itself: DESIGN.md 3.2" % (2 * d * 8 + 8 + 0.125),
         }
     ok_ = prof.get("sort", {})
     roof_sort = {

@@ -520,9 +520,8 @@ MPFMT_API int32_t mpfmt_timing_reset(mpfmt_ctx* ctx);
 MPFMT_API int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
 /* Tuning / test knobs.  "rdisc_path": 0 = auto, 1 = exact fp64 VALU pair kernel, 2 = fp16 MFMA distance-matrix
  * filter + exact fp64 refine (both give bit-identical graphs).  "timing": 0/1 event timing off/on.
- * "sweep_sorted" (default 1): the graph sweep gathers row states from the library's cell-sorted copy and visits the columns
- * in cell order, 0 = from the caller-order array.  "sweep_rounds" (default 1): round-table sweep kernel where it applies
- * (d <= 8, at most 256 boxes), 0 = the task-header kernel everywhere.  Same mask bits in every combination.
+ * "sweep_rounds" (default 1): round-table sweep kernel where it applies
+ * (d <= 8, at most 256 boxes), 0 = the task-header kernel everywhere.  Same mask bits either way.
  * "rdisc_half" (default 1): the single-pass build tests every pair of the ctx's own samples once and writes the hit records
  * of both columns (same CSC bit for bit; a build that overflows its logs is counted again whole).
  * "fuse_broad" (default 2): in mpfmt_graph_step* on such a build (AABB checker in the state space's own coordinates, d <= 6,
@@ -534,7 +533,7 @@ MPFMT_API int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg
  * "mf_target_items" (default 40000): work items (tile x slice of its chunk list, one wavefront each) the MFMA pair kernel aims for; the
  * slice count is made odd.  "mf_xcd_mode" (default -1 = by launch size): items reach the XCDs in interleaved groups of this many
  * (0 = one contiguous range per XCD, 1 = round robin).  "cell_fb_max" (default 8): position bits inside a cell that the cell sort's key
- * carries.  "lists_wide" (default -1 = by the number of tiles): chunk lists built by four wavefronts per tile (1) or one (0).
+ * carries.
  * "overlap" (default 1): the step runs its per-sample obstacle masks and the counter fill beside the chunk lists, and the degree count,
  * its scan, the mask preset and the capacity check beside the exact pair tests, on a second (lowest-priority) stream of the ctx forked
  * and joined with events -- from 65536 samples on (smaller steps are shorter than the events' latencies); 2 = always; 0 = every kernel

@@ -673,6 +673,7 @@ int32_t mpfmt_car_build(mpfmt_ctx* ctx, int kind, double rt, double sp, double r
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->deg, sizeof(int64_t) * (size_t)(N + 1)))) return rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->colptr, sizeof(int64_t) * (size_t)(N + 1)))) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (size_t)(N + 1), ctx->stream));
+    ctx->deg_zero_valid = false;
     if (cnnz > 0) {
         if (kind == 2)
             hipLaunchKernelGGL(k_car_cost<2>, dim3((unsigned)((cnnz + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xo, N, ax->colptr, ax->rowval,

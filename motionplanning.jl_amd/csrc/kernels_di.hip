@@ -493,6 +493,7 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
     if (!ctx->d_pairs) HIPCHK(ctx, hipMalloc((void**)&ctx->d_pairs, 514 * sizeof(unsigned long long)));     // (512 pair counters + the Euclidean build's longest-column word: one size everywhere)
     HIPCHK(ctx, hipMemsetAsync(ctx->d_pairs, 0, 2 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(int64_t) * (N + 1), ctx->stream));
+    ctx->deg_zero_valid = false;         // (this build writes every column's degree: a sharded r-disc step must not trust its own zeros any more)
     di_args a;
     a.X = ctx->Xo; a.N = N; a.rho = rho; a.r = r;
     a.i2 = 1.0 / (r * r); a.i3 = a.i2 / r; a.i4 = a.i2 * a.i2;

@@ -1693,17 +1693,11 @@ int32_t mpfmt_set_option(mpfmt_ctx* ctx, const char* name, int64_t value)
     if (strcmp(name, "wf_pos_space") == 0) { ctx->wf_pos_space = value < 0 ? 0 : (value > 2 ? 2 : (int32_t)value); return MPFMT_OK; }
     if (strcmp(name, "shard_blocks") == 0) { ctx->shard_blocks = value != 0; ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; ctx->cut_key.clear(); return MPFMT_OK; }
     if (strcmp(name, "index_halo") == 0) { ctx->index_halo = value != 0; ctx->grid_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0; return MPFMT_OK; }
-    if (strcmp(name, "lists_wide") == 0) { ctx->lists_wide = (int32_t)value; ctx->lists_r = -1.0; return MPFMT_OK; }
     if (strcmp(name, "cell_fb_max") == 0) { ctx->cell_fb_max = (int32_t)std::min<int64_t>(8, std::max<int64_t>(0, value)); ctx->grid_r = -1.0; return MPFMT_OK; }
     if (strcmp(name, "mf_target_items") == 0) { ctx->mf_target_items = value; return MPFMT_OK; }
     if (strcmp(name, "timing") == 0) { ctx->timing_enabled = value != 0; return MPFMT_OK; }
     if (strcmp(name, "sweep_rounds") == 0) {
         ctx->sweep_rounds = value != 0;
-        return MPFMT_OK;
-    }
-    if (strcmp(name, "sweep_sorted") == 0) {
-        ctx->sweep_sorted = value != 0;
-        ctx->graph_r = -1.0; ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false; ctx->spec_ready = false;
         return MPFMT_OK;
     }
     if (strcmp(name, "wf_force_sharded") == 0) { ctx->wf_force_sharded = value != 0; return MPFMT_OK; }

@@ -153,7 +153,7 @@ struct mpfmt_ctx {
     int32_t rdisc_path = 0;              // 0 auto, 1 exact fp64 VALU kernel, 2 MFMA filter + exact refine
     int32_t rdisc_path_used = 0;
     bool filter_valu = false;            // the counted graph's pair kernel ran the exact fp64 filter on the vector ALUs (k_rdisc_vf_w4) instead of the fp16 matrix-core one
-    int32_t lists_wide = -1;             // chunk lists built by four wavefronts per tile (1), one (0), or by the number of tiles (-1)
+    int32_t lists_wide = -1;             // (fixed; was an option until the A/B was settled) chunk lists built by four wavefronts per tile on small shards, one elsewhere
     int32_t cell_fb_max = 8;             // position bits inside a cell that the sort key carries (k_cellkey)
     int64_t mf_tail_min_items = 32768;   // ... in launches of at least this many items (smaller ones do not fill the chip: nothing to even out)
     int32_t* ord_ctr = nullptr;          // [8] inside the counter arena: the ordering kernel's per-XCD quarter counters (zeroed with the arena)
@@ -246,7 +246,7 @@ struct mpfmt_ctx {
     double* nzval = nullptr;
     int32_t* rowpos = nullptr;           // [nnz] cell-sorted position of each entry's row (single-pass build): the sweep gathers rows from Xs
     bool rowpos_valid = false;
-    int32_t sweep_sorted = 1;            // option: gather the sweep's rows from Xs in cell-sorted order with per-XCD task ranges (6x less HBM traffic,
+    int32_t sweep_sorted = 1;            // (fixed; was an option until the A/B was settled) gather the sweep's rows from Xs in cell-sorted order with per-XCD task ranges (6x less HBM traffic,
                                          // 74 % L2 hits): with the round-table sweep, whose instruction count no longer hides under the
                                          // caller-order gather (2.29 ms floor), this is the faster mode (2.2 vs 2.65 ms); on by default
     uint64_t* graph_free = nullptr;      // [ceil(nnz/64)]

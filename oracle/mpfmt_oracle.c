@@ -34,7 +34,19 @@
  * reference's 1-based convention where a test needs it.
  */
 #include <math.h>
-#include "../motionplanning.jl_amd/csrc/mp_math.h"
+/* Transcendental functions of the car models (src/statespaces/simplecars.jl calls Julia's libm): THIS oracle calls the C library's
+ * sin / cos / atan2 / acos -- an implementation the HIP library shares nothing with, so a car-model comparison against it is an
+ * independent check (costs to 1e-12, memberships exact away from the threshold).
+ * A SECOND build of this same file (liboracle_devmath.so: `-DORC_DEVICE_MATH -include <the product's mp_math.h>`, see the
+ * Makefile) swaps in the device's own polynomial versions.  It exists only for the explicitly labelled self-consistency tests
+ * ("one set of functions on both sides: every tie between words breaks identically, trees equal bit for bit") and carries no
+ * parity claim for the transcendental part.  This file itself includes nothing from motionplanning.jl_amd/. */
+#ifndef ORC_DEVICE_MATH
+#define mp_sin sin
+#define mp_cos cos
+#define mp_atan2 atan2
+#define mp_acos acos
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>

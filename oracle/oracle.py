@@ -30,39 +30,67 @@ class FmtResult(C.Structure):
                 ("collision_checks", C.c_int64), ("path_len", C.c_int64), ("nn_queries", C.c_int64)]
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+def build(force=False, devmath=False):
+    so = os.path.join(_HERE, "liboracle_devmath.so" if devmath else "liboracle.so")
     src = os.path.join(_HERE, "mpfmt_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
 
+def _declare(L):
+    L.orc_sqdist.restype = C.c_double
+    L.orc_dist.restype = C.c_double
+    L.orc_inball.restype = C.c_int64
+    L.orc_rdisc_count.restype = C.c_int64
+    L.orc_rdisc_fill.restype = None
+    L.orc_kdtree_build.restype = C.c_void_p
+    L.orc_kdtree_free.restype = None
+    L.orc_kdtree_inball.restype = C.c_int64
+    L.orc_expand.restype = C.c_int64
+    for f in (L.orc_mp_sin, L.orc_mp_cos, L.orc_mp_atan2, L.orc_mp_acos):
+        f.restype = C.c_double
+    L.orc_splitmix64.restype = C.c_uint64
+    L.orc_stream_uniform.restype = None
+    L.orc_euclid_steer.restype = None
+    L.orc_euclid_propagate.restype = None
+    L.orc_di_pairwise.restype = C.c_int64
+    L.orc_fmt_radius.restype = C.c_double
+    for f in ("orc_di_cost", "orc_di_dcost", "orc_di_ddcost"):
+        getattr(L, f).restype = C.c_double
+    return L
+
+
+_LIB_DEV = None          # the second build (liboracle_devmath.so): the car models' sin / cos / atan2 / acos are the DEVICE's own
+_USE_DEV = False
+
+
 def lib():
-    global _LIB
+    """The oracle library every wrapper below calls: liboracle.so (C library sin / cos / atan2 / acos -- independent of the product), or,
+    inside `with device_math():`, liboracle_devmath.so (the product's generated mp_math.h: self-consistency checks only)."""
+    global _LIB, _LIB_DEV
+    if _USE_DEV:
+        if _LIB_DEV is None:
+            _LIB_DEV = _declare(C.CDLL(build(devmath=True)))
+        return _LIB_DEV
     if _LIB is None:
-        _LIB = C.CDLL(build())
-        L = _LIB
-        L.orc_sqdist.restype = C.c_double
-        L.orc_dist.restype = C.c_double
-        L.orc_inball.restype = C.c_int64
-        L.orc_rdisc_count.restype = C.c_int64
-        L.orc_rdisc_fill.restype = None
-        L.orc_kdtree_build.restype = C.c_void_p
-        L.orc_kdtree_free.restype = None
-        L.orc_kdtree_inball.restype = C.c_int64
-        L.orc_expand.restype = C.c_int64
-        for f in (L.orc_mp_sin, L.orc_mp_cos, L.orc_mp_atan2, L.orc_mp_acos):
-            f.restype = C.c_double
-        L.orc_splitmix64.restype = C.c_uint64
-        L.orc_stream_uniform.restype = None
-        L.orc_euclid_steer.restype = None
-        L.orc_euclid_propagate.restype = None
-        L.orc_di_pairwise.restype = C.c_int64
-        L.orc_fmt_radius.restype = C.c_double
-        for f in ("orc_di_cost", "orc_di_dcost", "orc_di_ddcost"):
-            getattr(L, f).restype = C.c_double
+        _LIB = _declare(C.CDLL(build()))
     return _LIB
+
+
+class device_math:
+    """`with orc.device_math(): ...` -- the car-model functions of the oracle run with the transcendental functions the DEVICE compiles
+    (one implementation on both sides: ties between words break identically, so trees and controls can be compared bit for bit).
+    A labelled self-consistency check, not a parity claim: outside this block the oracle calls the C library."""
+    def __enter__(self):
+        global _USE_DEV
+        self._was = _USE_DEV
+        _USE_DEV = True
+        return self
+
+    def __exit__(self, *a):
+        global _USE_DEV
+        _USE_DEV = self._was
 
 
 def _d(a):

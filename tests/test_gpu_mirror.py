@@ -146,7 +146,11 @@ def test_dubins_planning_through_the_mirror(orc):
     md = P.solution.metadata
     lohi = CC.lohi()
     oc, orow, oval = orc.dubins_graph(X, rt, 1.0, md["r"])
-    ref = orc.dubins_fmtstar(X, rt, 1.0, oc, orow, oval, orc.GOAL_BALL, np.array([0.9, 0.9, 0.06]), lohi, SS.lo, SS.hi)
+    colptr, rowval, nzval = P.ctx.dubins_graph(rt, 1.0, md["r"])
+    # (the oracle's sin / cos / atan2 / acos are the C library's, the device's are mp_math.h: costs agree to 1e-12, not bit for bit --
+    # the recursion is pinned on the device's own edge costs so that no near-tie between two parents can break differently)
+    assert np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow) and np.allclose(nzval, oval, rtol=1e-12, atol=0)
+    ref = orc.dubins_fmtstar(X, rt, 1.0, oc, orow, nzval, orc.GOAL_BALL, np.array([0.9, 0.9, 0.06]), lohi, SS.lo, SS.hi)
     assert (status == "solved") == bool(ref["status"])
     assert np.array_equal(md["tree"] - 1, ref["A"]) and md["collision_checks"] == ref["collision_checks"]
     if ref["status"]:

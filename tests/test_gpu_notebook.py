@@ -82,7 +82,7 @@ def test_dubins_sweep_in_the_polygon_world(orc):
         colptr, rowval, nzval = ctx.dubins_graph(rt, 1.0, r)
         mask, nseg = ctx.dubins_graph_edges_free()
     oc, orow, oval = orc.dubins_graph(X, rt, 1.0, r)
-    assert np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow) and np.array_equal(nzval, oval)
+    assert np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow) and np.allclose(nzval, oval, rtol=1e-12, atol=0)
     bits = L.unpack_bits(mask, len(rowval))
     blocked = 0
     for x in range(N):

@@ -783,42 +783,86 @@ def _car_world(rng, N, M):
     return X, lohi, lo, hi
 
 
+# Two comparisons per test, kept apart on purpose:
+#   (1) PARITY against the oracle proper, whose sin / cos / atan2 / acos are the C library's -- an implementation the device shares
+#       nothing with: costs to 1e-12 relative, memberships / masks / segment counts exact (no cost of these seeded sets lies within
+#       1e-12 of the radius; the comparison reports one that does), the same word chosen, plans equal in status / cost / path, parents
+#       equal except where two words tie to rounding;
+#   (2) SELF-CONSISTENCY inside `with orc.device_math():` -- the oracle's second build compiles the product's own mp_math.h, so every
+#       tie breaks identically and everything is compared bit for bit.  That block proves the pipeline around the transcendental
+#       functions (word selection, ordering, sweep, recursion), not the functions themselves; tests/test_oracle.py checks those against
+#       200-bit mpmath.
+
+def _assert_car_graph_close(N, r, got, want):
+    """(colptr0, rowval0, nzval) of the device against the libm oracle's: memberships equal except where the oracle's cost is within
+    1e-12 r of the radius, costs of the common entries to 1e-12.  Returns the common entries' positions in both."""
+    gk = np.repeat(np.arange(N), np.diff(got[0])) * N + got[1]
+    wk = np.repeat(np.arange(N), np.diff(want[0])) * N + want[1]
+    com, gi, wi = np.intersect1d(gk, wk, assume_unique=True, return_indices=True)
+    og = np.setdiff1d(np.arange(len(gk)), gi); ow = np.setdiff1d(np.arange(len(wk)), wi)
+    assert (np.abs(got[2][og] - r) <= 1e-12 * r).all() and (np.abs(want[2][ow] - r) <= 1e-12 * r).all()
+    assert len(og) + len(ow) <= 1e-4 * len(com)
+    assert np.allclose(got[2][gi], want[2][wi], rtol=1e-12, atol=0)
+    return gi, wi
+
+
+def _assert_car_plan_close(got, want, N):
+    assert got["status"] == want["status"]
+    assert abs(got["cost"] - want["cost"]) <= 1e-12 * want["cost"]
+    fin = np.isfinite(want["C"])
+    assert np.array_equal(np.isfinite(got["C"]), fin) and np.allclose(got["C"][fin], want["C"][fin], rtol=1e-12, atol=0)
+    assert np.array_equal(got["path"] - 1, want["path"])
+    # (two parents reached by words of equal length up to rounding tie differently under different sin / cos: a handful per plan)
+    assert (got["A"] - 1 != want["A"]).sum() <= 0.005 * N
+    assert abs(got["collision_checks"] - want["collision_checks"]) <= 0.005 * want["collision_checks"]
+
+
 def test_dubins_steer_batch(ctx, orc):
     rng = np.random.default_rng(61)
     X0, _, _, _ = _car_world(rng, 4000, 1); X1, _, _, _ = _car_world(rng, 4000, 1)
     for rt in (0.05, 0.3, 2.0):
         cost, ctrl = ctx.dubins_steer(X0, X1, rt, 1.0)
+        # (1) parity: the oracle with the C library's transcendental functions
         want = [orc.dubins(a, b, rt, 1.0) for a, b in zip(X0, X1)]
         wc = np.array([w[0] for w in want]); wu = np.array([w[1] for w in want])
-        # sin / cos / atan2 / acos come from ONE header on both sides (mp_math.h): costs, the winning word and its segment
-        # durations are bit-identical
-        assert np.array_equal(cost, wc)
-        assert np.array_equal(ctrl, wu)
+        assert np.allclose(cost, wc, rtol=1e-12, atol=0)
+        assert np.array_equal(ctrl[:, :, 1:], wu[:, :, 1:]) and np.allclose(ctrl, wu, rtol=0, atol=1e-12)      # same word, same durations
+        # (2) self-consistency: ONE header on both sides (mp_math.h) -- costs, the winning word and its durations bit-identical
+        with orc.device_math():
+            want = [orc.dubins(a, b, rt, 1.0) for a, b in zip(X0, X1)]
+        assert np.array_equal(cost, np.array([w[0] for w in want])) and np.array_equal(ctrl, np.array([w[1] for w in want]))
 
 
 @pytest.mark.parametrize("N,rt,r", [(1500, 0.05, 0.25), (2500, 0.15, 0.3)])
 def test_dubins_graph_sweep_and_plan(ctx, orc, N, rt, r):
-    """Dubins backward sets, edge validity with the reference's arc waypoints, and a full plan, against the oracle:
-    graph, costs, masks, per-edge segment counts, tree, path and collision_checks all bit-exact (the transcendental functions
-    are mp_math.h's on both sides)."""
+    """Dubins backward sets, edge validity with the reference's arc waypoints, and a full plan, against the oracle: (1) the libm
+    oracle -- memberships, masks, per-edge segment counts exact, costs to 1e-12, plan equal in status / cost / path; (2) the
+    device-math build of the oracle: everything bit for bit, tree and collision_checks included."""
     rng = np.random.default_rng(70 + N)
     X, lohi, lo, hi = _car_world(rng, N, 12)
     X[0] = [0.05, 0.05, 0.6]; X[-1] = [0.95, 0.95, 0.8]
     ctx.upload_samples(X)
     ctx.upload_boxes(lohi, lo, hi, dw=2)
     colptr, rowval, nzval = ctx.dubins_graph(rt, 1.0, r)
-    oc, orow, oval = orc.dubins_graph(X, rt, 1.0, r)
     c0, r0 = to0(colptr, rowval)
-    assert np.array_equal(c0, oc) and np.array_equal(r0, orow)
-    assert np.array_equal(nzval, oval)
     assert len(r0) > 5 * N                                                # a real graph, not a trivial one
     mask, nseg = ctx.dubins_graph_edges_free()
-    omask, onseg = orc.dubins_graph_edges_free(X, rt, 1.0, oc, orow, lohi, lo, hi)
-    assert np.array_equal(mask, omask) and np.array_equal(nseg, onseg)
     assert 0.2 < mp._lib.unpack_bits(mask, len(r0)).mean() < 0.999
     goal = np.array([0.95, 0.95, 0.08])
     got = ctx.dubins_fmtstar(rt, 1.0, r, mp._lib.GOAL_BALL, goal)
-    want = orc.dubins_fmtstar(X, rt, 1.0, oc, orow, oval, orc.GOAL_BALL, goal, lohi, lo, hi, init_idx=0)
+    # (1) parity
+    oc, orow, oval = orc.dubins_graph(X, rt, 1.0, r)
+    gi, wi = _assert_car_graph_close(N, r, (c0, r0, nzval), (oc, orow, oval))
+    omask, onseg = orc.dubins_graph_edges_free(X, rt, 1.0, oc, orow, lohi, lo, hi)
+    assert np.array_equal(mp._lib.unpack_bits(mask, len(r0))[gi], orc.unpack(omask, len(orow))[wi]) and np.array_equal(nseg[gi], onseg[wi])
+    _assert_car_plan_close(got, orc.dubins_fmtstar(X, rt, 1.0, oc, orow, oval, orc.GOAL_BALL, goal, lohi, lo, hi, init_idx=0), N)
+    # (2) self-consistency (the oracle compiled with the device's mp_math.h)
+    with orc.device_math():
+        oc, orow, oval = orc.dubins_graph(X, rt, 1.0, r)
+        omask, onseg = orc.dubins_graph_edges_free(X, rt, 1.0, oc, orow, lohi, lo, hi)
+        want = orc.dubins_fmtstar(X, rt, 1.0, oc, orow, oval, orc.GOAL_BALL, goal, lohi, lo, hi, init_idx=0)
+    assert np.array_equal(c0, oc) and np.array_equal(r0, orow) and np.array_equal(nzval, oval)
+    assert np.array_equal(mask, omask) and np.array_equal(nseg, onseg)
     assert got["status"] == want["status"]
     assert np.array_equal(got["A"] - 1, want["A"]) and np.array_equal(got["path"] - 1, want["path"])
     assert got["collision_checks"] == want["collision_checks"]
@@ -827,6 +871,15 @@ def test_dubins_graph_sweep_and_plan(ctx, orc, N, rt, r):
 
 # ---- Reeds-Shepp car -----------------------------------------------------------------------------------
 
+def _rs_batch(want):
+    wc = np.array([w[0] for w in want])
+    wl = np.array([len(w[1]) for w in want])
+    wu = np.zeros((len(want), 5, 3))
+    for i, w in enumerate(want):
+        wu[i, :len(w[1])] = w[1]
+    return wc, wl, wu
+
+
 def test_reedsshepp_steer_batch(ctx, orc):
     rng = np.random.default_rng(62)
     X0, _, _, _ = _car_world(rng, 4000, 1); X1, _, _, _ = _car_world(rng, 4000, 1)
@@ -834,42 +887,52 @@ def test_reedsshepp_steer_batch(ctx, orc):
     X1[50:100, 2] = X0[50:100, 2]                                       # pure translations
     for rt in (0.05, 0.3, 2.0):
         cost, ctrl, nsegs = ctx.reedsshepp_steer(X0, X1, rt, 1.0)
-        want = [orc.reedsshepp(a, b, rt, 1.0) for a, b in zip(X0, X1)]
-        wc = np.array([w[0] for w in want])
-        wl = np.array([len(w[1]) for w in want])
-        wu = np.zeros((len(want), 5, 3))
-        for i, w in enumerate(want):
-            wu[i, :len(w[1])] = w[1]
-        assert np.array_equal(cost, wc)                                 # same transcendental functions on both sides (mp_math.h)
-        assert np.array_equal(nsegs, wl) and np.array_equal(ctrl, wu)  # ... so ties between words resolve identically
-        for i in range(len(want)):                                      # segments past nsegs are zero
+        # (1) parity: libm oracle -- costs to 1e-12, the same word (segment count, directions, gears), durations to 1e-12
+        wc, wl, wu = _rs_batch([orc.reedsshepp(a, b, rt, 1.0) for a, b in zip(X0, X1)])
+        assert np.allclose(cost, wc, rtol=1e-12, atol=1e-15)
+        assert np.array_equal(nsegs, wl) and np.array_equal(ctrl[:, :, 1:], wu[:, :, 1:]) and np.allclose(ctrl, wu, rtol=0, atol=1e-12)
+        # (2) self-consistency: same transcendental functions on both sides (mp_math.h), so ties between words resolve identically
+        with orc.device_math():
+            wc, wl, wu = _rs_batch([orc.reedsshepp(a, b, rt, 1.0) for a, b in zip(X0, X1)])
+        assert np.array_equal(cost, wc)
+        assert np.array_equal(nsegs, wl) and np.array_equal(ctrl, wu)
+        for i in range(len(wc)):                                        # segments past nsegs are zero
             assert not ctrl[i, nsegs[i]:].any()
 
 
 @pytest.mark.parametrize("N,rt,r", [(1500, 0.05, 0.2), (2500, 0.15, 0.25)])
 def test_reedsshepp_graph_sweep_and_plan(ctx, orc, N, rt, r):
     """Reeds-Shepp inball sets (column v holds d(v, w)), edge validity over the reference's waypoints, and a full plan
-    through the symmetric recursion, against the oracle: all bit-exact, like the Dubins test."""
+    through the symmetric recursion: (1) against the libm oracle -- memberships, masks, segment counts exact, costs to 1e-12, plan equal
+    in status / cost / path, parents equal up to a handful of ties; (2) against the device-math build of the oracle: bit for bit."""
     rng = np.random.default_rng(90 + N)
     X, lohi, lo, hi = _car_world(rng, N, 12)
     X[0] = [0.05, 0.05, 0.6]; X[-1] = [0.95, 0.95, 0.8]
     ctx.upload_samples(X)
     ctx.upload_boxes(lohi, lo, hi, dw=2)
     colptr, rowval, nzval = ctx.reedsshepp_graph(rt, 1.0, r)
-    oc, orow, oval = orc.rs_graph(X, rt, 1.0, r)
     c0, r0 = to0(colptr, rowval)
-    assert np.array_equal(c0, oc) and np.array_equal(r0, orow)
-    assert np.array_equal(nzval, oval)
     assert len(r0) > 5 * N
     mask, nseg = ctx.reedsshepp_graph_edges_free()
-    omask, onseg = orc.car_graph_edges_free(2, X, rt, 1.0, oc, orow, lohi, lo, hi)
-    assert np.array_equal(mask, omask) and np.array_equal(nseg, onseg)
     assert 0.2 < mp._lib.unpack_bits(mask, len(r0)).mean() < 0.999
     goal = np.array([0.95, 0.95, 0.08])
     got = ctx.reedsshepp_fmtstar(rt, 1.0, r, mp._lib.GOAL_BALL, goal)
-    # (Reeds-Shepp words of the C|C|C kind have length = turning radius x heading change, so two parents reached by such words
-    # tie up to rounding; with one set of transcendental functions on both sides the ties break identically.)
+    # (1) parity
+    oc, orow, oval = orc.rs_graph(X, rt, 1.0, r)
+    gi, wi = _assert_car_graph_close(N, r, (c0, r0, nzval), (oc, orow, oval))
+    omask, onseg = orc.car_graph_edges_free(2, X, rt, 1.0, oc, orow, lohi, lo, hi)
+    assert np.array_equal(mp._lib.unpack_bits(mask, len(r0))[gi], orc.unpack(omask, len(orow))[wi]) and np.array_equal(nseg[gi], onseg[wi])
     want = orc.rs_fmtstar(X, rt, 1.0, oc, orow, oval, orc.GOAL_BALL, goal, lohi, lo, hi, init_idx=0)
+    assert want["status"] == 1
+    _assert_car_plan_close(got, want, N)
+    # (2) self-consistency.  (Reeds-Shepp words of the C|C|C kind have length = turning radius x heading change, so two parents reached
+    # by such words tie up to rounding; with one set of transcendental functions on both sides the ties break identically.)
+    with orc.device_math():
+        oc, orow, oval = orc.rs_graph(X, rt, 1.0, r)
+        omask, onseg = orc.car_graph_edges_free(2, X, rt, 1.0, oc, orow, lohi, lo, hi)
+        want = orc.rs_fmtstar(X, rt, 1.0, oc, orow, oval, orc.GOAL_BALL, goal, lohi, lo, hi, init_idx=0)
+    assert np.array_equal(c0, oc) and np.array_equal(r0, orow) and np.array_equal(nzval, oval)
+    assert np.array_equal(mask, omask) and np.array_equal(nseg, onseg)
     assert got["status"] == want["status"] == 1
     assert np.array_equal(got["A"] - 1, want["A"]) and np.array_equal(got["path"] - 1, want["path"])
     assert got["collision_checks"] == want["collision_checks"]

@@ -14,12 +14,11 @@ L = mp._lib
 
 # ---- (a) the timed path against the oracle ---------------------------------------------------------------------------
 
-@pytest.mark.parametrize("world,sorted_rows,rounds", [(1, 0, 1), (3, 0, 1), (1, 1, 1), (3, 1, 1), (1, 0, 0), (3, 1, 0)])
-def test_graph_step_device_against_oracle(orc, world, sorted_rows, rounds):
+@pytest.mark.parametrize("world,rounds", [(1, 1), (3, 1), (1, 0), (3, 0)])
+def test_graph_step_device_against_oracle(orc, world, rounds):
     """Resident CSC + free mask of mpfmt_graph_step_device vs the oracle's graph and edge predicate: the first (careful)
     call, two speculative repeats, new samples under the same (N, r), a capacity-busting cluster (device flag voids the
-    kernels, host redoes the step) and the way back (capacities far too large).  Both row-gather modes of the sweep, both
-    sweep kernels (round table / task headers)."""
+    kernels, host redoes the step) and the way back (capacities far too large).  Both sweep kernels (round table / task headers)."""
     rng = np.random.default_rng(777)
     N, d, M = 12000, 4, 30
     X, lohi = random_world(rng, N, d, M, 0.03, 0.1)
@@ -35,7 +34,6 @@ def test_graph_step_device_against_oracle(orc, world, sorted_rows, rounds):
     for g in range(world):
         with mp.Context(0) as c:
             c.set_shard(g, world); c.set_option("rebuild_index", 1)
-            c.set_option("sweep_sorted", sorted_rows)        # rows gathered from the cell-sorted copy, per-XCD column ranges
             c.set_option("sweep_rounds", rounds)             # k_graph_sweep_rt (round table) or k_graph_sweep (task headers)
             c.upload_boxes(lohi, lo, hi)
             for it, (Xi, (oc, orow, oval, omask)) in enumerate(zip(Xs, refs)):
@@ -55,6 +53,84 @@ def test_graph_step_device_against_oracle(orc, world, sorted_rows, rounds):
                     assert np.array_equal(rowval, orow[oidx]) and np.array_equal(nzval, oval[oidx]), (g, it)
                     assert np.array_equal(L.unpack_bits(free.view(np.uint64), nnz), orc.unpack(omask, len(orow))[oidx]), (g, it)
                 assert nnz == deg.sum()
+
+
+@pytest.mark.parametrize("world,blocks,halo,N", [(2, 1, 1, 9000), (8, 1, 1, 9000), (8, 0, 1, 9000), (8, 1, 0, 9000), (8, 0, 0, 9000),
+                                                  (5, 1, 1, 14001), (8, 1, 1, 30011)])
+def test_shards_partition_the_columns(orc, world, blocks, halo, N):
+    """Every column belongs to exactly one shard: the per-rank degree arrays of a sharded step SUM to the oracle's degrees (a column no
+    rank owns, or one that lost rows to a missing halo tile, shows here -- comparing only the columns a rank reports would not), under both
+    cell-id orders (`shard_blocks`: block-major / row-major), with and without the shard + halo index (`index_halo`), with shard counts
+    that leave holes in the block-major id range (odd cell counts along a cut axis), over a careful step, a speculative repeat and new
+    samples; the owned columns' entries and edge bits against the oracle as well."""
+    rng = np.random.default_rng(8800 + world * 10 + blocks * 2 + halo)
+    d, M = 4, 24
+    r = 0.12 if N < 20000 else 0.095                          # (cells per axis: 8 / 10 -- and 7 for the third set below: odd)
+    X, lohi = random_world(rng, N, d, M, 0.03, 0.1)
+    lo, hi = np.full(d, 0.0), np.full(d, 1.0)
+    sets = [X, X, 0.02 + 0.96 * rng.random((N, d)) * np.array([1.0, 0.86, 1.0, 1.0])]
+    refs = []
+    for Xi in sets:
+        if refs and Xi is sets[0]:
+            refs.append(refs[0]); continue
+        oc, orow, oval = orc.rdisc_graph(Xi, r)
+        refs.append((oc, orow, oval, orc.unpack(orc.graph_edges_free(Xi, oc, orow, lohi, lo, hi), len(orow))))
+    degsum = [np.zeros(N, np.int64) for _ in sets]
+    for g in range(world):
+        with mp.Context(0) as c:
+            c.set_shard(g, world); c.set_option("rebuild_index", 1)
+            c.set_option("shard_blocks", blocks); c.set_option("index_halo", halo)
+            c.upload_boxes(lohi, lo, hi)
+            for it, (Xi, (oc, orow, oval, obits)) in enumerate(zip(sets, refs)):
+                c.upload_samples(Xi)
+                nnz = c.graph_step_device(r)
+                colptr, rowval, nzval, free = _resident_graph(c, N)
+                deg = np.diff(colptr)
+                assert nnz == deg.sum()
+                degsum[it] += deg
+                own = np.flatnonzero(deg)
+                oidx = np.concatenate([np.arange(oc[v], oc[v + 1]) for v in own]) if len(own) else np.zeros(0, np.int64)
+                assert np.array_equal(deg[own], np.diff(oc)[own]), (g, it)
+                assert np.array_equal(rowval, orow[oidx]) and np.array_equal(nzval, oval[oidx]), (g, it)
+                assert np.array_equal(L.unpack_bits(free.view(np.uint64), nnz), obits[oidx]), (g, it)
+    for it, (oc, _, _, _) in enumerate(refs):
+        assert np.array_equal(degsum[it], np.diff(oc)), it     # no column unowned, none owned twice, none short of a row
+
+
+def test_sharded_step_after_another_graph_build_on_the_ctx(orc):
+    """ADVICE r5: a sharded ctx skips the fill of its degree array when the last step's ordering pass left it zero (`deg_zero_valid`);
+    a double-integrator build in between writes EVERY column's degree into the same array.  Sequence: sharded Euclidean step, DI graph
+    (count + fill) on other samples, sharded step again -- graph, costs and mask of every step against the oracle, degrees summed
+    over the ranks."""
+    rng = np.random.default_rng(8899)
+    N, d, M, r, world = 6000, 4, 20, 0.14, 3
+    X, lohi = random_world(rng, N, d, M, 0.03, 0.1)
+    lo, hi = np.full(d, 0.0), np.full(d, 1.0)
+    oc, orow, oval = orc.rdisc_graph(X, r)
+    obits = orc.unpack(orc.graph_edges_free(X, oc, orow, lohi, lo, hi), len(orow))
+    Xdi = rng.random((1500, 4)) * np.array([1.0, 1.0, 0.5, 0.5])
+    degsum = [np.zeros(N, np.int64) for _ in range(3)]
+    for g in range(world):
+        with mp.Context(0) as c:
+            c.set_shard(g, world); c.set_option("rebuild_index", 1)
+            c.upload_boxes(lohi, lo, hi)
+            for it in range(3):
+                if it == 2:
+                    c.upload_samples(Xdi)
+                    dc, drow, dval, dt = c.di_graph(1.0, 0.9)                # writes deg[] of all 1500 columns
+                    assert dc[-1] - 1 == len(drow) and len(drow) > 0
+                c.upload_samples(X)
+                nnz = c.graph_step_device(r)
+                colptr, rowval, nzval, free = _resident_graph(c, N)
+                deg = np.diff(colptr)
+                degsum[it] += deg
+                own = np.flatnonzero(deg)
+                oidx = np.concatenate([np.arange(oc[v], oc[v + 1]) for v in own])
+                assert nnz == deg.sum() and np.array_equal(deg[own], np.diff(oc)[own]), (g, it)
+                assert np.array_equal(rowval, orow[oidx]) and np.array_equal(nzval, oval[oidx]), (g, it)
+                assert np.array_equal(L.unpack_bits(free.view(np.uint64), nnz), obits[oidx]), (g, it)
+    for it in range(3):
+        assert np.array_equal(degsum[it], np.diff(oc)), it
 
 
 @pytest.mark.parametrize("d,N,r", [(2, 6000, 0.03), (3, 7001, 0.09), (6, 20000, 0.42)])
@@ -455,9 +531,9 @@ def test_round_table_sweep_cases(orc, N, d, M, r, box_h, bounds):
     oc, orow, oval = orc.rdisc_graph(X, r)
     want = orc.graph_edges_free(X, oc, orow, lohi, lo, hi)
     masks = []
-    for sorted_rows, rounds in ((1, 1), (0, 1), (1, 0)):
+    for rounds in (1, 0):
         with mp.Context(0) as c:
-            c.set_option("sweep_sorted", sorted_rows); c.set_option("sweep_rounds", rounds)
+            c.set_option("sweep_rounds", rounds)
             c.upload_samples(X); c.upload_boxes(lohi, lo, hi)
             for _ in range(2):                                         # careful step, then the speculative one
                 nnz = c.graph_step_device(r)

@@ -516,8 +516,30 @@ def test_golden_di_pairs(orc):
 
 
 def test_mp_math_accuracy_against_mpmath(orc):
-    """mp_math.h (the fp64 sin / cos / atan2 / acos both the oracle and the device compile) against 200-bit mpmath: within
-    2 ulp on the ranges the car kernels use, exact special values, and the identities the word formulas rely on."""
+    """mp_math.h (the fp64 sin / cos / atan2 / acos the DEVICE compiles; reached here through the oracle's second build,
+    liboracle_devmath.so -- the oracle proper calls the C library) against 200-bit mpmath: within 2 ulp on the ranges the car kernels
+    use, exact special values, and the identities the word formulas rely on."""
+    with orc.device_math():
+        _mp_math_accuracy(orc)
+
+
+def test_oracle_proper_calls_the_c_library(orc):
+    """The oracle's own transcendental functions are libm's (independent of the product's mp_math.h): its exported hooks equal
+    math.sin / cos / atan2 / acos bit for bit, and the file includes nothing from the product's tree."""
+    import math
+    rng = np.random.default_rng(3)
+    for x in rng.uniform(-20, 20, 2000):
+        x = float(x)
+        assert orc.mp_sin(x) == math.sin(x) and orc.mp_cos(x) == math.cos(x)
+        assert orc.mp_atan2(x, 1.0 - x) == math.atan2(x, 1.0 - x)
+    for x in rng.uniform(-1, 1, 2000):
+        assert orc.mp_acos(float(x)) == math.acos(float(x))
+    src = open(os.path.join(os.path.dirname(orc.__file__), "mpfmt_oracle.c")).read()
+    includes = [ln for ln in src.splitlines() if ln.lstrip().startswith("#include")]
+    assert includes and all("<" in ln and ".." not in ln and "motionplanning" not in ln for ln in includes), includes
+
+
+def _mp_math_accuracy(orc):
     import mpmath
     mpmath.mp.prec = 200
     rng = np.random.default_rng(5)
