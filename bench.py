@@ -165,6 +165,166 @@ def stream_bench(args):
     ctx.close()
 
 
+VALU_OPS_FILE = os.path.join(ROOT, "profiles", "valu_ops.json")        # written by tools/pmc_valu.py from a rocprofv3 --pmc run
+
+
+def profiled_valu(so_path, workload):
+    """SQ_INSTS_VALU (wavefront instructions) per launch of a workload's dominant kernels from the committed PMC summary
+    (profiles/valu_ops.json, tools/pmc_valu.py); {} when the summary belongs to another build of the library (sha256)."""
+    import hashlib
+    try:
+        t = json.load(open(VALU_OPS_FILE))
+        sha = hashlib.sha256(open(so_path, "rb").read()).hexdigest()
+    except Exception:
+        return {}
+    e = t.get(workload, {})
+    return e if e.get("lib_sha256") == sha else {}
+
+
+def valu_roofline(kernel, insts_valu, avg_ms, source, note):
+    """A kernel bound by vector-ALU issue (neither HBM nor the matrix cores): achieved = measured vector lane-operations per second
+    (SQ_INSTS_VALU x 64 lanes / the kernel's HIP-event time), peak = 39.3e12 unfused lane-ops/s (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz,
+    SURVEY 8d).  insts_valu is None when no counter summary of THIS build is committed: achieved / frac are then null."""
+    ach = (insts_valu * 64.0 / (avg_ms * 1e-3)) if (insts_valu and avg_ms > 0) else None
+    return {"kernel": kernel, "bound": "valu", "achieved": ach, "peak": FP64_VALU_LANE_OPS, "unit": "lane-op/s",
+            "frac": (ach / FP64_VALU_LANE_OPS) if ach else None, "traffic": None, "avg_launch_ms": avg_ms,
+            "insts_valu_per_launch": insts_valu, "counter_source": source, "note": note}
+
+
+def di_bench(args):
+    """BASELINE configs[3]: kinodynamic FMT* with the double-integrator steer BVP (linearquadratic.jl:175-225), R^4 state, N = 1e5.
+    One step = mpfmt_di_graph_step_device: steer of all N^2 ordered pairs (closed-form cost + safeguarded Newton for the optimal
+    time), the sparse cost matrix as a CSC in HBM, then the 5-waypoint collision sweep of every kept edge.  Single GPU."""
+    import torch
+    import motionplanning_jl_amd as mp
+    torch.cuda.set_device(0)
+    w = mp.workloads.cfg4(args.n) if args.n else mp.workloads.cfg4()
+    ctx = mp.Context(0)
+    ctx.upload_samples(w.X); ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+    steps, warm = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+    for _ in range(warm):
+        nnz = ctx.di_graph_step_device(w.rho, w.r)
+    torch.cuda.synchronize()
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nnz = ctx.di_graph_step_device(w.rho, w.r)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = 1e3 * dt / steps
+    t_cnt, t_fill, t_swp = ctx.timing("di_count")[0], ctx.timing("di_fill")[0], ctx.timing("di_sweep")[0]
+    pairs = float(w.N) * float(w.N - 1)
+    prof = profiled_valu(mp._lib.so_path(), w.name)
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        orc.lib()
+        sub, t_cpu, n_sub, nz_sub = 1000, 0.0, 0, 0
+        rng = np.random.default_rng(0)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 12.0:
+            S = np.sort(rng.choice(w.N, size=sub, replace=False))
+            t1 = time.perf_counter()
+            oc, orow, oval, otv = orc.di_pairwise(w.X[S], w.rho, w.r)
+            orc.di_graph_edges_free(w.X[S], w.rho, w.r, oc, orow, w.lohi, w.ss_lo, w.ss_hi)
+            t_cpu += time.perf_counter() - t1
+            n_sub += 1; nz_sub += len(orow)
+        cpu = {"value": nz_sub / t_cpu, "unit": "edges checked/s", "cores": 1, "kind": "port",
+               "steer_pairs_per_s": n_sub * sub * (sub - 1) / t_cpu,
+               "sample": "oracle orc_di_pairwise (count + fill passes, as helper_data_structures steers every pair) + the 5-waypoint sweep on %d "
+                         "random %d-sample subsets of the N=%d set (%d pairs, %d edges) in %.1f s, 1 thread of %d host cores"
+                         % (n_sub, sub, w.N, n_sub * sub * (sub - 1), nz_sub, t_cpu, os.cpu_count() or 1)}
+    out = {"metric": "edges checked/sec + steer BVPs/sec, kinodynamic FMT* graph (double integrator, R^4, N=%d; BASELINE configs[3]; not the headline metric)" % w.N,
+           "value": nnz * steps / dt, "unit": "edges checked/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": w.name, "N": w.N, "d": int(w.X.shape[1]), "M": int(len(w.lohi)), "rho": w.rho, "r": w.r, "nnz": int(nnz),
+                      "mean_degree": nnz / w.N,
+                      "step": "mpfmt_di_graph_step_device: steer of all N(N-1) ordered pairs -> CSC (cost, t*) -> 5-waypoint sweep of every edge; outputs in HBM"},
+           "submetrics": {"steer_pairs_per_s": pairs * steps / dt, "di_count_ms": t_cnt, "di_fill_ms": t_fill, "di_sweep_ms": t_swp,
+                          "sweep_edges_per_s": nnz / (t_swp * 1e-3) if t_swp > 0 else None,
+                          "pairs_past_the_prefilter": ctx.stat("survivors")},
+           "roofline": valu_roofline("k_di_pairs<2, 2> (all-pairs steer: prefilter, closed-form cost, Newton for t*, slot lists)",
+                                     prof.get("k_di_pairs"), t_cnt, prof.get("source"),
+                                     "algorithmic HBM bytes are negligible beside the arithmetic (N x 32 B of states read per tile pair from L2, 20 B written per "
+                                     "kept edge = %.2f GB per step): the kernel is priced against vector-ALU issue.  di_count_ms also holds the pilot pass "
+                                     "(every 32nd tile) that sizes the slot lists and its read-back" % (20.0 * nnz / 1e9)),
+           "roofline_sweep": valu_roofline("k_di_sweep<2> (lane = edge: x(t*, s) at 5 waypoints, 4 segments against the workspace boxes)",
+                                           prof.get("k_di_sweep"), t_swp, prof.get("source"),
+                                           "reads 12 B + 8 B per edge and two 32-byte states (gathered), writes 1 bit + 1 byte per edge"),
+           "cpu_baseline": cpu}
+    print(json.dumps(out))
+    ctx.close()
+
+
+def mc_bench(args):
+    """BASELINE configs[4]: Monte-Carlo / adaptive-importance-sampling collision probability of candidate edges, 1e6 trajectory rollouts
+    per edge, in the north star's world (R^6, 200 boxes).  One step = mpfmt_mc_edges_collision (plain) on E candidate edges; the
+    adaptive-IS estimator (pilot + mixture) is timed beside it.  Single GPU."""
+    import torch
+    import motionplanning_jl_amd as mp
+    torch.cuda.set_device(0)
+    w = mp.workloads.cfg2(args.n) if args.n else mp.workloads.cfg2()          # (the R^6 / 200-box world; the sample set only supplies edge end points)
+    E, R, sigma = 256, 1_000_000, 0.03
+    rng = np.random.default_rng(5)
+    src = rng.integers(1, w.N + 1, size=E)
+    # candidate edges as an FMT* step poses them: a sample and a neighbour within r
+    ctx = mp.Context(0)
+    ctx.upload_samples(w.X); ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+    dst = np.empty(E, dtype=np.int64)
+    for k, v in enumerate(src):
+        inds, _ = ctx.rdisc_query(int(v), w.r)
+        dst[k] = inds[rng.integers(0, len(inds))] if len(inds) else v
+    steps, warm = max(1, min(args.steps, 10)), max(1, min(args.warmup, 1))
+    for _ in range(warm):
+        hits = ctx.mc_edges_collision(src, dst, sigma, R, seed=11)
+    torch.cuda.synchronize()
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        hits = ctx.mc_edges_collision(src, dst, sigma, R, seed=11 + k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = 1e3 * dt / steps
+    t1 = time.perf_counter()
+    for k in range(steps):
+        p_ais, _, _ = ctx.mc_edges_collision_ais(src, dst, sigma, R, seed=11 + k)
+    torch.cuda.synchronize()
+    ms_ais = 1e3 * (time.perf_counter() - t1) / steps
+    prof = profiled_valu(mp._lib.so_path(), "cfg5_mc_r6_m200")
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        orc.lib()
+        Rc, t_cpu, n_cpu = 20000, 0.0, 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 12.0:
+            tb = time.perf_counter()
+            orc.mc_edges(w.X, src[:16] - 1, dst[:16] - 1, sigma, Rc, 11 + n_cpu, w.lohi, w.ss_lo, w.ss_hi)
+            t_cpu += time.perf_counter() - tb
+            n_cpu += 1
+        cpu = {"value": n_cpu * 16 * Rc / t_cpu, "unit": "rollouts/s", "cores": 1, "kind": "port",
+               "sample": "oracle orc_mc_edges (the scalar loop the GPU sums are exact against): %d x 16 edges x %d rollouts in %.1f s, 1 thread of %d host cores"
+                         % (n_cpu, Rc, t_cpu, os.cpu_count() or 1)}
+    p = hits / float(R)
+    out = {"metric": "trajectory rollouts/sec, Monte-Carlo collision probability of candidate edges (R^6, 200 boxes, 1e6 rollouts per edge; BASELINE configs[4]; "
+                     "not the headline metric)",
+           "value": E * R * steps / dt, "unit": "rollouts/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "cfg5_mc_r6_m200", "edges": E, "rollouts_per_edge": R, "sigma": sigma, "d": w.d, "M": int(len(w.lohi)),
+                      "step": "mpfmt_mc_edges_collision on %d candidate edges (host index arrays in, host counts out: 6 KB over PCIe inside the step)" % E},
+           "submetrics": {"edges_per_s": E * steps / dt, "mean_collision_probability": float(p.mean()), "edges_with_p_below_1e-4": int((p < 1e-4).sum()),
+                          "adaptive_is": {"ms_per_step": ms_ais, "rollouts_per_s": E * R / (ms_ais * 1e-3), "mean_probability": float(np.mean(p_ais)),
+                                          "note": "mpfmt_mc_edges_collision_ais: 4096-rollout pilot per edge, cross-entropy mean shift, mixture of the nominal and the "
+                                                  "shifted density; same rollout count"}},
+           "roofline": valu_roofline("k_mc_edges<6> (lane = rollout: 12 Philox4x32-10 draws, perturbed segment against the edge's culled boxes)",
+                                     prof.get("k_mc_edges"), ms, prof.get("source"),
+                                     "no HBM stream at all (inputs: two states and <= 200 boxes per edge, outputs: one count): integer / fp64 vector issue bound; "
+                                     "avg_launch_ms here is the whole call incl. the 6 KB of PCIe"),
+           "cpu_baseline": cpu}
+    print(json.dumps(out))
+    ctx.close()
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -193,7 +353,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="north_star", choices=["north_star", "cfg2", "cfg1", "cfg3", "cfg3_full"])
+    ap.add_argument("--workload", default="north_star", choices=["north_star", "cfg2", "cfg1", "cfg3", "cfg3_full", "cfg4", "cfg5"])
     ap.add_argument("--n", type=int, default=0, help="override the sample count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the whole-solve submetric (wavefront FMT*)")
@@ -205,6 +365,10 @@ def main():
 
     if args.workload == "cfg3_full":
         return stream_bench(args)
+    if args.workload == "cfg4":
+        return di_bench(args)
+    if args.workload == "cfg5":
+        return mc_bench(args)
     one_device = bool(os.environ.get("MPFMT_BENCH_ONE_DEVICE"))
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:

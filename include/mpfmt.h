@@ -348,6 +348,13 @@ MPFMT_API int32_t mpfmt_di_graph_fill(mpfmt_ctx* ctx, int64_t* rowval, double* n
 MPFMT_API int32_t mpfmt_di_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg);
 MPFMT_API int32_t mpfmt_di_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, int32_t m, double rho, double r,
                        double* cost, double* topt);
+/* The same graph and edge bits with every output left in HBM (the device-resident form of helper_data_structures,
+ * linearquadratic.jl:68-77,196-225, + the per-edge is_free_motion of src/statespaces.jl:153-158): count, fill and -- when an obstacle
+ * set is uploaded -- the 5-waypoint sweep, one host synchronisation at the end.  Pointers (device addresses, valid until the next
+ * build on the ctx): colptr int64[N+1] 0-based, rowval int32[nnz] 0-based ascending per column, nzval / tval double[nnz],
+ * free_mask uint64[ceil(nnz/64)] and nseg uint8[nnz] (NULL without a sweep). */
+MPFMT_API int32_t mpfmt_di_graph_step_device(mpfmt_ctx* ctx, double rho, double r, int64_t* nnz);
+MPFMT_API int32_t mpfmt_di_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** rowval, void** nzval, void** tval, void** free_mask, void** nseg);
 MPFMT_API int32_t mpfmt_di_fmtstar(mpfmt_ctx* ctx, double rho, double r, int64_t init_idx, int32_t checkpts,
                          int32_t goal_kind, const double* goal_params,
                          int64_t* A, double* C, int64_t* path, mpfmt_fmt_result* res);

@@ -101,6 +101,8 @@ SYMBOLS = [
     ("mpfmt_di_graph_count", C.c_int32, [C.c_void_p, C.c_double, C.c_double, c_i64_p, c_i64_p]),
     ("mpfmt_di_graph_fill", C.c_int32, [C.c_void_p, c_i64_p, c_d_p, c_d_p]),
     ("mpfmt_di_graph_edges_free", C.c_int32, [C.c_void_p, c_u64_p, c_u8_p]),
+    ("mpfmt_di_graph_step_device", C.c_int32, [C.c_void_p, C.c_double, C.c_double, c_i64_p]),
+    ("mpfmt_di_graph_device_ptrs", C.c_int32, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 6),
     ("mpfmt_di_steer", C.c_int32, [C.c_void_p, c_d_p, c_d_p, C.c_int64, C.c_int32, C.c_double, C.c_double, c_d_p, c_d_p]),
     ("mpfmt_di_fmtstar", C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32, c_d_p,
                                      c_i64_p, c_d_p, c_i64_p, C.POINTER(FmtResult)]),
@@ -738,6 +740,19 @@ class Context:
         nseg = np.zeros(max(n, 1), dtype=np.uint8)
         self._chk(self._L.mpfmt_di_graph_edges_free(self._h, _up(mask), nseg.ctypes.data_as(c_u8_p)))
         return mask[:nwords(n)], nseg[:n]
+
+    def di_graph_step_device(self, rho, r):
+        """Double-integrator graph + 5-waypoint edge bits, outputs left in HBM (see include/mpfmt.h).  Returns nnz."""
+        nnz = C.c_int64()
+        self._chk(self._L.mpfmt_di_graph_step_device(self._h, float(rho), float(r), C.byref(nnz)))
+        self.nnz = nnz.value
+        return nnz.value
+
+    def di_graph_device_ptrs(self):
+        """(colptr, rowval, nzval, tval, free_mask, nseg) device addresses of the resident double-integrator graph."""
+        p = [C.c_void_p() for _ in range(6)]
+        self._chk(self._L.mpfmt_di_graph_device_ptrs(self._h, *[C.byref(x) for x in p]))
+        return tuple(x.value for x in p)
 
     def di_steer(self, X0, X1, rho, r):
         X0 = np.ascontiguousarray(X0, dtype=np.float64)

@@ -10,7 +10,6 @@
 // reductions and polynomials from + - * / sqrt, the SAME header the CPU oracle compiles: results are bit-identical); fmod / sqrt are the device
 // libm's, so costs agree with a CPU libm to a few ulp rather than bit for bit (the tests bound it).
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #include "mpfmt_internal.h"
 #include "mp_math.h"
 #include "sat2d_predicates.h"
@@ -636,16 +635,7 @@ static int32_t car_check(mpfmt_ctx* ctx, double rt, double sp, double r)
     return MPFMT_OK;
 }
 
-static int32_t car_scan(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t n)
-{
-    size_t tb = 0;
-    HIPCHK(ctx, rocprim::exclusive_scan(nullptr, tb, in, out, (int64_t)0, n, rocprim::plus<int64_t>(), ctx->stream));
-    void* tmp;
-    int32_t rc;
-    if ((rc = mpfmt_scratch(ctx, tb + 256, &tmp))) return rc;
-    HIPCHK(ctx, rocprim::exclusive_scan(tmp, tb, in, out, (int64_t)0, n, rocprim::plus<int64_t>(), ctx->stream));
-    return MPFMT_OK;
-}
+static int32_t car_scan(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t n) { return mpfmt_scan_i64(ctx, in, out, n); }
 
 int32_t mpfmt_car_build(mpfmt_ctx* ctx, int kind, double rt, double sp, double r)
 {

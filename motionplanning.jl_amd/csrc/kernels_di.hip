@@ -654,44 +654,123 @@ int32_t mpfmt_di_steer_launch(mpfmt_ctx* ctx, int m, const double* dX0, const do
 }
 
 #include <cstring>
-#include <rocprim/rocprim.hpp>
-static int32_t scan64(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t n)
-{
-    size_t tmp_bytes = 0;
-    HIPCHK(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (int64_t)0, n, rocprim::plus<int64_t>(), ctx->stream));
-    void* tmp;
-    int32_t rc;
-    if ((rc = mpfmt_scratch(ctx, tmp_bytes, &tmp))) return rc;
-    HIPCHK(ctx, rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (int64_t)0, n, rocprim::plus<int64_t>(), ctx->stream));
-    return MPFMT_OK;
-}
+static int32_t scan64(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t n) { return mpfmt_scan_i64(ctx, in, out, n); }
 
 
 // ---- CSC -> CSR on the device (forward sets of the directed planners) ------------------------------------------------------
-// The host transposition is 8.6e7 random read-modify-writes at cfg4 (0.7 s); here: stable radix sort of the entries by row,
-// row pointers by binary search in the sorted keys, targets by binary search in colptr.
-__global__ void k_iota_u32(uint32_t* __restrict__ v, int64_t n)
+// The host transposition is 8.6e7 random read-modify-writes at cfg4 (0.7 s).  Here, hand-written (rocprim's radix sort until round 5):
+//   k_tr_count   : one returning atomic per entry on its ROW's counter -- the count, and the entry's arrival number in its row;
+//   scan         : row counts -> rowptr (the library's own scan);
+//   k_tr_scatter : (column, entry) to rowptr[row] + arrival number -- rows complete, in arrival order;
+//   k_tr_order   : one wavefront per row puts its entries into ascending COLUMN order (a row's columns are all different: the order is
+//                  total, so the result does not depend on the arrival order): bucket ranks through LDS like k_di_sortcols, counting
+//                  beyond TR_SORT_MAX entries.
+__global__ void k_tr_count(const int32_t* __restrict__ rowval, int64_t nnz, int64_t* __restrict__ rowcnt, uint32_t* __restrict__ arr)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = (uint32_t)i;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    arr[e] = (uint32_t)atomicAdd((unsigned long long*)&rowcnt[rowval[e]], 1ull);
 }
-__global__ void k_lower_bound_rows(const uint32_t* __restrict__ keys, int64_t n, int64_t N, int64_t* __restrict__ rowptr)
+// one wavefront per column (its entries are consecutive: coalesced reads, the column index is uniform)
+__global__ __launch_bounds__(256) void k_tr_scatter(const int64_t* __restrict__ colptr, int64_t N, const int32_t* __restrict__ rowval,
+                                                    const uint32_t* __restrict__ arr, const int64_t* __restrict__ rowptr,
+                                                    int32_t* __restrict__ tcol, uint32_t* __restrict__ tent)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > N) return;
-    int64_t lo = 0, hi = n;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)keys[mid] < i) lo = mid + 1; else hi = mid; }
-    rowptr[i] = lo;
+    const int lane = threadIdx.x & 63;
+    const int64_t wpg = blockDim.x >> 6;
+    for (int64_t j = (int64_t)blockIdx.x * wpg + (threadIdx.x >> 6); j < N; j += (int64_t)gridDim.x * wpg) {
+        const int64_t b = colptr[j], e1 = colptr[j + 1];
+        for (int64_t e = b + lane; e < e1; e += 64) {
+            const int64_t o = rowptr[rowval[e]] + (int64_t)arr[e];
+            tcol[o] = (int32_t)j; tent[o] = (uint32_t)e;
+        }
+    }
 }
-__global__ void k_entry_column(const int64_t* __restrict__ colptr, int64_t N, const uint32_t* __restrict__ centry, int64_t n,
-                               int32_t* __restrict__ colidx)
+#define TR_SORT_MAX 4096
+#define TR_SORT_BUCKETS 1024
+__global__ __launch_bounds__(64) void k_tr_order(const int64_t* __restrict__ rowptr, int64_t N, const int32_t* __restrict__ tcol,
+                                                 const uint32_t* __restrict__ tent, int32_t* __restrict__ colidx, uint32_t* __restrict__ centry,
+                                                 uint32_t bucket_mul)
 {
-    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n) return;
-    const int64_t e = centry[a];
-    int64_t lo = 0, hi = N;                                  // largest j with colptr[j] <= e
-    while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (colptr[mid] <= e) lo = mid; else hi = mid; }
-    colidx[a] = (int32_t)lo;
+    __shared__ int32_t s_cnt[TR_SORT_BUCKETS], s_base[TR_SORT_BUCKETS];
+    __shared__ int32_t s_key[TR_SORT_MAX];       // columns grouped by bucket
+    __shared__ uint16_t s_arr[TR_SORT_MAX];      // arrival number of entry e inside its bucket
+    const int lane = threadIdx.x;
+    auto bucket_of = [&](int32_t key) -> int {
+        return bucket_mul ? min(TR_SORT_BUCKETS - 1, (int)__umulhi((uint32_t)key, bucket_mul)) : (key & (TR_SORT_BUCKETS - 1));
+    };
+    for (int64_t row = blockIdx.x; row < N; row += gridDim.x) {
+        const int64_t beg = rowptr[row];
+        const int64_t k = rowptr[row + 1] - beg;
+        if (k == 0) continue;
+        if (k <= TR_SORT_MAX) {
+            const int kk = (int)k;
+            __syncthreads();
+            for (int b = lane; b < TR_SORT_BUCKETS; b += 64) s_cnt[b] = 0;
+            __syncthreads();
+            for (int e = lane; e < kk; e += 64) s_arr[e] = (uint16_t)atomicAdd(&s_cnt[bucket_of(tcol[beg + e])], 1);
+            __syncthreads();
+            {   // exclusive scan of the bucket counts: 16 consecutive counts per lane
+                constexpr int R = TR_SORT_BUCKETS / 64;
+                int loc[R]; int tot = 0;
+#pragma unroll
+                for (int q = 0; q < R; ++q) { loc[q] = tot; tot += s_cnt[lane * R + q]; }
+                int inc = tot;
+#pragma unroll
+                for (int o2 = 1; o2 < 64; o2 <<= 1) { const int up = __shfl_up(inc, o2); if (lane >= o2) inc += up; }
+                const int excl = inc - tot;
+#pragma unroll
+                for (int q = 0; q < R; ++q) s_base[lane * R + q] = excl + loc[q];
+            }
+            __syncthreads();
+            for (int e = lane; e < kk; e += 64) { const int32_t key = tcol[beg + e]; s_key[s_base[bucket_of(key)] + s_arr[e]] = key; }
+            __syncthreads();
+            for (int e = lane; e < kk; e += 64) {
+                const int32_t key = tcol[beg + e];
+                const int bk = bucket_of(key);
+                const int b0 = s_base[bk], n = s_cnt[bk];
+                int r = 0;
+                for (int m2 = 0; m2 < n; ++m2) r += (s_key[b0 + m2] < key) ? 1 : 0;
+                const int64_t o = beg + b0 + r;
+                colidx[o] = key;
+                centry[o] = tent[beg + e];
+            }
+            continue;
+        }
+        for (int64_t e0 = 0; e0 < k; e0 += 64) {
+            const int64_t e = e0 + lane;
+            const int32_t mine = (e < k) ? tcol[beg + e] : 0x7fffffff;
+            int64_t rank = 0;
+            for (int64_t jj = 0; jj < k; ++jj) rank += (tcol[beg + jj] < mine) ? 1 : 0;    // uniform (broadcast) loads
+            if (e < k) { colidx[beg + rank] = mine; centry[beg + rank] = tent[beg + e]; }
+        }
+    }
+}
+
+// rowptr [N + 1] (device), colidx / centry [nnz] (device): the CSR view of the resident CSC.  Scratch layout: arrival numbers |
+// unordered columns | unordered entries | scan temporary (the outputs may themselves lie in the ctx's scratch buffer: the caller passes
+// the offset its own part ends at)
+static int32_t tr_build(mpfmt_ctx* ctx, char* scr, int64_t* d_rowptr, int32_t* d_colidx, uint32_t* d_centry)
+{
+    const int64_t N = ctx->N, nnz = ctx->nnz;
+    const size_t w = sizeof(uint32_t) * (size_t)nnz;
+    uint32_t* arr = (uint32_t*)scr; int32_t* tcol = (int32_t*)(scr + w); uint32_t* tent = (uint32_t*)(scr + 2 * w);
+    void* stmp = scr + ((3 * w + 255) & ~(size_t)255);
+    HIPCHK(ctx, hipMemsetAsync(d_rowptr, 0, sizeof(int64_t) * (size_t)(N + 1), ctx->stream));
+    const unsigned nb = (unsigned)((nnz + 255) / 256);
+    hipLaunchKernelGGL(k_tr_count, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t*)ctx->rowval, nnz, d_rowptr, arr);
+    int32_t rc;
+    if ((rc = mpfmt_scan_i64_tmp(ctx, d_rowptr, d_rowptr, (size_t)(N + 1), stmp))) return rc;
+    hipLaunchKernelGGL(k_tr_scatter, dim3((unsigned)std::min<int64_t>((N + 3) / 4, 1 << 20)), dim3(256), 0, ctx->stream, ctx->colptr, N,
+                       (const int32_t*)ctx->rowval, arr, d_rowptr, tcol, tent);
+    hipLaunchKernelGGL(k_tr_order, dim3((unsigned)std::min<int64_t>(N, 1 << 20)), dim3(64), 0, ctx->stream, d_rowptr, N, tcol, tent, d_colidx, d_centry,
+                       N > TR_SORT_BUCKETS ? (uint32_t)(((uint64_t)TR_SORT_BUCKETS << 32) / (uint64_t)N) : 0u);
+    HIPCHK(ctx, hipGetLastError());
+    return MPFMT_OK;
+}
+static size_t tr_scratch_bytes(int64_t N, int64_t nnz)
+{
+    return ((3 * sizeof(uint32_t) * (size_t)nnz + 255) & ~(size_t)255) + mpfmt_scan_tmp_bytes((size_t)(N + 1)) + 256;
 }
 
 // the forward sets left on the device (rowptr [N+1], colidx [nnz]) for the wavefront driver
@@ -700,25 +779,12 @@ int32_t mpfmt_csc_transpose_resident(mpfmt_ctx* ctx, int64_t* d_rowptr, int32_t*
     const int64_t N = ctx->N, nnz = ctx->nnz;
     if (nnz >= ((int64_t)1 << 32)) return mpfmt_fail(ctx, MPFMT_ERR_CAPACITY, "graph too large for the device transpose");
     if (nnz == 0) { HIPCHK(ctx, hipMemsetAsync(d_rowptr, 0, sizeof(int64_t) * (size_t)(N + 1), ctx->stream)); return MPFMT_OK; }
-    int bits = 1;
-    while (((int64_t)1 << bits) < N) ++bits;
-    size_t tb = 0;
-    HIPCHK(ctx, rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                          (size_t)nnz, 0, bits, ctx->stream));
     const size_t w = sizeof(uint32_t) * (size_t)nnz;
-    const size_t off_ko = 0, off_vi = off_ko + w, off_vo = off_vi + w, off_t = (off_vo + w + 255) & ~(size_t)255;
     void* scr;
     int32_t rc;
-    if ((rc = mpfmt_scratch(ctx, off_t + tb + 256, &scr))) return rc;
-    uint32_t* ko = (uint32_t*)((char*)scr + off_ko); uint32_t* vi = (uint32_t*)((char*)scr + off_vi); uint32_t* vo = (uint32_t*)((char*)scr + off_vo);
-    const unsigned nb = (unsigned)((nnz + 255) / 256);
-    hipLaunchKernelGGL(k_iota_u32, dim3(nb), dim3(256), 0, ctx->stream, vi, nnz);
-    // stable sort of the entries by row: inside a row the entries keep CSC order = ascending target column
-    HIPCHK(ctx, rocprim::radix_sort_pairs((char*)scr + off_t, tb, (const uint32_t*)ctx->rowval, ko, vi, vo, (size_t)nnz, 0, bits, ctx->stream));
-    hipLaunchKernelGGL(k_lower_bound_rows, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, ctx->stream, ko, nnz, N, d_rowptr);
-    hipLaunchKernelGGL(k_entry_column, dim3(nb), dim3(256), 0, ctx->stream, ctx->colptr, N, vo, nnz, d_colidx);
-    HIPCHK(ctx, hipGetLastError());
-    return MPFMT_OK;
+    if ((rc = mpfmt_scratch(ctx, w + 256 + tr_scratch_bytes(N, nnz), &scr))) return rc;
+    uint32_t* ce = (uint32_t*)scr;                            // (the entries' places: not wanted by this caller)
+    return tr_build(ctx, (char*)scr + ((w + 255) & ~(size_t)255), d_rowptr, d_colidx, ce);
 }
 
 int32_t mpfmt_csc_transpose_device(mpfmt_ctx* ctx, mpfmt_csr_host* out)
@@ -729,29 +795,18 @@ int32_t mpfmt_csc_transpose_device(mpfmt_ctx* ctx, mpfmt_csr_host* out)
     out->colidx.resize((size_t)std::max<int64_t>(nnz, 1));
     out->centry.resize((size_t)std::max<int64_t>(nnz, 1));
     if (nnz == 0) return MPFMT_OK;
-    int bits = 1;
-    while (((int64_t)1 << bits) < N) ++bits;
-    size_t tb = 0;
-    HIPCHK(ctx, rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                          (size_t)nnz, 0, bits, ctx->stream));
     const size_t w = sizeof(uint32_t) * (size_t)nnz;
-    const size_t off_ko = 0, off_vi = off_ko + w, off_vo = off_vi + w, off_ci = off_vo + w, off_rp = (off_ci + w + 255) & ~(size_t)255,
+    const size_t off_ce = 0, off_ci = off_ce + w, off_rp = (off_ci + w + 255) & ~(size_t)255,
                  off_t = (off_rp + sizeof(int64_t) * (size_t)(N + 1) + 255) & ~(size_t)255;
     void* scr;
     int32_t rc;
-    if ((rc = mpfmt_scratch(ctx, off_t + tb + 256, &scr))) return rc;
-    uint32_t* ko = (uint32_t*)((char*)scr + off_ko); uint32_t* vi = (uint32_t*)((char*)scr + off_vi);
-    uint32_t* vo = (uint32_t*)((char*)scr + off_vo); int32_t* ci = (int32_t*)((char*)scr + off_ci);
+    if ((rc = mpfmt_scratch(ctx, off_t + tr_scratch_bytes(N, nnz), &scr))) return rc;
+    uint32_t* ce = (uint32_t*)((char*)scr + off_ce); int32_t* ci = (int32_t*)((char*)scr + off_ci);
     int64_t* rp = (int64_t*)((char*)scr + off_rp);
-    const unsigned nb = (unsigned)((nnz + 255) / 256);
-    hipLaunchKernelGGL(k_iota_u32, dim3(nb), dim3(256), 0, ctx->stream, vi, nnz);
-    HIPCHK(ctx, rocprim::radix_sort_pairs((char*)scr + off_t, tb, (const uint32_t*)ctx->rowval, ko, vi, vo, (size_t)nnz, 0, bits, ctx->stream));
-    hipLaunchKernelGGL(k_lower_bound_rows, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, ctx->stream, ko, nnz, N, rp);
-    hipLaunchKernelGGL(k_entry_column, dim3(nb), dim3(256), 0, ctx->stream, ctx->colptr, N, vo, nnz, ci);
-    HIPCHK(ctx, hipGetLastError());
+    if ((rc = tr_build(ctx, (char*)scr + off_t, rp, ci, ce))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(out->rowptr.data(), rp, sizeof(int64_t) * (size_t)(N + 1), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(out->colidx.data(), ci, w, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(out->centry.data(), vo, w, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out->centry.data(), ce, w, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return MPFMT_OK;
 }

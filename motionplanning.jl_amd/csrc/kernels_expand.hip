@@ -10,7 +10,6 @@
 // Integer / bit work only, plus one fp64 add per backward neighbour (C[y] + d(y,x), unfused).
 #include "mpfmt_internal.h"
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #include <algorithm>
 
 __device__ __forceinline__ bool bit_at(const uint64_t* m, int64_t i) { return (m[i >> 6] >> (i & 63)) & 1ull; }
@@ -115,9 +114,7 @@ int32_t mpfmt_launch_expand(mpfmt_ctx* ctx, const uint64_t* d_W, const uint64_t*
     if (nz == 0 || N == 0) return MPFMT_OK;
     int32_t rc;
     // scratch: cand[words] | cnt[words+1] | off[words+1] | xs0[cap] | src1[cap] | mask[capwords] | scan tmp
-    size_t tmp_bytes = 0;
-    HIPCHK(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0,
-                                        (size_t)(words + 1), rocprim::plus<int64_t>(), ctx->stream));
+    const size_t tmp_bytes = mpfmt_scan_tmp_bytes((size_t)(words + 1));
     const size_t o_cand = 0, o_cnt = o_cand + 8 * words, o_off = o_cnt + 8 * (words + 1), o_xs = o_off + 8 * (words + 1),
                  o_src = o_xs + 8 * cap, o_mask = o_src + 8 * cap, o_tmp = (o_mask + 8 * ((cap + 63) / 64 + 1) + 255) & ~(size_t)255;
     void* scr;
@@ -136,8 +133,7 @@ int32_t mpfmt_launch_expand(mpfmt_ctx* ctx, const uint64_t* d_W, const uint64_t*
                        d_W, d_F, cand);
     const int B = 256;
     hipLaunchKernelGGL(k_popc_words, dim3((unsigned)((words + 1 + B - 1) / B)), dim3(B), 0, ctx->stream, cand, words, cnt);
-    HIPCHK(ctx, rocprim::exclusive_scan(s + o_tmp, tmp_bytes, cnt, off, (int64_t)0, (size_t)(words + 1),
-                                        rocprim::plus<int64_t>(), ctx->stream));
+    if ((rc = mpfmt_scan_i64_tmp(ctx, cnt, off, (size_t)(words + 1), s + o_tmp))) return rc;
     int64_t nx = 0;
     HIPCHK(ctx, hipMemcpyAsync(&nx, off + words, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

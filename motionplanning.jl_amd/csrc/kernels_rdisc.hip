@@ -899,15 +899,24 @@ static void fill_args(mpfmt_ctx* ctx, double r, rdisc_args& a)
     a.pairs = ctx->d_pairs;
 }
 
-static int32_t scan_i64(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t n)
+// the library's exclusive int64 scan for the other translation units (block / single / add above): tmp holds mpfmt_scan_tmp_bytes(n)
+size_t mpfmt_scan_tmp_bytes(size_t n) { return sizeof(int64_t) * ((n + 4095) / 4096 + 1); }
+int32_t mpfmt_scan_i64_tmp(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t n, void* tmp)
 {
-    void* tmp;
-    int32_t rc;
-    if ((rc = mpfmt_scratch(ctx, sizeof(int64_t) * ((n + 4095) / 4096 + 1), &tmp))) return rc;
+    if (n == 0) return MPFMT_OK;
     launch_scan<int64_t>(ctx->stream, in, out, (int64_t)n, (int64_t*)tmp);
     HIPCHK(ctx, hipGetLastError());
     return MPFMT_OK;
 }
+// ... with the temporary taken from the ctx's scratch buffer (nothing else of the caller's may live there)
+int32_t mpfmt_scan_i64(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t n)
+{
+    void* tmp;
+    int32_t rc;
+    if ((rc = mpfmt_scratch(ctx, mpfmt_scan_tmp_bytes(n), &tmp))) return rc;
+    return mpfmt_scan_i64_tmp(ctx, in, out, n, tmp);
+}
+static int32_t scan_i64(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t n) { return mpfmt_scan_i64(ctx, in, out, n); }
 
 // device-side verdict of a speculative step: any capacity that did not hold sets the flag every later kernel checks
 __global__ void k_spec_check(const int32_t* __restrict__ pool_flag, const int32_t* __restrict__ list_max, int64_t list_cap,

@@ -8,7 +8,6 @@
 //   is_free_state(v, CC, SS) through the same point kernel as checkpts (kernels_sweep.hip);
 //   ordered compaction: per-64-candidate popcounts -> exclusive scan -> accepted candidate k goes to slot have + k.
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #include "mpfmt_internal.h"
 
 struct philox_out { uint32_t x[4]; };
@@ -152,8 +151,7 @@ static int32_t sample_free_impl(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const 
         const int64_t words = B / 64;
         void* scr;
         // scratch: candidates | mask | counts | offsets | scan temp
-        size_t temp_bytes = 0;
-        rocprim::exclusive_scan(nullptr, temp_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)words, rocprim::plus<int64_t>(), ctx->stream);
+        const size_t temp_bytes = mpfmt_scan_tmp_bytes((size_t)(words + 1));
         const size_t offP = 0, offM = offP + sizeof(double) * (size_t)B * d, offC = offM + sizeof(uint64_t) * (size_t)words,
                      offO = offC + sizeof(int64_t) * (size_t)(words + 1), offT = offO + sizeof(int64_t) * (size_t)(words + 1);
         if ((rc = mpfmt_scratch(ctx, offT + temp_bytes + 256, &scr))) return rc;
@@ -167,7 +165,7 @@ static int32_t sample_free_impl(mpfmt_ctx* ctx, uint64_t seed, int64_t N, const 
         if ((rc = mpfmt_launch_states_free(ctx, P, B, mask))) return rc;
         hipLaunchKernelGGL(k_popc_words, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, mask, words, cnt);
         HIPCHK(ctx, hipMemsetAsync(cnt + words, 0, sizeof(int64_t), ctx->stream));
-        HIPCHK(ctx, rocprim::exclusive_scan(temp, temp_bytes, cnt, off, (int64_t)0, (size_t)(words + 1), rocprim::plus<int64_t>(), ctx->stream));
+        if ((rc = mpfmt_scan_i64_tmp(ctx, cnt, off, (size_t)(words + 1), temp))) return rc;
         hipLaunchKernelGGL(k_sample_compact, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, ctx->stream, P, mask, off, B, d, have,
                            need, c0, W, d_att);
         HIPCHK(ctx, hipGetLastError());

@@ -22,7 +22,6 @@
 // one __ballot = one UInt64 chunk of a Julia BitVector (LSB = lowest edge index).
 #include "mpfmt_internal.h"
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #include <algorithm>
 
 #define SWEEP_THREADS 256
@@ -1864,12 +1863,11 @@ static int32_t launch_graph_sweep_rt(mpfmt_ctx* ctx, double rpad, const int32_t*
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_table, sizeof(sweep_rd) * (size_t)cap))) return rc;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_total, sizeof(int64_t)))) return rc;
     if ((rc = mpfmt_sweep_prepare_ss(ctx))) return rc;
-    size_t tmp_bytes = 0;
-    HIPCHK(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, ctx->rt_cnt, ctx->rt_off, (int64_t)0, (size_t)(ncol + 1), rocprim::plus<int64_t>(), ctx->stream));
+    const size_t tmp_bytes = mpfmt_scan_tmp_bytes((size_t)(ncol + 1));
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->rt_tmp, tmp_bytes))) return rc;
     const unsigned nbk = (unsigned)((ncol + 1 + 255) / 256);
     hipLaunchKernelGGL(k_round_count, dim3(nbk), dim3(256), 0, ctx->stream, ctx->colptr, sweep_perm, sp_begin, sp_end, ctx->rt_cnt, spec_fail);
-    HIPCHK(ctx, rocprim::exclusive_scan(ctx->rt_tmp, tmp_bytes, ctx->rt_cnt, ctx->rt_off, (int64_t)0, (size_t)(ncol + 1), rocprim::plus<int64_t>(), ctx->stream));
+    if ((rc = mpfmt_scan_i64_tmp(ctx, ctx->rt_cnt, ctx->rt_off, (size_t)(ncol + 1), ctx->rt_tmp))) return rc;
     const unsigned nbf = (unsigned)((((ncol + 63) / 64 + 1) * 64 + 255) / 256);       // one wavefront per 64 columns + the one that pads and totals
     hipLaunchKernelGGL(k_round_fill, dim3(nbf), dim3(256), 0, ctx->stream, ctx->colptr, sweep_perm, sp_begin, sp_end, ctx->rt_off,
                        (sweep_rd*)ctx->rt_table, cap, ctx->rt_total, spec_fail);

@@ -1208,6 +1208,34 @@ int32_t mpfmt_di_graph_edges_free(mpfmt_ctx* ctx, uint64_t* mask, uint8_t* nseg)
     return MPFMT_OK;
 }
 
+// the double-integrator graph and its edge bits with every output left in HBM (bench.py --workload cfg4: no PCIe in the timed region)
+int32_t mpfmt_di_graph_step_device(mpfmt_ctx* ctx, double rho, double r, int64_t* nnz)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    int32_t rc;
+    if ((rc = di_check(ctx, rho, r))) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = mpfmt_di_count(ctx, rho, r))) return rc;
+    if ((rc = mpfmt_di_fill(ctx))) return rc;
+    if (ctx->have_boxes && (rc = mpfmt_di_sweep(ctx))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (nnz) *nnz = ctx->nnz;
+    return MPFMT_OK;
+}
+
+int32_t mpfmt_di_graph_device_ptrs(mpfmt_ctx* ctx, void** colptr, void** rowval, void** nzval, void** tval, void** free_mask, void** nseg)
+{
+    if (!ctx) return MPFMT_ERR_ARG;
+    if (!ctx->di_filled || ctx->steer_kind != 1) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no double-integrator graph resident");
+    if (colptr) *colptr = ctx->colptr;
+    if (rowval) *rowval = ctx->rowval;
+    if (nzval) *nzval = ctx->nzval;
+    if (tval) *tval = ctx->tval;
+    if (free_mask) *free_mask = ctx->di_swept ? (void*)ctx->graph_free : nullptr;
+    if (nseg) *nseg = ctx->di_swept ? (void*)ctx->di_nseg : nullptr;
+    return MPFMT_OK;
+}
+
 int32_t mpfmt_di_steer(mpfmt_ctx* ctx, const double* X0, const double* X1, int64_t n, int32_t m, double rho, double r,
                        double* cost, double* topt)
 {

@@ -358,6 +358,10 @@ int32_t mpfmt_launch_sample_masks(mpfmt_ctx* ctx, double r, void* zero = nullptr
 int32_t mpfmt_rdisc_stream_impl(mpfmt_ctx* ctx, double r, const double* C_host, const uint64_t* H_host, int32_t want_free,
                                 int64_t* deg, int64_t* nfree, int64_t* parent, double* cost, int64_t* nnz_out);
 int32_t mpfmt_launch_exact_pairs(mpfmt_ctx* ctx, const int32_t* spec_fail);
+// the library's own exclusive scan of int64 items on ctx->stream (k_scan_block / _single / _add, kernels_rdisc.hip); in == out allowed
+size_t mpfmt_scan_tmp_bytes(size_t n);
+int32_t mpfmt_scan_i64_tmp(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t n, void* tmp);      // tmp: mpfmt_scan_tmp_bytes(n) bytes of device memory
+int32_t mpfmt_scan_i64(mpfmt_ctx* ctx, const int64_t* in, int64_t* out, size_t n);                     // tmp from the ctx's scratch buffer
 int32_t mpfmt_launch_rdisc_query(mpfmt_ctx* ctx, int64_t v0, double r, int64_t* k_out,
                                  int64_t* inds_host, double* ds_host, int64_t cap);
 
