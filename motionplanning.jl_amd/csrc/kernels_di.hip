@@ -108,6 +108,7 @@ struct di_args {
     int64_t N;
     double rho, r;
     double i2, i3, i4;          // 1/r^2, 1/r^3, 1/r^4 for the multiply-only candidate pre-test
+    double r2;                  // r^2 (the second pre-test)
     int32_t S;                  // source slices per target tile
     int64_t ntiles;
     int32_t* slice_cnt;         // [S][ntiles*64]
@@ -218,7 +219,15 @@ __global__ __launch_bounds__(64) void k_di_pairs(di_args a)
             const double ta = 36.0 * ca * a.i4, tb = 24.0 * cb * a.i3, tc = 4.0 * cc * a.i2;
             const double cd = 1.0 - a.rho * ((ta - tb) + tc);
             const double slack = 1e-9 * (1.0 + a.rho * ((ta + fabs(tb)) + tc));
-            const bool pend = jact && (c0 + ii != j) && (cd > -slack);
+            // A second multiply-only test, for the other end of the reference's pipeline (`cost <= r` AFTER the Newton iteration,
+            // linearquadratic.jl:221): cost(t) = t + rho (12 a u^3 - 12 b u^2 + 4 c u), u = 1/t, = t + rho u q(u) with the quadratic
+            // q(u) = 12 a u^2 - 12 b u + 4 c >= m = 4 c - 3 b^2 / a (its minimum; a > 0), so cost(t) >= t + rho m / t >= 2 sqrt(rho m)
+            // for EVERY t > 0 -- wherever the iteration stops.  4 rho (4 a c - 3 b^2) > a r^2 therefore proves cost > r: the pair is
+            // dropped here instead of being steered and dropped there (same graph; 6.4 % of the pairs pass the first test, 1.8 % both,
+            // 0.87 % are edges at BASELINE configs[3]).  The margins (1e-9 relative on both sides) dwarf the rounding of either form.
+            const double l1 = 4.0 * ca * cc, l2 = 3.0 * cb * cb;
+            const bool far = 4.0 * a.rho * (l1 - l2) > (ca * a.r2) * (1.0 + 1e-9) + 4e-9 * a.rho * (l1 + l2);
+            const bool pend = jact && (c0 + ii != j) && (cd > -slack) && !far;
             const unsigned long long pm = __ballot(pend);
             if (pm) {
                 if (qcount > DI_QCAP - 64) drain(64);
@@ -496,7 +505,7 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
     ctx->deg_zero_valid = false;         // (this build writes every column's degree: a sharded r-disc step must not trust its own zeros any more)
     di_args a;
     a.X = ctx->Xo; a.N = N; a.rho = rho; a.r = r;
-    a.i2 = 1.0 / (r * r); a.i3 = a.i2 / r; a.i4 = a.i2 * a.i2;
+    a.i2 = 1.0 / (r * r); a.i3 = a.i2 / r; a.i4 = a.i2 * a.i2; a.r2 = r * r;
     a.S = S; a.ntiles = ntiles; a.slice_cnt = ctx->slice_cnt; a.colptr = ctx->colptr;
     a.rowtmp = nullptr; a.valtmp = nullptr; a.tvaltmp = nullptr; a.counters = ctx->d_pairs;
     a.tile_step = 1; a.pool_i = nullptr; a.pool_c = nullptr; a.pool_t = nullptr; a.pool_cap = 0; a.pool_flag = nullptr;
@@ -589,7 +598,7 @@ int32_t mpfmt_di_fill(mpfmt_ctx* ctx)
     const int64_t ntiles = (N + 63) / 64;
     di_args a;
     a.X = ctx->Xo; a.N = N; a.rho = ctx->di_rho; a.r = ctx->di_r;
-    a.i2 = 1.0 / (a.r * a.r); a.i3 = a.i2 / a.r; a.i4 = a.i2 * a.i2;
+    a.i2 = 1.0 / (a.r * a.r); a.i3 = a.i2 / a.r; a.i4 = a.i2 * a.i2; a.r2 = a.r * a.r;
     a.S = ctx->di_S; a.ntiles = ntiles; a.slice_cnt = ctx->slice_cnt; a.colptr = ctx->colptr;
     a.rowtmp = ctx->rowtmp; a.valtmp = ctx->valtmp; a.tvaltmp = ctx->tvaltmp; a.counters = nullptr;
     a.tile_step = 1; a.pool_i = nullptr; a.pool_c = nullptr; a.pool_t = nullptr; a.pool_cap = 0; a.pool_flag = nullptr;
