@@ -353,7 +353,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="north_star", choices=["north_star", "cfg2", "cfg1", "cfg3", "cfg3_full", "cfg4", "cfg5"])
+    ap.add_argument("--workload", default="north_star", choices=["north_star", "cfg2", "cfg1", "cfg3", "cfg3_full", "cfg4", "cfg5", "ns_clustered"])
     ap.add_argument("--n", type=int, default=0, help="override the sample count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the whole-solve submetric (wavefront FMT*)")

@@ -25,6 +25,7 @@ class Workload:
     ss_lo: np.ndarray
     ss_hi: np.ndarray
     seed: int = 0
+    draw: object = None    # non-uniform sample sets: draw(stream, N, d) -> (N, d) samples (None: i.i.d. uniform)
 
     @property
     def N(self):
@@ -109,7 +110,8 @@ def resample(w, k):
     the same N, init first, goal centre last, same obstacles and radius.  Stream seed = w.seed + 1000 k (pinned like every other)."""
     if k == 0:
         return w.X
-    X = Stream(w.seed + 1000 * k).random((w.N, w.d))
+    rng = Stream(w.seed + 1000 * k)
+    X = w.draw(rng, w.N, w.d) if w.draw else rng.random((w.N, w.d))
     X[0] = w.init
     X[-1] = w.goal_center
     return X
@@ -138,7 +140,43 @@ def cfg3(N=1_000_000, deg=256.0):
     return make("cfg3_r12_n1m_m200", N, d, 200, 0.20, 0.35, seed=4, r=r)
 
 
-BY_NAME = {"cfg1": cfg1, "cfg2": cfg2, "north_star": north_star, "cfg3": cfg3}
+def _box_muller(rng, n):
+    """n standard normals from 2 ceil(n/2) uniforms of the stream (Box-Muller, both branches)."""
+    m = (n + 1) // 2
+    u1 = 1.0 - rng.random(m)                       # (0, 1]
+    u2 = rng.random(m)
+    rad = np.sqrt(-2.0 * np.log(u1))
+    return np.concatenate([rad * np.cos(2 * np.pi * u2), rad * np.sin(2 * np.pi * u2)])[:n]
+
+
+def clustered_draw(frac=0.3, sigma=0.25, center=0.5):
+    """Sample sets that are NOT uniform: a fraction `frac` of the samples from an isotropic Gaussian (sigma per axis, redrawn uniformly
+    when it leaves the unit cube), the rest i.i.d. uniform -- at frac = 0.3, sigma = 0.25 in R^6 the density at the centre is ~5.7 x the
+    uniform one and 0.7 x far from it: what a planner's sample set looks like after goal / obstacle-aware sampling.  The clustered samples
+    are interleaved with the uniform ones (every sample decides by its own uniform), as a sampler with a bias probability emits them."""
+    def draw(rng, N, d):
+        X = rng.random((N, d))
+        pick = rng.random(N) < frac
+        G = center + sigma * _box_muller(rng, N * d).reshape(N, d)
+        ok = pick & np.all((G >= 0.0) & (G < 1.0), axis=1)
+        X[ok] = G[ok]
+        return X
+    return draw
+
+
+def north_star_clustered(N=1_000_000):
+    """The north star's world (R^6, 200 boxes, the fmt.jl:39 radius of N uniform samples) with CLUSTERED samples (clustered_draw): the
+    throughput-under-non-uniform-density workload: ~1.6 x the edges of the uniform set, columns up to ~6 x the mean."""
+    w = make("ns_r6_n1m_m200_clustered", N, 6, 200, 0.10, 0.20, seed=7)
+    w.draw = clustered_draw()
+    rng = Stream(w.seed + 500)
+    X = w.draw(rng, N, 6)
+    X[0] = w.init; X[-1] = w.goal_center
+    w.X = X
+    return w
+
+
+BY_NAME = {"cfg1": cfg1, "cfg2": cfg2, "north_star": north_star, "cfg3": cfg3, "ns_clustered": north_star_clustered}
 
 
 @dataclass

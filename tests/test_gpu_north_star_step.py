@@ -101,6 +101,55 @@ def test_north_star_step_path(orc):
             del cols, k1, k2, d, colptr, rowval, nzval, free, t
 
 
+def test_clustered_samples_at_the_north_star_size(orc):
+    """Throughput under NON-UNIFORM samples is only worth reporting if the timed form survives them: the north star's
+    world with 30 % of the samples in a Gaussian cluster (workloads.north_star_clustered: density ~5.7 x uniform at the centre, columns several
+    times the mean).  The cold call may have to redo its build (the log capacity of a cold ctx assumes a uniform density); from the SECOND
+    step on -- repeats and NEW clustered sample sets alike -- the step must run as (matrix-core pair kernel, half build, fused edge tests)
+    with no build redone.  Graph and mask against the oracle on sampled columns / edges, the densest columns included."""
+    import torch
+    w = mp.workloads.north_star_clustered()
+    N = w.N
+    rng = np.random.default_rng(43)
+    with mp.Context(0) as c:
+        c.set_option("rebuild_index", 1)
+        c.upload_samples(w.X); c.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+        redo = []
+        for it in range(3):
+            nnz = c.graph_step_device(w.r)
+            redo.append(c.stat("redo_count"))
+            form = (c.stat("rdisc_path_used"), c.stat("rdisc_half_used"), c.stat("sweep_form"))
+            if it >= 1:
+                assert form == (2, 1, 2), (it, form)
+                assert redo[it] == redo[it - 1], (it, redo, c.stat("redo_reason"))
+            if it != 1:
+                colptr, rowval, nzval, free = _resident_graph(c, N)
+                assert nnz == colptr[-1] and nnz > 1.2 * 107492200        # (the cluster adds edges: the density enters squared)
+                deg = np.diff(colptr)
+                assert deg.max() > 4 * deg.mean()                          # ... and long columns
+                _check_against_oracle(orc, w.X, w.r, w.lohi, w.ss_lo, w.ss_hi, colptr, rowval, nzval, free, rng, ncols=200, nedges=200000)
+                kd = orc.KDTree(w.X)
+                for v in np.argsort(deg)[-20:]:                            # the longest columns
+                    oi, od = kd.inball(int(v), w.r)
+                    a, b = int(colptr[v]), int(colptr[v + 1])
+                    assert np.array_equal(rowval[a:b], oi) and np.array_equal(nzval[a:b], od), v
+                del colptr, rowval, nzval, free, kd
+        for k in (1, 2):                                                   # new clustered sample sets of the same (N, r): bench.py's timed loop
+            X2 = mp.workloads.resample(w, k)
+            t = torch.from_numpy(X2).to("cuda:0")
+            torch.cuda.synchronize()
+            c.upload_samples_device(t.data_ptr(), N, w.d)
+            nnz = c.graph_step_device(w.r)
+            assert (c.stat("rdisc_path_used"), c.stat("rdisc_half_used"), c.stat("sweep_form")) == (2, 1, 2), k
+            assert c.stat("redo_count") == redo[-1], (k, c.stat("redo_count"), redo, c.stat("redo_reason"))
+            if k == 2:
+                colptr, rowval, nzval, free = _resident_graph(c, N)
+                assert nnz == colptr[-1]
+                _check_against_oracle(orc, X2, w.r, w.lohi, w.ss_lo, w.ss_hi, colptr, rowval, nzval, free, rng, ncols=200, nedges=200000)
+                del colptr, rowval, nzval, free
+            del t
+
+
 def test_upload_samples_device_equals_host_upload(orc):
     """mpfmt_upload_samples_device against mpfmt_upload_samples: same bounding box (hence the same grid), same graph and mask;
     a non-finite coordinate is refused."""
