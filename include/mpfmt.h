@@ -536,6 +536,8 @@ MPFMT_API int32_t mpfmt_timing_get(mpfmt_ctx* ctx, const char* name, double* avg
  * kernel, slab tests of the flagged pairs before the columns are ordered, the ordering pass writes the mask; 1 = flagged entries
  * tested after the ordering; 0 = the separate sweep kernel.  Same graph and mask bits in every combination; a sweep called on
  * its own (mpfmt_graph_sweep_device, mpfmt_graph_edges_free) is always the whole sweep.
+ * "di_path" (default 0 = auto): the double-integrator build's candidate test on the vector ALUs (1) or as an fp16 bilinear form on the
+ * matrix cores in front of the same fp64 tests (2; workspace dim <= 2 and a threshold the fp16 error bound leaves meaningful); same graph.
  * "wf_graphs" (default 0): a measured alternative kept for the record (LABNOTES.md).
  * "mf_target_items" (default 40000): work items (tile x slice of its chunk list, one wavefront each) the MFMA pair kernel aims for; the
  * slice count is made odd.  "mf_xcd_mode" (default -1 = by launch size): items reach the XCDs in interleaved groups of this many

@@ -19,110 +19,7 @@
 #include <algorithm>
 #include <cmath>
 
-#define DI_QCAP 256
-
-struct di_coef { double a, b, c; };     // |p|^2, p.(v0+v1), |v0|^2 + v0.v1 + |v1|^2
-
-template <int M>
-__device__ __forceinline__ di_coef di_coefs(const double* x0, const double* x1)
-{
-    di_coef k = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-        const double p = x1[i] - x0[i];
-        const double v0 = x0[M + i], v1 = x1[M + i];
-        k.a = k.a + p * p;
-        k.b = k.b + p * (v0 + v1);
-        k.c = k.c + ((v0 * v0 + v0 * v1) + v1 * v1);
-    }
-    return k;
-}
-__device__ __forceinline__ double di_cost(di_coef k, double rho, double t)
-{
-    const double t2 = t * t, t3 = t2 * t;
-    return t + rho * ((12.0 * k.a / t3 - 12.0 * k.b / t2) + 4.0 * k.c / t);
-}
-__device__ __forceinline__ double di_dcost(di_coef k, double rho, double t)
-{
-    const double t2 = t * t, t3 = t2 * t, t4 = t2 * t2;
-    return 1.0 - rho * ((36.0 * k.a / t4 - 24.0 * k.b / t3) + 4.0 * k.c / t2);
-}
-__device__ __forceinline__ double di_ddcost(di_coef k, double rho, double t)
-{
-    const double t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
-    return rho * ((144.0 * k.a / t5 - 72.0 * k.b / t4) + 8.0 * k.c / t3);
-}
-// topt_newton, linearquadratic.jl:175-190 (tol = 1e-6)
-__device__ __forceinline__ double di_topt_newton(di_coef k, double rho, double tm)
-{
-    const double tol = 1e-6;
-    double b = tm;
-    if (di_dcost(k, rho, b) < 0) return tm;
-    double a = tm / 100;
-    while (di_dcost(k, rho, a) > 0) a /= 2;
-    double t = tm / 2;
-    double cdval = di_dcost(k, rho, t);
-    while (fabs(cdval) > tol && fabs(a - b) > tol) {
-        t = t - cdval / di_ddcost(k, rho, t);
-        if (t < a || t > b) t = (a + b) / 2;
-        cdval = di_dcost(k, rho, t);
-        if (cdval > 0) b = t; else a = t;
-    }
-    return t;
-}
-// steer, linearquadratic.jl:191-195
-template <int M>
-__device__ __forceinline__ void di_steer(const double* x0, const double* x1, double rho, double r, double& cost, double& topt)
-{
-    int same = 1;
-#pragma unroll
-    for (int i = 0; i < 2 * M; ++i) same &= (int)(x0[i] == x1[i]);
-    if (same) { cost = 0.0; topt = 0.0; return; }
-    const di_coef k = di_coefs<M>(x0, x1);
-    const double t = di_topt_newton(k, rho, r);
-    cost = di_cost(k, rho, t);
-    topt = t;
-}
-// x(v, w, t, s): state on the optimal trajectory (closed form of the SymPy `x` closure, :137-138,156)
-template <int M>
-__device__ __forceinline__ void di_state(const double* x0, const double* x1, double t, double s, double* out)
-{
-    const double t2 = t * t, t3 = t2 * t;
-    const double s2 = s * s, s3 = s2 * s;
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-        const double v0 = x0[M + i], v1 = x1[M + i];
-        const double dp = (x1[i] - x0[i]) - t * v0;
-        const double dv = v1 - v0;
-        const double d1 = 12.0 * dp / t3 - 6.0 * dv / t2;
-        const double d2 = -6.0 * dp / t2 + 4.0 * dv / t;
-        const double e = (t - s) * d1 + d2;
-        out[i] = (x0[i] + s * v0) + (s3 / 3.0 * d1 + s2 / 2.0 * e);
-        out[M + i] = v0 + (s2 / 2.0 * d1 + s * e);
-    }
-}
-
-// ---- all-pairs sparse cost graph -----------------------------------------------------------------------------
-struct di_args {
-    const double* X;            // [N][2M] states, caller order
-    int64_t N;
-    double rho, r;
-    double i2, i3, i4;          // 1/r^2, 1/r^3, 1/r^4 for the multiply-only candidate pre-test
-    double r2;                  // r^2 (the second pre-test)
-    int32_t S;                  // source slices per target tile
-    int64_t ntiles;
-    int32_t* slice_cnt;         // [S][ntiles*64]
-    const int64_t* colptr;
-    int32_t* rowtmp;
-    double* valtmp;
-    double* tvaltmp;
-    unsigned long long* counters;   // [0] pairs tested, [1] candidates
-    int64_t tile_step;              // 1; > 1 for the pilot launch that only visits every tile_step-th tile
-    // single-pass slot lists (MODE 2): accepted hits kept per (item, target lane)
-    int32_t* pool_i; double* pool_c; double* pool_t;
-    int64_t pool_cap;
-    int32_t* pool_flag;
-};
+#include "di_steer.h"
 
 // MODE 0: count   1: fill the staging CSC from the counts   2: count AND keep the accepted hits in slot lists (single pass)
 template <int M, int MODE>
@@ -509,6 +406,16 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
     a.S = S; a.ntiles = ntiles; a.slice_cnt = ctx->slice_cnt; a.colptr = ctx->colptr;
     a.rowtmp = nullptr; a.valtmp = nullptr; a.tvaltmp = nullptr; a.counters = ctx->d_pairs;
     a.tile_step = 1; a.pool_i = nullptr; a.pool_c = nullptr; a.pool_t = nullptr; a.pool_cap = 0; a.pool_flag = nullptr;
+    // the candidate test on the matrix cores where it applies (kernels_di_mfma.hip): operands once per build
+    bool mf = false;
+    float negT = 0.f;
+    if (ctx->di_path != 1) {
+        double sp = 0.0, sv = 0.0, pc[2] = {0.0, 0.0};
+        if ((rc = mpfmt_di_mf_prepare(ctx, rho, r, &negT, &mf, &sp, &sv, pc))) return rc;
+        if (!mf && ctx->di_path == 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "di_path = 2: the matrix-core prefilter does not apply here (workspace dim > 2, or the fp16 error bound is not small against 1 / rho)");
+        if (mf && (rc = mpfmt_di_mf_build_operands(ctx, sp, sv, pc))) return rc;
+    }
+    ctx->di_mf = mf; ctx->di_negT = negT;
     mpfmt_timed tm1(ctx);
     // Single pass: the accepted hits of the count pass are kept in slot lists, so the pairs are not steered twice.  The
     // list capacity comes from a pilot over every 32nd tile (tiles are in caller order, i.e. statistically alike); an
@@ -530,7 +437,8 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
         }
         pa.slice_cnt = pcnt;
         HIPCHK(ctx, hipMemsetAsync(pcnt, 0, sizeof(int32_t) * (size_t)pa.S * npad, ctx->stream));
-        DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, 0>), dim3((unsigned)(ptiles * pa.S)), dim3(64), 0, ctx->stream, pa));
+        if (mf) { if ((rc = mpfmt_di_mf_launch(ctx, pa, 0, negT, (unsigned)(ptiles * pa.S)))) return rc; }
+        else { DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, 0>), dim3((unsigned)(ptiles * pa.S)), dim3(64), 0, ctx->stream, pa)); }
         std::vector<int32_t> sc((size_t)pa.S * npad);
         HIPCHK(ctx, hipMemcpyAsync(sc.data(), pcnt, sizeof(int32_t) * sc.size(), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -558,7 +466,8 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
         }
     }
     if (ntiles > 0) {
-        if (pool) { DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, 2>), dim3((unsigned)(ntiles * S)), dim3(64), 0, ctx->stream, a)); }
+        if (mf) { if ((rc = mpfmt_di_mf_launch(ctx, a, pool ? 2 : 0, negT, (unsigned)(ntiles * S)))) return rc; }
+        else if (pool) { DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, 2>), dim3((unsigned)(ntiles * S)), dim3(64), 0, ctx->stream, a)); }
         else { DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, 0>), dim3((unsigned)(ntiles * S)), dim3(64), 0, ctx->stream, a)); }
         hipLaunchKernelGGL(k_di_degree, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, ctx->slice_cnt, S, npad, N, ctx->deg);
         HIPCHK(ctx, hipGetLastError());
@@ -608,6 +517,8 @@ int32_t mpfmt_di_fill(mpfmt_ctx* ctx)
             hipLaunchKernelGGL(k_di_gather_slots, dim3((unsigned)std::min<int64_t>(N, 1 << 20)), dim3(64), 0, ctx->stream, ctx->di_pool_i,
                                ctx->di_pool_c, ctx->di_pool_t, ctx->di_pool_cap, a.S, ctx->slice_cnt, ntiles * 64, N, ctx->colptr,
                                ctx->rowtmp, ctx->valtmp, ctx->tvaltmp);
+        } else if (ctx->di_mf) {
+            if ((rc = mpfmt_di_mf_launch(ctx, a, 1, ctx->di_negT, (unsigned)(ntiles * a.S)))) return rc;      // (the count's own slices: whole chunks)
         } else {
             DISPATCH_M(m, hipLaunchKernelGGL((k_di_pairs<DM, 1>), dim3((unsigned)(ntiles * a.S)), dim3(64), 0, ctx->stream, a));
         }

@@ -263,6 +263,9 @@ struct mpfmt_ctx {
     bool di_counted = false, di_filled = false, di_swept = false;
     int32_t* di_pool_i = nullptr; double* di_pool_c = nullptr; double* di_pool_t = nullptr;   // DI single-pass slot lists
     int64_t di_pool_cap = 0; bool di_pool_valid = false;
+    void* di_ops = nullptr;              // matrix-core prefilter of the double-integrator build (kernels_di_mfma.hip): target- and source-role operands
+    bool di_mf = false; float di_negT = 0.f;     // the counted DI graph went through it; its threshold
+    int32_t di_path = 0;                 // option: 0 auto, 1 vector-ALU candidate test, 2 matrix-core prefilter
     int32_t steer_kind = 1;              // which steering graph the di_* state describes: 1 double integrator, 2 Dubins car, 3 Reeds-Shepp car
     double car_rt = 1.0, car_sp = 1.0;   // Dubins turning radius / speed of the built graph
     uint64_t* car_keep = nullptr;        // keep bits over the candidate (positions) graph
@@ -390,6 +393,10 @@ int32_t mpfmt_car_build(mpfmt_ctx* ctx, int kind, double rt, double sp, double r
 int32_t mpfmt_car_sweep(mpfmt_ctx* ctx);
 int32_t mpfmt_car_steer_batch(mpfmt_ctx* ctx, int kind, const double* d_X0, const double* d_X1, int64_t n, double rt, double sp, double* d_cost,
                               double* d_ctrl, int32_t* d_nseg);
+struct di_args;
+int32_t mpfmt_di_mf_prepare(mpfmt_ctx* ctx, double rho, double r, float* negT, bool* usable, double* sp_out, double* sv_out, double* pc);      // kernels_di_mfma.hip
+int32_t mpfmt_di_mf_build_operands(mpfmt_ctx* ctx, double sp, double sv, const double* pc_host);
+int32_t mpfmt_di_mf_launch(mpfmt_ctx* ctx, const di_args& a, int mode, float negT, unsigned nblk);
 int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r);
 int32_t mpfmt_di_fill(mpfmt_ctx* ctx);
 int32_t mpfmt_di_sweep(mpfmt_ctx* ctx);

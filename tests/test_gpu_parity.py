@@ -505,6 +505,46 @@ def test_di_graph_and_sweep(ctx, orc, N, rho, r):
     assert nseg.max() <= 4
 
 
+@pytest.mark.parametrize("m,N,rho,r,scale,offset", [(2, 3000, 1.0, 0.8, 1.0, 0.0), (2, 5000, 0.5, 1.1, 1.0, 0.0), (2, 4500, 2.0, 0.6, 1.0, 0.0),
+                                                 (2, 3000, 1.0, 0.9, 1.0, 50.0), (2, 3000, 1.0, 5.0, 7.0, -3.0), (1, 2500, 1.0, 0.7, 1.0, 0.0),
+                                                 (1, 2000, 3.0, 0.6, 1.0, 10.0), (2, 70, 1.0, 1.0, 1.0, 0.0), (2, 4097, 1.0, 0.25, 1.0, 0.0)])
+def test_di_matrix_core_prefilter_equals_the_vector_alu_test(orc, m, N, rho, r, scale, offset):
+    """The double-integrator build with its candidate test as an fp16 bilinear form on the matrix cores (option di_path = 2) against the
+    vector-ALU form (1) and the oracle: the same graph, costs and optimal times bit for bit -- and the same NUMBER of pairs reaching the
+    Newton iteration (stat `survivors`): both forms apply the identical fp64 tests behind their filter, so a pair the fp16 filter wrongly
+    dropped would show as a smaller count before it showed as a missing edge.  Radii small and large against the samples' extent, positions
+    far from the origin (the form is centred), scaled workspaces, other rho, one-dimensional workspaces, a set smaller than two tiles."""
+    rng = np.random.default_rng(300 + N + m)
+    vmax = 0.5 * scale
+    X = np.concatenate([offset + scale * rng.random((N, m)), vmax * (2 * rng.random((N, m)) - 1)], axis=1)
+    X[: N // 50, m:] = 0.0                                                # some states at rest
+    X[N // 50: N // 50 + 5] = X[:5]                                       # repeated states (steer returns (0, 0): never an edge)
+    got = {}
+    for path in (1, 2):
+        with mp.Context(0) as c:
+            c.set_option("di_path", 1 if path == 1 else 0)                # (0 = auto: the matrix cores wherever the error bound allows)
+            c.upload_samples(X)
+            got[path] = c.di_graph(rho, r) + (c.stat("survivors"), c.stat("di_path_used"))
+    assert got[1][5] == 1
+    # (r = 0.25 in a unit workspace: the scaled features reach ~100 and the fp16 bound is no longer small against 1 / rho -- the library must
+    # say so and keep the vector-ALU test; everywhere else the matrix-core form must have run)
+    assert got[2][5] == (1 if r == 0.25 else 2), got[2][5]
+    if r == 0.25:
+        with mp.Context(0) as c:
+            c.set_option("di_path", 2)
+            c.upload_samples(X)
+            with pytest.raises(Exception):
+                c.di_graph(rho, r)
+    for u, v in zip(got[1][:4], got[2][:4]):
+        assert np.array_equal(u, v)
+    assert got[1][4] == got[2][4], (got[1][4], got[2][4])
+    oc, orow, oval, otv = orc.di_pairwise(X, rho, r)
+    colptr, rowval, nzval, tval = got[2][:4]
+    assert np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow)
+    assert np.array_equal(nzval, oval) and np.array_equal(tval, otv)
+    assert len(orow) > N                                                  # a real graph
+
+
 def test_di_single_pass_build(orc):
     """N >= 4096 takes the single-pass build (hits kept in slot lists sized by a pilot); it must equal both the oracle and the
     two-pass build, and a capacity overflow must fall back cleanly."""
