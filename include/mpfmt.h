@@ -398,7 +398,9 @@ MPFMT_API int32_t mpfmt_pinned_free(void* p);
  * four arrays (64-byte aligned; *mask may be asked for or NULL; *nnz_out their length) -- the memory behind the SparseMatrixCSC of
  * ImmutableNNC(D, r) (src/nearneighbors.jl:23-28) and the BitVector of free edges in julia/MPFmtHIP.jl hip_precompute_step!, which
  * every later call of the same ctx reuses: the second graph of a problem costs the copy alone.  The arrays are overwritten by the
- * next export of this ctx. */
+ * next export of this ctx -- and FREED by one that needs a larger arena (a graph with more entries): pointers of an earlier export
+ * must be dropped before the call (julia/MPFmtHIP.jl re-wraps them after every export).  A call that fails on the ctx's state (no
+ * resident graph, mask asked for but not swept) leaves the arena and the earlier export untouched. */
 MPFMT_API int32_t mpfmt_export_arena(mpfmt_ctx* ctx, int64_t bytes, void** out);
 MPFMT_API int32_t mpfmt_graph_export_pinned(mpfmt_ctx* ctx, int64_t** colptr, int64_t** rowval, double** nzval, uint64_t** mask,
                                             int64_t* nnz_out, double* gb_per_s);

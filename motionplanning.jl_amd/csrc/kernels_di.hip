@@ -389,8 +389,20 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
     const int m = ctx->d / 2;
     int32_t rc;
     const int64_t ntiles = (N + 63) / 64, npad = ntiles * 64;
+    // the candidate test on the matrix cores where it applies (kernels_di_mfma.hip)
+    bool mf = false;
+    float negT = 0.f;
+    double mf_sp = 0.0, mf_sv = 0.0, mf_pc[2] = {0.0, 0.0};
+    if (ctx->di_path != 1) {
+        if ((rc = mpfmt_di_mf_prepare(ctx, rho, r, &negT, &mf, &mf_sp, &mf_sv, mf_pc))) return rc;
+        if (!mf && ctx->di_path == 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "di_path = 2: the matrix-core prefilter does not apply here (workspace dim > 2, or the fp16 error bound is not small against 1 / rho)");
+    }
+    ctx->di_mf = mf; ctx->di_negT = negT;
+    // work items = target tiles x source slices, one wavefront each.  The vector-ALU kernel aims for ~8 000 (an item's dense loop is long
+    // either way); the matrix-core kernel's items are dominated by their Newton drains and run at four wavefronts per SIMD: ~32 000 of
+    // them keep the 4 096 wave slots of the chip evenly filled to the end (9 400 items at six slices: three rounds and a long tail)
     int S = 1;
-    if (ntiles > 0) S = (int)std::min<int64_t>(64, std::max<int64_t>(1, (8192 + ntiles - 1) / ntiles));
+    if (ntiles > 0) S = (int)std::min<int64_t>(64, std::max<int64_t>(1, ((mf ? 32768 : 8192) + ntiles - 1) / ntiles));
     S = (int)std::min<int64_t>(S, std::max<int64_t>(1, N / 64));
     ctx->di_S = S;
     if ((rc = mpfmt_ensure(ctx, (void**)&ctx->slice_cnt, sizeof(int32_t) * (size_t)S * std::max<int64_t>(npad, 1)))) return rc;
@@ -406,16 +418,7 @@ int32_t mpfmt_di_count(mpfmt_ctx* ctx, double rho, double r)
     a.S = S; a.ntiles = ntiles; a.slice_cnt = ctx->slice_cnt; a.colptr = ctx->colptr;
     a.rowtmp = nullptr; a.valtmp = nullptr; a.tvaltmp = nullptr; a.counters = ctx->d_pairs;
     a.tile_step = 1; a.pool_i = nullptr; a.pool_c = nullptr; a.pool_t = nullptr; a.pool_cap = 0; a.pool_flag = nullptr;
-    // the candidate test on the matrix cores where it applies (kernels_di_mfma.hip): operands once per build
-    bool mf = false;
-    float negT = 0.f;
-    if (ctx->di_path != 1) {
-        double sp = 0.0, sv = 0.0, pc[2] = {0.0, 0.0};
-        if ((rc = mpfmt_di_mf_prepare(ctx, rho, r, &negT, &mf, &sp, &sv, pc))) return rc;
-        if (!mf && ctx->di_path == 2) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "di_path = 2: the matrix-core prefilter does not apply here (workspace dim > 2, or the fp16 error bound is not small against 1 / rho)");
-        if (mf && (rc = mpfmt_di_mf_build_operands(ctx, sp, sv, pc))) return rc;
-    }
-    ctx->di_mf = mf; ctx->di_negT = negT;
+    if (mf && (rc = mpfmt_di_mf_build_operands(ctx, mf_sp, mf_sv, mf_pc))) return rc;      // operands once per build
     mpfmt_timed tm1(ctx);
     // Single pass: the accepted hits of the count pass are kept in slot lists, so the pairs are not steered twice.  The
     // list capacity comes from a pilot over every 32nd tile (tiles are in caller order, i.e. statistically alike); an

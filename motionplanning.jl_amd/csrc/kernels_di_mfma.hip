@@ -84,7 +84,7 @@ __global__ void k_di_make_ops(const double* __restrict__ X, int64_t N, int64_t n
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
 // MODE 0: count   1: fill the staging CSC from the counts   2: count AND keep the accepted hits in slot lists (single pass)
 template <int M, int MODE>
-__global__ __launch_bounds__(64) void k_di_pairs_mf(dimf_args g)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_di_pairs_mf(dimf_args g)
 {
     const di_args& a = g.a;
     constexpr bool FILL = (MODE == 1);

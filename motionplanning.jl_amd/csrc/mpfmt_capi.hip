@@ -928,6 +928,9 @@ int32_t mpfmt_graph_export_pinned(mpfmt_ctx* ctx, int64_t** colptr, int64_t** ro
     if (!ctx) return MPFMT_ERR_ARG;
     if (!colptr || !rowval || !nzval) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "colptr / rowval / nzval is NULL");
     if (!ctx->graph_filled) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "no resident graph (mpfmt_graph_step_device / mpfmt_graph_build_device)");
+    // (every state error of mpfmt_graph_export is raised BEFORE the arena is touched: growing it frees the block the previous export's
+    // pointers -- still held by the caller on a failed call -- point into)
+    if (mask && !ctx->graph_swept) return mpfmt_fail(ctx, MPFMT_ERR_STATE, "the resident graph has not been swept");
     const int64_t N = ctx->N, nnz = ctx->nnz, words = (nnz + 63) / 64;
     auto al = [](size_t b) { return (b + 63) & ~(size_t)63; };
     const size_t o_cp = 0, o_rv = al(8 * (size_t)(N + 1)), o_nz = o_rv + al(8 * (size_t)std::max<int64_t>(nnz, 1));
