@@ -75,7 +75,8 @@ MPFMT_API int32_t mpfmt_set_shard(mpfmt_ctx* ctx, int32_t rank, int32_t world);
 /* X: d x N column-major host doubles (Julia's Vector{SVector{d,Float64}} as it lies in memory).  One PCIe copy; the set's bounding
  * box and the finiteness check run on the device beside it (one reduction over the uploaded copy -- a host loop over the coordinates
  * would cost more than the copy).  A non-finite coordinate returns MPFMT_ERR_ARG naming the first such sample (1-based) and leaves
- * the ctx WITHOUT a sample set, as for mpfmt_upload_samples_device below. */
+ * the ctx as it was -- the sample set it had, its index, graph and capacity hints (the copy lands in a second buffer that changes
+ * places with the ctx's only once the set has been accepted). */
 MPFMT_API int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t N, int32_t d);
 /* The same for a sample set that already lives in HBM of ctx's device (dX = device pointer, same d x N column-major layout): a batch
  * produced on the device -- the library's sampler (mpfmt_sample_free leaves its set in ctx already), a ROCArray -- becomes the
@@ -83,8 +84,7 @@ MPFMT_API int32_t mpfmt_upload_samples(mpfmt_ctx* ctx, const double* X, int64_t 
  * the set's bounding box and the finiteness check run on the device.
  * Ordering: dX is read on ctx's stream.  Whatever produced it must be complete on that stream -- hand the producer's stream to
  * mpfmt_set_stream first, or synchronise it before the call.  On return the copy is complete (dX may be reused).
- * A non-finite coordinate returns MPFMT_ERR_ARG and leaves the ctx WITHOUT a sample set (N = 0, no index, no graph): the copy runs
- * beside the check, so the previous set is gone either way and nothing of it is served afterwards. */
+ * A non-finite coordinate returns MPFMT_ERR_ARG and leaves the ctx as it was, as for mpfmt_upload_samples. */
 MPFMT_API int32_t mpfmt_upload_samples_device(mpfmt_ctx* ctx, const double* dX, int64_t N, int32_t d);
 
 /* ---- collision checker: PointRobotNDBoxes(boxes) (src/collisioncheckers/boxesND.jl:15-23) and the

@@ -232,7 +232,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     if (ctx->zarena) { hipFree(ctx->zarena); ctx->d_pairs = nullptr; ctx->pool_flag = nullptr; ctx->pair_cnt = nullptr; ctx->qlen = nullptr; }      // (they point into it)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->idx_arena, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
-                    ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops, ctx->di_ops,
+                    ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops, ctx->di_ops, ctx->Xo_next,
                     ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->qkey, ctx->qd2, ctx->qlen, ctx->smask, ctx->st_best, ctx->st_besti, ctx->st_nfree, ctx->pend_items, ctx->pend_cnt, ctx->pair_items, ctx->pair_cnt, ctx->lists, ctx->list_len, ctx->lists_stage, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev, ctx->bb_dev};
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
     if (ctx->export_arena) hipHostFree(ctx->export_arena);
@@ -312,8 +312,9 @@ __global__ __launch_bounds__(BBOX_THREADS) void k_bbox_partials(const double* __
 
 // Both uploads: the copy into the ctx's sample buffer (host-to-device or device-to-device) and, beside it on the same stream, the
 // finiteness check and the bounding box as ONE reduction on the device (a host loop over 6e6 coordinates costs 3 ms -- more than the
-// PCIe copy of them), one small read-back, one synchronisation.  A non-finite coordinate is found after the buffer has been
-// overwritten: the ctx then holds NO sample set -- nothing of the previous one (index, graph, hints) may be served after the error.
+// PCIe copy of them), one small read-back, one synchronisation.  The copy goes to a SECOND buffer that changes places with the ctx's
+// sample buffer only when the check has passed: a refused set (non-finite coordinate) leaves the ctx exactly as it was -- previous
+// samples, index, graph and hints included (round 5 overwrote first and left the ctx empty: ADVICE r5).
 static int32_t adopt_samples(mpfmt_ctx* ctx, const double* src, bool src_on_host, int64_t N, int32_t d)
 {
     if (N < 0 || N >= ((int64_t)1 << 31) - 64) return mpfmt_fail(ctx, MPFMT_ERR_ARG, "N = %lld out of range", (long long)N);
@@ -331,17 +332,34 @@ static int32_t adopt_samples(mpfmt_ctx* ctx, const double* src, bool src_on_host
     const int64_t stride = std::max<int64_t>(((int64_t)std::max(nb, 1) * BBOX_THREADS / d) * d, d);      // (rounded DOWN: every residue below it has a thread)
     double lo[MPFMT_MAX_DIM], hi[MPFMT_MAX_DIM];
     for (int i = 0; i < d; ++i) { lo[i] = 0.0; hi[i] = 0.0; }
-    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->Xo, sizeof(double) * (size_t)N * d))) return rc;
+    if ((rc = mpfmt_ensure(ctx, (void**)&ctx->Xo_next, sizeof(double) * (size_t)N * d))) return rc;
     if (N > 0) {
         HIPCHK(ctx, hipMemsetAsync(&dev->bad, 0, sizeof(int32_t), ctx->stream));
         // host samples: the PCIe copy, then the reduction over the copy; device samples: the reduction IS the copy
-        if (src_on_host) HIPCHK(ctx, hipMemcpyAsync(ctx->Xo, src, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_bbox_partials, dim3(nb), dim3(BBOX_THREADS), 0, ctx->stream, src_on_host ? (const double*)ctx->Xo : src, src_on_host ? (double*)nullptr : ctx->Xo,
+        if (src_on_host) HIPCHK(ctx, hipMemcpyAsync(ctx->Xo_next, src, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_bbox_partials, dim3(nb), dim3(BBOX_THREADS), 0, ctx->stream, src_on_host ? (const double*)ctx->Xo_next : src, src_on_host ? (double*)nullptr : ctx->Xo_next,
                            N, d, stride, &dev->part[0][0][0], &dev->bad);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(ctx->bb_host, dev, sizeof(bb_block), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (N > 0) {
+        const bb_block* h = (const bb_block*)ctx->bb_host;
+        if (h->bad) {
+            if (src_on_host)                                         // (name the sample, as the host check used to)
+                for (int64_t p = 0; p < N; ++p)
+                    for (int i = 0; i < d; ++i)
+                        if (!std::isfinite(src[p * d + i]))
+                            return mpfmt_fail(ctx, MPFMT_ERR_ARG, "sample %lld has a non-finite coordinate (the ctx keeps the sample set it had)", (long long)(p + 1));
+            return mpfmt_fail(ctx, MPFMT_ERR_ARG, "the sample set has a non-finite coordinate (the ctx keeps the sample set it had)");
+        }
+    }
+    // accepted: the new buffer becomes the ctx's sample set (the two members change places, capacities with them)
+    {
+        std::swap(ctx->Xo, ctx->Xo_next);
+        const size_t ca = ctx->caps[(void*)&ctx->Xo], cb = ctx->caps[(void*)&ctx->Xo_next];
+        ctx->caps[(void*)&ctx->Xo] = cb; ctx->caps[(void*)&ctx->Xo_next] = ca;
+    }
     ctx->samples_epoch += 1;
     ctx->grid_r = -1.0; ctx->graph_r = -1.0; ctx->ops_r = -1.0; ctx->lists_r = -1.0;
     ctx->graph_counted = ctx->graph_filled = ctx->graph_swept = false;
@@ -349,17 +367,6 @@ static int32_t adopt_samples(mpfmt_ctx* ctx, const double* src, bool src_on_host
     ctx->nnz = 0;
     if (N > 0) {
         const bb_block* h = (const bb_block*)ctx->bb_host;
-        if (h->bad) {
-            ctx->N = 0; ctx->d = d; ctx->ntiles = 0;
-            ctx->spec_ready = false; ctx->pool_valid = false; ctx->pend_valid = false; ctx->rowpos_valid = false;
-            for (int i = 0; i < d; ++i) { ctx->bb_lo[i] = 0.0; ctx->bb_hi[i] = 0.0; }
-            if (src_on_host)                                         // (name the sample, as the host check used to)
-                for (int64_t p = 0; p < N; ++p)
-                    for (int i = 0; i < d; ++i)
-                        if (!std::isfinite(src[p * d + i]))
-                            return mpfmt_fail(ctx, MPFMT_ERR_ARG, "sample %lld has a non-finite coordinate (the ctx now holds no samples)", (long long)(p + 1));
-            return mpfmt_fail(ctx, MPFMT_ERR_ARG, "the sample set has a non-finite coordinate (the ctx now holds no samples)");
-        }
         for (int i = 0; i < d; ++i) { lo[i] = INFINITY; hi[i] = -INFINITY; }
         for (int b = 0; b < nb; ++b)
             for (int i = 0; i < d; ++i) { lo[i] = std::min(lo[i], h->part[b][0][i]); hi[i] = std::max(hi[i], h->part[b][1][i]); }

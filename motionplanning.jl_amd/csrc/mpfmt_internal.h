@@ -103,6 +103,7 @@ struct mpfmt_ctx {
     int64_t N = 0;
     int32_t d = 0;
     double* Xo = nullptr;                // [N][d] original order (AoS = the caller's layout)
+    double* Xo_next = nullptr;           // where an upload lands: changes places with Xo once the set has been accepted (a refused set leaves the ctx as it was)
     double bb_lo[MPFMT_MAX_DIM], bb_hi[MPFMT_MAX_DIM];
     void* bb_dev = nullptr;              // mpfmt_upload_samples_device: per-block partial boxes, and their pinned host mirror
     void* bb_host = nullptr;

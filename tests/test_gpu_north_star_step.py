@@ -180,8 +180,8 @@ def test_upload_samples_device_equals_host_upload(orc):
         t = torch.from_numpy(X).to("cuda:0"); torch.cuda.synchronize()
         with pytest.raises(mp.MPFMTError):
             c.upload_samples_device(t.data_ptr(), N, d)
-        # the host upload checks on the device too: the error names the sample (1-based), the ctx then holds none, and a good set
-        # uploaded afterwards is served as if nothing had happened
+        # the host upload checks on the device too: the error names the sample (1-based), the ctx keeps what it had (here: nothing), and a
+        # good set uploaded afterwards is served as if nothing had happened
         c.upload_boxes(lohi, lo, hi)
         with pytest.raises(mp.MPFMTError, match="sample 124 "):
             c.upload_samples(X)
@@ -194,6 +194,19 @@ def test_upload_samples_device_equals_host_upload(orc):
         oc, orow, oval = orc.rdisc_graph(X, r)
         colptr, rowval, nzval, free = _resident_graph(c, N)
         assert np.array_equal(colptr, oc) and np.array_equal(rowval, orow) and np.array_equal(nzval, oval)
+        # a refused set leaves the ctx as it was: the resident graph stays readable, and the next step is the step of the OLD samples
+        Xbad = X.copy(); Xbad[N - 1, 0] = -np.inf
+        with pytest.raises(mp.MPFMTError, match="sample %d " % N):
+            c.upload_samples(Xbad)
+        tb = torch.from_numpy(Xbad).to("cuda:0"); torch.cuda.synchronize()
+        with pytest.raises(mp.MPFMTError):
+            c.upload_samples_device(tb.data_ptr(), N, d)
+        c2, r2, n2, f2 = _resident_graph(c, N)
+        assert np.array_equal(c2, colptr) and np.array_equal(r2, rowval) and np.array_equal(n2, nzval) and np.array_equal(f2, free)
+        c.set_option("rebuild_index", 1)
+        assert c.graph_step_device(r) == len(orow)
+        c2, r2, n2, f2 = _resident_graph(c, N)
+        assert np.array_equal(c2, oc) and np.array_equal(r2, orow) and np.array_equal(n2, oval) and np.array_equal(f2, free)
 
 
 def test_four_million_samples_step(orc):

@@ -542,7 +542,7 @@ def test_di_matrix_core_prefilter_equals_the_vector_alu_test(orc, m, N, rho, r, 
     colptr, rowval, nzval, tval = got[2][:4]
     assert np.array_equal(colptr - 1, oc) and np.array_equal(rowval - 1, orow)
     assert np.array_equal(nzval, oval) and np.array_equal(tval, otv)
-    assert len(orow) > (N if N > 1000 else 0)                             # a real graph
+    assert len(orow) > 0
 
 
 def test_di_single_pass_build(orc):
