@@ -31,6 +31,9 @@ for wl in cfg2 cfg3; do
   timeout 900 python3 bench.py --workload $wl --no-cpu-baseline --steps 10 --warmup 3 > profiles/${R}_bench_${wl}.json 2> /tmp/b_$wl.err || tail -3 /tmp/b_$wl.err
 done
 timeout 600 python3 bench.py --workload cfg1 --n 400000 --no-cpu-baseline --no-cold --no-solve --steps 20 > profiles/${R}_bench_cfg1_n400k.json 2> /tmp/b_c1.err || tail -3 /tmp/b_c1.err
+# round 6: BASELINE configs[3] / configs[4] with their counters (profiles/valu_ops.json is keyed to this build), and the clustered north star
+bash tools/r6_cfg45.sh ${R} > /tmp/cfg45.log 2>&1 || tail -5 /tmp/cfg45.log
+timeout 600 python3 bench.py --workload ns_clustered --no-cpu-baseline > profiles/${R}_bench_clustered.json 2> /tmp/b_cl.err || tail -3 /tmp/b_cl.err
 timeout 900 python3 tools/run_shard_sim.py > profiles/${R}_shard_sim.txt 2>&1
 timeout 900 python3 tools/run_shard_ab.py 8 > profiles/${R}_shard_ab_g8.txt 2>&1
 timeout 1500 python3 tools/run_form_grid.py > profiles/${R}_form_grid.txt 2>&1
