@@ -60,7 +60,7 @@ __device__ __forceinline__ int cell_of(double x, double lo, double inv_w, int g)
 // the scatter drawing its own numbers -- only a third of the samples is scattered on a rank of eight -- measured slower at every
 // shard count: 1.12 vs 1.07 ms per step at 8 ranks, 3.66 vs 3.62 unsharded)
 __global__ void k_cellkey_count(const double* __restrict__ Xo, int64_t N, int d, mpfmt_grid G, int fb,
-                                uint32_t* __restrict__ key, uint32_t* __restrict__ slot, int32_t* __restrict__ cellcnt)
+                                uint32_t* __restrict__ key, uint32_t* __restrict__ slot, int32_t* __restrict__ cellcnt, int64_t cstride)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
@@ -77,7 +77,7 @@ __global__ void k_cellkey_count(const double* __restrict__ Xo, int64_t N, int d,
         if (!(t == t)) fine = 0;
     }
     key[p] = ((uint32_t)id << fb) | fine;
-    slot[p] = (uint32_t)atomicAdd(&cellcnt[id], 1);
+    slot[p] = (uint32_t)atomicAdd(&cellcnt[id * cstride], 1);
 }
 
 // exclusive scan of up to 4096 consecutive items per call of a 1024-thread workgroup (thread = 4 items); returns the block's total.
@@ -123,13 +123,19 @@ __global__ __launch_bounds__(1024) void k_scan_single(const T* in, T* out, int64
 // and stored coalesced, summed by thread = a contiguous run of an ODD number of items (no bank conflicts), one barrier chain instead
 // of one per 4096 items
 #define SCAN_LDS_MAX 36864
-__global__ __launch_bounds__(1024) void k_scan_lds_i32(const int32_t* in, int32_t* out, int n)
+// the counters of a block-major id range, one per 64-byte line, back into the compact array the scan runs over
+__global__ void k_cellcnt_compact(const int32_t* __restrict__ pad, int32_t* __restrict__ out, int n, int64_t cstride)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pad[(size_t)i * cstride];
+}
+__global__ __launch_bounds__(1024) void k_scan_lds_i32(const int32_t* in, int32_t* out, int n, int64_t istride)
 {
     extern __shared__ int32_t s_a[];
     __shared__ int32_t s_w[17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = ((n + 1023) / 1024) | 1;
-    for (int i = tid; i < seg * 1024; i += 1024) s_a[i] = (i < n) ? in[i] : 0;
+    for (int i = tid; i < seg * 1024; i += 1024) s_a[i] = (i < n) ? in[(int64_t)i * istride] : 0;      // (istride > 1: one counter per 64-byte line, see mpfmt_build_grid)
     __syncthreads();
     int32_t t = 0;
     for (int k = 0; k < seg; ++k) t += s_a[tid * seg + k];
@@ -611,12 +617,29 @@ int32_t mpfmt_build_grid(mpfmt_ctx* ctx, double r, bool whole)
         HIPCHK(ctx, hipMemsetAsync(ctx->idx_arena, 0, ctx->tileneed ? arena_bytes : arena_cells, ctx->stream));
         ctx->list_max_clean = true;
         const int B = 256;
-        hipLaunchKernelGGL(k_cellkey_count, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream, ctx->Xo, N, d, G, fb, key, slot, ctx->cellstart);
-        if (G.ncells + 1 <= SCAN_LDS_MAX) {
+        // Block-major cell ids (sharded ctx): the counting atomics of k_cellkey_count on the compact counter array take 87 us instead of
+        // the row-major ids' 54 for the same 1e6 samples -- memory-side atomics, and the block-major id range (holes at every odd cut
+        // axis) lands its hot counters on few channels (tools/ubench/atomic_hist.hip: 24 atomics / ns whatever the layout, UNLESS the
+        // used counters alias).  One counter per 64-byte line restores the 54 us (A/B on one box, rank 3 of 8: 87.4 -> 54.8; the
+        // unsharded step: 54.8 -> 54.0, left compact); the padded array is cleared and compacted by two small launches.
+        const int64_t cstride = (G.nsplit > 0) ? 16 : 1;
+        int32_t* cnt = ctx->cellstart;
+        if (cstride > 1) {
+            const size_t need = sizeof(int32_t) * (size_t)(G.ncells + 2) * (size_t)cstride;
+            if ((rc = ensure(ctx, (void**)&ctx->cellcnt_pad, need))) return rc;
+            HIPCHK(ctx, hipMemsetAsync(ctx->cellcnt_pad, 0, need, ctx->stream));
+            cnt = ctx->cellcnt_pad;
+        }
+        hipLaunchKernelGGL(k_cellkey_count, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, ctx->stream, ctx->Xo, N, d, G, fb, key, slot, cnt, cstride);
+        const bool scan_lds = G.ncells + 1 <= SCAN_LDS_MAX;
+        if (cstride > 1 && !scan_lds)                            // (the LDS scan reads the padded counters itself)
+            hipLaunchKernelGGL(k_cellcnt_compact, dim3((unsigned)((G.ncells + 1 + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t*)cnt, ctx->cellstart,
+                               (int)(G.ncells + 1), cstride);
+        if (scan_lds) {
             const int seg = (int)(((G.ncells + 1 + 1023) / 1024) | 1);
             const size_t lds = sizeof(int32_t) * (size_t)seg * 1024;
             HIPCHK(ctx, hipFuncSetAttribute((const void*)k_scan_lds_i32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_scan_lds_i32, dim3(1), dim3(1024), lds, ctx->stream, (const int32_t*)ctx->cellstart, ctx->cellstart, (int)(G.ncells + 1));
+            hipLaunchKernelGGL(k_scan_lds_i32, dim3(1), dim3(1024), lds, ctx->stream, (const int32_t*)cnt, ctx->cellstart, (int)(G.ncells + 1), cstride);
         } else {
             launch_scan<int32_t>(ctx->stream, (const int32_t*)ctx->cellstart, ctx->cellstart, G.ncells + 1, bsum);
         }

@@ -232,7 +232,7 @@ int32_t mpfmt_ctx_destroy(mpfmt_ctx* ctx)
     if (ctx->zarena) { hipFree(ctx->zarena); ctx->d_pairs = nullptr; ctx->pool_flag = nullptr; ctx->pair_cnt = nullptr; ctx->qlen = nullptr; }      // (they point into it)
     void* bufs[] = {ctx->Xo, ctx->perm, ctx->iperm, ctx->cellkey, ctx->idx_arena, ctx->Xt, ctx->tile_lo, ctx->tile_hi, ctx->tile_sub, ctx->tile_sub32,
                     ctx->slice_cnt, ctx->deg, ctx->colptr, ctx->rowtmp, ctx->valtmp, ctx->rowval, ctx->nzval,
-                    ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops, ctx->di_ops, ctx->Xo_next,
+                    ctx->graph_free, ctx->d_pairs, ctx->boxes, ctx->scratch, ctx->degs, ctx->tptr, ctx->Xs, ctx->ops, ctx->di_ops, ctx->Xo_next, ctx->cellcnt_pad,
                     ctx->tvaltmp, ctx->tval, ctx->di_nseg, ctx->rowpos, ctx->pool_flag, ctx->qkey, ctx->qd2, ctx->qlen, ctx->smask, ctx->st_best, ctx->st_besti, ctx->st_nfree, ctx->pend_items, ctx->pend_cnt, ctx->pair_items, ctx->pair_cnt, ctx->lists, ctx->list_len, ctx->lists_stage, ctx->sweep_ctr, ctx->rt_cnt, ctx->rt_off, ctx->rt_tmp, ctx->rt_table, ctx->rt_total, ctx->rt_ss, ctx->ssflag_dev, ctx->shapes2d, ctx->car_keep, ctx->di_pool_i, ctx->di_pool_c, ctx->di_pool_t, ctx->spec_fail, ctx->rb_dev, ctx->bb_dev};
     if (ctx->rb_host) hipHostFree(ctx->rb_host);
     if (ctx->export_arena) hipHostFree(ctx->export_arena);

@@ -120,6 +120,7 @@ struct mpfmt_ctx {
     void* idx_arena = nullptr;
     int32_t* cellstart = nullptr;        // [ncells+1] (inside idx_arena)
     int32_t* list_max = nullptr;         // (inside idx_arena)
+    int32_t* cellcnt_pad = nullptr;      // block-major ids (sharded ctx): the cell counters of the count pass, one per 64-byte line (kernels_rdisc.hip)
     bool list_max_clean = false;         // zeroed by the index build's fill and not written since
     // sharded ctx on the matrix-core path: only the tiles this rank reads are built -- its own and the halo (the tiles of the cells next
     // to its own cells); tileneed [ntiles] marks them (nullptr: the index is whole)
