@@ -83,6 +83,9 @@ function hip_precompute_step!(P::MPProblem, r::Float64)
     CC = P.CC; N = length(P.V); ctx = CC.ctx
     nnz = Ref{Int64}(0)
     chk(ctx, ccall((:mpfmt_graph_step_device, libmpfmt), Int32, (Ptr{Void}, Float64, Ptr{Int64}), ctx, r, nnz))
+    # the arrays of the previous export live in the ctx's arena, which an export of a LARGER graph frees: drop them before the call
+    # (include/mpfmt.h, mpfmt_graph_export_pinned)
+    CC.D = spzeros(0, 0); CC.free = falses(0)
     pc = Ref{Ptr{Int64}}(C_NULL); pr = Ref{Ptr{Int64}}(C_NULL); pv = Ref{Ptr{Float64}}(C_NULL); pm = Ref{Ptr{UInt64}}(C_NULL)
     rate = Ref{Float64}(0.0)
     chk(ctx, ccall((:mpfmt_graph_export_pinned, libmpfmt), Int32,
