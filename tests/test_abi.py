@@ -88,3 +88,14 @@ def test_committed_counter_summary_is_keyed_to_a_library():
         pytest.skip("no counter summary")
     t = json.load(open(tj))
     assert isinstance(t.get("lib_sha256"), str) and len(t["lib_sha256"]) == 64
+    # ... but a stale summary is SAID: a warning in the CPU suite's report when the built library is not the profiled one
+    import hashlib
+    import warnings
+    so = mp._lib.so_path()
+    if os.path.exists(so):
+        sha = hashlib.sha256(open(so, "rb").read()).hexdigest()
+        if sha != t["lib_sha256"]:
+            warnings.warn("profiles/traffic.json was taken on another build of libmpfmt.so (%s..., built: %s...): bench.py will print "
+                          "roofline.traffic = null until tools/final_profiles.sh has been run on this build" % (t["lib_sha256"][:12], sha[:12]))
+    for name, e in (json.load(open(os.path.join(root, "profiles", "valu_ops.json"))) if os.path.exists(os.path.join(root, "profiles", "valu_ops.json")) else {}).items():
+        assert isinstance(e.get("lib_sha256"), str) and len(e["lib_sha256"]) == 64, name
