@@ -643,6 +643,11 @@ def main():
             "edge_broad_phase_in_drain": edge_form > 0,      # the kernel's time then includes 2 d v_cmpx per surviving box and hit (0.7 ms at the north star)
             "ordered_pairs_served_tflops": ach_tflops * (2.0 if half_build else 1.0),
             "valu_per_mfma": pk.get("valu_per_mfma"),
+            # the resource that binds this kernel: vector lane-operations issued per second (SQ_INSTS_VALU x 64 lanes / the kernel's HIP-event
+            # time) against the 39.3e12 lane-ops/s the vector ALUs can issue -- null without a counter summary of this build
+            "valu_issue": ({"insts_valu_per_launch": pk.get("insts_valu"), "lane_ops_per_s": pk["insts_valu"] * 64.0 / (pair_ms * 1e-3),
+                            "peak": FP64_VALU_LANE_OPS, "frac": pk["insts_valu"] * 64.0 / (pair_ms * 1e-3) / FP64_VALU_LANE_OPS}
+                           if (pk.get("insts_valu") and pair_ms > 0) else None),
             "valu_busy": pk.get("valu_busy"),
             "mfma_busy": pk.get("mfma_busy"),                # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), from the same PMC run
             "avg_launch_ms": pair_ms,
