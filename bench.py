@@ -353,7 +353,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="north_star", choices=["north_star", "cfg2", "cfg1", "cfg3", "cfg3_full", "cfg4", "cfg5", "ns_clustered"])
+    ap.add_argument("--workload", default="north_star", choices=["north_star", "cfg2", "cfg1", "cfg3", "cfg3_full", "cfg4", "cfg5", "ns_clustered", "ns_biased"])
     ap.add_argument("--n", type=int, default=0, help="override the sample count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the whole-solve submetric (wavefront FMT*)")
@@ -415,6 +415,12 @@ def main():
             ctx.set_option(opt, int(v))
     ctx.upload_samples(w.X)                       # inputs resident in HBM before the timed region
     ctx.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+    if getattr(w, "device_set", None):
+        # sample sets drawn by the library's own sampler (free space + goal bias), outside the timed region; resample() then serves them
+        drawn = [w.device_set(ctx, k) for k in range(max(1, args.sample_sets))]
+        w.X = drawn[0]
+        mp.workloads.resample = lambda w_, k, _d=drawn: _d[k % len(_d)]
+        ctx.upload_samples(w.X)
     # K sample sets of the same problem, all resident in HBM before the clock starts; step k hands set k mod K to the library by
     # device pointer (mpfmt_upload_samples_device: one device-to-device copy + the bounding box, inside the timed step) -- a planner
     # builds one graph per sample set, so no timed step sees the samples of the step before it

@@ -26,6 +26,8 @@ class Workload:
     ss_hi: np.ndarray
     seed: int = 0
     draw: object = None    # non-uniform sample sets: draw(stream, N, d) -> (N, d) samples (None: i.i.d. uniform)
+    device_set: object = None      # sample sets drawn by the library's sampler: device_set(ctx, k) -> (N, d)
+    goal_bias: float = 0.0
 
     @property
     def N(self):
@@ -176,7 +178,24 @@ def north_star_clustered(N=1_000_000):
     return w
 
 
-BY_NAME = {"cfg1": cfg1, "cfg2": cfg2, "north_star": north_star, "cfg3": cfg3, "ns_clustered": north_star_clustered}
+def north_star_biased(N=1_000_000, goal_bias=5e-4):
+    """The north star's world with the sample sets the LIBRARY's sampler draws (mpfmt_sample_free_biased, src/sampling.jl:11-45): free-space
+    samples (nothing inside an obstacle) with a goal bias.  `device_sets(ctx, k)` draws set k on the device (the obstacle set must be
+    uploaded); X here is a uniform placeholder until then.  goal_bias = 5e-4 puts ~500 of the 1e6 samples inside the goal ball (radius
+    0.15 < r): columns of ~600 entries -- what a stored graph allows.  (A bias of 0.3 would put 3e5 samples inside one r-ball: 9e10
+    edges, no CSC of that exists on any machine.)"""
+    w = make("ns_r6_n1m_m200_goalbias", N, 6, 200, 0.10, 0.20, seed=3)
+    w.goal_bias = goal_bias
+
+    def device_set(ctx, k):
+        X, _ = ctx.sample_free(1000 + k, w.N, init=w.init, goal_kind=1, goal_params=w.goal_params(), goal_ct=1, goal_bias=goal_bias)      # (1 = GOAL_BALL)
+        return X
+    w.device_set = device_set
+    return w
+
+
+BY_NAME = {"cfg1": cfg1, "cfg2": cfg2, "north_star": north_star, "cfg3": cfg3, "ns_clustered": north_star_clustered,
+           "ns_biased": north_star_biased}
 
 
 @dataclass

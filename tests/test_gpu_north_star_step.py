@@ -150,6 +150,48 @@ def test_clustered_samples_at_the_north_star_size(orc):
             del t
 
 
+def test_goal_biased_free_samples_at_the_north_star_size(orc):
+    """The sample sets the library's own sampler emits (mpfmt_sample_free_biased, src/sampling.jl:11-45: free space only, goal bias) through the timed
+    step at the north star's N and r: ~500 samples inside the goal ball (columns of ~600 entries against a mean of ~120), none inside an
+    obstacle.  From the second step on -- repeats and NEW biased sets -- (pair kernel, half build, fused edge tests) and no build redone;
+    graph and mask against the oracle on sampled columns, the goal ball's columns included."""
+    w = mp.workloads.north_star_biased()
+    N = w.N
+    rng = np.random.default_rng(44)
+    with mp.Context(0) as c:
+        c.set_option("rebuild_index", 1)
+        c.upload_samples(w.X); c.upload_boxes(w.lohi, w.ss_lo, w.ss_hi)
+        X = w.device_set(c, 0)
+        assert orc.unpack(orc.points_free(X[::97], w.lohi, w.ss_lo, w.ss_hi), len(X[::97])).all()        # free space only
+        ingoal = np.flatnonzero(np.linalg.norm(X - w.goal_center, axis=1) <= w.goal_radius)
+        assert 300 < len(ingoal) < 900, len(ingoal)
+        redo = []
+        for it in range(3):
+            nnz = c.graph_step_device(w.r)
+            redo.append(c.stat("redo_count"))
+            if it >= 1:
+                assert (c.stat("rdisc_path_used"), c.stat("rdisc_half_used"), c.stat("sweep_form")) == (2, 1, 2), it
+                assert redo[it] == redo[it - 1], (it, redo, c.stat("redo_reason"))
+        colptr, rowval, nzval, free = _resident_graph(c, N)
+        assert nnz == colptr[-1]
+        deg = np.diff(colptr)
+        assert deg[ingoal].mean() > 2 * deg.mean()
+        _check_against_oracle(orc, X, w.r, w.lohi, w.ss_lo, w.ss_hi, colptr, rowval, nzval, free, rng, ncols=200, nedges=200000)
+        kd = orc.KDTree(X)
+        for v in ingoal[:25]:
+            oi, od = kd.inball(int(v), w.r)
+            a, b = int(colptr[v]), int(colptr[v + 1])
+            assert np.array_equal(rowval[a:b], oi) and np.array_equal(nzval[a:b], od), v
+        del colptr, rowval, nzval, free, kd
+        for k in (1, 2):                                                   # new biased sets (the sampler leaves each uploaded)
+            X2 = w.device_set(c, k)
+            nnz = c.graph_step_device(w.r)
+            assert (c.stat("rdisc_path_used"), c.stat("rdisc_half_used"), c.stat("sweep_form")) == (2, 1, 2), k
+            assert c.stat("redo_count") == redo[-1], (k, c.stat("redo_count"), redo, c.stat("redo_reason"))
+        colptr, rowval, nzval, free = _resident_graph(c, N)
+        _check_against_oracle(orc, X2, w.r, w.lohi, w.ss_lo, w.ss_hi, colptr, rowval, nzval, free, rng, ncols=150, nedges=150000)
+
+
 def test_upload_samples_device_equals_host_upload(orc):
     """mpfmt_upload_samples_device against mpfmt_upload_samples: same bounding box (hence the same grid), same graph and mask;
     a non-finite coordinate is refused."""
